@@ -1,0 +1,176 @@
+#!/usr/bin/env python3
+"""bench.py — NDT grid-build throughput (bin + mean/cov + eigen + labels + ordering) on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+A "step" is one full build of the map from a device-resident cloud (`create2DMap`).  At N = 1 the
+workload is BASELINE.json configs[1]: 10 M uniform-random points, 0.5 m cubic voxels.
+At N > 1 every rank holds its own 10 M-point shard (weak scaling); see --mode.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
+BYTES_PER_POINT = 12           # one read of packed fp32 xyz          
+BYTES_PER_NODE = 76            # one write of the node's result row   
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--points", type=int, default=10_000_000, help="points per rank")
+    ap.add_argument("--grid-len", type=float, default=0.5)
+    ap.add_argument("--z-len", type=float, default=0.5)
+    ap.add_argument("--strategy", type=int, default=0)
+    ap.add_argument("--mode", choices=["replicas", "global"], default="replicas",
+                    help="N>1: independent per-rank maps (no collective) or one global map via RCCL stats exchange")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=2_000_000)
+    ap.add_argument("--check", action="store_true", help="also check a 300 k-point build against the oracle")
+    return ap.parse_args()
+
+
+def cpu_baseline(cloud, P, sample):
+    """Oracle (faithful restatement of the reference path) timed on this box's host cores, on the
+    first `sample` points of the same workload.  Reported, never the thing measured as `value`."""
+    from oracle import oracle
+    sub = np.ascontiguousarray(cloud[:sample + 1])
+    threads = oracle.max_threads()
+    t0 = time.perf_counter()
+    r = oracle.build_grid(sub, P["grid_len"], P["z_len"], P["slope_interval"], "slope", mode=oracle.MODE_INT_OPENMP,
+                          threads=threads, export=False)
+    dt = r["t_division"] + r["t_calculate"]
+    wall = time.perf_counter() - t0
+    n_ser = min(sample, 200_000)
+    r0 = oracle.build_grid(np.ascontiguousarray(cloud[:n_ser + 1]), P["grid_len"], P["z_len"], P["slope_interval"], "slope",
+                           mode=oracle.MODE_AS_SHIPPED, export=False)
+    dt0 = r0["t_division"] + r0["t_calculate"]
+    return {"value": round(sample / dt / 1e6, 4), "unit": "Mpoints/s", "cores": threads, "kind": "port",
+            "sample": f"first {sample} points of the workload, oracle mode 2 (OpenMP, integer keys); "
+                      f"division {r['t_division']:.2f}s + calculate {r['t_calculate']:.2f}s (wall {wall:.1f}s)",
+            "as_shipped_serial": {"value": round(n_ser / dt0 / 1e6, 4), "unit": "Mpoints/s", "cores": 1,
+                                  "sample": f"first {n_ser} points, oracle mode 0 (strings + multimap, as the reference runs)"}}
+
+
+def main():
+    a = parse()
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert torch.cuda.is_available(), "bench.py needs a GPU (libgndt has no CPU path)"
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+
+    import grid_ndt_amd as g
+    from tests import scenes
+    g.build_native()
+    P = dict(grid_len=a.grid_len, z_len=a.z_len, slope_interval=0.08, demand="slope")
+    n = a.points
+    cloud = scenes.uniform_box(n + 1, seed=0x5EED0002 + rank)     # point 0 = origin (receiver.cpp:145)
+    if world > 1 and a.mode == "global":
+        origin = scenes.uniform_box(1, seed=0x5EED0002)[0]
+    else:
+        origin = cloud[0]
+    dev = torch.device(f"cuda:{local}")
+    pts = torch.from_numpy(cloud[1:]).to(dev)
+    torch.cuda.synchronize()
+
+    m = g.TwoDmap(P["grid_len"], P["z_len"], device=local, max_nodes_hint=1 << 20, strategy=a.strategy)
+    m.setInterval(P["slope_interval"])
+    m.setCloudFirst(origin)
+    stream = torch.cuda.current_stream()
+
+    def step():
+        if world > 1 and a.mode == "global":
+            from grid_ndt_amd import dist as gdist
+            gdist.build_global_map(m, "slope", pts, rank * n, stream)
+        else:
+            m.create2DMap("slope", pts, stream)
+
+    for _ in range(a.warmup):
+        step()
+    m.sync()
+    m.set_profiling(True)
+    phase_sum = {}
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+        # phase events are read after the step; the read waits on the stream the kernels ran on
+        for k, v in m.phase_times_ms().items():
+            if v >= 0:
+                phase_sum[k] = phase_sum.get(k, 0.0) + v
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+    nodes, cols, slopes = m.sync()
+
+    if rank == 0:
+        ms_step = dt / a.steps * 1e3
+        total_points = n * world
+        value = total_points / (dt / a.steps) / 1e6
+        phases = {k: round(v / a.steps, 4) for k, v in phase_sum.items()}
+        acc_ms = phases.get("accumulate", float("nan"))
+        # dominant kernel: k_accumulate, which streams the N points once -> 12 B/point algorithmic
+        alg_bytes = BYTES_PER_POINT * n
+        achieved = alg_bytes / (acc_ms * 1e-3) / 1e9 if acc_ms == acc_ms and acc_ms > 0 else None
+        path_bytes = BYTES_PER_POINT * n + BYTES_PER_NODE * nodes
+        out = {
+            "metric": "NDT grid-build throughput (bin + mean/cov + eigen + labels + ordering)",
+            "value": round(value, 3), "unit": "Mpoints/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(ms_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "S2: 10M uniform-random points in [-100,100)^2 x [-1,1), 0.5 m cubic voxels, "
+                                   "demand=slope (BASELINE.json configs[1])" if n == 10_000_000 and a.grid_len == 0.5 and a.z_len == 0.5
+                       else f"uniform box, {n} points/rank, grid {a.grid_len}/{a.z_len}",
+                       "points_per_gpu": n, "nodes": int(nodes), "columns": int(cols), "slopes": int(slopes),
+                       "multi_gpu_mode": a.mode if world > 1 else "single", "strategy": a.strategy},
+            "roofline": {"bound": "hbm", "kernel": "k_accumulate",
+                         "achieved": round(achieved, 2) if achieved else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 5) if achieved else None, "traffic": None,
+                         "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": acc_ms},
+            "path_roofline": {"bytes": path_bytes, "achieved_GBps": round(path_bytes / (ms_step * 1e-3) / 1e9, 2),
+                              "frac": round(path_bytes / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
+            "phase_ms": phases,
+        }
+        if not a.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(cloud, P, min(a.cpu_sample, n))
+        elif world == 1:
+            out["cpu_baseline"] = None
+        if a.check:
+            from tests import parity
+            small = scenes.uniform_box(300_001)
+            ref = parity.ref_from_cloud(small, P)
+            _, o = parity.gpu_from_cloud(small, P, device=local)
+            out["check"] = parity.compare(o, ref)["ok"]
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

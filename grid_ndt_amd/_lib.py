@@ -1,0 +1,107 @@
+"""ctypes binding of libgndt.so (the C ABI declared in include/gndt.h).
+
+The shared library is built in-tree by `build_native()` (hipcc, gfx950).  There is no Python or CPU
+implementation of the path behind it: if the library is missing, loading raises.
+"""
+import ctypes as C
+import os
+import subprocess
+
+_CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB_PATH = os.path.join(_CSRC, "libgndt.so")
+SOURCES = ["gndt_api.hip", "gndt_codec.cpp"]
+HEADERS = ["gndt_kernels.hpp", "gndt_math.hpp", os.path.join(_ROOT, "include", "gndt.h")]
+
+GNDT_OK = 0
+ERR_NAMES = {0: "OK", 1: "INVALID", 2: "NO_DEVICE", 3: "HIP", 4: "KEY_RANGE", 5: "CAPACITY", 6: "NOMEM"}
+
+
+class GndtError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"gndt error {code} ({ERR_NAMES.get(code, '?')}): {msg}")
+        self.code = code
+
+
+class Params(C.Structure):
+    _fields_ = [("grid_len", C.c_float), ("z_len", C.c_float), ("slope_interval", C.c_float),
+                ("demand", C.c_int32), ("min_points", C.c_int32), ("device_id", C.c_int32),
+                ("strategy", C.c_int32), ("max_points_hint", C.c_uint64), ("max_nodes_hint", C.c_uint64)]
+
+
+class Cells(C.Structure):
+    _fields_ = [("num_nodes", C.c_uint64), ("num_columns", C.c_uint64), ("num_slopes", C.c_uint64),
+                ("sx", C.c_void_p), ("sy", C.c_void_p), ("sz", C.c_void_p), ("count", C.c_void_p),
+                ("first_idx", C.c_void_p), ("mean", C.c_void_p), ("cov", C.c_void_p), ("rough", C.c_void_p),
+                ("normal", C.c_void_p), ("flags", C.c_void_p)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("num_nodes", C.c_uint64), ("key", C.c_void_p), ("sums", C.c_void_p), ("count", C.c_void_p),
+                ("first_idx", C.c_void_p)]
+
+
+def build_native(force=False, verbose=False):
+    """Compile the HIP sources into grid_ndt_amd/csrc/libgndt.so for gfx950 (cross-compiles without a GPU)."""
+    srcs = [os.path.join(_CSRC, s) for s in SOURCES]
+    deps = srcs + [h if os.path.isabs(h) else os.path.join(_CSRC, h) for h in HEADERS]
+    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
+        return LIB_PATH
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
+           "-Wno-unused-command-line-argument", "-I", os.path.join(_ROOT, "include"), "-I", _CSRC, "-o", LIB_PATH] + srcs
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(hipcc --offload-arch=gfx950).  grid_ndt_amd has no fallback implementation.")
+    L = C.CDLL(LIB_PATH)
+    vp, sz, u64 = C.c_void_p, C.c_size_t, C.c_uint64
+    H = C.c_void_p
+    L.gndt_create.argtypes = [C.POINTER(Params), C.POINTER(H)]
+    L.gndt_destroy.argtypes = [H]
+    L.gndt_destroy.restype = None
+    L.gndt_last_error.argtypes = [H]
+    L.gndt_last_error.restype = C.c_char_p
+    L.gndt_set_origin.argtypes = [H, C.POINTER(C.c_float)]
+    L.gndt_build.argtypes = [H, vp, sz, sz]
+    L.gndt_build_device.argtypes = [H, vp, sz, sz, vp]
+    L.gndt_update.argtypes = [H, vp, sz, sz]
+    L.gndt_update_device.argtypes = [H, vp, sz, sz, vp]
+    L.gndt_reset.argtypes = [H, vp]
+    L.gndt_accumulate_device.argtypes = [H, vp, sz, sz, u64, vp]
+    L.gndt_finalize_device.argtypes = [H, vp]
+    L.gndt_sync.argtypes = [H, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64)]
+    L.gndt_export_device.argtypes = [H, C.POINTER(Cells)]
+    L.gndt_export.argtypes = [H, C.POINTER(Cells)]
+    L.gndt_stats_export_device.argtypes = [H, C.POINTER(Stats), vp]
+    L.gndt_stats_merge_device.argtypes = [H, C.POINTER(Stats), vp]
+    L.gndt_trans_morton_xyz.argtypes = [C.POINTER(C.c_float), C.c_float, C.c_float, C.POINTER(C.c_float), C.c_char_p,
+                                        C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_char_p]
+    L.gndt_count_morton.argtypes = [C.c_int32, C.c_int32, C.c_char_p]
+    L.gndt_morton_to_xy.argtypes = [C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    L.gndt_pack_key.argtypes = [C.c_int32, C.c_int32, C.c_int32]
+    L.gndt_pack_key.restype = u64
+    L.gndt_unpack_key.argtypes = [u64, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    L.gndt_unpack_key.restype = None
+    L.gndt_set_profiling.argtypes = [H, C.c_int]
+    L.gndt_get_phase_times.argtypes = [H, C.POINTER(C.c_double)]
+    L.gndt_device_info.argtypes = [C.c_int32, C.c_char_p, C.POINTER(C.c_int32), C.POINTER(u64)]
+    for name in ("gndt_create", "gndt_set_origin", "gndt_build", "gndt_build_device", "gndt_update", "gndt_update_device",
+                 "gndt_reset", "gndt_accumulate_device", "gndt_finalize_device", "gndt_sync", "gndt_export_device",
+                 "gndt_export", "gndt_stats_export_device", "gndt_stats_merge_device", "gndt_trans_morton_xyz",
+                 "gndt_count_morton", "gndt_morton_to_xy", "gndt_device_info", "gndt_set_profiling", "gndt_get_phase_times"):
+        getattr(L, name).restype = C.c_int
+    _lib = L
+    return L

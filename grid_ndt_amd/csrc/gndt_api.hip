@@ -1,0 +1,642 @@
+// gndt_api.hip — the C ABI of include/gndt.h over the kernels of gndt_kernels.hpp.
+// Host code here only owns memory, orders launches on a HIP stream and maps errors to status codes.
+// There is NO CPU fallback: without a HIP device every compute entry point fails with
+// GNDT_ERR_NO_DEVICE.
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+
+#include <hip/hip_runtime.h>
+#include <rocprim/device/device_radix_sort.hpp>
+
+#include "gndt.h"
+#include "gndt_kernels.hpp"
+
+using namespace gndt;
+
+namespace {
+thread_local std::string g_create_error;
+}
+
+struct gndt_handle {
+    gndt_params P{};
+    float origin[3] = {0, 0, 0};
+    bool origin_set = false;
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t last_stream = nullptr;
+
+    // node table
+    uint32_t cap = 0;  // slots, power of two
+    uint64_t* keys = nullptr;
+    NodeAcc* acc = nullptr;
+    uint64_t* col_keys = nullptr;
+    uint32_t* col_first = nullptr;
+    SlotAux* aux = nullptr;
+    // node list + ordering buffers (cap entries each)
+    uint32_t* node_slot = nullptr;
+    uint32_t* col_slot_of_node = nullptr;
+    uint64_t* sort_key = nullptr;
+    uint64_t* sort_key_out = nullptr;
+    uint32_t* sort_val = nullptr;
+    uint32_t* sort_val_out = nullptr;
+    void* sort_tmp = nullptr;
+    size_t sort_tmp_bytes = 0;
+
+    Counters* d_cnt = nullptr;
+    Counters* h_cnt = nullptr;  // pinned
+
+    // results
+    uint64_t out_cap = 0;
+    OutView out{};
+    uint64_t res_nodes = 0, res_columns = 0, res_slopes = 0;
+    bool results_valid = false;
+
+    // stats export buffers
+    uint64_t st_cap = 0;
+    uint64_t* st_key = nullptr;
+    double* st_sums = nullptr;
+    uint32_t* st_count = nullptr;
+    uint32_t* st_first = nullptr;
+
+    // staging for host input
+    void* stage = nullptr;
+    size_t stage_bytes = 0;
+
+    uint64_t stream_pos = 0;    // points accumulated since the last reset (first_idx base)
+    bool table_dirty = false;   // table holds nodes
+    bool list_valid = false;    // node_slot / col_slot_of_node describe the table's occupied slots
+
+    // optional phase timing (bench / profiling): events recorded on the launch stream
+    bool prof = false;
+    hipEvent_t ev[GNDT_NUM_PHASES + 1] = {};
+    bool ev_recorded[GNDT_NUM_PHASES + 1] = {};
+
+    std::string err;
+};
+
+namespace {
+
+#define HIP_TRY(h, expr)                                                                                 \
+    do {                                                                                                 \
+        hipError_t e__ = (expr);                                                                         \
+        if (e__ != hipSuccess) {                                                                         \
+            (h)->err = std::string(#expr) + ": " + hipGetErrorString(e__);                               \
+            return GNDT_ERR_HIP;                                                                         \
+        }                                                                                                \
+    } while (0)
+
+inline void mark(gndt_handle* h, int i, hipStream_t s) {
+    if (h->prof && h->ev[i]) { (void)hipEventRecord(h->ev[i], s); h->ev_recorded[i] = true; }
+}
+
+inline int grid_for(uint64_t work, int block = kBlock, int max_blocks = 256 * 8) {
+    uint64_t b = (work + block - 1) / block;
+    if (b < 1) b = 1;
+    if (b > (uint64_t)max_blocks) b = max_blocks;
+    return (int)b;
+}
+
+uint32_t pow2_ceil(uint64_t v) {
+    uint64_t p = 1024;
+    while (p < v && p < (1ull << 31)) p <<= 1;
+    return (uint32_t)p;
+}
+
+GridParams grid_params(const gndt_handle* h) {
+    GridParams g;
+    g.ox = h->origin[0]; g.oy = h->origin[1]; g.oz = h->origin[2];
+    g.grid_len = h->P.grid_len; g.z_len = h->P.z_len; g.slope_interval = h->P.slope_interval;
+    g.demand = h->P.demand; g.min_points = h->P.min_points;
+    return g;
+}
+
+void free_table(gndt_handle* h) {
+    void* ptrs[] = {h->keys, h->acc, h->col_keys, h->col_first, h->aux, h->node_slot, h->col_slot_of_node,
+                    h->sort_key, h->sort_key_out, h->sort_val, h->sort_val_out, h->sort_tmp};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    h->keys = nullptr; h->acc = nullptr; h->col_keys = nullptr; h->col_first = nullptr; h->aux = nullptr;
+    h->node_slot = nullptr; h->col_slot_of_node = nullptr; h->sort_key = nullptr; h->sort_key_out = nullptr;
+    h->sort_val = nullptr; h->sort_val_out = nullptr; h->sort_tmp = nullptr;
+    h->cap = 0;
+}
+
+int alloc_table(gndt_handle* h, uint32_t cap, hipStream_t s) {
+    free_table(h);
+    HIP_TRY(h, hipMalloc(&h->keys, (size_t)cap * sizeof(uint64_t)));
+    HIP_TRY(h, hipMalloc(&h->acc, (size_t)cap * sizeof(NodeAcc)));
+    HIP_TRY(h, hipMalloc(&h->col_keys, (size_t)cap * sizeof(uint64_t)));
+    HIP_TRY(h, hipMalloc(&h->col_first, (size_t)cap * sizeof(uint32_t)));
+    HIP_TRY(h, hipMalloc(&h->aux, (size_t)cap * sizeof(SlotAux)));
+    HIP_TRY(h, hipMalloc(&h->node_slot, (size_t)cap * sizeof(uint32_t)));
+    HIP_TRY(h, hipMalloc(&h->col_slot_of_node, (size_t)cap * sizeof(uint32_t)));
+    HIP_TRY(h, hipMalloc(&h->sort_key, (size_t)cap * sizeof(uint64_t)));
+    HIP_TRY(h, hipMalloc(&h->sort_key_out, (size_t)cap * sizeof(uint64_t)));
+    HIP_TRY(h, hipMalloc(&h->sort_val, (size_t)cap * sizeof(uint32_t)));
+    HIP_TRY(h, hipMalloc(&h->sort_val_out, (size_t)cap * sizeof(uint32_t)));
+    size_t tmp = 0;
+    HIP_TRY(h, rocprim::radix_sort_pairs(nullptr, tmp, h->sort_key, h->sort_key_out, h->sort_val, h->sort_val_out,
+                                         (size_t)cap, 0, 64, s));
+    h->sort_tmp_bytes = tmp;
+    HIP_TRY(h, hipMalloc(&h->sort_tmp, tmp ? tmp : 16));
+    h->cap = cap;
+    hipLaunchKernelGGL(k_clear_all, dim3(grid_for(cap)), dim3(kBlock), 0, s, h->keys, h->acc, h->col_keys,
+                       h->col_first, cap);
+    HIP_TRY(h, hipGetLastError());
+    h->table_dirty = false;
+    h->list_valid = false;
+    return GNDT_OK;
+}
+
+int ensure_out(gndt_handle* h, uint64_t n) {
+    if (n <= h->out_cap) return GNDT_OK;
+    void* ptrs[] = {h->out.sx, h->out.sy, h->out.sz, h->out.count, h->out.first_idx, h->out.mean, h->out.cov,
+                    h->out.rough, h->out.normal, h->out.flags};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    h->out = OutView{};
+    h->out_cap = 0;
+    uint64_t c = std::max<uint64_t>(1024, n + n / 8);
+    HIP_TRY(h, hipMalloc(&h->out.sx, c * 4));
+    HIP_TRY(h, hipMalloc(&h->out.sy, c * 4));
+    HIP_TRY(h, hipMalloc(&h->out.sz, c * 4));
+    HIP_TRY(h, hipMalloc(&h->out.count, c * 4));
+    HIP_TRY(h, hipMalloc(&h->out.first_idx, c * 4));
+    HIP_TRY(h, hipMalloc(&h->out.mean, c * 12));
+    HIP_TRY(h, hipMalloc(&h->out.cov, c * 24));
+    HIP_TRY(h, hipMalloc(&h->out.rough, c * 4));
+    HIP_TRY(h, hipMalloc(&h->out.normal, c * 12));
+    HIP_TRY(h, hipMalloc(&h->out.flags, c * 4));
+    h->out_cap = c;
+    return GNDT_OK;
+}
+
+int ensure_stats_buffers(gndt_handle* h, uint64_t n) {
+    if (n <= h->st_cap) return GNDT_OK;
+    void* ptrs[] = {h->st_key, h->st_sums, h->st_count, h->st_first};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    h->st_key = nullptr; h->st_sums = nullptr; h->st_count = nullptr; h->st_first = nullptr; h->st_cap = 0;
+    uint64_t c = std::max<uint64_t>(1024, n + n / 8);
+    HIP_TRY(h, hipMalloc(&h->st_key, c * 8));
+    HIP_TRY(h, hipMalloc(&h->st_sums, c * 72));
+    HIP_TRY(h, hipMalloc(&h->st_count, c * 4));
+    HIP_TRY(h, hipMalloc(&h->st_first, c * 4));
+    h->st_cap = c;
+    return GNDT_OK;
+}
+
+// read the device counters (synchronises the stream)
+int fetch_counters(gndt_handle* h, hipStream_t s) {
+    HIP_TRY(h, hipMemcpyAsync(h->h_cnt, h->d_cnt, sizeof(Counters), hipMemcpyDeviceToHost, s));
+    HIP_TRY(h, hipStreamSynchronize(s));
+    return GNDT_OK;
+}
+
+// slots wanted for `nodes` occupied entries (load factor <= 1/2)
+uint32_t cap_for_nodes(uint64_t nodes) { return pow2_ceil(std::max<uint64_t>(2048, nodes * 2)); }
+
+int check_ready(gndt_handle* h) {
+    if (!h) return GNDT_ERR_INVALID;
+    if (!h->origin_set) { h->err = "gndt_set_origin must be called first (setCloudFirst, receiver.cpp:145)"; return GNDT_ERR_INVALID; }
+    HIP_TRY(h, hipSetDevice(h->device));
+    return GNDT_OK;
+}
+
+int do_reset(gndt_handle* h, hipStream_t s) {
+    if (h->cap && h->table_dirty) {
+        if (h->list_valid) {
+            hipLaunchKernelGGL(k_clear_used, dim3(grid_for(h->cap / 8)), dim3(kBlock), 0, s, h->keys, h->acc, h->col_keys,
+                               h->col_first, h->node_slot, h->col_slot_of_node, h->d_cnt);
+        } else {
+            hipLaunchKernelGGL(k_clear_all, dim3(grid_for(h->cap)), dim3(kBlock), 0, s, h->keys, h->acc, h->col_keys,
+                               h->col_first, h->cap);
+        }
+        HIP_TRY(h, hipGetLastError());
+    }
+    hipLaunchKernelGGL(k_zero_counters, dim3(1), dim3(64), 0, s, h->d_cnt, 1);
+    HIP_TRY(h, hipGetLastError());
+    h->table_dirty = false;
+    h->list_valid = false;
+    h->results_valid = false;
+    h->stream_pos = 0;
+    return GNDT_OK;
+}
+
+// Grow the table to `new_cap` slots keeping its contents (export -> fresh table -> merge).
+int grow_table(gndt_handle* h, uint32_t new_cap, hipStream_t s);
+
+int do_scan(gndt_handle* h, hipStream_t s) {
+    hipLaunchKernelGGL(k_zero_counters, dim3(1), dim3(64), 0, s, h->d_cnt, 0);
+    hipLaunchKernelGGL(k_scan_nodes, dim3(grid_for(h->cap)), dim3(kBlock), 0, s, h->keys, h->acc, h->col_keys,
+                       h->col_first, h->node_slot, h->col_slot_of_node, h->aux, h->cap - 1, grid_params(h), h->d_cnt);
+    HIP_TRY(h, hipGetLastError());
+    h->list_valid = true;
+    return GNDT_OK;
+}
+
+int do_accumulate(gndt_handle* h, const void* xyz_dev, size_t n, size_t stride_bytes, uint64_t first_base,
+                  hipStream_t s) {
+    if (stride_bytes != 12 && stride_bytes != 16) { h->err = "stride_bytes must be 12 or 16"; return GNDT_ERR_INVALID; }
+    if (first_base + n >= 0xFFFFFFFFull) { h->err = "point index exceeds 32 bits"; return GNDT_ERR_INVALID; }
+    if (n == 0) return GNDT_OK;
+    const float* p = static_cast<const float*>(xyz_dev);
+    const int blocks = grid_for(n, kBlock, 256 * 16);
+    if (stride_bytes == 12)
+        hipLaunchKernelGGL(k_accumulate<3>, dim3(blocks), dim3(kBlock), 0, s, p, (uint64_t)n, (uint32_t)first_base,
+                           grid_params(h), h->keys, h->acc, h->cap - 1, h->d_cnt);
+    else
+        hipLaunchKernelGGL(k_accumulate<4>, dim3(blocks), dim3(kBlock), 0, s, p, (uint64_t)n, (uint32_t)first_base,
+                           grid_params(h), h->keys, h->acc, h->cap - 1, h->d_cnt);
+    HIP_TRY(h, hipGetLastError());
+    h->table_dirty = true;
+    h->list_valid = false;
+    h->results_valid = false;
+    return GNDT_OK;
+}
+
+// scan -> label -> order -> emit.  Synchronises once (the sort needs the node count on the host).
+int do_finalize(gndt_handle* h, hipStream_t s) {
+    int rc = do_scan(h, s);
+    if (rc) return rc;
+    mark(h, 3, s);
+    rc = fetch_counters(h, s);
+    if (rc) return rc;
+    if (h->h_cnt->err_table_full) {
+        h->err = "node table full (" + std::to_string(h->cap) + " slots): raise gndt_params.max_nodes_hint";
+        return GNDT_ERR_CAPACITY;
+    }
+    const uint32_t C = h->h_cnt->num_nodes;
+    rc = ensure_out(h, C);
+    if (rc) return rc;
+    if (C > 0) {
+        const GridParams gp = grid_params(h);
+        hipLaunchKernelGGL(k_label_nodes, dim3(grid_for(C)), dim3(kBlock), 0, s, h->keys, h->acc, h->col_first,
+                           h->node_slot, h->col_slot_of_node, h->aux, h->sort_key, h->sort_val, h->cap - 1, gp, h->d_cnt);
+        HIP_TRY(h, hipGetLastError());
+        mark(h, 4, s);
+        size_t tmp = h->sort_tmp_bytes;
+        HIP_TRY(h, rocprim::radix_sort_pairs(h->sort_tmp, tmp, h->sort_key, h->sort_key_out, h->sort_val,
+                                             h->sort_val_out, (size_t)C, 0, 64, s));
+        mark(h, 5, s);
+        hipLaunchKernelGGL(k_emit_nodes, dim3(grid_for(C)), dim3(kBlock), 0, s, h->keys, h->acc, h->aux, h->sort_val_out,
+                           h->out, gp, h->d_cnt);
+        HIP_TRY(h, hipGetLastError());
+        mark(h, 6, s);
+    }
+    HIP_TRY(h, hipMemcpyAsync(h->h_cnt, h->d_cnt, sizeof(Counters), hipMemcpyDeviceToHost, s));
+    h->results_valid = true;
+    h->last_stream = s;
+    return GNDT_OK;
+}
+
+int ensure_capacity_for(gndt_handle* h, uint64_t expected_nodes, hipStream_t s) {
+    const uint32_t want = cap_for_nodes(expected_nodes);
+    if (h->cap == 0) return alloc_table(h, want, s);
+    if (want > h->cap) return grow_table(h, want, s);
+    return GNDT_OK;
+}
+
+int grow_table(gndt_handle* h, uint32_t new_cap, hipStream_t s) {
+    if (!h->table_dirty) return alloc_table(h, new_cap, s);
+    // export current contents
+    int rc = GNDT_OK;
+    if (!h->list_valid) { rc = do_scan(h, s); if (rc) return rc; }
+    rc = fetch_counters(h, s);
+    if (rc) return rc;
+    const uint32_t C = h->h_cnt->num_nodes;
+    rc = ensure_stats_buffers(h, C);
+    if (rc) return rc;
+    if (C) {
+        hipLaunchKernelGGL(k_stats_export, dim3(grid_for(C)), dim3(kBlock), 0, s, h->keys, h->acc, h->node_slot, h->d_cnt,
+                           h->st_key, h->st_sums, h->st_count, h->st_first);
+        HIP_TRY(h, hipGetLastError());
+    }
+    HIP_TRY(h, hipStreamSynchronize(s));
+    rc = alloc_table(h, new_cap, s);
+    if (rc) return rc;
+    if (C) {
+        hipLaunchKernelGGL(k_stats_merge, dim3(grid_for(C)), dim3(kBlock), 0, s, h->keys, h->acc, h->cap - 1, h->st_key,
+                           h->st_sums, h->st_count, h->st_first, (uint64_t)C, h->d_cnt);
+        HIP_TRY(h, hipGetLastError());
+        h->table_dirty = true;
+    }
+    return GNDT_OK;
+}
+
+uint64_t expected_nodes_for_batch(const gndt_handle* h, uint64_t known_nodes, uint64_t n) {
+    if (h->P.max_nodes_hint) return std::max<uint64_t>(h->P.max_nodes_hint, known_nodes);
+    return known_nodes + n;   // worst case: every point opens a node
+}
+
+int stage_host_input(gndt_handle* h, const void* xyz_host, size_t n, size_t stride_bytes, hipStream_t s) {
+    const size_t bytes = n * stride_bytes;
+    if (bytes > h->stage_bytes) {
+        if (h->stage) (void)hipFree(h->stage);
+        h->stage = nullptr; h->stage_bytes = 0;
+        HIP_TRY(h, hipMalloc(&h->stage, bytes + 64));
+        h->stage_bytes = bytes;
+    }
+    if (bytes) HIP_TRY(h, hipMemcpyAsync(h->stage, xyz_host, bytes, hipMemcpyHostToDevice, s));
+    return GNDT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* gndt_last_error(const gndt_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int gndt_create(const gndt_params* params, gndt_handle** out) {
+    if (!params || !out) { g_create_error = "null argument"; return GNDT_ERR_INVALID; }
+    *out = nullptr;
+    if (!(params->grid_len > 0.f) || !(params->z_len > 0.f) || params->min_points < 1 ||
+        (params->demand != GNDT_DEMAND_SLOPE && params->demand != GNDT_DEMAND_TRUE)) {
+        g_create_error = "invalid gndt_params (grid_len/z_len must be > 0, demand 0|1, min_points >= 1)";
+        return GNDT_ERR_INVALID;
+    }
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) {
+        g_create_error = "no HIP device available (libgndt has no CPU path)";
+        return GNDT_ERR_NO_DEVICE;
+    }
+    if (params->device_id < 0 || params->device_id >= ndev) { g_create_error = "device_id out of range"; return GNDT_ERR_INVALID; }
+    gndt_handle* h = new (std::nothrow) gndt_handle;
+    if (!h) { g_create_error = "out of host memory"; return GNDT_ERR_NOMEM; }
+    h->P = *params;
+    h->device = params->device_id;
+    auto fail = [&](const char* what, hipError_t err) {
+        g_create_error = std::string(what) + ": " + hipGetErrorString(err);
+        gndt_destroy(h);
+        return GNDT_ERR_HIP;
+    };
+    if ((e = hipSetDevice(h->device)) != hipSuccess) return fail("hipSetDevice", e);
+    if ((e = hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking)) != hipSuccess) return fail("hipStreamCreate", e);
+    if ((e = hipMalloc(&h->d_cnt, sizeof(Counters))) != hipSuccess) return fail("hipMalloc", e);
+    if ((e = hipHostMalloc(&h->h_cnt, sizeof(Counters))) != hipSuccess) return fail("hipHostMalloc", e);
+    if ((e = hipMemset(h->d_cnt, 0, sizeof(Counters))) != hipSuccess) return fail("hipMemset", e);
+    memset(h->h_cnt, 0, sizeof(Counters));
+    h->last_stream = h->own_stream;
+    if (params->max_nodes_hint) {
+        int rc = alloc_table(h, cap_for_nodes(params->max_nodes_hint), h->own_stream);
+        if (rc) { g_create_error = h->err; gndt_destroy(h); return rc; }
+        if ((e = hipStreamSynchronize(h->own_stream)) != hipSuccess) return fail("hipStreamSynchronize", e);
+    }
+    *out = h;
+    return GNDT_OK;
+}
+
+void gndt_destroy(gndt_handle* h) {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    (void)hipDeviceSynchronize();
+    free_table(h);
+    void* ptrs[] = {h->out.sx, h->out.sy, h->out.sz, h->out.count, h->out.first_idx, h->out.mean, h->out.cov,
+                    h->out.rough, h->out.normal, h->out.flags, h->st_key, h->st_sums, h->st_count, h->st_first,
+                    h->stage, h->d_cnt};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    for (auto& e : h->ev)
+        if (e) (void)hipEventDestroy(e);
+    if (h->h_cnt) (void)hipHostFree(h->h_cnt);
+    if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+    delete h;
+}
+
+int gndt_set_origin(gndt_handle* h, const float origin_xyz[3]) {
+    if (!h || !origin_xyz) return GNDT_ERR_INVALID;
+    if (h->table_dirty) { h->err = "origin cannot change while the map holds points (call gndt_reset)"; return GNDT_ERR_INVALID; }
+    memcpy(h->origin, origin_xyz, 3 * sizeof(float));
+    h->origin_set = true;
+    return GNDT_OK;
+}
+
+int gndt_reset(gndt_handle* h, void* hip_stream) {
+    if (!h) return GNDT_ERR_INVALID;
+    HIP_TRY(h, hipSetDevice(h->device));
+    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
+    h->last_stream = s;
+    return do_reset(h, s);
+}
+
+int gndt_accumulate_device(gndt_handle* h, const void* xyz_dev, size_t n, size_t stride_bytes,
+                           uint64_t first_idx_base, void* hip_stream) {
+    int rc = check_ready(h);
+    if (rc) return rc;
+    if (!xyz_dev && n) { h->err = "null input"; return GNDT_ERR_INVALID; }
+    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
+    h->last_stream = s;
+    uint64_t known = h->results_valid ? h->res_nodes : (h->table_dirty ? h->h_cnt->num_nodes : 0);
+    rc = ensure_capacity_for(h, expected_nodes_for_batch(h, known, n), s);
+    if (rc) return rc;
+    mark(h, 1, s);
+    rc = do_accumulate(h, xyz_dev, n, stride_bytes, first_idx_base, s);
+    if (rc) return rc;
+    mark(h, 2, s);
+    h->stream_pos = std::max<uint64_t>(h->stream_pos, first_idx_base + n);
+    return GNDT_OK;
+}
+
+int gndt_finalize_device(gndt_handle* h, void* hip_stream) {
+    int rc = check_ready(h);
+    if (rc) return rc;
+    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
+    h->last_stream = s;
+    if (h->cap == 0) {
+        rc = alloc_table(h, cap_for_nodes(1024), s);
+        if (rc) return rc;
+    }
+    return do_finalize(h, s);
+}
+
+int gndt_build_device(gndt_handle* h, const void* xyz_dev, size_t n, size_t stride_bytes, void* hip_stream) {
+    int rc = check_ready(h);
+    if (rc) return rc;
+    if (!xyz_dev && n) { h->err = "null input"; return GNDT_ERR_INVALID; }
+    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
+    h->last_stream = s;
+    uint64_t expect = h->P.max_nodes_hint ? h->P.max_nodes_hint : std::max<uint64_t>(1024, n / 4);
+    for (int attempt = 0; attempt < 8; ++attempt) {
+        const uint32_t want = cap_for_nodes(expect);
+        if (h->cap < want) { rc = alloc_table(h, want, s); if (rc) return rc; }
+        mark(h, 0, s);
+        rc = do_reset(h, s);
+        if (rc) return rc;
+        mark(h, 1, s);
+        rc = do_accumulate(h, xyz_dev, n, stride_bytes, 0, s);
+        if (rc) return rc;
+        mark(h, 2, s);
+        h->stream_pos = n;
+        rc = do_finalize(h, s);
+        if (rc != GNDT_ERR_CAPACITY) return rc;
+        // table overflowed: the build starts from empty, so simply redo it in a larger table
+        h->list_valid = false;
+        expect = (uint64_t)h->cap * 2;   // cap_for_nodes doubles again -> 4x slots
+        if (expect > (1ull << 30)) break;
+    }
+    return GNDT_ERR_CAPACITY;
+}
+
+int gndt_update_device(gndt_handle* h, const void* xyz_dev, size_t n, size_t stride_bytes, void* hip_stream) {
+    int rc = check_ready(h);
+    if (rc) return rc;
+    rc = gndt_accumulate_device(h, xyz_dev, n, stride_bytes, h->stream_pos, hip_stream);
+    if (rc) return rc;
+    return gndt_finalize_device(h, hip_stream);
+}
+
+int gndt_build(gndt_handle* h, const void* xyz_host, size_t n, size_t stride_bytes) {
+    int rc = check_ready(h);
+    if (rc) return rc;
+    if (!xyz_host && n) { h->err = "null input"; return GNDT_ERR_INVALID; }
+    rc = stage_host_input(h, xyz_host, n, stride_bytes, h->own_stream);
+    if (rc) return rc;
+    rc = gndt_build_device(h, h->stage, n, stride_bytes, h->own_stream);
+    if (rc) return rc;
+    return gndt_sync(h, nullptr, nullptr, nullptr);
+}
+
+int gndt_update(gndt_handle* h, const void* xyz_host, size_t n, size_t stride_bytes) {
+    int rc = check_ready(h);
+    if (rc) return rc;
+    if (!xyz_host && n) { h->err = "null input"; return GNDT_ERR_INVALID; }
+    rc = stage_host_input(h, xyz_host, n, stride_bytes, h->own_stream);
+    if (rc) return rc;
+    rc = gndt_update_device(h, h->stage, n, stride_bytes, h->own_stream);
+    if (rc) return rc;
+    return gndt_sync(h, nullptr, nullptr, nullptr);
+}
+
+int gndt_sync(gndt_handle* h, uint64_t* num_nodes, uint64_t* num_columns, uint64_t* num_slopes) {
+    if (!h) return GNDT_ERR_INVALID;
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipStreamSynchronize(h->last_stream));
+    if (h->results_valid) {
+        h->res_nodes = h->h_cnt->num_nodes;
+        h->res_columns = h->h_cnt->num_columns;
+        h->res_slopes = h->h_cnt->num_slopes;
+    }
+    if (num_nodes) *num_nodes = h->res_nodes;
+    if (num_columns) *num_columns = h->res_columns;
+    if (num_slopes) *num_slopes = h->res_slopes;
+    if (h->h_cnt->err_key_range) {
+        h->err = std::to_string(h->h_cnt->err_key_range) +
+                 " point(s) outside the key range (|nx|,|ny| <= 65535: countMorton wraps beyond, Stopwatch.h:102-110)";
+        return GNDT_ERR_KEY_RANGE;
+    }
+    if (h->h_cnt->err_table_full) { h->err = "node table full: raise gndt_params.max_nodes_hint"; return GNDT_ERR_CAPACITY; }
+    return GNDT_OK;
+}
+
+int gndt_export_device(gndt_handle* h, gndt_cells* out) {
+    if (!h || !out) return GNDT_ERR_INVALID;
+    if (!h->results_valid) { h->err = "no finished build to export"; return GNDT_ERR_INVALID; }
+    int rc = gndt_sync(h, nullptr, nullptr, nullptr);
+    if (rc) return rc;
+    out->num_nodes = h->res_nodes; out->num_columns = h->res_columns; out->num_slopes = h->res_slopes;
+    out->sx = h->out.sx; out->sy = h->out.sy; out->sz = h->out.sz;
+    out->count = h->out.count; out->first_idx = h->out.first_idx;
+    out->mean = h->out.mean; out->cov = h->out.cov; out->rough = h->out.rough; out->normal = h->out.normal;
+    out->flags = h->out.flags;
+    return GNDT_OK;
+}
+
+int gndt_export(gndt_handle* h, gndt_cells* o) {
+    if (!h || !o) return GNDT_ERR_INVALID;
+    if (!h->results_valid) { h->err = "no finished build to export"; return GNDT_ERR_INVALID; }
+    int rc = gndt_sync(h, nullptr, nullptr, nullptr);
+    if (rc) return rc;
+    const uint64_t n = h->res_nodes;
+    o->num_nodes = n; o->num_columns = h->res_columns; o->num_slopes = h->res_slopes;
+    struct { void* dst; const void* src; size_t elem; } copies[] = {
+        {o->sx, h->out.sx, 4}, {o->sy, h->out.sy, 4}, {o->sz, h->out.sz, 4}, {o->count, h->out.count, 4},
+        {o->first_idx, h->out.first_idx, 4}, {o->mean, h->out.mean, 12}, {o->cov, h->out.cov, 24},
+        {o->rough, h->out.rough, 4}, {o->normal, h->out.normal, 12}, {o->flags, h->out.flags, 4}};
+    for (auto& c : copies)
+        if (c.dst && n) HIP_TRY(h, hipMemcpy(c.dst, c.src, n * c.elem, hipMemcpyDeviceToHost));
+    return GNDT_OK;
+}
+
+int gndt_stats_export_device(gndt_handle* h, gndt_stats* out, void* hip_stream) {
+    int rc = check_ready(h);
+    if (rc) return rc;
+    if (!out) return GNDT_ERR_INVALID;
+    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
+    h->last_stream = s;
+    if (h->cap == 0) { rc = alloc_table(h, cap_for_nodes(1024), s); if (rc) return rc; }
+    if (!h->list_valid) { rc = do_scan(h, s); if (rc) return rc; }
+    rc = fetch_counters(h, s);
+    if (rc) return rc;
+    if (h->h_cnt->err_table_full) { h->err = "node table full: raise gndt_params.max_nodes_hint"; return GNDT_ERR_CAPACITY; }
+    const uint32_t C = h->h_cnt->num_nodes;
+    rc = ensure_stats_buffers(h, C);
+    if (rc) return rc;
+    if (C) {
+        hipLaunchKernelGGL(k_stats_export, dim3(grid_for(C)), dim3(kBlock), 0, s, h->keys, h->acc, h->node_slot, h->d_cnt,
+                           h->st_key, h->st_sums, h->st_count, h->st_first);
+        HIP_TRY(h, hipGetLastError());
+    }
+    out->num_nodes = C;
+    out->key = h->st_key; out->sums = h->st_sums; out->count = h->st_count; out->first_idx = h->st_first;
+    return GNDT_OK;
+}
+
+int gndt_stats_merge_device(gndt_handle* h, const gndt_stats* in, void* hip_stream) {
+    int rc = check_ready(h);
+    if (rc) return rc;
+    if (!in) return GNDT_ERR_INVALID;
+    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
+    h->last_stream = s;
+    uint64_t known = h->table_dirty ? h->h_cnt->num_nodes : 0;
+    rc = ensure_capacity_for(h, std::max<uint64_t>(h->P.max_nodes_hint, known + in->num_nodes), s);
+    if (rc) return rc;
+    if (in->num_nodes) {
+        hipLaunchKernelGGL(k_stats_merge, dim3(grid_for(in->num_nodes)), dim3(kBlock), 0, s, h->keys, h->acc, h->cap - 1,
+                           in->key, in->sums, in->count, in->first_idx, (uint64_t)in->num_nodes, h->d_cnt);
+        HIP_TRY(h, hipGetLastError());
+        h->table_dirty = true;
+        h->list_valid = false;
+        h->results_valid = false;
+    }
+    return GNDT_OK;
+}
+
+int gndt_set_profiling(gndt_handle* h, int enable) {
+    if (!h) return GNDT_ERR_INVALID;
+    HIP_TRY(h, hipSetDevice(h->device));
+    if (enable)
+        for (auto& e : h->ev)
+            if (!e) HIP_TRY(h, hipEventCreate(&e));
+    for (auto& r : h->ev_recorded) r = false;
+    h->prof = enable != 0;
+    return GNDT_OK;
+}
+
+int gndt_get_phase_times(gndt_handle* h, double ms_out[GNDT_NUM_PHASES]) {
+    if (!h || !ms_out) return GNDT_ERR_INVALID;
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipStreamSynchronize(h->last_stream));
+    for (int i = 0; i < GNDT_NUM_PHASES; ++i) {
+        ms_out[i] = -1.0;
+        if (h->ev_recorded[i] && h->ev_recorded[i + 1]) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, h->ev[i], h->ev[i + 1]) == hipSuccess) ms_out[i] = ms;
+        }
+    }
+    return GNDT_OK;
+}
+
+int gndt_device_info(int32_t device_id, char name_out[128], int32_t* compute_units, uint64_t* hbm_bytes) {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_id) != hipSuccess) return GNDT_ERR_NO_DEVICE;
+    if (name_out) { strncpy(name_out, prop.name, 127); name_out[127] = 0; }
+    if (compute_units) *compute_units = prop.multiProcessorCount;
+    if (hbm_bytes) *hbm_bytes = prop.totalGlobalMem;
+    return GNDT_OK;
+}
+
+}  // extern "C"

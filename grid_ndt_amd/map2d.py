@@ -1,0 +1,287 @@
+"""Host-side mirror of the reference's map interface for the grid-build path, over libgndt's C ABI.
+
+`TwoDmap` keeps the reference's method names and argument meaning (include/map2D.h:485-507,
+592-668, 950-976); the loop `for i in 1..n-1: uniformDivision(points[i])` + `create2DMap(demand)`
+(src/receiver.cpp:150-160) becomes one call, `create2DMap(demand, cloud)`.  PyTorch appears only as
+the owner of device memory and streams.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import Cells, GndtError, Params, Stats
+
+DEMANDS = {"slope": 0, "true": 1}
+FLAG_HAS_STATS, FLAG_SLOPE, FLAG_DOWN = 1, 2, 4
+
+
+def _stream_ptr(stream):
+    if stream is None:
+        try:
+            import torch
+            if torch.cuda.is_available():
+                return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        except ImportError:
+            pass
+        return C.c_void_p(0)
+    if hasattr(stream, "cuda_stream"):
+        return C.c_void_p(stream.cuda_stream)
+    return C.c_void_p(int(stream))
+
+
+class _DevArray:
+    """Minimal __cuda_array_interface__ carrier so torch can view libgndt's device buffers zero-copy."""
+
+    def __init__(self, ptr, shape, typestr, owner):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False),
+                                         "version": 2, "strides": None}
+        self._owner = owner
+
+
+class TwoDmap:
+    """daysun::TwoDmap for the build path (include/map2D.h:190-194, 485-507)."""
+
+    def __init__(self, res, zres, device=0, max_nodes_hint=0, max_points_hint=0, strategy=0, min_points=3):
+        self._L = _lib.lib()
+        self.gridLen, self.zLen = float(res), float(zres)   # TwoDmap(res, zres), map2D.h:486
+        self.slope_interval = 0.0
+        self.device, self.strategy, self.min_points = int(device), int(strategy), int(min_points)
+        self.max_nodes_hint, self.max_points_hint = int(max_nodes_hint), int(max_points_hint)
+        self.cloudFirst = None
+        self._h = None
+        self._demand = None
+
+    # ---- setters / getters with the reference's names (map2D.h:487-502) ----
+    def getGridLen(self):
+        return self.gridLen
+
+    def getZLen(self):
+        return self.zLen
+
+    def setCloudFirst(self, p):
+        self.cloudFirst = tuple(float(v) for v in p[:3])
+        if self._h is not None:
+            self._destroy()
+
+    def setLen(self, length):
+        self.gridLen = float(length)
+        self._destroy()
+
+    def setZLen(self, length):
+        self.zLen = float(length)
+        self._destroy()
+
+    def setInterval(self, interval):
+        self.slope_interval = float(interval)
+        self._destroy()
+
+    def getInterval(self):
+        return self.slope_interval
+
+    # ---- transMortonXYZ (map2D.h:950-976): host codec, same strings as the reference's map keys ----
+    def transMortonXYZ(self, position):
+        o = (C.c_float * 3)(*self.cloudFirst)
+        p = (C.c_float * 3)(*[float(v) for v in position[:3]])
+        q = C.create_string_buffer(2)
+        key = C.create_string_buffer(16)
+        nx, ny, sz = C.c_int32(), C.c_int32(), C.c_int32()
+        rc = self._L.gndt_trans_morton_xyz(o, self.gridLen, self.zLen, p, q, C.byref(nx), C.byref(ny), C.byref(sz), key)
+        if rc:
+            raise GndtError(rc, "position outside the key range")
+        return key.value.decode(), sz.value
+
+    # ---- handle management ----
+    def _destroy(self):
+        if self._h is not None:
+            self._L.gndt_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self._destroy()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc:
+            msg = self._L.gndt_last_error(self._h)
+            raise GndtError(rc, msg.decode() if msg else "")
+
+    def _ensure(self, demand):
+        d = DEMANDS[demand] if isinstance(demand, str) else int(demand)
+        if self._h is not None and self._demand == d:
+            return
+        self._destroy()
+        if self.cloudFirst is None:
+            raise GndtError(1, "setCloudFirst must be called before building (receiver.cpp:145)")
+        P = Params(self.gridLen, self.zLen, self.slope_interval, d, self.min_points, self.device, self.strategy,
+                   self.max_points_hint, self.max_nodes_hint)
+        h = C.c_void_p()
+        rc = self._L.gndt_create(C.byref(P), C.byref(h))
+        if rc:
+            msg = self._L.gndt_last_error(None)
+            raise GndtError(rc, msg.decode() if msg else "")
+        self._h, self._demand = h, d
+        o = (C.c_float * 3)(*self.cloudFirst)
+        self._check(self._L.gndt_set_origin(self._h, o))
+
+    @staticmethod
+    def _as_input(points):
+        """-> (pointer, n, stride_bytes, is_device, keepalive)"""
+        try:
+            import torch
+            if isinstance(points, torch.Tensor):
+                assert points.dtype == torch.float32 and points.dim() == 2 and points.shape[1] in (3, 4)
+                t = points if points.is_contiguous() else points.contiguous()
+                return t.data_ptr(), t.shape[0], 4 * t.shape[1], t.is_cuda, t
+        except ImportError:
+            pass
+        a = np.ascontiguousarray(points, dtype=np.float32)
+        assert a.ndim == 2 and a.shape[1] in (3, 4)
+        return a.ctypes.data, a.shape[0], 4 * a.shape[1], False, a
+
+    # ---- the build: receiver.cpp:150-154 + map2D.h:592 ----
+    def create2DMap(self, demand, points, stream=None):
+        """`points` = the cloud WITHOUT point 0 ([N,3] or [N,4] float32; torch CUDA tensor, torch CPU
+        tensor or numpy).  Device input is enqueued on `stream` (default: torch's current stream)."""
+        self._ensure(demand)
+        ptr, n, stride, on_dev, keep = self._as_input(points)
+        if on_dev:
+            self._check(self._L.gndt_build_device(self._h, C.c_void_p(ptr), n, stride, _stream_ptr(stream)))
+        else:
+            self._check(self._L.gndt_build(self._h, C.c_void_p(ptr), n, stride))
+        self._keep = keep
+        return True
+
+    def change2DMap(self, demand, points, stream=None):
+        """Incremental add (intent of map2D.h:672-822 as defined in SURVEY Appendix A.7)."""
+        self._ensure(demand)
+        ptr, n, stride, on_dev, keep = self._as_input(points)
+        if on_dev:
+            self._check(self._L.gndt_update_device(self._h, C.c_void_p(ptr), n, stride, _stream_ptr(stream)))
+        else:
+            self._check(self._L.gndt_update(self._h, C.c_void_p(ptr), n, stride))
+        self._keep = keep
+        return True
+
+    # ---- split form for sharded clouds ----
+    def reset(self, demand="slope", stream=None):
+        self._ensure(demand)
+        self._check(self._L.gndt_reset(self._h, _stream_ptr(stream)))
+
+    def accumulate(self, demand, points, first_idx_base=0, stream=None):
+        self._ensure(demand)
+        ptr, n, stride, on_dev, keep = self._as_input(points)
+        if not on_dev:
+            raise GndtError(1, "accumulate takes device memory")
+        self._check(self._L.gndt_accumulate_device(self._h, C.c_void_p(ptr), n, stride, int(first_idx_base), _stream_ptr(stream)))
+        self._keep = keep
+
+    def finalize(self, stream=None):
+        self._check(self._L.gndt_finalize_device(self._h, _stream_ptr(stream)))
+
+    def stats_export(self, stream=None):
+        """Device-resident sufficient statistics as torch tensors (views of libgndt memory)."""
+        import torch
+        st = Stats()
+        self._check(self._L.gndt_stats_export_device(self._h, C.byref(st), _stream_ptr(stream)))
+        n = int(st.num_nodes)
+        dev = f"cuda:{self.device}"
+        if n == 0:
+            return {"key": torch.zeros(0, dtype=torch.int64, device=dev), "sums": torch.zeros(0, 9, dtype=torch.float64, device=dev),
+                    "count": torch.zeros(0, dtype=torch.int32, device=dev), "first_idx": torch.zeros(0, dtype=torch.int32, device=dev)}
+        mk = lambda p, shape, ts: torch.as_tensor(_DevArray(p, shape, ts, self), device=dev)
+        return {"key": mk(st.key, (n,), "<i8"), "sums": mk(st.sums, (n, 9), "<f8"),
+                "count": mk(st.count, (n,), "<i4"), "first_idx": mk(st.first_idx, (n,), "<i4")}
+
+    def stats_merge(self, key, sums, count, first_idx, stream=None):
+        st = Stats(int(key.shape[0]), key.data_ptr(), sums.data_ptr(), count.data_ptr(), first_idx.data_ptr())
+        self._check(self._L.gndt_stats_merge_device(self._h, C.byref(st), _stream_ptr(stream)))
+        self._keep = (key, sums, count, first_idx)
+
+    # ---- phase timing ----
+    PHASES = ("clear", "accumulate", "scan", "label", "sort", "emit")
+
+    def set_profiling(self, on=True, demand="slope"):
+        self._ensure(demand)
+        self._check(self._L.gndt_set_profiling(self._h, 1 if on else 0))
+
+    def phase_times_ms(self):
+        arr = (C.c_double * len(self.PHASES))()
+        self._check(self._L.gndt_get_phase_times(self._h, arr))
+        return {k: arr[i] for i, k in enumerate(self.PHASES)}
+
+    # ---- results ----
+    def sync(self):
+        n, k, s = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        self._check(self._L.gndt_sync(self._h, C.byref(n), C.byref(k), C.byref(s)))
+        return n.value, k.value, s.value
+
+    def export(self):
+        """Host copy of the SoA result (numpy), nodes in the reference's order."""
+        n, k, s = self.sync()
+        arrs = {"sx": np.zeros(n, np.int32), "sy": np.zeros(n, np.int32), "sz": np.zeros(n, np.int32),
+                "count": np.zeros(n, np.uint32), "first_idx": np.zeros(n, np.uint32),
+                "mean": np.zeros((n, 3), np.float32), "cov": np.zeros((n, 6), np.float32),
+                "rough": np.zeros(n, np.float32), "normal": np.zeros((n, 3), np.float32), "flags": np.zeros(n, np.uint32)}
+        c = Cells()
+        for name, a in arrs.items():
+            setattr(c, name, a.ctypes.data)
+        self._check(self._L.gndt_export(self._h, C.byref(c)))
+        arrs.update(num_nodes=int(c.num_nodes), num_columns=int(c.num_columns), num_slopes=int(c.num_slopes))
+        return arrs
+
+    def export_device(self):
+        """Zero-copy torch views of the device-resident SoA (valid until the next build)."""
+        import torch
+        c = Cells()
+        self._check(self._L.gndt_export_device(self._h, C.byref(c)))
+        n = int(c.num_nodes)
+        dev = f"cuda:{self.device}"
+        out = {"num_nodes": n, "num_columns": int(c.num_columns), "num_slopes": int(c.num_slopes)}
+        if n == 0:
+            return out
+        mk = lambda p, shape, ts: torch.as_tensor(_DevArray(p, shape, ts, self), device=dev)
+        for name, shape, ts in (("sx", (n,), "<i4"), ("sy", (n,), "<i4"), ("sz", (n,), "<i4"), ("count", (n,), "<i4"),
+                                ("first_idx", (n,), "<i4"), ("mean", (n, 3), "<f4"), ("cov", (n, 6), "<f4"),
+                                ("rough", (n,), "<f4"), ("normal", (n, 3), "<f4"), ("flags", (n,), "<i4")):
+            out[name] = mk(getattr(c, name), shape, ts)
+        return out
+
+
+def count_morton(a, b):
+    """countMorton (Stopwatch.h:116-147)."""
+    buf = C.create_string_buffer(16)
+    rc = _lib.lib().gndt_count_morton(int(a), int(b), buf)
+    if rc:
+        raise GndtError(rc, "count_morton")
+    return buf.value.decode()
+
+
+def morton_to_xy(m):
+    """mortonToXY (Stopwatch.h:171-189)."""
+    a, b = C.c_int32(), C.c_int32()
+    rc = _lib.lib().gndt_morton_to_xy(int(m), C.byref(a), C.byref(b))
+    if rc:
+        raise GndtError(rc, "morton_to_xy")
+    return a.value, b.value
+
+
+def trans_morton_xyz(origin, grid_len, z_len, p):
+    o = (C.c_float * 3)(*[float(v) for v in origin])
+    q = (C.c_float * 3)(*[float(v) for v in p])
+    quad = C.create_string_buffer(2)
+    key = C.create_string_buffer(16)
+    nx, ny, sz = C.c_int32(), C.c_int32(), C.c_int32()
+    rc = _lib.lib().gndt_trans_morton_xyz(o, float(grid_len), float(z_len), q, quad, C.byref(nx), C.byref(ny), C.byref(sz), key)
+    return rc, key.value.decode(), nx.value, ny.value, sz.value
+
+
+def device_info(device=0):
+    name = C.create_string_buffer(128)
+    cu, mem = C.c_int32(), C.c_uint64()
+    rc = _lib.lib().gndt_device_info(int(device), name, C.byref(cu), C.byref(mem))
+    if rc:
+        raise GndtError(rc, "no device")
+    return {"name": name.value.decode(), "compute_units": cu.value, "hbm_bytes": mem.value}

@@ -1,0 +1,176 @@
+/* gndt.h — C ABI of the MI355X-native NDT grid builder (libgndt.so).
+ *
+ * This is the drop-in boundary for ONE path of daysun/grid_ndt: the two statements of
+ * chatterCallback that build the map,
+ *     for (i = 1 .. n-1) uniformDivision(points[i], false);     src/receiver.cpp:150-154
+ *     map2D.create2DMap(demand);                                 src/receiver.cpp:160
+ * i.e. point -> (xy Morton key, z level) binning (include/map2D.h:950-976, src/receiver.cpp:41-93),
+ * the per-node mean / un-normalised scatter (map2D.h:611-627), the min-eigenpair that gives roughness
+ * and normal (map2D.h:110-133) and the order-dependent slope label (map2D.h:66-108, 630-643).
+ *
+ * The reference has no FFI of its own (the path is a free function plus methods of a header-only
+ * class working on a global `daysun::TwoDmap map2D`, receiver.cpp:35), so the entry points below are
+ * what a binding for this path would need; each names the reference statement it replaces.
+ * Plain pointers and sizes only; no C++ or torch types cross this boundary; nothing throws.
+ *
+ * Conventions kept from the reference:
+ *   - point 0 of a cloud is the ORIGIN and is not binned (receiver.cpp:145, 150): call
+ *     gndt_set_origin(h, &cloud[0]) and pass cloud+1, n-1 to gndt_build*.
+ *   - inputs hold no NaN/Inf (the publisher strips them, src/publisher.cpp:24-26).
+ *   - errors are status codes (the reference returns bool + prints, map2D.h:602-604).
+ *   - one caller per handle at a time (ros::spin() is single-threaded, receiver.cpp:283).
+ */
+#ifndef GNDT_H
+#define GNDT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct gndt_handle gndt_handle;
+
+enum {
+    GNDT_OK = 0,
+    GNDT_ERR_INVALID = 1,      /* bad argument / call order */
+    GNDT_ERR_NO_DEVICE = 2,    /* no usable HIP device: the product path never falls back to the CPU */
+    GNDT_ERR_HIP = 3,          /* a HIP runtime call failed; see gndt_last_error */
+    GNDT_ERR_KEY_RANGE = 4,    /* |nx| or |ny| > 65535 (countMorton wraps, Stopwatch.h:102-110) or |nz| >= 2^21 */
+    GNDT_ERR_CAPACITY = 5,     /* node table full and growth disabled */
+    GNDT_ERR_NOMEM = 6
+};
+
+enum { GNDT_DEMAND_SLOPE = 0, GNDT_DEMAND_TRUE = 1 };   /* create2DMap(demand), map2D.h:630, 644 */
+
+/* gndt_cells.flags */
+enum {
+    GNDT_FLAG_HAS_STATS = 1u,  /* node reached min_points: mean/cov/N are set (map2D.h:611) */
+    GNDT_FLAG_SLOPE = 2u,      /* a Slope object exists for the node (map2D.h:632 / :648) */
+    GNDT_FLAG_DOWN = 4u        /* Slope::down (map2D.h:636) */
+};
+
+/* accumulate strategy (how points reach the per-node sufficient statistics) */
+enum {
+    GNDT_STRATEGY_AUTO = 0,
+    GNDT_STRATEGY_ATOMIC = 1,     /* one pass, wave-aggregated fp64 atomics into the HBM node table */
+    GNDT_STRATEGY_PARTITION = 2   /* counting partition by column tile, then LDS-resident accumulation */
+};
+
+typedef struct {
+    float grid_len;         /* TwoDmap::gridLen  (setLen, map2D.h:493)   */
+    float z_len;            /* TwoDmap::zLen     (setZLen, map2D.h:496)  */
+    float slope_interval;   /* setInterval, map2D.h:499 */
+    int32_t demand;         /* GNDT_DEMAND_* */
+    int32_t min_points;     /* MINPOINTSIZE = 3, map2D.h:28 */
+    int32_t device_id;      /* HIP device ordinal */
+    int32_t strategy;       /* GNDT_STRATEGY_* */
+    uint64_t max_points_hint;  /* largest batch expected (0 = grow on demand) */
+    uint64_t max_nodes_hint;   /* occupied (xy,z) nodes expected (0 = derive from the batch size) */
+} gndt_params;
+
+/* Structure-of-arrays view of the finished map: one entry per occupied (xy,z) node — every OcNode of
+ * map_xy, including those with fewer than min_points points (they keep zero mean/cov, map2D.h:54-56).
+ * Order: columns in first-seen order (= morton_list, receiver.cpp:70), nodes of a column in
+ * first-seen order (= insertion order among equal keys of the multimap, receiver.cpp:88).
+ * 76 bytes per node.  Pointers are device or host memory depending on the call that filled them. */
+typedef struct {
+    uint64_t num_nodes;
+    uint64_t num_columns;    /* = morton_list.size() */
+    uint64_t num_slopes;
+    int32_t* sx;             /* signed x index: +nx in quadrants A,B (px > ox), -nx in C,D */
+    int32_t* sy;             /* signed y index: +ny in quadrants A,C (py > oy), -ny in B,D */
+    int32_t* sz;             /* morton_z: signed z level, never 0 (map2D.h:963-973) */
+    uint32_t* count;         /* points binned into the node */
+    uint32_t* first_idx;     /* index (in the accumulated stream) of the node's first point */
+    float* mean;             /* [num_nodes][3] OcNode::xyz_centroid / Slope::mean */
+    float* cov;              /* [num_nodes][6] upper triangle xx,xy,xz,yy,yz,zz of covariance_matrix (un-normalised) */
+    float* rough;            /* Slope::rough: min eigenvalue (0 -> 0.01, map2D.h:131) */
+    float* normal;           /* [num_nodes][3] Slope::normal: its eigenvector, unit length, sign free */
+    uint32_t* flags;         /* GNDT_FLAG_* */
+} gndt_cells;
+
+/* Per-node sufficient statistics (cell-local coordinates), the additive state exchanged between GPUs.
+ * v = p - centre(node); centre is a pure function of (key, origin, grid_len, z_len). */
+typedef struct {
+    uint64_t num_nodes;
+    uint64_t* key;           /* packed (sx,sy,sz), see gndt_pack_key */
+    double* sums;            /* [num_nodes][9]: Sum v (3), Sum v v^T upper triangle (6) */
+    uint32_t* count;
+    uint32_t* first_idx;
+} gndt_stats;
+
+/* ---- lifetime ------------------------------------------------------------------------------- */
+/* `TwoDmap map2D(res, zres)` + setInterval (receiver.cpp:35, 267-269) */
+int gndt_create(const gndt_params* params, gndt_handle** out);
+void gndt_destroy(gndt_handle* h);
+const char* gndt_last_error(const gndt_handle* h);   /* h may be NULL: last error of a failed create */
+
+/* `map2D.setCloudFirst(points[0])` (receiver.cpp:145, map2D.h:490) */
+int gndt_set_origin(gndt_handle* h, const float origin_xyz[3]);
+
+/* ---- build: replaces receiver.cpp:150-154 + :160 --------------------------------------------- */
+/* Host memory in (e.g. pcl::PointCloud<PointXYZ>::points.data()+1, stride 16).  Synchronous. */
+int gndt_build(gndt_handle* h, const void* xyz_host, size_t n, size_t stride_bytes);
+/* Device memory in; enqueues on `hip_stream` (a hipStream_t, may be NULL) and returns without
+ * synchronising.  stride_bytes is 12 (packed) or 16 (PointXYZ). */
+int gndt_build_device(gndt_handle* h, const void* xyz_dev, size_t n, size_t stride_bytes, void* hip_stream);
+
+/* Incremental add (the intent of changeCallback/change2DMap, receiver.cpp:179-212, map2D.h:672-822;
+ * semantics defined in SURVEY.md Appendix A.7): after update(F1) .. update(Fk) the map equals
+ * build(F1 || .. || Fk).  first_idx continues counting across calls. */
+int gndt_update(gndt_handle* h, const void* xyz_host, size_t n, size_t stride_bytes);
+int gndt_update_device(gndt_handle* h, const void* xyz_dev, size_t n, size_t stride_bytes, void* hip_stream);
+
+/* Split form of build for a cloud sharded over several GPUs:
+ *   accumulate (binning + sufficient statistics only)  ->  [exchange stats]  ->  finalize.
+ * `first_idx_base` is the global index of xyz_dev[0] so that first-seen order is global. */
+int gndt_reset(gndt_handle* h, void* hip_stream);
+int gndt_accumulate_device(gndt_handle* h, const void* xyz_dev, size_t n, size_t stride_bytes,
+                           uint64_t first_idx_base, void* hip_stream);
+int gndt_finalize_device(gndt_handle* h, void* hip_stream);
+
+/* ---- results --------------------------------------------------------------------------------- */
+/* Waits for the handle's pending work, reports counts and any deferred device-side error. */
+int gndt_sync(gndt_handle* h, uint64_t* num_nodes, uint64_t* num_columns, uint64_t* num_slopes);
+/* Device-resident SoA of the last build/finalize; valid until the next build/update/destroy. */
+int gndt_export_device(gndt_handle* h, gndt_cells* out);
+/* Copies into caller-allocated host arrays sized from gndt_sync's num_nodes (NULL arrays skipped). */
+int gndt_export(gndt_handle* h, gndt_cells* out_host);
+
+/* ---- statistics exchange (multi-GPU; additive over any partition of the points) --------------- */
+/* Device-resident compact list of this handle's occupied nodes. */
+int gndt_stats_export_device(gndt_handle* h, gndt_stats* out, void* hip_stream);
+/* Adds `in` (device memory) into the handle's table: sums add, counts add, first_idx takes the min. */
+int gndt_stats_merge_device(gndt_handle* h, const gndt_stats* in, void* hip_stream);
+
+/* ---- host key codec (consumers call transMortonXYZ on pos/goal: map2D.h:1071,1293; GlobalPlan.h:56) */
+/* `transMortonXYZ` (map2D.h:950-976): quadrant letter, 1-based indices, signed z level and the
+ * map key string (letter + decimal Morton, <= 12 chars + NUL). */
+int gndt_trans_morton_xyz(const float origin[3], float grid_len, float z_len, const float p[3],
+                          char* quadrant, int32_t* nx, int32_t* ny, int32_t* sz, char key_out[16]);
+/* `countMorton` (Stopwatch.h:116-147), decimal string of the 32-bit interleave. */
+int gndt_count_morton(int32_t a, int32_t b, char out[16]);
+/* `mortonToXY` (Stopwatch.h:171-189). */
+int gndt_morton_to_xy(int32_t morton, int32_t* a, int32_t* b);
+/* Packed 64-bit node key used by gndt_stats: bits 63..43 sx+2^20, 42..22 sy+2^20, 21..0 sz+2^21. */
+uint64_t gndt_pack_key(int32_t sx, int32_t sy, int32_t sz);
+void gndt_unpack_key(uint64_t key, int32_t* sx, int32_t* sy, int32_t* sz);
+
+/* ---- phase timing (bench.py / profiling) ------------------------------------------------------ */
+/* With profiling on, build/accumulate/finalize record HIP events on the launch stream around each
+ * phase; gndt_get_phase_times waits for them and returns milliseconds (-1 = phase did not run):
+ *   [0] clear previous map  [1] accumulate (binning + statistics)  [2] node scan
+ *   [3] slope labels + sort keys  [4] ordering sort  [5] emit (mean, scatter, eigen) */
+#define GNDT_NUM_PHASES 6
+int gndt_set_profiling(gndt_handle* h, int enable);
+int gndt_get_phase_times(gndt_handle* h, double ms_out[GNDT_NUM_PHASES]);
+
+/* Library / device information for logs: returns 0 and fills what it can. */
+int gndt_device_info(int32_t device_id, char name_out[128], int32_t* compute_units, uint64_t* hbm_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GNDT_H */

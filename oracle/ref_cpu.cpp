@@ -1,0 +1,531 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY.  Nothing under grid_ndt_amd/ or include/ may include, link
+// or call this file.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg use it,
+// and only as the checker / reported CPU baseline.
+//
+// A CPU restatement of the reference's NDT grid-build path (daysun/grid_ndt):
+//   src/receiver.cpp:41-93   uniformDivision      (find-or-create node, append point)
+//   src/receiver.cpp:145-160 chatterCallback      (origin = point 0, bin 1..N-1, create2DMap)
+//   include/map2D.h:950-976  transMortonXYZ       (quadrant + ceil-index key)
+//   include/Stopwatch.h:39-47,59-64,102-110,116-147,171-189  Morton string helpers
+//   include/map2D.h:592-668  create2DMap          (per-node Gaussian, slope label, eigen)
+//   include/map2D.h:66-108   OcNode::isSlope      (order-dependent up/down test)
+//   include/map2D.h:110-133  OcNode::countRoughNormal (min-eigen selection)
+//
+// PARITY STATUS: "parity unpinned" for the arithmetic.  The reference delegates mean/scatter to PCL
+// `common` (compute3DCentroid / computeCovarianceMatrix, map2D.h:621-622) and the eigen-solve to
+// Eigen (EigenSolver<Matrix3f>, map2D.h:111-113).  Neither library is vendored, version-pinned or
+// installed here, and the reference has no tests.  Their published behaviour is restated:
+//   * centroid  = sequential fp32 sum / n                       (PCL dense path)
+//   * scatter   = sequential fp32 sum of (p-c)(p-c)^T, NOT divided by n
+//   * eigen     = eigen-decomposition of the symmetric fp32 scatter; this file uses cyclic Jacobi in
+//                 fp32 (Eigen's general real-Schur QR is not restated bit-for-bit), and picks the
+//                 minimum with the reference's own comparison chain.
+// The key codec IS pinned: tests/golden/morton_known_answers.csv holds the answers the compiled
+// reference helpers gave in the survey container plus the header's own worked
+// example (Stopwatch.h:112-115, 166-170).
+//
+// Three build modes share one export:
+//   mode 0  "as shipped": single thread, decimal Morton strings, std::multimap<string,Node*>,
+//           std::list<string> morton_list — the structure the reference actually executes.
+//   mode 1  integer keys, single thread (same arithmetic, same order).
+//   mode 2  integer keys, OpenMP over all host cores (the honest CPU baseline of BASELINE.md §3).
+// Every mode also carries an fp64 "truth" (two-pass mean/scatter in double, Jacobi in double).
+//
+// Build: see oracle/Makefile  (g++ -O2 -fopenmp -ffp-contract=off; contraction must stay off so the
+// fp32 sums round the way the reference's x86-64 build does).
+
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <list>
+#include <map>
+#include <string>
+#include <unordered_map>
+#include <vector>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// Key codec (Stopwatch.h).  Written through strings on purpose: the wrap-around and the behaviour
+// on negative values are properties of the string procedure.
+// ------------------------------------------------------------------------------------------------
+
+// Stopwatch.h:39-47 / 49-57: binary digits of n, most significant first; empty for 0.
+// For negative n, C++ '%' yields -1 (truthy) and '/' truncates toward zero.
+std::string binary_digits(int n) {
+    std::string s;
+    int a = n;
+    while (a != 0) {
+        s.push_back((a % 2) != 0 ? '1' : '0');
+        a /= 2;
+    }
+    std::reverse(s.begin(), s.end());
+    return s;
+}
+
+// Stopwatch.h:102-110: parse leading 0/1 characters into an UNSIGNED 32-bit accumulator (older bits
+// fall off the top), then reinterpret as int.
+int parse_binary_u32(const std::string& str) {
+    uint32_t acc = 0;
+    for (char c : str) {
+        if (c != '0' && c != '1') break;
+        acc = (acc << 1) | static_cast<uint32_t>(c - '0');
+    }
+    return static_cast<int>(acc);
+}
+
+// Stopwatch.h:116-147: pad the shorter digit string with leading zeros, interleave so that each
+// pair is (digit of a, digit of b) from the most significant end, parse, print in decimal.
+std::string count_morton(int a, int b) {
+    std::string da = binary_digits(a), db = binary_digits(b);
+    if (da.size() < db.size()) da.insert(0, db.size() - da.size(), '0');
+    if (db.size() < da.size()) db.insert(0, da.size() - db.size(), '0');
+    std::string inter;
+    inter.reserve(2 * da.size());
+    for (size_t i = 0; i < da.size(); ++i) {
+        inter.push_back(da[i]);
+        inter.push_back(db[i]);
+    }
+    return std::to_string(parse_binary_u32(inter));
+}
+
+// Stopwatch.h:171-189: inverse (valid for a <= 32767).
+void morton_to_xy(int morton, int* a, int* b) {
+    std::string m = binary_digits(morton);
+    if (m.size() % 2 != 0) m.insert(0, 1, '0');
+    std::string da, db;
+    for (size_t i = 0; i + 1 < m.size(); i += 2) {
+        da.push_back(m[i]);
+        db.push_back(m[i + 1]);
+    }
+    *a = parse_binary_u32(da);
+    *b = parse_binary_u32(db);
+}
+
+struct Key {
+    char quadrant;  // 'A'..'D'  map2D.h:952-962
+    int nx, ny;     // 1-based ceil indices  map2D.h:965-970
+    int sz;         // signed z level (no level 0)  map2D.h:963-964, 973
+};
+
+// map2D.h:950-976.  All arithmetic in fp32; abs/ceil are the float overloads (SURVEY §8c probe).
+inline Key trans_key(const float o[3], float gridLen, float zLen, float px, float py, float pz) {
+    Key k;
+    if (px > o[0]) k.quadrant = (py > o[1]) ? 'A' : 'B';
+    else           k.quadrant = (py > o[1]) ? 'C' : 'D';
+    int zsign = (pz > o[2]) ? 1 : -1;
+    const float qx = std::fabs(px - o[0]) / gridLen;  // x86-64 SSE: every step rounds to fp32
+    const float qy = std::fabs(py - o[1]) / gridLen;
+    const float qz = std::fabs(pz - o[2]) / zLen;
+    int nx = static_cast<int>(std::ceil(qx));
+    int ny = static_cast<int>(std::ceil(qy));
+    int nz = static_cast<int>(std::ceil(qz));
+    if (nx == 0) nx = 1;
+    if (ny == 0) ny = 1;
+    if (nz == 0) nz = 1;
+    k.nx = nx; k.ny = ny; k.sz = zsign * nz;
+    return k;
+}
+
+inline int signed_x(const Key& k) { return (k.quadrant == 'A' || k.quadrant == 'B') ? k.nx : -k.nx; }
+inline int signed_y(const Key& k) { return (k.quadrant == 'A' || k.quadrant == 'C') ? k.ny : -k.ny; }
+
+// ------------------------------------------------------------------------------------------------
+// Node state (map2D.h:38-57) and result fields (Slope, map2D.h:136-146)
+// ------------------------------------------------------------------------------------------------
+struct Node {
+    std::string morton;   // quadrant + decimal Morton (mode 0 only)
+    Key key{};
+    std::vector<uint32_t> idx;  // indices of this node's points in arrival order (stands for test_cloud)
+    uint64_t first_idx = 0;
+    float mean[3] = {0, 0, 0};          // xyz_centroid, zero-initialised  map2D.h:55
+    float cov[6] = {0, 0, 0, 0, 0, 0};  // upper triangle xx,xy,xz,yy,yz,zz of covariance_matrix  map2D.h:54
+    int N = 0;                          // map2D.h:56
+    bool slope = false, down = false;   // a Slope object exists / its 'down' flag
+    float rough = 0.f, normal[3] = {0, 0, 0};
+    float evals[3] = {0, 0, 0};
+    // fp64 truth
+    double mean64[3] = {0, 0, 0}, cov64[6] = {0, 0, 0, 0, 0, 0}, rough64 = 0, normal64[3] = {0, 0, 0};
+    double evals64[3] = {0, 0, 0};
+};
+
+struct Params {
+    float grid_len, z_len, slope_interval;
+    int demand;  // 0 = "slope", 1 = "true"
+    int min_points;
+};
+
+// ---- Jacobi eigen-decomposition of a symmetric 3x3 (upper triangle in, eigenpairs out) ----
+template <typename T>
+void jacobi3(const T c[6], T evals[3], T evecs[3][3]) {
+    T a[3][3] = {{c[0], c[1], c[2]}, {c[1], c[3], c[4]}, {c[2], c[4], c[5]}};
+    T v[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        T off = std::fabs(a[0][1]) + std::fabs(a[0][2]) + std::fabs(a[1][2]);
+        if (off == T(0)) break;
+        for (int p = 0; p < 2; ++p)
+            for (int q = p + 1; q < 3; ++q) {
+                if (a[p][q] == T(0)) continue;
+                T theta = (a[q][q] - a[p][p]) / (T(2) * a[p][q]);
+                T t = (theta >= T(0) ? T(1) : T(-1)) / (std::fabs(theta) + std::sqrt(theta * theta + T(1)));
+                T cs = T(1) / std::sqrt(t * t + T(1)), sn = t * cs;
+                for (int k = 0; k < 3; ++k) {  // A <- A J
+                    T akp = a[k][p], akq = a[k][q];
+                    a[k][p] = cs * akp - sn * akq;
+                    a[k][q] = sn * akp + cs * akq;
+                }
+                for (int k = 0; k < 3; ++k) {  // A <- J^T A
+                    T apk = a[p][k], aqk = a[q][k];
+                    a[p][k] = cs * apk - sn * aqk;
+                    a[q][k] = sn * apk + cs * aqk;
+                }
+                for (int k = 0; k < 3; ++k) {
+                    T vkp = v[k][p], vkq = v[k][q];
+                    v[k][p] = cs * vkp - sn * vkq;
+                    v[k][q] = sn * vkp + cs * vkq;
+                }
+            }
+    }
+    for (int i = 0; i < 3; ++i) {
+        evals[i] = a[i][i];
+        for (int k = 0; k < 3; ++k) evecs[k][i] = v[k][i];
+    }
+}
+
+// map2D.h:114-130: index of the chosen eigenvalue; ties go to the higher index.
+template <typename T>
+inline int pick_min(const T e[3]) {
+    if (e[0] < e[1]) return (e[0] < e[2]) ? 0 : 2;
+    return (e[1] < e[2]) ? 1 : 2;
+}
+
+// map2D.h:611-627 (+ PCL semantics) and :110-133 for one node.
+void fit_node(Node& nd, const float* xyz, size_t stride, const Params& P) {
+    const size_t n = nd.idx.size();
+    if (n < static_cast<size_t>(P.min_points)) return;  // map2D.h:611; mean/cov/N stay zero
+    // pcl::compute3DCentroid, dense path: sequential fp32 sums, then divide.
+    float sx = 0.f, sy = 0.f, sz = 0.f;
+    for (uint32_t i : nd.idx) {
+        const float* p = xyz + static_cast<size_t>(i) * stride;
+        sx += p[0]; sy += p[1]; sz += p[2];
+    }
+    const float fn = static_cast<float>(n);
+    nd.mean[0] = sx / fn; nd.mean[1] = sy / fn; nd.mean[2] = sz / fn;
+    // pcl::computeCovarianceMatrix(cloud, centroid, C): sequential fp32, un-normalised.
+    float c00 = 0, c01 = 0, c02 = 0, c11 = 0, c12 = 0, c22 = 0;
+    for (uint32_t i : nd.idx) {
+        const float* p = xyz + static_cast<size_t>(i) * stride;
+        float dx = p[0] - nd.mean[0], dy = p[1] - nd.mean[1], dz = p[2] - nd.mean[2];
+        c11 += dy * dy; c12 += dy * dz; c22 += dz * dz;
+        c00 += dx * dx; c01 += dx * dy; c02 += dx * dz;
+    }
+    nd.cov[0] = c00; nd.cov[1] = c01; nd.cov[2] = c02; nd.cov[3] = c11; nd.cov[4] = c12; nd.cov[5] = c22;
+    nd.N += static_cast<int>(n);  // map2D.h:625
+
+    // fp64 truth: two-pass in double
+    double m[3] = {0, 0, 0};
+    for (uint32_t i : nd.idx) {
+        const float* p = xyz + static_cast<size_t>(i) * stride;
+        m[0] += p[0]; m[1] += p[1]; m[2] += p[2];
+    }
+    for (int k = 0; k < 3; ++k) { m[k] /= static_cast<double>(n); nd.mean64[k] = m[k]; }
+    double d[6] = {0, 0, 0, 0, 0, 0};
+    for (uint32_t i : nd.idx) {
+        const float* p = xyz + static_cast<size_t>(i) * stride;
+        double dx = p[0] - m[0], dy = p[1] - m[1], dz = p[2] - m[2];
+        d[0] += dx * dx; d[1] += dx * dy; d[2] += dx * dz; d[3] += dy * dy; d[4] += dy * dz; d[5] += dz * dz;
+    }
+    for (int k = 0; k < 6; ++k) nd.cov64[k] = d[k];
+}
+
+void eigen_node(Node& nd) {  // OcNode::countRoughNormal, map2D.h:110-133
+    float ev[3], vec[3][3];
+    jacobi3<float>(nd.cov, ev, vec);
+    int j = pick_min(ev);
+    nd.rough = ev[j];
+    for (int k = 0; k < 3; ++k) { nd.normal[k] = vec[k][j]; nd.evals[k] = ev[k]; }
+    if (nd.rough == 0.f) nd.rough = 0.01f;  // map2D.h:131-132
+    double ev64[3], vec64[3][3];
+    jacobi3<double>(nd.cov64, ev64, vec64);
+    int j64 = pick_min(ev64);
+    nd.rough64 = ev64[j64];
+    for (int k = 0; k < 3; ++k) { nd.normal64[k] = vec64[k][j64]; nd.evals64[k] = ev64[k]; }
+}
+
+// OcNode::isSlope, map2D.h:66-108, evaluated against the column's nodes in insertion order, reading
+// the centroids as they are at call time.
+bool is_slope(const Node& me, const std::vector<Node*>& column, float interval, bool& up, bool& down, int min_points) {
+    if (me.N < min_points) return false;
+    int zadd = me.key.sz + 1, zminus = me.key.sz - 1;
+    if (me.key.sz == -1) zadd = 1;
+    else if (me.key.sz == 1) zminus = -1;
+    bool zup = false, zdown = false;
+    for (const Node* o : column) {
+        if (zup && zdown) break;
+        if (zminus == o->key.sz && std::fabs(o->mean[2] - me.mean[2]) > interval) { zdown = true; down = true; }
+        if (zadd == o->key.sz && std::fabs(o->mean[2] - me.mean[2]) > interval) { zup = true; up = true; }
+    }
+    return !up;
+}
+
+// create2DMap body for one column (map2D.h:606-662)
+void process_column(std::vector<Node*>& column, const float* xyz, size_t stride, const Params& P) {
+    for (Node* nd : column) {
+        if (nd->idx.size() < static_cast<size_t>(P.min_points)) continue;
+        fit_node(*nd, xyz, stride, P);
+        bool up = false, down = false;
+        if (P.demand == 0) {
+            if (is_slope(*nd, column, P.slope_interval, up, down, P.min_points)) {
+                nd->slope = true; nd->down = down;
+                eigen_node(*nd);
+            }
+        } else {
+            nd->slope = true; nd->down = false;
+            eigen_node(*nd);
+        }
+    }
+}
+
+struct Grid {
+    std::vector<Node*> nodes;        // export order: first-seen column, then first-seen node
+    std::vector<uint32_t> col_start; // index into nodes of each column's first node (+ sentinel)
+    double t_division = 0, t_calculate = 0;
+    ~Grid() { for (Node* n : nodes) delete n; }
+};
+
+double now_s() {
+    struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec + 1e-9 * ts.tv_nsec;
+}
+
+inline uint64_t pack_key(int sx, int sy, int sz) {
+    return (static_cast<uint64_t>(static_cast<uint32_t>(sx + (1 << 20)) & 0x1FFFFF) << 43) |
+           (static_cast<uint64_t>(static_cast<uint32_t>(sy + (1 << 20)) & 0x1FFFFF) << 22) |
+           (static_cast<uint64_t>(static_cast<uint32_t>(sz + (1 << 21)) & 0x3FFFFF));
+}
+
+// ---- mode 0: the structure the reference executes -----------------------------------------------
+Grid* build_as_shipped(const float* xyz, size_t n, size_t stride, const float o[3], const Params& P) {
+    Grid* g = new Grid;
+    std::multimap<std::string, Node*> map_xy;   // map2D.h:485
+    std::list<std::string> morton_list;         // map2D.h:504
+    double t0 = now_s();
+    for (size_t i = 0; i < n; ++i) {            // receiver.cpp:150-154
+        const float* p = xyz + i * stride;
+        Key k = trans_key(o, P.grid_len, P.z_len, p[0], p[1], p[2]);
+        std::string morton_xy(1, k.quadrant);
+        morton_xy += count_morton(k.nx, k.ny);  // map2D.h:971-972
+        if (map_xy.count(morton_xy) == 0) {     // receiver.cpp:60-70
+            Node* nd = new Node; nd->morton = morton_xy; nd->key = k; nd->first_idx = i;
+            nd->idx.push_back(static_cast<uint32_t>(i));
+            map_xy.insert({morton_xy, nd});
+            morton_list.push_back(morton_xy);
+        } else {                                // receiver.cpp:71-91
+            auto range = map_xy.equal_range(morton_xy);
+            bool found = false;
+            for (auto it = range.first; it != range.second; ++it)
+                if (it->second->key.sz == k.sz) { it->second->idx.push_back(static_cast<uint32_t>(i)); found = true; break; }
+            if (!found) {
+                Node* nd = new Node; nd->morton = morton_xy; nd->key = k; nd->first_idx = i;
+                nd->idx.push_back(static_cast<uint32_t>(i));
+                map_xy.insert({morton_xy, nd});  // equal keys keep insertion order (C++11)
+            }
+        }
+    }
+    double t1 = now_s();
+    for (const std::string& key : morton_list) {  // map2D.h:595-664
+        auto range = map_xy.equal_range(key);
+        std::vector<Node*> column;
+        for (auto it = range.first; it != range.second; ++it) column.push_back(it->second);
+        process_column(column, xyz, stride, P);
+        g->col_start.push_back(static_cast<uint32_t>(g->nodes.size()));
+        for (Node* nd : column) g->nodes.push_back(nd);
+    }
+    g->col_start.push_back(static_cast<uint32_t>(g->nodes.size()));
+    double t2 = now_s();
+    g->t_division = t1 - t0; g->t_calculate = t2 - t1;
+    return g;
+}
+
+// ---- modes 1/2: integer keys; mode 2 shards nodes over OpenMP threads by key hash -----------------
+inline uint64_t mix64(uint64_t x) {
+    x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33;
+    return x;
+}
+
+Grid* build_int_keys(const float* xyz, size_t n, size_t stride, const float o[3], const Params& P, int threads) {
+    Grid* g = new Grid;
+    double t0 = now_s();
+    std::vector<uint64_t> keys(n);
+    std::vector<Key> kk(n);
+#pragma omp parallel for num_threads(threads) schedule(static)
+    for (long long i = 0; i < static_cast<long long>(n); ++i) {
+        const float* p = xyz + static_cast<size_t>(i) * stride;
+        Key k = trans_key(o, P.grid_len, P.z_len, p[0], p[1], p[2]);
+        kk[i] = k;
+        keys[i] = pack_key(signed_x(k), signed_y(k), k.sz);
+    }
+    // each thread owns the nodes whose key hashes to it, scans all keys in order (arrival order kept)
+    std::vector<std::vector<Node*>> owned(threads);
+#pragma omp parallel num_threads(threads)
+    {
+#ifdef _OPENMP
+        int t = omp_get_thread_num();
+#else
+        int t = 0;
+#endif
+        std::unordered_map<uint64_t, Node*> local;
+        local.reserve(n / (threads * 4) + 16);
+        std::vector<Node*>& mine = owned[t];
+        for (size_t i = 0; i < n; ++i) {
+            uint64_t k = keys[i];
+            if (static_cast<int>(mix64(k) % static_cast<uint64_t>(threads)) != t) continue;
+            auto it = local.find(k);
+            Node* nd;
+            if (it == local.end()) {
+                nd = new Node; nd->key = kk[i]; nd->first_idx = i;
+                local.emplace(k, nd); mine.push_back(nd);
+            } else nd = it->second;
+            nd->idx.push_back(static_cast<uint32_t>(i));
+        }
+    }
+    double t1 = now_s();
+    // group nodes into columns: column order = first-seen (min first_idx), nodes by first_idx
+    std::vector<Node*> all;
+    for (auto& v : owned) all.insert(all.end(), v.begin(), v.end());
+    std::unordered_map<uint64_t, uint64_t> col_first;
+    col_first.reserve(all.size());
+    for (Node* nd : all) {
+        uint64_t ck = pack_key(signed_x(nd->key), signed_y(nd->key), 0);
+        auto it = col_first.find(ck);
+        if (it == col_first.end()) col_first.emplace(ck, nd->first_idx);
+        else if (nd->first_idx < it->second) it->second = nd->first_idx;
+    }
+    std::vector<std::pair<std::pair<uint64_t, uint64_t>, Node*>> order(all.size());
+    for (size_t i = 0; i < all.size(); ++i) {
+        Node* nd = all[i];
+        uint64_t ck = pack_key(signed_x(nd->key), signed_y(nd->key), 0);
+        order[i] = {{col_first[ck], nd->first_idx}, nd};
+    }
+    std::sort(order.begin(), order.end(),
+              [](const auto& a, const auto& b) { return a.first < b.first; });
+    g->nodes.resize(all.size());
+    for (size_t i = 0; i < order.size(); ++i) {
+        g->nodes[i] = order[i].second;
+        if (i == 0 || order[i].first.first != order[i - 1].first.first) g->col_start.push_back(static_cast<uint32_t>(i));
+    }
+    g->col_start.push_back(static_cast<uint32_t>(g->nodes.size()));
+    const long long ncol = static_cast<long long>(g->col_start.size()) - 1;
+#pragma omp parallel for num_threads(threads) schedule(dynamic, 256)
+    for (long long c = 0; c < ncol; ++c) {
+        std::vector<Node*> column(g->nodes.begin() + g->col_start[c], g->nodes.begin() + g->col_start[c + 1]);
+        process_column(column, xyz, stride, P);
+    }
+    for (Node* nd : g->nodes) {  // mode 0 keeps the string; fill it here too so exports agree
+        nd->morton = std::string(1, nd->key.quadrant) + count_morton(nd->key.nx, nd->key.ny);
+    }
+    double t2 = now_s();
+    g->t_division = t1 - t0; g->t_calculate = t2 - t1;
+    return g;
+}
+
+}  // namespace
+
+extern "C" {
+
+// ---- key codec entry points ---------------------------------------------------------------------
+int oracle_count_morton(int a, int b, char* out, int cap) {
+    std::string s = count_morton(a, b);
+    if (static_cast<int>(s.size()) + 1 > cap) return -1;
+    std::memcpy(out, s.c_str(), s.size() + 1);
+    return 0;
+}
+void oracle_morton_to_xy(int morton, int* a, int* b) { morton_to_xy(morton, a, b); }
+
+// transMortonXYZ: out_key receives quadrant letter + decimal Morton, NUL-terminated (cap >= 16)
+void oracle_trans_morton_xyz(const float origin[3], float grid_len, float z_len, const float p[3],
+                             char* out_key, int* nx, int* ny, int* sz) {
+    Key k = trans_key(origin, grid_len, z_len, p[0], p[1], p[2]);
+    std::string s(1, k.quadrant);
+    s += count_morton(k.nx, k.ny);
+    std::memcpy(out_key, s.c_str(), s.size() + 1);
+    *nx = k.nx; *ny = k.ny; *sz = k.sz;
+}
+
+// ---- grid build ---------------------------------------------------------------------------------
+// xyz: n points, stride_floats floats apart (3 = packed, 4 = pcl::PointXYZ).  The caller passes the
+// cloud WITHOUT point 0 and gives point 0 as origin (receiver.cpp:145, 150).
+void* oracle_build(const float* xyz, size_t n, size_t stride_floats, const float origin[3],
+                   float grid_len, float z_len, float slope_interval, int demand, int min_points,
+                   int mode, int threads) {
+    Params P{grid_len, z_len, slope_interval, demand, min_points};
+    if (threads <= 0) {
+#ifdef _OPENMP
+        threads = omp_get_max_threads();
+#else
+        threads = 1;
+#endif
+    }
+    if (mode == 0) return build_as_shipped(xyz, n, stride_floats, origin, P);
+    return build_int_keys(xyz, n, stride_floats, origin, P, mode == 1 ? 1 : threads);
+}
+
+size_t oracle_num_nodes(void* h) { return static_cast<Grid*>(h)->nodes.size(); }
+size_t oracle_num_columns(void* h) { return static_cast<Grid*>(h)->col_start.size() - 1; }
+void oracle_times(void* h, double* division_s, double* calculate_s) {
+    Grid* g = static_cast<Grid*>(h);
+    *division_s = g->t_division; *calculate_s = g->t_calculate;
+}
+int oracle_max_threads() {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+// SoA export, nodes in reference order.  Any pointer may be NULL.
+// flags: bit0 has_stats (N>=min_points), bit1 slope object exists, bit2 slope.down
+void oracle_export(void* h, int32_t* sx, int32_t* sy, int32_t* sz, uint32_t* count, uint64_t* first_idx,
+                   float* mean /*[n][3]*/, float* cov /*[n][6]*/, float* evals /*[n][3]*/, float* rough,
+                   float* normal /*[n][3]*/, uint32_t* flags, double* mean64, double* cov64,
+                   double* rough64, double* normal64, double* evals64, char* morton /*[n][16]*/) {
+    Grid* g = static_cast<Grid*>(h);
+    for (size_t i = 0; i < g->nodes.size(); ++i) {
+        const Node& nd = *g->nodes[i];
+        if (sx) sx[i] = signed_x(nd.key);
+        if (sy) sy[i] = signed_y(nd.key);
+        if (sz) sz[i] = nd.key.sz;
+        if (count) count[i] = static_cast<uint32_t>(nd.idx.size());
+        if (first_idx) first_idx[i] = nd.first_idx;
+        for (int k = 0; k < 3; ++k) {
+            if (mean) mean[3 * i + k] = nd.mean[k];
+            if (normal) normal[3 * i + k] = nd.normal[k];
+            if (evals) evals[3 * i + k] = nd.evals[k];
+            if (mean64) mean64[3 * i + k] = nd.mean64[k];
+            if (normal64) normal64[3 * i + k] = nd.normal64[k];
+            if (evals64) evals64[3 * i + k] = nd.evals64[k];
+        }
+        for (int k = 0; k < 6; ++k) {
+            if (cov) cov[6 * i + k] = nd.cov[k];
+            if (cov64) cov64[6 * i + k] = nd.cov64[k];
+        }
+        if (rough) rough[i] = nd.rough;
+        if (rough64) rough64[i] = nd.rough64;
+        if (flags) flags[i] = (nd.N > 0 ? 1u : 0u) | (nd.slope ? 2u : 0u) | (nd.down ? 4u : 0u);
+        if (morton) {
+            std::memset(morton + 16 * i, 0, 16);
+            std::memcpy(morton + 16 * i, nd.morton.c_str(), std::min<size_t>(15, nd.morton.size()));
+        }
+    }
+}
+
+void oracle_free(void* h) { delete static_cast<Grid*>(h); }
+
+}  // extern "C"

@@ -1,0 +1,129 @@
+"""CPU emulation of libgndt's pipeline built from the SAME arithmetic header the kernels use
+(grid_ndt_amd/csrc/gndt_math.hpp via tests/host_math_shim.cpp) plus numpy for the data movement.
+It lets the CPU test tier check the kernel maths, the order-free restatement of the slope label and
+the parity tolerances against the oracle.  Test infrastructure only."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(_HERE)
+_SO = os.path.join(_HERE, "_host_math_shim.so")
+_lib = None
+
+
+def shim():
+    global _lib
+    if _lib is None:
+        src = os.path.join(_HERE, "host_math_shim.cpp")
+        hdr = os.path.join(_ROOT, "grid_ndt_amd", "csrc", "gndt_math.hpp")
+        if not os.path.exists(_SO) or os.path.getmtime(_SO) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+            subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-I",
+                                   os.path.join(_ROOT, "grid_ndt_amd", "csrc"), "-o", _SO, src])
+        _lib = C.CDLL(_SO)
+        _lib.shim_mean_z.restype = C.c_float
+        _lib.shim_mean_z.argtypes = [C.c_uint32, C.c_double, C.c_double]
+    return _lib
+
+
+def unpack(keys):
+    k = keys.astype(np.uint64)
+    sx = ((k >> np.uint64(43)) & np.uint64(0x1FFFFF)).astype(np.int64) - (1 << 20)
+    sy = ((k >> np.uint64(22)) & np.uint64(0x1FFFFF)).astype(np.int64) - (1 << 20)
+    sz = (k & np.uint64(0x3FFFFF)).astype(np.int64) - (1 << 21)
+    return sx.astype(np.int32), sy.astype(np.int32), sz.astype(np.int32)
+
+
+def accumulate(body, origin, grid_len, z_len, first_base=0):
+    """points -> (unique keys, count, first_idx, sums[.,9]) — what k_accumulate leaves in the table."""
+    L = shim()
+    body = np.ascontiguousarray(body, np.float32)
+    n, stride = body.shape
+    o = (C.c_float * 3)(*[float(v) for v in origin])
+    keys = np.zeros(n, np.uint64)
+    ok = np.zeros(n, np.uint8)
+    L.shim_point_keys(C.c_void_p(body.ctypes.data), C.c_uint64(n), C.c_int(stride), o, C.c_float(grid_len),
+                      C.c_float(z_len), C.c_void_p(keys.ctypes.data), C.c_void_p(ok.ctypes.data))
+    assert ok.all()
+    uk, inv = np.unique(keys, return_inverse=True)
+    cen = np.zeros((uk.size, 3), np.float64)
+    L.shim_centres(C.c_void_p(uk.ctypes.data), C.c_uint64(uk.size), o, C.c_float(grid_len), C.c_float(z_len),
+                   C.c_void_p(cen.ctypes.data))
+    v = body[:, :3].astype(np.float64) - cen[inv]
+    q = np.stack([v[:, 0], v[:, 1], v[:, 2], v[:, 0] * v[:, 0], v[:, 0] * v[:, 1], v[:, 0] * v[:, 2],
+                  v[:, 1] * v[:, 1], v[:, 1] * v[:, 2], v[:, 2] * v[:, 2]], 1)
+    sums = np.zeros((uk.size, 9), np.float64)
+    np.add.at(sums, inv, q)
+    count = np.bincount(inv, minlength=uk.size).astype(np.uint32)
+    first = np.full(uk.size, np.iinfo(np.int64).max, np.int64)
+    np.minimum.at(first, inv, np.arange(n, dtype=np.int64) + first_base)
+    return uk, count, first.astype(np.uint32), sums, cen
+
+
+def finalize(uk, count, first, sums, cen, slope_interval, demand="slope", min_points=3):
+    """table contents -> export dict in the reference's order (k_scan/k_label/sort/k_emit)."""
+    L = shim()
+    n = uk.size
+    sx, sy, sz = unpack(uk)
+    mean = np.zeros((n, 3), np.float32)
+    cov = np.zeros((n, 6), np.float32)
+    rough = np.zeros(n, np.float32)
+    normal = np.zeros((n, 3), np.float32)
+    count = np.ascontiguousarray(count, np.uint32)
+    sums = np.ascontiguousarray(sums)
+    cen = np.ascontiguousarray(cen)
+    L.shim_finalize(C.c_void_p(count.ctypes.data), C.c_void_p(sums.ctypes.data), C.c_void_p(cen.ctypes.data),
+                    C.c_uint64(n), C.c_int(min_points), C.c_void_p(mean.ctypes.data), C.c_void_p(cov.ctypes.data),
+                    C.c_void_p(rough.ctypes.data), C.c_void_p(normal.ctypes.data))
+    has = count >= min_points
+    mean_z = np.where(has, mean[:, 2], np.float32(0)).astype(np.float32)
+    lookup = {int(k): i for i, k in enumerate(uk)}
+    colkey = uk & ~np.uint64(0x3FFFFF)
+    col_first = {}
+    for i in range(n):
+        ck = int(colkey[i])
+        f = int(first[i])
+        if ck not in col_first or f < col_first[ck]:
+            col_first[ck] = f
+    flags = has.astype(np.uint32)
+    iv = np.float32(slope_interval)
+
+    def pack(x, y, z):
+        return ((x + (1 << 20)) << 43) | ((y + (1 << 20)) << 22) | (z + (1 << 21))
+
+    for i in range(n):
+        if not has[i]:
+            continue
+        slope, down = True, False
+        if demand == "slope":
+            up = False
+            z = int(sz[i])
+            for target, is_up in ((L.shim_level_above(z), True), (L.shim_level_below(z), False)):
+                j = lookup.get(pack(int(sx[i]), int(sy[i]), target))
+                if j is None:
+                    continue
+                visited = first[j] < first[i] and has[j]
+                oz = mean_z[j] if visited else np.float32(0)
+                if np.abs(np.float32(oz - mean_z[i])) > iv:
+                    if is_up:
+                        up = True
+                    else:
+                        down = True
+            slope = not up
+        if slope:
+            flags[i] |= 2
+            if down:
+                flags[i] |= 4
+    cf = np.array([col_first[int(c)] for c in colkey], np.int64)
+    order = np.lexsort((first.astype(np.int64), cf))
+    out = {"sx": sx[order], "sy": sy[order], "sz": sz[order], "count": count[order], "first_idx": first[order],
+           "mean": mean[order], "cov": cov[order], "rough": rough[order], "normal": normal[order], "flags": flags[order],
+           "num_nodes": n, "num_columns": len(col_first), "num_slopes": int(np.count_nonzero(flags & 2))}
+    return out
+
+
+def build(cloud, grid_len, z_len, slope_interval, demand="slope"):
+    t = accumulate(cloud[1:], cloud[0, :3], grid_len, z_len)
+    return finalize(*t, slope_interval, demand)

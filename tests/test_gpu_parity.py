@@ -1,0 +1,220 @@
+"""GPU tier (-m gpu): libgndt through its C ABI versus the CPU oracle on the same seeded inputs.
+Gates: keys / counts / order / labels bit-exact; covariance within 1e-5 relative (tests/parity.py)."""
+import numpy as np
+import pytest
+
+from tests import parity, scenes
+
+pytestmark = pytest.mark.gpu
+
+UNIFORM_CUBIC = dict(grid_len=0.5, z_len=0.5, slope_interval=0.08, demand="slope")
+UNIFORM_ZLAUNCH = dict(grid_len=0.5, z_len=0.1, slope_interval=0.08, demand="slope")   # receiver.cpp:35 default z
+TERRAIN = dict(grid_len=0.2, z_len=0.2, slope_interval=0.08, demand="slope")
+TERRAIN_TRUE = dict(grid_len=0.2, z_len=0.1, slope_interval=0.08, demand="true")
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _require_gpu():
+    import torch
+    assert torch.cuda.is_available(), "the gpu tier needs a GPU; libgndt has no CPU path"
+    import grid_ndt_amd as g
+    g.build_native()
+    from grid_ndt_amd import _lib
+    _lib.lib()
+
+
+CASES = {
+    "bridge_ground": (lambda: scenes.bridge_ground(), scenes.BRIDGE_PARAMS),            # reference's own scene
+    "campus_200k": (lambda: scenes.campus_frame(200000), scenes.CAMPUS_PARAMS),          # BASELINE configs[0] stand-in
+    "uniform_300k_cubic": (lambda: scenes.uniform_box(300000), UNIFORM_CUBIC),
+    "uniform_300k_z01": (lambda: scenes.uniform_box(300000), UNIFORM_ZLAUNCH),
+    "terrain_400k": (lambda: scenes.terrain_cloud(400000), TERRAIN),
+    "terrain_true": (lambda: scenes.terrain_cloud(200000), TERRAIN_TRUE),
+    "site_zero_padded": (lambda: scenes.site_two_storey(300000), dict(grid_len=0.1, z_len=0.1, slope_interval=0.08, demand="slope")),
+}
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_parity_device_input(name):
+    make, P = CASES[name]
+    cloud = make()
+    ref = parity.ref_from_cloud(cloud, P)
+    m, out = parity.gpu_from_cloud(cloud, P, on_device=True)
+    rep = parity.assert_parity(out, ref)
+    print(name, {k: v for k, v in rep.items() if k not in ("fail",)})
+
+
+def test_parity_host_input_and_pointxyz_stride():
+    cloud = scenes.campus_frame(50000)
+    P = scenes.CAMPUS_PARAMS
+    ref = parity.ref_from_cloud(cloud, P)
+    _, out12 = parity.gpu_from_cloud(cloud, P, on_device=False)
+    parity.assert_parity(out12, ref)
+    c4 = scenes.with_stride4(cloud)                      # pcl::PointXYZ: 16-byte points
+    _, out16h = parity.gpu_from_cloud(c4, P, on_device=False)
+    _, out16d = parity.gpu_from_cloud(c4, P, on_device=True)
+    for o in (out16h, out16d):
+        parity.assert_parity(o, ref)
+        for k in ("sx", "count", "first_idx", "flags"):
+            assert np.array_equal(o[k], out12[k])
+
+
+def test_rebuild_is_idempotent_and_clears_previous_map():
+    import torch
+    import grid_ndt_amd as g
+    a, b = scenes.campus_frame(60000), scenes.uniform_box(50000, seed=7)
+    P = scenes.CAMPUS_PARAMS
+    m = g.TwoDmap(P["grid_len"], P["z_len"])
+    m.setInterval(P["slope_interval"])
+    m.setCloudFirst(a[0])
+    ta, tb = torch.from_numpy(a[1:]).cuda(), torch.from_numpy(b[1:]).cuda()
+    m.create2DMap("slope", ta)
+    first = m.export()
+    m.create2DMap("slope", tb)          # a different cloud in between: its nodes must be gone afterwards
+    m.create2DMap("slope", ta)
+    again = m.export()
+    for k in ("sx", "sy", "sz", "count", "first_idx", "flags"):
+        assert np.array_equal(first[k], again[k]), k
+    assert np.allclose(first["cov"], again["cov"], rtol=1e-6, atol=0) and np.allclose(first["mean"], again["mean"], rtol=1e-7)
+
+
+def test_incremental_update_equals_batch_build():
+    """update(F1)..update(Fk) == build(F1||..||Fk), first_idx over the concatenation."""
+    import torch
+    import grid_ndt_amd as g
+    frames = scenes.terrain_frames(3, first_pose=5, points_per_frame=40000)
+    cloud = np.concatenate([frames[:1], frames], 0)       # point 0 (origin) = first point, then all frames
+    ref = parity.ref_from_cloud(cloud, TERRAIN)
+    m = g.TwoDmap(TERRAIN["grid_len"], TERRAIN["z_len"])
+    m.setInterval(TERRAIN["slope_interval"])
+    m.setCloudFirst(cloud[0])
+    for f in range(3):
+        t = torch.from_numpy(frames[f * 40000:(f + 1) * 40000]).cuda()
+        m.change2DMap("slope", t)
+    parity.assert_parity(m.export(), ref)
+
+
+def test_split_accumulate_finalize_and_stats_roundtrip():
+    """accumulate(shard A) + accumulate(shard B) == build(A||B); stats export -> merge into a second
+    handle reproduces the same map (the multi-GPU exchange primitive)."""
+    import torch
+    import grid_ndt_amd as g
+    cloud = scenes.campus_frame(80000)
+    P = scenes.CAMPUS_PARAMS
+    ref = parity.ref_from_cloud(cloud, P)
+    body = torch.from_numpy(cloud[1:]).cuda()
+    cut = 33333
+    m = g.TwoDmap(P["grid_len"], P["z_len"])
+    m.setInterval(P["slope_interval"])
+    m.setCloudFirst(cloud[0])
+    m.reset("slope")
+    m.accumulate("slope", body[cut:], first_idx_base=cut)   # out of order on purpose: first_idx is a min
+    m.accumulate("slope", body[:cut], first_idx_base=0)
+    st = m.stats_export()
+    torch.cuda.synchronize()
+    st = {k: v.clone() for k, v in st.items()}
+    m.finalize()
+    parity.assert_parity(m.export(), ref)
+    m2 = g.TwoDmap(P["grid_len"], P["z_len"])
+    m2.setInterval(P["slope_interval"])
+    m2.setCloudFirst(cloud[0])
+    m2.reset("slope")
+    half = st["key"].shape[0] // 2
+    for sl in (slice(0, half), slice(half, None)):
+        m2.stats_merge(st["key"][sl].contiguous(), st["sums"][sl].contiguous(), st["count"][sl].contiguous(),
+                       st["first_idx"][sl].contiguous())
+    m2.finalize()
+    parity.assert_parity(m2.export(), ref)
+
+
+def test_edge_inputs():
+    import torch
+    import grid_ndt_amd as g
+    m = g.TwoDmap(0.5, 0.1)
+    m.setInterval(0.08)
+    m.setCloudFirst((0, 0, 0))
+    # empty cloud
+    m.create2DMap("slope", torch.zeros((0, 3), dtype=torch.float32, device="cuda"))
+    assert m.sync() == (0, 0, 0)
+    # one and two points: nodes exist but carry no statistics (MINPOINTSIZE, map2D.h:28, 611)
+    pts = np.float32([[0.1, 0.1, 0.05], [0.2, 0.2, 0.05]])
+    m.create2DMap("slope", pts)
+    out = m.export()
+    assert out["num_nodes"] == 1 and out["count"][0] == 2 and out["flags"][0] == 0
+    assert not out["mean"].any() and not out["cov"].any()
+    # ragged sizes around the wave width, all in one cell (the wave-uniform path) and spread out
+    for n in (1, 63, 64, 65, 127, 129, 1000):
+        same = np.tile(np.float32([[3.3, -2.2, 0.77]]), (n, 1))
+        cloud = np.concatenate([np.float32([[0, 0, 0]]), same], 0)
+        ref = parity.ref_from_cloud(cloud, scenes.CAMPUS_PARAMS)
+        _, o = parity.gpu_from_cloud(cloud, scenes.CAMPUS_PARAMS)
+        parity.assert_parity(o, ref)
+    # key range: |nx| > 65535 must be an error, not a silent wrap (Stopwatch.h:102-110)
+    far = np.float32([[0.5 * 70000, 0, 0]] * 4)
+    with pytest.raises(g.GndtError) as e:
+        m.create2DMap("slope", far)
+    assert e.value.code == 4
+
+
+def test_table_growth_without_hint():
+    """No max_nodes_hint and every point in its own node: the build must grow its table and still agree."""
+    cloud = scenes.uniform_box(120000, half_xy=3000.0)
+    P = dict(grid_len=0.5, z_len=0.5, slope_interval=0.08, demand="slope")
+    ref = parity.ref_from_cloud(cloud, P)
+    _, out = parity.gpu_from_cloud(cloud, P)
+    parity.assert_parity(out, ref)
+    assert out["num_nodes"] > 100000
+
+
+def test_full_size_properties_10M():
+    """BASELINE configs[1] at full size: size-independent properties instead of the oracle."""
+    import torch
+    import grid_ndt_amd as g
+    cloud = scenes.uniform_box(10_000_000)
+    m = g.TwoDmap(0.5, 0.5, max_nodes_hint=1 << 20)
+    m.setInterval(0.08)
+    m.setCloudFirst(cloud[0])
+    t = torch.from_numpy(cloud[1:]).cuda()
+    m.create2DMap("slope", t)
+    out = m.export()
+    n = cloud.shape[0] - 1
+    assert int(out["count"].astype(np.int64).sum()) == n                       # every point binned once
+    keys = (out["sx"].astype(np.int64) << 42) ^ (out["sy"].astype(np.int64) << 21) ^ out["sz"].astype(np.int64)
+    assert np.unique(keys).size == out["num_nodes"]                            # one row per node
+    f = out["first_idx"].astype(np.int64)
+    assert np.unique(f).size == f.size and f.min() == 0 and f.max() < n
+    # order: columns by first-seen, nodes inside a column by first-seen
+    col = (out["sx"].astype(np.int64) << 32) ^ (out["sy"].astype(np.int64) & 0xFFFFFFFF)
+    new_col = np.concatenate([[True], col[1:] != col[:-1]])
+    assert int(new_col.sum()) == out["num_columns"] == np.unique(col).size       # columns are contiguous
+    col_first = f[new_col]
+    assert np.all(np.diff(col_first) > 0)
+    same = ~new_col[1:]
+    assert np.all(np.diff(f)[same] > 0)
+    has = (out["flags"] & 1) != 0
+    assert np.array_equal(has, out["count"] >= 3)
+    body = cloud[1:].astype(np.float64)
+    # trace(scatter) is additive: sum over nodes <= total scatter about the global mean
+    tr = (out["cov"][:, 0] + out["cov"][:, 3] + out["cov"][:, 5]).astype(np.float64).sum()
+    total_tr = ((body - body.mean(0)) ** 2).sum()
+    assert 0 < tr < total_tr
+    # a random sample of nodes against an independent numpy fp64 recomputation
+    rng = np.random.default_rng(0)
+    o = cloud[0]
+    pick = rng.choice(np.flatnonzero(has), 200, replace=False)
+    d = (cloud[1:] - o)
+    gl = np.float32(0.5)
+    nx = np.maximum(1, np.ceil(np.abs(d[:, 0]) / gl)).astype(np.int32) * np.where(cloud[1:, 0] > o[0], 1, -1)
+    ny = np.maximum(1, np.ceil(np.abs(d[:, 1]) / gl)).astype(np.int32) * np.where(cloud[1:, 1] > o[1], 1, -1)
+    nz = np.maximum(1, np.ceil(np.abs(d[:, 2]) / gl)).astype(np.int32) * np.where(cloud[1:, 2] > o[2], 1, -1)
+    for i in pick:
+        sel = (nx == out["sx"][i]) & (ny == out["sy"][i]) & (nz == out["sz"][i])
+        p = body[sel]
+        assert p.shape[0] == out["count"][i]
+        mu = p.mean(0)
+        S = (p - mu).T @ (p - mu)
+        ref_ut = np.array([S[0, 0], S[0, 1], S[0, 2], S[1, 1], S[1, 2], S[2, 2]])
+        assert np.abs(out["cov"][i] - ref_ut).max() <= 1e-5 * np.abs(ref_ut).max()
+        assert np.abs(out["mean"][i] - mu).max() <= 1e-5 * max(1.0, np.abs(mu).max())
+        ev = np.linalg.eigvalsh(S)
+        assert abs(out["rough"][i] - ev[0]) <= 1e-5 * np.trace(S)

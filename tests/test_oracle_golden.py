@@ -1,0 +1,117 @@
+"""CPU tier: pin the oracle and libgndt's host codec to the reference's known answers."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle
+from tests import scenes
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "morton_known_answers.csv")
+
+
+def golden_rows():
+    rows = []
+    for line in open(GOLD):
+        if line.startswith("#") or not line.strip():
+            continue
+        rows.append(tuple(int(x) for x in line.split(",")))
+    return rows
+
+
+def test_golden_file_has_header_example():
+    assert (5, 7, 55, 5, 7) in golden_rows()   # Stopwatch.h:112-115, 166-170
+
+
+@pytest.mark.parametrize("a,b,m,da,db", golden_rows())
+def test_oracle_count_morton_golden(a, b, m, da, db):
+    assert oracle.count_morton(a, b) == str(m)
+    assert oracle.morton_to_xy(m) == (da, db)
+
+
+@pytest.mark.parametrize("a,b,m,da,db", golden_rows())
+def test_gndt_codec_golden(native_lib, a, b, m, da, db):
+    import grid_ndt_amd as g
+    assert g.count_morton(a, b) == str(m)
+    assert g.morton_to_xy(m) == (da, db)
+
+
+def test_codec_matches_oracle_exhaustive_small(native_lib):
+    import grid_ndt_amd as g
+    rng = np.random.default_rng(1)
+    pairs = [(a, b) for a in range(0, 40) for b in range(0, 40)]
+    pairs += [tuple(int(v) for v in rng.integers(0, 70000, 2)) for _ in range(3000)]
+    pairs += [(32767, 32768), (65535, 1), (65536, 65536), (70000, 70000), (40000, 40000)]
+    for a, b in pairs:
+        s = oracle.count_morton(a, b)
+        assert g.count_morton(a, b) == s
+        assert g.morton_to_xy(int(s)) == oracle.morton_to_xy(int(s))
+    # SURVEY §8a row a4 probe values
+    assert oracle.count_morton(40000, 40000) == "-1007669248"
+    assert oracle.count_morton(70000, 70000) == "50544384"
+
+
+def test_trans_morton_xyz_matches_oracle(native_lib):
+    import grid_ndt_amd as g
+    rng = np.random.default_rng(2)
+    origin = (1.0, 1.0, 1.0)
+    for gl, zl in ((0.1, 0.05), (0.5, 0.1), (0.2, 0.2)):
+        pts = rng.uniform(-30, 30, (2000, 3)).astype(np.float32)
+        # points exactly on cell faces and on the origin planes (ceil boundaries, strict '>')
+        k = rng.integers(-50, 50, (500, 3)).astype(np.float32)
+        lattice = (np.float32(origin) + k * np.float32([gl, gl, zl])).astype(np.float32)
+        for p in np.concatenate([pts, lattice, np.float32([origin])], 0):
+            rc, key, nx, ny, sz = g.trans_morton_xyz(origin, gl, zl, p)
+            okey, onx, ony, osz = oracle.trans_morton_xyz(origin, gl, zl, p)
+            assert rc == 0 and (key, nx, ny, sz) == (okey, onx, ony, osz), (p, gl, zl)
+
+
+def test_trans_morton_edge_rules():
+    # d == 0 -> cell 1, '>' strict: equality goes to the D / down side (map2D.h:952-970)
+    key, nx, ny, sz = oracle.trans_morton_xyz((0, 0, 0), 0.5, 0.1, (0, 0, 0))
+    assert (key, nx, ny, sz) == ("D3", 1, 1, -1)
+    key, nx, ny, sz = oracle.trans_morton_xyz((0, 0, 0), 0.5, 0.1, (0.5, 0.5, 0.1))
+    assert (key[0], nx, ny, sz) == ("A", 1, 1, 1)
+    key, nx, ny, sz = oracle.trans_morton_xyz((0, 0, 0), 0.5, 0.1, (np.nextafter(np.float32(0.5), np.float32(1)), -0.5, -0.1))
+    assert (key[0], nx, ny, sz) == ("B", 2, 1, -1)
+
+
+def test_key_range_error(native_lib):
+    import grid_ndt_amd as g
+    rc, *_ = g.trans_morton_xyz((0, 0, 0), 0.1, 0.1, (6553.6 + 1.0, 0, 0))
+    assert rc == 4   # GNDT_ERR_KEY_RANGE: countMorton would wrap (Stopwatch.h:102-110)
+    rc, *_ = g.trans_morton_xyz((0, 0, 0), 0.1, 0.1, (6000.0, 0, 0))
+    assert rc == 0
+
+
+def test_bridge_ground_scene_matches_reference_generator():
+    # genePcd.cpp fills 295 841 of its 360 000 pre-allocated points (SURVEY §4 probe)
+    assert scenes.bridge_ground(pad_to=0).shape[0] == 295841
+    b = scenes.bridge_ground()
+    assert b.shape == (360000, 3) and tuple(b[0]) == (1.0, 1.0, 1.0)
+    assert int((np.abs(b).sum(1) == 0).sum()) == 64159
+
+
+def test_oracle_modes_agree_bitwise():
+    for cloud, P in ((scenes.bridge_ground(), scenes.BRIDGE_PARAMS), (scenes.campus_frame(60000), scenes.CAMPUS_PARAMS)):
+        r0 = oracle.build_grid(cloud, P["grid_len"], P["z_len"], P["slope_interval"], P["demand"], mode=0)
+        for mode in (1, 2):
+            r = oracle.build_grid(cloud, P["grid_len"], P["z_len"], P["slope_interval"], P["demand"], mode=mode, threads=4)
+            for k in ("sx", "sy", "sz", "count", "first_idx", "mean", "cov", "rough", "normal", "flags", "cov64"):
+                assert np.array_equal(r0[k], r[k]), (mode, k)
+            assert list(r0["morton"]) == list(r["morton"])
+
+
+def test_oracle_bridge_ground_regression():
+    r = oracle.build_grid(scenes.bridge_ground(), 0.1, 0.05, 0.08, "slope")
+    assert (r["num_nodes"], r["num_columns"]) == (22521, 9600)
+    assert int(np.count_nonzero(r["flags"] & 2)) == 14717
+    assert int(r["count"].max()) == 64159          # the (0,0,0) padding lands in ONE node
+    # numpy cross-check of the fp64 truth's eigenvalues on a few nodes
+    idx = np.flatnonzero(r["flags"] & 2)[:50]
+    c = r["cov64"][idx]
+    mats = np.stack([np.stack([c[:, 0], c[:, 1], c[:, 2]], 1), np.stack([c[:, 1], c[:, 3], c[:, 4]], 1),
+                     np.stack([c[:, 2], c[:, 4], c[:, 5]], 1)], 1)
+    ev = np.linalg.eigvalsh(mats)
+    mine = np.sort(r["evals64"][idx], axis=1)
+    assert np.allclose(ev, mine, rtol=0, atol=1e-9 * max(1.0, np.abs(ev).max()))
