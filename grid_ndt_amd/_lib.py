@@ -41,18 +41,48 @@ class Stats(C.Structure):
                 ("first_idx", C.c_void_p)]
 
 
+def _hip_runtime_dir():
+    """Directory of the HIP runtime libgndt must share with its host process.  PyTorch wheels bundle
+    their own libamdhip64.so / libhsa-runtime64.so; linking libgndt against /opt/rocm's copy would put
+    a second HIP runtime in the process (foreign streams, events and allocations).  GNDT_HIP_LIBDIR
+    overrides (e.g. /opt/rocm/lib for a C++/ROS host without torch)."""
+    env = os.environ.get("GNDT_HIP_LIBDIR")
+    if env:
+        return env
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec and spec.origin:
+            d = os.path.join(os.path.dirname(spec.origin), "lib")
+            if os.path.exists(os.path.join(d, "libamdhip64.so")):
+                return d
+    except Exception:
+        pass
+    return "/opt/rocm/lib"
+
+
 def build_native(force=False, verbose=False):
     """Compile the HIP sources into grid_ndt_amd/csrc/libgndt.so for gfx950 (cross-compiles without a GPU)."""
     srcs = [os.path.join(_CSRC, s) for s in SOURCES]
-    deps = srcs + [h if os.path.isabs(h) else os.path.join(_CSRC, h) for h in HEADERS]
+    deps = srcs + [h if os.path.isabs(h) else os.path.join(_CSRC, h) for h in HEADERS] + [os.path.abspath(__file__)]
     if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
         return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
-           "-Wno-unused-command-line-argument", "-I", os.path.join(_ROOT, "include"), "-I", _CSRC, "-o", LIB_PATH] + srcs
+    objs = []
+    for src in srcs:
+        obj = os.path.splitext(src)[0] + ".o"
+        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-c",
+               "-Wno-unused-command-line-argument", "-I", os.path.join(_ROOT, "include"), "-I", _CSRC, "-o", obj, src]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+        objs.append(obj)
+    libdir = _hip_runtime_dir()
+    link = ["g++", "-shared", "-o", LIB_PATH] + objs + ["-L", libdir, "-l:libamdhip64.so", "-Wl,-rpath," + libdir,
+                                                         "-Wl,--no-undefined", "-lpthread", "-ldl"]
     if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
+        print(" ".join(link))
+    subprocess.check_call(link)
     return LIB_PATH
 
 
@@ -66,6 +96,11 @@ def lib():
     if not os.path.exists(LIB_PATH):
         raise ImportError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                           "(hipcc --offload-arch=gfx950).  grid_ndt_amd has no fallback implementation.")
+    # One HIP runtime per process: load the copy the host process uses (torch's bundled one when torch
+    # is installed) before libgndt, so libgndt's DT_NEEDED libamdhip64.so.7 binds to it by soname.
+    rt = os.path.join(_hip_runtime_dir(), "libamdhip64.so")
+    if os.path.exists(rt):
+        C.CDLL(rt, mode=C.RTLD_GLOBAL)
     L = C.CDLL(LIB_PATH)
     vp, sz, u64 = C.c_void_p, C.c_size_t, C.c_uint64
     H = C.c_void_p

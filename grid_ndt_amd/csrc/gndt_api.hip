@@ -631,11 +631,22 @@ int gndt_get_phase_times(gndt_handle* h, double ms_out[GNDT_NUM_PHASES]) {
 }
 
 int gndt_device_info(int32_t device_id, char name_out[128], int32_t* compute_units, uint64_t* hbm_bytes) {
-    hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, device_id) != hipSuccess) return GNDT_ERR_NO_DEVICE;
-    if (name_out) { strncpy(name_out, prop.name, 127); name_out[127] = 0; }
-    if (compute_units) *compute_units = prop.multiProcessorCount;
-    if (hbm_bytes) *hbm_bytes = prop.totalGlobalMem;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device_id < 0 || device_id >= ndev) return GNDT_ERR_NO_DEVICE;
+    if (name_out) {
+        name_out[0] = 0;
+        (void)hipDeviceGetName(name_out, 128, device_id);
+    }
+    if (compute_units) {
+        int cu = 0;
+        (void)hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, device_id);
+        *compute_units = cu;
+    }
+    if (hbm_bytes) {
+        size_t total = 0;
+        (void)hipDeviceTotalMem(&total, device_id);
+        *hbm_bytes = total;
+    }
     return GNDT_OK;
 }
 

@@ -218,3 +218,28 @@ def test_full_size_properties_10M():
         assert np.abs(out["mean"][i] - mu).max() <= 1e-5 * max(1.0, np.abs(mu).max())
         ev = np.linalg.eigvalsh(S)
         assert abs(out["rough"][i] - ev[0]) <= 1e-5 * np.trace(S)
+
+
+def test_single_hip_runtime_and_foreign_stream():
+    """libgndt must share the process's HIP runtime with torch (streams/events/allocations are per
+    runtime), and honour a non-default torch stream handed across the C ABI."""
+    import torch
+    import grid_ndt_amd as g
+    maps = open("/proc/self/maps").read()
+    libs = {line.split()[-1] for line in maps.splitlines() if "libamdhip64" in line}
+    assert len(libs) == 1, libs
+    cloud = scenes.campus_frame(100000)
+    P = scenes.CAMPUS_PARAMS
+    ref = parity.ref_from_cloud(cloud, P)
+    m = g.TwoDmap(P["grid_len"], P["z_len"])
+    m.setInterval(P["slope_interval"])
+    m.setCloudFirst(cloud[0])
+    s = torch.cuda.Stream()
+    host = torch.from_numpy(cloud[1:]).pin_memory()
+    with torch.cuda.stream(s):
+        dev = host.to("cuda", non_blocking=True)      # the copy is only ordered with the build via stream s
+        m.create2DMap("slope", dev, stream=s)
+    parity.assert_parity(m.export(), ref)
+    views = m.export_device()
+    torch.cuda.synchronize()
+    assert int(views["count"].sum().item()) == cloud.shape[0] - 1
