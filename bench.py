@@ -134,9 +134,22 @@ def main():
         total_points = n * world
         value = total_points / (dt / a.steps) / 1e6
         phases = {k: round(v / a.steps, 4) for k, v in phase_sum.items()}
-        acc_ms = phases.get("accumulate", float("nan"))
-        # dominant kernel: k_accumulate, which streams the N points once -> 12 B/point algorithmic
-        alg_bytes = BYTES_PER_POINT * n
+        strat = m.STRATEGY_NAMES.get(m.last_strategy(), "?")
+        # Dominant kernel = the longest phase.  Its algorithmic bytes (DESIGN.md "Roofline accounting"):
+        # every kernel that streams the cloud moves 12 B/point; k_bucket_build also emits the nodes
+        # (12 B/point + 76 B/node); node-proportional kernels move 76 B/node.
+        kernel_of = {"accumulate": "k_accumulate", "hist": "k_part_hist", "scatter": "k_part_scatter",
+                     "bucket_build": "k_bucket_build", "scan": "k_scan_nodes", "label": "k_label_nodes",
+                     "sort": "rocprim::radix_sort_pairs", "emit": "k_emit_nodes" if strat == "atomic" else "k_emit_rows"}
+        cand = {k: v for k, v in phases.items() if k in kernel_of}
+        dom = max(cand, key=cand.get) if cand else None
+        acc_ms = cand.get(dom, float("nan")) if dom else float("nan")
+        if dom in ("accumulate", "hist", "scatter"):
+            alg_bytes = BYTES_PER_POINT * n
+        elif dom == "bucket_build":
+            alg_bytes = BYTES_PER_POINT * n + BYTES_PER_NODE * nodes
+        else:
+            alg_bytes = BYTES_PER_NODE * nodes
         achieved = alg_bytes / (acc_ms * 1e-3) / 1e9 if acc_ms == acc_ms and acc_ms > 0 else None
         path_bytes = BYTES_PER_POINT * n + BYTES_PER_NODE * nodes
         out = {
@@ -148,8 +161,8 @@ def main():
                                    "demand=slope (BASELINE.json configs[1])" if n == 10_000_000 and a.grid_len == 0.5 and a.z_len == 0.5
                        else f"uniform box, {n} points/rank, grid {a.grid_len}/{a.z_len}",
                        "points_per_gpu": n, "nodes": int(nodes), "columns": int(cols), "slopes": int(slopes),
-                       "multi_gpu_mode": a.mode if world > 1 else "single", "strategy": a.strategy},
-            "roofline": {"bound": "hbm", "kernel": "k_accumulate",
+                       "multi_gpu_mode": a.mode if world > 1 else "single", "strategy": strat},
+            "roofline": {"bound": "hbm", "kernel": kernel_of.get(dom),
                          "achieved": round(achieved, 2) if achieved else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5) if achieved else None, "traffic": None,
                          "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": acc_ms},

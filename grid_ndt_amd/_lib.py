@@ -132,6 +132,8 @@ def lib():
     L.gndt_unpack_key.restype = None
     L.gndt_set_profiling.argtypes = [H, C.c_int]
     L.gndt_get_phase_times.argtypes = [H, C.POINTER(C.c_double)]
+    L.gndt_last_strategy.argtypes = [H]
+    L.gndt_last_strategy.restype = C.c_int
     L.gndt_device_info.argtypes = [C.c_int32, C.c_char_p, C.POINTER(C.c_int32), C.POINTER(u64)]
     for name in ("gndt_create", "gndt_set_origin", "gndt_build", "gndt_build_device", "gndt_update", "gndt_update_device",
                  "gndt_reset", "gndt_accumulate_device", "gndt_finalize_device", "gndt_sync", "gndt_export_device",

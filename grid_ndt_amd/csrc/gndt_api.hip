@@ -13,6 +13,7 @@
 
 #include "gndt.h"
 #include "gndt_kernels.hpp"
+#include "gndt_partition.hpp"
 
 using namespace gndt;
 
@@ -68,6 +69,21 @@ struct gndt_handle {
     uint64_t stream_pos = 0;    // points accumulated since the last reset (first_idx base)
     bool table_dirty = false;   // table holds nodes
     bool list_valid = false;    // node_slot / col_slot_of_node describe the table's occupied slots
+
+    // strategy PARTITION buffers (gndt_partition.hpp)
+    struct Part {
+        uint64_t rec_cap = 0;      float4* recs = nullptr;
+        uint64_t hist_cap = 0;     uint32_t* hist = nullptr;
+        uint32_t bucket_cap = 0;   uint32_t* totals = nullptr; uint32_t* bucket_base = nullptr;
+        uint64_t stage_cap = 0;    StageRow* stage = nullptr;
+        uint32_t *ord_cf = nullptr, *ord_idx = nullptr, *ord_ncol = nullptr, *col_rank = nullptr, *col_size = nullptr,
+                 *col_base = nullptr, *inv = nullptr, *bsum_cols = nullptr;
+        uint64_t word_cap = 0;     uint32_t *bitmap = nullptr, *word_prefix = nullptr, *bsum_words = nullptr;
+        PartCounters* d_pc = nullptr;
+        PartCounters* h_pc = nullptr;   // pinned
+    } part;
+    int last_strategy = GNDT_STRATEGY_ATOMIC;
+    bool map_in_table = true;   // false after a PARTITION build: the HBM node table does not hold the map
 
     // optional phase timing (bench / profiling): events recorded on the launch stream
     bool prof = false;
@@ -344,6 +360,162 @@ int stage_host_input(gndt_handle* h, const void* xyz_host, size_t n, size_t stri
     return GNDT_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// strategy PARTITION (gndt_partition.hpp)
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+int grow_buf(gndt_handle* h, T*& p, uint64_t& cap, uint64_t want) {
+    if (want <= cap) return GNDT_OK;
+    if (p) (void)hipFree(p);
+    p = nullptr; cap = 0;
+    HIP_TRY(h, hipMalloc(&p, want * sizeof(T)));
+    cap = want;
+    return GNDT_OK;
+}
+
+void free_part(gndt_handle* h) {
+    auto& q = h->part;
+    void* ptrs[] = {q.recs, q.hist, q.totals, q.bucket_base, q.stage, q.ord_cf, q.ord_idx, q.ord_ncol, q.col_rank,
+                    q.col_size, q.col_base, q.inv, q.bsum_cols, q.bitmap, q.word_prefix, q.bsum_words, q.d_pc};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    if (q.h_pc) (void)hipHostFree(q.h_pc);
+    q = gndt_handle::Part{};
+}
+
+int ensure_stage(gndt_handle* h, uint64_t nodes) {
+    auto& q = h->part;
+    if (nodes <= q.stage_cap) return GNDT_OK;
+    void* ptrs[] = {q.stage, q.ord_cf, q.ord_idx, q.ord_ncol, q.col_rank, q.col_size, q.col_base, q.inv, q.bsum_cols};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    q.stage = nullptr; q.ord_cf = q.ord_idx = q.ord_ncol = q.col_rank = q.col_size = q.col_base = q.inv = q.bsum_cols = nullptr;
+    q.stage_cap = 0;
+    HIP_TRY(h, hipMalloc(&q.stage, nodes * sizeof(StageRow)));
+    uint32_t** arrs[] = {&q.ord_cf, &q.ord_idx, &q.ord_ncol, &q.col_rank, &q.col_size, &q.col_base, &q.inv};
+    for (auto a : arrs) HIP_TRY(h, hipMalloc(a, nodes * 4));
+    HIP_TRY(h, hipMalloc(&q.bsum_cols, ((nodes + kScanChunk - 1) / kScanChunk + 1) * 4));
+    q.stage_cap = nodes;
+    return GNDT_OK;
+}
+
+uint32_t choose_buckets(const gndt_handle* h, uint64_t n) {
+    const uint64_t nodes = h->P.max_nodes_hint ? h->P.max_nodes_hint : n / 8;
+    uint64_t want = std::max<uint64_t>(n / 4096, nodes / 300);
+    uint32_t B = 64;
+    while (B < want && B < 16384) B <<= 1;
+    return B;
+}
+
+// Returns GNDT_OK, an error, or -1 when the partition path cannot hold this input (caller falls back).
+int build_partition(gndt_handle* h, const void* xyz_dev, size_t n, size_t stride_bytes, hipStream_t s) {
+    auto& q = h->part;
+    if (stride_bytes != 12 && stride_bytes != 16) { h->err = "stride_bytes must be 12 or 16"; return GNDT_ERR_INVALID; }
+    if (n >= 0xFFFFFFFFull) { h->err = "point index exceeds 32 bits"; return GNDT_ERR_INVALID; }
+    const uint32_t B = choose_buckets(h, n);
+    const uint32_t nwg = (uint32_t)std::min<uint64_t>(1024, std::max<uint64_t>(1, n / 8192));
+    const uint64_t words = (n + 31) / 32 + 1;
+    int rc;
+    if ((rc = grow_buf(h, q.recs, q.rec_cap, n))) return rc;
+    if ((rc = grow_buf(h, q.hist, q.hist_cap, (uint64_t)nwg * B))) return rc;
+    if (B > q.bucket_cap) {
+        if (q.totals) (void)hipFree(q.totals);
+        if (q.bucket_base) (void)hipFree(q.bucket_base);
+        q.totals = q.bucket_base = nullptr; q.bucket_cap = 0;
+        HIP_TRY(h, hipMalloc(&q.totals, (size_t)B * 4));
+        HIP_TRY(h, hipMalloc(&q.bucket_base, ((size_t)B + 1) * 4));
+        q.bucket_cap = B;
+    }
+    if (words > q.word_cap) {
+        for (uint32_t** a : {&q.bitmap, &q.word_prefix, &q.bsum_words}) { if (*a) (void)hipFree(*a); *a = nullptr; }
+        q.word_cap = 0;
+        HIP_TRY(h, hipMalloc(&q.bitmap, words * 4));
+        HIP_TRY(h, hipMalloc(&q.word_prefix, words * 4));
+        HIP_TRY(h, hipMalloc(&q.bsum_words, ((words + kScanChunk - 1) / kScanChunk + 1) * 4));
+        q.word_cap = words;
+    }
+    if (!q.d_pc) {
+        HIP_TRY(h, hipMalloc(&q.d_pc, sizeof(PartCounters)));
+        HIP_TRY(h, hipHostMalloc(&q.h_pc, sizeof(PartCounters)));
+    }
+    uint64_t stage_want = std::max<uint64_t>(q.stage_cap, h->P.max_nodes_hint ? h->P.max_nodes_hint + h->P.max_nodes_hint / 8
+                                                                             : std::max<uint64_t>(4096, n / 4));
+    const GridParams gp = grid_params(h);
+    const float* p = static_cast<const float*>(xyz_dev);
+    for (int attempt = 0; attempt < 3; ++attempt) {
+        if ((rc = ensure_stage(h, stage_want))) return rc;
+        if ((rc = ensure_out(h, q.stage_cap))) return rc;
+        mark(h, 0, s);
+        // the HBM node table is not used by this strategy, but a previous atomic build may sit in it
+        if ((rc = do_reset(h, s))) return rc;
+        HIP_TRY(h, hipMemsetAsync(q.bitmap, 0, words * 4, s));
+        HIP_TRY(h, hipMemsetAsync(q.d_pc, 0, sizeof(PartCounters), s));
+        mark(h, 1, s);
+        const size_t lds = (size_t)B * 4;
+        if (stride_bytes == 12)
+            hipLaunchKernelGGL(k_part_hist<3>, dim3(nwg), dim3(kPartThreads), lds, s, p, (uint64_t)n, gp, B - 1, q.hist, h->d_cnt);
+        else
+            hipLaunchKernelGGL(k_part_hist<4>, dim3(nwg), dim3(kPartThreads), lds, s, p, (uint64_t)n, gp, B - 1, q.hist, h->d_cnt);
+        HIP_TRY(h, hipGetLastError());
+        mark(h, 2, s);
+        hipLaunchKernelGGL(k_part_offsets, dim3((B + 31) / 32), dim3(256), 0, s, q.hist, q.totals, B, nwg);
+        HIP_TRY(h, hipGetLastError());
+        mark(h, 3, s);
+        if (stride_bytes == 12)
+            hipLaunchKernelGGL(k_part_scatter<3>, dim3(nwg), dim3(kPartThreads), lds, s, p, (uint64_t)n, 0u, gp, B - 1, q.hist,
+                               q.totals, q.bucket_base, q.recs);
+        else
+            hipLaunchKernelGGL(k_part_scatter<4>, dim3(nwg), dim3(kPartThreads), lds, s, p, (uint64_t)n, 0u, gp, B - 1, q.hist,
+                               q.totals, q.bucket_base, q.recs);
+        HIP_TRY(h, hipGetLastError());
+        mark(h, 4, s);
+        hipLaunchKernelGGL(k_bucket_build, dim3(B), dim3(kBucketThreads), 0, s, q.recs, q.bucket_base, gp, q.stage,
+                           (uint32_t)q.stage_cap, q.ord_cf, q.ord_idx, q.ord_ncol, q.bitmap, h->d_cnt, q.d_pc);
+        HIP_TRY(h, hipGetLastError());
+        mark(h, 5, s);
+        const uint32_t nbw = (uint32_t)((words + kScanChunk - 1) / kScanChunk);
+        hipLaunchKernelGGL(k_scan_reduce<true>, dim3(nbw), dim3(kScanThreads), 0, s, q.bitmap, (const uint32_t*)nullptr,
+                           (uint32_t)words, q.bsum_words);
+        hipLaunchKernelGGL(k_scan_apply<true>, dim3(nbw), dim3(kScanThreads), 0, s, q.bitmap, (const uint32_t*)nullptr,
+                           (uint32_t)words, q.bsum_words, q.word_prefix);
+        HIP_TRY(h, hipGetLastError());
+        mark(h, 6, s);
+        hipLaunchKernelGGL(k_order_rank, dim3(grid_for(q.stage_cap)), dim3(kBlock), 0, s, q.ord_cf, q.ord_idx, q.ord_ncol,
+                           q.bitmap, q.word_prefix, q.col_rank, q.col_size, h->d_cnt, q.d_pc);
+        HIP_TRY(h, hipGetLastError());
+        mark(h, 7, s);
+        const uint32_t nbc = (uint32_t)((q.stage_cap + kScanChunk - 1) / kScanChunk);
+        hipLaunchKernelGGL(k_scan_reduce<false>, dim3(nbc), dim3(kScanThreads), 0, s, q.col_size, &h->d_cnt->num_columns, 0u,
+                           q.bsum_cols);
+        hipLaunchKernelGGL(k_scan_apply<false>, dim3(nbc), dim3(kScanThreads), 0, s, q.col_size, &h->d_cnt->num_columns, 0u,
+                           q.bsum_cols, q.col_base);
+        HIP_TRY(h, hipGetLastError());
+        mark(h, 8, s);
+        hipLaunchKernelGGL(k_order_dest, dim3(grid_for(q.stage_cap)), dim3(kBlock), 0, s, q.col_rank, q.ord_idx, q.col_base,
+                           q.inv, h->d_cnt, q.d_pc);
+        HIP_TRY(h, hipGetLastError());
+        mark(h, 9, s);
+        hipLaunchKernelGGL(k_emit_rows, dim3(grid_for(q.stage_cap)), dim3(kBlock), 0, s, q.stage, q.inv, h->out, h->d_cnt, q.d_pc);
+        HIP_TRY(h, hipGetLastError());
+        mark(h, 10, s);
+        HIP_TRY(h, hipMemcpyAsync(q.h_pc, q.d_pc, sizeof(PartCounters), hipMemcpyDeviceToHost, s));
+        HIP_TRY(h, hipMemcpyAsync(h->h_cnt, h->d_cnt, sizeof(Counters), hipMemcpyDeviceToHost, s));
+        HIP_TRY(h, hipStreamSynchronize(s));
+        if (q.h_pc->lds_overflow) return -1;                 // a bucket holds too many nodes for LDS
+        if (q.h_pc->stage_overflow) {                        // num_nodes kept counting: it is the true total
+            stage_want = (uint64_t)h->h_cnt->num_nodes + h->h_cnt->num_nodes / 8 + 1024;
+            continue;
+        }
+        h->results_valid = true;
+        h->map_in_table = false;
+        h->table_dirty = false;
+        h->last_strategy = GNDT_STRATEGY_PARTITION;
+        h->stream_pos = n;
+        return GNDT_OK;
+    }
+    return -1;
+}
+
 }  // namespace
 
 extern "C" {
@@ -395,6 +567,7 @@ void gndt_destroy(gndt_handle* h) {
     (void)hipSetDevice(h->device);
     (void)hipDeviceSynchronize();
     free_table(h);
+    free_part(h);
     void* ptrs[] = {h->out.sx, h->out.sy, h->out.sz, h->out.count, h->out.first_idx, h->out.mean, h->out.cov,
                     h->out.rough, h->out.normal, h->out.flags, h->st_key, h->st_sums, h->st_count, h->st_first,
                     h->stage, h->d_cnt};
@@ -420,6 +593,8 @@ int gndt_reset(gndt_handle* h, void* hip_stream) {
     HIP_TRY(h, hipSetDevice(h->device));
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
     h->last_stream = s;
+    h->map_in_table = true;
+    h->last_strategy = GNDT_STRATEGY_ATOMIC;
     return do_reset(h, s);
 }
 
@@ -430,6 +605,11 @@ int gndt_accumulate_device(gndt_handle* h, const void* xyz_dev, size_t n, size_t
     if (!xyz_dev && n) { h->err = "null input"; return GNDT_ERR_INVALID; }
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
     h->last_stream = s;
+    if (!h->map_in_table) {
+        h->err = "the current map was built by the PARTITION strategy, which keeps no additive state: create the handle "
+                 "with strategy = GNDT_STRATEGY_ATOMIC for incremental updates, or call gndt_reset first";
+        return GNDT_ERR_INVALID;
+    }
     uint64_t known = h->results_valid ? h->res_nodes : (h->table_dirty ? h->h_cnt->num_nodes : 0);
     rc = ensure_capacity_for(h, expected_nodes_for_batch(h, known, n), s);
     if (rc) return rc;
@@ -459,6 +639,16 @@ int gndt_build_device(gndt_handle* h, const void* xyz_dev, size_t n, size_t stri
     if (!xyz_dev && n) { h->err = "null input"; return GNDT_ERR_INVALID; }
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
     h->last_stream = s;
+    for (auto& r : h->ev_recorded) r = false;
+    int strategy = h->P.strategy;
+    if (strategy == GNDT_STRATEGY_AUTO) strategy = (n >= (1u << 18)) ? GNDT_STRATEGY_PARTITION : GNDT_STRATEGY_ATOMIC;
+    if (strategy == GNDT_STRATEGY_PARTITION) {
+        rc = build_partition(h, xyz_dev, n, stride_bytes, s);
+        if (rc != -1) return rc;
+        // does not fit the LDS-resident pipeline (too many nodes per bucket): same result via the atomic path
+    }
+    h->last_strategy = GNDT_STRATEGY_ATOMIC;
+    h->map_in_table = true;
     uint64_t expect = h->P.max_nodes_hint ? h->P.max_nodes_hint : std::max<uint64_t>(1024, n / 4);
     for (int attempt = 0; attempt < 8; ++attempt) {
         const uint32_t want = cap_for_nodes(expect);
@@ -629,6 +819,8 @@ int gndt_get_phase_times(gndt_handle* h, double ms_out[GNDT_NUM_PHASES]) {
     }
     return GNDT_OK;
 }
+
+int gndt_last_strategy(const gndt_handle* h) { return h ? h->last_strategy : GNDT_STRATEGY_AUTO; }
 
 int gndt_device_info(int32_t device_id, char name_out[128], int32_t* compute_units, uint64_t* hbm_bytes) {
     int ndev = 0;

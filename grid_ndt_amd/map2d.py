@@ -201,16 +201,23 @@ class TwoDmap:
         self._keep = (key, sums, count, first_idx)
 
     # ---- phase timing ----
-    PHASES = ("clear", "accumulate", "scan", "label", "sort", "emit")
+    PHASES = {1: ("clear", "accumulate", "scan", "label", "sort", "emit"),
+              2: ("clear", "hist", "offsets", "scatter", "bucket_build", "bitmap_scan", "rank", "column_scan", "dest", "emit")}
+    STRATEGY_NAMES = {1: "atomic", 2: "partition"}
 
     def set_profiling(self, on=True, demand="slope"):
         self._ensure(demand)
         self._check(self._L.gndt_set_profiling(self._h, 1 if on else 0))
 
+    def last_strategy(self):
+        """1 = ATOMIC, 2 = PARTITION: what the last build actually ran."""
+        return int(self._L.gndt_last_strategy(self._h))
+
     def phase_times_ms(self):
-        arr = (C.c_double * len(self.PHASES))()
+        arr = (C.c_double * 10)()
         self._check(self._L.gndt_get_phase_times(self._h, arr))
-        return {k: arr[i] for i, k in enumerate(self.PHASES)}
+        names = self.PHASES[self.last_strategy()]
+        return {k: arr[i] for i, k in enumerate(names)}
 
     # ---- results ----
     def sync(self):

@@ -160,12 +160,17 @@ void gndt_unpack_key(uint64_t key, int32_t* sx, int32_t* sy, int32_t* sz);
 
 /* ---- phase timing (bench.py / profiling) ------------------------------------------------------ */
 /* With profiling on, build/accumulate/finalize record HIP events on the launch stream around each
- * phase; gndt_get_phase_times waits for them and returns milliseconds (-1 = phase did not run):
- *   [0] clear previous map  [1] accumulate (binning + statistics)  [2] node scan
- *   [3] slope labels + sort keys  [4] ordering sort  [5] emit (mean, scatter, eigen) */
-#define GNDT_NUM_PHASES 6
+ * phase; gndt_get_phase_times waits for them and returns milliseconds (-1 = phase did not run).
+ * Phase names depend on the strategy the last build used (gndt_last_strategy):
+ *   ATOMIC:    [0] clear  [1] accumulate  [2] scan  [3] label  [4] sort  [5] emit
+ *   PARTITION: [0] clear  [1] hist  [2] offsets  [3] scatter  [4] bucket_build  [5] bitmap_scan
+ *              [6] rank  [7] column_scan  [8] dest  [9] emit */
+#define GNDT_NUM_PHASES 10
 int gndt_set_profiling(gndt_handle* h, int enable);
 int gndt_get_phase_times(gndt_handle* h, double ms_out[GNDT_NUM_PHASES]);
+/* GNDT_STRATEGY_ATOMIC or GNDT_STRATEGY_PARTITION: what the last build actually ran (AUTO resolves,
+ * and PARTITION falls back to ATOMIC when a bucket does not fit in LDS). */
+int gndt_last_strategy(const gndt_handle* h);
 
 /* Library / device information for logs: returns 0 and fills what it can. */
 int gndt_device_info(int32_t device_id, char name_out[128], int32_t* compute_units, uint64_t* hbm_bytes);

@@ -34,14 +34,43 @@ CASES = {
 }
 
 
+_REF_CACHE = {}
+
+
+def _case(name):
+    if name not in _REF_CACHE:
+        make, P = CASES[name]
+        cloud = make()
+        _REF_CACHE[name] = (cloud, P, parity.ref_from_cloud(cloud, P))
+    return _REF_CACHE[name]
+
+
+# which strategy a forced PARTITION build must end on: buckets with too many nodes fall back to ATOMIC
+EXPECT_PARTITION = {"bridge_ground": 2, "campus_200k": 2, "uniform_300k_cubic": 1, "uniform_300k_z01": 1,
+                    "terrain_400k": 2, "terrain_true": 2, "site_zero_padded": 1}
+
+
+@pytest.mark.parametrize("strategy", [1, 2], ids=["atomic", "partition"])
 @pytest.mark.parametrize("name", list(CASES))
-def test_parity_device_input(name):
-    make, P = CASES[name]
-    cloud = make()
-    ref = parity.ref_from_cloud(cloud, P)
-    m, out = parity.gpu_from_cloud(cloud, P, on_device=True)
+def test_parity_device_input(name, strategy):
+    cloud, P, ref = _case(name)
+    m, out = parity.gpu_from_cloud(cloud, P, on_device=True, strategy=strategy)
     rep = parity.assert_parity(out, ref)
-    print(name, {k: v for k, v in rep.items() if k not in ("fail",)})
+    ran = m.last_strategy()
+    print(name, "ran", m.STRATEGY_NAMES[ran], {k: v for k, v in rep.items() if k not in ("fail",)})
+    if strategy == 1:
+        assert ran == 1
+    else:
+        assert ran == EXPECT_PARTITION[name], (name, ran)
+
+
+def test_partition_with_node_hint_handles_dense_node_sets():
+    """With max_nodes_hint the bucket count follows the node count, so node-heavy clouds stay on the LDS path."""
+    for name in ("uniform_300k_cubic", "uniform_300k_z01", "site_zero_padded"):
+        cloud, P, ref = _case(name)
+        m, out = parity.gpu_from_cloud(cloud, P, strategy=2, max_nodes_hint=int(ref["num_nodes"]))
+        parity.assert_parity(out, ref)
+        assert m.last_strategy() == 2, name
 
 
 def test_parity_host_input_and_pointxyz_stride():
@@ -147,12 +176,19 @@ def test_edge_inputs():
         same = np.tile(np.float32([[3.3, -2.2, 0.77]]), (n, 1))
         cloud = np.concatenate([np.float32([[0, 0, 0]]), same], 0)
         ref = parity.ref_from_cloud(cloud, scenes.CAMPUS_PARAMS)
-        _, o = parity.gpu_from_cloud(cloud, scenes.CAMPUS_PARAMS)
-        parity.assert_parity(o, ref)
+        for strategy in (1, 2):
+            _, o = parity.gpu_from_cloud(cloud, scenes.CAMPUS_PARAMS, strategy=strategy)
+            parity.assert_parity(o, ref)
     # key range: |nx| > 65535 must be an error, not a silent wrap (Stopwatch.h:102-110)
     far = np.float32([[0.5 * 70000, 0, 0]] * 4)
     with pytest.raises(g.GndtError) as e:
         m.create2DMap("slope", far)
+    assert e.value.code == 4
+    m2 = g.TwoDmap(0.5, 0.1, strategy=2)
+    m2.setInterval(0.08)
+    m2.setCloudFirst((0, 0, 0))
+    with pytest.raises(g.GndtError) as e:
+        m2.create2DMap("slope", far)
     assert e.value.code == 4
 
 
@@ -177,6 +213,19 @@ def test_full_size_properties_10M():
     t = torch.from_numpy(cloud[1:]).cuda()
     m.create2DMap("slope", t)
     out = m.export()
+    assert m.last_strategy() == 2          # AUTO picks the LDS-resident pipeline at this size
+    # the two strategies must agree with each other at full size
+    ma = g.TwoDmap(0.5, 0.5, max_nodes_hint=1 << 20, strategy=1)
+    ma.setInterval(0.08)
+    ma.setCloudFirst(cloud[0])
+    ma.create2DMap("slope", t)
+    oa = ma.export()
+    assert ma.last_strategy() == 1
+    for k in ("sx", "sy", "sz", "count", "first_idx", "flags"):
+        assert np.array_equal(out[k], oa[k]), k
+    assert np.abs(out["cov"] - oa["cov"]).max() <= 1e-6 * np.abs(oa["cov"]).max()
+    assert np.abs(out["mean"] - oa["mean"]).max() < 1e-5
+    del ma
     n = cloud.shape[0] - 1
     assert int(out["count"].astype(np.int64).sum()) == n                       # every point binned once
     keys = (out["sx"].astype(np.int64) << 42) ^ (out["sy"].astype(np.int64) << 21) ^ out["sz"].astype(np.int64)
