@@ -39,6 +39,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=2_000_000)
     ap.add_argument("--check", action="store_true", help="also check a 300 k-point build against the oracle")
+    ap.add_argument("--stamps", action="store_true",
+                    help="diagnostic: after the timed run, one extra build with in-kernel phase stamps (stderr)")
+    ap.add_argument("--nodes-hint", type=int, default=1 << 20)
     return ap.parse_args()
 
 
@@ -92,7 +95,7 @@ def main():
     pts = torch.from_numpy(cloud[1:]).to(dev)
     torch.cuda.synchronize()
 
-    m = g.TwoDmap(P["grid_len"], P["z_len"], device=local, max_nodes_hint=1 << 20, strategy=a.strategy)
+    m = g.TwoDmap(P["grid_len"], P["z_len"], device=local, max_nodes_hint=a.nodes_hint, strategy=a.strategy)
     m.setInterval(P["slope_interval"])
     m.setCloudFirst(origin)
     stream = torch.cuda.current_stream()
@@ -180,6 +183,13 @@ def main():
             ref = parity.ref_from_cloud(small, P)
             _, o = parity.gpu_from_cloud(small, P, device=local)
             out["check"] = parity.compare(o, ref)["ok"]
+        if a.stamps and m.last_strategy() == 2:
+            os.environ["GNDT_STAMPS"] = "1"
+            m.create2DMap("slope", pts, stream)
+            cyc, nb = m.debug_bucket_phases()
+            tot = sum(cyc.values())
+            print("k_bucket_build phase stamps (mean shader cycles per bucket, %d buckets): " % nb +
+                  ", ".join(f"{k}={v:.0f} ({100 * v / tot:.0f}%)" for k, v in cyc.items()), file=sys.stderr)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

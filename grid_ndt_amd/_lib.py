@@ -11,7 +11,7 @@ _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 _ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.path.join(_CSRC, "libgndt.so")
 SOURCES = ["gndt_api.hip", "gndt_codec.cpp"]
-HEADERS = ["gndt_kernels.hpp", "gndt_math.hpp", os.path.join(_ROOT, "include", "gndt.h")]
+HEADERS = ["gndt_kernels.hpp", "gndt_partition.hpp", "gndt_math.hpp", os.path.join(_ROOT, "include", "gndt.h")]
 
 GNDT_OK = 0
 ERR_NAMES = {0: "OK", 1: "INVALID", 2: "NO_DEVICE", 3: "HIP", 4: "KEY_RANGE", 5: "CAPACITY", 6: "NOMEM"}
@@ -132,6 +132,8 @@ def lib():
     L.gndt_unpack_key.restype = None
     L.gndt_set_profiling.argtypes = [H, C.c_int]
     L.gndt_get_phase_times.argtypes = [H, C.POINTER(C.c_double)]
+    L.gndt_debug_bucket_phases.argtypes = [H, C.POINTER(C.c_double), C.POINTER(C.c_uint32)]
+    L.gndt_debug_bucket_phases.restype = C.c_int
     L.gndt_last_strategy.argtypes = [H]
     L.gndt_last_strategy.restype = C.c_int
     L.gndt_device_info.argtypes = [C.c_int32, C.c_char_p, C.POINTER(C.c_int32), C.POINTER(u64)]

@@ -7,6 +7,8 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <vector>
+#include <cstdlib>
 
 #include <hip/hip_runtime.h>
 #include <rocprim/device/device_radix_sort.hpp>
@@ -81,6 +83,8 @@ struct gndt_handle {
         uint64_t word_cap = 0;     uint32_t *bitmap = nullptr, *word_prefix = nullptr, *bsum_words = nullptr;
         PartCounters* d_pc = nullptr;
         PartCounters* h_pc = nullptr;   // pinned
+        unsigned long long* dbg = nullptr;  uint32_t dbg_buckets = 0;   // diagnostic phase stamps (GNDT_STAMPS=1)
+        uint32_t last_buckets = 0;
     } part;
     int last_strategy = GNDT_STRATEGY_ATOMIC;
     bool map_in_table = true;   // false after a PARTITION build: the HBM node table does not hold the map
@@ -376,7 +380,7 @@ int grow_buf(gndt_handle* h, T*& p, uint64_t& cap, uint64_t want) {
 void free_part(gndt_handle* h) {
     auto& q = h->part;
     void* ptrs[] = {q.recs, q.hist, q.totals, q.bucket_base, q.stage, q.ord_cf, q.ord_idx, q.ord_ncol, q.col_rank,
-                    q.col_size, q.col_base, q.inv, q.bsum_cols, q.bitmap, q.word_prefix, q.bsum_words, q.d_pc};
+                    q.col_size, q.col_base, q.inv, q.bsum_cols, q.bitmap, q.word_prefix, q.bsum_words, q.d_pc, q.dbg};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (q.h_pc) (void)hipHostFree(q.h_pc);
@@ -399,12 +403,13 @@ int ensure_stage(gndt_handle* h, uint64_t nodes) {
     return GNDT_OK;
 }
 
-uint32_t choose_buckets(const gndt_handle* h, uint64_t n) {
-    const uint64_t nodes = h->P.max_nodes_hint ? h->P.max_nodes_hint : n / 8;
-    uint64_t want = std::max<uint64_t>(n / 4096, nodes / 300);
-    uint32_t B = 64;
-    while (B < want && B < 16384) B <<= 1;
-    return B;
+// Bucket count: ~4096 points per bucket, and few enough nodes per bucket for the LDS table
+// (average load <= 0.3 of `slots`, which leaves room for the spread of a hash partition).
+uint32_t choose_buckets(const gndt_handle* h, uint64_t n, int slots) {
+    const uint64_t nodes = h->P.max_nodes_hint ? h->P.max_nodes_hint : n / 4;
+    uint64_t want = std::max<uint64_t>(n / 4096, (nodes * 10) / (uint64_t)(slots * 3));
+    want = std::min<uint64_t>(std::max<uint64_t>(want, 16), 16384);
+    return (uint32_t)want;
 }
 
 // Returns GNDT_OK, an error, or -1 when the partition path cannot hold this input (caller falls back).
@@ -412,7 +417,9 @@ int build_partition(gndt_handle* h, const void* xyz_dev, size_t n, size_t stride
     auto& q = h->part;
     if (stride_bytes != 12 && stride_bytes != 16) { h->err = "stride_bytes must be 12 or 16"; return GNDT_ERR_INVALID; }
     if (n >= 0xFFFFFFFFull) { h->err = "point index exceeds 32 bits"; return GNDT_ERR_INVALID; }
-    const uint32_t B = choose_buckets(h, n);
+    static const int bt = getenv("GNDT_BUCKET_THREADS") ? atoi(getenv("GNDT_BUCKET_THREADS")) : 512;
+    static const int bslots = getenv("GNDT_BUCKET_SLOTS") ? atoi(getenv("GNDT_BUCKET_SLOTS")) : 1024;
+    const uint32_t B = choose_buckets(h, n, bslots);
     const uint32_t nwg = (uint32_t)std::min<uint64_t>(1024, std::max<uint64_t>(1, n / 8192));
     const uint64_t words = (n + 31) / 32 + 1;
     int rc;
@@ -453,24 +460,39 @@ int build_partition(gndt_handle* h, const void* xyz_dev, size_t n, size_t stride
         mark(h, 1, s);
         const size_t lds = (size_t)B * 4;
         if (stride_bytes == 12)
-            hipLaunchKernelGGL(k_part_hist<3>, dim3(nwg), dim3(kPartThreads), lds, s, p, (uint64_t)n, gp, B - 1, q.hist, h->d_cnt);
+            hipLaunchKernelGGL(k_part_hist<3>, dim3(nwg), dim3(kPartThreads), lds, s, p, (uint64_t)n, gp, B, q.hist, h->d_cnt);
         else
-            hipLaunchKernelGGL(k_part_hist<4>, dim3(nwg), dim3(kPartThreads), lds, s, p, (uint64_t)n, gp, B - 1, q.hist, h->d_cnt);
+            hipLaunchKernelGGL(k_part_hist<4>, dim3(nwg), dim3(kPartThreads), lds, s, p, (uint64_t)n, gp, B, q.hist, h->d_cnt);
         HIP_TRY(h, hipGetLastError());
         mark(h, 2, s);
         hipLaunchKernelGGL(k_part_offsets, dim3((B + 31) / 32), dim3(256), 0, s, q.hist, q.totals, B, nwg);
         HIP_TRY(h, hipGetLastError());
         mark(h, 3, s);
         if (stride_bytes == 12)
-            hipLaunchKernelGGL(k_part_scatter<3>, dim3(nwg), dim3(kPartThreads), lds, s, p, (uint64_t)n, 0u, gp, B - 1, q.hist,
+            hipLaunchKernelGGL(k_part_scatter<3>, dim3(nwg), dim3(kPartThreads), lds, s, p, (uint64_t)n, 0u, gp, B, q.hist,
                                q.totals, q.bucket_base, q.recs);
         else
-            hipLaunchKernelGGL(k_part_scatter<4>, dim3(nwg), dim3(kPartThreads), lds, s, p, (uint64_t)n, 0u, gp, B - 1, q.hist,
+            hipLaunchKernelGGL(k_part_scatter<4>, dim3(nwg), dim3(kPartThreads), lds, s, p, (uint64_t)n, 0u, gp, B, q.hist,
                                q.totals, q.bucket_base, q.recs);
         HIP_TRY(h, hipGetLastError());
         mark(h, 4, s);
-        hipLaunchKernelGGL(k_bucket_build, dim3(B), dim3(kBucketThreads), 0, s, q.recs, q.bucket_base, gp, q.stage,
-                           (uint32_t)q.stage_cap, q.ord_cf, q.ord_idx, q.ord_ncol, q.bitmap, h->d_cnt, q.d_pc);
+        if (getenv("GNDT_STAMPS") && q.dbg_buckets < B) {
+            if (q.dbg) (void)hipFree(q.dbg);
+            q.dbg = nullptr; q.dbg_buckets = 0;
+            HIP_TRY(h, hipMalloc(&q.dbg, (size_t)B * 8 * sizeof(unsigned long long)));
+            q.dbg_buckets = B;
+        }
+        q.last_buckets = B;
+        {
+#define GNDT_LAUNCH_BUCKET(T_, H_)                                                                                     \
+    hipLaunchKernelGGL((k_bucket_build<T_, H_>), dim3(B), dim3(T_), 0, s, q.recs, q.bucket_base, gp, q.stage,          \
+                       (uint32_t)q.stage_cap, q.ord_cf, q.ord_idx, q.ord_ncol, q.bitmap, h->d_cnt, q.d_pc, q.dbg)
+            if (bslots == 1024 && bt == 1024) GNDT_LAUNCH_BUCKET(1024, 1024);
+            else if (bslots == 1024) GNDT_LAUNCH_BUCKET(512, 1024);
+            else if (bt == 256) GNDT_LAUNCH_BUCKET(256, 512);
+            else GNDT_LAUNCH_BUCKET(512, 512);
+#undef GNDT_LAUNCH_BUCKET
+        }
         HIP_TRY(h, hipGetLastError());
         mark(h, 5, s);
         const uint32_t nbw = (uint32_t)((words + kScanChunk - 1) / kScanChunk);
@@ -817,6 +839,22 @@ int gndt_get_phase_times(gndt_handle* h, double ms_out[GNDT_NUM_PHASES]) {
             if (hipEventElapsedTime(&ms, h->ev[i], h->ev[i + 1]) == hipSuccess) ms_out[i] = ms;
         }
     }
+    return GNDT_OK;
+}
+
+int gndt_debug_bucket_phases(gndt_handle* h, double cycles_out[6], uint32_t* buckets_out) {
+    if (!h || !cycles_out) return GNDT_ERR_INVALID;
+    auto& q = h->part;
+    if (!q.dbg || !q.last_buckets) { h->err = "no stamps: set GNDT_STAMPS=1 before a PARTITION build"; return GNDT_ERR_INVALID; }
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipStreamSynchronize(h->last_stream));
+    std::vector<unsigned long long> t((size_t)q.last_buckets * 8);
+    HIP_TRY(h, hipMemcpy(t.data(), q.dbg, t.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    for (int k = 0; k < 6; ++k) cycles_out[k] = 0.0;
+    for (uint32_t b = 0; b < q.last_buckets; ++b)
+        for (int k = 0; k < 6; ++k) cycles_out[k] += (double)(t[(size_t)b * 8 + k + 1] - t[(size_t)b * 8 + k]);
+    for (int k = 0; k < 6; ++k) cycles_out[k] /= q.last_buckets;
+    if (buckets_out) *buckets_out = q.last_buckets;
     return GNDT_OK;
 }
 

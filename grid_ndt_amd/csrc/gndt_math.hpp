@@ -118,6 +118,84 @@ GNDT_HD int pick_min_eigen(const double e[3]) {
     return (e[1] < e[2]) ? 1 : 2;
 }
 
+// ---- minimum eigenpair of a symmetric positive semi-definite 3x3, fast path ------------------------
+// What OcNode::countRoughNormal needs (map2D.h:110-133) is only the smallest eigenvalue and its
+// eigenvector.  Jacobi (above, kept as the in-repo cross-check) costs thousands of fp64 instructions per
+// node; this costs ~200:
+//   1. scale by max |S_ij|;
+//   2. fp32 trigonometric closed form for a start value (relative error ~1e-6 whatever the clustering);
+//   3. fp64 Newton on det(A - x I) started just LEFT of the estimate: for a cubic with real roots the
+//      iterates rise monotonically to the smallest root (quadratic when it is separated; when roots
+//      cluster the start value is already inside the tolerance);
+//   4. eigenvector = largest cross product of two rows of (A - x I); rank-deficient fall-backs below.
+// c = xx,xy,xz,yy,yz,zz.  Returns lambda (>= 0 up to rounding) and a unit vector.
+GNDT_HD void min_eigenpair_sym3(const double c[6], double& lambda, double v[3]) {
+    double s = fmax(fmax(fabs(c[0]), fabs(c[3])), fabs(c[5]));
+    s = fmax(s, fmax(fmax(fabs(c[1]), fabs(c[2])), fabs(c[4])));
+    v[0] = 0.0; v[1] = 0.0; v[2] = 1.0;
+    lambda = 0.0;
+    if (!(s > 0.0)) return;                       // all-zero scatter (identical points)
+    const double inv = 1.0 / s;
+    const double a00 = c[0] * inv, a01 = c[1] * inv, a02 = c[2] * inv, a11 = c[3] * inv, a12 = c[4] * inv, a22 = c[5] * inv;
+    const double c2 = a00 + a11 + a22;
+    const double c1 = (a00 * a11 - a01 * a01) + (a00 * a22 - a02 * a02) + (a11 * a22 - a12 * a12);
+    const double c0 = a00 * (a11 * a22 - a12 * a12) - a01 * (a01 * a22 - a12 * a02) + a02 * (a01 * a12 - a11 * a02);
+    // fp32 start value
+    const float q = (float)c2 * (1.0f / 3.0f);
+    const float b00 = (float)a00 - q, b11 = (float)a11 - q, b22 = (float)a22 - q;
+    const float f01 = (float)a01, f02 = (float)a02, f12 = (float)a12;
+    const float p2 = b00 * b00 + b11 * b11 + b22 * b22 + 2.0f * (f01 * f01 + f02 * f02 + f12 * f12);
+    double lam;
+    if (p2 < 1e-12f) {
+        lam = (double)q - 1e-5;                    // (numerically) isotropic
+    } else {
+        const float p = sqrtf(p2 * (1.0f / 6.0f));
+        const float ip = 1.0f / p;
+        const float d00 = b00 * ip, d11 = b11 * ip, d22 = b22 * ip, d01 = f01 * ip, d02 = f02 * ip, d12 = f12 * ip;
+        float r = 0.5f * (d00 * (d11 * d22 - d12 * d12) - d01 * (d01 * d22 - d12 * d02) + d02 * (d01 * d12 - d11 * d02));
+        r = fminf(1.0f, fmaxf(-1.0f, r));
+        const float phi = acosf(r) * (1.0f / 3.0f);
+        lam = (double)(q + 2.0f * p * cosf(phi + 2.0943951023931953f)) - 1e-5;
+    }
+    // separated root: 2-4 iterations (quadratic); double/triple root: halves the error each time
+    for (int it = 0; it < 26; ++it) {
+        const double f = ((c2 - lam) * lam - c1) * lam + c0;
+        const double fp = (2.0 * c2 - 3.0 * lam) * lam - c1;
+        if (!(fp < 0.0)) break;                    // past the first critical point: roots coincide to ~1e-5
+        const double step = f / fp;
+        lam -= step;
+        if (fabs(step) <= 1e-15) break;
+    }
+    lambda = lam * s;
+    // eigenvector
+    const double m00 = a00 - lam, m11 = a11 - lam, m22 = a22 - lam;
+    const double x0 = a01 * a12 - a02 * m11, y0 = a02 * a01 - m00 * a12, z0 = m00 * m11 - a01 * a01;   // r0 x r1
+    const double x1 = a01 * m22 - a02 * a12, y1 = a02 * a02 - m00 * m22, z1 = m00 * a12 - a01 * a02;   // r0 x r2
+    const double x2 = m11 * m22 - a12 * a12, y2 = a12 * a02 - a01 * m22, z2 = a01 * a12 - m11 * a02;   // r1 x r2
+    const double n0 = x0 * x0 + y0 * y0 + z0 * z0, n1 = x1 * x1 + y1 * y1 + z1 * z1, n2 = x2 * x2 + y2 * y2 + z2 * z2;
+    double vx = x0, vy = y0, vz = z0, nn = n0;
+    if (n1 > nn) { vx = x1; vy = y1; vz = z1; nn = n1; }
+    if (n2 > nn) { vx = x2; vy = y2; vz = z2; nn = n2; }
+    if (nn > 1e-26) {
+        const double k = 1.0 / sqrt(nn);
+        v[0] = vx * k; v[1] = vy * k; v[2] = vz * k;
+        return;
+    }
+    // (A - x I) has rank <= 1: the eigenspace is a plane.  Take a unit vector orthogonal to the largest row.
+    const double q0 = m00 * m00 + a01 * a01 + a02 * a02, q1 = a01 * a01 + m11 * m11 + a12 * a12, q2 = a02 * a02 + a12 * a12 + m22 * m22;
+    double rx = m00, ry = a01, rz = a02, qq = q0;
+    if (q1 > qq) { rx = a01; ry = m11; rz = a12; qq = q1; }
+    if (q2 > qq) { rx = a02; ry = a12; rz = m22; qq = q2; }
+    if (!(qq > 1e-26)) return;                     // A - x I == 0: every direction; keep (0,0,1)
+    // r x e_k with k = the smallest component of r
+    const double ax = fabs(rx), ay = fabs(ry), az = fabs(rz);
+    if (ax <= ay && ax <= az) { vx = 0.0; vy = rz; vz = -ry; }
+    else if (ay <= az) { vx = -rz; vy = 0.0; vz = rx; }
+    else { vx = ry; vy = -rx; vz = 0.0; }
+    const double k = 1.0 / sqrt(vx * vx + vy * vy + vz * vz);
+    v[0] = vx * k; v[1] = vy * k; v[2] = vz * k;
+}
+
 // ---- per-node finalisation -----------------------------------------------------------------------
 // From additive cell-local statistics (n, Sum v, Sum v v^T) to what OcNode / Slope hold:
 //   mean  = centre + Sum v / n                       (pcl::compute3DCentroid,  map2D.h:621)
@@ -130,10 +208,10 @@ struct NodeResult {
     float normal[3];
 };
 
-GNDT_HD void finalize_node(uint32_t n, const double sums[9], const double centre[3], NodeResult& r) {
+// mean (fp32, as the reference stores it) and un-normalised scatter (fp64) from the additive statistics
+GNDT_HD void node_moments(uint32_t n, const double sums[9], const double centre[3], float mean[3], double S[6]) {
     const double inv = 1.0 / (double)n;
-    double m[3] = {sums[0] * inv, sums[1] * inv, sums[2] * inv};
-    double S[6];
+    const double m[3] = {sums[0] * inv, sums[1] * inv, sums[2] * inv};
     S[0] = sums[3] - sums[0] * m[0];
     S[1] = sums[4] - sums[0] * m[1];
     S[2] = sums[5] - sums[0] * m[2];
@@ -144,21 +222,28 @@ GNDT_HD void finalize_node(uint32_t n, const double sums[9], const double centre
     if (S[0] < 0.0) S[0] = 0.0;
     if (S[3] < 0.0) S[3] = 0.0;
     if (S[5] < 0.0) S[5] = 0.0;
-    for (int k = 0; k < 3; ++k) r.mean[k] = (float)(centre[k] + m[k]);
-    for (int k = 0; k < 6; ++k) r.cov[k] = (float)S[k];
-    double ev[3], vec[3][3];
-    eigen_sym3(S, ev, vec);
-    int j = pick_min_eigen(ev);
-    double nx = vec[0][j], ny = vec[1][j], nz = vec[2][j];
-    double nn = sqrt(nx * nx + ny * ny + nz * nz);
-    if (nn > 0.0) { nx /= nn; ny /= nn; nz /= nn; }
+    for (int k = 0; k < 3; ++k) mean[k] = (float)(centre[k] + m[k]);
+}
+
+// roughness and normal from the scatter (OcNode::countRoughNormal, map2D.h:110-133)
+GNDT_HD void node_rough_normal(const double S[6], float& rough_out, float normal[3]) {
+    double lam, v[3];
+    min_eigenpair_sym3(S, lam, v);
+    double nx = v[0], ny = v[1], nz = v[2];
     // sign is unspecified in the reference (consumers fold the angle, map2D.h:477-482): point it up
     if (nz < 0.0 || (nz == 0.0 && (ny < 0.0 || (ny == 0.0 && nx < 0.0)))) { nx = -nx; ny = -ny; nz = -nz; }
-    float rough = (float)ev[j];
+    float rough = (float)lam;
     if (rough < 0.f) rough = 0.f;
     if (rough == 0.f) rough = 0.01f;   // map2D.h:131-132
-    r.rough = rough;
-    r.normal[0] = (float)nx; r.normal[1] = (float)ny; r.normal[2] = (float)nz;
+    rough_out = rough;
+    normal[0] = (float)nx; normal[1] = (float)ny; normal[2] = (float)nz;
+}
+
+GNDT_HD void finalize_node(uint32_t n, const double sums[9], const double centre[3], NodeResult& r) {
+    double S[6];
+    node_moments(n, sums, centre, r.mean, S);
+    for (int k = 0; k < 6; ++k) r.cov[k] = (float)S[k];
+    node_rough_normal(S, r.rough, r.normal);
 }
 
 // mean z as the reference stores it (fp32), used by the slope test

@@ -28,9 +28,8 @@
 namespace gndt {
 
 constexpr int kPartThreads = 512;    // k_part_hist / k_part_scatter
-constexpr int kBucketSlots = 1024;   // LDS node-table slots per bucket (H)
-constexpr int kBucketThreads = 512;
-constexpr int kBucketFill = 800;     // more distinct nodes than this in one bucket -> overflow
+// k_bucket_build is a template on <threads, LDS node-table slots>; a bucket holding more than
+// 0.78 * slots distinct nodes overflows (the host then re-runs on the atomic path).
 constexpr int kScanChunk = 8192;     // elements per block in the two-level scans
 constexpr int kScanThreads = 1024;
 
@@ -40,12 +39,13 @@ struct PartCounters {
     uint32_t pad[2];
 };
 
-struct alignas(16) StageRow {   // 128 bytes
+struct alignas(16) StageRow {   // 128 bytes = two 64-B lines, gathered whole by k_emit_rows
     int32_t sx, sy, sz;
     uint32_t count, first, flags;
-    float mean[3], cov[6], rough, normal[3];
     uint32_t col_first, idx_in_col, ncol;
-    uint32_t pad[10];
+    float mean[3];
+    double scatter[6];          // fp64: the eigen-solve runs in k_emit_rows (chip-wide parallelism)
+    uint32_t pad[8];
 };
 static_assert(sizeof(StageRow) == 128, "StageRow layout");
 
@@ -56,11 +56,15 @@ __host__ __device__ __forceinline__ uint32_t column_hash(int sx, int sy) {
     h ^= h >> 16;
     return h;
 }
+// bucket of a column: multiply-high range reduction, so the bucket count need not be a power of two
+__host__ __device__ __forceinline__ uint32_t bucket_of(uint32_t colh, uint32_t B) {
+    return (uint32_t)(((uint64_t)colh * (uint64_t)B) >> 32);
+}
 __device__ __forceinline__ uint32_t node_slot_hash(uint32_t colh, int sz) {
-    uint32_t g = colh ^ ((uint32_t)sz * 0xC2B2AE3Du);
-    g *= 0x27D4EB2Fu;
+    uint32_t g = (colh * 0x9E3779B1u) ^ ((uint32_t)sz * 0xC2B2AE3Du);
+    g ^= g >> 16; g *= 0x27D4EB2Fu;
     g ^= g >> 15;
-    return g >> 9;
+    return g;
 }
 
 // points of workgroup w: [w*chunk, min(n, (w+1)*chunk))
@@ -78,10 +82,9 @@ __device__ __forceinline__ void wg_range(uint64_t n, uint32_t nwg, uint32_t w, u
 // ---------------------------------------------------------------------------------------------
 template <int STRIDE_FLOATS>
 __global__ void __launch_bounds__(kPartThreads) k_part_hist(const float* __restrict__ xyz, uint64_t n, GridParams P,
-                                                            uint32_t bmask, uint32_t* __restrict__ hist,
+                                                            uint32_t B, uint32_t* __restrict__ hist,
                                                             Counters* __restrict__ cnt) {
     extern __shared__ uint32_t lh[];
-    const uint32_t B = bmask + 1;
     for (uint32_t i = threadIdx.x; i < B; i += kPartThreads) lh[i] = 0;
     __syncthreads();
     uint64_t lo, hi;
@@ -91,7 +94,7 @@ __global__ void __launch_bounds__(kPartThreads) k_part_hist(const float* __restr
         const float px = p[0], py = p[1], pz = p[2];
         PointKey k = point_key(px, py, pz, P.ox, P.oy, P.oz, P.grid_len, P.z_len);
         if (!k.ok) { atomicAdd(&cnt->err_key_range, 1u); continue; }
-        atomicAdd(&lh[column_hash(k.sx, k.sy) & bmask], 1u);
+        atomicAdd(&lh[bucket_of(column_hash(k.sx, k.sy), B)], 1u);
     }
     __syncthreads();
     uint32_t* out = hist + (uint64_t)blockIdx.x * B;
@@ -157,14 +160,13 @@ __device__ __forceinline__ void block_scan_totals(const uint32_t* __restrict__ t
 // ---------------------------------------------------------------------------------------------
 template <int STRIDE_FLOATS>
 __global__ void __launch_bounds__(kPartThreads) k_part_scatter(const float* __restrict__ xyz, uint64_t n, uint32_t first_base,
-                                                               GridParams P, uint32_t bmask,
+                                                               GridParams P, uint32_t B,
                                                                const uint32_t* __restrict__ hist,
                                                                const uint32_t* __restrict__ totals,
                                                                uint32_t* __restrict__ bucket_base,
                                                                float4* __restrict__ recs) {
     extern __shared__ uint32_t cur[];
     __shared__ uint32_t wave_sums[kPartThreads / 64];
-    const uint32_t B = bmask + 1;
     block_scan_totals(totals, B, cur, wave_sums);
     if (blockIdx.x == 0) {
         for (uint32_t i = threadIdx.x; i < B; i += kPartThreads) bucket_base[i] = cur[i];
@@ -180,7 +182,7 @@ __global__ void __launch_bounds__(kPartThreads) k_part_scatter(const float* __re
         const float px = p[0], py = p[1], pz = p[2];
         PointKey k = point_key(px, py, pz, P.ox, P.oy, P.oz, P.grid_len, P.z_len);
         if (!k.ok) continue;
-        const uint32_t pos = atomicAdd(&cur[column_hash(k.sx, k.sy) & bmask], 1u);
+        const uint32_t pos = atomicAdd(&cur[bucket_of(column_hash(k.sx, k.sy), B)], 1u);
         recs[pos] = make_float4(px, py, pz, __uint_as_float(first_base + (uint32_t)i));
     }
 }
@@ -188,6 +190,7 @@ __global__ void __launch_bounds__(kPartThreads) k_part_scatter(const float* __re
 // ---------------------------------------------------------------------------------------------
 // pass 3: one workgroup per bucket
 // ---------------------------------------------------------------------------------------------
+template <int kBucketSlots>
 struct BucketLds {
     unsigned long long key[kBucketSlots];
     double sum[9][kBucketSlots];
@@ -203,15 +206,18 @@ struct BucketLds {
     uint32_t n_nodes, n_list, stage_base, overflow;
 };
 
-__device__ __forceinline__ uint32_t lds_find_or_insert(volatile unsigned long long* keys, uint32_t start, uint64_t key,
-                                                       uint32_t* n_new) {
+// LDS open-addressing helpers.  They take the __shared__ arrays by reference to their element type's
+// address space (template on the array) so that the compiler keeps ds_* instructions; a generic
+// `volatile T*` parameter makes it fall back to flat_* loads.  A stale non-empty key cannot exist (keys
+// are written once), and a stale EMPTY is settled by the compare-and-swap.
+template <int kBucketSlots, typename KeyArray>
+__device__ __forceinline__ uint32_t lds_find_or_insert(KeyArray& keys, uint32_t start, uint64_t key, uint32_t* n_new) {
     uint32_t slot = start & (kBucketSlots - 1);
     for (int probe = 0; probe < kBucketSlots; ++probe) {
-        unsigned long long k = keys[slot];
+        const unsigned long long k = keys[slot];
         if (k == key) return slot;
         if (k == kEmptyKey) {
-            unsigned long long old = atomicCAS((unsigned long long*)&keys[slot], (unsigned long long)kEmptyKey,
-                                               (unsigned long long)key);
+            const unsigned long long old = atomicCAS(&keys[slot], (unsigned long long)kEmptyKey, (unsigned long long)key);
             if (old == kEmptyKey) { if (n_new) atomicAdd(n_new, 1u); return slot; }
             if (old == key) return slot;
         }
@@ -219,10 +225,11 @@ __device__ __forceinline__ uint32_t lds_find_or_insert(volatile unsigned long lo
     }
     return kBucketSlots;
 }
-__device__ __forceinline__ uint32_t lds_find(const volatile unsigned long long* keys, uint32_t start, uint64_t key) {
+template <int kBucketSlots, typename KeyArray>
+__device__ __forceinline__ uint32_t lds_find(const KeyArray& keys, uint32_t start, uint64_t key) {
     uint32_t slot = start & (kBucketSlots - 1);
     for (int probe = 0; probe < kBucketSlots; ++probe) {
-        unsigned long long k = keys[slot];
+        const unsigned long long k = keys[slot];
         if (k == key) return slot;
         if (k == kEmptyKey) return kBucketSlots;
         slot = (slot + 1) & (kBucketSlots - 1);
@@ -230,15 +237,21 @@ __device__ __forceinline__ uint32_t lds_find(const volatile unsigned long long* 
     return kBucketSlots;
 }
 
+template <int kBucketThreads, int kBucketSlots>
 __global__ void __launch_bounds__(kBucketThreads) k_bucket_build(const float4* __restrict__ recs,
                                                                  const uint32_t* __restrict__ bucket_base, GridParams P,
                                                                  StageRow* __restrict__ stage, uint32_t stage_cap,
                                                                  uint32_t* __restrict__ ord_cf, uint32_t* __restrict__ ord_idx,
                                                                  uint32_t* __restrict__ ord_ncol, uint32_t* __restrict__ bitmap,
-                                                                 Counters* __restrict__ cnt, PartCounters* __restrict__ pc) {
-    __shared__ BucketLds L;
+                                                                 Counters* __restrict__ cnt, PartCounters* __restrict__ pc,
+                                                                 unsigned long long* __restrict__ dbg) {
+    __shared__ BucketLds<kBucketSlots> L;
+    constexpr int kBucketFill = (kBucketSlots * 25) / 32;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
+    // diagnostic phase stamps (shader clock), only when the host passes a buffer: [bucket][8]
+#define GNDT_STAMP(k) do { if (dbg && tid == 0) dbg[(size_t)blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+    GNDT_STAMP(0);
     // ---- P0: clear ----
     for (int s = tid; s < kBucketSlots; s += kBucketThreads) {
         L.key[s] = kEmptyKey;
@@ -247,19 +260,22 @@ __global__ void __launch_bounds__(kBucketThreads) k_bucket_build(const float4* _
         for (int j = 0; j < 9; ++j) L.sum[j][s] = 0.0;
         L.cnt[s] = 0; L.first[s] = 0xFFFFFFFFu;
         L.cfirst[s] = 0xFFFFFFFFu; L.ccnt[s] = 0;
-        L.okey[s] = ~0ull; L.oslot[s] = 0;
     }
     if (tid == 0) { L.n_nodes = 0; L.n_list = 0; L.stage_base = 0; L.overflow = 0; }
     __syncthreads();
 
+    GNDT_STAMP(1);
     // ---- P1: accumulate this bucket's records into the LDS table ----
     const uint32_t lo = bucket_base[blockIdx.x], hi = bucket_base[blockIdx.x + 1];
     const uint32_t span = hi - lo;
     const uint32_t span_round = (span + 63u) & ~63u;
+    // software pipeline: the next record is in flight while this one goes through the LDS atomics
+    float4 nxt = make_float4(0.f, 0.f, 0.f, 0.f);
+    if ((uint32_t)tid < span) nxt = recs[lo + tid];
     for (uint32_t off = tid; off < span_round; off += kBucketThreads) {
         const bool live = off < span;
-        float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (live) r = recs[lo + off];
+        const float4 r = nxt;
+        if (off + kBucketThreads < span) nxt = recs[lo + off + kBucketThreads];
         PointKey k = point_key(r.x, r.y, r.z, P.ox, P.oy, P.oz, P.grid_len, P.z_len);
         const uint64_t key = live ? pack_key(k.sx, k.sy, k.sz) : kEmptyKey;
         double v0 = 0, v1 = 0, v2 = 0;
@@ -279,7 +295,7 @@ __global__ void __launch_bounds__(kBucketThreads) k_bucket_build(const float4* _
             for (int j = 0; j < 9; ++j) q[j] = wave_sum(q[j]);
             for (int o = 32; o > 0; o >>= 1) pidx = min(pidx, (uint32_t)__shfl_down((int)pidx, o, 64));
             if (lane == 0) {
-                const uint32_t s = lds_find_or_insert(L.key, h, key, &L.n_nodes);
+                const uint32_t s = lds_find_or_insert<kBucketSlots>(L.key, h, key, &L.n_nodes);
                 if (s >= kBucketSlots) L.overflow = 1;
                 else {
 #pragma unroll
@@ -289,7 +305,7 @@ __global__ void __launch_bounds__(kBucketThreads) k_bucket_build(const float4* _
                 }
             }
         } else if (live) {
-            const uint32_t s = lds_find_or_insert(L.key, h, key, &L.n_nodes);
+            const uint32_t s = lds_find_or_insert<kBucketSlots>(L.key, h, key, &L.n_nodes);
             if (s >= kBucketSlots) L.overflow = 1;
             else {
 #pragma unroll
@@ -305,6 +321,11 @@ __global__ void __launch_bounds__(kBucketThreads) k_bucket_build(const float4* _
         return;
     }
 
+    GNDT_STAMP(2);
+    // Reserve this bucket's staging rows now (one memory-side atomic per bucket): its ~microsecond round trip
+    // hides behind P2..P4; the value is only parked in LDS right before the barrier that precedes its use.
+    uint32_t stage_base_reg = 0;
+    if (tid == kBucketThreads - 1) stage_base_reg = atomicAdd(&cnt->num_nodes, L.n_nodes);
     // ---- P2: per node: fp32 mean-z for the slope test, column registration ----
     for (int s = tid; s < kBucketSlots; s += kBucketThreads) {
         const uint64_t key = L.key[s];
@@ -319,7 +340,7 @@ __global__ void __launch_bounds__(kBucketThreads) k_bucket_build(const float4* _
             fl = 1u;
         }
         L.mean_z[s] = mz;
-        const uint32_t cs = lds_find_or_insert(L.ckey, column_hash(sx, sy) >> 16, column_key(key), nullptr);
+        const uint32_t cs = lds_find_or_insert<kBucketSlots>(L.ckey, column_hash(sx, sy) * 0x85EBCA77u >> 12, column_key(key), nullptr);
         // the column table has as many slots as the node table and at most as many entries: never full
         atomicMin(&L.cfirst[cs], L.first[s]);
         atomicAdd(&L.ccnt[cs], 1u);
@@ -327,6 +348,7 @@ __global__ void __launch_bounds__(kBucketThreads) k_bucket_build(const float4* _
     }
     __syncthreads();
 
+    GNDT_STAMP(3);
     // ---- P3: slope labels (OcNode::isSlope, map2D.h:66-108) + sort list ----
     uint32_t my_slopes = 0;
     for (int s = tid; s < kBucketSlots; s += kBucketThreads) {
@@ -344,13 +366,13 @@ __global__ void __launch_bounds__(kBucketThreads) k_bucket_build(const float4* _
                 const float cz = L.mean_z[s];
                 bool up = false;
                 int za = level_above(sz), zb = level_below(sz);
-                uint32_t t = lds_find(L.key, node_slot_hash(ch, za), pack_key(sx, sy, za));
+                uint32_t t = lds_find<kBucketSlots>(L.key, node_slot_hash(ch, za), pack_key(sx, sy, za));
                 if (t < kBucketSlots) {
                     const bool visited = L.first[t] < my_first && (L.flags[t] & 1u);
                     const float oz = visited ? L.mean_z[t] : 0.f;
                     if (fabsf(oz - cz) > P.slope_interval) up = true;
                 }
-                t = lds_find(L.key, node_slot_hash(ch, zb), pack_key(sx, sy, zb));
+                t = lds_find<kBucketSlots>(L.key, node_slot_hash(ch, zb), pack_key(sx, sy, zb));
                 if (t < kBucketSlots) {
                     const bool visited = L.first[t] < my_first && (L.flags[t] & 1u);
                     const float oz = visited ? L.mean_z[t] : 0.f;
@@ -367,77 +389,81 @@ __global__ void __launch_bounds__(kBucketThreads) k_bucket_build(const float4* _
     __syncthreads();
     // NOTE: L.flags of OTHER slots is read above (bit 0 only) while this loop rewrites nothing in it.
 
-    // ---- P4: bitonic sort of the list by (column first-seen, node first-seen) ----
-    const uint32_t M = L.n_list;
-    uint32_t Mp = 64;
-    while (Mp < M) Mp <<= 1;
-    for (uint32_t k2 = 2; k2 <= Mp; k2 <<= 1) {
-        for (uint32_t j = k2 >> 1; j > 0; j >>= 1) {
-            for (uint32_t t = tid; t < Mp / 2; t += kBucketThreads) {
-                const uint32_t i = ((t / j) * 2 * j) + (t % j);
-                const uint32_t l = i + j;
-                const bool asc = ((i & k2) == 0);
-                const unsigned long long a = L.okey[i], b = L.okey[l];
-                if ((a > b) == asc) {
-                    L.okey[i] = b; L.okey[l] = a;
-                    const uint32_t sa = L.oslot[i]; L.oslot[i] = L.oslot[l]; L.oslot[l] = sa;
-                }
+    GNDT_STAMP(4);
+    // ---- P4: reserve the staging rows (one memory-side atomic per bucket, issued early so that its
+    //          round trip hides behind the ranking loop) ----
+    const uint32_t M = L.n_list;          // == L.n_nodes: every occupied slot is listed
+
+    // ---- P5: rank by counting instead of sorting.  Keys (column first-seen, node first-seen) are
+    //          unique, so   rank = #{keys below mine}   is the node's row in in-bucket reference order and
+    //          idx_in_col = #{keys below mine in my column}.  Every lane reads the same okey[j]: LDS broadcast.
+    uint32_t my_cols = 0;
+    uint32_t rank[(kBucketSlots + kBucketThreads - 1) / kBucketThreads];
+    uint32_t icol[(kBucketSlots + kBucketThreads - 1) / kBucketThreads];
+    {
+        int it = 0;
+        for (uint32_t i = tid; i < M; i += kBucketThreads, ++it) {
+            const unsigned long long mine = L.okey[i];
+            const uint32_t cf = (uint32_t)(mine >> 32);
+            uint32_t r = 0, c = 0;
+#pragma unroll 8
+            for (uint32_t j = 0; j < M; ++j) {
+                const unsigned long long o = L.okey[j];
+                const bool below = o < mine;
+                r += below ? 1u : 0u;
+                c += (below && (uint32_t)(o >> 32) == cf) ? 1u : 0u;
             }
-            __syncthreads();
+            rank[it] = r; icol[it] = c;
         }
     }
-    if (tid == 0) {
-        const uint32_t base = atomicAdd(&cnt->num_nodes, M);
-        L.stage_base = base;
-    }
+    if (tid == kBucketThreads - 1) L.stage_base = stage_base_reg;
     __syncthreads();
+    GNDT_STAMP(5);
     const uint32_t base = L.stage_base;
     if (base + M > stage_cap) {               // uniform
         if (tid == 0) atomicAdd(&pc->stage_overflow, M);
         return;
     }
-
-    // ---- P5: finalise and write the staging rows in in-bucket reference order ----
-    uint32_t my_cols = 0;
-    for (uint32_t i = tid; i < M; i += kBucketThreads) {
-        const uint32_t packed = L.oslot[i];
-        const uint32_t s = packed & 0xFFFFu, fl = (packed >> 16) & 7u;
-        const uint64_t key = L.key[s];
-        const uint32_t cf = (uint32_t)(L.okey[i] >> 32);
-        uint32_t idx_in_col = 0;
-        while (idx_in_col < i && (uint32_t)(L.okey[i - idx_in_col - 1] >> 32) == cf) ++idx_in_col;
-        const uint32_t cs = L.flags[s] >> 8;
-        StageRow row;
-        unpack_key(key, row.sx, row.sy, row.sz);
-        row.count = L.cnt[s]; row.first = L.first[s]; row.flags = fl;
-        NodeResult res;
-        for (int k = 0; k < 3; ++k) { res.mean[k] = 0.f; res.normal[k] = 0.f; }
-        for (int k = 0; k < 6; ++k) res.cov[k] = 0.f;
-        res.rough = 0.f;
-        if (fl & 1u) {
-            double sums[9];
+    {
+        int it = 0;
+        for (uint32_t i = tid; i < M; i += kBucketThreads, ++it) {
+            const uint32_t packed = L.oslot[i];
+            const uint32_t s = packed & 0xFFFFu, fl = (packed >> 16) & 7u;
+            const uint64_t key = L.key[s];
+            const uint32_t cf = (uint32_t)(L.okey[i] >> 32);
+            const uint32_t idx_in_col = icol[it];
+            const uint32_t cs = L.flags[s] >> 8;
+            StageRow row;
+            unpack_key(key, row.sx, row.sy, row.sz);
+            row.count = L.cnt[s]; row.first = L.first[s]; row.flags = fl;
+            for (int k = 0; k < 3; ++k) row.mean[k] = 0.f;
+            for (int k = 0; k < 6; ++k) row.scatter[k] = 0.0;
+            if (fl & 1u) {
+                double sums[9];
 #pragma unroll
-            for (int j = 0; j < 9; ++j) sums[j] = L.sum[j][s];
-            const double c[3] = {axis_centre(row.sx, P.ox, P.grid_len), axis_centre(row.sy, P.oy, P.grid_len),
-                                 axis_centre(row.sz, P.oz, P.z_len)};
-            finalize_node(row.count, sums, c, res);
-        }
-        for (int k = 0; k < 3; ++k) { row.mean[k] = res.mean[k]; row.normal[k] = res.normal[k]; }
-        for (int k = 0; k < 6; ++k) row.cov[k] = res.cov[k];
-        row.rough = res.rough;
-        row.col_first = cf; row.idx_in_col = idx_in_col; row.ncol = L.ccnt[cs];
-        for (int k = 0; k < 10; ++k) row.pad[k] = 0;
-        stage[base + i] = row;
-        ord_cf[base + i] = cf;
-        ord_idx[base + i] = idx_in_col;
-        if (idx_in_col == 0) {
-            ord_ncol[base + i] = row.ncol;
-            atomicOr(&bitmap[cf >> 5], 1u << (cf & 31u));
-            ++my_cols;
+                for (int j = 0; j < 9; ++j) sums[j] = L.sum[j][s];
+                const double c[3] = {axis_centre(row.sx, P.ox, P.grid_len), axis_centre(row.sy, P.oy, P.grid_len),
+                                     axis_centre(row.sz, P.oz, P.z_len)};
+                node_moments(row.count, sums, c, row.mean, row.scatter);
+            }
+            row.col_first = cf; row.idx_in_col = idx_in_col; row.ncol = L.ccnt[cs];
+            for (int k = 0; k < 8; ++k) row.pad[k] = 0;
+            const uint32_t dst = base + rank[it];
+            stage[dst] = row;
+            ord_cf[dst] = cf;
+            ord_idx[dst] = idx_in_col;
+            if (idx_in_col == 0) {
+                ord_ncol[dst] = row.ncol;
+                atomicOr(&bitmap[cf >> 5], 1u << (cf & 31u));
+                ++my_cols;
+            }
         }
     }
     if (my_slopes) atomicAdd(&cnt->num_slopes, my_slopes);
     if (my_cols) atomicAdd(&cnt->num_columns, my_cols);
+    __syncthreads();
+    GNDT_STAMP(6);
+#undef GNDT_STAMP
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -554,9 +580,11 @@ __global__ void __launch_bounds__(kBlock) k_emit_rows(const StageRow* __restrict
         const StageRow row = stage[inv[r]];
         out.sx[r] = row.sx; out.sy[r] = row.sy; out.sz[r] = row.sz;
         out.count[r] = row.count; out.first_idx[r] = row.first; out.flags[r] = row.flags;
-        for (int k = 0; k < 3; ++k) { out.mean[3 * r + k] = row.mean[k]; out.normal[3 * r + k] = row.normal[k]; }
-        for (int k = 0; k < 6; ++k) out.cov[6 * r + k] = row.cov[k];
-        out.rough[r] = row.rough;
+        float rough = 0.f, normal[3] = {0.f, 0.f, 0.f};
+        if (row.flags & 1u) node_rough_normal(row.scatter, rough, normal);
+        for (int k = 0; k < 3; ++k) { out.mean[3 * r + k] = row.mean[k]; out.normal[3 * r + k] = normal[k]; }
+        for (int k = 0; k < 6; ++k) out.cov[6 * r + k] = (float)row.scatter[k];
+        out.rough[r] = rough;
     }
 }
 

@@ -219,6 +219,13 @@ class TwoDmap:
         names = self.PHASES[self.last_strategy()]
         return {k: arr[i] for i, k in enumerate(names)}
 
+    def debug_bucket_phases(self):
+        """Mean shader cycles per bucket of k_bucket_build's phases (needs GNDT_STAMPS=1 in the environment)."""
+        arr = (C.c_double * 6)()
+        nb = C.c_uint32()
+        self._check(self._L.gndt_debug_bucket_phases(self._h, arr, C.byref(nb)))
+        return dict(zip(("clear", "accumulate", "columns", "labels", "sort", "emit"), list(arr))), nb.value
+
     # ---- results ----
     def sync(self):
         n, k, s = C.c_uint64(), C.c_uint64(), C.c_uint64()

@@ -36,3 +36,13 @@ float shim_mean_z(uint32_t n, double sum_vz, double cz) { return gndt::node_mean
 int shim_level_above(int z) { return gndt::level_above(z); }
 int shim_level_below(int z) { return gndt::level_below(z); }
 }
+extern "C" void shim_min_eigen(const double* S, uint64_t n, double* lam, double* vec) {
+    for (uint64_t i = 0; i < n; ++i) gndt::min_eigenpair_sym3(S + 6 * i, lam[i], vec + 3 * i);
+}
+extern "C" void shim_jacobi(const double* S, uint64_t n, double* evals, double* evecs) {
+    for (uint64_t i = 0; i < n; ++i) {
+        double ev[3], vv[3][3];
+        gndt::eigen_sym3(S + 6 * i, ev, vv);
+        for (int k = 0; k < 3; ++k) { evals[3 * i + k] = ev[k]; for (int j = 0; j < 3; ++j) evecs[9 * i + 3 * k + j] = vv[k][j]; }
+    }
+}

@@ -1,0 +1,98 @@
+"""CPU tier: the fast minimum-eigenpair routine the kernels use (gndt_math.hpp: min_eigenpair_sym3)
+against numpy.linalg.eigh on scatter matrices of every shape the path meets."""
+import ctypes as C
+
+import numpy as np
+
+from tests import host_emulation as he
+
+
+def _solve(S):
+    S = np.ascontiguousarray(S, np.float64)
+    n = S.shape[0]
+    lam = np.zeros(n)
+    vec = np.zeros((n, 3))
+    he.shim().shim_min_eigen(C.c_void_p(S.ctypes.data), C.c_uint64(n), C.c_void_p(lam.ctypes.data), C.c_void_p(vec.ctypes.data))
+    return lam, vec
+
+
+def _mats(S):
+    return np.stack([np.stack([S[:, 0], S[:, 1], S[:, 2]], 1), np.stack([S[:, 1], S[:, 3], S[:, 4]], 1),
+                     np.stack([S[:, 2], S[:, 4], S[:, 5]], 1)], 1)
+
+
+def _scatter(points):
+    d = points - points.mean(1, keepdims=True)
+    M = np.einsum("nki,nkj->nij", d, d)
+    return np.stack([M[:, 0, 0], M[:, 0, 1], M[:, 0, 2], M[:, 1, 1], M[:, 1, 2], M[:, 2, 2]], 1)
+
+
+def _check(S, name):
+    lam, vec = _solve(S)
+    w, V = np.linalg.eigh(_mats(S))
+    tr = np.maximum(w.sum(1), 1e-300)
+    err = np.abs(lam - w[:, 0]) / tr
+    assert np.all(np.isfinite(lam)) and np.all(np.isfinite(vec)), name
+    assert err.max() <= 2e-6, (name, err.max(), S[err.argmax()])
+    nrm = np.linalg.norm(vec, axis=1)
+    assert np.allclose(nrm, 1.0, atol=1e-12), name
+    sep = (w[:, 1] - w[:, 0]) > 1e-3 * w[:, 2]
+    if sep.any():
+        cosv = np.abs((vec[sep] * V[sep][:, :, 0]).sum(1))
+        assert (1 - cosv).max() <= 1e-9, (name, (1 - cosv).max())
+    # whatever the clustering, the vector must be a (near) eigenvector: |S v - lam v| small
+    r = np.einsum("nij,nj->ni", _mats(S), vec) - lam[:, None] * vec
+    scale = np.maximum(np.abs(S).max(1), 1e-300)
+    assert (np.linalg.norm(r, axis=1) / scale).max() <= 1e-5, (name, (np.linalg.norm(r, axis=1) / scale).max())
+
+
+def test_random_voxel_scatters():
+    rng = np.random.default_rng(0)
+    for npts in (3, 4, 8, 16, 200):
+        _check(_scatter(rng.uniform(-0.25, 0.25, (4000, npts, 3))), f"uniform{npts}")
+
+
+def test_flat_and_linear_cells():
+    rng = np.random.default_rng(1)
+    p = rng.uniform(-0.25, 0.25, (4000, 30, 3))
+    for thick in (1e-1, 1e-2, 1e-4, 1e-7, 0.0):
+        q = p.copy()
+        q[:, :, 2] *= thick                      # ground patches: lambda_min << lambda_max
+        _check(_scatter(q), f"flat{thick}")
+        # tilted planes
+        R = np.linalg.qr(rng.normal(size=(4000, 3, 3)))[0]
+        _check(_scatter(np.einsum("nij,nkj->nki", R, q)), f"tilted{thick}")
+    line = p.copy()
+    line[:, :, 1:] *= 1e-9                       # rank 1: two (near-)zero eigenvalues
+    _check(_scatter(line), "line")
+    line[:, :, 1:] = 0
+    _check(_scatter(line), "exact_line")
+
+
+def test_degenerate_and_scaled():
+    S = np.zeros((6, 6))
+    S[1] = [2, 0, 0, 2, 0, 2]                    # isotropic
+    S[2] = [3, 0, 0, 2, 0, 1]                    # diagonal
+    S[3] = [1, 0, 0, 1, 0, 0]                    # plane z = const (bridge_ground's ground)
+    S[4] = [0, 0, 0, 0, 0, 5]                    # vertical line
+    S[5] = [1, 1, 1, 1, 1, 1]                    # rank one, oblique
+    lam, vec = _solve(S)
+    assert lam[0] == 0 and tuple(vec[0]) == (0, 0, 1)      # identical points
+    assert abs(lam[1] - 2) < 1e-5 and abs(lam[2] - 1) < 1e-12 and abs(abs(vec[2][2]) - 1) < 1e-12
+    assert abs(lam[3]) < 1e-12 and abs(abs(vec[3][2]) - 1) < 1e-12
+    assert abs(lam[4]) < 5e-12 and abs(vec[4][2]) < 1e-6
+    assert abs(lam[5]) < 5e-12 and abs(vec[5].sum()) < 1e-5
+    rng = np.random.default_rng(2)
+    base = _scatter(rng.uniform(-1, 1, (2000, 10, 3)))
+    for scale in (1e-18, 1e-6, 1e6, 1e18):
+        _check(base * scale, f"scale{scale}")
+
+
+def test_matches_in_repo_jacobi():
+    rng = np.random.default_rng(3)
+    S = _scatter(rng.uniform(-0.1, 0.1, (3000, 12, 3)) * np.array([1.0, 0.6, 0.05]))
+    lam, _ = _solve(S)
+    ev = np.zeros((S.shape[0], 3))
+    vv = np.zeros((S.shape[0], 9))
+    he.shim().shim_jacobi(C.c_void_p(S.ctypes.data), C.c_uint64(S.shape[0]), C.c_void_p(ev.ctypes.data), C.c_void_p(vv.ctypes.data))
+    assert np.abs(lam - ev.min(1)).max() <= 1e-9 * np.abs(ev).max()

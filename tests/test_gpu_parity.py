@@ -266,7 +266,9 @@ def test_full_size_properties_10M():
         assert np.abs(out["cov"][i] - ref_ut).max() <= 1e-5 * np.abs(ref_ut).max()
         assert np.abs(out["mean"][i] - mu).max() <= 1e-5 * max(1.0, np.abs(mu).max())
         ev = np.linalg.eigvalsh(S)
-        assert abs(out["rough"][i] - ev[0]) <= 1e-5 * np.trace(S)
+        # 3-point nodes are exactly coplanar: lambda_min = 0 reads 0.01 (map2D.h:131-132)
+        lam = 0.0 if (out["rough"][i] == np.float32(0.01) and ev[0] < 1e-3) else out["rough"][i]
+        assert abs(lam - ev[0]) <= 1e-5 * np.trace(S)
 
 
 def test_single_hip_runtime_and_foreign_stream():
