@@ -134,6 +134,7 @@ def main():
 
     if rank == 0:
         ms_step = dt / a.steps * 1e3
+        default_workload = (n == 10_000_000 and a.grid_len == 0.5 and a.z_len == 0.5 and world == 1)
         total_points = n * world
         value = total_points / (dt / a.steps) / 1e6
         phases = {k: round(v / a.steps, 4) for k, v in phase_sum.items()}
@@ -154,6 +155,15 @@ def main():
         else:
             alg_bytes = BYTES_PER_NODE * nodes
         achieved = alg_bytes / (acc_ms * 1e-3) / 1e9 if acc_ms == acc_ms and acc_ms > 0 else None
+        # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process, so the
+        # figure is the one the committed rocprofv3 --pmc passes of THIS workload measured (profiles/),
+        # corrected as MI355X_MICROARCH.md prescribes; null for any other workload.
+        traffic = None
+        pmc_path = os.path.join(ROOT, "profiles", "r01_b_partition_pmc.json")
+        if default_workload and os.path.exists(pmc_path):
+            for name, rec in json.load(open(pmc_path))["kernels"].items():
+                if kernel_of.get(dom) and kernel_of[dom] in name:
+                    traffic = rec["hbm_bytes_corrected"]
         path_bytes = BYTES_PER_POINT * n + BYTES_PER_NODE * nodes
         out = {
             "metric": "NDT grid-build throughput (bin + mean/cov + eigen + labels + ordering)",
@@ -167,7 +177,8 @@ def main():
                        "multi_gpu_mode": a.mode if world > 1 else "single", "strategy": strat},
             "roofline": {"bound": "hbm", "kernel": kernel_of.get(dom),
                          "achieved": round(achieved, 2) if achieved else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5) if achieved else None, "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 5) if achieved else None, "traffic": traffic,
+                         "traffic_source": "profiles/r01_b_partition_pmc.json (rocprofv3 --pmc, separate passes)" if traffic else None,
                          "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": acc_ms},
             "path_roofline": {"bytes": path_bytes, "achieved_GBps": round(path_bytes / (ms_step * 1e-3) / 1e9, 2),
                               "frac": round(path_bytes / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},

@@ -294,3 +294,27 @@ def test_single_hip_runtime_and_foreign_stream():
     views = m.export_device()
     torch.cuda.synchronize()
     assert int(views["count"].sum().item()) == cloud.shape[0] - 1
+
+
+def test_global_map_exchange_on_rccl_single_rank():
+    """grid_ndt_amd/dist.py end to end on the GPU (backend nccl = RCCL, world_size 1): accumulate ->
+    stats export -> all_gather / all_reduce -> merge -> finalize must equal the plain build."""
+    import os
+    import torch
+    import torch.distributed as dist
+    import grid_ndt_amd as g
+    from grid_ndt_amd.dist import build_global_map
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29651")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    try:
+        cloud = scenes.terrain_cloud(200000)
+        ref = parity.ref_from_cloud(cloud, TERRAIN)
+        m = g.TwoDmap(TERRAIN["grid_len"], TERRAIN["z_len"])
+        m.setInterval(TERRAIN["slope_interval"])
+        m.setCloudFirst(cloud[0])
+        pts = torch.from_numpy(cloud[1:]).cuda()
+        build_global_map(m, "slope", pts, 0)
+        parity.assert_parity(m.export(), ref)
+    finally:
+        dist.destroy_process_group()
