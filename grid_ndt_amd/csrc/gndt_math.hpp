@@ -218,10 +218,16 @@ GNDT_HD void node_moments(uint32_t n, const double sums[9], const double centre[
     S[3] = sums[6] - sums[1] * m[1];
     S[4] = sums[7] - sums[1] * m[2];
     S[5] = sums[8] - sums[2] * m[2];
-    // a scatter matrix is positive semi-definite; cancellation can leave a diagonal at -1e-17
-    if (S[0] < 0.0) S[0] = 0.0;
-    if (S[3] < 0.0) S[3] = 0.0;
-    if (S[5] < 0.0) S[5] = 0.0;
+    // Noise floor.  S_kk = Sum v_k^2 - (Sum v_k)^2 / n is a difference of two fp64 sums of n terms, each
+    // carrying up to ~n * 2^-53 relative rounding.  A diagonal at or below that floor means the node has no
+    // extent along k at working precision (the reference's (0,0,0) padding: tens of thousands of identical
+    // points): it is exactly zero, and so are its off-diagonals (|S_jk| <= sqrt(S_jj S_kk)).  This also
+    // keeps the matrix positive semi-definite.
+    const double floor_rel = 2.0 * (double)n * 1.1102230246251565e-16;
+    const bool z0 = S[0] <= floor_rel * sums[3], z1 = S[3] <= floor_rel * sums[6], z2 = S[5] <= floor_rel * sums[8];
+    if (z0) { S[0] = 0.0; S[1] = 0.0; S[2] = 0.0; }
+    if (z1) { S[3] = 0.0; S[1] = 0.0; S[4] = 0.0; }
+    if (z2) { S[5] = 0.0; S[2] = 0.0; S[4] = 0.0; }
     for (int k = 0; k < 3; ++k) mean[k] = (float)(centre[k] + m[k]);
 }
 
