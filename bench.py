@@ -159,7 +159,7 @@ def main():
         # figure is the one the committed rocprofv3 --pmc passes of THIS workload measured (profiles/),
         # corrected as MI355X_MICROARCH.md prescribes; null for any other workload.
         traffic = None
-        pmc_path = os.path.join(ROOT, "profiles", "r01_b_partition_pmc.json")
+        pmc_path = os.path.join(ROOT, "profiles", "r01_c_partition_v2_pmc.json")
         if default_workload and os.path.exists(pmc_path):
             for name, rec in json.load(open(pmc_path))["kernels"].items():
                 if kernel_of.get(dom) and kernel_of[dom] in name:
@@ -178,7 +178,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": kernel_of.get(dom),
                          "achieved": round(achieved, 2) if achieved else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5) if achieved else None, "traffic": traffic,
-                         "traffic_source": "profiles/r01_b_partition_pmc.json (rocprofv3 --pmc, separate passes)" if traffic else None,
+                         "traffic_source": "profiles/r01_c_partition_v2_pmc.json (rocprofv3 --pmc, separate passes)" if traffic else None,
                          "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": acc_ms},
             "path_roofline": {"bytes": path_bytes, "achieved_GBps": round(path_bytes / (ms_step * 1e-3) / 1e9, 2),
                               "frac": round(path_bytes / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
@@ -198,7 +198,7 @@ def main():
             os.environ["GNDT_STAMPS"] = "1"
             m.create2DMap("slope", pts, stream)
             cyc, nb = m.debug_bucket_phases()
-            tot = sum(cyc.values())
+            tot = sum(list(cyc.values())[:6])
             print("k_bucket_build phase stamps (mean shader cycles per bucket, %d buckets): " % nb +
                   ", ".join(f"{k}={v:.0f} ({100 * v / tot:.0f}%)" for k, v in cyc.items()), file=sys.stderr)
         print(json.dumps(out))

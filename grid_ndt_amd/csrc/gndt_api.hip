@@ -16,6 +16,7 @@
 #include "gndt.h"
 #include "gndt_kernels.hpp"
 #include "gndt_partition.hpp"
+#include "gndt_bucket.hpp"
 
 using namespace gndt;
 
@@ -407,8 +408,8 @@ int ensure_stage(gndt_handle* h, uint64_t nodes) {
 // (average load <= 0.3 of `slots`, which leaves room for the spread of a hash partition).
 uint32_t choose_buckets(const gndt_handle* h, uint64_t n, int slots) {
     const uint64_t nodes = h->P.max_nodes_hint ? h->P.max_nodes_hint : n / 4;
-    uint64_t want = std::max<uint64_t>(n / 4096, (nodes * 10) / (uint64_t)(slots * 3));
-    want = std::min<uint64_t>(std::max<uint64_t>(want, 16), 16384);
+    uint64_t want = std::max<uint64_t>(n / (4 * (uint64_t)slots), (nodes * 10) / (uint64_t)(slots * 3));
+    want = std::min<uint64_t>(std::max<uint64_t>(want, 16), 32768);
     return (uint32_t)want;
 }
 
@@ -418,9 +419,10 @@ int build_partition(gndt_handle* h, const void* xyz_dev, size_t n, size_t stride
     if (stride_bytes != 12 && stride_bytes != 16) { h->err = "stride_bytes must be 12 or 16"; return GNDT_ERR_INVALID; }
     if (n >= 0xFFFFFFFFull) { h->err = "point index exceeds 32 bits"; return GNDT_ERR_INVALID; }
     static const int bt = getenv("GNDT_BUCKET_THREADS") ? atoi(getenv("GNDT_BUCKET_THREADS")) : 512;
-    static const int bslots = getenv("GNDT_BUCKET_SLOTS") ? atoi(getenv("GNDT_BUCKET_SLOTS")) : 1024;
+    static const int bslots = getenv("GNDT_BUCKET_SLOTS") ? atoi(getenv("GNDT_BUCKET_SLOTS")) : 512;
     const uint32_t B = choose_buckets(h, n, bslots);
-    const uint32_t nwg = (uint32_t)std::min<uint64_t>(1024, std::max<uint64_t>(1, n / 8192));
+    static const int part_wgs = getenv("GNDT_PART_WGS") ? atoi(getenv("GNDT_PART_WGS")) : 256;
+    const uint32_t nwg = (uint32_t)std::min<uint64_t>((uint64_t)part_wgs, std::max<uint64_t>(1, n / 8192));
     const uint64_t words = (n + 31) / 32 + 1;
     int rc;
     if ((rc = grow_buf(h, q.recs, q.rec_cap, n))) return rc;
@@ -459,6 +461,12 @@ int build_partition(gndt_handle* h, const void* xyz_dev, size_t n, size_t stride
         HIP_TRY(h, hipMemsetAsync(q.d_pc, 0, sizeof(PartCounters), s));
         mark(h, 1, s);
         const size_t lds = (size_t)B * 4;
+        if (lds > 48 * 1024) {   // beyond the default dynamic-LDS limit the kernels must be told (gfx950: 160 KiB/CU)
+            HIP_TRY(h, hipFuncSetAttribute((const void*)k_part_hist<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            HIP_TRY(h, hipFuncSetAttribute((const void*)k_part_hist<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            HIP_TRY(h, hipFuncSetAttribute((const void*)k_part_scatter<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            HIP_TRY(h, hipFuncSetAttribute((const void*)k_part_scatter<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        }
         if (stride_bytes == 12)
             hipLaunchKernelGGL(k_part_hist<3>, dim3(nwg), dim3(kPartThreads), lds, s, p, (uint64_t)n, gp, B, q.hist, h->d_cnt);
         else
@@ -479,7 +487,8 @@ int build_partition(gndt_handle* h, const void* xyz_dev, size_t n, size_t stride
         if (getenv("GNDT_STAMPS") && q.dbg_buckets < B) {
             if (q.dbg) (void)hipFree(q.dbg);
             q.dbg = nullptr; q.dbg_buckets = 0;
-            HIP_TRY(h, hipMalloc(&q.dbg, (size_t)B * 8 * sizeof(unsigned long long)));
+            HIP_TRY(h, hipMalloc(&q.dbg, (size_t)B * 16 * sizeof(unsigned long long)));
+            HIP_TRY(h, hipMemset(q.dbg, 0, (size_t)B * 16 * sizeof(unsigned long long)));
             q.dbg_buckets = B;
         }
         q.last_buckets = B;
@@ -487,7 +496,17 @@ int build_partition(gndt_handle* h, const void* xyz_dev, size_t n, size_t stride
 #define GNDT_LAUNCH_BUCKET(T_, H_)                                                                                     \
     hipLaunchKernelGGL((k_bucket_build<T_, H_>), dim3(B), dim3(T_), 0, s, q.recs, q.bucket_base, gp, q.stage,          \
                        (uint32_t)q.stage_cap, q.ord_cf, q.ord_idx, q.ord_ncol, q.bitmap, h->d_cnt, q.d_pc, q.dbg)
-            if (bslots == 1024 && bt == 1024) GNDT_LAUNCH_BUCKET(1024, 1024);
+            static const int bv = getenv("GNDT_BUCKET_V") ? atoi(getenv("GNDT_BUCKET_V")) : 2;
+#define GNDT_LAUNCH_BUCKET2(T_, H_, CH_)                                                                               \
+    hipLaunchKernelGGL((k_bucket_build2<T_, H_, CH_>), dim3(B), dim3(T_), 0, s, q.recs, q.bucket_base, gp, q.stage,    \
+                       (uint32_t)q.stage_cap, q.ord_cf, q.ord_idx, q.ord_ncol, q.bitmap, h->d_cnt, q.d_pc, q.dbg)
+            if (bv == 2 && bslots == 1024 && bt == 1024) GNDT_LAUNCH_BUCKET2(1024, 1024, 3072);
+            else if (bv == 2 && bslots == 1024) GNDT_LAUNCH_BUCKET2(512, 1024, 3584);
+            else if (bv == 2 && bslots == 512 && bt == 512) GNDT_LAUNCH_BUCKET2(512, 512, 1536);
+            else if (bv == 2 && bslots == 512) GNDT_LAUNCH_BUCKET2(256, 512, 1792);
+            else if (bv == 2 && bslots == 256) GNDT_LAUNCH_BUCKET2(256, 256, 1024);
+            else if (bv == 2 && bslots == 128) GNDT_LAUNCH_BUCKET2(128, 128, 512);
+            else if (bslots == 1024 && bt == 1024) GNDT_LAUNCH_BUCKET(1024, 1024);
             else if (bslots == 1024) GNDT_LAUNCH_BUCKET(512, 1024);
             else if (bt == 256) GNDT_LAUNCH_BUCKET(256, 512);
             else GNDT_LAUNCH_BUCKET(512, 512);
@@ -842,18 +861,25 @@ int gndt_get_phase_times(gndt_handle* h, double ms_out[GNDT_NUM_PHASES]) {
     return GNDT_OK;
 }
 
-int gndt_debug_bucket_phases(gndt_handle* h, double cycles_out[6], uint32_t* buckets_out) {
+int gndt_debug_bucket_phases(gndt_handle* h, double cycles_out[10], uint32_t* buckets_out) {
     if (!h || !cycles_out) return GNDT_ERR_INVALID;
     auto& q = h->part;
     if (!q.dbg || !q.last_buckets) { h->err = "no stamps: set GNDT_STAMPS=1 before a PARTITION build"; return GNDT_ERR_INVALID; }
     HIP_TRY(h, hipSetDevice(h->device));
     HIP_TRY(h, hipStreamSynchronize(h->last_stream));
-    std::vector<unsigned long long> t((size_t)q.last_buckets * 8);
+    std::vector<unsigned long long> t((size_t)q.last_buckets * 16);
     HIP_TRY(h, hipMemcpy(t.data(), q.dbg, t.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-    for (int k = 0; k < 6; ++k) cycles_out[k] = 0.0;
-    for (uint32_t b = 0; b < q.last_buckets; ++b)
-        for (int k = 0; k < 6; ++k) cycles_out[k] += (double)(t[(size_t)b * 8 + k + 1] - t[(size_t)b * 8 + k]);
-    for (int k = 0; k < 6; ++k) cycles_out[k] /= q.last_buckets;
+    for (int k = 0; k < 10; ++k) cycles_out[k] = 0.0;
+    for (uint32_t b = 0; b < q.last_buckets; ++b) {
+        const unsigned long long* s = &t[(size_t)b * 16];
+        for (int k = 0; k < 6; ++k) cycles_out[k] += (double)(s[k + 1] - s[k]);
+        // sub-phases of the accumulate phase (k_bucket_build2 only): load wait, classify, scan+scatter, reduce
+        if (s[8] && s[9] && s[10]) {
+            cycles_out[6] += (double)(s[8] - s[1]); cycles_out[7] += (double)(s[9] - s[8]);
+            cycles_out[8] += (double)(s[10] - s[9]); cycles_out[9] += (double)(s[2] - s[10]);
+        }
+    }
+    for (int k = 0; k < 10; ++k) cycles_out[k] /= q.last_buckets;
     if (buckets_out) *buckets_out = q.last_buckets;
     return GNDT_OK;
 }

@@ -27,7 +27,7 @@
 
 namespace gndt {
 
-constexpr int kPartThreads = 512;    // k_part_hist / k_part_scatter
+constexpr int kPartThreads = 1024;   // k_part_hist / k_part_scatter
 // k_bucket_build is a template on <threads, LDS node-table slots>; a bucket holding more than
 // 0.78 * slots distinct nodes overflows (the host then re-runs on the atomic path).
 constexpr int kScanChunk = 8192;     // elements per block in the two-level scans
@@ -250,7 +250,7 @@ __global__ void __launch_bounds__(kBucketThreads) k_bucket_build(const float4* _
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     // diagnostic phase stamps (shader clock), only when the host passes a buffer: [bucket][8]
-#define GNDT_STAMP(k) do { if (dbg && tid == 0) dbg[(size_t)blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define GNDT_STAMP(k) do { if (dbg && tid == 0) dbg[(size_t)blockIdx.x * 16 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
     GNDT_STAMP(0);
     // ---- P0: clear ----
     for (int s = tid; s < kBucketSlots; s += kBucketThreads) {

@@ -221,10 +221,11 @@ class TwoDmap:
 
     def debug_bucket_phases(self):
         """Mean shader cycles per bucket of k_bucket_build's phases (needs GNDT_STAMPS=1 in the environment)."""
-        arr = (C.c_double * 6)()
+        arr = (C.c_double * 10)()
         nb = C.c_uint32()
         self._check(self._L.gndt_debug_bucket_phases(self._h, arr, C.byref(nb)))
-        return dict(zip(("clear", "accumulate", "columns", "labels", "sort", "emit"), list(arr))), nb.value
+        names = ("clear", "accumulate", "columns", "labels", "order", "emit", "acc:load", "acc:classify", "acc:scatter", "acc:reduce")
+        return dict(zip(names, list(arr))), nb.value
 
     # ---- results ----
     def sync(self):

@@ -173,8 +173,9 @@ int gndt_get_phase_times(gndt_handle* h, double ms_out[GNDT_NUM_PHASES]);
 int gndt_last_strategy(const gndt_handle* h);
 /* Diagnostic (not for timed runs): with the environment variable GNDT_STAMPS=1 set, k_bucket_build
  * stamps the shader clock at its phase boundaries; this returns the mean cycles per bucket of
- * [0] clear [1] accumulate [2] columns [3] labels [4] sort [5] emit, and the bucket count. */
-int gndt_debug_bucket_phases(gndt_handle* h, double cycles_out[6], uint32_t* buckets_out);
+ * [0] clear [1] accumulate [2] columns [3] labels [4] order [5] emit, then the accumulate phase split into
+ * [6] load wait [7] classify [8] scan+scatter [9] reduce (first chunk), and the bucket count. */
+int gndt_debug_bucket_phases(gndt_handle* h, double cycles_out[10], uint32_t* buckets_out);
 
 /* Library / device information for logs: returns 0 and fills what it can. */
 int gndt_device_info(int32_t device_id, char name_out[128], int32_t* compute_units, uint64_t* hbm_bytes);
