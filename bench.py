@@ -76,7 +76,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert torch.cuda.is_available(), "bench.py needs a GPU (libgndt has no CPU path)"
     torch.cuda.set_device(local)
-    if world > 1:
+    use_dist = world > 1 or ("RANK" in os.environ and a.mode == "global")   # torchrun with one rank exercises the exchange too
+    if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
@@ -87,7 +88,8 @@ def main():
     P = dict(grid_len=a.grid_len, z_len=a.z_len, slope_interval=0.08, demand="slope")
     n = a.points
     cloud = scenes.uniform_box(n + 1, seed=0x5EED0002 + rank)     # point 0 = origin (receiver.cpp:145)
-    if world > 1 and a.mode == "global":
+    global_mode = use_dist and a.mode == "global"
+    if global_mode:
         origin = scenes.uniform_box(1, seed=0x5EED0002)[0]
     else:
         origin = cloud[0]
@@ -101,7 +103,7 @@ def main():
     stream = torch.cuda.current_stream()
 
     def step():
-        if world > 1 and a.mode == "global":
+        if global_mode:
             from grid_ndt_amd import dist as gdist
             gdist.build_global_map(m, "slope", pts, rank * n, stream)
         else:
@@ -112,7 +114,7 @@ def main():
     m.sync()
     m.set_profiling(True)
     phase_sum = {}
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -123,11 +125,11 @@ def main():
             if v >= 0:
                 phase_sum[k] = phase_sum.get(k, 0.0) + v
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     dt = time.perf_counter() - t0
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
     nodes, cols, slopes = m.sync()
@@ -174,7 +176,7 @@ def main():
                                    "demand=slope (BASELINE.json configs[1])" if n == 10_000_000 and a.grid_len == 0.5 and a.z_len == 0.5
                        else f"uniform box, {n} points/rank, grid {a.grid_len}/{a.z_len}",
                        "points_per_gpu": n, "nodes": int(nodes), "columns": int(cols), "slopes": int(slopes),
-                       "multi_gpu_mode": a.mode if world > 1 else "single", "strategy": strat},
+                       "multi_gpu_mode": a.mode if use_dist else "single", "strategy": strat},
             "roofline": {"bound": "hbm", "kernel": kernel_of.get(dom),
                          "achieved": round(achieved, 2) if achieved else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5) if achieved else None, "traffic": traffic,
@@ -202,7 +204,7 @@ def main():
             print("k_bucket_build phase stamps (mean shader cycles per bucket, %d buckets): " % nb +
                   ", ".join(f"{k}={v:.0f} ({100 * v / tot:.0f}%)" for k, v in cyc.items()), file=sys.stderr)
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

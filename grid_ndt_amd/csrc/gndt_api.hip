@@ -86,6 +86,7 @@ struct gndt_handle {
         PartCounters* h_pc = nullptr;   // pinned
         unsigned long long* dbg = nullptr;  uint32_t dbg_buckets = 0;   // diagnostic phase stamps (GNDT_STAMPS=1)
         uint32_t last_buckets = 0;
+        uint64_t nodes_learned = 0;   // node count of the last successful PARTITION build (+20 %)
     } part;
     int last_strategy = GNDT_STRATEGY_ATOMIC;
     bool map_in_table = true;   // false after a PARTITION build: the HBM node table does not hold the map
@@ -406,12 +407,13 @@ int ensure_stage(gndt_handle* h, uint64_t nodes) {
 
 // Bucket count: ~4096 points per bucket, and few enough nodes per bucket for the LDS table
 // (average load <= 0.3 of `slots`, which leaves room for the spread of a hash partition).
-uint32_t choose_buckets(const gndt_handle* h, uint64_t n, int slots) {
-    const uint64_t nodes = h->P.max_nodes_hint ? h->P.max_nodes_hint : n / 4;
-    uint64_t want = std::max<uint64_t>(n / (4 * (uint64_t)slots), (nodes * 10) / (uint64_t)(slots * 3));
-    want = std::min<uint64_t>(std::max<uint64_t>(want, 16), 32768);
-    return (uint32_t)want;
+// Bucket count for `nodes` expected nodes: ~4*slots points per bucket, and few enough nodes per bucket for
+// the LDS table (average load <= 0.3 of `slots`, which leaves room for the spread of a hash partition).
+uint64_t buckets_for(uint64_t n, uint64_t nodes, int slots) {
+    const uint64_t want = std::max<uint64_t>(n / (4 * (uint64_t)slots), (nodes * 10) / (uint64_t)(slots * 3));
+    return std::max<uint64_t>(want, 16);
 }
+constexpr uint64_t kMaxBuckets = 32768;   // 4-byte LDS cursor per bucket in the partition passes
 
 // Returns GNDT_OK, an error, or -1 when the partition path cannot hold this input (caller falls back).
 int build_partition(gndt_handle* h, const void* xyz_dev, size_t n, size_t stride_bytes, hipStream_t s) {
@@ -419,22 +421,14 @@ int build_partition(gndt_handle* h, const void* xyz_dev, size_t n, size_t stride
     if (stride_bytes != 12 && stride_bytes != 16) { h->err = "stride_bytes must be 12 or 16"; return GNDT_ERR_INVALID; }
     if (n >= 0xFFFFFFFFull) { h->err = "point index exceeds 32 bits"; return GNDT_ERR_INVALID; }
     static const int bt = getenv("GNDT_BUCKET_THREADS") ? atoi(getenv("GNDT_BUCKET_THREADS")) : 512;
-    static const int bslots = getenv("GNDT_BUCKET_SLOTS") ? atoi(getenv("GNDT_BUCKET_SLOTS")) : 512;
-    const uint32_t B = choose_buckets(h, n, bslots);
+    static const int env_slots = getenv("GNDT_BUCKET_SLOTS") ? atoi(getenv("GNDT_BUCKET_SLOTS")) : 0;
     static const int part_wgs = getenv("GNDT_PART_WGS") ? atoi(getenv("GNDT_PART_WGS")) : 256;
     const uint32_t nwg = (uint32_t)std::min<uint64_t>((uint64_t)part_wgs, std::max<uint64_t>(1, n / 8192));
     const uint64_t words = (n + 31) / 32 + 1;
     int rc;
     if ((rc = grow_buf(h, q.recs, q.rec_cap, n))) return rc;
-    if ((rc = grow_buf(h, q.hist, q.hist_cap, (uint64_t)nwg * B))) return rc;
-    if (B > q.bucket_cap) {
-        if (q.totals) (void)hipFree(q.totals);
-        if (q.bucket_base) (void)hipFree(q.bucket_base);
-        q.totals = q.bucket_base = nullptr; q.bucket_cap = 0;
-        HIP_TRY(h, hipMalloc(&q.totals, (size_t)B * 4));
-        HIP_TRY(h, hipMalloc(&q.bucket_base, ((size_t)B + 1) * 4));
-        q.bucket_cap = B;
-    }
+    // expected node count: the caller's hint, else what the previous build of this handle found, else n/4
+    uint64_t nodes_est = h->P.max_nodes_hint ? h->P.max_nodes_hint : (q.nodes_learned ? q.nodes_learned : std::max<uint64_t>(n / 4, 1024));
     if (words > q.word_cap) {
         for (uint32_t** a : {&q.bitmap, &q.word_prefix, &q.bsum_words}) { if (*a) (void)hipFree(*a); *a = nullptr; }
         q.word_cap = 0;
@@ -451,7 +445,23 @@ int build_partition(gndt_handle* h, const void* xyz_dev, size_t n, size_t stride
                                                                              : std::max<uint64_t>(4096, n / 4));
     const GridParams gp = grid_params(h);
     const float* p = static_cast<const float*>(xyz_dev);
-    for (int attempt = 0; attempt < 3; ++attempt) {
+    for (int attempt = 0; attempt < 5; ++attempt) {
+        // table size and bucket count for this attempt: 512-slot tables unless that needs too many buckets
+        int bslots = env_slots ? env_slots : 512;
+        uint64_t Bw = buckets_for(n, nodes_est, bslots);
+        if (!env_slots && Bw > kMaxBuckets) { bslots = 1024; Bw = buckets_for(n, nodes_est, bslots); }
+        if (Bw > kMaxBuckets) return -1;                       // too many nodes for one partition level: atomic path
+        const uint32_t B = (uint32_t)Bw;
+        if ((rc = grow_buf(h, q.hist, q.hist_cap, (uint64_t)nwg * B))) return rc;
+        if (B > q.bucket_cap) {
+            if (q.totals) (void)hipFree(q.totals);
+            if (q.bucket_base) (void)hipFree(q.bucket_base);
+            q.totals = q.bucket_base = nullptr; q.bucket_cap = 0;
+            HIP_TRY(h, hipMalloc(&q.totals, (size_t)B * 4));
+            HIP_TRY(h, hipMalloc(&q.bucket_base, ((size_t)B + 1) * 4));
+            q.bucket_cap = B;
+        }
+        stage_want = std::max<uint64_t>(stage_want, nodes_est + nodes_est / 8);
         if ((rc = ensure_stage(h, stage_want))) return rc;
         if ((rc = ensure_out(h, q.stage_cap))) return rc;
         mark(h, 0, s);
@@ -542,11 +552,15 @@ int build_partition(gndt_handle* h, const void* xyz_dev, size_t n, size_t stride
         HIP_TRY(h, hipMemcpyAsync(q.h_pc, q.d_pc, sizeof(PartCounters), hipMemcpyDeviceToHost, s));
         HIP_TRY(h, hipMemcpyAsync(h->h_cnt, h->d_cnt, sizeof(Counters), hipMemcpyDeviceToHost, s));
         HIP_TRY(h, hipStreamSynchronize(s));
-        if (q.h_pc->lds_overflow) return -1;                 // a bucket holds too many nodes for LDS
+        if (q.h_pc->lds_overflow) {                          // some bucket holds too many nodes for its LDS table:
+            nodes_est *= 3;                                  // the estimate was low; retry with more buckets
+            continue;
+        }
         if (q.h_pc->stage_overflow) {                        // num_nodes kept counting: it is the true total
             stage_want = (uint64_t)h->h_cnt->num_nodes + h->h_cnt->num_nodes / 8 + 1024;
             continue;
         }
+        q.nodes_learned = (uint64_t)h->h_cnt->num_nodes + h->h_cnt->num_nodes / 5;
         h->results_valid = true;
         h->map_in_table = false;
         h->table_dirty = false;
