@@ -13,10 +13,11 @@
 //                   LDS atomics per run (~1.5 runs per thread instead of 9 atomics per point)
 //   then, on the finished table
 //     D  columns  : column table + a linked list of each column's nodes
-//     E  labels   : slope test and index-in-column by walking the (short) column list: no hash probes
+//     E  labels   : slope test and index-in-column by walking the (short) column list: no hash probes;
+//                   the node's staging row is written in the same pass
 //     F  order    : column base = sum of the sizes of the columns first seen earlier (loop over the bucket's
 //                   columns, not its nodes); row = base + index in column
-//     G  emit     : mean + fp64 scatter -> 128-B staging row; bitmap bit per column-first index
+//     F  emit     : mean + fp64 scatter -> 128-B staging row; bitmap bit per column-first index
 //
 // Semantics are those of k_bucket_build (same gndt_math.hpp arithmetic); tests run both.
 #pragma once
@@ -43,16 +44,14 @@ struct BucketLds2 {
         } pts;
         struct {          // phases D-G
             unsigned long long ckey[H];
-            uint32_t cfirst[H], ccnt[H], chead[H], cbase[H];
-            unsigned long long clist[H];   // compact list of the bucket's columns: (first-seen << 32) | size
+            uint32_t cfirst[H], ccnt[H], chead[H];
             uint32_t next[H];       // next node (slot) of the same column, 0xFFFFFFFF ends
             float mean_z[H];
             uint32_t flags[H];      // bits 0..2 GNDT_FLAG_*, bits 8.. column slot
-            uint32_t icol[H];       // index of the node inside its column (first-seen order)
         } fin;
     } u;
     uint32_t wave_tot[16];
-    uint32_t n_nodes, n_cols, n_clist, n_slopes, stage_base, overflow;
+    uint32_t n_nodes, n_cols, n_clist, n_rows, n_slopes, stage_base, overflow;
 };
 
 template <int T, int H, int CH>
@@ -78,7 +77,7 @@ __global__ void __launch_bounds__(T) k_bucket_build2(const float4* __restrict__ 
         for (int j = 0; j < 9; ++j) L.sum[j][s] = 0.0;
         L.cnt[s] = 0; L.first[s] = 0xFFFFFFFFu; L.ccur[s] = 0;
     }
-    if (tid == 0) { L.n_nodes = 0; L.n_cols = 0; L.n_clist = 0; L.n_slopes = 0; L.stage_base = 0; L.overflow = 0; }
+    if (tid == 0) { L.n_nodes = 0; L.n_cols = 0; L.n_clist = 0; L.n_rows = 0; L.n_slopes = 0; L.stage_base = 0; L.overflow = 0; }
     __syncthreads();
     GNDT_STAMP(1);
 
@@ -236,8 +235,15 @@ __global__ void __launch_bounds__(T) k_bucket_build2(const float4* __restrict__ 
         L.u.fin.next[s] = atomicExch(&L.u.fin.chead[cs], (uint32_t)s);
         L.u.fin.flags[s] = fl | (cs << 8);
     }
+    if (tid == T - 1) L.stage_base = stage_base_reg;
     __syncthreads();
     GNDT_STAMP(3);
+    const uint32_t base0 = L.stage_base;
+    if (base0 + M > stage_cap) {               // uniform
+        if (tid == 0) atomicAdd(&pc->stage_overflow, M);
+        return;
+    }
+    if (tid == 0) atomicAdd(&cnt->num_columns, L.n_cols);
 
     // ---- E: slope labels (OcNode::isSlope, map2D.h:66-108) and index in column, by walking the column list ----
     uint32_t my_slopes = 0;
@@ -270,55 +276,11 @@ __global__ void __launch_bounds__(T) k_bucket_build2(const float4* __restrict__ 
             if (P.demand == 0) slope = !up; else down = false;
             if (slope) { fl |= 2u; if (down) fl |= 4u; ++my_slopes; }
         }
-        L.u.fin.flags[s] = fl;       // bit 0 of other slots is read above and never changes here
-        L.u.fin.icol[s] = icol;
-    }
-    // counters: aggregate in LDS, ONE memory-side atomic per bucket and counter (same-address global atomics
-    // serialise at the memory side and slow every other request down with them)
-    if (my_slopes) atomicAdd(&L.n_slopes, my_slopes);
-    for (int c = tid; c < H; c += T) {          // compact list of this bucket's columns for phase F
-        if (L.u.fin.ckey[c] == kEmptyKey) continue;
-        const uint32_t pos = atomicAdd(&L.n_clist, 1u);
-        L.u.fin.clist[pos] = ((unsigned long long)L.u.fin.cfirst[c] << 32) | (unsigned long long)L.u.fin.ccnt[c];
-    }
-    __syncthreads();
-    GNDT_STAMP(4);
-
-    // ---- F: column base rows: columns in first-seen order.  The column table is scanned by its own threads;
-    //         each occupied column sums the sizes of the columns seen before it. ----
-    for (int c = tid; c < H; c += T) {
-        if (L.u.fin.ckey[c] == kEmptyKey) continue;
-        const uint32_t cf = L.u.fin.cfirst[c];
-        const uint32_t ncl = L.n_clist;
-        uint32_t base = 0;
-#pragma unroll 4
-        for (uint32_t o = 0; o < ncl; ++o) {                // every lane reads the same entry: LDS broadcast
-            const unsigned long long e = L.u.fin.clist[o];
-            base += ((uint32_t)(e >> 32) < cf) ? (uint32_t)e : 0u;
-        }
-        L.u.fin.cbase[c] = base;
-    }
-    if (tid == T - 1) L.stage_base = stage_base_reg;
-    __syncthreads();
-    GNDT_STAMP(5);
-    if (tid == 0) {
-        if (L.n_slopes) atomicAdd(&cnt->num_slopes, L.n_slopes);
-        atomicAdd(&cnt->num_columns, L.n_clist);
-    }
-    const uint32_t base0 = L.stage_base;
-    if (base0 + M > stage_cap) {               // uniform
-        if (tid == 0) atomicAdd(&pc->stage_overflow, M);
-        return;
-    }
-
-    // ---- G: staging rows ----
-    for (int s = tid; s < H; s += T) {
-        const uint64_t key = L.key[s];
-        if (key == kEmptyKey) continue;
-        const uint32_t flw = L.u.fin.flags[s];
-        const uint32_t fl = flw & 7u, cs = flw >> 8;
-        const uint32_t idx_in_col = L.u.fin.icol[s];
+        // ---- F: staging row, written straight away (rows of a bucket need no order among themselves: the
+        //         global ordering kernels only use column first-seen and index in column) ----
+        const uint32_t idx_in_col = icol;
         const uint32_t cf = L.u.fin.cfirst[cs];
+        fl &= 7u;
         StageRow row;
         unpack_key(key, row.sx, row.sy, row.sz);
         row.count = L.cnt[s]; row.first = L.first[s]; row.flags = fl;
@@ -334,7 +296,7 @@ __global__ void __launch_bounds__(T) k_bucket_build2(const float4* __restrict__ 
         }
         row.col_first = cf; row.idx_in_col = idx_in_col; row.ncol = L.u.fin.ccnt[cs];
         for (int k = 0; k < 8; ++k) row.pad[k] = 0;
-        const uint32_t dst = base0 + L.u.fin.cbase[cs] + idx_in_col;
+        const uint32_t dst = base0 + atomicAdd(&L.n_rows, 1u);
         stage[dst] = row;
         ord_cf[dst] = cf;
         ord_idx[dst] = idx_in_col;
@@ -343,6 +305,12 @@ __global__ void __launch_bounds__(T) k_bucket_build2(const float4* __restrict__ 
             atomicOr(&bitmap[cf >> 5], 1u << (cf & 31u));
         }
     }
+    // counters: aggregated in LDS, ONE memory-side atomic per bucket and counter (same-address global atomics
+    // serialise at the memory side and slow every other request down with them)
+    if (my_slopes) atomicAdd(&L.n_slopes, my_slopes);
+    __syncthreads();
+    if (tid == 0 && L.n_slopes) atomicAdd(&cnt->num_slopes, L.n_slopes);
+    if (dbg) { GNDT_STAMP(4); GNDT_STAMP(5); }
     if (dbg) { __syncthreads(); GNDT_STAMP(6); }
 #undef GNDT_STAMP
 }
