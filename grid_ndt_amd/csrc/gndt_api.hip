@@ -466,9 +466,10 @@ int build_partition(gndt_handle* h, const void* xyz_dev, size_t n, size_t stride
         if ((rc = ensure_out(h, q.stage_cap))) return rc;
         mark(h, 0, s);
         // the HBM node table is not used by this strategy, but a previous atomic build may sit in it
-        if ((rc = do_reset(h, s))) return rc;
-        HIP_TRY(h, hipMemsetAsync(q.bitmap, 0, words * 4, s));
-        HIP_TRY(h, hipMemsetAsync(q.d_pc, 0, sizeof(PartCounters), s));
+        if (h->table_dirty) { if ((rc = do_reset(h, s))) return rc; }
+        h->results_valid = false;
+        hipLaunchKernelGGL(k_part_clear, dim3(grid_for(words, 256, 512)), dim3(256), 0, s, h->d_cnt, q.d_pc, q.bitmap, (uint64_t)words);
+        HIP_TRY(h, hipGetLastError());
         mark(h, 1, s);
         const size_t lds = (size_t)B * 4;
         if (lds > 48 * 1024) {   // beyond the default dynamic-LDS limit the kernels must be told (gfx950: 160 KiB/CU)

@@ -30,8 +30,8 @@ namespace gndt {
 constexpr int kPartThreads = 1024;   // k_part_hist / k_part_scatter
 // k_bucket_build is a template on <threads, LDS node-table slots>; a bucket holding more than
 // 0.78 * slots distinct nodes overflows (the host then re-runs on the atomic path).
-constexpr int kScanChunk = 8192;     // elements per block in the two-level scans
-constexpr int kScanThreads = 1024;
+constexpr int kScanChunk = 2048;     // elements per block in the two-level scans
+constexpr int kScanThreads = 256;
 
 struct PartCounters {
     uint32_t lds_overflow;     // buckets whose node table overflowed
@@ -75,6 +75,16 @@ __device__ __forceinline__ void wg_range(uint64_t n, uint32_t nwg, uint32_t w, u
     hi = lo + chunk;
     if (lo > n) lo = n;
     if (hi > n) hi = n;
+}
+
+// one launch that prepares a build: counters, partition flags and the column-first bitmap
+__global__ void __launch_bounds__(256) k_part_clear(Counters* __restrict__ cnt, PartCounters* __restrict__ pc,
+                                                    uint32_t* __restrict__ bitmap, uint64_t words) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        cnt->num_nodes = 0; cnt->num_columns = 0; cnt->num_slopes = 0; cnt->err_key_range = 0; cnt->err_table_full = 0;
+        pc->lds_overflow = 0; pc->stage_overflow = 0;
+    }
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < words; i += (uint64_t)gridDim.x * blockDim.x) bitmap[i] = 0u;
 }
 
 // ---------------------------------------------------------------------------------------------
