@@ -113,8 +113,9 @@ int gndt_set_origin(gndt_handle* h, const float origin_xyz[3]);
 /* ---- build: replaces receiver.cpp:150-154 + :160 --------------------------------------------- */
 /* Host memory in (e.g. pcl::PointCloud<PointXYZ>::points.data()+1, stride 16).  Synchronous. */
 int gndt_build(gndt_handle* h, const void* xyz_host, size_t n, size_t stride_bytes);
-/* Device memory in; enqueues on `hip_stream` (a hipStream_t, may be NULL) and returns without
- * synchronising.  stride_bytes is 12 (packed) or 16 (PointXYZ). */
+/* Device memory in; all work is enqueued on `hip_stream` (a hipStream_t, may be NULL = the handle's own
+ * stream).  stride_bytes is 12 (packed) or 16 (PointXYZ).  In this version the call waits for the stream once
+ * before returning (it reads the device-side overflow flags and node count); results are then ready. */
 int gndt_build_device(gndt_handle* h, const void* xyz_dev, size_t n, size_t stride_bytes, void* hip_stream);
 
 /* Incremental add (the intent of changeCallback/change2DMap, receiver.cpp:179-212, map2D.h:672-822;

@@ -371,28 +371,38 @@ Grid* build_int_keys(const float* xyz, size_t n, size_t stride, const float o[3]
         kk[i] = k;
         keys[i] = pack_key(signed_x(k), signed_y(k), k.sz);
     }
-    // each thread owns the nodes whose key hashes to it, scans all keys in order (arrival order kept)
+    // Parallel partition by key hash: thread t files the points of its contiguous index chunk into `threads`
+    // lists (one per owner); owner p then walks the lists of chunk 0, 1, 2, ... in that order, so every node
+    // sees its points in arrival order (what the fp32 sequential sums of the reference depend on).  O(n) work.
     std::vector<std::vector<Node*>> owned(threads);
+    std::vector<std::vector<std::vector<uint32_t>>> filed(threads, std::vector<std::vector<uint32_t>>(threads));
 #pragma omp parallel num_threads(threads)
     {
 #ifdef _OPENMP
-        int t = omp_get_thread_num();
+        const int t = omp_get_thread_num();
 #else
-        int t = 0;
+        const int t = 0;
 #endif
+        const size_t lo = n * static_cast<size_t>(t) / threads, hi = n * static_cast<size_t>(t + 1) / threads;
+        std::vector<std::vector<uint32_t>>& mine = filed[t];
+        for (auto& v : mine) v.reserve((hi - lo) / threads + 16);
+        for (size_t i = lo; i < hi; ++i)
+            mine[mix64(keys[i]) % static_cast<uint64_t>(threads)].push_back(static_cast<uint32_t>(i));
+#pragma omp barrier
         std::unordered_map<uint64_t, Node*> local;
-        local.reserve(n / (threads * 4) + 16);
-        std::vector<Node*>& mine = owned[t];
-        for (size_t i = 0; i < n; ++i) {
-            uint64_t k = keys[i];
-            if (static_cast<int>(mix64(k) % static_cast<uint64_t>(threads)) != t) continue;
-            auto it = local.find(k);
-            Node* nd;
-            if (it == local.end()) {
-                nd = new Node; nd->key = kk[i]; nd->first_idx = i;
-                local.emplace(k, nd); mine.push_back(nd);
-            } else nd = it->second;
-            nd->idx.push_back(static_cast<uint32_t>(i));
+        local.reserve(n / (static_cast<size_t>(threads) * 4) + 16);
+        std::vector<Node*>& nodes_of_t = owned[t];
+        for (int src = 0; src < threads; ++src) {
+            for (uint32_t i : filed[src][t]) {
+                const uint64_t k = keys[i];
+                auto it = local.find(k);
+                Node* nd;
+                if (it == local.end()) {
+                    nd = new Node; nd->key = kk[i]; nd->first_idx = i;
+                    local.emplace(k, nd); nodes_of_t.push_back(nd);
+                } else nd = it->second;
+                nd->idx.push_back(i);
+            }
         }
     }
     double t1 = now_s();
