@@ -87,6 +87,7 @@ struct gndt_handle {
         unsigned long long* dbg = nullptr;  uint32_t dbg_buckets = 0;   // diagnostic phase stamps (GNDT_STAMPS=1)
         uint32_t last_buckets = 0;
         uint64_t nodes_learned = 0;   // node count of the last successful PARTITION build (+20 %)
+        int good_slots = 0; uint64_t good_est = 0, good_n = 0;   // table size / estimate that worked last time
     } part;
     int last_strategy = GNDT_STRATEGY_ATOMIC;
     bool map_in_table = true;   // false after a PARTITION build: the HBM node table does not hold the map
@@ -419,7 +420,7 @@ constexpr uint64_t kMaxBuckets = 32768;   // 4-byte LDS cursor per bucket in the
 int build_partition(gndt_handle* h, const void* xyz_dev, size_t n, size_t stride_bytes, hipStream_t s) {
     auto& q = h->part;
     if (stride_bytes != 12 && stride_bytes != 16) { h->err = "stride_bytes must be 12 or 16"; return GNDT_ERR_INVALID; }
-    if (n >= 0xFFFFFFFFull) { h->err = "point index exceeds 32 bits"; return GNDT_ERR_INVALID; }
+    if (n >= 0x7FFFFFFFull) return -1;   // bit 31 of the record index word carries the weight flag: atomic path beyond 2^31 points
     static const int bt = getenv("GNDT_BUCKET_THREADS") ? atoi(getenv("GNDT_BUCKET_THREADS")) : 512;
     static const int env_slots = getenv("GNDT_BUCKET_SLOTS") ? atoi(getenv("GNDT_BUCKET_SLOTS")) : 0;
     static const int part_wgs = getenv("GNDT_PART_WGS") ? atoi(getenv("GNDT_PART_WGS")) : 256;
@@ -447,7 +448,8 @@ int build_partition(gndt_handle* h, const void* xyz_dev, size_t n, size_t stride
     const float* p = static_cast<const float*>(xyz_dev);
     for (int attempt = 0; attempt < 5; ++attempt) {
         // table size and bucket count for this attempt: 512-slot tables unless that needs too many buckets
-        int bslots = env_slots ? env_slots : 512;
+        // attempt 0: 512-slot tables; an overflow first doubles the table (same estimate), then raises the estimate
+        int bslots = env_slots ? env_slots : (attempt == 0 ? 512 : 1024);
         uint64_t Bw = buckets_for(n, nodes_est, bslots);
         if (!env_slots && Bw > kMaxBuckets) { bslots = 1024; Bw = buckets_for(n, nodes_est, bslots); }
         if (Bw > kMaxBuckets) return -1;                       // too many nodes for one partition level: atomic path
@@ -504,24 +506,15 @@ int build_partition(gndt_handle* h, const void* xyz_dev, size_t n, size_t stride
         }
         q.last_buckets = B;
         {
-#define GNDT_LAUNCH_BUCKET(T_, H_)                                                                                     \
-    hipLaunchKernelGGL((k_bucket_build<T_, H_>), dim3(B), dim3(T_), 0, s, q.recs, q.bucket_base, gp, q.stage,          \
-                       (uint32_t)q.stage_cap, q.ord_cf, q.ord_idx, q.ord_ncol, q.bitmap, h->d_cnt, q.d_pc, q.dbg)
-            static const int bv = getenv("GNDT_BUCKET_V") ? atoi(getenv("GNDT_BUCKET_V")) : 2;
 #define GNDT_LAUNCH_BUCKET2(T_, H_, CH_)                                                                               \
     hipLaunchKernelGGL((k_bucket_build2<T_, H_, CH_>), dim3(B), dim3(T_), 0, s, q.recs, q.bucket_base, gp, q.stage,    \
                        (uint32_t)q.stage_cap, q.ord_cf, q.ord_idx, q.ord_ncol, q.bitmap, h->d_cnt, q.d_pc, q.dbg)
-            if (bv == 2 && bslots == 1024 && bt == 1024) GNDT_LAUNCH_BUCKET2(1024, 1024, 3072);
-            else if (bv == 2 && bslots == 1024) GNDT_LAUNCH_BUCKET2(512, 1024, 3584);
-            else if (bv == 2 && bslots == 512 && bt == 512) GNDT_LAUNCH_BUCKET2(512, 512, 1536);
-            else if (bv == 2 && bslots == 512) GNDT_LAUNCH_BUCKET2(256, 512, 1792);
-            else if (bv == 2 && bslots == 256) GNDT_LAUNCH_BUCKET2(256, 256, 1024);
-            else if (bv == 2 && bslots == 128) GNDT_LAUNCH_BUCKET2(128, 128, 512);
-            else if (bslots == 1024 && bt == 1024) GNDT_LAUNCH_BUCKET(1024, 1024);
-            else if (bslots == 1024) GNDT_LAUNCH_BUCKET(512, 1024);
-            else if (bt == 256) GNDT_LAUNCH_BUCKET(256, 512);
-            else GNDT_LAUNCH_BUCKET(512, 512);
-#undef GNDT_LAUNCH_BUCKET
+            if (bslots == 1024 && bt == 1024) GNDT_LAUNCH_BUCKET2(1024, 1024, 3072);
+            else if (bslots == 1024) GNDT_LAUNCH_BUCKET2(512, 1024, 3584);
+            else if (bslots == 512 && bt == 256) GNDT_LAUNCH_BUCKET2(256, 512, 1792);
+            else if (bslots == 256) GNDT_LAUNCH_BUCKET2(256, 256, 1024);
+            else GNDT_LAUNCH_BUCKET2(512, 512, 1536);
+#undef GNDT_LAUNCH_BUCKET2
         }
         HIP_TRY(h, hipGetLastError());
         mark(h, 5, s);
@@ -554,7 +547,7 @@ int build_partition(gndt_handle* h, const void* xyz_dev, size_t n, size_t stride
         HIP_TRY(h, hipMemcpyAsync(h->h_cnt, h->d_cnt, sizeof(Counters), hipMemcpyDeviceToHost, s));
         HIP_TRY(h, hipStreamSynchronize(s));
         if (q.h_pc->lds_overflow) {                          // some bucket holds too many nodes for its LDS table:
-            nodes_est *= 3;                                  // the estimate was low; retry with more buckets
+            if (attempt >= 1 || env_slots) nodes_est *= 2;   // (attempt 0 -> 1 only switches to the 1024-slot table)
             continue;
         }
         if (q.h_pc->stage_overflow) {                        // num_nodes kept counting: it is the true total
@@ -562,6 +555,7 @@ int build_partition(gndt_handle* h, const void* xyz_dev, size_t n, size_t stride
             continue;
         }
         q.nodes_learned = (uint64_t)h->h_cnt->num_nodes + h->h_cnt->num_nodes / 5;
+        q.good_slots = bslots; q.good_est = nodes_est; q.good_n = n;
         h->results_valid = true;
         h->map_in_table = false;
         h->table_dirty = false;
@@ -697,7 +691,7 @@ int gndt_build_device(gndt_handle* h, const void* xyz_dev, size_t n, size_t stri
     h->last_stream = s;
     for (auto& r : h->ev_recorded) r = false;
     int strategy = h->P.strategy;
-    if (strategy == GNDT_STRATEGY_AUTO) strategy = (n >= (1u << 18)) ? GNDT_STRATEGY_PARTITION : GNDT_STRATEGY_ATOMIC;
+    if (strategy == GNDT_STRATEGY_AUTO) strategy = (n >= (1u << 16)) ? GNDT_STRATEGY_PARTITION : GNDT_STRATEGY_ATOMIC;
     if (strategy == GNDT_STRATEGY_PARTITION) {
         rc = build_partition(h, xyz_dev, n, stride_bytes, s);
         if (rc != -1) return rc;

@@ -165,7 +165,7 @@ __global__ void __launch_bounds__(T) k_bucket_build2(const float4* __restrict__ 
                 const bool ok = p < nchunk;
                 qs[j] = ok ? (uint32_t)L.u.pts.slot[p] : 0xFFFFFFFFu;
                 qx[j] = ok ? L.u.pts.x[p] : 0.f; qy[j] = ok ? L.u.pts.y[p] : 0.f; qz[j] = ok ? L.u.pts.z[p] : 0.f;
-                qi[j] = ok ? L.u.pts.idx[p] : 0xFFFFFFFFu;
+                qi[j] = ok ? L.u.pts.idx[p] : 0xFFFFFFFFu;      // bit 31: the record stands for 64 identical points
             }
             uint32_t cur = 0xFFFFFFFFu, rn = 0, rfirst = 0xFFFFFFFFu;
             double a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0, a5 = 0, a6 = 0, a7 = 0, a8 = 0;
@@ -189,13 +189,16 @@ __global__ void __launch_bounds__(T) k_bucket_build2(const float4* __restrict__ 
                     }
                 }
                 if (s != 0xFFFFFFFFu) {
+                    const bool w64 = (qi[j] & kWeight64Flag) != 0u;
+                    const double w = w64 ? 64.0 : 1.0;
                     const double v0 = (double)qx[j] - c0, v1 = (double)qy[j] - c1, v2 = (double)qz[j] - c2;
-                    a0 += v0; a1 += v1; a2 += v2;
+                    const double w0 = w * v0, w1 = w * v1, w2 = w * v2;     // exact: w is a power of two
+                    a0 += w0; a1 += w1; a2 += w2;
                     // fused multiply-add on purpose: one rounding per term (the sums are order-free anyway)
-                    a3 = fma(v0, v0, a3); a4 = fma(v0, v1, a4); a5 = fma(v0, v2, a5);
-                    a6 = fma(v1, v1, a6); a7 = fma(v1, v2, a7); a8 = fma(v2, v2, a8);
-                    ++rn;
-                    rfirst = min(rfirst, qi[j]);
+                    a3 = fma(w0, v0, a3); a4 = fma(w0, v1, a4); a5 = fma(w0, v2, a5);
+                    a6 = fma(w1, v1, a6); a7 = fma(w1, v2, a7); a8 = fma(w2, v2, a8);
+                    rn += w64 ? 64u : 1u;
+                    rfirst = min(rfirst, qi[j] & ~kWeight64Flag);
                 }
             }
             if (cur != 0xFFFFFFFFu) {

@@ -9,9 +9,9 @@
 //   k_part_hist      points -> bucket histogram per workgroup                      reads 12 B/pt
 //   k_part_offsets   per-bucket exclusive scan over workgroups (+ bucket totals)
 //   k_part_scatter   points -> {x,y,z,idx} records grouped by bucket               reads 12, writes 16 B/pt
-//   k_bucket_build   one workgroup per bucket: LDS hash table of nodes, fp64 LDS atomics,
-//                    column table, slope labels, bitonic sort by (column first-seen, node first-seen),
-//                    mean/scatter/eigen -> 128-B staging rows                      reads 16 B/pt, writes 128 B/node
+//   k_bucket_build2  (gndt_bucket.hpp) one workgroup per bucket: LDS node table, sort-based accumulation,
+//                    column lists, slope labels, mean + fp64 scatter -> 128-B staging rows
+//                                                                                   reads 16 B/pt, writes 128 B/node
 //   k_scan_*         bitmap of column-first point indices -> column rank; column sizes -> row offsets
 //   k_order_*        destination row of every node (reference order), inverse permutation
 //   k_emit_rows      staging rows -> SoA result in reference order                 reads 128, writes 76 B/node
@@ -67,6 +67,16 @@ __device__ __forceinline__ uint32_t node_slot_hash(uint32_t colh, int sz) {
     return g;
 }
 
+constexpr uint32_t kWeight64Flag = 0x80000000u;   // in a record's index word: the record stands for 64 identical points
+
+// true (wave-uniformly) iff all 64 lanes are `use` and hold bit-identical coordinates
+__device__ __forceinline__ bool wave_all_identical(float px, float py, float pz, bool use) {
+    const uint32_t ux = __float_as_uint(px), uy = __float_as_uint(py), uz = __float_as_uint(pz);
+    const uint32_t fx = (uint32_t)__builtin_amdgcn_readfirstlane((int)ux), fy = (uint32_t)__builtin_amdgcn_readfirstlane((int)uy),
+                   fz = (uint32_t)__builtin_amdgcn_readfirstlane((int)uz);
+    return __all(use && ux == fx && uy == fy && uz == fz) != 0;
+}
+
 // points of workgroup w: [w*chunk, min(n, (w+1)*chunk))
 __device__ __forceinline__ void wg_range(uint64_t n, uint32_t nwg, uint32_t w, uint64_t& lo, uint64_t& hi) {
     uint64_t chunk = (n + nwg - 1) / nwg;
@@ -99,12 +109,18 @@ __global__ void __launch_bounds__(kPartThreads) k_part_hist(const float* __restr
     __syncthreads();
     uint64_t lo, hi;
     wg_range(n, gridDim.x, blockIdx.x, lo, hi);
-    for (uint64_t i = lo + threadIdx.x; i < hi; i += kPartThreads) {
-        const float* p = xyz + i * STRIDE_FLOATS;
-        const float px = p[0], py = p[1], pz = p[2];
+    const uint64_t hi_round = lo + ((hi - lo + 63) & ~63ull);       // whole waves, so that the wave vote below is defined
+    for (uint64_t i = lo + threadIdx.x; i < hi_round; i += kPartThreads) {
+        const bool live = i < hi;
+        float px = 0.f, py = 0.f, pz = 0.f;
+        if (live) { const float* p = xyz + i * STRIDE_FLOATS; px = p[0]; py = p[1]; pz = p[2]; }
         PointKey k = point_key(px, py, pz, P.ox, P.oy, P.oz, P.grid_len, P.z_len);
-        if (!k.ok) { atomicAdd(&cnt->err_key_range, 1u); continue; }
-        atomicAdd(&lh[bucket_of(column_hash(k.sx, k.sy), B)], 1u);
+        if (live && !k.ok) atomicAdd(&cnt->err_key_range, 1u);
+        const bool use = live && k.ok;
+        // 64 consecutive identical points (the (0,0,0) padding of the reference's clouds) become ONE
+        // weighted record: counted once here, written once by k_part_scatter
+        const bool same = wave_all_identical(px, py, pz, use);
+        if (use && (!same || (threadIdx.x & 63) == 0)) atomicAdd(&lh[bucket_of(column_hash(k.sx, k.sy), B)], 1u);
     }
     __syncthreads();
     uint32_t* out = hist + (uint64_t)blockIdx.x * B;
@@ -187,35 +203,26 @@ __global__ void __launch_bounds__(kPartThreads) k_part_scatter(const float* __re
     __syncthreads();
     uint64_t lo, hi;
     wg_range(n, gridDim.x, blockIdx.x, lo, hi);
-    for (uint64_t i = lo + threadIdx.x; i < hi; i += kPartThreads) {
-        const float* p = xyz + i * STRIDE_FLOATS;
-        const float px = p[0], py = p[1], pz = p[2];
+    const uint64_t hi_round = lo + ((hi - lo + 63) & ~63ull);
+    for (uint64_t i = lo + threadIdx.x; i < hi_round; i += kPartThreads) {
+        const bool live = i < hi;
+        float px = 0.f, py = 0.f, pz = 0.f;
+        if (live) { const float* p = xyz + i * STRIDE_FLOATS; px = p[0]; py = p[1]; pz = p[2]; }
         PointKey k = point_key(px, py, pz, P.ox, P.oy, P.oz, P.grid_len, P.z_len);
-        if (!k.ok) continue;
-        const uint32_t pos = atomicAdd(&cur[bucket_of(column_hash(k.sx, k.sy), B)], 1u);
-        recs[pos] = make_float4(px, py, pz, __uint_as_float(first_base + (uint32_t)i));
+        const bool use = live && k.ok;
+        const bool same = wave_all_identical(px, py, pz, use);
+        if (use && (!same || (threadIdx.x & 63) == 0)) {
+            const uint32_t pos = atomicAdd(&cur[bucket_of(column_hash(k.sx, k.sy), B)], 1u);
+            // bit 31 of the index word marks a record that stands for 64 identical points (lane 0 = the first of them)
+            const uint32_t idx = (first_base + (uint32_t)i) | (same ? kWeight64Flag : 0u);
+            recs[pos] = make_float4(px, py, pz, __uint_as_float(idx));
+        }
     }
 }
 
 // ---------------------------------------------------------------------------------------------
 // pass 3: one workgroup per bucket
 // ---------------------------------------------------------------------------------------------
-template <int kBucketSlots>
-struct BucketLds {
-    unsigned long long key[kBucketSlots];
-    double sum[9][kBucketSlots];
-    uint32_t cnt[kBucketSlots];
-    uint32_t first[kBucketSlots];
-    float mean_z[kBucketSlots];
-    uint32_t flags[kBucketSlots];          // bits 0..2 GNDT_FLAG_*, bits 8.. column slot
-    unsigned long long ckey[kBucketSlots]; // column table
-    uint32_t cfirst[kBucketSlots];
-    uint32_t ccnt[kBucketSlots];
-    unsigned long long okey[kBucketSlots]; // sort list: (column first << 32) | node first
-    uint32_t oslot[kBucketSlots];
-    uint32_t n_nodes, n_list, stage_base, overflow;
-};
-
 // LDS open-addressing helpers.  They take the __shared__ arrays by reference to their element type's
 // address space (template on the array) so that the compiler keeps ds_* instructions; a generic
 // `volatile T*` parameter makes it fall back to flat_* loads.  A stale non-empty key cannot exist (keys
@@ -245,235 +252,6 @@ __device__ __forceinline__ uint32_t lds_find(const KeyArray& keys, uint32_t star
         slot = (slot + 1) & (kBucketSlots - 1);
     }
     return kBucketSlots;
-}
-
-template <int kBucketThreads, int kBucketSlots>
-__global__ void __launch_bounds__(kBucketThreads) k_bucket_build(const float4* __restrict__ recs,
-                                                                 const uint32_t* __restrict__ bucket_base, GridParams P,
-                                                                 StageRow* __restrict__ stage, uint32_t stage_cap,
-                                                                 uint32_t* __restrict__ ord_cf, uint32_t* __restrict__ ord_idx,
-                                                                 uint32_t* __restrict__ ord_ncol, uint32_t* __restrict__ bitmap,
-                                                                 Counters* __restrict__ cnt, PartCounters* __restrict__ pc,
-                                                                 unsigned long long* __restrict__ dbg) {
-    __shared__ BucketLds<kBucketSlots> L;
-    constexpr int kBucketFill = (kBucketSlots * 25) / 32;
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    // diagnostic phase stamps (shader clock), only when the host passes a buffer: [bucket][8]
-#define GNDT_STAMP(k) do { if (dbg && tid == 0) dbg[(size_t)blockIdx.x * 16 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
-    GNDT_STAMP(0);
-    // ---- P0: clear ----
-    for (int s = tid; s < kBucketSlots; s += kBucketThreads) {
-        L.key[s] = kEmptyKey;
-        L.ckey[s] = kEmptyKey;
-#pragma unroll
-        for (int j = 0; j < 9; ++j) L.sum[j][s] = 0.0;
-        L.cnt[s] = 0; L.first[s] = 0xFFFFFFFFu;
-        L.cfirst[s] = 0xFFFFFFFFu; L.ccnt[s] = 0;
-    }
-    if (tid == 0) { L.n_nodes = 0; L.n_list = 0; L.stage_base = 0; L.overflow = 0; }
-    __syncthreads();
-
-    GNDT_STAMP(1);
-    // ---- P1: accumulate this bucket's records into the LDS table ----
-    const uint32_t lo = bucket_base[blockIdx.x], hi = bucket_base[blockIdx.x + 1];
-    const uint32_t span = hi - lo;
-    const uint32_t span_round = (span + 63u) & ~63u;
-    // software pipeline: the next record is in flight while this one goes through the LDS atomics
-    float4 nxt = make_float4(0.f, 0.f, 0.f, 0.f);
-    if ((uint32_t)tid < span) nxt = recs[lo + tid];
-    for (uint32_t off = tid; off < span_round; off += kBucketThreads) {
-        const bool live = off < span;
-        const float4 r = nxt;
-        if (off + kBucketThreads < span) nxt = recs[lo + off + kBucketThreads];
-        PointKey k = point_key(r.x, r.y, r.z, P.ox, P.oy, P.oz, P.grid_len, P.z_len);
-        const uint64_t key = live ? pack_key(k.sx, k.sy, k.sz) : kEmptyKey;
-        double v0 = 0, v1 = 0, v2 = 0;
-        if (live) {
-            v0 = (double)r.x - axis_centre(k.sx, P.ox, P.grid_len);
-            v1 = (double)r.y - axis_centre(k.sy, P.oy, P.grid_len);
-            v2 = (double)r.z - axis_centre(k.sz, P.oz, P.z_len);
-        }
-        double q[9] = {v0, v1, v2, v0 * v0, v0 * v1, v0 * v2, v1 * v1, v1 * v2, v2 * v2};
-        uint32_t pidx = __float_as_uint(r.w);
-        const uint32_t h = node_slot_hash(column_hash(k.sx, k.sy), k.sz);
-        const uint64_t key0 = ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(key >> 32)) << 32) |
-                              (uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)key);
-        const bool uniform = __all(live && key == key0);
-        if (uniform) {
-#pragma unroll
-            for (int j = 0; j < 9; ++j) q[j] = wave_sum(q[j]);
-            for (int o = 32; o > 0; o >>= 1) pidx = min(pidx, (uint32_t)__shfl_down((int)pidx, o, 64));
-            if (lane == 0) {
-                const uint32_t s = lds_find_or_insert<kBucketSlots>(L.key, h, key, &L.n_nodes);
-                if (s >= kBucketSlots) L.overflow = 1;
-                else {
-#pragma unroll
-                    for (int j = 0; j < 9; ++j) atomicAdd(&L.sum[j][s], q[j]);
-                    atomicAdd(&L.cnt[s], 64u);
-                    atomicMin(&L.first[s], pidx);
-                }
-            }
-        } else if (live) {
-            const uint32_t s = lds_find_or_insert<kBucketSlots>(L.key, h, key, &L.n_nodes);
-            if (s >= kBucketSlots) L.overflow = 1;
-            else {
-#pragma unroll
-                for (int j = 0; j < 9; ++j) atomicAdd(&L.sum[j][s], q[j]);
-                atomicAdd(&L.cnt[s], 1u);
-                atomicMin(&L.first[s], pidx);
-            }
-        }
-    }
-    __syncthreads();
-    if (L.overflow || L.n_nodes > (uint32_t)kBucketFill) {   // uniform across the block
-        if (tid == 0) atomicAdd(&pc->lds_overflow, 1u);
-        return;
-    }
-
-    GNDT_STAMP(2);
-    // Reserve this bucket's staging rows now (one memory-side atomic per bucket): its ~microsecond round trip
-    // hides behind P2..P4; the value is only parked in LDS right before the barrier that precedes its use.
-    uint32_t stage_base_reg = 0;
-    if (tid == kBucketThreads - 1) stage_base_reg = atomicAdd(&cnt->num_nodes, L.n_nodes);
-    // ---- P2: per node: fp32 mean-z for the slope test, column registration ----
-    for (int s = tid; s < kBucketSlots; s += kBucketThreads) {
-        const uint64_t key = L.key[s];
-        if (key == kEmptyKey) continue;
-        int sx, sy, sz;
-        unpack_key(key, sx, sy, sz);
-        const uint32_t n = L.cnt[s];
-        uint32_t fl = 0;
-        float mz = 0.f;
-        if (n >= (uint32_t)P.min_points) {
-            mz = node_mean_z(n, L.sum[2][s], axis_centre(sz, P.oz, P.z_len));
-            fl = 1u;
-        }
-        L.mean_z[s] = mz;
-        const uint32_t cs = lds_find_or_insert<kBucketSlots>(L.ckey, column_hash(sx, sy) * 0x85EBCA77u >> 12, column_key(key), nullptr);
-        // the column table has as many slots as the node table and at most as many entries: never full
-        atomicMin(&L.cfirst[cs], L.first[s]);
-        atomicAdd(&L.ccnt[cs], 1u);
-        L.flags[s] = fl | (cs << 8);
-    }
-    __syncthreads();
-
-    GNDT_STAMP(3);
-    // ---- P3: slope labels (OcNode::isSlope, map2D.h:66-108) + sort list ----
-    uint32_t my_slopes = 0;
-    for (int s = tid; s < kBucketSlots; s += kBucketThreads) {
-        const uint64_t key = L.key[s];
-        if (key == kEmptyKey) continue;
-        uint32_t fl = L.flags[s];
-        const uint32_t cs = fl >> 8;
-        const uint32_t my_first = L.first[s];
-        if (fl & 1u) {
-            bool slope = true, down = false;
-            if (P.demand == 0) {
-                int sx, sy, sz;
-                unpack_key(key, sx, sy, sz);
-                const uint32_t ch = column_hash(sx, sy);
-                const float cz = L.mean_z[s];
-                bool up = false;
-                int za = level_above(sz), zb = level_below(sz);
-                uint32_t t = lds_find<kBucketSlots>(L.key, node_slot_hash(ch, za), pack_key(sx, sy, za));
-                if (t < kBucketSlots) {
-                    const bool visited = L.first[t] < my_first && (L.flags[t] & 1u);
-                    const float oz = visited ? L.mean_z[t] : 0.f;
-                    if (fabsf(oz - cz) > P.slope_interval) up = true;
-                }
-                t = lds_find<kBucketSlots>(L.key, node_slot_hash(ch, zb), pack_key(sx, sy, zb));
-                if (t < kBucketSlots) {
-                    const bool visited = L.first[t] < my_first && (L.flags[t] & 1u);
-                    const float oz = visited ? L.mean_z[t] : 0.f;
-                    if (fabsf(oz - cz) > P.slope_interval) down = true;
-                }
-                slope = !up;
-            }
-            if (slope) { fl |= 2u; if (down) fl |= 4u; ++my_slopes; }
-        }
-        const uint32_t pos = atomicAdd(&L.n_list, 1u);
-        L.okey[pos] = ((uint64_t)L.cfirst[cs] << 32) | (uint64_t)my_first;
-        L.oslot[pos] = (uint32_t)s | ((fl & 7u) << 16);   // flags bits 0..2 ride along (slot < 1024)
-    }
-    __syncthreads();
-    // NOTE: L.flags of OTHER slots is read above (bit 0 only) while this loop rewrites nothing in it.
-
-    GNDT_STAMP(4);
-    // ---- P4: reserve the staging rows (one memory-side atomic per bucket, issued early so that its
-    //          round trip hides behind the ranking loop) ----
-    const uint32_t M = L.n_list;          // == L.n_nodes: every occupied slot is listed
-
-    // ---- P5: rank by counting instead of sorting.  Keys (column first-seen, node first-seen) are
-    //          unique, so   rank = #{keys below mine}   is the node's row in in-bucket reference order and
-    //          idx_in_col = #{keys below mine in my column}.  Every lane reads the same okey[j]: LDS broadcast.
-    uint32_t my_cols = 0;
-    uint32_t rank[(kBucketSlots + kBucketThreads - 1) / kBucketThreads];
-    uint32_t icol[(kBucketSlots + kBucketThreads - 1) / kBucketThreads];
-    {
-        int it = 0;
-        for (uint32_t i = tid; i < M; i += kBucketThreads, ++it) {
-            const unsigned long long mine = L.okey[i];
-            const uint32_t cf = (uint32_t)(mine >> 32);
-            uint32_t r = 0, c = 0;
-#pragma unroll 8
-            for (uint32_t j = 0; j < M; ++j) {
-                const unsigned long long o = L.okey[j];
-                const bool below = o < mine;
-                r += below ? 1u : 0u;
-                c += (below && (uint32_t)(o >> 32) == cf) ? 1u : 0u;
-            }
-            rank[it] = r; icol[it] = c;
-        }
-    }
-    if (tid == kBucketThreads - 1) L.stage_base = stage_base_reg;
-    __syncthreads();
-    GNDT_STAMP(5);
-    const uint32_t base = L.stage_base;
-    if (base + M > stage_cap) {               // uniform
-        if (tid == 0) atomicAdd(&pc->stage_overflow, M);
-        return;
-    }
-    {
-        int it = 0;
-        for (uint32_t i = tid; i < M; i += kBucketThreads, ++it) {
-            const uint32_t packed = L.oslot[i];
-            const uint32_t s = packed & 0xFFFFu, fl = (packed >> 16) & 7u;
-            const uint64_t key = L.key[s];
-            const uint32_t cf = (uint32_t)(L.okey[i] >> 32);
-            const uint32_t idx_in_col = icol[it];
-            const uint32_t cs = L.flags[s] >> 8;
-            StageRow row;
-            unpack_key(key, row.sx, row.sy, row.sz);
-            row.count = L.cnt[s]; row.first = L.first[s]; row.flags = fl;
-            for (int k = 0; k < 3; ++k) row.mean[k] = 0.f;
-            for (int k = 0; k < 6; ++k) row.scatter[k] = 0.0;
-            if (fl & 1u) {
-                double sums[9];
-#pragma unroll
-                for (int j = 0; j < 9; ++j) sums[j] = L.sum[j][s];
-                const double c[3] = {axis_centre(row.sx, P.ox, P.grid_len), axis_centre(row.sy, P.oy, P.grid_len),
-                                     axis_centre(row.sz, P.oz, P.z_len)};
-                node_moments(row.count, sums, c, row.mean, row.scatter);
-            }
-            row.col_first = cf; row.idx_in_col = idx_in_col; row.ncol = L.ccnt[cs];
-            for (int k = 0; k < 8; ++k) row.pad[k] = 0;
-            const uint32_t dst = base + rank[it];
-            stage[dst] = row;
-            ord_cf[dst] = cf;
-            ord_idx[dst] = idx_in_col;
-            if (idx_in_col == 0) {
-                ord_ncol[dst] = row.ncol;
-                atomicOr(&bitmap[cf >> 5], 1u << (cf & 31u));
-                ++my_cols;
-            }
-        }
-    }
-    if (my_slopes) atomicAdd(&cnt->num_slopes, my_slopes);
-    if (my_cols) atomicAdd(&cnt->num_columns, my_cols);
-    __syncthreads();
-    GNDT_STAMP(6);
-#undef GNDT_STAMP
 }
 
 // ---------------------------------------------------------------------------------------------

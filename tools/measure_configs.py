@@ -1,0 +1,107 @@
+#!/usr/bin/env python3
+"""Measure the BASELINE.json configurations other than the bench line
+on one MI355X and print a JSON document.  Not part of bench.py's contract; the output is kept under profiles/.
+
+    python tools/measure_configs.py [--terrain-points 32000000] [--frames 100] > gpurun_out/configs.json
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def timed_builds(g, torch, cloud, P, steps=10, warmup=2, hint=0, strategy=0):
+    m = g.TwoDmap(P["grid_len"], P["z_len"], max_nodes_hint=hint, strategy=strategy)
+    m.setInterval(P["slope_interval"])
+    m.setCloudFirst(cloud[0])
+    pts = torch.from_numpy(np.ascontiguousarray(cloud[1:])).cuda()
+    for _ in range(warmup):
+        m.create2DMap(P.get("demand", "slope"), pts)
+    m.sync()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        m.create2DMap(P.get("demand", "slope"), pts)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    nodes, cols, slopes = m.sync()
+    n = cloud.shape[0] - 1
+    bytes_alg = 12 * n + 76 * nodes
+    return {"points": n, "nodes": int(nodes), "columns": int(cols), "slopes": int(slopes), "ms_per_build": round(dt * 1e3, 4),
+            "Mpoints_per_s": round(n / dt / 1e6, 1), "strategy": m.STRATEGY_NAMES[m.last_strategy()],
+            "path_GBps": round(bytes_alg / dt / 1e9, 1), "path_frac_of_8TBps": round(bytes_alg / dt / 8e12, 4)}, m
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--terrain-points", type=int, default=32_000_000)
+    ap.add_argument("--frames", type=int, default=100)
+    a = ap.parse_args()
+    import torch
+    import grid_ndt_amd as g
+    from tests import parity, scenes
+    g.build_native()
+    out = {"device": g.device_info(0)}
+
+    # S1: single ~200 k frame + the reference's own bridge_ground scene, checked against the oracle
+    for name, cloud, P in (("S1_campus_200k", scenes.campus_frame(200000), scenes.CAMPUS_PARAMS),
+                           ("S1_bridge_ground", scenes.bridge_ground(), scenes.BRIDGE_PARAMS)):
+        r, m = timed_builds(g, torch, cloud, P, steps=20)
+        r["parity_vs_oracle"] = parity.compare(m.export(), parity.ref_from_cloud(cloud, P))["ok"]
+        out[name] = r
+
+    # S2 and its launch-default z variant (zLen 0.1: ~3.2 M nodes, ~3 points per node)
+    cloud = scenes.uniform_box(10_000_001)
+    out["S2_uniform_10M_cubic"], _ = timed_builds(g, torch, cloud, dict(grid_len=0.5, z_len=0.5, slope_interval=0.08), hint=1 << 20)
+    out["S2_uniform_10M_z01"], _ = timed_builds(g, torch, cloud, dict(grid_len=0.5, z_len=0.1, slope_interval=0.08), hint=3_400_000)
+    del cloud
+
+    # S3 on one GPU: LiDAR-ordered terrain, 0.2 m cubic voxels
+    t0 = time.perf_counter()
+    cloud = scenes.terrain_cloud(a.terrain_points)
+    gen = time.perf_counter() - t0
+    r, _ = timed_builds(g, torch, cloud, dict(grid_len=0.2, z_len=0.2, slope_interval=0.08), steps=5)
+    r["scene_generation_s"] = round(gen, 1)
+    out[f"S3_terrain_{a.terrain_points // 1_000_000}M_1gpu"] = r
+
+    # S4: streaming 10 Hz frames of 131 072 points, incremental update per frame (strategy ATOMIC keeps the
+    # additive statistics); latency per frame = accumulate + re-finalise of the whole map
+    frames = scenes.terrain_frames(a.frames, first_pose=0)
+    m = g.TwoDmap(0.2, 0.2, strategy=1, max_nodes_hint=4_000_000)
+    m.setInterval(0.08)
+    m.setCloudFirst(frames[0])
+    lat = []
+    ppf = scenes.FRAME_POINTS
+    dev_frames = [torch.from_numpy(frames[f * ppf:(f + 1) * ppf]).cuda() for f in range(a.frames)]
+    torch.cuda.synchronize()
+    for f in range(a.frames):
+        t0 = time.perf_counter()
+        m.change2DMap("slope", dev_frames[f])
+        m.sync()
+        lat.append((time.perf_counter() - t0) * 1e3)
+    nodes, cols, slopes = m.sync()
+    lat_s = np.sort(np.array(lat[5:]))
+    out["S4_streaming_128k_frames"] = {"frames": a.frames, "points_per_frame": ppf, "final_nodes": int(nodes),
+                                       "latency_ms_p50": round(float(np.percentile(lat_s, 50)), 3),
+                                       "latency_ms_p99": round(float(np.percentile(lat_s, 99)), 3),
+                                       "latency_ms_max": round(float(lat_s.max()), 3), "budget_ms": 100.0,
+                                       "Mpoints_per_s_at_p50": round(ppf / np.percentile(lat_s, 50) / 1e3, 1),
+                                       "note": "host-timed incl. the per-frame sync; not hipGraph-captured yet"}
+    del m, dev_frames
+
+    # S5 stand-in: two-storey site, 15 % of the points at (0,0,0) (the converters' pre-allocated clouds)
+    cloud = scenes.site_two_storey(20_000_000)
+    r, _ = timed_builds(g, torch, cloud, dict(grid_len=0.1, z_len=0.1, slope_interval=0.08), steps=5)
+    r["max_points_in_one_node"] = 3_000_000
+    out["S5_site_20M_zero_padded"] = r
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()
