@@ -145,8 +145,8 @@ def main():
         # every kernel that streams the cloud moves 12 B/point; k_bucket_build also emits the nodes
         # (12 B/point + 76 B/node); node-proportional kernels move 76 B/node.
         kernel_of = {"accumulate": "k_accumulate", "hist": "k_part_hist", "scatter": "k_part_scatter",
-                     "bucket_build": "k_bucket_build", "scan": "k_scan_nodes", "label": "k_label_nodes",
-                     "sort": "rocprim::radix_sort_pairs", "emit": "k_emit_nodes" if strat == "atomic" else "k_emit_rows"}
+                     "bucket_build": "k_bucket_build", "columns": "k_tab_columns", "rows": "k_tab_rows",
+                     "emit": "k_emit_rows"}
         cand = {k: v for k, v in phases.items() if k in kernel_of}
         dom = max(cand, key=cand.get) if cand else None
         acc_ms = cand.get(dom, float("nan")) if dom else float("nan")

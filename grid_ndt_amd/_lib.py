@@ -11,7 +11,7 @@ _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 _ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.path.join(_CSRC, "libgndt.so")
 SOURCES = ["gndt_api.hip", "gndt_codec.cpp"]
-HEADERS = ["gndt_kernels.hpp", "gndt_partition.hpp", "gndt_bucket.hpp", "gndt_math.hpp", os.path.join(_ROOT, "include", "gndt.h")]
+HEADERS = ["gndt_kernels.hpp", "gndt_table.hpp", "gndt_partition.hpp", "gndt_bucket.hpp", "gndt_math.hpp", os.path.join(_ROOT, "include", "gndt.h")]
 
 GNDT_OK = 0
 ERR_NAMES = {0: "OK", 1: "INVALID", 2: "NO_DEVICE", 3: "HIP", 4: "KEY_RANGE", 5: "CAPACITY", 6: "NOMEM"}

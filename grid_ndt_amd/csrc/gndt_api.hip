@@ -11,12 +11,12 @@
 #include <cstdlib>
 
 #include <hip/hip_runtime.h>
-#include <rocprim/device/device_radix_sort.hpp>
 
 #include "gndt.h"
 #include "gndt_kernels.hpp"
 #include "gndt_partition.hpp"
 #include "gndt_bucket.hpp"
+#include "gndt_table.hpp"
 
 using namespace gndt;
 
@@ -42,12 +42,9 @@ struct gndt_handle {
     // node list + ordering buffers (cap entries each)
     uint32_t* node_slot = nullptr;
     uint32_t* col_slot_of_node = nullptr;
-    uint64_t* sort_key = nullptr;
-    uint64_t* sort_key_out = nullptr;
-    uint32_t* sort_val = nullptr;
-    uint32_t* sort_val_out = nullptr;
-    void* sort_tmp = nullptr;
-    size_t sort_tmp_bytes = 0;
+    uint32_t* col_cnt = nullptr;
+    uint32_t* col_head = nullptr;
+    uint32_t* node_next = nullptr;
 
     Counters* d_cnt = nullptr;
     Counters* h_cnt = nullptr;  // pinned
@@ -69,9 +66,9 @@ struct gndt_handle {
     void* stage = nullptr;
     size_t stage_bytes = 0;
 
-    uint64_t stream_pos = 0;    // points accumulated since the last reset (first_idx base)
+    uint64_t stream_pos = 0;    // points accumulated since the last reset (host mirror of the device-side first_idx base)
+    uint64_t nodes_bound = 0;   // host-side upper bound of the nodes in the table (no sync needed to size buffers)
     bool table_dirty = false;   // table holds nodes
-    bool list_valid = false;    // node_slot / col_slot_of_node describe the table's occupied slots
 
     // strategy PARTITION buffers (gndt_partition.hpp)
     struct Part {
@@ -138,39 +135,32 @@ GridParams grid_params(const gndt_handle* h) {
 
 void free_table(gndt_handle* h) {
     void* ptrs[] = {h->keys, h->acc, h->col_keys, h->col_first, h->aux, h->node_slot, h->col_slot_of_node,
-                    h->sort_key, h->sort_key_out, h->sort_val, h->sort_val_out, h->sort_tmp};
+                    h->col_cnt, h->col_head, h->node_next};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     h->keys = nullptr; h->acc = nullptr; h->col_keys = nullptr; h->col_first = nullptr; h->aux = nullptr;
-    h->node_slot = nullptr; h->col_slot_of_node = nullptr; h->sort_key = nullptr; h->sort_key_out = nullptr;
-    h->sort_val = nullptr; h->sort_val_out = nullptr; h->sort_tmp = nullptr;
+    h->node_slot = nullptr; h->col_slot_of_node = nullptr; h->col_cnt = nullptr; h->col_head = nullptr; h->node_next = nullptr;
     h->cap = 0;
 }
 
+// A fresh, empty table of `cap` slots.  The device counters are NOT touched: the caller decides (reset vs growth).
 int alloc_table(gndt_handle* h, uint32_t cap, hipStream_t s) {
     free_table(h);
     HIP_TRY(h, hipMalloc(&h->keys, (size_t)cap * sizeof(uint64_t)));
     HIP_TRY(h, hipMalloc(&h->acc, (size_t)cap * sizeof(NodeAcc)));
     HIP_TRY(h, hipMalloc(&h->col_keys, (size_t)cap * sizeof(uint64_t)));
     HIP_TRY(h, hipMalloc(&h->col_first, (size_t)cap * sizeof(uint32_t)));
+    HIP_TRY(h, hipMalloc(&h->col_cnt, (size_t)cap * sizeof(uint32_t)));
+    HIP_TRY(h, hipMalloc(&h->col_head, (size_t)cap * sizeof(uint32_t)));
     HIP_TRY(h, hipMalloc(&h->aux, (size_t)cap * sizeof(SlotAux)));
     HIP_TRY(h, hipMalloc(&h->node_slot, (size_t)cap * sizeof(uint32_t)));
     HIP_TRY(h, hipMalloc(&h->col_slot_of_node, (size_t)cap * sizeof(uint32_t)));
-    HIP_TRY(h, hipMalloc(&h->sort_key, (size_t)cap * sizeof(uint64_t)));
-    HIP_TRY(h, hipMalloc(&h->sort_key_out, (size_t)cap * sizeof(uint64_t)));
-    HIP_TRY(h, hipMalloc(&h->sort_val, (size_t)cap * sizeof(uint32_t)));
-    HIP_TRY(h, hipMalloc(&h->sort_val_out, (size_t)cap * sizeof(uint32_t)));
-    size_t tmp = 0;
-    HIP_TRY(h, rocprim::radix_sort_pairs(nullptr, tmp, h->sort_key, h->sort_key_out, h->sort_val, h->sort_val_out,
-                                         (size_t)cap, 0, 64, s));
-    h->sort_tmp_bytes = tmp;
-    HIP_TRY(h, hipMalloc(&h->sort_tmp, tmp ? tmp : 16));
+    HIP_TRY(h, hipMalloc(&h->node_next, (size_t)cap * sizeof(uint32_t)));
     h->cap = cap;
     hipLaunchKernelGGL(k_clear_all, dim3(grid_for(cap)), dim3(kBlock), 0, s, h->keys, h->acc, h->col_keys,
-                       h->col_first, cap);
+                       h->col_first, h->col_cnt, h->col_head, cap);
     HIP_TRY(h, hipGetLastError());
     h->table_dirty = false;
-    h->list_valid = false;
     return GNDT_OK;
 }
 
@@ -229,146 +219,8 @@ int check_ready(gndt_handle* h) {
     return GNDT_OK;
 }
 
-int do_reset(gndt_handle* h, hipStream_t s) {
-    if (h->cap && h->table_dirty) {
-        if (h->list_valid) {
-            hipLaunchKernelGGL(k_clear_used, dim3(grid_for(h->cap / 8)), dim3(kBlock), 0, s, h->keys, h->acc, h->col_keys,
-                               h->col_first, h->node_slot, h->col_slot_of_node, h->d_cnt);
-        } else {
-            hipLaunchKernelGGL(k_clear_all, dim3(grid_for(h->cap)), dim3(kBlock), 0, s, h->keys, h->acc, h->col_keys,
-                               h->col_first, h->cap);
-        }
-        HIP_TRY(h, hipGetLastError());
-    }
-    hipLaunchKernelGGL(k_zero_counters, dim3(1), dim3(64), 0, s, h->d_cnt, 1);
-    HIP_TRY(h, hipGetLastError());
-    h->table_dirty = false;
-    h->list_valid = false;
-    h->results_valid = false;
-    h->stream_pos = 0;
-    return GNDT_OK;
-}
-
-// Grow the table to `new_cap` slots keeping its contents (export -> fresh table -> merge).
-int grow_table(gndt_handle* h, uint32_t new_cap, hipStream_t s);
-
-int do_scan(gndt_handle* h, hipStream_t s) {
-    hipLaunchKernelGGL(k_zero_counters, dim3(1), dim3(64), 0, s, h->d_cnt, 0);
-    hipLaunchKernelGGL(k_scan_nodes, dim3(grid_for(h->cap)), dim3(kBlock), 0, s, h->keys, h->acc, h->col_keys,
-                       h->col_first, h->node_slot, h->col_slot_of_node, h->aux, h->cap - 1, grid_params(h), h->d_cnt);
-    HIP_TRY(h, hipGetLastError());
-    h->list_valid = true;
-    return GNDT_OK;
-}
-
-int do_accumulate(gndt_handle* h, const void* xyz_dev, size_t n, size_t stride_bytes, uint64_t first_base,
-                  hipStream_t s) {
-    if (stride_bytes != 12 && stride_bytes != 16) { h->err = "stride_bytes must be 12 or 16"; return GNDT_ERR_INVALID; }
-    if (first_base + n >= 0xFFFFFFFFull) { h->err = "point index exceeds 32 bits"; return GNDT_ERR_INVALID; }
-    if (n == 0) return GNDT_OK;
-    const float* p = static_cast<const float*>(xyz_dev);
-    const int blocks = grid_for(n, kBlock, 256 * 16);
-    if (stride_bytes == 12)
-        hipLaunchKernelGGL(k_accumulate<3>, dim3(blocks), dim3(kBlock), 0, s, p, (uint64_t)n, (uint32_t)first_base,
-                           grid_params(h), h->keys, h->acc, h->cap - 1, h->d_cnt);
-    else
-        hipLaunchKernelGGL(k_accumulate<4>, dim3(blocks), dim3(kBlock), 0, s, p, (uint64_t)n, (uint32_t)first_base,
-                           grid_params(h), h->keys, h->acc, h->cap - 1, h->d_cnt);
-    HIP_TRY(h, hipGetLastError());
-    h->table_dirty = true;
-    h->list_valid = false;
-    h->results_valid = false;
-    return GNDT_OK;
-}
-
-// scan -> label -> order -> emit.  Synchronises once (the sort needs the node count on the host).
-int do_finalize(gndt_handle* h, hipStream_t s) {
-    int rc = do_scan(h, s);
-    if (rc) return rc;
-    mark(h, 3, s);
-    rc = fetch_counters(h, s);
-    if (rc) return rc;
-    if (h->h_cnt->err_table_full) {
-        h->err = "node table full (" + std::to_string(h->cap) + " slots): raise gndt_params.max_nodes_hint";
-        return GNDT_ERR_CAPACITY;
-    }
-    const uint32_t C = h->h_cnt->num_nodes;
-    rc = ensure_out(h, C);
-    if (rc) return rc;
-    if (C > 0) {
-        const GridParams gp = grid_params(h);
-        hipLaunchKernelGGL(k_label_nodes, dim3(grid_for(C)), dim3(kBlock), 0, s, h->keys, h->acc, h->col_first,
-                           h->node_slot, h->col_slot_of_node, h->aux, h->sort_key, h->sort_val, h->cap - 1, gp, h->d_cnt);
-        HIP_TRY(h, hipGetLastError());
-        mark(h, 4, s);
-        size_t tmp = h->sort_tmp_bytes;
-        HIP_TRY(h, rocprim::radix_sort_pairs(h->sort_tmp, tmp, h->sort_key, h->sort_key_out, h->sort_val,
-                                             h->sort_val_out, (size_t)C, 0, 64, s));
-        mark(h, 5, s);
-        hipLaunchKernelGGL(k_emit_nodes, dim3(grid_for(C)), dim3(kBlock), 0, s, h->keys, h->acc, h->aux, h->sort_val_out,
-                           h->out, gp, h->d_cnt);
-        HIP_TRY(h, hipGetLastError());
-        mark(h, 6, s);
-    }
-    HIP_TRY(h, hipMemcpyAsync(h->h_cnt, h->d_cnt, sizeof(Counters), hipMemcpyDeviceToHost, s));
-    h->results_valid = true;
-    h->last_stream = s;
-    return GNDT_OK;
-}
-
-int ensure_capacity_for(gndt_handle* h, uint64_t expected_nodes, hipStream_t s) {
-    const uint32_t want = cap_for_nodes(expected_nodes);
-    if (h->cap == 0) return alloc_table(h, want, s);
-    if (want > h->cap) return grow_table(h, want, s);
-    return GNDT_OK;
-}
-
-int grow_table(gndt_handle* h, uint32_t new_cap, hipStream_t s) {
-    if (!h->table_dirty) return alloc_table(h, new_cap, s);
-    // export current contents
-    int rc = GNDT_OK;
-    if (!h->list_valid) { rc = do_scan(h, s); if (rc) return rc; }
-    rc = fetch_counters(h, s);
-    if (rc) return rc;
-    const uint32_t C = h->h_cnt->num_nodes;
-    rc = ensure_stats_buffers(h, C);
-    if (rc) return rc;
-    if (C) {
-        hipLaunchKernelGGL(k_stats_export, dim3(grid_for(C)), dim3(kBlock), 0, s, h->keys, h->acc, h->node_slot, h->d_cnt,
-                           h->st_key, h->st_sums, h->st_count, h->st_first);
-        HIP_TRY(h, hipGetLastError());
-    }
-    HIP_TRY(h, hipStreamSynchronize(s));
-    rc = alloc_table(h, new_cap, s);
-    if (rc) return rc;
-    if (C) {
-        hipLaunchKernelGGL(k_stats_merge, dim3(grid_for(C)), dim3(kBlock), 0, s, h->keys, h->acc, h->cap - 1, h->st_key,
-                           h->st_sums, h->st_count, h->st_first, (uint64_t)C, h->d_cnt);
-        HIP_TRY(h, hipGetLastError());
-        h->table_dirty = true;
-    }
-    return GNDT_OK;
-}
-
-uint64_t expected_nodes_for_batch(const gndt_handle* h, uint64_t known_nodes, uint64_t n) {
-    if (h->P.max_nodes_hint) return std::max<uint64_t>(h->P.max_nodes_hint, known_nodes);
-    return known_nodes + n;   // worst case: every point opens a node
-}
-
-int stage_host_input(gndt_handle* h, const void* xyz_host, size_t n, size_t stride_bytes, hipStream_t s) {
-    const size_t bytes = n * stride_bytes;
-    if (bytes > h->stage_bytes) {
-        if (h->stage) (void)hipFree(h->stage);
-        h->stage = nullptr; h->stage_bytes = 0;
-        HIP_TRY(h, hipMalloc(&h->stage, bytes + 64));
-        h->stage_bytes = bytes;
-    }
-    if (bytes) HIP_TRY(h, hipMemcpyAsync(h->stage, xyz_host, bytes, hipMemcpyHostToDevice, s));
-    return GNDT_OK;
-}
-
 // ---------------------------------------------------------------------------------------------
-// strategy PARTITION (gndt_partition.hpp)
+// buffers shared by both strategies' finalisation: staging rows, ordering arrays, column-first bitmap
 // ---------------------------------------------------------------------------------------------
 template <typename T>
 int grow_buf(gndt_handle* h, T*& p, uint64_t& cap, uint64_t want) {
@@ -408,6 +260,211 @@ int ensure_stage(gndt_handle* h, uint64_t nodes) {
 
 // Bucket count: ~4096 points per bucket, and few enough nodes per bucket for the LDS table
 // (average load <= 0.3 of `slots`, which leaves room for the spread of a hash partition).
+int ensure_words(gndt_handle* h, uint64_t words) {
+    auto& q = h->part;
+    if (words <= q.word_cap) return GNDT_OK;
+    for (uint32_t** a : {&q.bitmap, &q.word_prefix, &q.bsum_words}) { if (*a) (void)hipFree(*a); *a = nullptr; }
+    q.word_cap = 0;
+    words += words / 4;
+    HIP_TRY(h, hipMalloc(&q.bitmap, words * 4));
+    HIP_TRY(h, hipMalloc(&q.word_prefix, words * 4));
+    HIP_TRY(h, hipMalloc(&q.bsum_words, ((words + kScanChunk - 1) / kScanChunk + 1) * 4));
+    q.word_cap = words;
+    return GNDT_OK;
+}
+
+int ensure_part_counters(gndt_handle* h) {
+    auto& q = h->part;
+    if (q.d_pc) return GNDT_OK;
+    HIP_TRY(h, hipMalloc(&q.d_pc, sizeof(PartCounters)));
+    HIP_TRY(h, hipHostMalloc(&q.h_pc, sizeof(PartCounters)));
+    HIP_TRY(h, hipMemset(q.d_pc, 0, sizeof(PartCounters)));
+    memset(q.h_pc, 0, sizeof(PartCounters));
+    return GNDT_OK;
+}
+
+// bitmap scan -> column rank -> column sizes scan -> row of every staged node -> SoA rows (marks 5..10 with `m0` = 5)
+int launch_order_and_emit(gndt_handle* h, uint64_t words, int m0, hipStream_t s) {
+    auto& q = h->part;
+    const uint32_t nbw = (uint32_t)((words + kScanChunk - 1) / kScanChunk);
+    hipLaunchKernelGGL(k_scan_reduce<true>, dim3(nbw), dim3(kScanThreads), 0, s, q.bitmap, (const uint32_t*)nullptr,
+                       (uint32_t)words, q.bsum_words);
+    hipLaunchKernelGGL(k_scan_apply<true>, dim3(nbw), dim3(kScanThreads), 0, s, q.bitmap, (const uint32_t*)nullptr,
+                       (uint32_t)words, q.bsum_words, q.word_prefix);
+    HIP_TRY(h, hipGetLastError());
+    mark(h, m0 + 1, s);
+    hipLaunchKernelGGL(k_order_rank, dim3(grid_for(q.stage_cap)), dim3(kBlock), 0, s, q.ord_cf, q.ord_idx, q.ord_ncol,
+                       q.bitmap, q.word_prefix, q.col_rank, q.col_size, h->d_cnt, q.d_pc);
+    HIP_TRY(h, hipGetLastError());
+    mark(h, m0 + 2, s);
+    const uint32_t nbc = (uint32_t)((q.stage_cap + kScanChunk - 1) / kScanChunk);
+    hipLaunchKernelGGL(k_scan_reduce<false>, dim3(nbc), dim3(kScanThreads), 0, s, q.col_size, &h->d_cnt->num_columns, 0u,
+                       q.bsum_cols);
+    hipLaunchKernelGGL(k_scan_apply<false>, dim3(nbc), dim3(kScanThreads), 0, s, q.col_size, &h->d_cnt->num_columns, 0u,
+                       q.bsum_cols, q.col_base);
+    HIP_TRY(h, hipGetLastError());
+    mark(h, m0 + 3, s);
+    hipLaunchKernelGGL(k_order_dest, dim3(grid_for(q.stage_cap)), dim3(kBlock), 0, s, q.col_rank, q.ord_idx, q.col_base,
+                       q.inv, h->d_cnt, q.d_pc);
+    HIP_TRY(h, hipGetLastError());
+    mark(h, m0 + 4, s);
+    hipLaunchKernelGGL(k_emit_rows, dim3(grid_for(q.stage_cap)), dim3(kBlock), 0, s, q.stage, q.inv, h->out, h->d_cnt, q.d_pc);
+    HIP_TRY(h, hipGetLastError());
+    mark(h, m0 + 5, s);
+    return GNDT_OK;
+}
+
+TableView table_view(const gndt_handle* h) {
+    TableView T;
+    T.keys = h->keys; T.acc = h->acc; T.aux = h->aux; T.col_keys = h->col_keys; T.col_first = h->col_first;
+    T.col_cnt = h->col_cnt; T.col_head = h->col_head; T.node_slot = h->node_slot; T.col_slot_of_node = h->col_slot_of_node;
+    T.node_next = h->node_next; T.cap_mask = h->cap - 1;
+    return T;
+}
+
+int do_reset(gndt_handle* h, hipStream_t s) {
+    if (h->cap && h->table_dirty) {
+        hipLaunchKernelGGL(k_clear_used, dim3(grid_for(h->cap / 8)), dim3(kBlock), 0, s, h->keys, h->acc, h->col_keys,
+                           h->col_first, h->col_cnt, h->col_head, h->node_slot, h->col_slot_of_node, h->d_cnt);
+        HIP_TRY(h, hipGetLastError());
+    }
+    hipLaunchKernelGGL(k_zero_counters, dim3(1), dim3(64), 0, s, h->d_cnt);
+    HIP_TRY(h, hipGetLastError());
+    h->table_dirty = false;
+    h->results_valid = false;
+    h->stream_pos = 0;
+    h->nodes_bound = 0;
+    return GNDT_OK;
+}
+
+// Grow the table to `new_cap` slots keeping its contents (export -> fresh table -> merge).
+int grow_table(gndt_handle* h, uint32_t new_cap, hipStream_t s);
+
+// `base_from_device`: first_idx base = the device-side stream position (incremental updates)
+int do_accumulate(gndt_handle* h, const void* xyz_dev, size_t n, size_t stride_bytes, uint64_t first_base,
+                  int base_from_device, hipStream_t s) {
+    if (stride_bytes != 12 && stride_bytes != 16) { h->err = "stride_bytes must be 12 or 16"; return GNDT_ERR_INVALID; }
+    if (first_base + n >= 0xFFFFFFFFull) { h->err = "point index exceeds 32 bits"; return GNDT_ERR_INVALID; }
+    if (n == 0) return GNDT_OK;
+    const float* p = static_cast<const float*>(xyz_dev);
+    const int blocks = grid_for(n, kBlock, 256 * 16);
+    if (stride_bytes == 12)
+        hipLaunchKernelGGL(k_accumulate<3>, dim3(blocks), dim3(kBlock), 0, s, p, (uint64_t)n, (uint32_t)first_base,
+                           base_from_device, grid_params(h), h->keys, h->acc, h->cap - 1, h->node_slot, h->d_cnt);
+    else
+        hipLaunchKernelGGL(k_accumulate<4>, dim3(blocks), dim3(kBlock), 0, s, p, (uint64_t)n, (uint32_t)first_base,
+                           base_from_device, grid_params(h), h->keys, h->acc, h->cap - 1, h->node_slot, h->d_cnt);
+    HIP_TRY(h, hipGetLastError());
+    if (base_from_device) {
+        hipLaunchKernelGGL(k_advance_stream, dim3(1), dim3(64), 0, s, h->d_cnt, (uint32_t)n);
+        HIP_TRY(h, hipGetLastError());
+    }
+    h->table_dirty = true;
+    h->results_valid = false;
+    h->nodes_bound = std::min<uint64_t>(h->nodes_bound + n, h->cap);
+    return GNDT_OK;
+}
+
+// columns -> labels + staging rows -> ordering -> emit.  Everything is sized on the device; nothing waits for
+// the host, so accumulate + finalize can be captured in a hipGraph once the buffers exist.
+int do_finalize(gndt_handle* h, hipStream_t s) {
+    auto& q = h->part;
+    int rc;
+    // host-side upper bounds only: rows <= slots/2 at a healthy load; points seen so far (or the caller's hint)
+    const uint64_t rows_bound = std::max<uint64_t>(1024, h->cap / 2 + 1);
+    const uint64_t pts_bound = std::max<uint64_t>(std::max<uint64_t>(h->stream_pos, h->P.max_points_hint), 64);
+    const uint64_t words = (pts_bound + 31) / 32 + 1;
+    if ((rc = ensure_part_counters(h))) return rc;
+    if ((rc = ensure_stage(h, rows_bound))) return rc;
+    if ((rc = ensure_out(h, q.stage_cap))) return rc;
+    if ((rc = ensure_words(h, words))) return rc;
+    const TableView T = table_view(h);
+    const GridParams gp = grid_params(h);
+    mark(h, 2, s);
+    hipLaunchKernelGGL(k_tab_begin, dim3(grid_for(std::max<uint64_t>(words, h->cap / 4), kBlock, 1024)), dim3(kBlock), 0, s, T,
+                       h->d_cnt, q.d_pc, q.bitmap, (uint64_t)words);
+    hipLaunchKernelGGL(k_tab_columns, dim3(grid_for(rows_bound)), dim3(kBlock), 0, s, T, gp, h->d_cnt);
+    HIP_TRY(h, hipGetLastError());
+    mark(h, 3, s);
+    hipLaunchKernelGGL(k_tab_rows, dim3(grid_for(rows_bound)), dim3(kBlock), 0, s, T, gp, q.stage, (uint32_t)q.stage_cap,
+                       q.ord_cf, q.ord_idx, q.ord_ncol, q.bitmap, (uint64_t)words, h->d_cnt, q.d_pc);
+    HIP_TRY(h, hipGetLastError());
+    mark(h, 4, s);
+    if ((rc = launch_order_and_emit(h, words, 4, s))) return rc;
+    hipLaunchKernelGGL(k_tab_end, dim3(1), dim3(64), 0, s, h->d_cnt);
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipMemcpyAsync(q.h_pc, q.d_pc, sizeof(PartCounters), hipMemcpyDeviceToHost, s));
+    HIP_TRY(h, hipMemcpyAsync(h->h_cnt, h->d_cnt, sizeof(Counters), hipMemcpyDeviceToHost, s));
+    h->results_valid = true;
+    h->last_stream = s;
+    return GNDT_OK;
+}
+
+uint64_t expected_nodes_for_batch(const gndt_handle* h, uint64_t known_nodes, uint64_t n) {
+    if (h->P.max_nodes_hint) return std::max<uint64_t>(h->P.max_nodes_hint, known_nodes);
+    return known_nodes + n;   // worst case: every point opens a node
+}
+
+// Make room for `extra` more points (or merged nodes).  The host only tracks an upper bound of the node count;
+// when that bound asks for a larger table the real count is fetched (one sync) before anything is moved.
+int ensure_capacity_for(gndt_handle* h, uint64_t extra, hipStream_t s) {
+    uint32_t want = cap_for_nodes(expected_nodes_for_batch(h, h->nodes_bound, extra));
+    if (h->cap == 0) return alloc_table(h, want, s);
+    if (want <= h->cap) return GNDT_OK;
+    if (h->table_dirty) {
+        int rc = fetch_counters(h, s);
+        if (rc) return rc;
+        h->nodes_bound = h->h_cnt->num_nodes;
+        want = cap_for_nodes(expected_nodes_for_batch(h, h->nodes_bound, extra));
+        if (want <= h->cap) return GNDT_OK;
+    }
+    return grow_table(h, want, s);
+}
+
+int grow_table(gndt_handle* h, uint32_t new_cap, hipStream_t s) {
+    if (!h->table_dirty) return alloc_table(h, new_cap, s);
+    // export the current contents (the node list is always valid), rebuild, merge back
+    int rc = fetch_counters(h, s);
+    if (rc) return rc;
+    const uint32_t C = h->h_cnt->num_nodes;
+    rc = ensure_stats_buffers(h, C);
+    if (rc) return rc;
+    if (C) {
+        hipLaunchKernelGGL(k_stats_export, dim3(grid_for(C)), dim3(kBlock), 0, s, h->keys, h->acc, h->node_slot, h->d_cnt,
+                           h->st_key, h->st_sums, h->st_count, h->st_first);
+        HIP_TRY(h, hipGetLastError());
+    }
+    HIP_TRY(h, hipStreamSynchronize(s));
+    rc = alloc_table(h, new_cap, s);
+    if (rc) return rc;
+    // the new table is empty: node list restarts, nobody owns a column entry yet (stream position is kept)
+    HIP_TRY(h, hipMemsetAsync(&h->d_cnt->num_nodes, 0, sizeof(uint32_t), s));
+    HIP_TRY(h, hipMemsetAsync(&h->d_cnt->prev_nodes, 0, sizeof(uint32_t), s));
+    if (C) {
+        hipLaunchKernelGGL(k_stats_merge, dim3(grid_for(C)), dim3(kBlock), 0, s, h->keys, h->acc, h->cap - 1, h->node_slot,
+                           h->st_key, h->st_sums, h->st_count, h->st_first, (uint64_t)C, h->d_cnt);
+        HIP_TRY(h, hipGetLastError());
+        h->table_dirty = true;
+    }
+    h->nodes_bound = C;
+    return GNDT_OK;
+}
+
+int stage_host_input(gndt_handle* h, const void* xyz_host, size_t n, size_t stride_bytes, hipStream_t s) {
+    const size_t bytes = n * stride_bytes;
+    if (bytes > h->stage_bytes) {
+        if (h->stage) (void)hipFree(h->stage);
+        h->stage = nullptr; h->stage_bytes = 0;
+        HIP_TRY(h, hipMalloc(&h->stage, bytes + 64));
+        h->stage_bytes = bytes;
+    }
+    if (bytes) HIP_TRY(h, hipMemcpyAsync(h->stage, xyz_host, bytes, hipMemcpyHostToDevice, s));
+    return GNDT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// strategy PARTITION (gndt_partition.hpp): the build
+// ---------------------------------------------------------------------------------------------
 // Bucket count for `nodes` expected nodes: ~4*slots points per bucket, and few enough nodes per bucket for
 // the LDS table (average load <= 0.3 of `slots`, which leaves room for the spread of a hash partition).
 uint64_t buckets_for(uint64_t n, uint64_t nodes, int slots) {
@@ -430,18 +487,8 @@ int build_partition(gndt_handle* h, const void* xyz_dev, size_t n, size_t stride
     if ((rc = grow_buf(h, q.recs, q.rec_cap, n))) return rc;
     // expected node count: the caller's hint, else what the previous build of this handle found, else n/4
     uint64_t nodes_est = h->P.max_nodes_hint ? h->P.max_nodes_hint : (q.nodes_learned ? q.nodes_learned : std::max<uint64_t>(n / 4, 1024));
-    if (words > q.word_cap) {
-        for (uint32_t** a : {&q.bitmap, &q.word_prefix, &q.bsum_words}) { if (*a) (void)hipFree(*a); *a = nullptr; }
-        q.word_cap = 0;
-        HIP_TRY(h, hipMalloc(&q.bitmap, words * 4));
-        HIP_TRY(h, hipMalloc(&q.word_prefix, words * 4));
-        HIP_TRY(h, hipMalloc(&q.bsum_words, ((words + kScanChunk - 1) / kScanChunk + 1) * 4));
-        q.word_cap = words;
-    }
-    if (!q.d_pc) {
-        HIP_TRY(h, hipMalloc(&q.d_pc, sizeof(PartCounters)));
-        HIP_TRY(h, hipHostMalloc(&q.h_pc, sizeof(PartCounters)));
-    }
+    if ((rc = ensure_words(h, words))) return rc;
+    if ((rc = ensure_part_counters(h))) return rc;
     uint64_t stage_want = std::max<uint64_t>(q.stage_cap, h->P.max_nodes_hint ? h->P.max_nodes_hint + h->P.max_nodes_hint / 8
                                                                              : std::max<uint64_t>(4096, n / 4));
     const GridParams gp = grid_params(h);
@@ -518,31 +565,7 @@ int build_partition(gndt_handle* h, const void* xyz_dev, size_t n, size_t stride
         }
         HIP_TRY(h, hipGetLastError());
         mark(h, 5, s);
-        const uint32_t nbw = (uint32_t)((words + kScanChunk - 1) / kScanChunk);
-        hipLaunchKernelGGL(k_scan_reduce<true>, dim3(nbw), dim3(kScanThreads), 0, s, q.bitmap, (const uint32_t*)nullptr,
-                           (uint32_t)words, q.bsum_words);
-        hipLaunchKernelGGL(k_scan_apply<true>, dim3(nbw), dim3(kScanThreads), 0, s, q.bitmap, (const uint32_t*)nullptr,
-                           (uint32_t)words, q.bsum_words, q.word_prefix);
-        HIP_TRY(h, hipGetLastError());
-        mark(h, 6, s);
-        hipLaunchKernelGGL(k_order_rank, dim3(grid_for(q.stage_cap)), dim3(kBlock), 0, s, q.ord_cf, q.ord_idx, q.ord_ncol,
-                           q.bitmap, q.word_prefix, q.col_rank, q.col_size, h->d_cnt, q.d_pc);
-        HIP_TRY(h, hipGetLastError());
-        mark(h, 7, s);
-        const uint32_t nbc = (uint32_t)((q.stage_cap + kScanChunk - 1) / kScanChunk);
-        hipLaunchKernelGGL(k_scan_reduce<false>, dim3(nbc), dim3(kScanThreads), 0, s, q.col_size, &h->d_cnt->num_columns, 0u,
-                           q.bsum_cols);
-        hipLaunchKernelGGL(k_scan_apply<false>, dim3(nbc), dim3(kScanThreads), 0, s, q.col_size, &h->d_cnt->num_columns, 0u,
-                           q.bsum_cols, q.col_base);
-        HIP_TRY(h, hipGetLastError());
-        mark(h, 8, s);
-        hipLaunchKernelGGL(k_order_dest, dim3(grid_for(q.stage_cap)), dim3(kBlock), 0, s, q.col_rank, q.ord_idx, q.col_base,
-                           q.inv, h->d_cnt, q.d_pc);
-        HIP_TRY(h, hipGetLastError());
-        mark(h, 9, s);
-        hipLaunchKernelGGL(k_emit_rows, dim3(grid_for(q.stage_cap)), dim3(kBlock), 0, s, q.stage, q.inv, h->out, h->d_cnt, q.d_pc);
-        HIP_TRY(h, hipGetLastError());
-        mark(h, 10, s);
+        if ((rc = launch_order_and_emit(h, words, 5, s))) return rc;
         HIP_TRY(h, hipMemcpyAsync(q.h_pc, q.d_pc, sizeof(PartCounters), hipMemcpyDeviceToHost, s));
         HIP_TRY(h, hipMemcpyAsync(h->h_cnt, h->d_cnt, sizeof(Counters), hipMemcpyDeviceToHost, s));
         HIP_TRY(h, hipStreamSynchronize(s));
@@ -660,14 +683,15 @@ int gndt_accumulate_device(gndt_handle* h, const void* xyz_dev, size_t n, size_t
                  "with strategy = GNDT_STRATEGY_ATOMIC for incremental updates, or call gndt_reset first";
         return GNDT_ERR_INVALID;
     }
-    uint64_t known = h->results_valid ? h->res_nodes : (h->table_dirty ? h->h_cnt->num_nodes : 0);
-    rc = ensure_capacity_for(h, expected_nodes_for_batch(h, known, n), s);
+    rc = ensure_capacity_for(h, n, s);
     if (rc) return rc;
     mark(h, 1, s);
-    rc = do_accumulate(h, xyz_dev, n, stride_bytes, first_idx_base, s);
+    rc = do_accumulate(h, xyz_dev, n, stride_bytes, first_idx_base, 0, s);
     if (rc) return rc;
     mark(h, 2, s);
     h->stream_pos = std::max<uint64_t>(h->stream_pos, first_idx_base + n);
+    hipLaunchKernelGGL(k_raise_stream, dim3(1), dim3(64), 0, s, h->d_cnt, (uint32_t)h->stream_pos);
+    HIP_TRY(h, hipGetLastError());
     return GNDT_OK;
 }
 
@@ -707,14 +731,17 @@ int gndt_build_device(gndt_handle* h, const void* xyz_dev, size_t n, size_t stri
         rc = do_reset(h, s);
         if (rc) return rc;
         mark(h, 1, s);
-        rc = do_accumulate(h, xyz_dev, n, stride_bytes, 0, s);
+        rc = do_accumulate(h, xyz_dev, n, stride_bytes, 0, 0, s);
         if (rc) return rc;
-        mark(h, 2, s);
         h->stream_pos = n;
+        hipLaunchKernelGGL(k_raise_stream, dim3(1), dim3(64), 0, s, h->d_cnt, (uint32_t)n);
+        HIP_TRY(h, hipGetLastError());
         rc = do_finalize(h, s);
-        if (rc != GNDT_ERR_CAPACITY) return rc;
-        // table overflowed: the build starts from empty, so simply redo it in a larger table
-        h->list_valid = false;
+        if (rc) return rc;
+        // a build returns with its results ready: wait once and look at the device-side flags
+        HIP_TRY(h, hipStreamSynchronize(s));
+        if (!h->h_cnt->err_table_full && !h->part.h_pc->stage_overflow) return GNDT_OK;
+        // table (or staging) overflowed: the build starts from empty, so simply redo it in a larger table
         expect = (uint64_t)h->cap * 2;   // cap_for_nodes doubles again -> 4x slots
         if (expect > (1ull << 30)) break;
     }
@@ -724,9 +751,26 @@ int gndt_build_device(gndt_handle* h, const void* xyz_dev, size_t n, size_t stri
 int gndt_update_device(gndt_handle* h, const void* xyz_dev, size_t n, size_t stride_bytes, void* hip_stream) {
     int rc = check_ready(h);
     if (rc) return rc;
-    rc = gndt_accumulate_device(h, xyz_dev, n, stride_bytes, h->stream_pos, hip_stream);
+    if (!xyz_dev && n) { h->err = "null input"; return GNDT_ERR_INVALID; }
+    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
+    h->last_stream = s;
+    if (!h->map_in_table) {
+        h->err = "the current map was built by the PARTITION strategy, which keeps no additive state: create the handle "
+                 "with strategy = GNDT_STRATEGY_ATOMIC for incremental updates, or call gndt_reset first";
+        return GNDT_ERR_INVALID;
+    }
+    for (auto& r : h->ev_recorded) r = false;
+    h->last_strategy = GNDT_STRATEGY_ATOMIC;
+    // Host side: only upper bounds, so that buffers exist (allocation happens outside any graph capture: run one
+    // frame eagerly first, or give max_nodes_hint / max_points_hint).  The first_idx base is the DEVICE-side
+    // stream position, which k_advance_stream bumps, so a captured update can be replayed frame after frame.
+    rc = ensure_capacity_for(h, n, s);
     if (rc) return rc;
-    return gndt_finalize_device(h, hip_stream);
+    mark(h, 1, s);
+    rc = do_accumulate(h, xyz_dev, n, stride_bytes, h->stream_pos, 1, s);
+    if (rc) return rc;
+    h->stream_pos += n;
+    return do_finalize(h, s);
 }
 
 int gndt_build(gndt_handle* h, const void* xyz_host, size_t n, size_t stride_bytes) {
@@ -769,6 +813,14 @@ int gndt_sync(gndt_handle* h, uint64_t* num_nodes, uint64_t* num_columns, uint64
         return GNDT_ERR_KEY_RANGE;
     }
     if (h->h_cnt->err_table_full) { h->err = "node table full: raise gndt_params.max_nodes_hint"; return GNDT_ERR_CAPACITY; }
+    if (h->results_valid && h->part.h_pc && h->part.h_pc->stage_overflow) {
+        h->err = "more nodes than result rows: raise gndt_params.max_nodes_hint";
+        return GNDT_ERR_CAPACITY;
+    }
+    if (h->results_valid && h->part.h_pc && h->part.h_pc->index_overflow) {
+        h->err = "point stream ran past the column-order bitmap (replayed graph?): raise gndt_params.max_points_hint";
+        return GNDT_ERR_CAPACITY;
+    }
     return GNDT_OK;
 }
 
@@ -808,7 +860,6 @@ int gndt_stats_export_device(gndt_handle* h, gndt_stats* out, void* hip_stream) 
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
     h->last_stream = s;
     if (h->cap == 0) { rc = alloc_table(h, cap_for_nodes(1024), s); if (rc) return rc; }
-    if (!h->list_valid) { rc = do_scan(h, s); if (rc) return rc; }
     rc = fetch_counters(h, s);
     if (rc) return rc;
     if (h->h_cnt->err_table_full) { h->err = "node table full: raise gndt_params.max_nodes_hint"; return GNDT_ERR_CAPACITY; }
@@ -831,16 +882,20 @@ int gndt_stats_merge_device(gndt_handle* h, const gndt_stats* in, void* hip_stre
     if (!in) return GNDT_ERR_INVALID;
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
     h->last_stream = s;
-    uint64_t known = h->table_dirty ? h->h_cnt->num_nodes : 0;
-    rc = ensure_capacity_for(h, std::max<uint64_t>(h->P.max_nodes_hint, known + in->num_nodes), s);
+    rc = ensure_capacity_for(h, in->num_nodes, s);
     if (rc) return rc;
     if (in->num_nodes) {
         hipLaunchKernelGGL(k_stats_merge, dim3(grid_for(in->num_nodes)), dim3(kBlock), 0, s, h->keys, h->acc, h->cap - 1,
-                           in->key, in->sums, in->count, in->first_idx, (uint64_t)in->num_nodes, h->d_cnt);
+                           h->node_slot, in->key, in->sums, in->count, in->first_idx, (uint64_t)in->num_nodes, h->d_cnt);
         HIP_TRY(h, hipGetLastError());
         h->table_dirty = true;
-        h->list_valid = false;
         h->results_valid = false;
+        // the merged first indices tell how far the point stream reaches (sizes the column-order bitmap);
+        // the exchange path may wait for the host, and learns the exact node count on the way
+        rc = fetch_counters(h, s);
+        if (rc) return rc;
+        h->stream_pos = std::max<uint64_t>(h->stream_pos, h->h_cnt->stream_pos);
+        h->nodes_bound = h->h_cnt->num_nodes;
     }
     return GNDT_OK;
 }

@@ -1,20 +1,19 @@
-// gndt_kernels.hpp — HIP kernels of the NDT grid build for gfx950 (MI355X).
+// gndt_kernels.hpp — strategy ATOMIC: the persistent node table in HBM (gfx950 / MI355X).
 //
-// Data layout in HBM (all owned by the handle, see gndt_api.hip):
-//   keys[cap]      u64   open-addressing node table, kEmptyKey = free; linear probing
-//   acc[cap]       NodeAcc (80 B): additive cell-local statistics of the node in that slot
-//   col_keys[cap]  u64   column table (key with the z field cleared)
-//   col_first[cap] u32   first-seen point index of the column (min over its nodes)
-//   node_slot[C]   u32   compact list of occupied slots (unordered)
-//   aux[cap]       SlotAux: fp32 mean-z for the slope test + label flags
-//   out.*          SoA result rows in reference order (gndt_cells)
+// Data layout (owned by the handle, gndt_api.hip):
+//   keys[cap]        u64   open-addressing node table, kEmptyKey = free; linear probing
+//   acc[cap]         NodeAcc (80 B): additive cell-local statistics of the node in that slot
+//   node_slot[C]     u32   the occupied slots in insertion order: a node is appended when its key is inserted,
+//                          so the list is always valid and nothing ever scans the whole table
+//   col_keys / col_first / col_cnt / col_head [cap]   column table, rebuilt for the touched columns by finalize
+//   node_next[C], col_slot_of_node[C]                 per-column linked list of nodes, column slot of each node
+//   aux[cap]         fp32 mean-z of the node (for the slope test)
 //
-// Pipeline (strategy ATOMIC):
-//   k_accumulate   points -> key -> find-or-insert -> fp64 atomics            (receiver.cpp:41-93)
-//   k_scan_nodes   occupied slots -> node list, column table, mean-z           (map2D.h:611-627, part)
-//   k_label_nodes  per node: slope label from z+-1 neighbours, sort key        (map2D.h:66-108)
-//   radix sort     nodes by (column first-seen, node first-seen)               (morton_list / multimap order)
-//   k_emit_nodes   per rank: mean, scatter, eigen -> SoA rows                  (map2D.h:621-627, 110-133)
+// Kernels here: k_accumulate (points -> statistics; src/receiver.cpp:41-93), the table clears, and the
+// statistics export / merge used by table growth and by the multi-GPU exchange.  Finalisation (labels, order,
+// result rows) is in gndt_table.hpp and reuses the staging rows and ordering kernels of the partition path.
+// Every size a kernel needs is read from device memory (Counters), so accumulate + finalize never wait for the
+// host: an incremental update can be captured in a hipGraph and replayed per frame (BASELINE configs[3]).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -36,12 +35,14 @@ struct SlotAux {
 };
 
 struct Counters {
-    uint32_t num_nodes;
+    uint32_t num_nodes;       // nodes in the table (ATOMIC) / staged rows (PARTITION)
     uint32_t num_columns;
     uint32_t num_slopes;
     uint32_t err_key_range;   // points outside the key range
     uint32_t err_table_full;  // inserts that found no slot
-    uint32_t pad[3];
+    uint32_t stream_pos;      // points accumulated so far by gndt_update* (device-side first_idx base)
+    uint32_t prev_nodes;      // nodes that went through the last finalize (their column entries exist)
+    uint32_t pad;
 };
 
 struct GridParams {
@@ -65,7 +66,9 @@ constexpr int kBlock = 256;
 // Find the slot holding `key`, inserting it if absent.  Returns cap on failure (table full).
 // A plain load may return a stale EMPTY (per-XCD L2s are not coherent) but never a stale key,
 // because a slot's key is written once; the CAS executes at the memory side and settles it.
-__device__ __forceinline__ uint32_t find_or_insert(uint64_t* __restrict__ keys, uint32_t cap_mask, uint64_t key) {
+__device__ __forceinline__ uint32_t find_or_insert(uint64_t* __restrict__ keys, uint32_t cap_mask, uint64_t key,
+                                                   bool& inserted) {
+    inserted = false;
     uint32_t slot = (uint32_t)mix64(key) & cap_mask;
     for (uint32_t probe = 0; probe <= cap_mask; ++probe) {
         uint64_t k = keys[slot];
@@ -73,11 +76,26 @@ __device__ __forceinline__ uint32_t find_or_insert(uint64_t* __restrict__ keys, 
         if (k == kEmptyKey) {
             unsigned long long old = atomicCAS((unsigned long long*)&keys[slot], (unsigned long long)kEmptyKey,
                                                (unsigned long long)key);
-            if (old == kEmptyKey || old == key) return slot;
+            if (old == kEmptyKey) { inserted = true; return slot; }
+            if (old == key) return slot;
         }
         slot = (slot + 1) & cap_mask;
     }
     return cap_mask + 1;
+}
+
+// Append the slots of freshly inserted nodes to the node list: one counter atomic per wave instruction (the
+// counter is ONE word; per-lane atomics on it would serialise at the memory side).
+__device__ __forceinline__ void append_new_nodes(bool inserted, uint32_t slot, uint32_t* __restrict__ node_slot,
+                                                 Counters* __restrict__ cnt) {
+    const unsigned long long m = __ballot(inserted);
+    if (m == 0ull) return;
+    const int lane = threadIdx.x & 63;
+    const int leader = (int)__builtin_ctzll(m);
+    uint32_t base = 0;
+    if (lane == leader) base = atomicAdd(&cnt->num_nodes, (uint32_t)__popcll(m));
+    base = (uint32_t)__shfl((int)base, leader, 64);
+    if (inserted) node_slot[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = slot;
 }
 
 // Lookup only.  Returns cap_mask+1 when absent.
@@ -100,11 +118,14 @@ __device__ __forceinline__ double wave_sum(double v) {
 // ---------------------------------------------------------------------------------------------
 // k_clear_all: whole-table initialisation (once at create / after growth)
 // ---------------------------------------------------------------------------------------------
-__global__ void k_clear_all(uint64_t* keys, NodeAcc* acc, uint64_t* col_keys, uint32_t* col_first, uint32_t cap) {
+__global__ void k_clear_all(uint64_t* keys, NodeAcc* acc, uint64_t* col_keys, uint32_t* col_first, uint32_t* col_cnt,
+                            uint32_t* col_head, uint32_t cap) {
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < cap; i += gridDim.x * blockDim.x) {
         keys[i] = kEmptyKey;
         col_keys[i] = kEmptyKey;
         col_first[i] = 0xFFFFFFFFu;
+        col_cnt[i] = 0u;
+        col_head[i] = 0xFFFFFFFFu;
         NodeAcc a;
         for (int k = 0; k < 9; ++k) a.s[k] = 0.0;
         a.count = 0; a.first = 0xFFFFFFFFu;
@@ -112,28 +133,34 @@ __global__ void k_clear_all(uint64_t* keys, NodeAcc* acc, uint64_t* col_keys, ui
     }
 }
 
-// k_clear_used: undo the previous build by visiting only its occupied slots (O(C), not O(cap)).
-__global__ void k_clear_used(uint64_t* keys, NodeAcc* acc, uint64_t* col_keys, uint32_t* col_first,
-                             const uint32_t* node_slot, const uint32_t* col_slot_of_node, const Counters* prev) {
-    const uint32_t n = prev->num_nodes;
+// k_clear_used: empty the map by visiting only its occupied slots (O(C), not O(cap)).  Nodes that went through a
+// finalize (i < prev_nodes) also own a column-table entry.
+__global__ void k_clear_used(uint64_t* keys, NodeAcc* acc, uint64_t* col_keys, uint32_t* col_first, uint32_t* col_cnt,
+                             uint32_t* col_head, const uint32_t* node_slot, const uint32_t* col_slot_of_node,
+                             const Counters* cur) {
+    const uint32_t n = cur->num_nodes, np = cur->prev_nodes;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const uint32_t slot = node_slot[i];
-        const uint32_t cs = col_slot_of_node[i];   // nodes of one column write the same values: benign
         keys[slot] = kEmptyKey;
         NodeAcc a;
         for (int k = 0; k < 9; ++k) a.s[k] = 0.0;
         a.count = 0; a.first = 0xFFFFFFFFu;
         acc[slot] = a;
-        col_keys[cs] = kEmptyKey;
-        col_first[cs] = 0xFFFFFFFFu;
+        if (i < np) {
+            const uint32_t cs = col_slot_of_node[i];   // nodes of one column write the same values: benign
+            col_keys[cs] = kEmptyKey;
+            col_first[cs] = 0xFFFFFFFFu;
+            col_cnt[cs] = 0u;
+            col_head[cs] = 0xFFFFFFFFu;
+        }
     }
 }
 
-// zero the per-finalize counters (node/column/slope); `all` also clears the sticky error counters
-__global__ void k_zero_counters(Counters* c, int all) {
+// all counters to zero (after the clear that read them)
+__global__ void k_zero_counters(Counters* c) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
-        c->num_nodes = 0; c->num_columns = 0; c->num_slopes = 0;
-        if (all) { c->err_key_range = 0; c->err_table_full = 0; }
+        c->num_nodes = 0; c->num_columns = 0; c->num_slopes = 0; c->err_key_range = 0; c->err_table_full = 0;
+        c->stream_pos = 0; c->prev_nodes = 0;
     }
 }
 
@@ -144,14 +171,17 @@ __global__ void k_zero_counters(Counters* c, int all) {
 // HBM roofline view: reads 12 (or 16) B/point; the 11 atomics per point execute at the memory side.
 // When every lane of a wave holds the same key (the (0,0,0) padding of the reference's own clouds,
 // SURVEY §4) the wave reduces in registers and issues one set of atomics.
+// first_idx of point i = first_base + i, or cnt->stream_pos + i when `base_from_device` (incremental updates:
+// the base then lives on the device, so a captured graph can be replayed frame after frame).
 // ---------------------------------------------------------------------------------------------
 template <int STRIDE_FLOATS>
 __global__ void __launch_bounds__(kBlock) k_accumulate(const float* __restrict__ xyz, uint64_t n, uint32_t first_base,
-                                                       GridParams P, uint64_t* __restrict__ keys,
+                                                       int base_from_device, GridParams P, uint64_t* __restrict__ keys,
                                                        NodeAcc* __restrict__ acc, uint32_t cap_mask,
-                                                       Counters* __restrict__ cnt) {
+                                                       uint32_t* __restrict__ node_slot, Counters* __restrict__ cnt) {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     const uint64_t n_round = (n + 63) & ~63ull;   // keep waves converged for the wave-uniform test
+    const uint32_t base = base_from_device ? cnt->stream_pos : first_base;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_round; i += stride) {
         const bool live = i < n;
         float px = 0.f, py = 0.f, pz = 0.f;
@@ -170,7 +200,7 @@ __global__ void __launch_bounds__(kBlock) k_accumulate(const float* __restrict__
             v[2] = (double)pz - axis_centre(k.sz, P.oz, P.z_len);
         }
         double q[9] = {v[0], v[1], v[2], v[0] * v[0], v[0] * v[1], v[0] * v[2], v[1] * v[1], v[1] * v[2], v[2] * v[2]};
-        uint32_t pidx = first_base + (uint32_t)i;
+        uint32_t pidx = base + (uint32_t)i;
 
         // wave-uniform key?  (all 64 lanes live, ok and equal)
         const uint64_t key0 = ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(key >> 32)) << 32) |
@@ -182,9 +212,11 @@ __global__ void __launch_bounds__(kBlock) k_accumulate(const float* __restrict__
             uint32_t pmin = pidx;
             for (int off = 32; off > 0; off >>= 1) pmin = min(pmin, (uint32_t)__shfl_down((int)pmin, off, 64));
             if ((threadIdx.x & 63) == 0) {
-                uint32_t slot = find_or_insert(keys, cap_mask, key);
+                bool inserted;
+                uint32_t slot = find_or_insert(keys, cap_mask, key, inserted);
                 if (slot > cap_mask) { atomicAdd(&cnt->err_table_full, 1u); }
                 else {
+                    if (inserted) node_slot[atomicAdd(&cnt->num_nodes, 1u)] = slot;
                     NodeAcc* a = acc + slot;
 #pragma unroll
                     for (int j = 0; j < 9; ++j) unsafeAtomicAdd(&a->s[j], q[j]);
@@ -193,9 +225,11 @@ __global__ void __launch_bounds__(kBlock) k_accumulate(const float* __restrict__
                 }
             }
         } else if (ok) {
-            uint32_t slot = find_or_insert(keys, cap_mask, key);
-            if (slot > cap_mask) { atomicAdd(&cnt->err_table_full, 1u); }
-            else {
+            bool inserted;
+            uint32_t slot = find_or_insert(keys, cap_mask, key, inserted);
+            if (slot > cap_mask) { atomicAdd(&cnt->err_table_full, 1u); inserted = false; }
+            append_new_nodes(inserted, slot, node_slot, cnt);
+            if (slot <= cap_mask) {
                 NodeAcc* a = acc + slot;
 #pragma unroll
                 for (int j = 0; j < 9; ++j) unsafeAtomicAdd(&a->s[j], q[j]);
@@ -206,153 +240,18 @@ __global__ void __launch_bounds__(kBlock) k_accumulate(const float* __restrict__
     }
 }
 
-// ---------------------------------------------------------------------------------------------
-// k_scan_nodes: visit every slot; for occupied ones append to the node list, register the column
-// (first-seen = min over its nodes), and store the fp32 mean-z the slope test compares.
-// ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(kBlock) k_scan_nodes(const uint64_t* __restrict__ keys, const NodeAcc* __restrict__ acc,
-                                                       uint64_t* __restrict__ col_keys, uint32_t* __restrict__ col_first,
-                                                       uint32_t* __restrict__ node_slot, uint32_t* __restrict__ col_slot_of_node,
-                                                       SlotAux* __restrict__ aux, uint32_t cap_mask, GridParams P,
-                                                       Counters* __restrict__ cnt) {
-    const uint32_t cap = cap_mask + 1;
-    const uint32_t cap_round = (cap + 63) & ~63u;
-    for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < cap_round; s += gridDim.x * blockDim.x) {
-        uint64_t key = (s < cap) ? keys[s] : kEmptyKey;
-        const bool occ = key != kEmptyKey;
-        // wave-aggregated append
-        const unsigned long long m = __ballot(occ);
-        uint32_t base = 0;
-        const int lane = threadIdx.x & 63;
-        if (m != 0ull) {
-            if (lane == (int)__builtin_ctzll(m)) base = atomicAdd(&cnt->num_nodes, (uint32_t)__popcll(m));
-            base = (uint32_t)__shfl((int)base, (int)__builtin_ctzll(m), 64);
-        }
-        if (!occ) continue;
-        const uint32_t idx = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-        node_slot[idx] = s;
-        const NodeAcc a = acc[s];
-        int sx, sy, sz;
-        unpack_key(key, sx, sy, sz);
-        SlotAux x;
-        x.flags = 0;
-        x.mean_z = 0.f;
-        if (a.count >= (uint32_t)P.min_points) {
-            x.mean_z = node_mean_z(a.count, a.s[2], axis_centre(sz, P.oz, P.z_len));
-            x.flags = 1u;  // GNDT_FLAG_HAS_STATS
-        }
-        aux[s] = x;
-        // column registration
-        const uint64_t ck = column_key(key);
-        uint32_t cs = (uint32_t)mix64(ck) & cap_mask;
-        bool placed = false;
-        for (uint32_t probe = 0; probe <= cap_mask && !placed; ++probe) {
-            uint64_t k = col_keys[cs];
-            if (k == ck) placed = true;
-            else if (k == kEmptyKey) {
-                unsigned long long old = atomicCAS((unsigned long long*)&col_keys[cs], (unsigned long long)kEmptyKey,
-                                                   (unsigned long long)ck);
-                if (old == kEmptyKey) placed = true;
-                else if (old == ck) placed = true;
-            }
-            if (!placed) cs = (cs + 1) & cap_mask;
-        }
-        col_slot_of_node[idx] = cs;
-        atomicMin(&col_first[cs], a.first);
-    }
+// after an incremental accumulate: advance the device-side stream position
+__global__ void k_advance_stream(Counters* c, uint32_t n) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) c->stream_pos += n;
+}
+
+// after an accumulate with a caller-given base: the stream position is at least `v`
+__global__ void k_raise_stream(Counters* c, uint32_t v) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) c->stream_pos = max(c->stream_pos, v);
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_label_nodes: OcNode::isSlope (include/map2D.h:66-108) without the visiting order:
-//   a neighbour's centroid is "already computed" iff it was first seen earlier in the same column
-//   and has >= min_points points; otherwise the reference reads its zero-initialised centroid.
-// Also emits the 64-bit sort key (column first-seen, node first-seen).
-// ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(kBlock) k_label_nodes(const uint64_t* __restrict__ keys, const NodeAcc* __restrict__ acc,
-                                                        const uint32_t* __restrict__ col_first,
-                                                        const uint32_t* __restrict__ node_slot,
-                                                        const uint32_t* __restrict__ col_slot_of_node,
-                                                        SlotAux* __restrict__ aux, uint64_t* __restrict__ sort_key,
-                                                        uint32_t* __restrict__ sort_val, uint32_t cap_mask, GridParams P,
-                                                        Counters* __restrict__ cnt) {
-    const uint32_t n = cnt->num_nodes;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const uint32_t s = node_slot[i];
-        const uint64_t key = keys[s];
-        const uint32_t my_first = acc[s].first;
-        const uint32_t my_count = acc[s].count;
-        const uint32_t cfirst = col_first[col_slot_of_node[i]];
-        sort_key[i] = ((uint64_t)cfirst << 32) | (uint64_t)my_first;
-        sort_val[i] = s;
-        if (cfirst == my_first) atomicAdd(&cnt->num_columns, 1u);   // this node opened its column (morton_list entry)
-        uint32_t flags = aux[s].flags;
-        if (my_count >= (uint32_t)P.min_points) {
-            bool slope = true, down = false;
-            if (P.demand == 0) {
-                int sx, sy, sz;
-                unpack_key(key, sx, sy, sz);
-                const float cz = aux[s].mean_z;
-                bool up = false;
-                // node one level up
-                uint32_t t = find_slot(keys, cap_mask, pack_key(sx, sy, level_above(sz)));
-                if (t <= cap_mask) {
-                    const bool visited = acc[t].first < my_first && acc[t].count >= (uint32_t)P.min_points;
-                    const float oz = visited ? aux[t].mean_z : 0.f;
-                    if (fabsf(oz - cz) > P.slope_interval) up = true;
-                }
-                t = find_slot(keys, cap_mask, pack_key(sx, sy, level_below(sz)));
-                if (t <= cap_mask) {
-                    const bool visited = acc[t].first < my_first && acc[t].count >= (uint32_t)P.min_points;
-                    const float oz = visited ? aux[t].mean_z : 0.f;
-                    if (fabsf(oz - cz) > P.slope_interval) down = true;
-                }
-                slope = !up;
-            }
-            if (slope) {
-                flags |= 2u;  // GNDT_FLAG_SLOPE
-                if (down) flags |= 4u;
-                atomicAdd(&cnt->num_slopes, 1u);
-            }
-        }
-        aux[s].flags = flags;
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// k_emit_nodes: one thread per output row (rank in reference order): mean, scatter, eigen.
-// Algorithmic bytes: 80 B statistics in, 76 B result out per node.
-// ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(kBlock) k_emit_nodes(const uint64_t* __restrict__ keys, const NodeAcc* __restrict__ acc,
-                                                       const SlotAux* __restrict__ aux, const uint32_t* __restrict__ order,
-                                                       OutView out, GridParams P, const Counters* __restrict__ cnt) {
-    const uint32_t n = cnt->num_nodes;
-    for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x) {
-        const uint32_t s = order[r];
-        const uint64_t key = keys[s];
-        const NodeAcc a = acc[s];
-        int sx, sy, sz;
-        unpack_key(key, sx, sy, sz);
-        out.sx[r] = sx; out.sy[r] = sy; out.sz[r] = sz;
-        out.count[r] = a.count;
-        out.first_idx[r] = a.first;
-        out.flags[r] = aux[s].flags;
-        NodeResult res;
-        for (int k = 0; k < 3; ++k) { res.mean[k] = 0.f; res.normal[k] = 0.f; }
-        for (int k = 0; k < 6; ++k) res.cov[k] = 0.f;
-        res.rough = 0.f;
-        if (a.count >= (uint32_t)P.min_points) {
-            const double c[3] = {axis_centre(sx, P.ox, P.grid_len), axis_centre(sy, P.oy, P.grid_len),
-                                 axis_centre(sz, P.oz, P.z_len)};
-            finalize_node(a.count, a.s, c, res);
-        }
-        for (int k = 0; k < 3; ++k) { out.mean[3 * r + k] = res.mean[k]; out.normal[3 * r + k] = res.normal[k]; }
-        for (int k = 0; k < 6; ++k) out.cov[6 * r + k] = res.cov[k];
-        out.rough[r] = res.rough;
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// statistics exchange helpers (multi-GPU): compact export and additive merge
+// statistics exchange helpers (table growth, multi-GPU): compact export and additive merge
 // ---------------------------------------------------------------------------------------------
 __global__ void k_stats_export(const uint64_t* __restrict__ keys, const NodeAcc* __restrict__ acc,
                                const uint32_t* __restrict__ node_slot, const Counters* __restrict__ cnt,
@@ -369,20 +268,37 @@ __global__ void k_stats_export(const uint64_t* __restrict__ keys, const NodeAcc*
     }
 }
 
-__global__ void k_stats_merge(uint64_t* __restrict__ keys, NodeAcc* __restrict__ acc, uint32_t cap_mask,
-                              const uint64_t* __restrict__ ikey, const double* __restrict__ isums,
-                              const uint32_t* __restrict__ icount, const uint32_t* __restrict__ ifirst, uint64_t n,
-                              Counters* __restrict__ cnt) {
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
-        const uint64_t key = ikey[i];
-        if (key == kEmptyKey || icount[i] == 0) continue;
-        uint32_t slot = find_or_insert(keys, cap_mask, key);
-        if (slot > cap_mask) { atomicAdd(&cnt->err_table_full, 1u); continue; }
-        NodeAcc* a = acc + slot;
-        for (int k = 0; k < 9; ++k) unsafeAtomicAdd(&a->s[k], isums[9 * i + k]);
-        atomicAdd(&a->count, icount[i]);
-        atomicMin(&a->first, ifirst[i]);
+__global__ void __launch_bounds__(kBlock) k_stats_merge(uint64_t* __restrict__ keys, NodeAcc* __restrict__ acc, uint32_t cap_mask,
+                                                        uint32_t* __restrict__ node_slot, const uint64_t* __restrict__ ikey,
+                                                        const double* __restrict__ isums, const uint32_t* __restrict__ icount,
+                                                        const uint32_t* __restrict__ ifirst, uint64_t n,
+                                                        Counters* __restrict__ cnt) {
+    __shared__ uint32_t s_bound;
+    if (threadIdx.x == 0) s_bound = 0;
+    __syncthreads();
+    uint32_t bound = 0;   // one past the largest first_idx merged: the stream position is at least that
+    const uint64_t n_round = (n + 63) & ~63ull;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_round; i += (uint64_t)gridDim.x * blockDim.x) {
+        const bool live = i < n && ikey[i] != kEmptyKey && icount[i] != 0;
+        bool inserted = false;
+        uint32_t slot = cap_mask + 1;
+        if (live) {
+            slot = find_or_insert(keys, cap_mask, ikey[i], inserted);
+            if (slot > cap_mask) { atomicAdd(&cnt->err_table_full, 1u); inserted = false; }
+        }
+        append_new_nodes(inserted, slot, node_slot, cnt);
+        if (live && slot <= cap_mask) {
+            NodeAcc* a = acc + slot;
+            for (int k = 0; k < 9; ++k) unsafeAtomicAdd(&a->s[k], isums[9 * i + k]);
+            atomicAdd(&a->count, icount[i]);
+            const uint32_t f = ifirst[i];
+            atomicMin(&a->first, f);
+            if (f != 0xFFFFFFFFu) bound = max(bound, f + 1u);
+        }
     }
+    if (bound) atomicMax(&s_bound, bound);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_bound) atomicMax(&cnt->stream_pos, s_bound);
 }
 
 }  // namespace gndt

@@ -36,7 +36,8 @@ constexpr int kScanThreads = 256;
 struct PartCounters {
     uint32_t lds_overflow;     // buckets whose node table overflowed
     uint32_t stage_overflow;   // nodes that did not fit the staging rows
-    uint32_t pad[2];
+    uint32_t index_overflow;   // column-first indices beyond the bitmap (table path: stream ran past max_points_hint)
+    uint32_t pad;
 };
 
 struct alignas(16) StageRow {   // 128 bytes = two 64-B lines, gathered whole by k_emit_rows
@@ -92,7 +93,7 @@ __global__ void __launch_bounds__(256) k_part_clear(Counters* __restrict__ cnt, 
                                                     uint32_t* __restrict__ bitmap, uint64_t words) {
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         cnt->num_nodes = 0; cnt->num_columns = 0; cnt->num_slopes = 0; cnt->err_key_range = 0; cnt->err_table_full = 0;
-        pc->lds_overflow = 0; pc->stage_overflow = 0;
+        pc->lds_overflow = 0; pc->stage_overflow = 0; pc->index_overflow = 0;
     }
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < words; i += (uint64_t)gridDim.x * blockDim.x) bitmap[i] = 0u;
 }
@@ -338,7 +339,7 @@ __global__ void __launch_bounds__(kBlock) k_order_rank(const uint32_t* __restric
                                                        const uint32_t* __restrict__ bitmap, const uint32_t* __restrict__ word_prefix,
                                                        uint32_t* __restrict__ col_rank, uint32_t* __restrict__ col_size,
                                                        const Counters* __restrict__ cnt, const PartCounters* __restrict__ pc) {
-    if (pc->lds_overflow | pc->stage_overflow) return;   // the host re-runs the build; staged rows are incomplete
+    if (pc->lds_overflow | pc->stage_overflow | pc->index_overflow) return;   // the host re-runs the build; staged rows are incomplete
     const uint32_t n = cnt->num_nodes;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const uint32_t cf = ord_cf[i];
@@ -352,7 +353,7 @@ __global__ void __launch_bounds__(kBlock) k_order_rank(const uint32_t* __restric
 __global__ void __launch_bounds__(kBlock) k_order_dest(const uint32_t* __restrict__ col_rank, const uint32_t* __restrict__ ord_idx,
                                                        const uint32_t* __restrict__ col_base, uint32_t* __restrict__ inv,
                                                        const Counters* __restrict__ cnt, const PartCounters* __restrict__ pc) {
-    if (pc->lds_overflow | pc->stage_overflow) return;
+    if (pc->lds_overflow | pc->stage_overflow | pc->index_overflow) return;
     const uint32_t n = cnt->num_nodes;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
         inv[col_base[col_rank[i]] + ord_idx[i]] = i;
@@ -362,7 +363,7 @@ __global__ void __launch_bounds__(kBlock) k_order_dest(const uint32_t* __restric
 __global__ void __launch_bounds__(kBlock) k_emit_rows(const StageRow* __restrict__ stage, const uint32_t* __restrict__ inv,
                                                       OutView out, const Counters* __restrict__ cnt,
                                                       const PartCounters* __restrict__ pc) {
-    if (pc->lds_overflow | pc->stage_overflow) return;
+    if (pc->lds_overflow | pc->stage_overflow | pc->index_overflow) return;
     const uint32_t n = cnt->num_nodes;
     for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x) {
         const StageRow row = stage[inv[r]];

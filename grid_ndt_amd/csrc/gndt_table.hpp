@@ -1,0 +1,148 @@
+// gndt_table.hpp — finalisation of the persistent node table (strategy ATOMIC): from the additive statistics to
+// result rows in reference order, without ever waiting for the host.
+//
+//   k_tab_begin     zero the per-finalize counters and the column-first bitmap; forget the column lists of the
+//                   nodes that were finalised before (their columns are rebuilt below)
+//   k_tab_columns   per node: fp32 mean-z, column registration (first-seen = min over its nodes), linked list
+//   k_tab_rows      per node: slope label (OcNode::isSlope, map2D.h:66-108) and index in column by walking the
+//                   column's list; mean + fp64 scatter -> 128-B staging row; bit per column-first index
+//   then the partition path's ordering (k_scan_*, k_order_*) and k_emit_rows (gndt_partition.hpp)
+//   k_tab_end       remember how many nodes now own a column entry
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "gndt_partition.hpp"
+
+namespace gndt {
+
+struct TableView {
+    uint64_t* keys; NodeAcc* acc; SlotAux* aux;
+    uint64_t* col_keys; uint32_t* col_first; uint32_t* col_cnt; uint32_t* col_head;
+    uint32_t* node_slot; uint32_t* col_slot_of_node; uint32_t* node_next;
+    uint32_t cap_mask;
+};
+
+__global__ void __launch_bounds__(kBlock) k_tab_begin(TableView T, Counters* __restrict__ cnt, PartCounters* __restrict__ pc,
+                                                      uint32_t* __restrict__ bitmap, uint64_t words) {
+    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, gsz = (uint64_t)gridDim.x * blockDim.x;
+    if (gid == 0) { cnt->num_columns = 0; cnt->num_slopes = 0; pc->lds_overflow = 0; pc->stage_overflow = 0; pc->index_overflow = 0; }
+    for (uint64_t i = gid; i < words; i += gsz) bitmap[i] = 0u;
+    const uint32_t np = cnt->prev_nodes;
+    for (uint64_t i = gid; i < np; i += gsz) {
+        const uint32_t cs = T.col_slot_of_node[i];
+        T.col_head[cs] = 0xFFFFFFFFu;
+        T.col_cnt[cs] = 0u;
+    }
+}
+
+__global__ void __launch_bounds__(kBlock) k_tab_columns(TableView T, GridParams P, const Counters* __restrict__ cnt) {
+    const uint32_t n = cnt->num_nodes;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const uint32_t s = T.node_slot[i];
+        const uint64_t key = T.keys[s];
+        const NodeAcc a = T.acc[s];
+        int sx, sy, sz;
+        unpack_key(key, sx, sy, sz);
+        SlotAux x;
+        x.flags = 0u; x.mean_z = 0.f;
+        if (a.count >= (uint32_t)P.min_points) { x.mean_z = node_mean_z(a.count, a.s[2], axis_centre(sz, P.oz, P.z_len)); x.flags = 1u; }
+        T.aux[s] = x;
+        const uint64_t ck = column_key(key);
+        uint32_t cs = (uint32_t)mix64(ck) & T.cap_mask;
+        for (uint32_t probe = 0; probe <= T.cap_mask; ++probe) {
+            const uint64_t k = T.col_keys[cs];
+            if (k == ck) break;
+            if (k == kEmptyKey) {
+                const unsigned long long old = atomicCAS((unsigned long long*)&T.col_keys[cs], (unsigned long long)kEmptyKey,
+                                                         (unsigned long long)ck);
+                if (old == kEmptyKey || old == ck) break;
+            }
+            cs = (cs + 1) & T.cap_mask;
+        }
+        T.col_slot_of_node[i] = cs;
+        atomicMin(&T.col_first[cs], a.first);
+        atomicAdd(&T.col_cnt[cs], 1u);
+        T.node_next[i] = atomicExch(&T.col_head[cs], i);
+    }
+}
+
+__global__ void __launch_bounds__(kBlock) k_tab_rows(TableView T, GridParams P, StageRow* __restrict__ stage, uint32_t stage_cap,
+                                                     uint32_t* __restrict__ ord_cf, uint32_t* __restrict__ ord_idx,
+                                                     uint32_t* __restrict__ ord_ncol, uint32_t* __restrict__ bitmap,
+                                                     uint64_t words, Counters* __restrict__ cnt,
+                                                     PartCounters* __restrict__ pc) {
+    __shared__ uint32_t s_slopes, s_cols;
+    if (threadIdx.x == 0) { s_slopes = 0; s_cols = 0; }
+    __syncthreads();
+    const uint32_t n = cnt->num_nodes;
+    if (n > stage_cap) { if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&pc->stage_overflow, n); return; }
+    uint32_t my_slopes = 0, my_cols = 0;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const uint32_t s = T.node_slot[i];
+        const uint64_t key = T.keys[s];
+        const NodeAcc a = T.acc[s];
+        const uint32_t cs = T.col_slot_of_node[i];
+        uint32_t fl = T.aux[s].flags & 1u;
+        const float cz = T.aux[s].mean_z;
+        StageRow row;
+        unpack_key(key, row.sx, row.sy, row.sz);
+        const int za = level_above(row.sz), zb = level_below(row.sz);
+        uint32_t icol = 0;
+        bool up = false, down = false;
+        for (uint32_t t = T.col_head[cs]; t != 0xFFFFFFFFu; t = T.node_next[t]) {
+            if (t == i) continue;
+            const uint32_t ts = T.node_slot[t];
+            const uint32_t tf = T.acc[ts].first;
+            icol += (tf < a.first) ? 1u : 0u;
+            const int tz = (int)(T.keys[ts] & 0x3FFFFFu) - (1 << 21);
+            if (tz == za || tz == zb) {
+                const SlotAux tx = T.aux[ts];
+                const bool visited = tf < a.first && (tx.flags & 1u);
+                const float oz = visited ? tx.mean_z : 0.f;
+                const bool far = fabsf(oz - cz) > P.slope_interval;
+                if (tz == za) up = up || far; else down = down || far;
+            }
+        }
+        if (fl & 1u) {
+            bool slope = true;
+            if (P.demand == 0) slope = !up; else down = false;
+            if (slope) { fl |= 2u; if (down) fl |= 4u; ++my_slopes; }
+        }
+        row.count = a.count; row.first = a.first; row.flags = fl;
+        for (int k = 0; k < 3; ++k) row.mean[k] = 0.f;
+        for (int k = 0; k < 6; ++k) row.scatter[k] = 0.0;
+        if (fl & 1u) {
+            const double c[3] = {axis_centre(row.sx, P.ox, P.grid_len), axis_centre(row.sy, P.oy, P.grid_len),
+                                 axis_centre(row.sz, P.oz, P.z_len)};
+            node_moments(a.count, a.s, c, row.mean, row.scatter);
+        }
+        const uint32_t cf = T.col_first[cs];
+        row.col_first = cf; row.idx_in_col = icol; row.ncol = T.col_cnt[cs];
+        for (int k = 0; k < 8; ++k) row.pad[k] = 0;
+        stage[i] = row;
+        ord_cf[i] = cf;
+        ord_idx[i] = icol;
+        if (icol == 0) {
+            ord_ncol[i] = row.ncol;
+            // the bitmap was sized from the host's view of the stream (max_points_hint for captured updates)
+            if ((uint64_t)(cf >> 5) < words) atomicOr(&bitmap[cf >> 5], 1u << (cf & 31u));
+            else atomicAdd(&pc->index_overflow, 1u);
+            ++my_cols;
+        }
+    }
+    // one memory-side atomic per block and counter
+    if (my_slopes) atomicAdd(&s_slopes, my_slopes);
+    if (my_cols) atomicAdd(&s_cols, my_cols);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (s_slopes) atomicAdd(&cnt->num_slopes, s_slopes);
+        if (s_cols) atomicAdd(&cnt->num_columns, s_cols);
+    }
+}
+
+__global__ void k_tab_end(Counters* cnt) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) cnt->prev_nodes = cnt->num_nodes;
+}
+
+}  // namespace gndt

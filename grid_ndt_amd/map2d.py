@@ -201,7 +201,7 @@ class TwoDmap:
         self._keep = (key, sums, count, first_idx)
 
     # ---- phase timing ----
-    PHASES = {1: ("clear", "accumulate", "scan", "label", "sort", "emit"),
+    PHASES = {1: ("clear", "accumulate", "columns", "rows", "bitmap_scan", "rank", "column_scan", "dest", "emit"),
               2: ("clear", "hist", "offsets", "scatter", "bucket_build", "bitmap_scan", "rank", "column_scan", "dest", "emit")}
     STRATEGY_NAMES = {1: "atomic", 2: "partition"}
 

@@ -163,7 +163,8 @@ void gndt_unpack_key(uint64_t key, int32_t* sx, int32_t* sy, int32_t* sz);
 /* With profiling on, build/accumulate/finalize record HIP events on the launch stream around each
  * phase; gndt_get_phase_times waits for them and returns milliseconds (-1 = phase did not run).
  * Phase names depend on the strategy the last build used (gndt_last_strategy):
- *   ATOMIC:    [0] clear  [1] accumulate  [2] scan  [3] label  [4] sort  [5] emit
+ *   ATOMIC:    [0] clear  [1] accumulate  [2] columns  [3] rows  [4] bitmap_scan  [5] rank
+ *              [6] column_scan  [7] dest  [8] emit
  *   PARTITION: [0] clear  [1] hist  [2] offsets  [3] scatter  [4] bucket_build  [5] bitmap_scan
  *              [6] rank  [7] column_scan  [8] dest  [9] emit */
 #define GNDT_NUM_PHASES 10

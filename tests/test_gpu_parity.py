@@ -124,6 +124,39 @@ def test_incremental_update_equals_batch_build():
     parity.assert_parity(m.export(), ref)
 
 
+def test_update_replayed_from_a_hip_graph_equals_batch_build():
+    """BASELINE configs[3] (streaming frames): one incremental update is captured in a hipGraph and replayed per
+    frame.  Nothing in accumulate + finalize waits for the host; the first_idx base lives on the device."""
+    import torch
+    import grid_ndt_amd as g
+    nf, ppf = 6, 30000
+    frames = scenes.terrain_frames(nf, first_pose=3, points_per_frame=ppf)
+    cloud = np.concatenate([frames[:1], frames], 0)
+    ref = parity.ref_from_cloud(cloud, TERRAIN)
+    m = g.TwoDmap(TERRAIN["grid_len"], TERRAIN["z_len"], strategy=1, max_nodes_hint=200000, max_points_hint=nf * ppf)
+    m.setInterval(TERRAIN["slope_interval"])
+    m.setCloudFirst(cloud[0])
+    buf = torch.empty(ppf, 3, dtype=torch.float32, device="cuda")
+    host = [torch.from_numpy(frames[f * ppf:(f + 1) * ppf]).cuda() for f in range(nf)]
+    buf.copy_(host[0])
+    m.change2DMap("slope", buf)          # eager first frame: allocates every buffer
+    m.sync()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        m.change2DMap("slope", buf)      # captured, not executed
+    for f in range(1, nf):
+        buf.copy_(host[f])
+        graph.replay()
+    torch.cuda.synchronize()
+    parity.assert_parity(m.export(), ref)
+    # running past max_points_hint is reported, not silently mis-ordered
+    buf.copy_(host[0] + 1000.0)
+    graph.replay()
+    torch.cuda.synchronize()
+    with pytest.raises(g.GndtError):
+        m.sync()
+
+
 def test_split_accumulate_finalize_and_stats_roundtrip():
     """accumulate(shard A) + accumulate(shard B) == build(A||B); stats export -> merge into a second
     handle reproduces the same map (the multi-GPU exchange primitive)."""
