@@ -71,29 +71,47 @@ def main():
     out[f"S3_terrain_{a.terrain_points // 1_000_000}M_1gpu"] = r
 
     # S4: streaming 10 Hz frames of 131 072 points, incremental update per frame (strategy ATOMIC keeps the
-    # additive statistics); latency per frame = accumulate + re-finalise of the whole map
+    # additive statistics); latency per frame = accumulate + re-finalise of the whole map.  Measured twice:
+    # eager launches, and one update captured in a hipGraph and replayed per frame (BASELINE configs[3]).
     frames = scenes.terrain_frames(a.frames, first_pose=0)
-    m = g.TwoDmap(0.2, 0.2, strategy=1, max_nodes_hint=4_000_000)
-    m.setInterval(0.08)
-    m.setCloudFirst(frames[0])
-    lat = []
     ppf = scenes.FRAME_POINTS
     dev_frames = [torch.from_numpy(frames[f * ppf:(f + 1) * ppf]).cuda() for f in range(a.frames)]
-    torch.cuda.synchronize()
-    for f in range(a.frames):
-        t0 = time.perf_counter()
-        m.change2DMap("slope", dev_frames[f])
+
+    def stream(graph_mode):
+        m = g.TwoDmap(0.2, 0.2, strategy=1, max_nodes_hint=4_000_000, max_points_hint=a.frames * ppf)
+        m.setInterval(0.08)
+        m.setCloudFirst(frames[0])
+        buf = torch.empty(ppf, 3, dtype=torch.float32, device="cuda")
+        buf.copy_(dev_frames[0])
+        m.change2DMap("slope", buf)
         m.sync()
-        lat.append((time.perf_counter() - t0) * 1e3)
-    nodes, cols, slopes = m.sync()
-    lat_s = np.sort(np.array(lat[5:]))
-    out["S4_streaming_128k_frames"] = {"frames": a.frames, "points_per_frame": ppf, "final_nodes": int(nodes),
-                                       "latency_ms_p50": round(float(np.percentile(lat_s, 50)), 3),
-                                       "latency_ms_p99": round(float(np.percentile(lat_s, 99)), 3),
-                                       "latency_ms_max": round(float(lat_s.max()), 3), "budget_ms": 100.0,
-                                       "Mpoints_per_s_at_p50": round(ppf / np.percentile(lat_s, 50) / 1e3, 1),
-                                       "note": "host-timed incl. the per-frame sync; not hipGraph-captured yet"}
-    del m, dev_frames
+        graph = None
+        if graph_mode:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                m.change2DMap("slope", buf)
+        lat = []
+        torch.cuda.synchronize()
+        for f in range(1, a.frames):
+            buf.copy_(dev_frames[f])
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            if graph_mode:
+                graph.replay()
+            else:
+                m.change2DMap("slope", buf)
+            torch.cuda.synchronize()
+            lat.append((time.perf_counter() - t0) * 1e3)
+        nodes, cols, slopes = m.sync()
+        lat_s = np.sort(np.array(lat[4:]))
+        return {"final_nodes": int(nodes), "latency_ms_p50": round(float(np.percentile(lat_s, 50)), 3),
+                "latency_ms_p99": round(float(np.percentile(lat_s, 99)), 3), "latency_ms_max": round(float(lat_s.max()), 3),
+                "Mpoints_per_s_at_p50": round(ppf / np.percentile(lat_s, 50) / 1e3, 1)}
+
+    out["S4_streaming_128k_frames"] = {"frames": a.frames, "points_per_frame": ppf, "budget_ms": 100.0,
+                                       "eager": stream(False), "hip_graph_replay": stream(True),
+                                       "note": "host-timed around one frame incl. the device sync; the whole map is re-finalised per frame"}
+    del dev_frames
 
     # S5 stand-in: two-storey site, 15 % of the points at (0,0,0) (the converters' pre-allocated clouds)
     cloud = scenes.site_two_storey(20_000_000)
