@@ -11,7 +11,7 @@ _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 _ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.path.join(_CSRC, "libgndt.so")
 SOURCES = ["gndt_api.hip", "gndt_codec.cpp"]
-HEADERS = ["gndt_kernels.hpp", "gndt_table.hpp", "gndt_partition.hpp", "gndt_bucket.hpp", "gndt_math.hpp", os.path.join(_ROOT, "include", "gndt.h")]
+HEADERS = ["gndt_kernels.hpp", "gndt_table.hpp", "gndt_cost.hpp", "gndt_partition.hpp", "gndt_bucket.hpp", "gndt_math.hpp", os.path.join(_ROOT, "include", "gndt.h")]
 
 GNDT_OK = 0
 ERR_NAMES = {0: "OK", 1: "INVALID", 2: "NO_DEVICE", 3: "HIP", 4: "KEY_RANGE", 5: "CAPACITY", 6: "NOMEM"}
@@ -34,6 +34,15 @@ class Cells(C.Structure):
                 ("sx", C.c_void_p), ("sy", C.c_void_p), ("sz", C.c_void_p), ("count", C.c_void_p),
                 ("first_idx", C.c_void_p), ("mean", C.c_void_p), ("cov", C.c_void_p), ("rough", C.c_void_p),
                 ("normal", C.c_void_p), ("flags", C.c_void_p)]
+
+
+class Robot(C.Structure):
+    _fields_ = [("radius", C.c_float), ("reachable_height", C.c_float), ("max_rough", C.c_float), ("max_angle_deg", C.c_float)]
+
+
+class CostStats(C.Structure):
+    _fields_ = [("goal_status", C.c_int32), ("ring", C.c_uint32), ("levels", C.c_uint32), ("reserved", C.c_uint32),
+                ("traversable", C.c_uint64), ("closed", C.c_uint64), ("check_pushes", C.c_uint64)]
 
 
 class Stats(C.Structure):
@@ -122,6 +131,9 @@ def lib():
     L.gndt_export.argtypes = [H, C.POINTER(Cells)]
     L.gndt_stats_export_device.argtypes = [H, C.POINTER(Stats), vp]
     L.gndt_stats_merge_device.argtypes = [H, C.POINTER(Stats), vp]
+    L.gndt_compute_cost.argtypes = [H, C.POINTER(C.c_float), C.POINTER(Robot), vp]
+    L.gndt_cost_export_device.argtypes = [H, C.POINTER(vp), C.POINTER(vp), C.POINTER(CostStats)]
+    L.gndt_cost_export.argtypes = [H, vp, vp, C.POINTER(CostStats)]
     L.gndt_trans_morton_xyz.argtypes = [C.POINTER(C.c_float), C.c_float, C.c_float, C.POINTER(C.c_float), C.c_char_p,
                                         C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_char_p]
     L.gndt_count_morton.argtypes = [C.c_int32, C.c_int32, C.c_char_p]
@@ -140,6 +152,7 @@ def lib():
     for name in ("gndt_create", "gndt_set_origin", "gndt_build", "gndt_build_device", "gndt_update", "gndt_update_device",
                  "gndt_reset", "gndt_accumulate_device", "gndt_finalize_device", "gndt_sync", "gndt_export_device",
                  "gndt_export", "gndt_stats_export_device", "gndt_stats_merge_device", "gndt_trans_morton_xyz",
+                 "gndt_compute_cost", "gndt_cost_export_device", "gndt_cost_export",
                  "gndt_count_morton", "gndt_morton_to_xy", "gndt_device_info", "gndt_set_profiling", "gndt_get_phase_times"):
         getattr(L, name).restype = C.c_int
     _lib = L

@@ -17,6 +17,7 @@
 #include "gndt_partition.hpp"
 #include "gndt_bucket.hpp"
 #include "gndt_table.hpp"
+#include "gndt_cost.hpp"
 
 using namespace gndt;
 
@@ -86,6 +87,17 @@ struct gndt_handle {
         uint64_t nodes_learned = 0;   // node count of the last successful PARTITION build (+20 %)
         int good_slots = 0; uint64_t good_est = 0, good_n = 0;   // table size / estimate that worked last time
     } part;
+    // cost-map flood over the finished grid (gndt_cost.hpp)
+    struct Cost {
+        uint64_t node_cap = 0;     uint32_t *h_bits = nullptr, *pushed = nullptr, *state = nullptr, *f[2] = {nullptr, nullptr};
+        uint32_t ctab_size = 0;    uint64_t* ctab_key = nullptr; uint32_t* ctab_val = nullptr;
+        uint32_t* ring = nullptr;
+        CostCounters* d_cc = nullptr;
+        CostCounters* h_cc = nullptr;   // pinned
+        uint64_t serial = 0;            // result_serial the flood was computed for (0 = none)
+        int ring_n = 0;
+    } cost;
+    uint64_t result_serial = 0;         // bumped whenever a build / finalize produces new result rows
     int last_strategy = GNDT_STRATEGY_ATOMIC;
     bool map_in_table = true;   // false after a PARTITION build: the HBM node table does not hold the map
 
@@ -230,6 +242,15 @@ int grow_buf(gndt_handle* h, T*& p, uint64_t& cap, uint64_t want) {
     HIP_TRY(h, hipMalloc(&p, want * sizeof(T)));
     cap = want;
     return GNDT_OK;
+}
+
+void free_cost(gndt_handle* h) {
+    auto& c = h->cost;
+    void* ptrs[] = {c.h_bits, c.pushed, c.state, c.f[0], c.f[1], c.ctab_key, c.ctab_val, c.ring, c.d_cc};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    if (c.h_cc) (void)hipHostFree(c.h_cc);
+    c = gndt_handle::Cost{};
 }
 
 void free_part(gndt_handle* h) {
@@ -396,6 +417,7 @@ int do_finalize(gndt_handle* h, hipStream_t s) {
     HIP_TRY(h, hipMemcpyAsync(q.h_pc, q.d_pc, sizeof(PartCounters), hipMemcpyDeviceToHost, s));
     HIP_TRY(h, hipMemcpyAsync(h->h_cnt, h->d_cnt, sizeof(Counters), hipMemcpyDeviceToHost, s));
     h->results_valid = true;
+    ++h->result_serial;
     h->last_stream = s;
     return GNDT_OK;
 }
@@ -580,6 +602,7 @@ int build_partition(gndt_handle* h, const void* xyz_dev, size_t n, size_t stride
         q.nodes_learned = (uint64_t)h->h_cnt->num_nodes + h->h_cnt->num_nodes / 5;
         q.good_slots = bslots; q.good_est = nodes_est; q.good_n = n;
         h->results_valid = true;
+        ++h->result_serial;
         h->map_in_table = false;
         h->table_dirty = false;
         h->last_strategy = GNDT_STRATEGY_PARTITION;
@@ -641,6 +664,7 @@ void gndt_destroy(gndt_handle* h) {
     (void)hipDeviceSynchronize();
     free_table(h);
     free_part(h);
+    free_cost(h);
     void* ptrs[] = {h->out.sx, h->out.sy, h->out.sz, h->out.count, h->out.first_idx, h->out.mean, h->out.cov,
                     h->out.rough, h->out.normal, h->out.flags, h->st_key, h->st_sums, h->st_count, h->st_first,
                     h->stage, h->d_cnt};
@@ -850,6 +874,120 @@ int gndt_export(gndt_handle* h, gndt_cells* o) {
         {o->rough, h->out.rough, 4}, {o->normal, h->out.normal, 12}, {o->flags, h->out.flags, 4}};
     for (auto& c : copies)
         if (c.dst && n) HIP_TRY(h, hipMemcpy(c.dst, c.src, n * c.elem, hipMemcpyDeviceToHost));
+    return GNDT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// cost-map flood (TwoDmap::computeCost, include/map2D.h:1285-1397) over the finished grid
+// ---------------------------------------------------------------------------------------------
+constexpr int kCostBlocks = 128, kCostThreads = 64, kCostBatch = 32;
+
+int gndt_compute_cost(gndt_handle* h, const float goal_xyz[3], const gndt_robot* robot, void* hip_stream) {
+    int rc = check_ready(h);
+    if (rc) return rc;
+    if (!goal_xyz) { h->err = "null goal"; return GNDT_ERR_INVALID; }
+    if (!h->results_valid) { h->err = "no finished build to flood (computeCost runs after create2DMap, receiver.cpp:160, 171)"; return GNDT_ERR_INVALID; }
+    rc = gndt_sync(h, nullptr, nullptr, nullptr);
+    if (rc) return rc;
+    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
+    auto& c = h->cost;
+    c.serial = 0;
+    const uint64_t n = h->res_nodes, K = h->res_columns;
+    if (!c.d_cc) {
+        HIP_TRY(h, hipMalloc(&c.d_cc, sizeof(CostCounters)));
+        HIP_TRY(h, hipHostMalloc(&c.h_cc, sizeof(CostCounters)));
+        HIP_TRY(h, hipMalloc(&c.ring, (size_t)kCostBlocks * kCostThreads * kRingCap * sizeof(uint32_t)));
+    }
+    if (n > c.node_cap) {
+        for (uint32_t** a : {&c.h_bits, &c.pushed, &c.state, &c.f[0], &c.f[1]}) { if (*a) (void)hipFree(*a); *a = nullptr; }
+        c.node_cap = 0;
+        const uint64_t cap = std::max<uint64_t>(1024, n + n / 8);
+        for (uint32_t** a : {&c.h_bits, &c.pushed, &c.state, &c.f[0], &c.f[1]}) HIP_TRY(h, hipMalloc(a, cap * 4));
+        c.node_cap = cap;
+    }
+    const uint32_t tsize = pow2_ceil(std::max<uint64_t>(1024, 2 * K));
+    if (tsize > c.ctab_size) {
+        if (c.ctab_key) (void)hipFree(c.ctab_key);
+        if (c.ctab_val) (void)hipFree(c.ctab_val);
+        c.ctab_key = nullptr; c.ctab_val = nullptr; c.ctab_size = 0;
+        HIP_TRY(h, hipMalloc(&c.ctab_key, (size_t)tsize * 8));
+        HIP_TRY(h, hipMalloc(&c.ctab_val, (size_t)tsize * 4));
+        c.ctab_size = tsize;
+    }
+    Robot R{0.25f, 0.15f, 100.f, 30.f};   // receiver.cpp:33, robot.h:38-46
+    if (robot) R = Robot{robot->radius, robot->reachable_height, robot->max_rough, robot->max_angle_deg};
+    c.ring_n = cost_ring_depth(R.r, h->P.grid_len);
+    CostView V;
+    V.sx = h->out.sx; V.sy = h->out.sy; V.sz = h->out.sz;
+    V.mean = h->out.mean; V.normal = h->out.normal; V.rough = h->out.rough; V.flags = h->out.flags;
+    V.col_base = h->part.col_base; V.col_size = h->part.col_size;
+    V.ctab_key = c.ctab_key; V.ctab_val = c.ctab_val; V.ctab_mask = c.ctab_size - 1;
+    V.slope_interval = h->P.slope_interval; V.demand_true = h->P.demand == GNDT_DEMAND_TRUE ? 1 : 0;
+    // the goal's key through the same codec the build uses (transMortonXYZ, map2D.h:1293)
+    const PointKey gk = point_key(goal_xyz[0], goal_xyz[1], goal_xyz[2], h->origin[0], h->origin[1], h->origin[2],
+                                  h->P.grid_len, h->P.z_len);
+    hipLaunchKernelGGL(k_cost_clear, dim3(grid_for(std::max<uint64_t>(n, c.ctab_size))), dim3(256), 0, s, c.h_bits, c.pushed,
+                       c.state, (uint32_t)n, c.ctab_key, c.ctab_size, c.d_cc);
+    if (K)
+        hipLaunchKernelGGL(k_cost_columns, dim3(grid_for(K)), dim3(256), 0, s, h->out.sx, h->out.sy, h->part.col_base,
+                           (uint32_t)K, c.ctab_key, c.ctab_val, c.ctab_size - 1, c.d_cc);
+    if (gk.ok && K)
+        hipLaunchKernelGGL(k_cost_goal, dim3(1), dim3(64), 0, s, V, gk.sx, gk.sy, gk.sz, c.h_bits, c.pushed, c.f[0], c.d_cc);
+    HIP_TRY(h, hipGetLastError());
+    // One launch per layer.  The layer count is only known on the device, so layers are enqueued in batches and
+    // the frontier size of the next layer is read back after each batch (empty layers are no-ops).
+    uint32_t level = 0;
+    for (;;) {
+        for (int b = 0; b < kCostBatch; ++b, ++level)
+            hipLaunchKernelGGL(k_cost_level, dim3(kCostBlocks), dim3(kCostThreads), 0, s, V, R, c.ring_n, level, c.h_bits,
+                               c.pushed, c.state, c.f[level & 1u], c.f[(level + 1u) & 1u], c.ring, c.d_cc);
+        HIP_TRY(h, hipGetLastError());
+        HIP_TRY(h, hipMemcpyAsync(c.h_cc, c.d_cc, sizeof(CostCounters), hipMemcpyDeviceToHost, s));
+        HIP_TRY(h, hipStreamSynchronize(s));
+        if (c.h_cc->frontier[level % 3u] == 0u) break;
+        if (level > (1u << 24)) { h->err = "cost flood did not terminate"; return GNDT_ERR_HIP; }
+    }
+    if (c.h_cc->range_error) {
+        h->err = "cost map: column indices beyond 32767 (mortonToXY decodes no further, Stopwatch.h:171-189)";
+        return GNDT_ERR_KEY_RANGE;
+    }
+    if (c.h_cc->ring_overflow) {
+        h->err = "cost map: a collision ring holds more than " + std::to_string(kRingCap) + " slopes (robot radius too large for this grid)";
+        return GNDT_ERR_CAPACITY;
+    }
+    c.serial = h->result_serial;
+    return GNDT_OK;
+}
+
+static int cost_ready(gndt_handle* h, gndt_cost_stats* st) {
+    if (!h) return GNDT_ERR_INVALID;
+    if (!h->results_valid || h->cost.serial == 0 || h->cost.serial != h->result_serial) {
+        h->err = "no cost map for the current grid (call gndt_compute_cost after the build)";
+        return GNDT_ERR_INVALID;
+    }
+    if (st) {
+        const CostCounters* cc = h->cost.h_cc;
+        st->goal_status = cc->goal_status; st->ring = (uint32_t)h->cost.ring_n; st->levels = cc->levels; st->reserved = 0;
+        st->traversable = cc->traversable; st->closed = cc->closed; st->check_pushes = cc->check_pushes;
+    }
+    return GNDT_OK;
+}
+
+int gndt_cost_export_device(gndt_handle* h, const float** h_dev, const uint32_t** state_dev, gndt_cost_stats* stats) {
+    int rc = cost_ready(h, stats);
+    if (rc) return rc;
+    if (h_dev) *h_dev = reinterpret_cast<const float*>(h->cost.h_bits);
+    if (state_dev) *state_dev = h->cost.state;
+    return GNDT_OK;
+}
+
+int gndt_cost_export(gndt_handle* h, float* h_out, uint32_t* state_out, gndt_cost_stats* stats) {
+    int rc = cost_ready(h, stats);
+    if (rc) return rc;
+    HIP_TRY(h, hipSetDevice(h->device));
+    const uint64_t n = h->res_nodes;
+    if (h_out && n) HIP_TRY(h, hipMemcpy(h_out, h->cost.h_bits, n * 4, hipMemcpyDeviceToHost));
+    if (state_out && n) HIP_TRY(h, hipMemcpy(state_out, h->cost.state, n * 4, hipMemcpyDeviceToHost));
     return GNDT_OK;
 }
 

@@ -10,7 +10,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import Cells, GndtError, Params, Stats
+from ._lib import Cells, CostStats, GndtError, Params, Robot, Stats
 
 DEMANDS = {"slope": 0, "true": 1}
 FLAG_HAS_STATS, FLAG_SLOPE, FLAG_DOWN = 1, 2, 4
@@ -226,6 +226,38 @@ class TwoDmap:
         self._check(self._L.gndt_debug_bucket_phases(self._h, arr, C.byref(nb)))
         names = ("clear", "accumulate", "columns", "labels", "order", "emit", "acc:load", "acc:classify", "acc:scatter", "acc:reduce")
         return dict(zip(names, list(arr))), nb.value
+
+    # ---- cost map (TwoDmap::computeCost, map2D.h:1285-1397) ----
+    def computeCost(self, goal, robot=None, stream=None):
+        """Flood the finished grid from the slope under `goal` (xyz).  `robot`: dict with radius,
+        reachable_height, max_rough, max_angle_deg (defaults: RobotSphere(0.25), robot.h:38-46).
+        Returns the statistics dict; h / state per result row come from cost_export()."""
+        g = (C.c_float * 3)(*[float(v) for v in goal])
+        rb = None
+        if robot is not None:
+            d = dict(radius=0.25, reachable_height=0.15, max_rough=100.0, max_angle_deg=30.0)
+            d.update(robot)
+            rb = C.byref(Robot(d["radius"], d["reachable_height"], d["max_rough"], d["max_angle_deg"]))
+        self._check(self._L.gndt_compute_cost(self._h, g, rb, _stream_ptr(stream)))
+        st = CostStats()
+        self._check(self._L.gndt_cost_export(self._h, None, None, C.byref(st)))
+        return self._cost_stats(st)
+
+    @staticmethod
+    def _cost_stats(st):
+        return {"rc": int(st.goal_status), "ring": int(st.ring), "levels": int(st.levels), "traversable": int(st.traversable),
+                "closed": int(st.closed), "check_pushes": int(st.check_pushes)}
+
+    def cost_export(self):
+        """Host copy of Slope::h (fp32, FLT_MAX = unreached) and the flood state per result row."""
+        n, _, _ = self.sync()
+        h = np.zeros(n, np.float32)
+        state = np.zeros(n, np.uint32)
+        st = CostStats()
+        self._check(self._L.gndt_cost_export(self._h, h.ctypes.data, state.ctypes.data, C.byref(st)))
+        out = self._cost_stats(st)
+        out.update(h=h, state=state.astype(np.uint8))
+        return out
 
     # ---- results ----
     def sync(self):

@@ -146,6 +146,39 @@ int gndt_stats_export_device(gndt_handle* h, gndt_stats* out, void* hip_stream);
 /* Adds `in` (device memory) into the handle's table: sums add, counts add, first_idx takes the min. */
 int gndt_stats_merge_device(gndt_handle* h, const gndt_stats* in, void* hip_stream);
 
+/* ---- cost map over the finished grid -------------------------------------
+ * gndt_compute_cost replaces TwoDmap::computeCost (include/map2D.h:1285-1397; called at receiver.cpp:171
+ * right after create2DMap): the FIFO flood from the goal slope with CollisionCheck (:351-411; the 3D variants
+ * :414-474 when the handle's demand is "true") and AccessibleNeighbors (:530-588).  It fills, per result row,
+ *   h      Slope::h  (FLT_MAX where the row has no Slope, was never reached, or collided and was not relaxed again)
+ *   state  0 = untouched, 1 = traversable (the reference's `traversability` list), 2 = closed (collision)
+ * bit-identical to the reference's sequential flood on the same grid (DESIGN.md "Cost map").
+ * The call returns when the flood is complete.  Column indices must not exceed 32767 (mortonToXY's range,
+ * Stopwatch.h:171-189).  `robot` NULL = RobotSphere(0.25) with robot.h:38-46's thresholds. */
+typedef struct gndt_robot {
+    float radius;            /* RobotSphere::r            receiver.cpp:33  */
+    float reachable_height;  /* getReachableHeight() 0.15  robot.h:38-39   */
+    float max_rough;         /* getRough() 100             robot.h:40-43   */
+    float max_angle_deg;     /* getAngle() 30              robot.h:44-46   */
+} gndt_robot;
+
+typedef struct gndt_cost_stats {
+    int32_t goal_status;     /* 0 flood ran; 1 no cell at the goal (reference: nothing happens); 2 no slope at the
+                                goal's level ("Goal position wrong", map2D.h:1304-1306) */
+    uint32_t ring;           /* n = (ceil(2r/gridLen)-1)/2, the collision ring depth (map2D.h:1310) */
+    uint32_t levels;         /* layers of the flood */
+    uint32_t reserved;
+    uint64_t traversable;    /* traversability.size() (map2D.h:1382) */
+    uint64_t closed;         /* slopes closed by a collision */
+    uint64_t check_pushes;   /* checkList.size() (map2D.h:1383) */
+} gndt_cost_stats;
+
+int gndt_compute_cost(gndt_handle* h, const float goal_xyz[3], const gndt_robot* robot, void* hip_stream);
+/* Device-resident h (fp32) and state (u32) per result row; valid until the next build/update/compute_cost. */
+int gndt_cost_export_device(gndt_handle* h, const float** h_dev, const uint32_t** state_dev, gndt_cost_stats* stats);
+/* Copies into caller-allocated host arrays of num_nodes elements (NULL arrays skipped). */
+int gndt_cost_export(gndt_handle* h, float* h_out, uint32_t* state_out, gndt_cost_stats* stats);
+
 /* ---- host key codec (consumers call transMortonXYZ on pos/goal: map2D.h:1071,1293; GlobalPlan.h:56) */
 /* `transMortonXYZ` (map2D.h:950-976): quadrant letter, 1-based indices, signed z level and the
  * map key string (letter + decimal Morton, <= 12 chars + NUL). */

@@ -16,8 +16,8 @@ _lib = None
 
 def build(force=False):
     """Compile oracle/ref_cpu.cpp -> oracle/liboracle.so (g++, a second or two)."""
-    src = os.path.join(_HERE, "ref_cpu.cpp")
-    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, f) for f in ("ref_cpu.cpp", "cost_cpu.cpp", "ref_codec.hpp", "Makefile")]
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-B", "liboracle.so"], stdout=subprocess.DEVNULL)
     return _LIB_PATH
 
@@ -43,6 +43,10 @@ def lib():
         L.oracle_max_threads.restype = C.c_int
         L.oracle_export.argtypes = [C.c_void_p] + [C.c_void_p] * 17
         L.oracle_free.argtypes = [C.c_void_p]
+        L.oracle_compute_cost.argtypes = [C.c_size_t] + [C.c_void_p] * 8 + [C.POINTER(C.c_float), C.c_float, C.c_float, C.c_float,
+                                          C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int, C.c_void_p, C.c_void_p,
+                                          C.c_void_p, C.c_void_p]
+        L.oracle_compute_cost.restype = C.c_int
         _lib = L
     return _lib
 
@@ -114,3 +118,35 @@ def build_grid(cloud, grid_len, z_len, slope_interval, demand="slope", min_point
 
 def max_threads():
     return lib().oracle_max_threads()
+
+
+# RobotSphere thresholds (include/robot.h:12, 38-46): radius 0.25 (receiver.cpp:33), reachable height 0.15,
+# roughness 100, angle 30 degrees
+ROBOT_DEFAULT = dict(radius=0.25, reachable_height=0.15, max_rough=100.0, max_angle_deg=30.0)
+COST_AS_SHIPPED, COST_FLAGS = 0, 1
+
+
+def compute_cost(cells, origin, grid_len, z_len, slope_interval, goal, demand="slope", robot=None, mode=COST_FLAGS):
+    """TwoDmap::computeCost (map2D.h:1285-1397) on an exported grid (`cells`: dict with sx, sy, sz, count, mean,
+    normal, rough, flags in reference node order).  Returns dict(rc, h, state, traversable, closed, check_pushes,
+    ring, angle_margin_deg, height_margin)."""
+    rb = dict(ROBOT_DEFAULT)
+    rb.update(robot or {})
+    n = int(len(cells["sx"]))
+    arr = {k: np.ascontiguousarray(cells[k], dtype=t) for k, t in
+           (("sx", np.int32), ("sy", np.int32), ("sz", np.int32), ("count", np.uint32), ("mean", np.float32),
+            ("normal", np.float32), ("rough", np.float32), ("flags", np.uint32))}
+    h = np.zeros(n, np.float32)
+    state = np.zeros(n, np.uint8)
+    stats = np.zeros(4, np.int64)
+    margins = np.zeros(2, np.float64)
+    o = (C.c_float * 3)(*[float(v) for v in origin])
+    g = (C.c_float * 3)(*[float(v) for v in goal])
+    r4 = (C.c_float * 4)(float(rb["radius"]), float(rb["reachable_height"]), float(rb["max_rough"]), float(rb["max_angle_deg"]))
+    dem = {"slope": 0, "true": 1}[demand] if isinstance(demand, str) else int(demand)
+    rc = lib().oracle_compute_cost(n, *[arr[k].ctypes.data for k in ("sx", "sy", "sz", "count", "mean", "normal", "rough", "flags")],
+                                   o, float(grid_len), float(z_len), float(slope_interval), dem, g, r4, int(mode),
+                                   h.ctypes.data, state.ctypes.data, stats.ctypes.data, margins.ctypes.data)
+    return {"rc": rc, "h": h, "state": state, "traversable": int(stats[0]), "closed": int(stats[1]),
+            "check_pushes": int(stats[2]), "ring": int(stats[3]), "angle_margin_deg": float(margins[0]),
+            "height_margin": float(margins[1])}

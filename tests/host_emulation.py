@@ -18,8 +18,8 @@ def shim():
     global _lib
     if _lib is None:
         src = os.path.join(_HERE, "host_math_shim.cpp")
-        hdr = os.path.join(_ROOT, "grid_ndt_amd", "csrc", "gndt_math.hpp")
-        if not os.path.exists(_SO) or os.path.getmtime(_SO) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+        hdrs = [os.path.join(_ROOT, "grid_ndt_amd", "csrc", f) for f in ("gndt_math.hpp", "gndt_cost.hpp")]
+        if not os.path.exists(_SO) or os.path.getmtime(_SO) < max(os.path.getmtime(f) for f in [src] + hdrs):
             subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-I",
                                    os.path.join(_ROOT, "grid_ndt_amd", "csrc"), "-o", _SO, src])
         _lib = C.CDLL(_SO)
@@ -127,3 +127,29 @@ def finalize(uk, count, first, sums, cen, slope_interval, demand="slope", min_po
 def build(cloud, grid_len, z_len, slope_interval, demand="slope"):
     t = accumulate(cloud[1:], cloud[0, :3], grid_len, z_len)
     return finalize(*t, slope_interval, demand)
+
+
+def cost_levelsync(cells, grid_len, slope_interval, goal_key, demand="slope", robot=None):
+    """The level-synchronous flood of gndt_cost.hpp run on the host (same per-slope code as the kernels).
+    `goal_key` = (sx, sy, sz) of the goal.  Returns dict(rc, h, state, traversable, closed, check_pushes, ring,
+    levels, ring_overflow)."""
+    rb = dict(radius=0.25, reachable_height=0.15, max_rough=100.0, max_angle_deg=30.0)
+    rb.update(robot or {})
+    n = int(len(cells["sx"]))
+    arr = {k: np.ascontiguousarray(cells[k], dtype=t) for k, t in
+           (("sx", np.int32), ("sy", np.int32), ("sz", np.int32), ("mean", np.float32), ("normal", np.float32),
+            ("rough", np.float32), ("flags", np.uint32))}
+    h = np.zeros(n, np.float32)
+    state = np.zeros(n, np.uint8)
+    stats = np.zeros(6, np.int64)
+    r4 = (C.c_float * 4)(float(rb["radius"]), float(rb["reachable_height"]), float(rb["max_rough"]), float(rb["max_angle_deg"]))
+    L = shim()
+    L.shim_cost.restype = C.c_int
+    L.shim_cost.argtypes = [C.c_uint64] + [C.c_void_p] * 7 + [C.c_float, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int,
+                            C.POINTER(C.c_float), C.c_void_p, C.c_void_p, C.c_void_p]
+    dem = {"slope": 0, "true": 1}[demand] if isinstance(demand, str) else int(demand)
+    rc = L.shim_cost(n, *[arr[k].ctypes.data for k in ("sx", "sy", "sz", "mean", "normal", "rough", "flags")],
+                     float(slope_interval), dem, float(grid_len), int(goal_key[0]), int(goal_key[1]), int(goal_key[2]), r4,
+                     h.ctypes.data, state.ctypes.data, stats.ctypes.data)
+    return {"rc": rc, "h": h, "state": state, "traversable": int(stats[0]), "closed": int(stats[1]),
+            "check_pushes": int(stats[2]), "ring": int(stats[3]), "levels": int(stats[4]), "ring_overflow": int(stats[5])}

@@ -46,3 +46,63 @@ extern "C" void shim_jacobi(const double* S, uint64_t n, double* evals, double* 
         for (int k = 0; k < 3; ++k) { evals[3 * i + k] = ev[k]; for (int j = 0; j < 3; ++j) evecs[9 * i + 3 * k + j] = vv[k][j]; }
     }
 }
+
+// ---- cost-map flood (grid_ndt_amd/csrc/gndt_cost.hpp): the per-slope logic the kernels run, driven level by
+// level on the host exactly as k_cost_level is launched layer after layer ----
+#include <vector>
+#include "gndt_cost.hpp"
+extern "C" int shim_cost(uint64_t n, const int32_t* sx, const int32_t* sy, const int32_t* sz, const float* mean,
+                         const float* normal, const float* rough, const uint32_t* flags, float slope_interval,
+                         int demand_true, float grid_len, int gx, int gy, int gz, const float robot4[4], float* h_out,
+                         uint8_t* state_out, int64_t stats[6]) {
+    using namespace gndt;
+    // columns are contiguous in the reference order
+    std::vector<uint32_t> col_base, col_size;
+    for (uint64_t i = 0; i < n; ++i) {
+        if (i == 0 || sx[i] != sx[i - 1] || sy[i] != sy[i - 1]) { col_base.push_back((uint32_t)i); col_size.push_back(0); }
+        ++col_size.back();
+    }
+    uint32_t tsize = 1024;
+    while (tsize < 2 * col_base.size()) tsize <<= 1;
+    std::vector<uint64_t> tkey(tsize, kEmptyKey);
+    std::vector<uint32_t> tval(tsize, 0);
+    for (uint32_t c = 0; c < col_base.size(); ++c) {
+        const uint64_t key = column_pack(sx[col_base[c]], sy[col_base[c]]);
+        uint32_t s = (uint32_t)mix64(key) & (tsize - 1);
+        while (tkey[s] != kEmptyKey) s = (s + 1) & (tsize - 1);
+        tkey[s] = key; tval[s] = c;
+    }
+    CostView V{sx, sy, sz, mean, normal, rough, flags, col_base.data(), col_size.data(), tkey.data(), tval.data(), tsize - 1,
+               slope_interval, demand_true};
+    Robot R{robot4[0], robot4[1], robot4[2], robot4[3]};
+    const int ring_n = cost_ring_depth(R.r, grid_len);
+    std::vector<uint32_t> hb(n, 0x7F7FFFFFu), pushed(n, 0), state(n, 0), frontier, next, ring(kRingCap);
+    int64_t trav = 0, closed = 0, checks = 0, levels = 0, overflow = 0;
+    int goal_status = 1;
+    const uint32_t gc = ctab_find(V, gx, gy);
+    if (gc != kNoColumn) {
+        goal_status = 2;
+        for (uint32_t t = col_base[gc]; t < col_base[gc] + col_size[gc]; ++t)
+            if (sz[t] == gz && row_has_slope(V, t)) { hb[t] = 0; pushed[t] = 1; frontier.push_back(t); goal_status = 0; break; }
+    }
+    while (!frontier.empty()) {
+        ++levels;
+        next.clear();
+        for (uint32_t q : frontier) {
+            const int hit = cost_collide(V, R, q, ring_n, ring.data());
+            if (hit < 0) { ++overflow; continue; }
+            if (hit) { hb[q] = 0x7F7FFFFFu; state[q] = 2; ++closed; continue; }
+            state[q] = 1; ++trav;
+            checks += cost_expand(V, R, q, bits_float(hb[q]), [&](uint32_t t, float cand) {
+                const uint32_t cb = float_bits(cand);
+                const uint32_t old = hb[t];
+                if (cb < old) hb[t] = cb;
+                if (old > cb && pushed[t] == 0) { pushed[t] = 1; next.push_back(t); }
+            });
+        }
+        frontier.swap(next);
+    }
+    for (uint64_t i = 0; i < n; ++i) { h_out[i] = bits_float(hb[i]); state_out[i] = (uint8_t)state[i]; }
+    stats[0] = trav; stats[1] = closed; stats[2] = checks; stats[3] = ring_n; stats[4] = levels; stats[5] = overflow;
+    return goal_status;
+}

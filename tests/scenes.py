@@ -235,6 +235,44 @@ def site_two_storey(n=20_000_000, seed=0x5EED0005, zero_fraction=0.15, chunk=1 <
     return out
 
 
+# --------------------------------------------------------------------------------------------------
+# Cost-map scene: gently rolling ground with everything the flood has to react to —
+# kerbs higher than the robot's reachable height (0.15 m, robot.h:38), a raised platform reached by a
+# ramp, free-standing walls, overhanging slabs 0.3 m above the ground (closer than the robot's diameter:
+# collision), and a sparsely sampled region whose normals are noisy (angle gate).  The area straddles the
+# origin so the flood crosses all four quadrant seams (countLRFB, map2D.h:226-255).
+# --------------------------------------------------------------------------------------------------
+COST_PARAMS = dict(grid_len=0.5, z_len=0.25, slope_interval=0.08, demand="slope")
+DRIVABLE_GOAL = (-5.2, -3.3, float(0.35 * np.sin(-5.2 / 7.0) + 0.25 * np.cos(-3.3 / 5.0)))
+
+
+def drivable_site(n=400000, seed=0x5EED0006, half=30.0):
+    i = np.arange(n, dtype=np.uint64)
+    x = (u01(i, seed) * 2 - 1) * half
+    y = (u01(i, seed + 1) * 2 - 1) * half
+    sel = u01(i, seed + 2)
+    # thin the north-east corner: few points per cell -> noisy normals, some cells without statistics
+    thin = (x > 0.5 * half) & (y > 0.5 * half) & (sel > 0.08)
+    z = 0.35 * np.sin(x / 7.0) + 0.25 * np.cos(y / 5.0) + 0.004 * normal01(i, seed + 3)
+    # platform (+0.45 m) with a ramp on its west side
+    plat = (x > 8) & (x < 16) & (y > -6) & (y < 4)
+    z = np.where(plat, z + 0.45, z)
+    ramp = (x > 3) & (x <= 8) & (y > -3) & (y < 1)
+    z = np.where(ramp, z + 0.45 * (x - 3) / 5.0, z)
+    # kerb: a 0.3 m step along y = -12 for x < 0
+    z = np.where((y < -12) & (x < 0), z - 0.3, z)
+    # walls: points spread over 0..2 m above the ground in two strips
+    wall = ((np.abs(x + 10) < 0.3) & (y > 0) & (y < 15)) | ((np.abs(y - 18) < 0.3) & (x > -20) & (x < 5))
+    z = np.where(wall & (sel < 0.7), z + 2.0 * u01(i, seed + 4), z)
+    # overhanging slab 0.3 m above the ground (a second surface in the same columns)
+    slab = (x > -25) & (x < -18) & (y > -8) & (y < -2)
+    z = np.where(slab & (sel < 0.5), z + 0.3, z)
+    keep = ~thin
+    pts = np.stack([x, y, z], 1)[keep].astype(np.float32)
+    origin = np.array([[0.013, -0.021, float(0.35 * np.sin(0.013 / 7.0) + 0.25 * np.cos(-0.021 / 5.0))]], np.float32)
+    return np.concatenate([origin, pts], 0)
+
+
 def with_stride4(cloud):
     """pcl::PointXYZ layout: 16-byte points, 4th float is padding (set to 1.0 like PCL's data[3])."""
     out = np.ones((cloud.shape[0], 4), np.float32)

@@ -1,0 +1,165 @@
+"""CPU tier for the cost-map flood (TwoDmap::computeCost, map2D.h:1285-1397).
+
+The reference has no tests for this path, so the oracle (oracle/cost_cpu.cpp) is pinned by hand-derived
+cases, by running its two executions (std::list "as shipped" vs flags) against each other, and the product's
+level-synchronous restructuring (grid_ndt_amd/csrc/gndt_cost.hpp, run on the host through the test shim) is
+checked bit for bit against the oracle's sequential FIFO flood."""
+import numpy as np
+import pytest
+
+from oracle import oracle
+from tests import host_emulation as he
+from tests import scenes
+
+FLT_MAX = np.float32(3.4028234663852886e38)
+UP = (0.0, 0.0, 1.0)
+
+
+def make_cells(rows):
+    """rows: list of (sx, sy, sz, mean_xyz, normal, is_slope); columns must be contiguous."""
+    n = len(rows)
+    c = {"sx": np.array([r[0] for r in rows], np.int32), "sy": np.array([r[1] for r in rows], np.int32),
+         "sz": np.array([r[2] for r in rows], np.int32), "count": np.full(n, 10, np.uint32),
+         "mean": np.array([r[3] for r in rows], np.float32).reshape(n, 3),
+         "normal": np.array([r[4] for r in rows], np.float32).reshape(n, 3), "rough": np.full(n, 0.01, np.float32),
+         "flags": np.array([1 | (2 if r[5] else 0) for r in rows], np.uint32)}
+    return c
+
+
+def centre(s):
+    return s - 0.5 if s > 0 else s + 0.5
+
+
+def flat_row(sx, sy, z=0.1, normal=UP, slope=True, sz=1):
+    return (sx, sy, sz, (centre(sx), centre(sy), z), normal, slope)
+
+
+def run_both(cells, goal, demand="slope", robot=None, grid_len=1.0):
+    o = oracle.compute_cost(cells, (0, 0, 0), grid_len, 1.0, 0.08, goal, demand=demand, robot=robot, mode=oracle.COST_AS_SHIPPED)
+    f = oracle.compute_cost(cells, (0, 0, 0), grid_len, 1.0, 0.08, goal, demand=demand, robot=robot, mode=oracle.COST_FLAGS)
+    assert o["rc"] == f["rc"] and (o["h"] == f["h"]).all() and (o["state"] == f["state"]).all()
+    key, nx, ny, sz = oracle.trans_morton_xyz((0, 0, 0), grid_len, 1.0, goal)
+    gk = (nx if key[0] in "AB" else -nx, ny if key[0] in "AC" else -ny, sz)
+    e = he.cost_levelsync(cells, grid_len, 0.08, gk, demand=demand, robot=robot)
+    assert e["rc"] == o["rc"] and (e["h"] == o["h"]).all() and (e["state"] == o["state"]).all()
+    assert e["traversable"] == o["traversable"] and e["closed"] == o["closed"] and e["check_pushes"] == o["check_pushes"]
+    return o
+
+
+def test_corridor_across_the_quadrant_seam_accumulates_unit_steps():
+    # cells sx = -3,-2,-1,1,2,3 (there is no cell 0: countLRFB hands x==1 over to the mirrored quadrant)
+    xs = [-3, -2, -1, 1, 2, 3]
+    cells = make_cells([flat_row(x, 1) for x in xs])
+    c = run_both(cells, (-2.5, 0.5, 0.1))
+    assert c["rc"] == 0 and c["traversable"] == 6 and c["closed"] == 0
+    np.testing.assert_array_equal(c["h"], np.array([0, 1, 2, 3, 4, 5], np.float32))
+    np.testing.assert_array_equal(c["state"], np.ones(6, np.uint8))
+    # the same along y, through the A/B seam
+    cells = make_cells([flat_row(2, y) for y in xs])
+    c = run_both(cells, (1.5, 2.5, 0.1))
+    np.testing.assert_array_equal(c["h"], np.array([5, 4, 3, 2, 1, 0], np.float32))
+
+
+def test_height_gate_and_angle_gate_stop_the_flood():
+    # a 0.2 m step (> reachable height 0.15) between sx=2 and sx=3; a 0.1 m step passes
+    cells = make_cells([flat_row(1, 1), flat_row(2, 1, z=0.2), flat_row(3, 1, z=0.4), flat_row(4, 1, z=0.4)])
+    c = run_both(cells, (0.5, 0.5, 0.1))
+    assert c["traversable"] == 2
+    assert c["h"][0] == 0 and c["h"][2] == FLT_MAX and c["h"][3] == FLT_MAX
+    d = np.float32(np.sqrt(np.float64(1.0) + np.float64(np.float32(0.1) - np.float32(0.2)) ** 2))
+    assert c["h"][1] == d
+    # the angle is taken between NEIGHBOURING normals: 0 -> 20 degrees passes, 20 -> 55 does not (<= 30, robot.h:44)
+    n20 = (np.sin(np.radians(20.0)), 0.0, np.cos(np.radians(20.0)))
+    n45 = (np.sin(np.radians(55.0)), 0.0, np.cos(np.radians(55.0)))
+    cells = make_cells([flat_row(1, 1), flat_row(2, 1, normal=n20), flat_row(3, 1, normal=n45), flat_row(4, 1, normal=n45)])
+    c = run_both(cells, (0.5, 0.5, 0.1))
+    assert c["traversable"] == 2 and c["h"][2] == FLT_MAX
+    # antiparallel normals fold to the same angle (an > 90 -> 180 - an)
+    cells = make_cells([flat_row(1, 1), flat_row(2, 1, normal=(0, 0, -1))])
+    c = run_both(cells, (0.5, 0.5, 0.1))
+    assert c["traversable"] == 2 and c["h"][1] == 1
+
+
+def test_overhang_in_the_same_cell_is_a_collision():
+    # a second slope 0.3 m above in cell sx=2: closer than 2r = 0.5 and more than 0.15 above -> collide (map2D.h:399-403)
+    rows = [flat_row(1, 1), flat_row(2, 1), (2, 1, 2, (1.5, 0.5, 0.4), UP, True), flat_row(3, 1)]
+    c = run_both(make_cells(rows), (0.5, 0.5, 0.1))
+    assert c["state"].tolist() == [1, 2, 0, 0] and c["closed"] == 1
+    assert c["h"][1] == FLT_MAX and c["h"][3] == FLT_MAX
+    # 0.6 m above: not within the robot's diameter -> free, and the flood goes on underneath
+    rows[2] = (2, 1, 2, (1.5, 0.5, 0.7), UP, True)
+    c = run_both(make_cells(rows), (0.5, 0.5, 0.1))
+    assert c["state"].tolist() == [1, 1, 0, 1] and c["h"][3] == 2
+
+
+def test_ring_collision_looks_n_cells_around():
+    # r = 0.8, gridLen 1 -> n = (ceil(1.6) - 1) / 2 = 0 (fp32, truncated); r = 1.3 -> n = 1
+    # cell (3,1) is 0.1 higher than (2,1) and (4,1) 0.1 higher again: every step passes the height gate, but seen
+    # from (2,1) with ring 2 the slope of (4,1) is 0.2 above -> collide (map2D.h:388-391)
+    rows = [flat_row(1, 1), flat_row(2, 1), flat_row(3, 1, z=0.2), flat_row(4, 1, z=0.3)]
+    c = run_both(make_cells(rows), (0.5, 0.5, 0.1), robot={"radius": 0.8})
+    assert c["ring"] == 0 and c["state"].tolist() == [1, 1, 1, 1]
+    c = run_both(make_cells(rows), (0.5, 0.5, 0.1), robot={"radius": 2.3})
+    assert c["ring"] == 2
+    # (1,1): ring reaches (3,1) at +0.1 only -> free; (2,1): ring reaches (4,1) at +0.2 -> collide
+    assert c["state"].tolist()[:2] == [1, 2]
+
+
+def test_goal_lookup_statuses():
+    cells = make_cells([flat_row(1, 1), flat_row(2, 1, slope=False)])
+    assert run_both(cells, (10.5, 0.5, 0.1))["rc"] == 1          # no cell there: the reference does nothing
+    assert run_both(cells, (0.5, 0.5, 2.5))["rc"] == 2           # cell, but no slope at that level ("Goal position wrong")
+    assert run_both(cells, (1.5, 0.5, 0.1))["rc"] == 2           # node without a Slope object
+    c = run_both(cells, (0.5, 0.5, 0.1))
+    assert c["rc"] == 0 and c["traversable"] == 1 and c["check_pushes"] == 0
+
+
+def test_demand_true_uses_lazy_up_and_ungated_ring():
+    # demand "true": a node one level up whose centroid differs by more than the interval makes countUp true
+    # (map2D.h:147-177) -> the slope below collides (CollisionCheck3D, :417-420)
+    rows = [flat_row(1, 1), flat_row(2, 1), (2, 1, 2, (1.5, 0.5, 1.2), UP, True), flat_row(3, 1)]
+    c = run_both(make_cells(rows), (0.5, 0.5, 0.1), demand="true")
+    assert c["state"].tolist()[1] == 2
+    c = run_both(make_cells(rows), (0.5, 0.5, 0.1), demand="slope")
+    assert c["state"].tolist()[1] == 1                            # 1.1 above: outside 2r, and `up` is never set for "slope"
+
+
+@pytest.mark.parametrize("demand", ["slope", "true"])
+@pytest.mark.parametrize("radius", [0.25, 0.6, 1.3])
+def test_level_synchronous_flood_equals_fifo_oracle_on_a_site(demand, radius):
+    cloud = scenes.drivable_site()
+    P = scenes.COST_PARAMS
+    ref = oracle.build_grid(cloud, P["grid_len"], P["z_len"], P["slope_interval"], mode=oracle.MODE_INT_SERIAL, demand=demand)
+    goal = scenes.DRIVABLE_GOAL
+    rb = {"radius": radius}
+    o = oracle.compute_cost(ref, cloud[0], P["grid_len"], P["z_len"], P["slope_interval"], goal, demand=demand, robot=rb)
+    assert o["rc"] == 0 and o["traversable"] > 8000 and o["closed"] > 0
+    key, nx, ny, sz = oracle.trans_morton_xyz(cloud[0], P["grid_len"], P["z_len"], goal)
+    gk = (nx if key[0] in "AB" else -nx, ny if key[0] in "AC" else -ny, sz)
+    e = he.cost_levelsync(ref, P["grid_len"], P["slope_interval"], gk, demand=demand, robot=rb)
+    assert e["ring_overflow"] == 0 and e["levels"] > 50
+    np.testing.assert_array_equal(e["h"], o["h"])
+    np.testing.assert_array_equal(e["state"], o["state"])
+    assert (e["traversable"], e["closed"], e["check_pushes"], e["ring"]) == (o["traversable"], o["closed"], o["check_pushes"], o["ring"])
+    if radius == 0.25:
+        s = oracle.compute_cost(ref, cloud[0], P["grid_len"], P["z_len"], P["slope_interval"], goal, demand=demand, robot=rb,
+                                mode=oracle.COST_AS_SHIPPED)
+        np.testing.assert_array_equal(s["h"], o["h"])
+        np.testing.assert_array_equal(s["state"], o["state"])
+
+
+def test_flood_properties_on_the_site():
+    """Size-independent properties: h = 0 only at the goal; every reached slope's h is at least the straight-line
+    distance to the goal's mean (each step costs the distance between means); untouched slopes keep FLT_MAX."""
+    cloud = scenes.drivable_site()
+    P = scenes.COST_PARAMS
+    ref = oracle.build_grid(cloud, P["grid_len"], P["z_len"], P["slope_interval"], mode=oracle.MODE_INT_SERIAL)
+    o = oracle.compute_cost(ref, cloud[0], P["grid_len"], P["z_len"], P["slope_interval"], scenes.DRIVABLE_GOAL)
+    h, st = o["h"], o["state"]
+    reached = h < FLT_MAX
+    assert (h == 0).sum() == 1
+    g = ref["mean"][np.nonzero(h == 0)[0][0]].astype(np.float64)
+    d = np.sqrt(((ref["mean"].astype(np.float64) - g) ** 2).sum(1))
+    assert (h[reached] >= d[reached] * (1 - 1e-5)).all()
+    assert (st[~reached] != 1).all() and (h[st == 0] == FLT_MAX).sum() == (st == 0).sum() - ((st == 0) & reached).sum()
+    assert ((ref["flags"] & 2) == 0)[reached].sum() == 0

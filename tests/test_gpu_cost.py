@@ -1,0 +1,88 @@
+"""GPU tier for the cost-map flood: gndt_compute_cost (HIP, one launch per layer) against the oracle's sequential
+FIFO restatement of TwoDmap::computeCost (map2D.h:1285-1397) run on the SAME grid — the grid the GPU built and
+exported — so that h (fp32) and the flood state compare bit for bit."""
+import numpy as np
+import pytest
+
+from oracle import oracle
+from tests import scenes
+
+pytestmark = pytest.mark.gpu
+FLT_MAX = np.float32(3.4028234663852886e38)
+
+
+def _build(cloud, P, demand="slope", strategy=0):
+    import torch
+    import grid_ndt_amd as g
+    m = g.TwoDmap(P["grid_len"], P["z_len"], strategy=strategy)
+    m.setInterval(P["slope_interval"])
+    m.setCloudFirst(cloud[0])
+    m.create2DMap(demand, torch.from_numpy(np.ascontiguousarray(cloud[1:])).cuda())
+    return m
+
+
+def _check(m, cloud, P, goal, demand, robot):
+    cells = m.export()
+    st = m.computeCost(goal, robot=robot)
+    got = m.cost_export()
+    ref = oracle.compute_cost(cells, cloud[0], P["grid_len"], P["z_len"], P["slope_interval"], goal, demand=demand, robot=robot)
+    assert st["rc"] == ref["rc"]
+    # the only non-IEEE step is acosf (device libm vs glibc): exactness is claimed while no decision sits on the threshold
+    assert ref["angle_margin_deg"] > 1e-3, "scene puts an angle within 1e-3 deg of the gate: pick another seed"
+    np.testing.assert_array_equal(got["h"], ref["h"])
+    np.testing.assert_array_equal(got["state"], ref["state"])
+    assert (st["traversable"], st["closed"], st["check_pushes"], st["ring"]) == \
+           (ref["traversable"], ref["closed"], ref["check_pushes"], ref["ring"])
+    return st, got
+
+
+@pytest.mark.parametrize("demand", ["slope", "true"])
+@pytest.mark.parametrize("strategy", [1, 2])
+def test_cost_map_equals_reference_flood(demand, strategy):
+    cloud = scenes.drivable_site()
+    P = scenes.COST_PARAMS
+    m = _build(cloud, P, demand, strategy)
+    for radius in (0.25, 0.6, 1.3):
+        st, got = _check(m, cloud, P, scenes.DRIVABLE_GOAL, demand, {"radius": radius})
+        assert st["traversable"] > 8000 and st["closed"] > 0 and st["levels"] > 50
+    # a second goal on the platform, another robot
+    _check(m, cloud, P, (12.0, -1.0, 0.45 + 0.35 * np.sin(12.0 / 7.0) + 0.25 * np.cos(-1.0 / 5.0)), demand,
+           {"radius": 0.25, "reachable_height": 0.1, "max_angle_deg": 20.0})
+
+
+def test_cost_map_goal_statuses_and_lifetime():
+    import torch
+    import grid_ndt_amd as g
+    cloud = scenes.drivable_site(60000)
+    P = scenes.COST_PARAMS
+    m = g.TwoDmap(P["grid_len"], P["z_len"])
+    m.setInterval(P["slope_interval"])
+    m.setCloudFirst(cloud[0])
+    with pytest.raises(g.GndtError):
+        m.computeCost(scenes.DRIVABLE_GOAL)                    # nothing built yet
+    pts = torch.from_numpy(np.ascontiguousarray(cloud[1:])).cuda()
+    m.create2DMap("slope", pts)
+    assert m.computeCost((500.0, 500.0, 0.0))["rc"] == 1       # no cell: the reference silently does nothing
+    got = m.cost_export()
+    assert (got["h"] == FLT_MAX).all() and (got["state"] == 0).all()
+    assert m.computeCost((scenes.DRIVABLE_GOAL[0], scenes.DRIVABLE_GOAL[1], 40.0))["rc"] == 2   # "Goal position wrong"
+    assert m.computeCost(scenes.DRIVABLE_GOAL)["rc"] == 0
+    m.create2DMap("slope", pts)                                # a new grid invalidates the flood
+    with pytest.raises(g.GndtError):
+        m.cost_export()
+
+
+def test_cost_map_on_a_large_terrain():
+    """~2M points of LiDAR-ordered terrain at 0.5 m cells: tens of thousands of slopes, hundreds of layers."""
+    cloud = scenes.terrain_cloud(2_000_000)
+    P = dict(grid_len=0.5, z_len=0.25, slope_interval=0.08)
+    m = _build(cloud, P, "slope", 0)
+    cells = m.export()
+    rows = np.nonzero((cells["flags"] & 2) != 0)[0]
+    goal = cells["mean"][rows[len(rows) // 3]]
+    st, got = _check(m, cloud, P, goal, "slope", None)
+    assert st["rc"] == 0
+    reached = got["h"] < FLT_MAX
+    g0 = cells["mean"][np.nonzero(got["h"] == 0)[0][0]].astype(np.float64)
+    d = np.sqrt(((cells["mean"].astype(np.float64) - g0) ** 2).sum(1))
+    assert (got["h"][reached] >= d[reached] * (1 - 1e-5)).all()
