@@ -15,6 +15,7 @@
 // over its types.
 #pragma once
 #include <cfloat>
+#include <cmath>
 #include <cstdint>
 #include <cstdlib>
 #include <list>
@@ -141,6 +142,43 @@ void materialise_into(const gndt_cells& c, Map& out) {
     }
 }
 
+// Write the flood's h (gndt_cost_export, one value per result row) into the Slope objects of containers that
+// were materialised from the same export: what computeCost leaves behind in Slope::h (map2D.h:1301, 1329, 1340).
+template <class Map>
+void apply_cost_into(const gndt_cells& c, const float* h, Map& out) {
+    int32_t cur_sx = 0, cur_sy = 0;
+    typename decltype(out.map_cell)::iterator cell = out.map_cell.end();
+    for (uint64_t i = 0; i < c.num_nodes; ++i) {
+        if (i == 0 || c.sx[i] != cur_sx || c.sy[i] != cur_sy) {
+            cur_sx = c.sx[i]; cur_sy = c.sy[i];
+            cell = out.map_cell.find(column_key(cur_sx, cur_sy));
+        }
+        if (!(c.flags[i] & GNDT_FLAG_SLOPE) || cell == out.map_cell.end()) continue;
+        auto it = cell->second->map_slope.find((int)c.sz[i]);
+        if (it != cell->second->map_slope.end()) it->second->h = h[i];
+    }
+}
+
+// include/robot.h:12-46 (ROS-free; setPos/setGoal take the parsed vectors)
+class RobotSphere {
+    float r;
+    Vector3f position, goal;
+public:
+    explicit RobotSphere(float rr) : r(rr) {
+        position.d[0] = 30.02865f; position.d[1] = 1.2212f; position.d[2] = 0.40626f;      // robot.h:33-34
+        goal.d[0] = 63.02865f; goal.d[1] = -37.2212f; goal.d[2] = 1.3026f;
+    }
+    RobotSphere(float rr, const Vector3f& pos, const Vector3f& g) : r(rr), position(pos), goal(g) {}
+    float getRobotR() const { return r; }
+    Vector3f getPosition() const { return position; }
+    Vector3f getGoal() const { return goal; }
+    float getReachableHeight() const { return 0.15f; }    // robot.h:38-39
+    float getRough() const { return 100.f; }              // robot.h:40-43
+    float getAngle() const { return 30.f; }               // robot.h:44-46
+    void setPos(const Vector3f& p) { position = p; }
+    void setGoal(const Vector3f& g) { goal = g; }
+};
+
 // daysun::TwoDmap for the build path (include/map2D.h:190-194, 485-507, 592, 950).
 class TwoDmap {
     float gridLen, zLen;
@@ -149,6 +187,8 @@ class TwoDmap {
     gndt_handle* handle = nullptr;
     int handle_demand = -1;
     std::string last_error;
+    CellsHost host;                     // the export the containers were built from (rows <-> Slope objects)
+    gndt_cost_stats cost_stats{};
 public:
     std::multimap<std::string, OcNode*> map_xy;
     std::list<std::string> morton_list;
@@ -192,13 +232,84 @@ public:
         uint64_t nodes = 0, cols = 0, slopes = 0;
         if (rc == GNDT_OK) rc = gndt_sync(handle, &nodes, &cols, &slopes);
         if (rc != GNDT_OK) { last_error = gndt_last_error(handle); return false; }   // "wrong" (map2D.h:602-604)
-        CellsHost host;
         host.resize(nodes);
         rc = gndt_export(handle, &host.view);
         if (rc != GNDT_OK) { last_error = gndt_last_error(handle); return false; }
         clear();
         materialise_into<TwoDmap, OcNode, Slope, Cell>(host.view, *this);
         return true;
+    }
+
+    // Replaces TwoDmap::computeCost (include/map2D.h:1285-1397; receiver.cpp:171): the flood runs on the GPU over the
+    // grid create2DMap left there, then Slope::h of every slope is set as the reference's loop would leave it.
+    // Returns false on an ABI error; goal-lookup failures behave like the reference (nothing is changed).
+    bool computeCost(const Vector3f& goal, RobotSphere& robot, const std::string& demand) {
+        (void)demand;                                   // the handle already carries the demand of create2DMap
+        if (!handle) { last_error = "computeCost before create2DMap"; return false; }
+        gndt_robot R{robot.getRobotR(), robot.getReachableHeight(), robot.getRough(), robot.getAngle()};
+        int rc = gndt_compute_cost(handle, goal.d, &R, nullptr);
+        std::vector<float> h(host.view.num_nodes);
+        if (rc == GNDT_OK) rc = gndt_cost_export(handle, h.data(), nullptr, &cost_stats);
+        if (rc != GNDT_OK) { last_error = gndt_last_error(handle); return false; }
+        if (cost_stats.goal_status == 0) apply_cost_into(host.view, h.data(), *this);
+        return true;
+    }
+    const gndt_cost_stats& costStats() const { return cost_stats; }
+    const gndt_cells& exported() const { return host.view; }   // the rows the containers were built from
+
+    // include/map2D.h:523-526
+    float TravelCost(const Vector3f& cur, const Vector3f& des, float = 0) const {
+        const float dx = cur(0) - des(0), dy = cur(1) - des(1), dz = cur(2) - des(2);
+        return (float)std::sqrt(((double)dx * (double)dx + (double)dy * (double)dy) + (double)dz * (double)dz);
+    }
+
+    // include/map2D.h:477-482
+    static float countAngle(const Vector3f& n1, const Vector3f& n2) {
+        const float dot = n1(0) * n2(0) + (n1(1) * n2(1) + n1(2) * n2(2));
+        const double l1 = std::sqrt(((double)n1(0) * n1(0) + (double)n1(1) * n1(1)) + (double)n1(2) * n1(2));
+        const double l2 = std::sqrt(((double)n2(0) * n2(0) + (double)n2(1) * n2(1)) + (double)n2(2) * n2(2));
+        const float res = (float)((double)dot / (l1 * l2));
+        float an = (float)((double)(std::acos(res) * 180.0f) / 3.14159265358979323846);
+        if (an > 90) an = 180 - an;
+        return an;
+    }
+
+    // Slope::countUp (include/map2D.h:147-177), evaluated against this map's map_xy
+    bool countUp(Slope* s) const {
+        int zadd = s->morton_z + 1;
+        if (s->morton_z == -1) zadd = 1;
+        bool zup = false;
+        for (auto it = map_xy.find(s->morton_xy); it != map_xy.end() && it->first == s->morton_xy && !zup; ++it)
+            if (zadd == it->second->z && std::fabs(it->second->xyz_centroid(2) - s->mean(2)) > slope_interval) zup = true;
+        s->up = zup;
+        return zup;
+    }
+
+    // include/map2D.h:530-548 with countReachable :262-294 and countLRFB :197-259: the accessible slopes of the four
+    // neighbouring cells (left, right, forward, back; ascending z inside a cell).  comand: 2.5 planner / collision
+    // ring, 3 every slope, 4 3-D planner (evaluates `up` lazily).
+    std::list<Slope*> AccessibleNeighbors(Slope* slope, RobotSphere& robot, float comand) {
+        std::list<Slope*> list;
+        const char q = slope->morton_xy[0];
+        int32_t x = 0, y = 0;
+        gndt_morton_to_xy((int32_t)std::atoi(slope->morton_xy.c_str() + 1), &x, &y);
+        const int sx = (q == 'A' || q == 'B') ? x : -x, sy = (q == 'A' || q == 'C') ? y : -y;
+        auto step = [](int v, int d) { int r = v + d; if (r == 0) r += d; return r; };   // no cell 0 (map2D.h:226-255)
+        const int nb[4][2] = {{sx, step(sy, -1)}, {sx, step(sy, +1)}, {step(sx, +1), sy}, {step(sx, -1), sy}};
+        for (const auto& c : nb) {
+            auto mit = map_cell.find(column_key(c[0], c[1]));
+            if (mit == map_cell.end()) continue;
+            for (auto& kv : mit->second->map_slope) {
+                Slope* s = kv.second;
+                if (comand == 3) { list.push_back(s); continue; }
+                if (comand == 4) s->up = countUp(s);
+                if (s->up) continue;
+                if (s->rough <= robot.getRough() && countAngle(s->normal, slope->normal) <= robot.getAngle() &&
+                    std::fabs(s->mean(2) - slope->mean(2)) <= robot.getReachableHeight())
+                    list.push_back(s);
+            }
+        }
+        return list;
     }
 
     void clear() {
@@ -230,5 +341,81 @@ inline void materialise(const gndt_cells& c, TwoDmap& out) {
     out.clear();
     materialise_into<TwoDmap, OcNode, Slope, Cell>(c, out);
 }
+
+// include/GlobalPlan.h:15-166 — the A* planner that consumes Slope::h, restated against these containers with the
+// reference's own quirks kept: the open queue is a multimap on f; isContaninedOpen only looks at the entries whose
+// key equals the candidate's current f AT THE FRONT of the queue (GlobalPlan.h:32-45), so a slope that is open
+// with a larger f is re-inserted (a second queue entry) with g, f and father overwritten unconditionally.
+class AstarPlanar {
+    std::multimap<float, Slope*> open_queue;
+    std::list<Slope*> closed_list;
+    Vector3f start, goal;
+    static bool same(const Slope* a, const Slope* b) { return a->morton_xy == b->morton_xy && a->morton_z == b->morton_z; }
+    bool isContainedClosed(const Slope* s) const {
+        for (const Slope* c : closed_list)
+            if (same(c, s)) return true;
+        return false;
+    }
+    bool isContaninedOpen(const Slope* s, std::multimap<float, Slope*>::iterator& found) {
+        for (auto it = open_queue.begin(); it != open_queue.end(); ++it) {
+            if (it->first != s->f) break;
+            if (same(it->second, s)) { found = it; return true; }
+        }
+        return false;
+    }
+public:
+    std::list<Slope*> global_path;
+    AstarPlanar(const Vector3f& s, const Vector3f& g) : start(s), goal(g) {}
+
+    bool findRoute(TwoDmap& map2D, RobotSphere& robot, const std::string& demand) {
+        std::string morton_xy, g_xy;
+        int morton_z = 0, g_z = 0;
+        bool route = false;
+        map2D.transMortonXYZ(start, morton_xy, morton_z);
+        map2D.transMortonXYZ(goal, g_xy, g_z);
+        auto it = map2D.map_cell.find(morton_xy);
+        if (it == map2D.map_cell.end()) return false;
+        auto ss = it->second->map_slope.find(morton_z);
+        if (ss == it->second->map_slope.end()) return false;
+        ss->second->g = 0;
+        ss->second->f = ss->second->g + ss->second->h;
+        open_queue.insert(std::make_pair(ss->second->f, ss->second));
+        const float comand = (demand == "true") ? 4.f : 2.5f;
+        while (!open_queue.empty()) {
+            auto it_open = open_queue.begin();
+            Slope* temp = it_open->second;
+            if (temp->morton_xy == g_xy && temp->morton_z == g_z) {
+                route = true;
+                global_path.push_front(temp);
+                break;
+            }
+            std::list<Slope*> nei = map2D.AccessibleNeighbors(temp, robot, comand);
+            for (Slope* s : nei) {
+                std::multimap<float, Slope*>::iterator found;
+                if (isContainedClosed(s) || s->h == FLT_MAX) {
+                } else if (isContaninedOpen(s, found)) {
+                    const float cand = temp->g + map2D.TravelCost(temp->mean, s->mean);
+                    if (s->g > cand) {
+                        s->g = cand;
+                        s->f = s->g + s->h;
+                        s->father = temp;
+                        open_queue.erase(found);
+                        open_queue.insert(std::make_pair(s->f, s));
+                    }
+                } else {
+                    s->g = temp->g + map2D.TravelCost(temp->mean, s->mean);
+                    s->f = s->g + s->h;
+                    s->father = temp;
+                    open_queue.insert(std::make_pair(s->f, s));
+                }
+            }
+            closed_list.push_back(temp);
+            open_queue.erase(it_open);
+        }
+        if (!route) return false;
+        for (Slope* i = global_path.front(); i->father != nullptr; i = global_path.front()) global_path.push_front(i->father);
+        return true;
+    }
+};
 
 }  // namespace gndt_compat

@@ -14,6 +14,7 @@
 //   include/map2D.h:147-177    Slope::countUp             lazily evaluated `up` for demand "true"
 //   include/map2D.h:523-526    TravelCost                 Euclidean distance between slope means
 //   include/robot.h:38-46      RobotSphere thresholds     reachable height 0.15, rough 100, angle 30
+//   include/GlobalPlan.h:15-166 AstarPlanar::findRoute    the A* planner that consumes Slope::h
 //
 // It works on an EXPORTED grid (the SoA rows of gndt_cells / oracle_export, reference node order) and rebuilds
 // the containers the reference walks: map_cell (std::map<string, Cell>), Cell::map_slope (std::map<int, Slope*>,
@@ -53,7 +54,8 @@ struct SlopeO {   // map2D.h:136-146
     float normal[3];
     float rough;
     float mean[3];
-    float h;
+    float h, g, f;
+    SlopeO* father;
     std::string morton_xy;
     int morton_z;
     bool up, down;
@@ -312,19 +314,88 @@ int compute_cost(CostMap& M, const float goal[3], const RobotO& robot, int mode,
     return 0;
 }
 
-}  // namespace
+// include/GlobalPlan.h:49-166.  Returns the path (goal last) as slope pointers; empty = "not find the road".
+struct Astar {
+    std::multimap<float, SlopeO*> open_queue;     // MyCompare is plain `<` (GlobalPlan.h:9-13)
+    std::list<SlopeO*> closed_list;
+    std::list<SlopeO*> global_path;
 
-extern "C" {
+    static bool same(const SlopeO* a, const SlopeO* b) { return a->morton_xy.compare(b->morton_xy) == 0 && a->morton_z == b->morton_z; }
+    bool contained_closed(const SlopeO* s) const {            // GlobalPlan.h:20-28
+        for (const SlopeO* c : closed_list)
+            if (same(c, s)) return true;
+        return false;
+    }
+    // GlobalPlan.h:30-45: walks from the FRONT of the queue and stops at the first key that differs from s->f
+    bool contained_open(const SlopeO* s, std::multimap<float, SlopeO*>::iterator& iTemp) {
+        auto it = open_queue.begin();
+        while (it != open_queue.end()) {
+            if (it->first != s->f) break;
+            if (same(it->second, s)) { iTemp = it; return true; }
+            ++it;
+        }
+        return false;
+    }
 
-// Rows are the exported grid in reference order.  Outputs: h[n] (FLT_MAX where no slope / never reached),
-// state[n] (0 untouched, 1 traversable, 2 closed), stats[4] = {traversable, closed, checkList pushes, ring depth n},
-// margins[2] = {min |angle - limit| in degrees, min ||dz| - reachable| in metres} over every gate evaluated.
-int oracle_compute_cost(size_t n, const int32_t* sx, const int32_t* sy, const int32_t* sz, const uint32_t* count,
-                        const float* mean, const float* normal, const float* rough, const uint32_t* flags,
-                        const float origin[3], float grid_len, float z_len, float slope_interval, int demand_true,
-                        const float goal[3], const float robot4[4], int mode, float* h_out, uint8_t* state_out,
-                        int64_t stats[4], double margins[2]) {
-    CostMap M;
+    bool find_route(CostMap& M, const float start[3], const float goal[3], const RobotO& robot) {
+        const Key sk = trans_key(M.origin, M.gridLen, M.zLen, start[0], start[1], start[2]);
+        const Key gk = trans_key(M.origin, M.gridLen, M.zLen, goal[0], goal[1], goal[2]);
+        const std::string morton_xy = std::string(1, sk.quadrant) + count_morton(sk.nx, sk.ny);
+        const std::string g_xy = std::string(1, gk.quadrant) + count_morton(gk.nx, gk.ny);
+        bool route = false;
+        auto it = M.map_cell.find(morton_xy);
+        if (it == M.map_cell.end()) return false;
+        auto ss = it->second.map_slope.find(sk.sz);
+        if (ss == it->second.map_slope.end()) return false;
+        ss->second->g = 0;
+        ss->second->f = ss->second->g + ss->second->h;
+        open_queue.insert(std::make_pair(ss->second->f, ss->second));
+        while (open_queue.size() != 0) {
+            auto it_Open = open_queue.begin();
+            SlopeO* temp = it_Open->second;
+            if (temp->morton_xy.compare(g_xy) == 0 && temp->morton_z == gk.sz) {
+                route = true;
+                global_path.push_front(temp);
+                break;
+            }
+            float tmp = 2.5f;
+            if (M.demand_true) tmp = 4;
+            std::list<SlopeO*> nei = accessible_neighbors(M, temp, robot, tmp);
+            for (SlopeO* s : nei) {
+                std::multimap<float, SlopeO*>::iterator itTemp;
+                if (contained_closed(s) || s->h == FLT_MAX) {
+                    // do nothing
+                } else if (contained_open(s, itTemp)) {
+                    if (s->g > temp->g + travel_cost(temp->mean, s->mean)) {
+                        s->g = temp->g + travel_cost(temp->mean, s->mean);
+                        s->f = s->g + s->h;
+                        s->father = temp;
+                        open_queue.erase(itTemp);
+                        open_queue.insert(std::make_pair(s->f, s));
+                    }
+                } else {
+                    s->g = temp->g + travel_cost(temp->mean, s->mean);
+                    s->f = s->g + s->h;
+                    s->father = temp;
+                    open_queue.insert(std::make_pair(s->f, s));
+                }
+            }
+            closed_list.push_back(temp);
+            open_queue.erase(it_Open);
+        }
+        if (!route) return false;
+        SlopeO* i = global_path.front();
+        while (i->father != nullptr) {
+            global_path.push_front(i->father);
+            i = global_path.front();
+        }
+        return true;
+    }
+};
+
+void load_map(CostMap& M, size_t n, const int32_t* sx, const int32_t* sy, const int32_t* sz, const float* mean,
+              const float* normal, const float* rough, const uint32_t* flags, const float origin[3], float grid_len,
+              float z_len, float slope_interval, int demand_true) {
     M.gridLen = grid_len; M.zLen = z_len; M.slope_interval = slope_interval; M.demand_true = demand_true != 0;
     for (int k = 0; k < 3; ++k) M.origin[k] = origin[k];
     for (size_t i = 0; i < n; ++i) {
@@ -332,14 +403,14 @@ int oracle_compute_cost(size_t n, const int32_t* sx, const int32_t* sy, const in
         NodeO nd;
         nd.z = sz[i];
         nd.cz = (flags[i] & 1u) ? mean[3 * i + 2] : 0.f;
-        (void)count;
         M.map_xy.insert(std::make_pair(key, nd));
         M.map_cell[key];       // create2DMap makes a Cell for every key of morton_list, slopes or not (map2D.h:598-600)
         if (flags[i] & 2u) {   // a Slope object exists (map2D.h:632, 648)
             SlopeO* s = new SlopeO();
             for (int k = 0; k < 3; ++k) { s->normal[k] = normal[3 * i + k]; s->mean[k] = mean[3 * i + k]; }
             s->rough = rough[i];
-            s->h = FLT_MAX;
+            s->h = s->g = s->f = FLT_MAX;     // map2D.h:637
+            s->father = nullptr;
             s->morton_xy = key;
             s->morton_z = sz[i];
             s->up = false;                       // value-initialised, never assigned in "slope" (map2D.h:636)
@@ -350,6 +421,26 @@ int oracle_compute_cost(size_t n, const int32_t* sx, const int32_t* sy, const in
             M.map_cell[key].map_slope[sz[i]] = s;
         }
     }
+}
+
+}  // namespace
+
+extern "C" {
+
+// Rows are the exported grid in reference order.  Outputs: h[n] (FLT_MAX where no slope / never reached),
+// state[n] (0 untouched, 1 traversable, 2 closed), stats[4] = {traversable, closed, checkList pushes, ring depth n},
+// margins[2] = {min |angle - limit| in degrees, min ||dz| - reachable| in metres} over every gate evaluated.
+// With `start` non-null the planner runs afterwards (receiver.cpp:171-175): path_rows[0..*path_len) = the rows of
+// global_path from the start slope to the goal slope (*path_len = 0: no route).
+int oracle_compute_cost(size_t n, const int32_t* sx, const int32_t* sy, const int32_t* sz, const uint32_t* count,
+                        const float* mean, const float* normal, const float* rough, const uint32_t* flags,
+                        const float origin[3], float grid_len, float z_len, float slope_interval, int demand_true,
+                        const float goal[3], const float robot4[4], int mode, float* h_out, uint8_t* state_out,
+                        int64_t stats[4], double margins[2], const float* start, int32_t* path_rows, int64_t path_cap,
+                        int64_t* path_len) {
+    (void)count;
+    CostMap M;
+    load_map(M, n, sx, sy, sz, mean, normal, rough, flags, origin, grid_len, z_len, slope_interval, demand_true);
     RobotO robot{robot4[0], robot4[1], robot4[2], robot4[3]};
     std::vector<char> state(n, 0);
     const int rc = compute_cost(M, goal, robot, mode, state);
@@ -360,6 +451,15 @@ int oracle_compute_cost(size_t n, const int32_t* sx, const int32_t* sy, const in
     stats[0] = trav; stats[1] = closed; stats[2] = M.check_pushes;
     stats[3] = (int64_t)((std::ceil(2 * robot.r / grid_len) - 1) / 2);
     margins[0] = M.min_angle_margin; margins[1] = M.min_height_margin;
+    if (start && path_len) {
+        *path_len = 0;
+        Astar planner;
+        if (planner.find_route(M, start, goal, robot)) {
+            int64_t k = 0;
+            for (SlopeO* s : planner.global_path) { if (k < path_cap) path_rows[k] = s->row; ++k; }
+            *path_len = k;
+        }
+    }
     return rc;
 }
 

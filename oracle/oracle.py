@@ -45,7 +45,7 @@ def lib():
         L.oracle_free.argtypes = [C.c_void_p]
         L.oracle_compute_cost.argtypes = [C.c_size_t] + [C.c_void_p] * 8 + [C.POINTER(C.c_float), C.c_float, C.c_float, C.c_float,
                                           C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int, C.c_void_p, C.c_void_p,
-                                          C.c_void_p, C.c_void_p]
+                                          C.c_void_p, C.c_void_p, C.POINTER(C.c_float), C.c_void_p, C.c_int64, C.c_void_p]
         L.oracle_compute_cost.restype = C.c_int
         _lib = L
     return _lib
@@ -126,10 +126,11 @@ ROBOT_DEFAULT = dict(radius=0.25, reachable_height=0.15, max_rough=100.0, max_an
 COST_AS_SHIPPED, COST_FLAGS = 0, 1
 
 
-def compute_cost(cells, origin, grid_len, z_len, slope_interval, goal, demand="slope", robot=None, mode=COST_FLAGS):
+def compute_cost(cells, origin, grid_len, z_len, slope_interval, goal, demand="slope", robot=None, mode=COST_FLAGS, start=None):
     """TwoDmap::computeCost (map2D.h:1285-1397) on an exported grid (`cells`: dict with sx, sy, sz, count, mean,
     normal, rough, flags in reference node order).  Returns dict(rc, h, state, traversable, closed, check_pushes,
-    ring, angle_margin_deg, height_margin)."""
+    ring, angle_margin_deg, height_margin).  With `start` (xyz) AstarPlanar::findRoute (GlobalPlan.h:49-166) runs
+    afterwards and `path` holds the rows of its global_path, start slope first (empty: no route)."""
     rb = dict(ROBOT_DEFAULT)
     rb.update(robot or {})
     n = int(len(cells["sx"]))
@@ -144,9 +145,13 @@ def compute_cost(cells, origin, grid_len, z_len, slope_interval, goal, demand="s
     g = (C.c_float * 3)(*[float(v) for v in goal])
     r4 = (C.c_float * 4)(float(rb["radius"]), float(rb["reachable_height"]), float(rb["max_rough"]), float(rb["max_angle_deg"]))
     dem = {"slope": 0, "true": 1}[demand] if isinstance(demand, str) else int(demand)
+    path = np.zeros(max(n, 1), np.int32)
+    plen = np.zeros(1, np.int64)
+    st = (C.c_float * 3)(*[float(v) for v in start]) if start is not None else None
     rc = lib().oracle_compute_cost(n, *[arr[k].ctypes.data for k in ("sx", "sy", "sz", "count", "mean", "normal", "rough", "flags")],
                                    o, float(grid_len), float(z_len), float(slope_interval), dem, g, r4, int(mode),
-                                   h.ctypes.data, state.ctypes.data, stats.ctypes.data, margins.ctypes.data)
-    return {"rc": rc, "h": h, "state": state, "traversable": int(stats[0]), "closed": int(stats[1]),
+                                   h.ctypes.data, state.ctypes.data, stats.ctypes.data, margins.ctypes.data,
+                                   st, path.ctypes.data, n, plen.ctypes.data)
+    return {"rc": rc, "path": path[:int(plen[0])].copy(), "h": h, "state": state, "traversable": int(stats[0]), "closed": int(stats[1]),
             "check_pushes": int(stats[2]), "ring": int(stats[3]), "angle_margin_deg": float(margins[0]),
             "height_margin": float(margins[1])}
