@@ -206,23 +206,33 @@ GNDT_HD int cost_ring_depth(float r, float grid_len) {
 GNDT_HD uint32_t float_bits(float f) { union { float f; uint32_t u; } v; v.f = f; return v.u; }
 GNDT_HD float bits_float(uint32_t u) { union { float f; uint32_t u; } v; v.u = u; return v.f; }
 
-// Expansion of one popped slope (map2D.h:1312-1345 / 1346-1378): calls relax(neighbour_row, candidate_h) for
-// every accessible neighbour and returns the number of checkList pushes.
+// Expansion of one popped slope (map2D.h:1312-1345 / 1346-1378) towards ONE of its four neighbour cells
+// (0 left, 1 right, 2 forward, 3 back): calls relax(neighbour_row, candidate_h) for every accessible slope of that
+// cell and returns the number of checkList pushes.
+template <typename Relax>
+GNDT_HD uint32_t cost_expand_dir(const CostView& V, const Robot& R, uint32_t q, float hq, int dir, Relax relax) {
+    GNDT_FP_STRICT
+    const int sx = V.sx[q], sy = V.sy[q];
+    const uint32_t c = dir == 0 ? ctab_find(V, sx, step_skip0(sy, -1))
+                     : dir == 1 ? ctab_find(V, sx, step_skip0(sy, +1))
+                     : dir == 2 ? ctab_find(V, step_skip0(sx, +1), sy)
+                                : ctab_find(V, step_skip0(sx, -1), sy);
+    if (c == kNoColumn) return 0u;
+    uint32_t checks = 0;
+    const uint32_t b = V.col_base[c], e = b + V.col_size[c];
+    for (uint32_t t = b; t < e; ++t) {
+        if (!row_has_slope(V, t)) continue;
+        ++checks;                                   // checkList.push_back (up is false / not consulted)
+        if (!cost_gates(V, R, t, V.normal + 3 * q, V.mean + 3 * q)) continue;
+        relax(t, hq + cost_travel(V.mean + 3 * q, V.mean + 3 * t));
+    }
+    return checks;
+}
+
 template <typename Relax>
 GNDT_HD uint32_t cost_expand(const CostView& V, const Robot& R, uint32_t q, float hq, Relax relax) {
-    GNDT_FP_STRICT
-    uint32_t col[4], checks = 0;
-    neighbour_columns(V, q, col);
-    for (int k = 0; k < 4; ++k) {
-        if (col[k] == kNoColumn) continue;
-        const uint32_t b = V.col_base[col[k]], e = b + V.col_size[col[k]];
-        for (uint32_t t = b; t < e; ++t) {
-            if (!row_has_slope(V, t)) continue;
-            ++checks;                                   // checkList.push_back (up is false / not consulted)
-            if (!cost_gates(V, R, t, V.normal + 3 * q, V.mean + 3 * q)) continue;
-            relax(t, hq + cost_travel(V.mean + 3 * q, V.mean + 3 * t));
-        }
-    }
+    uint32_t checks = 0;
+    for (int dir = 0; dir < 4; ++dir) checks += cost_expand_dir(V, R, q, hq, dir, relax);
     return checks;
 }
 
@@ -293,7 +303,8 @@ __global__ void k_cost_goal(CostView V, int gx, int gy, int gz, uint32_t* __rest
     }
 }
 
-// one layer of the flood: collision check, then expansion, of every slope in the layer
+// one layer of the flood: collision check, then expansion, of every slope in the layer.  Four lanes share a slope
+// (one per neighbour cell): layers are short, so the kernel is latency-bound and the serial work per lane counts.
 __global__ void __launch_bounds__(64) k_cost_level(CostView V, Robot R, int ring_n, uint32_t level, uint32_t* __restrict__ h_bits,
                                                    uint32_t* __restrict__ pushed, uint32_t* __restrict__ state,
                                                    const uint32_t* __restrict__ f_in, uint32_t* __restrict__ f_out,
@@ -306,21 +317,26 @@ __global__ void __launch_bounds__(64) k_cost_level(CostView V, Robot R, int ring
     if (n_in == 0u) return;
     uint32_t* out_count = &cc->frontier[(level + 1u) % 3u];
     const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t quad = tid >> 2, dir = tid & 3u, quads = (gridDim.x * blockDim.x) >> 2;
+    const int leader = (int)(threadIdx.x & 63u & ~3u);
     uint32_t trav = 0, closed = 0, checks = 0;
-    for (uint32_t i = tid; i < n_in; i += gridDim.x * blockDim.x) {
+    for (uint32_t i = quad; i < n_in; i += quads) {
         const uint32_t q = f_in[i];
-        const int hit = cost_collide(V, R, q, ring_n, ring_scratch + (size_t)tid * kRingCap);
-        if (hit < 0) { atomicAdd(&cc->ring_overflow, 1u); continue; }
+        int hit = 0;
+        if (dir == 0u) hit = cost_collide(V, R, q, ring_n, ring_scratch + (size_t)quad * kRingCap);
+        hit = __shfl(hit, leader, 64);
+        if (hit < 0) { if (dir == 0u) atomicAdd(&cc->ring_overflow, 1u); continue; }
         if (hit) {
-            h_bits[q] = 0x7F7FFFFFu;                  // Q.front()->h = FLT_MAX (map2D.h:1340)
-            state[q] = 2u;
-            ++closed;
+            if (dir == 0u) {
+                h_bits[q] = 0x7F7FFFFFu;              // Q.front()->h = FLT_MAX (map2D.h:1340)
+                state[q] = 2u;
+                ++closed;
+            }
             continue;
         }
-        state[q] = 1u;
-        ++trav;
+        if (dir == 0u) { state[q] = 1u; ++trav; }
         const float hq = bits_float(h_bits[q]);
-        checks += cost_expand(V, R, q, hq, [&](uint32_t t, float cand) {
+        checks += cost_expand_dir(V, R, q, hq, (int)dir, [&](uint32_t t, float cand) {
             const uint32_t cb = float_bits(cand);
             const uint32_t old = atomicMin(&h_bits[t], cb);
             if (old > cb && atomicCAS(&pushed[t], 0u, 1u) == 0u) f_out[atomicAdd(out_count, 1u)] = t;
