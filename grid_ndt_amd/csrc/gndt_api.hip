@@ -102,9 +102,22 @@ struct gndt_handle {
     bool map_in_table = true;   // false after a PARTITION build: the HBM node table does not hold the map
 
     // optional phase timing (bench / profiling): events recorded on the launch stream
-    bool prof = false;
-    hipEvent_t ev[GNDT_NUM_PHASES + 1] = {};
-    bool ev_recorded[GNDT_NUM_PHASES + 1] = {};
+    int prof = 0;               // 0 off, 1 every phase, 2 only the dominant phase of the strategy in use
+    // one event set per build in a ring, so that back-to-back (un-synchronised) builds can all be timed
+    static constexpr int kEvSets = 32;
+    hipEvent_t ev[kEvSets][GNDT_NUM_PHASES + 1] = {};
+    bool ev_recorded[kEvSets][GNDT_NUM_PHASES + 1] = {};
+    int ev_set = 0;
+
+    // A PARTITION build is launched without waiting for it; its overflow flags are looked at (and the build
+    // re-run with more room if they are set) by the next call that needs the result.
+    struct Pending {
+        bool active = false;
+        const void* xyz = nullptr; size_t n = 0, stride = 0;
+        hipStream_t s = nullptr;
+        int attempt = 0, bslots = 0;
+        uint64_t nodes_est = 0, stage_want = 0;
+    } pending;
 
     std::string err;
 };
@@ -121,7 +134,20 @@ namespace {
     } while (0)
 
 inline void mark(gndt_handle* h, int i, hipStream_t s) {
-    if (h->prof && h->ev[i]) { (void)hipEventRecord(h->ev[i], s); h->ev_recorded[i] = true; }
+    if (!h->prof || !h->ev[h->ev_set][i]) return;
+    if (h->prof == 2) {   // k_bucket_build2 sits between marks 4 and 5, k_accumulate between 1 and 2
+        const int lo = h->last_strategy == GNDT_STRATEGY_PARTITION ? 4 : 1;
+        if (i != lo && i != lo + 1) return;
+    }
+    (void)hipEventRecord(h->ev[h->ev_set][i], s);
+    h->ev_recorded[h->ev_set][i] = true;
+}
+
+// a new build / update starts: next event set of the ring
+inline void next_event_set(gndt_handle* h) {
+    if (!h->prof) return;
+    h->ev_set = (h->ev_set + 1) % gndt_handle::kEvSets;
+    for (auto& r : h->ev_recorded[h->ev_set]) r = false;
 }
 
 inline int grid_for(uint64_t work, int block = kBlock, int max_blocks = 256 * 8) {
@@ -280,7 +306,7 @@ int ensure_stage(gndt_handle* h, uint64_t nodes) {
 }
 
 // Bucket count: ~4096 points per bucket, and few enough nodes per bucket for the LDS table
-// (average load <= 0.3 of `slots`, which leaves room for the spread of a hash partition).
+// (average load <= 0.4 of `slots`: the overflow limit of 0.78 is then ~6 sigma of the column count away).
 int ensure_words(gndt_handle* h, uint64_t words) {
     auto& q = h->part;
     if (words <= q.word_cap) return GNDT_OK;
@@ -488,128 +514,174 @@ int stage_host_input(gndt_handle* h, const void* xyz_host, size_t n, size_t stri
 // strategy PARTITION (gndt_partition.hpp): the build
 // ---------------------------------------------------------------------------------------------
 // Bucket count for `nodes` expected nodes: ~4*slots points per bucket, and few enough nodes per bucket for
-// the LDS table (average load <= 0.3 of `slots`, which leaves room for the spread of a hash partition).
+// the LDS table (average load <= 0.4 of `slots`: the overflow limit of 0.78 is then ~6 sigma of the column count away).
 uint64_t buckets_for(uint64_t n, uint64_t nodes, int slots) {
-    const uint64_t want = std::max<uint64_t>(n / (4 * (uint64_t)slots), (nodes * 10) / (uint64_t)(slots * 3));
+    static const int load_pct = getenv("GNDT_BUCKET_LOAD") ? atoi(getenv("GNDT_BUCKET_LOAD")) : 40;   // tuning knob
+    const uint64_t want = std::max<uint64_t>(n / (4 * (uint64_t)slots), (nodes * 100) / ((uint64_t)slots * load_pct));
     return std::max<uint64_t>(want, 16);
 }
 constexpr uint64_t kMaxBuckets = 32768;   // 4-byte LDS cursor per bucket in the partition passes
 
-// Returns GNDT_OK, an error, or -1 when the partition path cannot hold this input (caller falls back).
-int build_partition(gndt_handle* h, const void* xyz_dev, size_t n, size_t stride_bytes, hipStream_t s) {
+// One attempt of the PARTITION build: every launch plus the asynchronous read-back of the counters and overflow
+// flags; no host wait.  Returns GNDT_OK, an error, or -1 when the partition path cannot hold this input.
+int partition_launch(gndt_handle* h, gndt_handle::Pending& P) {
     auto& q = h->part;
-    if (stride_bytes != 12 && stride_bytes != 16) { h->err = "stride_bytes must be 12 or 16"; return GNDT_ERR_INVALID; }
-    if (n >= 0x7FFFFFFFull) return -1;   // bit 31 of the record index word carries the weight flag: atomic path beyond 2^31 points
+    const size_t n = P.n, stride_bytes = P.stride;
+    hipStream_t s = P.s;
+    const int attempt = P.attempt;
+    uint64_t& nodes_est = P.nodes_est;
+    uint64_t& stage_want = P.stage_want;
     static const int bt = getenv("GNDT_BUCKET_THREADS") ? atoi(getenv("GNDT_BUCKET_THREADS")) : 512;
     static const int env_slots = getenv("GNDT_BUCKET_SLOTS") ? atoi(getenv("GNDT_BUCKET_SLOTS")) : 0;
     static const int part_wgs = getenv("GNDT_PART_WGS") ? atoi(getenv("GNDT_PART_WGS")) : 256;
     const uint32_t nwg = (uint32_t)std::min<uint64_t>((uint64_t)part_wgs, std::max<uint64_t>(1, n / 8192));
     const uint64_t words = (n + 31) / 32 + 1;
     int rc;
-    if ((rc = grow_buf(h, q.recs, q.rec_cap, n))) return rc;
-    // expected node count: the caller's hint, else what the previous build of this handle found, else n/4
-    uint64_t nodes_est = h->P.max_nodes_hint ? h->P.max_nodes_hint : (q.nodes_learned ? q.nodes_learned : std::max<uint64_t>(n / 4, 1024));
-    if ((rc = ensure_words(h, words))) return rc;
-    if ((rc = ensure_part_counters(h))) return rc;
-    uint64_t stage_want = std::max<uint64_t>(q.stage_cap, h->P.max_nodes_hint ? h->P.max_nodes_hint + h->P.max_nodes_hint / 8
-                                                                             : std::max<uint64_t>(4096, n / 4));
     const GridParams gp = grid_params(h);
-    const float* p = static_cast<const float*>(xyz_dev);
-    for (int attempt = 0; attempt < 5; ++attempt) {
-        // table size and bucket count for this attempt: 512-slot tables unless that needs too many buckets
-        // attempt 0: 512-slot tables; an overflow first doubles the table (same estimate), then raises the estimate
-        int bslots = env_slots ? env_slots : (attempt == 0 ? 512 : 1024);
-        uint64_t Bw = buckets_for(n, nodes_est, bslots);
-        if (!env_slots && Bw > kMaxBuckets) { bslots = 1024; Bw = buckets_for(n, nodes_est, bslots); }
-        if (Bw > kMaxBuckets) return -1;                       // too many nodes for one partition level: atomic path
-        const uint32_t B = (uint32_t)Bw;
-        if ((rc = grow_buf(h, q.hist, q.hist_cap, (uint64_t)nwg * B))) return rc;
-        if (B > q.bucket_cap) {
-            if (q.totals) (void)hipFree(q.totals);
-            if (q.bucket_base) (void)hipFree(q.bucket_base);
-            q.totals = q.bucket_base = nullptr; q.bucket_cap = 0;
-            HIP_TRY(h, hipMalloc(&q.totals, (size_t)B * 4));
-            HIP_TRY(h, hipMalloc(&q.bucket_base, ((size_t)B + 1) * 4));
-            q.bucket_cap = B;
-        }
-        stage_want = std::max<uint64_t>(stage_want, nodes_est + nodes_est / 8);
-        if ((rc = ensure_stage(h, stage_want))) return rc;
-        if ((rc = ensure_out(h, q.stage_cap))) return rc;
-        mark(h, 0, s);
-        // the HBM node table is not used by this strategy, but a previous atomic build may sit in it
-        if (h->table_dirty) { if ((rc = do_reset(h, s))) return rc; }
-        h->results_valid = false;
-        hipLaunchKernelGGL(k_part_clear, dim3(grid_for(words, 256, 512)), dim3(256), 0, s, h->d_cnt, q.d_pc, q.bitmap, (uint64_t)words);
-        HIP_TRY(h, hipGetLastError());
-        mark(h, 1, s);
-        const size_t lds = (size_t)B * 4;
-        if (lds > 48 * 1024) {   // beyond the default dynamic-LDS limit the kernels must be told (gfx950: 160 KiB/CU)
-            HIP_TRY(h, hipFuncSetAttribute((const void*)k_part_hist<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            HIP_TRY(h, hipFuncSetAttribute((const void*)k_part_hist<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            HIP_TRY(h, hipFuncSetAttribute((const void*)k_part_scatter<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            HIP_TRY(h, hipFuncSetAttribute((const void*)k_part_scatter<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        }
-        if (stride_bytes == 12)
-            hipLaunchKernelGGL(k_part_hist<3>, dim3(nwg), dim3(kPartThreads), lds, s, p, (uint64_t)n, gp, B, q.hist, h->d_cnt);
-        else
-            hipLaunchKernelGGL(k_part_hist<4>, dim3(nwg), dim3(kPartThreads), lds, s, p, (uint64_t)n, gp, B, q.hist, h->d_cnt);
-        HIP_TRY(h, hipGetLastError());
-        mark(h, 2, s);
-        hipLaunchKernelGGL(k_part_offsets, dim3((B + 31) / 32), dim3(256), 0, s, q.hist, q.totals, B, nwg);
-        HIP_TRY(h, hipGetLastError());
-        mark(h, 3, s);
-        if (stride_bytes == 12)
-            hipLaunchKernelGGL(k_part_scatter<3>, dim3(nwg), dim3(kPartThreads), lds, s, p, (uint64_t)n, 0u, gp, B, q.hist,
-                               q.totals, q.bucket_base, q.recs);
-        else
-            hipLaunchKernelGGL(k_part_scatter<4>, dim3(nwg), dim3(kPartThreads), lds, s, p, (uint64_t)n, 0u, gp, B, q.hist,
-                               q.totals, q.bucket_base, q.recs);
-        HIP_TRY(h, hipGetLastError());
-        mark(h, 4, s);
-        if (getenv("GNDT_STAMPS") && q.dbg_buckets < B) {
-            if (q.dbg) (void)hipFree(q.dbg);
-            q.dbg = nullptr; q.dbg_buckets = 0;
-            HIP_TRY(h, hipMalloc(&q.dbg, (size_t)B * 16 * sizeof(unsigned long long)));
-            HIP_TRY(h, hipMemset(q.dbg, 0, (size_t)B * 16 * sizeof(unsigned long long)));
-            q.dbg_buckets = B;
-        }
-        q.last_buckets = B;
-        {
-#define GNDT_LAUNCH_BUCKET2(T_, H_, CH_)                                                                               \
-    hipLaunchKernelGGL((k_bucket_build2<T_, H_, CH_>), dim3(B), dim3(T_), 0, s, q.recs, q.bucket_base, gp, q.stage,    \
-                       (uint32_t)q.stage_cap, q.ord_cf, q.ord_idx, q.ord_ncol, q.bitmap, h->d_cnt, q.d_pc, q.dbg)
-            if (bslots == 1024 && bt == 1024) GNDT_LAUNCH_BUCKET2(1024, 1024, 3072);
-            else if (bslots == 1024) GNDT_LAUNCH_BUCKET2(512, 1024, 3584);
-            else if (bslots == 512 && bt == 256) GNDT_LAUNCH_BUCKET2(256, 512, 1792);
-            else if (bslots == 256) GNDT_LAUNCH_BUCKET2(256, 256, 1024);
-            else GNDT_LAUNCH_BUCKET2(512, 512, 1536);
-#undef GNDT_LAUNCH_BUCKET2
-        }
-        HIP_TRY(h, hipGetLastError());
-        mark(h, 5, s);
-        if ((rc = launch_order_and_emit(h, words, 5, s))) return rc;
-        HIP_TRY(h, hipMemcpyAsync(q.h_pc, q.d_pc, sizeof(PartCounters), hipMemcpyDeviceToHost, s));
-        HIP_TRY(h, hipMemcpyAsync(h->h_cnt, h->d_cnt, sizeof(Counters), hipMemcpyDeviceToHost, s));
-        HIP_TRY(h, hipStreamSynchronize(s));
-        if (q.h_pc->lds_overflow) {                          // some bucket holds too many nodes for its LDS table:
-            if (attempt >= 1 || env_slots) nodes_est *= 2;   // (attempt 0 -> 1 only switches to the 1024-slot table)
-            continue;
-        }
-        if (q.h_pc->stage_overflow) {                        // num_nodes kept counting: it is the true total
-            stage_want = (uint64_t)h->h_cnt->num_nodes + h->h_cnt->num_nodes / 8 + 1024;
-            continue;
-        }
-        q.nodes_learned = (uint64_t)h->h_cnt->num_nodes + h->h_cnt->num_nodes / 5;
-        q.good_slots = bslots; q.good_est = nodes_est; q.good_n = n;
-        h->results_valid = true;
-        ++h->result_serial;
-        h->map_in_table = false;
-        h->table_dirty = false;
-        h->last_strategy = GNDT_STRATEGY_PARTITION;
-        h->stream_pos = n;
-        return GNDT_OK;
+    const float* p = static_cast<const float*>(P.xyz);
+    // table size and bucket count for this attempt: 512-slot tables unless that needs too many buckets
+    // attempt 0: 512-slot tables; an overflow first doubles the table (same estimate), then raises the estimate
+    int bslots = env_slots ? env_slots : (attempt == 0 ? 512 : 1024);
+    uint64_t Bw = buckets_for(n, nodes_est, bslots);
+    if (!env_slots && Bw > kMaxBuckets) { bslots = 1024; Bw = buckets_for(n, nodes_est, bslots); }
+    if (Bw > kMaxBuckets) return -1;                       // too many nodes for one partition level: atomic path
+    const uint32_t B = (uint32_t)Bw;
+    if ((rc = grow_buf(h, q.hist, q.hist_cap, (uint64_t)nwg * B))) return rc;
+    if (B > q.bucket_cap) {
+        if (q.totals) (void)hipFree(q.totals);
+        if (q.bucket_base) (void)hipFree(q.bucket_base);
+        q.totals = q.bucket_base = nullptr; q.bucket_cap = 0;
+        HIP_TRY(h, hipMalloc(&q.totals, (size_t)B * 4));
+        HIP_TRY(h, hipMalloc(&q.bucket_base, ((size_t)B + 1) * 4));
+        q.bucket_cap = B;
     }
-    return -1;
+    stage_want = std::max<uint64_t>(stage_want, nodes_est + nodes_est / 8);
+    if ((rc = ensure_stage(h, stage_want))) return rc;
+    if ((rc = ensure_out(h, q.stage_cap))) return rc;
+    mark(h, 0, s);
+    // the HBM node table is not used by this strategy, but a previous atomic build may sit in it
+    if (h->table_dirty) { if ((rc = do_reset(h, s))) return rc; }
+    h->results_valid = false;
+    hipLaunchKernelGGL(k_part_clear, dim3(grid_for(words, 256, 512)), dim3(256), 0, s, h->d_cnt, q.d_pc, q.bitmap, (uint64_t)words);
+    HIP_TRY(h, hipGetLastError());
+    mark(h, 1, s);
+    const size_t lds = (size_t)B * 4;
+    if (lds > 48 * 1024) {   // beyond the default dynamic-LDS limit the kernels must be told (gfx950: 160 KiB/CU)
+        HIP_TRY(h, hipFuncSetAttribute((const void*)k_part_hist<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIP_TRY(h, hipFuncSetAttribute((const void*)k_part_hist<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIP_TRY(h, hipFuncSetAttribute((const void*)k_part_scatter<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIP_TRY(h, hipFuncSetAttribute((const void*)k_part_scatter<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    }
+    if (stride_bytes == 12)
+        hipLaunchKernelGGL(k_part_hist<3>, dim3(nwg), dim3(kPartThreads), lds, s, p, (uint64_t)n, gp, B, q.hist, h->d_cnt);
+    else
+        hipLaunchKernelGGL(k_part_hist<4>, dim3(nwg), dim3(kPartThreads), lds, s, p, (uint64_t)n, gp, B, q.hist, h->d_cnt);
+    HIP_TRY(h, hipGetLastError());
+    mark(h, 2, s);
+    hipLaunchKernelGGL(k_part_offsets, dim3((B + 31) / 32), dim3(256), 0, s, q.hist, q.totals, B, nwg);
+    HIP_TRY(h, hipGetLastError());
+    mark(h, 3, s);
+    if (stride_bytes == 12)
+        hipLaunchKernelGGL(k_part_scatter<3>, dim3(nwg), dim3(kPartThreads), lds, s, p, (uint64_t)n, 0u, gp, B, q.hist,
+                           q.totals, q.bucket_base, q.recs);
+    else
+        hipLaunchKernelGGL(k_part_scatter<4>, dim3(nwg), dim3(kPartThreads), lds, s, p, (uint64_t)n, 0u, gp, B, q.hist,
+                           q.totals, q.bucket_base, q.recs);
+    HIP_TRY(h, hipGetLastError());
+    mark(h, 4, s);
+    if (getenv("GNDT_STAMPS") && q.dbg_buckets < B) {
+        if (q.dbg) (void)hipFree(q.dbg);
+        q.dbg = nullptr; q.dbg_buckets = 0;
+        HIP_TRY(h, hipMalloc(&q.dbg, (size_t)B * 16 * sizeof(unsigned long long)));
+        HIP_TRY(h, hipMemset(q.dbg, 0, (size_t)B * 16 * sizeof(unsigned long long)));
+        q.dbg_buckets = B;
+    }
+    q.last_buckets = B;
+    {
+#define GNDT_LAUNCH_BUCKET2(T_, H_, CH_)                                                                               \
+hipLaunchKernelGGL((k_bucket_build2<T_, H_, CH_>), dim3(B), dim3(T_), 0, s, q.recs, q.bucket_base, gp, q.stage,    \
+                   (uint32_t)q.stage_cap, q.ord_cf, q.ord_idx, q.ord_ncol, q.bitmap, h->d_cnt, q.d_pc, q.dbg)
+        if (bslots == 1024 && bt == 1024) GNDT_LAUNCH_BUCKET2(1024, 1024, 3072);
+        else if (bslots == 1024) GNDT_LAUNCH_BUCKET2(512, 1024, 3584);
+        else if (bslots == 512 && bt == 256) GNDT_LAUNCH_BUCKET2(256, 512, 1792);
+        else if (bslots == 256) GNDT_LAUNCH_BUCKET2(256, 256, 1024);
+        else GNDT_LAUNCH_BUCKET2(512, 512, 1536);
+#undef GNDT_LAUNCH_BUCKET2
+    }
+    HIP_TRY(h, hipGetLastError());
+    mark(h, 5, s);
+    if ((rc = launch_order_and_emit(h, words, 5, s))) return rc;
+    HIP_TRY(h, hipMemcpyAsync(q.h_pc, q.d_pc, sizeof(PartCounters), hipMemcpyDeviceToHost, s));
+    HIP_TRY(h, hipMemcpyAsync(h->h_cnt, h->d_cnt, sizeof(Counters), hipMemcpyDeviceToHost, s));
+    P.bslots = bslots;
+    return GNDT_OK;
+}
+
+int build_atomic(gndt_handle* h, const void* xyz_dev, size_t n, size_t stride_bytes, hipStream_t s);
+
+// Start a PARTITION build (attempt 0) and leave it pending.
+int partition_begin(gndt_handle* h, const void* xyz_dev, size_t n, size_t stride_bytes, hipStream_t s) {
+    auto& q = h->part;
+    if (stride_bytes != 12 && stride_bytes != 16) { h->err = "stride_bytes must be 12 or 16"; return GNDT_ERR_INVALID; }
+    if (n >= 0x7FFFFFFFull) return -1;   // bit 31 of the record index word carries the weight flag: atomic path beyond 2^31 points
+    int rc;
+    if ((rc = grow_buf(h, q.recs, q.rec_cap, n))) return rc;
+    if ((rc = ensure_words(h, (n + 31) / 32 + 1))) return rc;
+    if ((rc = ensure_part_counters(h))) return rc;
+    auto& P = h->pending;
+    P = gndt_handle::Pending{};
+    P.xyz = xyz_dev; P.n = n; P.stride = stride_bytes; P.s = s; P.attempt = 0;
+    // expected node count: the caller's hint, else what the previous build of this handle found, else n/4
+    P.nodes_est = h->P.max_nodes_hint ? h->P.max_nodes_hint : (q.nodes_learned ? q.nodes_learned : std::max<uint64_t>(n / 4, 1024));
+    P.stage_want = std::max<uint64_t>(q.stage_cap, h->P.max_nodes_hint ? h->P.max_nodes_hint + h->P.max_nodes_hint / 8
+                                                                       : std::max<uint64_t>(4096, n / 4));
+    const int prev_strategy = h->last_strategy;
+    h->last_strategy = GNDT_STRATEGY_PARTITION;
+    rc = partition_launch(h, P);
+    if (rc) { h->last_strategy = prev_strategy; return rc; }
+    P.active = true;
+    h->results_valid = false;
+    h->map_in_table = false;
+    h->stream_pos = n;
+    h->last_stream = s;
+    return GNDT_OK;
+}
+
+// Wait for the pending build and look at its flags; re-run it with more room while they ask for it (the input
+// must still be valid: it is the caller's until gndt_sync / gndt_export returns).
+int partition_resolve(gndt_handle* h) {
+    auto& P = h->pending;
+    if (!P.active) return GNDT_OK;
+    auto& q = h->part;
+    static const int env_slots = getenv("GNDT_BUCKET_SLOTS") ? atoi(getenv("GNDT_BUCKET_SLOTS")) : 0;
+    int rc = GNDT_OK;
+    for (;;) {
+        if (hipStreamSynchronize(P.s) != hipSuccess) { P.active = false; h->err = "hipStreamSynchronize failed"; return GNDT_ERR_HIP; }
+        bool again = false;
+        if (q.h_pc->lds_overflow) {                            // some bucket holds too many nodes for its LDS table:
+            if (P.attempt >= 1 || env_slots) P.nodes_est *= 2;   // (attempt 0 -> 1 only switches to the 1024-slot table)
+            again = true;
+        } else if (q.h_pc->stage_overflow) {                   // num_nodes kept counting: it is the true total
+            P.stage_want = (uint64_t)h->h_cnt->num_nodes + h->h_cnt->num_nodes / 8 + 1024;
+            again = true;
+        }
+        if (!again) {
+            q.nodes_learned = (uint64_t)h->h_cnt->num_nodes + h->h_cnt->num_nodes / 5;
+            q.good_slots = P.bslots; q.good_est = P.nodes_est; q.good_n = P.n;
+            h->results_valid = true;
+            ++h->result_serial;
+            h->table_dirty = false;
+            P.active = false;
+            return GNDT_OK;
+        }
+        rc = -1;
+        if (++P.attempt < 5) rc = partition_launch(h, P);
+        if (rc == GNDT_OK) continue;
+        P.active = false;
+        if (rc != -1) return rc;
+        // does not fit the LDS-resident pipeline (too many nodes per bucket): same result via the atomic path
+        return build_atomic(h, P.xyz, P.n, P.stride, P.s);
+    }
 }
 
 }  // namespace
@@ -670,8 +742,9 @@ void gndt_destroy(gndt_handle* h) {
                     h->stage, h->d_cnt};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
-    for (auto& e : h->ev)
-        if (e) (void)hipEventDestroy(e);
+    for (auto& set : h->ev)
+        for (auto& e : set)
+            if (e) (void)hipEventDestroy(e);
     if (h->h_cnt) (void)hipHostFree(h->h_cnt);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     delete h;
@@ -690,6 +763,7 @@ int gndt_reset(gndt_handle* h, void* hip_stream) {
     HIP_TRY(h, hipSetDevice(h->device));
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
     h->last_stream = s;
+    h->pending.active = false;
     h->map_in_table = true;
     h->last_strategy = GNDT_STRATEGY_ATOMIC;
     return do_reset(h, s);
@@ -731,20 +805,12 @@ int gndt_finalize_device(gndt_handle* h, void* hip_stream) {
     return do_finalize(h, s);
 }
 
-int gndt_build_device(gndt_handle* h, const void* xyz_dev, size_t n, size_t stride_bytes, void* hip_stream) {
-    int rc = check_ready(h);
-    if (rc) return rc;
-    if (!xyz_dev && n) { h->err = "null input"; return GNDT_ERR_INVALID; }
-    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
-    h->last_stream = s;
-    for (auto& r : h->ev_recorded) r = false;
-    int strategy = h->P.strategy;
-    if (strategy == GNDT_STRATEGY_AUTO) strategy = (n >= (1u << 16)) ? GNDT_STRATEGY_PARTITION : GNDT_STRATEGY_ATOMIC;
-    if (strategy == GNDT_STRATEGY_PARTITION) {
-        rc = build_partition(h, xyz_dev, n, stride_bytes, s);
-        if (rc != -1) return rc;
-        // does not fit the LDS-resident pipeline (too many nodes per bucket): same result via the atomic path
-    }
+}  // extern "C"
+
+namespace {
+// strategy ATOMIC from empty; waits for the result (the retry on a full table needs the device-side flags)
+int build_atomic(gndt_handle* h, const void* xyz_dev, size_t n, size_t stride_bytes, hipStream_t s) {
+    int rc;
     h->last_strategy = GNDT_STRATEGY_ATOMIC;
     h->map_in_table = true;
     uint64_t expect = h->P.max_nodes_hint ? h->P.max_nodes_hint : std::max<uint64_t>(1024, n / 4);
@@ -771,6 +837,29 @@ int gndt_build_device(gndt_handle* h, const void* xyz_dev, size_t n, size_t stri
     }
     return GNDT_ERR_CAPACITY;
 }
+}  // namespace
+
+extern "C" {
+
+int gndt_build_device(gndt_handle* h, const void* xyz_dev, size_t n, size_t stride_bytes, void* hip_stream) {
+    int rc = check_ready(h);
+    if (rc) return rc;
+    if (!xyz_dev && n) { h->err = "null input"; return GNDT_ERR_INVALID; }
+    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
+    h->pending.active = false;          // a build still pending is being replaced: nobody will ask for its result
+    h->last_stream = s;
+    next_event_set(h);
+    int strategy = h->P.strategy;
+    if (strategy == GNDT_STRATEGY_AUTO) strategy = (n >= (1u << 16)) ? GNDT_STRATEGY_PARTITION : GNDT_STRATEGY_ATOMIC;
+    if (strategy == GNDT_STRATEGY_PARTITION) {
+        // launched, not awaited: gndt_sync / gndt_export* (or whatever needs the result next) waits, checks the
+        // overflow flags and re-runs with more room if needed.  xyz_dev stays the caller's until then.
+        rc = partition_begin(h, xyz_dev, n, stride_bytes, s);
+        if (rc != -1) return rc;
+        // does not fit the LDS-resident pipeline: same result via the atomic path
+    }
+    return build_atomic(h, xyz_dev, n, stride_bytes, s);
+}
 
 int gndt_update_device(gndt_handle* h, const void* xyz_dev, size_t n, size_t stride_bytes, void* hip_stream) {
     int rc = check_ready(h);
@@ -783,7 +872,7 @@ int gndt_update_device(gndt_handle* h, const void* xyz_dev, size_t n, size_t str
                  "with strategy = GNDT_STRATEGY_ATOMIC for incremental updates, or call gndt_reset first";
         return GNDT_ERR_INVALID;
     }
-    for (auto& r : h->ev_recorded) r = false;
+    next_event_set(h);
     h->last_strategy = GNDT_STRATEGY_ATOMIC;
     // Host side: only upper bounds, so that buffers exist (allocation happens outside any graph capture: run one
     // frame eagerly first, or give max_nodes_hint / max_points_hint).  The first_idx base is the DEVICE-side
@@ -822,6 +911,7 @@ int gndt_update(gndt_handle* h, const void* xyz_host, size_t n, size_t stride_by
 int gndt_sync(gndt_handle* h, uint64_t* num_nodes, uint64_t* num_columns, uint64_t* num_slopes) {
     if (!h) return GNDT_ERR_INVALID;
     HIP_TRY(h, hipSetDevice(h->device));
+    { const int prc = partition_resolve(h); if (prc) return prc; }
     HIP_TRY(h, hipStreamSynchronize(h->last_stream));
     if (h->results_valid) {
         h->res_nodes = h->h_cnt->num_nodes;
@@ -850,6 +940,7 @@ int gndt_sync(gndt_handle* h, uint64_t* num_nodes, uint64_t* num_columns, uint64
 
 int gndt_export_device(gndt_handle* h, gndt_cells* out) {
     if (!h || !out) return GNDT_ERR_INVALID;
+    { const int prc = partition_resolve(h); if (prc) return prc; }
     if (!h->results_valid) { h->err = "no finished build to export"; return GNDT_ERR_INVALID; }
     int rc = gndt_sync(h, nullptr, nullptr, nullptr);
     if (rc) return rc;
@@ -863,6 +954,7 @@ int gndt_export_device(gndt_handle* h, gndt_cells* out) {
 
 int gndt_export(gndt_handle* h, gndt_cells* o) {
     if (!h || !o) return GNDT_ERR_INVALID;
+    { const int prc = partition_resolve(h); if (prc) return prc; }
     if (!h->results_valid) { h->err = "no finished build to export"; return GNDT_ERR_INVALID; }
     int rc = gndt_sync(h, nullptr, nullptr, nullptr);
     if (rc) return rc;
@@ -886,6 +978,7 @@ int gndt_compute_cost(gndt_handle* h, const float goal_xyz[3], const gndt_robot*
     int rc = check_ready(h);
     if (rc) return rc;
     if (!goal_xyz) { h->err = "null goal"; return GNDT_ERR_INVALID; }
+    { const int prc = partition_resolve(h); if (prc) return prc; }
     if (!h->results_valid) { h->err = "no finished build to flood (computeCost runs after create2DMap, receiver.cpp:160, 171)"; return GNDT_ERR_INVALID; }
     rc = gndt_sync(h, nullptr, nullptr, nullptr);
     if (rc) return rc;
@@ -997,6 +1090,10 @@ int gndt_stats_export_device(gndt_handle* h, gndt_stats* out, void* hip_stream) 
     if (!out) return GNDT_ERR_INVALID;
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
     h->last_stream = s;
+    if (!h->map_in_table) {
+        h->err = "the current map was built by the PARTITION strategy, which keeps no additive state (use strategy ATOMIC)";
+        return GNDT_ERR_INVALID;
+    }
     if (h->cap == 0) { rc = alloc_table(h, cap_for_nodes(1024), s); if (rc) return rc; }
     rc = fetch_counters(h, s);
     if (rc) return rc;
@@ -1042,24 +1139,32 @@ int gndt_set_profiling(gndt_handle* h, int enable) {
     if (!h) return GNDT_ERR_INVALID;
     HIP_TRY(h, hipSetDevice(h->device));
     if (enable)
-        for (auto& e : h->ev)
-            if (!e) HIP_TRY(h, hipEventCreate(&e));
-    for (auto& r : h->ev_recorded) r = false;
-    h->prof = enable != 0;
+        for (auto& set : h->ev)
+            for (auto& e : set)
+                if (!e) HIP_TRY(h, hipEventCreate(&e));
+    for (auto& set : h->ev_recorded)
+        for (auto& r : set) r = false;
+    h->prof = enable < 0 ? 0 : (enable > 2 ? 1 : enable);
     return GNDT_OK;
 }
 
+// Mean duration of every phase over the builds recorded since the last call (at most the last kEvSets).
 int gndt_get_phase_times(gndt_handle* h, double ms_out[GNDT_NUM_PHASES]) {
     if (!h || !ms_out) return GNDT_ERR_INVALID;
     HIP_TRY(h, hipSetDevice(h->device));
     HIP_TRY(h, hipStreamSynchronize(h->last_stream));
     for (int i = 0; i < GNDT_NUM_PHASES; ++i) {
-        ms_out[i] = -1.0;
-        if (h->ev_recorded[i] && h->ev_recorded[i + 1]) {
+        double sum = 0.0;
+        int cnt = 0;
+        for (int k = 0; k < gndt_handle::kEvSets; ++k) {
+            if (!(h->ev_recorded[k][i] && h->ev_recorded[k][i + 1])) continue;
             float ms = 0.f;
-            if (hipEventElapsedTime(&ms, h->ev[i], h->ev[i + 1]) == hipSuccess) ms_out[i] = ms;
+            if (hipEventElapsedTime(&ms, h->ev[k][i], h->ev[k][i + 1]) == hipSuccess) { sum += ms; ++cnt; }
         }
+        ms_out[i] = cnt ? sum / cnt : -1.0;
     }
+    for (auto& set : h->ev_recorded)
+        for (auto& r : set) r = false;
     return GNDT_OK;
 }
 

@@ -207,7 +207,7 @@ class TwoDmap:
 
     def set_profiling(self, on=True, demand="slope"):
         self._ensure(demand)
-        self._check(self._L.gndt_set_profiling(self._h, 1 if on else 0))
+        self._check(self._L.gndt_set_profiling(self._h, int(on)))
 
     def last_strategy(self):
         """1 = ATOMIC, 2 = PARTITION: what the last build actually ran."""

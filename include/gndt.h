@@ -201,6 +201,8 @@ void gndt_unpack_key(uint64_t key, int32_t* sx, int32_t* sy, int32_t* sz);
  *   PARTITION: [0] clear  [1] hist  [2] offsets  [3] scatter  [4] bucket_build  [5] bitmap_scan
  *              [6] rank  [7] column_scan  [8] dest  [9] emit */
 #define GNDT_NUM_PHASES 10
+/* enable: 0 off, 1 events around every phase, 2 only around the dominant phase of the strategy in use
+ * (bucket_build / accumulate): two events per build instead of eleven. */
 int gndt_set_profiling(gndt_handle* h, int enable);
 int gndt_get_phase_times(gndt_handle* h, double ms_out[GNDT_NUM_PHASES]);
 /* GNDT_STRATEGY_ATOMIC or GNDT_STRATEGY_PARTITION: what the last build actually ran (AUTO resolves,
