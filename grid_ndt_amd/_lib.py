@@ -131,6 +131,8 @@ def lib():
     L.gndt_export.argtypes = [H, C.POINTER(Cells)]
     L.gndt_stats_export_device.argtypes = [H, C.POINTER(Stats), vp]
     L.gndt_stats_merge_device.argtypes = [H, C.POINTER(Stats), vp]
+    L.gndt_shard_stats_device.argtypes = [H, vp, C.c_size_t, C.c_size_t, u64, C.POINTER(Stats), vp]
+    L.gndt_finalize_stats_device.argtypes = [H, C.POINTER(Stats), u64, vp]
     L.gndt_compute_cost.argtypes = [H, C.POINTER(C.c_float), C.POINTER(Robot), vp]
     L.gndt_cost_export_device.argtypes = [H, C.POINTER(vp), C.POINTER(vp), C.POINTER(CostStats)]
     L.gndt_cost_export.argtypes = [H, vp, vp, C.POINTER(CostStats)]
@@ -153,6 +155,7 @@ def lib():
                  "gndt_reset", "gndt_accumulate_device", "gndt_finalize_device", "gndt_sync", "gndt_export_device",
                  "gndt_export", "gndt_stats_export_device", "gndt_stats_merge_device", "gndt_trans_morton_xyz",
                  "gndt_compute_cost", "gndt_cost_export_device", "gndt_cost_export",
+                 "gndt_shard_stats_device", "gndt_finalize_stats_device",
                  "gndt_count_morton", "gndt_morton_to_xy", "gndt_device_info", "gndt_set_profiling", "gndt_get_phase_times"):
         getattr(L, name).restype = C.c_int
     _lib = L

@@ -117,6 +117,8 @@ struct gndt_handle {
         hipStream_t s = nullptr;
         int attempt = 0, bslots = 0;
         uint64_t nodes_est = 0, stage_want = 0;
+        bool stats_only = false;        // gndt_shard_stats_device: statistics out, no labels / ordering / rows
+        uint32_t first_base = 0;        // global index of xyz[0] (shards of a global cloud)
     } pending;
 
     std::string err;
@@ -556,8 +558,12 @@ int partition_launch(gndt_handle* h, gndt_handle::Pending& P) {
         q.bucket_cap = B;
     }
     stage_want = std::max<uint64_t>(stage_want, nodes_est + nodes_est / 8);
-    if ((rc = ensure_stage(h, stage_want))) return rc;
-    if ((rc = ensure_out(h, q.stage_cap))) return rc;
+    if (P.stats_only) {
+        if ((rc = ensure_stats_buffers(h, stage_want))) return rc;
+    } else {
+        if ((rc = ensure_stage(h, stage_want))) return rc;
+        if ((rc = ensure_out(h, q.stage_cap))) return rc;
+    }
     mark(h, 0, s);
     // the HBM node table is not used by this strategy, but a previous atomic build may sit in it
     if (h->table_dirty) { if ((rc = do_reset(h, s))) return rc; }
@@ -582,10 +588,10 @@ int partition_launch(gndt_handle* h, gndt_handle::Pending& P) {
     HIP_TRY(h, hipGetLastError());
     mark(h, 3, s);
     if (stride_bytes == 12)
-        hipLaunchKernelGGL(k_part_scatter<3>, dim3(nwg), dim3(kPartThreads), lds, s, p, (uint64_t)n, 0u, gp, B, q.hist,
+        hipLaunchKernelGGL(k_part_scatter<3>, dim3(nwg), dim3(kPartThreads), lds, s, p, (uint64_t)n, P.first_base, gp, B, q.hist,
                            q.totals, q.bucket_base, q.recs);
     else
-        hipLaunchKernelGGL(k_part_scatter<4>, dim3(nwg), dim3(kPartThreads), lds, s, p, (uint64_t)n, 0u, gp, B, q.hist,
+        hipLaunchKernelGGL(k_part_scatter<4>, dim3(nwg), dim3(kPartThreads), lds, s, p, (uint64_t)n, P.first_base, gp, B, q.hist,
                            q.totals, q.bucket_base, q.recs);
     HIP_TRY(h, hipGetLastError());
     mark(h, 4, s);
@@ -598,19 +604,24 @@ int partition_launch(gndt_handle* h, gndt_handle::Pending& P) {
     }
     q.last_buckets = B;
     {
-#define GNDT_LAUNCH_BUCKET2(T_, H_, CH_)                                                                               \
-hipLaunchKernelGGL((k_bucket_build2<T_, H_, CH_>), dim3(B), dim3(T_), 0, s, q.recs, q.bucket_base, gp, q.stage,    \
-                   (uint32_t)q.stage_cap, q.ord_cf, q.ord_idx, q.ord_ncol, q.bitmap, h->d_cnt, q.d_pc, q.dbg)
-        if (bslots == 1024 && bt == 1024) GNDT_LAUNCH_BUCKET2(1024, 1024, 3072);
-        else if (bslots == 1024) GNDT_LAUNCH_BUCKET2(512, 1024, 3584);
-        else if (bslots == 512 && bt == 256) GNDT_LAUNCH_BUCKET2(256, 512, 1792);
-        else if (bslots == 256) GNDT_LAUNCH_BUCKET2(256, 256, 1024);
-        else GNDT_LAUNCH_BUCKET2(512, 512, 1536);
+#define GNDT_LAUNCH_BUCKET2(T_, H_, CH_, S_)                                                                           \
+    hipLaunchKernelGGL((k_bucket_build2<T_, H_, CH_, S_>), dim3(B), dim3(T_), 0, s, q.recs, q.bucket_base, gp, q.stage, \
+                       (uint32_t)(S_ ? h->st_cap : q.stage_cap), q.ord_cf, q.ord_idx, q.ord_ncol, q.bitmap, h->d_cnt,   \
+                       q.d_pc, q.dbg, StatsOut{h->st_key, h->st_sums, h->st_count, h->st_first})
+            if (P.stats_only) {
+                if (bslots == 1024) GNDT_LAUNCH_BUCKET2(512, 1024, 3584, true);
+                else GNDT_LAUNCH_BUCKET2(512, 512, 1536, true);
+            }
+            else if (bslots == 1024 && bt == 1024) GNDT_LAUNCH_BUCKET2(1024, 1024, 3072, false);
+            else if (bslots == 1024) GNDT_LAUNCH_BUCKET2(512, 1024, 3584, false);
+            else if (bslots == 512 && bt == 256) GNDT_LAUNCH_BUCKET2(256, 512, 1792, false);
+            else if (bslots == 256) GNDT_LAUNCH_BUCKET2(256, 256, 1024, false);
+            else GNDT_LAUNCH_BUCKET2(512, 512, 1536, false);
 #undef GNDT_LAUNCH_BUCKET2
     }
     HIP_TRY(h, hipGetLastError());
     mark(h, 5, s);
-    if ((rc = launch_order_and_emit(h, words, 5, s))) return rc;
+    if (!P.stats_only && (rc = launch_order_and_emit(h, words, 5, s))) return rc;
     HIP_TRY(h, hipMemcpyAsync(q.h_pc, q.d_pc, sizeof(PartCounters), hipMemcpyDeviceToHost, s));
     HIP_TRY(h, hipMemcpyAsync(h->h_cnt, h->d_cnt, sizeof(Counters), hipMemcpyDeviceToHost, s));
     P.bslots = bslots;
@@ -668,8 +679,10 @@ int partition_resolve(gndt_handle* h) {
         if (!again) {
             q.nodes_learned = (uint64_t)h->h_cnt->num_nodes + h->h_cnt->num_nodes / 5;
             q.good_slots = P.bslots; q.good_est = P.nodes_est; q.good_n = P.n;
-            h->results_valid = true;
-            ++h->result_serial;
+            if (!P.stats_only) {
+                h->results_valid = true;
+                ++h->result_serial;
+            }
             h->table_dirty = false;
             P.active = false;
             return GNDT_OK;
@@ -678,7 +691,7 @@ int partition_resolve(gndt_handle* h) {
         if (++P.attempt < 5) rc = partition_launch(h, P);
         if (rc == GNDT_OK) continue;
         P.active = false;
-        if (rc != -1) return rc;
+        if (rc != -1 || P.stats_only) return rc;   // (a statistics-only run reports -1: its caller falls back)
         // does not fit the LDS-resident pipeline (too many nodes per bucket): same result via the atomic path
         return build_atomic(h, P.xyz, P.n, P.stride, P.s);
     }
@@ -1081,6 +1094,94 @@ int gndt_cost_export(gndt_handle* h, float* h_out, uint32_t* state_out, gndt_cos
     const uint64_t n = h->res_nodes;
     if (h_out && n) HIP_TRY(h, hipMemcpy(h_out, h->cost.h_bits, n * 4, hipMemcpyDeviceToHost));
     if (state_out && n) HIP_TRY(h, hipMemcpy(state_out, h->cost.state, n * 4, hipMemcpyDeviceToHost));
+    return GNDT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// one global map from a sharded cloud: shard -> statistics (PARTITION pipeline, no node table), and
+// merged statistics (sorted by key) -> map
+// ---------------------------------------------------------------------------------------------
+int gndt_shard_stats_device(gndt_handle* h, const void* xyz_dev, size_t n, size_t stride_bytes, uint64_t first_idx_base,
+                            gndt_stats* out, void* hip_stream) {
+    int rc = check_ready(h);
+    if (rc) return rc;
+    if (!out || (!xyz_dev && n)) { h->err = "null argument"; return GNDT_ERR_INVALID; }
+    if (first_idx_base + n >= 0x7FFFFFFFull) { h->err = "point index exceeds 31 bits"; return GNDT_ERR_INVALID; }
+    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
+    h->pending.active = false;
+    h->last_stream = s;
+    next_event_set(h);
+    rc = -1;
+    if (n >= (1u << 12) && h->P.strategy != GNDT_STRATEGY_ATOMIC && stride_bytes != 0) {
+        auto& q = h->part;
+        if ((rc = grow_buf(h, q.recs, q.rec_cap, n))) return rc;
+        if ((rc = ensure_words(h, (n + 31) / 32 + 1))) return rc;
+        if ((rc = ensure_part_counters(h))) return rc;
+        auto& P = h->pending;
+        P = gndt_handle::Pending{};
+        P.xyz = xyz_dev; P.n = n; P.stride = stride_bytes; P.s = s;
+        P.stats_only = true; P.first_base = (uint32_t)first_idx_base;
+        P.nodes_est = h->P.max_nodes_hint ? h->P.max_nodes_hint : (q.nodes_learned ? q.nodes_learned : std::max<uint64_t>(n / 4, 1024));
+        P.stage_want = std::max<uint64_t>(h->st_cap, std::max<uint64_t>(4096, n / 4));
+        h->results_valid = false;
+        const int prev = h->last_strategy;
+        h->last_strategy = GNDT_STRATEGY_PARTITION;
+        rc = partition_launch(h, P);
+        if (rc == GNDT_OK) { P.active = true; rc = partition_resolve(h); }
+        if (rc != -1) {
+            if (rc) { h->last_strategy = prev; return rc; }
+            if (h->h_cnt->err_key_range) {
+                h->err = std::to_string(h->h_cnt->err_key_range) + " point(s) outside the key range";
+                return GNDT_ERR_KEY_RANGE;
+            }
+            out->num_nodes = h->h_cnt->num_nodes;
+            out->key = h->st_key; out->sums = h->st_sums; out->count = h->st_count; out->first_idx = h->st_first;
+            return GNDT_OK;
+        }
+        h->last_strategy = prev;
+    }
+    // small shards, strategy ATOMIC, or too many nodes per bucket: through the node table
+    h->pending.active = false;
+    if ((rc = gndt_reset(h, hip_stream))) return rc;
+    if ((rc = gndt_accumulate_device(h, xyz_dev, n, stride_bytes, first_idx_base, hip_stream))) return rc;
+    return gndt_stats_export_device(h, out, hip_stream);
+}
+
+int gndt_finalize_stats_device(gndt_handle* h, const gndt_stats* in, uint64_t total_points, void* hip_stream) {
+    int rc = check_ready(h);
+    if (rc) return rc;
+    if (!in || (in->num_nodes && (!in->key || !in->sums || !in->count || !in->first_idx))) { h->err = "null statistics"; return GNDT_ERR_INVALID; }
+    if (in->num_nodes >= 0xFFFFFFFFull || total_points >= 0xFFFFFFFFull) { h->err = "too many nodes / points"; return GNDT_ERR_INVALID; }
+    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
+    h->pending.active = false;
+    h->last_stream = s;
+    next_event_set(h);
+    auto& q = h->part;
+    const uint64_t n = in->num_nodes;
+    const uint64_t words = (std::max<uint64_t>(total_points, 64) + 31) / 32 + 1;
+    if ((rc = ensure_part_counters(h))) return rc;
+    if ((rc = ensure_stage(h, std::max<uint64_t>(1024, n)))) return rc;
+    if ((rc = ensure_out(h, q.stage_cap))) return rc;
+    if ((rc = ensure_words(h, words))) return rc;
+    if (h->table_dirty) { if ((rc = do_reset(h, s))) return rc; }
+    h->results_valid = false;
+    mark(h, 0, s);
+    hipLaunchKernelGGL(k_part_clear, dim3(grid_for(words, 256, 512)), dim3(256), 0, s, h->d_cnt, q.d_pc, q.bitmap, (uint64_t)words);
+    HIP_TRY(h, hipGetLastError());
+    mark(h, 4, s);
+    hipLaunchKernelGGL(k_stats_rows, dim3(grid_for(std::max<uint64_t>(n, 1))), dim3(kBlock), 0, s, in->key, in->sums, in->count,
+                       in->first_idx, (uint32_t)n, grid_params(h), q.stage, q.ord_cf, q.ord_idx, q.ord_ncol, q.bitmap,
+                       (uint64_t)words, h->d_cnt, q.d_pc);
+    HIP_TRY(h, hipGetLastError());
+    mark(h, 5, s);
+    if ((rc = launch_order_and_emit(h, words, 5, s))) return rc;
+    HIP_TRY(h, hipMemcpyAsync(q.h_pc, q.d_pc, sizeof(PartCounters), hipMemcpyDeviceToHost, s));
+    HIP_TRY(h, hipMemcpyAsync(h->h_cnt, h->d_cnt, sizeof(Counters), hipMemcpyDeviceToHost, s));
+    h->results_valid = true;
+    ++h->result_serial;
+    h->map_in_table = false;
+    h->last_strategy = GNDT_STRATEGY_PARTITION;
+    h->stream_pos = total_points;
     return GNDT_OK;
 }
 

@@ -54,13 +54,21 @@ struct BucketLds2 {
     uint32_t n_nodes, n_cols, n_clist, n_rows, n_slopes, stage_base, overflow;
 };
 
-template <int T, int H, int CH>
+// Compact per-node statistics (the gndt_stats layout): what a shard of a multi-GPU build hands to the exchange.
+struct StatsOut {
+    uint64_t* key; double* sums; uint32_t* count; uint32_t* first;
+};
+
+// STATS = false: the bucket's nodes leave as staging rows (labels, moments) for the ordering + emit kernels.
+// STATS = true : they leave as additive statistics (key, 9 sums, count, first index) and nothing else is done:
+//                the shard's contribution to a global map (gndt_shard_stats_device).
+template <int T, int H, int CH, bool STATS = false>
 __global__ void __launch_bounds__(T) k_bucket_build2(const float4* __restrict__ recs, const uint32_t* __restrict__ bucket_base,
                                                      GridParams P, StageRow* __restrict__ stage, uint32_t stage_cap,
                                                      uint32_t* __restrict__ ord_cf, uint32_t* __restrict__ ord_idx,
                                                      uint32_t* __restrict__ ord_ncol, uint32_t* __restrict__ bitmap,
                                                      Counters* __restrict__ cnt, PartCounters* __restrict__ pc,
-                                                     unsigned long long* __restrict__ dbg) {
+                                                     unsigned long long* __restrict__ dbg, StatsOut so) {
     static_assert(CH % T == 0, "chunk must be a multiple of the block");
     static_assert(H % T == 0 || T % H == 0, "slots vs threads");
     constexpr int PER = CH / T;                 // points per thread and chunk
@@ -218,6 +226,27 @@ __global__ void __launch_bounds__(T) k_bucket_build2(const float4* __restrict__ 
     uint32_t stage_base_reg = 0;
     const uint32_t M = L.n_nodes;
     if (tid == T - 1) stage_base_reg = atomicAdd(&cnt->num_nodes, M);
+
+    if constexpr (STATS) {
+        if (tid == T - 1) L.stage_base = stage_base_reg;
+        __syncthreads();
+        const uint32_t sbase = L.stage_base;
+        if (sbase + M > stage_cap) {               // uniform
+            if (tid == 0) atomicAdd(&pc->stage_overflow, M);
+            return;
+        }
+        for (int s = tid; s < H; s += T) {
+            const uint64_t key = L.key[s];
+            if (key == kEmptyKey) continue;
+            const uint32_t dst = sbase + atomicAdd(&L.n_rows, 1u);
+            so.key[dst] = key;
+#pragma unroll
+            for (int j = 0; j < 9; ++j) so.sums[9 * (size_t)dst + j] = L.sum[j][s];
+            so.count[dst] = L.cnt[s];
+            so.first[dst] = L.first[s];
+        }
+        return;
+    }
 
     // ---- D: columns (the pts image is dead: its LDS now holds the column tables) ----
     for (int s = tid; s < H; s += T) { L.u.fin.ckey[s] = kEmptyKey; L.u.fin.cfirst[s] = 0xFFFFFFFFu; L.u.fin.ccnt[s] = 0; L.u.fin.chead[s] = 0xFFFFFFFFu; }

@@ -145,4 +145,85 @@ __global__ void k_tab_end(Counters* cnt) {
     if (threadIdx.x == 0 && blockIdx.x == 0) cnt->prev_nodes = cnt->num_nodes;
 }
 
+// ---------------------------------------------------------------------------------------------
+// k_stats_rows: merged statistics of a global map (unique nodes SORTED BY KEY, so the nodes of a column are
+// adjacent) -> staging rows, without any table: the column of node i is the run of equal column keys around
+// it; label, index in column and the column's first-seen index come from one walk over that run.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock) k_stats_rows(const uint64_t* __restrict__ key, const double* __restrict__ sums,
+                                                       const uint32_t* __restrict__ count, const uint32_t* __restrict__ first,
+                                                       uint32_t n, GridParams P, StageRow* __restrict__ stage,
+                                                       uint32_t* __restrict__ ord_cf, uint32_t* __restrict__ ord_idx,
+                                                       uint32_t* __restrict__ ord_ncol, uint32_t* __restrict__ bitmap,
+                                                       uint64_t words, Counters* __restrict__ cnt,
+                                                       PartCounters* __restrict__ pc) {
+    __shared__ uint32_t s_slopes, s_cols;
+    if (threadIdx.x == 0) { s_slopes = 0; s_cols = 0; }
+    __syncthreads();
+    if (blockIdx.x == 0 && threadIdx.x == 0) cnt->num_nodes = n;
+    uint32_t my_slopes = 0, my_cols = 0;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const uint64_t k = key[i], ck = column_key(k);
+        StageRow row;
+        unpack_key(k, row.sx, row.sy, row.sz);
+        const uint32_t my_first = first[i], my_count = count[i];
+        const double cz_centre = axis_centre(row.sz, P.oz, P.z_len);
+        uint32_t fl = 0;
+        float cz = 0.f;
+        if (my_count >= (uint32_t)P.min_points) { cz = node_mean_z(my_count, sums[9 * (size_t)i + 2], cz_centre); fl = 1u; }
+        const int za = level_above(row.sz), zb = level_below(row.sz);
+        uint32_t lo = i, hi = i + 1;
+        while (lo > 0 && column_key(key[lo - 1]) == ck) --lo;
+        while (hi < n && column_key(key[hi]) == ck) ++hi;
+        uint32_t icol = 0, cf = my_first;
+        bool up = false, down = false;
+        for (uint32_t t = lo; t < hi; ++t) {
+            if (t == i) continue;
+            const uint32_t tf = first[t];
+            cf = min(cf, tf);
+            icol += (tf < my_first) ? 1u : 0u;
+            const int tz = (int)(key[t] & 0x3FFFFFu) - (1 << 21);
+            if (tz == za || tz == zb) {
+                const uint32_t tc = count[t];
+                const bool visited = tf < my_first && tc >= (uint32_t)P.min_points;
+                const float oz = visited ? node_mean_z(tc, sums[9 * (size_t)t + 2], axis_centre(tz, P.oz, P.z_len)) : 0.f;
+                const bool far = fabsf(oz - cz) > P.slope_interval;
+                if (tz == za) up = up || far; else down = down || far;
+            }
+        }
+        if (fl & 1u) {
+            bool slope = true;
+            if (P.demand == 0) slope = !up; else down = false;
+            if (slope) { fl |= 2u; if (down) fl |= 4u; ++my_slopes; }
+        }
+        row.count = my_count; row.first = my_first; row.flags = fl;
+        for (int j = 0; j < 3; ++j) row.mean[j] = 0.f;
+        for (int j = 0; j < 6; ++j) row.scatter[j] = 0.0;
+        if (fl & 1u) {
+            double sm[9];
+            for (int j = 0; j < 9; ++j) sm[j] = sums[9 * (size_t)i + j];
+            const double c[3] = {axis_centre(row.sx, P.ox, P.grid_len), axis_centre(row.sy, P.oy, P.grid_len), cz_centre};
+            node_moments(my_count, sm, c, row.mean, row.scatter);
+        }
+        row.col_first = cf; row.idx_in_col = icol; row.ncol = hi - lo;
+        for (int j = 0; j < 8; ++j) row.pad[j] = 0;
+        stage[i] = row;
+        ord_cf[i] = cf;
+        ord_idx[i] = icol;
+        if (icol == 0) {
+            ord_ncol[i] = row.ncol;
+            if ((uint64_t)(cf >> 5) < words) atomicOr(&bitmap[cf >> 5], 1u << (cf & 31u));
+            else atomicAdd(&pc->index_overflow, 1u);
+            ++my_cols;
+        }
+    }
+    if (my_slopes) atomicAdd(&s_slopes, my_slopes);
+    if (my_cols) atomicAdd(&s_cols, my_cols);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (s_slopes) atomicAdd(&cnt->num_slopes, s_slopes);
+        if (s_cols) atomicAdd(&cnt->num_columns, s_cols);
+    }
+}
+
 }  // namespace gndt

@@ -48,20 +48,22 @@ def merge_stats(key, sums, count, first_idx, group=None):
     return union, g_sums, g_count, g_first
 
 
-def build_global_map(m, demand, shard, first_idx_base, stream=None, group=None):
+def build_global_map(m, demand, shard, first_idx_base, stream=None, group=None, total_points=None):
     """`m`: a TwoDmap whose origin is the GLOBAL cloud's point 0 on every rank; `shard`: this rank's
     device-resident points; `first_idx_base`: global index of shard[0].  On return `m` holds the map of
-    the whole cloud (same on every rank)."""
-    m.reset(demand, stream)
-    m.accumulate(demand, shard, first_idx_base, stream)
-    st = m.stats_export(stream)
+    the whole cloud (same on every rank).  Per rank: shard -> statistics through the counting-partition pipeline
+    (no node table), one exchange, then the merged statistics (already sorted by key: the canonical order) ->
+    labels, order and rows in one pass."""
+    st = m.shard_stats(demand, shard, first_idx_base, stream)
     if stream is not None and hasattr(stream, "synchronize"):
         stream.synchronize()
     else:
         torch.cuda.synchronize()
     key, sums, count, first = merge_stats(st["key"].clone(), st["sums"].clone(), st["count"].clone(),
                                           st["first_idx"].clone(), group)
-    m.reset(demand, stream)
-    m.stats_merge(key.contiguous(), sums.contiguous(), count.contiguous(), first.contiguous(), stream)
-    m.finalize(stream)
+    if total_points is None:
+        t = torch.tensor([int(shard.shape[0])], dtype=torch.int64, device=key.device)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        total_points = int(t.item())
+    m.finalize_stats(key.contiguous(), sums.contiguous(), count.contiguous(), first.contiguous(), total_points, stream)
     return key.shape[0]

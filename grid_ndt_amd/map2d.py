@@ -195,6 +195,36 @@ class TwoDmap:
         return {"key": mk(st.key, (n,), "<i8"), "sums": mk(st.sums, (n, 9), "<f8"),
                 "count": mk(st.count, (n,), "<i4"), "first_idx": mk(st.first_idx, (n,), "<i4")}
 
+    def _stats_tensors(self, st):
+        import torch
+        n = int(st.num_nodes)
+        dev = f"cuda:{self.device}"
+        if n == 0:
+            return {"key": torch.zeros(0, dtype=torch.int64, device=dev), "sums": torch.zeros(0, 9, dtype=torch.float64, device=dev),
+                    "count": torch.zeros(0, dtype=torch.int32, device=dev), "first_idx": torch.zeros(0, dtype=torch.int32, device=dev)}
+        mk = lambda p, shape, ts: torch.as_tensor(_DevArray(p, shape, ts, self), device=dev)
+        return {"key": mk(st.key, (n,), "<i8"), "sums": mk(st.sums, (n, 9), "<f8"),
+                "count": mk(st.count, (n,), "<i4"), "first_idx": mk(st.first_idx, (n,), "<i4")}
+
+    def shard_stats(self, demand, points, first_idx_base=0, stream=None):
+        """This rank's shard of a global cloud -> the statistics of its occupied nodes (torch views of libgndt
+        memory, valid until the next call): the counting-partition pipeline, no node table."""
+        self._ensure(demand)
+        ptr, n, stride, on_dev, keep = self._as_input(points)
+        if not on_dev:
+            raise GndtError(1, "shard_stats takes device memory")
+        st = Stats()
+        self._check(self._L.gndt_shard_stats_device(self._h, C.c_void_p(ptr), n, stride, int(first_idx_base), C.byref(st),
+                                                    _stream_ptr(stream)))
+        self._keep = keep
+        return self._stats_tensors(st)
+
+    def finalize_stats(self, key, sums, count, first_idx, total_points, stream=None):
+        """Merged statistics of the whole cloud (unique nodes sorted by key) -> the map."""
+        st = Stats(int(key.shape[0]), key.data_ptr(), sums.data_ptr(), count.data_ptr(), first_idx.data_ptr())
+        self._check(self._L.gndt_finalize_stats_device(self._h, C.byref(st), int(total_points), _stream_ptr(stream)))
+        self._keep = (key, sums, count, first_idx)
+
     def stats_merge(self, key, sums, count, first_idx, stream=None):
         st = Stats(int(key.shape[0]), key.data_ptr(), sums.data_ptr(), count.data_ptr(), first_idx.data_ptr())
         self._check(self._L.gndt_stats_merge_device(self._h, C.byref(st), _stream_ptr(stream)))

@@ -146,6 +146,18 @@ int gndt_stats_export_device(gndt_handle* h, gndt_stats* out, void* hip_stream);
 /* Adds `in` (device memory) into the handle's table: sums add, counts add, first_idx takes the min. */
 int gndt_stats_merge_device(gndt_handle* h, const gndt_stats* in, void* hip_stream);
 
+/* One global map from a cloud sharded over several GPUs, without the node table:
+ *   gndt_shard_stats_device   this rank's shard -> compact statistics of its occupied nodes (the counting
+ *                             partition + LDS bucket pipeline of a normal build, statistics out instead of rows);
+ *                             `first_idx_base` = global index of xyz_dev[0].  Returns with `out` filled.
+ *   [exchange: union of keys, sum of sums/counts, min of first_idx — grid_ndt_amd/dist.py over RCCL]
+ *   gndt_finalize_stats_device  the merged statistics -> the map.  `in` must hold every node once, SORTED BY KEY
+ *                             (any total order of the packed keys: a column's nodes are then adjacent);
+ *                             `total_points` = number of points of the whole cloud (first_idx < total_points). */
+int gndt_shard_stats_device(gndt_handle* h, const void* xyz_dev, size_t n, size_t stride_bytes, uint64_t first_idx_base,
+                            gndt_stats* out, void* hip_stream);
+int gndt_finalize_stats_device(gndt_handle* h, const gndt_stats* in, uint64_t total_points, void* hip_stream);
+
 /* ---- cost map over the finished grid -------------------------------------
  * gndt_compute_cost replaces TwoDmap::computeCost (include/map2D.h:1285-1397; called at receiver.cpp:171
  * right after create2DMap): the FIFO flood from the goal slope with CollisionCheck (:351-411; the 3D variants

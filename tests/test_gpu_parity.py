@@ -330,6 +330,49 @@ def test_single_hip_runtime_and_foreign_stream():
     assert int(views["count"].sum().item()) == cloud.shape[0] - 1
 
 
+@pytest.mark.parametrize("strategy", [0, 1])
+@pytest.mark.parametrize("scene", ["terrain", "campus_true"])
+def test_sharded_cloud_statistics_merge_to_the_global_map(strategy, scene):
+    """Three shards of one cloud, each turned into statistics by its own handle (shard_stats: the counting
+    partition for strategy AUTO, the node table for ATOMIC), merged the way grid_ndt_amd/dist.py merges them
+    (union of keys, sums add, first-seen takes the min), finalised from the key-sorted statistics: must equal
+    the oracle's map of the whole cloud."""
+    import torch
+    import grid_ndt_amd as g
+    cloud, P = {"terrain": (scenes.terrain_cloud(400000), TERRAIN),
+                "campus_true": (scenes.campus_frame(200000), dict(scenes.CAMPUS_PARAMS, demand="true"))}[scene]
+    ref = parity.ref_from_cloud(cloud, P)
+    body = torch.from_numpy(cloud[1:]).cuda()
+    n = body.shape[0]
+    cuts = [0, n // 5, n // 5 + 70001, n]
+    parts = []
+    for r in range(3):
+        m = g.TwoDmap(P["grid_len"], P["z_len"], strategy=strategy)
+        m.setInterval(P["slope_interval"])
+        m.setCloudFirst(cloud[0])
+        st = m.shard_stats(P["demand"], body[cuts[r]:cuts[r + 1]], first_idx_base=cuts[r])
+        assert m.last_strategy() == (2 if strategy == 0 else 1)
+        parts.append({k: v.clone() for k, v in st.items()})
+        assert int(parts[-1]["count"].sum().item()) == cuts[r + 1] - cuts[r]
+    keys = torch.cat([p["key"] for p in parts])
+    union, inv = torch.unique(keys, return_inverse=True)
+    c = union.shape[0]
+    sums = torch.zeros((c, 9), dtype=torch.float64, device="cuda").index_add_(0, inv, torch.cat([p["sums"] for p in parts]))
+    count = torch.zeros(c, dtype=torch.int32, device="cuda").index_add_(0, inv, torch.cat([p["count"] for p in parts]))
+    first = torch.full((c,), 2**31 - 1, dtype=torch.int32, device="cuda").scatter_reduce_(
+        0, inv, torch.cat([p["first_idx"] for p in parts]), reduce="amin")
+    m = g.TwoDmap(P["grid_len"], P["z_len"], strategy=strategy)
+    m.setInterval(P["slope_interval"])
+    m.setCloudFirst(cloud[0])
+    m._ensure(P["demand"])
+    m.finalize_stats(union, sums, count, first, total_points=n)
+    parity.assert_parity(m.export(), ref)
+    # a first index beyond total_points is reported, not silently mis-ordered
+    m.finalize_stats(union, sums, count, first, total_points=1000)
+    with pytest.raises(g.GndtError):
+        m.sync()
+
+
 def test_global_map_exchange_on_rccl_single_rank():
     """grid_ndt_amd/dist.py end to end on the GPU (backend nccl = RCCL, world_size 1): accumulate ->
     stats export -> all_gather / all_reduce -> merge -> finalize must equal the plain build."""
