@@ -515,11 +515,18 @@ int stage_host_input(gndt_handle* h, const void* xyz_host, size_t n, size_t stri
 // ---------------------------------------------------------------------------------------------
 // strategy PARTITION (gndt_partition.hpp): the build
 // ---------------------------------------------------------------------------------------------
-// Bucket count for `nodes` expected nodes: ~4*slots points per bucket, and few enough nodes per bucket for
-// the LDS table (average load <= 0.4 of `slots`: the overflow limit of 0.78 is then ~6 sigma of the column count away).
+// Bucket count for `nodes` expected nodes.  Few, large buckets are better for both the scatter (longer runs per
+// workgroup and bucket) and the bucket kernel (fixed costs per bucket): as many points per bucket as two chunks of
+// the bucket kernel take (2800 leaves room for the spread of a hash partition), unless the LDS node table says
+// otherwise: average load <= 0.5 of `slots` against an estimate that already carries a 20 % margin, i.e. ~0.42 of
+// the slots really used, ~5 sigma of the column count below the overflow limit of 0.78.  (An overflow is not an
+// error: the build is re-run with the larger table / more buckets.)
 uint64_t buckets_for(uint64_t n, uint64_t nodes, int slots) {
-    static const int load_pct = getenv("GNDT_BUCKET_LOAD") ? atoi(getenv("GNDT_BUCKET_LOAD")) : 40;   // tuning knob
-    const uint64_t want = std::max<uint64_t>(n / (4 * (uint64_t)slots), (nodes * 100) / ((uint64_t)slots * load_pct));
+    static const int load_pct = getenv("GNDT_BUCKET_LOAD") ? atoi(getenv("GNDT_BUCKET_LOAD")) : 50;       // tuning knobs
+    static const int pts_target = getenv("GNDT_BUCKET_POINTS") ? atoi(getenv("GNDT_BUCKET_POINTS")) : 0;
+    if (pts_target) return std::max<uint64_t>(n / (uint64_t)pts_target, 16);
+    const uint64_t per_bucket = slots >= 1024 ? 6400 : 2800;
+    const uint64_t want = std::max<uint64_t>(n / per_bucket, (nodes * 100) / ((uint64_t)slots * load_pct));
     return std::max<uint64_t>(want, 16);
 }
 constexpr uint64_t kMaxBuckets = 32768;   // 4-byte LDS cursor per bucket in the partition passes
