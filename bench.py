@@ -156,6 +156,7 @@ def main():
         # every kernel that streams the cloud moves 12 B/point; k_bucket_build also emits the nodes
         # (12 B/point + 76 B/node); node-proportional kernels move 76 B/node.
         kernel_of = {"accumulate": "k_accumulate", "hist": "k_part_hist", "scatter": "k_part_scatter",
+                     "level1": "k_part2_level1", "level2": "k_part2_level2",
                      "bucket_build": "k_bucket_build", "columns": "k_tab_columns", "rows": "k_tab_rows",
                      "emit": "k_emit_rows"}
         cand = {k: v for k, v in phases.items() if k in kernel_of}
@@ -164,7 +165,7 @@ def main():
         # two live events bracket (it is, unless the untimed breakdown says another phase is longer)
         acc_ms = live.get(dom, cand.get(dom, float("nan"))) if dom else float("nan")
         timed_live = dom in live
-        if dom in ("accumulate", "hist", "scatter"):
+        if dom in ("accumulate", "hist", "scatter", "level1", "level2"):
             alg_bytes = BYTES_PER_POINT * n
         elif dom == "bucket_build":
             alg_bytes = BYTES_PER_POINT * n + BYTES_PER_NODE * nodes
@@ -210,7 +211,7 @@ def main():
             ref = parity.ref_from_cloud(small, P)
             _, o = parity.gpu_from_cloud(small, P, device=local)
             out["check"] = parity.compare(o, ref)["ok"]
-        if a.stamps and m.last_strategy() == 2:
+        if a.stamps and m.last_strategy() in (2, 3):
             os.environ["GNDT_STAMPS"] = "1"
             m.create2DMap("slope", pts, stream)
             cyc, nb = m.debug_bucket_phases()

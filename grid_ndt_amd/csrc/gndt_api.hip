@@ -74,6 +74,11 @@ struct gndt_handle {
     // strategy PARTITION buffers (gndt_partition.hpp)
     struct Part {
         uint64_t rec_cap = 0;      float4* recs = nullptr;
+        // two-level partition: level-1 regions, cursors of both levels, record ranges of the fine buckets
+        uint64_t rec1_cap = 0;     float4* recs1 = nullptr;
+        uint64_t cur_cap = 0;      uint32_t *cursors = nullptr, *range_lo = nullptr, *range_hi = nullptr;
+        bool two_level_ok = true;  // cleared when the regions a cloud needs are too large: exact path from then on
+        double fill1_ratio = 0.0, fill2_ratio = 0.0;   // fullest region / mean region seen on this handle (0 = unknown)
         uint64_t hist_cap = 0;     uint32_t* hist = nullptr;
         uint32_t bucket_cap = 0;   uint32_t* totals = nullptr; uint32_t* bucket_base = nullptr;
         uint64_t stage_cap = 0;    StageRow* stage = nullptr;
@@ -117,6 +122,8 @@ struct gndt_handle {
         hipStream_t s = nullptr;
         int attempt = 0, bslots = 0;
         uint64_t nodes_est = 0, stage_want = 0;
+        bool two_level = false;         // this attempt used the two-level partition
+        double mean1 = 0.0, mean2 = 0.0;  // its mean region fills (to turn the fullest region into a ratio)
         bool stats_only = false;        // gndt_shard_stats_device: statistics out, no labels / ordering / rows
         uint32_t first_base = 0;        // global index of xyz[0] (shards of a global cloud)
     } pending;
@@ -138,7 +145,7 @@ namespace {
 inline void mark(gndt_handle* h, int i, hipStream_t s) {
     if (!h->prof || !h->ev[h->ev_set][i]) return;
     if (h->prof == 2) {   // k_bucket_build2 sits between marks 4 and 5, k_accumulate between 1 and 2
-        const int lo = h->last_strategy == GNDT_STRATEGY_PARTITION ? 4 : 1;
+        const int lo = h->last_strategy != GNDT_STRATEGY_ATOMIC ? 4 : 1;
         if (i != lo && i != lo + 1) return;
     }
     (void)hipEventRecord(h->ev[h->ev_set][i], s);
@@ -283,7 +290,7 @@ void free_cost(gndt_handle* h) {
 
 void free_part(gndt_handle* h) {
     auto& q = h->part;
-    void* ptrs[] = {q.recs, q.hist, q.totals, q.bucket_base, q.stage, q.ord_cf, q.ord_idx, q.ord_ncol, q.col_rank,
+    void* ptrs[] = {q.recs, q.recs1, q.cursors, q.range_lo, q.range_hi, q.hist, q.totals, q.bucket_base, q.stage, q.ord_cf, q.ord_idx, q.ord_ncol, q.col_rank,
                     q.col_size, q.col_base, q.inv, q.bsum_cols, q.bitmap, q.word_prefix, q.bsum_words, q.d_pc, q.dbg};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -552,9 +559,88 @@ int partition_launch(gndt_handle* h, gndt_handle::Pending& P) {
     // attempt 0: 512-slot tables; an overflow first doubles the table (same estimate), then raises the estimate
     int bslots = env_slots ? env_slots : (attempt == 0 ? 512 : 1024);
     uint64_t Bw = buckets_for(n, nodes_est, bslots);
-    if (!env_slots && Bw > kMaxBuckets) { bslots = 1024; Bw = buckets_for(n, nodes_est, bslots); }
-    if (Bw > kMaxBuckets) return -1;                       // too many nodes for one partition level: atomic path
+    // Two-level partition (no counting passes) for large builds; the exact single-level counting partition for small
+    // ones, when asked for (GNDT_STRATEGY_PARTITION_EXACT), and after a region overflowed once on this handle.
+    static const int env_two = getenv("GNDT_TWO_LEVEL") ? atoi(getenv("GNDT_TWO_LEVEL")) : -1;
+    bool two = h->P.strategy != GNDT_STRATEGY_PARTITION_EXACT && q.two_level_ok &&
+               (n >= (1u << 20) || h->P.strategy == GNDT_STRATEGY_PARTITION_TWO_LEVEL) &&
+               Bw <= (uint64_t)kMaxFan * kMaxFan;
+    if (env_two == 0) two = false;
+    if (!two) {
+        if (!env_slots && Bw > kMaxBuckets) { bslots = 1024; Bw = buckets_for(n, nodes_est, bslots); }
+        if (Bw > kMaxBuckets) return -1;                   // too many nodes for one partition level: atomic path
+    }
     const uint32_t B = (uint32_t)Bw;
+    P.two_level = two;
+    h->last_strategy = two ? GNDT_STRATEGY_PARTITION : GNDT_STRATEGY_PARTITION_EXACT;
+    stage_want = std::max<uint64_t>(stage_want, nodes_est + nodes_est / 8);
+    if (P.stats_only) {
+        if ((rc = ensure_stats_buffers(h, stage_want))) return rc;
+    } else {
+        if ((rc = ensure_stage(h, stage_want))) return rc;
+        if ((rc = ensure_out(h, q.stage_cap))) return rc;
+    }
+    const uint32_t* range_lo = nullptr;
+    const uint32_t* range_hi = nullptr;
+    const float4* bucket_recs = nullptr;
+    if (two) {
+        uint32_t F1 = 1;
+        while ((uint64_t)F1 * F1 < B) ++F1;                // fan-out ~ sqrt(B) per level, <= kMaxFan
+        const uint32_t F2 = (B + F1 - 1) / F1;
+        F1 = (B + F2 - 1) / F2;
+        // Fixed region capacities: 2x the mean for the (large) coarse regions, 6x + 1024 for a bucket, or what the
+        // fullest region of an earlier build on this handle needed (+25 %): LiDAR clouds load the columns near the
+        // sensor far above the average.  HBM is plentiful and only touched lines cost, but past 24 records of
+        // capacity per point the exact counting partition is the better deal.
+        const double r1 = std::max(2.0, q.fill1_ratio * 1.25), r2 = std::max(6.0, q.fill2_ratio * 1.25);
+        const uint64_t cap1w = (uint64_t)(r1 * (double)(n / F1)) + 2 * kTile;
+        const uint64_t cap2w = (uint64_t)(r2 * (double)(n / B)) + 1024;
+        if ((uint64_t)F1 * cap1w > 4 * (uint64_t)n + (1u << 22) || (uint64_t)B * cap2w > 24 * (uint64_t)n + (1u << 24) ||
+            (uint64_t)B * cap2w >= 0xF0000000ull) {
+            q.two_level_ok = false;
+            return partition_launch(h, P);                 // (re-enters on the exact path)
+        }
+        const uint32_t cap1 = (uint32_t)cap1w, cap2 = (uint32_t)cap2w;
+        P.mean1 = (double)(n / F1); P.mean2 = (double)(n / B);
+        if ((rc = grow_buf(h, q.recs1, q.rec1_cap, (uint64_t)F1 * cap1))) return rc;
+        if ((rc = grow_buf(h, q.recs, q.rec_cap, (uint64_t)B * cap2))) return rc;
+        if (B > q.cur_cap) {
+            for (uint32_t** a : {&q.cursors, &q.range_lo, &q.range_hi}) { if (*a) (void)hipFree(*a); *a = nullptr; }
+            q.cur_cap = 0;
+            const uint64_t c = (uint64_t)B + B / 4;
+            HIP_TRY(h, hipMalloc(&q.cursors, ((size_t)kMaxFan + c) * 4));      // [kMaxFan] level 1, then [c] level 2
+            HIP_TRY(h, hipMalloc(&q.range_lo, c * 4));
+            HIP_TRY(h, hipMalloc(&q.range_hi, c * 4));
+            q.cur_cap = c;
+        }
+        uint32_t* cursor1 = q.cursors;
+        uint32_t* cursor2 = q.cursors + kMaxFan;
+        mark(h, 0, s);
+        if (h->table_dirty) { if ((rc = do_reset(h, s))) return rc; }
+        h->results_valid = false;
+        hipLaunchKernelGGL(k_part_clear, dim3(grid_for(words, 256, 512)), dim3(256), 0, s, h->d_cnt, q.d_pc, q.bitmap, (uint64_t)words);
+        HIP_TRY(h, hipMemsetAsync(q.cursors, 0, ((size_t)kMaxFan + B) * 4, s));
+        HIP_TRY(h, hipGetLastError());
+        mark(h, 1, s);
+        const uint32_t tiles1 = (uint32_t)((n + kTile - 1) / kTile);
+        if (stride_bytes == 12)
+            hipLaunchKernelGGL(k_part2_level1<3>, dim3(tiles1), dim3(kTileThreads), 0, s, p, (uint64_t)n, P.first_base, gp, B, F1, F2,
+                               cursor1, cap1, q.recs1, h->d_cnt, q.d_pc);
+        else
+            hipLaunchKernelGGL(k_part2_level1<4>, dim3(tiles1), dim3(kTileThreads), 0, s, p, (uint64_t)n, P.first_base, gp, B, F1, F2,
+                               cursor1, cap1, q.recs1, h->d_cnt, q.d_pc);
+        HIP_TRY(h, hipGetLastError());
+        mark(h, 2, s);
+        mark(h, 3, s);
+        hipLaunchKernelGGL(k_part2_level2, dim3((cap1 + kTile - 1) / kTile, F1), dim3(kTileThreads), 0, s, q.recs1, cursor1, cap1, gp,
+                           B, F2, cursor2, cap2, q.recs, q.d_pc);
+        hipLaunchKernelGGL(k_part2_ranges, dim3(grid_for(B, 256, 64)), dim3(256), 0, s, cursor1, F1, cursor2, cap2, B, q.range_lo,
+                           q.range_hi, q.d_pc);
+        HIP_TRY(h, hipGetLastError());
+        mark(h, 4, s);
+        range_lo = q.range_lo; range_hi = q.range_hi;
+    } else {
+    if ((rc = grow_buf(h, q.recs, q.rec_cap, n))) return rc;
     if ((rc = grow_buf(h, q.hist, q.hist_cap, (uint64_t)nwg * B))) return rc;
     if (B > q.bucket_cap) {
         if (q.totals) (void)hipFree(q.totals);
@@ -563,13 +649,6 @@ int partition_launch(gndt_handle* h, gndt_handle::Pending& P) {
         HIP_TRY(h, hipMalloc(&q.totals, (size_t)B * 4));
         HIP_TRY(h, hipMalloc(&q.bucket_base, ((size_t)B + 1) * 4));
         q.bucket_cap = B;
-    }
-    stage_want = std::max<uint64_t>(stage_want, nodes_est + nodes_est / 8);
-    if (P.stats_only) {
-        if ((rc = ensure_stats_buffers(h, stage_want))) return rc;
-    } else {
-        if ((rc = ensure_stage(h, stage_want))) return rc;
-        if ((rc = ensure_out(h, q.stage_cap))) return rc;
     }
     mark(h, 0, s);
     // the HBM node table is not used by this strategy, but a previous atomic build may sit in it
@@ -602,6 +681,9 @@ int partition_launch(gndt_handle* h, gndt_handle::Pending& P) {
                            q.totals, q.bucket_base, q.recs);
     HIP_TRY(h, hipGetLastError());
     mark(h, 4, s);
+    range_lo = q.bucket_base; range_hi = q.bucket_base + 1;
+    }
+    bucket_recs = q.recs;
     if (getenv("GNDT_STAMPS") && q.dbg_buckets < B) {
         if (q.dbg) (void)hipFree(q.dbg);
         q.dbg = nullptr; q.dbg_buckets = 0;
@@ -612,7 +694,7 @@ int partition_launch(gndt_handle* h, gndt_handle::Pending& P) {
     q.last_buckets = B;
     {
 #define GNDT_LAUNCH_BUCKET2(T_, H_, CH_, S_)                                                                           \
-    hipLaunchKernelGGL((k_bucket_build2<T_, H_, CH_, S_>), dim3(B), dim3(T_), 0, s, q.recs, q.bucket_base, gp, q.stage, \
+    hipLaunchKernelGGL((k_bucket_build2<T_, H_, CH_, S_>), dim3(B), dim3(T_), 0, s, bucket_recs, range_lo, range_hi, gp, q.stage, \
                        (uint32_t)(S_ ? h->st_cap : q.stage_cap), q.ord_cf, q.ord_idx, q.ord_ncol, q.bitmap, h->d_cnt,   \
                        q.d_pc, q.dbg, StatsOut{h->st_key, h->st_sums, h->st_count, h->st_first})
             if (P.stats_only) {
@@ -643,7 +725,6 @@ int partition_begin(gndt_handle* h, const void* xyz_dev, size_t n, size_t stride
     if (stride_bytes != 12 && stride_bytes != 16) { h->err = "stride_bytes must be 12 or 16"; return GNDT_ERR_INVALID; }
     if (n >= 0x7FFFFFFFull) return -1;   // bit 31 of the record index word carries the weight flag: atomic path beyond 2^31 points
     int rc;
-    if ((rc = grow_buf(h, q.recs, q.rec_cap, n))) return rc;
     if ((rc = ensure_words(h, (n + 31) / 32 + 1))) return rc;
     if ((rc = ensure_part_counters(h))) return rc;
     auto& P = h->pending;
@@ -676,7 +757,17 @@ int partition_resolve(gndt_handle* h) {
     for (;;) {
         if (hipStreamSynchronize(P.s) != hipSuccess) { P.active = false; h->err = "hipStreamSynchronize failed"; return GNDT_ERR_HIP; }
         bool again = false;
-        if (q.h_pc->lds_overflow) {                            // some bucket holds too many nodes for its LDS table:
+        if (P.two_level && P.mean1 > 0 && P.mean2 > 0) {       // remember how uneven this handle's latest cloud was
+            q.fill1_ratio = q.h_pc->max_fill1 / P.mean1;      // (the latest build: bucket counts change between attempts)
+            q.fill2_ratio = q.h_pc->max_fill2 / P.mean2;
+            if (getenv("GNDT_VERBOSE"))
+                fprintf(stderr, "[gndt] two-level partition: fullest coarse region %.2fx the mean, fullest bucket %.2fx, overflow %u\n",
+                        q.h_pc->max_fill1 / P.mean1, q.h_pc->max_fill2 / P.mean2, q.h_pc->part_overflow);
+        }
+        if (q.h_pc->part_overflow) {                           // a fixed-capacity region of the two-level partition was too
+            --P.attempt;                                       // small: same table size and estimate again, regions sized
+            again = true;                                      // from the fullest one (or the exact path if that is too much)
+        } else if (q.h_pc->lds_overflow) {                            // some bucket holds too many nodes for its LDS table:
             if (P.attempt >= 1 || env_slots) P.nodes_est *= 2;   // (attempt 0 -> 1 only switches to the 1024-slot table)
             again = true;
         } else if (q.h_pc->stage_overflow) {                   // num_nodes kept counting: it is the true total
@@ -871,7 +962,7 @@ int gndt_build_device(gndt_handle* h, const void* xyz_dev, size_t n, size_t stri
     next_event_set(h);
     int strategy = h->P.strategy;
     if (strategy == GNDT_STRATEGY_AUTO) strategy = (n >= (1u << 16)) ? GNDT_STRATEGY_PARTITION : GNDT_STRATEGY_ATOMIC;
-    if (strategy == GNDT_STRATEGY_PARTITION) {
+    if (strategy == GNDT_STRATEGY_PARTITION || strategy == GNDT_STRATEGY_PARTITION_EXACT || strategy == GNDT_STRATEGY_PARTITION_TWO_LEVEL) {
         // launched, not awaited: gndt_sync / gndt_export* (or whatever needs the result next) waits, checks the
         // overflow flags and re-runs with more room if needed.  xyz_dev stays the caller's until then.
         rc = partition_begin(h, xyz_dev, n, stride_bytes, s);
@@ -1121,7 +1212,6 @@ int gndt_shard_stats_device(gndt_handle* h, const void* xyz_dev, size_t n, size_
     rc = -1;
     if (n >= (1u << 12) && h->P.strategy != GNDT_STRATEGY_ATOMIC && stride_bytes != 0) {
         auto& q = h->part;
-        if ((rc = grow_buf(h, q.recs, q.rec_cap, n))) return rc;
         if ((rc = ensure_words(h, (n + 31) / 32 + 1))) return rc;
         if ((rc = ensure_part_counters(h))) return rc;
         auto& P = h->pending;

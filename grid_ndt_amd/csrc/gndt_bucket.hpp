@@ -63,7 +63,8 @@ struct StatsOut {
 // STATS = true : they leave as additive statistics (key, 9 sums, count, first index) and nothing else is done:
 //                the shard's contribution to a global map (gndt_shard_stats_device).
 template <int T, int H, int CH, bool STATS = false>
-__global__ void __launch_bounds__(T) k_bucket_build2(const float4* __restrict__ recs, const uint32_t* __restrict__ bucket_base,
+__global__ void __launch_bounds__(T) k_bucket_build2(const float4* __restrict__ recs, const uint32_t* __restrict__ range_lo,
+                                                     const uint32_t* __restrict__ range_hi,
                                                      GridParams P, StageRow* __restrict__ stage, uint32_t stage_cap,
                                                      uint32_t* __restrict__ ord_cf, uint32_t* __restrict__ ord_idx,
                                                      uint32_t* __restrict__ ord_ncol, uint32_t* __restrict__ bitmap,
@@ -89,7 +90,7 @@ __global__ void __launch_bounds__(T) k_bucket_build2(const float4* __restrict__ 
     __syncthreads();
     GNDT_STAMP(1);
 
-    const uint32_t lo = bucket_base[blockIdx.x], hi = bucket_base[blockIdx.x + 1];
+    const uint32_t lo = range_lo[blockIdx.x], hi = range_hi[blockIdx.x];   // exact path: bucket_base[b], bucket_base[b+1]
     for (uint32_t cbeg = lo; cbeg < hi; cbeg += CH) {
         const uint32_t nchunk = min((uint32_t)CH, hi - cbeg);
         // ---- A: classify ----

@@ -37,7 +37,10 @@ struct PartCounters {
     uint32_t lds_overflow;     // buckets whose node table overflowed
     uint32_t stage_overflow;   // nodes that did not fit the staging rows
     uint32_t index_overflow;   // column-first indices beyond the bitmap (table path: stream ran past max_points_hint)
-    uint32_t pad;
+    uint32_t part_overflow;    // two-level partition: reservations beyond a region's fixed capacity
+    uint32_t max_fill1;        // two-level partition: fullest coarse region / fullest bucket (true counts, also when
+    uint32_t max_fill2;        //   they exceed the capacity: the host sizes the retry from them)
+    uint32_t pad[2];
 };
 
 struct alignas(16) StageRow {   // 128 bytes = two 64-B lines, gathered whole by k_emit_rows
@@ -93,7 +96,8 @@ __global__ void __launch_bounds__(256) k_part_clear(Counters* __restrict__ cnt, 
                                                     uint32_t* __restrict__ bitmap, uint64_t words) {
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         cnt->num_nodes = 0; cnt->num_columns = 0; cnt->num_slopes = 0; cnt->err_key_range = 0; cnt->err_table_full = 0;
-        pc->lds_overflow = 0; pc->stage_overflow = 0; pc->index_overflow = 0;
+        pc->lds_overflow = 0; pc->stage_overflow = 0; pc->index_overflow = 0; pc->part_overflow = 0;
+        pc->max_fill1 = 0; pc->max_fill2 = 0;
     }
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < words; i += (uint64_t)gridDim.x * blockDim.x) bitmap[i] = 0u;
 }
@@ -222,6 +226,162 @@ __global__ void __launch_bounds__(kPartThreads) k_part_scatter(const float* __re
 }
 
 // ---------------------------------------------------------------------------------------------
+// Two-level partition without counting passes (large builds).
+//
+// The single-level scatter above writes 16-B records to ~B = thousands of places at once: every store is its own
+// memory transaction (~50 G/s on MI355X), lines leave L2 half-written, and a histogram pass over the cloud has to
+// come first.  Here a record moves twice, each time through an LDS tile sort with a fan-out of at most 256:
+//   level 1  cloud tile (4096 points)   -> F1 coarse buckets (coarse = fine bucket / F2)
+//   level 2  coarse-bucket tile          -> its F2 fine buckets
+// A tile counts its digits in LDS, reserves space with ONE memory-side atomic per digit and tile, sorts the tile in
+// LDS by digit and copies it out so that consecutive lanes write consecutive records (runs of 4096/F records,
+// full lines).  Regions have a fixed capacity (cloud-independent layout, no histogram, no offsets pass): level-1
+// region c starts at c*cap1, fine bucket b at b*cap2; the fill comes from the cursors.  A region that would
+// overflow raises PartCounters::part_overflow and the host re-runs the build on the exact counting path.
+// Record order inside a bucket depends on the order in which tiles reserve; nothing downstream depends on it.
+// ---------------------------------------------------------------------------------------------
+constexpr int kTileThreads = 512;
+constexpr int kTilePer = 8;
+constexpr int kTile = kTileThreads * kTilePer;      // 4096 records = 64 KB of LDS
+constexpr int kMaxFan = 256;
+
+struct TileLds {
+    float4 rec[kTile];
+    uint32_t hist[kMaxFan];
+    uint32_t scan[kMaxFan + 1];
+    uint32_t gbase[kMaxFan];
+    uint32_t wave_tot[kTileThreads / 64];
+};
+
+// r[j] / dig[j]: this thread's records and their digits (0xFFFFFFFF = no record).  Region of digit d starts at
+// out[region0 + d * region_stride] and holds `cap` records; cursor[d] counts what is reserved in it.
+__device__ __forceinline__ void tile_partition(TileLds& L, const float4 (&r)[kTilePer], const uint32_t (&dig)[kTilePer],
+                                               uint32_t nd, uint32_t* __restrict__ cursor, uint32_t cap, uint64_t region0,
+                                               uint64_t region_stride, float4* __restrict__ out,
+                                               PartCounters* __restrict__ pc) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (uint32_t d = tid; d < nd; d += kTileThreads) L.hist[d] = 0u;
+    __syncthreads();
+    uint32_t rank[kTilePer];
+#pragma unroll
+    for (int j = 0; j < kTilePer; ++j) rank[j] = (dig[j] != 0xFFFFFFFFu) ? atomicAdd(&L.hist[dig[j]], 1u) : 0u;
+    __syncthreads();
+    // reserve space (one memory-side atomic per digit present in the tile) and scan the tile's counts
+    uint32_t c = 0;
+    if ((uint32_t)tid < nd) {
+        c = L.hist[tid];
+        uint32_t g = 0;
+        if (c) {
+            g = atomicAdd(&cursor[tid], c);
+            if (g + c > cap) atomicAdd(&pc->part_overflow, 1u);
+        }
+        L.gbase[tid] = g;
+    }
+    uint32_t incl = c;
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)incl, o, 64); if (lane >= o) incl += t; }
+    if (lane == 63) L.wave_tot[wave] = incl;
+    __syncthreads();
+    if ((uint32_t)tid < nd) {
+        uint32_t base = incl - c;
+        for (int w = 0; w < wave; ++w) base += L.wave_tot[w];
+        L.scan[tid] = base;
+        if ((uint32_t)tid == nd - 1) L.scan[nd] = base + c;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < kTilePer; ++j)
+        if (dig[j] != 0xFFFFFFFFu) L.rec[L.scan[dig[j]] + rank[j]] = r[j];
+    __syncthreads();
+    const uint32_t total = L.scan[nd];
+    for (uint32_t j = tid; j < total; j += kTileThreads) {
+        uint32_t lo = 0, hi = nd;                       // digit of sorted slot j: last d with scan[d] <= j
+        while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (L.scan[mid] <= j) lo = mid; else hi = mid; }
+        const uint32_t within = L.gbase[lo] + (j - L.scan[lo]);
+        if (within < cap) out[region0 + (uint64_t)lo * region_stride + within] = L.rec[j];
+    }
+}
+
+// level 1: the cloud -> coarse regions.  One tile per workgroup.
+template <int STRIDE_FLOATS>
+__global__ void __launch_bounds__(kTileThreads) k_part2_level1(const float* __restrict__ xyz, uint64_t n, uint32_t first_base,
+                                                               GridParams P, uint32_t B, uint32_t F1, uint32_t F2,
+                                                               uint32_t* __restrict__ cursor1, uint32_t cap1,
+                                                               float4* __restrict__ recs1, Counters* __restrict__ cnt,
+                                                               PartCounters* __restrict__ pc) {
+    __shared__ TileLds L;
+    const uint64_t t0 = (uint64_t)blockIdx.x * kTile;
+    float4 r[kTilePer];
+    uint32_t dig[kTilePer];
+#pragma unroll
+    for (int j = 0; j < kTilePer; ++j) {
+        const uint64_t i = t0 + (uint64_t)j * kTileThreads + threadIdx.x;    // a wave holds 64 consecutive points
+        const bool live = i < n;
+        float px = 0.f, py = 0.f, pz = 0.f;
+        if (live) { const float* p = xyz + i * STRIDE_FLOATS; px = p[0]; py = p[1]; pz = p[2]; }
+        const PointKey k = point_key(px, py, pz, P.ox, P.oy, P.oz, P.grid_len, P.z_len);
+        if (live && !k.ok) atomicAdd(&cnt->err_key_range, 1u);
+        const bool use = live && k.ok;
+        const bool same = wave_all_identical(px, py, pz, use);               // 64 identical points -> one weighted record
+        dig[j] = 0xFFFFFFFFu;
+        if (use && (!same || (threadIdx.x & 63) == 0)) {
+            dig[j] = bucket_of(column_hash(k.sx, k.sy), B) / F2;
+            const uint32_t idx = (first_base + (uint32_t)i) | (same ? kWeight64Flag : 0u);
+            r[j] = make_float4(px, py, pz, __uint_as_float(idx));
+        }
+    }
+    tile_partition(L, r, dig, F1, cursor1, cap1, 0ull, (uint64_t)cap1, recs1, pc);
+}
+
+// level 2: coarse region blockIdx.y, tile blockIdx.x of it -> the fine buckets of that region
+__global__ void __launch_bounds__(kTileThreads) k_part2_level2(const float4* __restrict__ recs1, const uint32_t* __restrict__ cursor1,
+                                                               uint32_t cap1, GridParams P, uint32_t B, uint32_t F2,
+                                                               uint32_t* __restrict__ cursor2, uint32_t cap2,
+                                                               float4* __restrict__ recs2, PartCounters* __restrict__ pc) {
+    __shared__ TileLds L;
+    const uint32_t c = blockIdx.y;
+    const uint32_t have = min(cursor1[c], cap1);
+    const uint32_t t0 = blockIdx.x * kTile;
+    if (t0 >= have) return;
+    const uint32_t b0 = c * F2, nd = min(F2, B - b0);
+    const float4* src = recs1 + (uint64_t)c * cap1;
+    float4 r[kTilePer];
+    uint32_t dig[kTilePer];
+#pragma unroll
+    for (int j = 0; j < kTilePer; ++j) {
+        const uint32_t i = t0 + (uint32_t)j * kTileThreads + threadIdx.x;
+        dig[j] = 0xFFFFFFFFu;
+        if (i < have) {
+            r[j] = src[i];
+            const PointKey k = point_key(r[j].x, r[j].y, r[j].z, P.ox, P.oy, P.oz, P.grid_len, P.z_len);
+            dig[j] = bucket_of(column_hash(k.sx, k.sy), B) - b0;
+        }
+    }
+    tile_partition(L, r, dig, nd, cursor2 + b0, cap2, (uint64_t)b0 * cap2, (uint64_t)cap2, recs2, pc);
+}
+
+// the fine buckets' record ranges for the bucket kernel, and the fullest region of either level
+__global__ void __launch_bounds__(256) k_part2_ranges(const uint32_t* __restrict__ cursor1, uint32_t F1,
+                                                      const uint32_t* __restrict__ cursor2, uint32_t cap2, uint32_t B,
+                                                      uint32_t* __restrict__ lo, uint32_t* __restrict__ hi,
+                                                      PartCounters* __restrict__ pc) {
+    __shared__ uint32_t m1, m2;
+    if (threadIdx.x == 0) { m1 = 0; m2 = 0; }
+    __syncthreads();
+    uint32_t a = 0, b2 = 0;
+    for (uint32_t b = blockIdx.x * blockDim.x + threadIdx.x; b < B; b += gridDim.x * blockDim.x) {
+        const uint32_t c = cursor2[b];
+        lo[b] = b * cap2;
+        hi[b] = b * cap2 + min(c, cap2);
+        b2 = max(b2, c);
+        if (b < F1) a = max(a, cursor1[b]);
+    }
+    if (a) atomicMax(&m1, a);
+    if (b2) atomicMax(&m2, b2);
+    __syncthreads();
+    if (threadIdx.x == 0) { if (m1) atomicMax(&pc->max_fill1, m1); if (m2) atomicMax(&pc->max_fill2, m2); }
+}
+
+// ---------------------------------------------------------------------------------------------
 // pass 3: one workgroup per bucket
 // ---------------------------------------------------------------------------------------------
 // LDS open-addressing helpers.  They take the __shared__ arrays by reference to their element type's
@@ -339,7 +499,7 @@ __global__ void __launch_bounds__(kBlock) k_order_rank(const uint32_t* __restric
                                                        const uint32_t* __restrict__ bitmap, const uint32_t* __restrict__ word_prefix,
                                                        uint32_t* __restrict__ col_rank, uint32_t* __restrict__ col_size,
                                                        const Counters* __restrict__ cnt, const PartCounters* __restrict__ pc) {
-    if (pc->lds_overflow | pc->stage_overflow | pc->index_overflow) return;   // the host re-runs the build; staged rows are incomplete
+    if (pc->lds_overflow | pc->stage_overflow | pc->index_overflow | pc->part_overflow) return;   // the host re-runs the build; staged rows are incomplete
     const uint32_t n = cnt->num_nodes;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const uint32_t cf = ord_cf[i];
@@ -353,7 +513,7 @@ __global__ void __launch_bounds__(kBlock) k_order_rank(const uint32_t* __restric
 __global__ void __launch_bounds__(kBlock) k_order_dest(const uint32_t* __restrict__ col_rank, const uint32_t* __restrict__ ord_idx,
                                                        const uint32_t* __restrict__ col_base, uint32_t* __restrict__ inv,
                                                        const Counters* __restrict__ cnt, const PartCounters* __restrict__ pc) {
-    if (pc->lds_overflow | pc->stage_overflow | pc->index_overflow) return;
+    if (pc->lds_overflow | pc->stage_overflow | pc->index_overflow | pc->part_overflow) return;
     const uint32_t n = cnt->num_nodes;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
         inv[col_base[col_rank[i]] + ord_idx[i]] = i;
@@ -363,7 +523,7 @@ __global__ void __launch_bounds__(kBlock) k_order_dest(const uint32_t* __restric
 __global__ void __launch_bounds__(kBlock) k_emit_rows(const StageRow* __restrict__ stage, const uint32_t* __restrict__ inv,
                                                       OutView out, const Counters* __restrict__ cnt,
                                                       const PartCounters* __restrict__ pc) {
-    if (pc->lds_overflow | pc->stage_overflow | pc->index_overflow) return;
+    if (pc->lds_overflow | pc->stage_overflow | pc->index_overflow | pc->part_overflow) return;
     const uint32_t n = cnt->num_nodes;
     for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x) {
         const StageRow row = stage[inv[r]];

@@ -26,7 +26,7 @@ struct TableView {
 __global__ void __launch_bounds__(kBlock) k_tab_begin(TableView T, Counters* __restrict__ cnt, PartCounters* __restrict__ pc,
                                                       uint32_t* __restrict__ bitmap, uint64_t words) {
     const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, gsz = (uint64_t)gridDim.x * blockDim.x;
-    if (gid == 0) { cnt->num_columns = 0; cnt->num_slopes = 0; pc->lds_overflow = 0; pc->stage_overflow = 0; pc->index_overflow = 0; }
+    if (gid == 0) { cnt->num_columns = 0; cnt->num_slopes = 0; pc->lds_overflow = 0; pc->stage_overflow = 0; pc->index_overflow = 0; pc->part_overflow = 0; }
     for (uint64_t i = gid; i < words; i += gsz) bitmap[i] = 0u;
     const uint32_t np = cnt->prev_nodes;
     for (uint64_t i = gid; i < np; i += gsz) {

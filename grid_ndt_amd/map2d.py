@@ -232,15 +232,16 @@ class TwoDmap:
 
     # ---- phase timing ----
     PHASES = {1: ("clear", "accumulate", "columns", "rows", "bitmap_scan", "rank", "column_scan", "dest", "emit"),
-              2: ("clear", "hist", "offsets", "scatter", "bucket_build", "bitmap_scan", "rank", "column_scan", "dest", "emit")}
-    STRATEGY_NAMES = {1: "atomic", 2: "partition"}
+              2: ("clear", "level1", "unused", "level2", "bucket_build", "bitmap_scan", "rank", "column_scan", "dest", "emit"),
+              3: ("clear", "hist", "offsets", "scatter", "bucket_build", "bitmap_scan", "rank", "column_scan", "dest", "emit")}
+    STRATEGY_NAMES = {1: "atomic", 2: "partition", 3: "partition_exact"}
 
     def set_profiling(self, on=True, demand="slope"):
         self._ensure(demand)
         self._check(self._L.gndt_set_profiling(self._h, int(on)))
 
     def last_strategy(self):
-        """1 = ATOMIC, 2 = PARTITION: what the last build actually ran."""
+        """1 = ATOMIC, 2 = PARTITION (two-level), 3 = PARTITION_EXACT: what the last build actually ran."""
         return int(self._L.gndt_last_strategy(self._h))
 
     def phase_times_ms(self):

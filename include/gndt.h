@@ -55,7 +55,10 @@ enum {
 enum {
     GNDT_STRATEGY_AUTO = 0,
     GNDT_STRATEGY_ATOMIC = 1,     /* one pass, wave-aggregated fp64 atomics into the HBM node table */
-    GNDT_STRATEGY_PARTITION = 2   /* counting partition by column tile, then LDS-resident accumulation */
+    GNDT_STRATEGY_PARTITION = 2,  /* partition by column hash, then LDS-resident accumulation; large builds use the
+                                     two-level partition without counting passes and fall back to the exact one */
+    GNDT_STRATEGY_PARTITION_EXACT = 3,      /* always the single-level counting partition (histogram + offsets + scatter) */
+    GNDT_STRATEGY_PARTITION_TWO_LEVEL = 4   /* the two-level partition whatever the size (PARTITION picks it from 2^20 points) */
 };
 
 typedef struct {
@@ -210,14 +213,15 @@ void gndt_unpack_key(uint64_t key, int32_t* sx, int32_t* sy, int32_t* sz);
  * Phase names depend on the strategy the last build used (gndt_last_strategy):
  *   ATOMIC:    [0] clear  [1] accumulate  [2] columns  [3] rows  [4] bitmap_scan  [5] rank
  *              [6] column_scan  [7] dest  [8] emit
- *   PARTITION: [0] clear  [1] hist  [2] offsets  [3] scatter  [4] bucket_build  [5] bitmap_scan
- *              [6] rank  [7] column_scan  [8] dest  [9] emit */
+ *   PARTITION_EXACT: [0] clear  [1] hist  [2] offsets  [3] scatter  [4] bucket_build  [5] bitmap_scan
+ *              [6] rank  [7] column_scan  [8] dest  [9] emit
+ *   PARTITION (two-level): as PARTITION_EXACT with [1] level1  [2] (unused)  [3] level2 */
 #define GNDT_NUM_PHASES 10
 /* enable: 0 off, 1 events around every phase, 2 only around the dominant phase of the strategy in use
  * (bucket_build / accumulate): two events per build instead of eleven. */
 int gndt_set_profiling(gndt_handle* h, int enable);
 int gndt_get_phase_times(gndt_handle* h, double ms_out[GNDT_NUM_PHASES]);
-/* GNDT_STRATEGY_ATOMIC or GNDT_STRATEGY_PARTITION: what the last build actually ran (AUTO resolves,
+/* GNDT_STRATEGY_ATOMIC, _PARTITION (two-level) or _PARTITION_EXACT: what the last build actually ran (AUTO resolves,
  * and PARTITION falls back to ATOMIC when a bucket does not fit in LDS). */
 int gndt_last_strategy(const gndt_handle* h);
 /* Diagnostic (not for timed runs): with the environment variable GNDT_STAMPS=1 set, k_bucket_build

@@ -37,7 +37,7 @@ def _check(m, cloud, P, goal, demand, robot):
 
 
 @pytest.mark.parametrize("demand", ["slope", "true"])
-@pytest.mark.parametrize("strategy", [1, 2])
+@pytest.mark.parametrize("strategy", [1, 3, 4])
 def test_cost_map_equals_reference_flood(demand, strategy):
     cloud = scenes.drivable_site()
     P = scenes.COST_PARAMS
