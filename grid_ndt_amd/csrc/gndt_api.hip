@@ -592,17 +592,20 @@ int partition_launch(gndt_handle* h, gndt_handle::Pending& P) {
         // fullest region of an earlier build on this handle needed (+25 %): LiDAR clouds load the columns near the
         // sensor far above the average.  HBM is plentiful and only touched lines cost, but past 24 records of
         // capacity per point the exact counting partition is the better deal.
+        const uint32_t R = std::max<uint32_t>(1, std::min<uint32_t>(8, kMaxFan / F1));   // sub-regions per coarse region
+        const uint32_t V = F1 * R;
+        constexpr uint64_t kTile1 = (uint64_t)kTileThreads * kTilePer1, kTile2 = (uint64_t)kTileThreads * kTilePer2;
         const double r1 = std::max(2.0, q.fill1_ratio * 1.25), r2 = std::max(6.0, q.fill2_ratio * 1.25);
-        const uint64_t cap1w = (uint64_t)(r1 * (double)(n / F1)) + 2 * kTile;
+        const uint64_t cap1w = (uint64_t)(r1 * (double)(n / V)) + 2 * kTile1;
         const uint64_t cap2w = (uint64_t)(r2 * (double)(n / B)) + 1024;
-        if ((uint64_t)F1 * cap1w > 4 * (uint64_t)n + (1u << 22) || (uint64_t)B * cap2w > 24 * (uint64_t)n + (1u << 24) ||
+        if ((uint64_t)V * cap1w > 4 * (uint64_t)n + (1u << 24) || (uint64_t)B * cap2w > 24 * (uint64_t)n + (1u << 24) ||
             (uint64_t)B * cap2w >= 0xF0000000ull) {
             q.two_level_ok = false;
             return partition_launch(h, P);                 // (re-enters on the exact path)
         }
         const uint32_t cap1 = (uint32_t)cap1w, cap2 = (uint32_t)cap2w;
-        P.mean1 = (double)(n / F1); P.mean2 = (double)(n / B);
-        if ((rc = grow_buf(h, q.recs1, q.rec1_cap, (uint64_t)F1 * cap1))) return rc;
+        P.mean1 = (double)(n / V); P.mean2 = (double)(n / B);
+        if ((rc = grow_buf(h, q.recs1, q.rec1_cap, (uint64_t)V * cap1))) return rc;
         if ((rc = grow_buf(h, q.recs, q.rec_cap, (uint64_t)B * cap2))) return rc;
         if (B > q.cur_cap) {
             for (uint32_t** a : {&q.cursors, &q.range_lo, &q.range_hi}) { if (*a) (void)hipFree(*a); *a = nullptr; }
@@ -618,23 +621,23 @@ int partition_launch(gndt_handle* h, gndt_handle::Pending& P) {
         mark(h, 0, s);
         if (h->table_dirty) { if ((rc = do_reset(h, s))) return rc; }
         h->results_valid = false;
-        hipLaunchKernelGGL(k_part_clear, dim3(grid_for(words, 256, 512)), dim3(256), 0, s, h->d_cnt, q.d_pc, q.bitmap, (uint64_t)words);
-        HIP_TRY(h, hipMemsetAsync(q.cursors, 0, ((size_t)kMaxFan + B) * 4, s));
+        hipLaunchKernelGGL(k_part_clear, dim3(grid_for(words, 256, 512)), dim3(256), 0, s, h->d_cnt, q.d_pc, q.bitmap, (uint64_t)words,
+                           q.cursors, (uint32_t)(kMaxFan + B));
         HIP_TRY(h, hipGetLastError());
         mark(h, 1, s);
-        const uint32_t tiles1 = (uint32_t)((n + kTile - 1) / kTile);
+        const uint32_t tiles1 = (uint32_t)((n + kTile1 - 1) / kTile1);
         if (stride_bytes == 12)
-            hipLaunchKernelGGL(k_part2_level1<3>, dim3(tiles1), dim3(kTileThreads), 0, s, p, (uint64_t)n, P.first_base, gp, B, F1, F2,
+            hipLaunchKernelGGL(k_part2_level1<3>, dim3(tiles1), dim3(kTileThreads), 0, s, p, (uint64_t)n, P.first_base, gp, B, F1, F2, R,
                                cursor1, cap1, q.recs1, h->d_cnt, q.d_pc);
         else
-            hipLaunchKernelGGL(k_part2_level1<4>, dim3(tiles1), dim3(kTileThreads), 0, s, p, (uint64_t)n, P.first_base, gp, B, F1, F2,
+            hipLaunchKernelGGL(k_part2_level1<4>, dim3(tiles1), dim3(kTileThreads), 0, s, p, (uint64_t)n, P.first_base, gp, B, F1, F2, R,
                                cursor1, cap1, q.recs1, h->d_cnt, q.d_pc);
         HIP_TRY(h, hipGetLastError());
         mark(h, 2, s);
         mark(h, 3, s);
-        hipLaunchKernelGGL(k_part2_level2, dim3((cap1 + kTile - 1) / kTile, F1), dim3(kTileThreads), 0, s, q.recs1, cursor1, cap1, gp,
-                           B, F2, cursor2, cap2, q.recs, q.d_pc);
-        hipLaunchKernelGGL(k_part2_ranges, dim3(grid_for(B, 256, 64)), dim3(256), 0, s, cursor1, F1, cursor2, cap2, B, q.range_lo,
+        hipLaunchKernelGGL(k_part2_level2, dim3((uint32_t)((cap1 + kTile2 - 1) / kTile2), V), dim3(kTileThreads), 0, s, q.recs1, cursor1,
+                           cap1, R, gp, B, F2, cursor2, cap2, q.recs, q.d_pc);
+        hipLaunchKernelGGL(k_part2_ranges, dim3(grid_for(B, 256, 64)), dim3(256), 0, s, cursor1, V, cursor2, cap2, B, q.range_lo,
                            q.range_hi, q.d_pc);
         HIP_TRY(h, hipGetLastError());
         mark(h, 4, s);
@@ -654,7 +657,8 @@ int partition_launch(gndt_handle* h, gndt_handle::Pending& P) {
     // the HBM node table is not used by this strategy, but a previous atomic build may sit in it
     if (h->table_dirty) { if ((rc = do_reset(h, s))) return rc; }
     h->results_valid = false;
-    hipLaunchKernelGGL(k_part_clear, dim3(grid_for(words, 256, 512)), dim3(256), 0, s, h->d_cnt, q.d_pc, q.bitmap, (uint64_t)words);
+    hipLaunchKernelGGL(k_part_clear, dim3(grid_for(words, 256, 512)), dim3(256), 0, s, h->d_cnt, q.d_pc, q.bitmap, (uint64_t)words,
+                       (uint32_t*)nullptr, 0u);
     HIP_TRY(h, hipGetLastError());
     mark(h, 1, s);
     const size_t lds = (size_t)B * 4;
@@ -1263,7 +1267,8 @@ int gndt_finalize_stats_device(gndt_handle* h, const gndt_stats* in, uint64_t to
     if (h->table_dirty) { if ((rc = do_reset(h, s))) return rc; }
     h->results_valid = false;
     mark(h, 0, s);
-    hipLaunchKernelGGL(k_part_clear, dim3(grid_for(words, 256, 512)), dim3(256), 0, s, h->d_cnt, q.d_pc, q.bitmap, (uint64_t)words);
+    hipLaunchKernelGGL(k_part_clear, dim3(grid_for(words, 256, 512)), dim3(256), 0, s, h->d_cnt, q.d_pc, q.bitmap, (uint64_t)words,
+                       (uint32_t*)nullptr, 0u);
     HIP_TRY(h, hipGetLastError());
     mark(h, 4, s);
     hipLaunchKernelGGL(k_stats_rows, dim3(grid_for(std::max<uint64_t>(n, 1))), dim3(kBlock), 0, s, in->key, in->sums, in->count,

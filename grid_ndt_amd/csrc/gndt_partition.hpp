@@ -93,13 +93,15 @@ __device__ __forceinline__ void wg_range(uint64_t n, uint32_t nwg, uint32_t w, u
 
 // one launch that prepares a build: counters, partition flags and the column-first bitmap
 __global__ void __launch_bounds__(256) k_part_clear(Counters* __restrict__ cnt, PartCounters* __restrict__ pc,
-                                                    uint32_t* __restrict__ bitmap, uint64_t words) {
+                                                    uint32_t* __restrict__ bitmap, uint64_t words,
+                                                    uint32_t* __restrict__ cursors, uint32_t n_cursors) {
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         cnt->num_nodes = 0; cnt->num_columns = 0; cnt->num_slopes = 0; cnt->err_key_range = 0; cnt->err_table_full = 0;
         pc->lds_overflow = 0; pc->stage_overflow = 0; pc->index_overflow = 0; pc->part_overflow = 0;
         pc->max_fill1 = 0; pc->max_fill2 = 0;
     }
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < words; i += (uint64_t)gridDim.x * blockDim.x) bitmap[i] = 0u;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_cursors; i += gridDim.x * blockDim.x) cursors[i] = 0u;   // two-level partition
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -241,12 +243,14 @@ __global__ void __launch_bounds__(kPartThreads) k_part_scatter(const float* __re
 // Record order inside a bucket depends on the order in which tiles reserve; nothing downstream depends on it.
 // ---------------------------------------------------------------------------------------------
 constexpr int kTileThreads = 512;
-constexpr int kTilePer = 8;
-constexpr int kTile = kTileThreads * kTilePer;      // 4096 records = 64 KB of LDS
+constexpr int kTilePer1 = 8;       // level 1: 4096 records per tile (68 KB of LDS): fewer reservations on its few cursors
+constexpr int kTilePer2 = 4;       // level 2: 2048 records per tile (34 KB): four tiles resident per CU
 constexpr int kMaxFan = 256;
 
+template <int PER>
 struct TileLds {
-    float4 rec[kTile];
+    float4 rec[kTileThreads * PER];
+    uint8_t digit[kTileThreads * PER];   // digit of every sorted slot (kMaxFan <= 256)
     uint32_t hist[kMaxFan];
     uint32_t scan[kMaxFan + 1];
     uint32_t gbase[kMaxFan];
@@ -255,16 +259,17 @@ struct TileLds {
 
 // r[j] / dig[j]: this thread's records and their digits (0xFFFFFFFF = no record).  Region of digit d starts at
 // out[region0 + d * region_stride] and holds `cap` records; cursor[d] counts what is reserved in it.
-__device__ __forceinline__ void tile_partition(TileLds& L, const float4 (&r)[kTilePer], const uint32_t (&dig)[kTilePer],
+template <int PER>
+__device__ __forceinline__ void tile_partition(TileLds<PER>& L, const float4 (&r)[PER], const uint32_t (&dig)[PER],
                                                uint32_t nd, uint32_t* __restrict__ cursor, uint32_t cap, uint64_t region0,
                                                uint64_t region_stride, float4* __restrict__ out,
                                                PartCounters* __restrict__ pc) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (uint32_t d = tid; d < nd; d += kTileThreads) L.hist[d] = 0u;
     __syncthreads();
-    uint32_t rank[kTilePer];
+    uint32_t rank[PER];
 #pragma unroll
-    for (int j = 0; j < kTilePer; ++j) rank[j] = (dig[j] != 0xFFFFFFFFu) ? atomicAdd(&L.hist[dig[j]], 1u) : 0u;
+    for (int j = 0; j < PER; ++j) rank[j] = (dig[j] != 0xFFFFFFFFu) ? atomicAdd(&L.hist[dig[j]], 1u) : 0u;
     __syncthreads();
     // reserve space (one memory-side atomic per digit present in the tile) and scan the tile's counts
     uint32_t c = 0;
@@ -289,31 +294,42 @@ __device__ __forceinline__ void tile_partition(TileLds& L, const float4 (&r)[kTi
     }
     __syncthreads();
 #pragma unroll
-    for (int j = 0; j < kTilePer; ++j)
-        if (dig[j] != 0xFFFFFFFFu) L.rec[L.scan[dig[j]] + rank[j]] = r[j];
+    for (int j = 0; j < PER; ++j)
+        if (dig[j] != 0xFFFFFFFFu) {
+            const uint32_t pos = L.scan[dig[j]] + rank[j];
+            L.rec[pos] = r[j];
+            L.digit[pos] = (uint8_t)dig[j];
+        }
     __syncthreads();
     const uint32_t total = L.scan[nd];
-    for (uint32_t j = tid; j < total; j += kTileThreads) {
-        uint32_t lo = 0, hi = nd;                       // digit of sorted slot j: last d with scan[d] <= j
-        while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (L.scan[mid] <= j) lo = mid; else hi = mid; }
-        const uint32_t within = L.gbase[lo] + (j - L.scan[lo]);
-        if (within < cap) out[region0 + (uint64_t)lo * region_stride + within] = L.rec[j];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {                // consecutive lanes copy consecutive sorted slots
+        const uint32_t j = (uint32_t)k * kTileThreads + tid;
+        if (j < total) {
+            const uint32_t d = L.digit[j];
+            const uint32_t within = L.gbase[d] + (j - L.scan[d]);
+            if (within < cap) out[region0 + (uint64_t)d * region_stride + within] = L.rec[j];
+        }
     }
 }
 
-// level 1: the cloud -> coarse regions.  One tile per workgroup.
+// level 1: the cloud -> coarse regions.  One tile per workgroup.  Every coarse region is split into R sub-regions
+// with their own cursors (tile t fills sub-region t % R): a cursor is ONE word, and thousands of tiles reserving
+// on the same few words would serialise at the memory side (~90 same-address atomics per microsecond).
 template <int STRIDE_FLOATS>
 __global__ void __launch_bounds__(kTileThreads) k_part2_level1(const float* __restrict__ xyz, uint64_t n, uint32_t first_base,
-                                                               GridParams P, uint32_t B, uint32_t F1, uint32_t F2,
+                                                               GridParams P, uint32_t B, uint32_t F1, uint32_t F2, uint32_t R,
                                                                uint32_t* __restrict__ cursor1, uint32_t cap1,
                                                                float4* __restrict__ recs1, Counters* __restrict__ cnt,
                                                                PartCounters* __restrict__ pc) {
-    __shared__ TileLds L;
-    const uint64_t t0 = (uint64_t)blockIdx.x * kTile;
-    float4 r[kTilePer];
-    uint32_t dig[kTilePer];
+    constexpr int PER = kTilePer1;
+    __shared__ TileLds<PER> L;
+    const uint64_t t0 = (uint64_t)blockIdx.x * (kTileThreads * PER);
+    const uint32_t rep = blockIdx.x % R;
+    float4 r[PER];
+    uint32_t dig[PER];
 #pragma unroll
-    for (int j = 0; j < kTilePer; ++j) {
+    for (int j = 0; j < PER; ++j) {
         const uint64_t i = t0 + (uint64_t)j * kTileThreads + threadIdx.x;    // a wave holds 64 consecutive points
         const bool live = i < n;
         float px = 0.f, py = 0.f, pz = 0.f;
@@ -324,30 +340,31 @@ __global__ void __launch_bounds__(kTileThreads) k_part2_level1(const float* __re
         const bool same = wave_all_identical(px, py, pz, use);               // 64 identical points -> one weighted record
         dig[j] = 0xFFFFFFFFu;
         if (use && (!same || (threadIdx.x & 63) == 0)) {
-            dig[j] = bucket_of(column_hash(k.sx, k.sy), B) / F2;
+            dig[j] = (bucket_of(column_hash(k.sx, k.sy), B) / F2) * R + rep;
             const uint32_t idx = (first_base + (uint32_t)i) | (same ? kWeight64Flag : 0u);
             r[j] = make_float4(px, py, pz, __uint_as_float(idx));
         }
     }
-    tile_partition(L, r, dig, F1, cursor1, cap1, 0ull, (uint64_t)cap1, recs1, pc);
+    tile_partition<PER>(L, r, dig, F1 * R, cursor1, cap1, 0ull, (uint64_t)cap1, recs1, pc);
 }
 
-// level 2: coarse region blockIdx.y, tile blockIdx.x of it -> the fine buckets of that region
+// level 2: sub-region blockIdx.y (of coarse region blockIdx.y / R), tile blockIdx.x of it -> that region's fine buckets
 __global__ void __launch_bounds__(kTileThreads) k_part2_level2(const float4* __restrict__ recs1, const uint32_t* __restrict__ cursor1,
-                                                               uint32_t cap1, GridParams P, uint32_t B, uint32_t F2,
+                                                               uint32_t cap1, uint32_t R, GridParams P, uint32_t B, uint32_t F2,
                                                                uint32_t* __restrict__ cursor2, uint32_t cap2,
                                                                float4* __restrict__ recs2, PartCounters* __restrict__ pc) {
-    __shared__ TileLds L;
-    const uint32_t c = blockIdx.y;
-    const uint32_t have = min(cursor1[c], cap1);
-    const uint32_t t0 = blockIdx.x * kTile;
+    constexpr int PER = kTilePer2;
+    __shared__ TileLds<PER> L;
+    const uint32_t v = blockIdx.y, c = v / R;
+    const uint32_t have = min(cursor1[v], cap1);
+    const uint32_t t0 = blockIdx.x * (kTileThreads * PER);
     if (t0 >= have) return;
     const uint32_t b0 = c * F2, nd = min(F2, B - b0);
-    const float4* src = recs1 + (uint64_t)c * cap1;
-    float4 r[kTilePer];
-    uint32_t dig[kTilePer];
+    const float4* src = recs1 + (uint64_t)v * cap1;
+    float4 r[PER];
+    uint32_t dig[PER];
 #pragma unroll
-    for (int j = 0; j < kTilePer; ++j) {
+    for (int j = 0; j < PER; ++j) {
         const uint32_t i = t0 + (uint32_t)j * kTileThreads + threadIdx.x;
         dig[j] = 0xFFFFFFFFu;
         if (i < have) {
@@ -356,7 +373,7 @@ __global__ void __launch_bounds__(kTileThreads) k_part2_level2(const float4* __r
             dig[j] = bucket_of(column_hash(k.sx, k.sy), B) - b0;
         }
     }
-    tile_partition(L, r, dig, nd, cursor2 + b0, cap2, (uint64_t)b0 * cap2, (uint64_t)cap2, recs2, pc);
+    tile_partition<PER>(L, r, dig, nd, cursor2 + b0, cap2, (uint64_t)b0 * cap2, (uint64_t)cap2, recs2, pc);
 }
 
 // the fine buckets' record ranges for the bucket kernel, and the fullest region of either level
@@ -368,12 +385,14 @@ __global__ void __launch_bounds__(256) k_part2_ranges(const uint32_t* __restrict
     if (threadIdx.x == 0) { m1 = 0; m2 = 0; }
     __syncthreads();
     uint32_t a = 0, b2 = 0;
-    for (uint32_t b = blockIdx.x * blockDim.x + threadIdx.x; b < B; b += gridDim.x * blockDim.x) {
-        const uint32_t c = cursor2[b];
-        lo[b] = b * cap2;
-        hi[b] = b * cap2 + min(c, cap2);
-        b2 = max(b2, c);
-        if (b < F1) a = max(a, cursor1[b]);
+    for (uint32_t b = blockIdx.x * blockDim.x + threadIdx.x; b < max(B, F1); b += gridDim.x * blockDim.x) {
+        if (b < B) {
+            const uint32_t c = cursor2[b];
+            lo[b] = b * cap2;
+            hi[b] = b * cap2 + min(c, cap2);
+            b2 = max(b2, c);
+        }
+        if (b < F1) a = max(a, cursor1[b]);      // F1 here = number of level-1 (sub-)regions
     }
     if (a) atomicMax(&m1, a);
     if (b2) atomicMax(&m2, b2);

@@ -44,3 +44,46 @@ def test_shard_additivity_and_first_idx_min():
         sums[pos] += part[3]
     assert np.array_equal(cnt, whole[1]) and np.array_equal(first, whole[2])
     assert np.allclose(sums, whole[3], rtol=1e-12, atol=1e-12)
+
+
+def test_keys_on_and_around_cell_boundaries_match_the_reference_arithmetic():
+    """point_key must give the
+    reference's (int)ceilf(fabsf(p - o) / len) (map2D.h:965-970) for points ON cell boundaries, a few ulps either
+    side of them, and everywhere else — for awkward cell sizes too."""
+    from oracle import oracle
+    rng = np.random.default_rng(7)
+    for gl, zl, origin in ((0.5, 0.1, (0.0, 0.0, 0.0)), (0.2, 0.2, (1.37, -2.11, 0.3)), (0.1, 0.05, (-7.3, 4.4, 1.0)),
+                           (1.0 / 3.0, 0.07, (0.013, -0.021, 0.44)), (0.3, 0.3, (100.25, -200.5, 3.0))):
+        o = np.float32(origin)
+        k = rng.integers(1, 60000, size=(60000, 3)).astype(np.float64)
+        sign = rng.choice([-1.0, 1.0], size=k.shape)
+        lens = np.array([gl, gl, zl], np.float64)
+        base = (o.astype(np.float64) + sign * k * lens).astype(np.float32)          # on (or next to) a boundary
+        pts = [base]
+        for steps in (1, 2, 3, 5):
+            pts.append(np.nextafter(base, np.float32(np.inf)) if steps == 1 else base + np.spacing(base) * steps)
+            pts.append(np.nextafter(base, np.float32(-np.inf)) if steps == 1 else base - np.spacing(base) * steps)
+        pts.append((o + (rng.random((60000, 3)) * 2 - 1) * np.float32([3000, 3000, 50])).astype(np.float32))
+        pts = np.concatenate(pts, 0).astype(np.float32)
+        # the reference arithmetic in numpy fp32 (correctly rounded divide, like x86-64 SSE)
+        d = np.abs(pts - o)
+        q = np.ceil(d / np.float32([gl, gl, zl])).astype(np.int64)
+        q[q == 0] = 1
+        want = np.where(pts > o, q, -q)
+        ok_ref = (q[:, 0] <= 65535) & (q[:, 1] <= 65535) & (q[:, 2] <= (1 << 21) - 1)
+        keys = np.zeros(pts.shape[0], np.uint64)
+        ok = np.zeros(pts.shape[0], np.uint8)
+        oc = (he.C.c_float * 3)(*[float(v) for v in o])
+        he.shim().shim_point_keys(pts.ctypes.data_as(he.C.c_void_p), he.C.c_uint64(pts.shape[0]), 3, oc, he.C.c_float(gl),
+                                  he.C.c_float(zl), keys.ctypes.data_as(he.C.c_void_p), ok.ctypes.data_as(he.C.c_void_p))
+        sx, sy, sz = he.unpack(keys)
+        good = ok_ref & (ok != 0)
+        assert (ok != 0).tolist() == ok_ref.tolist()
+        got = np.stack([sx, sy, sz], 1)[good]
+        assert np.array_equal(got, want[good])
+        # spot-check the numpy statement itself against the oracle's C++ on a few hundred points
+        for i in rng.integers(0, pts.shape[0], 300):
+            if not good[i]:
+                continue
+            key, nx, ny, z = oracle.trans_morton_xyz(o, gl, zl, pts[i])
+            assert (abs(int(want[i, 0])), abs(int(want[i, 1])), int(want[i, 2])) == (nx, ny, z)
