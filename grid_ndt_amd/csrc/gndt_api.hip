@@ -584,15 +584,16 @@ int partition_launch(gndt_handle* h, gndt_handle::Pending& P) {
     const uint32_t* range_hi = nullptr;
     const float4* bucket_recs = nullptr;
     if (two) {
-        uint32_t F1 = 1;
-        while ((uint64_t)F1 * F1 < B) ++F1;                // fan-out ~ sqrt(B) per level, <= kMaxFan
-        const uint32_t F2 = (B + F1 - 1) / F1;
-        F1 = (B + F2 - 1) / F2;
+        uint32_t F2_shift = 1;                             // fan-out ~ sqrt(B) per level, F2 a power of two, both <= kMaxFan
+        while (F2_shift < 8 && (1ull << (2 * F2_shift)) < B) ++F2_shift;
+        const uint32_t F2 = 1u << F2_shift;
+        const uint32_t F1 = (B + F2 - 1) / F2;
         // Fixed region capacities: 2x the mean for the (large) coarse regions, 6x + 1024 for a bucket, or what the
         // fullest region of an earlier build on this handle needed (+25 %): LiDAR clouds load the columns near the
         // sensor far above the average.  HBM is plentiful and only touched lines cost, but past 24 records of
         // capacity per point the exact counting partition is the better deal.
-        const uint32_t R = std::max<uint32_t>(1, std::min<uint32_t>(8, kMaxFan / F1));   // sub-regions per coarse region
+        static const int env_rep = getenv("GNDT_L1_REP") ? atoi(getenv("GNDT_L1_REP")) : 1;   // measured: 1 is best at 4096-point tiles
+        const uint32_t R = std::max<uint32_t>(1, std::min<uint32_t>((uint32_t)env_rep, kMaxFan / F1));   // sub-regions per coarse region
         const uint32_t V = F1 * R;
         constexpr uint64_t kTile1 = (uint64_t)kTileThreads * kTilePer1, kTile2 = (uint64_t)kTileThreads * kTilePer2;
         const double r1 = std::max(2.0, q.fill1_ratio * 1.25), r2 = std::max(6.0, q.fill2_ratio * 1.25);
@@ -627,10 +628,10 @@ int partition_launch(gndt_handle* h, gndt_handle::Pending& P) {
         mark(h, 1, s);
         const uint32_t tiles1 = (uint32_t)((n + kTile1 - 1) / kTile1);
         if (stride_bytes == 12)
-            hipLaunchKernelGGL(k_part2_level1<3>, dim3(tiles1), dim3(kTileThreads), 0, s, p, (uint64_t)n, P.first_base, gp, B, F1, F2, R,
+            hipLaunchKernelGGL(k_part2_level1<3>, dim3(tiles1), dim3(kTileThreads), 0, s, p, (uint64_t)n, P.first_base, gp, B, F1, F2_shift, R,
                                cursor1, cap1, q.recs1, h->d_cnt, q.d_pc);
         else
-            hipLaunchKernelGGL(k_part2_level1<4>, dim3(tiles1), dim3(kTileThreads), 0, s, p, (uint64_t)n, P.first_base, gp, B, F1, F2, R,
+            hipLaunchKernelGGL(k_part2_level1<4>, dim3(tiles1), dim3(kTileThreads), 0, s, p, (uint64_t)n, P.first_base, gp, B, F1, F2_shift, R,
                                cursor1, cap1, q.recs1, h->d_cnt, q.d_pc);
         HIP_TRY(h, hipGetLastError());
         mark(h, 2, s);

@@ -313,12 +313,12 @@ __device__ __forceinline__ void tile_partition(TileLds<PER>& L, const float4 (&r
     }
 }
 
-// level 1: the cloud -> coarse regions.  One tile per workgroup.  Every coarse region is split into R sub-regions
-// with their own cursors (tile t fills sub-region t % R): a cursor is ONE word, and thousands of tiles reserving
-// on the same few words would serialise at the memory side (~90 same-address atomics per microsecond).
+// level 1: the cloud -> coarse regions.  One tile per workgroup.  A coarse region can be split into R sub-regions
+// with their own cursors (tile t fills sub-region t % R) to spread the reservations of thousands of tiles over
+// more words (same-address atomics serialise at the memory side); with 4096-point tiles R = 1 measured best.
 template <int STRIDE_FLOATS>
 __global__ void __launch_bounds__(kTileThreads) k_part2_level1(const float* __restrict__ xyz, uint64_t n, uint32_t first_base,
-                                                               GridParams P, uint32_t B, uint32_t F1, uint32_t F2, uint32_t R,
+                                                               GridParams P, uint32_t B, uint32_t F1, uint32_t F2_shift, uint32_t R,
                                                                uint32_t* __restrict__ cursor1, uint32_t cap1,
                                                                float4* __restrict__ recs1, Counters* __restrict__ cnt,
                                                                PartCounters* __restrict__ pc) {
@@ -340,7 +340,7 @@ __global__ void __launch_bounds__(kTileThreads) k_part2_level1(const float* __re
         const bool same = wave_all_identical(px, py, pz, use);               // 64 identical points -> one weighted record
         dig[j] = 0xFFFFFFFFu;
         if (use && (!same || (threadIdx.x & 63) == 0)) {
-            dig[j] = (bucket_of(column_hash(k.sx, k.sy), B) / F2) * R + rep;
+            dig[j] = (bucket_of(column_hash(k.sx, k.sy), B) >> F2_shift) * R + rep;      // F2 is a power of two
             const uint32_t idx = (first_base + (uint32_t)i) | (same ? kWeight64Flag : 0u);
             r[j] = make_float4(px, py, pz, __uint_as_float(idx));
         }
