@@ -627,11 +627,12 @@ int partition_launch(gndt_handle* h, gndt_handle::Pending& P) {
         HIP_TRY(h, hipGetLastError());
         mark(h, 1, s);
         const uint32_t tiles1 = (uint32_t)((n + kTile1 - 1) / kTile1);
+        static const uint32_t l1_wgs = getenv("GNDT_L1_WGS") ? (uint32_t)atoi(getenv("GNDT_L1_WGS")) : 1024u;   // persistent workgroups (2 resident per CU)
         if (stride_bytes == 12)
-            hipLaunchKernelGGL(k_part2_level1<3>, dim3(tiles1), dim3(kTileThreads), 0, s, p, (uint64_t)n, P.first_base, gp, B, F1, F2_shift, R,
+            hipLaunchKernelGGL(k_part2_level1<3>, dim3(std::min<uint32_t>(tiles1, l1_wgs)), dim3(kTileThreads), 0, s, p, (uint64_t)n, P.first_base, gp, B, F1, F2_shift, R,
                                cursor1, cap1, q.recs1, h->d_cnt, q.d_pc);
         else
-            hipLaunchKernelGGL(k_part2_level1<4>, dim3(tiles1), dim3(kTileThreads), 0, s, p, (uint64_t)n, P.first_base, gp, B, F1, F2_shift, R,
+            hipLaunchKernelGGL(k_part2_level1<4>, dim3(std::min<uint32_t>(tiles1, l1_wgs)), dim3(kTileThreads), 0, s, p, (uint64_t)n, P.first_base, gp, B, F1, F2_shift, R,
                                cursor1, cap1, q.recs1, h->d_cnt, q.d_pc);
         HIP_TRY(h, hipGetLastError());
         mark(h, 2, s);

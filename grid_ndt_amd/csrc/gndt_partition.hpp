@@ -243,7 +243,7 @@ __global__ void __launch_bounds__(kPartThreads) k_part_scatter(const float* __re
 // Record order inside a bucket depends on the order in which tiles reserve; nothing downstream depends on it.
 // ---------------------------------------------------------------------------------------------
 constexpr int kTileThreads = 512;
-constexpr int kTilePer1 = 8;       // level 1: 4096 records per tile (68 KB of LDS): fewer reservations on its few cursors
+constexpr int kTilePer1 = 8;       // level 1: 4096 records per tile (68 KB of LDS); smaller tiles measured slower here
 constexpr int kTilePer2 = 4;       // level 2: 2048 records per tile (34 KB): four tiles resident per CU
 constexpr int kMaxFan = 256;
 
@@ -271,16 +271,12 @@ __device__ __forceinline__ void tile_partition(TileLds<PER>& L, const float4 (&r
 #pragma unroll
     for (int j = 0; j < PER; ++j) rank[j] = (dig[j] != 0xFFFFFFFFu) ? atomicAdd(&L.hist[dig[j]], 1u) : 0u;
     __syncthreads();
-    // reserve space (one memory-side atomic per digit present in the tile) and scan the tile's counts
-    uint32_t c = 0;
+    // reserve space (one memory-side atomic per digit present in the tile) and scan the tile's counts.  The atomic's
+    // round trip (~2 us) is not waited for here: its result is only needed by the copy-out, after the tile is sorted.
+    uint32_t c = 0, g = 0;
     if ((uint32_t)tid < nd) {
         c = L.hist[tid];
-        uint32_t g = 0;
-        if (c) {
-            g = atomicAdd(&cursor[tid], c);
-            if (g + c > cap) atomicAdd(&pc->part_overflow, 1u);
-        }
-        L.gbase[tid] = g;
+        if (c) g = atomicAdd(&cursor[tid], c);
     }
     uint32_t incl = c;
     for (int o = 1; o < 64; o <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)incl, o, 64); if (lane >= o) incl += t; }
@@ -300,6 +296,10 @@ __device__ __forceinline__ void tile_partition(TileLds<PER>& L, const float4 (&r
             L.rec[pos] = r[j];
             L.digit[pos] = (uint8_t)dig[j];
         }
+    if ((uint32_t)tid < nd) {
+        if (c && g + c > cap) atomicAdd(&pc->part_overflow, 1u);
+        L.gbase[tid] = g;
+    }
     __syncthreads();
     const uint32_t total = L.scan[nd];
 #pragma unroll
@@ -324,28 +324,49 @@ __global__ void __launch_bounds__(kTileThreads) k_part2_level1(const float* __re
                                                                PartCounters* __restrict__ pc) {
     constexpr int PER = kTilePer1;
     __shared__ TileLds<PER> L;
-    const uint64_t t0 = (uint64_t)blockIdx.x * (kTileThreads * PER);
-    const uint32_t rep = blockIdx.x % R;
-    float4 r[PER];
-    uint32_t dig[PER];
+    // Persistent workgroups, software-pipelined: the loads of tile t+1 are in flight while tile t is keyed, sorted
+    // in LDS and copied out (the kernel is latency-bound: ~70 % of a wave's life is spent parked on waits).
+    const uint64_t ntiles = (n + (uint64_t)kTileThreads * PER - 1) / ((uint64_t)kTileThreads * PER);
+    float nx[PER], ny[PER], nz[PER];
+    auto load_tile = [&](uint64_t tile) {
+        const uint64_t t0 = tile * (kTileThreads * PER);
 #pragma unroll
-    for (int j = 0; j < PER; ++j) {
-        const uint64_t i = t0 + (uint64_t)j * kTileThreads + threadIdx.x;    // a wave holds 64 consecutive points
-        const bool live = i < n;
-        float px = 0.f, py = 0.f, pz = 0.f;
-        if (live) { const float* p = xyz + i * STRIDE_FLOATS; px = p[0]; py = p[1]; pz = p[2]; }
-        const PointKey k = point_key(px, py, pz, P.ox, P.oy, P.oz, P.grid_len, P.z_len);
-        if (live && !k.ok) atomicAdd(&cnt->err_key_range, 1u);
-        const bool use = live && k.ok;
-        const bool same = wave_all_identical(px, py, pz, use);               // 64 identical points -> one weighted record
-        dig[j] = 0xFFFFFFFFu;
-        if (use && (!same || (threadIdx.x & 63) == 0)) {
-            dig[j] = (bucket_of(column_hash(k.sx, k.sy), B) >> F2_shift) * R + rep;      // F2 is a power of two
-            const uint32_t idx = (first_base + (uint32_t)i) | (same ? kWeight64Flag : 0u);
-            r[j] = make_float4(px, py, pz, __uint_as_float(idx));
+        for (int j = 0; j < PER; ++j) {
+            const uint64_t i = t0 + (uint64_t)j * kTileThreads + threadIdx.x;    // a wave holds 64 consecutive points
+            nx[j] = 0.f; ny[j] = 0.f; nz[j] = 0.f;
+            if (i < n) { const float* p = xyz + i * STRIDE_FLOATS; nx[j] = p[0]; ny[j] = p[1]; nz[j] = p[2]; }
         }
+    };
+    uint64_t tile = blockIdx.x;
+    if (tile < ntiles) load_tile(tile);
+    for (; tile < ntiles; tile += gridDim.x) {
+        const uint64_t t0 = tile * (kTileThreads * PER);
+        const uint32_t rep = (uint32_t)(tile % R);
+        float cx[PER], cy[PER], cz[PER];
+#pragma unroll
+        for (int j = 0; j < PER; ++j) { cx[j] = nx[j]; cy[j] = ny[j]; cz[j] = nz[j]; }
+        if (tile + gridDim.x < ntiles) load_tile(tile + gridDim.x);
+        float4 r[PER];
+        uint32_t dig[PER];
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            const uint64_t i = t0 + (uint64_t)j * kTileThreads + threadIdx.x;
+            const bool live = i < n;
+            const float px = cx[j], py = cy[j], pz = cz[j];
+            const PointKey k = point_key(px, py, pz, P.ox, P.oy, P.oz, P.grid_len, P.z_len);
+            if (live && !k.ok) atomicAdd(&cnt->err_key_range, 1u);
+            const bool use = live && k.ok;
+            const bool same = wave_all_identical(px, py, pz, use);               // 64 identical points -> one weighted record
+            dig[j] = 0xFFFFFFFFu;
+            if (use && (!same || (threadIdx.x & 63) == 0)) {
+                dig[j] = (bucket_of(column_hash(k.sx, k.sy), B) >> F2_shift) * R + rep;      // F2 is a power of two
+                const uint32_t idx = (first_base + (uint32_t)i) | (same ? kWeight64Flag : 0u);
+                r[j] = make_float4(px, py, pz, __uint_as_float(idx));
+            }
+        }
+        tile_partition<PER>(L, r, dig, F1 * R, cursor1, cap1, 0ull, (uint64_t)cap1, recs1, pc);
+        __syncthreads();                                   // the tile's LDS image is reused by the next iteration
     }
-    tile_partition<PER>(L, r, dig, F1 * R, cursor1, cap1, 0ull, (uint64_t)cap1, recs1, pc);
 }
 
 // level 2: sub-region blockIdx.y (of coarse region blockIdx.y / R), tile blockIdx.x of it -> that region's fine buckets
