@@ -176,7 +176,7 @@ def main():
         # figure is the one the committed rocprofv3 --pmc passes of THIS workload measured (profiles/),
         # corrected as MI355X_MICROARCH.md prescribes; null for any other workload.
         traffic = None
-        pmc_path = os.path.join(ROOT, "profiles", "r01_c_partition_v2_pmc.json")
+        pmc_path = os.path.join(ROOT, "profiles", "r01_d_two_level_pmc.json")
         if default_workload and os.path.exists(pmc_path):
             for name, rec in json.load(open(pmc_path))["kernels"].items():
                 if kernel_of.get(dom) and kernel_of[dom] in name:
@@ -195,7 +195,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": kernel_of.get(dom),
                          "achieved": round(achieved, 2) if achieved else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5) if achieved else None, "traffic": traffic,
-                         "traffic_source": "profiles/r01_c_partition_v2_pmc.json (rocprofv3 --pmc, separate passes)" if traffic else None,
+                         "traffic_source": "profiles/r01_d_two_level_pmc.json (rocprofv3 --pmc, separate passes)" if traffic else None,
                          "kernel_ms_measured_in_timed_region": timed_live, "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": round(acc_ms, 4) if acc_ms == acc_ms else None},
             "path_roofline": {"bytes": path_bytes, "achieved_GBps": round(path_bytes / (ms_step * 1e-3) / 1e9, 2),
                               "frac": round(path_bytes / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
