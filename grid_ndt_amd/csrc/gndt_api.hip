@@ -565,7 +565,7 @@ int partition_launch(gndt_handle* h, gndt_handle::Pending& P) {
     bool two = h->P.strategy != GNDT_STRATEGY_PARTITION_EXACT && q.two_level_ok &&
                (n >= (1u << 20) || h->P.strategy == GNDT_STRATEGY_PARTITION_TWO_LEVEL) &&
                Bw <= (uint64_t)kMaxFan * kMaxFan;
-    if (env_two == 0) two = false;
+    if (env_two == 0 || n == 0) two = false;
     if (!two) {
         if (!env_slots && Bw > kMaxBuckets) { bslots = 1024; Bw = buckets_for(n, nodes_est, bslots); }
         if (Bw > kMaxBuckets) return -1;                   // too many nodes for one partition level: atomic path

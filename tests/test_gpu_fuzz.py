@@ -1,0 +1,62 @@
+"""GPU tier: seeded random clouds against the oracle, every strategy.  Small clouds with the structure that breaks
+binning code: points exactly on cell boundaries and a few ulps off them, duplicates, runs of 64+ identical points
+(the reference converters' padding), clusters that put dozens of points in one node, isolated far points, negative
+and positive quadrants, awkward cell sizes."""
+import numpy as np
+import pytest
+
+from tests import parity
+
+pytestmark = pytest.mark.gpu
+
+CELLS = [(0.5, 0.1), (0.2, 0.2), (0.1, 0.05), (1.0 / 3.0, 0.07), (0.25, 0.5)]
+
+
+def _cloud(seed):
+    rng = np.random.default_rng(seed)
+    gl, zl = CELLS[seed % len(CELLS)]
+    origin = (rng.random(3) * 20 - 10).astype(np.float32)
+    n = int(rng.integers(1, 6000))
+    parts = []
+    k = rng.integers(0, 5, size=6)
+    # clusters: many points per node
+    for _ in range(int(k[0]) + 1):
+        c = origin + (rng.random(3) * 8 - 4) * np.float32([1, 1, 0.2])
+        parts.append((c + rng.normal(0, [0.15, 0.15, 0.02], size=(max(n // 6, 1), 3))).astype(np.float32))
+    # lattice points on cell boundaries, and neighbours a few ulps away
+    ij = rng.integers(-40, 40, size=(max(n // 8, 1), 3)).astype(np.float64)
+    lat = (origin.astype(np.float64) + ij * np.array([gl, gl, zl])).astype(np.float32)
+    parts += [lat, np.nextafter(lat, np.float32(np.inf)), np.nextafter(lat, np.float32(-np.inf))]
+    # duplicates of existing points and a padding run of identical points (>= 64 in a row somewhere)
+    base = np.concatenate(parts, 0)
+    parts.append(base[rng.integers(0, base.shape[0], size=max(n // 10, 1))])
+    if k[1] >= 2:
+        parts.append(np.tile(np.float32([[0, 0, 0]]), (int(rng.integers(64, 400)), 1)))
+    # isolated far points
+    parts.append((origin + (rng.random((max(n // 20, 1), 3)) * 2 - 1) * np.float32([900, 900, 30])).astype(np.float32))
+    body = np.concatenate(parts, 0)
+    if k[2] >= 2:
+        body = body[rng.permutation(body.shape[0])]
+    cloud = np.concatenate([origin[None, :], body], 0).astype(np.float32)
+    P = dict(grid_len=gl, z_len=zl, slope_interval=0.08, demand="true" if seed % 7 == 0 else "slope")
+    return cloud, P
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_structured_clouds_every_strategy(seed):
+    cloud, P = _cloud(1000 + seed)
+    ref = parity.ref_from_cloud(cloud, P)
+    for strategy in (1, 3, 4):
+        m, out = parity.gpu_from_cloud(cloud, P, on_device=True, strategy=strategy)
+        parity.assert_parity(out, ref)
+
+
+def test_single_points_and_tiny_clouds():
+    for n in (0, 1, 2, 3, 4, 5, 63, 64, 65):
+        rng = np.random.default_rng(n)
+        cloud = np.concatenate([np.float32([[0.1, 0.2, 0.3]]), rng.random((n, 3)).astype(np.float32)], 0)
+        P = dict(grid_len=0.5, z_len=0.1, slope_interval=0.08, demand="slope")
+        ref = parity.ref_from_cloud(cloud, P)
+        for strategy in (1, 3, 4):
+            _, out = parity.gpu_from_cloud(cloud, P, on_device=True, strategy=strategy)
+            parity.assert_parity(out, ref)
