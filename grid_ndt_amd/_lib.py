@@ -10,8 +10,8 @@ import subprocess
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 _ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.path.join(_CSRC, "libgndt.so")
-SOURCES = ["gndt_api.hip", "gndt_codec.cpp"]
-HEADERS = ["gndt_kernels.hpp", "gndt_table.hpp", "gndt_cost.hpp", "gndt_partition.hpp", "gndt_bucket.hpp", "gndt_math.hpp", os.path.join(_ROOT, "include", "gndt.h")]
+SOURCES = ["gndt_api.hip", "gndt_codec.cpp", "gndt_io.cpp"]
+HEADERS = ["gndt_kernels.hpp", "gndt_table.hpp", "gndt_cost.hpp", "gndt_pack.hpp", "gndt_partition.hpp", "gndt_bucket.hpp", "gndt_math.hpp", os.path.join(_ROOT, "include", "gndt.h")]
 
 GNDT_OK = 0
 ERR_NAMES = {0: "OK", 1: "INVALID", 2: "NO_DEVICE", 3: "HIP", 4: "KEY_RANGE", 5: "CAPACITY", 6: "NOMEM"}
@@ -43,6 +43,15 @@ class Robot(C.Structure):
 class CostStats(C.Structure):
     _fields_ = [("goal_status", C.c_int32), ("ring", C.c_uint32), ("levels", C.c_uint32), ("reserved", C.c_uint32),
                 ("traversable", C.c_uint64), ("closed", C.c_uint64), ("check_pushes", C.c_uint64)]
+
+
+class PointLayout(C.Structure):
+    _fields_ = [("point_step", C.c_uint32), ("offset_x", C.c_uint32), ("offset_y", C.c_uint32), ("offset_z", C.c_uint32)]
+
+
+class Pcd(C.Structure):
+    _fields_ = [("num_points", C.c_uint64), ("layout", PointLayout), ("data_kind", C.c_int32), ("reserved", C.c_int32),
+                ("data", C.c_void_p)]
 
 
 class Stats(C.Structure):
@@ -133,6 +142,11 @@ def lib():
     L.gndt_stats_merge_device.argtypes = [H, C.POINTER(Stats), vp]
     L.gndt_shard_stats_device.argtypes = [H, vp, C.c_size_t, C.c_size_t, u64, C.POINTER(Stats), vp]
     L.gndt_finalize_stats_device.argtypes = [H, C.POINTER(Stats), u64, vp]
+    L.gndt_pcd_read.argtypes = [C.c_char_p, C.POINTER(Pcd), C.c_char_p]
+    L.gndt_pcd_free.argtypes = [C.POINTER(Pcd)]
+    L.gndt_pcd_free.restype = None
+    L.gndt_pack_points_device.argtypes = [H, vp, C.c_size_t, C.POINTER(PointLayout), vp, C.POINTER(u64), vp]
+    L.gndt_build_cloud.argtypes = [H, vp, C.c_size_t, C.POINTER(PointLayout)]
     L.gndt_compute_cost.argtypes = [H, C.POINTER(C.c_float), C.POINTER(Robot), vp]
     L.gndt_cost_export_device.argtypes = [H, C.POINTER(vp), C.POINTER(vp), C.POINTER(CostStats)]
     L.gndt_cost_export.argtypes = [H, vp, vp, C.POINTER(CostStats)]
@@ -156,6 +170,7 @@ def lib():
                  "gndt_export", "gndt_stats_export_device", "gndt_stats_merge_device", "gndt_trans_morton_xyz",
                  "gndt_compute_cost", "gndt_cost_export_device", "gndt_cost_export",
                  "gndt_shard_stats_device", "gndt_finalize_stats_device",
+                 "gndt_pcd_read", "gndt_pack_points_device", "gndt_build_cloud",
                  "gndt_count_morton", "gndt_morton_to_xy", "gndt_device_info", "gndt_set_profiling", "gndt_get_phase_times"):
         getattr(L, name).restype = C.c_int
     _lib = L

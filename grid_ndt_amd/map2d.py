@@ -10,7 +10,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import Cells, CostStats, GndtError, Params, Robot, Stats
+from ._lib import Cells, CostStats, GndtError, Params, Pcd, PointLayout, Robot, Stats
 
 DEMANDS = {"slope": 0, "true": 1}
 FLAG_HAS_STATS, FLAG_SLOPE, FLAG_DOWN = 1, 2, 4
@@ -108,12 +108,12 @@ class TwoDmap:
             msg = self._L.gndt_last_error(self._h)
             raise GndtError(rc, msg.decode() if msg else "")
 
-    def _ensure(self, demand):
+    def _ensure(self, demand, need_origin=True):
         d = DEMANDS[demand] if isinstance(demand, str) else int(demand)
         if self._h is not None and self._demand == d:
             return
         self._destroy()
-        if self.cloudFirst is None:
+        if self.cloudFirst is None and need_origin:
             raise GndtError(1, "setCloudFirst must be called before building (receiver.cpp:145)")
         P = Params(self.gridLen, self.zLen, self.slope_interval, d, self.min_points, self.device, self.strategy,
                    self.max_points_hint, self.max_nodes_hint)
@@ -123,8 +123,9 @@ class TwoDmap:
             msg = self._L.gndt_last_error(None)
             raise GndtError(rc, msg.decode() if msg else "")
         self._h, self._demand = h, d
-        o = (C.c_float * 3)(*self.cloudFirst)
-        self._check(self._L.gndt_set_origin(self._h, o))
+        if self.cloudFirst is not None:
+            o = (C.c_float * 3)(*self.cloudFirst)
+            self._check(self._L.gndt_set_origin(self._h, o))
 
     @staticmethod
     def _as_input(points):
@@ -163,6 +164,31 @@ class TwoDmap:
         else:
             self._check(self._L.gndt_update(self._h, C.c_void_p(ptr), n, stride))
         self._keep = keep
+        return True
+
+    # ---- input side: raw records (PointCloud2 / .pcd payload) ----
+    def pack_points(self, raw, point_step, offsets=(0, 4, 8), demand="slope", stream=None):
+        """Raw point records on the device (torch uint8/float32 tensor of n * point_step bytes) -> packed xyz torch
+        tensor [n_valid, 3]; rows with a NaN/Inf coordinate dropped, order kept (receiver.cpp:140-143, publisher.cpp:24-26)."""
+        import torch
+        self._ensure(demand, need_origin=False)
+        nbytes = raw.numel() * raw.element_size()
+        n = nbytes // int(point_step)
+        out = torch.empty((max(n, 1), 3), dtype=torch.float32, device=raw.device)
+        lay = PointLayout(int(point_step), int(offsets[0]), int(offsets[1]), int(offsets[2]))
+        nv = C.c_uint64()
+        self._check(self._L.gndt_pack_points_device(self._h, C.c_void_p(raw.data_ptr()), n, C.byref(lay), C.c_void_p(out.data_ptr()),
+                                                    C.byref(nv), _stream_ptr(stream)))
+        return out[:int(nv.value)]
+
+    def build_cloud(self, demand, raw, point_step, offsets=(0, 4, 8)):
+        """chatterCallback in one call (receiver.cpp:137-160): raw host records (numpy, n * point_step bytes) -> NaN
+        strip on the device, origin := first valid point, build of the rest."""
+        self._ensure(demand, need_origin=False)
+        raw = np.ascontiguousarray(raw)
+        n = raw.nbytes // int(point_step)
+        lay = PointLayout(int(point_step), int(offsets[0]), int(offsets[1]), int(offsets[2]))
+        self._check(self._L.gndt_build_cloud(self._h, C.c_void_p(raw.ctypes.data), n, C.byref(lay)))
         return True
 
     # ---- split form for sharded clouds ----
@@ -363,3 +389,20 @@ def device_info(device=0):
     if rc:
         raise GndtError(rc, "no device")
     return {"name": name.value.decode(), "compute_units": cu.value, "hbm_bytes": mem.value}
+
+
+def read_pcd(path):
+    """pcl::io::loadPCDFile's part of src/publisher.cpp:19: header + payload of a .pcd file (`DATA ascii` or `binary`).
+    Returns (raw, point_step, (off_x, off_y, off_z)): raw = numpy uint8 array of num_points * point_step bytes."""
+    L = _lib.lib()
+    p = Pcd()
+    err = C.create_string_buffer(256)
+    rc = L.gndt_pcd_read(str(path).encode(), C.byref(p), err)
+    if rc:
+        raise GndtError(rc, err.value.decode())
+    try:
+        nbytes = int(p.num_points) * int(p.layout.point_step)
+        raw = np.ctypeslib.as_array((C.c_uint8 * max(nbytes, 1)).from_address(p.data))[:nbytes].copy() if nbytes else np.zeros(0, np.uint8)
+    finally:
+        L.gndt_pcd_free(C.byref(p))
+    return raw, int(p.layout.point_step), (int(p.layout.offset_x), int(p.layout.offset_y), int(p.layout.offset_z))

@@ -194,6 +194,34 @@ int gndt_cost_export_device(gndt_handle* h, const float** h_dev, const uint32_t*
 /* Copies into caller-allocated host arrays of num_nodes elements (NULL arrays skipped). */
 int gndt_cost_export(gndt_handle* h, float* h_out, uint32_t* state_out, gndt_cost_stats* stats);
 
+/* ---- input side ---------------------------------------------------------
+ * Where x, y, z sit inside one raw point record: sensor_msgs::PointCloud2 fields / point_step, the records of a
+ * binary .pcd, or pcl::PointXYZ itself (step 16, offsets 0, 4, 8).  Offsets are multiples of 4. */
+typedef struct gndt_point_layout {
+    uint32_t point_step, offset_x, offset_y, offset_z;
+} gndt_point_layout;
+
+/* A .pcd file as pcl::io::loadPCDFile reads it (src/publisher.cpp:19): header + payload.  `DATA binary` payloads are
+ * returned as they are in the file (`layout` says where x, y, z are), `DATA ascii` as packed xyz.  Host-only. */
+typedef struct gndt_pcd {
+    uint64_t num_points;
+    gndt_point_layout layout;
+    int32_t data_kind;          /* 0 ascii (converted), 1 binary */
+    int32_t reserved;
+    void* data;                 /* num_points * layout.point_step bytes, released by gndt_pcd_free */
+} gndt_pcd;
+int gndt_pcd_read(const char* path, gndt_pcd* out, char err[256]);
+void gndt_pcd_free(gndt_pcd* pcd);
+
+/* Raw records on the device -> packed fp32 xyz on the device ([n][3], caller-allocated), rows with a non-finite
+ * coordinate dropped, order kept: pcl::fromPCLPointCloud2 (receiver.cpp:140-143) + pcl::removeNaNFromPointCloud
+ * (publisher.cpp:24-26).  *n_valid (host) = rows written; the call returns when it is known. */
+int gndt_pack_points_device(gndt_handle* h, const void* raw_dev, size_t n, const gndt_point_layout* layout,
+                            float* xyz_out_dev, uint64_t* n_valid, void* hip_stream);
+/* chatterCallback in one call (receiver.cpp:137-160): raw host records -> device, NaN strip, origin := the first
+ * valid point (receiver.cpp:145), build of the rest.  Returns like gndt_build. */
+int gndt_build_cloud(gndt_handle* h, const void* raw_host, size_t n, const gndt_point_layout* layout);
+
 /* ---- host key codec (consumers call transMortonXYZ on pos/goal: map2D.h:1071,1293; GlobalPlan.h:56) */
 /* `transMortonXYZ` (map2D.h:950-976): quadrant letter, 1-based indices, signed z level and the
  * map key string (letter + decimal Morton, <= 12 chars + NUL). */
