@@ -1463,11 +1463,8 @@ int gndt_debug_bucket_phases(gndt_handle* h, double cycles_out[10], uint32_t* bu
     for (uint32_t b = 0; b < q.last_buckets; ++b) {
         const unsigned long long* s = &t[(size_t)b * 16];
         for (int k = 0; k < 6; ++k) cycles_out[k] += (double)(s[k + 1] - s[k]);
-        // sub-phases of the accumulate phase (k_bucket_build2 only): load wait, classify, scan+scatter, reduce
-        if (s[8] && s[9] && s[10]) {
-            cycles_out[6] += (double)(s[8] - s[1]); cycles_out[7] += (double)(s[9] - s[8]);
-            cycles_out[8] += (double)(s[10] - s[9]); cycles_out[9] += (double)(s[2] - s[10]);
-        }
+        // sub-phases of the accumulate phase, summed over the bucket's chunks: load wait, classify, scan+scatter, reduce
+        for (int k = 0; k < 4; ++k) cycles_out[6 + k] += (double)s[8 + k];
     }
     for (int k = 0; k < 10; ++k) cycles_out[k] /= q.last_buckets;
     if (buckets_out) *buckets_out = q.last_buckets;

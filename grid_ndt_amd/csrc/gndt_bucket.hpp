@@ -91,6 +91,9 @@ __global__ void __launch_bounds__(T) k_bucket_build2(const float4* __restrict__ 
     GNDT_STAMP(1);
 
     const uint32_t lo = range_lo[blockIdx.x], hi = range_hi[blockIdx.x];   // exact path: bucket_base[b], bucket_base[b+1]
+    unsigned long long acc_t[4] = {0, 0, 0, 0}, t_prev = 0;     // diagnostic: load / classify / scatter / reduce, all chunks
+#define GNDT_LAP(k) do { if (dbg && tid == 0) { const unsigned long long t_now = __builtin_amdgcn_s_memtime(); acc_t[k] += t_now - t_prev; t_prev = t_now; } } while (0)
+    if (dbg && tid == 0) t_prev = __builtin_amdgcn_s_memtime();
     for (uint32_t cbeg = lo; cbeg < hi; cbeg += CH) {
         const uint32_t nchunk = min((uint32_t)CH, hi - cbeg);
         // ---- A: classify ----
@@ -101,7 +104,8 @@ __global__ void __launch_bounds__(T) k_bucket_build2(const float4* __restrict__ 
             const uint32_t off = (uint32_t)j * T + tid;
             rec[j] = (off < nchunk) ? recs[cbeg + off] : make_float4(0.f, 0.f, 0.f, 0.f);
         }
-        if (cbeg == lo) { if (dbg && tid == 0) { float keep = 0.f; for (int j = 0; j < PER; ++j) keep += rec[j].x; if (keep == 1.2345e-30f) dbg[1] = 0; } GNDT_STAMP(8); }
+        if (dbg && tid == 0) { float keep = 0.f; for (int j = 0; j < PER; ++j) keep += rec[j].x; if (keep == 1.2345e-30f) dbg[1] = 0; }
+        GNDT_LAP(0);
         // Staged so that the PER independent points overlap their latencies: all keys and hashes (VALU), then
         // all first probes (plain LDS loads), then the rare slow paths, then all arrival-rank atomics.
         uint64_t pkey[PER];
@@ -130,7 +134,7 @@ __global__ void __launch_bounds__(T) k_bucket_build2(const float4* __restrict__ 
         for (int j = 0; j < PER; ++j)
             if (tag[j] != 0xFFFFFFFFu) tag[j] |= atomicAdd(&L.ccur[tag[j] >> 16], 1u);
         __syncthreads();
-        if (cbeg == lo) GNDT_STAMP(9);
+        GNDT_LAP(1);
         if (L.overflow || L.n_nodes > (uint32_t)kFill) {     // uniform
             if (tid == 0) atomicAdd(&pc->lds_overflow, 1u);
             return;
@@ -161,7 +165,7 @@ __global__ void __launch_bounds__(T) k_bucket_build2(const float4* __restrict__ 
             }
         }
         __syncthreads();
-        if (cbeg == lo) GNDT_STAMP(10);
+        GNDT_LAP(2);
         // ---- C: run-length accumulation over the sorted image ----
         {
             const uint32_t p0 = (uint32_t)tid * PER;
@@ -220,7 +224,10 @@ __global__ void __launch_bounds__(T) k_bucket_build2(const float4* __restrict__ 
         __syncthreads();
         for (int s = tid; s < H; s += T) L.ccur[s] = 0;     // next chunk (nobody reads ccur before the next barrier)
         __syncthreads();
+        GNDT_LAP(3);
     }
+#undef GNDT_LAP
+    if (dbg && tid == 0) for (int k = 0; k < 4; ++k) dbg[(size_t)blockIdx.x * 16 + 8 + k] = acc_t[k];
     GNDT_STAMP(2);
 
     // Reserve the staging rows now: the memory-side atomic's round trip hides behind phases D-F.
