@@ -117,13 +117,20 @@ int gndt_set_origin(gndt_handle* h, const float origin_xyz[3]);
 /* Host memory in (e.g. pcl::PointCloud<PointXYZ>::points.data()+1, stride 16).  Synchronous. */
 int gndt_build(gndt_handle* h, const void* xyz_host, size_t n, size_t stride_bytes);
 /* Device memory in; all work is enqueued on `hip_stream` (a hipStream_t, may be NULL = the handle's own
- * stream).  stride_bytes is 12 (packed) or 16 (PointXYZ).  In this version the call waits for the stream once
- * before returning (it reads the device-side overflow flags and node count); results are then ready. */
+ * stream).  stride_bytes is 12 (packed) or 16 (PointXYZ).
+ * Partition strategies: the call returns once everything is enqueued.  The device-side overflow flags are read by
+ * the next call that needs the result (gndt_sync, gndt_export*, gndt_compute_cost, ...), which waits for the
+ * stream and, if a table or region was too small, re-runs the build with more room — so `xyz_dev` must stay valid
+ * and unchanged until then (a later gndt_build* / gndt_reset on the handle abandons the pending build instead).
+ * Strategy ATOMIC waits for the stream once before returning. */
 int gndt_build_device(gndt_handle* h, const void* xyz_dev, size_t n, size_t stride_bytes, void* hip_stream);
 
 /* Incremental add (the intent of changeCallback/change2DMap, receiver.cpp:179-212, map2D.h:672-822;
  * semantics defined in SURVEY.md Appendix A.7): after update(F1) .. update(Fk) the map equals
- * build(F1 || .. || Fk).  first_idx continues counting across calls. */
+ * build(F1 || .. || Fk).  first_idx continues counting across calls.  Needs a handle of strategy ATOMIC (the node
+ * table keeps the additive state).  gndt_update_device never waits for the host: every size it needs lives on the
+ * device, so once the buffers exist (one eager frame, or max_nodes_hint + max_points_hint) the call can be captured
+ * in a hipGraph and replayed per frame; table / row / index overflow is reported by gndt_sync. */
 int gndt_update(gndt_handle* h, const void* xyz_host, size_t n, size_t stride_bytes);
 int gndt_update_device(gndt_handle* h, const void* xyz_dev, size_t n, size_t stride_bytes, void* hip_stream);
 
