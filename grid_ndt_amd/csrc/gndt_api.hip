@@ -905,6 +905,7 @@ int gndt_accumulate_device(gndt_handle* h, const void* xyz_dev, size_t n, size_t
                  "with strategy = GNDT_STRATEGY_ATOMIC for incremental updates, or call gndt_reset first";
         return GNDT_ERR_INVALID;
     }
+    h->pending.active = false;
     rc = ensure_capacity_for(h, n, s);
     if (rc) return rc;
     mark(h, 1, s);
@@ -922,6 +923,12 @@ int gndt_finalize_device(gndt_handle* h, void* hip_stream) {
     if (rc) return rc;
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
     h->last_stream = s;
+    if (!h->map_in_table) {
+        h->err = "nothing accumulated in the node table: the current map was built by a PARTITION strategy (call gndt_reset, "
+                 "then gndt_accumulate_device / gndt_stats_merge_device)";
+        return GNDT_ERR_INVALID;
+    }
+    h->pending.active = false;
     if (h->cap == 0) {
         rc = alloc_table(h, cap_for_nodes(1024), s);
         if (rc) return rc;
@@ -1400,6 +1407,11 @@ int gndt_stats_merge_device(gndt_handle* h, const gndt_stats* in, void* hip_stre
     if (!in) return GNDT_ERR_INVALID;
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
     h->last_stream = s;
+    if (!h->map_in_table) {
+        h->err = "the current map was built by a PARTITION strategy and does not live in the node table: call gndt_reset first";
+        return GNDT_ERR_INVALID;
+    }
+    h->pending.active = false;
     rc = ensure_capacity_for(h, in->num_nodes, s);
     if (rc) return rc;
     if (in->num_nodes) {

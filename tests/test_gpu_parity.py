@@ -420,3 +420,26 @@ def test_large_terrain_both_strategies_agree():
     sc = np.abs(b["cov"]).max(1)
     assert (np.abs(a["cov"] - b["cov"]).max(1) <= 1e-6 * np.maximum(sc, 1e-30)).all()
     assert np.abs(a["mean"] - b["mean"]).max() <= 1e-5
+
+
+def test_table_entry_points_refuse_a_partition_built_map():
+    """The additive state lives in the node table; after a PARTITION build (pending or finished) the table calls must
+    say so instead of reading counters that describe another pipeline, and gndt_reset makes them usable again."""
+    import torch
+    import grid_ndt_amd as g
+    cloud = scenes.campus_frame(150000)
+    P = scenes.CAMPUS_PARAMS
+    m = g.TwoDmap(P["grid_len"], P["z_len"], strategy=3)
+    m.setInterval(P["slope_interval"])
+    m.setCloudFirst(cloud[0])
+    pts = torch.from_numpy(cloud[1:]).cuda()
+    m.create2DMap("slope", pts)                       # launched, still pending
+    for call in (lambda: m.finalize(), lambda: m.accumulate("slope", pts[:1000]), lambda: m.change2DMap("slope", pts[:1000]),
+                 lambda: m.stats_export()):
+        with pytest.raises(g.GndtError):
+            call()
+    parity.assert_parity(m.export(), parity.ref_from_cloud(cloud, P))      # the pending build is still resolved correctly
+    m.reset("slope")
+    m.accumulate("slope", pts)
+    m.finalize()
+    parity.assert_parity(m.export(), parity.ref_from_cloud(cloud, P))
