@@ -62,23 +62,24 @@ struct StatsOut {
 // STATS = false: the bucket's nodes leave as staging rows (labels, moments) for the ordering + emit kernels.
 // STATS = true : they leave as additive statistics (key, 9 sums, count, first index) and nothing else is done:
 //                the shard's contribution to a global map (gndt_shard_stats_device).
-template <int T, int H, int CH, bool STATS = false>
-__global__ void __launch_bounds__(T) k_bucket_build2(const float4* __restrict__ recs, const uint32_t* __restrict__ range_lo,
-                                                     const uint32_t* __restrict__ range_hi,
-                                                     GridParams P, StageRow* __restrict__ stage, uint32_t stage_cap,
-                                                     uint32_t* __restrict__ ord_cf, uint32_t* __restrict__ ord_idx,
-                                                     uint32_t* __restrict__ ord_ncol, uint32_t* __restrict__ bitmap,
-                                                     Counters* __restrict__ cnt, PartCounters* __restrict__ pc,
-                                                     unsigned long long* __restrict__ dbg, StatsOut so) {
+template <int T, int H, int CH, bool STATS>
+__device__ __forceinline__ void bucket_build_one(BucketLds2<H, CH>& L, const uint32_t bucket, const uint32_t num_buckets,
+                                                 const float4* __restrict__ recs, const uint32_t* __restrict__ range_lo,
+                                                 const uint32_t* __restrict__ range_hi, const GridParams& P,
+                                                 StageRow* __restrict__ stage, uint32_t stage_cap,
+                                                 uint32_t* __restrict__ ord_cf, uint32_t* __restrict__ ord_idx,
+                                                 uint32_t* __restrict__ ord_ncol, uint32_t* __restrict__ bitmap,
+                                                 Counters* __restrict__ cnt, PartCounters* __restrict__ pc,
+                                                 unsigned long long* __restrict__ dbg, const StatsOut& so,
+                                                 float4 (&pre)[CH / T], uint32_t& pre_bucket, uint32_t& pre_cbeg) {
     static_assert(CH % T == 0, "chunk must be a multiple of the block");
     static_assert(H % T == 0 || T % H == 0, "slots vs threads");
     constexpr int PER = CH / T;                 // points per thread and chunk
     constexpr int SPT = (H + T - 1) / T;        // slots per thread in the per-slot loops
     constexpr int kFill = (H * 25) / 32;
-    __shared__ BucketLds2<H, CH> L;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
-#define GNDT_STAMP(k) do { if (dbg && tid == 0) dbg[(size_t)blockIdx.x * 16 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define GNDT_STAMP(k) do { if (dbg && tid == 0) dbg[(size_t)bucket * 16 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
     GNDT_STAMP(0);
     for (int s = tid; s < H; s += T) {
         L.key[s] = kEmptyKey;
@@ -90,7 +91,10 @@ __global__ void __launch_bounds__(T) k_bucket_build2(const float4* __restrict__ 
     __syncthreads();
     GNDT_STAMP(1);
 
-    const uint32_t lo = range_lo[blockIdx.x], hi = range_hi[blockIdx.x];   // exact path: bucket_base[b], bucket_base[b+1]
+    const uint32_t lo = range_lo[bucket], hi = range_hi[bucket];   // exact path: bucket_base[b], bucket_base[b+1]
+    const uint32_t nb = bucket + gridDim.x;                        // this workgroup's next bucket
+    uint32_t nlo = 0, nhi = 0;
+    if (nb < num_buckets) { nlo = range_lo[nb]; nhi = range_hi[nb]; }
     unsigned long long acc_t[4] = {0, 0, 0, 0}, t_prev = 0;     // diagnostic: load / classify / scatter / reduce, all chunks
 #define GNDT_LAP(k) do { if (dbg && tid == 0) { const unsigned long long t_now = __builtin_amdgcn_s_memtime(); acc_t[k] += t_now - t_prev; t_prev = t_now; } } while (0)
     if (dbg && tid == 0) t_prev = __builtin_amdgcn_s_memtime();
@@ -99,10 +103,29 @@ __global__ void __launch_bounds__(T) k_bucket_build2(const float4* __restrict__ 
         // ---- A: classify ----
         float4 rec[PER];
         uint32_t tag[PER];                      // slot << 16 | arrival rank (CH <= 65536)
+        if (pre_bucket == bucket && pre_cbeg == cbeg) {           // (uniform) the records were loaded a chunk ago
 #pragma unroll
-        for (int j = 0; j < PER; ++j) {
-            const uint32_t off = (uint32_t)j * T + tid;
-            rec[j] = (off < nchunk) ? recs[cbeg + off] : make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int j = 0; j < PER; ++j) rec[j] = pre[j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < PER; ++j) {
+                const uint32_t off = (uint32_t)j * T + tid;
+                rec[j] = (off < nchunk) ? recs[cbeg + off] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+        {   // issue the loads of the chunk this workgroup processes next: the rest of this bucket, or its next bucket
+            uint32_t pb = bucket, pc = cbeg + CH, pe = hi;
+            if (pc >= hi) { pb = nb; pc = nlo; pe = nhi; }
+            pre_bucket = 0xFFFFFFFFu;
+            if (pb < num_buckets && pc < pe) {
+                const uint32_t pn = min((uint32_t)CH, pe - pc);
+#pragma unroll
+                for (int j = 0; j < PER; ++j) {
+                    const uint32_t off = (uint32_t)j * T + tid;
+                    pre[j] = (off < pn) ? recs[pc + off] : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+                pre_bucket = pb; pre_cbeg = pc;
+            }
         }
         if (dbg && tid == 0) { float keep = 0.f; for (int j = 0; j < PER; ++j) keep += rec[j].x; if (keep == 1.2345e-30f) dbg[1] = 0; }
         GNDT_LAP(0);
@@ -227,7 +250,7 @@ __global__ void __launch_bounds__(T) k_bucket_build2(const float4* __restrict__ 
         GNDT_LAP(3);
     }
 #undef GNDT_LAP
-    if (dbg && tid == 0) for (int k = 0; k < 4; ++k) dbg[(size_t)blockIdx.x * 16 + 8 + k] = acc_t[k];
+    if (dbg && tid == 0) for (int k = 0; k < 4; ++k) dbg[(size_t)bucket * 16 + 8 + k] = acc_t[k];
     GNDT_STAMP(2);
 
     // Reserve the staging rows now: the memory-side atomic's round trip hides behind phases D-F.
@@ -353,6 +376,28 @@ __global__ void __launch_bounds__(T) k_bucket_build2(const float4* __restrict__ 
     if (dbg) { GNDT_STAMP(4); GNDT_STAMP(5); }
     if (dbg) { __syncthreads(); GNDT_STAMP(6); }
 #undef GNDT_STAMP
+}
+
+
+// Bucket b, b + gridDim.x, ... (one bucket per workgroup unless the grid is smaller than the bucket count); the records of
+// the chunk a workgroup processes next are loaded into registers while it works on the current one.  128 VGPRs at most:
+// two 512-thread workgroups per CU are what the LDS allows, and they need 4 waves per SIMD.
+template <int T, int H, int CH, bool STATS = false>
+__global__ void __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) k_bucket_build2(const float4* __restrict__ recs, const uint32_t* __restrict__ range_lo,
+                                                     const uint32_t* __restrict__ range_hi, uint32_t num_buckets,
+                                                     GridParams P, StageRow* __restrict__ stage, uint32_t stage_cap,
+                                                     uint32_t* __restrict__ ord_cf, uint32_t* __restrict__ ord_idx,
+                                                     uint32_t* __restrict__ ord_ncol, uint32_t* __restrict__ bitmap,
+                                                     Counters* __restrict__ cnt, PartCounters* __restrict__ pc,
+                                                     unsigned long long* __restrict__ dbg, StatsOut so) {
+    __shared__ BucketLds2<H, CH> L;
+    float4 pre[CH / T];
+    uint32_t pre_bucket = 0xFFFFFFFFu, pre_cbeg = 0;
+    for (uint32_t bucket = blockIdx.x; bucket < num_buckets; bucket += gridDim.x) {
+        bucket_build_one<T, H, CH, STATS>(L, bucket, num_buckets, recs, range_lo, range_hi, P, stage, stage_cap, ord_cf, ord_idx,
+                                          ord_ncol, bitmap, cnt, pc, dbg, so, pre, pre_bucket, pre_cbeg);
+        __syncthreads();        // the LDS tables are re-initialised by the next bucket
+    }
 }
 
 }  // namespace gndt
