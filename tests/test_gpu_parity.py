@@ -443,3 +443,32 @@ def test_table_entry_points_refuse_a_partition_built_map():
     m.accumulate("slope", pts)
     m.finalize()
     parity.assert_parity(m.export(), parity.ref_from_cloud(cloud, P))
+
+
+def test_partition_build_replayed_from_a_hip_graph():
+    """A PARTITION build enqueues its kernels and the read-back of its flags without waiting for the host, so once its
+    buffers exist it can be captured in a hipGraph and replayed on new data in the same device buffer."""
+    import torch
+    import grid_ndt_amd as g
+    n = 1_200_000                                        # large enough for the two-level partition
+    clouds = [scenes.uniform_box(n + 1, seed=0x5EED0100 + k, half_xy=40.0) for k in range(3)]
+    origin = clouds[0][0]
+    m = g.TwoDmap(0.5, 0.5, strategy=2, max_nodes_hint=200000)
+    m.setInterval(0.08)
+    m.setCloudFirst(origin)
+    buf = torch.empty(n, 3, dtype=torch.float32, device="cuda")
+    buf.copy_(torch.from_numpy(clouds[0][1:]))
+    for _ in range(2):                                    # eager builds: every buffer exists, capacities are learnt
+        m.create2DMap("slope", buf)
+        m.sync()
+    assert m.last_strategy() == 2
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        m.create2DMap("slope", buf)
+    for k in (1, 2):
+        buf.copy_(torch.from_numpy(clouds[k][1:]))
+        graph.replay()
+        torch.cuda.synchronize()
+        cloud = np.concatenate([origin[None, :], clouds[k][1:]], 0)
+        ref = parity.ref_from_cloud(cloud, dict(grid_len=0.5, z_len=0.5, slope_interval=0.08, demand="slope"))
+        parity.assert_parity(m.export(), ref)
