@@ -82,9 +82,10 @@ struct gndt_handle {
         uint64_t rec_cap = 0;      float4* recs = nullptr;
         // two-level partition: level-1 regions, cursors of both levels, record ranges of the fine buckets
         uint64_t rec1_cap = 0;     float4* recs1 = nullptr;
-        uint64_t cur_cap = 0;      uint32_t *cursors = nullptr, *range_lo = nullptr, *range_hi = nullptr;
+        uint64_t cur_cap = 0;      uint32_t *cursors = nullptr, *range_lo = nullptr, *range_hi = nullptr, *range_cap = nullptr;
+        int two_level_failures = 0;   // builds whose regions overflowed although sized from the sample
         bool two_level_ok = true;  // cleared when the regions a cloud needs are too large: exact path from then on
-        double fill1_ratio = 0.0, fill2_ratio = 0.0;   // fullest region / mean region seen on this handle (0 = unknown)
+        double fill1_ratio = 0.0;   // fullest level-1 region / mean seen on this handle (0 = unknown)
         uint64_t hist_cap = 0;     uint32_t* hist = nullptr;
         uint32_t bucket_cap = 0;   uint32_t* totals = nullptr; uint32_t* bucket_base = nullptr;
         uint64_t stage_cap = 0;    StageRow* stage = nullptr;
@@ -129,7 +130,7 @@ struct gndt_handle {
         int attempt = 0, bslots = 0;
         uint64_t nodes_est = 0, stage_want = 0;
         bool two_level = false;         // this attempt used the two-level partition
-        double mean1 = 0.0, mean2 = 0.0;  // its mean region fills (to turn the fullest region into a ratio)
+        double mean1 = 0.0;             // its mean level-1 region fill (to turn the fullest region into a ratio)
         bool stats_only = false;        // gndt_shard_stats_device: statistics out, no labels / ordering / rows
         uint32_t first_base = 0;        // global index of xyz[0] (shards of a global cloud)
     } pending;
@@ -296,7 +297,7 @@ void free_cost(gndt_handle* h) {
 
 void free_part(gndt_handle* h) {
     auto& q = h->part;
-    void* ptrs[] = {q.recs, q.recs1, q.cursors, q.range_lo, q.range_hi, q.hist, q.totals, q.bucket_base, q.stage, q.ord_cf, q.ord_idx, q.ord_ncol, q.col_rank,
+    void* ptrs[] = {q.recs, q.recs1, q.cursors, q.range_lo, q.range_hi, q.range_cap, q.hist, q.totals, q.bucket_base, q.stage, q.ord_cf, q.ord_idx, q.ord_ncol, q.col_rank,
                     q.col_size, q.col_base, q.inv, q.bsum_cols, q.bitmap, q.word_prefix, q.bsum_words, q.d_pc, q.dbg};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -594,58 +595,62 @@ int partition_launch(gndt_handle* h, gndt_handle::Pending& P) {
         while (F2_shift < 8 && (1ull << (2 * F2_shift)) < B) ++F2_shift;
         const uint32_t F2 = 1u << F2_shift;
         const uint32_t F1 = (B + F2 - 1) / F2;
-        // Fixed region capacities: 2x the mean for the (large) coarse regions, 6x + 1024 for a bucket, or what the
-        // fullest region of an earlier build on this handle needed (+25 %): LiDAR clouds load the columns near the
-        // sensor far above the average.  HBM is plentiful and only touched lines cost, but past 24 records of
-        // capacity per point the exact counting partition is the better deal.
+        // Level-1 regions are large and hash-balanced: a fixed capacity of 2x the mean (or 1.25x the fullest one an
+        // earlier build on this handle saw).  The buckets' regions are laid out on the device from a 1-in-64 sample
+        // level 1 takes (k_part2_layout: 1.6x the estimate + 1024 each), so LiDAR clouds' hot columns get the room they
+        // need and the records take 1.6 n + 1024 B slots in all.  If a region overflows all the same, the build is
+        // re-run; a second failure sends this handle to the exact counting partition.
         static const int env_rep = getenv("GNDT_L1_REP") ? atoi(getenv("GNDT_L1_REP")) : 1;   // measured: 1 is best at 4096-point tiles
         const uint32_t R = std::max<uint32_t>(1, std::min<uint32_t>((uint32_t)env_rep, kMaxFan / F1));   // sub-regions per coarse region
         const uint32_t V = F1 * R;
         constexpr uint64_t kTile1 = (uint64_t)kTileThreads * kTilePer1, kTile2 = (uint64_t)kTileThreads * kTilePer2;
-        const double r1 = std::max(2.0, q.fill1_ratio * 1.25), r2 = std::max(6.0, q.fill2_ratio * 1.25);
+        const double r1 = std::max(2.0, q.fill1_ratio * 1.25);
         const uint64_t cap1w = (uint64_t)(r1 * (double)(n / V)) + 2 * kTile1;
-        const uint64_t cap2w = (uint64_t)(r2 * (double)(n / B)) + 1024;
-        if ((uint64_t)V * cap1w > 4 * (uint64_t)n + (1u << 24) || (uint64_t)B * cap2w > 24 * (uint64_t)n + (1u << 24) ||
-            (uint64_t)B * cap2w >= 0xF0000000ull) {
+        const uint64_t recs_want = n + (n * 3) / 5 + n / 8 + 1024ull * B + 4096;     // 1.6 n + 1024 B, and sampling slack
+        if ((uint64_t)V * cap1w > 4 * (uint64_t)n + (1u << 24) || recs_want >= 0xF0000000ull || q.two_level_failures >= 2) {
             q.two_level_ok = false;
             return partition_launch(h, P);                 // (re-enters on the exact path)
         }
-        const uint32_t cap1 = (uint32_t)cap1w, cap2 = (uint32_t)cap2w;
-        P.mean1 = (double)(n / V); P.mean2 = (double)(n / B);
+        const uint32_t cap1 = (uint32_t)cap1w;
+        P.mean1 = (double)(n / V);
         if ((rc = grow_buf(h, q.recs1, q.rec1_cap, (uint64_t)V * cap1))) return rc;
-        if ((rc = grow_buf(h, q.recs, q.rec_cap, (uint64_t)B * cap2))) return rc;
+        if ((rc = grow_buf(h, q.recs, q.rec_cap, recs_want))) return rc;
         if (B > q.cur_cap) {
-            for (uint32_t** a : {&q.cursors, &q.range_lo, &q.range_hi}) { if (*a) (void)hipFree(*a); *a = nullptr; }
+            for (uint32_t** a : {&q.cursors, &q.range_lo, &q.range_hi, &q.range_cap}) { if (*a) (void)hipFree(*a); *a = nullptr; }
             q.cur_cap = 0;
             const uint64_t c = (uint64_t)B + B / 4;
-            HIP_TRY(h, hipMalloc(&q.cursors, ((size_t)kMaxFan + c) * 4));      // [kMaxFan] level 1, then [c] level 2
+            HIP_TRY(h, hipMalloc(&q.cursors, ((size_t)kMaxFan + 2 * c) * 4));  // [kMaxFan] level 1, [c] level 2, [c] samples
             HIP_TRY(h, hipMalloc(&q.range_lo, c * 4));
             HIP_TRY(h, hipMalloc(&q.range_hi, c * 4));
+            HIP_TRY(h, hipMalloc(&q.range_cap, c * 4));
             q.cur_cap = c;
         }
         uint32_t* cursor1 = q.cursors;
         uint32_t* cursor2 = q.cursors + kMaxFan;
+        uint32_t* est2 = cursor2 + B;
         mark(h, 0, s);
         if (h->table_dirty) { if ((rc = do_reset(h, s))) return rc; }
         h->results_valid = false;
         hipLaunchKernelGGL(k_part_clear, dim3(grid_for(words, 256, 512)), dim3(256), 0, s, h->d_cnt, q.d_pc, q.bitmap, (uint64_t)words,
-                           q.cursors, (uint32_t)(kMaxFan + B));
+                           q.cursors, (uint32_t)(kMaxFan + 2 * B));
         HIP_TRY(h, hipGetLastError());
         mark(h, 1, s);
         const uint32_t tiles1 = (uint32_t)((n + kTile1 - 1) / kTile1);
         static const uint32_t l1_wgs = getenv("GNDT_L1_WGS") ? (uint32_t)atoi(getenv("GNDT_L1_WGS")) : 1024u;   // persistent workgroups (2 resident per CU)
         if (stride_bytes == 12)
             hipLaunchKernelGGL(k_part2_level1<3>, dim3(std::min<uint32_t>(tiles1, l1_wgs)), dim3(kTileThreads), 0, s, p, (uint64_t)n, P.first_base, gp, B, F1, F2_shift, R,
-                               cursor1, cap1, q.recs1, h->d_cnt, q.d_pc);
+                               cursor1, cap1, est2, q.recs1, h->d_cnt, q.d_pc);
         else
             hipLaunchKernelGGL(k_part2_level1<4>, dim3(std::min<uint32_t>(tiles1, l1_wgs)), dim3(kTileThreads), 0, s, p, (uint64_t)n, P.first_base, gp, B, F1, F2_shift, R,
-                               cursor1, cap1, q.recs1, h->d_cnt, q.d_pc);
+                               cursor1, cap1, est2, q.recs1, h->d_cnt, q.d_pc);
         HIP_TRY(h, hipGetLastError());
         mark(h, 2, s);
+        hipLaunchKernelGGL(k_part2_layout, dim3(1), dim3(1024), 0, s, est2, B, q.range_lo, q.range_cap, (uint64_t)q.rec_cap, q.d_pc);
+        HIP_TRY(h, hipGetLastError());
         mark(h, 3, s);
         hipLaunchKernelGGL(k_part2_level2, dim3((uint32_t)((cap1 + kTile2 - 1) / kTile2), V), dim3(kTileThreads), 0, s, q.recs1, cursor1,
-                           cap1, R, gp, B, F2, cursor2, cap2, q.recs, q.d_pc);
-        hipLaunchKernelGGL(k_part2_ranges, dim3(grid_for(B, 256, 64)), dim3(256), 0, s, cursor1, V, cursor2, cap2, B, q.range_lo,
+                           cap1, R, gp, B, F2, cursor2, q.range_lo, q.range_cap, q.recs, q.d_pc);
+        hipLaunchKernelGGL(k_part2_ranges, dim3(grid_for(B, 256, 64)), dim3(256), 0, s, cursor1, V, cursor2, q.range_cap, B, q.range_lo,
                            q.range_hi, q.d_pc);
         HIP_TRY(h, hipGetLastError());
         mark(h, 4, s);
@@ -772,16 +777,16 @@ int partition_resolve(gndt_handle* h) {
     for (;;) {
         if (hipStreamSynchronize(P.s) != hipSuccess) { P.active = false; h->err = "hipStreamSynchronize failed"; return GNDT_ERR_HIP; }
         bool again = false;
-        if (P.two_level && P.mean1 > 0 && P.mean2 > 0) {       // remember how uneven this handle's latest cloud was
-            q.fill1_ratio = q.h_pc->max_fill1 / P.mean1;      // (the latest build: bucket counts change between attempts)
-            q.fill2_ratio = q.h_pc->max_fill2 / P.mean2;
+        if (P.two_level && P.mean1 > 0) {                      // remember how uneven the level-1 regions of the latest cloud were
+            q.fill1_ratio = q.h_pc->max_fill1 / P.mean1;
             if (getenv("GNDT_VERBOSE"))
-                fprintf(stderr, "[gndt] two-level partition: fullest coarse region %.2fx the mean, fullest bucket %.2fx, overflow %u\n",
-                        q.h_pc->max_fill1 / P.mean1, q.h_pc->max_fill2 / P.mean2, q.h_pc->part_overflow);
+                fprintf(stderr, "[gndt] two-level partition: fullest level-1 region %.2fx the mean, overflow %u\n",
+                        q.h_pc->max_fill1 / P.mean1, q.h_pc->part_overflow);
         }
-        if (q.h_pc->part_overflow) {                           // a fixed-capacity region of the two-level partition was too
-            --P.attempt;                                       // small: same table size and estimate again, regions sized
-            again = true;                                      // from the fullest one (or the exact path if that is too much)
+        if (q.h_pc->part_overflow) {                           // a region of the two-level partition was too small: same table
+            ++q.two_level_failures;                            // size and estimate again (level-1 regions sized from the fullest
+            --P.attempt;                                       // one seen; after two failures the exact counting partition)
+            again = true;
         } else if (q.h_pc->lds_overflow) {                            // some bucket holds too many nodes for its LDS table:
             if (P.attempt >= 1 || env_slots) P.nodes_est *= 2;   // (attempt 0 -> 1 only switches to the 1024-slot table)
             again = true;

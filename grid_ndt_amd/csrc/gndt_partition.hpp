@@ -38,9 +38,8 @@ struct PartCounters {
     uint32_t stage_overflow;   // nodes that did not fit the staging rows
     uint32_t index_overflow;   // column-first indices beyond the bitmap (table path: stream ran past max_points_hint)
     uint32_t part_overflow;    // two-level partition: reservations beyond a region's fixed capacity
-    uint32_t max_fill1;        // two-level partition: fullest coarse region / fullest bucket (true counts, also when
-    uint32_t max_fill2;        //   they exceed the capacity: the host sizes the retry from them)
-    uint32_t pad[2];
+    uint32_t max_fill1;        // two-level partition: fullest level-1 region (true count, also beyond its capacity: the
+    uint32_t pad[3];           //   host sizes the retry from it)
 };
 
 struct alignas(16) StageRow {   // 128 bytes = two 64-B lines, gathered whole by k_emit_rows
@@ -98,7 +97,7 @@ __global__ void __launch_bounds__(256) k_part_clear(Counters* __restrict__ cnt, 
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         cnt->num_nodes = 0; cnt->num_columns = 0; cnt->num_slopes = 0; cnt->err_key_range = 0; cnt->err_table_full = 0;
         pc->lds_overflow = 0; pc->stage_overflow = 0; pc->index_overflow = 0; pc->part_overflow = 0;
-        pc->max_fill1 = 0; pc->max_fill2 = 0;
+        pc->max_fill1 = 0;
     }
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < words; i += (uint64_t)gridDim.x * blockDim.x) bitmap[i] = 0u;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_cursors; i += gridDim.x * blockDim.x) cursors[i] = 0u;   // two-level partition
@@ -246,6 +245,7 @@ constexpr int kTileThreads = 512;
 constexpr int kTilePer1 = 8;       // level 1: 4096 records per tile (68 KB of LDS); smaller tiles measured slower here
 constexpr int kTilePer2 = 4;       // level 2: 2048 records per tile (34 KB): four tiles resident per CU
 constexpr int kMaxFan = 256;
+constexpr uint32_t kSampleEvery = 64;      // level 1 samples one record in 64 to size the buckets' regions (the hash test below is >> 26)
 
 template <int PER>
 struct TileLds {
@@ -254,15 +254,18 @@ struct TileLds {
     uint32_t hist[kMaxFan];
     uint32_t scan[kMaxFan + 1];
     uint32_t gbase[kMaxFan];
+    uint32_t dbase[kMaxFan], dcap[kMaxFan];     // individually laid out regions (level 2)
     uint32_t wave_tot[kTileThreads / 64];
 };
 
-// r[j] / dig[j]: this thread's records and their digits (0xFFFFFFFF = no record).  Region of digit d starts at
-// out[region0 + d * region_stride] and holds `cap` records; cursor[d] counts what is reserved in it.
+// r[j] / dig[j]: this thread's records and their digits (0xFFFFFFFF = no record).  cursor[d] counts what is reserved in
+// the region of digit d.  Regions are either evenly spaced (dbase == nullptr: digit d at out[region0 + d * region_stride],
+// `cap` records each) or laid out individually (digit d at out[dbase[d]], dcap[d] records).
 template <int PER>
 __device__ __forceinline__ void tile_partition(TileLds<PER>& L, const float4 (&r)[PER], const uint32_t (&dig)[PER],
                                                uint32_t nd, uint32_t* __restrict__ cursor, uint32_t cap, uint64_t region0,
-                                               uint64_t region_stride, float4* __restrict__ out,
+                                               uint64_t region_stride, const uint32_t* __restrict__ dbase,
+                                               const uint32_t* __restrict__ dcap, float4* __restrict__ out,
                                                PartCounters* __restrict__ pc) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (uint32_t d = tid; d < nd; d += kTileThreads) L.hist[d] = 0u;
@@ -297,8 +300,10 @@ __device__ __forceinline__ void tile_partition(TileLds<PER>& L, const float4 (&r
             L.digit[pos] = (uint8_t)dig[j];
         }
     if ((uint32_t)tid < nd) {
-        if (c && g + c > cap) atomicAdd(&pc->part_overflow, 1u);
+        const uint32_t room = dbase ? dcap[tid] : cap;
+        if (c && g + c > room) atomicAdd(&pc->part_overflow, 1u);
         L.gbase[tid] = g;
+        if (dbase) { L.dbase[tid] = dbase[tid]; L.dcap[tid] = room; }
     }
     __syncthreads();
     const uint32_t total = L.scan[nd];
@@ -308,7 +313,8 @@ __device__ __forceinline__ void tile_partition(TileLds<PER>& L, const float4 (&r
         if (j < total) {
             const uint32_t d = L.digit[j];
             const uint32_t within = L.gbase[d] + (j - L.scan[d]);
-            if (within < cap) out[region0 + (uint64_t)d * region_stride + within] = L.rec[j];
+            if (dbase) { if (within < L.dcap[d]) out[(uint64_t)L.dbase[d] + within] = L.rec[j]; }
+            else if (within < cap) out[region0 + (uint64_t)d * region_stride + within] = L.rec[j];
         }
     }
 }
@@ -320,6 +326,7 @@ template <int STRIDE_FLOATS>
 __global__ void __launch_bounds__(kTileThreads) k_part2_level1(const float* __restrict__ xyz, uint64_t n, uint32_t first_base,
                                                                GridParams P, uint32_t B, uint32_t F1, uint32_t F2_shift, uint32_t R,
                                                                uint32_t* __restrict__ cursor1, uint32_t cap1,
+                                                               uint32_t* __restrict__ est2,
                                                                float4* __restrict__ recs1, Counters* __restrict__ cnt,
                                                                PartCounters* __restrict__ pc) {
     constexpr int PER = kTilePer1;
@@ -359,23 +366,59 @@ __global__ void __launch_bounds__(kTileThreads) k_part2_level1(const float* __re
             const bool same = wave_all_identical(px, py, pz, use);               // 64 identical points -> one weighted record
             dig[j] = 0xFFFFFFFFu;
             if (use && (!same || (threadIdx.x & 63) == 0)) {
-                dig[j] = (bucket_of(column_hash(k.sx, k.sy), B) >> F2_shift) * R + rep;      // F2 is a power of two
+                const uint32_t b = bucket_of(column_hash(k.sx, k.sy), B);
+                dig[j] = (b >> F2_shift) * R + rep;                                  // F2 is a power of two
+                // One record in kSampleEvery votes for its bucket (k_part2_layout sizes the buckets' regions from the
+                // votes).  Chosen by a hash of the point index: a fixed stride would alias with the scan pattern of a
+                // spinning LiDAR (the same azimuths every ring) and with the lane-0 records of compressed waves.
+                if ((((uint32_t)i * 0x9E3779B1u) >> 26) == 0u) atomicAdd(&est2[b], 1u);
                 const uint32_t idx = (first_base + (uint32_t)i) | (same ? kWeight64Flag : 0u);
                 r[j] = make_float4(px, py, pz, __uint_as_float(idx));
             }
         }
-        tile_partition<PER>(L, r, dig, F1 * R, cursor1, cap1, 0ull, (uint64_t)cap1, recs1, pc);
+        tile_partition<PER>(L, r, dig, F1 * R, cursor1, cap1, 0ull, (uint64_t)cap1, nullptr, nullptr, recs1, pc);
         __syncthreads();                                   // the tile's LDS image is reused by the next iteration
     }
+}
+
+// Region of every bucket from the sample level 1 took: capacity = 1.6 x the estimate + 1024 records (a bucket of 2800
+// records has ~44 samples, sigma 15 %: 1.6x + 1024 is 6 sigma; LiDAR clouds' hot columns simply get the room they need),
+// base = exclusive prefix.  One workgroup; writes lo[] (= base) and cap[].
+__global__ void __launch_bounds__(1024) k_part2_layout(const uint32_t* __restrict__ est2, uint32_t B, uint32_t* __restrict__ lo,
+                                                       uint32_t* __restrict__ cap, uint64_t rec_capacity,
+                                                       PartCounters* __restrict__ pc) {
+    __shared__ uint32_t wsum[16];
+    __shared__ uint32_t carry;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) carry = 0;
+    __syncthreads();
+    for (uint32_t b0 = 0; b0 < B; b0 += 1024) {
+        const uint32_t b = b0 + tid;
+        uint32_t c = 0;
+        if (b < B) { c = (uint32_t)(((uint64_t)est2[b] * kSampleEvery * 8) / 5) + 1024u; cap[b] = c; }
+        uint32_t incl = c;
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)incl, o, 64); if (lane >= o) incl += t; }
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        uint32_t base = carry + incl - c;
+        for (int w = 0; w < wave; ++w) base += wsum[w];
+        if (b < B) lo[b] = base;
+        __syncthreads();
+        if (tid == 1023) carry = base + c;
+        __syncthreads();
+    }
+    if (tid == 0 && (uint64_t)carry > rec_capacity) atomicAdd(&pc->part_overflow, 1u);
 }
 
 // level 2: sub-region blockIdx.y (of coarse region blockIdx.y / R), tile blockIdx.x of it -> that region's fine buckets
 __global__ void __launch_bounds__(kTileThreads) k_part2_level2(const float4* __restrict__ recs1, const uint32_t* __restrict__ cursor1,
                                                                uint32_t cap1, uint32_t R, GridParams P, uint32_t B, uint32_t F2,
-                                                               uint32_t* __restrict__ cursor2, uint32_t cap2,
-                                                               float4* __restrict__ recs2, PartCounters* __restrict__ pc) {
+                                                               uint32_t* __restrict__ cursor2, const uint32_t* __restrict__ lo,
+                                                               const uint32_t* __restrict__ cap, float4* __restrict__ recs2,
+                                                               PartCounters* __restrict__ pc) {
     constexpr int PER = kTilePer2;
     __shared__ TileLds<PER> L;
+    if (pc->part_overflow) return;                       // level 1 or the layout already gave up: the build is re-run
     const uint32_t v = blockIdx.y, c = v / R;
     const uint32_t have = min(cursor1[v], cap1);
     const uint32_t t0 = blockIdx.x * (kTileThreads * PER);
@@ -394,31 +437,25 @@ __global__ void __launch_bounds__(kTileThreads) k_part2_level2(const float4* __r
             dig[j] = bucket_of(column_hash(k.sx, k.sy), B) - b0;
         }
     }
-    tile_partition<PER>(L, r, dig, nd, cursor2 + b0, cap2, (uint64_t)b0 * cap2, (uint64_t)cap2, recs2, pc);
+    tile_partition<PER>(L, r, dig, nd, cursor2 + b0, 0u, 0ull, 0ull, lo + b0, cap + b0, recs2, pc);
 }
 
-// the fine buckets' record ranges for the bucket kernel, and the fullest region of either level
-__global__ void __launch_bounds__(256) k_part2_ranges(const uint32_t* __restrict__ cursor1, uint32_t F1,
-                                                      const uint32_t* __restrict__ cursor2, uint32_t cap2, uint32_t B,
-                                                      uint32_t* __restrict__ lo, uint32_t* __restrict__ hi,
+// the fine buckets' record ranges for the bucket kernel (lo[] is the layout's base), and the fullest level-1 region
+__global__ void __launch_bounds__(256) k_part2_ranges(const uint32_t* __restrict__ cursor1, uint32_t V,
+                                                      const uint32_t* __restrict__ cursor2, const uint32_t* __restrict__ cap,
+                                                      uint32_t B, const uint32_t* __restrict__ lo, uint32_t* __restrict__ hi,
                                                       PartCounters* __restrict__ pc) {
-    __shared__ uint32_t m1, m2;
-    if (threadIdx.x == 0) { m1 = 0; m2 = 0; }
+    __shared__ uint32_t m1;
+    if (threadIdx.x == 0) m1 = 0;
     __syncthreads();
-    uint32_t a = 0, b2 = 0;
-    for (uint32_t b = blockIdx.x * blockDim.x + threadIdx.x; b < max(B, F1); b += gridDim.x * blockDim.x) {
-        if (b < B) {
-            const uint32_t c = cursor2[b];
-            lo[b] = b * cap2;
-            hi[b] = b * cap2 + min(c, cap2);
-            b2 = max(b2, c);
-        }
-        if (b < F1) a = max(a, cursor1[b]);      // F1 here = number of level-1 (sub-)regions
+    uint32_t a = 0;
+    for (uint32_t b = blockIdx.x * blockDim.x + threadIdx.x; b < max(B, V); b += gridDim.x * blockDim.x) {
+        if (b < B) hi[b] = lo[b] + min(cursor2[b], cap[b]);
+        if (b < V) a = max(a, cursor1[b]);
     }
     if (a) atomicMax(&m1, a);
-    if (b2) atomicMax(&m2, b2);
     __syncthreads();
-    if (threadIdx.x == 0) { if (m1) atomicMax(&pc->max_fill1, m1); if (m2) atomicMax(&pc->max_fill2, m2); }
+    if (threadIdx.x == 0 && m1) atomicMax(&pc->max_fill1, m1);
 }
 
 // ---------------------------------------------------------------------------------------------
