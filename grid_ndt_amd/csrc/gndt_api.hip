@@ -89,9 +89,10 @@ struct gndt_handle {
         uint64_t hist_cap = 0;     uint32_t* hist = nullptr;
         uint32_t bucket_cap = 0;   uint32_t* totals = nullptr; uint32_t* bucket_base = nullptr;
         uint64_t stage_cap = 0;    StageRow* stage = nullptr;
-        uint32_t *ord_cf = nullptr, *ord_idx = nullptr, *ord_ncol = nullptr, *col_rank = nullptr, *col_size = nullptr,
-                 *col_base = nullptr, *inv = nullptr, *bsum_cols = nullptr;
-        uint64_t word_cap = 0;     uint32_t *bitmap = nullptr, *word_prefix = nullptr, *bsum_words = nullptr;
+        uint32_t *ord_cf = nullptr, *ord_idx = nullptr, *inv = nullptr, *row_ncol = nullptr;
+        // column order (gndt_partition.hpp ColumnOrder): per bitmap word, and per point index for ncol_at
+        uint64_t word_cap = 0;     uint32_t *bitmap = nullptr, *word_weight = nullptr, *word_base = nullptr, *bsum_words = nullptr,
+                                            *ncol_at = nullptr;
         PartCounters* d_pc = nullptr;
         PartCounters* h_pc = nullptr;   // pinned
         unsigned long long* dbg = nullptr;  uint32_t dbg_buckets = 0;   // diagnostic phase stamps (GNDT_STAMPS=1)
@@ -297,8 +298,8 @@ void free_cost(gndt_handle* h) {
 
 void free_part(gndt_handle* h) {
     auto& q = h->part;
-    void* ptrs[] = {q.recs, q.recs1, q.cursors, q.range_lo, q.range_hi, q.range_cap, q.hist, q.totals, q.bucket_base, q.stage, q.ord_cf, q.ord_idx, q.ord_ncol, q.col_rank,
-                    q.col_size, q.col_base, q.inv, q.bsum_cols, q.bitmap, q.word_prefix, q.bsum_words, q.d_pc, q.dbg};
+    void* ptrs[] = {q.recs, q.recs1, q.cursors, q.range_lo, q.range_hi, q.range_cap, q.hist, q.totals, q.bucket_base, q.stage, q.ord_cf, q.ord_idx, q.inv, q.row_ncol,
+                    q.bitmap, q.word_weight, q.word_base, q.bsum_words, q.ncol_at, q.d_pc, q.dbg};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (q.h_pc) (void)hipHostFree(q.h_pc);
@@ -308,15 +309,14 @@ void free_part(gndt_handle* h) {
 int ensure_stage(gndt_handle* h, uint64_t nodes) {
     auto& q = h->part;
     if (nodes <= q.stage_cap) return GNDT_OK;
-    void* ptrs[] = {q.stage, q.ord_cf, q.ord_idx, q.ord_ncol, q.col_rank, q.col_size, q.col_base, q.inv, q.bsum_cols};
+    void* ptrs[] = {q.stage, q.ord_cf, q.ord_idx, q.inv, q.row_ncol};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
-    q.stage = nullptr; q.ord_cf = q.ord_idx = q.ord_ncol = q.col_rank = q.col_size = q.col_base = q.inv = q.bsum_cols = nullptr;
+    q.stage = nullptr; q.ord_cf = q.ord_idx = q.inv = q.row_ncol = nullptr;
     q.stage_cap = 0;
     HIP_TRY(h, hipMalloc(&q.stage, nodes * sizeof(StageRow)));
-    uint32_t** arrs[] = {&q.ord_cf, &q.ord_idx, &q.ord_ncol, &q.col_rank, &q.col_size, &q.col_base, &q.inv};
+    uint32_t** arrs[] = {&q.ord_cf, &q.ord_idx, &q.inv, &q.row_ncol};
     for (auto a : arrs) HIP_TRY(h, hipMalloc(a, nodes * 4));
-    HIP_TRY(h, hipMalloc(&q.bsum_cols, ((nodes + kScanChunk - 1) / kScanChunk + 1) * 4));
     q.stage_cap = nodes;
     return GNDT_OK;
 }
@@ -326,12 +326,14 @@ int ensure_stage(gndt_handle* h, uint64_t nodes) {
 int ensure_words(gndt_handle* h, uint64_t words) {
     auto& q = h->part;
     if (words <= q.word_cap) return GNDT_OK;
-    for (uint32_t** a : {&q.bitmap, &q.word_prefix, &q.bsum_words}) { if (*a) (void)hipFree(*a); *a = nullptr; }
+    for (uint32_t** a : {&q.bitmap, &q.word_weight, &q.word_base, &q.bsum_words, &q.ncol_at}) { if (*a) (void)hipFree(*a); *a = nullptr; }
     q.word_cap = 0;
     words += words / 4;
     HIP_TRY(h, hipMalloc(&q.bitmap, words * 4));
-    HIP_TRY(h, hipMalloc(&q.word_prefix, words * 4));
+    HIP_TRY(h, hipMalloc(&q.word_weight, words * 4));
+    HIP_TRY(h, hipMalloc(&q.word_base, words * 4));
     HIP_TRY(h, hipMalloc(&q.bsum_words, ((words + kScanChunk - 1) / kScanChunk + 1) * 4));
+    HIP_TRY(h, hipMalloc(&q.ncol_at, words * 32 * 4));     // one entry per point index, touched only at column-first indices
     q.word_cap = words;
     return GNDT_OK;
 }
@@ -350,28 +352,20 @@ int ensure_part_counters(gndt_handle* h) {
 int launch_order_and_emit(gndt_handle* h, uint64_t words, int m0, hipStream_t s) {
     auto& q = h->part;
     const uint32_t nbw = (uint32_t)((words + kScanChunk - 1) / kScanChunk);
-    hipLaunchKernelGGL(k_scan_reduce<true>, dim3(nbw), dim3(kScanThreads), 0, s, q.bitmap, (const uint32_t*)nullptr,
+    hipLaunchKernelGGL(k_scan_reduce<false>, dim3(nbw), dim3(kScanThreads), 0, s, q.word_weight, (const uint32_t*)nullptr,
                        (uint32_t)words, q.bsum_words);
-    hipLaunchKernelGGL(k_scan_apply<true>, dim3(nbw), dim3(kScanThreads), 0, s, q.bitmap, (const uint32_t*)nullptr,
-                       (uint32_t)words, q.bsum_words, q.word_prefix);
+    hipLaunchKernelGGL(k_scan_apply<false>, dim3(nbw), dim3(kScanThreads), 0, s, q.word_weight, (const uint32_t*)nullptr,
+                       (uint32_t)words, q.bsum_words, q.word_base);
     HIP_TRY(h, hipGetLastError());
     mark(h, m0 + 1, s);
-    hipLaunchKernelGGL(k_order_rank, dim3(grid_for(q.stage_cap)), dim3(kBlock), 0, s, q.ord_cf, q.ord_idx, q.ord_ncol,
-                       q.bitmap, q.word_prefix, q.col_rank, q.col_size, h->d_cnt, q.d_pc);
-    HIP_TRY(h, hipGetLastError());
-    mark(h, m0 + 2, s);
-    const uint32_t nbc = (uint32_t)((q.stage_cap + kScanChunk - 1) / kScanChunk);
-    hipLaunchKernelGGL(k_scan_reduce<false>, dim3(nbc), dim3(kScanThreads), 0, s, q.col_size, &h->d_cnt->num_columns, 0u,
-                       q.bsum_cols);
-    hipLaunchKernelGGL(k_scan_apply<false>, dim3(nbc), dim3(kScanThreads), 0, s, q.col_size, &h->d_cnt->num_columns, 0u,
-                       q.bsum_cols, q.col_base);
-    HIP_TRY(h, hipGetLastError());
+    mark(h, m0 + 2, s);       // (the column-rank and column-scan passes of earlier versions: phases kept for the ABI, empty)
     mark(h, m0 + 3, s);
-    hipLaunchKernelGGL(k_order_dest, dim3(grid_for(q.stage_cap)), dim3(kBlock), 0, s, q.col_rank, q.ord_idx, q.col_base,
-                       q.inv, h->d_cnt, q.d_pc);
+    hipLaunchKernelGGL(k_order_dest, dim3(grid_for(q.stage_cap)), dim3(kBlock), 0, s, q.ord_cf, q.ord_idx, q.bitmap, q.word_base,
+                       q.ncol_at, q.inv, h->d_cnt, q.d_pc);
     HIP_TRY(h, hipGetLastError());
     mark(h, m0 + 4, s);
-    hipLaunchKernelGGL(k_emit_rows, dim3(grid_for(q.stage_cap)), dim3(kBlock), 0, s, q.stage, q.inv, h->out, h->d_cnt, q.d_pc);
+    hipLaunchKernelGGL(k_emit_rows, dim3(grid_for(q.stage_cap)), dim3(kBlock), 0, s, q.stage, q.inv, h->out, q.row_ncol, h->d_cnt,
+                       q.d_pc);
     HIP_TRY(h, hipGetLastError());
     mark(h, m0 + 5, s);
     return GNDT_OK;
@@ -445,12 +439,12 @@ int do_finalize(gndt_handle* h, hipStream_t s) {
     const GridParams gp = grid_params(h);
     mark(h, 2, s);
     hipLaunchKernelGGL(k_tab_begin, dim3(grid_for(std::max<uint64_t>(words, h->cap / 4), kBlock, 1024)), dim3(kBlock), 0, s, T,
-                       h->d_cnt, q.d_pc, q.bitmap, (uint64_t)words);
+                       h->d_cnt, q.d_pc, q.bitmap, q.word_weight, (uint64_t)words);
     hipLaunchKernelGGL(k_tab_columns, dim3(grid_for(rows_bound)), dim3(kBlock), 0, s, T, gp, h->d_cnt);
     HIP_TRY(h, hipGetLastError());
     mark(h, 3, s);
     hipLaunchKernelGGL(k_tab_rows, dim3(grid_for(rows_bound)), dim3(kBlock), 0, s, T, gp, q.stage, (uint32_t)q.stage_cap,
-                       q.ord_cf, q.ord_idx, q.ord_ncol, q.bitmap, (uint64_t)words, h->d_cnt, q.d_pc);
+                       q.ord_cf, q.ord_idx, ColumnOrder{q.bitmap, q.word_weight, q.ncol_at}, (uint64_t)words, h->d_cnt, q.d_pc);
     HIP_TRY(h, hipGetLastError());
     mark(h, 4, s);
     if ((rc = launch_order_and_emit(h, words, 4, s))) return rc;
@@ -631,7 +625,7 @@ int partition_launch(gndt_handle* h, gndt_handle::Pending& P) {
         mark(h, 0, s);
         if (h->table_dirty) { if ((rc = do_reset(h, s))) return rc; }
         h->results_valid = false;
-        hipLaunchKernelGGL(k_part_clear, dim3(grid_for(words, 256, 512)), dim3(256), 0, s, h->d_cnt, q.d_pc, q.bitmap, (uint64_t)words,
+        hipLaunchKernelGGL(k_part_clear, dim3(grid_for(words, 256, 512)), dim3(256), 0, s, h->d_cnt, q.d_pc, q.bitmap, q.word_weight, (uint64_t)words,
                            q.cursors, (uint32_t)(kMaxFan + 2 * B));
         HIP_TRY(h, hipGetLastError());
         mark(h, 1, s);
@@ -670,7 +664,7 @@ int partition_launch(gndt_handle* h, gndt_handle::Pending& P) {
     // the HBM node table is not used by this strategy, but a previous atomic build may sit in it
     if (h->table_dirty) { if ((rc = do_reset(h, s))) return rc; }
     h->results_valid = false;
-    hipLaunchKernelGGL(k_part_clear, dim3(grid_for(words, 256, 512)), dim3(256), 0, s, h->d_cnt, q.d_pc, q.bitmap, (uint64_t)words,
+    hipLaunchKernelGGL(k_part_clear, dim3(grid_for(words, 256, 512)), dim3(256), 0, s, h->d_cnt, q.d_pc, q.bitmap, q.word_weight, (uint64_t)words,
                        (uint32_t*)nullptr, 0u);
     HIP_TRY(h, hipGetLastError());
     mark(h, 1, s);
@@ -715,7 +709,7 @@ int partition_launch(gndt_handle* h, gndt_handle::Pending& P) {
     {
 #define GNDT_LAUNCH_BUCKET2(T_, H_, CH_, S_)                                                                           \
     hipLaunchKernelGGL((k_bucket_build2<T_, H_, CH_, S_>), dim3(std::min<uint32_t>(B, bucket_wgs)), dim3(T_), 0, s, bucket_recs, range_lo, range_hi, B, gp, q.stage, \
-                       (uint32_t)(S_ ? h->st_cap : q.stage_cap), q.ord_cf, q.ord_idx, q.ord_ncol, q.bitmap, h->d_cnt,   \
+                       (uint32_t)(S_ ? h->st_cap : q.stage_cap), q.ord_cf, q.ord_idx, ColumnOrder{q.bitmap, q.word_weight, q.ncol_at}, h->d_cnt,   \
                        q.d_pc, q.dbg, StatsOut{h->st_key, h->st_sums, h->st_count, h->st_first})
             if (P.stats_only) {
                 if (bslots == 1024) GNDT_LAUNCH_BUCKET2(512, 1024, 3584, true);
@@ -1152,7 +1146,7 @@ int gndt_compute_cost(gndt_handle* h, const float goal_xyz[3], const gndt_robot*
     CostView V;
     V.sx = h->out.sx; V.sy = h->out.sy; V.sz = h->out.sz;
     V.mean = h->out.mean; V.normal = h->out.normal; V.rough = h->out.rough; V.flags = h->out.flags;
-    V.col_base = h->part.col_base; V.col_size = h->part.col_size;
+    V.row_ncol = h->part.row_ncol;
     V.ctab_key = c.ctab_key; V.ctab_val = c.ctab_val; V.ctab_mask = c.ctab_size - 1;
     V.slope_interval = h->P.slope_interval; V.demand_true = h->P.demand == GNDT_DEMAND_TRUE ? 1 : 0;
     // the goal's key through the same codec the build uses (transMortonXYZ, map2D.h:1293)
@@ -1161,8 +1155,8 @@ int gndt_compute_cost(gndt_handle* h, const float goal_xyz[3], const gndt_robot*
     hipLaunchKernelGGL(k_cost_clear, dim3(grid_for(std::max<uint64_t>(n, c.ctab_size))), dim3(256), 0, s, c.h_bits, c.pushed,
                        c.state, (uint32_t)n, c.ctab_key, c.ctab_size, c.d_cc);
     if (K)
-        hipLaunchKernelGGL(k_cost_columns, dim3(grid_for(K)), dim3(256), 0, s, h->out.sx, h->out.sy, h->part.col_base,
-                           (uint32_t)K, c.ctab_key, c.ctab_val, c.ctab_size - 1, c.d_cc);
+        hipLaunchKernelGGL(k_cost_columns, dim3(grid_for(n)), dim3(256), 0, s, h->out.sx, h->out.sy, h->part.row_ncol,
+                           (uint32_t)n, c.ctab_key, c.ctab_val, c.ctab_size - 1, c.d_cc);
     if (gk.ok && K)
         hipLaunchKernelGGL(k_cost_goal, dim3(1), dim3(64), 0, s, V, gk.sx, gk.sy, gk.sz, c.h_bits, c.pushed, c.f[0], c.d_cc);
     HIP_TRY(h, hipGetLastError());
@@ -1291,12 +1285,12 @@ int gndt_finalize_stats_device(gndt_handle* h, const gndt_stats* in, uint64_t to
     if (h->table_dirty) { if ((rc = do_reset(h, s))) return rc; }
     h->results_valid = false;
     mark(h, 0, s);
-    hipLaunchKernelGGL(k_part_clear, dim3(grid_for(words, 256, 512)), dim3(256), 0, s, h->d_cnt, q.d_pc, q.bitmap, (uint64_t)words,
+    hipLaunchKernelGGL(k_part_clear, dim3(grid_for(words, 256, 512)), dim3(256), 0, s, h->d_cnt, q.d_pc, q.bitmap, q.word_weight, (uint64_t)words,
                        (uint32_t*)nullptr, 0u);
     HIP_TRY(h, hipGetLastError());
     mark(h, 4, s);
     hipLaunchKernelGGL(k_stats_rows, dim3(grid_for(std::max<uint64_t>(n, 1))), dim3(kBlock), 0, s, in->key, in->sums, in->count,
-                       in->first_idx, (uint32_t)n, grid_params(h), q.stage, q.ord_cf, q.ord_idx, q.ord_ncol, q.bitmap,
+                       in->first_idx, (uint32_t)n, grid_params(h), q.stage, q.ord_cf, q.ord_idx, ColumnOrder{q.bitmap, q.word_weight, q.ncol_at},
                        (uint64_t)words, h->d_cnt, q.d_pc);
     HIP_TRY(h, hipGetLastError());
     mark(h, 5, s);
@@ -1345,9 +1339,9 @@ int gndt_pack_points_device(gndt_handle* h, const void* raw_dev, size_t n, const
     hipLaunchKernelGGL(k_scan_reduce<true>, dim3(nbw), dim3(kScanThreads), 0, s, q.bitmap, (const uint32_t*)nullptr,
                        (uint32_t)words, q.bsum_words);
     hipLaunchKernelGGL(k_scan_apply<true>, dim3(nbw), dim3(kScanThreads), 0, s, q.bitmap, (const uint32_t*)nullptr,
-                       (uint32_t)words, q.bsum_words, q.word_prefix);
+                       (uint32_t)words, q.bsum_words, q.word_base);
     hipLaunchKernelGGL(k_pack_write, dim3(grid_for(n, 256, 256 * 16)), dim3(256), 0, s, raw, (uint64_t)n, L, q.bitmap,
-                       q.word_prefix, xyz_out_dev, h->d_nvalid);
+                       q.word_base, xyz_out_dev, h->d_nvalid);
     HIP_TRY(h, hipGetLastError());
     HIP_TRY(h, hipMemcpyAsync(h->h_nvalid, h->d_nvalid, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     HIP_TRY(h, hipStreamSynchronize(s));

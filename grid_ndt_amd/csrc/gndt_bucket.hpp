@@ -68,7 +68,7 @@ __device__ __forceinline__ void bucket_build_one(BucketLds2<H, CH>& L, const uin
                                                  const uint32_t* __restrict__ range_hi, const GridParams& P,
                                                  StageRow* __restrict__ stage, uint32_t stage_cap,
                                                  uint32_t* __restrict__ ord_cf, uint32_t* __restrict__ ord_idx,
-                                                 uint32_t* __restrict__ ord_ncol, uint32_t* __restrict__ bitmap,
+                                                 const ColumnOrder& O,
                                                  Counters* __restrict__ cnt, PartCounters* __restrict__ pc,
                                                  unsigned long long* __restrict__ dbg, const StatsOut& so,
                                                  float4 (&pre)[CH / T], uint32_t& pre_bucket, uint32_t& pre_cbeg) {
@@ -363,10 +363,7 @@ __device__ __forceinline__ void bucket_build_one(BucketLds2<H, CH>& L, const uin
         stage[dst] = row;
         ord_cf[dst] = cf;
         ord_idx[dst] = idx_in_col;
-        if (idx_in_col == 0) {
-            ord_ncol[dst] = row.ncol;
-            atomicOr(&bitmap[cf >> 5], 1u << (cf & 31u));
-        }
+        if (idx_in_col == 0) note_column(O, cf, row.ncol);
     }
     // counters: aggregated in LDS, ONE memory-side atomic per bucket and counter (same-address global atomics
     // serialise at the memory side and slow every other request down with them)
@@ -387,7 +384,7 @@ __global__ void __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) 
                                                      const uint32_t* __restrict__ range_hi, uint32_t num_buckets,
                                                      GridParams P, StageRow* __restrict__ stage, uint32_t stage_cap,
                                                      uint32_t* __restrict__ ord_cf, uint32_t* __restrict__ ord_idx,
-                                                     uint32_t* __restrict__ ord_ncol, uint32_t* __restrict__ bitmap,
+                                                     ColumnOrder O,
                                                      Counters* __restrict__ cnt, PartCounters* __restrict__ pc,
                                                      unsigned long long* __restrict__ dbg, StatsOut so) {
     __shared__ BucketLds2<H, CH> L;
@@ -395,7 +392,7 @@ __global__ void __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) 
     uint32_t pre_bucket = 0xFFFFFFFFu, pre_cbeg = 0;
     for (uint32_t bucket = blockIdx.x; bucket < num_buckets; bucket += gridDim.x) {
         bucket_build_one<T, H, CH, STATS>(L, bucket, num_buckets, recs, range_lo, range_hi, P, stage, stage_cap, ord_cf, ord_idx,
-                                          ord_ncol, bitmap, cnt, pc, dbg, so, pre, pre_bucket, pre_cbeg);
+                                          O, cnt, pc, dbg, so, pre, pre_bucket, pre_cbeg);
         __syncthreads();        // the LDS tables are re-initialised by the next bucket
     }
 }

@@ -48,9 +48,9 @@ struct CostView {
     const int32_t *sx, *sy, *sz;
     const float *mean, *normal, *rough;
     const uint32_t* flags;
-    // columns by rank: rows [col_base[c], col_base[c] + col_size[c])
-    const uint32_t *col_base, *col_size;
-    // (sx, sy) -> column rank, open addressing
+    // row_ncol[r] = number of nodes of the column that STARTS at row r (its nodes are rows [r, r + row_ncol[r])), 0 elsewhere
+    const uint32_t* row_ncol;
+    // (sx, sy) -> first row of the column, open addressing
     const uint64_t* ctab_key;
     const uint32_t* ctab_val;
     uint32_t ctab_mask;
@@ -115,7 +115,7 @@ GNDT_HD bool row_up(const CostView& V, uint32_t row) {
     if (c == kNoColumn) return false;
     const int zadd = level_above(V.sz[row]);
     const float mz = V.mean[3 * row + 2];
-    const uint32_t b = V.col_base[c], e = b + V.col_size[c];
+    const uint32_t b = c, e = c + V.row_ncol[c];
     for (uint32_t t = b; t < e; ++t) {
         if (V.sz[t] != zadd) continue;
         const float cz = (V.flags[t] & 1u) ? V.mean[3 * t + 2] : 0.f;
@@ -155,7 +155,7 @@ GNDT_HD int cost_collide(const CostView& V, const Robot& R, uint32_t slope, int 
             neighbour_columns(V, cur, col);
             for (int k = 0; k < 4; ++k) {
                 if (col[k] == kNoColumn) continue;
-                const uint32_t b = V.col_base[col[k]], e = b + V.col_size[col[k]];
+                const uint32_t b = col[k], e = b + V.row_ncol[b];
                 for (uint32_t t = b; t < e; ++t) {
                     if (!row_has_slope(V, t)) continue;
                     // comand 3 (3D ring): every slope of the cell; comand 2.5: up == false and the three gates
@@ -181,7 +181,7 @@ GNDT_HD int cost_collide(const CostView& V, const Robot& R, uint32_t slope, int 
     // the next slope above in the same cell (map_slope is ascending in z)
     const uint32_t c = ctab_find(V, V.sx[slope], V.sy[slope]);
     if (c == kNoColumn) return 0;
-    const uint32_t b = V.col_base[c], e = b + V.col_size[c];
+    const uint32_t b = c, e = c + V.row_ncol[c];
     const int myz = V.sz[slope];
     uint32_t next = kNoColumn;
     int next_z = 0;
@@ -219,7 +219,7 @@ GNDT_HD uint32_t cost_expand_dir(const CostView& V, const Robot& R, uint32_t q, 
                                 : ctab_find(V, step_skip0(sx, -1), sy);
     if (c == kNoColumn) return 0u;
     uint32_t checks = 0;
-    const uint32_t b = V.col_base[c], e = b + V.col_size[c];
+    const uint32_t b = c, e = c + V.row_ncol[c];
     for (uint32_t t = b; t < e; ++t) {
         if (!row_has_slope(V, t)) continue;
         ++checks;                                   // checkList.push_back (up is false / not consulted)
@@ -263,13 +263,13 @@ __global__ void __launch_bounds__(256) k_cost_clear(uint32_t* __restrict__ h_bit
     }
 }
 
-// column rank -> hash table entry keyed by the column's (sx, sy)
+// first row of every column -> hash table entry keyed by the column's (sx, sy)
 __global__ void __launch_bounds__(256) k_cost_columns(const int32_t* __restrict__ sx, const int32_t* __restrict__ sy,
-                                                      const uint32_t* __restrict__ col_base, uint32_t num_columns,
+                                                      const uint32_t* __restrict__ row_ncol, uint32_t num_rows,
                                                       uint64_t* __restrict__ ctab_key, uint32_t* __restrict__ ctab_val,
                                                       uint32_t ctab_mask, CostCounters* __restrict__ cc) {
-    for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < num_columns; c += gridDim.x * blockDim.x) {
-        const uint32_t row = col_base[c];
+    for (uint32_t row = blockIdx.x * blockDim.x + threadIdx.x; row < num_rows; row += gridDim.x * blockDim.x) {
+        if (row_ncol[row] == 0u) continue;              // not the first row of a column
         const int x = sx[row], y = sy[row];
         if (abs(x) > kCostMaxXY || abs(y) > kCostMaxXY) atomicAdd(&cc->range_error, 1u);
         const uint64_t key = column_pack(x, y);
@@ -277,7 +277,7 @@ __global__ void __launch_bounds__(256) k_cost_columns(const int32_t* __restrict_
         for (;;) {
             const unsigned long long old = atomicCAS((unsigned long long*)&ctab_key[s], (unsigned long long)kEmptyKey,
                                                      (unsigned long long)key);
-            if (old == kEmptyKey) { ctab_val[s] = c; break; }
+            if (old == kEmptyKey) { ctab_val[s] = row; break; }
             s = (s + 1) & ctab_mask;
         }
     }
@@ -290,7 +290,7 @@ __global__ void k_cost_goal(CostView V, int gx, int gy, int gz, uint32_t* __rest
     const uint32_t c = ctab_find(V, gx, gy);
     if (c == kNoColumn) { cc->goal_status = 1; return; }
     cc->goal_status = 2;
-    const uint32_t b = V.col_base[c], e = b + V.col_size[c];
+    const uint32_t b = c, e = c + V.row_ncol[c];
     for (uint32_t t = b; t < e; ++t) {
         if (V.sz[t] == gz && row_has_slope(V, t)) {
             h_bits[t] = 0u;

@@ -12,7 +12,7 @@
 //   k_bucket_build2  (gndt_bucket.hpp) one workgroup per bucket: LDS node table, sort-based accumulation,
 //                    column lists, slope labels, mean + fp64 scatter -> 128-B staging rows
 //                                                                                   reads 16 B/pt, writes 128 B/node
-//   k_scan_*         bitmap of column-first point indices -> column rank; column sizes -> row offsets
+//   k_scan_*         prefix of the per-word column weights (ColumnOrder)
 //   k_order_*        destination row of every node (reference order), inverse permutation
 //   k_emit_rows      staging rows -> SoA result in reference order                 reads 128, writes 76 B/node
 //
@@ -51,6 +51,22 @@ struct alignas(16) StageRow {   // 128 bytes = two 64-B lines, gathered whole by
     uint32_t pad[8];
 };
 static_assert(sizeof(StageRow) == 128, "StageRow layout");
+
+// What the producer of the staging rows records for every column, at the column's first-seen point index cf (the
+// row with idx_in_col == 0 does it).  The final row of a node is then
+//     (nodes of the columns first seen before cf) + idx_in_col
+//   = exclusive prefix of word_weight up to word cf>>5  +  ncol_at of the earlier columns inside that word  + idx_in_col,
+// which needs one scan over the bitmap words and no sort, no column ranks, no scan over the columns.
+struct ColumnOrder {
+    uint32_t* bitmap;        // bit cf
+    uint32_t* word_weight;   // [cf >> 5] += nodes of the column
+    uint32_t* ncol_at;       // [cf] = nodes of the column (read only where the bit is set)
+};
+__device__ __forceinline__ void note_column(const ColumnOrder& O, uint32_t cf, uint32_t ncol) {
+    atomicOr(&O.bitmap[cf >> 5], 1u << (cf & 31u));
+    atomicAdd(&O.word_weight[cf >> 5], ncol);
+    O.ncol_at[cf] = ncol;
+}
 
 __host__ __device__ __forceinline__ uint32_t column_hash(int sx, int sy) {
     uint32_t h = (uint32_t)sx * 0x9E3779B1u ^ (uint32_t)sy * 0x85EBCA77u;
@@ -92,14 +108,14 @@ __device__ __forceinline__ void wg_range(uint64_t n, uint32_t nwg, uint32_t w, u
 
 // one launch that prepares a build: counters, partition flags and the column-first bitmap
 __global__ void __launch_bounds__(256) k_part_clear(Counters* __restrict__ cnt, PartCounters* __restrict__ pc,
-                                                    uint32_t* __restrict__ bitmap, uint64_t words,
-                                                    uint32_t* __restrict__ cursors, uint32_t n_cursors) {
+                                                    uint32_t* __restrict__ bitmap, uint32_t* __restrict__ word_weight,
+                                                    uint64_t words, uint32_t* __restrict__ cursors, uint32_t n_cursors) {
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         cnt->num_nodes = 0; cnt->num_columns = 0; cnt->num_slopes = 0; cnt->err_key_range = 0; cnt->err_table_full = 0;
         pc->lds_overflow = 0; pc->stage_overflow = 0; pc->index_overflow = 0; pc->part_overflow = 0;
         pc->max_fill1 = 0;
     }
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < words; i += (uint64_t)gridDim.x * blockDim.x) bitmap[i] = 0u;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < words; i += (uint64_t)gridDim.x * blockDim.x) { bitmap[i] = 0u; word_weight[i] = 0u; }
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_cursors; i += gridDim.x * blockDim.x) cursors[i] = 0u;   // two-level partition
 }
 
@@ -570,42 +586,34 @@ __global__ void __launch_bounds__(kScanThreads) k_scan_apply(const uint32_t* __r
 // ---------------------------------------------------------------------------------------------
 // ordering
 // ---------------------------------------------------------------------------------------------
-// column rank of every staged node = number of column-first bits below its column's first index
-__global__ void __launch_bounds__(kBlock) k_order_rank(const uint32_t* __restrict__ ord_cf, const uint32_t* __restrict__ ord_idx,
-                                                       const uint32_t* __restrict__ ord_ncol,
-                                                       const uint32_t* __restrict__ bitmap, const uint32_t* __restrict__ word_prefix,
-                                                       uint32_t* __restrict__ col_rank, uint32_t* __restrict__ col_size,
+// destination row of every staged node (see ColumnOrder), as the inverse permutation the emit kernel gathers by
+__global__ void __launch_bounds__(kBlock) k_order_dest(const uint32_t* __restrict__ ord_cf, const uint32_t* __restrict__ ord_idx,
+                                                       const uint32_t* __restrict__ bitmap, const uint32_t* __restrict__ word_base,
+                                                       const uint32_t* __restrict__ ncol_at, uint32_t* __restrict__ inv,
                                                        const Counters* __restrict__ cnt, const PartCounters* __restrict__ pc) {
     if (pc->lds_overflow | pc->stage_overflow | pc->index_overflow | pc->part_overflow) return;   // the host re-runs the build; staged rows are incomplete
     const uint32_t n = cnt->num_nodes;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const uint32_t cf = ord_cf[i];
-        const uint32_t w = cf >> 5, bit = cf & 31u;
-        const uint32_t rank = word_prefix[w] + (uint32_t)__popc(bitmap[w] & ((1u << bit) - 1u));
-        col_rank[i] = rank;
-        if (ord_idx[i] == 0) col_size[rank] = ord_ncol[i];
+        const uint32_t w = cf >> 5;
+        uint32_t m = bitmap[w] & ((1u << (cf & 31u)) - 1u);       // columns first seen earlier inside the same word (rare)
+        uint32_t row = word_base[w] + ord_idx[i];
+        while (m) { row += ncol_at[(w << 5) + (uint32_t)__builtin_ctz(m)]; m &= m - 1u; }
+        inv[row] = i;
     }
-}
-
-__global__ void __launch_bounds__(kBlock) k_order_dest(const uint32_t* __restrict__ col_rank, const uint32_t* __restrict__ ord_idx,
-                                                       const uint32_t* __restrict__ col_base, uint32_t* __restrict__ inv,
-                                                       const Counters* __restrict__ cnt, const PartCounters* __restrict__ pc) {
-    if (pc->lds_overflow | pc->stage_overflow | pc->index_overflow | pc->part_overflow) return;
-    const uint32_t n = cnt->num_nodes;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
-        inv[col_base[col_rank[i]] + ord_idx[i]] = i;
 }
 
 // staging rows -> SoA result rows in reference order
 __global__ void __launch_bounds__(kBlock) k_emit_rows(const StageRow* __restrict__ stage, const uint32_t* __restrict__ inv,
-                                                      OutView out, const Counters* __restrict__ cnt,
-                                                      const PartCounters* __restrict__ pc) {
+                                                      OutView out, uint32_t* __restrict__ row_ncol,
+                                                      const Counters* __restrict__ cnt, const PartCounters* __restrict__ pc) {
     if (pc->lds_overflow | pc->stage_overflow | pc->index_overflow | pc->part_overflow) return;
     const uint32_t n = cnt->num_nodes;
     for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x) {
         const StageRow row = stage[inv[r]];
         out.sx[r] = row.sx; out.sy[r] = row.sy; out.sz[r] = row.sz;
         out.count[r] = row.count; out.first_idx[r] = row.first; out.flags[r] = row.flags;
+        row_ncol[r] = row.idx_in_col == 0u ? row.ncol : 0u;        // the consumers' column index (gndt_cost.hpp)
         float rough = 0.f, normal[3] = {0.f, 0.f, 0.f};
         if (row.flags & 1u) node_rough_normal(row.scatter, rough, normal);
         for (int k = 0; k < 3; ++k) { out.mean[3 * r + k] = row.mean[k]; out.normal[3 * r + k] = normal[k]; }

@@ -24,10 +24,11 @@ struct TableView {
 };
 
 __global__ void __launch_bounds__(kBlock) k_tab_begin(TableView T, Counters* __restrict__ cnt, PartCounters* __restrict__ pc,
-                                                      uint32_t* __restrict__ bitmap, uint64_t words) {
+                                                      uint32_t* __restrict__ bitmap, uint32_t* __restrict__ word_weight,
+                                                      uint64_t words) {
     const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, gsz = (uint64_t)gridDim.x * blockDim.x;
     if (gid == 0) { cnt->num_columns = 0; cnt->num_slopes = 0; pc->lds_overflow = 0; pc->stage_overflow = 0; pc->index_overflow = 0; pc->part_overflow = 0; }
-    for (uint64_t i = gid; i < words; i += gsz) bitmap[i] = 0u;
+    for (uint64_t i = gid; i < words; i += gsz) { bitmap[i] = 0u; word_weight[i] = 0u; }
     const uint32_t np = cnt->prev_nodes;
     for (uint64_t i = gid; i < np; i += gsz) {
         const uint32_t cs = T.col_slot_of_node[i];
@@ -69,8 +70,7 @@ __global__ void __launch_bounds__(kBlock) k_tab_columns(TableView T, GridParams 
 
 __global__ void __launch_bounds__(kBlock) k_tab_rows(TableView T, GridParams P, StageRow* __restrict__ stage, uint32_t stage_cap,
                                                      uint32_t* __restrict__ ord_cf, uint32_t* __restrict__ ord_idx,
-                                                     uint32_t* __restrict__ ord_ncol, uint32_t* __restrict__ bitmap,
-                                                     uint64_t words, Counters* __restrict__ cnt,
+                                                     ColumnOrder O, uint64_t words, Counters* __restrict__ cnt,
                                                      PartCounters* __restrict__ pc) {
     __shared__ uint32_t s_slopes, s_cols;
     if (threadIdx.x == 0) { s_slopes = 0; s_cols = 0; }
@@ -124,9 +124,8 @@ __global__ void __launch_bounds__(kBlock) k_tab_rows(TableView T, GridParams P, 
         ord_cf[i] = cf;
         ord_idx[i] = icol;
         if (icol == 0) {
-            ord_ncol[i] = row.ncol;
             // the bitmap was sized from the host's view of the stream (max_points_hint for captured updates)
-            if ((uint64_t)(cf >> 5) < words) atomicOr(&bitmap[cf >> 5], 1u << (cf & 31u));
+            if ((uint64_t)(cf >> 5) < words) note_column(O, cf, row.ncol);
             else atomicAdd(&pc->index_overflow, 1u);
             ++my_cols;
         }
@@ -154,8 +153,7 @@ __global__ void __launch_bounds__(kBlock) k_stats_rows(const uint64_t* __restric
                                                        const uint32_t* __restrict__ count, const uint32_t* __restrict__ first,
                                                        uint32_t n, GridParams P, StageRow* __restrict__ stage,
                                                        uint32_t* __restrict__ ord_cf, uint32_t* __restrict__ ord_idx,
-                                                       uint32_t* __restrict__ ord_ncol, uint32_t* __restrict__ bitmap,
-                                                       uint64_t words, Counters* __restrict__ cnt,
+                                                       ColumnOrder O, uint64_t words, Counters* __restrict__ cnt,
                                                        PartCounters* __restrict__ pc) {
     __shared__ uint32_t s_slopes, s_cols;
     if (threadIdx.x == 0) { s_slopes = 0; s_cols = 0; }
@@ -211,8 +209,7 @@ __global__ void __launch_bounds__(kBlock) k_stats_rows(const uint64_t* __restric
         ord_cf[i] = cf;
         ord_idx[i] = icol;
         if (icol == 0) {
-            ord_ncol[i] = row.ncol;
-            if ((uint64_t)(cf >> 5) < words) atomicOr(&bitmap[cf >> 5], 1u << (cf & 31u));
+            if ((uint64_t)(cf >> 5) < words) note_column(O, cf, row.ncol);
             else atomicAdd(&pc->index_overflow, 1u);
             ++my_cols;
         }

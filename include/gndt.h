@@ -247,7 +247,8 @@ void gndt_unpack_key(uint64_t key, int32_t* sx, int32_t* sy, int32_t* sz);
  * phase; gndt_get_phase_times waits for them and returns milliseconds (-1 = phase did not run).
  * Phase names depend on the strategy the last build used (gndt_last_strategy):
  *   ATOMIC:    [0] clear  [1] accumulate  [2] columns  [3] rows  [4] bitmap_scan  [5] rank
- *              [6] column_scan  [7] dest  [8] emit
+ *              [6] column_scan  [7] dest  [8] emit   (bitmap_scan = prefix of the per-word column weights; rank and
+ *              column_scan are empty since the ordering needs neither: kept so that phase indices stay put)
  *   PARTITION_EXACT: [0] clear  [1] hist  [2] offsets  [3] scatter  [4] bucket_build  [5] bitmap_scan
  *              [6] rank  [7] column_scan  [8] dest  [9] emit
  *   PARTITION (two-level): as PARTITION_EXACT with [1] level1  [2] (unused)  [3] level2 */

@@ -57,10 +57,10 @@ extern "C" int shim_cost(uint64_t n, const int32_t* sx, const int32_t* sy, const
                          uint8_t* state_out, int64_t stats[6]) {
     using namespace gndt;
     // columns are contiguous in the reference order
-    std::vector<uint32_t> col_base, col_size;
+    std::vector<uint32_t> col_base, row_ncol(n ? n : 1, 0u);
     for (uint64_t i = 0; i < n; ++i) {
-        if (i == 0 || sx[i] != sx[i - 1] || sy[i] != sy[i - 1]) { col_base.push_back((uint32_t)i); col_size.push_back(0); }
-        ++col_size.back();
+        if (i == 0 || sx[i] != sx[i - 1] || sy[i] != sy[i - 1]) col_base.push_back((uint32_t)i);
+        ++row_ncol[col_base.back()];
     }
     uint32_t tsize = 1024;
     while (tsize < 2 * col_base.size()) tsize <<= 1;
@@ -70,9 +70,9 @@ extern "C" int shim_cost(uint64_t n, const int32_t* sx, const int32_t* sy, const
         const uint64_t key = column_pack(sx[col_base[c]], sy[col_base[c]]);
         uint32_t s = (uint32_t)mix64(key) & (tsize - 1);
         while (tkey[s] != kEmptyKey) s = (s + 1) & (tsize - 1);
-        tkey[s] = key; tval[s] = c;
+        tkey[s] = key; tval[s] = col_base[c];
     }
-    CostView V{sx, sy, sz, mean, normal, rough, flags, col_base.data(), col_size.data(), tkey.data(), tval.data(), tsize - 1,
+    CostView V{sx, sy, sz, mean, normal, rough, flags, row_ncol.data(), tkey.data(), tval.data(), tsize - 1,
                slope_interval, demand_true};
     Robot R{robot4[0], robot4[1], robot4[2], robot4[3]};
     const int ring_n = cost_ring_depth(R.r, grid_len);
@@ -82,7 +82,7 @@ extern "C" int shim_cost(uint64_t n, const int32_t* sx, const int32_t* sy, const
     const uint32_t gc = ctab_find(V, gx, gy);
     if (gc != kNoColumn) {
         goal_status = 2;
-        for (uint32_t t = col_base[gc]; t < col_base[gc] + col_size[gc]; ++t)
+        for (uint32_t t = gc; t < gc + row_ncol[gc]; ++t)
             if (sz[t] == gz && row_has_slope(V, t)) { hb[t] = 0; pushed[t] = 1; frontier.push_back(t); goal_status = 0; break; }
     }
     while (!frontier.empty()) {
