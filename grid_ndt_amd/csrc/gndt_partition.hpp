@@ -6,6 +6,11 @@
 // that one workgroup owns every node of its bucket's columns and can keep their statistics, the slope
 // labels and the in-bucket ordering in LDS:
 //
+//   partition, large builds: two levels through LDS tile sorts, no counting passes (see "Two-level partition" below)
+//   k_part2_level1   points -> {x,y,z,idx} records grouped by coarse region        reads 12, writes 16 B/pt
+//   k_part2_layout   the buckets' regions from level 1's 1-in-64 sample
+//   k_part2_level2   coarse regions -> buckets                                     reads 16, writes 16 B/pt
+//   partition, small builds and the fallback: exact single-level counting partition
 //   k_part_hist      points -> bucket histogram per workgroup                      reads 12 B/pt
 //   k_part_offsets   per-bucket exclusive scan over workgroups (+ bucket totals)
 //   k_part_scatter   points -> {x,y,z,idx} records grouped by bucket               reads 12, writes 16 B/pt
@@ -17,8 +22,9 @@
 //   k_emit_rows      staging rows -> SoA result in reference order                 reads 128, writes 76 B/node
 //
 // Reference semantics are the ones of gndt_kernels.hpp (same gndt_math.hpp arithmetic); only the data
-// movement differs.  Anything that does not fit (LDS table overflow, staging overflow) raises a flag
-// and the host re-runs the build on the atomic path, so results never depend on the strategy.
+// movement differs.  Anything that does not fit (LDS table overflow, staging overflow, a partition region) raises
+// a flag and the host re-runs the build with more room, in the end on the atomic path: results never depend on
+// the strategy.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
