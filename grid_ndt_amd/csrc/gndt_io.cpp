@@ -3,7 +3,9 @@
 // HEIGHT, VIEWPOINT, POINTS, DATA) followed by `DATA ascii` (one point per line) or `DATA binary` (POINTS records
 // of sum(SIZE*COUNT) bytes).  Only what the path needs is kept: where x, y, z sit in a record.  The payload is
 // handed on as it is in the file (binary) or as packed xyz (ascii); NaN stripping and unpacking happen on the GPU
-// (gndt_pack.hpp).  `binary_compressed` (LZF) is not read.
+// (gndt_pack.hpp).  `DATA binary_compressed` is PCL's own container: two uint32 (compressed size, uncompressed size),
+// then an LZF stream (Marc Lehmann's liblzf format, restated below from its published description) whose output holds
+// the fields one after the other (all x, then all y, ...: structure of arrays); it is de-interleaved into records here.
 #include <errno.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -20,6 +22,31 @@ namespace {
 
 void set_err(char err[256], const std::string& m) {
     if (err) { strncpy(err, m.c_str(), 255); err[255] = 0; }
+}
+
+// LZF decompression.  A control byte c < 32 starts a literal run of c + 1 bytes; otherwise it is a back reference of
+// length (c >> 5) + 2 (a length field of 7 is extended by the next byte) at distance ((c & 31) << 8 | next byte) + 1.
+// Returns the number of bytes produced, or 0 on a malformed stream.
+size_t lzf_decompress(const unsigned char* in, size_t in_len, unsigned char* out, size_t out_len) {
+    size_t ip = 0, op = 0;
+    while (ip < in_len) {
+        unsigned ctrl = in[ip++];
+        if (ctrl < 32) {
+            const size_t run = ctrl + 1;
+            if (ip + run > in_len || op + run > out_len) return 0;
+            memcpy(out + op, in + ip, run);
+            ip += run; op += run;
+        } else {
+            size_t len = ctrl >> 5;
+            if (len == 7) { if (ip >= in_len) return 0; len += in[ip++]; }
+            if (ip >= in_len) return 0;
+            const size_t dist = ((size_t)(ctrl & 31u) << 8 | in[ip++]) + 1;
+            len += 2;
+            if (dist > op || op + len > out_len) return 0;
+            for (size_t k = 0; k < len; ++k, ++op) out[op] = out[op - dist];     // may overlap: byte by byte
+        }
+    }
+    return op;
 }
 
 std::vector<std::string> split(const std::string& line) {
@@ -113,8 +140,29 @@ int gndt_pcd_read(const char* path, gndt_pcd* out, char err[256]) {
                 p = end;
             }
         }
+    } else if (data_kind == "binary_compressed") {
+        out->data_kind = 2;
+        out->layout.point_step = step; out->layout.offset_x = off[0]; out->layout.offset_y = off[1]; out->layout.offset_z = off[2];
+        uint32_t sizes2[2];
+        if (fread(sizes2, 4, 2, f) != 2) return fail("binary_compressed: missing size words");
+        const size_t csize = sizes2[0], usize = sizes2[1];
+        if (usize != (size_t)points * step) return fail("binary_compressed: uncompressed size is not POINTS * record size");
+        std::vector<unsigned char> comp(csize ? csize : 1), soa(usize ? usize : 1);
+        if (fread(comp.data(), 1, csize, f) != csize) return fail("binary_compressed: payload shorter than its size word");
+        if (usize && lzf_decompress(comp.data(), csize, soa.data(), usize) != usize) return fail("binary_compressed: malformed LZF stream");
+        unsigned char* rec = (unsigned char*)malloc(usize ? usize : 1);
+        if (!rec) return fail("out of memory");
+        out->data = rec;
+        // structure of arrays (field after field, each with POINTS * SIZE * COUNT bytes) -> array of records
+        size_t src = 0, foff = 0;
+        for (size_t fi = 0; fi < fields.size(); ++fi) {
+            const size_t fbytes = (size_t)sizes[fi] * counts[fi];
+            for (uint64_t i = 0; i < points; ++i) memcpy(rec + i * step + foff, soa.data() + src + i * fbytes, fbytes);
+            src += (size_t)points * fbytes;
+            foff += fbytes;
+        }
     } else {
-        return fail("DATA " + data_kind + " is not supported (ascii and binary are)");
+        return fail("DATA " + data_kind + " is not supported (ascii, binary and binary_compressed are)");
     }
     fclose(f);
     return GNDT_OK;

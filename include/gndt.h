@@ -209,11 +209,11 @@ typedef struct gndt_point_layout {
 } gndt_point_layout;
 
 /* A .pcd file as pcl::io::loadPCDFile reads it (src/publisher.cpp:19): header + payload.  `DATA binary` payloads are
- * returned as they are in the file (`layout` says where x, y, z are), `DATA ascii` as packed xyz.  Host-only. */
+ * returned as they are in the file (binary_compressed ones after LZF decompression and re-interleaving) (`layout` says where x, y, z are), `DATA ascii` as packed xyz.  Host-only. */
 typedef struct gndt_pcd {
     uint64_t num_points;
     gndt_point_layout layout;
-    int32_t data_kind;          /* 0 ascii (converted), 1 binary */
+    int32_t data_kind;          /* 0 ascii (converted to packed xyz), 1 binary, 2 binary_compressed (decompressed, records rebuilt) */
     int32_t reserved;
     void* data;                 /* num_points * layout.point_step bytes, released by gndt_pcd_free */
 } gndt_pcd;

@@ -25,6 +25,51 @@ def _write_pcd(path, fields, sizes, types, counts, arr_bytes, n, kind, ascii_row
             f.write(("\n".join(ascii_rows) + "\n").encode())
 
 
+def _lzf_compress(data):
+    """A small LZF encoder for the fixtures (greedy, hash of 3 bytes): literal runs of <= 32 bytes and back references of
+    3..264 bytes at distances <= 8192 — every construct the decoder has to handle."""
+    data = bytes(data)
+    n = len(data)
+    out = bytearray()
+    lit = bytearray()
+    table = {}
+    i = 0
+
+    def flush():
+        k = 0
+        while k < len(lit):
+            run = lit[k:k + 32]
+            out.append(len(run) - 1)
+            out.extend(run)
+            k += 32
+        lit.clear()
+
+    while i < n:
+        key = data[i:i + 3]
+        j = table.get(key, -1) if i + 3 <= n else -1
+        if i + 3 <= n:
+            table[key] = i
+        if j >= 0 and i - j <= 8192:
+            m = 3
+            while i + m < n and m < 264 and data[j + m] == data[i + m]:
+                m += 1
+            flush()
+            dist = i - j - 1
+            ln = m - 2
+            if ln < 7:
+                out.append((ln << 5) | (dist >> 8))
+            else:
+                out.append((7 << 5) | (dist >> 8))
+                out.append(ln - 7)
+            out.append(dist & 0xFF)
+            i += m
+        else:
+            lit.append(data[i])
+            i += 1
+    flush()
+    return bytes(out)
+
+
 def _cloud_with_nans(n, seed=3):
     rng = np.random.default_rng(seed)
     xyz = (rng.random((n, 3)) * 40 - 20).astype(np.float32)
@@ -64,11 +109,29 @@ def test_pcd_reader_binary_and_ascii(tmp_path, native_lib):
     raw, step, off = g.read_pcd(p)
     assert (step, off) == (12, (0, 4, 8))
     assert np.array_equal(raw.view(np.float32).reshape(n, 3), xyz, equal_nan=True)    # %.9g round-trips fp32
-    # errors: missing file, compressed payload, truncated payload, no xyz
+    # binary_compressed: LZF over the fields stored one after the other (all x, all y, ...), here with runs that compress
+    q = xyz.copy()
+    q[100:900, 2] = 1.25                                    # a constant stretch -> long back references
+    q[2000:2600] = q[1000:1600]                             # a repeated block
+    a = np.zeros(n, rec)
+    a["x"], a["y"], a["z"], a["i"], a["rgb"] = q[:, 0], q[:, 1], q[:, 2], 3.0, 0x00112233
+    soa = b"".join(np.ascontiguousarray(a[f]).tobytes() for f in ("i", "x", "y", "rgb", "z", "nrm", "ring"))
+    comp = _lzf_compress(soa)
+    assert len(comp) < len(soa)
+    payload = np.array([len(comp), len(soa)], "<u4").tobytes() + comp
+    p = str(tmp_path / "lzf.pcd")
+    _write_pcd(p, ["intensity", "x", "y", "rgb", "z", "normal", "ring"], [4, 4, 4, 4, 4, 4, 2], ["F", "F", "F", "U", "F", "F", "U"],
+               [1, 1, 1, 1, 1, 3, 2], payload, n, "binary_compressed")
+    raw, step, off = g.read_pcd(p)
+    assert step == 36 and off == (4, 8, 16)
+    assert raw.tobytes() == a.tobytes()                     # records rebuilt byte for byte
+    # errors: missing file, corrupt compressed payload, truncated payload, no xyz
     with pytest.raises(g.GndtError):
         g.read_pcd(str(tmp_path / "missing.pcd"))
-    p = str(tmp_path / "lzf.pcd")
-    _write_pcd(p, ["x", "y", "z"], [4, 4, 4], ["F", "F", "F"], [1, 1, 1], b"", n, "binary_compressed")
+    p = str(tmp_path / "badlzf.pcd")
+    bad = np.array([len(comp), len(soa)], "<u4").tobytes() + comp[:len(comp) // 2] + b"\xff\xff\xff" + comp[len(comp) // 2 + 3:]
+    _write_pcd(p, ["intensity", "x", "y", "rgb", "z", "normal", "ring"], [4, 4, 4, 4, 4, 4, 2], ["F", "F", "F", "U", "F", "F", "U"],
+               [1, 1, 1, 1, 1, 3, 2], bad[:-40], n, "binary_compressed")
     with pytest.raises(g.GndtError):
         g.read_pcd(p)
     p = str(tmp_path / "short.pcd")
