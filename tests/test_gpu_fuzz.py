@@ -60,3 +60,29 @@ def test_single_points_and_tiny_clouds():
         for strategy in (1, 3, 4):
             _, out = parity.gpu_from_cloud(cloud, P, on_device=True, strategy=strategy)
             parity.assert_parity(out, ref)
+
+
+@pytest.mark.parametrize("kind", ["pole", "identical", "two_hot_columns"])
+def test_degenerate_large_clouds_fall_through_the_partition_paths(kind):
+    """Clouds above the two-level threshold whose points sit in one column, one node or two columns: the fixed-capacity
+    level-1 regions, the sampled bucket layout and the LDS node tables cannot all hold them, so the build has to walk
+    its retries (learnt capacity, exact partition, larger tables, node table in HBM) and still return the oracle's map."""
+    rng = np.random.default_rng(11)
+    n = 1_300_000
+    if kind == "pole":                                       # one column, ~4000 z levels
+        xyz = np.stack([0.3 + 0.1 * rng.random(n), -0.7 + 0.1 * rng.random(n), rng.random(n) * 400.0 - 200.0], 1)
+    elif kind == "identical":                                # one node (and the converters' padding pattern)
+        xyz = np.tile(np.float64([[2.25, -3.5, 0.125]]), (n, 1))
+    else:                                                    # two hot columns among ordinary ground
+        xyz = np.stack([rng.random(n) * 60 - 30, rng.random(n) * 60 - 30, 0.02 * rng.normal(size=n)], 1)
+        hot = rng.random(n) < 0.6
+        xyz[hot, 0] = np.where(rng.random(hot.sum()) < 0.5, 1.26, -7.31) + 0.01 * rng.random(hot.sum())
+        xyz[hot, 1] = 4.03 + 0.01 * rng.random(hot.sum())
+        xyz[hot, 2] = rng.random(hot.sum()) * 3.0
+    cloud = np.concatenate([np.float32([[0.0, 0.0, 0.0]]), xyz.astype(np.float32)], 0)
+    P = dict(grid_len=0.5, z_len=0.1, slope_interval=0.08, demand="slope")
+    ref = parity.ref_from_cloud(cloud, P)
+    for strategy in (0, 4):
+        m, out = parity.gpu_from_cloud(cloud, P, on_device=True, strategy=strategy)
+        parity.assert_parity(out, ref)
+
