@@ -142,6 +142,7 @@ def lib():
     L.gndt_stats_merge_device.argtypes = [H, C.POINTER(Stats), vp]
     L.gndt_shard_stats_device.argtypes = [H, vp, C.c_size_t, C.c_size_t, u64, C.POINTER(Stats), vp]
     L.gndt_finalize_stats_device.argtypes = [H, C.POINTER(Stats), u64, vp]
+    L.gndt_get_origin.argtypes = [H, C.POINTER(C.c_float)]
     L.gndt_pcd_read.argtypes = [C.c_char_p, C.POINTER(Pcd), C.c_char_p]
     L.gndt_pcd_free.argtypes = [C.POINTER(Pcd)]
     L.gndt_pcd_free.restype = None
@@ -170,7 +171,7 @@ def lib():
                  "gndt_export", "gndt_stats_export_device", "gndt_stats_merge_device", "gndt_trans_morton_xyz",
                  "gndt_compute_cost", "gndt_cost_export_device", "gndt_cost_export",
                  "gndt_shard_stats_device", "gndt_finalize_stats_device",
-                 "gndt_pcd_read", "gndt_pack_points_device", "gndt_build_cloud",
+                 "gndt_pcd_read", "gndt_pack_points_device", "gndt_build_cloud", "gndt_get_origin",
                  "gndt_count_morton", "gndt_morton_to_xy", "gndt_device_info", "gndt_set_profiling", "gndt_get_phase_times"):
         getattr(L, name).restype = C.c_int
     _lib = L

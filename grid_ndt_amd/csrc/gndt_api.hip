@@ -884,6 +884,12 @@ int gndt_set_origin(gndt_handle* h, const float origin_xyz[3]) {
     return GNDT_OK;
 }
 
+int gndt_get_origin(const gndt_handle* h, float origin_xyz[3]) {
+    if (!h || !origin_xyz || !h->origin_set) return GNDT_ERR_INVALID;
+    memcpy(origin_xyz, h->origin, 3 * sizeof(float));
+    return GNDT_OK;
+}
+
 int gndt_reset(gndt_handle* h, void* hip_stream) {
     if (!h) return GNDT_ERR_INVALID;
     HIP_TRY(h, hipSetDevice(h->device));

@@ -112,6 +112,8 @@ const char* gndt_last_error(const gndt_handle* h);   /* h may be NULL: last erro
 
 /* `map2D.setCloudFirst(points[0])` (receiver.cpp:145, map2D.h:490) */
 int gndt_set_origin(gndt_handle* h, const float origin_xyz[3]);
+/* The origin in use (gndt_build_cloud takes it from the first valid point of the cloud). */
+int gndt_get_origin(const gndt_handle* h, float origin_xyz[3]);
 
 /* ---- build: replaces receiver.cpp:150-154 + :160 --------------------------------------------- */
 /* Host memory in (e.g. pcl::PointCloud<PointXYZ>::points.data()+1, stride 16).  Synchronous. */

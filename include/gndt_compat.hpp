@@ -312,6 +312,25 @@ public:
         return list;
     }
 
+    // The whole of chatterCallback's front half (src/receiver.cpp:140-160) from a raw cloud: records as a PointCloud2 /
+    // .pcd payload lays them out -> NaN rows dropped on the device (publisher.cpp:24-26), origin := the first valid
+    // point (receiver.cpp:145), division + create2DMap of the rest.
+    bool create2DMapFromRaw(const std::string& demand, const void* raw, size_t n, const gndt_point_layout& layout) {
+        const int d = (demand == "true") ? GNDT_DEMAND_TRUE : GNDT_DEMAND_SLOPE;
+        if (!ensure_handle(d)) return false;
+        int rc = gndt_build_cloud(handle, raw, n, &layout);
+        uint64_t nodes = 0, cols = 0, slopes = 0;
+        if (rc == GNDT_OK) rc = gndt_sync(handle, &nodes, &cols, &slopes);
+        if (rc == GNDT_OK) rc = gndt_get_origin(handle, cloudFirst.d);
+        if (rc != GNDT_OK) { last_error = gndt_last_error(handle); return false; }
+        host.resize(nodes);
+        rc = gndt_export(handle, &host.view);
+        if (rc != GNDT_OK) { last_error = gndt_last_error(handle); return false; }
+        clear();
+        materialise_into<TwoDmap, OcNode, Slope, Cell>(host.view, *this);
+        return true;
+    }
+
     void clear() {
         for (auto& kv : map_xy) delete kv.second;
         for (auto& kv : map_cell) {
