@@ -564,9 +564,12 @@ int partition_launch(gndt_handle* h, gndt_handle::Pending& P) {
     // ones, when asked for (GNDT_STRATEGY_PARTITION_EXACT), and after a region overflowed once on this handle.
     static const int env_two = getenv("GNDT_TWO_LEVEL") ? atoi(getenv("GNDT_TWO_LEVEL")) : -1;
     bool two = h->P.strategy != GNDT_STRATEGY_PARTITION_EXACT && q.two_level_ok &&
-               (n >= (1u << 20) || h->P.strategy == GNDT_STRATEGY_PARTITION_TWO_LEVEL) &&
-               Bw <= (uint64_t)kMaxFan * kMaxFan;
+               (n >= (1u << 20) || h->P.strategy == GNDT_STRATEGY_PARTITION_TWO_LEVEL);
     if (env_two == 0 || n == 0) two = false;
+    if (two && Bw > (uint64_t)kMaxFan * kMaxFan) {         // more buckets than two levels address: larger tables, fewer buckets
+        if (!env_slots) { bslots = 1024; Bw = buckets_for(n, nodes_est, bslots); }
+        if (Bw > (uint64_t)kMaxFan * kMaxFan) two = false;
+    }
     if (!two) {
         if (!env_slots && Bw > kMaxBuckets) { bslots = 1024; Bw = buckets_for(n, nodes_est, bslots); }
         if (Bw > kMaxBuckets) return -1;                   // too many nodes for one partition level: atomic path
@@ -586,13 +589,13 @@ int partition_launch(gndt_handle* h, gndt_handle::Pending& P) {
     const float4* bucket_recs = nullptr;
     if (two) {
         uint32_t F2_shift = 1;                             // fan-out ~ sqrt(B) per level, F2 a power of two, both <= kMaxFan
-        while (F2_shift < 8 && (1ull << (2 * F2_shift)) < B) ++F2_shift;
+        while (F2_shift < 9 && (1ull << (2 * F2_shift)) < B) ++F2_shift;
         const uint32_t F2 = 1u << F2_shift;
         const uint32_t F1 = (B + F2 - 1) / F2;
         // Level-1 regions are large and hash-balanced: a fixed capacity of 2x the mean (or 1.25x the fullest one an
         // earlier build on this handle saw).  The buckets' regions are laid out on the device from a 1-in-64 sample
-        // level 1 takes (k_part2_layout: 1.6x the estimate + 1024 each), so LiDAR clouds' hot columns get the room they
-        // need and the records take 1.6 n + 1024 B slots in all.  If a region overflows all the same, the build is
+        // level 1 takes (k_part2_layout: 2x the estimate + 2048 each), so LiDAR clouds' hot columns get the room they
+        // need and the records take 2 n + 2048 B slots in all.  If a region overflows all the same, the build is
         // re-run; a second failure sends this handle to the exact counting partition.
         static const int env_rep = getenv("GNDT_L1_REP") ? atoi(getenv("GNDT_L1_REP")) : 1;   // measured: 1 is best at 4096-point tiles
         const uint32_t R = std::max<uint32_t>(1, std::min<uint32_t>((uint32_t)env_rep, kMaxFan / F1));   // sub-regions per coarse region
@@ -600,7 +603,7 @@ int partition_launch(gndt_handle* h, gndt_handle::Pending& P) {
         constexpr uint64_t kTile1 = (uint64_t)kTileThreads * kTilePer1, kTile2 = (uint64_t)kTileThreads * kTilePer2;
         const double r1 = std::max(2.0, q.fill1_ratio * 1.25);
         const uint64_t cap1w = (uint64_t)(r1 * (double)(n / V)) + 2 * kTile1;
-        const uint64_t recs_want = n + (n * 3) / 5 + n / 8 + 1024ull * B + 4096;     // 1.6 n + 1024 B, and sampling slack
+        const uint64_t recs_want = 2 * (uint64_t)n + n / 8 + 2048ull * B + 4096;     // 2 n + 2048 B, and sampling slack
         if ((uint64_t)V * cap1w > 4 * (uint64_t)n + (1u << 24) || recs_want >= 0xF0000000ull || q.two_level_failures >= 2) {
             q.two_level_ok = false;
             return partition_launch(h, P);                 // (re-enters on the exact path)
@@ -631,19 +634,25 @@ int partition_launch(gndt_handle* h, gndt_handle::Pending& P) {
         mark(h, 1, s);
         const uint32_t tiles1 = (uint32_t)((n + kTile1 - 1) / kTile1);
         static const uint32_t l1_wgs = getenv("GNDT_L1_WGS") ? (uint32_t)atoi(getenv("GNDT_L1_WGS")) : 1024u;   // persistent workgroups (2 resident per CU)
-        if (stride_bytes == 12)
-            hipLaunchKernelGGL(k_part2_level1<3>, dim3(std::min<uint32_t>(tiles1, l1_wgs)), dim3(kTileThreads), 0, s, p, (uint64_t)n, P.first_base, gp, B, F1, F2_shift, R,
-                               cursor1, cap1, est2, q.recs1, h->d_cnt, q.d_pc);
-        else
-            hipLaunchKernelGGL(k_part2_level1<4>, dim3(std::min<uint32_t>(tiles1, l1_wgs)), dim3(kTileThreads), 0, s, p, (uint64_t)n, P.first_base, gp, B, F1, F2_shift, R,
-                               cursor1, cap1, est2, q.recs1, h->d_cnt, q.d_pc);
+        const bool wide = std::max(V, F2) > 256;           // LDS arrays for a fan-out of 512 (fewer resident tiles) only when needed
+        const dim3 g1(std::min<uint32_t>(tiles1, l1_wgs)), g2((uint32_t)((cap1 + kTile2 - 1) / kTile2), V);
+#define GNDT_L1(SF_, FAN_)                                                                                                  \
+    hipLaunchKernelGGL((k_part2_level1<SF_, FAN_>), g1, dim3(kTileThreads), 0, s, p, (uint64_t)n, P.first_base, gp, B, F1, F2_shift, \
+                       R, cursor1, cap1, est2, q.recs1, h->d_cnt, q.d_pc)
+        if (stride_bytes == 12) { if (wide) GNDT_L1(3, 512); else GNDT_L1(3, 256); }
+        else { if (wide) GNDT_L1(4, 512); else GNDT_L1(4, 256); }
+#undef GNDT_L1
         HIP_TRY(h, hipGetLastError());
         mark(h, 2, s);
         hipLaunchKernelGGL(k_part2_layout, dim3(1), dim3(1024), 0, s, est2, B, q.range_lo, q.range_cap, (uint64_t)q.rec_cap, q.d_pc);
         HIP_TRY(h, hipGetLastError());
         mark(h, 3, s);
-        hipLaunchKernelGGL(k_part2_level2, dim3((uint32_t)((cap1 + kTile2 - 1) / kTile2), V), dim3(kTileThreads), 0, s, q.recs1, cursor1,
-                           cap1, R, gp, B, F2, cursor2, q.range_lo, q.range_cap, q.recs, q.d_pc);
+        if (wide)
+            hipLaunchKernelGGL(k_part2_level2<512>, g2, dim3(kTileThreads), 0, s, q.recs1, cursor1, cap1, R, gp, B, F2, cursor2,
+                               q.range_lo, q.range_cap, q.recs, q.d_pc);
+        else
+            hipLaunchKernelGGL(k_part2_level2<256>, g2, dim3(kTileThreads), 0, s, q.recs1, cursor1, cap1, R, gp, B, F2, cursor2,
+                               q.range_lo, q.range_cap, q.recs, q.d_pc);
         hipLaunchKernelGGL(k_part2_ranges, dim3(grid_for(B, 256, 64)), dim3(256), 0, s, cursor1, V, cursor2, q.range_cap, B, q.range_lo,
                            q.range_hi, q.d_pc);
         HIP_TRY(h, hipGetLastError());
@@ -969,7 +978,11 @@ int build_atomic(gndt_handle* h, const void* xyz_dev, size_t n, size_t stride_by
         if (rc) return rc;
         // a build returns with its results ready: wait once and look at the device-side flags
         HIP_TRY(h, hipStreamSynchronize(s));
-        if (!h->h_cnt->err_table_full && !h->part.h_pc->stage_overflow) return GNDT_OK;
+        if (!h->h_cnt->err_table_full && !h->part.h_pc->stage_overflow) {
+            // what a later PARTITION build of a similar cloud should expect (a first build without a hint guesses n / 4)
+            h->part.nodes_learned = (uint64_t)h->h_cnt->num_nodes + h->h_cnt->num_nodes / 5;
+            return GNDT_OK;
+        }
         // table (or staging) overflowed: the build starts from empty, so simply redo it in a larger table
         expect = (uint64_t)h->cap * 2;   // cap_for_nodes doubles again -> 4x slots
         if (expect > (1ull << 30)) break;

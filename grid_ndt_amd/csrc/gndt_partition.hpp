@@ -29,6 +29,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "gndt_kernels.hpp"
 
 namespace gndt {
@@ -253,7 +255,7 @@ __global__ void __launch_bounds__(kPartThreads) k_part_scatter(const float* __re
 //
 // The single-level scatter above writes 16-B records to ~B = thousands of places at once: every store is its own
 // memory transaction (~50 G/s on MI355X), lines leave L2 half-written, and a histogram pass over the cloud has to
-// come first.  Here a record moves twice, each time through an LDS tile sort with a fan-out of at most 256:
+// come first.  Here a record moves twice, each time through an LDS tile sort with a fan-out of at most 512:
 //   level 1  cloud tile (4096 points)   -> F1 coarse buckets (coarse = fine bucket / F2)
 //   level 2  coarse-bucket tile          -> its F2 fine buckets
 // A tile counts its digits in LDS, reserves space with ONE memory-side atomic per digit and tile, sorts the tile in
@@ -266,25 +268,27 @@ __global__ void __launch_bounds__(kPartThreads) k_part_scatter(const float* __re
 constexpr int kTileThreads = 512;
 constexpr int kTilePer1 = 8;       // level 1: 4096 records per tile (68 KB of LDS); smaller tiles measured slower here
 constexpr int kTilePer2 = 4;       // level 2: 2048 records per tile (34 KB): four tiles resident per CU
-constexpr int kMaxFan = 256;
+constexpr int kMaxFan = 512;               // fan-out per level: up to 512 x 512 buckets
 constexpr uint32_t kSampleEvery = 64;      // level 1 samples one record in 64 to size the buckets' regions (the hash test below is >> 26)
 
-template <int PER>
+// FAN = 256 or 512: the fan-out the LDS arrays are sized for (the small variant keeps four level-2 tiles per CU)
+template <int PER, int FAN>
 struct TileLds {
+    using Digit = typename std::conditional<(FAN <= 256), uint8_t, uint16_t>::type;
     float4 rec[kTileThreads * PER];
-    uint8_t digit[kTileThreads * PER];   // digit of every sorted slot (kMaxFan <= 256)
-    uint32_t hist[kMaxFan];
-    uint32_t scan[kMaxFan + 1];
-    uint32_t gbase[kMaxFan];
-    uint32_t dbase[kMaxFan], dcap[kMaxFan];     // individually laid out regions (level 2)
+    Digit digit[kTileThreads * PER];     // digit of every sorted slot
+    uint32_t hist[FAN];
+    uint32_t scan[FAN + 1];
+    uint32_t gbase[FAN];
+    uint32_t dbase[FAN], dcap[FAN];      // individually laid out regions (level 2)
     uint32_t wave_tot[kTileThreads / 64];
 };
 
 // r[j] / dig[j]: this thread's records and their digits (0xFFFFFFFF = no record).  cursor[d] counts what is reserved in
 // the region of digit d.  Regions are either evenly spaced (dbase == nullptr: digit d at out[region0 + d * region_stride],
 // `cap` records each) or laid out individually (digit d at out[dbase[d]], dcap[d] records).
-template <int PER>
-__device__ __forceinline__ void tile_partition(TileLds<PER>& L, const float4 (&r)[PER], const uint32_t (&dig)[PER],
+template <int PER, int FAN>
+__device__ __forceinline__ void tile_partition(TileLds<PER, FAN>& L, const float4 (&r)[PER], const uint32_t (&dig)[PER],
                                                uint32_t nd, uint32_t* __restrict__ cursor, uint32_t cap, uint64_t region0,
                                                uint64_t region_stride, const uint32_t* __restrict__ dbase,
                                                const uint32_t* __restrict__ dcap, float4* __restrict__ out,
@@ -319,7 +323,7 @@ __device__ __forceinline__ void tile_partition(TileLds<PER>& L, const float4 (&r
         if (dig[j] != 0xFFFFFFFFu) {
             const uint32_t pos = L.scan[dig[j]] + rank[j];
             L.rec[pos] = r[j];
-            L.digit[pos] = (uint8_t)dig[j];
+            L.digit[pos] = (typename TileLds<PER, FAN>::Digit)dig[j];
         }
     if ((uint32_t)tid < nd) {
         const uint32_t room = dbase ? dcap[tid] : cap;
@@ -344,7 +348,7 @@ __device__ __forceinline__ void tile_partition(TileLds<PER>& L, const float4 (&r
 // level 1: the cloud -> coarse regions.  One tile per workgroup.  A coarse region can be split into R sub-regions
 // with their own cursors (tile t fills sub-region t % R) to spread the reservations of thousands of tiles over
 // more words (same-address atomics serialise at the memory side); with 4096-point tiles R = 1 measured best.
-template <int STRIDE_FLOATS>
+template <int STRIDE_FLOATS, int FAN>
 __global__ void __launch_bounds__(kTileThreads) k_part2_level1(const float* __restrict__ xyz, uint64_t n, uint32_t first_base,
                                                                GridParams P, uint32_t B, uint32_t F1, uint32_t F2_shift, uint32_t R,
                                                                uint32_t* __restrict__ cursor1, uint32_t cap1,
@@ -352,7 +356,7 @@ __global__ void __launch_bounds__(kTileThreads) k_part2_level1(const float* __re
                                                                float4* __restrict__ recs1, Counters* __restrict__ cnt,
                                                                PartCounters* __restrict__ pc) {
     constexpr int PER = kTilePer1;
-    __shared__ TileLds<PER> L;
+    __shared__ TileLds<PER, FAN> L;
     // Persistent workgroups, software-pipelined: the loads of tile t+1 are in flight while tile t is keyed, sorted
     // in LDS and copied out (the kernel is latency-bound: ~70 % of a wave's life is spent parked on waits).
     const uint64_t ntiles = (n + (uint64_t)kTileThreads * PER - 1) / ((uint64_t)kTileThreads * PER);
@@ -398,14 +402,15 @@ __global__ void __launch_bounds__(kTileThreads) k_part2_level1(const float* __re
                 r[j] = make_float4(px, py, pz, __uint_as_float(idx));
             }
         }
-        tile_partition<PER>(L, r, dig, F1 * R, cursor1, cap1, 0ull, (uint64_t)cap1, nullptr, nullptr, recs1, pc);
+        tile_partition<PER, FAN>(L, r, dig, F1 * R, cursor1, cap1, 0ull, (uint64_t)cap1, nullptr, nullptr, recs1, pc);
         __syncthreads();                                   // the tile's LDS image is reused by the next iteration
     }
 }
 
-// Region of every bucket from the sample level 1 took: capacity = 1.6 x the estimate + 1024 records (a bucket of 2800
-// records has ~44 samples, sigma 15 %: 1.6x + 1024 is 6 sigma; LiDAR clouds' hot columns simply get the room they need),
-// base = exclusive prefix.  One workgroup; writes lo[] (= base) and cap[].
+// Region of every bucket from the sample level 1 took: capacity = 2 x the estimate + 2048 records.  (A bucket of c records
+// has c/64 +- sqrt(c/64) votes; it overflows if c > 2 x 64 x votes + 2048, which for c = 2000..5000 is 6 sigma or more away
+// and never happens below 2048: with 50 000 buckets, 1.6x + 1024 still overflowed a handful per build.)  LiDAR clouds' hot
+// columns simply get the room they need.  base = exclusive prefix.  One workgroup; writes lo[] (= base) and cap[].
 __global__ void __launch_bounds__(1024) k_part2_layout(const uint32_t* __restrict__ est2, uint32_t B, uint32_t* __restrict__ lo,
                                                        uint32_t* __restrict__ cap, uint64_t rec_capacity,
                                                        PartCounters* __restrict__ pc) {
@@ -417,7 +422,7 @@ __global__ void __launch_bounds__(1024) k_part2_layout(const uint32_t* __restric
     for (uint32_t b0 = 0; b0 < B; b0 += 1024) {
         const uint32_t b = b0 + tid;
         uint32_t c = 0;
-        if (b < B) { c = (uint32_t)(((uint64_t)est2[b] * kSampleEvery * 8) / 5) + 1024u; cap[b] = c; }
+        if (b < B) { c = (uint32_t)((uint64_t)est2[b] * kSampleEvery * 2) + 2048u; cap[b] = c; }
         uint32_t incl = c;
         for (int o = 1; o < 64; o <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)incl, o, 64); if (lane >= o) incl += t; }
         if (lane == 63) wsum[wave] = incl;
@@ -433,13 +438,14 @@ __global__ void __launch_bounds__(1024) k_part2_layout(const uint32_t* __restric
 }
 
 // level 2: sub-region blockIdx.y (of coarse region blockIdx.y / R), tile blockIdx.x of it -> that region's fine buckets
+template <int FAN>
 __global__ void __launch_bounds__(kTileThreads) k_part2_level2(const float4* __restrict__ recs1, const uint32_t* __restrict__ cursor1,
                                                                uint32_t cap1, uint32_t R, GridParams P, uint32_t B, uint32_t F2,
                                                                uint32_t* __restrict__ cursor2, const uint32_t* __restrict__ lo,
                                                                const uint32_t* __restrict__ cap, float4* __restrict__ recs2,
                                                                PartCounters* __restrict__ pc) {
     constexpr int PER = kTilePer2;
-    __shared__ TileLds<PER> L;
+    __shared__ TileLds<PER, FAN> L;
     if (pc->part_overflow) return;                       // level 1 or the layout already gave up: the build is re-run
     const uint32_t v = blockIdx.y, c = v / R;
     const uint32_t have = min(cursor1[v], cap1);
@@ -459,7 +465,7 @@ __global__ void __launch_bounds__(kTileThreads) k_part2_level2(const float4* __r
             dig[j] = bucket_of(column_hash(k.sx, k.sy), B) - b0;
         }
     }
-    tile_partition<PER>(L, r, dig, nd, cursor2 + b0, 0u, 0ull, 0ull, lo + b0, cap + b0, recs2, pc);
+    tile_partition<PER, FAN>(L, r, dig, nd, cursor2 + b0, 0u, 0ull, 0ull, lo + b0, cap + b0, recs2, pc);
 }
 
 // the fine buckets' record ranges for the bucket kernel (lo[] is the layout's base), and the fullest level-1 region
