@@ -348,7 +348,7 @@ int ensure_part_counters(gndt_handle* h) {
     return GNDT_OK;
 }
 
-// bitmap scan -> column rank -> column sizes scan -> row of every staged node -> SoA rows (marks 5..10 with `m0` = 5)
+// prefix of the per-word column weights -> row of every staged node -> SoA rows (marks m0+1 .. m0+5)
 int launch_order_and_emit(gndt_handle* h, uint64_t words, int m0, hipStream_t s) {
     auto& q = h->part;
     const uint32_t nbw = (uint32_t)((words + kScanChunk - 1) / kScanChunk);

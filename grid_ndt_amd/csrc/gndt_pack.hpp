@@ -5,7 +5,7 @@
 //   pcl::removeNaNFromPointCloud                                  src/publisher.cpp:24-26
 // Order matters downstream: point 0 is the origin (receiver.cpp:145) and nodes are listed in first-seen order.
 // Stable compaction without a sort: one validity bit per point (a wave ballot = one 64-bit store), popcount
-// prefix over the bitmap words (the scan kernels of the ordering pass), destination = prefix + popcount below.
+// prefix over the bitmap words (the two-level scan kernels of gndt_partition.hpp), destination = prefix + popcount below.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
