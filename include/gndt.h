@@ -132,7 +132,9 @@ int gndt_build_device(gndt_handle* h, const void* xyz_dev, size_t n, size_t stri
  * build(F1 || .. || Fk).  first_idx continues counting across calls.  Needs a handle of strategy ATOMIC (the node
  * table keeps the additive state).  gndt_update_device never waits for the host: every size it needs lives on the
  * device, so once the buffers exist (one eager frame, or max_nodes_hint + max_points_hint) the call can be captured
- * in a hipGraph and replayed per frame; table / row / index overflow is reported by gndt_sync. */
+ * in a hipGraph and replayed per frame; table / row / index overflow is reported by gndt_sync.
+ * Point indices (first_idx) are 32-bit: a map holds at most 2^32 - 2 points between two gndt_reset calls (about an hour of
+ * a 10 Hz, 131 072-point stream); the next update then fails with GNDT_ERR_INVALID instead of wrapping. */
 int gndt_update(gndt_handle* h, const void* xyz_host, size_t n, size_t stride_bytes);
 int gndt_update_device(gndt_handle* h, const void* xyz_dev, size_t n, size_t stride_bytes, void* hip_stream);
 
