@@ -47,6 +47,9 @@ struct gndt_handle {
     uint32_t* col_cnt = nullptr;
     uint32_t* col_head = nullptr;
     uint32_t* node_next = nullptr;
+    // incremental updates: slot -> node index, touch marks, the lists of touched nodes / columns
+    uint32_t *index_of_slot = nullptr, *touch_epoch = nullptr, *col_epoch = nullptr, *touched = nullptr, *touched_cols = nullptr;
+    bool incr_ok = false;       // the persistent staging rows / order of the table path describe the current map
 
     Counters* d_cnt = nullptr;
     Counters* h_cnt = nullptr;  // pinned
@@ -91,6 +94,7 @@ struct gndt_handle {
         uint64_t stage_cap = 0;    StageRow* stage = nullptr;
         uint32_t *ord_cf = nullptr, *ord_idx = nullptr, *inv = nullptr, *row_ncol = nullptr;
         // column order (gndt_partition.hpp ColumnOrder): per bitmap word, and per point index for ncol_at
+        uint64_t words_init = 0;   // bitmap / word_weight words the table path's column order has initialised
         uint64_t word_cap = 0;     uint32_t *bitmap = nullptr, *word_weight = nullptr, *word_base = nullptr, *bsum_words = nullptr,
                                             *ncol_at = nullptr;
         PartCounters* d_pc = nullptr;
@@ -190,11 +194,14 @@ GridParams grid_params(const gndt_handle* h) {
 
 void free_table(gndt_handle* h) {
     void* ptrs[] = {h->keys, h->acc, h->col_keys, h->col_first, h->aux, h->node_slot, h->col_slot_of_node,
-                    h->col_cnt, h->col_head, h->node_next};
+                    h->col_cnt, h->col_head, h->node_next, h->index_of_slot, h->touch_epoch, h->col_epoch, h->touched,
+                    h->touched_cols};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     h->keys = nullptr; h->acc = nullptr; h->col_keys = nullptr; h->col_first = nullptr; h->aux = nullptr;
     h->node_slot = nullptr; h->col_slot_of_node = nullptr; h->col_cnt = nullptr; h->col_head = nullptr; h->node_next = nullptr;
+    h->index_of_slot = h->touch_epoch = h->col_epoch = h->touched = h->touched_cols = nullptr;
+    h->incr_ok = false;
     h->cap = 0;
 }
 
@@ -211,9 +218,11 @@ int alloc_table(gndt_handle* h, uint32_t cap, hipStream_t s) {
     HIP_TRY(h, hipMalloc(&h->node_slot, (size_t)cap * sizeof(uint32_t)));
     HIP_TRY(h, hipMalloc(&h->col_slot_of_node, (size_t)cap * sizeof(uint32_t)));
     HIP_TRY(h, hipMalloc(&h->node_next, (size_t)cap * sizeof(uint32_t)));
+    for (uint32_t** a : {&h->index_of_slot, &h->touch_epoch, &h->col_epoch, &h->touched, &h->touched_cols})
+        HIP_TRY(h, hipMalloc(a, (size_t)cap * sizeof(uint32_t)));
     h->cap = cap;
     hipLaunchKernelGGL(k_clear_all, dim3(grid_for(cap)), dim3(kBlock), 0, s, h->keys, h->acc, h->col_keys,
-                       h->col_first, h->col_cnt, h->col_head, cap);
+                       h->col_first, h->col_cnt, h->col_head, h->touch_epoch, h->col_epoch, cap);
     HIP_TRY(h, hipGetLastError());
     h->table_dirty = false;
     return GNDT_OK;
@@ -376,6 +385,8 @@ TableView table_view(const gndt_handle* h) {
     T.keys = h->keys; T.acc = h->acc; T.aux = h->aux; T.col_keys = h->col_keys; T.col_first = h->col_first;
     T.col_cnt = h->col_cnt; T.col_head = h->col_head; T.node_slot = h->node_slot; T.col_slot_of_node = h->col_slot_of_node;
     T.node_next = h->node_next; T.cap_mask = h->cap - 1;
+    T.index_of_slot = h->index_of_slot; T.touch_epoch = h->touch_epoch; T.col_epoch = h->col_epoch;
+    T.touched = h->touched; T.touched_cols = h->touched_cols;
     return T;
 }
 
@@ -391,6 +402,7 @@ int do_reset(gndt_handle* h, hipStream_t s) {
     h->results_valid = false;
     h->stream_pos = 0;
     h->nodes_bound = 0;
+    h->incr_ok = false;
     return GNDT_OK;
 }
 
@@ -399,7 +411,7 @@ int grow_table(gndt_handle* h, uint32_t new_cap, hipStream_t s);
 
 // `base_from_device`: first_idx base = the device-side stream position (incremental updates)
 int do_accumulate(gndt_handle* h, const void* xyz_dev, size_t n, size_t stride_bytes, uint64_t first_base,
-                  int base_from_device, hipStream_t s) {
+                  int base_from_device, hipStream_t s, int mark = 0) {
     if (stride_bytes != 12 && stride_bytes != 16) { h->err = "stride_bytes must be 12 or 16"; return GNDT_ERR_INVALID; }
     if (first_base + n >= 0xFFFFFFFFull) { h->err = "point index exceeds 32 bits"; return GNDT_ERR_INVALID; }
     if (n == 0) return GNDT_OK;
@@ -407,11 +419,14 @@ int do_accumulate(gndt_handle* h, const void* xyz_dev, size_t n, size_t stride_b
     const int blocks = grid_for(n, kBlock, 256 * 16);
     if (stride_bytes == 12)
         hipLaunchKernelGGL(k_accumulate<3>, dim3(blocks), dim3(kBlock), 0, s, p, (uint64_t)n, (uint32_t)first_base,
-                           base_from_device, grid_params(h), h->keys, h->acc, h->cap - 1, h->node_slot, h->d_cnt);
+                           base_from_device, grid_params(h), h->keys, h->acc, h->cap - 1, h->node_slot, h->index_of_slot,
+                           h->touch_epoch, h->touched, mark, h->d_cnt);
     else
         hipLaunchKernelGGL(k_accumulate<4>, dim3(blocks), dim3(kBlock), 0, s, p, (uint64_t)n, (uint32_t)first_base,
-                           base_from_device, grid_params(h), h->keys, h->acc, h->cap - 1, h->node_slot, h->d_cnt);
+                           base_from_device, grid_params(h), h->keys, h->acc, h->cap - 1, h->node_slot, h->index_of_slot,
+                           h->touch_epoch, h->touched, mark, h->d_cnt);
     HIP_TRY(h, hipGetLastError());
+    if (!mark) h->incr_ok = false;                    // nodes changed without being listed: the next finalisation redoes every column
     if (base_from_device) {
         hipLaunchKernelGGL(k_advance_stream, dim3(1), dim3(64), 0, s, h->d_cnt, (uint32_t)n);
         HIP_TRY(h, hipGetLastError());
@@ -424,28 +439,50 @@ int do_accumulate(gndt_handle* h, const void* xyz_dev, size_t n, size_t stride_b
 
 // columns -> labels + staging rows -> ordering -> emit.  Everything is sized on the device; nothing waits for
 // the host, so accumulate + finalize can be captured in a hipGraph once the buffers exist.
-int do_finalize(gndt_handle* h, hipStream_t s) {
+int do_finalize(gndt_handle* h, hipStream_t s, bool incremental = false, uint64_t touched_bound = 0) {
     auto& q = h->part;
     int rc;
     // host-side upper bounds only: rows <= slots/2 at a healthy load; points seen so far (or the caller's hint)
     const uint64_t rows_bound = std::max<uint64_t>(1024, h->cap / 2 + 1);
     const uint64_t pts_bound = std::max<uint64_t>(std::max<uint64_t>(h->stream_pos, h->P.max_points_hint), 64);
     const uint64_t words = (pts_bound + 31) / 32 + 1;
+    // The incremental form needs what the last finalisation left behind (staging rows, order keys, column order): any
+    // reallocation, or anything else that touched those buffers, sends this call down the full path.
+    if (!h->incr_ok || rows_bound > q.stage_cap || words > q.word_cap || !q.d_pc) incremental = false;
     if ((rc = ensure_part_counters(h))) return rc;
     if ((rc = ensure_stage(h, rows_bound))) return rc;
     if ((rc = ensure_out(h, q.stage_cap))) return rc;
     if ((rc = ensure_words(h, words))) return rc;
     const TableView T = table_view(h);
     const GridParams gp = grid_params(h);
+    const ColumnOrder O{q.bitmap, q.word_weight, q.ncol_at};
     mark(h, 2, s);
-    hipLaunchKernelGGL(k_tab_begin, dim3(grid_for(std::max<uint64_t>(words, h->cap / 4), kBlock, 1024)), dim3(kBlock), 0, s, T,
-                       h->d_cnt, q.d_pc, q.bitmap, q.word_weight, (uint64_t)words);
-    hipLaunchKernelGGL(k_tab_columns, dim3(grid_for(rows_bound)), dim3(kBlock), 0, s, T, gp, h->d_cnt);
-    HIP_TRY(h, hipGetLastError());
-    mark(h, 3, s);
-    hipLaunchKernelGGL(k_tab_rows, dim3(grid_for(rows_bound)), dim3(kBlock), 0, s, T, gp, q.stage, (uint32_t)q.stage_cap,
-                       q.ord_cf, q.ord_idx, ColumnOrder{q.bitmap, q.word_weight, q.ncol_at}, (uint64_t)words, h->d_cnt, q.d_pc);
-    HIP_TRY(h, hipGetLastError());
+    if (incremental) {
+        if (words > q.words_init) {                        // the stream grew past the words the order has seen: they start empty
+            HIP_TRY(h, hipMemsetAsync(q.bitmap + q.words_init, 0, (words - q.words_init) * 4, s));
+            HIP_TRY(h, hipMemsetAsync(q.word_weight + q.words_init, 0, (words - q.words_init) * 4, s));
+            q.words_init = words;
+        }
+        const uint64_t tb = std::max<uint64_t>(std::min<uint64_t>(touched_bound, rows_bound), 64);
+        hipLaunchKernelGGL(k_tab_touch, dim3(grid_for(tb)), dim3(kBlock), 0, s, T, gp, h->d_cnt, q.d_pc);
+        HIP_TRY(h, hipGetLastError());
+        hipLaunchKernelGGL(k_tab_expand, dim3(grid_for(tb)), dim3(kBlock), 0, s, T, h->d_cnt);
+        HIP_TRY(h, hipGetLastError());
+        mark(h, 3, s);
+        hipLaunchKernelGGL(k_tab_rows_touched, dim3(grid_for(4 * tb, kBlock, 4096)), dim3(kBlock), 0, s, T, gp, q.stage,
+                           (uint32_t)q.stage_cap, q.ord_cf, q.ord_idx, O, (uint64_t)words, h->d_cnt, q.d_pc);
+        HIP_TRY(h, hipGetLastError());
+    } else {
+        hipLaunchKernelGGL(k_tab_begin, dim3(grid_for(std::max<uint64_t>(words, h->cap / 4), kBlock, 1024)), dim3(kBlock), 0, s, T,
+                           h->d_cnt, q.d_pc, q.bitmap, q.word_weight, (uint64_t)words);
+        hipLaunchKernelGGL(k_tab_columns, dim3(grid_for(rows_bound)), dim3(kBlock), 0, s, T, gp, h->d_cnt);
+        HIP_TRY(h, hipGetLastError());
+        mark(h, 3, s);
+        hipLaunchKernelGGL(k_tab_rows, dim3(grid_for(rows_bound)), dim3(kBlock), 0, s, T, gp, q.stage, (uint32_t)q.stage_cap,
+                           q.ord_cf, q.ord_idx, O, (uint64_t)words, h->d_cnt, q.d_pc);
+        HIP_TRY(h, hipGetLastError());
+        q.words_init = words;
+    }
     mark(h, 4, s);
     if ((rc = launch_order_and_emit(h, words, 4, s))) return rc;
     hipLaunchKernelGGL(k_tab_end, dim3(1), dim3(64), 0, s, h->d_cnt);
@@ -455,6 +492,7 @@ int do_finalize(gndt_handle* h, hipStream_t s) {
     h->results_valid = true;
     ++h->result_serial;
     h->last_stream = s;
+    h->incr_ok = true;
     return GNDT_OK;
 }
 
@@ -500,7 +538,7 @@ int grow_table(gndt_handle* h, uint32_t new_cap, hipStream_t s) {
     HIP_TRY(h, hipMemsetAsync(&h->d_cnt->prev_nodes, 0, sizeof(uint32_t), s));
     if (C) {
         hipLaunchKernelGGL(k_stats_merge, dim3(grid_for(C)), dim3(kBlock), 0, s, h->keys, h->acc, h->cap - 1, h->node_slot,
-                           h->st_key, h->st_sums, h->st_count, h->st_first, (uint64_t)C, h->d_cnt);
+                           h->index_of_slot, h->st_key, h->st_sums, h->st_count, h->st_first, (uint64_t)C, h->d_cnt);
         HIP_TRY(h, hipGetLastError());
         h->table_dirty = true;
     }
@@ -1032,10 +1070,14 @@ int gndt_update_device(gndt_handle* h, const void* xyz_dev, size_t n, size_t str
     rc = ensure_capacity_for(h, n, s);
     if (rc) return rc;
     mark(h, 1, s);
-    rc = do_accumulate(h, xyz_dev, n, stride_bytes, h->stream_pos, 1, s);
+    // The frame's points list the nodes they touch; if the staging rows and the column order of the last finalisation
+    // are still in place, only the columns holding a touched node are relabelled (the ordering and the emit pass
+    // still cover the whole map: rows move when a column in front of them grows).
+    const bool incr = h->incr_ok;
+    rc = do_accumulate(h, xyz_dev, n, stride_bytes, h->stream_pos, 1, s, incr ? 1 : 0);
     if (rc) return rc;
     h->stream_pos += n;
-    return do_finalize(h, s);
+    return do_finalize(h, s, incr, n);
 }
 
 int gndt_build(gndt_handle* h, const void* xyz_host, size_t n, size_t stride_bytes) {
@@ -1347,6 +1389,7 @@ int gndt_pack_points_device(gndt_handle* h, const void* raw_dev, size_t n, const
     auto& q = h->part;
     const uint64_t words = ((n + 63) / 64) * 2;
     if ((rc = ensure_words(h, words))) return rc;
+    h->incr_ok = false;                        // the order's bitmap is used as scratch here
     if (!h->d_nvalid) {
         HIP_TRY(h, hipMalloc(&h->d_nvalid, sizeof(uint32_t)));
         HIP_TRY(h, hipHostMalloc(&h->h_nvalid, sizeof(uint32_t)));
@@ -1437,7 +1480,9 @@ int gndt_stats_merge_device(gndt_handle* h, const gndt_stats* in, void* hip_stre
     if (rc) return rc;
     if (in->num_nodes) {
         hipLaunchKernelGGL(k_stats_merge, dim3(grid_for(in->num_nodes)), dim3(kBlock), 0, s, h->keys, h->acc, h->cap - 1,
-                           h->node_slot, in->key, in->sums, in->count, in->first_idx, (uint64_t)in->num_nodes, h->d_cnt);
+                           h->node_slot, h->index_of_slot, in->key, in->sums, in->count, in->first_idx, (uint64_t)in->num_nodes,
+                           h->d_cnt);
+        h->incr_ok = false;
         HIP_TRY(h, hipGetLastError());
         h->table_dirty = true;
         h->results_valid = false;

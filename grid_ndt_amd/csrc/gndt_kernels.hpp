@@ -42,6 +42,10 @@ struct Counters {
     uint32_t err_table_full;  // inserts that found no slot
     uint32_t stream_pos;      // points accumulated so far by gndt_update* (device-side first_idx base)
     uint32_t prev_nodes;      // nodes that went through the last finalize (their column entries exist)
+    uint32_t epoch;           // stamps "touched since the last finalize" marks; bumped by every finalize, never 0 once in use
+    uint32_t n_touched;       // nodes an incremental update has touched so far (list: touched[])
+    uint32_t n_tcols;         // columns holding a touched node (list: touched_cols[])
+    uint32_t n_work;          // nodes of those columns (list: reuses touched[])
     uint32_t pad;
 };
 
@@ -87,7 +91,7 @@ __device__ __forceinline__ uint32_t find_or_insert(uint64_t* __restrict__ keys, 
 // Append the slots of freshly inserted nodes to the node list: one counter atomic per wave instruction (the
 // counter is ONE word; per-lane atomics on it would serialise at the memory side).
 __device__ __forceinline__ void append_new_nodes(bool inserted, uint32_t slot, uint32_t* __restrict__ node_slot,
-                                                 Counters* __restrict__ cnt) {
+                                                 uint32_t* __restrict__ index_of_slot, Counters* __restrict__ cnt) {
     const unsigned long long m = __ballot(inserted);
     if (m == 0ull) return;
     const int lane = threadIdx.x & 63;
@@ -95,7 +99,26 @@ __device__ __forceinline__ void append_new_nodes(bool inserted, uint32_t slot, u
     uint32_t base = 0;
     if (lane == leader) base = atomicAdd(&cnt->num_nodes, (uint32_t)__popcll(m));
     base = (uint32_t)__shfl((int)base, leader, 64);
-    if (inserted) node_slot[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = slot;
+    if (inserted) {
+        const uint32_t idx = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        node_slot[idx] = slot;
+        index_of_slot[slot] = idx;
+    }
+}
+
+// Incremental updates: the first point that reaches a node since the last finalize puts the node's slot on the touched
+// list (wave-aggregated append: the list counter is ONE word).
+__device__ __forceinline__ void mark_touched(uint32_t slot, uint32_t epoch, uint32_t* __restrict__ touch_epoch,
+                                             uint32_t* __restrict__ touched, Counters* __restrict__ cnt) {
+    const bool first = atomicExch(&touch_epoch[slot], epoch) != epoch;
+    const unsigned long long m = __ballot(first);
+    if (m == 0ull) return;
+    const int lane = threadIdx.x & 63;
+    const int leader = (int)__builtin_ctzll(m);
+    uint32_t base = 0;
+    if (lane == leader) base = atomicAdd(&cnt->n_touched, (uint32_t)__popcll(m));
+    base = (uint32_t)__shfl((int)base, leader, 64);
+    if (first) touched[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = slot;
 }
 
 // Lookup only.  Returns cap_mask+1 when absent.
@@ -119,13 +142,15 @@ __device__ __forceinline__ double wave_sum(double v) {
 // k_clear_all: whole-table initialisation (once at create / after growth)
 // ---------------------------------------------------------------------------------------------
 __global__ void k_clear_all(uint64_t* keys, NodeAcc* acc, uint64_t* col_keys, uint32_t* col_first, uint32_t* col_cnt,
-                            uint32_t* col_head, uint32_t cap) {
+                            uint32_t* col_head, uint32_t* touch_epoch, uint32_t* col_epoch, uint32_t cap) {
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < cap; i += gridDim.x * blockDim.x) {
         keys[i] = kEmptyKey;
         col_keys[i] = kEmptyKey;
         col_first[i] = 0xFFFFFFFFu;
         col_cnt[i] = 0u;
         col_head[i] = 0xFFFFFFFFu;
+        touch_epoch[i] = 0u;
+        col_epoch[i] = 0u;
         NodeAcc a;
         for (int k = 0; k < 9; ++k) a.s[k] = 0.0;
         a.count = 0; a.first = 0xFFFFFFFFu;
@@ -160,7 +185,8 @@ __global__ void k_clear_used(uint64_t* keys, NodeAcc* acc, uint64_t* col_keys, u
 __global__ void k_zero_counters(Counters* c) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         c->num_nodes = 0; c->num_columns = 0; c->num_slopes = 0; c->err_key_range = 0; c->err_table_full = 0;
-        c->stream_pos = 0; c->prev_nodes = 0;
+        c->stream_pos = 0; c->prev_nodes = 0; c->n_touched = 0; c->n_tcols = 0; c->n_work = 0;
+        c->epoch = c->epoch + 1u;                     // stale touch marks of the previous map can never match again
     }
 }
 
@@ -178,8 +204,11 @@ template <int STRIDE_FLOATS>
 __global__ void __launch_bounds__(kBlock) k_accumulate(const float* __restrict__ xyz, uint64_t n, uint32_t first_base,
                                                        int base_from_device, GridParams P, uint64_t* __restrict__ keys,
                                                        NodeAcc* __restrict__ acc, uint32_t cap_mask,
-                                                       uint32_t* __restrict__ node_slot, Counters* __restrict__ cnt) {
+                                                       uint32_t* __restrict__ node_slot, uint32_t* __restrict__ index_of_slot,
+                                                       uint32_t* __restrict__ touch_epoch, uint32_t* __restrict__ touched,
+                                                       int mark, Counters* __restrict__ cnt) {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    const uint32_t epoch = cnt->epoch;
     const uint64_t n_round = (n + 63) & ~63ull;   // keep waves converged for the wave-uniform test
     const uint32_t base = base_from_device ? cnt->stream_pos : first_base;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_round; i += stride) {
@@ -216,7 +245,8 @@ __global__ void __launch_bounds__(kBlock) k_accumulate(const float* __restrict__
                 uint32_t slot = find_or_insert(keys, cap_mask, key, inserted);
                 if (slot > cap_mask) { atomicAdd(&cnt->err_table_full, 1u); }
                 else {
-                    if (inserted) node_slot[atomicAdd(&cnt->num_nodes, 1u)] = slot;
+                    if (inserted) { const uint32_t idx = atomicAdd(&cnt->num_nodes, 1u); node_slot[idx] = slot; index_of_slot[slot] = idx; }
+                    if (mark && atomicExch(&touch_epoch[slot], epoch) != epoch) touched[atomicAdd(&cnt->n_touched, 1u)] = slot;
                     NodeAcc* a = acc + slot;
 #pragma unroll
                     for (int j = 0; j < 9; ++j) unsafeAtomicAdd(&a->s[j], q[j]);
@@ -228,8 +258,9 @@ __global__ void __launch_bounds__(kBlock) k_accumulate(const float* __restrict__
             bool inserted;
             uint32_t slot = find_or_insert(keys, cap_mask, key, inserted);
             if (slot > cap_mask) { atomicAdd(&cnt->err_table_full, 1u); inserted = false; }
-            append_new_nodes(inserted, slot, node_slot, cnt);
+            append_new_nodes(inserted, slot, node_slot, index_of_slot, cnt);
             if (slot <= cap_mask) {
+                if (mark) mark_touched(slot, epoch, touch_epoch, touched, cnt);
                 NodeAcc* a = acc + slot;
 #pragma unroll
                 for (int j = 0; j < 9; ++j) unsafeAtomicAdd(&a->s[j], q[j]);
@@ -269,7 +300,8 @@ __global__ void k_stats_export(const uint64_t* __restrict__ keys, const NodeAcc*
 }
 
 __global__ void __launch_bounds__(kBlock) k_stats_merge(uint64_t* __restrict__ keys, NodeAcc* __restrict__ acc, uint32_t cap_mask,
-                                                        uint32_t* __restrict__ node_slot, const uint64_t* __restrict__ ikey,
+                                                        uint32_t* __restrict__ node_slot, uint32_t* __restrict__ index_of_slot,
+                                                        const uint64_t* __restrict__ ikey,
                                                         const double* __restrict__ isums, const uint32_t* __restrict__ icount,
                                                         const uint32_t* __restrict__ ifirst, uint64_t n,
                                                         Counters* __restrict__ cnt) {
@@ -286,7 +318,7 @@ __global__ void __launch_bounds__(kBlock) k_stats_merge(uint64_t* __restrict__ k
             slot = find_or_insert(keys, cap_mask, ikey[i], inserted);
             if (slot > cap_mask) { atomicAdd(&cnt->err_table_full, 1u); inserted = false; }
         }
-        append_new_nodes(inserted, slot, node_slot, cnt);
+        append_new_nodes(inserted, slot, node_slot, index_of_slot, cnt);
         if (live && slot <= cap_mask) {
             NodeAcc* a = acc + slot;
             for (int k = 0; k < 9; ++k) unsafeAtomicAdd(&a->s[k], isums[9 * i + k]);

@@ -7,7 +7,16 @@
 //   k_tab_rows      per node: slope label (OcNode::isSlope, map2D.h:66-108) and index in column by walking the
 //                   column's list; mean + fp64 scatter -> 128-B staging row; bit per column-first index
 //   then the partition path's ordering (k_scan_*, k_order_*) and k_emit_rows (gndt_partition.hpp)
-//   k_tab_end       remember how many nodes now own a column entry
+//   k_tab_end       remember how many nodes now own a column entry; next epoch
+//
+// Incremental updates (gndt_update_device; SURVEY §8(f) rank 2: "per-frame re-labelling of touched columns"): the staging
+// rows, the per-node order keys and the column order (bitmap, word weights) persist between finalisations, k_accumulate
+// lists the nodes a frame touched, and only their columns are redone:
+//   k_tab_touch          touched nodes: fp32 mean-z; new nodes join their column; the columns go on a list
+//   k_tab_expand         the nodes of the listed columns as a flat work list
+//   k_tab_rows_touched   every listed node: label, index in column, moments -> its staging row; the column's weight in
+//                        the order changes by the nodes it gained
+// followed by the same ordering + emit over the whole map (rows move when a column in front of them grows).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -20,8 +29,70 @@ struct TableView {
     uint64_t* keys; NodeAcc* acc; SlotAux* aux;
     uint64_t* col_keys; uint32_t* col_first; uint32_t* col_cnt; uint32_t* col_head;
     uint32_t* node_slot; uint32_t* col_slot_of_node; uint32_t* node_next;
+    uint32_t* index_of_slot; uint32_t* touch_epoch; uint32_t* col_epoch;      // incremental updates
+    uint32_t* touched; uint32_t* touched_cols;
     uint32_t cap_mask;
 };
+
+// the column-table slot of a column key, inserting it if new
+__device__ __forceinline__ uint32_t tab_column_slot(const TableView& T, uint64_t ck) {
+    uint32_t cs = (uint32_t)mix64(ck) & T.cap_mask;
+    for (uint32_t probe = 0; probe <= T.cap_mask; ++probe) {
+        const uint64_t k = T.col_keys[cs];
+        if (k == ck) break;
+        if (k == kEmptyKey) {
+            const unsigned long long old = atomicCAS((unsigned long long*)&T.col_keys[cs], (unsigned long long)kEmptyKey,
+                                                     (unsigned long long)ck);
+            if (old == kEmptyKey || old == ck) break;
+        }
+        cs = (cs + 1) & T.cap_mask;
+    }
+    return cs;
+}
+
+// The staging row of node i from the table's current state: slope label (OcNode::isSlope, map2D.h:66-108) and index in
+// column by walking the column's list, mean + fp64 scatter from the additive statistics.
+__device__ __forceinline__ void tab_make_row(const TableView& T, const GridParams& P, uint32_t i, StageRow& row) {
+    const uint32_t s = T.node_slot[i];
+    const uint64_t key = T.keys[s];
+    const NodeAcc a = T.acc[s];
+    const uint32_t cs = T.col_slot_of_node[i];
+    uint32_t fl = T.aux[s].flags & 1u;
+    const float cz = T.aux[s].mean_z;
+    unpack_key(key, row.sx, row.sy, row.sz);
+    const int za = level_above(row.sz), zb = level_below(row.sz);
+    uint32_t icol = 0;
+    bool up = false, down = false;
+    for (uint32_t t = T.col_head[cs]; t != 0xFFFFFFFFu; t = T.node_next[t]) {
+        if (t == i) continue;
+        const uint32_t ts = T.node_slot[t];
+        const uint32_t tf = T.acc[ts].first;
+        icol += (tf < a.first) ? 1u : 0u;
+        const int tz = (int)(T.keys[ts] & 0x3FFFFFu) - (1 << 21);
+        if (tz == za || tz == zb) {
+            const SlotAux tx = T.aux[ts];
+            const bool visited = tf < a.first && (tx.flags & 1u);
+            const float oz = visited ? tx.mean_z : 0.f;
+            const bool far = fabsf(oz - cz) > P.slope_interval;
+            if (tz == za) up = up || far; else down = down || far;
+        }
+    }
+    if (fl & 1u) {
+        bool slope = true;
+        if (P.demand == 0) slope = !up; else down = false;
+        if (slope) { fl |= 2u; if (down) fl |= 4u; }
+    }
+    row.count = a.count; row.first = a.first; row.flags = fl;
+    for (int k = 0; k < 3; ++k) row.mean[k] = 0.f;
+    for (int k = 0; k < 6; ++k) row.scatter[k] = 0.0;
+    if (fl & 1u) {
+        const double c[3] = {axis_centre(row.sx, P.ox, P.grid_len), axis_centre(row.sy, P.oy, P.grid_len),
+                             axis_centre(row.sz, P.oz, P.z_len)};
+        node_moments(a.count, a.s, c, row.mean, row.scatter);
+    }
+    row.col_first = T.col_first[cs]; row.idx_in_col = icol; row.ncol = T.col_cnt[cs];
+    for (int k = 0; k < 8; ++k) row.pad[k] = 0;
+}
 
 __global__ void __launch_bounds__(kBlock) k_tab_begin(TableView T, Counters* __restrict__ cnt, PartCounters* __restrict__ pc,
                                                       uint32_t* __restrict__ bitmap, uint32_t* __restrict__ word_weight,
@@ -49,18 +120,7 @@ __global__ void __launch_bounds__(kBlock) k_tab_columns(TableView T, GridParams 
         x.flags = 0u; x.mean_z = 0.f;
         if (a.count >= (uint32_t)P.min_points) { x.mean_z = node_mean_z(a.count, a.s[2], axis_centre(sz, P.oz, P.z_len)); x.flags = 1u; }
         T.aux[s] = x;
-        const uint64_t ck = column_key(key);
-        uint32_t cs = (uint32_t)mix64(ck) & T.cap_mask;
-        for (uint32_t probe = 0; probe <= T.cap_mask; ++probe) {
-            const uint64_t k = T.col_keys[cs];
-            if (k == ck) break;
-            if (k == kEmptyKey) {
-                const unsigned long long old = atomicCAS((unsigned long long*)&T.col_keys[cs], (unsigned long long)kEmptyKey,
-                                                         (unsigned long long)ck);
-                if (old == kEmptyKey || old == ck) break;
-            }
-            cs = (cs + 1) & T.cap_mask;
-        }
+        const uint32_t cs = tab_column_slot(T, column_key(key));
         T.col_slot_of_node[i] = cs;
         atomicMin(&T.col_first[cs], a.first);
         atomicAdd(&T.col_cnt[cs], 1u);
@@ -79,53 +139,15 @@ __global__ void __launch_bounds__(kBlock) k_tab_rows(TableView T, GridParams P, 
     if (n > stage_cap) { if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&pc->stage_overflow, n); return; }
     uint32_t my_slopes = 0, my_cols = 0;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const uint32_t s = T.node_slot[i];
-        const uint64_t key = T.keys[s];
-        const NodeAcc a = T.acc[s];
-        const uint32_t cs = T.col_slot_of_node[i];
-        uint32_t fl = T.aux[s].flags & 1u;
-        const float cz = T.aux[s].mean_z;
         StageRow row;
-        unpack_key(key, row.sx, row.sy, row.sz);
-        const int za = level_above(row.sz), zb = level_below(row.sz);
-        uint32_t icol = 0;
-        bool up = false, down = false;
-        for (uint32_t t = T.col_head[cs]; t != 0xFFFFFFFFu; t = T.node_next[t]) {
-            if (t == i) continue;
-            const uint32_t ts = T.node_slot[t];
-            const uint32_t tf = T.acc[ts].first;
-            icol += (tf < a.first) ? 1u : 0u;
-            const int tz = (int)(T.keys[ts] & 0x3FFFFFu) - (1 << 21);
-            if (tz == za || tz == zb) {
-                const SlotAux tx = T.aux[ts];
-                const bool visited = tf < a.first && (tx.flags & 1u);
-                const float oz = visited ? tx.mean_z : 0.f;
-                const bool far = fabsf(oz - cz) > P.slope_interval;
-                if (tz == za) up = up || far; else down = down || far;
-            }
-        }
-        if (fl & 1u) {
-            bool slope = true;
-            if (P.demand == 0) slope = !up; else down = false;
-            if (slope) { fl |= 2u; if (down) fl |= 4u; ++my_slopes; }
-        }
-        row.count = a.count; row.first = a.first; row.flags = fl;
-        for (int k = 0; k < 3; ++k) row.mean[k] = 0.f;
-        for (int k = 0; k < 6; ++k) row.scatter[k] = 0.0;
-        if (fl & 1u) {
-            const double c[3] = {axis_centre(row.sx, P.ox, P.grid_len), axis_centre(row.sy, P.oy, P.grid_len),
-                                 axis_centre(row.sz, P.oz, P.z_len)};
-            node_moments(a.count, a.s, c, row.mean, row.scatter);
-        }
-        const uint32_t cf = T.col_first[cs];
-        row.col_first = cf; row.idx_in_col = icol; row.ncol = T.col_cnt[cs];
-        for (int k = 0; k < 8; ++k) row.pad[k] = 0;
+        tab_make_row(T, P, i, row);
+        if (row.flags & 2u) ++my_slopes;
         stage[i] = row;
-        ord_cf[i] = cf;
-        ord_idx[i] = icol;
-        if (icol == 0) {
+        ord_cf[i] = row.col_first;
+        ord_idx[i] = row.idx_in_col;
+        if (row.idx_in_col == 0) {
             // the bitmap was sized from the host's view of the stream (max_points_hint for captured updates)
-            if ((uint64_t)(cf >> 5) < words) note_column(O, cf, row.ncol);
+            if ((uint64_t)(row.col_first >> 5) < words) note_column(O, row.col_first, row.ncol);
             else atomicAdd(&pc->index_overflow, 1u);
             ++my_cols;
         }
@@ -141,7 +163,115 @@ __global__ void __launch_bounds__(kBlock) k_tab_rows(TableView T, GridParams P, 
 }
 
 __global__ void k_tab_end(Counters* cnt) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) cnt->prev_nodes = cnt->num_nodes;
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        cnt->prev_nodes = cnt->num_nodes;
+        cnt->n_touched = 0; cnt->n_tcols = 0; cnt->n_work = 0;
+        cnt->epoch = cnt->epoch + 1u;
+    }
+}
+
+// Incremental finalisation, step 1: the nodes the frame touched.
+__global__ void __launch_bounds__(kBlock) k_tab_touch(TableView T, GridParams P, Counters* __restrict__ cnt,
+                                                      PartCounters* __restrict__ pc) {
+    const uint32_t n = cnt->n_touched, np = cnt->prev_nodes, epoch = cnt->epoch;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { pc->lds_overflow = 0; pc->stage_overflow = 0; pc->index_overflow = 0; pc->part_overflow = 0; }
+    const uint32_t n_round = (n + 63u) & ~63u;                 // whole waves for the aggregated list append
+    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n_round; j += gridDim.x * blockDim.x) {
+        bool first = false;
+        uint32_t cs = 0;
+        if (j < n) {
+            const uint32_t s = T.touched[j];
+            const uint32_t i = T.index_of_slot[s];
+            const uint64_t key = T.keys[s];
+            const NodeAcc a = T.acc[s];
+            const int sz = (int)(key & 0x3FFFFFu) - (1 << 21);
+            SlotAux x;
+            x.flags = 0u; x.mean_z = 0.f;
+            if (a.count >= (uint32_t)P.min_points) { x.mean_z = node_mean_z(a.count, a.s[2], axis_centre(sz, P.oz, P.z_len)); x.flags = 1u; }
+            T.aux[s] = x;
+            if (i >= np) {                                     // a node born in this frame joins its column
+                cs = tab_column_slot(T, column_key(key));
+                T.col_slot_of_node[i] = cs;
+                atomicMin(&T.col_first[cs], a.first);
+                atomicAdd(&T.col_cnt[cs], 1u);
+                T.node_next[i] = atomicExch(&T.col_head[cs], i);
+            } else {
+                cs = T.col_slot_of_node[i];
+            }
+            first = atomicExch(&T.col_epoch[cs], epoch) != epoch;
+        }
+        const unsigned long long m = __ballot(first);
+        if (m) {
+            const int lane = threadIdx.x & 63, leader = (int)__builtin_ctzll(m);
+            uint32_t base = 0;
+            if (lane == leader) base = atomicAdd(&cnt->n_tcols, (uint32_t)__popcll(m));
+            base = (uint32_t)__shfl((int)base, leader, 64);
+            if (first) T.touched_cols[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = cs;
+        }
+    }
+}
+
+// Incremental finalisation, step 2: the nodes of the touched columns, as a flat work list (it reuses touched[], which
+// step 1 has consumed).  A wave adds up its columns' node counts and reserves the space with one atomic.
+__global__ void __launch_bounds__(kBlock) k_tab_expand(TableView T, Counters* __restrict__ cnt) {
+    const uint32_t nc = cnt->n_tcols;
+    const uint32_t nc_round = (nc + 63u) & ~63u;
+    for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < nc_round; c += gridDim.x * blockDim.x) {
+        uint32_t cs = 0, n = 0;
+        if (c < nc) { cs = T.touched_cols[c]; n = T.col_cnt[cs]; }
+        uint32_t incl = n;
+        const int lane = threadIdx.x & 63;
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)incl, o, 64); if (lane >= o) incl += t; }
+        const uint32_t total = (uint32_t)__shfl((int)incl, 63, 64);
+        uint32_t base = 0;
+        if (lane == 63 && total) base = atomicAdd(&cnt->n_work, total);
+        base = (uint32_t)__shfl((int)base, 63, 64) + incl - n;
+        if (c < nc)
+            for (uint32_t t = T.col_head[cs]; t != 0xFFFFFFFFu; t = T.node_next[t]) T.touched[base++] = t;
+    }
+}
+
+// Incremental finalisation, step 3: a fresh staging row for every listed node; the first node of a column also updates
+// the column's place in the order by what the column gained.
+__global__ void __launch_bounds__(kBlock) k_tab_rows_touched(TableView T, GridParams P, StageRow* __restrict__ stage,
+                                                             uint32_t stage_cap, uint32_t* __restrict__ ord_cf,
+                                                             uint32_t* __restrict__ ord_idx, ColumnOrder O, uint64_t words,
+                                                             Counters* __restrict__ cnt, PartCounters* __restrict__ pc) {
+    __shared__ int s_slopes;
+    __shared__ uint32_t s_cols;
+    if (threadIdx.x == 0) { s_slopes = 0; s_cols = 0; }
+    __syncthreads();
+    const uint32_t nw = cnt->n_work, np = cnt->prev_nodes;
+    if (cnt->num_nodes > stage_cap) { if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&pc->stage_overflow, cnt->num_nodes); return; }
+    int my_slopes = 0;
+    uint32_t my_cols = 0;
+    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < nw; j += gridDim.x * blockDim.x) {
+        const uint32_t t = T.touched[j];
+        const uint32_t old_flags = (t < np) ? stage[t].flags : 0u;
+        StageRow row;
+        tab_make_row(T, P, t, row);
+        my_slopes += (int)((row.flags >> 1) & 1u) - (int)((old_flags >> 1) & 1u);
+        stage[t] = row;
+        ord_cf[t] = row.col_first;
+        ord_idx[t] = row.idx_in_col;
+        if (row.idx_in_col == 0) {
+            // the column in the order: a stream only appends (first-seen indices grow), so cf is stable once the column exists
+            const uint32_t cf = row.col_first, w = cf >> 5, bit = 1u << (cf & 31u);
+            if ((uint64_t)w >= words) { atomicAdd(&pc->index_overflow, 1u); continue; }
+            const bool had = (O.bitmap[w] & bit) != 0u;
+            const uint32_t old_n = had ? O.ncol_at[cf] : 0u;
+            if (!had) { atomicOr(&O.bitmap[w], bit); ++my_cols; }
+            if (row.ncol != old_n) atomicAdd(&O.word_weight[w], row.ncol - old_n);
+            O.ncol_at[cf] = row.ncol;
+        }
+    }
+    if (my_slopes) atomicAdd(&s_slopes, my_slopes);
+    if (my_cols) atomicAdd(&s_cols, my_cols);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (s_slopes) atomicAdd(&cnt->num_slopes, (uint32_t)s_slopes);     // two's complement: also subtracts
+        if (s_cols) atomicAdd(&cnt->num_columns, s_cols);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------

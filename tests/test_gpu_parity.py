@@ -472,3 +472,36 @@ def test_partition_build_replayed_from_a_hip_graph():
         cloud = np.concatenate([origin[None, :], clouds[k][1:]], 0)
         ref = parity.ref_from_cloud(cloud, dict(grid_len=0.5, z_len=0.5, slope_interval=0.08, demand="slope"))
         parity.assert_parity(m.export(), ref)
+
+
+def test_long_stream_incremental_finalisation_equals_batch_builds():
+    """gndt_update relabels only the columns a frame touched (after the first, full, finalisation).  A stream of uneven
+    frames — some only revisiting old nodes, some opening columns, small ones that lift nodes over the 3-point threshold —
+    must equal the batch build of the concatenation at every checkpoint; a call that borrows the order's buffers in the
+    middle (pack_points) and a table that has to grow must not disturb it."""
+    import torch
+    import grid_ndt_amd as g
+    ppf = 20000
+    frames = scenes.terrain_frames(12, first_pose=2, points_per_frame=ppf)
+    cuts = [0]
+    rng = np.random.default_rng(5)
+    while cuts[-1] < frames.shape[0]:
+        cuts.append(min(frames.shape[0], cuts[-1] + int(rng.choice([37, 500, 7000, 20000, 33000]))))
+    m = g.TwoDmap(TERRAIN["grid_len"], TERRAIN["z_len"], strategy=1)       # no hint: the table grows on the way
+    m.setInterval(TERRAIN["slope_interval"])
+    m.setCloudFirst(frames[0])
+    dev = torch.from_numpy(frames).cuda()
+    for k in range(len(cuts) - 1):
+        m.change2DMap("slope", dev[cuts[k]:cuts[k + 1]])
+        if k == 5:
+            junk = torch.zeros(1000, 4, dtype=torch.float32, device="cuda")
+            assert m.pack_points(junk, 16).shape[0] == 1000           # uses the order's bitmap as scratch
+        if k in (2, 6, len(cuts) - 2):
+            cloud = np.concatenate([frames[:1], frames[:cuts[k + 1]]], 0)
+            parity.assert_parity(m.export(), parity.ref_from_cloud(cloud, TERRAIN))
+    # revisiting exactly the same points again doubles every count and keeps keys, order and labels' inputs consistent
+    before = m.export()
+    m.change2DMap("slope", dev[:cuts[3]])
+    after = m.export()
+    assert np.array_equal(after["sx"], before["sx"]) and np.array_equal(after["first_idx"], before["first_idx"])
+    assert int(after["count"].astype(np.int64).sum()) == int(before["count"].astype(np.int64).sum()) + cuts[3]
