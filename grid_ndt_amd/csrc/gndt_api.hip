@@ -109,6 +109,7 @@ struct gndt_handle {
         uint64_t node_cap = 0;     uint32_t *h_bits = nullptr, *pushed = nullptr, *state = nullptr, *f[2] = {nullptr, nullptr};
         uint32_t ctab_size = 0;    uint64_t* ctab_key = nullptr; uint32_t* ctab_val = nullptr;
         uint32_t* ring = nullptr;
+        uint32_t* nbr = nullptr;       // [4 * node_cap] neighbour columns of every row
         CostCounters* d_cc = nullptr;
         CostCounters* h_cc = nullptr;   // pinned
         uint64_t serial = 0;            // result_serial the flood was computed for (0 = none)
@@ -298,7 +299,7 @@ int grow_buf(gndt_handle* h, T*& p, uint64_t& cap, uint64_t want) {
 
 void free_cost(gndt_handle* h) {
     auto& c = h->cost;
-    void* ptrs[] = {c.h_bits, c.pushed, c.state, c.f[0], c.f[1], c.ctab_key, c.ctab_val, c.ring, c.d_cc};
+    void* ptrs[] = {c.h_bits, c.pushed, c.state, c.f[0], c.f[1], c.ctab_key, c.ctab_val, c.ring, c.nbr, c.d_cc};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (c.h_cc) (void)hipHostFree(c.h_cc);
@@ -1186,10 +1187,11 @@ int gndt_compute_cost(gndt_handle* h, const float goal_xyz[3], const gndt_robot*
         HIP_TRY(h, hipMalloc(&c.ring, (size_t)kCostBlocks * kCostThreads * kRingCap * sizeof(uint32_t)));
     }
     if (n > c.node_cap) {
-        for (uint32_t** a : {&c.h_bits, &c.pushed, &c.state, &c.f[0], &c.f[1]}) { if (*a) (void)hipFree(*a); *a = nullptr; }
+        for (uint32_t** a : {&c.h_bits, &c.pushed, &c.state, &c.f[0], &c.f[1], &c.nbr}) { if (*a) (void)hipFree(*a); *a = nullptr; }
         c.node_cap = 0;
         const uint64_t cap = std::max<uint64_t>(1024, n + n / 8);
         for (uint32_t** a : {&c.h_bits, &c.pushed, &c.state, &c.f[0], &c.f[1]}) HIP_TRY(h, hipMalloc(a, cap * 4));
+        HIP_TRY(h, hipMalloc(&c.nbr, cap * 16));
         c.node_cap = cap;
     }
     const uint32_t tsize = pow2_ceil(std::max<uint64_t>(1024, 2 * K));
@@ -1209,6 +1211,7 @@ int gndt_compute_cost(gndt_handle* h, const float goal_xyz[3], const gndt_robot*
     V.mean = h->out.mean; V.normal = h->out.normal; V.rough = h->out.rough; V.flags = h->out.flags;
     V.row_ncol = h->part.row_ncol;
     V.ctab_key = c.ctab_key; V.ctab_val = c.ctab_val; V.ctab_mask = c.ctab_size - 1;
+    V.nbr = nullptr;
     V.slope_interval = h->P.slope_interval; V.demand_true = h->P.demand == GNDT_DEMAND_TRUE ? 1 : 0;
     // the goal's key through the same codec the build uses (transMortonXYZ, map2D.h:1293)
     const PointKey gk = point_key(goal_xyz[0], goal_xyz[1], goal_xyz[2], h->origin[0], h->origin[1], h->origin[2],
@@ -1218,6 +1221,10 @@ int gndt_compute_cost(gndt_handle* h, const float goal_xyz[3], const gndt_robot*
     if (K)
         hipLaunchKernelGGL(k_cost_columns, dim3(grid_for(n)), dim3(256), 0, s, h->out.sx, h->out.sy, h->part.row_ncol,
                            (uint32_t)n, c.ctab_key, c.ctab_val, c.ctab_size - 1, c.d_cc);
+    if (K) {
+        hipLaunchKernelGGL(k_cost_neighbours, dim3(grid_for(4 * n)), dim3(256), 0, s, V, (uint32_t)n, c.nbr);   // (probes: V.nbr is null)
+        V.nbr = c.nbr;
+    }
     if (gk.ok && K)
         hipLaunchKernelGGL(k_cost_goal, dim3(1), dim3(64), 0, s, V, gk.sx, gk.sy, gk.sz, c.h_bits, c.pushed, c.f[0], c.d_cc);
     HIP_TRY(h, hipGetLastError());

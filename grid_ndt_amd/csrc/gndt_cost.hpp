@@ -54,6 +54,9 @@ struct CostView {
     const uint64_t* ctab_key;
     const uint32_t* ctab_val;
     uint32_t ctab_mask;
+    // optional: nbr[4 * row + k] = first row of the row's k-th neighbour column (left, right, forward, back) or kNoColumn,
+    // precomputed for every row so that the per-layer kernels do not probe the hash table (null: probe)
+    const uint32_t* nbr;
     float slope_interval;
     int demand_true;
 };
@@ -133,6 +136,10 @@ GNDT_HD bool cost_gates(const CostView& V, const Robot& R, uint32_t s, const flo
 
 // The four neighbour columns in the reference's order: left, right, forward, back (map2D.h:540-546).
 GNDT_HD void neighbour_columns(const CostView& V, uint32_t row, uint32_t col[4]) {
+    if (V.nbr) {
+        for (int k = 0; k < 4; ++k) col[k] = V.nbr[4 * (size_t)row + k];
+        return;
+    }
     const int sx = V.sx[row], sy = V.sy[row];
     col[0] = ctab_find(V, sx, step_skip0(sy, -1));
     col[1] = ctab_find(V, sx, step_skip0(sy, +1));
@@ -212,11 +219,16 @@ GNDT_HD float bits_float(uint32_t u) { union { float f; uint32_t u; } v; v.u = u
 template <typename Relax>
 GNDT_HD uint32_t cost_expand_dir(const CostView& V, const Robot& R, uint32_t q, float hq, int dir, Relax relax) {
     GNDT_FP_STRICT
-    const int sx = V.sx[q], sy = V.sy[q];
-    const uint32_t c = dir == 0 ? ctab_find(V, sx, step_skip0(sy, -1))
-                     : dir == 1 ? ctab_find(V, sx, step_skip0(sy, +1))
-                     : dir == 2 ? ctab_find(V, step_skip0(sx, +1), sy)
-                                : ctab_find(V, step_skip0(sx, -1), sy);
+    uint32_t c;
+    if (V.nbr) {
+        c = V.nbr[4 * (size_t)q + dir];
+    } else {
+        const int sx = V.sx[q], sy = V.sy[q];
+        c = dir == 0 ? ctab_find(V, sx, step_skip0(sy, -1))
+          : dir == 1 ? ctab_find(V, sx, step_skip0(sy, +1))
+          : dir == 2 ? ctab_find(V, step_skip0(sx, +1), sy)
+                     : ctab_find(V, step_skip0(sx, -1), sy);
+    }
     if (c == kNoColumn) return 0u;
     uint32_t checks = 0;
     const uint32_t b = c, e = c + V.row_ncol[c];
@@ -280,6 +292,18 @@ __global__ void __launch_bounds__(256) k_cost_columns(const int32_t* __restrict_
             if (old == kEmptyKey) { ctab_val[s] = row; break; }
             s = (s + 1) & ctab_mask;
         }
+    }
+}
+
+// the four neighbour columns of every row, once per flood (the layers then follow plain indices)
+__global__ void __launch_bounds__(256) k_cost_neighbours(CostView V, uint32_t num_rows, uint32_t* __restrict__ nbr) {
+    for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < 4u * num_rows; t += gridDim.x * blockDim.x) {
+        const uint32_t row = t >> 2, k = t & 3u;
+        const int sx = V.sx[row], sy = V.sy[row];
+        nbr[t] = k == 0 ? ctab_find(V, sx, step_skip0(sy, -1))
+               : k == 1 ? ctab_find(V, sx, step_skip0(sy, +1))
+               : k == 2 ? ctab_find(V, step_skip0(sx, +1), sy)
+                        : ctab_find(V, step_skip0(sx, -1), sy);
     }
 }
 

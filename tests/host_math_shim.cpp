@@ -72,7 +72,7 @@ extern "C" int shim_cost(uint64_t n, const int32_t* sx, const int32_t* sy, const
         while (tkey[s] != kEmptyKey) s = (s + 1) & (tsize - 1);
         tkey[s] = key; tval[s] = col_base[c];
     }
-    CostView V{sx, sy, sz, mean, normal, rough, flags, row_ncol.data(), tkey.data(), tval.data(), tsize - 1,
+    CostView V{sx, sy, sz, mean, normal, rough, flags, row_ncol.data(), tkey.data(), tval.data(), tsize - 1, nullptr,
                slope_interval, demand_true};
     Robot R{robot4[0], robot4[1], robot4[2], robot4[3]};
     const int ring_n = cost_ring_depth(R.r, grid_len);
