@@ -148,14 +148,15 @@ def assert_parity(gpu, ref, demand="slope"):
 def ref_from_cloud(cloud, params, mode=0, threads=0):
     from oracle import oracle
     return oracle.build_grid(cloud, params["grid_len"], params["z_len"], params["slope_interval"],
-                             params.get("demand", "slope"), mode=mode, threads=threads)
+                             params.get("demand", "slope"), min_points=params.get("min_points", 3), mode=mode, threads=threads)
 
 
 def gpu_from_cloud(cloud, params, device=0, on_device=True, strategy=0, max_nodes_hint=0):
     """Run libgndt the way chatterCallback would: origin = point 0, bin points 1..n-1."""
     import torch
     import grid_ndt_amd as g
-    m = g.TwoDmap(params["grid_len"], params["z_len"], device=device, strategy=strategy, max_nodes_hint=max_nodes_hint)
+    m = g.TwoDmap(params["grid_len"], params["z_len"], device=device, strategy=strategy, max_nodes_hint=max_nodes_hint,
+                  min_points=params.get("min_points", 3))
     m.setInterval(params["slope_interval"])
     m.setCloudFirst(cloud[0, :3])
     body = cloud[1:]

@@ -86,3 +86,16 @@ def test_degenerate_large_clouds_fall_through_the_partition_paths(kind):
         m, out = parity.gpu_from_cloud(cloud, P, on_device=True, strategy=strategy)
         parity.assert_parity(out, ref)
 
+
+
+@pytest.mark.parametrize("min_points", [1, 2, 5])
+def test_min_points_other_than_the_reference_constant(min_points):
+    """MINPOINTSIZE is 3 in the reference (map2D.h:28); the handle takes it as a parameter and every place that tests it
+    (statistics, the `visited` rule of the slope test, the lazily evaluated `up`) must follow."""
+    cloud, P = _cloud(1100)
+    P = dict(P, min_points=min_points)
+    ref = parity.ref_from_cloud(cloud, P)
+    assert ((ref["flags"] & 1) != 0).sum() != ((parity.ref_from_cloud(cloud, dict(P, min_points=3))["flags"] & 1) != 0).sum()
+    for strategy in (1, 3, 4):
+        _, out = parity.gpu_from_cloud(cloud, P, on_device=True, strategy=strategy)
+        parity.assert_parity(out, ref)
