@@ -174,7 +174,9 @@ __global__ void k_tab_end(Counters* cnt) {
 __global__ void __launch_bounds__(kBlock) k_tab_touch(TableView T, GridParams P, Counters* __restrict__ cnt,
                                                       PartCounters* __restrict__ pc) {
     const uint32_t n = cnt->n_touched, np = cnt->prev_nodes, epoch = cnt->epoch;
-    if (blockIdx.x == 0 && threadIdx.x == 0) { pc->lds_overflow = 0; pc->stage_overflow = 0; pc->index_overflow = 0; pc->part_overflow = 0; }
+    // (stage_overflow and index_overflow stay set once raised: an incremental finalisation builds on the rows and the
+    //  column order of the previous ones, so a frame that could not be recorded invalidates the map until a reset)
+    if (blockIdx.x == 0 && threadIdx.x == 0) { pc->lds_overflow = 0; pc->part_overflow = 0; }
     const uint32_t n_round = (n + 63u) & ~63u;                 // whole waves for the aggregated list append
     for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n_round; j += gridDim.x * blockDim.x) {
         bool first = false;
