@@ -1,17 +1,25 @@
 #!/usr/bin/env python3
 """bench.py — NDT grid-build throughput (bin + mean/cov + eigen + labels + ordering) on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
-    (N > 1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py --gpus N --steps K --warmup W [--workload S1|S2|S2z|S3|S5] [--mode global|replicas]
 
-A "step" is one full build of the map from a device-resident cloud (`create2DMap`).  At N = 1 the
-workload is BASELINE.json configs[1]: 10 M uniform-random points, 0.5 m cubic voxels.
-At N > 1 every rank holds its own 10 M-point shard (weak scaling); see --mode.
-Prints ONE JSON line on rank 0.
+A "step" is one full build of the map from a device-resident cloud (`create2DMap`, receiver.cpp:150-160).
+
+N = 1 (default): BASELINE.json configs[1] — S2, 10 M uniform-random points, 0.5 m cubic voxels.
+N > 1 (default): BASELINE.json configs[2] — S3, ONE global map of a 100 M-point LiDAR-ordered terrain cloud, 0.2 m cubic
+         voxels, sharded over the ranks as contiguous index ranges (strong scaling: the total is fixed), per-node
+         statistics exchanged over RCCL (`--mode global`).  `--mode replicas` builds one independent map per rank
+         instead (frame-level batches: no collective, weak scaling).
+
+With N > 1 and no RANK in the environment this script starts the N ranks itself (`python -m torch.distributed.run`
+as a child process, before anything here touches the GPU) and relays their output; under torchrun it is a rank.
+Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -24,99 +32,232 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md, ch
 BYTES_PER_POINT = 12           # one read of packed fp32 xyz          
 BYTES_PER_NODE = 76            # one write of the node's result row   
 
+WORKLOADS = {
+    "S1": dict(desc="S1: single 200 k-point campus frame (freiburg2_16 stand-in), grid 0.5 / z 0.1 m (BASELINE.json configs[0])",
+               points=200_000, grid_len=0.5, z_len=0.1, hint=0),
+    "S2": dict(desc="S2: 10M uniform-random points in [-100,100)^2 x [-1,1), 0.5 m cubic voxels, demand=slope (BASELINE.json configs[1])",
+               points=10_000_000, grid_len=0.5, z_len=0.5, hint=1 << 20),
+    "S2z": dict(desc="S2 variant: 10M uniform-random points, grid 0.5 / z 0.1 m (the reference's launch default)",
+                points=10_000_000, grid_len=0.5, z_len=0.1, hint=3_400_000),
+    "S3": dict(desc="S3: LiDAR-ordered outdoor terrain, 0.2 m cubic voxels, demand=slope (BASELINE.json configs[2])",
+               points=100_000_000, grid_len=0.2, z_len=0.2, hint=0),
+    "S5": dict(desc="S5: two-storey site (site125 stand-in), 15 % of the points at (0,0,0), 0.1 m cubic voxels (BASELINE.json configs[4])",
+               points=20_000_000, grid_len=0.1, z_len=0.1, hint=0),
+}
+
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--points", type=int, default=10_000_000, help="points per rank")
-    ap.add_argument("--grid-len", type=float, default=0.5)
-    ap.add_argument("--z-len", type=float, default=0.5)
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default=None, help="default: S2 at N = 1, S3 at N > 1")
+    ap.add_argument("--points", type=int, default=0, help="binned points of the workload, all ranks together (0 = its BASELINE size)")
     ap.add_argument("--strategy", type=int, default=0)
-    ap.add_argument("--mode", choices=["replicas", "global"], default="replicas",
-                    help="N>1: independent per-rank maps (no collective) or one global map via RCCL stats exchange")
+    ap.add_argument("--mode", choices=["replicas", "global"], default=None,
+                    help="N>1: one global map via the RCCL statistics exchange (default) or independent per-rank maps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=2_000_000)
+    ap.add_argument("--no-extras", action="store_true", help="skip the single-build latency / no-hint / H2D-D2H measurements")
+    ap.add_argument("--cpu-sample", type=int, default=0, help="points of the CPU baseline's sample (0 = the whole workload, capped at 10 M)")
     ap.add_argument("--check", action="store_true", help="also check a 300 k-point build against the oracle")
     ap.add_argument("--stamps", action="store_true",
                     help="diagnostic: after the timed run, one extra build with in-kernel phase stamps (stderr)")
-    ap.add_argument("--nodes-hint", type=int, default=1 << 20)
+    ap.add_argument("--nodes-hint", type=int, default=-1, help="max_nodes_hint (-1 = the workload's default)")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="CPU-only check of the self-launch path: the ranks rendezvous over gloo, shard a small cloud "
+                         "exactly as the timed run would, and rank 0 prints what every rank got")
     return ap.parse_args()
 
 
-def cpu_baseline(cloud, P, sample):
-    """Oracle (faithful restatement of the reference path) timed on this box's host cores, on the
-    first `sample` points of the same workload.  Reported, never the thing measured as `value`."""
+def self_launch(a):
+    """`python bench.py --gpus N` without a launcher: start the ranks as a child job.  The parent never touches the
+    GPU (device_count does not initialise it on this image); it only relays the child's exit code."""
+    import torch
+    have = torch.cuda.device_count()
+    if have < a.gpus and not a.launch_check:
+        print(f"bench.py: --gpus {a.gpus} but only {have} GPU(s) visible", file=sys.stderr)
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def make_cloud(name, nb, rank, world, global_mode):
+    """`nb` = binned points of the workload (the cloud has nb + 1: point 0 is the origin, receiver.cpp:145).
+    -> (origin xyz, this rank's points [n,3] float32 WITHOUT the origin point, index of its first point in the
+    accumulated stream, total binned points of the job)."""
+    from grid_ndt_amd import scenes
+    if name == "S3":
+        ppf = scenes.FRAME_POINTS
+        origin = scenes.terrain_frames(1, 0)[0].copy()
+        if global_mode:                                       # contiguous index ranges of ONE cloud: global indices 1 .. nb
+            lo, hi = 1 + rank * nb // world, 1 + (rank + 1) * nb // world
+        else:                                                 # replicas: every rank its own stretch of the pose stream
+            lo, hi = 1 + rank * (nb + 1), (rank + 1) * (nb + 1)
+            if rank:
+                origin = scenes.terrain_frames(1, (lo - 1) // ppf)[(lo - 1) % ppf].copy()
+        f0, f1 = lo // ppf, (hi + ppf - 1) // ppf
+        pts = scenes.terrain_frames(f1 - f0, f0)[lo - f0 * ppf: hi - f0 * ppf]
+        return origin, np.ascontiguousarray(pts), (lo - 1) if global_mode else 0, (nb if global_mode else nb * world)
+    seed_shift = 0 if global_mode else rank
+    if name in ("S2", "S2z"):
+        cloud = scenes.uniform_box(nb + 1, seed=0x5EED0002 + seed_shift)
+    elif name == "S1":
+        cloud = scenes.campus_frame(nb + 1, seed=0x5EED0001 + seed_shift)
+    else:
+        cloud = scenes.site_two_storey(nb + 1, seed=0x5EED0005 + seed_shift)
+    origin = cloud[0].copy()
+    if global_mode:
+        lo, hi = 1 + rank * nb // world, 1 + (rank + 1) * nb // world
+        return origin, np.ascontiguousarray(cloud[lo:hi]), lo - 1, nb
+    return origin, np.ascontiguousarray(cloud[1:]), 0, nb * world
+
+
+def cpu_baseline(origin, pts, P, sample):
+    """Oracle (faithful restatement of the reference path) timed on this box's host cores on the first `sample`
+    points of the same workload: reported beside `value`, never the thing measured as `value`."""
     from oracle import oracle
-    sub = np.ascontiguousarray(cloud[:sample + 1])
+    sub = np.ascontiguousarray(np.concatenate([origin[None, :], pts[:sample]], 0))
     threads = oracle.max_threads()
-    t0 = time.perf_counter()
-    r = oracle.build_grid(sub, P["grid_len"], P["z_len"], P["slope_interval"], "slope", mode=oracle.MODE_INT_OPENMP,
-                          threads=threads, export=False)
-    dt = r["t_division"] + r["t_calculate"]
-    wall = time.perf_counter() - t0
+    runs = {}
+    for label, th in (("all_cores", threads), ("one_core", 1)):
+        t0 = time.perf_counter()
+        r = oracle.build_grid(sub, P["grid_len"], P["z_len"], P["slope_interval"], "slope", mode=oracle.MODE_INT_OPENMP,
+                              threads=th, export=False)
+        runs[label] = (r["t_division"], r["t_calculate"], time.perf_counter() - t0)
     n_ser = min(sample, 200_000)
-    r0 = oracle.build_grid(np.ascontiguousarray(cloud[:n_ser + 1]), P["grid_len"], P["z_len"], P["slope_interval"], "slope",
+    r0 = oracle.build_grid(np.ascontiguousarray(sub[:n_ser + 1]), P["grid_len"], P["z_len"], P["slope_interval"], "slope",
                            mode=oracle.MODE_AS_SHIPPED, export=False)
     dt0 = r0["t_division"] + r0["t_calculate"]
-    return {"value": round(sample / dt / 1e6, 4), "unit": "Mpoints/s", "cores": threads, "kind": "port",
-            "sample": f"first {sample} points of the workload, oracle mode 2 (OpenMP, integer keys); "
-                      f"division {r['t_division']:.2f}s + calculate {r['t_calculate']:.2f}s (wall {wall:.1f}s)",
+    d, c, wall = runs["all_cores"]
+    d1, c1, _ = runs["one_core"]
+    whole = sample >= pts.shape[0]
+    return {"value": round(sample / (d + c) / 1e6, 4), "unit": "Mpoints/s", "cores": threads, "kind": "port",
+            "sample": (f"all {sample} points of the workload" if whole else f"first {sample} points of the workload") +
+                      f", oracle mode 2 (OpenMP, integer keys); division {d:.2f}s + calculate {c:.2f}s (wall {wall:.1f}s)",
+            "same_code_one_core": {"value": round(sample / (d1 + c1) / 1e6, 4), "unit": "Mpoints/s", "cores": 1},
             "as_shipped_serial": {"value": round(n_ser / dt0 / 1e6, 4), "unit": "Mpoints/s", "cores": 1,
                                   "sample": f"first {n_ser} points, oracle mode 0 (strings + multimap, as the reference runs)"}}
 
 
+def committed_traffic(kernel_substr):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes — only when that profile
+    was taken from THIS source tree (hash of the kernel sources stored in the profile); otherwise null."""
+    from grid_ndt_amd import _lib
+    prof_dir = os.path.join(ROOT, "profiles")
+    cur = _lib.source_hash()
+    best = None
+    for fn in sorted(os.listdir(prof_dir)) if os.path.isdir(prof_dir) else []:
+        if not fn.endswith("_pmc.json"):
+            continue
+        try:
+            doc = json.load(open(os.path.join(prof_dir, fn)))
+        except Exception:
+            continue
+        if doc.get("source_hash") != cur:
+            continue
+        for name, rec in doc.get("kernels", {}).items():
+            if kernel_substr and kernel_substr in name:
+                best = (rec.get("hbm_bytes_corrected"), f"profiles/{fn} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, "
+                                                         f"source_hash {cur[:12]})")
+    return best if best else (None, None)
+
+
+def launch_check(a, rank, world):
+    """No GPU: proves that `bench.py --gpus N` reaches N ranks with the right arguments and that the shards of the
+    default N > 1 workload tile the cloud (tests/test_bench_launcher.py)."""
+    import torch
+    import torch.distributed as dist
+    if world != a.gpus:
+        print(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+        sys.exit(2)
+    dist.init_process_group("gloo")
+    wname = a.workload or ("S3" if world > 1 else "S2")
+    mode = a.mode or ("global" if world > 1 else "single")
+    total = a.points or 300_000
+    origin, pts, base, job = make_cloud(wname, total, rank, world, mode == "global")
+    mine = torch.tensor([base, pts.shape[0], job], dtype=torch.int64)
+    got = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(got, mine)
+    if rank == 0:
+        print(json.dumps({"launch_check": True, "n_gpus": world, "workload": wname, "mode": mode,
+                          "shards": [[int(v) for v in g] for g in got], "origin": [float(v) for v in origin]}))
+    dist.destroy_process_group()
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(self_launch(a))
+
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if a.launch_check:
+        return launch_check(a, rank, world)
     assert torch.cuda.is_available(), "bench.py needs a GPU (libgndt has no CPU path)"
+    if world != a.gpus:
+        print(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+        sys.exit(2)
     torch.cuda.set_device(local)
-    use_dist = world > 1 or ("RANK" in os.environ and a.mode == "global")   # torchrun with one rank exercises the exchange too
+    mode = a.mode or ("global" if world > 1 else "single")
+    use_dist = world > 1 or ("RANK" in os.environ and mode == "global")   # torchrun with one rank exercises the exchange too
     if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
-    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    global_mode = use_dist and mode == "global"
 
     import grid_ndt_amd as g
-    from tests import scenes
     g.build_native()
-    P = dict(grid_len=a.grid_len, z_len=a.z_len, slope_interval=0.08, demand="slope")
-    n = a.points
-    cloud = scenes.uniform_box(n + 1, seed=0x5EED0002 + rank)     # point 0 = origin (receiver.cpp:145)
-    global_mode = use_dist and a.mode == "global"
-    if global_mode:
-        origin = scenes.uniform_box(1, seed=0x5EED0002)[0]
-    else:
-        origin = cloud[0]
+    wname = a.workload or ("S3" if world > 1 else "S2")
+    W = WORKLOADS[wname]
+    total = a.points or W["points"]
+    hint = W["hint"] if a.nodes_hint < 0 else a.nodes_hint
+    P = dict(grid_len=W["grid_len"], z_len=W["z_len"], slope_interval=0.08, demand="slope")
+    t_gen = time.perf_counter()
+    origin, host_pts, first_base, job_points = make_cloud(wname, total, rank, world, global_mode)
+    t_gen = time.perf_counter() - t_gen
+    n = host_pts.shape[0]
     dev = torch.device(f"cuda:{local}")
-    pts = torch.from_numpy(cloud[1:]).to(dev)
     torch.cuda.synchronize()
+    t_h2d = time.perf_counter()
+    pts = torch.from_numpy(host_pts).to(dev)
+    torch.cuda.synchronize()
+    t_h2d = time.perf_counter() - t_h2d
 
-    m = g.TwoDmap(P["grid_len"], P["z_len"], device=local, max_nodes_hint=a.nodes_hint, strategy=a.strategy)
-    m.setInterval(P["slope_interval"])
-    m.setCloudFirst(origin)
+    def new_map(nodes_hint):
+        mm = g.TwoDmap(P["grid_len"], P["z_len"], device=local, max_nodes_hint=nodes_hint, strategy=a.strategy)
+        mm.setInterval(P["slope_interval"])
+        mm.setCloudFirst(origin)
+        return mm
+
+    m = new_map(hint)
     stream = torch.cuda.current_stream()
+    exch = {}
 
-    def step():
+    def step(mm=None):
+        mm = mm or m
         if global_mode:
             from grid_ndt_amd import dist as gdist
-            gdist.build_global_map(m, "slope", pts, rank * n, stream)
+            gdist.build_global_map(mm, "slope", pts, first_base, stream, total_points=job_points, timings=exch)
         else:
-            m.create2DMap("slope", pts, stream)
+            mm.create2DMap("slope", pts, stream)
 
     for _ in range(a.warmup):
         step()
-    m.sync()
+    m.sync()                         # overflow flags of the warm-up builds are looked at here (a retry would show)
+    exch.clear()
     # Timed region: HIP events only around the dominant kernel of the strategy in use (two per build, on the launch
     # stream); the full per-phase breakdown comes from a few extra, untimed builds afterwards (events between all
     # kernels cost ~5 % of the step, which would be charged to `value`).
     m.set_profiling(2)
-    phase_sum = {}
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
@@ -128,16 +269,13 @@ def main():
     if use_dist:
         dist.barrier()
     dt = time.perf_counter() - t0
-    # HIP events were recorded on the launch stream around every phase of every step (one event set per build,
-    # a ring of 32); they are read once, after the timed region: mean duration per phase over the timed builds
+    exch_timed = {k: v / max(1, a.steps) for k, v in exch.items()}
     live = {k: v for k, v in m.phase_times_ms().items() if v >= 0}
     m.set_profiling(1)
     for _ in range(3):
         step()
     m.sync()
-    for k, v in m.phase_times_ms().items():
-        if v >= 0:
-            phase_sum[k] = v * a.steps
+    phases = {k: round(v, 4) for k, v in m.phase_times_ms().items() if v >= 0}
     m.set_profiling(0)
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
     if use_dist:
@@ -145,68 +283,95 @@ def main():
     dt = float(t.item())
     nodes, cols, slopes = m.sync()
 
+    # ---- extras (untimed, rank 0 of a single-GPU run): what a 10 Hz callback sees, the no-hint path, PCIe legs ----
+    extras = {}
+    if world == 1 and not a.no_extras and not global_mode:
+        lat = []
+        for _ in range(7):
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            step()
+            m.sync()
+            lat.append((time.perf_counter() - t1) * 1e3)
+        extras["single_build_latency_ms"] = {"median": round(float(np.median(lat)), 4), "min": round(min(lat), 4),
+                                             "what": "one build, launch -> gndt_sync returns (host-timed, stream idle before)"}
+        if hint:
+            m2 = new_map(0)
+            for _ in range(3):
+                step(m2)
+            m2.sync()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(a.steps):
+                step(m2)
+            m2.sync()
+            torch.cuda.synchronize()
+            extras["no_hint_auto"] = {"ms_per_step": round((time.perf_counter() - t1) / a.steps * 1e3, 4),
+                                      "what": "same workload, max_nodes_hint = 0 (node count learned from the previous build)"}
+            del m2
+        t1 = time.perf_counter()
+        res = m.export()
+        extras["d2h_export_ms"] = round((time.perf_counter() - t1) * 1e3, 3)
+        extras["h2d_cloud_ms"] = round(t_h2d * 1e3, 3)
+        extras["pcie_note"] = "pageable host memory, torch copy; never part of `value`"
+        del res
+
     if rank == 0:
         ms_step = dt / a.steps * 1e3
-        default_workload = (n == 10_000_000 and a.grid_len == 0.5 and a.z_len == 0.5 and world == 1)
-        total_points = n * world
-        value = total_points / (dt / a.steps) / 1e6
-        phases = {k: round(v / a.steps, 4) for k, v in phase_sum.items()}
+        value = job_points / (dt / a.steps) / 1e6
         strat = m.STRATEGY_NAMES.get(m.last_strategy(), "?")
         # Dominant kernel = the longest phase.  Its algorithmic bytes (DESIGN.md "Roofline accounting"):
-        # every kernel that streams the cloud moves 12 B/point; k_bucket_build also emits the nodes
+        # every kernel that streams the cloud moves 12 B/point; the bucket kernel also emits the nodes
         # (12 B/point + 76 B/node); node-proportional kernels move 76 B/node.
-        kernel_of = {"accumulate": "k_accumulate", "hist": "k_part_hist", "scatter": "k_part_scatter",
-                     "level1": "k_part2_level1", "level2": "k_part2_level2",
-                     "bucket_build": "k_bucket_build", "columns": "k_tab_columns", "rows": "k_tab_rows",
-                     "emit": "k_emit_rows"}
+        kernel_of = m.KERNEL_OF_PHASE
         cand = {k: v for k, v in phases.items() if k in kernel_of}
         dom = max(cand, key=cand.get) if cand else None
-        # the dominant kernel's duration is the one measured live in the timed region when it is the phase the
-        # two live events bracket (it is, unless the untimed breakdown says another phase is longer)
         acc_ms = live.get(dom, cand.get(dom, float("nan"))) if dom else float("nan")
         timed_live = dom in live
-        if dom in ("accumulate", "hist", "scatter", "level1", "level2"):
+        if dom in m.POINT_PHASES:
             alg_bytes = BYTES_PER_POINT * n
-        elif dom == "bucket_build":
+        elif dom in m.POINT_AND_NODE_PHASES:
             alg_bytes = BYTES_PER_POINT * n + BYTES_PER_NODE * nodes
         else:
             alg_bytes = BYTES_PER_NODE * nodes
         achieved = alg_bytes / (acc_ms * 1e-3) / 1e9 if acc_ms == acc_ms and acc_ms > 0 else None
-        # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process, so the
-        # figure is the one the committed rocprofv3 --pmc passes of THIS workload measured (profiles/),
-        # corrected as MI355X_MICROARCH.md prescribes; null for any other workload.
-        traffic = None
-        pmc_path = os.path.join(ROOT, "profiles", "r01_d_two_level_pmc.json")
-        if default_workload and os.path.exists(pmc_path):
-            for name, rec in json.load(open(pmc_path))["kernels"].items():
-                if kernel_of.get(dom) and kernel_of[dom] in name:
-                    traffic = rec["hbm_bytes_corrected"]
-        path_bytes = BYTES_PER_POINT * n + BYTES_PER_NODE * nodes
+        traffic, traffic_src = (None, None)
+        if wname == "S2" and world == 1 and total == WORKLOADS["S2"]["points"]:
+            traffic, traffic_src = committed_traffic(kernel_of.get(dom))
+        path_bytes = BYTES_PER_POINT * job_points + BYTES_PER_NODE * nodes * (world if mode == "replicas" else 1)
         out = {
             "metric": "NDT grid-build throughput (bin + mean/cov + eigen + labels + ordering)",
             "value": round(value, 3), "unit": "Mpoints/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": round(ms_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "S2: 10M uniform-random points in [-100,100)^2 x [-1,1), 0.5 m cubic voxels, "
-                                   "demand=slope (BASELINE.json configs[1])" if n == 10_000_000 and a.grid_len == 0.5 and a.z_len == 0.5
-                       else f"uniform box, {n} points/rank, grid {a.grid_len}/{a.z_len}",
-                       "points_per_gpu": n, "nodes": int(nodes), "columns": int(cols), "slopes": int(slopes),
-                       "multi_gpu_mode": a.mode if use_dist else "single", "strategy": strat},
+            "ms_per_step": round(ms_step, 4), "higher_is_better": True,
+            "scaling": "strong" if global_mode else "weak", "vs_baseline": None,
+            "dtype": "f64", "io_dtype": "f32", "data": "synthetic",
+            "config": {"workload": W["desc"] + (f", {total} points" if total != W["points"] else ""),
+                       "points_total": int(job_points), "points_per_gpu": int(n), "nodes": int(nodes), "columns": int(cols),
+                       "slopes": int(slopes), "multi_gpu_mode": mode, "strategy": strat, "max_nodes_hint": int(hint),
+                       "scene_generation_s": round(t_gen, 1)},
             "roofline": {"bound": "hbm", "kernel": kernel_of.get(dom),
                          "achieved": round(achieved, 2) if achieved else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5) if achieved else None, "traffic": traffic,
-                         "traffic_source": "profiles/r01_d_two_level_pmc.json (rocprofv3 --pmc, separate passes)" if traffic else None,
-                         "kernel_ms_measured_in_timed_region": timed_live, "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": round(acc_ms, 4) if acc_ms == acc_ms else None},
+                         "traffic_source": traffic_src,
+                         "kernel_ms_measured_in_timed_region": timed_live, "algorithmic_bytes_per_launch": alg_bytes,
+                         "kernel_ms": round(acc_ms, 4) if acc_ms == acc_ms else None},
             "path_roofline": {"bytes": path_bytes, "achieved_GBps": round(path_bytes / (ms_step * 1e-3) / 1e9, 2),
                               "frac": round(path_bytes / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
             "phase_ms": phases,
         }
+        if global_mode:
+            out["exchange"] = {k: round(v, 4) for k, v in exch_timed.items()}
+            out["exchange"]["ranks"] = world
+            out["exchange"]["backend"] = "rccl"
+        out.update(extras)
         if not a.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(cloud, P, min(a.cpu_sample, n))
+            sample = a.cpu_sample or min(n, 10_000_000)
+            out["cpu_baseline"] = cpu_baseline(origin, host_pts, P, min(sample, n))
         elif world == 1:
             out["cpu_baseline"] = None
         if a.check:
             from tests import parity
+            from grid_ndt_amd import scenes
             small = scenes.uniform_box(300_001)
             ref = parity.ref_from_cloud(small, P)
             _, o = parity.gpu_from_cloud(small, P, device=local)
@@ -216,7 +381,7 @@ def main():
             m.create2DMap("slope", pts, stream)
             cyc, nb = m.debug_bucket_phases()
             tot = sum(list(cyc.values())[:6])
-            print("k_bucket_build phase stamps (mean shader cycles per bucket, %d buckets): " % nb +
+            print("bucket kernel phase stamps (mean shader cycles per bucket, %d buckets): " % nb +
                   ", ".join(f"{k}={v:.0f} ({100 * v / tot:.0f}%)" for k, v in cyc.items()), file=sys.stderr)
         print(json.dumps(out))
     if use_dist:

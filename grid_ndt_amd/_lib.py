@@ -79,6 +79,18 @@ def _hip_runtime_dir():
     return "/opt/rocm/lib"
 
 
+def source_hash():
+    """sha256 over the kernel / host sources libgndt is built from: profiles/ store it next to the PMC figures so that
+    bench.py can tell whether a committed HBM-traffic measurement belongs to the code it is timing."""
+    import hashlib
+    h = hashlib.sha256()
+    names = sorted(set(SOURCES + [x for x in HEADERS if not os.path.isabs(x)]))
+    for nm in names + [os.path.join(_ROOT, "include", "gndt.h")]:
+        with open(nm if os.path.isabs(nm) else os.path.join(_CSRC, nm), "rb") as f:
+            h.update(os.path.basename(nm).encode() + b"\0" + f.read())
+    return h.hexdigest()
+
+
 def build_native(force=False, verbose=False):
     """Compile the HIP sources into grid_ndt_amd/csrc/libgndt.so for gfx950 (cross-compiles without a GPU)."""
     srcs = [os.path.join(_CSRC, s) for s in SOURCES]

@@ -48,22 +48,34 @@ def merge_stats(key, sums, count, first_idx, group=None):
     return union, g_sums, g_count, g_first
 
 
-def build_global_map(m, demand, shard, first_idx_base, stream=None, group=None, total_points=None):
+def build_global_map(m, demand, shard, first_idx_base, stream=None, group=None, total_points=None, timings=None):
     """`m`: a TwoDmap whose origin is the GLOBAL cloud's point 0 on every rank; `shard`: this rank's
     device-resident points; `first_idx_base`: global index of shard[0].  On return `m` holds the map of
     the whole cloud (same on every rank).  Per rank: shard -> statistics through the counting-partition pipeline
     (no node table), one exchange, then the merged statistics (already sorted by key: the canonical order) ->
     labels, order and rows in one pass."""
+    import time
+    t0 = time.perf_counter()
     st = m.shard_stats(demand, shard, first_idx_base, stream)
     if stream is not None and hasattr(stream, "synchronize"):
         stream.synchronize()
     else:
         torch.cuda.synchronize()
+    t1 = time.perf_counter()
     key, sums, count, first = merge_stats(st["key"].clone(), st["sums"].clone(), st["count"].clone(),
                                           st["first_idx"].clone(), group)
     if total_points is None:
         t = torch.tensor([int(shard.shape[0])], dtype=torch.int64, device=key.device)
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
         total_points = int(t.item())
+    if timings is not None and key.is_cuda:
+        torch.cuda.synchronize()
+    t2 = time.perf_counter()
     m.finalize_stats(key.contiguous(), sums.contiguous(), count.contiguous(), first.contiguous(), total_points, stream)
+    if timings is not None:
+        if key.is_cuda:
+            torch.cuda.synchronize()
+        t3 = time.perf_counter()
+        for k, v in (("shard_ms", t1 - t0), ("exchange_ms", t2 - t1), ("finalize_ms", t3 - t2)):
+            timings[k] = timings.get(k, 0.0) + v * 1e3
     return key.shape[0]

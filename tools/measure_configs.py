@@ -45,7 +45,8 @@ def main():
     a = ap.parse_args()
     import torch
     import grid_ndt_amd as g
-    from tests import parity, scenes
+    from tests import parity
+    from grid_ndt_amd import scenes
     g.build_native()
     out = {"device": g.device_info(0)}
 

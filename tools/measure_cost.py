@@ -24,7 +24,7 @@ def main():
     import torch
     import grid_ndt_amd as g
     from oracle import oracle
-    from tests import scenes
+    from grid_ndt_amd import scenes
     g.build_native()
     out = {"device": g.device_info(0)}
 

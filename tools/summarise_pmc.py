@@ -5,8 +5,13 @@ import collections
 import csv
 import glob
 import json
+import os
 import re
+import subprocess
 import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 
 
 def load(d, counter):
@@ -27,6 +32,14 @@ def main():
     out = {"note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), bench.py --steps 3 --warmup 1, S2 10M points; "
                    "KiB per launch as reported; hbm_bytes_corrected applies MI355X_MICROARCH.md's gfx950 correction "
                    "(FETCH_SIZE x2 for wide coalesced reads)", "kernels": {}}
+    # identity of the code the counters belong to: bench.py only quotes `traffic` when it matches the loaded sources
+    from grid_ndt_amd import _lib
+    out["source_hash"] = _lib.source_hash()
+    try:
+        out["git_head"] = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "HEAD"], stderr=subprocess.DEVNULL).decode().strip()
+    except Exception:
+        out["git_head"] = None          # the GPU box's snapshot carries no .git: tools/collect_profiles.sh notes HEAD beside it
+    total = 0
     for k in sorted(set(fetch) | set(write)):
         if not k.startswith("gndt::"):
             continue
@@ -34,6 +47,9 @@ def main():
         w = write.get(k, 0.0) / max(nw.get(k, 1), 1)
         out["kernels"][k] = {"launches": int(nf.get(k, nw.get(k, 0))), "FETCH_SIZE_KiB": round(f, 1), "WRITE_SIZE_KiB": round(w, 1),
                              "hbm_bytes_corrected": int((2 * f + w) * 1024)}
+        total += out["kernels"][k]["hbm_bytes_corrected"] * out["kernels"][k]["launches"]
+    steps = max((v["launches"] for k, v in out["kernels"].items() if "k_emit_rows" in k), default=1)
+    out["hbm_bytes_per_build_all_kernels"] = int(total / max(steps, 1))
     print(json.dumps(out, indent=1))
 
 

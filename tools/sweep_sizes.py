@@ -16,7 +16,7 @@ sys.path.insert(0, ROOT)
 def main():
     import torch
     import grid_ndt_amd as g
-    from tests import scenes
+    from grid_ndt_amd import scenes
     g.build_native()
     rows = []
     big_u = scenes.uniform_box(30_000_001)
