@@ -377,7 +377,7 @@ def main():
             _, o = parity.gpu_from_cloud(small, P, device=local)
             out["check"] = parity.compare(o, ref)["ok"]
         if a.stamps and m.last_strategy() in (2, 3):
-            os.environ["GNDT_STAMPS"] = "1"
+            m.enable_stamps(True)
             m.create2DMap("slope", pts, stream)
             cyc, nb = m.debug_bucket_phases()
             tot = sum(list(cyc.values())[:6])

@@ -1,0 +1,390 @@
+// gndt_api_build.hip — strategy PARTITION (gndt_partition.hpp, gndt_bucket.hpp): launch, pending-build resolution, gndt_build*.
+#include "gndt_handle.hpp"
+#include "gndt_bucket.hpp"
+using namespace gndt;
+using namespace gndt_host;
+
+namespace gndt_host {
+
+// prefix of the per-word column weights -> row of every staged node -> SoA rows (marks m0+1 .. m0+5)
+int launch_order_and_emit(gndt_handle* h, uint64_t words, int m0, hipStream_t s) {
+    auto& q = h->part;
+    const uint32_t nbw = (uint32_t)((words + kScanChunk - 1) / kScanChunk);
+    hipLaunchKernelGGL(k_scan_reduce<false>, dim3(nbw), dim3(kScanThreads), 0, s, q.word_weight, (const uint32_t*)nullptr,
+                       (uint32_t)words, q.bsum_words);
+    hipLaunchKernelGGL(k_scan_apply<false>, dim3(nbw), dim3(kScanThreads), 0, s, q.word_weight, (const uint32_t*)nullptr,
+                       (uint32_t)words, q.bsum_words, q.word_base);
+    HIP_TRY(h, hipGetLastError());
+    mark(h, m0 + 1, s);
+    mark(h, m0 + 2, s);       // (the column-rank and column-scan passes of earlier versions: phases kept for the ABI, empty)
+    mark(h, m0 + 3, s);
+    hipLaunchKernelGGL(k_order_dest, dim3(grid_for(q.stage_cap)), dim3(kBlock), 0, s, q.ord_cf, q.ord_idx, q.bitmap, q.word_base,
+                       q.ncol_at, q.inv, h->d_cnt, q.d_pc);
+    HIP_TRY(h, hipGetLastError());
+    mark(h, m0 + 4, s);
+    hipLaunchKernelGGL(k_emit_rows, dim3(grid_for(q.stage_cap)), dim3(kBlock), 0, s, q.stage, q.inv, h->out, q.row_ncol, h->d_cnt,
+                       q.d_pc);
+    HIP_TRY(h, hipGetLastError());
+    mark(h, m0 + 5, s);
+    return GNDT_OK;
+}
+
+namespace {
+// ---------------------------------------------------------------------------------------------
+// strategy PARTITION (gndt_partition.hpp): the build
+// ---------------------------------------------------------------------------------------------
+// Bucket count for `nodes` expected nodes.  Few, large buckets are better for both the scatter (longer runs per
+// workgroup and bucket) and the bucket kernel (fixed costs per bucket): as many points per bucket as two chunks of
+// the bucket kernel take (2800 leaves room for the spread of a hash partition), unless the LDS node table says
+// otherwise: average load <= 0.5 of `slots` against an estimate that already carries a 20 % margin, i.e. ~0.42 of
+// the slots really used, ~5 sigma of the column count below the overflow limit of 0.78.  (An overflow is not an
+// error: the build is re-run with the larger table / more buckets.)
+uint64_t buckets_for(uint64_t n, uint64_t nodes, int slots) {
+    const int load_pct = tuning().bucket_load, pts_target = tuning().bucket_points;
+    if (pts_target) return std::max<uint64_t>(n / (uint64_t)pts_target, 16);
+    const uint64_t per_bucket = slots >= 1024 ? 6400 : 2800;
+    const uint64_t want = std::max<uint64_t>(n / per_bucket, (nodes * 100) / ((uint64_t)slots * load_pct));
+    return std::max<uint64_t>(want, 16);
+}
+constexpr uint64_t kMaxBuckets = 32768;   // 4-byte LDS cursor per bucket in the partition passes
+
+}  // namespace
+
+// One attempt of the PARTITION build: every launch plus the asynchronous read-back of the counters and overflow
+// flags; no host wait.  Returns GNDT_OK, an error, or -1 when the partition path cannot hold this input.
+int partition_launch(gndt_handle* h, gndt_handle::Pending& P) {
+    auto& q = h->part;
+    const size_t n = P.n, stride_bytes = P.stride;
+    hipStream_t s = P.s;
+    const int attempt = P.attempt;
+    uint64_t& nodes_est = P.nodes_est;
+    uint64_t& stage_want = P.stage_want;
+    const int bt = tuning().bucket_threads, env_slots = tuning().bucket_slots, part_wgs = tuning().part_wgs;
+    const uint32_t nwg = (uint32_t)std::min<uint64_t>((uint64_t)part_wgs, std::max<uint64_t>(1, n / 8192));
+    const uint64_t words = (n + 31) / 32 + 1;
+    int rc;
+    const GridParams gp = P.gp;                        // as they were at launch (a retry must not pick up a new origin)
+    const float* p = static_cast<const float*>(P.xyz);
+    // table size and bucket count for this attempt: 512-slot tables unless that needs too many buckets
+    // attempt 0: 512-slot tables; an overflow first doubles the table (same estimate), then raises the estimate
+    int bslots = env_slots ? env_slots : (attempt == 0 ? 512 : 1024);
+    uint64_t Bw = buckets_for(n, nodes_est, bslots);
+    // Two-level partition (no counting passes) for large builds; the exact single-level counting partition for small
+    // ones, when asked for (GNDT_STRATEGY_PARTITION_EXACT), and after a region overflowed once on this handle.
+    const int env_two = tuning().two_level;
+    bool two = h->P.strategy != GNDT_STRATEGY_PARTITION_EXACT && q.two_level_ok &&
+               (n >= (1u << 20) || h->P.strategy == GNDT_STRATEGY_PARTITION_TWO_LEVEL);
+    if (env_two == 0 || n == 0) two = false;
+    if (two && Bw > (uint64_t)kMaxFan * kMaxFan) {         // more buckets than two levels address: larger tables, fewer buckets
+        if (!env_slots) { bslots = 1024; Bw = buckets_for(n, nodes_est, bslots); }
+        if (Bw > (uint64_t)kMaxFan * kMaxFan) two = false;
+    }
+    if (!two) {
+        if (!env_slots && Bw > kMaxBuckets) { bslots = 1024; Bw = buckets_for(n, nodes_est, bslots); }
+        if (Bw > kMaxBuckets) return -1;                   // too many nodes for one partition level: atomic path
+    }
+    const uint32_t B = (uint32_t)Bw;
+    P.two_level = two;
+    h->last_strategy = two ? GNDT_STRATEGY_PARTITION : GNDT_STRATEGY_PARTITION_EXACT;
+    stage_want = std::max<uint64_t>(stage_want, nodes_est + nodes_est / 8);
+    if (P.stats_only) {
+        if ((rc = ensure_stats_buffers(h, stage_want))) return rc;
+    } else {
+        if ((rc = ensure_stage(h, stage_want))) return rc;
+        if ((rc = ensure_out(h, q.stage_cap))) return rc;
+    }
+    const uint32_t* range_lo = nullptr;
+    const uint32_t* range_hi = nullptr;
+    const float4* bucket_recs = nullptr;
+    if (two) {
+        uint32_t F2_shift = 1;                             // fan-out ~ sqrt(B) per level, F2 a power of two, both <= kMaxFan
+        while (F2_shift < 9 && (1ull << (2 * F2_shift)) < B) ++F2_shift;
+        const uint32_t F2 = 1u << F2_shift;
+        const uint32_t F1 = (B + F2 - 1) / F2;
+        // Level-1 regions are large and hash-balanced: a fixed capacity of 2x the mean (or 1.25x the fullest one an
+        // earlier build on this handle saw).  The buckets' regions are laid out on the device from a 1-in-64 sample
+        // level 1 takes (k_part2_layout: 2x the estimate + 2048 each), so LiDAR clouds' hot columns get the room they
+        // need and the records take 2 n + 2048 B slots in all.  If a region overflows all the same, the build is
+        // re-run; a second failure sends this handle to the exact counting partition.
+        const int env_rep = tuning().l1_rep;   // measured: 1 is best at 4096-point tiles
+        const uint32_t R = std::max<uint32_t>(1, std::min<uint32_t>((uint32_t)env_rep, kMaxFan / F1));   // sub-regions per coarse region
+        const uint32_t V = F1 * R;
+        constexpr uint64_t kTile1 = (uint64_t)kTileThreads * kTilePer1, kTile2 = (uint64_t)kTileThreads * kTilePer2;
+        const double r1 = std::max(2.0, q.fill1_ratio * 1.25);
+        const uint64_t cap1w = (uint64_t)(r1 * (double)(n / V)) + 2 * kTile1;
+        const uint64_t recs_want = 2 * (uint64_t)n + n / 8 + 2048ull * B + 4096;     // 2 n + 2048 B, and sampling slack
+        if ((uint64_t)V * cap1w > 4 * (uint64_t)n + (1u << 24) || recs_want >= 0xF0000000ull || q.two_level_failures >= 2) {
+            q.two_level_ok = false;
+            return partition_launch(h, P);                 // (re-enters on the exact path)
+        }
+        const uint32_t cap1 = (uint32_t)cap1w;
+        P.mean1 = (double)(n / V);
+        if ((rc = grow_buf(h, q.recs1, q.rec1_cap, (uint64_t)V * cap1))) return rc;
+        if ((rc = grow_buf(h, q.recs, q.rec_cap, recs_want))) return rc;
+        if (B > q.cur_cap) {
+            for (uint32_t** a : {&q.cursors, &q.range_lo, &q.range_hi, &q.range_cap}) { if (*a) (void)hipFree(*a); *a = nullptr; }
+            q.cur_cap = 0;
+            const uint64_t c = (uint64_t)B + B / 4;
+            HIP_TRY(h, hipMalloc(&q.cursors, ((size_t)kMaxFan + 2 * c) * 4));  // [kMaxFan] level 1, [c] level 2, [c] samples
+            HIP_TRY(h, hipMalloc(&q.range_lo, c * 4));
+            HIP_TRY(h, hipMalloc(&q.range_hi, c * 4));
+            HIP_TRY(h, hipMalloc(&q.range_cap, c * 4));
+            q.cur_cap = c;
+        }
+        uint32_t* cursor1 = q.cursors;
+        uint32_t* cursor2 = q.cursors + kMaxFan;
+        uint32_t* est2 = cursor2 + B;
+        mark(h, 0, s);
+        if (h->table_dirty) { if ((rc = do_reset(h, s))) return rc; }
+        h->results_valid = false;
+        hipLaunchKernelGGL(k_part_clear, dim3(grid_for(words, 256, 512)), dim3(256), 0, s, h->d_cnt, q.d_pc, q.bitmap, q.word_weight, (uint64_t)words,
+                           q.cursors, (uint32_t)(kMaxFan + 2 * B));
+        HIP_TRY(h, hipGetLastError());
+        mark(h, 1, s);
+        const uint32_t tiles1 = (uint32_t)((n + kTile1 - 1) / kTile1);
+        const uint32_t l1_wgs = tuning().l1_wgs;   // persistent workgroups (2 resident per CU)
+        const bool wide = std::max(V, F2) > 256;           // LDS arrays for a fan-out of 512 (fewer resident tiles) only when needed
+        const dim3 g1(std::min<uint32_t>(tiles1, l1_wgs)), g2((uint32_t)((cap1 + kTile2 - 1) / kTile2), V);
+#define GNDT_L1(SF_, FAN_)                                                                                                  \
+    hipLaunchKernelGGL((k_part2_level1<SF_, FAN_>), g1, dim3(kTileThreads), 0, s, p, (uint64_t)n, P.first_base, gp, B, F1, F2_shift, \
+                       R, cursor1, cap1, est2, q.recs1, h->d_cnt, q.d_pc)
+        if (stride_bytes == 12) { if (wide) GNDT_L1(3, 512); else GNDT_L1(3, 256); }
+        else { if (wide) GNDT_L1(4, 512); else GNDT_L1(4, 256); }
+#undef GNDT_L1
+        HIP_TRY(h, hipGetLastError());
+        mark(h, 2, s);
+        hipLaunchKernelGGL(k_part2_layout, dim3(1), dim3(1024), 0, s, est2, B, q.range_lo, q.range_cap, (uint64_t)q.rec_cap, q.d_pc);
+        HIP_TRY(h, hipGetLastError());
+        mark(h, 3, s);
+        if (wide)
+            hipLaunchKernelGGL(k_part2_level2<512>, g2, dim3(kTileThreads), 0, s, q.recs1, cursor1, cap1, R, gp, B, F2, cursor2,
+                               q.range_lo, q.range_cap, q.recs, q.d_pc);
+        else
+            hipLaunchKernelGGL(k_part2_level2<256>, g2, dim3(kTileThreads), 0, s, q.recs1, cursor1, cap1, R, gp, B, F2, cursor2,
+                               q.range_lo, q.range_cap, q.recs, q.d_pc);
+        hipLaunchKernelGGL(k_part2_ranges, dim3(grid_for(B, 256, 64)), dim3(256), 0, s, cursor1, V, cursor2, q.range_cap, B, q.range_lo,
+                           q.range_hi, q.d_pc);
+        HIP_TRY(h, hipGetLastError());
+        mark(h, 4, s);
+        range_lo = q.range_lo; range_hi = q.range_hi;
+    } else {
+    if ((rc = grow_buf(h, q.recs, q.rec_cap, n))) return rc;
+    if ((rc = grow_buf(h, q.hist, q.hist_cap, (uint64_t)nwg * B))) return rc;
+    if (B > q.bucket_cap) {
+        if (q.totals) (void)hipFree(q.totals);
+        if (q.bucket_base) (void)hipFree(q.bucket_base);
+        q.totals = q.bucket_base = nullptr; q.bucket_cap = 0;
+        HIP_TRY(h, hipMalloc(&q.totals, (size_t)B * 4));
+        HIP_TRY(h, hipMalloc(&q.bucket_base, ((size_t)B + 1) * 4));
+        q.bucket_cap = B;
+    }
+    mark(h, 0, s);
+    // the HBM node table is not used by this strategy, but a previous atomic build may sit in it
+    if (h->table_dirty) { if ((rc = do_reset(h, s))) return rc; }
+    h->results_valid = false;
+    hipLaunchKernelGGL(k_part_clear, dim3(grid_for(words, 256, 512)), dim3(256), 0, s, h->d_cnt, q.d_pc, q.bitmap, q.word_weight, (uint64_t)words,
+                       (uint32_t*)nullptr, 0u);
+    HIP_TRY(h, hipGetLastError());
+    mark(h, 1, s);
+    const size_t lds = (size_t)B * 4;
+    if (lds > 48 * 1024) {   // beyond the default dynamic-LDS limit the kernels must be told (gfx950: 160 KiB/CU)
+        HIP_TRY(h, hipFuncSetAttribute((const void*)k_part_hist<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIP_TRY(h, hipFuncSetAttribute((const void*)k_part_hist<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIP_TRY(h, hipFuncSetAttribute((const void*)k_part_scatter<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIP_TRY(h, hipFuncSetAttribute((const void*)k_part_scatter<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    }
+    if (stride_bytes == 12)
+        hipLaunchKernelGGL(k_part_hist<3>, dim3(nwg), dim3(kPartThreads), lds, s, p, (uint64_t)n, gp, B, q.hist, h->d_cnt);
+    else
+        hipLaunchKernelGGL(k_part_hist<4>, dim3(nwg), dim3(kPartThreads), lds, s, p, (uint64_t)n, gp, B, q.hist, h->d_cnt);
+    HIP_TRY(h, hipGetLastError());
+    mark(h, 2, s);
+    hipLaunchKernelGGL(k_part_offsets, dim3((B + 31) / 32), dim3(256), 0, s, q.hist, q.totals, B, nwg);
+    HIP_TRY(h, hipGetLastError());
+    mark(h, 3, s);
+    if (stride_bytes == 12)
+        hipLaunchKernelGGL(k_part_scatter<3>, dim3(nwg), dim3(kPartThreads), lds, s, p, (uint64_t)n, P.first_base, gp, B, q.hist,
+                           q.totals, q.bucket_base, q.recs);
+    else
+        hipLaunchKernelGGL(k_part_scatter<4>, dim3(nwg), dim3(kPartThreads), lds, s, p, (uint64_t)n, P.first_base, gp, B, q.hist,
+                           q.totals, q.bucket_base, q.recs);
+    HIP_TRY(h, hipGetLastError());
+    mark(h, 4, s);
+    range_lo = q.bucket_base; range_hi = q.bucket_base + 1;
+    }
+    bucket_recs = q.recs;
+    if (tuning().stamps && q.dbg_buckets < B) {
+        if (q.dbg) (void)hipFree(q.dbg);
+        q.dbg = nullptr; q.dbg_buckets = 0;
+        HIP_TRY(h, hipMalloc(&q.dbg, (size_t)B * 16 * sizeof(unsigned long long)));
+        HIP_TRY(h, hipMemset(q.dbg, 0, (size_t)B * 16 * sizeof(unsigned long long)));
+        q.dbg_buckets = B;
+    }
+    q.last_buckets = B;
+    // one workgroup per bucket by default: persistent workgroups (GNDT_BUCKET_WGS=512) measured 8 % slower, the
+    // hardware's dynamic workgroup scheduling balances uneven buckets better than a static stride
+    const uint32_t bucket_wgs = tuning().bucket_wgs;
+    {
+#define GNDT_LAUNCH_BUCKET2(T_, H_, CH_, S_)                                                                           \
+    hipLaunchKernelGGL((k_bucket_build2<T_, H_, CH_, S_>), dim3(std::min<uint32_t>(B, bucket_wgs)), dim3(T_), 0, s, bucket_recs, range_lo, range_hi, B, gp, q.stage, \
+                       (uint32_t)(S_ ? h->st_cap : q.stage_cap), q.ord_cf, q.ord_idx, ColumnOrder{q.bitmap, q.word_weight, q.ncol_at}, h->d_cnt,   \
+                       q.d_pc, tuning().stamps ? q.dbg : nullptr, StatsOut{h->st_key, h->st_sums, h->st_count, h->st_first})
+            if (P.stats_only) {
+                if (bslots == 1024) GNDT_LAUNCH_BUCKET2(512, 1024, 3584, true);
+                else GNDT_LAUNCH_BUCKET2(512, 512, 1536, true);
+            }
+            else if (bslots == 1024 && bt == 1024) GNDT_LAUNCH_BUCKET2(1024, 1024, 3072, false);
+            else if (bslots == 1024) GNDT_LAUNCH_BUCKET2(512, 1024, 3584, false);
+            else if (bslots == 512 && bt == 256) GNDT_LAUNCH_BUCKET2(256, 512, 1792, false);
+            else if (bslots == 256) GNDT_LAUNCH_BUCKET2(256, 256, 1024, false);
+            else GNDT_LAUNCH_BUCKET2(512, 512, 1536, false);
+#undef GNDT_LAUNCH_BUCKET2
+    }
+    HIP_TRY(h, hipGetLastError());
+    mark(h, 5, s);
+    if (!P.stats_only && (rc = launch_order_and_emit(h, words, 5, s))) return rc;
+    HIP_TRY(h, hipMemcpyAsync(q.h_pc, q.d_pc, sizeof(PartCounters), hipMemcpyDeviceToHost, s));
+    HIP_TRY(h, hipMemcpyAsync(h->h_cnt, h->d_cnt, sizeof(Counters), hipMemcpyDeviceToHost, s));
+    P.bslots = bslots;
+    return GNDT_OK;
+}
+
+namespace {
+// Start a PARTITION build (attempt 0) and leave it pending.
+int partition_begin(gndt_handle* h, const void* xyz_dev, size_t n, size_t stride_bytes, hipStream_t s) {
+    auto& q = h->part;
+    if (stride_bytes != 12 && stride_bytes != 16) { h->err = "stride_bytes must be 12 or 16"; return GNDT_ERR_INVALID; }
+    if (n >= 0x7FFFFFFFull) return -1;   // bit 31 of the record index word carries the weight flag: atomic path beyond 2^31 points
+    int rc;
+    if ((rc = ensure_words(h, (n + 31) / 32 + 1))) return rc;
+    if ((rc = ensure_part_counters(h))) return rc;
+    auto& P = h->pending;
+    P = gndt_handle::Pending{};
+    P.xyz = xyz_dev; P.n = n; P.stride = stride_bytes; P.s = s; P.attempt = 0;
+    P.gp = grid_params(h);
+    // expected node count: the caller's hint, else what the previous build of this handle found, else n/4
+    P.nodes_est = h->P.max_nodes_hint ? h->P.max_nodes_hint : (q.nodes_learned ? q.nodes_learned : std::max<uint64_t>(n / 4, 1024));
+    P.stage_want = std::max<uint64_t>(q.stage_cap, h->P.max_nodes_hint ? h->P.max_nodes_hint + h->P.max_nodes_hint / 8
+                                                                       : std::max<uint64_t>(4096, n / 4));
+    const int prev_strategy = h->last_strategy;
+    h->last_strategy = GNDT_STRATEGY_PARTITION;
+    rc = partition_launch(h, P);
+    if (rc) { h->last_strategy = prev_strategy; return rc; }
+    P.active = true;
+    h->results_valid = false;
+    h->map_in_table = false;
+    h->stream_pos = n;
+    h->last_stream = s;
+    return GNDT_OK;
+}
+
+}  // namespace
+
+// Wait for the pending build and look at its flags; re-run it with more room while they ask for it (the input
+// must still be valid: it is the caller's until gndt_sync / gndt_export returns).
+int partition_resolve(gndt_handle* h) {
+    auto& P = h->pending;
+    if (!P.active) return GNDT_OK;
+    auto& q = h->part;
+    const int env_slots = tuning().bucket_slots;
+    int rc = GNDT_OK;
+    for (;;) {
+        if (hipStreamSynchronize(P.s) != hipSuccess) { P.active = false; h->err = "hipStreamSynchronize failed"; return GNDT_ERR_HIP; }
+        bool again = false;
+        if (P.two_level && P.mean1 > 0) {                      // remember how uneven the level-1 regions of the latest cloud were
+            q.fill1_ratio = q.h_pc->max_fill1 / P.mean1;
+            if (tuning().verbose)
+                fprintf(stderr, "[gndt] two-level partition: fullest level-1 region %.2fx the mean, overflow %u\n",
+                        q.h_pc->max_fill1 / P.mean1, q.h_pc->part_overflow);
+        }
+        if (q.h_pc->part_overflow) {                           // a region of the two-level partition was too small: same table
+            ++q.two_level_failures;                            // size and estimate again (level-1 regions sized from the fullest
+            --P.attempt;                                       // one seen; after two failures the exact counting partition)
+            again = true;
+        } else if (q.h_pc->lds_overflow) {                            // some bucket holds too many nodes for its LDS table:
+            if (P.attempt >= 1 || env_slots) P.nodes_est *= 2;   // (attempt 0 -> 1 only switches to the 1024-slot table)
+            again = true;
+        } else if (q.h_pc->stage_overflow) {                   // num_nodes kept counting: it is the true total
+            P.stage_want = (uint64_t)h->h_cnt->num_nodes + h->h_cnt->num_nodes / 8 + 1024;
+            again = true;
+        }
+        if (!again) {
+            q.nodes_learned = (uint64_t)h->h_cnt->num_nodes + h->h_cnt->num_nodes / 5;
+            q.good_slots = P.bslots; q.good_est = P.nodes_est; q.good_n = P.n;
+            if (!P.stats_only) {
+                h->results_valid = true;
+                ++h->result_serial;
+            }
+            h->table_dirty = false;
+            P.active = false;
+            return GNDT_OK;
+        }
+        rc = -1;
+        if (++P.attempt < 5) rc = partition_launch(h, P);
+        if (rc == GNDT_OK) continue;
+        P.active = false;
+        if (rc != -1 || P.stats_only) return rc;   // (a statistics-only run reports -1: its caller falls back)
+        // does not fit the LDS-resident pipeline (too many nodes per bucket): same result via the atomic path
+        return build_atomic(h, P.xyz, P.n, P.stride, P.s);
+    }
+}
+
+
+}  // namespace gndt_host
+
+extern "C" {
+
+int gndt_build_device(gndt_handle* h, const void* xyz_dev, size_t n, size_t stride_bytes, void* hip_stream) {
+    int rc = check_ready(h);
+    if (rc) return rc;
+    if (!xyz_dev && n) { h->err = "null input"; return GNDT_ERR_INVALID; }
+    hipStream_t s = stream_of(h, hip_stream);
+    h->pending.active = false;          // a build still pending is being replaced: nobody will ask for its result
+    { const int urc = use_stream(h, s); if (urc) return urc; }
+    next_event_set(h);
+    int strategy = h->P.strategy;
+    if (strategy == GNDT_STRATEGY_AUTO) strategy = (n >= (1u << 16)) ? GNDT_STRATEGY_PARTITION : GNDT_STRATEGY_ATOMIC;
+    if (strategy == GNDT_STRATEGY_PARTITION || strategy == GNDT_STRATEGY_PARTITION_EXACT || strategy == GNDT_STRATEGY_PARTITION_TWO_LEVEL) {
+        // launched, not awaited: gndt_sync / gndt_export* (or whatever needs the result next) waits, checks the
+        // overflow flags and re-runs with more room if needed.  xyz_dev stays the caller's until then.
+        rc = partition_begin(h, xyz_dev, n, stride_bytes, s);
+        if (rc != -1) return rc;
+        // does not fit the LDS-resident pipeline: same result via the atomic path
+    }
+    return build_atomic(h, xyz_dev, n, stride_bytes, s);
+}
+
+int gndt_build(gndt_handle* h, const void* xyz_host, size_t n, size_t stride_bytes) {
+    int rc = check_ready(h);
+    if (rc) return rc;
+    if (!xyz_host && n) { h->err = "null input"; return GNDT_ERR_INVALID; }
+    rc = stage_host_input(h, xyz_host, n, stride_bytes, h->own_stream);
+    if (rc) return rc;
+    rc = gndt_build_device(h, h->stage, n, stride_bytes, h->own_stream);
+    if (rc) return rc;
+    return gndt_sync(h, nullptr, nullptr, nullptr);
+}
+
+int gndt_debug_enable_stamps(int on) { tuning_force_stamps(on != 0); return GNDT_OK; }
+
+int gndt_debug_bucket_phases(gndt_handle* h, double cycles_out[10], uint32_t* buckets_out) {
+    if (!h || !cycles_out) return GNDT_ERR_INVALID;
+    auto& q = h->part;
+    if (!q.dbg || !q.last_buckets) { h->err = "no stamps: set GNDT_STAMPS=1 (or call gndt_debug_enable_stamps) before a PARTITION build"; return GNDT_ERR_INVALID; }
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipStreamSynchronize(h->last_stream));
+    std::vector<unsigned long long> t((size_t)q.last_buckets * 16);
+    HIP_TRY(h, hipMemcpy(t.data(), q.dbg, t.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    for (int k = 0; k < 10; ++k) cycles_out[k] = 0.0;
+    for (uint32_t b = 0; b < q.last_buckets; ++b) {
+        const unsigned long long* s = &t[(size_t)b * 16];
+        for (int k = 0; k < 6; ++k) cycles_out[k] += (double)(s[k + 1] - s[k]);
+        // sub-phases of the accumulate phase, summed over the bucket's chunks: load wait, classify, scan+scatter, reduce
+        for (int k = 0; k < 4; ++k) cycles_out[6 + k] += (double)s[8 + k];
+    }
+    for (int k = 0; k < 10; ++k) cycles_out[k] /= q.last_buckets;
+    if (buckets_out) *buckets_out = q.last_buckets;
+    return GNDT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,377 @@
+// gndt_api_core.hip — handle life cycle, origin, sync / export, profiling, and the buffers every strategy shares.
+#include "gndt_handle.hpp"
+
+using namespace gndt;
+using namespace gndt_host;
+
+namespace {
+thread_local std::string g_create_error;
+}
+
+namespace gndt_host {
+
+const Tuning& tuning_mut_ref();
+namespace {
+Tuning parse_tuning() {
+    Tuning t;
+    auto geti = [](const char* k, int d) { const char* v = getenv(k); return v ? atoi(v) : d; };
+    t.bucket_load = geti("GNDT_BUCKET_LOAD", t.bucket_load);
+    t.bucket_points = geti("GNDT_BUCKET_POINTS", t.bucket_points);
+    t.bucket_threads = geti("GNDT_BUCKET_THREADS", t.bucket_threads);
+    t.bucket_slots = geti("GNDT_BUCKET_SLOTS", t.bucket_slots);
+    t.part_wgs = geti("GNDT_PART_WGS", t.part_wgs);
+    t.two_level = geti("GNDT_TWO_LEVEL", t.two_level);
+    t.l1_rep = geti("GNDT_L1_REP", t.l1_rep);
+    t.l1_wgs = (uint32_t)geti("GNDT_L1_WGS", (int)t.l1_wgs);
+    if (getenv("GNDT_BUCKET_WGS")) t.bucket_wgs = (uint32_t)atoi(getenv("GNDT_BUCKET_WGS"));
+    t.stamps = getenv("GNDT_STAMPS") != nullptr;
+    t.verbose = getenv("GNDT_VERBOSE") != nullptr;
+    return t;
+}
+Tuning& tuning_storage() { static Tuning t = parse_tuning(); return t; }
+}  // namespace
+const Tuning& tuning() { return tuning_storage(); }
+void tuning_force_stamps(bool on) { tuning_storage().stamps = on; }
+
+int ensure_out(gndt_handle* h, uint64_t n) {
+    if (n <= h->out_cap) return GNDT_OK;
+    void* ptrs[] = {h->out.sx, h->out.sy, h->out.sz, h->out.count, h->out.first_idx, h->out.mean, h->out.cov,
+                    h->out.rough, h->out.normal, h->out.flags};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    h->out = OutView{};
+    h->out_cap = 0;
+    uint64_t c = std::max<uint64_t>(1024, n + n / 8);
+    HIP_TRY(h, hipMalloc(&h->out.sx, c * 4));
+    HIP_TRY(h, hipMalloc(&h->out.sy, c * 4));
+    HIP_TRY(h, hipMalloc(&h->out.sz, c * 4));
+    HIP_TRY(h, hipMalloc(&h->out.count, c * 4));
+    HIP_TRY(h, hipMalloc(&h->out.first_idx, c * 4));
+    HIP_TRY(h, hipMalloc(&h->out.mean, c * 12));
+    HIP_TRY(h, hipMalloc(&h->out.cov, c * 24));
+    HIP_TRY(h, hipMalloc(&h->out.rough, c * 4));
+    HIP_TRY(h, hipMalloc(&h->out.normal, c * 12));
+    HIP_TRY(h, hipMalloc(&h->out.flags, c * 4));
+    h->out_cap = c;
+    return GNDT_OK;
+}
+
+int ensure_stats_buffers(gndt_handle* h, uint64_t n) {
+    if (n <= h->st_cap) return GNDT_OK;
+    void* ptrs[] = {h->st_key, h->st_sums, h->st_count, h->st_first};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    h->st_key = nullptr; h->st_sums = nullptr; h->st_count = nullptr; h->st_first = nullptr; h->st_cap = 0;
+    uint64_t c = std::max<uint64_t>(1024, n + n / 8);
+    HIP_TRY(h, hipMalloc(&h->st_key, c * 8));
+    HIP_TRY(h, hipMalloc(&h->st_sums, c * 72));
+    HIP_TRY(h, hipMalloc(&h->st_count, c * 4));
+    HIP_TRY(h, hipMalloc(&h->st_first, c * 4));
+    h->st_cap = c;
+    return GNDT_OK;
+}
+
+// read the device counters (synchronises the stream)
+int fetch_counters(gndt_handle* h, hipStream_t s) {
+    HIP_TRY(h, hipMemcpyAsync(h->h_cnt, h->d_cnt, sizeof(Counters), hipMemcpyDeviceToHost, s));
+    HIP_TRY(h, hipStreamSynchronize(s));
+    return GNDT_OK;
+}
+
+int check_ready(gndt_handle* h) {
+    if (!h) return GNDT_ERR_INVALID;
+    if (!h->origin_set) { h->err = "gndt_set_origin must be called first (setCloudFirst, receiver.cpp:145)"; return GNDT_ERR_INVALID; }
+    HIP_TRY(h, hipSetDevice(h->device));
+    return GNDT_OK;
+}
+
+void free_part(gndt_handle* h) {
+    auto& q = h->part;
+    void* ptrs[] = {q.recs, q.recs1, q.cursors, q.range_lo, q.range_hi, q.range_cap, q.hist, q.totals, q.bucket_base, q.stage, q.ord_cf, q.ord_idx, q.inv, q.row_ncol,
+                    q.bitmap, q.word_weight, q.word_base, q.bsum_words, q.ncol_at, q.d_pc, q.dbg};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    if (q.h_pc) (void)hipHostFree(q.h_pc);
+    q = gndt_handle::Part{};
+}
+
+int ensure_stage(gndt_handle* h, uint64_t nodes) {
+    auto& q = h->part;
+    if (nodes <= q.stage_cap) return GNDT_OK;
+    void* ptrs[] = {q.stage, q.ord_cf, q.ord_idx, q.inv, q.row_ncol};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    q.stage = nullptr; q.ord_cf = q.ord_idx = q.inv = q.row_ncol = nullptr;
+    q.stage_cap = 0;
+    HIP_TRY(h, hipMalloc(&q.stage, nodes * sizeof(StageRow)));
+    uint32_t** arrs[] = {&q.ord_cf, &q.ord_idx, &q.inv, &q.row_ncol};
+    for (auto a : arrs) HIP_TRY(h, hipMalloc(a, nodes * 4));
+    q.stage_cap = nodes;
+    return GNDT_OK;
+}
+
+// Bucket count: ~4096 points per bucket, and few enough nodes per bucket for the LDS table
+// (average load <= 0.4 of `slots`: the overflow limit of 0.78 is then ~6 sigma of the column count away).
+int ensure_words(gndt_handle* h, uint64_t words) {
+    auto& q = h->part;
+    if (words <= q.word_cap) return GNDT_OK;
+    for (uint32_t** a : {&q.bitmap, &q.word_weight, &q.word_base, &q.bsum_words, &q.ncol_at}) { if (*a) (void)hipFree(*a); *a = nullptr; }
+    q.word_cap = 0;
+    words += words / 4;
+    HIP_TRY(h, hipMalloc(&q.bitmap, words * 4));
+    HIP_TRY(h, hipMalloc(&q.word_weight, words * 4));
+    HIP_TRY(h, hipMalloc(&q.word_base, words * 4));
+    HIP_TRY(h, hipMalloc(&q.bsum_words, ((words + kScanChunk - 1) / kScanChunk + 1) * 4));
+    HIP_TRY(h, hipMalloc(&q.ncol_at, words * 32 * 4));     // one entry per point index, touched only at column-first indices
+    q.word_cap = words;
+    return GNDT_OK;
+}
+
+int ensure_part_counters(gndt_handle* h) {
+    auto& q = h->part;
+    if (q.d_pc) return GNDT_OK;
+    HIP_TRY(h, hipMalloc(&q.d_pc, sizeof(PartCounters)));
+    HIP_TRY(h, hipHostMalloc(&q.h_pc, sizeof(PartCounters)));
+    HIP_TRY(h, hipMemset(q.d_pc, 0, sizeof(PartCounters)));
+    memset(q.h_pc, 0, sizeof(PartCounters));
+    return GNDT_OK;
+}
+
+int stage_host_input(gndt_handle* h, const void* xyz_host, size_t n, size_t stride_bytes, hipStream_t s) {
+    const size_t bytes = n * stride_bytes;
+    if (bytes > h->stage_bytes) {
+        if (h->stage) (void)hipFree(h->stage);
+        h->stage = nullptr; h->stage_bytes = 0;
+        HIP_TRY(h, hipMalloc(&h->stage, bytes + 64));
+        h->stage_bytes = bytes;
+    }
+    if (bytes) HIP_TRY(h, hipMemcpyAsync(h->stage, xyz_host, bytes, hipMemcpyHostToDevice, s));
+    return GNDT_OK;
+}
+
+
+// The handle's buffers are shared by whatever was enqueued last; when the caller moves to another stream the new
+// work is ordered behind it (the round-1 code reused them with no cross-stream dependency).
+int use_stream(gndt_handle* h, hipStream_t s) {
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(s, &cap);
+    // (a stream under graph capture cannot wait for un-captured work: the caller orders the capture itself)
+    if (h->last_stream && h->last_stream != s && cap == hipStreamCaptureStatusNone) {
+        if (!h->xstream_ev) HIP_TRY(h, hipEventCreateWithFlags(&h->xstream_ev, hipEventDisableTiming));
+        HIP_TRY(h, hipEventRecord(h->xstream_ev, h->last_stream));
+        HIP_TRY(h, hipStreamWaitEvent(s, h->xstream_ev, 0));
+    }
+    h->last_stream = s;
+    return GNDT_OK;
+}
+
+}  // namespace gndt_host
+
+extern "C" {
+
+const char* gndt_last_error(const gndt_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int gndt_create(const gndt_params* params, gndt_handle** out) {
+    if (!params || !out) { g_create_error = "null argument"; return GNDT_ERR_INVALID; }
+    *out = nullptr;
+    if (!(params->grid_len > 0.f) || !(params->z_len > 0.f) || params->min_points < 1 ||
+        (params->demand != GNDT_DEMAND_SLOPE && params->demand != GNDT_DEMAND_TRUE)) {
+        g_create_error = "invalid gndt_params (grid_len/z_len must be > 0, demand 0|1, min_points >= 1)";
+        return GNDT_ERR_INVALID;
+    }
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) {
+        g_create_error = "no HIP device available (libgndt has no CPU path)";
+        return GNDT_ERR_NO_DEVICE;
+    }
+    if (params->device_id < 0 || params->device_id >= ndev) { g_create_error = "device_id out of range"; return GNDT_ERR_INVALID; }
+    gndt_handle* h = new (std::nothrow) gndt_handle;
+    if (!h) { g_create_error = "out of host memory"; return GNDT_ERR_NOMEM; }
+    h->P = *params;
+    h->device = params->device_id;
+    auto fail = [&](const char* what, hipError_t err) {
+        g_create_error = std::string(what) + ": " + hipGetErrorString(err);
+        gndt_destroy(h);
+        return GNDT_ERR_HIP;
+    };
+    if ((e = hipSetDevice(h->device)) != hipSuccess) return fail("hipSetDevice", e);
+    if ((e = hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking)) != hipSuccess) return fail("hipStreamCreate", e);
+    if ((e = hipMalloc(&h->d_cnt, sizeof(Counters))) != hipSuccess) return fail("hipMalloc", e);
+    if ((e = hipHostMalloc(&h->h_cnt, sizeof(Counters))) != hipSuccess) return fail("hipHostMalloc", e);
+    if ((e = hipMemset(h->d_cnt, 0, sizeof(Counters))) != hipSuccess) return fail("hipMemset", e);
+    memset(h->h_cnt, 0, sizeof(Counters));
+    h->last_stream = h->own_stream;
+    if (params->max_nodes_hint) {
+        int rc = alloc_table(h, cap_for_nodes(params->max_nodes_hint), h->own_stream);
+        if (rc) { g_create_error = h->err; gndt_destroy(h); return rc; }
+        if ((e = hipStreamSynchronize(h->own_stream)) != hipSuccess) return fail("hipStreamSynchronize", e);
+    }
+    *out = h;
+    return GNDT_OK;
+}
+
+void gndt_destroy(gndt_handle* h) {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    (void)hipDeviceSynchronize();
+    free_table(h);
+    free_part(h);
+    free_cost(h);
+    void* ptrs[] = {h->out.sx, h->out.sy, h->out.sz, h->out.count, h->out.first_idx, h->out.mean, h->out.cov,
+                    h->out.rough, h->out.normal, h->out.flags, h->st_key, h->st_sums, h->st_count, h->st_first,
+                    h->stage, h->d_cnt, h->packed, h->d_nvalid};
+    if (h->h_nvalid) (void)hipHostFree(h->h_nvalid);
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    for (auto& set : h->ev)
+        for (auto& e : set)
+            if (e) (void)hipEventDestroy(e);
+    if (h->h_cnt) (void)hipHostFree(h->h_cnt);
+    if (h->xstream_ev) (void)hipEventDestroy(h->xstream_ev);
+    if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+    delete h;
+}
+
+int gndt_set_origin(gndt_handle* h, const float origin_xyz[3]) {
+    if (!h || !origin_xyz) return GNDT_ERR_INVALID;
+    // a build still pending belongs to the OLD origin: settle it (flags, retries) before the origin moves
+    if (h->pending.active) { const int prc = partition_resolve(h); if (prc) return prc; }
+    if (h->table_dirty) { h->err = "origin cannot change while the map holds points (call gndt_reset)"; return GNDT_ERR_INVALID; }
+    memcpy(h->origin, origin_xyz, 3 * sizeof(float));
+    h->origin_set = true;
+    return GNDT_OK;
+}
+
+int gndt_get_origin(const gndt_handle* h, float origin_xyz[3]) {
+    if (!h || !origin_xyz || !h->origin_set) return GNDT_ERR_INVALID;
+    memcpy(origin_xyz, h->origin, 3 * sizeof(float));
+    return GNDT_OK;
+}
+
+int gndt_reset(gndt_handle* h, void* hip_stream) {
+    if (!h) return GNDT_ERR_INVALID;
+    HIP_TRY(h, hipSetDevice(h->device));
+    hipStream_t s = stream_of(h, hip_stream);
+    { const int urc = use_stream(h, s); if (urc) return urc; }
+    h->pending.active = false;
+    h->map_in_table = true;
+    h->last_strategy = GNDT_STRATEGY_ATOMIC;
+    return do_reset(h, s);
+}
+int gndt_sync(gndt_handle* h, uint64_t* num_nodes, uint64_t* num_columns, uint64_t* num_slopes) {
+    if (!h) return GNDT_ERR_INVALID;
+    HIP_TRY(h, hipSetDevice(h->device));
+    { const int prc = partition_resolve(h); if (prc) return prc; }
+    HIP_TRY(h, hipStreamSynchronize(h->last_stream));
+    if (h->results_valid) {
+        h->res_nodes = h->h_cnt->num_nodes;
+        h->res_columns = h->h_cnt->num_columns;
+        h->res_slopes = h->h_cnt->num_slopes;
+    }
+    if (num_nodes) *num_nodes = h->res_nodes;
+    if (num_columns) *num_columns = h->res_columns;
+    if (num_slopes) *num_slopes = h->res_slopes;
+    if (h->h_cnt->err_key_range) {
+        h->err = std::to_string(h->h_cnt->err_key_range) +
+                 " point(s) outside the key range (|nx|,|ny| <= 65535: countMorton wraps beyond, Stopwatch.h:102-110)";
+        return GNDT_ERR_KEY_RANGE;
+    }
+    if (h->h_cnt->err_table_full) { h->err = "node table full: raise gndt_params.max_nodes_hint"; return GNDT_ERR_CAPACITY; }
+    if (h->results_valid && h->part.h_pc && h->part.h_pc->stage_overflow) {
+        h->err = "more nodes than result rows: raise gndt_params.max_nodes_hint";
+        return GNDT_ERR_CAPACITY;
+    }
+    if (h->results_valid && h->part.h_pc && h->part.h_pc->index_overflow) {
+        h->err = "point stream ran past the column-order bitmap (replayed graph?): raise gndt_params.max_points_hint";
+        return GNDT_ERR_CAPACITY;
+    }
+    return GNDT_OK;
+}
+
+int gndt_export_device(gndt_handle* h, gndt_cells* out) {
+    if (!h || !out) return GNDT_ERR_INVALID;
+    { const int prc = partition_resolve(h); if (prc) return prc; }
+    if (!h->results_valid) { h->err = "no finished build to export"; return GNDT_ERR_INVALID; }
+    int rc = gndt_sync(h, nullptr, nullptr, nullptr);
+    if (rc) return rc;
+    out->num_nodes = h->res_nodes; out->num_columns = h->res_columns; out->num_slopes = h->res_slopes;
+    out->sx = h->out.sx; out->sy = h->out.sy; out->sz = h->out.sz;
+    out->count = h->out.count; out->first_idx = h->out.first_idx;
+    out->mean = h->out.mean; out->cov = h->out.cov; out->rough = h->out.rough; out->normal = h->out.normal;
+    out->flags = h->out.flags;
+    return GNDT_OK;
+}
+
+int gndt_export(gndt_handle* h, gndt_cells* o) {
+    if (!h || !o) return GNDT_ERR_INVALID;
+    { const int prc = partition_resolve(h); if (prc) return prc; }
+    if (!h->results_valid) { h->err = "no finished build to export"; return GNDT_ERR_INVALID; }
+    int rc = gndt_sync(h, nullptr, nullptr, nullptr);
+    if (rc) return rc;
+    const uint64_t n = h->res_nodes;
+    o->num_nodes = n; o->num_columns = h->res_columns; o->num_slopes = h->res_slopes;
+    struct { void* dst; const void* src; size_t elem; } copies[] = {
+        {o->sx, h->out.sx, 4}, {o->sy, h->out.sy, 4}, {o->sz, h->out.sz, 4}, {o->count, h->out.count, 4},
+        {o->first_idx, h->out.first_idx, 4}, {o->mean, h->out.mean, 12}, {o->cov, h->out.cov, 24},
+        {o->rough, h->out.rough, 4}, {o->normal, h->out.normal, 12}, {o->flags, h->out.flags, 4}};
+    for (auto& c : copies)
+        if (c.dst && n) HIP_TRY(h, hipMemcpy(c.dst, c.src, n * c.elem, hipMemcpyDeviceToHost));
+    return GNDT_OK;
+}
+
+int gndt_set_profiling(gndt_handle* h, int enable) {
+    if (!h) return GNDT_ERR_INVALID;
+    HIP_TRY(h, hipSetDevice(h->device));
+    if (enable)
+        for (auto& set : h->ev)
+            for (auto& e : set)
+                if (!e) HIP_TRY(h, hipEventCreate(&e));
+    for (auto& set : h->ev_recorded)
+        for (auto& r : set) r = false;
+    h->prof = enable < 0 ? 0 : (enable > 2 ? 1 : enable);
+    return GNDT_OK;
+}
+
+// Mean duration of every phase over the builds recorded since the last call (at most the last kEvSets).
+int gndt_get_phase_times(gndt_handle* h, double ms_out[GNDT_NUM_PHASES]) {
+    if (!h || !ms_out) return GNDT_ERR_INVALID;
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipStreamSynchronize(h->last_stream));
+    for (int i = 0; i < GNDT_NUM_PHASES; ++i) {
+        double sum = 0.0;
+        int cnt = 0;
+        for (int k = 0; k < gndt_handle::kEvSets; ++k) {
+            if (!(h->ev_recorded[k][i] && h->ev_recorded[k][i + 1])) continue;
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, h->ev[k][i], h->ev[k][i + 1]) == hipSuccess) { sum += ms; ++cnt; }
+        }
+        ms_out[i] = cnt ? sum / cnt : -1.0;
+    }
+    for (auto& set : h->ev_recorded)
+        for (auto& r : set) r = false;
+    return GNDT_OK;
+}
+int gndt_last_strategy(const gndt_handle* h) { return h ? h->last_strategy : GNDT_STRATEGY_AUTO; }
+
+int gndt_device_info(int32_t device_id, char name_out[128], int32_t* compute_units, uint64_t* hbm_bytes) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device_id < 0 || device_id >= ndev) return GNDT_ERR_NO_DEVICE;
+    if (name_out) {
+        name_out[0] = 0;
+        (void)hipDeviceGetName(name_out, 128, device_id);
+    }
+    if (compute_units) {
+        int cu = 0;
+        (void)hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, device_id);
+        *compute_units = cu;
+    }
+    if (hbm_bytes) {
+        size_t total = 0;
+        (void)hipDeviceTotalMem(&total, device_id);
+        *hbm_bytes = total;
+    }
+    return GNDT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,141 @@
+// gndt_api_cost.hip — cost-map flood (TwoDmap::computeCost, include/map2D.h:1285-1397) over the finished grid.
+#include "gndt_handle.hpp"
+
+using namespace gndt;
+using namespace gndt_host;
+
+namespace gndt_host {
+
+void free_cost(gndt_handle* h) {
+    auto& c = h->cost;
+    void* ptrs[] = {c.h_bits, c.pushed, c.state, c.f[0], c.f[1], c.ctab_key, c.ctab_val, c.ring, c.nbr, c.d_cc};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    if (c.h_cc) (void)hipHostFree(c.h_cc);
+    c = gndt_handle::Cost{};
+}
+
+
+}  // namespace gndt_host
+
+extern "C" {
+
+constexpr int kCostBlocks = 128, kCostThreads = 64, kCostBatch = 32;
+
+int gndt_compute_cost(gndt_handle* h, const float goal_xyz[3], const gndt_robot* robot, void* hip_stream) {
+    int rc = check_ready(h);
+    if (rc) return rc;
+    if (!goal_xyz) { h->err = "null goal"; return GNDT_ERR_INVALID; }
+    { const int prc = partition_resolve(h); if (prc) return prc; }
+    if (!h->results_valid) { h->err = "no finished build to flood (computeCost runs after create2DMap, receiver.cpp:160, 171)"; return GNDT_ERR_INVALID; }
+    rc = gndt_sync(h, nullptr, nullptr, nullptr);
+    if (rc) return rc;
+    hipStream_t s = stream_of(h, hip_stream);
+    auto& c = h->cost;
+    c.serial = 0;
+    const uint64_t n = h->res_nodes, K = h->res_columns;
+    if (!c.d_cc) {
+        HIP_TRY(h, hipMalloc(&c.d_cc, sizeof(CostCounters)));
+        HIP_TRY(h, hipHostMalloc(&c.h_cc, sizeof(CostCounters)));
+        HIP_TRY(h, hipMalloc(&c.ring, (size_t)kCostBlocks * kCostThreads * kRingCap * sizeof(uint32_t)));
+    }
+    if (n > c.node_cap) {
+        for (uint32_t** a : {&c.h_bits, &c.pushed, &c.state, &c.f[0], &c.f[1], &c.nbr}) { if (*a) (void)hipFree(*a); *a = nullptr; }
+        c.node_cap = 0;
+        const uint64_t cap = std::max<uint64_t>(1024, n + n / 8);
+        for (uint32_t** a : {&c.h_bits, &c.pushed, &c.state, &c.f[0], &c.f[1]}) HIP_TRY(h, hipMalloc(a, cap * 4));
+        HIP_TRY(h, hipMalloc(&c.nbr, cap * 16));
+        c.node_cap = cap;
+    }
+    const uint32_t tsize = pow2_ceil(std::max<uint64_t>(1024, 2 * K));
+    if (tsize > c.ctab_size) {
+        if (c.ctab_key) (void)hipFree(c.ctab_key);
+        if (c.ctab_val) (void)hipFree(c.ctab_val);
+        c.ctab_key = nullptr; c.ctab_val = nullptr; c.ctab_size = 0;
+        HIP_TRY(h, hipMalloc(&c.ctab_key, (size_t)tsize * 8));
+        HIP_TRY(h, hipMalloc(&c.ctab_val, (size_t)tsize * 4));
+        c.ctab_size = tsize;
+    }
+    Robot R{0.25f, 0.15f, 100.f, 30.f};   // receiver.cpp:33, robot.h:38-46
+    if (robot) R = Robot{robot->radius, robot->reachable_height, robot->max_rough, robot->max_angle_deg};
+    c.ring_n = cost_ring_depth(R.r, h->P.grid_len);
+    CostView V;
+    V.sx = h->out.sx; V.sy = h->out.sy; V.sz = h->out.sz;
+    V.mean = h->out.mean; V.normal = h->out.normal; V.rough = h->out.rough; V.flags = h->out.flags;
+    V.row_ncol = h->part.row_ncol;
+    V.ctab_key = c.ctab_key; V.ctab_val = c.ctab_val; V.ctab_mask = c.ctab_size - 1;
+    V.nbr = nullptr;
+    V.slope_interval = h->P.slope_interval; V.demand_true = h->P.demand == GNDT_DEMAND_TRUE ? 1 : 0;
+    // the goal's key through the same codec the build uses (transMortonXYZ, map2D.h:1293)
+    const PointKey gk = point_key(goal_xyz[0], goal_xyz[1], goal_xyz[2], h->origin[0], h->origin[1], h->origin[2],
+                                  h->P.grid_len, h->P.z_len);
+    hipLaunchKernelGGL(k_cost_clear, dim3(grid_for(std::max<uint64_t>(n, c.ctab_size))), dim3(256), 0, s, c.h_bits, c.pushed,
+                       c.state, (uint32_t)n, c.ctab_key, c.ctab_size, c.d_cc);
+    if (K)
+        hipLaunchKernelGGL(k_cost_columns, dim3(grid_for(n)), dim3(256), 0, s, h->out.sx, h->out.sy, h->part.row_ncol,
+                           (uint32_t)n, c.ctab_key, c.ctab_val, c.ctab_size - 1, c.d_cc);
+    if (K) {
+        hipLaunchKernelGGL(k_cost_neighbours, dim3(grid_for(4 * n)), dim3(256), 0, s, V, (uint32_t)n, c.nbr);   // (probes: V.nbr is null)
+        V.nbr = c.nbr;
+    }
+    if (gk.ok && K)
+        hipLaunchKernelGGL(k_cost_goal, dim3(1), dim3(64), 0, s, V, gk.sx, gk.sy, gk.sz, c.h_bits, c.pushed, c.f[0], c.d_cc);
+    HIP_TRY(h, hipGetLastError());
+    // One launch per layer.  The layer count is only known on the device, so layers are enqueued in batches and
+    // the frontier size of the next layer is read back after each batch (empty layers are no-ops).
+    uint32_t level = 0;
+    for (;;) {
+        for (int b = 0; b < kCostBatch; ++b, ++level)
+            hipLaunchKernelGGL(k_cost_level, dim3(kCostBlocks), dim3(kCostThreads), 0, s, V, R, c.ring_n, level, c.h_bits,
+                               c.pushed, c.state, c.f[level & 1u], c.f[(level + 1u) & 1u], c.ring, c.d_cc);
+        HIP_TRY(h, hipGetLastError());
+        HIP_TRY(h, hipMemcpyAsync(c.h_cc, c.d_cc, sizeof(CostCounters), hipMemcpyDeviceToHost, s));
+        HIP_TRY(h, hipStreamSynchronize(s));
+        if (c.h_cc->frontier[level % 3u] == 0u) break;
+        if (level > (1u << 24)) { h->err = "cost flood did not terminate"; return GNDT_ERR_HIP; }
+    }
+    if (c.h_cc->range_error) {
+        h->err = "cost map: column indices beyond 32767 (mortonToXY decodes no further, Stopwatch.h:171-189)";
+        return GNDT_ERR_KEY_RANGE;
+    }
+    if (c.h_cc->ring_overflow) {
+        h->err = "cost map: a collision ring holds more than " + std::to_string(kRingCap) + " slopes (robot radius too large for this grid)";
+        return GNDT_ERR_CAPACITY;
+    }
+    c.serial = h->result_serial;
+    return GNDT_OK;
+}
+
+static int cost_ready(gndt_handle* h, gndt_cost_stats* st) {
+    if (!h) return GNDT_ERR_INVALID;
+    if (!h->results_valid || h->cost.serial == 0 || h->cost.serial != h->result_serial) {
+        h->err = "no cost map for the current grid (call gndt_compute_cost after the build)";
+        return GNDT_ERR_INVALID;
+    }
+    if (st) {
+        const CostCounters* cc = h->cost.h_cc;
+        st->goal_status = cc->goal_status; st->ring = (uint32_t)h->cost.ring_n; st->levels = cc->levels; st->reserved = 0;
+        st->traversable = cc->traversable; st->closed = cc->closed; st->check_pushes = cc->check_pushes;
+    }
+    return GNDT_OK;
+}
+
+int gndt_cost_export_device(gndt_handle* h, const float** h_dev, const uint32_t** state_dev, gndt_cost_stats* stats) {
+    int rc = cost_ready(h, stats);
+    if (rc) return rc;
+    if (h_dev) *h_dev = reinterpret_cast<const float*>(h->cost.h_bits);
+    if (state_dev) *state_dev = h->cost.state;
+    return GNDT_OK;
+}
+
+int gndt_cost_export(gndt_handle* h, float* h_out, uint32_t* state_out, gndt_cost_stats* stats) {
+    int rc = cost_ready(h, stats);
+    if (rc) return rc;
+    HIP_TRY(h, hipSetDevice(h->device));
+    const uint64_t n = h->res_nodes;
+    if (h_out && n) HIP_TRY(h, hipMemcpy(h_out, h->cost.h_bits, n * 4, hipMemcpyDeviceToHost));
+    if (state_out && n) HIP_TRY(h, hipMemcpy(state_out, h->cost.state, n * 4, hipMemcpyDeviceToHost));
+    return GNDT_OK;
+}
+
+}  // extern "C"

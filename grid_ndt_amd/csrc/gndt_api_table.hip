@@ -1,0 +1,396 @@
+// gndt_api_table.hip — strategy ATOMIC: the HBM node table (accumulate, incremental update, finalize, statistics export / merge).
+#include "gndt_handle.hpp"
+#include "gndt_table.hpp"
+using namespace gndt;
+using namespace gndt_host;
+
+namespace gndt_host {
+
+void free_table(gndt_handle* h) {
+    void* ptrs[] = {h->keys, h->acc, h->col_keys, h->col_first, h->aux, h->node_slot, h->col_slot_of_node,
+                    h->col_cnt, h->col_head, h->node_next, h->index_of_slot, h->touch_epoch, h->col_epoch, h->touched,
+                    h->touched_cols};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    h->keys = nullptr; h->acc = nullptr; h->col_keys = nullptr; h->col_first = nullptr; h->aux = nullptr;
+    h->node_slot = nullptr; h->col_slot_of_node = nullptr; h->col_cnt = nullptr; h->col_head = nullptr; h->node_next = nullptr;
+    h->index_of_slot = h->touch_epoch = h->col_epoch = h->touched = h->touched_cols = nullptr;
+    h->incr_ok = false;
+    h->cap = 0;
+}
+
+// A fresh, empty table of `cap` slots.  The device counters are NOT touched: the caller decides (reset vs growth).
+int alloc_table(gndt_handle* h, uint32_t cap, hipStream_t s) {
+    free_table(h);
+    HIP_TRY(h, hipMalloc(&h->keys, (size_t)cap * sizeof(uint64_t)));
+    HIP_TRY(h, hipMalloc(&h->acc, (size_t)cap * sizeof(NodeAcc)));
+    HIP_TRY(h, hipMalloc(&h->col_keys, (size_t)cap * sizeof(uint64_t)));
+    HIP_TRY(h, hipMalloc(&h->col_first, (size_t)cap * sizeof(uint32_t)));
+    HIP_TRY(h, hipMalloc(&h->col_cnt, (size_t)cap * sizeof(uint32_t)));
+    HIP_TRY(h, hipMalloc(&h->col_head, (size_t)cap * sizeof(uint32_t)));
+    HIP_TRY(h, hipMalloc(&h->aux, (size_t)cap * sizeof(SlotAux)));
+    HIP_TRY(h, hipMalloc(&h->node_slot, (size_t)cap * sizeof(uint32_t)));
+    HIP_TRY(h, hipMalloc(&h->col_slot_of_node, (size_t)cap * sizeof(uint32_t)));
+    HIP_TRY(h, hipMalloc(&h->node_next, (size_t)cap * sizeof(uint32_t)));
+    for (uint32_t** a : {&h->index_of_slot, &h->touch_epoch, &h->col_epoch, &h->touched, &h->touched_cols})
+        HIP_TRY(h, hipMalloc(a, (size_t)cap * sizeof(uint32_t)));
+    h->cap = cap;
+    hipLaunchKernelGGL(k_clear_all, dim3(grid_for(cap)), dim3(kBlock), 0, s, h->keys, h->acc, h->col_keys,
+                       h->col_first, h->col_cnt, h->col_head, h->touch_epoch, h->col_epoch, cap);
+    HIP_TRY(h, hipGetLastError());
+    h->table_dirty = false;
+    return GNDT_OK;
+}
+
+namespace {
+TableView table_view(const gndt_handle* h) {
+    TableView T;
+    T.keys = h->keys; T.acc = h->acc; T.aux = h->aux; T.col_keys = h->col_keys; T.col_first = h->col_first;
+    T.col_cnt = h->col_cnt; T.col_head = h->col_head; T.node_slot = h->node_slot; T.col_slot_of_node = h->col_slot_of_node;
+    T.node_next = h->node_next; T.cap_mask = h->cap - 1;
+    T.index_of_slot = h->index_of_slot; T.touch_epoch = h->touch_epoch; T.col_epoch = h->col_epoch;
+    T.touched = h->touched; T.touched_cols = h->touched_cols;
+    return T;
+}
+
+}  // namespace
+
+int do_reset(gndt_handle* h, hipStream_t s) {
+    if (h->cap && h->table_dirty) {
+        hipLaunchKernelGGL(k_clear_used, dim3(grid_for(h->cap / 8)), dim3(kBlock), 0, s, h->keys, h->acc, h->col_keys,
+                           h->col_first, h->col_cnt, h->col_head, h->node_slot, h->col_slot_of_node, h->d_cnt);
+        HIP_TRY(h, hipGetLastError());
+    }
+    hipLaunchKernelGGL(k_zero_counters, dim3(1), dim3(64), 0, s, h->d_cnt);
+    HIP_TRY(h, hipGetLastError());
+    h->table_dirty = false;
+    h->results_valid = false;
+    h->stream_pos = 0;
+    h->nodes_bound = 0;
+    h->incr_ok = false;
+    return GNDT_OK;
+}
+
+namespace {
+// Grow the table to `new_cap` slots keeping its contents (export -> fresh table -> merge).
+int grow_table(gndt_handle* h, uint32_t new_cap, hipStream_t s);
+
+// `base_from_device`: first_idx base = the device-side stream position (incremental updates)
+int do_accumulate(gndt_handle* h, const void* xyz_dev, size_t n, size_t stride_bytes, uint64_t first_base,
+                  int base_from_device, hipStream_t s, int mark = 0) {
+    if (stride_bytes != 12 && stride_bytes != 16) { h->err = "stride_bytes must be 12 or 16"; return GNDT_ERR_INVALID; }
+    if (first_base + n >= 0xFFFFFFFFull) { h->err = "point index exceeds 32 bits"; return GNDT_ERR_INVALID; }
+    if (n == 0) return GNDT_OK;
+    const float* p = static_cast<const float*>(xyz_dev);
+    const int blocks = grid_for(n, kBlock, 256 * 16);
+    if (stride_bytes == 12)
+        hipLaunchKernelGGL(k_accumulate<3>, dim3(blocks), dim3(kBlock), 0, s, p, (uint64_t)n, (uint32_t)first_base,
+                           base_from_device, grid_params(h), h->keys, h->acc, h->cap - 1, h->node_slot, h->index_of_slot,
+                           h->touch_epoch, h->touched, mark, h->d_cnt);
+    else
+        hipLaunchKernelGGL(k_accumulate<4>, dim3(blocks), dim3(kBlock), 0, s, p, (uint64_t)n, (uint32_t)first_base,
+                           base_from_device, grid_params(h), h->keys, h->acc, h->cap - 1, h->node_slot, h->index_of_slot,
+                           h->touch_epoch, h->touched, mark, h->d_cnt);
+    HIP_TRY(h, hipGetLastError());
+    if (!mark) h->incr_ok = false;                    // nodes changed without being listed: the next finalisation redoes every column
+    if (base_from_device) {
+        hipLaunchKernelGGL(k_advance_stream, dim3(1), dim3(64), 0, s, h->d_cnt, (uint32_t)n);
+        HIP_TRY(h, hipGetLastError());
+    }
+    h->table_dirty = true;
+    h->results_valid = false;
+    h->nodes_bound = std::min<uint64_t>(h->nodes_bound + n, h->cap);
+    return GNDT_OK;
+}
+
+// columns -> labels + staging rows -> ordering -> emit.  Everything is sized on the device; nothing waits for
+// the host, so accumulate + finalize can be captured in a hipGraph once the buffers exist.
+int do_finalize(gndt_handle* h, hipStream_t s, bool incremental = false, uint64_t touched_bound = 0) {
+    auto& q = h->part;
+    int rc;
+    // host-side upper bounds only: rows <= slots/2 at a healthy load; points seen so far (or the caller's hint)
+    const uint64_t rows_bound = std::max<uint64_t>(1024, h->cap / 2 + 1);
+    const uint64_t pts_bound = std::max<uint64_t>(std::max<uint64_t>(h->stream_pos, h->P.max_points_hint), 64);
+    const uint64_t words = (pts_bound + 31) / 32 + 1;
+    // The incremental form needs what the last finalisation left behind (staging rows, order keys, column order): any
+    // reallocation, or anything else that touched those buffers, sends this call down the full path.
+    if (!h->incr_ok || rows_bound > q.stage_cap || words > q.word_cap || !q.d_pc) incremental = false;
+    if ((rc = ensure_part_counters(h))) return rc;
+    if ((rc = ensure_stage(h, rows_bound))) return rc;
+    if ((rc = ensure_out(h, q.stage_cap))) return rc;
+    if ((rc = ensure_words(h, words))) return rc;
+    const TableView T = table_view(h);
+    const GridParams gp = grid_params(h);
+    const ColumnOrder O{q.bitmap, q.word_weight, q.ncol_at};
+    mark(h, 2, s);
+    if (incremental) {
+        if (words > q.words_init) {                        // the stream grew past the words the order has seen: they start empty
+            HIP_TRY(h, hipMemsetAsync(q.bitmap + q.words_init, 0, (words - q.words_init) * 4, s));
+            HIP_TRY(h, hipMemsetAsync(q.word_weight + q.words_init, 0, (words - q.words_init) * 4, s));
+            q.words_init = words;
+        }
+        const uint64_t tb = std::max<uint64_t>(std::min<uint64_t>(touched_bound, rows_bound), 64);
+        hipLaunchKernelGGL(k_tab_touch, dim3(grid_for(tb)), dim3(kBlock), 0, s, T, gp, h->d_cnt, q.d_pc);
+        HIP_TRY(h, hipGetLastError());
+        hipLaunchKernelGGL(k_tab_expand, dim3(grid_for(tb)), dim3(kBlock), 0, s, T, h->d_cnt);
+        HIP_TRY(h, hipGetLastError());
+        mark(h, 3, s);
+        hipLaunchKernelGGL(k_tab_rows_touched, dim3(grid_for(4 * tb, kBlock, 4096)), dim3(kBlock), 0, s, T, gp, q.stage,
+                           (uint32_t)q.stage_cap, q.ord_cf, q.ord_idx, O, (uint64_t)words, h->d_cnt, q.d_pc);
+        HIP_TRY(h, hipGetLastError());
+    } else {
+        hipLaunchKernelGGL(k_tab_begin, dim3(grid_for(std::max<uint64_t>(words, h->cap / 4), kBlock, 1024)), dim3(kBlock), 0, s, T,
+                           h->d_cnt, q.d_pc, q.bitmap, q.word_weight, (uint64_t)words);
+        hipLaunchKernelGGL(k_tab_columns, dim3(grid_for(rows_bound)), dim3(kBlock), 0, s, T, gp, h->d_cnt);
+        HIP_TRY(h, hipGetLastError());
+        mark(h, 3, s);
+        hipLaunchKernelGGL(k_tab_rows, dim3(grid_for(rows_bound)), dim3(kBlock), 0, s, T, gp, q.stage, (uint32_t)q.stage_cap,
+                           q.ord_cf, q.ord_idx, O, (uint64_t)words, h->d_cnt, q.d_pc);
+        HIP_TRY(h, hipGetLastError());
+        q.words_init = words;
+    }
+    mark(h, 4, s);
+    if ((rc = launch_order_and_emit(h, words, 4, s))) return rc;
+    hipLaunchKernelGGL(k_tab_end, dim3(1), dim3(64), 0, s, h->d_cnt);
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipMemcpyAsync(q.h_pc, q.d_pc, sizeof(PartCounters), hipMemcpyDeviceToHost, s));
+    HIP_TRY(h, hipMemcpyAsync(h->h_cnt, h->d_cnt, sizeof(Counters), hipMemcpyDeviceToHost, s));
+    h->results_valid = true;
+    ++h->result_serial;
+    h->last_stream = s;
+    h->incr_ok = true;
+    return GNDT_OK;
+}
+
+uint64_t expected_nodes_for_batch(const gndt_handle* h, uint64_t known_nodes, uint64_t n) {
+    if (h->P.max_nodes_hint) return std::max<uint64_t>(h->P.max_nodes_hint, known_nodes);
+    return known_nodes + n;   // worst case: every point opens a node
+}
+
+// Make room for `extra` more points (or merged nodes).  The host only tracks an upper bound of the node count;
+// when that bound asks for a larger table the real count is fetched (one sync) before anything is moved.
+int ensure_capacity_for(gndt_handle* h, uint64_t extra, hipStream_t s) {
+    uint32_t want = cap_for_nodes(expected_nodes_for_batch(h, h->nodes_bound, extra));
+    if (h->cap == 0) return alloc_table(h, want, s);
+    if (want <= h->cap) return GNDT_OK;
+    if (h->table_dirty) {
+        int rc = fetch_counters(h, s);
+        if (rc) return rc;
+        h->nodes_bound = h->h_cnt->num_nodes;
+        want = cap_for_nodes(expected_nodes_for_batch(h, h->nodes_bound, extra));
+        if (want <= h->cap) return GNDT_OK;
+    }
+    return grow_table(h, want, s);
+}
+
+int grow_table(gndt_handle* h, uint32_t new_cap, hipStream_t s) {
+    if (!h->table_dirty) return alloc_table(h, new_cap, s);
+    // export the current contents (the node list is always valid), rebuild, merge back
+    int rc = fetch_counters(h, s);
+    if (rc) return rc;
+    const uint32_t C = h->h_cnt->num_nodes;
+    rc = ensure_stats_buffers(h, C);
+    if (rc) return rc;
+    if (C) {
+        hipLaunchKernelGGL(k_stats_export, dim3(grid_for(C)), dim3(kBlock), 0, s, h->keys, h->acc, h->node_slot, h->d_cnt,
+                           h->st_key, h->st_sums, h->st_count, h->st_first);
+        HIP_TRY(h, hipGetLastError());
+    }
+    HIP_TRY(h, hipStreamSynchronize(s));
+    rc = alloc_table(h, new_cap, s);
+    if (rc) return rc;
+    // the new table is empty: node list restarts, nobody owns a column entry yet (stream position is kept)
+    HIP_TRY(h, hipMemsetAsync(&h->d_cnt->num_nodes, 0, sizeof(uint32_t), s));
+    HIP_TRY(h, hipMemsetAsync(&h->d_cnt->prev_nodes, 0, sizeof(uint32_t), s));
+    if (C) {
+        hipLaunchKernelGGL(k_stats_merge, dim3(grid_for(C)), dim3(kBlock), 0, s, h->keys, h->acc, h->cap - 1, h->node_slot,
+                           h->index_of_slot, h->st_key, h->st_sums, h->st_count, h->st_first, (uint64_t)C, h->d_cnt);
+        HIP_TRY(h, hipGetLastError());
+        h->table_dirty = true;
+    }
+    h->nodes_bound = C;
+    return GNDT_OK;
+}
+
+}  // namespace
+
+// strategy ATOMIC from empty; waits for the result (the retry on a full table needs the device-side flags)
+int build_atomic(gndt_handle* h, const void* xyz_dev, size_t n, size_t stride_bytes, hipStream_t s) {
+    int rc;
+    h->last_strategy = GNDT_STRATEGY_ATOMIC;
+    h->map_in_table = true;
+    uint64_t expect = h->P.max_nodes_hint ? h->P.max_nodes_hint : std::max<uint64_t>(1024, n / 4);
+    for (int attempt = 0; attempt < 8; ++attempt) {
+        const uint32_t want = cap_for_nodes(expect);
+        if (h->cap < want) { rc = alloc_table(h, want, s); if (rc) return rc; }
+        mark(h, 0, s);
+        rc = do_reset(h, s);
+        if (rc) return rc;
+        mark(h, 1, s);
+        rc = do_accumulate(h, xyz_dev, n, stride_bytes, 0, 0, s);
+        if (rc) return rc;
+        h->stream_pos = n;
+        hipLaunchKernelGGL(k_raise_stream, dim3(1), dim3(64), 0, s, h->d_cnt, (uint32_t)n);
+        HIP_TRY(h, hipGetLastError());
+        rc = do_finalize(h, s);
+        if (rc) return rc;
+        // a build returns with its results ready: wait once and look at the device-side flags
+        HIP_TRY(h, hipStreamSynchronize(s));
+        if (!h->h_cnt->err_table_full && !h->part.h_pc->stage_overflow) {
+            // what a later PARTITION build of a similar cloud should expect (a first build without a hint guesses n / 4)
+            h->part.nodes_learned = (uint64_t)h->h_cnt->num_nodes + h->h_cnt->num_nodes / 5;
+            return GNDT_OK;
+        }
+        // table (or staging) overflowed: the build starts from empty, so simply redo it in a larger table
+        expect = (uint64_t)h->cap * 2;   // cap_for_nodes doubles again -> 4x slots
+        if (expect > (1ull << 30)) break;
+    }
+    return GNDT_ERR_CAPACITY;
+}
+
+}  // namespace gndt_host
+
+extern "C" {
+
+int gndt_accumulate_device(gndt_handle* h, const void* xyz_dev, size_t n, size_t stride_bytes,
+                           uint64_t first_idx_base, void* hip_stream) {
+    int rc = check_ready(h);
+    if (rc) return rc;
+    if (!xyz_dev && n) { h->err = "null input"; return GNDT_ERR_INVALID; }
+    hipStream_t s = stream_of(h, hip_stream);
+    { const int urc = use_stream(h, s); if (urc) return urc; }
+    if (!h->map_in_table) {
+        h->err = "the current map was built by the PARTITION strategy, which keeps no additive state: create the handle "
+                 "with strategy = GNDT_STRATEGY_ATOMIC for incremental updates, or call gndt_reset first";
+        return GNDT_ERR_INVALID;
+    }
+    h->pending.active = false;
+    rc = ensure_capacity_for(h, n, s);
+    if (rc) return rc;
+    mark(h, 1, s);
+    rc = do_accumulate(h, xyz_dev, n, stride_bytes, first_idx_base, 0, s);
+    if (rc) return rc;
+    mark(h, 2, s);
+    h->stream_pos = std::max<uint64_t>(h->stream_pos, first_idx_base + n);
+    hipLaunchKernelGGL(k_raise_stream, dim3(1), dim3(64), 0, s, h->d_cnt, (uint32_t)h->stream_pos);
+    HIP_TRY(h, hipGetLastError());
+    return GNDT_OK;
+}
+
+int gndt_finalize_device(gndt_handle* h, void* hip_stream) {
+    int rc = check_ready(h);
+    if (rc) return rc;
+    hipStream_t s = stream_of(h, hip_stream);
+    { const int urc = use_stream(h, s); if (urc) return urc; }
+    if (!h->map_in_table) {
+        h->err = "nothing accumulated in the node table: the current map was built by a PARTITION strategy (call gndt_reset, "
+                 "then gndt_accumulate_device / gndt_stats_merge_device)";
+        return GNDT_ERR_INVALID;
+    }
+    h->pending.active = false;
+    if (h->cap == 0) {
+        rc = alloc_table(h, cap_for_nodes(1024), s);
+        if (rc) return rc;
+    }
+    return do_finalize(h, s);
+}
+
+int gndt_update_device(gndt_handle* h, const void* xyz_dev, size_t n, size_t stride_bytes, void* hip_stream) {
+    int rc = check_ready(h);
+    if (rc) return rc;
+    if (!xyz_dev && n) { h->err = "null input"; return GNDT_ERR_INVALID; }
+    hipStream_t s = stream_of(h, hip_stream);
+    { const int urc = use_stream(h, s); if (urc) return urc; }
+    if (!h->map_in_table) {
+        h->err = "the current map was built by the PARTITION strategy, which keeps no additive state: create the handle "
+                 "with strategy = GNDT_STRATEGY_ATOMIC for incremental updates, or call gndt_reset first";
+        return GNDT_ERR_INVALID;
+    }
+    next_event_set(h);
+    h->last_strategy = GNDT_STRATEGY_ATOMIC;
+    // Host side: only upper bounds, so that buffers exist (allocation happens outside any graph capture: run one
+    // frame eagerly first, or give max_nodes_hint / max_points_hint).  The first_idx base is the DEVICE-side
+    // stream position, which k_advance_stream bumps, so a captured update can be replayed frame after frame.
+    rc = ensure_capacity_for(h, n, s);
+    if (rc) return rc;
+    mark(h, 1, s);
+    // The frame's points list the nodes they touch; if the staging rows and the column order of the last finalisation
+    // are still in place, only the columns holding a touched node are relabelled (the ordering and the emit pass
+    // still cover the whole map: rows move when a column in front of them grows).
+    const bool incr = h->incr_ok;
+    rc = do_accumulate(h, xyz_dev, n, stride_bytes, h->stream_pos, 1, s, incr ? 1 : 0);
+    if (rc) return rc;
+    h->stream_pos += n;
+    return do_finalize(h, s, incr, n);
+}
+
+int gndt_update(gndt_handle* h, const void* xyz_host, size_t n, size_t stride_bytes) {
+    int rc = check_ready(h);
+    if (rc) return rc;
+    if (!xyz_host && n) { h->err = "null input"; return GNDT_ERR_INVALID; }
+    rc = stage_host_input(h, xyz_host, n, stride_bytes, h->own_stream);
+    if (rc) return rc;
+    rc = gndt_update_device(h, h->stage, n, stride_bytes, h->own_stream);
+    if (rc) return rc;
+    return gndt_sync(h, nullptr, nullptr, nullptr);
+}
+
+int gndt_stats_export_device(gndt_handle* h, gndt_stats* out, void* hip_stream) {
+    int rc = check_ready(h);
+    if (rc) return rc;
+    if (!out) return GNDT_ERR_INVALID;
+    hipStream_t s = stream_of(h, hip_stream);
+    { const int urc = use_stream(h, s); if (urc) return urc; }
+    if (!h->map_in_table) {
+        h->err = "the current map was built by the PARTITION strategy, which keeps no additive state (use strategy ATOMIC)";
+        return GNDT_ERR_INVALID;
+    }
+    if (h->cap == 0) { rc = alloc_table(h, cap_for_nodes(1024), s); if (rc) return rc; }
+    rc = fetch_counters(h, s);
+    if (rc) return rc;
+    if (h->h_cnt->err_table_full) { h->err = "node table full: raise gndt_params.max_nodes_hint"; return GNDT_ERR_CAPACITY; }
+    const uint32_t C = h->h_cnt->num_nodes;
+    rc = ensure_stats_buffers(h, C);
+    if (rc) return rc;
+    if (C) {
+        hipLaunchKernelGGL(k_stats_export, dim3(grid_for(C)), dim3(kBlock), 0, s, h->keys, h->acc, h->node_slot, h->d_cnt,
+                           h->st_key, h->st_sums, h->st_count, h->st_first);
+        HIP_TRY(h, hipGetLastError());
+    }
+    out->num_nodes = C;
+    out->key = h->st_key; out->sums = h->st_sums; out->count = h->st_count; out->first_idx = h->st_first;
+    return GNDT_OK;
+}
+
+int gndt_stats_merge_device(gndt_handle* h, const gndt_stats* in, void* hip_stream) {
+    int rc = check_ready(h);
+    if (rc) return rc;
+    if (!in) return GNDT_ERR_INVALID;
+    hipStream_t s = stream_of(h, hip_stream);
+    { const int urc = use_stream(h, s); if (urc) return urc; }
+    if (!h->map_in_table) {
+        h->err = "the current map was built by a PARTITION strategy and does not live in the node table: call gndt_reset first";
+        return GNDT_ERR_INVALID;
+    }
+    h->pending.active = false;
+    rc = ensure_capacity_for(h, in->num_nodes, s);
+    if (rc) return rc;
+    if (in->num_nodes) {
+        hipLaunchKernelGGL(k_stats_merge, dim3(grid_for(in->num_nodes)), dim3(kBlock), 0, s, h->keys, h->acc, h->cap - 1,
+                           h->node_slot, h->index_of_slot, in->key, in->sums, in->count, in->first_idx, (uint64_t)in->num_nodes,
+                           h->d_cnt);
+        h->incr_ok = false;
+        HIP_TRY(h, hipGetLastError());
+        h->table_dirty = true;
+        h->results_valid = false;
+        // the merged first indices tell how far the point stream reaches (sizes the column-order bitmap);
+        // the exchange path may wait for the host, and learns the exact node count on the way
+        rc = fetch_counters(h, s);
+        if (rc) return rc;
+        h->stream_pos = std::max<uint64_t>(h->stream_pos, h->h_cnt->stream_pos);
+        h->nodes_bound = h->h_cnt->num_nodes;
+    }
+    return GNDT_OK;
+}
+
+}  // extern "C"

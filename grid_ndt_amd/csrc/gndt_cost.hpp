@@ -262,7 +262,7 @@ struct CostCounters {
     unsigned long long check_pushes;
 };
 
-__global__ void __launch_bounds__(256) k_cost_clear(uint32_t* __restrict__ h_bits, uint32_t* __restrict__ pushed,
+static __global__ void __launch_bounds__(256) k_cost_clear(uint32_t* __restrict__ h_bits, uint32_t* __restrict__ pushed,
                                                     uint32_t* __restrict__ state, uint32_t n, uint64_t* __restrict__ ctab_key,
                                                     uint32_t ctab_size, CostCounters* __restrict__ cc) {
     const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x, gsz = gridDim.x * blockDim.x;
@@ -276,7 +276,7 @@ __global__ void __launch_bounds__(256) k_cost_clear(uint32_t* __restrict__ h_bit
 }
 
 // first row of every column -> hash table entry keyed by the column's (sx, sy)
-__global__ void __launch_bounds__(256) k_cost_columns(const int32_t* __restrict__ sx, const int32_t* __restrict__ sy,
+static __global__ void __launch_bounds__(256) k_cost_columns(const int32_t* __restrict__ sx, const int32_t* __restrict__ sy,
                                                       const uint32_t* __restrict__ row_ncol, uint32_t num_rows,
                                                       uint64_t* __restrict__ ctab_key, uint32_t* __restrict__ ctab_val,
                                                       uint32_t ctab_mask, CostCounters* __restrict__ cc) {
@@ -296,7 +296,7 @@ __global__ void __launch_bounds__(256) k_cost_columns(const int32_t* __restrict_
 }
 
 // the four neighbour columns of every row, once per flood (the layers then follow plain indices)
-__global__ void __launch_bounds__(256) k_cost_neighbours(CostView V, uint32_t num_rows, uint32_t* __restrict__ nbr) {
+static __global__ void __launch_bounds__(256) k_cost_neighbours(CostView V, uint32_t num_rows, uint32_t* __restrict__ nbr) {
     for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < 4u * num_rows; t += gridDim.x * blockDim.x) {
         const uint32_t row = t >> 2, k = t & 3u;
         const int sx = V.sx[row], sy = V.sy[row];
@@ -308,7 +308,7 @@ __global__ void __launch_bounds__(256) k_cost_neighbours(CostView V, uint32_t nu
 }
 
 // goal lookup (map2D.h:1294-1307): the slope of the goal's cell at the goal's level gets h = 0 and is queued
-__global__ void k_cost_goal(CostView V, int gx, int gy, int gz, uint32_t* __restrict__ h_bits, uint32_t* __restrict__ pushed,
+static __global__ void k_cost_goal(CostView V, int gx, int gy, int gz, uint32_t* __restrict__ h_bits, uint32_t* __restrict__ pushed,
                             uint32_t* __restrict__ frontier0, CostCounters* __restrict__ cc) {
     if (blockIdx.x != 0 || threadIdx.x != 0) return;
     const uint32_t c = ctab_find(V, gx, gy);
@@ -329,7 +329,7 @@ __global__ void k_cost_goal(CostView V, int gx, int gy, int gz, uint32_t* __rest
 
 // one layer of the flood: collision check, then expansion, of every slope in the layer.  Four lanes share a slope
 // (one per neighbour cell): layers are short, so the kernel is latency-bound and the serial work per lane counts.
-__global__ void __launch_bounds__(64) k_cost_level(CostView V, Robot R, int ring_n, uint32_t level, uint32_t* __restrict__ h_bits,
+static __global__ void __launch_bounds__(64) k_cost_level(CostView V, Robot R, int ring_n, uint32_t level, uint32_t* __restrict__ h_bits,
                                                    uint32_t* __restrict__ pushed, uint32_t* __restrict__ state,
                                                    const uint32_t* __restrict__ f_in, uint32_t* __restrict__ f_out,
                                                    uint32_t* __restrict__ ring_scratch, CostCounters* __restrict__ cc) {

@@ -1,0 +1,255 @@
+// gndt_handle.hpp — the handle behind include/gndt.h and the host-side helpers its translation units share.
+// Host code only owns memory, orders launches on a HIP stream and maps errors to status codes; the entry points are
+// grouped by what they drive:
+//   gndt_api_core.hip   handle life cycle, origin, sync / export, profiling, shared buffers
+//   gndt_api_table.hip  strategy ATOMIC: the HBM node table (accumulate, update, finalize, statistics export / merge)
+//   gndt_api_build.hip  strategy PARTITION: launch, pending-build resolution, gndt_build*
+//   gndt_api_dist.hip   one global map from a sharded cloud (shard statistics, exchange, finalize from statistics)
+//   gndt_api_cost.hip   cost-map flood over the finished grid
+//   gndt_api_io.hip     input side (record unpack + NaN strip, gndt_build_cloud)
+// There is NO CPU fallback: without a HIP device every compute entry point fails with GNDT_ERR_NO_DEVICE.
+#pragma once
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include <hip/hip_runtime.h>
+
+#include "gndt.h"
+#include "gndt_kernels.hpp"
+#include "gndt_partition.hpp"
+#include "gndt_cost.hpp"
+
+using namespace gndt;   // host translation units of libgndt only: nothing else includes this header
+
+struct gndt_handle {
+    gndt_params P{};
+    float origin[3] = {0, 0, 0};
+    bool origin_set = false;
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t last_stream = nullptr;
+    hipEvent_t xstream_ev = nullptr;   // orders work on a new stream behind what the previous one still runs (use_stream)
+
+    // node table
+    uint32_t cap = 0;  // slots, power of two
+    uint64_t* keys = nullptr;
+    NodeAcc* acc = nullptr;
+    uint64_t* col_keys = nullptr;
+    uint32_t* col_first = nullptr;
+    SlotAux* aux = nullptr;
+    // node list + ordering buffers (cap entries each)
+    uint32_t* node_slot = nullptr;
+    uint32_t* col_slot_of_node = nullptr;
+    uint32_t* col_cnt = nullptr;
+    uint32_t* col_head = nullptr;
+    uint32_t* node_next = nullptr;
+    // incremental updates: slot -> node index, touch marks, the lists of touched nodes / columns
+    uint32_t *index_of_slot = nullptr, *touch_epoch = nullptr, *col_epoch = nullptr, *touched = nullptr, *touched_cols = nullptr;
+    bool incr_ok = false;       // the persistent staging rows / order of the table path describe the current map
+
+    Counters* d_cnt = nullptr;
+    Counters* h_cnt = nullptr;  // pinned
+
+    // results
+    uint64_t out_cap = 0;
+    OutView out{};
+    uint64_t res_nodes = 0, res_columns = 0, res_slopes = 0;
+    bool results_valid = false;
+
+    // stats export buffers
+    uint64_t st_cap = 0;
+    uint64_t* st_key = nullptr;
+    double* st_sums = nullptr;
+    uint32_t* st_count = nullptr;
+    uint32_t* st_first = nullptr;
+
+    // staging for host input
+    void* stage = nullptr;
+    size_t stage_bytes = 0;
+    // gndt_build_cloud: packed xyz of the unpacked, NaN-stripped cloud; pinned word for the valid count
+    float* packed = nullptr;
+    uint64_t packed_cap = 0;
+    uint32_t* d_nvalid = nullptr;
+    uint32_t* h_nvalid = nullptr;
+
+    uint64_t stream_pos = 0;    // points accumulated since the last reset (host mirror of the device-side first_idx base)
+    uint64_t nodes_bound = 0;   // host-side upper bound of the nodes in the table (no sync needed to size buffers)
+    bool table_dirty = false;   // table holds nodes
+
+    // strategy PARTITION buffers (gndt_partition.hpp)
+    struct Part {
+        uint64_t rec_cap = 0;      float4* recs = nullptr;
+        // two-level partition: level-1 regions, cursors of both levels, record ranges of the fine buckets
+        uint64_t rec1_cap = 0;     float4* recs1 = nullptr;
+        uint64_t cur_cap = 0;      uint32_t *cursors = nullptr, *range_lo = nullptr, *range_hi = nullptr, *range_cap = nullptr;
+        int two_level_failures = 0;   // builds whose regions overflowed although sized from the sample
+        bool two_level_ok = true;  // cleared when the regions a cloud needs are too large: exact path from then on
+        double fill1_ratio = 0.0;   // fullest level-1 region / mean seen on this handle (0 = unknown)
+        uint64_t hist_cap = 0;     uint32_t* hist = nullptr;
+        uint32_t bucket_cap = 0;   uint32_t* totals = nullptr; uint32_t* bucket_base = nullptr;
+        uint64_t stage_cap = 0;    StageRow* stage = nullptr;
+        uint32_t *ord_cf = nullptr, *ord_idx = nullptr, *inv = nullptr, *row_ncol = nullptr;
+        // column order (gndt_partition.hpp ColumnOrder): per bitmap word, and per point index for ncol_at
+        uint64_t words_init = 0;   // bitmap / word_weight words the table path's column order has initialised
+        uint64_t word_cap = 0;     uint32_t *bitmap = nullptr, *word_weight = nullptr, *word_base = nullptr, *bsum_words = nullptr,
+                                            *ncol_at = nullptr;
+        PartCounters* d_pc = nullptr;
+        PartCounters* h_pc = nullptr;   // pinned
+        unsigned long long* dbg = nullptr;  uint32_t dbg_buckets = 0;   // diagnostic phase stamps (GNDT_STAMPS=1)
+        uint32_t last_buckets = 0;
+        uint64_t nodes_learned = 0;   // node count of the last successful PARTITION build (+20 %)
+        int good_slots = 0; uint64_t good_est = 0, good_n = 0;   // table size / estimate that worked last time
+    } part;
+    // cost-map flood over the finished grid (gndt_cost.hpp)
+    struct Cost {
+        uint64_t node_cap = 0;     uint32_t *h_bits = nullptr, *pushed = nullptr, *state = nullptr, *f[2] = {nullptr, nullptr};
+        uint32_t ctab_size = 0;    uint64_t* ctab_key = nullptr; uint32_t* ctab_val = nullptr;
+        uint32_t* ring = nullptr;
+        uint32_t* nbr = nullptr;       // [4 * node_cap] neighbour columns of every row
+        CostCounters* d_cc = nullptr;
+        CostCounters* h_cc = nullptr;   // pinned
+        uint64_t serial = 0;            // result_serial the flood was computed for (0 = none)
+        int ring_n = 0;
+    } cost;
+    uint64_t result_serial = 0;         // bumped whenever a build / finalize produces new result rows
+    int last_strategy = GNDT_STRATEGY_ATOMIC;
+    bool map_in_table = true;   // false after a PARTITION build: the HBM node table does not hold the map
+
+    // optional phase timing (bench / profiling): events recorded on the launch stream
+    int prof = 0;               // 0 off, 1 every phase, 2 only the dominant phase of the strategy in use
+    // one event set per build in a ring, so that back-to-back (un-synchronised) builds can all be timed
+    static constexpr int kEvSets = 32;
+    hipEvent_t ev[kEvSets][GNDT_NUM_PHASES + 1] = {};
+    bool ev_recorded[kEvSets][GNDT_NUM_PHASES + 1] = {};
+    int ev_set = 0;
+
+    // A PARTITION build is launched without waiting for it; its overflow flags are looked at (and the build
+    // re-run with more room if they are set) by the next call that needs the result.
+    struct Pending {
+        bool active = false;
+        const void* xyz = nullptr; size_t n = 0, stride = 0;
+        hipStream_t s = nullptr;
+        int attempt = 0, bslots = 0;
+        uint64_t nodes_est = 0, stage_want = 0;
+        bool two_level = false;         // this attempt used the two-level partition
+        double mean1 = 0.0;             // its mean level-1 region fill (to turn the fullest region into a ratio)
+        bool stats_only = false;        // gndt_shard_stats_device: statistics out, no labels / ordering / rows
+        gndt::GridParams gp{};          // origin and grid parameters AS THEY WERE when the build was launched: a retry
+                                        // re-runs the same build even if the handle's origin has moved on since
+        uint32_t first_base = 0;        // global index of xyz[0] (shards of a global cloud)
+    } pending;
+
+    std::string err;
+};
+
+namespace gndt_host {
+using namespace gndt;
+
+// Diagnostic / tuning knobs from the environment, parsed ONCE per process (DESIGN.md "Diagnostic and tuning knobs").
+struct Tuning {
+    int bucket_load = 50;        // GNDT_BUCKET_LOAD    average LDS-table load (percent) that sizes the bucket count
+    int bucket_points = 0;       // GNDT_BUCKET_POINTS  points per bucket (0 = derived)
+    int bucket_threads = 512;    // GNDT_BUCKET_THREADS k_bucket_build2 variant
+    int bucket_slots = 0;        // GNDT_BUCKET_SLOTS   k_bucket_build2 variant (0 = 512, 1024 on retry)
+    int part_wgs = 256;          // GNDT_PART_WGS       workgroups of the exact counting partition
+    int two_level = -1;          // GNDT_TWO_LEVEL      0 = never use the two-level partition
+    int l1_rep = 1;              // GNDT_L1_REP         level-1 cursor replicas
+    uint32_t l1_wgs = 1024;      // GNDT_L1_WGS         persistent level-1 workgroups
+    uint32_t bucket_wgs = 0xFFFFFFFFu;   // GNDT_BUCKET_WGS   persistent bucket workgroups (default: one per bucket)
+    bool stamps = false;         // GNDT_STAMPS=1       in-kernel phase stamps of the bucket kernel
+    bool verbose = false;        // GNDT_VERBOSE=1      stderr line per resolved two-level build
+};
+const Tuning& tuning();
+void tuning_force_stamps(bool on);   // bench.py --stamps flips this after the timed run
+
+#define HIP_TRY(h, expr)                                                                                 \
+    do {                                                                                                 \
+        hipError_t e__ = (expr);                                                                         \
+        if (e__ != hipSuccess) {                                                                         \
+            (h)->err = std::string(#expr) + ": " + hipGetErrorString(e__);                               \
+            return GNDT_ERR_HIP;                                                                         \
+        }                                                                                                \
+    } while (0)
+
+inline void mark(gndt_handle* h, int i, hipStream_t s) {
+    if (!h->prof || !h->ev[h->ev_set][i]) return;
+    if (h->prof == 2) {   // k_bucket_build2 sits between marks 4 and 5, k_accumulate between 1 and 2
+        const int lo = h->last_strategy != GNDT_STRATEGY_ATOMIC ? 4 : 1;
+        if (i != lo && i != lo + 1) return;
+    }
+    (void)hipEventRecord(h->ev[h->ev_set][i], s);
+    h->ev_recorded[h->ev_set][i] = true;
+}
+
+// a new build / update starts: next event set of the ring
+inline void next_event_set(gndt_handle* h) {
+    if (!h->prof) return;
+    h->ev_set = (h->ev_set + 1) % gndt_handle::kEvSets;
+    for (auto& r : h->ev_recorded[h->ev_set]) r = false;
+}
+
+inline int grid_for(uint64_t work, int block = kBlock, int max_blocks = 256 * 8) {
+    uint64_t b = (work + block - 1) / block;
+    if (b < 1) b = 1;
+    if (b > (uint64_t)max_blocks) b = max_blocks;
+    return (int)b;
+}
+
+inline uint32_t pow2_ceil(uint64_t v) {
+    uint64_t p = 1024;
+    while (p < v && p < (1ull << 31)) p <<= 1;
+    return (uint32_t)p;
+}
+
+inline GridParams grid_params(const gndt_handle* h) {
+    GridParams g;
+    g.ox = h->origin[0]; g.oy = h->origin[1]; g.oz = h->origin[2];
+    g.grid_len = h->P.grid_len; g.z_len = h->P.z_len; g.slope_interval = h->P.slope_interval;
+    g.demand = h->P.demand; g.min_points = h->P.min_points;
+    return g;
+}
+
+// slots wanted for `nodes` occupied entries (load factor <= 1/2)
+inline uint32_t cap_for_nodes(uint64_t nodes) { return pow2_ceil(std::max<uint64_t>(2048, nodes * 2)); }
+
+inline hipStream_t stream_of(gndt_handle* h, void* hip_stream) { return hip_stream ? (hipStream_t)hip_stream : h->own_stream; }
+
+template <typename T>
+int grow_buf(gndt_handle* h, T*& p, uint64_t& cap, uint64_t want) {
+    if (want <= cap) return GNDT_OK;
+    if (p) (void)hipFree(p);
+    p = nullptr; cap = 0;
+    HIP_TRY(h, hipMalloc(&p, want * sizeof(T)));
+    cap = want;
+    return GNDT_OK;
+}
+
+// ---- gndt_api_core.hip: shared buffers ----
+int check_ready(gndt_handle* h);
+int use_stream(gndt_handle* h, hipStream_t s);     // work moves to stream s: it waits for what the handle's last stream still runs
+int ensure_out(gndt_handle* h, uint64_t n);
+int ensure_stats_buffers(gndt_handle* h, uint64_t n);
+int ensure_stage(gndt_handle* h, uint64_t nodes);
+int ensure_words(gndt_handle* h, uint64_t words);
+int ensure_part_counters(gndt_handle* h);
+int fetch_counters(gndt_handle* h, hipStream_t s);   // read the device counters (synchronises the stream)
+int stage_host_input(gndt_handle* h, const void* xyz_host, size_t n, size_t stride_bytes, hipStream_t s);
+void free_part(gndt_handle* h);
+// ---- gndt_api_table.hip ----
+void free_table(gndt_handle* h);
+int alloc_table(gndt_handle* h, uint32_t cap, hipStream_t s);
+int do_reset(gndt_handle* h, hipStream_t s);
+int build_atomic(gndt_handle* h, const void* xyz_dev, size_t n, size_t stride_bytes, hipStream_t s);
+// ---- gndt_api_build.hip ----
+int launch_order_and_emit(gndt_handle* h, uint64_t words, int m0, hipStream_t s);
+int partition_launch(gndt_handle* h, gndt_handle::Pending& P);
+int partition_resolve(gndt_handle* h);
+// ---- gndt_api_cost.hip ----
+void free_cost(gndt_handle* h);
+
+}  // namespace gndt_host

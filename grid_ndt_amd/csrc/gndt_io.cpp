@@ -11,6 +11,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/stat.h>
 
 #include <sstream>
 #include <string>
@@ -97,24 +98,45 @@ int gndt_pcd_read(const char* path, gndt_pcd* out, char err[256]) {
     if (counts.empty()) counts.assign(fields.size(), 1);
     if (types.empty()) types.assign(fields.size(), "F");
     if (counts.size() != fields.size() || types.size() != fields.size()) return fail("TYPE / COUNT inconsistent with FIELDS");
-    if (!have_points) points = width * height;
-    uint32_t step = 0, off[3] = {0, 0, 0}, col[3] = {0, 0, 0};
+    // Every size below comes from the header: nothing is multiplied, allocated or copied before it has been bounded
+    // (a crafted POINTS / WIDTH x HEIGHT / SIZE x COUNT must not wrap 64 bits or outrun the file).
+    constexpr uint64_t kMaxPoints = 0xFFFFFFFEull;          // the build path indexes points with 32 bits
+    constexpr uint64_t kMaxStep = 1u << 20;                  // a single record beyond 1 MiB is not a point cloud
+    if (!have_points) {
+        if (height && width > kMaxPoints / height) return fail("WIDTH x HEIGHT exceeds the 32-bit point index");
+        points = width * height;
+    }
+    if (points == 0) return fail("POINTS is zero");
+    if (points > kMaxPoints) return fail("POINTS exceeds the 32-bit point index of the build path");
+    uint64_t step64 = 0, column64 = 0;
+    uint32_t off[3] = {0, 0, 0}, col[3] = {0, 0, 0};
     bool found[3] = {false, false, false};
-    uint32_t column = 0;
     for (size_t i = 0; i < fields.size(); ++i) {
+        if (sizes[i] == 0 || sizes[i] > 8 || counts[i] > kMaxStep) return fail("SIZE must be 1..8 and COUNT reasonable");
         for (int a = 0; a < 3; ++a)
             if (fields[i] == std::string(1, "xyz"[a])) {
-                if (sizes[i] != 4 || types[i] != "F") return fail("x/y/z must be 4-byte floats (pcl::PointXYZ)");
-                off[a] = step; col[a] = column; found[a] = true;
+                if (sizes[i] != 4 || types[i] != "F" || counts[i] != 1) return fail("x/y/z must be single 4-byte floats (pcl::PointXYZ)");
+                off[a] = (uint32_t)step64; col[a] = (uint32_t)column64; found[a] = true;
             }
-        step += sizes[i] * counts[i];
-        column += counts[i];
+        step64 += (uint64_t)sizes[i] * counts[i];
+        column64 += counts[i];
+        if (step64 > kMaxStep) return fail("record size (sum of SIZE x COUNT) is implausibly large");
     }
     if (!found[0] || !found[1] || !found[2]) return fail("no x, y, z fields");
+    const uint32_t step = (uint32_t)step64, column = (uint32_t)column64;
+    // what is left of the file bounds every payload (binary: exactly; ascii: at least 2 bytes per value and line)
+    uint64_t remaining = 0;
+    {
+        struct stat st;
+        const long here = ftell(f);
+        if (here < 0 || fstat(fileno(f), &st) != 0 || st.st_size < here) return fail("cannot size the file");
+        remaining = (uint64_t)st.st_size - (uint64_t)here;
+    }
     out->num_points = points;
     if (data_kind == "binary") {
         out->data_kind = 1;
         out->layout.point_step = step; out->layout.offset_x = off[0]; out->layout.offset_y = off[1]; out->layout.offset_z = off[2];
+        if (points > remaining / step) return fail("payload shorter than POINTS * record size");
         const size_t bytes = (size_t)points * step;
         out->data = malloc(bytes ? bytes : 1);
         if (!out->data) return fail("out of memory");
@@ -122,7 +144,8 @@ int gndt_pcd_read(const char* path, gndt_pcd* out, char err[256]) {
     } else if (data_kind == "ascii") {
         out->data_kind = 0;
         out->layout.point_step = 12; out->layout.offset_x = 0; out->layout.offset_y = 4; out->layout.offset_z = 8;
-        float* xyz = (float*)malloc(points ? points * 12 : 1);
+        if (points > remaining / 2) return fail("fewer lines than POINTS");       // a data line takes at least "0\n"
+        float* xyz = (float*)malloc((size_t)points * 12);
         if (!xyz) return fail("out of memory");
         out->data = xyz;
         std::string line;
@@ -146,7 +169,8 @@ int gndt_pcd_read(const char* path, gndt_pcd* out, char err[256]) {
         uint32_t sizes2[2];
         if (fread(sizes2, 4, 2, f) != 2) return fail("binary_compressed: missing size words");
         const size_t csize = sizes2[0], usize = sizes2[1];
-        if (usize != (size_t)points * step) return fail("binary_compressed: uncompressed size is not POINTS * record size");
+        if (points > 0xFFFFFFFFull / step || usize != (size_t)points * step) return fail("binary_compressed: uncompressed size is not POINTS * record size");
+        if (csize > remaining - 8) return fail("binary_compressed: payload shorter than its size word");
         std::vector<unsigned char> comp(csize ? csize : 1), soa(usize ? usize : 1);
         if (fread(comp.data(), 1, csize, f) != csize) return fail("binary_compressed: payload shorter than its size word");
         if (usize && lzf_decompress(comp.data(), csize, soa.data(), usize) != usize) return fail("binary_compressed: malformed LZF stream");

@@ -141,7 +141,7 @@ __device__ __forceinline__ double wave_sum(double v) {
 // ---------------------------------------------------------------------------------------------
 // k_clear_all: whole-table initialisation (once at create / after growth)
 // ---------------------------------------------------------------------------------------------
-__global__ void k_clear_all(uint64_t* keys, NodeAcc* acc, uint64_t* col_keys, uint32_t* col_first, uint32_t* col_cnt,
+static __global__ void k_clear_all(uint64_t* keys, NodeAcc* acc, uint64_t* col_keys, uint32_t* col_first, uint32_t* col_cnt,
                             uint32_t* col_head, uint32_t* touch_epoch, uint32_t* col_epoch, uint32_t cap) {
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < cap; i += gridDim.x * blockDim.x) {
         keys[i] = kEmptyKey;
@@ -160,7 +160,7 @@ __global__ void k_clear_all(uint64_t* keys, NodeAcc* acc, uint64_t* col_keys, ui
 
 // k_clear_used: empty the map by visiting only its occupied slots (O(C), not O(cap)).  Nodes that went through a
 // finalize (i < prev_nodes) also own a column-table entry.
-__global__ void k_clear_used(uint64_t* keys, NodeAcc* acc, uint64_t* col_keys, uint32_t* col_first, uint32_t* col_cnt,
+static __global__ void k_clear_used(uint64_t* keys, NodeAcc* acc, uint64_t* col_keys, uint32_t* col_first, uint32_t* col_cnt,
                              uint32_t* col_head, const uint32_t* node_slot, const uint32_t* col_slot_of_node,
                              const Counters* cur) {
     const uint32_t n = cur->num_nodes, np = cur->prev_nodes;
@@ -182,7 +182,7 @@ __global__ void k_clear_used(uint64_t* keys, NodeAcc* acc, uint64_t* col_keys, u
 }
 
 // all counters to zero (after the clear that read them)
-__global__ void k_zero_counters(Counters* c) {
+static __global__ void k_zero_counters(Counters* c) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         c->num_nodes = 0; c->num_columns = 0; c->num_slopes = 0; c->err_key_range = 0; c->err_table_full = 0;
         c->stream_pos = 0; c->prev_nodes = 0; c->n_touched = 0; c->n_tcols = 0; c->n_work = 0;
@@ -272,19 +272,19 @@ __global__ void __launch_bounds__(kBlock) k_accumulate(const float* __restrict__
 }
 
 // after an incremental accumulate: advance the device-side stream position
-__global__ void k_advance_stream(Counters* c, uint32_t n) {
+static __global__ void k_advance_stream(Counters* c, uint32_t n) {
     if (threadIdx.x == 0 && blockIdx.x == 0) c->stream_pos += n;
 }
 
 // after an accumulate with a caller-given base: the stream position is at least `v`
-__global__ void k_raise_stream(Counters* c, uint32_t v) {
+static __global__ void k_raise_stream(Counters* c, uint32_t v) {
     if (threadIdx.x == 0 && blockIdx.x == 0) c->stream_pos = max(c->stream_pos, v);
 }
 
 // ---------------------------------------------------------------------------------------------
 // statistics exchange helpers (table growth, multi-GPU): compact export and additive merge
 // ---------------------------------------------------------------------------------------------
-__global__ void k_stats_export(const uint64_t* __restrict__ keys, const NodeAcc* __restrict__ acc,
+static __global__ void k_stats_export(const uint64_t* __restrict__ keys, const NodeAcc* __restrict__ acc,
                                const uint32_t* __restrict__ node_slot, const Counters* __restrict__ cnt,
                                uint64_t* __restrict__ okey, double* __restrict__ osums, uint32_t* __restrict__ ocount,
                                uint32_t* __restrict__ ofirst) {
@@ -299,7 +299,7 @@ __global__ void k_stats_export(const uint64_t* __restrict__ keys, const NodeAcc*
     }
 }
 
-__global__ void __launch_bounds__(kBlock) k_stats_merge(uint64_t* __restrict__ keys, NodeAcc* __restrict__ acc, uint32_t cap_mask,
+static __global__ void __launch_bounds__(kBlock) k_stats_merge(uint64_t* __restrict__ keys, NodeAcc* __restrict__ acc, uint32_t cap_mask,
                                                         uint32_t* __restrict__ node_slot, uint32_t* __restrict__ index_of_slot,
                                                         const uint64_t* __restrict__ ikey,
                                                         const double* __restrict__ isums, const uint32_t* __restrict__ icount,

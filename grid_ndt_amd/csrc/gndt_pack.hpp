@@ -23,7 +23,7 @@ __device__ __forceinline__ float load_field(const unsigned char* rec, uint32_t o
 }
 
 // grid covers n rounded up to whole waves
-__global__ void __launch_bounds__(256) k_pack_flags(const unsigned char* __restrict__ raw, uint64_t n, PointLayout L,
+static __global__ void __launch_bounds__(256) k_pack_flags(const unsigned char* __restrict__ raw, uint64_t n, PointLayout L,
                                                     unsigned long long* __restrict__ valid_bits) {
     const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
@@ -41,7 +41,7 @@ __global__ void __launch_bounds__(256) k_pack_flags(const unsigned char* __restr
 }
 
 // word_prefix: exclusive popcount prefix over the 32-bit words of valid_bits
-__global__ void __launch_bounds__(256) k_pack_write(const unsigned char* __restrict__ raw, uint64_t n, PointLayout L,
+static __global__ void __launch_bounds__(256) k_pack_write(const unsigned char* __restrict__ raw, uint64_t n, PointLayout L,
                                                     const uint32_t* __restrict__ valid_words,
                                                     const uint32_t* __restrict__ word_prefix, float* __restrict__ xyz_out,
                                                     uint32_t* __restrict__ n_valid) {

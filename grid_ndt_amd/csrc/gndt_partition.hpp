@@ -115,7 +115,7 @@ __device__ __forceinline__ void wg_range(uint64_t n, uint32_t nwg, uint32_t w, u
 }
 
 // one launch that prepares a build: counters, partition flags and the column-first bitmap
-__global__ void __launch_bounds__(256) k_part_clear(Counters* __restrict__ cnt, PartCounters* __restrict__ pc,
+static __global__ void __launch_bounds__(256) k_part_clear(Counters* __restrict__ cnt, PartCounters* __restrict__ pc,
                                                     uint32_t* __restrict__ bitmap, uint32_t* __restrict__ word_weight,
                                                     uint64_t words, uint32_t* __restrict__ cursors, uint32_t n_cursors) {
     if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -161,7 +161,7 @@ __global__ void __launch_bounds__(kPartThreads) k_part_hist(const float* __restr
 // pass 1b: for every bucket, exclusive scan of its counts over the workgroups (in place) and the
 // bucket total.  Block = 32 buckets x 8 workgroup segments.
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_part_offsets(uint32_t* __restrict__ hist, uint32_t* __restrict__ totals,
+static __global__ void __launch_bounds__(256) k_part_offsets(uint32_t* __restrict__ hist, uint32_t* __restrict__ totals,
                                                       uint32_t B, uint32_t nwg) {
     __shared__ uint32_t seg[8][32];
     const uint32_t bx = threadIdx.x & 31, wy = threadIdx.x >> 5;
@@ -411,7 +411,7 @@ __global__ void __launch_bounds__(kTileThreads) k_part2_level1(const float* __re
 // has c/64 +- sqrt(c/64) votes; it overflows if c > 2 x 64 x votes + 2048, which for c = 2000..5000 is 6 sigma or more away
 // and never happens below 2048: with 50 000 buckets, 1.6x + 1024 still overflowed a handful per build.)  LiDAR clouds' hot
 // columns simply get the room they need.  base = exclusive prefix.  One workgroup; writes lo[] (= base) and cap[].
-__global__ void __launch_bounds__(1024) k_part2_layout(const uint32_t* __restrict__ est2, uint32_t B, uint32_t* __restrict__ lo,
+static __global__ void __launch_bounds__(1024) k_part2_layout(const uint32_t* __restrict__ est2, uint32_t B, uint32_t* __restrict__ lo,
                                                        uint32_t* __restrict__ cap, uint64_t rec_capacity,
                                                        PartCounters* __restrict__ pc) {
     __shared__ uint32_t wsum[16];
@@ -469,7 +469,7 @@ __global__ void __launch_bounds__(kTileThreads) k_part2_level2(const float4* __r
 }
 
 // the fine buckets' record ranges for the bucket kernel (lo[] is the layout's base), and the fullest level-1 region
-__global__ void __launch_bounds__(256) k_part2_ranges(const uint32_t* __restrict__ cursor1, uint32_t V,
+static __global__ void __launch_bounds__(256) k_part2_ranges(const uint32_t* __restrict__ cursor1, uint32_t V,
                                                       const uint32_t* __restrict__ cursor2, const uint32_t* __restrict__ cap,
                                                       uint32_t B, const uint32_t* __restrict__ lo, uint32_t* __restrict__ hi,
                                                       PartCounters* __restrict__ pc) {
@@ -599,7 +599,7 @@ __global__ void __launch_bounds__(kScanThreads) k_scan_apply(const uint32_t* __r
 // ordering
 // ---------------------------------------------------------------------------------------------
 // destination row of every staged node (see ColumnOrder), as the inverse permutation the emit kernel gathers by
-__global__ void __launch_bounds__(kBlock) k_order_dest(const uint32_t* __restrict__ ord_cf, const uint32_t* __restrict__ ord_idx,
+static __global__ void __launch_bounds__(kBlock) k_order_dest(const uint32_t* __restrict__ ord_cf, const uint32_t* __restrict__ ord_idx,
                                                        const uint32_t* __restrict__ bitmap, const uint32_t* __restrict__ word_base,
                                                        const uint32_t* __restrict__ ncol_at, uint32_t* __restrict__ inv,
                                                        const Counters* __restrict__ cnt, const PartCounters* __restrict__ pc) {
@@ -616,7 +616,7 @@ __global__ void __launch_bounds__(kBlock) k_order_dest(const uint32_t* __restric
 }
 
 // staging rows -> SoA result rows in reference order
-__global__ void __launch_bounds__(kBlock) k_emit_rows(const StageRow* __restrict__ stage, const uint32_t* __restrict__ inv,
+static __global__ void __launch_bounds__(kBlock) k_emit_rows(const StageRow* __restrict__ stage, const uint32_t* __restrict__ inv,
                                                       OutView out, uint32_t* __restrict__ row_ncol,
                                                       const Counters* __restrict__ cnt, const PartCounters* __restrict__ pc) {
     if (pc->lds_overflow | pc->stage_overflow | pc->index_overflow | pc->part_overflow) return;

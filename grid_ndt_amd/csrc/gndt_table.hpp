@@ -94,7 +94,7 @@ __device__ __forceinline__ void tab_make_row(const TableView& T, const GridParam
     for (int k = 0; k < 8; ++k) row.pad[k] = 0;
 }
 
-__global__ void __launch_bounds__(kBlock) k_tab_begin(TableView T, Counters* __restrict__ cnt, PartCounters* __restrict__ pc,
+static __global__ void __launch_bounds__(kBlock) k_tab_begin(TableView T, Counters* __restrict__ cnt, PartCounters* __restrict__ pc,
                                                       uint32_t* __restrict__ bitmap, uint32_t* __restrict__ word_weight,
                                                       uint64_t words) {
     const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, gsz = (uint64_t)gridDim.x * blockDim.x;
@@ -108,7 +108,7 @@ __global__ void __launch_bounds__(kBlock) k_tab_begin(TableView T, Counters* __r
     }
 }
 
-__global__ void __launch_bounds__(kBlock) k_tab_columns(TableView T, GridParams P, const Counters* __restrict__ cnt) {
+static __global__ void __launch_bounds__(kBlock) k_tab_columns(TableView T, GridParams P, const Counters* __restrict__ cnt) {
     const uint32_t n = cnt->num_nodes;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const uint32_t s = T.node_slot[i];
@@ -128,7 +128,7 @@ __global__ void __launch_bounds__(kBlock) k_tab_columns(TableView T, GridParams 
     }
 }
 
-__global__ void __launch_bounds__(kBlock) k_tab_rows(TableView T, GridParams P, StageRow* __restrict__ stage, uint32_t stage_cap,
+static __global__ void __launch_bounds__(kBlock) k_tab_rows(TableView T, GridParams P, StageRow* __restrict__ stage, uint32_t stage_cap,
                                                      uint32_t* __restrict__ ord_cf, uint32_t* __restrict__ ord_idx,
                                                      ColumnOrder O, uint64_t words, Counters* __restrict__ cnt,
                                                      PartCounters* __restrict__ pc) {
@@ -162,7 +162,7 @@ __global__ void __launch_bounds__(kBlock) k_tab_rows(TableView T, GridParams P, 
     }
 }
 
-__global__ void k_tab_end(Counters* cnt) {
+static __global__ void k_tab_end(Counters* cnt) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         cnt->prev_nodes = cnt->num_nodes;
         cnt->n_touched = 0; cnt->n_tcols = 0; cnt->n_work = 0;
@@ -171,7 +171,7 @@ __global__ void k_tab_end(Counters* cnt) {
 }
 
 // Incremental finalisation, step 1: the nodes the frame touched.
-__global__ void __launch_bounds__(kBlock) k_tab_touch(TableView T, GridParams P, Counters* __restrict__ cnt,
+static __global__ void __launch_bounds__(kBlock) k_tab_touch(TableView T, GridParams P, Counters* __restrict__ cnt,
                                                       PartCounters* __restrict__ pc) {
     const uint32_t n = cnt->n_touched, np = cnt->prev_nodes, epoch = cnt->epoch;
     // (stage_overflow and index_overflow stay set once raised: an incremental finalisation builds on the rows and the
@@ -215,7 +215,7 @@ __global__ void __launch_bounds__(kBlock) k_tab_touch(TableView T, GridParams P,
 
 // Incremental finalisation, step 2: the nodes of the touched columns, as a flat work list (it reuses touched[], which
 // step 1 has consumed).  A wave adds up its columns' node counts and reserves the space with one atomic.
-__global__ void __launch_bounds__(kBlock) k_tab_expand(TableView T, Counters* __restrict__ cnt) {
+static __global__ void __launch_bounds__(kBlock) k_tab_expand(TableView T, Counters* __restrict__ cnt) {
     const uint32_t nc = cnt->n_tcols;
     const uint32_t nc_round = (nc + 63u) & ~63u;
     for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < nc_round; c += gridDim.x * blockDim.x) {
@@ -235,7 +235,7 @@ __global__ void __launch_bounds__(kBlock) k_tab_expand(TableView T, Counters* __
 
 // Incremental finalisation, step 3: a fresh staging row for every listed node; the first node of a column also updates
 // the column's place in the order by what the column gained.
-__global__ void __launch_bounds__(kBlock) k_tab_rows_touched(TableView T, GridParams P, StageRow* __restrict__ stage,
+static __global__ void __launch_bounds__(kBlock) k_tab_rows_touched(TableView T, GridParams P, StageRow* __restrict__ stage,
                                                              uint32_t stage_cap, uint32_t* __restrict__ ord_cf,
                                                              uint32_t* __restrict__ ord_idx, ColumnOrder O, uint64_t words,
                                                              Counters* __restrict__ cnt, PartCounters* __restrict__ pc) {
@@ -281,7 +281,7 @@ __global__ void __launch_bounds__(kBlock) k_tab_rows_touched(TableView T, GridPa
 // adjacent) -> staging rows, without any table: the column of node i is the run of equal column keys around
 // it; label, index in column and the column's first-seen index come from one walk over that run.
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(kBlock) k_stats_rows(const uint64_t* __restrict__ key, const double* __restrict__ sums,
+static __global__ void __launch_bounds__(kBlock) k_stats_rows(const uint64_t* __restrict__ key, const double* __restrict__ sums,
                                                        const uint32_t* __restrict__ count, const uint32_t* __restrict__ first,
                                                        uint32_t n, GridParams P, StageRow* __restrict__ stage,
                                                        uint32_t* __restrict__ ord_cf, uint32_t* __restrict__ ord_idx,

@@ -283,6 +283,9 @@ class TwoDmap:
         names = self.PHASES[self.last_strategy()]
         return {k: arr[i] for i, k in enumerate(names)}
 
+    def enable_stamps(self, on=True):
+        self._L.gndt_debug_enable_stamps(int(bool(on)))
+
     def debug_bucket_phases(self):
         """Mean shader cycles per bucket of k_bucket_build's phases (needs GNDT_STAMPS=1 in the environment)."""
         arr = (C.c_double * 10)()

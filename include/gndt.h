@@ -269,6 +269,8 @@ int gndt_last_strategy(const gndt_handle* h);
  * [0] clear [1] accumulate [2] columns [3] labels [4] order [5] emit, then the accumulate phase split into
  * [6] load wait [7] classify [8] scan+scatter [9] reduce (first chunk), and the bucket count. */
 int gndt_debug_bucket_phases(gndt_handle* h, double cycles_out[10], uint32_t* buckets_out);
+/* Switch the stamps on or off for the builds that follow (the environment is only read once per process). */
+int gndt_debug_enable_stamps(int on);
 
 /* Library / device information for logs: returns 0 and fills what it can. */
 int gndt_device_info(int32_t device_id, char name_out[128], int32_t* compute_units, uint64_t* hbm_bytes);

@@ -144,6 +144,41 @@ def test_pcd_reader_binary_and_ascii(tmp_path, native_lib):
         g.read_pcd(p)
 
 
+def test_pcd_reader_rejects_headers_whose_sizes_wrap_or_outrun_the_file(tmp_path, native_lib):
+    """A crafted header must not wrap POINTS * record size or make the reader write past its allocation."""
+    import grid_ndt_amd as g
+    xyz = np.arange(12, dtype=np.float32).reshape(4, 3)
+    cases = {
+        # POINTS * 12 == 2^64 + 8: malloc(8) then 12-byte writes (the round-1 finding)
+        "wrap_ascii": dict(n=1537228672809129302, kind="ascii", rows=["1 2 3"]),
+        "wrap_binary": dict(n=1537228672809129302, kind="binary"),
+        "beyond_u32": dict(n=0xFFFFFFFF, kind="binary"),
+        "more_points_than_bytes": dict(n=1000, kind="binary"),
+        "more_points_than_lines": dict(n=1000, kind="ascii", rows=["1 2 3", "4 5 6"]),
+        "zero_points": dict(n=0, kind="binary"),
+    }
+    for name, c in cases.items():
+        p = str(tmp_path / (name + ".pcd"))
+        _write_pcd(p, ["x", "y", "z"], [4, 4, 4], ["F", "F", "F"], [1, 1, 1], xyz.tobytes(), c["n"], c["kind"], ascii_rows=c.get("rows"))
+        with pytest.raises(g.GndtError):
+            g.read_pcd(p)
+    # WIDTH x HEIGHT wrapping without a POINTS line, and SIZE x COUNT wrapping the record size
+    p = str(tmp_path / "wh.pcd")
+    _write_pcd(p, ["x", "y", "z"], [4, 4, 4], ["F", "F", "F"], [1, 1, 1], xyz.tobytes(), 4, "binary", width=1 << 40, height=1 << 40, with_points=False)
+    with pytest.raises(g.GndtError):
+        g.read_pcd(p)
+    p = str(tmp_path / "step.pcd")
+    _write_pcd(p, ["x", "y", "z", "blob"], [4, 4, 4, 4], ["F", "F", "F", "U"], [1, 1, 1, 0x40000000], xyz.tobytes(), 4, "binary")
+    with pytest.raises(g.GndtError):
+        g.read_pcd(p)
+    # compressed: an uncompressed-size word that does not match, a compressed size beyond the file
+    for name, words in (("usize", [8, 999]), ("csize", [1 << 30, 48])):
+        p = str(tmp_path / (name + ".pcd"))
+        _write_pcd(p, ["x", "y", "z"], [4, 4, 4], ["F", "F", "F"], [1, 1, 1], np.array(words, "<u4").tobytes() + b"\x00" * 8, 4, "binary_compressed")
+        with pytest.raises(g.GndtError):
+            g.read_pcd(p)
+
+
 @pytest.mark.gpu
 def test_pack_points_strips_nan_rows_and_keeps_order():
     import torch
