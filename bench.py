@@ -380,9 +380,8 @@ def main():
             m.enable_stamps(True)
             m.create2DMap("slope", pts, stream)
             cyc, nb = m.debug_bucket_phases()
-            tot = sum(list(cyc.values())[:6])
             print("bucket kernel phase stamps (mean shader cycles per bucket, %d buckets): " % nb +
-                  ", ".join(f"{k}={v:.0f} ({100 * v / tot:.0f}%)" for k, v in cyc.items()), file=sys.stderr)
+                  ", ".join(f"{k}={v:.0f}" for k, v in cyc.items() if k != "-"), file=sys.stderr)
         print(json.dumps(out))
     if use_dist:
         dist.destroy_process_group()

@@ -1,10 +1,12 @@
 // gndt_api_build.hip — strategy PARTITION (gndt_partition.hpp, gndt_bucket.hpp): launch, pending-build resolution, gndt_build*.
 #include "gndt_handle.hpp"
-#include "gndt_bucket.hpp"
+#include "gndt_bucket4.hpp"
 using namespace gndt;
 using namespace gndt_host;
 
 namespace gndt_host {
+
+constexpr int kOwnerChunk = 2560;       // records per chunk of k_bucket_owner (40 KB of LDS)
 
 // prefix of the per-word column weights -> row of every staged node -> SoA rows (marks m0+1 .. m0+5)
 int launch_order_and_emit(gndt_handle* h, uint64_t words, int m0, hipStream_t s) {
@@ -42,8 +44,12 @@ namespace {
 uint64_t buckets_for(uint64_t n, uint64_t nodes, int slots) {
     const int load_pct = tuning().bucket_load, pts_target = tuning().bucket_points;
     if (pts_target) return std::max<uint64_t>(n / (uint64_t)pts_target, 16);
-    const uint64_t per_bucket = slots >= 1024 ? 6400 : 2800;
-    const uint64_t want = std::max<uint64_t>(n / per_bucket, (nodes * 100) / ((uint64_t)slots * load_pct));
+    // k_bucket_owner takes a bucket in ONE chunk of kOwnerChunk records when it can: mean 1600 leaves 3 sigma of the
+    // column-granular spread of a hash partition (a fuller bucket simply takes a second chunk)
+    const uint64_t per_bucket = slots >= 1024 ? 6400 : (tuning().bucket_kernel == 4 ? (slots == 256 ? 800 : 1600) : 2800);
+    // (k_bucket_owner: two lanes own a node, so a 512-thread workgroup holds 256 nodes: average load 1/4 of that table)
+    const uint64_t node_room = (slots < 1024 && tuning().bucket_kernel == 4) ? (uint64_t)slots * load_pct * 2 / 3 : (uint64_t)slots * load_pct;
+    const uint64_t want = std::max<uint64_t>(n / per_bucket, (nodes * 100) / node_room);
     return std::max<uint64_t>(want, 16);
 }
 constexpr uint64_t kMaxBuckets = 32768;   // 4-byte LDS cursor per bucket in the partition passes
@@ -59,7 +65,7 @@ int partition_launch(gndt_handle* h, gndt_handle::Pending& P) {
     const int attempt = P.attempt;
     uint64_t& nodes_est = P.nodes_est;
     uint64_t& stage_want = P.stage_want;
-    const int bt = tuning().bucket_threads, env_slots = tuning().bucket_slots, part_wgs = tuning().part_wgs;
+    const int env_slots = tuning().bucket_slots, part_wgs = tuning().part_wgs;
     const uint32_t nwg = (uint32_t)std::min<uint64_t>((uint64_t)part_wgs, std::max<uint64_t>(1, n / 8192));
     const uint64_t words = (n + 31) / 32 + 1;
     int rc;
@@ -224,19 +230,35 @@ int partition_launch(gndt_handle* h, gndt_handle::Pending& P) {
     // one workgroup per bucket by default: persistent workgroups (GNDT_BUCKET_WGS=512) measured 8 % slower, the
     // hardware's dynamic workgroup scheduling balances uneven buckets better than a static stride
     const uint32_t bucket_wgs = tuning().bucket_wgs;
-    {
+    const dim3 bgrid(std::min<uint32_t>(B, bucket_wgs));
+    const ColumnOrder order{q.bitmap, q.word_weight, q.ncol_at};
+    const StatsOut stats_out{h->st_key, h->st_sums, h->st_count, h->st_first};
+    unsigned long long* dbg = tuning().stamps ? q.dbg : nullptr;
+    if (tuning().bucket_kernel == 4 && bslots != 1024) {
+        // k_bucket_owner (gndt_bucket4.hpp): nodes owned by threads, statistics in registers
+#define GNDT_LAUNCH_OWNER(T_, CH_, S_)                                                                                              \
+    hipLaunchKernelGGL((k_bucket_owner<T_, T_, CH_, S_>), bgrid, dim3(T_), 0, s, bucket_recs, range_lo, range_hi, B, gp, q.stage,  \
+                       (uint32_t)(S_ ? h->st_cap : q.stage_cap), q.ord_cf, q.ord_idx, order, h->d_cnt, q.d_pc, dbg, stats_out)
+        if (bslots == 256) { if (P.stats_only) GNDT_LAUNCH_OWNER(256, 1280, true); else GNDT_LAUNCH_OWNER(256, 1280, false); }
+        else { if (P.stats_only) GNDT_LAUNCH_OWNER(512, kOwnerChunk, true); else GNDT_LAUNCH_OWNER(512, kOwnerChunk, false); }
+#undef GNDT_LAUNCH_OWNER
+    } else if (tuning().bucket_kernel != 2) {
+        // k_bucket_direct (gndt_bucket3.hpp): 512-slot tables with three workgroups per CU, 1024-slot tables on a retry
+#define GNDT_LAUNCH_DIRECT(T_, H_, S_)                                                                                          \
+    hipLaunchKernelGGL((k_bucket_direct<T_, H_, S_>), bgrid, dim3(T_), 0, s, bucket_recs, range_lo, range_hi, B, gp, q.stage,    \
+                       (uint32_t)(S_ ? h->st_cap : q.stage_cap), q.ord_cf, q.ord_idx, order, h->d_cnt, q.d_pc, dbg, stats_out)
+        if (bslots == 1024) { if (P.stats_only) GNDT_LAUNCH_DIRECT(1024, 1024, true); else GNDT_LAUNCH_DIRECT(1024, 1024, false); }
+        else { if (P.stats_only) GNDT_LAUNCH_DIRECT(512, 512, true); else GNDT_LAUNCH_DIRECT(512, 512, false); }
+#undef GNDT_LAUNCH_DIRECT
+    } else {
 #define GNDT_LAUNCH_BUCKET2(T_, H_, CH_, S_)                                                                           \
-    hipLaunchKernelGGL((k_bucket_build2<T_, H_, CH_, S_>), dim3(std::min<uint32_t>(B, bucket_wgs)), dim3(T_), 0, s, bucket_recs, range_lo, range_hi, B, gp, q.stage, \
-                       (uint32_t)(S_ ? h->st_cap : q.stage_cap), q.ord_cf, q.ord_idx, ColumnOrder{q.bitmap, q.word_weight, q.ncol_at}, h->d_cnt,   \
-                       q.d_pc, tuning().stamps ? q.dbg : nullptr, StatsOut{h->st_key, h->st_sums, h->st_count, h->st_first})
+    hipLaunchKernelGGL((k_bucket_build2<T_, H_, CH_, S_>), bgrid, dim3(T_), 0, s, bucket_recs, range_lo, range_hi, B, gp, q.stage, \
+                       (uint32_t)(S_ ? h->st_cap : q.stage_cap), q.ord_cf, q.ord_idx, order, h->d_cnt, q.d_pc, dbg, stats_out)
             if (P.stats_only) {
                 if (bslots == 1024) GNDT_LAUNCH_BUCKET2(512, 1024, 3584, true);
                 else GNDT_LAUNCH_BUCKET2(512, 512, 1536, true);
             }
-            else if (bslots == 1024 && bt == 1024) GNDT_LAUNCH_BUCKET2(1024, 1024, 3072, false);
             else if (bslots == 1024) GNDT_LAUNCH_BUCKET2(512, 1024, 3584, false);
-            else if (bslots == 512 && bt == 256) GNDT_LAUNCH_BUCKET2(256, 512, 1792, false);
-            else if (bslots == 256) GNDT_LAUNCH_BUCKET2(256, 256, 1024, false);
             else GNDT_LAUNCH_BUCKET2(512, 512, 1536, false);
 #undef GNDT_LAUNCH_BUCKET2
     }
@@ -378,7 +400,7 @@ int gndt_debug_bucket_phases(gndt_handle* h, double cycles_out[10], uint32_t* bu
     for (int k = 0; k < 10; ++k) cycles_out[k] = 0.0;
     for (uint32_t b = 0; b < q.last_buckets; ++b) {
         const unsigned long long* s = &t[(size_t)b * 16];
-        for (int k = 0; k < 6; ++k) cycles_out[k] += (double)(s[k + 1] - s[k]);
+        for (int k = 0; k < 6; ++k) if (s[k + 1] > s[k]) cycles_out[k] += (double)(s[k + 1] - s[k]);   // (a kernel stamps only the boundaries it has)
         // sub-phases of the accumulate phase, summed over the bucket's chunks: load wait, classify, scan+scatter, reduce
         for (int k = 0; k < 4; ++k) cycles_out[6 + k] += (double)s[8 + k];
     }

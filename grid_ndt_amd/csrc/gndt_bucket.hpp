@@ -133,9 +133,11 @@ __device__ __forceinline__ void bucket_build_one(BucketLds2<H, CH>& L, const uin
         // all first probes (plain LDS loads), then the rare slow paths, then all arrival-rank atomics.
         uint64_t pkey[PER];
         uint32_t ph[PER];
+        bool kok[PER];
 #pragma unroll
         for (int j = 0; j < PER; ++j) {
-            const PointKey k = point_key(rec[j].x, rec[j].y, rec[j].z, P.ox, P.oy, P.oz, P.grid_len, P.z_len);
+            const PointKey k = point_key_fast(rec[j].x, rec[j].y, rec[j].z, P.ox, P.oy, P.oz, P.grid_len, P.z_len, P.inv_grid, P.inv_z);
+            kok[j] = k.ok;                       // (x, y were range-checked by the partition; z is checked here)
             pkey[j] = pack_key(k.sx, k.sy, k.sz);
             ph[j] = node_slot_hash(column_hash(k.sx, k.sy), k.sz) & (uint32_t)(H - 1);
         }
@@ -146,7 +148,8 @@ __device__ __forceinline__ void bucket_build_one(BucketLds2<H, CH>& L, const uin
         for (int j = 0; j < PER; ++j) {
             const uint32_t off = (uint32_t)j * T + tid;
             tag[j] = 0xFFFFFFFFu;
-            if (off < nchunk) {
+            if (off < nchunk && !kok[j]) atomicAdd(&cnt->err_key_range, 1u);
+            if (off < nchunk && kok[j]) {
                 uint32_t s = ph[j];
                 if (k0[j] != pkey[j]) s = lds_find_or_insert<H>(L.key, ph[j], pkey[j], &L.n_nodes);
                 if (s >= (uint32_t)H) L.overflow = 1;
@@ -358,7 +361,6 @@ __device__ __forceinline__ void bucket_build_one(BucketLds2<H, CH>& L, const uin
             node_moments(row.count, sums, c, row.mean, row.scatter);
         }
         row.col_first = cf; row.idx_in_col = idx_in_col; row.ncol = L.u.fin.ccnt[cs];
-        for (int k = 0; k < 8; ++k) row.pad[k] = 0;
         const uint32_t dst = base0 + atomicAdd(&L.n_rows, 1u);
         stage[dst] = row;
         ord_cf[dst] = cf;

@@ -1,0 +1,310 @@
+// gndt_bucket3.hpp — k_bucket_direct: one workgroup per bucket, third generation.
+//
+// k_bucket_build2 (gndt_bucket.hpp) sorts every chunk of a bucket by node inside LDS so that runs of one node can be
+// summed in registers.  Counted on the ISA it spends ~270 vector + ~170 scalar instructions per point in four
+// barrier-separated phases per chunk (rank atomics, scan, scatter, re-read, run logic) and is issue-bound in those
+// phases: 242 us for the 10 M-point bench scene.  This kernel does the obvious thing instead, made cheap:
+//
+//   accumulate (no barrier, no chunking: every wave streams its share of the bucket's records)
+//       record -> key (divide-free exact index, gndt_math.hpp) -> LDS node table slot (first probe hits ~always)
+//              -> v = p - centre(node) in fp64 -> 9 x ds_add_f64 + count + first-seen straight into the table
+//   then, on the finished table
+//       compact the occupied slots (wave ballots), so that the per-node phases run on dense lanes
+//       columns : column table + per-column linked list of nodes, fp32 mean-z
+//       rows    : slope label and index in column by walking the short list; mean + fp64 scatter -> 96-B staging row
+//
+// ~120 instructions per point, bounded by the LDS atomic unit (ds_add_f64: ~2.5 lanes per clock and CU) instead of
+// by instruction issue.  Hot buckets need no special casing (no chunk image to overflow); 64 identical consecutive
+// points still arrive as ONE weighted record (gndt_partition.hpp).  Semantics are those of k_bucket_build2 (same
+// gndt_math.hpp arithmetic, same order-free label rule); tests run every strategy against the oracle.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "gndt_bucket.hpp"
+
+namespace gndt {
+
+#ifndef GNDT_DIRECT_WAVES
+#define GNDT_DIRECT_WAVES 5      // waves per SIMD the register allocation aims at (512-slot variant): 5 = 96 VGPRs, no spills
+#endif
+
+template <int H>
+struct BucketLds3 {           // 52.0 KB at H = 512: three workgroups per CU
+    unsigned long long key[H];
+    double sum[9][H];
+    uint32_t cnt[H];
+    uint32_t first[H];
+    // per-node phases
+    float mean_z[H];
+    uint32_t chead[H];          // column table: head of the column's node list (a node slot), kNoNode = free.  The column's
+    uint32_t next[H];           //   key is the key of ANY node on its list, so no separate column keys are kept
+    uint16_t list[H];           // the occupied slots, compacted
+    uint16_t cslot[H];          // column slot of the node in this slot
+    uint32_t n_nodes, n_cols, n_slopes, n_list, stage_base, overflow, err_range, pad;
+};
+constexpr uint32_t kNoNode = 0xFFFFFFFFu;
+
+// slot of a node inside its bucket's table.  The bucket is chosen by the TOP bits of the column hash (bucket_of), so its
+// low bits are still uniform inside a bucket; the z level is spread over them with a full-rate 24-bit multiply.
+__device__ __forceinline__ uint32_t node_slot3(uint32_t colh, int sz) {
+    uint32_t g = colh ^ __umul24((uint32_t)sz & 0xFFFFFFu, 0x9E3779u);
+    g ^= g >> 11;
+    return g;
+}
+
+template <int T, int H, bool STATS>
+__device__ __forceinline__ void bucket_direct_one(BucketLds3<H>& L, const uint32_t bucket, const float4* __restrict__ recs,
+                                                  const uint32_t lo, const uint32_t hi, const GridParams& P,
+                                                  StageRow* __restrict__ stage, uint32_t stage_cap,
+                                                  uint32_t* __restrict__ ord_cf, uint32_t* __restrict__ ord_idx,
+                                                  const ColumnOrder& O, Counters* __restrict__ cnt,
+                                                  PartCounters* __restrict__ pc, unsigned long long* __restrict__ dbg,
+                                                  const StatsOut& so) {
+    static_assert(H <= 65535, "slot indices are kept in 16 bits");
+    constexpr int kFill = (H * 25) / 32;
+    constexpr int U = 2;                           // records in flight per thread
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+#define GNDT_STAMP3(k) do { if (dbg && tid == 0) dbg[(size_t)bucket * 16 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+    GNDT_STAMP3(0);
+    for (int s = tid; s < H; s += T) {
+        L.key[s] = kEmptyKey;
+#pragma unroll
+        for (int j = 0; j < 9; ++j) L.sum[j][s] = 0.0;
+        L.cnt[s] = 0; L.first[s] = 0xFFFFFFFFu;
+        L.chead[s] = kNoNode;
+    }
+    if (tid == 0) { L.n_nodes = 0; L.n_cols = 0; L.n_slopes = 0; L.n_list = 0; L.stage_base = 0; L.overflow = 0; L.err_range = 0; }
+    __syncthreads();
+    GNDT_STAMP3(1);
+
+    // ---- accumulate: no barrier until every record of the bucket is in the table ----
+    const double hx = 0.5 * (double)P.grid_len, hz = 0.5 * (double)P.z_len;
+    const double ox = (double)P.ox, oy = (double)P.oy, oz = (double)P.oz;
+    // A thread takes U = 2 ADJACENT records per iteration (32 bytes, a wave reads 2 KB in one piece).  Clouds with locality
+    // (scan-ordered LiDAR, the zero padding) keep their order inside a bucket, so neighbouring records often belong to the
+    // same node: the pair is then added as ONE contribution, and a wave whose 128 records all fall into one node adds them
+    // with one set of atomics.  The records of the next iteration are loaded while this one is keyed and accumulated;
+    // out-of-range lanes re-read the bucket's last record instead of branching around the load.
+    float4 nxt[U];
+    if (lo < hi) {
+#pragma unroll
+        for (int j = 0; j < U; ++j) nxt[j] = recs[min(lo + (uint32_t)(U * tid + j), hi - 1u)];
+    }
+    for (uint32_t base = lo; base < hi; base += (uint32_t)(U * T)) {
+        float4 rec[U];
+        bool use[U];
+#pragma unroll
+        for (int j = 0; j < U; ++j) { rec[j] = nxt[j]; use[j] = base + (uint32_t)(U * tid + j) < hi; }
+        if (base + (uint32_t)(U * T) < hi) {       // uniform
+#pragma unroll
+            for (int j = 0; j < U; ++j) nxt[j] = recs[min(base + (uint32_t)(U * T + U * tid + j), hi - 1u)];
+        }
+        PointKey k[U];
+        uint32_t slot[U];
+        unsigned long long pkey[U], k0[U];
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            k[j] = point_key_fast(rec[j].x, rec[j].y, rec[j].z, P.ox, P.oy, P.oz, P.grid_len, P.z_len, P.inv_grid, P.inv_z);
+            pkey[j] = pack_key(k[j].sx, k[j].sy, k[j].sz);
+            slot[j] = node_slot3(column_hash(k[j].sx, k[j].sy), k[j].sz) & (uint32_t)(H - 1);
+            if (use[j] && !k[j].ok) { atomicAdd(&L.err_range, 1u); use[j] = false; }   // |nz| beyond the key range (x, y: the partition)
+        }
+        const bool pair = use[0] && use[1] && pkey[0] == pkey[1];      // both records in one node: one contribution
+        if (pair) use[1] = false;
+#pragma unroll
+        for (int j = 0; j < U; ++j) k0[j] = L.key[slot[j]];
+        double c[U][9];
+        uint32_t cn[U], cf[U];
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            const uint32_t iw = __float_as_uint(rec[j].w);
+            // v = p - centre(node): the centre is axis_centre(), spelled so that it costs one convert and one fma per axis
+            const double v0 = (double)rec[j].x - fma((double)(2 * k[j].sx - (k[j].sx > 0 ? 1 : -1)), hx, ox);
+            const double v1 = (double)rec[j].y - fma((double)(2 * k[j].sy - (k[j].sy > 0 ? 1 : -1)), hx, oy);
+            const double v2 = (double)rec[j].z - fma((double)(2 * k[j].sz - (k[j].sz > 0 ? 1 : -1)), hz, oz);
+            const bool w64 = (iw & kWeight64Flag) != 0u;          // 64 identical points in one record (exact: power of two)
+            const double wf = w64 ? 64.0 : 1.0;
+            const double w0 = wf * v0, w1 = wf * v1, w2 = wf * v2;
+            c[j][0] = w0; c[j][1] = w1; c[j][2] = w2;
+            c[j][3] = w0 * v0; c[j][4] = w0 * v1; c[j][5] = w0 * v2; c[j][6] = w1 * v1; c[j][7] = w1 * v2; c[j][8] = w2 * v2;
+            cn[j] = w64 ? 64u : 1u;
+            cf[j] = iw & ~kWeight64Flag;
+        }
+        if (pair) {
+#pragma unroll
+            for (int q = 0; q < 9; ++q) c[0][q] += c[1][q];
+            cn[0] += cn[1]; cf[0] = min(cf[0], cf[1]);
+        }
+        // a wave whose records all sit in ONE node (dense cells, the zero padding): sum across the wave, one lane adds
+        if (__all(pair) && __all(pkey[0] == __shfl(pkey[0], 0, 64))) {
+#pragma unroll
+            for (int q = 0; q < 9; ++q) c[0][q] = wave_sum(c[0][q]);          // (lane 0 holds the total)
+            for (int off = 32; off > 0; off >>= 1) { cn[0] += (uint32_t)__shfl_down((int)cn[0], off, 64); cf[0] = min(cf[0], (uint32_t)__shfl_down((int)cf[0], off, 64)); }
+            use[0] = lane == 0;
+        }
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            uint32_t s = slot[j];
+            bool u = use[j];
+            if (u && k0[j] != pkey[j]) {                               // first probe missed: new node or a collision
+                s = lds_find_or_insert<H>(L.key, slot[j], pkey[j], &L.n_nodes);
+                if (s >= (uint32_t)H) { L.overflow = 1; u = false; }
+            }
+            if (u) {
+                atomicAdd(&L.sum[0][s], c[j][0]); atomicAdd(&L.sum[1][s], c[j][1]); atomicAdd(&L.sum[2][s], c[j][2]);
+                atomicAdd(&L.sum[3][s], c[j][3]); atomicAdd(&L.sum[4][s], c[j][4]); atomicAdd(&L.sum[5][s], c[j][5]);
+                atomicAdd(&L.sum[6][s], c[j][6]); atomicAdd(&L.sum[7][s], c[j][7]); atomicAdd(&L.sum[8][s], c[j][8]);
+                atomicAdd(&L.cnt[s], cn[j]);
+                atomicMin(&L.first[s], cf[j]);
+            }
+        }
+    }
+    __syncthreads();
+    GNDT_STAMP3(2);
+    const uint32_t M = L.n_nodes;
+    if (L.overflow || M > (uint32_t)kFill) {     // uniform
+        if (tid == 0) atomicAdd(&pc->lds_overflow, 1u);
+        return;
+    }
+    // Reserve the staging rows now: the memory-side atomic's round trip hides behind the per-node phases.
+    uint32_t stage_base_reg = 0;
+    if (tid == T - 1) stage_base_reg = atomicAdd(&cnt->num_nodes, M);
+    if (tid == 0 && L.err_range) atomicAdd(&cnt->err_key_range, L.err_range);
+
+    // ---- compact the occupied slots: the per-node phases then run on dense lanes (M of H slots are in use) ----
+    for (int s0 = 0; s0 < H; s0 += T) {
+        const int s = s0 + tid;
+        const bool occ = s < H && L.key[s] != kEmptyKey;
+        const unsigned long long m = __ballot(occ);
+        uint32_t wbase = 0;
+        if (lane == 0 && m) wbase = atomicAdd(&L.n_list, (uint32_t)__popcll(m));
+        wbase = (uint32_t)__shfl((int)wbase, 0, 64);
+        if (occ) L.list[wbase + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)s;
+    }
+    if (tid == T - 1) L.stage_base = stage_base_reg;
+    __syncthreads();
+    const uint32_t sbase = L.stage_base;
+    if (sbase + M > stage_cap) {                   // uniform
+        if (tid == 0) atomicAdd(&pc->stage_overflow, M);
+        return;
+    }
+
+    if constexpr (STATS) {
+        for (uint32_t i = tid; i < M; i += T) {
+            const uint32_t s = L.list[i];
+            const uint32_t dst = sbase + i;
+            so.key[dst] = L.key[s];
+#pragma unroll
+            for (int j = 0; j < 9; ++j) so.sums[9 * (size_t)dst + j] = L.sum[j][s];
+            so.count[dst] = L.cnt[s];
+            so.first[dst] = L.first[s];
+        }
+        return;
+    }
+
+    // ---- columns: every node joins the list of its column; fp32 mean-z of the nodes that have statistics ----
+    for (uint32_t i = tid; i < M; i += T) {
+        const uint32_t s = L.list[i];
+        const uint64_t key = L.key[s];
+        int sx, sy, sz;
+        unpack_key(key, sx, sy, sz);
+        const uint32_t n = L.cnt[s];
+        L.mean_z[s] = (n >= (uint32_t)P.min_points) ? node_mean_z(n, L.sum[2][s], axis_centre(sz, P.oz, P.z_len)) : 0.f;
+        const uint64_t ck = column_key(key);
+        uint32_t c = ((column_hash(sx, sy) * 0x85EBCA77u) >> 12) & (uint32_t)(H - 1);
+        for (int probe = 0; probe < H; ++probe) {            // (terminates: the table has more slots than nodes)
+            uint32_t head = L.chead[c];
+            if (head == kNoNode) {
+                head = atomicCAS(&L.chead[c], kNoNode, s);
+                if (head == kNoNode) { L.next[s] = kNoNode; atomicAdd(&L.n_cols, 1u); break; }      // first node of a new column
+            }
+            if (column_key(L.key[head]) == ck) { L.next[s] = atomicExch(&L.chead[c], s); break; }   // push in front
+            c = (c + 1) & (uint32_t)(H - 1);
+        }
+        L.cslot[s] = (uint16_t)c;
+    }
+    __syncthreads();
+    GNDT_STAMP3(3);
+    if (tid == 0) atomicAdd(&cnt->num_columns, L.n_cols);
+
+    // ---- rows: slope label (OcNode::isSlope, map2D.h:66-108), index in column, column size and first-seen index by
+    //      walking the column's short list; mean + fp64 scatter -> staging row ----
+    uint32_t my_slopes = 0;
+    for (uint32_t i = tid; i < M; i += T) {
+        const uint32_t s = L.list[i];
+        const uint64_t key = L.key[s];
+        const uint32_t my_first = L.first[s];
+        int sx, sy, sz;
+        unpack_key(key, sx, sy, sz);
+        const int za = level_above(sz), zb = level_below(sz);
+        const float cz = L.mean_z[s];
+        const uint32_t my_n = L.cnt[s];
+        uint32_t icol = 0, ncol = 0, cf = 0xFFFFFFFFu;
+        bool up = false, down = false;
+        for (uint32_t t = L.chead[L.cslot[s]]; t != kNoNode; t = L.next[t]) {
+            const uint32_t tf = L.first[t];
+            ++ncol;
+            cf = min(cf, tf);
+            if (t == s) continue;
+            icol += (tf < my_first) ? 1u : 0u;
+            const int tz = (int)(L.key[t] & 0x3FFFFFu) - (1 << 21);
+            if (tz == za || tz == zb) {
+                const bool visited = tf < my_first && L.cnt[t] >= (uint32_t)P.min_points;
+                const float oz2 = visited ? L.mean_z[t] : 0.f;
+                const bool far = fabsf(oz2 - cz) > P.slope_interval;
+                if (tz == za) up = up || far; else down = down || far;
+            }
+        }
+        uint32_t fl = (my_n >= (uint32_t)P.min_points) ? 1u : 0u;
+        if (fl) {
+            bool slope = true;
+            if (P.demand == 0) slope = !up; else down = false;
+            if (slope) { fl |= 2u; if (down) fl |= 4u; ++my_slopes; }
+        }
+        StageRow row;
+        row.sx = sx; row.sy = sy; row.sz = sz;
+        row.count = my_n; row.first = my_first; row.flags = fl;
+        for (int k = 0; k < 3; ++k) row.mean[k] = 0.f;
+        for (int k = 0; k < 6; ++k) row.scatter[k] = 0.0;
+        if (fl & 1u) {
+            double sums[9];
+#pragma unroll
+            for (int j = 0; j < 9; ++j) sums[j] = L.sum[j][s];
+            const double c[3] = {axis_centre(sx, P.ox, P.grid_len), axis_centre(sy, P.oy, P.grid_len), axis_centre(sz, P.oz, P.z_len)};
+            node_moments(row.count, sums, c, row.mean, row.scatter);
+        }
+        row.col_first = cf; row.idx_in_col = icol; row.ncol = ncol;
+        const uint32_t dst = sbase + i;
+        stage[dst] = row;
+        ord_cf[dst] = cf;
+        ord_idx[dst] = icol;
+        if (icol == 0) note_column(O, cf, ncol);
+    }
+    // counters: aggregated in LDS, ONE memory-side atomic per bucket and counter
+    if (my_slopes) atomicAdd(&L.n_slopes, my_slopes);
+    __syncthreads();
+    if (tid == 0 && L.n_slopes) atomicAdd(&cnt->num_slopes, L.n_slopes);
+    GNDT_STAMP3(4);
+#undef GNDT_STAMP3
+}
+
+// Bucket b, b + gridDim.x, ...  With 512-slot tables three 512-thread workgroups share a CU (52 KB of LDS each): six waves
+// per SIMD, i.e. at most 80 VGPRs; the 1024-slot variant (retries) runs one 1024-thread workgroup per CU.
+template <int T, int H, bool STATS = false>
+__global__ void __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(H <= 512 ? GNDT_DIRECT_WAVES : 4, H <= 512 ? GNDT_DIRECT_WAVES : 4))) k_bucket_direct(const float4* __restrict__ recs, const uint32_t* __restrict__ range_lo,
+                                                     const uint32_t* __restrict__ range_hi, uint32_t num_buckets, GridParams P,
+                                                     StageRow* __restrict__ stage, uint32_t stage_cap,
+                                                     uint32_t* __restrict__ ord_cf, uint32_t* __restrict__ ord_idx, ColumnOrder O,
+                                                     Counters* __restrict__ cnt, PartCounters* __restrict__ pc,
+                                                     unsigned long long* __restrict__ dbg, StatsOut so) {
+    __shared__ BucketLds3<H> L;
+    for (uint32_t bucket = blockIdx.x; bucket < num_buckets; bucket += gridDim.x) {
+        bucket_direct_one<T, H, STATS>(L, bucket, recs, range_lo[bucket], range_hi[bucket], P, stage, stage_cap, ord_cf, ord_idx, O,
+                                       cnt, pc, dbg, so);
+        __syncthreads();        // the LDS tables are re-initialised by the next bucket
+    }
+}
+
+}  // namespace gndt

@@ -154,7 +154,7 @@ using namespace gndt;
 struct Tuning {
     int bucket_load = 50;        // GNDT_BUCKET_LOAD    average LDS-table load (percent) that sizes the bucket count
     int bucket_points = 0;       // GNDT_BUCKET_POINTS  points per bucket (0 = derived)
-    int bucket_threads = 512;    // GNDT_BUCKET_THREADS k_bucket_build2 variant
+    int bucket_kernel = 3;       // GNDT_BUCKET_KERNEL  3 = k_bucket_direct (default), 4 = k_bucket_owner, 2 = k_bucket_build2 (A/B measurements)
     int bucket_slots = 0;        // GNDT_BUCKET_SLOTS   k_bucket_build2 variant (0 = 512, 1024 on retry)
     int part_wgs = 256;          // GNDT_PART_WGS       workgroups of the exact counting partition
     int two_level = -1;          // GNDT_TWO_LEVEL      0 = never use the two-level partition
@@ -211,6 +211,7 @@ inline GridParams grid_params(const gndt_handle* h) {
     g.ox = h->origin[0]; g.oy = h->origin[1]; g.oz = h->origin[2];
     g.grid_len = h->P.grid_len; g.z_len = h->P.z_len; g.slope_interval = h->P.slope_interval;
     g.demand = h->P.demand; g.min_points = h->P.min_points;
+    g.inv_grid = 1.0f / g.grid_len; g.inv_z = 1.0f / g.z_len;     // correctly rounded on the host
     return g;
 }
 

@@ -53,6 +53,7 @@ struct GridParams {
     float ox, oy, oz;
     float grid_len, z_len, slope_interval;
     int demand, min_points;
+    float inv_grid, inv_z;     // RN(1 / grid_len), RN(1 / z_len): axis_index_fast (gndt_math.hpp)
 };
 
 struct OutView {

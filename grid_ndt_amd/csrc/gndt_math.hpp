@@ -52,6 +52,36 @@ GNDT_HD int axis_index(float p, float o, float len, bool& ok, int limit) {
     return (p > o) ? n : -n;
 }
 
+// The same index without the divide whenever that is PROVABLY the same.  inv_len = RN(1/len) (host, IEEE).
+//   q~ = RN(a * inv_len) carries at most 1.5 * 2^-23 relative error against the exact quotient Q, the reference's
+//   q = RN(Q) at most 2^-24, so |q~ - q| < 1.8e-7 * Q.  If no integer lies within 2.4e-7 * q~ of q~, none lies
+//   between q~ and q (nor on q), hence ceilf(q~) == ceilf(q).  Otherwise (q~ within ~2 ulp of an integer, or not
+//   finite) the IEEE divide decides, exactly as axis_index does.  About one axis value in
+//   10^4 takes the slow branch at the index magnitudes of the benchmark scenes; results are bit-identical always
+//   (tests/test_host_math.py drives both forms over lattice-adversarial inputs).
+// One axis of that: ceil of the divide-free quotient, and whether it is undecided.  Spelled with two products instead of
+// distances: q~ (1 - 3e-7) and q~ (1 + 3e-7) bracket the reference's quotient (3e-7 leaves room for their own rounding),
+// so if both have the same ceiling, that is the ceiling.  NaN compares unequal -> undecided -> the divide reports it.
+GNDT_HD float axis_ceil_try(float p, float o, float inv_len, bool& undecided) {
+    const float q = fabsf(p - o) * inv_len;
+    const float c_hi = ceilf(q * 1.0000003f), c_lo = ceilf(q * 0.9999997f);
+    undecided = undecided || !(c_hi == c_lo);
+    return c_hi;
+}
+// c = ceilf(|p - o| / len) however obtained -> signed index (the tail of axis_index)
+GNDT_HD int axis_from_ceil(float c, float p, float o, bool& ok, int limit) {
+    ok = ok && (c <= (float)limit);
+    int n = (int)fminf(c, (float)limit);         // (NaN -> limit; ok is already false)
+    if (n == 0) n = 1;
+    return (p > o) ? n : -n;
+}
+GNDT_HD int axis_index_fast(float p, float o, float len, float inv_len, bool& ok, int limit) {
+    bool und = false;
+    float c = axis_ceil_try(p, o, inv_len, und);
+    if (und) c = ceilf(fabsf(p - o) / len);      // undecided: the reference's own arithmetic
+    return axis_from_ceil(c, p, o, ok, limit);
+}
+
 struct PointKey {
     int sx, sy, sz;
     bool ok;
@@ -63,6 +93,26 @@ GNDT_HD PointKey point_key(float px, float py, float pz, float ox, float oy, flo
     k.sx = axis_index(px, ox, grid_len, k.ok, kMaxXY);
     k.sy = axis_index(py, oy, grid_len, k.ok, kMaxXY);
     k.sz = axis_index(pz, oz, z_len, k.ok, kMaxZ);
+    return k;
+}
+
+// All three axes with ONE (rare) branch: if any axis is undecided, all three take the IEEE divide.
+GNDT_HD PointKey point_key_fast(float px, float py, float pz, float ox, float oy, float oz, float grid_len, float z_len,
+                                float inv_grid, float inv_z) {
+    bool und = false;
+    float cx = axis_ceil_try(px, ox, inv_grid, und);
+    float cy = axis_ceil_try(py, oy, inv_grid, und);
+    float cz = axis_ceil_try(pz, oz, inv_z, und);
+    if (und) {
+        cx = ceilf(fabsf(px - ox) / grid_len);
+        cy = ceilf(fabsf(py - oy) / grid_len);
+        cz = ceilf(fabsf(pz - oz) / z_len);
+    }
+    PointKey k;
+    k.ok = true;
+    k.sx = axis_from_ceil(cx, px, ox, k.ok, kMaxXY);
+    k.sy = axis_from_ceil(cy, py, oy, k.ok, kMaxXY);
+    k.sz = axis_from_ceil(cz, pz, oz, k.ok, kMaxZ);
     return k;
 }
 

@@ -50,15 +50,14 @@ struct PartCounters {
     uint32_t pad[3];           //   host sizes the retry from it)
 };
 
-struct alignas(16) StageRow {   // 128 bytes = two 64-B lines, gathered whole by k_emit_rows
+struct alignas(16) StageRow {   // 96 bytes, gathered whole by k_emit_rows (round 1 padded it to 128: a quarter of the node traffic)
     int32_t sx, sy, sz;
     uint32_t count, first, flags;
     uint32_t col_first, idx_in_col, ncol;
     float mean[3];
     double scatter[6];          // fp64: the eigen-solve runs in k_emit_rows (chip-wide parallelism)
-    uint32_t pad[8];
 };
-static_assert(sizeof(StageRow) == 128, "StageRow layout");
+static_assert(sizeof(StageRow) == 96, "StageRow layout");
 
 // What the producer of the staging rows records for every column, at the column's first-seen point index cf (the
 // row with idx_in_col == 0 does it).  The final row of a node is then
@@ -76,22 +75,41 @@ __device__ __forceinline__ void note_column(const ColumnOrder& O, uint32_t cf, u
     O.ncol_at[cf] = ncol;
 }
 
+// Hash of a column.  |sx|, |sy| <= 65535, so the biased indices fit 18 bits: two FULL-RATE 24-bit multiplies, one 32-bit
+// multiply (quarter rate on CDNA) and two xor-shifts.  Columns per bucket come out Poisson-distributed on lattices of
+// 160 k .. 4 M columns for 4096 .. 32768 buckets (checked offline against the five-multiply version this replaces).
 __host__ __device__ __forceinline__ uint32_t column_hash(int sx, int sy) {
-    uint32_t h = (uint32_t)sx * 0x9E3779B1u ^ (uint32_t)sy * 0x85EBCA77u;
-    h ^= h >> 16; h *= 0x7FEB352Du;
-    h ^= h >> 15; h *= 0x846CA68Bu;
-    h ^= h >> 16;
+    const uint32_t a = (uint32_t)(sx + 65536) & 0x3FFFFu, b = (uint32_t)(sy + 65536) & 0x3FFFFu;
+    uint32_t h = a * 0x9E3779u + b * 0x85EBCBu;         // (both operands < 2^24: v_mul_u32_u24)
+    h ^= h >> 15; h *= 0x2C1B3C6Du;
+    h ^= h >> 13;
     return h;
 }
-// bucket of a column: multiply-high range reduction, so the bucket count need not be a power of two
+// bucket of a column: range reduction of the hash's top 24 bits, so the bucket count need not be a power of two
+// (B < 2^24; 24 x 24-bit product: two full-rate instructions instead of a quarter-rate 32 x 32 high multiply)
 __host__ __device__ __forceinline__ uint32_t bucket_of(uint32_t colh, uint32_t B) {
-    return (uint32_t)(((uint64_t)colh * (uint64_t)B) >> 32);
+    return (uint32_t)(((uint64_t)(colh >> 8) * (uint64_t)(B & 0xFFFFFFu)) >> 24);
 }
 __device__ __forceinline__ uint32_t node_slot_hash(uint32_t colh, int sz) {
     uint32_t g = (colh * 0x9E3779B1u) ^ ((uint32_t)sz * 0xC2B2AE3Du);
     g ^= g >> 16; g *= 0x27D4EB2Fu;
     g ^= g >> 15;
     return g;
+}
+
+// The column part of a point's key, divide-free (axis_index_fast): what the partition passes need.  The z level is only
+// computed where the node is (the bucket kernel), which also reports a z index beyond the key range.
+__device__ __forceinline__ void column_of_point(float px, float py, const GridParams& P, int& sx, int& sy, bool& ok) {
+    bool und = false;
+    float cx = axis_ceil_try(px, P.ox, P.inv_grid, und);
+    float cy = axis_ceil_try(py, P.oy, P.inv_grid, und);
+    if (und) {                                   // (rare: one branch for both axes)
+        cx = ceilf(fabsf(px - P.ox) / P.grid_len);
+        cy = ceilf(fabsf(py - P.oy) / P.grid_len);
+    }
+    ok = true;
+    sx = axis_from_ceil(cx, px, P.ox, ok, kMaxXY);
+    sy = axis_from_ceil(cy, py, P.oy, ok, kMaxXY);
 }
 
 constexpr uint32_t kWeight64Flag = 0x80000000u;   // in a record's index word: the record stands for 64 identical points
@@ -144,13 +162,15 @@ __global__ void __launch_bounds__(kPartThreads) k_part_hist(const float* __restr
         const bool live = i < hi;
         float px = 0.f, py = 0.f, pz = 0.f;
         if (live) { const float* p = xyz + i * STRIDE_FLOATS; px = p[0]; py = p[1]; pz = p[2]; }
-        PointKey k = point_key(px, py, pz, P.ox, P.oy, P.oz, P.grid_len, P.z_len);
-        if (live && !k.ok) atomicAdd(&cnt->err_key_range, 1u);
-        const bool use = live && k.ok;
+        int sx, sy;
+        bool kok;
+        column_of_point(px, py, P, sx, sy, kok);
+        if (live && !kok) atomicAdd(&cnt->err_key_range, 1u);
+        const bool use = live && kok;
         // 64 consecutive identical points (the (0,0,0) padding of the reference's clouds) become ONE
         // weighted record: counted once here, written once by k_part_scatter
         const bool same = wave_all_identical(px, py, pz, use);
-        if (use && (!same || (threadIdx.x & 63) == 0)) atomicAdd(&lh[bucket_of(column_hash(k.sx, k.sy), B)], 1u);
+        if (use && (!same || (threadIdx.x & 63) == 0)) atomicAdd(&lh[bucket_of(column_hash(sx, sy), B)], 1u);
     }
     __syncthreads();
     uint32_t* out = hist + (uint64_t)blockIdx.x * B;
@@ -238,11 +258,13 @@ __global__ void __launch_bounds__(kPartThreads) k_part_scatter(const float* __re
         const bool live = i < hi;
         float px = 0.f, py = 0.f, pz = 0.f;
         if (live) { const float* p = xyz + i * STRIDE_FLOATS; px = p[0]; py = p[1]; pz = p[2]; }
-        PointKey k = point_key(px, py, pz, P.ox, P.oy, P.oz, P.grid_len, P.z_len);
-        const bool use = live && k.ok;
+        int sx, sy;
+        bool kok;
+        column_of_point(px, py, P, sx, sy, kok);
+        const bool use = live && kok;
         const bool same = wave_all_identical(px, py, pz, use);
         if (use && (!same || (threadIdx.x & 63) == 0)) {
-            const uint32_t pos = atomicAdd(&cur[bucket_of(column_hash(k.sx, k.sy), B)], 1u);
+            const uint32_t pos = atomicAdd(&cur[bucket_of(column_hash(sx, sy), B)], 1u);
             // bit 31 of the index word marks a record that stands for 64 identical points (lane 0 = the first of them)
             const uint32_t idx = (first_base + (uint32_t)i) | (same ? kWeight64Flag : 0u);
             recs[pos] = make_float4(px, py, pz, __uint_as_float(idx));
@@ -363,11 +385,13 @@ __global__ void __launch_bounds__(kTileThreads) k_part2_level1(const float* __re
     float nx[PER], ny[PER], nz[PER];
     auto load_tile = [&](uint64_t tile) {
         const uint64_t t0 = tile * (kTileThreads * PER);
+        const float* __restrict__ base = xyz + t0 * STRIDE_FLOATS;            // uniform: the 64-bit arithmetic stays scalar
+        const uint32_t have = (uint32_t)min((uint64_t)(kTileThreads * PER), n - t0);
 #pragma unroll
         for (int j = 0; j < PER; ++j) {
-            const uint64_t i = t0 + (uint64_t)j * kTileThreads + threadIdx.x;    // a wave holds 64 consecutive points
+            const uint32_t i = (uint32_t)(j * kTileThreads) + threadIdx.x;     // a wave holds 64 consecutive points
             nx[j] = 0.f; ny[j] = 0.f; nz[j] = 0.f;
-            if (i < n) { const float* p = xyz + i * STRIDE_FLOATS; nx[j] = p[0]; ny[j] = p[1]; nz[j] = p[2]; }
+            if (i < have) { const float* p = base + i * (uint32_t)STRIDE_FLOATS; nx[j] = p[0]; ny[j] = p[1]; nz[j] = p[2]; }
         }
     };
     uint64_t tile = blockIdx.x;
@@ -386,13 +410,15 @@ __global__ void __launch_bounds__(kTileThreads) k_part2_level1(const float* __re
             const uint64_t i = t0 + (uint64_t)j * kTileThreads + threadIdx.x;
             const bool live = i < n;
             const float px = cx[j], py = cy[j], pz = cz[j];
-            const PointKey k = point_key(px, py, pz, P.ox, P.oy, P.oz, P.grid_len, P.z_len);
-            if (live && !k.ok) atomicAdd(&cnt->err_key_range, 1u);
-            const bool use = live && k.ok;
+            int sx, sy;
+            bool kok;
+            column_of_point(px, py, P, sx, sy, kok);
+            if (live && !kok) atomicAdd(&cnt->err_key_range, 1u);
+            const bool use = live && kok;
             const bool same = wave_all_identical(px, py, pz, use);               // 64 identical points -> one weighted record
             dig[j] = 0xFFFFFFFFu;
             if (use && (!same || (threadIdx.x & 63) == 0)) {
-                const uint32_t b = bucket_of(column_hash(k.sx, k.sy), B);
+                const uint32_t b = bucket_of(column_hash(sx, sy), B);
                 dig[j] = (b >> F2_shift) * R + rep;                                  // F2 is a power of two
                 // One record in kSampleEvery votes for its bucket (k_part2_layout sizes the buckets' regions from the
                 // votes).  Chosen by a hash of the point index: a fixed stride would alias with the scan pattern of a
@@ -461,8 +487,10 @@ __global__ void __launch_bounds__(kTileThreads) k_part2_level2(const float4* __r
         dig[j] = 0xFFFFFFFFu;
         if (i < have) {
             r[j] = src[i];
-            const PointKey k = point_key(r[j].x, r[j].y, r[j].z, P.ox, P.oy, P.oz, P.grid_len, P.z_len);
-            dig[j] = bucket_of(column_hash(k.sx, k.sy), B) - b0;
+            int sx, sy;
+            bool kok;
+            column_of_point(r[j].x, r[j].y, P, sx, sy, kok);
+            dig[j] = bucket_of(column_hash(sx, sy), B) - b0;
         }
     }
     tile_partition<PER, FAN>(L, r, dig, nd, cursor2 + b0, 0u, 0ull, 0ull, lo + b0, cap + b0, recs2, pc);

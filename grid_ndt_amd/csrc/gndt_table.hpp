@@ -91,7 +91,6 @@ __device__ __forceinline__ void tab_make_row(const TableView& T, const GridParam
         node_moments(a.count, a.s, c, row.mean, row.scatter);
     }
     row.col_first = T.col_first[cs]; row.idx_in_col = icol; row.ncol = T.col_cnt[cs];
-    for (int k = 0; k < 8; ++k) row.pad[k] = 0;
 }
 
 static __global__ void __launch_bounds__(kBlock) k_tab_begin(TableView T, Counters* __restrict__ cnt, PartCounters* __restrict__ pc,
@@ -336,7 +335,6 @@ static __global__ void __launch_bounds__(kBlock) k_stats_rows(const uint64_t* __
             node_moments(my_count, sm, c, row.mean, row.scatter);
         }
         row.col_first = cf; row.idx_in_col = icol; row.ncol = hi - lo;
-        for (int j = 0; j < 8; ++j) row.pad[j] = 0;
         stage[i] = row;
         ord_cf[i] = cf;
         ord_idx[i] = icol;

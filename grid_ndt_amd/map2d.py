@@ -291,7 +291,8 @@ class TwoDmap:
         arr = (C.c_double * 10)()
         nb = C.c_uint32()
         self._check(self._L.gndt_debug_bucket_phases(self._h, arr, C.byref(nb)))
-        names = ("clear", "accumulate", "columns", "labels", "order", "emit", "acc:load", "acc:classify", "acc:scatter", "acc:reduce")
+        # (k_bucket_owner fills [0..3] and the four accumulate sub-phases classify / scan / scatter / reduce in [6..9])
+        names = ("clear", "accumulate", "columns", "rows", "-", "-", "acc:0", "acc:1", "acc:2", "acc:3")
         return dict(zip(names, list(arr))), nb.value
 
     # ---- cost map (TwoDmap::computeCost, map2D.h:1285-1397) ----

@@ -13,6 +13,17 @@ void shim_point_keys(const float* xyz, uint64_t n, int stride, const float o[3],
         ok[i] = k.ok;
     }
 }
+// the divide-free form the hot kernels use (axis_index_fast): must agree with shim_point_keys bit for bit
+void shim_point_keys_fast(const float* xyz, uint64_t n, int stride, const float o[3], float gl, float zl,
+                          uint64_t* keys, uint8_t* ok) {
+    const float ig = 1.0f / gl, iz = 1.0f / zl;
+    for (uint64_t i = 0; i < n; ++i) {
+        const float* p = xyz + i * stride;
+        gndt::PointKey k = gndt::point_key_fast(p[0], p[1], p[2], o[0], o[1], o[2], gl, zl, ig, iz);
+        keys[i] = gndt::pack_key(k.sx, k.sy, k.sz);
+        ok[i] = k.ok;
+    }
+}
 void shim_centres(const uint64_t* keys, uint64_t n, const float o[3], float gl, float zl, double* c) {
     for (uint64_t i = 0; i < n; ++i) {
         int sx, sy, sz;

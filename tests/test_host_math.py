@@ -76,6 +76,12 @@ def test_keys_on_and_around_cell_boundaries_match_the_reference_arithmetic():
         oc = (he.C.c_float * 3)(*[float(v) for v in o])
         he.shim().shim_point_keys(pts.ctypes.data_as(he.C.c_void_p), he.C.c_uint64(pts.shape[0]), 3, oc, he.C.c_float(gl),
                                   he.C.c_float(zl), keys.ctypes.data_as(he.C.c_void_p), ok.ctypes.data_as(he.C.c_void_p))
+        # the divide-free form the hot kernels run (axis_index_fast) is the same function, bit for bit
+        keys_f = np.zeros(pts.shape[0], np.uint64)
+        ok_f = np.zeros(pts.shape[0], np.uint8)
+        he.shim().shim_point_keys_fast(pts.ctypes.data_as(he.C.c_void_p), he.C.c_uint64(pts.shape[0]), 3, oc, he.C.c_float(gl),
+                                       he.C.c_float(zl), keys_f.ctypes.data_as(he.C.c_void_p), ok_f.ctypes.data_as(he.C.c_void_p))
+        assert np.array_equal(ok_f, ok) and np.array_equal(keys_f[ok != 0], keys[ok != 0])
         sx, sy, sz = he.unpack(keys)
         good = ok_ref & (ok != 0)
         assert (ok != 0).tolist() == ok_ref.tolist()
@@ -87,3 +93,28 @@ def test_keys_on_and_around_cell_boundaries_match_the_reference_arithmetic():
                 continue
             key, nx, ny, z = oracle.trans_morton_xyz(o, gl, zl, pts[i])
             assert (abs(int(want[i, 0])), abs(int(want[i, 1])), int(want[i, 2])) == (nx, ny, z)
+
+
+def test_divide_free_key_agrees_with_the_ieee_form_on_extreme_inputs():
+    """axis_index_fast vs axis_index where no numpy restatement is needed: zeros, denormals, huge values, Inf, NaN,
+    points exactly on the origin planes, indices around the key-range limits."""
+    rng = np.random.default_rng(11)
+    special = np.float32([0.0, -0.0, 1e-45, -1e-45, 1e-38, 1e-30, 1e30, -1e30, np.inf, -np.inf, np.nan, 3.4e38, 65535 * 0.5, 65536 * 0.5,
+                          -65535 * 0.5, 32767.5, 1048575.0, 2097151 * 0.1, 2097152 * 0.1])
+    grid = np.stack(np.meshgrid(special, special, special, indexing="ij"), -1).reshape(-1, 3)
+    near = (rng.integers(-70000, 70000, size=(200000, 3)) * np.float64([0.5, 0.5, 0.1])).astype(np.float32)
+    near = np.concatenate([near, np.nextafter(near, np.float32(np.inf)), np.nextafter(near, np.float32(-np.inf))], 0)
+    pts = np.ascontiguousarray(np.concatenate([grid, near], 0), np.float32)
+    for o in ((0.0, 0.0, 0.0), (0.25, -0.5, 0.05), (1e-3, 7.0, -2.0)):
+        oc = (he.C.c_float * 3)(*o)
+        out = []
+        for fn in (he.shim().shim_point_keys, he.shim().shim_point_keys_fast):
+            keys = np.zeros(pts.shape[0], np.uint64)
+            ok = np.zeros(pts.shape[0], np.uint8)
+            fn(pts.ctypes.data_as(he.C.c_void_p), he.C.c_uint64(pts.shape[0]), 3, oc, he.C.c_float(0.5), he.C.c_float(0.1),
+               keys.ctypes.data_as(he.C.c_void_p), ok.ctypes.data_as(he.C.c_void_p))
+            out.append((keys, ok))
+        assert np.array_equal(out[0][1], out[1][1])
+        good = out[0][1] != 0
+        assert np.array_equal(out[0][0][good], out[1][0][good])
+        assert good.sum() > 100000 and (~good).sum() > 1000
