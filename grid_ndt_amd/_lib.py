@@ -104,7 +104,7 @@ def build_native(force=False, verbose=False):
         obj = os.path.splitext(src)[0] + ".o"
         cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-c",
                "-Wno-unused-command-line-argument", "-Wno-unused-function", "-Wno-pass-failed", "-fno-slp-vectorize",
-               "-I", os.path.join(_ROOT, "include"), "-I", _CSRC, "-o", obj, src]
+               "-I", os.path.join(_ROOT, "include"), "-I", _CSRC, "-o", obj, src] + os.environ.get("GNDT_EXTRA_CXXFLAGS", "").split()
         if verbose:
             print(" ".join(cmd))
         procs.append((cmd, subprocess.Popen(cmd)))

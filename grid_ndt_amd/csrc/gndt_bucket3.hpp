@@ -45,6 +45,11 @@ struct BucketLds3 {           // 52.0 KB at H = 512: three workgroups per CU
 };
 constexpr uint32_t kNoNode = 0xFFFFFFFFu;
 
+// Workgroup barrier that orders LDS traffic ONLY.  __syncthreads() also waits for every global store of the wave to be
+// acknowledged (~1-2 us once staging rows have been written); the phases of the bucket kernels hand over LDS contents,
+// their global stores are read by later kernels.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // slot of a node inside its bucket's table.  The bucket is chosen by the TOP bits of the column hash (bucket_of), so its
 // low bits are still uniform inside a bucket; the z level is spread over them with a full-rate 24-bit multiply.
 __device__ __forceinline__ uint32_t node_slot3(uint32_t colh, int sz) {
@@ -204,14 +209,34 @@ __device__ __forceinline__ void bucket_direct_one(BucketLds3<H>& L, const uint32
         return;
     }
 
-    // ---- columns: every node joins the list of its column; fp32 mean-z of the nodes that have statistics ----
-    for (uint32_t i = tid; i < M; i += T) {
+    // ---- per-node work, spread over the whole workgroup: items [0, M) join their column's list and set the fp32 mean-z,
+    //      items [M, 2M) turn the sums into mean + fp64 scatter and write that part of the staging row (nothing in it
+    //      depends on the columns), so the M nodes keep 2M lanes busy instead of M ----
+    for (uint32_t w = tid; w < 2u * M; w += T) {
+        const bool moments = w >= M;
+        const uint32_t i = moments ? w - M : w;
         const uint32_t s = L.list[i];
         const uint64_t key = L.key[s];
         int sx, sy, sz;
         unpack_key(key, sx, sy, sz);
         const uint32_t n = L.cnt[s];
-        L.mean_z[s] = (n >= (uint32_t)P.min_points) ? node_mean_z(n, L.sum[2][s], axis_centre(sz, P.oz, P.z_len)) : 0.f;
+        const bool has = n >= (uint32_t)P.min_points;
+        if (moments) {
+            StageRow* __restrict__ const row = stage + sbase + i;
+            float mean[3] = {0.f, 0.f, 0.f};
+            double S[6] = {0, 0, 0, 0, 0, 0};
+            if (has) {
+                double sums[9];
+#pragma unroll
+                for (int j = 0; j < 9; ++j) sums[j] = L.sum[j][s];
+                const double c[3] = {axis_centre(sx, P.ox, P.grid_len), axis_centre(sy, P.oy, P.grid_len), axis_centre(sz, P.oz, P.z_len)};
+                node_moments(n, sums, c, mean, S);
+            }
+            for (int q = 0; q < 3; ++q) row->mean[q] = mean[q];
+            for (int q = 0; q < 6; ++q) row->scatter[q] = S[q];
+            continue;
+        }
+        L.mean_z[s] = has ? node_mean_z(n, L.sum[2][s], axis_centre(sz, P.oz, P.z_len)) : 0.f;
         const uint64_t ck = column_key(key);
         uint32_t c = ((column_hash(sx, sy) * 0x85EBCA77u) >> 12) & (uint32_t)(H - 1);
         for (int probe = 0; probe < H; ++probe) {            // (terminates: the table has more slots than nodes)
@@ -225,12 +250,12 @@ __device__ __forceinline__ void bucket_direct_one(BucketLds3<H>& L, const uint32
         }
         L.cslot[s] = (uint16_t)c;
     }
-    __syncthreads();
+    lds_barrier();                                 // (the moments' row stores stay in flight)
     GNDT_STAMP3(3);
     if (tid == 0) atomicAdd(&cnt->num_columns, L.n_cols);
 
     // ---- rows: slope label (OcNode::isSlope, map2D.h:66-108), index in column, column size and first-seen index by
-    //      walking the column's short list; mean + fp64 scatter -> staging row ----
+    //      walking the column's short list -> the head of the staging row ----
     uint32_t my_slopes = 0;
     for (uint32_t i = tid; i < M; i += T) {
         const uint32_t s = L.list[i];
@@ -263,28 +288,18 @@ __device__ __forceinline__ void bucket_direct_one(BucketLds3<H>& L, const uint32
             if (P.demand == 0) slope = !up; else down = false;
             if (slope) { fl |= 2u; if (down) fl |= 4u; ++my_slopes; }
         }
-        StageRow row;
-        row.sx = sx; row.sy = sy; row.sz = sz;
-        row.count = my_n; row.first = my_first; row.flags = fl;
-        for (int k = 0; k < 3; ++k) row.mean[k] = 0.f;
-        for (int k = 0; k < 6; ++k) row.scatter[k] = 0.0;
-        if (fl & 1u) {
-            double sums[9];
-#pragma unroll
-            for (int j = 0; j < 9; ++j) sums[j] = L.sum[j][s];
-            const double c[3] = {axis_centre(sx, P.ox, P.grid_len), axis_centre(sy, P.oy, P.grid_len), axis_centre(sz, P.oz, P.z_len)};
-            node_moments(row.count, sums, c, row.mean, row.scatter);
-        }
-        row.col_first = cf; row.idx_in_col = icol; row.ncol = ncol;
         const uint32_t dst = sbase + i;
-        stage[dst] = row;
+        StageRow* __restrict__ const row = stage + dst;
+        row->sx = sx; row->sy = sy; row->sz = sz;
+        row->count = my_n; row->first = my_first; row->flags = fl;
+        row->col_first = cf; row->idx_in_col = icol; row->ncol = ncol;
         ord_cf[dst] = cf;
         ord_idx[dst] = icol;
         if (icol == 0) note_column(O, cf, ncol);
     }
     // counters: aggregated in LDS, ONE memory-side atomic per bucket and counter
     if (my_slopes) atomicAdd(&L.n_slopes, my_slopes);
-    __syncthreads();
+    lds_barrier();
     if (tid == 0 && L.n_slopes) atomicAdd(&cnt->num_slopes, L.n_slopes);
     GNDT_STAMP3(4);
 #undef GNDT_STAMP3
@@ -303,7 +318,7 @@ __global__ void __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(H <= 512
     for (uint32_t bucket = blockIdx.x; bucket < num_buckets; bucket += gridDim.x) {
         bucket_direct_one<T, H, STATS>(L, bucket, recs, range_lo[bucket], range_hi[bucket], P, stage, stage_cap, ord_cf, ord_idx, O,
                                        cnt, pc, dbg, so);
-        __syncthreads();        // the LDS tables are re-initialised by the next bucket
+        lds_barrier();          // the LDS tables are re-initialised by the next bucket
     }
 }
 

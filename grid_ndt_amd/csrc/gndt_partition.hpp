@@ -289,7 +289,10 @@ __global__ void __launch_bounds__(kPartThreads) k_part_scatter(const float* __re
 // ---------------------------------------------------------------------------------------------
 constexpr int kTileThreads = 512;
 constexpr int kTilePer1 = 8;       // level 1: 4096 records per tile (68 KB of LDS); smaller tiles measured slower here
-constexpr int kTilePer2 = 4;       // level 2: 2048 records per tile (34 KB): four tiles resident per CU
+#ifndef GNDT_TILE_PER2
+#define GNDT_TILE_PER2 4
+#endif
+constexpr int kTilePer2 = GNDT_TILE_PER2;       // level 2: 2048 records per tile (34 KB): four tiles resident per CU
 constexpr int kMaxFan = 512;               // fan-out per level: up to 512 x 512 buckets
 constexpr uint32_t kSampleEvery = 64;      // level 1 samples one record in 64 to size the buckets' regions (the hash test below is >> 26)
 
@@ -316,6 +319,9 @@ __device__ __forceinline__ void tile_partition(TileLds<PER, FAN>& L, const float
                                                const uint32_t* __restrict__ dcap, float4* __restrict__ out,
                                                PartCounters* __restrict__ pc) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // the regions' bases / capacities do not depend on the tile: requested first, used by the copy-out
+    uint32_t my_dbase = 0, my_room = cap;
+    if (dbase && (uint32_t)tid < nd) { my_dbase = dbase[tid]; my_room = dcap[tid]; }
     for (uint32_t d = tid; d < nd; d += kTileThreads) L.hist[d] = 0u;
     __syncthreads();
     uint32_t rank[PER];
@@ -348,10 +354,9 @@ __device__ __forceinline__ void tile_partition(TileLds<PER, FAN>& L, const float
             L.digit[pos] = (typename TileLds<PER, FAN>::Digit)dig[j];
         }
     if ((uint32_t)tid < nd) {
-        const uint32_t room = dbase ? dcap[tid] : cap;
-        if (c && g + c > room) atomicAdd(&pc->part_overflow, 1u);
+        if (c && g + c > my_room) atomicAdd(&pc->part_overflow, 1u);
         L.gbase[tid] = g;
-        if (dbase) { L.dbase[tid] = dbase[tid]; L.dcap[tid] = room; }
+        if (dbase) { L.dbase[tid] = my_dbase; L.dcap[tid] = my_room; }
     }
     __syncthreads();
     const uint32_t total = L.scan[nd];
