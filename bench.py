@@ -41,6 +41,8 @@ WORKLOADS = {
                 points=10_000_000, grid_len=0.5, z_len=0.1, hint=3_400_000),
     "S3": dict(desc="S3: LiDAR-ordered outdoor terrain, 0.2 m cubic voxels, demand=slope (BASELINE.json configs[2])",
                points=100_000_000, grid_len=0.2, z_len=0.2, hint=0),
+    "S4": dict(desc="S4: streaming 10 Hz LiDAR frames of 131072 points over the S3 terrain, incremental update per frame, 0.2 m cubic "
+                    "voxels (BASELINE.json configs[3])", points=131_072, grid_len=0.2, z_len=0.2, hint=4_000_000),
     "S5": dict(desc="S5: two-storey site (site125 stand-in), 15 % of the points at (0,0,0), 0.1 m cubic voxels (BASELINE.json configs[4])",
                points=20_000_000, grid_len=0.1, z_len=0.1, hint=0),
 }
@@ -63,6 +65,7 @@ def parse():
     ap.add_argument("--stamps", action="store_true",
                     help="diagnostic: after the timed run, one extra build with in-kernel phase stamps (stderr)")
     ap.add_argument("--nodes-hint", type=int, default=-1, help="max_nodes_hint (-1 = the workload's default)")
+    ap.add_argument("--graph", action="store_true", help="S4: replay one captured update per frame (hipGraph) instead of eager launches")
     ap.add_argument("--launch-check", action="store_true",
                     help="CPU-only check of the self-launch path: the ranks rendezvous over gloo, shard a small cloud "
                          "exactly as the timed run would, and rank 0 prints what every rank got")
@@ -190,8 +193,81 @@ def launch_check(a, rank, world):
     dist.destroy_process_group()
 
 
+def run_stream(a):
+    """--workload S4: a step is ONE frame of 131072 points added to the map (gndt_update_device: accumulate into the HBM node
+    table, relabel the touched columns, re-order and re-emit the rows).  `value` counts the timed frames' points against the
+    wall time of the back-to-back loop; the per-frame latency (launch -> results ready) is measured in a second, synchronised
+    pass over the same frames."""
+    import torch
+    import grid_ndt_amd as g
+    from grid_ndt_amd import scenes
+    g.build_native()
+    W = WORKLOADS["S4"]
+    ppf = scenes.FRAME_POINTS
+    nframes = a.warmup + a.steps + 1
+    frames = scenes.terrain_frames(nframes, 0)
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(0)
+    dev_frames = [torch.from_numpy(frames[f * ppf:(f + 1) * ppf]).to(dev) for f in range(nframes)]
+    hint = W["hint"] if a.nodes_hint < 0 else a.nodes_hint
+
+    def run(sync_each):
+        m = g.TwoDmap(W["grid_len"], W["z_len"], strategy=a.strategy or 1, max_nodes_hint=hint, max_points_hint=nframes * ppf)
+        m.setInterval(0.08)
+        m.setCloudFirst(frames[0])
+        buf = torch.empty(ppf, 3, dtype=torch.float32, device=dev)
+        buf.copy_(dev_frames[0][:ppf])
+        m.change2DMap("slope", buf)      # frame 0 (its point 0 is the origin AND a point of the stream, as tools/measure_configs.py did)
+        m.sync()
+        graph = None
+        if a.graph:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                m.change2DMap("slope", buf)
+        lat = []
+        for f in range(1, a.warmup + 1):
+            buf.copy_(dev_frames[f])
+            graph.replay() if graph else m.change2DMap("slope", buf)
+        m.sync()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for f in range(a.warmup + 1, nframes):
+            buf.copy_(dev_frames[f])
+            if sync_each:
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+            graph.replay() if graph else m.change2DMap("slope", buf)
+            if sync_each:
+                torch.cuda.synchronize()
+                lat.append((time.perf_counter() - t1) * 1e3)
+        nodes, cols, slopes = m.sync()
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0, lat, (nodes, cols, slopes), m
+
+    dt, _, (nodes, cols, slopes), m = run(False)
+    strat = m.STRATEGY_NAMES.get(m.last_strategy(), "?")
+    del m
+    _, lat, _, _ = run(True)
+    lat = np.sort(np.array(lat))
+    ms_step = dt / a.steps * 1e3
+    path_bytes = BYTES_PER_POINT * ppf + BYTES_PER_NODE * nodes      # a frame re-emits the whole map's rows
+    out = {"metric": "NDT grid-build throughput (bin + mean/cov + eigen + labels + ordering)", "value": round(ppf / (dt / a.steps) / 1e6, 3),
+           "unit": "Mpoints/s", "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_step, 4), "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None, "dtype": "f64", "io_dtype": "f32", "data": "synthetic",
+           "config": {"workload": W["desc"], "points_per_frame": ppf, "frames_timed": a.steps, "nodes_at_the_end": int(nodes), "columns": int(cols),
+                      "slopes": int(slopes), "strategy": strat, "hip_graph_replay": bool(a.graph), "max_nodes_hint": int(hint)},
+           "frame_latency_ms": {"p50": round(float(np.percentile(lat, 50)), 4), "p99": round(float(np.percentile(lat, 99)), 4),
+                                "max": round(float(lat.max()), 4), "budget": 100.0,
+                                "what": "one frame, launch -> device idle (host-timed, synchronised before and after)"},
+           "roofline": None, "path_roofline": {"bytes": int(path_bytes), "frac": round(path_bytes / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
+           "cpu_baseline": None}
+    print(json.dumps(out))
+
+
 def main():
     a = parse()
+    if a.workload == "S4":
+        return run_stream(a)
     if a.gpus > 1 and "RANK" not in os.environ:
         sys.exit(self_launch(a))
 

@@ -365,7 +365,27 @@ int gndt_build_device(gndt_handle* h, const void* xyz_dev, size_t n, size_t stri
     { const int urc = use_stream(h, s); if (urc) return urc; }
     next_event_set(h);
     int strategy = h->P.strategy;
-    if (strategy == GNDT_STRATEGY_AUTO) strategy = (n >= (1u << 16)) ? GNDT_STRATEGY_PARTITION : GNDT_STRATEGY_ATOMIC;
+    if (strategy == GNDT_STRATEGY_AUTO) {
+        strategy = (n >= (1u << 16)) ? GNDT_STRATEGY_PARTITION : GNDT_STRATEGY_ATOMIC;
+        // Clouds that keep their scan order can be built in ONE pass (strategy TILE) when a flush of a workgroup's private
+        // table carries many points per node.  That ratio is MEASURED on a sample of this cloud (64 tiles of 2048
+        // consecutive points, ~20 us + one host wait); the answer is kept for the handle and re-measured when the cloud
+        // size changes by a quarter or after 64 builds.
+        if (n >= (1u << 18)) {
+            const bool stale = h->tile_choice < 0 || ++h->tile_choice_age >= 64 ||
+                               n > h->tile_choice_n + h->tile_choice_n / 4 || n + n / 4 < h->tile_choice_n;
+            if (stale) {
+                double ratio = 0.0;
+                rc = locality_sample(h, xyz_dev, n, stride_bytes, 64, &ratio, s);
+                if (rc) return rc;
+                h->tile_choice = ratio >= tuning().tile_ratio ? 1 : 0;
+                h->tile_choice_n = n; h->tile_choice_age = 0; h->tile_ratio_seen = ratio;
+                if (tuning().verbose) fprintf(stderr, "[gndt] locality sample: %.1f points per partial -> %s\n", ratio, h->tile_choice ? "TILE" : "PARTITION");
+            }
+            if (h->tile_choice == 1) strategy = GNDT_STRATEGY_TILE;
+        }
+    }
+    if (strategy == GNDT_STRATEGY_TILE) return build_atomic(h, xyz_dev, n, stride_bytes, s, true);
     if (strategy == GNDT_STRATEGY_PARTITION || strategy == GNDT_STRATEGY_PARTITION_EXACT || strategy == GNDT_STRATEGY_PARTITION_TWO_LEVEL) {
         // launched, not awaited: gndt_sync / gndt_export* (or whatever needs the result next) waits, checks the
         // overflow flags and re-runs with more room if needed.  xyz_dev stays the caller's until then.

@@ -24,6 +24,8 @@ Tuning parse_tuning() {
     t.l1_rep = geti("GNDT_L1_REP", t.l1_rep);
     t.l1_wgs = (uint32_t)geti("GNDT_L1_WGS", (int)t.l1_wgs);
     if (getenv("GNDT_BUCKET_WGS")) t.bucket_wgs = (uint32_t)atoi(getenv("GNDT_BUCKET_WGS"));
+    if (getenv("GNDT_TILE_RATIO")) t.tile_ratio = atof(getenv("GNDT_TILE_RATIO"));
+    t.update_tile = geti("GNDT_UPDATE_TILE", t.update_tile);
     t.stamps = getenv("GNDT_STAMPS") != nullptr;
     t.verbose = getenv("GNDT_VERBOSE") != nullptr;
     return t;
@@ -156,7 +158,7 @@ int use_stream(gndt_handle* h, hipStream_t s) {
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     (void)hipStreamIsCapturing(s, &cap);
     // (a stream under graph capture cannot wait for un-captured work: the caller orders the capture itself)
-    if (h->last_stream && h->last_stream != s && cap == hipStreamCaptureStatusNone) {
+    if (h->last_stream != s && cap == hipStreamCaptureStatusNone) {     // (last_stream is always a stream: own_stream from gndt_create on)
         if (!h->xstream_ev) HIP_TRY(h, hipEventCreateWithFlags(&h->xstream_ev, hipEventDisableTiming));
         HIP_TRY(h, hipEventRecord(h->xstream_ev, h->last_stream));
         HIP_TRY(h, hipStreamWaitEvent(s, h->xstream_ev, 0));
@@ -229,6 +231,8 @@ void gndt_destroy(gndt_handle* h) {
             if (e) (void)hipEventDestroy(e);
     if (h->h_cnt) (void)hipHostFree(h->h_cnt);
     if (h->xstream_ev) (void)hipEventDestroy(h->xstream_ev);
+    if (h->d_sample) (void)hipFree(h->d_sample);
+    if (h->h_sample) (void)hipHostFree(h->h_sample);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     delete h;
 }

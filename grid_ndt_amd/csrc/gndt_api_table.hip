@@ -1,6 +1,7 @@
 // gndt_api_table.hip — strategy ATOMIC: the HBM node table (accumulate, incremental update, finalize, statistics export / merge).
 #include "gndt_handle.hpp"
 #include "gndt_table.hpp"
+#include "gndt_tile.hpp"
 using namespace gndt;
 using namespace gndt_host;
 
@@ -77,13 +78,24 @@ int grow_table(gndt_handle* h, uint32_t new_cap, hipStream_t s);
 
 // `base_from_device`: first_idx base = the device-side stream position (incremental updates)
 int do_accumulate(gndt_handle* h, const void* xyz_dev, size_t n, size_t stride_bytes, uint64_t first_base,
-                  int base_from_device, hipStream_t s, int mark = 0) {
+                  int base_from_device, hipStream_t s, int mark = 0, bool tile = false) {
     if (stride_bytes != 12 && stride_bytes != 16) { h->err = "stride_bytes must be 12 or 16"; return GNDT_ERR_INVALID; }
     if (first_base + n >= 0xFFFFFFFFull) { h->err = "point index exceeds 32 bits"; return GNDT_ERR_INVALID; }
     if (n == 0) return GNDT_OK;
     const float* p = static_cast<const float*>(xyz_dev);
     const int blocks = grid_for(n, kBlock, 256 * 16);
-    if (stride_bytes == 12)
+    if (tile) {
+        // strategy TILE: contiguous ranges, LDS-privatised partials (gndt_tile.hpp); two resident workgroups per CU
+        const int wgs = (int)std::min<uint64_t>(512, (n + kTileCheck - 1) / kTileCheck);
+        if (stride_bytes == 12)
+            hipLaunchKernelGGL(k_tile_accumulate<3>, dim3(wgs), dim3(kTileT), 0, s, p, (uint64_t)n, (uint32_t)first_base, base_from_device,
+                               grid_params(h), h->keys, h->acc, h->cap - 1, h->node_slot, h->index_of_slot, h->touch_epoch, h->touched, mark,
+                               h->d_cnt);
+        else
+            hipLaunchKernelGGL(k_tile_accumulate<4>, dim3(wgs), dim3(kTileT), 0, s, p, (uint64_t)n, (uint32_t)first_base, base_from_device,
+                               grid_params(h), h->keys, h->acc, h->cap - 1, h->node_slot, h->index_of_slot, h->touch_epoch, h->touched, mark,
+                               h->d_cnt);
+    } else if (stride_bytes == 12)
         hipLaunchKernelGGL(k_accumulate<3>, dim3(blocks), dim3(kBlock), 0, s, p, (uint64_t)n, (uint32_t)first_base,
                            base_from_device, grid_params(h), h->keys, h->acc, h->cap - 1, h->node_slot, h->index_of_slot,
                            h->touch_epoch, h->touched, mark, h->d_cnt);
@@ -215,9 +227,29 @@ int grow_table(gndt_handle* h, uint32_t new_cap, hipStream_t s) {
 }  // namespace
 
 // strategy ATOMIC from empty; waits for the result (the retry on a full table needs the device-side flags)
-int build_atomic(gndt_handle* h, const void* xyz_dev, size_t n, size_t stride_bytes, hipStream_t s) {
+int locality_sample(gndt_handle* h, const void* xyz_dev, size_t n, size_t stride_bytes, uint32_t tiles, double* ratio, hipStream_t s) {
+    if (stride_bytes != 12 && stride_bytes != 16) { h->err = "stride_bytes must be 12 or 16"; return GNDT_ERR_INVALID; }
+    *ratio = 0.0;
+    if (n == 0 || tiles == 0) return GNDT_OK;
+    if (!h->d_sample) {
+        HIP_TRY(h, hipMalloc(&h->d_sample, 2 * sizeof(unsigned long long)));
+        HIP_TRY(h, hipHostMalloc(&h->h_sample, 2 * sizeof(unsigned long long)));
+    }
+    tiles = (uint32_t)std::min<uint64_t>(tiles, (n + kTileCheck - 1) / kTileCheck);
+    HIP_TRY(h, hipMemsetAsync(h->d_sample, 0, 2 * sizeof(unsigned long long), s));
+    const float* p = static_cast<const float*>(xyz_dev);
+    if (stride_bytes == 12) hipLaunchKernelGGL(k_tile_sample<3>, dim3(tiles), dim3(kTileT), 0, s, p, (uint64_t)n, grid_params(h), tiles, h->d_sample);
+    else hipLaunchKernelGGL(k_tile_sample<4>, dim3(tiles), dim3(kTileT), 0, s, p, (uint64_t)n, grid_params(h), tiles, h->d_sample);
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipMemcpyAsync(h->h_sample, h->d_sample, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+    HIP_TRY(h, hipStreamSynchronize(s));
+    *ratio = h->h_sample[1] ? (double)h->h_sample[0] / (double)h->h_sample[1] : (double)h->h_sample[0];
+    return GNDT_OK;
+}
+
+int build_atomic(gndt_handle* h, const void* xyz_dev, size_t n, size_t stride_bytes, hipStream_t s, bool tile) {
     int rc;
-    h->last_strategy = GNDT_STRATEGY_ATOMIC;
+    h->last_strategy = tile ? GNDT_STRATEGY_TILE : GNDT_STRATEGY_ATOMIC;
     h->map_in_table = true;
     uint64_t expect = h->P.max_nodes_hint ? h->P.max_nodes_hint : std::max<uint64_t>(1024, n / 4);
     for (int attempt = 0; attempt < 8; ++attempt) {
@@ -227,7 +259,7 @@ int build_atomic(gndt_handle* h, const void* xyz_dev, size_t n, size_t stride_by
         rc = do_reset(h, s);
         if (rc) return rc;
         mark(h, 1, s);
-        rc = do_accumulate(h, xyz_dev, n, stride_bytes, 0, 0, s);
+        rc = do_accumulate(h, xyz_dev, n, stride_bytes, 0, 0, s, 0, tile);
         if (rc) return rc;
         h->stream_pos = n;
         hipLaunchKernelGGL(k_raise_stream, dim3(1), dim3(64), 0, s, h->d_cnt, (uint32_t)n);
@@ -318,7 +350,9 @@ int gndt_update_device(gndt_handle* h, const void* xyz_dev, size_t n, size_t str
     // are still in place, only the columns holding a touched node are relabelled (the ordering and the emit pass
     // still cover the whole map: rows move when a column in front of them grows).
     const bool incr = h->incr_ok;
-    rc = do_accumulate(h, xyz_dev, n, stride_bytes, h->stream_pos, 1, s, incr ? 1 : 0);
+    bool tile = n >= 4096 && (h->P.strategy == GNDT_STRATEGY_TILE || (h->P.strategy == GNDT_STRATEGY_AUTO && h->tile_choice == 1));
+    if (tuning().update_tile >= 0) tile = n >= 4096 && tuning().update_tile == 1;
+    rc = do_accumulate(h, xyz_dev, n, stride_bytes, h->stream_pos, 1, s, incr ? 1 : 0, tile);
     if (rc) return rc;
     h->stream_pos += n;
     return do_finalize(h, s, incr, n);
@@ -391,6 +425,17 @@ int gndt_stats_merge_device(gndt_handle* h, const gndt_stats* in, void* hip_stre
         h->nodes_bound = h->h_cnt->num_nodes;
     }
     return GNDT_OK;
+}
+
+
+int gndt_locality_sample(gndt_handle* h, const void* xyz_dev, size_t n, size_t stride_bytes, uint32_t tiles, double* points_per_partial,
+                         void* hip_stream) {
+    int rc = check_ready(h);
+    if (rc) return rc;
+    if (!points_per_partial || (!xyz_dev && n)) { h->err = "null argument"; return GNDT_ERR_INVALID; }
+    hipStream_t s = stream_of(h, hip_stream);
+    { const int urc = use_stream(h, s); if (urc) return urc; }
+    return locality_sample(h, xyz_dev, n, stride_bytes, tiles, points_per_partial, s);
 }
 
 }  // extern "C"

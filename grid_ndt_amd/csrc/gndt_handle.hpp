@@ -118,6 +118,9 @@ struct gndt_handle {
     } cost;
     uint64_t result_serial = 0;         // bumped whenever a build / finalize produces new result rows
     int last_strategy = GNDT_STRATEGY_ATOMIC;
+    // strategy AUTO: what the locality sample said last time, for which cloud size, and how many builds ago
+    int tile_choice = -1;  uint64_t tile_choice_n = 0;  int tile_choice_age = 0;  double tile_ratio_seen = 0.0;
+    unsigned long long* d_sample = nullptr;  unsigned long long* h_sample = nullptr;   // k_tile_sample's two counters (pinned copy)
     bool map_in_table = true;   // false after a PARTITION build: the HBM node table does not hold the map
 
     // optional phase timing (bench / profiling): events recorded on the launch stream
@@ -161,6 +164,9 @@ struct Tuning {
     int l1_rep = 1;              // GNDT_L1_REP         level-1 cursor replicas
     uint32_t l1_wgs = 1024;      // GNDT_L1_WGS         persistent level-1 workgroups
     uint32_t bucket_wgs = 0xFFFFFFFFu;   // GNDT_BUCKET_WGS   persistent bucket workgroups (default: one per bucket)
+    double tile_ratio = 48.0;    // GNDT_TILE_RATIO     AUTO takes strategy TILE from this many points per partial on (sampled; the
+                                 //                     measured crossover, profiles/r02_tile_calibration.json)
+    int update_tile = -1;        // GNDT_UPDATE_TILE    incremental updates through the tile kernel: 1 always, 0 never, -1 = by strategy
     bool stamps = false;         // GNDT_STAMPS=1       in-kernel phase stamps of the bucket kernel
     bool verbose = false;        // GNDT_VERBOSE=1      stderr line per resolved two-level build
 };
@@ -218,7 +224,12 @@ inline GridParams grid_params(const gndt_handle* h) {
 // slots wanted for `nodes` occupied entries (load factor <= 1/2)
 inline uint32_t cap_for_nodes(uint64_t nodes) { return pow2_ceil(std::max<uint64_t>(2048, nodes * 2)); }
 
-inline hipStream_t stream_of(gndt_handle* h, void* hip_stream) { return hip_stream ? (hipStream_t)hip_stream : h->own_stream; }
+// NULL = the handle's own stream; hipStreamLegacy (the null stream by its explicit name) = the null stream handle itself,
+// which every HIP call accepts (some do not accept the named constant)
+inline hipStream_t stream_of(gndt_handle* h, void* hip_stream) {
+    if (!hip_stream) return h->own_stream;
+    return (hipStream_t)hip_stream == hipStreamLegacy ? (hipStream_t) nullptr : (hipStream_t)hip_stream;
+}
 
 template <typename T>
 int grow_buf(gndt_handle* h, T*& p, uint64_t& cap, uint64_t want) {
@@ -245,7 +256,8 @@ void free_part(gndt_handle* h);
 void free_table(gndt_handle* h);
 int alloc_table(gndt_handle* h, uint32_t cap, hipStream_t s);
 int do_reset(gndt_handle* h, hipStream_t s);
-int build_atomic(gndt_handle* h, const void* xyz_dev, size_t n, size_t stride_bytes, hipStream_t s);
+int build_atomic(gndt_handle* h, const void* xyz_dev, size_t n, size_t stride_bytes, hipStream_t s, bool tile = false);
+int locality_sample(gndt_handle* h, const void* xyz_dev, size_t n, size_t stride_bytes, uint32_t tiles, double* ratio, hipStream_t s);
 // ---- gndt_api_build.hip ----
 int launch_order_and_emit(gndt_handle* h, uint64_t words, int m0, hipStream_t s);
 int partition_launch(gndt_handle* h, gndt_handle::Pending& P);

@@ -16,17 +16,23 @@ DEMANDS = {"slope": 0, "true": 1}
 FLAG_HAS_STATS, FLAG_SLOPE, FLAG_DOWN = 1, 2, 4
 
 
+_HIP_STREAM_LEGACY = 1      # hipStreamLegacy ((hipStream_t)1): the null stream by its explicit name
+
+
 def _stream_ptr(stream):
+    """libgndt takes NULL as "the handle's own (non-blocking) stream".  torch's default stream IS the null stream
+    (cuda_stream == 0), and work the caller enqueues there — filling the input buffer, say — is not ordered with a
+    non-blocking stream: the null stream is therefore passed by its explicit name, hipStreamLegacy."""
     if stream is None:
         try:
             import torch
             if torch.cuda.is_available():
-                return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+                return C.c_void_p(torch.cuda.current_stream().cuda_stream or _HIP_STREAM_LEGACY)
         except ImportError:
             pass
         return C.c_void_p(0)
     if hasattr(stream, "cuda_stream"):
-        return C.c_void_p(stream.cuda_stream)
+        return C.c_void_p(stream.cuda_stream or _HIP_STREAM_LEGACY)
     return C.c_void_p(int(stream))
 
 
@@ -258,9 +264,10 @@ class TwoDmap:
 
     # ---- phase timing ----
     PHASES = {1: ("clear", "accumulate", "columns", "rows", "bitmap_scan", "rank", "column_scan", "dest", "emit"),
+              5: ("clear", "accumulate", "columns", "rows", "bitmap_scan", "rank", "column_scan", "dest", "emit"),
               2: ("clear", "level1", "unused", "level2", "bucket_build", "bitmap_scan", "rank", "column_scan", "dest", "emit"),
               3: ("clear", "hist", "offsets", "scatter", "bucket_build", "bitmap_scan", "rank", "column_scan", "dest", "emit")}
-    STRATEGY_NAMES = {1: "atomic", 2: "partition", 3: "partition_exact"}
+    STRATEGY_NAMES = {1: "atomic", 2: "partition", 3: "partition_exact", 5: "tile"}
     # phase -> the kernel that fills it, and what each phase's kernel moves algorithmically (bench.py's roofline line):
     # kernels that stream the cloud 12 B/point, the bucket kernel 12 B/point + 76 B/node, node kernels 76 B/node
     KERNEL_OF_PHASE = {"accumulate": "k_accumulate", "hist": "k_part_hist", "scatter": "k_part_scatter",
@@ -272,6 +279,16 @@ class TwoDmap:
     def set_profiling(self, on=True, demand="slope"):
         self._ensure(demand)
         self._check(self._L.gndt_set_profiling(self._h, int(on)))
+
+    def locality_sample(self, points, tiles=64, demand="slope", stream=None):
+        """Points per partial that strategy TILE would flush, measured on `tiles` tiles of the device-resident cloud."""
+        self._ensure(demand)
+        ptr, n, stride, on_dev, keep = self._as_input(points)
+        if not on_dev:
+            raise GndtError(1, "locality_sample takes device memory")
+        r = C.c_double()
+        self._check(self._L.gndt_locality_sample(self._h, C.c_void_p(ptr), n, stride, int(tiles), C.byref(r), _stream_ptr(stream)))
+        return r.value
 
     def last_strategy(self):
         """1 = ATOMIC, 2 = PARTITION (two-level), 3 = PARTITION_EXACT: what the last build actually ran."""

@@ -58,7 +58,11 @@ enum {
     GNDT_STRATEGY_PARTITION = 2,  /* partition by column hash, then LDS-resident accumulation; large builds use the
                                      two-level partition without counting passes and fall back to the exact one */
     GNDT_STRATEGY_PARTITION_EXACT = 3,      /* always the single-level counting partition (histogram + offsets + scatter) */
-    GNDT_STRATEGY_PARTITION_TWO_LEVEL = 4   /* the two-level partition whatever the size (PARTITION picks it from 2^20 points) */
+    GNDT_STRATEGY_PARTITION_TWO_LEVEL = 4,  /* the two-level partition whatever the size (PARTITION picks it from 2^20 points) */
+    GNDT_STRATEGY_TILE = 5        /* one pass for clouds that keep their scan order: contiguous ranges of the cloud, node table
+                                     privatised in LDS per workgroup, ONE partial per distinct node and flush into the HBM node
+                                     table (gndt_tile.hpp).  AUTO takes it when a sample of the cloud shows enough points per
+                                     partial (gndt_locality_sample); like ATOMIC it keeps additive state (updates, statistics) */
 };
 
 typedef struct {
@@ -119,7 +123,8 @@ int gndt_get_origin(const gndt_handle* h, float origin_xyz[3]);
 /* Host memory in (e.g. pcl::PointCloud<PointXYZ>::points.data()+1, stride 16).  Synchronous. */
 int gndt_build(gndt_handle* h, const void* xyz_host, size_t n, size_t stride_bytes);
 /* Device memory in; all work is enqueued on `hip_stream` (a hipStream_t, may be NULL = the handle's own
- * stream).  stride_bytes is 12 (packed) or 16 (PointXYZ).
+ * NON-BLOCKING stream: work the caller has on the null stream is not ordered with it — a caller that fills its input on the
+ * null stream passes hipStreamLegacy, the null stream's explicit name, instead).  stride_bytes is 12 (packed) or 16 (PointXYZ).
  * Partition strategies: the call returns once everything is enqueued.  The device-side overflow flags are read by
  * the next call that needs the result (gndt_sync, gndt_export*, gndt_compute_cost, ...), which waits for the
  * stream and, if a table or region was too small, re-runs the build with more room — so `xyz_dev` must stay valid
@@ -263,6 +268,10 @@ int gndt_set_profiling(gndt_handle* h, int enable);
 int gndt_get_phase_times(gndt_handle* h, double ms_out[GNDT_NUM_PHASES]);
 /* GNDT_STRATEGY_ATOMIC, _PARTITION (two-level) or _PARTITION_EXACT: what the last build actually ran (AUTO resolves,
  * and PARTITION falls back to ATOMIC when a bucket does not fit in LDS). */
+/* The measurement AUTO bases that choice on, for logs and tuning: `tiles` tiles of 2048 consecutive points spread over the
+ * cloud; *points_per_partial = points looked at / distinct nodes met per tile.  Waits for the result. */
+int gndt_locality_sample(gndt_handle* h, const void* xyz_dev, size_t n, size_t stride_bytes, uint32_t tiles, double* points_per_partial,
+                         void* hip_stream);
 int gndt_last_strategy(const gndt_handle* h);
 /* Diagnostic (not for timed runs): with the environment variable GNDT_STAMPS=1 set, k_bucket_build
  * stamps the shader clock at its phase boundaries; this returns the mean cycles per bucket of

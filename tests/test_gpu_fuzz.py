@@ -46,7 +46,7 @@ def _cloud(seed):
 def test_random_structured_clouds_every_strategy(seed):
     cloud, P = _cloud(1000 + seed)
     ref = parity.ref_from_cloud(cloud, P)
-    for strategy in (1, 3, 4):
+    for strategy in (1, 3, 4, 5):
         m, out = parity.gpu_from_cloud(cloud, P, on_device=True, strategy=strategy)
         parity.assert_parity(out, ref)
 

@@ -49,7 +49,7 @@ def _case(name):
 # partition forced at any size (2 = PARTITION picks it from 2^20 points).  A forced partition build must end on
 # the LDS-resident pipeline: a low node estimate is retried with more buckets (the ATOMIC fallback is for clouds
 # needing more buckets than one level can address), an overflowing two-level region falls back to the exact one.
-@pytest.mark.parametrize("strategy", [1, 3, 4], ids=["atomic", "partition_exact", "partition_two_level"])
+@pytest.mark.parametrize("strategy", [1, 3, 4, 5], ids=["atomic", "partition_exact", "partition_two_level", "tile"])
 @pytest.mark.parametrize("name", list(CASES))
 def test_parity_device_input(name, strategy):
     cloud, P, ref = _case(name)
@@ -58,7 +58,7 @@ def test_parity_device_input(name, strategy):
     ran = m.last_strategy()
     print(name, "ran", m.STRATEGY_NAMES[ran], {k: v for k, v in rep.items() if k not in ("fail",)})
     # (a two-level build whose fixed-capacity regions overflow ends on the exact partition: allowed, not expected here)
-    assert ran == {1: 1, 3: 3, 4: 2}[strategy], (name, ran)
+    assert ran == {1: 1, 3: 3, 4: 2, 5: 5}[strategy], (name, ran)
 
 
 def test_partition_with_node_hint_handles_dense_node_sets():
@@ -207,7 +207,7 @@ def test_edge_inputs():
         same = np.tile(np.float32([[3.3, -2.2, 0.77]]), (n, 1))
         cloud = np.concatenate([np.float32([[0, 0, 0]]), same], 0)
         ref = parity.ref_from_cloud(cloud, scenes.CAMPUS_PARAMS)
-        for strategy in (1, 3, 4):
+        for strategy in (1, 3, 4, 5):
             _, o = parity.gpu_from_cloud(cloud, scenes.CAMPUS_PARAMS, strategy=strategy)
             parity.assert_parity(o, ref)
     # key range: |nx| > 65535 must be an error, not a silent wrap (Stopwatch.h:102-110)
@@ -512,3 +512,37 @@ def test_long_stream_incremental_finalisation_equals_batch_builds():
     after = m.export()
     assert np.array_equal(after["sx"], before["sx"]) and np.array_equal(after["first_idx"], before["first_idx"])
     assert int(after["count"].astype(np.int64).sum()) == int(before["count"].astype(np.int64).sum()) + cuts[3]
+
+
+@pytest.mark.gpu
+def test_auto_takes_the_one_pass_tile_strategy_only_where_the_sampled_locality_pays():
+    """Strategy AUTO measures points per partial on a sample of the cloud (gndt_locality_sample) before it picks the
+    one-pass TILE path.  A dense scan-ordered cloud (many consecutive points per node) must take it and still equal the
+    partition result; a shuffled cloud must not."""
+    import torch
+    import grid_ndt_amd as g
+    rng = np.random.default_rng(5)
+    n = 600_000
+    # dense raster: 300 points per 0.5 m cell in a row, rows one after the other -> long runs of one node
+    t = np.arange(n)
+    x = (t % 60_000) * (100.0 / 60_000) * 0.1 + 0.0003 * rng.random(n)
+    y = (t // 60_000) * 0.5 + 0.2 + 0.1 * rng.random(n)
+    z = 0.05 * np.sin(x) + 0.01 * rng.random(n)
+    dense = np.ascontiguousarray(np.stack([x, y, z], 1).astype(np.float32))
+    shuffled = np.ascontiguousarray(dense[rng.permutation(n)])
+    shuffled[0] = dense[0]
+    P = dict(grid_len=0.5, z_len=0.25, slope_interval=0.08, demand="slope")
+    res = {}
+    for name, cloud in (("dense", dense), ("shuffled", shuffled)):
+        m = g.TwoDmap(P["grid_len"], P["z_len"], strategy=0)
+        m.setInterval(P["slope_interval"]); m.setCloudFirst(cloud[0])
+        pts = torch.from_numpy(cloud[1:]).cuda()
+        ratio = m.locality_sample(pts)
+        m.create2DMap("slope", pts)
+        m.sync()
+        res[name] = (ratio, m.last_strategy(), m.export())
+        print(name, "points per partial %.1f" % ratio, "->", m.STRATEGY_NAMES[m.last_strategy()])
+    assert res["dense"][0] > 48 and res["dense"][1] == 5
+    assert res["shuffled"][0] < 24 and res["shuffled"][1] in (2, 3)
+    ref = parity.ref_from_cloud(dense, P)
+    parity.assert_parity(res["dense"][2], ref)
