@@ -6,6 +6,7 @@
 //    equal the oracle's flood of the SAME exported grid bit for bit, and the planner's route must be the oracle's.
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -55,7 +56,17 @@ static RefPlan reference_plan(const gndt_cells& c, const float* origin, float gl
     return r;
 }
 
+// PLAN_PRINT=1: the planner's route as "key/z key/z ..." (start -> goal) and Slope::h at the start, so that a test can
+// hold it against a route derived by hand (tests/test_planner_hand_routes.py)
+static void print_route(const std::list<Slope*>& got) {
+    if (!std::getenv("PLAN_PRINT")) return;
+    std::printf("route:");
+    for (const Slope* s : got) std::printf(" %s/%d", s->morton_xy.c_str(), s->morton_z);
+    std::printf("\nh_start: %.9g\n", got.empty() ? -1.0 : (double)got.front()->h);
+}
+
 static int same_route(const std::list<Slope*>& got, const RefPlan& ref, const gndt_cells& c, const char* what) {
+    print_route(got);
     CHECK(got.size() == ref.path.size(), "%s: route length %zu != oracle %zu", what, got.size(), ref.path.size());
     size_t k = 0;
     for (const Slope* s : got) {

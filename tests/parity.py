@@ -11,6 +11,11 @@ TOL_COV = 1e-5        # max_ij |d C_ij| <= TOL * max_ij |C_ij|          (vs the 
 TOL_COV_TRUTH = 2e-6  # same against the fp64 truth (fp32 output rounding + fp64 accumulation noise)
 TOL_ROUGH = 1e-5      # |d lambda_min| <= TOL * trace(C)
 TOL_NORMAL = 1e-6     # 1 - |cos| when the minimum eigenvalue is separated: (l_mid - l_min) > 1e-3 * l_max
+# The 1e-5 covariance gate is widened for a node only where the fp32 oracle ITSELF is further than that from the exact
+# scatter, or where the fp32 inputs cannot resolve the scatter at all.  Both escapes are counted and capped:
+MAX_WIDENED_FRACTION = 1e-3   # of the nodes with statistics may pass on a widened allowance ...
+MAX_WIDENING = 10.0           # ... and none by more than this factor over 1e-5
+MAX_UNRESOLVED_FRACTION = 1e-3   # nodes whose scatter lies below the input resolution floor
 
 
 def compare(gpu, ref, demand="slope"):
@@ -84,7 +89,14 @@ def compare(gpu, ref, demand="slope"):
     rep["cov_err"] = float(e32.max())
     rep["cov_err_truth"] = float(e64.max())
     rep["ref_fp32_self_err"] = float(ref_self.max())
-    rep["cov_nodes_over_1e-5_vs_fp32"] = int(np.count_nonzero(e32 > TOL_COV))
+    widened = e32 > TOL_COV                       # nodes that can only pass through one of the escapes below
+    rep["cov_nodes_over_1e-5_vs_fp32"] = int(np.count_nonzero(widened))
+    rep["cov_widening_max"] = float((e32[widened] / TOL_COV).max()) if widened.any() else 1.0
+    n_has = int(np.count_nonzero(has))
+    if np.count_nonzero(widened) > max(1, int(MAX_WIDENED_FRACTION * n_has)):
+        fail(f"{int(np.count_nonzero(widened))} of {n_has} nodes need a widened covariance allowance (cap {MAX_WIDENED_FRACTION:g})")
+    if rep["cov_widening_max"] > MAX_WIDENING:
+        fail(f"covariance allowance widened {rep['cov_widening_max']:.1f}x on some node (cap {MAX_WIDENING:g}x)")
     # Resolution floor of the INPUT: fp32 coordinates near |p| are spaced ulp = 2^-23 |p| apart, so a node whose points
     # differ by a few ulps (lattice points and their float neighbours, duplicates with rounding) has a scatter of the
     # order count * ulp^2 that no arithmetic can resolve to 2e-6 of itself; below that floor only the size is checked.
@@ -94,6 +106,8 @@ def compare(gpu, ref, demand="slope"):
         fail(f"cov error vs fp32 oracle {float((e32 / allow32).max()):.2f}x allowance (max {rep['cov_err']:.3e})")
     over = d64 > np.maximum(TOL_COV_TRUTH * scale, floor)
     rep["cov_nodes_below_input_resolution"] = int(np.count_nonzero(scale <= floor))
+    if rep["cov_nodes_below_input_resolution"] > max(2, int(MAX_UNRESOLVED_FRACTION * n_has)):
+        fail(f"{rep['cov_nodes_below_input_resolution']} nodes below the input resolution floor (cap {MAX_UNRESOLVED_FRACTION:g})")
     if np.any(over):
         worst = float((d64 / np.maximum(TOL_COV_TRUTH * scale, floor)).max())
         fail(f"cov error vs fp64 truth {worst:.2f}x allowance (max rel {rep['cov_err_truth']:.3e}, gate {TOL_COV_TRUTH})")
