@@ -43,6 +43,7 @@ def lib():
         L.oracle_max_threads.restype = C.c_int
         L.oracle_export.argtypes = [C.c_void_p] + [C.c_void_p] * 17
         L.oracle_free.argtypes = [C.c_void_p]
+        L.oracle_set_truth.argtypes = [C.c_int]
         L.oracle_compute_cost.argtypes = [C.c_size_t] + [C.c_void_p] * 8 + [C.POINTER(C.c_float), C.c_float, C.c_float, C.c_float,
                                           C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int, C.c_void_p, C.c_void_p,
                                           C.c_void_p, C.c_void_p, C.POINTER(C.c_float), C.c_void_p, C.c_int64, C.c_void_p]
@@ -77,7 +78,7 @@ MODE_AS_SHIPPED, MODE_INT_SERIAL, MODE_INT_OPENMP = 0, 1, 2
 
 
 def build_grid(cloud, grid_len, z_len, slope_interval, demand="slope", min_points=3, mode=MODE_AS_SHIPPED,
-               threads=0, export=True):
+               threads=0, export=True, truth=None):
     """Run the reference path on `cloud` ([N, 3|4] float32, point 0 = origin and is not binned:
     receiver.cpp:145, 150).  Returns a dict of numpy arrays in the reference's node order."""
     cloud = np.ascontiguousarray(cloud, dtype=np.float32)
@@ -87,6 +88,8 @@ def build_grid(cloud, grid_len, z_len, slope_interval, demand="slope", min_point
     body = cloud[1:]
     dem = {"slope": 0, "true": 1}[demand] if isinstance(demand, str) else int(demand)
     L = lib()
+    # the fp64 "truth" beside the reference arithmetic is for the parity gates; a timed baseline (export=False) leaves it out
+    L.oracle_set_truth(int(export if truth is None else truth))
     h = L.oracle_build(body.ctypes.data if body.size else None, body.shape[0], stride, origin, float(grid_len),
                        float(z_len), float(slope_interval), dem, int(min_points), int(mode), int(threads))
     try:

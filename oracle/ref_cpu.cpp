@@ -47,6 +47,7 @@
 #include <vector>
 #ifdef _OPENMP
 #include <omp.h>
+#include <parallel/algorithm>
 #endif
 
 #include "ref_codec.hpp"
@@ -60,7 +61,11 @@ struct Node {
     std::string morton;   // quadrant + decimal Morton (mode 0 only)
     Key key{};
     std::vector<uint32_t> idx;  // indices of this node's points in arrival order (stands for test_cloud)
+    const uint32_t* idx_ptr = nullptr;  // mode 2 keeps them in one flat array per owner thread instead (same order)
+    uint32_t idx_n = 0;
     uint64_t first_idx = 0;
+    size_t count() const { return idx_ptr ? idx_n : idx.size(); }
+    const uint32_t* points() const { return idx_ptr ? idx_ptr : idx.data(); }
     float mean[3] = {0, 0, 0};          // xyz_centroid, zero-initialised  map2D.h:55
     float cov[6] = {0, 0, 0, 0, 0, 0};  // upper triangle xx,xy,xz,yy,yz,zz of covariance_matrix  map2D.h:54
     int N = 0;                          // map2D.h:56
@@ -71,6 +76,8 @@ struct Node {
     double mean64[3] = {0, 0, 0}, cov64[6] = {0, 0, 0, 0, 0, 0}, rough64 = 0, normal64[3] = {0, 0, 0};
     double evals64[3] = {0, 0, 0};
 };
+
+bool g_with_truth = true;    // the fp64 two-pass "truth" beside the reference arithmetic (oracle_set_truth)
 
 struct Params {
     float grid_len, z_len, slope_interval;
@@ -124,11 +131,13 @@ inline int pick_min(const T e[3]) {
 
 // map2D.h:611-627 (+ PCL semantics) and :110-133 for one node.
 void fit_node(Node& nd, const float* xyz, size_t stride, const Params& P) {
-    const size_t n = nd.idx.size();
+    const size_t n = nd.count();
+    const uint32_t* const pts = nd.points();
     if (n < static_cast<size_t>(P.min_points)) return;  // map2D.h:611; mean/cov/N stay zero
     // pcl::compute3DCentroid, dense path: sequential fp32 sums, then divide.
     float sx = 0.f, sy = 0.f, sz = 0.f;
-    for (uint32_t i : nd.idx) {
+    for (size_t q_ = 0; q_ < n; ++q_) {
+        const uint32_t i = pts[q_];
         const float* p = xyz + static_cast<size_t>(i) * stride;
         sx += p[0]; sy += p[1]; sz += p[2];
     }
@@ -136,7 +145,8 @@ void fit_node(Node& nd, const float* xyz, size_t stride, const Params& P) {
     nd.mean[0] = sx / fn; nd.mean[1] = sy / fn; nd.mean[2] = sz / fn;
     // pcl::computeCovarianceMatrix(cloud, centroid, C): sequential fp32, un-normalised.
     float c00 = 0, c01 = 0, c02 = 0, c11 = 0, c12 = 0, c22 = 0;
-    for (uint32_t i : nd.idx) {
+    for (size_t q_ = 0; q_ < n; ++q_) {
+        const uint32_t i = pts[q_];
         const float* p = xyz + static_cast<size_t>(i) * stride;
         float dx = p[0] - nd.mean[0], dy = p[1] - nd.mean[1], dz = p[2] - nd.mean[2];
         c11 += dy * dy; c12 += dy * dz; c22 += dz * dz;
@@ -145,15 +155,18 @@ void fit_node(Node& nd, const float* xyz, size_t stride, const Params& P) {
     nd.cov[0] = c00; nd.cov[1] = c01; nd.cov[2] = c02; nd.cov[3] = c11; nd.cov[4] = c12; nd.cov[5] = c22;
     nd.N += static_cast<int>(n);  // map2D.h:625
 
+    if (!g_with_truth) return;      // (the timed CPU baseline does only what the reference does)
     // fp64 truth: two-pass in double
     double m[3] = {0, 0, 0};
-    for (uint32_t i : nd.idx) {
+    for (size_t q_ = 0; q_ < n; ++q_) {
+        const uint32_t i = pts[q_];
         const float* p = xyz + static_cast<size_t>(i) * stride;
         m[0] += p[0]; m[1] += p[1]; m[2] += p[2];
     }
     for (int k = 0; k < 3; ++k) { m[k] /= static_cast<double>(n); nd.mean64[k] = m[k]; }
     double d[6] = {0, 0, 0, 0, 0, 0};
-    for (uint32_t i : nd.idx) {
+    for (size_t q_ = 0; q_ < n; ++q_) {
+        const uint32_t i = pts[q_];
         const float* p = xyz + static_cast<size_t>(i) * stride;
         double dx = p[0] - m[0], dy = p[1] - m[1], dz = p[2] - m[2];
         d[0] += dx * dx; d[1] += dx * dy; d[2] += dx * dz; d[3] += dy * dy; d[4] += dy * dz; d[5] += dz * dz;
@@ -168,6 +181,7 @@ void eigen_node(Node& nd) {  // OcNode::countRoughNormal, map2D.h:110-133
     nd.rough = ev[j];
     for (int k = 0; k < 3; ++k) { nd.normal[k] = vec[k][j]; nd.evals[k] = ev[k]; }
     if (nd.rough == 0.f) nd.rough = 0.01f;  // map2D.h:131-132
+    if (!g_with_truth) return;
     double ev64[3], vec64[3][3];
     jacobi3<double>(nd.cov64, ev64, vec64);
     int j64 = pick_min(ev64);
@@ -194,7 +208,7 @@ bool is_slope(const Node& me, const std::vector<Node*>& column, float interval, 
 // create2DMap body for one column (map2D.h:606-662)
 void process_column(std::vector<Node*>& column, const float* xyz, size_t stride, const Params& P) {
     for (Node* nd : column) {
-        if (nd->idx.size() < static_cast<size_t>(P.min_points)) continue;
+        if (nd->count() < static_cast<size_t>(P.min_points)) continue;
         fit_node(*nd, xyz, stride, P);
         bool up = false, down = false;
         if (P.demand == 0) {
@@ -213,7 +227,10 @@ struct Grid {
     std::vector<Node*> nodes;        // export order: first-seen column, then first-seen node
     std::vector<uint32_t> col_start; // index into nodes of each column's first node (+ sentinel)
     double t_division = 0, t_calculate = 0;
-    ~Grid() { for (Node* n : nodes) delete n; }
+    // mode 2: nodes and their point lists live in per-thread pools
+    std::vector<std::vector<Node>> node_pool;
+    std::vector<std::vector<uint32_t>> idx_pool;
+    ~Grid() { if (node_pool.empty()) for (Node* n : nodes) delete n; }
 };
 
 double now_s() {
@@ -276,83 +293,137 @@ inline uint64_t mix64(uint64_t x) {
     return x;
 }
 
+// Mode 1 (threads == 1) and mode 2 (OpenMP): the CPU baseline bench.py times.  Same arithmetic as mode 0 — every node
+// sees its points in arrival order, which the reference's sequential fp32 sums depend on — but none of its containers:
+//   keys      packed integer key of every point                                             parallel over points
+//   partition counting sort of the point indices by OWNER = hash(column) mod threads, stable  two parallel passes, flat
+//   group     every owner: open-addressing table key -> node, then the nodes' point lists as  parallel over owners,
+//             one flat array (count, prefix, fill): no per-node allocation, no vector growth    no sharing
+//   order     columns by first-seen index (all nodes of a column sit with one owner), nodes of  parallel sort
+//             a column by first-seen index
+//   calculate create2DMap's per-column body (process_column)                                 parallel over columns
 Grid* build_int_keys(const float* xyz, size_t n, size_t stride, const float o[3], const Params& P, int threads) {
     Grid* g = new Grid;
+    if (threads < 1) threads = 1;
+    const size_t T = static_cast<size_t>(threads);
     double t0 = now_s();
     std::vector<uint64_t> keys(n);
     std::vector<Key> kk(n);
+    std::vector<uint16_t> owner(n);
 #pragma omp parallel for num_threads(threads) schedule(static)
     for (long long i = 0; i < static_cast<long long>(n); ++i) {
         const float* p = xyz + static_cast<size_t>(i) * stride;
         Key k = trans_key(o, P.grid_len, P.z_len, p[0], p[1], p[2]);
         kk[i] = k;
         keys[i] = pack_key(signed_x(k), signed_y(k), k.sz);
+        owner[i] = static_cast<uint16_t>(mix64(keys[i] & ~0x3FFFFFull) % T);      // by COLUMN: a column's nodes share an owner
     }
-    // Parallel partition by key hash: thread t files the points of its contiguous index chunk into `threads`
-    // lists (one per owner); owner p then walks the lists of chunk 0, 1, 2, ... in that order, so every node
-    // sees its points in arrival order (what the fp32 sequential sums of the reference depend on).  O(n) work.
-    std::vector<std::vector<Node*>> owned(threads);
-    std::vector<std::vector<std::vector<uint32_t>>> filed(threads, std::vector<std::vector<uint32_t>>(threads));
+    // stable counting sort of the indices by owner: cnt[chunk][owner] -> offsets -> perm
+    std::vector<size_t> cnt(T * T, 0), start(T + 1, 0);
+    std::vector<uint32_t> perm(n);
 #pragma omp parallel num_threads(threads)
     {
 #ifdef _OPENMP
-        const int t = omp_get_thread_num();
+        const size_t t = static_cast<size_t>(omp_get_thread_num());
 #else
-        const int t = 0;
+        const size_t t = 0;
 #endif
-        const size_t lo = n * static_cast<size_t>(t) / threads, hi = n * static_cast<size_t>(t + 1) / threads;
-        std::vector<std::vector<uint32_t>>& mine = filed[t];
-        for (auto& v : mine) v.reserve((hi - lo) / threads + 16);
-        for (size_t i = lo; i < hi; ++i)
-            mine[mix64(keys[i]) % static_cast<uint64_t>(threads)].push_back(static_cast<uint32_t>(i));
+        const size_t lo = n * t / T, hi = n * (t + 1) / T;
+        size_t* mine = &cnt[t * T];
+        for (size_t i = lo; i < hi; ++i) ++mine[owner[i]];
 #pragma omp barrier
-        std::unordered_map<uint64_t, Node*> local;
-        local.reserve(n / (static_cast<size_t>(threads) * 4) + 16);
-        std::vector<Node*>& nodes_of_t = owned[t];
-        for (int src = 0; src < threads; ++src) {
-            for (uint32_t i : filed[src][t]) {
-                const uint64_t k = keys[i];
-                auto it = local.find(k);
-                Node* nd;
-                if (it == local.end()) {
-                    nd = new Node; nd->key = kk[i]; nd->first_idx = i;
-                    local.emplace(k, nd); nodes_of_t.push_back(nd);
-                } else nd = it->second;
-                nd->idx.push_back(i);
+#pragma omp single
+        {
+            size_t run = 0;
+            for (size_t ow = 0; ow < T; ++ow) {
+                start[ow] = run;
+                for (size_t c = 0; c < T; ++c) { const size_t v = cnt[c * T + ow]; cnt[c * T + ow] = run; run += v; }
             }
+            start[T] = run;
+        }
+        for (size_t i = lo; i < hi; ++i) perm[mine[owner[i]]++] = static_cast<uint32_t>(i);
+    }
+    // every owner groups its points into nodes
+    g->node_pool.resize(T);
+    g->idx_pool.resize(T);
+    struct Col { uint64_t first; uint32_t owner, begin, end; };      // a column = nodes [begin, end) of its owner's pool
+    std::vector<std::vector<Col>> cols_of(T);
+#pragma omp parallel num_threads(threads)
+    {
+#ifdef _OPENMP
+        const size_t t = static_cast<size_t>(omp_get_thread_num());
+#else
+        const size_t t = 0;
+#endif
+        const size_t lo = start[t], hi = start[t + 1], m = hi - lo;
+        size_t cap = 16;
+        while (cap < 2 * m) cap <<= 1;
+        std::vector<uint64_t> tkey(cap, ~0ull);
+        std::vector<uint32_t> tval(cap), nid(m), ncount;
+        std::vector<Node>& pool = g->node_pool[t];
+        pool.reserve(m / 4 + 16);
+        for (size_t q = 0; q < m; ++q) {
+            const uint32_t i = perm[lo + q];
+            const uint64_t k = keys[i];
+            size_t s = static_cast<size_t>(mix64(k) >> 20) & (cap - 1);
+            while (tkey[s] != ~0ull && tkey[s] != k) s = (s + 1) & (cap - 1);
+            if (tkey[s] == ~0ull) {
+                tkey[s] = k; tval[s] = static_cast<uint32_t>(pool.size());
+                pool.emplace_back();
+                pool.back().key = kk[i]; pool.back().first_idx = i;
+                ncount.push_back(0);
+            }
+            nid[q] = tval[s];
+            ++ncount[tval[s]];
+        }
+        std::vector<uint32_t>& flat = g->idx_pool[t];
+        flat.resize(m);
+        std::vector<uint32_t> fill(pool.size());
+        uint32_t run = 0;
+        for (size_t v = 0; v < pool.size(); ++v) { fill[v] = run; pool[v].idx_ptr = flat.data() + run; pool[v].idx_n = ncount[v]; run += ncount[v]; }
+        for (size_t q = 0; q < m; ++q) flat[fill[nid[q]]++] = perm[lo + q];      // arrival order kept inside every node
+        // columns of this owner: sort its nodes by (column key, first-seen); a column's first-seen = its first node's
+        std::vector<uint32_t> ord(pool.size());
+        for (size_t v = 0; v < ord.size(); ++v) ord[v] = static_cast<uint32_t>(v);
+        auto colkey = [&](uint32_t v) { return pack_key(signed_x(pool[v].key), signed_y(pool[v].key), 0); };
+        std::sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t b) {
+            const uint64_t ca = colkey(a), cb = colkey(b);
+            return ca != cb ? ca < cb : pool[a].first_idx < pool[b].first_idx;
+        });
+        std::vector<Node> sorted;
+        sorted.reserve(pool.size());
+        for (uint32_t v : ord) sorted.push_back(pool[v]);
+        pool.swap(sorted);
+        for (size_t v = 0; v < pool.size();) {
+            size_t e = v + 1;
+            const uint64_t ck = colkey(static_cast<uint32_t>(v));
+            while (e < pool.size() && colkey(static_cast<uint32_t>(e)) == ck) ++e;
+            cols_of[t].push_back(Col{pool[v].first_idx, static_cast<uint32_t>(t), static_cast<uint32_t>(v), static_cast<uint32_t>(e)});
+            v = e;
         }
     }
     double t1 = now_s();
-    // group nodes into columns: column order = first-seen (min first_idx), nodes by first_idx
-    std::vector<Node*> all;
-    for (auto& v : owned) all.insert(all.end(), v.begin(), v.end());
-    std::unordered_map<uint64_t, uint64_t> col_first;
-    col_first.reserve(all.size());
-    for (Node* nd : all) {
-        uint64_t ck = pack_key(signed_x(nd->key), signed_y(nd->key), 0);
-        auto it = col_first.find(ck);
-        if (it == col_first.end()) col_first.emplace(ck, nd->first_idx);
-        else if (nd->first_idx < it->second) it->second = nd->first_idx;
-    }
-    std::vector<std::pair<std::pair<uint64_t, uint64_t>, Node*>> order(all.size());
-    for (size_t i = 0; i < all.size(); ++i) {
-        Node* nd = all[i];
-        uint64_t ck = pack_key(signed_x(nd->key), signed_y(nd->key), 0);
-        order[i] = {{col_first[ck], nd->first_idx}, nd};
-    }
-    std::sort(order.begin(), order.end(),
-              [](const auto& a, const auto& b) { return a.first < b.first; });
-    g->nodes.resize(all.size());
-    for (size_t i = 0; i < order.size(); ++i) {
-        g->nodes[i] = order[i].second;
-        if (i == 0 || order[i].first.first != order[i - 1].first.first) g->col_start.push_back(static_cast<uint32_t>(i));
-    }
-    g->col_start.push_back(static_cast<uint32_t>(g->nodes.size()));
-    const long long ncol = static_cast<long long>(g->col_start.size()) - 1;
+    // global column order = first-seen order (morton_list, receiver.cpp:70)
+    std::vector<Col> cols;
+    for (auto& v : cols_of) cols.insert(cols.end(), v.begin(), v.end());
+#ifdef _OPENMP
+    __gnu_parallel::sort(cols.begin(), cols.end(), [](const Col& a, const Col& b) { return a.first < b.first; }, __gnu_parallel::default_parallel_tag(threads));
+#else
+    std::sort(cols.begin(), cols.end(), [](const Col& a, const Col& b) { return a.first < b.first; });
+#endif
+    g->col_start.resize(cols.size() + 1);
+    size_t total = 0;
+    for (size_t c = 0; c < cols.size(); ++c) { g->col_start[c] = static_cast<uint32_t>(total); total += cols[c].end - cols[c].begin; }
+    g->col_start[cols.size()] = static_cast<uint32_t>(total);
+    g->nodes.resize(total);
+    const long long ncol = static_cast<long long>(cols.size());
 #pragma omp parallel for num_threads(threads) schedule(dynamic, 256)
     for (long long c = 0; c < ncol; ++c) {
-        std::vector<Node*> column(g->nodes.begin() + g->col_start[c], g->nodes.begin() + g->col_start[c + 1]);
+        const Col& cl = cols[c];
+        std::vector<Node*> column;
+        for (uint32_t v = cl.begin; v < cl.end; ++v) column.push_back(&g->node_pool[cl.owner][v]);
         process_column(column, xyz, stride, P);
+        std::copy(column.begin(), column.end(), g->nodes.begin() + g->col_start[c]);
     }
     double t2 = now_s();
     g->t_division = t1 - t0; g->t_calculate = t2 - t1;
@@ -370,6 +441,8 @@ Grid* build_int_keys(const float* xyz, size_t n, size_t stride, const float o[3]
 }  // namespace
 
 extern "C" {
+
+void oracle_set_truth(int on) { g_with_truth = on != 0; }
 
 // ---- key codec entry points ---------------------------------------------------------------------
 int oracle_count_morton(int a, int b, char* out, int cap) {
@@ -434,7 +507,7 @@ void oracle_export(void* h, int32_t* sx, int32_t* sy, int32_t* sz, uint32_t* cou
         if (sx) sx[i] = signed_x(nd.key);
         if (sy) sy[i] = signed_y(nd.key);
         if (sz) sz[i] = nd.key.sz;
-        if (count) count[i] = static_cast<uint32_t>(nd.idx.size());
+        if (count) count[i] = static_cast<uint32_t>(nd.count());
         if (first_idx) first_idx[i] = nd.first_idx;
         for (int k = 0; k < 3; ++k) {
             if (mean) mean[3 * i + k] = nd.mean[k];
