@@ -149,6 +149,8 @@ def lib():
     L.gndt_build_device.argtypes = [H, vp, sz, sz, vp]
     L.gndt_update.argtypes = [H, vp, sz, sz]
     L.gndt_update_device.argtypes = [H, vp, sz, sz, vp]
+    L.gndt_remove.argtypes = [H, vp, sz, sz]
+    L.gndt_remove_device.argtypes = [H, vp, sz, sz, vp]
     L.gndt_reset.argtypes = [H, vp]
     L.gndt_accumulate_device.argtypes = [H, vp, sz, sz, u64, vp]
     L.gndt_finalize_device.argtypes = [H, vp]
@@ -188,6 +190,7 @@ def lib():
     L.gndt_last_strategy.restype = C.c_int
     L.gndt_device_info.argtypes = [C.c_int32, C.c_char_p, C.POINTER(C.c_int32), C.POINTER(u64)]
     for name in ("gndt_create", "gndt_set_origin", "gndt_build", "gndt_build_device", "gndt_update", "gndt_update_device",
+                 "gndt_remove", "gndt_remove_device",
                  "gndt_reset", "gndt_accumulate_device", "gndt_finalize_device", "gndt_sync", "gndt_export_device",
                  "gndt_export", "gndt_stats_export_device", "gndt_stats_merge_device", "gndt_trans_morton_xyz",
                  "gndt_compute_cost", "gndt_cost_export_device", "gndt_cost_export",

@@ -428,6 +428,55 @@ int gndt_stats_merge_device(gndt_handle* h, const gndt_stats* in, void* hip_stre
 }
 
 
+int gndt_remove_device(gndt_handle* h, const void* xyz_dev, size_t n, size_t stride_bytes, void* hip_stream) {
+    int rc = check_ready(h);
+    if (rc) return rc;
+    if (!xyz_dev && n) { h->err = "null input"; return GNDT_ERR_INVALID; }
+    if (stride_bytes != 12 && stride_bytes != 16) { h->err = "stride_bytes must be 12 or 16"; return GNDT_ERR_INVALID; }
+    hipStream_t s = stream_of(h, hip_stream);
+    { const int urc = use_stream(h, s); if (urc) return urc; }
+    if (!h->map_in_table || h->cap == 0) {
+        h->err = "gndt_remove needs the additive node table: build with strategy ATOMIC / TILE or through gndt_update*";
+        return GNDT_ERR_INVALID;
+    }
+    h->pending.active = false;
+    next_event_set(h);
+    h->last_strategy = GNDT_STRATEGY_ATOMIC;
+    if (n) {
+        const float* p = static_cast<const float*>(xyz_dev);
+        const int blocks = grid_for(n, kBlock, 256 * 16);
+        if (stride_bytes == 12) hipLaunchKernelGGL(k_remove<3>, dim3(blocks), dim3(kBlock), 0, s, p, (uint64_t)n, grid_params(h), h->keys, h->acc, h->cap - 1, h->d_cnt);
+        else hipLaunchKernelGGL(k_remove<4>, dim3(blocks), dim3(kBlock), 0, s, p, (uint64_t)n, grid_params(h), h->keys, h->acc, h->cap - 1, h->d_cnt);
+        HIP_TRY(h, hipGetLastError());
+    }
+    h->incr_ok = false;                                // every row is redone
+    h->results_valid = false;
+    if ((rc = fetch_counters(h, s))) return rc;        // (waits) misses and deaths are only known on the device
+    if (h->h_cnt->err_remove) {
+        h->err = std::to_string(h->h_cnt->err_remove) + " point(s) to remove were never added (or their node is already empty): the map is "
+                 "partly updated, call gndt_reset";
+        HIP_TRY(h, hipMemsetAsync(&h->d_cnt->err_remove, 0, sizeof(uint32_t), s));
+        return GNDT_ERR_INVALID;
+    }
+    if (h->h_cnt->n_dead) {
+        // drop the empty nodes: statistics out, fresh table, merge back (k_stats_merge skips entries without points)
+        HIP_TRY(h, hipMemsetAsync(&h->d_cnt->n_dead, 0, sizeof(uint32_t), s));
+        if ((rc = grow_table(h, h->cap, s))) return rc;
+    }
+    return do_finalize(h, s);
+}
+
+int gndt_remove(gndt_handle* h, const void* xyz_host, size_t n, size_t stride_bytes) {
+    int rc = check_ready(h);
+    if (rc) return rc;
+    if (!xyz_host && n) { h->err = "null input"; return GNDT_ERR_INVALID; }
+    rc = stage_host_input(h, xyz_host, n, stride_bytes, h->own_stream);
+    if (rc) return rc;
+    rc = gndt_remove_device(h, h->stage, n, stride_bytes, h->own_stream);
+    if (rc) return rc;
+    return gndt_sync(h, nullptr, nullptr, nullptr);
+}
+
 int gndt_locality_sample(gndt_handle* h, const void* xyz_dev, size_t n, size_t stride_bytes, uint32_t tiles, double* points_per_partial,
                          void* hip_stream) {
     int rc = check_ready(h);

@@ -46,6 +46,8 @@ struct Counters {
     uint32_t n_touched;       // nodes an incremental update has touched so far (list: touched[])
     uint32_t n_tcols;         // columns holding a touched node (list: touched_cols[])
     uint32_t n_work;          // nodes of those columns (list: reuses touched[])
+    uint32_t n_dead;          // gndt_remove*: nodes whose last point was taken away (dropped by the compaction that follows)
+    uint32_t err_remove;      // gndt_remove*: points whose node does not exist or is already empty
     uint32_t pad;
 };
 
@@ -186,7 +188,7 @@ static __global__ void k_clear_used(uint64_t* keys, NodeAcc* acc, uint64_t* col_
 static __global__ void k_zero_counters(Counters* c) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         c->num_nodes = 0; c->num_columns = 0; c->num_slopes = 0; c->err_key_range = 0; c->err_table_full = 0;
-        c->stream_pos = 0; c->prev_nodes = 0; c->n_touched = 0; c->n_tcols = 0; c->n_work = 0;
+        c->stream_pos = 0; c->prev_nodes = 0; c->n_touched = 0; c->n_tcols = 0; c->n_work = 0; c->n_dead = 0; c->err_remove = 0;
         c->epoch = c->epoch + 1u;                     // stale touch marks of the previous map can never match again
     }
 }
@@ -269,6 +271,34 @@ __global__ void __launch_bounds__(kBlock) k_accumulate(const float* __restrict__
                 atomicMin(&a->first, pidx);
             }
         }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_remove: the inverse of k_accumulate (intent of del2DMap, include/map2D.h:826-915: points leave their nodes, a node
+// whose last point leaves is deleted).  The statistics are additive, so a point is taken away by subtracting its
+// contribution about the same node centre; `first` (the node's place in the order) stays.  A point whose node does not
+// exist, or is already empty, is counted in err_remove and changes nothing.
+// ---------------------------------------------------------------------------------------------
+template <int STRIDE_FLOATS>
+__global__ void __launch_bounds__(kBlock) k_remove(const float* __restrict__ xyz, uint64_t n, GridParams P,
+                                                   const uint64_t* __restrict__ keys, NodeAcc* __restrict__ acc, uint32_t cap_mask,
+                                                   Counters* __restrict__ cnt) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const float* p = xyz + i * STRIDE_FLOATS;
+        const PointKey k = point_key(p[0], p[1], p[2], P.ox, P.oy, P.oz, P.grid_len, P.z_len);
+        uint32_t slot = cap_mask + 1;
+        if (k.ok) slot = find_slot(keys, cap_mask, pack_key(k.sx, k.sy, k.sz));
+        if (slot > cap_mask) { atomicAdd(&cnt->err_remove, 1u); continue; }
+        NodeAcc* a = acc + slot;
+        const uint32_t before = atomicSub(&a->count, 1u);
+        if (before == 0u) { atomicAdd(&a->count, 1u); atomicAdd(&cnt->err_remove, 1u); continue; }   // nothing left to take
+        if (before == 1u) atomicAdd(&cnt->n_dead, 1u);
+        const double v0 = (double)p[0] - axis_centre(k.sx, P.ox, P.grid_len), v1 = (double)p[1] - axis_centre(k.sy, P.oy, P.grid_len),
+                     v2 = (double)p[2] - axis_centre(k.sz, P.oz, P.z_len);
+        const double q[9] = {v0, v1, v2, v0 * v0, v0 * v1, v0 * v2, v1 * v1, v1 * v2, v2 * v2};
+#pragma unroll
+        for (int j = 0; j < 9; ++j) unsafeAtomicAdd(&a->s[j], -q[j]);
     }
 }
 

@@ -172,6 +172,18 @@ class TwoDmap:
         self._keep = keep
         return True
 
+    def del2DMap(self, demand, points, stream=None):
+        """Incremental delete (intent of map2D.h:826-915 as defined in include/gndt.h): `points` were added before and leave
+        their nodes; empty nodes are deleted, surviving nodes keep their place in the order."""
+        self._ensure(demand)
+        ptr, n, stride, on_dev, keep = self._as_input(points)
+        if on_dev:
+            self._check(self._L.gndt_remove_device(self._h, C.c_void_p(ptr), n, stride, _stream_ptr(stream)))
+        else:
+            self._check(self._L.gndt_remove(self._h, C.c_void_p(ptr), n, stride))
+        self._keep = keep
+        return True
+
     # ---- input side: raw records (PointCloud2 / .pcd payload) ----
     def pack_points(self, raw, point_step, offsets=(0, 4, 8), demand="slope", stream=None):
         """Raw point records on the device (torch uint8/float32 tensor of n * point_step bytes) -> packed xyz torch

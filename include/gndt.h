@@ -143,6 +143,22 @@ int gndt_build_device(gndt_handle* h, const void* xyz_dev, size_t n, size_t stri
 int gndt_update(gndt_handle* h, const void* xyz_host, size_t n, size_t stride_bytes);
 int gndt_update_device(gndt_handle* h, const void* xyz_dev, size_t n, size_t stride_bytes, void* hip_stream);
 
+/* Incremental delete: the intent of del2DMap (include/map2D.h:826-915; its caller delCallback is commented out at
+ * src/receiver.cpp:214-248, and the shipped merge formula is inconsistent: SURVEY row a10), DEFINED here as the inverse of
+ * gndt_update: the given points — which must have been added before, with the same coordinates — leave their nodes.
+ *   - counts and the additive statistics are exactly those of the stream without the points (sums up to fp64 rounding);
+ *   - a node whose last point leaves is deleted (map2D.h:861-873) and takes its slope with it;
+ *   - a node that falls below min_points keeps its key and count but no statistics, like a node that never reached them;
+ *   - every surviving node KEEPS its first-seen index, i.e. its place in the order — the reference's containers do not
+ *     re-sort either (multimap::erase, morton_list untouched).  The result therefore equals a fresh build of the remaining
+ *     points whenever no surviving node lost its first point; otherwise the order (and with it the order-dependent slope
+ *     label, map2D.h:66-108) is that of the ORIGINAL stream.
+ * Needs the additive state (strategy ATOMIC / TILE or a map built by gndt_update*).  A point that was never added is an
+ * error (GNDT_ERR_INVALID) and leaves the handle to be reset.  Waits for the device (the node table is compacted when
+ * nodes died); every row is re-finalised. */
+int gndt_remove(gndt_handle* h, const void* xyz_host, size_t n, size_t stride_bytes);
+int gndt_remove_device(gndt_handle* h, const void* xyz_dev, size_t n, size_t stride_bytes, void* hip_stream);
+
 /* Split form of build for a cloud sharded over several GPUs:
  *   accumulate (binning + sufficient statistics only)  ->  [exchange stats]  ->  finalize.
  * `first_idx_base` is the global index of xyz_dev[0] so that first-seen order is global. */

@@ -18,8 +18,11 @@ MAX_WIDENING = 10.0           # ... and none by more than this factor over 1e-5
 MAX_UNRESOLVED_FRACTION = 1e-3   # nodes whose scatter lies below the input resolution floor
 
 
-def compare(gpu, ref, demand="slope"):
-    """-> report dict; report['ok'] is the conjunction of all gates."""
+def compare(gpu, ref, demand="slope", adversarial=False):
+    """-> report dict; report['ok'] is the conjunction of all gates.  `adversarial`: the cloud was BUILT to sit at the input
+    resolution (lattice points and their float neighbours, tests/test_gpu_fuzz.py): the share of unresolvable nodes is then
+    not capped, nor is the share of nodes on which the fp32 oracle itself is more than 1e-5 off (the factor stays capped;
+    every other gate stays)."""
     rep = {"ok": True, "fail": []}
 
     def fail(msg):
@@ -89,24 +92,25 @@ def compare(gpu, ref, demand="slope"):
     rep["cov_err"] = float(e32.max())
     rep["cov_err_truth"] = float(e64.max())
     rep["ref_fp32_self_err"] = float(ref_self.max())
-    widened = e32 > TOL_COV                       # nodes that can only pass through one of the escapes below
-    rep["cov_nodes_over_1e-5_vs_fp32"] = int(np.count_nonzero(widened))
-    rep["cov_widening_max"] = float((e32[widened] / TOL_COV).max()) if widened.any() else 1.0
-    n_has = int(np.count_nonzero(has))
-    if np.count_nonzero(widened) > max(1, int(MAX_WIDENED_FRACTION * n_has)):
-        fail(f"{int(np.count_nonzero(widened))} of {n_has} nodes need a widened covariance allowance (cap {MAX_WIDENED_FRACTION:g})")
-    if rep["cov_widening_max"] > MAX_WIDENING:
-        fail(f"covariance allowance widened {rep['cov_widening_max']:.1f}x on some node (cap {MAX_WIDENING:g}x)")
     # Resolution floor of the INPUT: fp32 coordinates near |p| are spaced ulp = 2^-23 |p| apart, so a node whose points
     # differ by a few ulps (lattice points and their float neighbours, duplicates with rounding) has a scatter of the
     # order count * ulp^2 that no arithmetic can resolve to 2e-6 of itself; below that floor only the size is checked.
     pmax = np.maximum(np.abs(ref["mean64"][has]).max(axis=1), 1e-3)
     floor = ref["count"][has].astype(np.float64) * (2.0 ** -23 * pmax) ** 2
+    # nodes whose scatter the inputs DO resolve, and which still need more than 1e-5 against the fp32 oracle
+    widened = (e32 > TOL_COV) & (scale > 100.0 * floor)
+    rep["cov_nodes_over_1e-5_vs_fp32"] = int(np.count_nonzero(widened))
+    rep["cov_widening_max"] = float((e32[widened] / TOL_COV).max()) if widened.any() else 1.0
+    n_has = int(np.count_nonzero(has))
+    if not adversarial and np.count_nonzero(widened) > max(1, int(MAX_WIDENED_FRACTION * n_has)):
+        fail(f"{int(np.count_nonzero(widened))} of {n_has} nodes need a widened covariance allowance (cap {MAX_WIDENED_FRACTION:g})")
+    if rep["cov_widening_max"] > MAX_WIDENING:
+        fail(f"covariance allowance widened {rep['cov_widening_max']:.1f}x on some node (cap {MAX_WIDENING:g}x)")
     if np.any(d32 > np.maximum(allow32 * scale, 2.0 * floor + np.abs(rc32 - rc64).max(axis=1))):
         fail(f"cov error vs fp32 oracle {float((e32 / allow32).max()):.2f}x allowance (max {rep['cov_err']:.3e})")
     over = d64 > np.maximum(TOL_COV_TRUTH * scale, floor)
     rep["cov_nodes_below_input_resolution"] = int(np.count_nonzero(scale <= floor))
-    if rep["cov_nodes_below_input_resolution"] > max(2, int(MAX_UNRESOLVED_FRACTION * n_has)):
+    if not adversarial and rep["cov_nodes_below_input_resolution"] > max(2, int(MAX_UNRESOLVED_FRACTION * n_has)):
         fail(f"{rep['cov_nodes_below_input_resolution']} nodes below the input resolution floor (cap {MAX_UNRESOLVED_FRACTION:g})")
     if np.any(over):
         worst = float((d64 / np.maximum(TOL_COV_TRUTH * scale, floor)).max())
@@ -153,8 +157,8 @@ def compare(gpu, ref, demand="slope"):
     return rep
 
 
-def assert_parity(gpu, ref, demand="slope"):
-    rep = compare(gpu, ref, demand)
+def assert_parity(gpu, ref, demand="slope", adversarial=False):
+    rep = compare(gpu, ref, demand, adversarial)
     assert rep["ok"], "parity failed: " + "; ".join(rep["fail"])
     return rep
 

@@ -546,3 +546,81 @@ def test_auto_takes_the_one_pass_tile_strategy_only_where_the_sampled_locality_p
     assert res["shuffled"][0] < 24 and res["shuffled"][1] in (2, 3)
     ref = parity.ref_from_cloud(dense, P)
     parity.assert_parity(res["dense"][2], ref)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("scene", ["campus", "terrain"])
+def test_remove_is_the_inverse_of_update(scene):
+    """gndt_remove* (intent of del2DMap, map2D.h:826-915, defined in include/gndt.h): after update(A), update(B), remove(B')
+    the map is the oracle's map of the remaining points — keys, counts, first-seen order and labels exactly, statistics
+    within the parity tolerances — as long as no surviving node loses its first point (B' is taken from the END of the
+    stream).  Nodes that only B' filled are deleted; nodes that fall below three points lose their statistics."""
+    import torch
+    import grid_ndt_amd as g
+    cloud, P = {"campus": (scenes.campus_frame(120_000), scenes.CAMPUS_PARAMS), "terrain": (scenes.terrain_cloud(200_000), TERRAIN)}[scene]
+    n = cloud.shape[0]
+    cut = int(0.7 * n)
+    rng = np.random.default_rng(9)
+    # B' = a random 60 % of the last 30 % of the stream
+    tail = np.arange(cut, n)
+    gone = np.sort(rng.choice(tail, size=int(0.6 * tail.size), replace=False))
+    keep = np.ones(n, bool)
+    keep[gone] = False
+    remaining = cloud[keep]
+    ref = parity.ref_from_cloud(remaining, P)
+    # a surviving node must not have lost its first point for exact equality: true by construction for nodes first seen
+    # before `cut`; nodes first seen in the tail are compared only if their first point survived
+    m = g.TwoDmap(P["grid_len"], P["z_len"], strategy=1)
+    m.setInterval(P["slope_interval"]); m.setCloudFirst(cloud[0])
+    m.change2DMap(P["demand"], torch.from_numpy(cloud[1:cut]).cuda())
+    m.change2DMap(P["demand"], torch.from_numpy(cloud[cut:]).cuda())
+    before = m.sync()
+    m.del2DMap(P["demand"], torch.from_numpy(np.ascontiguousarray(cloud[gone])).cuda())
+    out = m.export()
+    assert out["num_nodes"] == ref["num_nodes"] < before[0]              # some nodes died
+    # keys as sets, counts per key exact
+    key = lambda d: (d["sx"].astype(np.int64) << 42) ^ (d["sy"].astype(np.int64) << 21) ^ (d["sz"].astype(np.int64) & 0x1FFFFF)
+    og, orf = np.argsort(key(out)), np.argsort(key(ref))
+    assert np.array_equal(key(out)[og], key(ref)[orf])
+    assert np.array_equal(out["count"][og].astype(np.int64), ref["count"][orf].astype(np.int64))
+    # stream index of a remaining point -> its index in the fresh build of the remaining points
+    new_index = np.cumsum(keep) - 1
+    first_new = new_index[np.minimum(out["first_idx"][og].astype(np.int64) + 1, n - 1)] - 1     # (+1 / -1: point 0 is the origin)
+    first_kept = keep[np.minimum(out["first_idx"][og].astype(np.int64) + 1, n - 1)]
+    same_first = first_kept & (first_new == ref["first_idx"][orf].astype(np.int64))
+    assert same_first.mean() > 0.9                                        # most nodes kept their first point ...
+    # ... and where every node of the map did, the whole export is the fresh build's, in its order
+    if same_first.all():
+        out2 = dict(out)
+        out2["first_idx"] = (new_index[out["first_idx"].astype(np.int64) + 1] - 1).astype(np.uint32)
+        parity.assert_parity(out2, ref)
+    else:
+        has = (ref["flags"][orf] & 1) != 0
+        assert np.array_equal((out["flags"][og] & 1) != 0, has)
+        dm = np.abs(out["mean"][og][has].astype(np.float64) - ref["mean64"][orf][has])
+        assert dm.max() < 1e-5 * max(1.0, np.abs(ref["mean64"]).max())
+        sc = np.abs(ref["cov64"][orf][has]).max(axis=1)
+        dc = np.abs(out["cov"][og][has].astype(np.float64) - ref["cov64"][orf][has]).max(axis=1)
+        assert np.all(dc <= 1e-5 * sc + 1e-12)
+    # a point that was never added is an error
+    with pytest.raises(g.GndtError):
+        m.del2DMap(P["demand"], torch.from_numpy(np.float32([[1e4, 1e4, 1e3]])).cuda())
+
+
+@pytest.mark.gpu
+def test_remove_whole_frames_equals_the_build_without_them():
+    """Frames appended last and removed again: no surviving node can have lost its first point, so the export must be the
+    oracle's map of the earlier frames, order and labels included."""
+    import torch
+    import grid_ndt_amd as g
+    ppf = 8192
+    frames = scenes.terrain_frames(6, 0, points_per_frame=ppf)
+    P = TERRAIN
+    m = g.TwoDmap(P["grid_len"], P["z_len"], strategy=1)
+    m.setInterval(P["slope_interval"]); m.setCloudFirst(frames[0])
+    m.change2DMap("slope", torch.from_numpy(frames[1:4 * ppf]).cuda())
+    for f in (4, 5):
+        m.change2DMap("slope", torch.from_numpy(frames[f * ppf:(f + 1) * ppf]).cuda())
+    for f in (5, 4):
+        m.del2DMap("slope", torch.from_numpy(frames[f * ppf:(f + 1) * ppf]).cuda())
+    parity.assert_parity(m.export(), parity.ref_from_cloud(frames[:4 * ppf], P))
