@@ -12,7 +12,7 @@ _ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.path.join(_CSRC, "libgndt.so")
 SOURCES = ["gndt_api_core.hip", "gndt_api_table.hip", "gndt_api_build.hip", "gndt_api_dist.hip", "gndt_api_cost.hip",
            "gndt_api_io.hip", "gndt_codec.cpp", "gndt_io.cpp"]
-HEADERS = ["gndt_handle.hpp", "gndt_kernels.hpp", "gndt_table.hpp", "gndt_cost.hpp", "gndt_pack.hpp", "gndt_partition.hpp", "gndt_bucket.hpp", "gndt_bucket3.hpp", "gndt_bucket4.hpp", "gndt_tile.hpp", "gndt_math.hpp", os.path.join(_ROOT, "include", "gndt.h")]
+HEADERS = ["gndt_handle.hpp", "gndt_kernels.hpp", "gndt_table.hpp", "gndt_cost.hpp", "gndt_pack.hpp", "gndt_partition.hpp", "gndt_bucket.hpp", "gndt_bucket3.hpp", "gndt_bucket4.hpp", "gndt_tile.hpp", "gndt_exchange.hpp", "gndt_math.hpp", os.path.join(_ROOT, "include", "gndt.h")]
 
 GNDT_OK = 0
 ERR_NAMES = {0: "OK", 1: "INVALID", 2: "NO_DEVICE", 3: "HIP", 4: "KEY_RANGE", 5: "CAPACITY", 6: "NOMEM"}
@@ -58,6 +58,11 @@ class Pcd(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("num_nodes", C.c_uint64), ("key", C.c_void_p), ("sums", C.c_void_p), ("count", C.c_void_p),
                 ("first_idx", C.c_void_p)]
+
+
+class ExchangeTimes(C.Structure):
+    _fields_ = [("shard_ms", C.c_float), ("exchange_ms", C.c_float), ("finalize_ms", C.c_float), ("ranks", C.c_uint32),
+                ("local_nodes", C.c_uint64), ("global_nodes", C.c_uint64), ("bytes_reduced", C.c_uint64)]
 
 
 def _hip_runtime_dir():
@@ -184,6 +189,14 @@ def lib():
     L.gndt_debug_bucket_phases.restype = C.c_int
     L.gndt_debug_enable_stamps.argtypes = [C.c_int]
     L.gndt_debug_enable_stamps.restype = C.c_int
+    L.gndt_comm_unique_id.argtypes = [C.c_char_p]
+    L.gndt_comm_create.argtypes = [C.c_char_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(vp)]
+    L.gndt_comm_destroy.argtypes = [vp]
+    L.gndt_comm_destroy.restype = None
+    L.gndt_comm_last_error.restype = C.c_char_p
+    L.gndt_build_global_device.argtypes = [H, vp, vp, C.c_size_t, C.c_size_t, u64, u64, C.POINTER(ExchangeTimes), vp]
+    for name in ("gndt_comm_unique_id", "gndt_comm_create", "gndt_build_global_device"):
+        getattr(L, name).restype = C.c_int
     L.gndt_locality_sample.argtypes = [H, vp, C.c_size_t, C.c_size_t, C.c_uint32, C.POINTER(C.c_double), vp]
     L.gndt_locality_sample.restype = C.c_int
     L.gndt_last_strategy.argtypes = [H]

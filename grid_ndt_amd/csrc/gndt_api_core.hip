@@ -230,6 +230,12 @@ void gndt_destroy(gndt_handle* h) {
         for (auto& e : set)
             if (e) (void)hipEventDestroy(e);
     if (h->h_cnt) (void)hipHostFree(h->h_cnt);
+    {
+        auto& X = h->exch;
+        void* xp[] = {X.d_counts, X.keys_in, X.keys_all, X.keys_sorted, X.canon, X.d_unique, X.d_missing, X.scratch, X.packed, X.pfirst, X.r_sums, X.r_count};
+        for (void* p : xp) if (p) (void)hipFree(p);
+        if (X.h_counts) (void)hipHostFree(X.h_counts);
+    }
     if (h->xstream_ev) (void)hipEventDestroy(h->xstream_ev);
     if (h->d_sample) (void)hipFree(h->d_sample);
     if (h->h_sample) (void)hipHostFree(h->h_sample);

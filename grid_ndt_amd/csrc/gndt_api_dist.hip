@@ -1,8 +1,30 @@
 // gndt_api_dist.hip — one global map from a sharded cloud: shard -> statistics (PARTITION pipeline, no node table), and merged statistics (sorted by key) -> map.
 #include "gndt_handle.hpp"
 #include "gndt_table.hpp"
+#include "gndt_exchange.hpp"
+
+#include <rocprim/rocprim.hpp>
+
 using namespace gndt;
 using namespace gndt_host;
+
+struct gndt_comm {
+    ncclComm_t nccl = nullptr;
+    int rank = 0, world = 1, device = 0;
+};
+
+namespace {
+thread_local std::string g_comm_error;
+
+#define RCCL_TRY(h, expr)                                                                                \
+    do {                                                                                                 \
+        ncclResult_t r__ = (expr);                                                                       \
+        if (r__ != ncclSuccess) {                                                                        \
+            (h)->err = std::string(#expr) + ": " + rccl().GetErrorString(r__);                           \
+            return GNDT_ERR_HIP;                                                                         \
+        }                                                                                                \
+    } while (0)
+}  // namespace
 
 extern "C" {
 
@@ -88,6 +110,138 @@ int gndt_finalize_stats_device(gndt_handle* h, const gndt_stats* in, uint64_t to
     h->map_in_table = false;
     h->last_strategy = GNDT_STRATEGY_PARTITION;
     h->stream_pos = total_points;
+    return GNDT_OK;
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// the exchange behind the C ABI (gndt_exchange.hpp): communicator helpers and the whole sharded build
+// ---------------------------------------------------------------------------------------------
+const char* gndt_comm_last_error(void) { return g_comm_error.c_str(); }
+
+int gndt_comm_unique_id(char id_out[GNDT_COMM_ID_BYTES]) {
+    if (!id_out) return GNDT_ERR_INVALID;
+    if (!rccl().ok()) { g_comm_error = "librccl.so not found (dlopen)"; return GNDT_ERR_NO_DEVICE; }
+    static_assert(sizeof(ncclUniqueId) <= GNDT_COMM_ID_BYTES, "unique id size");
+    ncclUniqueId id;
+    const ncclResult_t r = rccl().GetUniqueId(&id);
+    if (r != ncclSuccess) { g_comm_error = rccl().GetErrorString(r); return GNDT_ERR_HIP; }
+    memset(id_out, 0, GNDT_COMM_ID_BYTES);
+    memcpy(id_out, &id, sizeof id);
+    return GNDT_OK;
+}
+
+int gndt_comm_create(const char id[GNDT_COMM_ID_BYTES], int32_t rank, int32_t world, int32_t device_id, gndt_comm** out) {
+    if (!id || !out || world < 1 || rank < 0 || rank >= world) { g_comm_error = "bad argument"; return GNDT_ERR_INVALID; }
+    *out = nullptr;
+    if (!rccl().ok()) { g_comm_error = "librccl.so not found (dlopen)"; return GNDT_ERR_NO_DEVICE; }
+    if (hipSetDevice(device_id) != hipSuccess) { g_comm_error = "hipSetDevice failed"; return GNDT_ERR_HIP; }
+    ncclUniqueId nid;
+    memcpy(&nid, id, sizeof nid);
+    gndt_comm* c = new (std::nothrow) gndt_comm;
+    if (!c) return GNDT_ERR_NOMEM;
+    const ncclResult_t r = rccl().CommInitRank(&c->nccl, world, nid, rank);
+    if (r != ncclSuccess) { g_comm_error = std::string("ncclCommInitRank: ") + rccl().GetErrorString(r); delete c; return GNDT_ERR_HIP; }
+    c->rank = rank; c->world = world; c->device = device_id;
+    *out = c;
+    return GNDT_OK;
+}
+
+void gndt_comm_destroy(gndt_comm* c) {
+    if (!c) return;
+    if (c->nccl && rccl().ok()) (void)rccl().CommDestroy(c->nccl);
+    delete c;
+}
+
+int gndt_build_global_device(gndt_handle* h, gndt_comm* c, const void* shard_xyz_dev, size_t n, size_t stride_bytes,
+                             uint64_t first_idx_base, uint64_t total_points, gndt_exchange_times* times, void* hip_stream) {
+    int rc = check_ready(h);
+    if (rc) return rc;
+    if (!c || !c->nccl) { h->err = "no communicator"; return GNDT_ERR_INVALID; }
+    hipStream_t s = stream_of(h, hip_stream);
+    auto& X = h->exch;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    if (times) for (auto& e : ev) HIP_TRY(h, hipEventCreate(&e));
+    auto stamp = [&](int i) { if (times) (void)hipEventRecord(ev[i], s); };
+    stamp(0);
+    // 1. this rank's shard -> statistics of its occupied nodes (the partition pipeline's statistics epilogue)
+    gndt_stats st;
+    rc = gndt_shard_stats_device(h, shard_xyz_dev, n, stride_bytes, first_idx_base, &st, hip_stream);
+    if (rc) return rc;
+    stamp(1);
+    const uint32_t m = (uint32_t)st.num_nodes;
+    // 2. node counts of every rank (one tiny all-gather; the host needs them to size the key exchange)
+    const int W = c->world;
+    if ((rc = grow_buf(h, X.d_counts, X.counts_cap, (uint64_t)W))) return rc;
+    if (!X.h_counts) HIP_TRY(h, hipHostMalloc(&X.h_counts, 1024 * sizeof(unsigned long long)));
+    if (W > 1024) { h->err = "more than 1024 ranks"; return GNDT_ERR_INVALID; }
+    X.h_counts[c->rank] = m;
+    HIP_TRY(h, hipMemcpyAsync(X.d_counts + c->rank, X.h_counts + c->rank, sizeof(unsigned long long), hipMemcpyHostToDevice, s));
+    RCCL_TRY(h, rccl().AllGather(X.d_counts + c->rank, X.d_counts, 1, ncclUint64, c->nccl, s));
+    HIP_TRY(h, hipMemcpyAsync(X.h_counts, X.d_counts, (size_t)W * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+    HIP_TRY(h, hipStreamSynchronize(s));
+    uint64_t m_max = 1;
+    for (int r = 0; r < W; ++r) m_max = std::max<uint64_t>(m_max, X.h_counts[r]);
+    // 3. every rank's keys, padded to the longest list -> sorted unique union = canonical node order (identical on all ranks)
+    const uint64_t all = m_max * (uint64_t)W;
+    if (all >= 0xFFFFFFFFull) { h->err = "too many nodes for the exchange"; return GNDT_ERR_CAPACITY; }
+    if ((rc = grow_buf(h, X.keys_in, X.keys_in_cap, m_max))) return rc;
+    if ((rc = grow_buf(h, X.keys_all, X.keys_all_cap, all))) return rc;
+    if ((rc = grow_buf(h, X.keys_sorted, X.keys_sorted_cap, all))) return rc;
+    if ((rc = grow_buf(h, X.canon, X.canon_cap, all))) return rc;
+    if (!X.d_unique) HIP_TRY(h, hipMalloc(&X.d_unique, sizeof(unsigned int)));
+    if (m) HIP_TRY(h, hipMemcpyAsync(X.keys_in, st.key, (size_t)m * 8, hipMemcpyDeviceToDevice, s));
+    hipLaunchKernelGGL(k_exchange_pad, dim3(grid_for(m_max)), dim3(256), 0, s, X.keys_in, m, (uint32_t)m_max);
+    RCCL_TRY(h, rccl().AllGather(X.keys_in, X.keys_all, m_max, ncclUint64, c->nccl, s));
+    size_t tmp = 0, tmp2 = 0;
+    HIP_TRY(h, rocprim::radix_sort_keys(nullptr, tmp, X.keys_all, X.keys_sorted, (size_t)all, 0, 64, s));
+    HIP_TRY(h, rocprim::unique(nullptr, tmp2, X.keys_sorted, X.canon, X.d_unique, (size_t)all, rocprim::equal_to<uint64_t>(), s));
+    if ((rc = grow_buf(h, X.scratch, X.scratch_cap, (uint64_t)std::max(tmp, tmp2) + 256))) return rc;
+    size_t tb = (size_t)X.scratch_cap;
+    HIP_TRY(h, rocprim::radix_sort_keys(X.scratch, tb, X.keys_all, X.keys_sorted, (size_t)all, 0, 64, s));
+    tb = (size_t)X.scratch_cap;
+    HIP_TRY(h, rocprim::unique(X.scratch, tb, X.keys_sorted, X.canon, X.d_unique, (size_t)all, rocprim::equal_to<uint64_t>(), s));
+    unsigned int n_unique = 0;
+    HIP_TRY(h, hipMemcpyAsync(&n_unique, X.d_unique, sizeof n_unique, hipMemcpyDeviceToHost, s));
+    HIP_TRY(h, hipStreamSynchronize(s));
+    // (the pad value sorts last: drop it if some rank had fewer nodes than the longest list)
+    bool padded = false;
+    for (int r = 0; r < W; ++r) padded = padded || X.h_counts[r] < m_max;
+    if (m_max == 1) { bool any = false; for (int r = 0; r < W; ++r) any = any || X.h_counts[r] > 0; if (!any) padded = true; }
+    const uint32_t C = n_unique - (padded && n_unique ? 1u : 0u);
+    // 4. local statistics scattered into the canonical order, ONE packed sum all-reduce and one min all-reduce
+    if ((rc = grow_buf(h, X.packed, X.packed_cap, (uint64_t)std::max<uint32_t>(C, 1) * kExWidth))) return rc;
+    if ((rc = grow_buf(h, X.pfirst, X.pfirst_cap, (uint64_t)std::max<uint32_t>(C, 1)))) return rc;
+    if ((rc = grow_buf(h, X.r_sums, X.r_sums_cap, (uint64_t)std::max<uint32_t>(C, 1) * 9))) return rc;
+    if ((rc = grow_buf(h, X.r_count, X.r_count_cap, (uint64_t)std::max<uint32_t>(C, 1)))) return rc;
+    if (!X.d_missing) { HIP_TRY(h, hipMalloc(&X.d_missing, sizeof(uint32_t))); HIP_TRY(h, hipMemsetAsync(X.d_missing, 0, sizeof(uint32_t), s)); }
+    if (C) {
+        hipLaunchKernelGGL(k_exchange_init, dim3(grid_for((uint64_t)C * kExWidth)), dim3(256), 0, s, X.packed, X.pfirst, C);
+        if (m) hipLaunchKernelGGL(k_exchange_scatter, dim3(grid_for(m)), dim3(256), 0, s, (const uint64_t*)st.key, (const double*)st.sums,
+                                  (const uint32_t*)st.count, (const uint32_t*)st.first_idx, m, (const uint64_t*)X.canon, C, X.packed,
+                                  X.pfirst, X.d_missing);
+        HIP_TRY(h, hipGetLastError());
+        RCCL_TRY(h, rccl().AllReduce(X.packed, X.packed, (size_t)C * kExWidth, ncclDouble, ncclSum, c->nccl, s));
+        RCCL_TRY(h, rccl().AllReduce(X.pfirst, X.pfirst, (size_t)C, ncclUint32, ncclMin, c->nccl, s));
+        hipLaunchKernelGGL(k_exchange_unpack, dim3(grid_for(C)), dim3(256), 0, s, (const double*)X.packed, C, X.r_sums, X.r_count);
+        HIP_TRY(h, hipGetLastError());
+    }
+    stamp(2);
+    // 5. every rank: the reduced statistics (sorted by key) -> labels, order, rows: the map of the WHOLE cloud
+    gndt_stats red;
+    red.num_nodes = C; red.key = X.canon; red.sums = X.r_sums; red.count = X.r_count; red.first_idx = X.pfirst;
+    rc = gndt_finalize_stats_device(h, &red, total_points, hip_stream);
+    if (rc) return rc;
+    stamp(3);
+    if (times) {
+        HIP_TRY(h, hipStreamSynchronize(s));
+        float a = 0, b = 0, d = 0;
+        (void)hipEventElapsedTime(&a, ev[0], ev[1]); (void)hipEventElapsedTime(&b, ev[1], ev[2]); (void)hipEventElapsedTime(&d, ev[2], ev[3]);
+        times->shard_ms = a; times->exchange_ms = b; times->finalize_ms = d;
+        times->local_nodes = m; times->global_nodes = C; times->ranks = (uint32_t)W;
+        times->bytes_reduced = (uint64_t)C * (kExWidth * 8 + 4);
+        for (auto& e : ev) (void)hipEventDestroy(e);
+    }
     return GNDT_OK;
 }
 

@@ -116,6 +116,16 @@ struct gndt_handle {
         uint64_t serial = 0;            // result_serial the flood was computed for (0 = none)
         int ring_n = 0;
     } cost;
+    // statistics exchange of a sharded build (gndt_exchange.hpp, gndt_api_dist.hip)
+    struct Exchange {
+        unsigned long long* d_counts = nullptr; uint64_t counts_cap = 0; unsigned long long* h_counts = nullptr;
+        uint64_t *keys_in = nullptr, *keys_all = nullptr, *keys_sorted = nullptr, *canon = nullptr;
+        uint64_t keys_in_cap = 0, keys_all_cap = 0, keys_sorted_cap = 0, canon_cap = 0;
+        unsigned int* d_unique = nullptr;  uint32_t* d_missing = nullptr;
+        char* scratch = nullptr; uint64_t scratch_cap = 0;
+        double* packed = nullptr; uint64_t packed_cap = 0;  uint32_t* pfirst = nullptr; uint64_t pfirst_cap = 0;
+        double* r_sums = nullptr; uint64_t r_sums_cap = 0;  uint32_t* r_count = nullptr; uint64_t r_count_cap = 0;
+    } exch;
     uint64_t result_serial = 0;         // bumped whenever a build / finalize produces new result rows
     int last_strategy = GNDT_STRATEGY_ATOMIC;
     // strategy AUTO: what the locality sample said last time, for which cloud size, and how many builds ago

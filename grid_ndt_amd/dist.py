@@ -12,14 +12,55 @@ first-seen index combines with min, so ONE collective round bui
 torch.distributed is the transport (backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in the CPU
 tests); the reduction operands are only the OCCUPIED nodes, never the points.
 """
+import ctypes as C
+
 import torch
 import torch.distributed as dist
 
 INT32_MAX = 2**31 - 1
 
 
+class Communicator:
+    """The RCCL communicator libgndt's own exchange runs on (gndt_comm_*, include/gndt.h).  The 128-byte unique id is made
+    by rank 0 inside libgndt and handed to the other ranks through the process group that is already up (any backend):
+    that is the only use of torch.distributed on this path — the data never passes through it."""
+
+    def __init__(self, device, group=None):
+        from . import _lib
+        self._L = _lib.lib()
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        buf = C.create_string_buffer(128)
+        if rank == 0:
+            rc = self._L.gndt_comm_unique_id(buf)
+            if rc:
+                raise _lib.GndtError(rc, (self._L.gndt_comm_last_error() or b"").decode())
+        on_gpu = dist.get_backend(group) == "nccl"
+        t = torch.tensor(list(buf.raw), dtype=torch.uint8, device=f"cuda:{device}" if on_gpu else "cpu")
+        dist.broadcast(t, src=0, group=group)
+        ident = bytes(t.cpu().tolist())
+        h = C.c_void_p()
+        rc = self._L.gndt_comm_create(ident, rank, world, int(device), C.byref(h))
+        if rc:
+            raise _lib.GndtError(rc, (self._L.gndt_comm_last_error() or b"").decode())
+        self.handle, self.rank, self.world = h, rank, world
+
+    def close(self):
+        if self.handle:
+            self._L.gndt_comm_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def merge_stats(key, sums, count, first_idx, group=None):
-    """key [n] int64 (packed node keys, unique per rank), sums [n, 9] float64, count [n] int32,
+    """The same exchange spelled with torch.distributed collectives, for backends libgndt's RCCL path cannot use (the
+    world_size-2 gloo tests on CPU): all-gather of the keys -> sorted unique union -> ONE packed sum all-reduce over
+    [C, 10] fp64 (9 sums + count) and one min all-reduce (first-seen).
+    key [n] int64 (packed node keys, unique per rank), sums [n, 9] float64, count [n] int32,
     first_idx [n] int32 (global point indices, < 2^31).  Returns the globally reduced
     (key, sums, count, first_idx) in canonical (sorted-key) order, identical on every rank."""
     world = dist.get_world_size(group)
@@ -36,15 +77,15 @@ def merge_stats(key, sums, count, first_idx, group=None):
     union = torch.unique(torch.cat([g[:s] for g, s in zip(gathered, sizes)]))     # sorted: the canonical order
     c = union.shape[0]
     pos = torch.searchsorted(union, key)
-    g_sums = torch.zeros((c, 9), dtype=torch.float64, device=dev)
-    g_count = torch.zeros((c,), dtype=torch.int32, device=dev)
+    packed = torch.zeros((c, 10), dtype=torch.float64, device=dev)                 # 9 sums + the count (exact in fp64)
     g_first = torch.full((c,), INT32_MAX, dtype=torch.int32, device=dev)
-    g_sums[pos] = sums
-    g_count[pos] = count
+    packed[pos, :9] = sums
+    packed[pos, 9] = count.to(torch.float64)
     g_first[pos] = first_idx
-    dist.all_reduce(g_sums, op=dist.ReduceOp.SUM, group=group)
-    dist.all_reduce(g_count, op=dist.ReduceOp.SUM, group=group)
+    dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=group)
     dist.all_reduce(g_first, op=dist.ReduceOp.MIN, group=group)
+    g_sums = packed[:, :9].contiguous()
+    g_count = packed[:, 9].round().to(torch.int32)
     return union, g_sums, g_count, g_first
 
 

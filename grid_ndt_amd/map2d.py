@@ -10,7 +10,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import Cells, CostStats, GndtError, Params, Pcd, PointLayout, Robot, Stats
+from ._lib import Cells, CostStats, ExchangeTimes, GndtError, Params, Pcd, PointLayout, Robot, Stats
 
 DEMANDS = {"slope": 0, "true": 1}
 FLAG_HAS_STATS, FLAG_SLOPE, FLAG_DOWN = 1, 2, 4
@@ -262,6 +262,22 @@ class TwoDmap:
                                                     _stream_ptr(stream)))
         self._keep = keep
         return self._stats_tensors(st)
+
+    def build_global(self, comm, demand, points, first_idx_base, total_points, stream=None, timed=False):
+        """This rank's contiguous range of a sharded cloud -> the map of the WHOLE cloud on every rank: shard statistics,
+        RCCL exchange (called from C++ inside libgndt) and finalisation in one call.  `comm`: grid_ndt_amd.dist.Communicator."""
+        self._ensure(demand)
+        ptr, n, stride, on_dev, keep = self._as_input(points)
+        if not on_dev:
+            raise GndtError(1, "build_global takes device memory")
+        t = ExchangeTimes()
+        self._check(self._L.gndt_build_global_device(self._h, comm.handle, C.c_void_p(ptr), n, stride, int(first_idx_base), int(total_points),
+                                                     C.byref(t) if timed else None, _stream_ptr(stream)))
+        self._keep = keep
+        if timed:
+            return {"shard_ms": t.shard_ms, "exchange_ms": t.exchange_ms, "finalize_ms": t.finalize_ms, "ranks": int(t.ranks),
+                    "local_nodes": int(t.local_nodes), "global_nodes": int(t.global_nodes), "bytes_reduced": int(t.bytes_reduced)}
+        return None
 
     def finalize_stats(self, key, sums, count, first_idx, total_points, stream=None):
         """Merged statistics of the whole cloud (unique nodes sorted by key) -> the map."""

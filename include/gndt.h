@@ -193,6 +193,29 @@ int gndt_shard_stats_device(gndt_handle* h, const void* xyz_dev, size_t n, size_
                             gndt_stats* out, void* hip_stream);
 int gndt_finalize_stats_device(gndt_handle* h, const gndt_stats* in, uint64_t total_points, void* hip_stream);
 
+/* The whole sharded build behind the C ABI, RCCL called from C++ (resolved with dlopen: single-GPU users do not need it):
+ * one process per GPU, every rank calls gndt_build_global_device with ITS contiguous range of the cloud; on return every
+ * rank's handle holds the map of the whole cloud (origin = the global cloud's point 0 on every rank).
+ *   shard -> statistics | all-gather of the occupied keys -> canonical order | ONE packed all-reduce (9 sums + count, fp64)
+ *   + one min all-reduce (first-seen) | finalize from the reduced statistics.
+ * The communicator: rank 0 calls gndt_comm_unique_id and hands the 128 bytes to the other ranks by its own means (a file,
+ * MPI, torch.distributed ...); every rank then calls gndt_comm_create. */
+#define GNDT_COMM_ID_BYTES 128
+typedef struct gndt_comm gndt_comm;
+typedef struct {
+    float shard_ms, exchange_ms, finalize_ms;     /* device time of the three stages (HIP events on the stream) */
+    uint32_t ranks;
+    uint64_t local_nodes, global_nodes, bytes_reduced;
+} gndt_exchange_times;
+int gndt_comm_unique_id(char id_out[GNDT_COMM_ID_BYTES]);
+int gndt_comm_create(const char id[GNDT_COMM_ID_BYTES], int32_t rank, int32_t world, int32_t device_id, gndt_comm** out);
+void gndt_comm_destroy(gndt_comm* c);
+const char* gndt_comm_last_error(void);
+/* first_idx_base = index of shard[0] in the whole cloud's binned points; total_points = binned points of the whole cloud.
+ * `times` may be NULL (it makes the call wait for the stream). */
+int gndt_build_global_device(gndt_handle* h, gndt_comm* c, const void* shard_xyz_dev, size_t n, size_t stride_bytes,
+                             uint64_t first_idx_base, uint64_t total_points, gndt_exchange_times* times, void* hip_stream);
+
 /* ---- cost map over the finished grid -------------------------------------
  * gndt_compute_cost replaces TwoDmap::computeCost (include/map2D.h:1285-1397; called at receiver.cpp:171
  * right after create2DMap): the FIFO flood from the goal slope with CollisionCheck (:351-411; the 3D variants

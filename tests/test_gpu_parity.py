@@ -399,6 +399,24 @@ def test_global_map_exchange_on_rccl_single_rank():
         pts = torch.from_numpy(cloud[1:]).cuda()
         build_global_map(m, "slope", pts, 0)
         parity.assert_parity(m.export(), ref)
+        # the same build with the exchange inside libgndt (RCCL called from C++, gndt_build_global_device): the
+        # communicator's id travels over the process group, the data does not
+        from grid_ndt_amd.dist import Communicator
+        comm = Communicator(0)
+        m2 = g.TwoDmap(TERRAIN["grid_len"], TERRAIN["z_len"])
+        m2.setInterval(TERRAIN["slope_interval"])
+        m2.setCloudFirst(cloud[0])
+        t = m2.build_global(comm, "slope", pts, 0, pts.shape[0], timed=True)
+        print("exchange inside libgndt:", t)
+        assert t["ranks"] == 1 and t["global_nodes"] == t["local_nodes"] == ref["num_nodes"]
+        parity.assert_parity(m2.export(), ref)
+        # a rank whose shard is empty still takes part
+        m3 = g.TwoDmap(TERRAIN["grid_len"], TERRAIN["z_len"])
+        m3.setInterval(TERRAIN["slope_interval"])
+        m3.setCloudFirst(cloud[0])
+        m3.build_global(comm, "slope", pts[:0], 0, 0)
+        assert m3.sync() == (0, 0, 0)
+        comm.close()
     finally:
         dist.destroy_process_group()
 
