@@ -13,15 +13,16 @@ from tests.test_input_side import _write_pcd
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _build_example():
+def _build_example(name="receiver_main"):
     from grid_ndt_amd import _lib
-    exe = os.path.join(ROOT, "examples", "receiver_main")
+    exe = os.path.join(ROOT, "examples", name)
     src = exe + ".cpp"
     deps = [src, os.path.join(ROOT, "include", "gndt_compat.hpp"), os.path.join(ROOT, "include", "gndt.h"), _lib.LIB_PATH]
     if not os.path.exists(exe) or any(os.path.getmtime(d) > os.path.getmtime(exe) for d in deps):
         csrc = os.path.dirname(_lib.LIB_PATH)
         hip = _lib._hip_runtime_dir()
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-I", os.path.join(ROOT, "include"), "-o", exe, src, "-L", csrc,
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-D__HIP_PLATFORM_AMD__", "-I", os.path.join(ROOT, "include"), "-I", "/opt/rocm/include",
+                               "-o", exe, src, "-L", csrc,
                                "-l:libgndt.so", "-L", hip, "-l:libamdhip64.so", f"-Wl,-rpath,{csrc}", f"-Wl,-rpath,{hip}"])
     return exe
 
@@ -71,3 +72,24 @@ def test_example_route_equals_the_oracle(tmp_path, native_lib):
             i, j = rows[a], rows[b]
             dx, dy = abs(int(ref["sx"][i]) - int(ref["sx"][j])), abs(int(ref["sy"][i]) - int(ref["sy"][j]))
             assert sorted((min(dx, 2), min(dy, 2))) in ([0, 1], [0, 2])      # one step along one axis (2 = across the seam -1 -> 1)
+
+
+def test_sharded_example_builds(native_lib):
+    _build_example("sharded_build")
+
+
+@pytest.mark.gpu
+def test_sharded_example_one_rank_equals_the_oracle(tmp_path, native_lib):
+    """examples/sharded_build.cpp: the sharded build from a plain C++ host (RCCL inside libgndt), here with one rank."""
+    from tests import parity
+    exe = _build_example("sharded_build")
+    cloud = scenes.terrain_cloud(150_000)
+    P = dict(grid_len=0.2, z_len=0.2, slope_interval=0.08, demand="slope")
+    path = str(tmp_path / "cloud.f32")
+    np.ascontiguousarray(cloud, np.float32).tofile(path)
+    r = subprocess.run([exe, path, str(cloud.shape[0]), "0.2", "0.2", "0.08", "0", "1", str(tmp_path / "id.bin"), "0"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    ref = parity.ref_from_cloud(cloud, P)
+    want = f"nodes {ref['num_nodes']} columns {ref['num_columns']} slopes {int(np.count_nonzero(ref['flags'] & 2))}"
+    assert want in r.stdout, r.stdout
