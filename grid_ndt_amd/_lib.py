@@ -187,6 +187,8 @@ def lib():
     L.gndt_get_phase_times.argtypes = [H, C.POINTER(C.c_double)]
     L.gndt_debug_bucket_phases.argtypes = [H, C.POINTER(C.c_double), C.POINTER(C.c_uint32)]
     L.gndt_debug_bucket_phases.restype = C.c_int
+    L.gndt_debug_retry_count.argtypes = [H, C.POINTER(u64)]
+    L.gndt_debug_retry_count.restype = C.c_int
     L.gndt_debug_enable_stamps.argtypes = [C.c_int]
     L.gndt_debug_enable_stamps.restype = C.c_int
     L.gndt_comm_unique_id.argtypes = [C.c_char_p]

@@ -41,8 +41,8 @@ namespace {
 // otherwise: average load <= 0.5 of `slots` against an estimate that already carries a 20 % margin, i.e. ~0.42 of
 // the slots really used, ~5 sigma of the column count below the overflow limit of 0.78.  (An overflow is not an
 // error: the build is re-run with the larger table / more buckets.)
-uint64_t buckets_for(uint64_t n, uint64_t nodes, int slots) {
-    const int load_pct = tuning().bucket_load, pts_target = tuning().bucket_points;
+uint64_t buckets_for(uint64_t n, uint64_t nodes, int slots, int load_pct) {
+    const int pts_target = tuning().bucket_points;
     if (pts_target) return std::max<uint64_t>(n / (uint64_t)pts_target, 16);
     // k_bucket_owner takes a bucket in ONE chunk of kOwnerChunk records when it can: mean 1600 leaves 3 sigma of the
     // column-granular spread of a hash partition (a fuller bucket simply takes a second chunk)
@@ -69,12 +69,14 @@ int partition_launch(gndt_handle* h, gndt_handle::Pending& P) {
     const uint32_t nwg = (uint32_t)std::min<uint64_t>((uint64_t)part_wgs, std::max<uint64_t>(1, n / 8192));
     const uint64_t words = (n + 31) / 32 + 1;
     int rc;
+    // identical consecutive points travel as weighted records whose index word gives up two bits (gndt_partition.hpp)
+    const uint32_t compress = ((uint64_t)P.first_base + n < (uint64_t)kWeightIndexLimit) ? 1u : 0u;
     const GridParams gp = P.gp;                        // as they were at launch (a retry must not pick up a new origin)
     const float* p = static_cast<const float*>(P.xyz);
     // table size and bucket count for this attempt: 512-slot tables unless that needs too many buckets
     // attempt 0: 512-slot tables; an overflow first doubles the table (same estimate), then raises the estimate
     int bslots = env_slots ? env_slots : (attempt == 0 ? 512 : 1024);
-    uint64_t Bw = buckets_for(n, nodes_est, bslots);
+    uint64_t Bw = buckets_for(n, nodes_est, bslots, q.load_pct);
     // Two-level partition (no counting passes) for large builds; the exact single-level counting partition for small
     // ones, when asked for (GNDT_STRATEGY_PARTITION_EXACT), and after a region overflowed once on this handle.
     const int env_two = tuning().two_level;
@@ -82,11 +84,11 @@ int partition_launch(gndt_handle* h, gndt_handle::Pending& P) {
                (n >= (1u << 20) || h->P.strategy == GNDT_STRATEGY_PARTITION_TWO_LEVEL);
     if (env_two == 0 || n == 0) two = false;
     if (two && Bw > (uint64_t)kMaxFan * kMaxFan) {         // more buckets than two levels address: larger tables, fewer buckets
-        if (!env_slots) { bslots = 1024; Bw = buckets_for(n, nodes_est, bslots); }
+        if (!env_slots) { bslots = 1024; Bw = buckets_for(n, nodes_est, bslots, q.load_pct); }
         if (Bw > (uint64_t)kMaxFan * kMaxFan) two = false;
     }
     if (!two) {
-        if (!env_slots && Bw > kMaxBuckets) { bslots = 1024; Bw = buckets_for(n, nodes_est, bslots); }
+        if (!env_slots && Bw > kMaxBuckets) { bslots = 1024; Bw = buckets_for(n, nodes_est, bslots, q.load_pct); }
         if (Bw > kMaxBuckets) return -1;                   // too many nodes for one partition level: atomic path
     }
     const uint32_t B = (uint32_t)Bw;
@@ -153,7 +155,7 @@ int partition_launch(gndt_handle* h, gndt_handle::Pending& P) {
         const dim3 g1(std::min<uint32_t>(tiles1, l1_wgs)), g2((uint32_t)((cap1 + kTile2 - 1) / kTile2), V);
 #define GNDT_L1(SF_, FAN_)                                                                                                  \
     hipLaunchKernelGGL((k_part2_level1<SF_, FAN_>), g1, dim3(kTileThreads), 0, s, p, (uint64_t)n, P.first_base, gp, B, F1, F2_shift, \
-                       R, cursor1, cap1, est2, q.recs1, h->d_cnt, q.d_pc)
+                       R, cursor1, cap1, est2, q.recs1, h->d_cnt, q.d_pc, compress)
         if (stride_bytes == 12) { if (wide) GNDT_L1(3, 512); else GNDT_L1(3, 256); }
         else { if (wide) GNDT_L1(4, 512); else GNDT_L1(4, 256); }
 #undef GNDT_L1
@@ -200,9 +202,9 @@ int partition_launch(gndt_handle* h, gndt_handle::Pending& P) {
         HIP_TRY(h, hipFuncSetAttribute((const void*)k_part_scatter<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
     if (stride_bytes == 12)
-        hipLaunchKernelGGL(k_part_hist<3>, dim3(nwg), dim3(kPartThreads), lds, s, p, (uint64_t)n, gp, B, q.hist, h->d_cnt);
+        hipLaunchKernelGGL(k_part_hist<3>, dim3(nwg), dim3(kPartThreads), lds, s, p, (uint64_t)n, gp, B, q.hist, h->d_cnt, compress);
     else
-        hipLaunchKernelGGL(k_part_hist<4>, dim3(nwg), dim3(kPartThreads), lds, s, p, (uint64_t)n, gp, B, q.hist, h->d_cnt);
+        hipLaunchKernelGGL(k_part_hist<4>, dim3(nwg), dim3(kPartThreads), lds, s, p, (uint64_t)n, gp, B, q.hist, h->d_cnt, compress);
     HIP_TRY(h, hipGetLastError());
     mark(h, 2, s);
     hipLaunchKernelGGL(k_part_offsets, dim3((B + 31) / 32), dim3(256), 0, s, q.hist, q.totals, B, nwg);
@@ -210,10 +212,10 @@ int partition_launch(gndt_handle* h, gndt_handle::Pending& P) {
     mark(h, 3, s);
     if (stride_bytes == 12)
         hipLaunchKernelGGL(k_part_scatter<3>, dim3(nwg), dim3(kPartThreads), lds, s, p, (uint64_t)n, P.first_base, gp, B, q.hist,
-                           q.totals, q.bucket_base, q.recs);
+                           q.totals, q.bucket_base, q.recs, compress);
     else
         hipLaunchKernelGGL(k_part_scatter<4>, dim3(nwg), dim3(kPartThreads), lds, s, p, (uint64_t)n, P.first_base, gp, B, q.hist,
-                           q.totals, q.bucket_base, q.recs);
+                           q.totals, q.bucket_base, q.recs, compress);
     HIP_TRY(h, hipGetLastError());
     mark(h, 4, s);
     range_lo = q.bucket_base; range_hi = q.bucket_base + 1;
@@ -284,8 +286,15 @@ int partition_begin(gndt_handle* h, const void* xyz_dev, size_t n, size_t stride
     P = gndt_handle::Pending{};
     P.xyz = xyz_dev; P.n = n; P.stride = stride_bytes; P.s = s; P.attempt = 0;
     P.gp = grid_params(h);
+    // What the last build of a cloud of this size needed (larger tables, a doubled estimate) is where this one starts: without
+    // it every build of such a cloud would first fail with the small tables and be run twice.
+    const bool similar = q.good_n && n <= 2 * q.good_n && 2 * n >= q.good_n;
+    if (similar && q.good_slots == 1024) P.attempt = 1;
     // expected node count: the caller's hint, else what the previous build of this handle found, else n/4
     P.nodes_est = h->P.max_nodes_hint ? h->P.max_nodes_hint : (q.nodes_learned ? q.nodes_learned : std::max<uint64_t>(n / 4, 1024));
+    P.est_reliable = h->P.max_nodes_hint != 0 || q.nodes_learned != 0;      // (not the n / 4 guess of a first build)
+    if (similar && q.good_slots == 1024) P.nodes_est = std::max<uint64_t>(P.nodes_est, q.good_est);   // (an estimate that had to be doubled)
+    P.est0 = P.nodes_est;
     P.stage_want = std::max<uint64_t>(q.stage_cap, h->P.max_nodes_hint ? h->P.max_nodes_hint + h->P.max_nodes_hint / 8
                                                                        : std::max<uint64_t>(4096, n / 4));
     const int prev_strategy = h->last_strategy;
@@ -319,11 +328,17 @@ int partition_resolve(gndt_handle* h) {
                 fprintf(stderr, "[gndt] two-level partition: fullest level-1 region %.2fx the mean, overflow %u\n",
                         q.h_pc->max_fill1 / P.mean1, q.h_pc->part_overflow);
         }
+        if (tuning().verbose && (q.h_pc->part_overflow | q.h_pc->lds_overflow | q.h_pc->stage_overflow))
+            fprintf(stderr, "[gndt] build of %zu points, attempt %d (%d-slot tables, %llu nodes expected): region overflow %u, table overflow %u, "
+                            "staging overflow %u -> re-run\n", P.n, P.attempt, P.bslots, (unsigned long long)P.nodes_est, q.h_pc->part_overflow,
+                    q.h_pc->lds_overflow, q.h_pc->stage_overflow);
         if (q.h_pc->part_overflow) {                           // a region of the two-level partition was too small: same table
             ++q.two_level_failures;                            // size and estimate again (level-1 regions sized from the fullest
             --P.attempt;                                       // one seen; after two failures the exact counting partition)
             again = true;
         } else if (q.h_pc->lds_overflow) {                            // some bucket holds too many nodes for its LDS table:
+            // (Lowering the average table load instead — more, smaller buckets — was measured: 1.19 ms against 0.80 ms with the
+            // 1024-slot tables on the 3 M-node variant of the bench scene, and it does not help a hot column at all.)
             if (P.attempt >= 1 || env_slots) P.nodes_est *= 2;   // (attempt 0 -> 1 only switches to the 1024-slot table)
             again = true;
         } else if (q.h_pc->stage_overflow) {                   // num_nodes kept counting: it is the true total
@@ -332,7 +347,11 @@ int partition_resolve(gndt_handle* h) {
         }
         if (!again) {
             q.nodes_learned = (uint64_t)h->h_cnt->num_nodes + h->h_cnt->num_nodes / 5;
-            q.good_slots = P.bslots; q.good_est = P.nodes_est; q.good_n = P.n;
+            // the larger tables are remembered only if the small ones failed although the estimate was adequate (a first build
+            // without a hint guesses n / 4 nodes: its failure says nothing about the cloud)
+            const bool est_was_fine = P.est_reliable && P.est0 >= (uint64_t)h->h_cnt->num_nodes;
+            q.good_slots = (P.bslots == 1024 && !est_was_fine) ? 0 : P.bslots;
+            q.good_est = P.nodes_est; q.good_n = P.n;
             if (!P.stats_only) {
                 h->results_valid = true;
                 ++h->result_serial;
@@ -342,6 +361,7 @@ int partition_resolve(gndt_handle* h) {
             return GNDT_OK;
         }
         rc = -1;
+        ++q.retries_total;
         if (++P.attempt < 5) rc = partition_launch(h, P);
         if (rc == GNDT_OK) continue;
         P.active = false;
@@ -405,6 +425,12 @@ int gndt_build(gndt_handle* h, const void* xyz_host, size_t n, size_t stride_byt
     rc = gndt_build_device(h, h->stage, n, stride_bytes, h->own_stream);
     if (rc) return rc;
     return gndt_sync(h, nullptr, nullptr, nullptr);
+}
+
+int gndt_debug_retry_count(gndt_handle* h, uint64_t* retries) {
+    if (!h || !retries) return GNDT_ERR_INVALID;
+    *retries = h->part.retries_total;
+    return GNDT_OK;
 }
 
 int gndt_debug_enable_stamps(int on) { tuning_force_stamps(on != 0); return GNDT_OK; }

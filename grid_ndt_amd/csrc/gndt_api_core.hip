@@ -209,6 +209,7 @@ int gndt_create(const gndt_params* params, gndt_handle** out) {
         if (rc) { g_create_error = h->err; gndt_destroy(h); return rc; }
         if ((e = hipStreamSynchronize(h->own_stream)) != hipSuccess) return fail("hipStreamSynchronize", e);
     }
+    h->part.load_pct = tuning().bucket_load;
     *out = h;
     return GNDT_OK;
 }

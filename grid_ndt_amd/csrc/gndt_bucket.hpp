@@ -228,16 +228,16 @@ __device__ __forceinline__ void bucket_build_one(BucketLds2<H, CH>& L, const uin
                     }
                 }
                 if (s != 0xFFFFFFFFu) {
-                    const bool w64 = (qi[j] & kWeight64Flag) != 0u;
-                    const double w = w64 ? 64.0 : 1.0;
+                    const uint32_t wn = record_weight(qi[j]);
+                    const double w = (double)wn;
                     const double v0 = (double)qx[j] - c0, v1 = (double)qy[j] - c1, v2 = (double)qz[j] - c2;
                     const double w0 = w * v0, w1 = w * v1, w2 = w * v2;     // exact: w is a power of two
                     a0 += w0; a1 += w1; a2 += w2;
                     // fused multiply-add on purpose: one rounding per term (the sums are order-free anyway)
                     a3 = fma(w0, v0, a3); a4 = fma(w0, v1, a4); a5 = fma(w0, v2, a5);
                     a6 = fma(w1, v1, a6); a7 = fma(w1, v2, a7); a8 = fma(w2, v2, a8);
-                    rn += w64 ? 64u : 1u;
-                    rfirst = min(rfirst, qi[j] & ~kWeight64Flag);
+                    rn += wn;
+                    rfirst = min(rfirst, record_index(qi[j]));
                 }
             }
             if (cur != 0xFFFFFFFFu) {

@@ -11,7 +11,8 @@
 //   then, on the finished table
 //       compact the occupied slots (wave ballots), so that the per-node phases run on dense lanes
 //       columns : column table + per-column linked list of nodes, fp32 mean-z
-//       rows    : slope label and index in column by walking the short list; mean + fp64 scatter -> 96-B staging row
+//       rows    : slope label and index in column by walking the short list; mean + fp64 scatter -> 96-B staging row,
+//                 written WHOLE by one lane (a row written in two parts by two lanes cost twice the bytes at the memory side)
 //
 // ~120 instructions per point, bounded by the LDS atomic unit (ds_add_f64: ~2.5 lanes per clock and CU) instead of
 // by instruction issue.  Hot buckets need no special casing (no chunk image to overflow); 64 identical consecutive
@@ -45,9 +46,8 @@ struct BucketLds3 {           // 52.0 KB at H = 512: three workgroups per CU
 };
 constexpr uint32_t kNoNode = 0xFFFFFFFFu;
 
-// Workgroup barrier that orders LDS traffic ONLY.  __syncthreads() also waits for every global store of the wave to be
-// acknowledged (~1-2 us once staging rows have been written); the phases of the bucket kernels hand over LDS contents,
-// their global stores are read by later kernels.
+// Workgroup barrier that orders LDS traffic ONLY (__syncthreads() also waits for the wave's global stores): the phases of
+// the bucket kernels hand over LDS contents, their global stores are read by later kernels.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // slot of a node inside its bucket's table.  The bucket is chosen by the TOP bits of the column hash (bucket_of), so its
@@ -129,13 +129,13 @@ __device__ __forceinline__ void bucket_direct_one(BucketLds3<H>& L, const uint32
             const double v0 = (double)rec[j].x - fma((double)(2 * k[j].sx - (k[j].sx > 0 ? 1 : -1)), hx, ox);
             const double v1 = (double)rec[j].y - fma((double)(2 * k[j].sy - (k[j].sy > 0 ? 1 : -1)), hx, oy);
             const double v2 = (double)rec[j].z - fma((double)(2 * k[j].sz - (k[j].sz > 0 ? 1 : -1)), hz, oz);
-            const bool w64 = (iw & kWeight64Flag) != 0u;          // 64 identical points in one record (exact: power of two)
-            const double wf = w64 ? 64.0 : 1.0;
+            const uint32_t wn = record_weight(iw);                // 64 or 512 identical points in one record (exact: powers of two)
+            const double wf = (double)wn;
             const double w0 = wf * v0, w1 = wf * v1, w2 = wf * v2;
             c[j][0] = w0; c[j][1] = w1; c[j][2] = w2;
             c[j][3] = w0 * v0; c[j][4] = w0 * v1; c[j][5] = w0 * v2; c[j][6] = w1 * v1; c[j][7] = w1 * v2; c[j][8] = w2 * v2;
-            cn[j] = w64 ? 64u : 1u;
-            cf[j] = iw & ~kWeight64Flag;
+            cn[j] = wn;
+            cf[j] = record_index(iw);
         }
         if (pair) {
 #pragma unroll
@@ -209,34 +209,14 @@ __device__ __forceinline__ void bucket_direct_one(BucketLds3<H>& L, const uint32
         return;
     }
 
-    // ---- per-node work, spread over the whole workgroup: items [0, M) join their column's list and set the fp32 mean-z,
-    //      items [M, 2M) turn the sums into mean + fp64 scatter and write that part of the staging row (nothing in it
-    //      depends on the columns), so the M nodes keep 2M lanes busy instead of M ----
-    for (uint32_t w = tid; w < 2u * M; w += T) {
-        const bool moments = w >= M;
-        const uint32_t i = moments ? w - M : w;
+    // ---- columns: every node joins the list of its column; fp32 mean-z of the nodes that have statistics ----
+    for (uint32_t i = tid; i < M; i += T) {
         const uint32_t s = L.list[i];
         const uint64_t key = L.key[s];
         int sx, sy, sz;
         unpack_key(key, sx, sy, sz);
         const uint32_t n = L.cnt[s];
-        const bool has = n >= (uint32_t)P.min_points;
-        if (moments) {
-            StageRow* __restrict__ const row = stage + sbase + i;
-            float mean[3] = {0.f, 0.f, 0.f};
-            double S[6] = {0, 0, 0, 0, 0, 0};
-            if (has) {
-                double sums[9];
-#pragma unroll
-                for (int j = 0; j < 9; ++j) sums[j] = L.sum[j][s];
-                const double c[3] = {axis_centre(sx, P.ox, P.grid_len), axis_centre(sy, P.oy, P.grid_len), axis_centre(sz, P.oz, P.z_len)};
-                node_moments(n, sums, c, mean, S);
-            }
-            for (int q = 0; q < 3; ++q) row->mean[q] = mean[q];
-            for (int q = 0; q < 6; ++q) row->scatter[q] = S[q];
-            continue;
-        }
-        L.mean_z[s] = has ? node_mean_z(n, L.sum[2][s], axis_centre(sz, P.oz, P.z_len)) : 0.f;
+        L.mean_z[s] = (n >= (uint32_t)P.min_points) ? node_mean_z(n, L.sum[2][s], axis_centre(sz, P.oz, P.z_len)) : 0.f;
         const uint64_t ck = column_key(key);
         uint32_t c = ((column_hash(sx, sy) * 0x85EBCA77u) >> 12) & (uint32_t)(H - 1);
         for (int probe = 0; probe < H; ++probe) {            // (terminates: the table has more slots than nodes)
@@ -250,12 +230,12 @@ __device__ __forceinline__ void bucket_direct_one(BucketLds3<H>& L, const uint32
         }
         L.cslot[s] = (uint16_t)c;
     }
-    lds_barrier();                                 // (the moments' row stores stay in flight)
+    __syncthreads();
     GNDT_STAMP3(3);
     if (tid == 0) atomicAdd(&cnt->num_columns, L.n_cols);
 
     // ---- rows: slope label (OcNode::isSlope, map2D.h:66-108), index in column, column size and first-seen index by
-    //      walking the column's short list -> the head of the staging row ----
+    //      walking the column's short list; mean + fp64 scatter -> staging row ----
     uint32_t my_slopes = 0;
     for (uint32_t i = tid; i < M; i += T) {
         const uint32_t s = L.list[i];
@@ -288,11 +268,21 @@ __device__ __forceinline__ void bucket_direct_one(BucketLds3<H>& L, const uint32
             if (P.demand == 0) slope = !up; else down = false;
             if (slope) { fl |= 2u; if (down) fl |= 4u; ++my_slopes; }
         }
+        StageRow row;
+        row.sx = sx; row.sy = sy; row.sz = sz;
+        row.count = my_n; row.first = my_first; row.flags = fl;
+        for (int k = 0; k < 3; ++k) row.mean[k] = 0.f;
+        for (int k = 0; k < 6; ++k) row.scatter[k] = 0.0;
+        if (fl & 1u) {
+            double sums[9];
+#pragma unroll
+            for (int j = 0; j < 9; ++j) sums[j] = L.sum[j][s];
+            const double c[3] = {axis_centre(sx, P.ox, P.grid_len), axis_centre(sy, P.oy, P.grid_len), axis_centre(sz, P.oz, P.z_len)};
+            node_moments(row.count, sums, c, row.mean, row.scatter);
+        }
+        row.col_first = cf; row.idx_in_col = icol; row.ncol = ncol;
         const uint32_t dst = sbase + i;
-        StageRow* __restrict__ const row = stage + dst;
-        row->sx = sx; row->sy = sy; row->sz = sz;
-        row->count = my_n; row->first = my_first; row->flags = fl;
-        row->col_first = cf; row->idx_in_col = icol; row->ncol = ncol;
+        stage[dst] = row;
         ord_cf[dst] = cf;
         ord_idx[dst] = icol;
         if (icol == 0) note_column(O, cf, ncol);

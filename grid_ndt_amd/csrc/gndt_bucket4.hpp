@@ -82,15 +82,15 @@ struct OwnerAcc {               // one node's additive statistics, in the owning
 __device__ __forceinline__ void owner_add(OwnerAcc& a, const float4& r, double c0, double c1, double c2) {
     const uint32_t iw = __float_as_uint(r.w);
     const double v0 = (double)r.x - c0, v1 = (double)r.y - c1, v2 = (double)r.z - c2;
-    const bool w64 = (iw & kWeight64Flag) != 0u;          // 64 identical points in one record (exact: power of two)
-    const double wf = w64 ? 64.0 : 1.0;
+    const uint32_t wn = record_weight(iw);                // 64 or 512 identical points in one record (exact: powers of two)
+    const double wf = (double)wn;
     const double w0 = wf * v0, w1 = wf * v1, w2 = wf * v2;
     a.s0 += w0; a.s1 += w1; a.s2 += w2;
     // fused multiply-add on purpose: one rounding per term (the sums are order-free anyway)
     a.s3 = fma(w0, v0, a.s3); a.s4 = fma(w0, v1, a.s4); a.s5 = fma(w0, v2, a.s5);
     a.s6 = fma(w1, v1, a.s6); a.s7 = fma(w1, v2, a.s7); a.s8 = fma(w2, v2, a.s8);
-    a.cnt += w64 ? 64u : 1u;
-    a.first = min(a.first, iw & ~kWeight64Flag);
+    a.cnt += wn;
+    a.first = min(a.first, record_index(iw));
 }
 
 __device__ __forceinline__ double wave_sum_all(double v) {   // every lane gets the sum

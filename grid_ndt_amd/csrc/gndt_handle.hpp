@@ -104,6 +104,8 @@ struct gndt_handle {
         uint32_t last_buckets = 0;
         uint64_t nodes_learned = 0;   // node count of the last successful PARTITION build (+20 %)
         int good_slots = 0; uint64_t good_est = 0, good_n = 0;   // table size / estimate that worked last time
+        int load_pct = 60;          // average LDS-table load (percent) the bucket count aims at
+        uint64_t retries_total = 0; // builds re-run because a table / region / staging area was too small (gndt_debug_retry_count)
     } part;
     // cost-map flood over the finished grid (gndt_cost.hpp)
     struct Cost {
@@ -148,7 +150,8 @@ struct gndt_handle {
         const void* xyz = nullptr; size_t n = 0, stride = 0;
         hipStream_t s = nullptr;
         int attempt = 0, bslots = 0;
-        uint64_t nodes_est = 0, stage_want = 0;
+        uint64_t nodes_est = 0, stage_want = 0, est0 = 0;   // est0: the estimate the first attempt used
+        bool est_reliable = false;      //   ... and whether it came from a hint / an earlier build rather than the n / 4 guess
         bool two_level = false;         // this attempt used the two-level partition
         double mean1 = 0.0;             // its mean level-1 region fill (to turn the fullest region into a ratio)
         bool stats_only = false;        // gndt_shard_stats_device: statistics out, no labels / ordering / rows
@@ -165,7 +168,7 @@ using namespace gndt;
 
 // Diagnostic / tuning knobs from the environment, parsed ONCE per process (DESIGN.md "Diagnostic and tuning knobs").
 struct Tuning {
-    int bucket_load = 50;        // GNDT_BUCKET_LOAD    average LDS-table load (percent) that sizes the bucket count
+    int bucket_load = 60;        // GNDT_BUCKET_LOAD    average LDS-table load (percent) that sizes the bucket count
     int bucket_points = 0;       // GNDT_BUCKET_POINTS  points per bucket (0 = derived)
     int bucket_kernel = 3;       // GNDT_BUCKET_KERNEL  3 = k_bucket_direct (default), 4 = k_bucket_owner, 2 = k_bucket_build2 (A/B measurements)
     int bucket_slots = 0;        // GNDT_BUCKET_SLOTS   k_bucket_build2 variant (0 = 512, 1024 on retry)

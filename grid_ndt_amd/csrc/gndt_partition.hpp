@@ -112,7 +112,13 @@ __device__ __forceinline__ void column_of_point(float px, float py, const GridPa
     sy = axis_from_ceil(cy, py, P.oy, ok, kMaxXY);
 }
 
-constexpr uint32_t kWeight64Flag = 0x80000000u;   // in a record's index word: the record stands for 64 identical points
+// A record's index word.  Bit 31: the record stands for 64 identical consecutive points (one wave of the partition pass:
+// the (0,0,0) padding of the reference's own clouds); with bit 30 as well for 512 of them (all eight groups a
+// wave handles in a tile).  Weighted records keep the index of their FIRST point in the low 30 bits; clouds of 2^30 points
+// or more are simply not compressed.
+constexpr uint32_t kWeight64Flag = 0x80000000u, kWeight512Flag = 0x40000000u, kWeightIndexLimit = 0x40000000u;
+__host__ __device__ __forceinline__ uint32_t record_weight(uint32_t iw) { return (iw & kWeight64Flag) ? ((iw & kWeight512Flag) ? 512u : 64u) : 1u; }
+__host__ __device__ __forceinline__ uint32_t record_index(uint32_t iw) { return (iw & kWeight64Flag) ? (iw & (kWeightIndexLimit - 1u)) : iw; }
 
 // true (wave-uniformly) iff all 64 lanes are `use` and hold bit-identical coordinates
 __device__ __forceinline__ bool wave_all_identical(float px, float py, float pz, bool use) {
@@ -151,7 +157,7 @@ static __global__ void __launch_bounds__(256) k_part_clear(Counters* __restrict_
 template <int STRIDE_FLOATS>
 __global__ void __launch_bounds__(kPartThreads) k_part_hist(const float* __restrict__ xyz, uint64_t n, GridParams P,
                                                             uint32_t B, uint32_t* __restrict__ hist,
-                                                            Counters* __restrict__ cnt) {
+                                                            Counters* __restrict__ cnt, uint32_t compress) {
     extern __shared__ uint32_t lh[];
     for (uint32_t i = threadIdx.x; i < B; i += kPartThreads) lh[i] = 0;
     __syncthreads();
@@ -169,7 +175,7 @@ __global__ void __launch_bounds__(kPartThreads) k_part_hist(const float* __restr
         const bool use = live && kok;
         // 64 consecutive identical points (the (0,0,0) padding of the reference's clouds) become ONE
         // weighted record: counted once here, written once by k_part_scatter
-        const bool same = wave_all_identical(px, py, pz, use);
+        const bool same = compress && wave_all_identical(px, py, pz, use);
         if (use && (!same || (threadIdx.x & 63) == 0)) atomicAdd(&lh[bucket_of(column_hash(sx, sy), B)], 1u);
     }
     __syncthreads();
@@ -240,7 +246,7 @@ __global__ void __launch_bounds__(kPartThreads) k_part_scatter(const float* __re
                                                                const uint32_t* __restrict__ hist,
                                                                const uint32_t* __restrict__ totals,
                                                                uint32_t* __restrict__ bucket_base,
-                                                               float4* __restrict__ recs) {
+                                                               float4* __restrict__ recs, uint32_t compress) {
     extern __shared__ uint32_t cur[];
     __shared__ uint32_t wave_sums[kPartThreads / 64];
     block_scan_totals(totals, B, cur, wave_sums);
@@ -262,7 +268,7 @@ __global__ void __launch_bounds__(kPartThreads) k_part_scatter(const float* __re
         bool kok;
         column_of_point(px, py, P, sx, sy, kok);
         const bool use = live && kok;
-        const bool same = wave_all_identical(px, py, pz, use);
+        const bool same = compress && wave_all_identical(px, py, pz, use);
         if (use && (!same || (threadIdx.x & 63) == 0)) {
             const uint32_t pos = atomicAdd(&cur[bucket_of(column_hash(sx, sy), B)], 1u);
             // bit 31 of the index word marks a record that stands for 64 identical points (lane 0 = the first of them)
@@ -376,12 +382,12 @@ __device__ __forceinline__ void tile_partition(TileLds<PER, FAN>& L, const float
 // with their own cursors (tile t fills sub-region t % R) to spread the reservations of thousands of tiles over
 // more words (same-address atomics serialise at the memory side); with 4096-point tiles R = 1 measured best.
 template <int STRIDE_FLOATS, int FAN>
-__global__ void __launch_bounds__(kTileThreads) k_part2_level1(const float* __restrict__ xyz, uint64_t n, uint32_t first_base,
+__global__ void __launch_bounds__(kTileThreads) __attribute__((amdgpu_waves_per_eu(4, 4))) k_part2_level1(const float* __restrict__ xyz, uint64_t n, uint32_t first_base,
                                                                GridParams P, uint32_t B, uint32_t F1, uint32_t F2_shift, uint32_t R,
                                                                uint32_t* __restrict__ cursor1, uint32_t cap1,
                                                                uint32_t* __restrict__ est2,
                                                                float4* __restrict__ recs1, Counters* __restrict__ cnt,
-                                                               PartCounters* __restrict__ pc) {
+                                                               PartCounters* __restrict__ pc, uint32_t compress) {
     constexpr int PER = kTilePer1;
     __shared__ TileLds<PER, FAN> L;
     // Persistent workgroups, software-pipelined: the loads of tile t+1 are in flight while tile t is keyed, sorted
@@ -408,6 +414,18 @@ __global__ void __launch_bounds__(kTileThreads) k_part2_level1(const float* __re
 #pragma unroll
         for (int j = 0; j < PER; ++j) { cx[j] = nx[j]; cy[j] = ny[j]; cz[j] = nz[j]; }
         if (tile + gridDim.x < ntiles) load_tile(tile + gridDim.x);
+        // All 512 points this wave holds in the tile bit-identical (a stretch of the converters' zero padding)?  Then they go
+        // out as ONE record of weight 512 instead of eight of weight 64: the bucket that collects the padding gets 8x fewer.
+        bool all8 = compress != 0u && t0 + (uint64_t)kTileThreads * PER <= n;
+        {
+            const uint32_t fx = (uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(cx[0])),
+                           fy = (uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(cy[0])),
+                           fz = (uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(cz[0]));
+            bool mine = true;
+#pragma unroll
+            for (int j = 0; j < PER; ++j) mine = mine && __float_as_uint(cx[j]) == fx && __float_as_uint(cy[j]) == fy && __float_as_uint(cz[j]) == fz;
+            all8 = all8 && __all(mine) != 0;
+        }
         float4 r[PER];
         uint32_t dig[PER];
 #pragma unroll
@@ -420,16 +438,16 @@ __global__ void __launch_bounds__(kTileThreads) k_part2_level1(const float* __re
             column_of_point(px, py, P, sx, sy, kok);
             if (live && !kok) atomicAdd(&cnt->err_key_range, 1u);
             const bool use = live && kok;
-            const bool same = wave_all_identical(px, py, pz, use);               // 64 identical points -> one weighted record
+            const bool same = all8 || (compress && wave_all_identical(px, py, pz, use));   // 64 identical points -> one weighted record
             dig[j] = 0xFFFFFFFFu;
-            if (use && (!same || (threadIdx.x & 63) == 0)) {
+            if (use && (!same || ((threadIdx.x & 63) == 0 && (!all8 || j == 0)))) {
                 const uint32_t b = bucket_of(column_hash(sx, sy), B);
                 dig[j] = (b >> F2_shift) * R + rep;                                  // F2 is a power of two
                 // One record in kSampleEvery votes for its bucket (k_part2_layout sizes the buckets' regions from the
                 // votes).  Chosen by a hash of the point index: a fixed stride would alias with the scan pattern of a
                 // spinning LiDAR (the same azimuths every ring) and with the lane-0 records of compressed waves.
                 if ((((uint32_t)i * 0x9E3779B1u) >> 26) == 0u) atomicAdd(&est2[b], 1u);
-                const uint32_t idx = (first_base + (uint32_t)i) | (same ? kWeight64Flag : 0u);
+                const uint32_t idx = (first_base + (uint32_t)i) | (same ? (all8 ? (kWeight64Flag | kWeight512Flag) : kWeight64Flag) : 0u);
                 r[j] = make_float4(px, py, pz, __uint_as_float(idx));
             }
         }

@@ -328,6 +328,11 @@ class TwoDmap:
         names = self.PHASES[self.last_strategy()]
         return {k: arr[i] for i, k in enumerate(names)}
 
+    def retry_count(self):
+        r = C.c_uint64()
+        self._check(self._L.gndt_debug_retry_count(self._h, C.byref(r)))
+        return int(r.value)
+
     def enable_stamps(self, on=True):
         self._L.gndt_debug_enable_stamps(int(bool(on)))
 

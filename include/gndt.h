@@ -317,6 +317,10 @@ int gndt_last_strategy(const gndt_handle* h);
  * [0] clear [1] accumulate [2] columns [3] labels [4] order [5] emit, then the accumulate phase split into
  * [6] load wait [7] classify [8] scan+scatter [9] reduce (first chunk), and the bucket count. */
 int gndt_debug_bucket_phases(gndt_handle* h, double cycles_out[10], uint32_t* buckets_out);
+/* How many times this handle has re-run a PARTITION build because an LDS table, a partition region or the staging rows were
+ * too small (each is a whole extra build).  A build is launched without waiting and its flags are only looked at by the call
+ * that needs the result: a benchmark that enqueues builds back to back should check that this does not move. */
+int gndt_debug_retry_count(gndt_handle* h, uint64_t* retries);
 /* Switch the stamps on or off for the builds that follow (the environment is only read once per process). */
 int gndt_debug_enable_stamps(int on);
 
