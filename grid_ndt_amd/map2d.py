@@ -6,6 +6,7 @@
 the owner of device memory and streams.
 """
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -293,13 +294,15 @@ class TwoDmap:
     # ---- phase timing ----
     PHASES = {1: ("clear", "accumulate", "columns", "rows", "bitmap_scan", "rank", "column_scan", "dest", "emit"),
               5: ("clear", "accumulate", "columns", "rows", "bitmap_scan", "rank", "column_scan", "dest", "emit"),
-              2: ("clear", "level1", "unused", "level2", "bucket_build", "bitmap_scan", "rank", "column_scan", "dest", "emit"),
+              2: ("clear", "level1", "layout", "level2", "bucket_build", "bitmap_scan", "rank", "column_scan", "dest", "emit"),
               3: ("clear", "hist", "offsets", "scatter", "bucket_build", "bitmap_scan", "rank", "column_scan", "dest", "emit")}
     STRATEGY_NAMES = {1: "atomic", 2: "partition", 3: "partition_exact", 5: "tile"}
     # phase -> the kernel that fills it, and what each phase's kernel moves algorithmically (bench.py's roofline line):
     # kernels that stream the cloud 12 B/point, the bucket kernel 12 B/point + 76 B/node, node kernels 76 B/node
     KERNEL_OF_PHASE = {"accumulate": "k_accumulate", "hist": "k_part_hist", "scatter": "k_part_scatter",
-                       "level1": "k_part2_level1", "level2": "k_part2_level2", "bucket_build": "k_bucket_build",
+                       "level1": "k_part2_level1", "level2": "k_part2_level2",
+                       # GNDT_BUCKET_KERNEL picks the bucket kernel (gndt_api_build.hip); k_bucket_direct unless told otherwise
+                       "bucket_build": {"2": "k_bucket_build2", "4": "k_bucket_owner"}.get(os.environ.get("GNDT_BUCKET_KERNEL", ""), "k_bucket_direct"),
                        "columns": "k_tab_columns", "rows": "k_tab_rows", "emit": "k_emit_rows"}
     POINT_PHASES = ("accumulate", "hist", "scatter", "level1", "level2")
     POINT_AND_NODE_PHASES = ("bucket_build",)
