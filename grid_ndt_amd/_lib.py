@@ -65,6 +65,14 @@ class ExchangeTimes(C.Structure):
                 ("local_nodes", C.c_uint64), ("global_nodes", C.c_uint64), ("bytes_reduced", C.c_uint64)]
 
 
+class OwnedInfo(C.Structure):
+    _fields_ = [("owned_points", C.c_uint64), ("local_nodes", C.c_uint64), ("local_columns", C.c_uint64),
+                ("global_nodes", C.c_uint64), ("global_columns", C.c_uint64), ("global_slopes", C.c_uint64),
+                ("bytes_sent", C.c_uint64), ("bytes_received", C.c_uint64),
+                ("split_ms", C.c_float), ("exchange_ms", C.c_float), ("build_ms", C.c_float), ("order_ms", C.c_float),
+                ("ranks", C.c_uint32)]
+
+
 def _hip_runtime_dir():
     """Directory of the HIP runtime libgndt must share with its host process.  PyTorch wheels bundle
     their own libamdhip64.so / libhsa-runtime64.so; linking libgndt against /opt/rocm's copy would put
@@ -197,7 +205,13 @@ def lib():
     L.gndt_comm_destroy.restype = None
     L.gndt_comm_last_error.restype = C.c_char_p
     L.gndt_build_global_device.argtypes = [H, vp, vp, C.c_size_t, C.c_size_t, u64, u64, C.POINTER(ExchangeTimes), vp]
-    for name in ("gndt_comm_unique_id", "gndt_comm_create", "gndt_build_global_device"):
+    L.gndt_owner_split_device.argtypes = [H, vp, C.c_size_t, C.c_size_t, u64, u64, C.c_uint32, C.POINTER(vp), C.POINTER(u64), vp]
+    L.gndt_build_records_device.argtypes = [H, vp, C.c_size_t, u64, vp]
+    L.gndt_owned_columns_device.argtypes = [H, C.POINTER(vp), C.POINTER(u64), vp]
+    L.gndt_owned_global_rows_device.argtypes = [H, vp, u64, u64, C.POINTER(vp), C.POINTER(u64), C.POINTER(u64), vp]
+    L.gndt_build_owned_device.argtypes = [H, vp, vp, C.c_size_t, C.c_size_t, u64, u64, C.POINTER(vp), C.POINTER(OwnedInfo), vp]
+    for name in ("gndt_comm_unique_id", "gndt_comm_create", "gndt_build_global_device", "gndt_owner_split_device",
+                 "gndt_build_records_device", "gndt_owned_columns_device", "gndt_owned_global_rows_device", "gndt_build_owned_device"):
         getattr(L, name).restype = C.c_int
     L.gndt_locality_sample.argtypes = [H, vp, C.c_size_t, C.c_size_t, C.c_uint32, C.POINTER(C.c_double), vp]
     L.gndt_locality_sample.restype = C.c_int

@@ -67,10 +67,12 @@ int partition_launch(gndt_handle* h, gndt_handle::Pending& P) {
     uint64_t& stage_want = P.stage_want;
     const int env_slots = tuning().bucket_slots, part_wgs = tuning().part_wgs;
     const uint32_t nwg = (uint32_t)std::min<uint64_t>((uint64_t)part_wgs, std::max<uint64_t>(1, n / 8192));
-    const uint64_t words = (n + 31) / 32 + 1;
+    const uint64_t words = ((P.index_range ? (size_t)P.index_range : n) + 31) / 32 + 1;
     int rc;
-    // identical consecutive points travel as weighted records whose index word gives up two bits (gndt_partition.hpp)
-    const uint32_t compress = ((uint64_t)P.first_base + n < (uint64_t)kWeightIndexLimit) ? 1u : 0u;
+    // identical consecutive points travel as weighted records whose index word gives up two bits (gndt_partition.hpp);
+    // records from an owner split were compressed where they came from and keep their index words
+    const uint32_t compress = (!P.records && (uint64_t)P.first_base + n < (uint64_t)kWeightIndexLimit) ? 1u : 0u;
+    const uint32_t part_mode = P.records ? kPartModeRecords : 0u;
     const GridParams gp = P.gp;                        // as they were at launch (a retry must not pick up a new origin)
     const float* p = static_cast<const float*>(P.xyz);
     // table size and bucket count for this attempt: 512-slot tables unless that needs too many buckets
@@ -156,9 +158,14 @@ int partition_launch(gndt_handle* h, gndt_handle::Pending& P) {
 #define GNDT_L1(SF_, FAN_)                                                                                                  \
     hipLaunchKernelGGL((k_part2_level1<SF_, FAN_>), g1, dim3(kTileThreads), 0, s, p, (uint64_t)n, P.first_base, gp, B, F1, F2_shift, \
                        R, cursor1, cap1, est2, q.recs1, h->d_cnt, q.d_pc, compress)
-        if (stride_bytes == 12) { if (wide) GNDT_L1(3, 512); else GNDT_L1(3, 256); }
+#define GNDT_L1R(FAN_)                                                                                                      \
+    hipLaunchKernelGGL((k_part2_level1<4, FAN_, true>), g1, dim3(kTileThreads), 0, s, p, (uint64_t)n, P.first_base, gp, B, F1,   \
+                       F2_shift, R, cursor1, cap1, est2, q.recs1, h->d_cnt, q.d_pc, compress)
+        if (P.records) { if (wide) GNDT_L1R(512); else GNDT_L1R(256); }
+        else if (stride_bytes == 12) { if (wide) GNDT_L1(3, 512); else GNDT_L1(3, 256); }
         else { if (wide) GNDT_L1(4, 512); else GNDT_L1(4, 256); }
 #undef GNDT_L1
+#undef GNDT_L1R
         HIP_TRY(h, hipGetLastError());
         mark(h, 2, s);
         hipLaunchKernelGGL(k_part2_layout, dim3(1), dim3(1024), 0, s, est2, B, q.range_lo, q.range_cap, (uint64_t)q.rec_cap, q.d_pc);
@@ -202,9 +209,9 @@ int partition_launch(gndt_handle* h, gndt_handle::Pending& P) {
         HIP_TRY(h, hipFuncSetAttribute((const void*)k_part_scatter<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
     if (stride_bytes == 12)
-        hipLaunchKernelGGL(k_part_hist<3>, dim3(nwg), dim3(kPartThreads), lds, s, p, (uint64_t)n, gp, B, q.hist, h->d_cnt, compress);
+        hipLaunchKernelGGL(k_part_hist<3>, dim3(nwg), dim3(kPartThreads), lds, s, p, (uint64_t)n, gp, B, q.hist, h->d_cnt, compress, part_mode);
     else
-        hipLaunchKernelGGL(k_part_hist<4>, dim3(nwg), dim3(kPartThreads), lds, s, p, (uint64_t)n, gp, B, q.hist, h->d_cnt, compress);
+        hipLaunchKernelGGL(k_part_hist<4>, dim3(nwg), dim3(kPartThreads), lds, s, p, (uint64_t)n, gp, B, q.hist, h->d_cnt, compress, part_mode);
     HIP_TRY(h, hipGetLastError());
     mark(h, 2, s);
     hipLaunchKernelGGL(k_part_offsets, dim3((B + 31) / 32), dim3(256), 0, s, q.hist, q.totals, B, nwg);
@@ -212,10 +219,10 @@ int partition_launch(gndt_handle* h, gndt_handle::Pending& P) {
     mark(h, 3, s);
     if (stride_bytes == 12)
         hipLaunchKernelGGL(k_part_scatter<3>, dim3(nwg), dim3(kPartThreads), lds, s, p, (uint64_t)n, P.first_base, gp, B, q.hist,
-                           q.totals, q.bucket_base, q.recs, compress);
+                           q.totals, q.bucket_base, q.recs, compress, part_mode);
     else
         hipLaunchKernelGGL(k_part_scatter<4>, dim3(nwg), dim3(kPartThreads), lds, s, p, (uint64_t)n, P.first_base, gp, B, q.hist,
-                           q.totals, q.bucket_base, q.recs, compress);
+                           q.totals, q.bucket_base, q.recs, compress, part_mode);
     HIP_TRY(h, hipGetLastError());
     mark(h, 4, s);
     range_lo = q.bucket_base; range_hi = q.bucket_base + 1;
@@ -273,18 +280,20 @@ int partition_launch(gndt_handle* h, gndt_handle::Pending& P) {
     return GNDT_OK;
 }
 
-namespace {
-// Start a PARTITION build (attempt 0) and leave it pending.
-int partition_begin(gndt_handle* h, const void* xyz_dev, size_t n, size_t stride_bytes, hipStream_t s) {
+// Start a PARTITION build (attempt 0) and leave it pending.  `records`: the input is 16-B records {x, y, z, index word} whose
+// index words (point indices below `index_range`, weight flags included) are taken as they are (gndt_build_records_device).
+int partition_begin(gndt_handle* h, const void* xyz_dev, size_t n, size_t stride_bytes, hipStream_t s, bool records, uint64_t index_range) {
     auto& q = h->part;
     if (stride_bytes != 12 && stride_bytes != 16) { h->err = "stride_bytes must be 12 or 16"; return GNDT_ERR_INVALID; }
-    if (n >= 0x7FFFFFFFull) return -1;   // bit 31 of the record index word carries the weight flag: atomic path beyond 2^31 points
+    if (records && stride_bytes != 16) { h->err = "records are 16 bytes"; return GNDT_ERR_INVALID; }
+    if (n >= 0x7FFFFFFFull || index_range >= 0x7FFFFFFFull) return -1;   // bit 31 of the record index word carries the weight flag: atomic path beyond 2^31 points
     int rc;
-    if ((rc = ensure_words(h, (n + 31) / 32 + 1))) return rc;
+    if ((rc = ensure_words(h, ((index_range ? (size_t)index_range : n) + 31) / 32 + 1))) return rc;
     if ((rc = ensure_part_counters(h))) return rc;
     auto& P = h->pending;
     P = gndt_handle::Pending{};
     P.xyz = xyz_dev; P.n = n; P.stride = stride_bytes; P.s = s; P.attempt = 0;
+    P.records = records; P.index_range = index_range;
     P.gp = grid_params(h);
     // What the last build of a cloud of this size needed (larger tables, a doubled estimate) is where this one starts: without
     // it every build of such a cloud would first fail with the small tables and be run twice.
@@ -304,12 +313,10 @@ int partition_begin(gndt_handle* h, const void* xyz_dev, size_t n, size_t stride
     P.active = true;
     h->results_valid = false;
     h->map_in_table = false;
-    h->stream_pos = n;
+    h->stream_pos = index_range ? index_range : n;
     h->last_stream = s;
     return GNDT_OK;
 }
-
-}  // namespace
 
 // Wait for the pending build and look at its flags; re-run it with more room while they ask for it (the input
 // must still be valid: it is the caller's until gndt_sync / gndt_export returns).
@@ -366,6 +373,7 @@ int partition_resolve(gndt_handle* h) {
         if (rc == GNDT_OK) continue;
         P.active = false;
         if (rc != -1 || P.stats_only) return rc;   // (a statistics-only run reports -1: its caller falls back)
+        if (P.records) { h->err = "the records do not fit the partition pipeline (too many nodes per bucket)"; return GNDT_ERR_CAPACITY; }
         // does not fit the LDS-resident pipeline (too many nodes per bucket): same result via the atomic path
         return build_atomic(h, P.xyz, P.n, P.stride, P.s);
     }

@@ -5,6 +5,8 @@
 
 #include <rocprim/rocprim.hpp>
 
+#include <vector>
+
 using namespace gndt;
 using namespace gndt_host;
 
@@ -240,6 +242,284 @@ int gndt_build_global_device(gndt_handle* h, gndt_comm* c, const void* shard_xyz
         times->shard_ms = a; times->exchange_ms = b; times->finalize_ms = d;
         times->local_nodes = m; times->global_nodes = C; times->ranks = (uint32_t)W;
         times->bytes_reduced = (uint64_t)C * (kExWidth * 8 + 4);
+        for (auto& e : ev) (void)hipEventDestroy(e);
+    }
+    return GNDT_OK;
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// owner-partitioned build (gndt_exchange.hpp, second half): the points travel
+// ---------------------------------------------------------------------------------------------
+}  // extern "C"
+
+namespace {
+
+constexpr uint32_t kMaxRanks = 1024;
+
+// shard -> records grouped by owner (X.send_recs, X.send_off[0..W]); waits for the stream
+int owner_split(gndt_handle* h, const void* xyz, size_t n, size_t stride_bytes, uint64_t first_base, uint64_t total_points, uint32_t W,
+                hipStream_t s) {
+    auto& q = h->part;
+    auto& X = h->exch;
+    if (stride_bytes != 12 && stride_bytes != 16) { h->err = "stride_bytes must be 12 or 16"; return GNDT_ERR_INVALID; }
+    if (W < 1 || W > kMaxRanks) { h->err = "world must be 1..1024"; return GNDT_ERR_INVALID; }
+    if (first_base + n > total_points || total_points >= 0x7FFFFFFFull) { h->err = "shard outside the cloud, or more than 2^31 points"; return GNDT_ERR_INVALID; }
+    int rc;
+    if ((rc = ensure_part_counters(h))) return rc;
+    if (!X.d_split_cnt) HIP_TRY(h, hipMalloc(&X.d_split_cnt, sizeof(Counters)));
+    if (!X.h_split_cnt) HIP_TRY(h, hipHostMalloc(&X.h_split_cnt, sizeof(Counters)));
+    if (!X.h_matrix) HIP_TRY(h, hipHostMalloc(&X.h_matrix, ((size_t)kMaxRanks * kMaxRanks + kMaxRanks + 1) * sizeof(uint32_t)));
+    HIP_TRY(h, hipMemsetAsync(X.d_split_cnt, 0, sizeof(Counters), s));
+    const uint32_t nwg = (uint32_t)std::min<uint64_t>((uint64_t)tuning().part_wgs, std::max<uint64_t>(1, n / 8192));
+    if ((rc = grow_buf(h, q.hist, q.hist_cap, (uint64_t)nwg * W))) return rc;
+    if (W > q.bucket_cap) {
+        if (q.totals) (void)hipFree(q.totals);
+        if (q.bucket_base) (void)hipFree(q.bucket_base);
+        q.totals = q.bucket_base = nullptr; q.bucket_cap = 0;
+        HIP_TRY(h, hipMalloc(&q.totals, (size_t)W * 4));
+        HIP_TRY(h, hipMalloc(&q.bucket_base, ((size_t)W + 1) * 4));
+        q.bucket_cap = W;
+    }
+    if ((rc = grow_buf(h, X.send_recs, X.send_cap, std::max<uint64_t>(n, 1)))) return rc;
+    const GridParams gp = grid_params(h);
+    const uint32_t compress = total_points < (uint64_t)kWeightIndexLimit ? 1u : 0u;
+    const float* p = static_cast<const float*>(xyz);
+    const size_t lds = (size_t)W * 4;
+    if (stride_bytes == 12)
+        hipLaunchKernelGGL(k_part_hist<3>, dim3(nwg), dim3(kPartThreads), lds, s, p, (uint64_t)n, gp, W, q.hist, X.d_split_cnt, compress, kPartModeOwner);
+    else
+        hipLaunchKernelGGL(k_part_hist<4>, dim3(nwg), dim3(kPartThreads), lds, s, p, (uint64_t)n, gp, W, q.hist, X.d_split_cnt, compress, kPartModeOwner);
+    hipLaunchKernelGGL(k_part_offsets, dim3((W + 31) / 32), dim3(256), 0, s, q.hist, q.totals, W, nwg);
+    if (stride_bytes == 12)
+        hipLaunchKernelGGL(k_part_scatter<3>, dim3(nwg), dim3(kPartThreads), lds, s, p, (uint64_t)n, (uint32_t)first_base, gp, W, q.hist, q.totals,
+                           q.bucket_base, X.send_recs, compress, kPartModeOwner);
+    else
+        hipLaunchKernelGGL(k_part_scatter<4>, dim3(nwg), dim3(kPartThreads), lds, s, p, (uint64_t)n, (uint32_t)first_base, gp, W, q.hist, q.totals,
+                           q.bucket_base, X.send_recs, compress, kPartModeOwner);
+    HIP_TRY(h, hipGetLastError());
+    uint32_t* h_base = X.h_matrix + (size_t)kMaxRanks * kMaxRanks;
+    HIP_TRY(h, hipMemcpyAsync(h_base, q.bucket_base, ((size_t)W + 1) * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(h, hipMemcpyAsync(X.h_split_cnt, X.d_split_cnt, sizeof(Counters), hipMemcpyDeviceToHost, s));
+    HIP_TRY(h, hipStreamSynchronize(s));
+    for (uint32_t r = 0; r <= W; ++r) X.send_off[r] = h_base[r];
+    if (X.h_split_cnt->err_key_range) {
+        h->err = std::to_string(X.h_split_cnt->err_key_range) + " point(s) outside the key range";
+        return GNDT_ERR_KEY_RANGE;
+    }
+    return GNDT_OK;
+}
+
+// the records this rank owns -> its map (launched, not awaited)
+int build_records(gndt_handle* h, const void* recs, size_t n, uint64_t total_points, hipStream_t s) {
+    h->pending.active = false;
+    { const int urc = use_stream(h, s); if (urc) return urc; }
+    next_event_set(h);
+    const int rc = partition_begin(h, recs, n, 16, s, true, std::max<uint64_t>(total_points, 1));
+    if (rc == -1) { h->err = "the records do not fit the partition pipeline"; return GNDT_ERR_CAPACITY; }
+    return rc;
+}
+
+// columns of the finished local map as (first-seen index << 32 | node count) pairs in X.pairs; count in X.d_npairs[0]
+int owned_columns_launch(gndt_handle* h, hipStream_t s, uint32_t& ncols_host) {
+    auto& q = h->part;
+    auto& X = h->exch;
+    int rc = partition_resolve(h);
+    if (rc) return rc;
+    if (!h->results_valid || h->map_in_table) { h->err = "no finished PARTITION build on this handle"; return GNDT_ERR_INVALID; }
+    if (h->h_cnt->err_key_range) { h->err = std::to_string(h->h_cnt->err_key_range) + " point(s) outside the key range"; return GNDT_ERR_KEY_RANGE; }
+    ncols_host = h->h_cnt->num_columns;
+    if ((rc = grow_buf(h, X.pairs, X.pairs_cap, std::max<uint64_t>(ncols_host, 1)))) return rc;
+    if (!X.d_npairs) HIP_TRY(h, hipMalloc(&X.d_npairs, 2 * sizeof(uint32_t)));
+    HIP_TRY(h, hipMemsetAsync(X.d_npairs, 0, 2 * sizeof(uint32_t), s));
+    hipLaunchKernelGGL(k_owned_columns, dim3(grid_for(std::max<uint64_t>(h->h_cnt->num_nodes, 1))), dim3(256), 0, s, h->out.first_idx, q.row_ncol,
+                       h->d_cnt, X.pairs, (uint32_t)X.pairs_cap, X.d_npairs);
+    HIP_TRY(h, hipGetLastError());
+    return GNDT_OK;
+}
+
+// everybody's column pairs -> global row of every local row (X.global_row), totals of the whole map in X.d_totals[0..1]
+int global_rows_launch(gndt_handle* h, const unsigned long long* all_pairs, uint64_t n_all, uint64_t total_points, hipStream_t s) {
+    auto& q = h->part;
+    auto& X = h->exch;
+    int rc;
+    const uint64_t words = (std::max<uint64_t>(total_points, 1) + 31) / 32 + 1;
+    if (words > q.word_cap) { h->err = "total_points differs from the build's"; return GNDT_ERR_INVALID; }
+    if (!X.d_totals) HIP_TRY(h, hipMalloc(&X.d_totals, 4 * sizeof(unsigned long long)));
+    if (!X.h_totals) HIP_TRY(h, hipHostMalloc(&X.h_totals, 4 * sizeof(unsigned long long)));
+    if (!X.d_npairs) HIP_TRY(h, hipMalloc(&X.d_npairs, 2 * sizeof(uint32_t)));
+    if ((rc = grow_buf(h, X.global_row, X.global_row_cap, std::max<uint64_t>(h->h_cnt->num_nodes, 1)))) return rc;
+    // the local order is finished (rows emitted): its arrays now take the column order of the WHOLE map
+    HIP_TRY(h, hipMemsetAsync(q.bitmap, 0, words * 4, s));
+    HIP_TRY(h, hipMemsetAsync(q.word_weight, 0, words * 4, s));
+    HIP_TRY(h, hipMemsetAsync(X.d_totals, 0, 2 * sizeof(unsigned long long), s));
+    HIP_TRY(h, hipMemsetAsync(X.d_npairs + 1, 0, sizeof(uint32_t), s));
+    if (n_all)
+        hipLaunchKernelGGL(k_pairs_note, dim3(grid_for(n_all)), dim3(256), 0, s, all_pairs, n_all, ColumnOrder{q.bitmap, q.word_weight, q.ncol_at},
+                           words, X.d_totals, X.d_npairs + 1);
+    const uint32_t nbw = (uint32_t)((words + kScanChunk - 1) / kScanChunk);
+    hipLaunchKernelGGL(k_scan_reduce<false>, dim3(nbw), dim3(kScanThreads), 0, s, q.word_weight, (const uint32_t*)nullptr, (uint32_t)words, q.bsum_words);
+    hipLaunchKernelGGL(k_scan_apply<false>, dim3(nbw), dim3(kScanThreads), 0, s, q.word_weight, (const uint32_t*)nullptr, (uint32_t)words, q.bsum_words,
+                       q.word_base);
+    hipLaunchKernelGGL(k_global_rows, dim3(grid_for(std::max<uint64_t>(h->h_cnt->num_nodes, 1))), dim3(256), 0, s, h->out.first_idx, q.row_ncol, h->d_cnt,
+                       q.bitmap, q.word_base, q.ncol_at, X.global_row);
+    HIP_TRY(h, hipGetLastError());
+    return GNDT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int gndt_owner_split_device(gndt_handle* h, const void* shard_xyz_dev, size_t n, size_t stride_bytes, uint64_t first_idx_base,
+                            uint64_t total_points, uint32_t world, const void** records_dev, uint64_t* counts_host, void* hip_stream) {
+    int rc = check_ready(h);
+    if (rc) return rc;
+    if (!records_dev || !counts_host || (!shard_xyz_dev && n)) { h->err = "null argument"; return GNDT_ERR_INVALID; }
+    hipStream_t s = stream_of(h, hip_stream);
+    h->pending.active = false;
+    { const int urc = use_stream(h, s); if (urc) return urc; }
+    if ((rc = owner_split(h, shard_xyz_dev, n, stride_bytes, first_idx_base, total_points, world, s))) return rc;
+    for (uint32_t r = 0; r < world; ++r) counts_host[r] = h->exch.send_off[r + 1] - h->exch.send_off[r];
+    *records_dev = h->exch.send_recs;
+    return GNDT_OK;
+}
+
+int gndt_build_records_device(gndt_handle* h, const void* records_dev, size_t n_records, uint64_t total_points, void* hip_stream) {
+    int rc = check_ready(h);
+    if (rc) return rc;
+    if (!records_dev && n_records) { h->err = "null input"; return GNDT_ERR_INVALID; }
+    return build_records(h, records_dev, n_records, total_points, stream_of(h, hip_stream));
+}
+
+int gndt_owned_columns_device(gndt_handle* h, const uint64_t** pairs_dev, uint64_t* n_pairs, void* hip_stream) {
+    int rc = check_ready(h);
+    if (rc) return rc;
+    if (!pairs_dev || !n_pairs) { h->err = "null argument"; return GNDT_ERR_INVALID; }
+    hipStream_t s = stream_of(h, hip_stream);
+    { const int urc = use_stream(h, s); if (urc) return urc; }
+    uint32_t nc = 0;
+    if ((rc = owned_columns_launch(h, s, nc))) return rc;
+    HIP_TRY(h, hipStreamSynchronize(s));
+    *pairs_dev = reinterpret_cast<const uint64_t*>(h->exch.pairs);
+    *n_pairs = nc;
+    return GNDT_OK;
+}
+
+int gndt_owned_global_rows_device(gndt_handle* h, const uint64_t* all_pairs_dev, uint64_t n_all, uint64_t total_points,
+                                  const uint32_t** global_row_dev, uint64_t* global_nodes, uint64_t* global_columns, void* hip_stream) {
+    int rc = check_ready(h);
+    if (rc) return rc;
+    if (!global_row_dev || (!all_pairs_dev && n_all)) { h->err = "null argument"; return GNDT_ERR_INVALID; }
+    hipStream_t s = stream_of(h, hip_stream);
+    { const int urc = use_stream(h, s); if (urc) return urc; }
+    if ((rc = partition_resolve(h))) return rc;
+    if (!h->results_valid || h->map_in_table) { h->err = "no finished PARTITION build on this handle"; return GNDT_ERR_INVALID; }
+    auto& X = h->exch;
+    if ((rc = global_rows_launch(h, reinterpret_cast<const unsigned long long*>(all_pairs_dev), n_all, total_points, s))) return rc;
+    uint32_t bad = 0;
+    HIP_TRY(h, hipMemcpyAsync(X.h_totals, X.d_totals, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+    HIP_TRY(h, hipMemcpyAsync(&bad, X.d_npairs + 1, sizeof bad, hipMemcpyDeviceToHost, s));
+    HIP_TRY(h, hipStreamSynchronize(s));
+    if (bad) { h->err = std::to_string(bad) + " column pair(s) with an index beyond total_points"; return GNDT_ERR_INVALID; }
+    *global_row_dev = X.global_row;
+    if (global_nodes) *global_nodes = X.h_totals[0];
+    if (global_columns) *global_columns = X.h_totals[1];
+    return GNDT_OK;
+}
+
+int gndt_build_owned_device(gndt_handle* h, gndt_comm* c, const void* shard_xyz_dev, size_t n, size_t stride_bytes,
+                            uint64_t first_idx_base, uint64_t total_points, const uint32_t** global_row_dev,
+                            gndt_owned_info* info, void* hip_stream) {
+    int rc = check_ready(h);
+    if (rc) return rc;
+    if (!c || !c->nccl) { h->err = "no communicator"; return GNDT_ERR_INVALID; }
+    if (!shard_xyz_dev && n) { h->err = "null input"; return GNDT_ERR_INVALID; }
+    const int W = c->world, me = c->rank;
+    if (W > 1 && !rccl().p2p()) { h->err = "this RCCL has no ncclSend / ncclRecv"; return GNDT_ERR_NO_DEVICE; }
+    hipStream_t s = stream_of(h, hip_stream);
+    h->pending.active = false;
+    { const int urc = use_stream(h, s); if (urc) return urc; }
+    auto& q = h->part;
+    auto& X = h->exch;
+    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    if (info) for (auto& e : ev) HIP_TRY(h, hipEventCreate(&e));
+    auto stamp = [&](int i) { if (info) (void)hipEventRecord(ev[i], s); };
+    stamp(0);
+    // 1. split by owner
+    if ((rc = owner_split(h, shard_xyz_dev, n, stride_bytes, first_idx_base, total_points, (uint32_t)W, s))) return rc;
+    stamp(1);
+    // 2. who sends how much to whom (W x W counts), then the runs themselves
+    if ((rc = grow_buf(h, X.d_matrix, X.matrix_cap, (uint64_t)W * W))) return rc;
+    RCCL_TRY(h, rccl().AllGather(q.totals, X.d_matrix, (size_t)W, ncclUint32, c->nccl, s));
+    HIP_TRY(h, hipMemcpyAsync(X.h_matrix, X.d_matrix, (size_t)W * W * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(h, hipStreamSynchronize(s));
+    std::vector<uint64_t> recv_off((size_t)W + 1, 0);
+    for (int r = 0; r < W; ++r) recv_off[r + 1] = recv_off[r] + X.h_matrix[(size_t)r * W + me];      // what rank r holds for me
+    const uint64_t n_own = recv_off[W];
+    if ((rc = grow_buf(h, X.own_recs, X.own_cap, std::max<uint64_t>(n_own, 1)))) return rc;
+    uint64_t sent = 0, received = 0;
+    {
+        const uint64_t mine = X.send_off[me + 1] - X.send_off[me];
+        if (mine) HIP_TRY(h, hipMemcpyAsync(X.own_recs + recv_off[me], X.send_recs + X.send_off[me], mine * sizeof(float4), hipMemcpyDeviceToDevice, s));
+    }
+    if (W > 1) {
+        RCCL_TRY(h, rccl().GroupStart());
+        for (int r = 0; r < W; ++r) {
+            if (r == me) continue;
+            const uint64_t out = X.send_off[r + 1] - X.send_off[r], in = recv_off[r + 1] - recv_off[r];
+            if (out) RCCL_TRY(h, rccl().Send(X.send_recs + X.send_off[r], (size_t)out * 4, ncclFloat, r, c->nccl, s));
+            if (in) RCCL_TRY(h, rccl().Recv(X.own_recs + recv_off[r], (size_t)in * 4, ncclFloat, r, c->nccl, s));
+            sent += out * sizeof(float4); received += in * sizeof(float4);
+        }
+        RCCL_TRY(h, rccl().GroupEnd());
+    }
+    stamp(2);
+    // 3. the columns this rank owns, finished: the ordinary pipeline on the records
+    if ((rc = build_records(h, X.own_recs, (size_t)n_own, total_points, s))) return rc;
+    uint32_t ncols = 0;
+    if ((rc = owned_columns_launch(h, s, ncols))) return rc;            // (waits for the build: overflow re-runs happen here)
+    stamp(3);
+    // 4. everybody's columns -> the global row of every local row
+    if (!X.d_counts) { if ((rc = grow_buf(h, X.d_counts, X.counts_cap, (uint64_t)kMaxRanks))) return rc; }
+    if (!X.h_counts) HIP_TRY(h, hipHostMalloc(&X.h_counts, 1024 * sizeof(unsigned long long)));
+    X.h_counts[me] = ncols;
+    HIP_TRY(h, hipMemcpyAsync(X.d_counts + me, X.h_counts + me, sizeof(unsigned long long), hipMemcpyHostToDevice, s));
+    RCCL_TRY(h, rccl().AllGather(X.d_counts + me, X.d_counts, 1, ncclUint64, c->nccl, s));
+    HIP_TRY(h, hipMemcpyAsync(X.h_counts, X.d_counts, (size_t)W * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+    HIP_TRY(h, hipStreamSynchronize(s));
+    uint64_t m_max = 1;
+    for (int r = 0; r < W; ++r) m_max = std::max<uint64_t>(m_max, X.h_counts[r]);
+    if (m_max > X.pairs_cap) {                          // (another rank owns more columns: a longer send buffer, contents kept)
+        unsigned long long* bigger = nullptr;
+        HIP_TRY(h, hipMalloc(&bigger, m_max * sizeof(unsigned long long)));
+        if (ncols) HIP_TRY(h, hipMemcpyAsync(bigger, X.pairs, (size_t)ncols * sizeof(unsigned long long), hipMemcpyDeviceToDevice, s));
+        HIP_TRY(h, hipStreamSynchronize(s));
+        (void)hipFree(X.pairs);
+        X.pairs = bigger; X.pairs_cap = m_max;
+    }
+    hipLaunchKernelGGL(k_pairs_pad, dim3(grid_for(m_max)), dim3(256), 0, s, X.pairs, ncols, (uint32_t)m_max);
+    if ((rc = grow_buf(h, X.pairs_all, X.pairs_all_cap, m_max * (uint64_t)W))) return rc;
+    RCCL_TRY(h, rccl().AllGather(X.pairs, X.pairs_all, (size_t)m_max, ncclUint64, c->nccl, s));
+    if ((rc = global_rows_launch(h, X.pairs_all, m_max * (uint64_t)W, total_points, s))) return rc;
+    // slopes and owned points of the whole map
+    X.h_totals[2] = h->h_cnt->num_slopes; X.h_totals[3] = n_own;
+    HIP_TRY(h, hipMemcpyAsync(X.d_totals + 2, X.h_totals + 2, 2 * sizeof(unsigned long long), hipMemcpyHostToDevice, s));
+    RCCL_TRY(h, rccl().AllReduce(X.d_totals + 2, X.d_totals + 2, 2, ncclUint64, ncclSum, c->nccl, s));
+    uint32_t bad = 0;
+    HIP_TRY(h, hipMemcpyAsync(X.h_totals, X.d_totals, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+    HIP_TRY(h, hipMemcpyAsync(&bad, X.d_npairs + 1, sizeof bad, hipMemcpyDeviceToHost, s));
+    stamp(4);
+    HIP_TRY(h, hipStreamSynchronize(s));
+    if (bad) { h->err = std::to_string(bad) + " column pair(s) with an index beyond total_points"; return GNDT_ERR_INVALID; }
+    if (global_row_dev) *global_row_dev = X.global_row;
+    if (info) {
+        float t[4] = {0, 0, 0, 0};
+        for (int i = 0; i < 4; ++i) (void)hipEventElapsedTime(&t[i], ev[i], ev[i + 1]);
+        info->split_ms = t[0]; info->exchange_ms = t[1]; info->build_ms = t[2]; info->order_ms = t[3];
+        info->owned_points = n_own; info->local_nodes = h->h_cnt->num_nodes; info->local_columns = ncols;
+        info->global_nodes = X.h_totals[0]; info->global_columns = X.h_totals[1]; info->global_slopes = X.h_totals[2];
+        info->bytes_sent = sent; info->bytes_received = received; info->ranks = (uint32_t)W;
         for (auto& e : ev) (void)hipEventDestroy(e);
     }
     return GNDT_OK;

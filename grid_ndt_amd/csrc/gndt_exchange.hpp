@@ -18,7 +18,7 @@
 
 #include <rccl/rccl.h>          // types and prototypes only: the functions come from dlopen
 
-#include "gndt_math.hpp"
+#include "gndt_partition.hpp"
 
 namespace gndt {
 
@@ -29,8 +29,13 @@ struct RcclApi {
     decltype(&ncclCommDestroy) CommDestroy = nullptr;
     decltype(&ncclAllGather) AllGather = nullptr;
     decltype(&ncclAllReduce) AllReduce = nullptr;
+    decltype(&ncclSend) Send = nullptr;
+    decltype(&ncclRecv) Recv = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
     bool ok() const { return lib && GetUniqueId && CommInitRank && CommDestroy && AllGather && AllReduce && GetErrorString; }
+    bool p2p() const { return Send && Recv && GroupStart && GroupEnd; }
 };
 
 // the RCCL the process already has (PyTorch bundles its own librccl.so) or the system one
@@ -54,6 +59,10 @@ inline const RcclApi& rccl() {
             a.AllGather = (decltype(a.AllGather))dlsym(a.lib, "ncclAllGather");
             a.AllReduce = (decltype(a.AllReduce))dlsym(a.lib, "ncclAllReduce");
             a.GetErrorString = (decltype(a.GetErrorString))dlsym(a.lib, "ncclGetErrorString");
+            a.Send = (decltype(a.Send))dlsym(a.lib, "ncclSend");
+            a.Recv = (decltype(a.Recv))dlsym(a.lib, "ncclRecv");
+            a.GroupStart = (decltype(a.GroupStart))dlsym(a.lib, "ncclGroupStart");
+            a.GroupEnd = (decltype(a.GroupEnd))dlsym(a.lib, "ncclGroupEnd");
         }
         return a;
     }();
@@ -100,6 +109,83 @@ static __global__ void __launch_bounds__(256) k_exchange_unpack(const double* __
 // keys padded to a common length with kEmptyKey (sorts last); after sort + unique the pad is the last entry, if present
 static __global__ void k_exchange_pad(uint64_t* __restrict__ buf, uint32_t have, uint32_t padded) {
     for (uint32_t i = have + blockIdx.x * blockDim.x + threadIdx.x; i < padded; i += gridDim.x * blockDim.x) buf[i] = kEmptyKey;
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Owner-partitioned build (gndt_build_owned_device): points travel, statistics do not.
+//
+//   every rank   splits its shard by owner_of(column) into W runs of 16-B records {x, y, z, global index | weight flags}
+//                (k_part_hist / k_part_scatter in owner mode; identical consecutive points already folded into weighted records)
+//   all-to-all   the runs (ncclSend / ncclRecv in one group): a rank receives every point of the columns it owns
+//   every rank   builds ITS columns with the ordinary PARTITION pipeline from the records (index words taken as they are):
+//                statistics, labels and rows are final, nothing is merged afterwards
+//   all-gather   every rank's columns as (first-seen index, node count) pairs, 8 B per column: with everybody's pairs in the
+//                column-order arrays (bitmap, word weights, ncol_at) the usual prefix gives the row every local row has in the
+//                map of the WHOLE cloud (k_global_rows)
+// Per rank and build: (W-1)/W of its points leave (16 B each) and as many arrive, plus 8 B per column of the global map —
+// against 84 B per node of the global map through a ring all-reduce for the statistics exchange above.
+// ---------------------------------------------------------------------------------------------
+constexpr unsigned long long kNoPair = 0xFFFFFFFFFFFFFFFFull;
+
+// the columns of the local map: (first-seen index of the column, its node count), in any order
+static __global__ void __launch_bounds__(256) k_owned_columns(const uint32_t* __restrict__ first_idx, const uint32_t* __restrict__ row_ncol,
+                                                              const Counters* __restrict__ cnt, unsigned long long* __restrict__ pairs,
+                                                              uint32_t pairs_cap, uint32_t* __restrict__ n_pairs) {
+    const uint32_t n = cnt->num_nodes;
+    const uint32_t n_round = (n + 63u) & ~63u;
+    for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < n_round; r += gridDim.x * blockDim.x) {
+        const uint32_t nc = r < n ? row_ncol[r] : 0u;
+        const unsigned long long m = __ballot(nc != 0u);
+        if (!m) continue;
+        const int lane = threadIdx.x & 63, leader = (int)__builtin_ctzll(m);
+        uint32_t base = 0;
+        if (lane == leader) base = atomicAdd(n_pairs, (uint32_t)__popcll(m));
+        base = (uint32_t)__shfl((int)base, leader, 64);
+        if (nc) {
+            const uint32_t pos = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+            if (pos < pairs_cap) pairs[pos] = ((unsigned long long)first_idx[r] << 32) | nc;
+        }
+    }
+}
+
+static __global__ void __launch_bounds__(256) k_pairs_pad(unsigned long long* __restrict__ pairs, uint32_t have, uint32_t padded) {
+    for (uint32_t i = have + blockIdx.x * blockDim.x + threadIdx.x; i < padded; i += gridDim.x * blockDim.x) pairs[i] = kNoPair;
+}
+
+// everybody's columns into the column-order arrays (cleared before)
+static __global__ void __launch_bounds__(256) k_pairs_note(const unsigned long long* __restrict__ pairs, uint64_t n, ColumnOrder O,
+                                                           uint64_t words, unsigned long long* __restrict__ totals, uint32_t* __restrict__ bad) {
+    unsigned long long nodes = 0, cols = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const unsigned long long pr = pairs[i];
+        if (pr == kNoPair) continue;
+        const uint32_t cf = (uint32_t)(pr >> 32), nc = (uint32_t)pr;
+        if ((uint64_t)(cf >> 5) >= words) { atomicAdd(bad, 1u); continue; }
+        note_column(O, cf, nc);
+        nodes += nc; ++cols;
+    }
+    nodes = (unsigned long long)wave_sum((double)nodes);      // (exact: far below 2^53)
+    cols = (unsigned long long)wave_sum((double)cols);
+    if ((threadIdx.x & 63) == 0 && cols) { atomicAdd(&totals[0], nodes); atomicAdd(&totals[1], cols); }
+}
+
+// row of every local row in the map of the whole cloud: the column's position from the global column order, then the nodes
+// of the column in their local (= global) order.  One lane per column head; columns are short.
+static __global__ void __launch_bounds__(256) k_global_rows(const uint32_t* __restrict__ first_idx, const uint32_t* __restrict__ row_ncol,
+                                                            const Counters* __restrict__ cnt, const uint32_t* __restrict__ bitmap,
+                                                            const uint32_t* __restrict__ word_base, const uint32_t* __restrict__ ncol_at,
+                                                            uint32_t* __restrict__ global_row) {
+    const uint32_t n = cnt->num_nodes;
+    for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x) {
+        const uint32_t nc = row_ncol[r];
+        if (!nc) continue;
+        const uint32_t cf = first_idx[r], w = cf >> 5;
+        uint32_t m = bitmap[w] & ((1u << (cf & 31u)) - 1u);
+        uint32_t row = word_base[w];
+        while (m) { row += ncol_at[(w << 5) + (uint32_t)__builtin_ctz(m)]; m &= m - 1u; }
+        for (uint32_t i = 0; i < nc; ++i) global_row[r + i] = row + i;
+    }
 }
 
 }  // namespace gndt

@@ -127,6 +127,15 @@ struct gndt_handle {
         char* scratch = nullptr; uint64_t scratch_cap = 0;
         double* packed = nullptr; uint64_t packed_cap = 0;  uint32_t* pfirst = nullptr; uint64_t pfirst_cap = 0;
         double* r_sums = nullptr; uint64_t r_sums_cap = 0;  uint32_t* r_count = nullptr; uint64_t r_count_cap = 0;
+        // owner-partitioned build (gndt_build_owned_device): records grouped by owner, the records this rank owns, its
+        // columns as (first-seen index, node count) pairs, everybody's pairs, the global row of every local row
+        float4* send_recs = nullptr; uint64_t send_cap = 0;  float4* own_recs = nullptr; uint64_t own_cap = 0;
+        uint32_t* d_matrix = nullptr; uint64_t matrix_cap = 0;  uint32_t* h_matrix = nullptr;     // [W x W] send counts
+        gndt::Counters* d_split_cnt = nullptr;  gndt::Counters* h_split_cnt = nullptr;
+        unsigned long long* pairs = nullptr; uint64_t pairs_cap = 0;  unsigned long long* pairs_all = nullptr; uint64_t pairs_all_cap = 0;
+        uint32_t* d_npairs = nullptr;  uint32_t* global_row = nullptr; uint64_t global_row_cap = 0;
+        unsigned long long* d_totals = nullptr;  unsigned long long* h_totals = nullptr;          // [4] nodes, columns, slopes, points
+        uint64_t send_off[1025] = {};   // host: start of every owner's records in send_recs (after gndt_owner_split_device)
     } exch;
     uint64_t result_serial = 0;         // bumped whenever a build / finalize produces new result rows
     int last_strategy = GNDT_STRATEGY_ATOMIC;
@@ -158,6 +167,8 @@ struct gndt_handle {
         gndt::GridParams gp{};          // origin and grid parameters AS THEY WERE when the build was launched: a retry
                                         // re-runs the same build even if the handle's origin has moved on since
         uint32_t first_base = 0;        // global index of xyz[0] (shards of a global cloud)
+        bool records = false;           // the input is 16-B records {x, y, z, index word} (owner-partitioned build): the index
+        uint64_t index_range = 0;       //   word is taken as it is; point indices then run over [0, index_range) (0: n)
     } pending;
 
     std::string err;
@@ -274,6 +285,7 @@ int locality_sample(gndt_handle* h, const void* xyz_dev, size_t n, size_t stride
 // ---- gndt_api_build.hip ----
 int launch_order_and_emit(gndt_handle* h, uint64_t words, int m0, hipStream_t s);
 int partition_launch(gndt_handle* h, gndt_handle::Pending& P);
+int partition_begin(gndt_handle* h, const void* xyz_dev, size_t n, size_t stride_bytes, hipStream_t s, bool records = false, uint64_t index_range = 0);
 int partition_resolve(gndt_handle* h);
 // ---- gndt_api_cost.hip ----
 void free_cost(gndt_handle* h);

@@ -90,6 +90,23 @@ __host__ __device__ __forceinline__ uint32_t column_hash(int sx, int sy) {
 __host__ __device__ __forceinline__ uint32_t bucket_of(uint32_t colh, uint32_t B) {
     return (uint32_t)(((uint64_t)(colh >> 8) * (uint64_t)(B & 0xFFFFFFu)) >> 24);
 }
+// Owner rank of a column when a cloud is sharded over W GPUs and every rank builds the columns it owns (gndt_api_dist.hip).
+// A SECOND hash of the column, independent of column_hash: the buckets and LDS slots of the owner's local build are chosen
+// by column_hash, whose distribution must not be narrowed by the choice of the owner.
+__host__ __device__ __forceinline__ uint32_t owner_of(int sx, int sy, uint32_t W) {
+    const uint32_t a = (uint32_t)(sx + 65536) & 0x3FFFFu, b = (uint32_t)(sy + 65536) & 0x3FFFFu;
+    uint32_t h = a * 0xC2B2AEu + b * 0x27D4EBu;
+    h ^= h >> 13; h *= 0x85EBCA77u;
+    h ^= h >> 16; h *= 0x9E3779B1u;
+    h ^= h >> 15;
+    return (uint32_t)(((uint64_t)(h >> 8) * (uint64_t)(W & 0xFFFFFFu)) >> 24);
+}
+// k_part_hist / k_part_scatter modes
+constexpr uint32_t kPartModeOwner = 1u;      // digit = owner_of(column, B) instead of bucket_of(column_hash, B): the owner split
+constexpr uint32_t kPartModeRecords = 2u;    // input is 16-B records {x, y, z, index word}: the index word is taken as it is
+__device__ __forceinline__ uint32_t part_digit(int sx, int sy, uint32_t B, uint32_t mode) {
+    return (mode & kPartModeOwner) ? owner_of(sx, sy, B) : bucket_of(column_hash(sx, sy), B);
+}
 __device__ __forceinline__ uint32_t node_slot_hash(uint32_t colh, int sz) {
     uint32_t g = (colh * 0x9E3779B1u) ^ ((uint32_t)sz * 0xC2B2AE3Du);
     g ^= g >> 16; g *= 0x27D4EB2Fu;
@@ -157,7 +174,7 @@ static __global__ void __launch_bounds__(256) k_part_clear(Counters* __restrict_
 template <int STRIDE_FLOATS>
 __global__ void __launch_bounds__(kPartThreads) k_part_hist(const float* __restrict__ xyz, uint64_t n, GridParams P,
                                                             uint32_t B, uint32_t* __restrict__ hist,
-                                                            Counters* __restrict__ cnt, uint32_t compress) {
+                                                            Counters* __restrict__ cnt, uint32_t compress, uint32_t mode) {
     extern __shared__ uint32_t lh[];
     for (uint32_t i = threadIdx.x; i < B; i += kPartThreads) lh[i] = 0;
     __syncthreads();
@@ -176,7 +193,7 @@ __global__ void __launch_bounds__(kPartThreads) k_part_hist(const float* __restr
         // 64 consecutive identical points (the (0,0,0) padding of the reference's clouds) become ONE
         // weighted record: counted once here, written once by k_part_scatter
         const bool same = compress && wave_all_identical(px, py, pz, use);
-        if (use && (!same || (threadIdx.x & 63) == 0)) atomicAdd(&lh[bucket_of(column_hash(sx, sy), B)], 1u);
+        if (use && (!same || (threadIdx.x & 63) == 0)) atomicAdd(&lh[part_digit(sx, sy, B, mode)], 1u);
     }
     __syncthreads();
     uint32_t* out = hist + (uint64_t)blockIdx.x * B;
@@ -246,7 +263,7 @@ __global__ void __launch_bounds__(kPartThreads) k_part_scatter(const float* __re
                                                                const uint32_t* __restrict__ hist,
                                                                const uint32_t* __restrict__ totals,
                                                                uint32_t* __restrict__ bucket_base,
-                                                               float4* __restrict__ recs, uint32_t compress) {
+                                                               float4* __restrict__ recs, uint32_t compress, uint32_t mode) {
     extern __shared__ uint32_t cur[];
     __shared__ uint32_t wave_sums[kPartThreads / 64];
     block_scan_totals(totals, B, cur, wave_sums);
@@ -263,16 +280,21 @@ __global__ void __launch_bounds__(kPartThreads) k_part_scatter(const float* __re
     for (uint64_t i = lo + threadIdx.x; i < hi_round; i += kPartThreads) {
         const bool live = i < hi;
         float px = 0.f, py = 0.f, pz = 0.f;
-        if (live) { const float* p = xyz + i * STRIDE_FLOATS; px = p[0]; py = p[1]; pz = p[2]; }
+        uint32_t word = 0u;
+        if (live) {
+            const float* p = xyz + i * STRIDE_FLOATS; px = p[0]; py = p[1]; pz = p[2];
+            if constexpr (STRIDE_FLOATS == 4) { if (mode & kPartModeRecords) word = __float_as_uint(p[3]); }
+        }
         int sx, sy;
         bool kok;
         column_of_point(px, py, P, sx, sy, kok);
         const bool use = live && kok;
         const bool same = compress && wave_all_identical(px, py, pz, use);
         if (use && (!same || (threadIdx.x & 63) == 0)) {
-            const uint32_t pos = atomicAdd(&cur[bucket_of(column_hash(sx, sy), B)], 1u);
-            // bit 31 of the index word marks a record that stands for 64 identical points (lane 0 = the first of them)
-            const uint32_t idx = (first_base + (uint32_t)i) | (same ? kWeight64Flag : 0u);
+            const uint32_t pos = atomicAdd(&cur[part_digit(sx, sy, B, mode)], 1u);
+            // bit 31 of the index word marks a record that stands for 64 identical points (lane 0 = the first of them);
+            // records that come from another rank's split carry their index word (and weight) with them
+            const uint32_t idx = (mode & kPartModeRecords) ? word : ((first_base + (uint32_t)i) | (same ? kWeight64Flag : 0u));
             recs[pos] = make_float4(px, py, pz, __uint_as_float(idx));
         }
     }
@@ -381,7 +403,7 @@ __device__ __forceinline__ void tile_partition(TileLds<PER, FAN>& L, const float
 // level 1: the cloud -> coarse regions.  One tile per workgroup.  A coarse region can be split into R sub-regions
 // with their own cursors (tile t fills sub-region t % R) to spread the reservations of thousands of tiles over
 // more words (same-address atomics serialise at the memory side); with 4096-point tiles R = 1 measured best.
-template <int STRIDE_FLOATS, int FAN>
+template <int STRIDE_FLOATS, int FAN, bool IDXW = false>
 __global__ void __launch_bounds__(kTileThreads) __attribute__((amdgpu_waves_per_eu(4, 4))) k_part2_level1(const float* __restrict__ xyz, uint64_t n, uint32_t first_base,
                                                                GridParams P, uint32_t B, uint32_t F1, uint32_t F2_shift, uint32_t R,
                                                                uint32_t* __restrict__ cursor1, uint32_t cap1,
@@ -394,6 +416,7 @@ __global__ void __launch_bounds__(kTileThreads) __attribute__((amdgpu_waves_per_
     // in LDS and copied out (the kernel is latency-bound: ~70 % of a wave's life is spent parked on waits).
     const uint64_t ntiles = (n + (uint64_t)kTileThreads * PER - 1) / ((uint64_t)kTileThreads * PER);
     float nx[PER], ny[PER], nz[PER];
+    uint32_t nw[IDXW ? PER : 1];                   // IDXW: the input is 16-B records whose 4th word is the index word (taken as it is)
     auto load_tile = [&](uint64_t tile) {
         const uint64_t t0 = tile * (kTileThreads * PER);
         const float* __restrict__ base = xyz + t0 * STRIDE_FLOATS;            // uniform: the 64-bit arithmetic stays scalar
@@ -402,7 +425,10 @@ __global__ void __launch_bounds__(kTileThreads) __attribute__((amdgpu_waves_per_
         for (int j = 0; j < PER; ++j) {
             const uint32_t i = (uint32_t)(j * kTileThreads) + threadIdx.x;     // a wave holds 64 consecutive points
             nx[j] = 0.f; ny[j] = 0.f; nz[j] = 0.f;
-            if (i < have) { const float* p = base + i * (uint32_t)STRIDE_FLOATS; nx[j] = p[0]; ny[j] = p[1]; nz[j] = p[2]; }
+            if (i < have) {
+                const float* p = base + i * (uint32_t)STRIDE_FLOATS; nx[j] = p[0]; ny[j] = p[1]; nz[j] = p[2];
+                if constexpr (IDXW) nw[j] = __float_as_uint(p[3]);
+            }
         }
     };
     uint64_t tile = blockIdx.x;
@@ -411,13 +437,14 @@ __global__ void __launch_bounds__(kTileThreads) __attribute__((amdgpu_waves_per_
         const uint64_t t0 = tile * (kTileThreads * PER);
         const uint32_t rep = (uint32_t)(tile % R);
         float cx[PER], cy[PER], cz[PER];
+        uint32_t cw[IDXW ? PER : 1];
 #pragma unroll
-        for (int j = 0; j < PER; ++j) { cx[j] = nx[j]; cy[j] = ny[j]; cz[j] = nz[j]; }
+        for (int j = 0; j < PER; ++j) { cx[j] = nx[j]; cy[j] = ny[j]; cz[j] = nz[j]; if constexpr (IDXW) cw[j] = nw[j]; }
         if (tile + gridDim.x < ntiles) load_tile(tile + gridDim.x);
         // All 512 points this wave holds in the tile bit-identical (a stretch of the converters' zero padding)?  Then they go
         // out as ONE record of weight 512 instead of eight of weight 64: the bucket that collects the padding gets 8x fewer.
-        bool all8 = compress != 0u && t0 + (uint64_t)kTileThreads * PER <= n;
-        {
+        bool all8 = !IDXW && compress != 0u && t0 + (uint64_t)kTileThreads * PER <= n;
+        if constexpr (!IDXW) {
             const uint32_t fx = (uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(cx[0])),
                            fy = (uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(cy[0])),
                            fz = (uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(cz[0]));
@@ -438,7 +465,7 @@ __global__ void __launch_bounds__(kTileThreads) __attribute__((amdgpu_waves_per_
             column_of_point(px, py, P, sx, sy, kok);
             if (live && !kok) atomicAdd(&cnt->err_key_range, 1u);
             const bool use = live && kok;
-            const bool same = all8 || (compress && wave_all_identical(px, py, pz, use));   // 64 identical points -> one weighted record
+            const bool same = !IDXW && (all8 || (compress && wave_all_identical(px, py, pz, use)));   // 64 identical points -> one weighted record
             dig[j] = 0xFFFFFFFFu;
             if (use && (!same || ((threadIdx.x & 63) == 0 && (!all8 || j == 0)))) {
                 const uint32_t b = bucket_of(column_hash(sx, sy), B);
@@ -447,7 +474,8 @@ __global__ void __launch_bounds__(kTileThreads) __attribute__((amdgpu_waves_per_
                 // votes).  Chosen by a hash of the point index: a fixed stride would alias with the scan pattern of a
                 // spinning LiDAR (the same azimuths every ring) and with the lane-0 records of compressed waves.
                 if ((((uint32_t)i * 0x9E3779B1u) >> 26) == 0u) atomicAdd(&est2[b], 1u);
-                const uint32_t idx = (first_base + (uint32_t)i) | (same ? (all8 ? (kWeight64Flag | kWeight512Flag) : kWeight64Flag) : 0u);
+                uint32_t idx = (first_base + (uint32_t)i) | (same ? (all8 ? (kWeight64Flag | kWeight512Flag) : kWeight64Flag) : 0u);
+                if constexpr (IDXW) idx = cw[j];                                   // (the host passes compress = 0 with records)
                 r[j] = make_float4(px, py, pz, __uint_as_float(idx));
             }
         }

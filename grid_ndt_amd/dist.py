@@ -44,6 +44,23 @@ class Communicator:
             raise _lib.GndtError(rc, (self._L.gndt_comm_last_error() or b"").decode())
         self.handle, self.rank, self.world = h, rank, world
 
+    @classmethod
+    def single(cls, device=0):
+        """A communicator of ONE rank, without torch.distributed (tests, single-GPU hosts that use the sharded entry points)."""
+        from . import _lib
+        self = cls.__new__(cls)
+        self._L = _lib.lib()
+        buf = C.create_string_buffer(128)
+        rc = self._L.gndt_comm_unique_id(buf)
+        if rc:
+            raise _lib.GndtError(rc, (self._L.gndt_comm_last_error() or b"").decode())
+        h = C.c_void_p()
+        rc = self._L.gndt_comm_create(buf.raw, 0, 1, int(device), C.byref(h))
+        if rc:
+            raise _lib.GndtError(rc, (self._L.gndt_comm_last_error() or b"").decode())
+        self.handle, self.rank, self.world = h, 0, 1
+        return self
+
     def close(self):
         if self.handle:
             self._L.gndt_comm_destroy(self.handle)

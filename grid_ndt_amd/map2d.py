@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 from . import _lib
-from ._lib import Cells, CostStats, ExchangeTimes, GndtError, Params, Pcd, PointLayout, Robot, Stats
+from ._lib import Cells, CostStats, ExchangeTimes, GndtError, OwnedInfo, Params, Pcd, PointLayout, Robot, Stats
 
 DEMANDS = {"slope": 0, "true": 1}
 FLAG_HAS_STATS, FLAG_SLOPE, FLAG_DOWN = 1, 2, 4
@@ -279,6 +279,74 @@ class TwoDmap:
             return {"shard_ms": t.shard_ms, "exchange_ms": t.exchange_ms, "finalize_ms": t.finalize_ms, "ranks": int(t.ranks),
                     "local_nodes": int(t.local_nodes), "global_nodes": int(t.global_nodes), "bytes_reduced": int(t.bytes_reduced)}
         return None
+
+    # ---- owner-partitioned build of a sharded cloud (include/gndt.h): the points travel, the map stays sharded by owner ----
+    def _dev_view(self, ptr, nbytes, dtype, shape):
+        """torch view of device memory libgndt owns (valid until the next call on the handle)."""
+        import torch
+        dev = f"cuda:{self.device}"
+        if nbytes == 0 or not ptr:
+            return torch.empty(shape, dtype=dtype, device=dev)
+        ts = {torch.float32: "<f4", torch.int64: "<i8", torch.int32: "<i4"}[dtype]
+        return torch.as_tensor(_DevArray(ptr, shape, ts, self), device=dev)
+
+    def owner_split(self, demand, points, first_idx_base, total_points, world, stream=None):
+        """This rank's contiguous range of the cloud -> its points as 16-B records grouped by owner rank.
+        Returns (records [n, 4] float32 device view, counts per owner)."""
+        self._ensure(demand)
+        ptr, n, stride, on_dev, keep = self._as_input(points)
+        if not on_dev:
+            raise GndtError(1, "owner_split takes device memory")
+        recs = C.c_void_p()
+        counts = (C.c_uint64 * int(world))()
+        self._check(self._L.gndt_owner_split_device(self._h, C.c_void_p(ptr), n, stride, int(first_idx_base), int(total_points), int(world),
+                                                    C.byref(recs), counts, _stream_ptr(stream)))
+        self._keep = keep
+        import torch
+        cnt = [int(c) for c in counts]
+        total = sum(cnt)
+        return self._dev_view(recs.value or 0, total * 16, torch.float32, (total, 4)), cnt
+
+    def build_records(self, demand, records, total_points, stream=None):
+        """The records this rank owns ([m, 4] float32 on the device: x, y, z, index word) -> its part of the map."""
+        self._ensure(demand)
+        if records.dim() != 2 or records.shape[1] != 4 or not records.is_contiguous() or not records.is_cuda:
+            raise GndtError(1, "records must be a contiguous [m, 4] float32 device tensor")
+        self._check(self._L.gndt_build_records_device(self._h, C.c_void_p(records.data_ptr()), int(records.shape[0]), int(total_points),
+                                                      _stream_ptr(stream)))
+        self._keep = records
+
+    def owned_columns(self, stream=None):
+        """(first-seen index << 32 | node count) of every column of the local map: int64 device view."""
+        import torch
+        p, n = C.c_void_p(), C.c_uint64()
+        self._check(self._L.gndt_owned_columns_device(self._h, C.byref(p), C.byref(n), _stream_ptr(stream)))
+        return self._dev_view(p.value or 0, int(n.value) * 8, torch.int64, (int(n.value),))
+
+    def owned_global_rows(self, all_pairs, total_points, stream=None):
+        """Everybody's column pairs (int64 device tensor) -> (global row of every local row: int32 device view, nodes and
+        columns of the whole map)."""
+        import torch
+        p, gn, gc = C.c_void_p(), C.c_uint64(), C.c_uint64()
+        self._check(self._L.gndt_owned_global_rows_device(self._h, C.c_void_p(all_pairs.data_ptr()), int(all_pairs.shape[0]), int(total_points),
+                                                          C.byref(p), C.byref(gn), C.byref(gc), _stream_ptr(stream)))
+        n = self.sync()[0]
+        return self._dev_view(p.value or 0, n * 4, torch.int32, (n,)), int(gn.value), int(gc.value)
+
+    def build_owned(self, comm, demand, points, first_idx_base, total_points, stream=None):
+        """Owner-partitioned build over RCCL (called from C++ inside libgndt): this rank's range of the cloud in, the columns
+        this rank owns out (export()), plus the global row of each of its rows.  Returns (global_row view, info dict)."""
+        import torch
+        self._ensure(demand)
+        ptr, n, stride, on_dev, keep = self._as_input(points)
+        if not on_dev:
+            raise GndtError(1, "build_owned takes device memory")
+        info, p = OwnedInfo(), C.c_void_p()
+        self._check(self._L.gndt_build_owned_device(self._h, comm.handle, C.c_void_p(ptr), n, stride, int(first_idx_base), int(total_points),
+                                                    C.byref(p), C.byref(info), _stream_ptr(stream)))
+        self._keep = keep
+        d = {k: (float(getattr(info, k)) if k.endswith("_ms") else int(getattr(info, k))) for k, _ in OwnedInfo._fields_}
+        return self._dev_view(p.value or 0, d["local_nodes"] * 4, torch.int32, (d["local_nodes"],)), d
 
     def finalize_stats(self, key, sums, count, first_idx, total_points, stream=None):
         """Merged statistics of the whole cloud (unique nodes sorted by key) -> the map."""

@@ -216,6 +216,45 @@ const char* gndt_comm_last_error(void);
 int gndt_build_global_device(gndt_handle* h, gndt_comm* c, const void* shard_xyz_dev, size_t n, size_t stride_bytes,
                              uint64_t first_idx_base, uint64_t total_points, gndt_exchange_times* times, void* hip_stream);
 
+/* ---- owner-partitioned build of a sharded cloud: the POINTS travel, statistics do not ----------------------------
+ * No reference counterpart (the reference is single-process).  Every column of the grid has an owner rank (a hash of its
+ * xy cell); each rank sends every point to the owner of its column (all-to-all, 16 B per point, consecutive identical points
+ * folded into weighted records first), builds the columns it owns with the ordinary pipeline — statistics, labels and rows
+ * are final — and learns, from an all-gather of 8 B per column, which row each of its rows has in the map of the WHOLE
+ * cloud.  The map stays sharded by owner:
+ *     gndt_export* on the handle   = this rank's columns, in the reference's order among themselves
+ *     global_row[r]                = the row that local row r has in the single-process map of the whole cloud
+ * so the union of all ranks' rows scattered by global_row IS that map (tests/test_gpu_owner.py assembles it and compares it
+ * with the oracle).  Per rank a build moves (W-1)/W of its points out and as many in; gndt_build_global_device moves 84 B per
+ * node of the global map through an all-reduce and leaves the whole map on every rank.
+ *
+ * gndt_build_owned_device does all of it over RCCL.  The four steps are also exported one by one for hosts that bring their
+ * own transport (MPI, a ROS bridge) and for the single-GPU tests that play W ranks on one device:
+ *   gndt_owner_split_device    shard -> records grouped by owner; counts_host[world] and the device pointer of the runs
+ *                              (valid until the next call on the handle); waits for the stream
+ *   gndt_build_records_device  the records a rank owns (runs of all ranks, concatenated in any order) -> its map; like
+ *                              gndt_build_device it is launched, not awaited.  total_points = binned points of the whole cloud
+ *   gndt_owned_columns_device  (first-seen index << 32 | node count) per column of the local map; waits
+ *   gndt_owned_global_rows_device  everybody's pairs (any order, entries of ~0 are skipped) -> global_row of every local row
+ *                              (device pointer, valid until the next build), node / column count of the whole map; waits */
+typedef struct gndt_owned_info {
+    uint64_t owned_points;          /* records this rank received (weighted records count once) */
+    uint64_t local_nodes, local_columns;
+    uint64_t global_nodes, global_columns, global_slopes;
+    uint64_t bytes_sent, bytes_received;   /* over the links (the run a rank keeps for itself is not counted) */
+    float split_ms, exchange_ms, build_ms, order_ms;   /* device time of the stages (HIP events on the stream) */
+    uint32_t ranks;
+} gndt_owned_info;
+int gndt_owner_split_device(gndt_handle* h, const void* shard_xyz_dev, size_t n, size_t stride_bytes, uint64_t first_idx_base,
+                            uint64_t total_points, uint32_t world, const void** records_dev, uint64_t* counts_host, void* hip_stream);
+int gndt_build_records_device(gndt_handle* h, const void* records_dev, size_t n_records, uint64_t total_points, void* hip_stream);
+int gndt_owned_columns_device(gndt_handle* h, const uint64_t** pairs_dev, uint64_t* n_pairs, void* hip_stream);
+int gndt_owned_global_rows_device(gndt_handle* h, const uint64_t* all_pairs_dev, uint64_t n_all, uint64_t total_points,
+                                  const uint32_t** global_row_dev, uint64_t* global_nodes, uint64_t* global_columns, void* hip_stream);
+int gndt_build_owned_device(gndt_handle* h, gndt_comm* c, const void* shard_xyz_dev, size_t n, size_t stride_bytes,
+                            uint64_t first_idx_base, uint64_t total_points, const uint32_t** global_row_dev,
+                            gndt_owned_info* info, void* hip_stream);
+
 /* ---- cost map over the finished grid -------------------------------------
  * gndt_compute_cost replaces TwoDmap::computeCost (include/map2D.h:1285-1397; called at receiver.cpp:171
  * right after create2DMap): the FIFO flood from the goal slope with CollisionCheck (:351-411; the 3D variants

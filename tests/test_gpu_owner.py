@@ -1,0 +1,132 @@
+"""GPU tier: the owner-partitioned build of a sharded cloud (include/gndt.h, gndt_build_owned_device and its four steps).
+
+One MI355X plays W ranks: W handles, every "rank" splits its contiguous range of the cloud by column owner, the runs are
+handed over with device copies (what ncclSend / ncclRecv do between GPUs), every rank builds the columns it owns from the
+records it received and learns the global row of each of its rows from everybody's column pairs.  The union of the ranks'
+rows, scattered by global_row, must be the oracle's map of the whole cloud — keys, order, first-seen indices and labels bit
+for bit, statistics within the parity tolerances.  The RCCL composition itself runs with world_size 1 on the box."""
+import numpy as np
+import pytest
+
+from grid_ndt_amd import scenes
+from tests import parity
+
+pytestmark = pytest.mark.gpu
+
+TERRAIN = dict(grid_len=0.2, z_len=0.2, slope_interval=0.08, demand="slope")
+
+
+def _ranks(cloud, P, W, strategy=0):
+    import grid_ndt_amd as g
+    maps = []
+    for _ in range(W):
+        m = g.TwoDmap(P["grid_len"], P["z_len"], strategy=strategy, min_points=P.get("min_points", 3))
+        m.setInterval(P["slope_interval"])
+        m.setCloudFirst(cloud[0, :3])
+        maps.append(m)
+    return maps
+
+
+def owner_build_on_one_gpu(cloud, P, W, bounds=None, strategy=0):
+    """-> (assembled global map as an export() dict, per-rank details)."""
+    import torch
+    maps = _ranks(cloud, P, W, strategy)
+    pts = torch.from_numpy(np.ascontiguousarray(cloud[1:])).cuda()
+    n = int(pts.shape[0])
+    bounds = bounds or [n * r // W for r in range(W + 1)]
+    demand = P.get("demand", "slope")
+    pieces = [[None] * W for _ in range(W)]
+    for r in range(W):
+        recs, cnt = maps[r].owner_split(demand, pts[bounds[r]:bounds[r + 1]], bounds[r], n, W)
+        off = np.concatenate([[0], np.cumsum(cnt)]).astype(np.int64)
+        assert recs.shape[0] == off[-1] <= bounds[r + 1] - bounds[r]          # (weighted records fold identical points)
+        for o in range(W):
+            pieces[r][o] = recs[off[o]:off[o + 1]].clone()
+    owned_points = []
+    for o in range(W):
+        own = torch.cat([pieces[r][o] for r in range(W)], 0).contiguous()
+        owned_points.append(int(own.shape[0]))
+        maps[o].build_records(demand, own, n)
+    pairs = [maps[o].owned_columns().clone() for o in range(W)]
+    pad = torch.full((5,), -1, dtype=torch.int64, device="cuda")              # (the all-gather's padding is skipped)
+    allp = torch.cat([x for p in pairs for x in (p, pad)]).contiguous()
+    outs = []
+    for o in range(W):
+        grow, gn, gc = maps[o].owned_global_rows(allp, n)
+        outs.append((maps[o].export(), grow.cpu().numpy().astype(np.int64), gn, gc))
+    N, K = outs[0][2], outs[0][3]
+    glob = {k: np.zeros((N,) + v.shape[1:], v.dtype) for k, v in outs[0][0].items() if isinstance(v, np.ndarray)}
+    seen = np.zeros(N, bool)
+    for out, grow, gn, gc in outs:
+        assert (gn, gc) == (N, K)
+        assert grow.shape[0] == out["num_nodes"]
+        assert not seen[grow].any()
+        seen[grow] = True
+        for k in glob:
+            glob[k][grow] = out[k]
+    assert seen.all()                                                          # the ranks' rows tile [0, N)
+    glob.update(num_nodes=N, num_columns=K, num_slopes=sum(o[0]["num_slopes"] for o in outs))
+    return glob, dict(owned_points=owned_points, local_nodes=[o[0]["num_nodes"] for o in outs], pairs=[int(p.shape[0]) for p in pairs])
+
+
+@pytest.mark.parametrize("W", [1, 2, 3, 4])
+def test_owner_partitioned_build_of_the_campus_frame_equals_the_oracle(W):
+    cloud, P = scenes.campus_frame(150_000), scenes.CAMPUS_PARAMS
+    ref = parity.ref_from_cloud(cloud, P)
+    glob, info = owner_build_on_one_gpu(cloud, P, W)
+    parity.assert_parity(glob, ref)
+    assert sum(info["local_nodes"]) == ref["num_nodes"]
+    if W > 1:                                                                  # the owner hash spreads the columns
+        assert min(info["local_nodes"]) > 0.5 * ref["num_nodes"] / W
+
+
+def test_owner_partitioned_build_with_zero_padding_and_uneven_shards():
+    """The reference's own scene: 64 k points at (0,0,0) travel as weighted records (folded where they are split, taken as
+    they are by the owner's build); shards of very different sizes, one of them empty."""
+    cloud, P = scenes.bridge_ground(), scenes.BRIDGE_PARAMS
+    n = cloud.shape[0] - 1
+    ref = parity.ref_from_cloud(cloud, P)
+    glob, info = owner_build_on_one_gpu(cloud, P, 4, bounds=[0, 1000, 1000, n - 70_000, n])
+    parity.assert_parity(glob, ref)
+    assert sum(info["owned_points"]) < n - 60_000                              # the padding was folded
+
+
+def test_owner_partitioned_large_build_takes_the_two_level_partition():
+    """Above 2^20 records per rank the owner's build is the two-level pipeline reading records (index words taken as they
+    are); the assembled map equals the single-GPU build of the same cloud exactly, row for row."""
+    import torch
+    import grid_ndt_amd as g
+    cloud = scenes.terrain_cloud(5_000_000)
+    P = TERRAIN
+    glob, info = owner_build_on_one_gpu(cloud, P, 2)
+    assert min(info["owned_points"]) > (1 << 20)
+    m, one = parity.gpu_from_cloud(cloud, P, on_device=True)
+    assert m.last_strategy() == 2
+    for k in ("sx", "sy", "sz", "count", "first_idx", "flags"):
+        assert np.array_equal(glob[k], one[k]), k
+    assert glob["num_nodes"] == one["num_nodes"] and glob["num_columns"] == one["num_columns"] and glob["num_slopes"] == one["num_slopes"]
+    # statistics: different summation order only
+    assert np.allclose(glob["mean"], one["mean"], rtol=0, atol=1e-6)
+    scale = np.abs(one["cov"]).max(axis=1, keepdims=True) + 1e-30
+    assert (np.abs(glob["cov"] - one["cov"]) / scale).max() < 1e-5
+
+
+def test_owner_build_over_rccl_with_one_rank():
+    """gndt_build_owned_device end to end (RCCL from C++, world_size 1: split, self hand-over, build, column all-gather)."""
+    import torch
+    import grid_ndt_amd as g
+    from grid_ndt_amd.dist import Communicator
+    cloud, P = scenes.campus_frame(150_000), scenes.CAMPUS_PARAMS
+    ref = parity.ref_from_cloud(cloud, P)
+    comm = Communicator.single()
+    m = _ranks(cloud, P, 1)[0]
+    pts = torch.from_numpy(np.ascontiguousarray(cloud[1:])).cuda()
+    grow, info = m.build_owned(comm, P["demand"], pts, 0, pts.shape[0])
+    out = m.export()
+    parity.assert_parity(out, ref)
+    assert np.array_equal(grow.cpu().numpy(), np.arange(out["num_nodes"]))
+    assert info["global_nodes"] == ref["num_nodes"] and info["global_columns"] == ref["num_columns"]
+    assert info["global_slopes"] == out["num_slopes"] and info["ranks"] == 1 and info["bytes_sent"] == 0
+    # a second build on the same handle (steady state) gives the same rows
+    grow2, info2 = m.build_owned(comm, P["demand"], pts, 0, pts.shape[0])
+    assert np.array_equal(grow2.cpu().numpy(), grow.cpu().numpy()) and info2["global_nodes"] == info["global_nodes"]
