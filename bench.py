@@ -1,15 +1,17 @@
 #!/usr/bin/env python3
 """bench.py — NDT grid-build throughput (bin + mean/cov + eigen + labels + ordering) on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W [--workload S1|S2|S2z|S3|S5] [--mode global|replicas]
+    python bench.py --gpus N --steps K --warmup W [--workload S1|S2|S2z|S3|S5] [--mode owner|global|replicas]
 
 A "step" is one full build of the map from a device-resident cloud (`create2DMap`, receiver.cpp:150-160).
 
 N = 1 (default): BASELINE.json configs[1] — S2, 10 M uniform-random points, 0.5 m cubic voxels.
 N > 1 (default): BASELINE.json configs[2] — S3, ONE global map of a 100 M-point LiDAR-ordered terrain cloud, 0.2 m cubic
-         voxels, sharded over the ranks as contiguous index ranges (strong scaling: the total is fixed), per-node
-         statistics exchanged over RCCL (`--mode global`).  `--mode replicas` builds one independent map per rank
-         instead (frame-level batches: no collective, weak scaling).
+         voxels, sharded over the ranks as contiguous index ranges (strong scaling: the total is fixed).  `--mode owner`
+         (default): every point goes to the rank that owns its column (RCCL all-to-all of 16-B records), each rank builds
+         its columns, 8 B per column give every row its place in the global map — the map stays sharded by owner.
+         `--mode global`: per-node statistics all-reduced, the whole map on every rank.  `--mode replicas` builds one
+         independent map per rank instead (frame-level batches: no collective, weak scaling).
 
 With N > 1 and no RANK in the environment this script starts the N ranks itself (`python -m torch.distributed.run`
 as a child process, before anything here touches the GPU) and relays their output; under torchrun it is a rank.
@@ -56,8 +58,9 @@ def parse():
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default=None, help="default: S2 at N = 1, S3 at N > 1")
     ap.add_argument("--points", type=int, default=0, help="binned points of the workload, all ranks together (0 = its BASELINE size)")
     ap.add_argument("--strategy", type=int, default=0)
-    ap.add_argument("--mode", choices=["replicas", "global"], default=None,
-                    help="N>1: one global map via the RCCL statistics exchange (default) or independent per-rank maps")
+    ap.add_argument("--mode", choices=["replicas", "global", "owner"], default=None,
+                    help="N>1: ONE map of a sharded cloud — 'owner' (default: points travel to the owner of their column, map sharded "
+                         "by owner) or 'global' (statistics all-reduced, whole map on every rank) — or independent per-rank maps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the single-build latency / no-hint / H2D-D2H measurements")
     ap.add_argument("--cpu-sample", type=int, default=0, help="points of the CPU baseline's sample (0 = the whole workload, capped at 10 M)")
@@ -181,9 +184,9 @@ def launch_check(a, rank, world):
         sys.exit(2)
     dist.init_process_group("gloo")
     wname = a.workload or ("S3" if world > 1 else "S2")
-    mode = a.mode or ("global" if world > 1 else "single")
+    mode = a.mode or ("owner" if world > 1 else "single")
     total = a.points or 300_000
-    origin, pts, base, job = make_cloud(wname, total, rank, world, mode == "global")
+    origin, pts, base, job = make_cloud(wname, total, rank, world, mode in ("global", "owner"))
     mine = torch.tensor([base, pts.shape[0], job], dtype=torch.int64)
     got = [torch.zeros_like(mine) for _ in range(world)]
     dist.all_gather(got, mine)
@@ -283,12 +286,13 @@ def main():
         print(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}", file=sys.stderr)
         sys.exit(2)
     torch.cuda.set_device(local)
-    mode = a.mode or ("global" if world > 1 else "single")
-    use_dist = world > 1 or ("RANK" in os.environ and mode == "global")   # torchrun with one rank exercises the exchange too
+    mode = a.mode or ("owner" if world > 1 else "single")
+    use_dist = world > 1 or ("RANK" in os.environ and mode in ("global", "owner"))   # torchrun with one rank exercises the exchange too
     if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
-    global_mode = use_dist and mode == "global"
+    global_mode = use_dist and mode in ("global", "owner")      # ONE cloud sharded over the ranks
+    owner_mode = use_dist and mode == "owner"
 
     import grid_ndt_amd as g
     g.build_native()
@@ -324,7 +328,13 @@ def main():
 
     def step(mm=None, timed=False):
         mm = mm or m
-        if global_mode:
+        if owner_mode:
+            _, t = mm.build_owned(comm, "slope", pts, first_base, job_points, stream)
+            for k in ("split_ms", "exchange_ms", "build_ms", "order_ms"):
+                exch[k] = exch.get(k, 0.0) + t[k]
+            exch.update({k: t[k] for k in ("owned_points", "local_nodes", "local_columns", "global_nodes", "global_columns", "global_slopes",
+                                           "bytes_sent", "bytes_received")})
+        elif global_mode:
             t = mm.build_global(comm, "slope", pts, first_base, job_points, stream, timed=timed)
             if t:
                 for k in ("shard_ms", "exchange_ms", "finalize_ms"):
@@ -378,6 +388,11 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
     nodes, cols, slopes = m.sync()
+    n_local = n
+    if owner_mode:                       # the handle holds this rank's columns; the map of the whole cloud has:
+        n_local = int(exch_timed.get("owned_points", n))
+        local_nodes = nodes
+        nodes, cols, slopes = int(exch_timed["global_nodes"]), int(exch_timed["global_columns"]), int(exch_timed["global_slopes"])
 
     # ---- extras (untimed, rank 0 of a single-GPU run): what a 10 Hz callback sees, the no-hint path, PCIe legs ----
     extras = {}
@@ -424,12 +439,13 @@ def main():
         dom = max(cand, key=cand.get) if cand else None
         acc_ms = live.get(dom, cand.get(dom, float("nan"))) if dom else float("nan")
         timed_live = dom in live
+        k_nodes = local_nodes if owner_mode else nodes       # what ONE launch of the kernel on rank 0 processed
         if dom in m.POINT_PHASES:
-            alg_bytes = BYTES_PER_POINT * n
+            alg_bytes = BYTES_PER_POINT * n_local
         elif dom in m.POINT_AND_NODE_PHASES:
-            alg_bytes = BYTES_PER_POINT * n + BYTES_PER_NODE * nodes
+            alg_bytes = BYTES_PER_POINT * n_local + BYTES_PER_NODE * k_nodes
         else:
-            alg_bytes = BYTES_PER_NODE * nodes
+            alg_bytes = BYTES_PER_NODE * k_nodes
         achieved = alg_bytes / (acc_ms * 1e-3) / 1e9 if acc_ms == acc_ms and acc_ms > 0 else None
         traffic, traffic_src = (None, None)
         if wname == "S2" and world == 1 and total == WORKLOADS["S2"]["points"]:
@@ -459,7 +475,9 @@ def main():
         if global_mode:
             out["exchange"] = {k: (round(v, 4) if isinstance(v, float) else v) for k, v in exch_timed.items()}
             out["exchange"]["ranks"] = world
-            out["exchange"]["backend"] = "rccl (called from C++ inside libgndt: gndt_build_global_device)"
+            out["exchange"]["backend"] = ("rccl (called from C++ inside libgndt: gndt_build_owned_device — all-to-all of 16-B point records, "
+                                          "all-gather of 8 B per column; the map stays sharded by column owner)") if owner_mode else \
+                                         "rccl (called from C++ inside libgndt: gndt_build_global_device — statistics all-reduce, whole map on every rank)"
         out.update(extras)
         if not a.no_cpu_baseline and world == 1:
             sample = a.cpu_sample or min(n, 10_000_000)

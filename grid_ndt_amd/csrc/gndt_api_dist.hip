@@ -257,9 +257,10 @@ namespace {
 
 constexpr uint32_t kMaxRanks = 1024;
 
-// shard -> records grouped by owner (X.send_recs, X.send_off[0..W]); waits for the stream
-int owner_split(gndt_handle* h, const void* xyz, size_t n, size_t stride_bytes, uint64_t first_base, uint64_t total_points, uint32_t W,
-                hipStream_t s) {
+// shard -> records grouped by owner (X.send_recs); the run starts and the counters come back with the stream
+// (owner_split_finish after the next wait)
+int owner_split_launch(gndt_handle* h, const void* xyz, size_t n, size_t stride_bytes, uint64_t first_base, uint64_t total_points, uint32_t W,
+                       hipStream_t s) {
     auto& q = h->part;
     auto& X = h->exch;
     if (stride_bytes != 12 && stride_bytes != 16) { h->err = "stride_bytes must be 12 or 16"; return GNDT_ERR_INVALID; }
@@ -301,7 +302,11 @@ int owner_split(gndt_handle* h, const void* xyz, size_t n, size_t stride_bytes, 
     uint32_t* h_base = X.h_matrix + (size_t)kMaxRanks * kMaxRanks;
     HIP_TRY(h, hipMemcpyAsync(h_base, q.bucket_base, ((size_t)W + 1) * 4, hipMemcpyDeviceToHost, s));
     HIP_TRY(h, hipMemcpyAsync(X.h_split_cnt, X.d_split_cnt, sizeof(Counters), hipMemcpyDeviceToHost, s));
-    HIP_TRY(h, hipStreamSynchronize(s));
+    return GNDT_OK;
+}
+int owner_split_finish(gndt_handle* h, uint32_t W) {        // (after the stream has been waited for)
+    auto& X = h->exch;
+    const uint32_t* h_base = X.h_matrix + (size_t)kMaxRanks * kMaxRanks;
     for (uint32_t r = 0; r <= W; ++r) X.send_off[r] = h_base[r];
     if (X.h_split_cnt->err_key_range) {
         h->err = std::to_string(X.h_split_cnt->err_key_range) + " point(s) outside the key range";
@@ -371,6 +376,13 @@ int global_rows_launch(gndt_handle* h, const unsigned long long* all_pairs, uint
 
 extern "C" {
 
+int gndt_owner_of_columns(const int32_t* sx, const int32_t* sy, size_t n, uint32_t world, uint32_t* owner_out) {
+    if ((!sx || !sy || !owner_out) && n) return GNDT_ERR_INVALID;
+    if (world < 1 || world > kMaxRanks) return GNDT_ERR_INVALID;
+    for (size_t i = 0; i < n; ++i) owner_out[i] = owner_of(sx[i], sy[i], world);
+    return GNDT_OK;
+}
+
 int gndt_owner_split_device(gndt_handle* h, const void* shard_xyz_dev, size_t n, size_t stride_bytes, uint64_t first_idx_base,
                             uint64_t total_points, uint32_t world, const void** records_dev, uint64_t* counts_host, void* hip_stream) {
     int rc = check_ready(h);
@@ -379,7 +391,9 @@ int gndt_owner_split_device(gndt_handle* h, const void* shard_xyz_dev, size_t n,
     hipStream_t s = stream_of(h, hip_stream);
     h->pending.active = false;
     { const int urc = use_stream(h, s); if (urc) return urc; }
-    if ((rc = owner_split(h, shard_xyz_dev, n, stride_bytes, first_idx_base, total_points, world, s))) return rc;
+    if ((rc = owner_split_launch(h, shard_xyz_dev, n, stride_bytes, first_idx_base, total_points, world, s))) return rc;
+    HIP_TRY(h, hipStreamSynchronize(s));
+    if ((rc = owner_split_finish(h, world))) return rc;
     for (uint32_t r = 0; r < world; ++r) counts_host[r] = h->exch.send_off[r + 1] - h->exch.send_off[r];
     *records_dev = h->exch.send_recs;
     return GNDT_OK;
@@ -446,14 +460,18 @@ int gndt_build_owned_device(gndt_handle* h, gndt_comm* c, const void* shard_xyz_
     if (info) for (auto& e : ev) HIP_TRY(h, hipEventCreate(&e));
     auto stamp = [&](int i) { if (info) (void)hipEventRecord(ev[i], s); };
     stamp(0);
-    // 1. split by owner
-    if ((rc = owner_split(h, shard_xyz_dev, n, stride_bytes, first_idx_base, total_points, (uint32_t)W, s))) return rc;
-    stamp(1);
-    // 2. who sends how much to whom (W x W counts), then the runs themselves
+    // 1. split by owner; who sends how much to whom (W x W counts) follows on the stream: ONE wait for both
     if ((rc = grow_buf(h, X.d_matrix, X.matrix_cap, (uint64_t)W * W))) return rc;
+    if ((rc = owner_split_launch(h, shard_xyz_dev, n, stride_bytes, first_idx_base, total_points, (uint32_t)W, s))) return rc;
+    stamp(1);
     RCCL_TRY(h, rccl().AllGather(q.totals, X.d_matrix, (size_t)W, ncclUint32, c->nccl, s));
     HIP_TRY(h, hipMemcpyAsync(X.h_matrix, X.d_matrix, (size_t)W * W * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     HIP_TRY(h, hipStreamSynchronize(s));
+    // (points outside the key range were dropped by the split: the other ranks are already on their way into the exchange, so
+    // this rank takes part in it to the end and reports the error then)
+    const int split_rc = owner_split_finish(h, (uint32_t)W);
+    const std::string split_err = split_rc ? h->err : std::string();
+    // 2. the runs themselves
     std::vector<uint64_t> recv_off((size_t)W + 1, 0);
     for (int r = 0; r < W; ++r) recv_off[r + 1] = recv_off[r] + X.h_matrix[(size_t)r * W + me];      // what rank r holds for me
     const uint64_t n_own = recv_off[W];
@@ -512,6 +530,7 @@ int gndt_build_owned_device(gndt_handle* h, gndt_comm* c, const void* shard_xyz_
     stamp(4);
     HIP_TRY(h, hipStreamSynchronize(s));
     if (bad) { h->err = std::to_string(bad) + " column pair(s) with an index beyond total_points"; return GNDT_ERR_INVALID; }
+    if (split_rc) { h->err = split_err; return split_rc; }
     if (global_row_dev) *global_row_dev = X.global_row;
     if (info) {
         float t[4] = {0, 0, 0, 0};

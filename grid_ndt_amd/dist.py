@@ -137,3 +137,76 @@ def build_global_map(m, demand, shard, first_idx_base, stream=None, group=None, 
         for k, v in (("shard_ms", t1 - t0), ("exchange_ms", t2 - t1), ("finalize_ms", t3 - t2)):
             timings[k] = timings.get(k, 0.0) + v * 1e3
     return key.shape[0]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Owner-partitioned build (include/gndt.h: gndt_build_owned_device) spelled with torch.distributed point-to-point calls:
+# the transport for backends libgndt's own RCCL path cannot use (the world_size-2 gloo tests on CPU) and the model for
+# hosts that bring their own (MPI, a ROS bridge): the four exported steps with the hand-over in between.
+# ---------------------------------------------------------------------------------------------------------------------
+def owner_of_columns(sx, sy, world):
+    """Owner rank of every column (numpy int32 arrays): libgndt's own hash (host helper, no GPU)."""
+    import numpy as np
+    from . import _lib
+    sx = np.ascontiguousarray(sx, np.int32)
+    sy = np.ascontiguousarray(sy, np.int32)
+    out = np.zeros(sx.shape[0], np.uint32)
+    rc = _lib.lib().gndt_owner_of_columns(sx.ctypes.data, sy.ctypes.data, sx.shape[0], int(world), out.ctypes.data)
+    if rc:
+        raise _lib.GndtError(rc, "gndt_owner_of_columns")
+    return out
+
+
+def exchange_records(records, counts, group=None):
+    """records [m, 4] (any 4-byte dtype) grouped by owner rank, counts[r] of them for rank r  ->  the records this rank owns:
+    the runs every rank holds for it, in rank order.  Sizes first (all-gather), then one send / receive per peer."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    dev = records.device
+    mine = torch.tensor(list(counts), dtype=torch.int64, device=dev)
+    table = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(table, mine, group=group)
+    incoming = [int(table[r][rank]) for r in range(world)]                 # what rank r holds for this rank
+    off = [0]
+    for c in counts:
+        off.append(off[-1] + int(c))
+    bits = records.view(torch.int32)                                       # index words are bit patterns, never numbers
+    got = [torch.empty((incoming[r], 4), dtype=torch.int32, device=dev) for r in range(world)]
+    got[rank].copy_(bits[off[rank]:off[rank + 1]])
+    ops = []
+    for r in range(world):
+        if r == rank:
+            continue
+        if off[r + 1] > off[r]:
+            ops.append(dist.P2POp(dist.isend, bits[off[r]:off[r + 1]].contiguous(), r, group))
+        if incoming[r]:
+            ops.append(dist.P2POp(dist.irecv, got[r], r, group))
+    if ops:
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+    return torch.cat(got, 0).contiguous().view(records.dtype)
+
+
+def gather_column_pairs(pairs, group=None):
+    """Every rank's (first-seen index << 32 | node count) column pairs -> all of them on every rank (int64; the padding of
+    the all-gather is -1, which gndt_owned_global_rows_device skips)."""
+    world = dist.get_world_size(group)
+    n = torch.tensor([pairs.shape[0]], dtype=torch.int64, device=pairs.device)
+    sizes = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(sizes, n, group=group)
+    m = max(1, max(int(x) for x in sizes))
+    padded = torch.full((m,), -1, dtype=torch.int64, device=pairs.device)
+    padded[:pairs.shape[0]] = pairs
+    out = [torch.empty_like(padded) for _ in range(world)]
+    dist.all_gather(out, padded, group=group)
+    return torch.cat(out)
+
+
+def build_owned_map(m, demand, shard, first_idx_base, total_points, group=None, stream=None):
+    """The owner-partitioned build with torch.distributed as the transport: this rank's contiguous range of the cloud in;
+    afterwards `m` holds the columns this rank owns.  Returns (global row of every local row, nodes, columns of the whole map)."""
+    world = dist.get_world_size(group)
+    recs, counts = m.owner_split(demand, shard, first_idx_base, total_points, world, stream)
+    own = exchange_records(recs, counts, group)
+    m.build_records(demand, own, total_points, stream)
+    allp = gather_column_pairs(m.owned_columns(stream).clone(), group)
+    return m.owned_global_rows(allp, total_points, stream)

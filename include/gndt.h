@@ -245,6 +245,8 @@ typedef struct gndt_owned_info {
     float split_ms, exchange_ms, build_ms, order_ms;   /* device time of the stages (HIP events on the stream) */
     uint32_t ranks;
 } gndt_owned_info;
+/* owner rank of the columns (sx[i], sy[i]) among `world` ranks: the hash gndt_owner_split_device uses (host helper, no GPU) */
+int gndt_owner_of_columns(const int32_t* sx, const int32_t* sy, size_t n, uint32_t world, uint32_t* owner_out);
 int gndt_owner_split_device(gndt_handle* h, const void* shard_xyz_dev, size_t n, size_t stride_bytes, uint64_t first_idx_base,
                             uint64_t total_points, uint32_t world, const void** records_dev, uint64_t* counts_host, void* hip_stream);
 int gndt_build_records_device(gndt_handle* h, const void* records_dev, size_t n_records, uint64_t total_points, void* hip_stream);

@@ -36,8 +36,24 @@ def unpack(keys):
     return sx.astype(np.int32), sy.astype(np.int32), sz.astype(np.int32)
 
 
-def accumulate(body, origin, grid_len, z_len, first_base=0):
-    """points -> (unique keys, count, first_idx, sums[.,9]) — what k_accumulate leaves in the table."""
+def point_columns(body, origin, grid_len, z_len):
+    """(sx, sy) of every point: the column part of the kernels' own key."""
+    L = shim()
+    body = np.ascontiguousarray(body, np.float32)
+    n, stride = body.shape
+    o = (C.c_float * 3)(*[float(v) for v in origin])
+    keys = np.zeros(n, np.uint64)
+    ok = np.zeros(n, np.uint8)
+    L.shim_point_keys(C.c_void_p(body.ctypes.data), C.c_uint64(n), C.c_int(stride), o, C.c_float(grid_len),
+                      C.c_float(z_len), C.c_void_p(keys.ctypes.data), C.c_void_p(ok.ctypes.data))
+    assert ok.all()
+    sx, sy, _ = unpack(keys)
+    return sx, sy
+
+
+def accumulate(body, origin, grid_len, z_len, first_base=0, idx=None):
+    """points -> (unique keys, count, first_idx, sums[.,9]) — what k_accumulate leaves in the table.
+    `idx`: explicit global index of every point (records of an owner-partitioned build) instead of first_base + position."""
     L = shim()
     body = np.ascontiguousarray(body, np.float32)
     n, stride = body.shape
@@ -58,7 +74,7 @@ def accumulate(body, origin, grid_len, z_len, first_base=0):
     np.add.at(sums, inv, q)
     count = np.bincount(inv, minlength=uk.size).astype(np.uint32)
     first = np.full(uk.size, np.iinfo(np.int64).max, np.int64)
-    np.minimum.at(first, inv, np.arange(n, dtype=np.int64) + first_base)
+    np.minimum.at(first, inv, (np.arange(n, dtype=np.int64) + first_base) if idx is None else np.asarray(idx, np.int64))
     return uk, count, first.astype(np.uint32), sums, cen
 
 

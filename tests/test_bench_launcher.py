@@ -22,7 +22,7 @@ def _run(args):
 
 def test_self_launch_two_ranks_shards_the_default_multi_gpu_workload():
     out = _run(["--gpus", "2", "--launch-check", "--points", "300000"])
-    assert out["n_gpus"] == 2 and out["workload"] == "S3" and out["mode"] == "global"
+    assert out["n_gpus"] == 2 and out["workload"] == "S3" and out["mode"] == "owner"
     (b0, n0, j0), (b1, n1, j1) = out["shards"]
     assert j0 == j1 == 300000                     # point 0 is the origin and is not binned (receiver.cpp:145, 150)
     assert b0 == 0 and b1 == n0 and n0 + n1 == 300000   # contiguous index ranges that tile the binned points

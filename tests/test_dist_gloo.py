@@ -57,3 +57,93 @@ def test_two_rank_merge_matches_single_process_and_oracle():
     out = he.finalize(key.view(np.uint64), cnt.astype(np.uint32), first.astype(np.uint32), sums, cen[order],
                       P["slope_interval"], P["demand"])
     parity.assert_parity(out, parity.ref_from_cloud(cloud, P))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# owner-partitioned build (include/gndt.h: gndt_build_owned_device): the protocol on two gloo ranks.  The device steps are
+# played by the host emulation (same arithmetic header), the transport is grid_ndt_amd/dist.py's (exchange_records,
+# gather_column_pairs) and the owner of a column is libgndt's own hash (gndt_owner_of_columns).
+# ---------------------------------------------------------------------------------------------------------------------
+def _column_pairs(local):
+    """(first-seen index << 32 | node count) per column of a map in reference order + the first row of every column."""
+    col = (local["sx"].astype(np.int64) << 32) ^ (local["sy"].astype(np.int64) & 0xFFFFFFFF)
+    head = np.flatnonzero(np.concatenate([[True], col[1:] != col[:-1]])) if col.size else np.zeros(0, np.int64)
+    ncol = np.diff(np.concatenate([head, [col.size]]))
+    return (local["first_idx"][head].astype(np.int64) << 32) | ncol.astype(np.int64), head, ncol
+
+
+def _global_rows(all_pairs, head, ncol, local):
+    """What k_pairs_note + the word-weight prefix + k_global_rows compute: columns ordered by first-seen index."""
+    p = all_pairs[all_pairs != -1]
+    cf, nc = p >> 32, p & 0xFFFFFFFF
+    order = np.argsort(cf, kind="stable")
+    base = np.concatenate([[0], np.cumsum(nc[order])])
+    pos = {int(c): int(b) for c, b in zip(cf[order], base[:-1])}
+    rows = np.zeros(local["sx"].shape[0], np.int64)
+    for h, k in zip(head, ncol):
+        rows[h:h + k] = pos[int(local["first_idx"][h])] + np.arange(k)
+    return rows, int(base[-1]), int(p.size)
+
+
+def _owner_worker(rank, world, port, cut, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from grid_ndt_amd.dist import exchange_records, gather_column_pairs, owner_of_columns
+    cloud = scenes.campus_frame(50000)
+    body, origin = cloud[1:], cloud[0]
+    total = body.shape[0]
+    lo, hi = (0, cut) if rank == 0 else (cut, total)
+    shard = body[lo:hi]
+    # step 1 (gndt_owner_split_device): records {x, y, z, global index} grouped by the owner of their column
+    sx, sy = he.point_columns(shard, origin, P["grid_len"], P["z_len"])
+    owner = owner_of_columns(sx, sy, world)
+    order = np.argsort(owner, kind="stable")
+    recs = np.zeros((shard.shape[0], 4), np.float32)
+    recs[:, :3] = shard[order, :3]
+    recs[:, 3] = (np.arange(lo, hi, dtype=np.uint32)[order]).view(np.float32)
+    counts = np.bincount(owner, minlength=world).tolist()
+    own = exchange_records(torch.from_numpy(recs), counts).numpy()
+    idx = np.ascontiguousarray(own[:, 3]).view(np.uint32).astype(np.int64)
+    # every point of a column this rank owns is here, and nothing else
+    sx2, sy2 = he.point_columns(own, origin, P["grid_len"], P["z_len"])
+    assert np.all(owner_of_columns(sx2, sy2, world) == rank)
+    # step 2 (gndt_build_records_device): the ordinary build on the records, index words taken as they are
+    uk, cnt, first, sums, cen = he.accumulate(own, origin, P["grid_len"], P["z_len"], idx=idx)
+    local = he.finalize(uk, cnt, first, sums, cen, P["slope_interval"], P["demand"])
+    # steps 3 + 4 (gndt_owned_columns_device, gndt_owned_global_rows_device)
+    pairs, head, ncol = _column_pairs(local)
+    allp = gather_column_pairs(torch.from_numpy(pairs)).numpy()
+    rows, n_glob, k_glob = _global_rows(allp, head, ncol, local)
+    q.put((rank, local, rows, n_glob, k_glob, int(own.shape[0])))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_owner_partitioned_build_assembles_the_oracle_map():
+    world, port = 2, 29619
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_owner_worker, args=(r, world, port, 17777, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {r[0]: r[1:] for r in (q.get(timeout=300) for _ in range(world))}
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    cloud = scenes.campus_frame(50000)
+    ref = parity.ref_from_cloud(cloud, P)
+    N, K = res[0][2], res[0][3]
+    assert (N, K) == (res[1][2], res[1][3]) == (ref["num_nodes"], ref["num_columns"])
+    assert res[0][4] + res[1][4] == cloud.shape[0] - 1 and min(res[0][4], res[1][4]) > 0.3 * cloud.shape[0]   # a real split
+    glob = {k: np.zeros((N,) + v.shape[1:], v.dtype) for k, v in res[0][0].items() if isinstance(v, np.ndarray)}
+    seen = np.zeros(N, bool)
+    for r in range(world):
+        local, rows = res[r][0], res[r][1]
+        assert not seen[rows].any()
+        seen[rows] = True
+        for k in glob:
+            glob[k][rows] = local[k]
+    assert seen.all()
+    glob.update(num_nodes=N, num_columns=K, num_slopes=sum(res[r][0]["num_slopes"] for r in range(world)))
+    parity.assert_parity(glob, ref)

@@ -130,3 +130,27 @@ def test_owner_build_over_rccl_with_one_rank():
     # a second build on the same handle (steady state) gives the same rows
     grow2, info2 = m.build_owned(comm, P["demand"], pts, 0, pts.shape[0])
     assert np.array_equal(grow2.cpu().numpy(), grow.cpu().numpy()) and info2["global_nodes"] == info["global_nodes"]
+
+
+def test_owner_build_with_torch_distributed_as_the_transport():
+    """grid_ndt_amd.dist.build_owned_map: the four exported steps with torch.distributed (backend nccl = RCCL, world_size 1)
+    doing the hand-over — the model for hosts that bring their own transport."""
+    import os
+    import torch
+    import torch.distributed as dist
+    from grid_ndt_amd.dist import build_owned_map
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29653")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    try:
+        cloud = scenes.terrain_cloud(200_000)
+        ref = parity.ref_from_cloud(cloud, TERRAIN)
+        m = _ranks(cloud, TERRAIN, 1)[0]
+        pts = torch.from_numpy(np.ascontiguousarray(cloud[1:])).cuda()
+        grow, gn, gc = build_owned_map(m, "slope", pts, 0, pts.shape[0])
+        out = m.export()
+        parity.assert_parity(out, ref)
+        assert (gn, gc) == (ref["num_nodes"], ref["num_columns"])
+        assert np.array_equal(grow.cpu().numpy(), np.arange(out["num_nodes"]))
+    finally:
+        dist.destroy_process_group()
