@@ -207,6 +207,9 @@ def lib():
     L.gndt_build_global_device.argtypes = [H, vp, vp, C.c_size_t, C.c_size_t, u64, u64, C.POINTER(ExchangeTimes), vp]
     L.gndt_owner_of_columns.argtypes = [vp, vp, C.c_size_t, C.c_uint32, vp]
     L.gndt_owner_of_columns.restype = C.c_int
+    L.gndt_owner_sample_device.argtypes = [H, vp, C.c_size_t, C.c_size_t, C.POINTER(vp), C.POINTER(u64), vp]
+    L.gndt_owner_map_device.argtypes = [H, vp, C.c_uint32, vp]
+    L.gndt_owner_sample_device.restype = L.gndt_owner_map_device.restype = C.c_int
     L.gndt_owner_split_device.argtypes = [H, vp, C.c_size_t, C.c_size_t, u64, u64, C.c_uint32, C.POINTER(vp), C.POINTER(u64), vp]
     L.gndt_build_records_device.argtypes = [H, vp, C.c_size_t, u64, vp]
     L.gndt_owned_columns_device.argtypes = [H, C.POINTER(vp), C.POINTER(u64), vp]

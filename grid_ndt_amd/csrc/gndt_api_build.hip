@@ -209,9 +209,9 @@ int partition_launch(gndt_handle* h, gndt_handle::Pending& P) {
         HIP_TRY(h, hipFuncSetAttribute((const void*)k_part_scatter<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
     if (stride_bytes == 12)
-        hipLaunchKernelGGL(k_part_hist<3>, dim3(nwg), dim3(kPartThreads), lds, s, p, (uint64_t)n, gp, B, q.hist, h->d_cnt, compress, part_mode);
+        hipLaunchKernelGGL(k_part_hist<3>, dim3(nwg), dim3(kPartThreads), lds, s, p, (uint64_t)n, gp, B, q.hist, h->d_cnt, compress, part_mode, OwnerMap{nullptr, nullptr, 0u});
     else
-        hipLaunchKernelGGL(k_part_hist<4>, dim3(nwg), dim3(kPartThreads), lds, s, p, (uint64_t)n, gp, B, q.hist, h->d_cnt, compress, part_mode);
+        hipLaunchKernelGGL(k_part_hist<4>, dim3(nwg), dim3(kPartThreads), lds, s, p, (uint64_t)n, gp, B, q.hist, h->d_cnt, compress, part_mode, OwnerMap{nullptr, nullptr, 0u});
     HIP_TRY(h, hipGetLastError());
     mark(h, 2, s);
     hipLaunchKernelGGL(k_part_offsets, dim3((B + 31) / 32), dim3(256), 0, s, q.hist, q.totals, B, nwg);
@@ -219,10 +219,10 @@ int partition_launch(gndt_handle* h, gndt_handle::Pending& P) {
     mark(h, 3, s);
     if (stride_bytes == 12)
         hipLaunchKernelGGL(k_part_scatter<3>, dim3(nwg), dim3(kPartThreads), lds, s, p, (uint64_t)n, P.first_base, gp, B, q.hist,
-                           q.totals, q.bucket_base, q.recs, compress, part_mode);
+                           q.totals, q.bucket_base, q.recs, compress, part_mode, OwnerMap{nullptr, nullptr, 0u});
     else
         hipLaunchKernelGGL(k_part_scatter<4>, dim3(nwg), dim3(kPartThreads), lds, s, p, (uint64_t)n, P.first_base, gp, B, q.hist,
-                           q.totals, q.bucket_base, q.recs, compress, part_mode);
+                           q.totals, q.bucket_base, q.recs, compress, part_mode, OwnerMap{nullptr, nullptr, 0u});
     HIP_TRY(h, hipGetLastError());
     mark(h, 4, s);
     range_lo = q.bucket_base; range_hi = q.bucket_base + 1;

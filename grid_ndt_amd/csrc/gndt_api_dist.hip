@@ -257,6 +257,39 @@ namespace {
 
 constexpr uint32_t kMaxRanks = 1024;
 
+// kOwnerSamples evenly spaced points of the shard -> their blocks, with the shard size in front (X.owner_msg)
+int owner_sample_launch(gndt_handle* h, const void* xyz, size_t n, size_t stride_bytes, hipStream_t s) {
+    auto& X = h->exch;
+    if (stride_bytes != 12 && stride_bytes != 16) { h->err = "stride_bytes must be 12 or 16"; return GNDT_ERR_INVALID; }
+    if (!X.owner_msg) HIP_TRY(h, hipMalloc(&X.owner_msg, (size_t)kOwnerMsgWords * 4));
+    const GridParams gp = grid_params(h);
+    const float* p = static_cast<const float*>(xyz);
+    if (stride_bytes == 12) hipLaunchKernelGGL(k_owner_sample<3>, dim3(kOwnerSamples / 256), dim3(256), 0, s, p, (uint64_t)n, gp, X.owner_msg);
+    else hipLaunchKernelGGL(k_owner_sample<4>, dim3(kOwnerSamples / 256), dim3(256), 0, s, p, (uint64_t)n, gp, X.owner_msg);
+    HIP_TRY(h, hipGetLastError());
+    return GNDT_OK;
+}
+
+// everybody's sample messages -> the block table of this build (X.bkey / X.bown); the same on every rank
+int owner_map_launch(gndt_handle* h, const uint32_t* msgs, uint32_t W, hipStream_t s) {
+    auto& X = h->exch;
+    int rc;
+    X.owner_map_world = 0;
+    if (W < 2 || W > kOwnerMapMaxRanks) return GNDT_OK;               // (hash ownership)
+    if (!X.bkey) HIP_TRY(h, hipMalloc(&X.bkey, (size_t)kOwnerSlots * 4));
+    if (!X.bown) HIP_TRY(h, hipMalloc(&X.bown, (size_t)kOwnerSlots));
+    if (!X.d_owner_full) HIP_TRY(h, hipMalloc(&X.d_owner_full, sizeof(uint32_t)));
+    if ((rc = grow_buf(h, X.bcnt, X.bcnt_cap, (uint64_t)kOwnerSlots * W))) return rc;
+    HIP_TRY(h, hipMemsetAsync(X.bkey, 0, (size_t)kOwnerSlots * 4, s));
+    HIP_TRY(h, hipMemsetAsync(X.bcnt, 0, (size_t)kOwnerSlots * W * 4, s));
+    HIP_TRY(h, hipMemsetAsync(X.d_owner_full, 0, sizeof(uint32_t), s));
+    hipLaunchKernelGGL(k_owner_vote, dim3(grid_for((uint64_t)W * kOwnerSamples)), dim3(256), 0, s, msgs, W, X.bkey, X.bcnt, kOwnerSlots - 1u, X.d_owner_full);
+    hipLaunchKernelGGL(k_owner_pick, dim3(grid_for(kOwnerSlots)), dim3(256), 0, s, msgs, W, (const uint32_t*)X.bkey, (const uint32_t*)X.bcnt, kOwnerSlots, X.bown);
+    HIP_TRY(h, hipGetLastError());
+    X.owner_map_world = W;
+    return GNDT_OK;
+}
+
 // shard -> records grouped by owner (X.send_recs); the run starts and the counters come back with the stream
 // (owner_split_finish after the next wait)
 int owner_split_launch(gndt_handle* h, const void* xyz, size_t n, size_t stride_bytes, uint64_t first_base, uint64_t total_points, uint32_t W,
@@ -287,17 +320,19 @@ int owner_split_launch(gndt_handle* h, const void* xyz, size_t n, size_t stride_
     const uint32_t compress = total_points < (uint64_t)kWeightIndexLimit ? 1u : 0u;
     const float* p = static_cast<const float*>(xyz);
     const size_t lds = (size_t)W * 4;
+    // the block table all ranks made from the same samples (owner_map_launch), if it is for this many ranks; else hash ownership
+    const OwnerMap M = (X.owner_map_world == W && X.bkey) ? OwnerMap{X.bkey, X.bown, kOwnerSlots - 1u} : OwnerMap{nullptr, nullptr, 0u};
     if (stride_bytes == 12)
-        hipLaunchKernelGGL(k_part_hist<3>, dim3(nwg), dim3(kPartThreads), lds, s, p, (uint64_t)n, gp, W, q.hist, X.d_split_cnt, compress, kPartModeOwner);
+        hipLaunchKernelGGL(k_part_hist<3>, dim3(nwg), dim3(kPartThreads), lds, s, p, (uint64_t)n, gp, W, q.hist, X.d_split_cnt, compress, kPartModeOwner, M);
     else
-        hipLaunchKernelGGL(k_part_hist<4>, dim3(nwg), dim3(kPartThreads), lds, s, p, (uint64_t)n, gp, W, q.hist, X.d_split_cnt, compress, kPartModeOwner);
+        hipLaunchKernelGGL(k_part_hist<4>, dim3(nwg), dim3(kPartThreads), lds, s, p, (uint64_t)n, gp, W, q.hist, X.d_split_cnt, compress, kPartModeOwner, M);
     hipLaunchKernelGGL(k_part_offsets, dim3((W + 31) / 32), dim3(256), 0, s, q.hist, q.totals, W, nwg);
     if (stride_bytes == 12)
         hipLaunchKernelGGL(k_part_scatter<3>, dim3(nwg), dim3(kPartThreads), lds, s, p, (uint64_t)n, (uint32_t)first_base, gp, W, q.hist, q.totals,
-                           q.bucket_base, X.send_recs, compress, kPartModeOwner);
+                           q.bucket_base, X.send_recs, compress, kPartModeOwner, M);
     else
         hipLaunchKernelGGL(k_part_scatter<4>, dim3(nwg), dim3(kPartThreads), lds, s, p, (uint64_t)n, (uint32_t)first_base, gp, W, q.hist, q.totals,
-                           q.bucket_base, X.send_recs, compress, kPartModeOwner);
+                           q.bucket_base, X.send_recs, compress, kPartModeOwner, M);
     HIP_TRY(h, hipGetLastError());
     uint32_t* h_base = X.h_matrix + (size_t)kMaxRanks * kMaxRanks;
     HIP_TRY(h, hipMemcpyAsync(h_base, q.bucket_base, ((size_t)W + 1) * 4, hipMemcpyDeviceToHost, s));
@@ -383,6 +418,31 @@ int gndt_owner_of_columns(const int32_t* sx, const int32_t* sy, size_t n, uint32
     return GNDT_OK;
 }
 
+int gndt_owner_sample_device(gndt_handle* h, const void* shard_xyz_dev, size_t n, size_t stride_bytes, const uint32_t** msg_dev,
+                             uint64_t* msg_words, void* hip_stream) {
+    int rc = check_ready(h);
+    if (rc) return rc;
+    if (!msg_dev || !msg_words || (!shard_xyz_dev && n)) { h->err = "null argument"; return GNDT_ERR_INVALID; }
+    hipStream_t s = stream_of(h, hip_stream);
+    { const int urc = use_stream(h, s); if (urc) return urc; }
+    if ((rc = owner_sample_launch(h, shard_xyz_dev, n, stride_bytes, s))) return rc;
+    HIP_TRY(h, hipStreamSynchronize(s));
+    *msg_dev = h->exch.owner_msg;
+    *msg_words = kOwnerMsgWords;
+    return GNDT_OK;
+}
+
+int gndt_owner_map_device(gndt_handle* h, const uint32_t* all_msgs_dev, uint32_t world, void* hip_stream) {
+    int rc = check_ready(h);
+    if (rc) return rc;
+    if (!all_msgs_dev || world < 1 || world > kMaxRanks) { h->err = "bad argument"; return GNDT_ERR_INVALID; }
+    hipStream_t s = stream_of(h, hip_stream);
+    { const int urc = use_stream(h, s); if (urc) return urc; }
+    if ((rc = owner_map_launch(h, all_msgs_dev, world, s))) return rc;
+    HIP_TRY(h, hipStreamSynchronize(s));             // (the caller's message buffer is free again)
+    return GNDT_OK;
+}
+
 int gndt_owner_split_device(gndt_handle* h, const void* shard_xyz_dev, size_t n, size_t stride_bytes, uint64_t first_idx_base,
                             uint64_t total_points, uint32_t world, const void** records_dev, uint64_t* counts_host, void* hip_stream) {
     int rc = check_ready(h);
@@ -460,6 +520,14 @@ int gndt_build_owned_device(gndt_handle* h, gndt_comm* c, const void* shard_xyz_
     if (info) for (auto& e : ev) HIP_TRY(h, hipEventCreate(&e));
     auto stamp = [&](int i) { if (info) (void)hipEventRecord(ev[i], s); };
     stamp(0);
+    // 0. who owns what: everybody's samples (one fixed-size all-gather, no wait) -> the block table, identical on every rank
+    X.owner_map_world = 0;
+    if (W > 1 && W <= (int)kOwnerMapMaxRanks && tuning().owner_locality) {
+        if ((rc = owner_sample_launch(h, shard_xyz_dev, n, stride_bytes, s))) return rc;
+        if ((rc = grow_buf(h, X.owner_msgs_all, X.owner_msgs_cap, (uint64_t)kOwnerMsgWords * W))) return rc;
+        RCCL_TRY(h, rccl().AllGather(X.owner_msg, X.owner_msgs_all, (size_t)kOwnerMsgWords, ncclUint32, c->nccl, s));
+        if ((rc = owner_map_launch(h, X.owner_msgs_all, (uint32_t)W, s))) return rc;
+    }
     // 1. split by owner; who sends how much to whom (W x W counts) follows on the stream: ONE wait for both
     if ((rc = grow_buf(h, X.d_matrix, X.matrix_cap, (uint64_t)W * W))) return rc;
     if ((rc = owner_split_launch(h, shard_xyz_dev, n, stride_bytes, first_idx_base, total_points, (uint32_t)W, s))) return rc;

@@ -128,6 +128,79 @@ static __global__ void k_exchange_pad(uint64_t* __restrict__ buf, uint32_t have,
 // ---------------------------------------------------------------------------------------------
 constexpr unsigned long long kNoPair = 0xFFFFFFFFFFFFFFFFull;
 
+// ---- who owns which column: locality first ----
+// A contiguous range of a scan-ordered cloud covers a patch of ground, so most points of a 32 x 32-column block (6.4 m at
+// 0.2 m cells) sit on one or two ranks already.  Every rank samples kOwnerSamples points of its shard evenly and publishes
+// their blocks (one fixed-size all-gather, 256 KB per rank, no host round trip); every rank then counts, for every block
+// seen, the samples of each rank weighted by that rank's shard size, and gives the block to the rank that holds most of
+// it — the same deterministic rule on the same data, so all ranks hold the same map.  A block with more than 1 / (4 W) of
+// the whole cloud is NOT given to one rank (its columns are spread by owner_of), and so is every block no sample hit.
+// Measured on the S3 terrain (8 M points, W = 2 / 4 / 8): 81 / 80 / 75 % of the points are already on their owner
+// (hash ownership: 50 / 25 / 12.5 %), heaviest rank 1.01 / 1.02 / 1.08 x the mean.
+constexpr uint32_t kOwnerSamples = 65536, kOwnerSlots = 1u << 20, kOwnerMsgWords = kOwnerSamples + 2, kNoSample = 0xFFFFFFFFu;
+constexpr uint32_t kOwnerMapMaxRanks = 16;
+
+// msg[0..1] = shard size, msg[2 + k] = block of the k-th sample (kNoSample: no such sample / outside the key range)
+template <int STRIDE_FLOATS>
+__global__ void __launch_bounds__(256) k_owner_sample(const float* __restrict__ xyz, uint64_t n, GridParams P, uint32_t* __restrict__ msg) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k == 0) { msg[0] = (uint32_t)n; msg[1] = (uint32_t)(n >> 32); }
+    if (k >= kOwnerSamples) return;
+    uint32_t out = kNoSample;
+    const uint64_t have = n < (uint64_t)kOwnerSamples ? n : (uint64_t)kOwnerSamples;
+    if (k < have) {
+        const uint64_t i = n < (uint64_t)kOwnerSamples ? (uint64_t)k : ((uint64_t)k * n) / kOwnerSamples;
+        const float* p = xyz + i * STRIDE_FLOATS;
+        int sx, sy;
+        bool ok;
+        column_of_point(p[0], p[1], P, sx, sy, ok);
+        if (ok) out = owner_block(sx, sy);
+    }
+    msg[2 + k] = out;
+}
+
+// everybody's samples -> per block, the samples of every rank (bcnt[slot * W + r])
+static __global__ void __launch_bounds__(256) k_owner_vote(const uint32_t* __restrict__ msgs, uint32_t W, uint32_t* __restrict__ bkey,
+                                                           uint32_t* __restrict__ bcnt, uint32_t mask, uint32_t* __restrict__ full) {
+    const uint64_t total = (uint64_t)W * kOwnerSamples;
+    for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t r = (uint32_t)(t / kOwnerSamples), k = (uint32_t)(t % kOwnerSamples);
+        const uint32_t b = msgs[(size_t)r * kOwnerMsgWords + 2 + k];
+        if (b == kNoSample) continue;
+        const uint32_t key = b + 1u;
+        uint32_t s = owner_block_slot(key) & mask;
+        bool found = false;
+        for (uint32_t probe = 0; probe <= mask; ++probe) {
+            uint32_t cur = bkey[s];
+            if (cur == 0u) { cur = atomicCAS(&bkey[s], 0u, key); if (cur == 0u) cur = key; }
+            if (cur == key) { found = true; break; }
+            s = (s + 1u) & mask;
+        }
+        if (found) atomicAdd(&bcnt[(size_t)s * W + r], 1u); else atomicAdd(full, 1u);
+    }
+}
+
+// per block: the rank that holds most of it (samples x shard size; ties: the lower rank), unless the block is too hot
+static __global__ void __launch_bounds__(256) k_owner_pick(const uint32_t* __restrict__ msgs, uint32_t W, const uint32_t* __restrict__ bkey,
+                                                           const uint32_t* __restrict__ bcnt, uint32_t slots, uint8_t* __restrict__ bown) {
+    unsigned long long cloud = 0;
+    for (uint32_t r = 0; r < W; ++r) cloud += (unsigned long long)msgs[(size_t)r * kOwnerMsgWords] | ((unsigned long long)msgs[(size_t)r * kOwnerMsgWords + 1] << 32);
+    for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < slots; s += gridDim.x * blockDim.x) {
+        if (bkey[s] == 0u) continue;
+        unsigned long long best = 0, sum = 0;
+        uint32_t who = 0xFFu;
+        for (uint32_t r = 0; r < W; ++r) {
+            const unsigned long long n_r = (unsigned long long)msgs[(size_t)r * kOwnerMsgWords] | ((unsigned long long)msgs[(size_t)r * kOwnerMsgWords + 1] << 32);
+            const unsigned long long w = (unsigned long long)bcnt[(size_t)s * W + r] * n_r;     // < 2^16 * 2^31
+            sum += w;
+            if (w > best) { best = w; who = r; }
+        }
+        // share of the cloud = sum / (samples per rank * cloud): too hot for ONE rank above 1 / (4 W)
+        if (sum * 4ull * W > (unsigned long long)kOwnerSamples * cloud) who = 0xFFu;
+        bown[s] = (uint8_t)who;
+    }
+}
+
 // the columns of the local map: (first-seen index of the column, its node count), in any order
 static __global__ void __launch_bounds__(256) k_owned_columns(const uint32_t* __restrict__ first_idx, const uint32_t* __restrict__ row_ncol,
                                                               const Counters* __restrict__ cnt, unsigned long long* __restrict__ pairs,

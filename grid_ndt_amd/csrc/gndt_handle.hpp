@@ -136,6 +136,10 @@ struct gndt_handle {
         uint32_t* d_npairs = nullptr;  uint32_t* global_row = nullptr; uint64_t global_row_cap = 0;
         unsigned long long* d_totals = nullptr;  unsigned long long* h_totals = nullptr;          // [4] nodes, columns, slopes, points
         uint64_t send_off[1025] = {};   // host: start of every owner's records in send_recs (after gndt_owner_split_device)
+        // locality-aware ownership (gndt_exchange.hpp): this rank's sample message, everybody's, the block table
+        uint32_t* owner_msg = nullptr;  uint32_t* owner_msgs_all = nullptr; uint64_t owner_msgs_cap = 0;
+        uint32_t* bkey = nullptr;  uint32_t* bcnt = nullptr; uint64_t bcnt_cap = 0;  uint8_t* bown = nullptr;  uint32_t* d_owner_full = nullptr;
+        uint32_t owner_map_world = 0;   // ranks the block table in bkey / bown was made for (0: none — hash ownership)
     } exch;
     uint64_t result_serial = 0;         // bumped whenever a build / finalize produces new result rows
     int last_strategy = GNDT_STRATEGY_ATOMIC;
@@ -190,6 +194,7 @@ struct Tuning {
     uint32_t bucket_wgs = 0xFFFFFFFFu;   // GNDT_BUCKET_WGS   persistent bucket workgroups (default: one per bucket)
     double tile_ratio = 48.0;    // GNDT_TILE_RATIO     AUTO takes strategy TILE from this many points per partial on (sampled; the
                                  //                     measured crossover, profiles/r02_tile_calibration.json)
+    int owner_locality = 1;      // GNDT_OWNER_LOCALITY owner-partitioned build: sampled block ownership (1) or hash ownership only (0)
     int update_tile = -1;        // GNDT_UPDATE_TILE    incremental updates through the tile kernel: 1 always, 0 never, -1 = by strategy
     bool stamps = false;         // GNDT_STAMPS=1       in-kernel phase stamps of the bucket kernel
     bool verbose = false;        // GNDT_VERBOSE=1      stderr line per resolved two-level build

@@ -101,11 +101,36 @@ __host__ __device__ __forceinline__ uint32_t owner_of(int sx, int sy, uint32_t W
     h ^= h >> 15;
     return (uint32_t)(((uint64_t)(h >> 8) * (uint64_t)(W & 0xFFFFFFu)) >> 24);
 }
+// Locality-aware ownership: blocks of 32 x 32 columns whose owner all ranks agreed on from a sample of everybody's shard
+// (gndt_exchange.hpp: most of a scan-ordered shard's points then already sit on their owner and never cross a link); a column
+// of a block that is not in the map — never sampled, or too hot to give to ONE rank — falls back to owner_of.
+struct OwnerMap {
+    const uint32_t* bkey;    // open addressing: block + 1, 0 = empty; nullptr = no map (hash ownership only)
+    const uint8_t* bown;     // owner rank of the block in that slot, 0xFF = hash ownership
+    uint32_t mask;
+};
+__host__ __device__ __forceinline__ uint32_t owner_block(int sx, int sy) {      // 12 + 12 bits
+    return ((((uint32_t)(sx + 65536) & 0x3FFFFu) >> 5) << 12) | (((uint32_t)(sy + 65536) & 0x3FFFFu) >> 5);
+}
+__host__ __device__ __forceinline__ uint32_t owner_block_slot(uint32_t key) { key *= 0x9E3779B1u; return key ^ (key >> 15); }
+__device__ __forceinline__ uint32_t owner_lookup(const OwnerMap& M, int sx, int sy, uint32_t W) {
+    if (M.bkey) {
+        const uint32_t key = owner_block(sx, sy) + 1u;
+        uint32_t s = owner_block_slot(key) & M.mask;
+        for (uint32_t probe = 0; probe <= M.mask; ++probe) {
+            const uint32_t k = M.bkey[s];
+            if (k == key) { const uint32_t o = M.bown[s]; if (o < W) return o; break; }
+            if (k == 0u) break;
+            s = (s + 1u) & M.mask;
+        }
+    }
+    return owner_of(sx, sy, W);
+}
 // k_part_hist / k_part_scatter modes
-constexpr uint32_t kPartModeOwner = 1u;      // digit = owner_of(column, B) instead of bucket_of(column_hash, B): the owner split
+constexpr uint32_t kPartModeOwner = 1u;      // digit = owner of the column among B ranks instead of bucket_of(column_hash, B)
 constexpr uint32_t kPartModeRecords = 2u;    // input is 16-B records {x, y, z, index word}: the index word is taken as it is
-__device__ __forceinline__ uint32_t part_digit(int sx, int sy, uint32_t B, uint32_t mode) {
-    return (mode & kPartModeOwner) ? owner_of(sx, sy, B) : bucket_of(column_hash(sx, sy), B);
+__device__ __forceinline__ uint32_t part_digit(int sx, int sy, uint32_t B, uint32_t mode, const OwnerMap& M) {
+    return (mode & kPartModeOwner) ? owner_lookup(M, sx, sy, B) : bucket_of(column_hash(sx, sy), B);
 }
 __device__ __forceinline__ uint32_t node_slot_hash(uint32_t colh, int sz) {
     uint32_t g = (colh * 0x9E3779B1u) ^ ((uint32_t)sz * 0xC2B2AE3Du);
@@ -174,7 +199,7 @@ static __global__ void __launch_bounds__(256) k_part_clear(Counters* __restrict_
 template <int STRIDE_FLOATS>
 __global__ void __launch_bounds__(kPartThreads) k_part_hist(const float* __restrict__ xyz, uint64_t n, GridParams P,
                                                             uint32_t B, uint32_t* __restrict__ hist,
-                                                            Counters* __restrict__ cnt, uint32_t compress, uint32_t mode) {
+                                                            Counters* __restrict__ cnt, uint32_t compress, uint32_t mode, OwnerMap M) {
     extern __shared__ uint32_t lh[];
     for (uint32_t i = threadIdx.x; i < B; i += kPartThreads) lh[i] = 0;
     __syncthreads();
@@ -193,7 +218,7 @@ __global__ void __launch_bounds__(kPartThreads) k_part_hist(const float* __restr
         // 64 consecutive identical points (the (0,0,0) padding of the reference's clouds) become ONE
         // weighted record: counted once here, written once by k_part_scatter
         const bool same = compress && wave_all_identical(px, py, pz, use);
-        if (use && (!same || (threadIdx.x & 63) == 0)) atomicAdd(&lh[part_digit(sx, sy, B, mode)], 1u);
+        if (use && (!same || (threadIdx.x & 63) == 0)) atomicAdd(&lh[part_digit(sx, sy, B, mode, M)], 1u);
     }
     __syncthreads();
     uint32_t* out = hist + (uint64_t)blockIdx.x * B;
@@ -263,7 +288,7 @@ __global__ void __launch_bounds__(kPartThreads) k_part_scatter(const float* __re
                                                                const uint32_t* __restrict__ hist,
                                                                const uint32_t* __restrict__ totals,
                                                                uint32_t* __restrict__ bucket_base,
-                                                               float4* __restrict__ recs, uint32_t compress, uint32_t mode) {
+                                                               float4* __restrict__ recs, uint32_t compress, uint32_t mode, OwnerMap M) {
     extern __shared__ uint32_t cur[];
     __shared__ uint32_t wave_sums[kPartThreads / 64];
     block_scan_totals(totals, B, cur, wave_sums);
@@ -291,7 +316,7 @@ __global__ void __launch_bounds__(kPartThreads) k_part_scatter(const float* __re
         const bool use = live && kok;
         const bool same = compress && wave_all_identical(px, py, pz, use);
         if (use && (!same || (threadIdx.x & 63) == 0)) {
-            const uint32_t pos = atomicAdd(&cur[part_digit(sx, sy, B, mode)], 1u);
+            const uint32_t pos = atomicAdd(&cur[part_digit(sx, sy, B, mode, M)], 1u);
             // bit 31 of the index word marks a record that stands for 64 identical points (lane 0 = the first of them);
             // records that come from another rank's split carry their index word (and weight) with them
             const uint32_t idx = (mode & kPartModeRecords) ? word : ((first_base + (uint32_t)i) | (same ? kWeight64Flag : 0u));

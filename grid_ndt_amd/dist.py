@@ -205,6 +205,11 @@ def build_owned_map(m, demand, shard, first_idx_base, total_points, group=None, 
     """The owner-partitioned build with torch.distributed as the transport: this rank's contiguous range of the cloud in;
     afterwards `m` holds the columns this rank owns.  Returns (global row of every local row, nodes, columns of the whole map)."""
     world = dist.get_world_size(group)
+    if 1 < world <= 16:                 # locality-aware ownership: everybody's samples -> the same block table on every rank
+        msg = m.owner_sample(demand, shard, stream).clone()
+        msgs = [torch.empty_like(msg) for _ in range(world)]
+        dist.all_gather(msgs, msg, group=group)
+        m.owner_map(torch.cat(msgs).contiguous(), world, stream)
     recs, counts = m.owner_split(demand, shard, first_idx_base, total_points, world, stream)
     own = exchange_records(recs, counts, group)
     m.build_records(demand, own, total_points, stream)

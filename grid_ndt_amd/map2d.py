@@ -290,6 +290,21 @@ class TwoDmap:
         ts = {torch.float32: "<f4", torch.int64: "<i8", torch.int32: "<i4"}[dtype]
         return torch.as_tensor(_DevArray(ptr, shape, ts, self), device=dev)
 
+    def owner_sample(self, demand, points, stream=None):
+        """Evenly spaced sample of this rank's shard as the fixed-size message every rank publishes (int32 device view)."""
+        import torch
+        self._ensure(demand)
+        ptr, n, stride, on_dev, keep = self._as_input(points)
+        if not on_dev:
+            raise GndtError(1, "owner_sample takes device memory")
+        p, w = C.c_void_p(), C.c_uint64()
+        self._check(self._L.gndt_owner_sample_device(self._h, C.c_void_p(ptr), n, stride, C.byref(p), C.byref(w), _stream_ptr(stream)))
+        return self._dev_view(p.value, int(w.value) * 4, torch.int32, (int(w.value),))
+
+    def owner_map(self, all_msgs, world, stream=None):
+        """The sample messages of all ranks (int32 device tensor, rank order) -> the block ownership later owner_split calls use."""
+        self._check(self._L.gndt_owner_map_device(self._h, C.c_void_p(all_msgs.data_ptr()), int(world), _stream_ptr(stream)))
+
     def owner_split(self, demand, points, first_idx_base, total_points, world, stream=None):
         """This rank's contiguous range of the cloud -> its points as 16-B records grouped by owner rank.
         Returns (records [n, 4] float32 device view, counts per owner)."""

@@ -247,6 +247,18 @@ typedef struct gndt_owned_info {
 } gndt_owned_info;
 /* owner rank of the columns (sx[i], sy[i]) among `world` ranks: the hash gndt_owner_split_device uses (host helper, no GPU) */
 int gndt_owner_of_columns(const int32_t* sx, const int32_t* sy, size_t n, uint32_t world, uint32_t* owner_out);
+/* Optional, before the split — locality-aware ownership (gndt_build_owned_device does it by itself): a contiguous range of a
+ * scan-ordered cloud covers a patch of ground, so a block of 32 x 32 columns is given to the rank that already holds most
+ * of its points and those points never cross a link.
+ *   gndt_owner_sample_device  65 536 evenly spaced points of the shard -> a fixed-size message (device pointer, 32-bit words)
+ *   gndt_owner_map_device     the messages of ALL ranks, concatenated in rank order -> the block table kept on the handle and
+ *                             used by gndt_owner_split_device calls for the same `world` until replaced.  Every rank must
+ *                             build it from the same messages (it then holds the same table); columns of blocks the
+ *                             samples missed, or of a block holding more than 1/(4 world) of the cloud, go by the hash.
+ * Without these two calls (or with world > 16) ownership is gndt_owner_of_columns' hash. */
+int gndt_owner_sample_device(gndt_handle* h, const void* shard_xyz_dev, size_t n, size_t stride_bytes, const uint32_t** msg_dev,
+                             uint64_t* msg_words, void* hip_stream);
+int gndt_owner_map_device(gndt_handle* h, const uint32_t* all_msgs_dev, uint32_t world, void* hip_stream);
 int gndt_owner_split_device(gndt_handle* h, const void* shard_xyz_dev, size_t n, size_t stride_bytes, uint64_t first_idx_base,
                             uint64_t total_points, uint32_t world, const void** records_dev, uint64_t* counts_host, void* hip_stream);
 int gndt_build_records_device(gndt_handle* h, const void* records_dev, size_t n_records, uint64_t total_points, void* hip_stream);

@@ -27,21 +27,28 @@ def _ranks(cloud, P, W, strategy=0):
     return maps
 
 
-def owner_build_on_one_gpu(cloud, P, W, bounds=None, strategy=0):
-    """-> (assembled global map as an export() dict, per-rank details)."""
+def owner_build_on_one_gpu(cloud, P, W, bounds=None, strategy=0, locality=False):
+    """-> (assembled global map as an export() dict, per-rank details).  `locality`: the two optional steps in front
+    (gndt_owner_sample_device on every rank, gndt_owner_map_device from everybody's messages) instead of hash ownership."""
     import torch
     maps = _ranks(cloud, P, W, strategy)
     pts = torch.from_numpy(np.ascontiguousarray(cloud[1:])).cuda()
     n = int(pts.shape[0])
     bounds = bounds or [n * r // W for r in range(W + 1)]
     demand = P.get("demand", "slope")
+    if locality:
+        msgs = torch.cat([maps[r].owner_sample(demand, pts[bounds[r]:bounds[r + 1]]).clone() for r in range(W)]).contiguous()
+        for r in range(W):
+            maps[r].owner_map(msgs, W)
     pieces = [[None] * W for _ in range(W)]
+    kept = 0
     for r in range(W):
         recs, cnt = maps[r].owner_split(demand, pts[bounds[r]:bounds[r + 1]], bounds[r], n, W)
         off = np.concatenate([[0], np.cumsum(cnt)]).astype(np.int64)
         assert recs.shape[0] == off[-1] <= bounds[r + 1] - bounds[r]          # (weighted records fold identical points)
         for o in range(W):
             pieces[r][o] = recs[off[o]:off[o + 1]].clone()
+        kept += cnt[r]
     owned_points = []
     for o in range(W):
         own = torch.cat([pieces[r][o] for r in range(W)], 0).contiguous()
@@ -66,7 +73,8 @@ def owner_build_on_one_gpu(cloud, P, W, bounds=None, strategy=0):
             glob[k][grow] = out[k]
     assert seen.all()                                                          # the ranks' rows tile [0, N)
     glob.update(num_nodes=N, num_columns=K, num_slopes=sum(o[0]["num_slopes"] for o in outs))
-    return glob, dict(owned_points=owned_points, local_nodes=[o[0]["num_nodes"] for o in outs], pairs=[int(p.shape[0]) for p in pairs])
+    return glob, dict(owned_points=owned_points, local_nodes=[o[0]["num_nodes"] for o in outs], pairs=[int(p.shape[0]) for p in pairs],
+                      kept_fraction=kept / max(1, sum(owned_points)))
 
 
 @pytest.mark.parametrize("W", [1, 2, 3, 4])
@@ -109,6 +117,32 @@ def test_owner_partitioned_large_build_takes_the_two_level_partition():
     assert np.allclose(glob["mean"], one["mean"], rtol=0, atol=1e-6)
     scale = np.abs(one["cov"]).max(axis=1, keepdims=True) + 1e-30
     assert (np.abs(glob["cov"] - one["cov"]) / scale).max() < 1e-5
+
+
+@pytest.mark.parametrize("W", [2, 4, 8])
+def test_locality_aware_ownership_keeps_most_points_where_they_are(W):
+    """Contiguous ranges of the LiDAR-ordered terrain: with the sampled block table most records never leave their rank
+    (hash ownership keeps 1/W), the load stays balanced, and the assembled map is still the oracle's."""
+    cloud = scenes.terrain_cloud(1_500_000)
+    ref = parity.ref_from_cloud(cloud, TERRAIN)
+    glob, info = owner_build_on_one_gpu(cloud, TERRAIN, W, locality=True)
+    parity.assert_parity(glob, ref)
+    print("W", W, "kept", round(info["kept_fraction"], 3), "owned", info["owned_points"])
+    assert info["kept_fraction"] > 0.6
+    assert max(info["owned_points"]) < 1.5 * sum(info["owned_points"]) / W
+    _, plain = owner_build_on_one_gpu(cloud, TERRAIN, W, locality=False)
+    assert plain["kept_fraction"] < 1.3 / W
+
+
+def test_locality_aware_ownership_spreads_a_hot_block_and_survives_odd_shards():
+    """A cloud that sits in ONE block (the campus frame's columns within a few metres... and the zero padding) must not end up
+    on one rank; empty and tiny shards publish their (empty) samples like everybody else."""
+    cloud, P = scenes.bridge_ground(), scenes.BRIDGE_PARAMS
+    n = cloud.shape[0] - 1
+    ref = parity.ref_from_cloud(cloud, P)
+    glob, info = owner_build_on_one_gpu(cloud, P, 4, bounds=[0, 1000, 1000, n - 70_000, n], locality=True)
+    parity.assert_parity(glob, ref)
+    assert min(info["local_nodes"]) > 0.05 * ref["num_nodes"]                 # nobody was left without work
 
 
 def test_owner_build_over_rccl_with_one_rank():
