@@ -25,7 +25,7 @@
     } while (0)
 
 int main(int argc, char** argv) {
-    if (argc < 9) { std::printf("usage: %s cloud.f32 points gridLen zLen slope_interval rank world id_file [device]\n", argv[0]); return 2; }
+    if (argc < 9) { std::printf("usage: %s cloud.f32 points gridLen zLen slope_interval rank world id_file [device [global|owner]]\n", argv[0]); return 2; }
     const size_t points = std::strtoull(argv[2], nullptr, 10);
     const int rank = std::atoi(argv[6]), world = std::atoi(argv[7]);
     const int device = argc > 9 ? std::atoi(argv[9]) : rank;
@@ -66,6 +66,21 @@ int main(int argc, char** argv) {
     void* d_shard = nullptr;
     if (hipSetDevice(device) != hipSuccess || hipMalloc(&d_shard, shard.size() * 4) != hipSuccess ||
         hipMemcpy(d_shard, shard.data(), shard.size() * 4, hipMemcpyHostToDevice) != hipSuccess) { std::printf("ERROR: device copy\n"); return 1; }
+    if (argc > 10 && std::string(argv[10]) == "owner") {
+        // the points travel: every rank ends with the columns it owns and the global row of each of its rows
+        gndt_owned_info info;
+        const uint32_t* global_row = nullptr;           // device pointer: row of local row r in the map of the whole cloud
+        CHECK(gndt_build_owned_device(h, comm, d_shard, n, 12, lo - 1, nb, &global_row, &info, nullptr));
+        std::printf("rank %d/%d: shard %zu points -> owns %llu points, %llu nodes; global map: nodes %llu columns %llu slopes %llu  "
+                    "(split %.3f ms, exchange %.3f ms [%llu B out], build %.3f ms, order %.3f ms)\n", rank, world, n,
+                    (unsigned long long)info.owned_points, (unsigned long long)info.local_nodes, (unsigned long long)info.global_nodes,
+                    (unsigned long long)info.global_columns, (unsigned long long)info.global_slopes, info.split_ms, info.exchange_ms,
+                    (unsigned long long)info.bytes_sent, info.build_ms, info.order_ms);
+        (void)hipFree(d_shard);
+        gndt_destroy(h);
+        gndt_comm_destroy(comm);
+        return 0;
+    }
     gndt_exchange_times t;
     CHECK(gndt_build_global_device(h, comm, d_shard, n, 12, lo - 1, nb, &t, nullptr));
     uint64_t nodes = 0, columns = 0, slopes = 0;

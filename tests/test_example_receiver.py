@@ -87,9 +87,10 @@ def test_sharded_example_one_rank_equals_the_oracle(tmp_path, native_lib):
     P = dict(grid_len=0.2, z_len=0.2, slope_interval=0.08, demand="slope")
     path = str(tmp_path / "cloud.f32")
     np.ascontiguousarray(cloud, np.float32).tofile(path)
-    r = subprocess.run([exe, path, str(cloud.shape[0]), "0.2", "0.2", "0.08", "0", "1", str(tmp_path / "id.bin"), "0"],
-                       capture_output=True, text=True, timeout=300)
-    assert r.returncode == 0, r.stdout + r.stderr
     ref = parity.ref_from_cloud(cloud, P)
     want = f"nodes {ref['num_nodes']} columns {ref['num_columns']} slopes {int(np.count_nonzero(ref['flags'] & 2))}"
-    assert want in r.stdout, r.stdout
+    for mode in ("global", "owner"):          # statistics all-reduced / points sent to the owner of their column
+        r = subprocess.run([exe, path, str(cloud.shape[0]), "0.2", "0.2", "0.08", "0", "1", str(tmp_path / f"id_{mode}.bin"), "0", mode],
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert want in r.stdout, r.stdout
