@@ -236,12 +236,13 @@ void gndt_destroy(gndt_handle* h) {
         auto& X = h->exch;
         void* xp[] = {X.d_counts, X.keys_in, X.keys_all, X.keys_sorted, X.canon, X.d_unique, X.d_missing, X.scratch, X.packed, X.pfirst, X.r_sums, X.r_count,
                       X.send_recs, X.own_recs, X.d_matrix, X.d_split_cnt, X.pairs, X.pairs_all, X.d_npairs, X.global_row, X.d_totals,
-                      X.owner_msg, X.owner_msgs_all, X.bkey, X.bcnt, X.bown, X.d_owner_full};
+                      X.owner_msg, X.owner_msgs_all, X.bkey, X.bcnt, X.bown, X.d_owner_full, X.d_colmsg, X.gw};
         for (void* p : xp) if (p) (void)hipFree(p);
         if (X.h_counts) (void)hipHostFree(X.h_counts);
         if (X.h_matrix) (void)hipHostFree(X.h_matrix);
         if (X.h_split_cnt) (void)hipHostFree(X.h_split_cnt);
         if (X.h_totals) (void)hipHostFree(X.h_totals);
+        if (X.h_colmsg) (void)hipHostFree(X.h_colmsg);
     }
     if (h->xstream_ev) (void)hipEventDestroy(h->xstream_ev);
     if (h->d_sample) (void)hipFree(h->d_sample);

@@ -361,21 +361,28 @@ int build_records(gndt_handle* h, const void* recs, size_t n, uint64_t total_poi
 }
 
 // columns of the finished local map as (first-seen index << 32 | node count) pairs in X.pairs; count in X.d_npairs[0]
-int owned_columns_launch(gndt_handle* h, hipStream_t s, uint32_t& ncols_host) {
+// (the build may still be running: sizes come from the staging capacity, the kernel reads the node count on the device and
+// does nothing if the build raised an overflow flag)
+int owned_columns_enqueue(gndt_handle* h, hipStream_t s) {
     auto& q = h->part;
     auto& X = h->exch;
+    int rc;
+    if ((rc = grow_buf(h, X.pairs, X.pairs_cap, std::max<uint64_t>(q.stage_cap, 1)))) return rc;
+    if (!X.d_npairs) HIP_TRY(h, hipMalloc(&X.d_npairs, 2 * sizeof(uint32_t)));
+    HIP_TRY(h, hipMemsetAsync(X.d_npairs, 0, 2 * sizeof(uint32_t), s));
+    const uint32_t col_wgs = (uint32_t)std::min<uint64_t>(2048, (std::max<uint64_t>(q.stage_cap, 1) + kColChunk - 1) / kColChunk);
+    hipLaunchKernelGGL(k_owned_columns, dim3(col_wgs), dim3(256), 0, s, h->out.first_idx, q.row_ncol,
+                       h->d_cnt, q.d_pc, X.pairs, (uint32_t)X.pairs_cap, X.d_npairs);
+    HIP_TRY(h, hipGetLastError());
+    return GNDT_OK;
+}
+int owned_columns_launch(gndt_handle* h, hipStream_t s, uint32_t& ncols_host) {
     int rc = partition_resolve(h);
     if (rc) return rc;
     if (!h->results_valid || h->map_in_table) { h->err = "no finished PARTITION build on this handle"; return GNDT_ERR_INVALID; }
     if (h->h_cnt->err_key_range) { h->err = std::to_string(h->h_cnt->err_key_range) + " point(s) outside the key range"; return GNDT_ERR_KEY_RANGE; }
     ncols_host = h->h_cnt->num_columns;
-    if ((rc = grow_buf(h, X.pairs, X.pairs_cap, std::max<uint64_t>(ncols_host, 1)))) return rc;
-    if (!X.d_npairs) HIP_TRY(h, hipMalloc(&X.d_npairs, 2 * sizeof(uint32_t)));
-    HIP_TRY(h, hipMemsetAsync(X.d_npairs, 0, 2 * sizeof(uint32_t), s));
-    hipLaunchKernelGGL(k_owned_columns, dim3(grid_for(std::max<uint64_t>(h->h_cnt->num_nodes, 1))), dim3(256), 0, s, h->out.first_idx, q.row_ncol,
-                       h->d_cnt, X.pairs, (uint32_t)X.pairs_cap, X.d_npairs);
-    HIP_TRY(h, hipGetLastError());
-    return GNDT_OK;
+    return owned_columns_enqueue(h, s);
 }
 
 // everybody's column pairs -> global row of every local row (X.global_row), totals of the whole map in X.d_totals[0..1]
@@ -390,13 +397,13 @@ int global_rows_launch(gndt_handle* h, const unsigned long long* all_pairs, uint
     if (!X.d_npairs) HIP_TRY(h, hipMalloc(&X.d_npairs, 2 * sizeof(uint32_t)));
     if ((rc = grow_buf(h, X.global_row, X.global_row_cap, std::max<uint64_t>(h->h_cnt->num_nodes, 1)))) return rc;
     // the local order is finished (rows emitted): its arrays now take the column order of the WHOLE map
-    HIP_TRY(h, hipMemsetAsync(q.bitmap, 0, words * 4, s));
-    HIP_TRY(h, hipMemsetAsync(q.word_weight, 0, words * 4, s));
-    HIP_TRY(h, hipMemsetAsync(X.d_totals, 0, 2 * sizeof(unsigned long long), s));
-    HIP_TRY(h, hipMemsetAsync(X.d_npairs + 1, 0, sizeof(uint32_t), s));
+    if ((rc = grow_buf(h, X.gw, X.gw_cap, words))) return rc;
+    hipLaunchKernelGGL(k_order_clear, dim3(grid_for(words, 256, 512)), dim3(256), 0, s, X.gw, (uint64_t)words, X.d_totals, X.d_npairs + 1);
     if (n_all)
-        hipLaunchKernelGGL(k_pairs_note, dim3(grid_for(n_all)), dim3(256), 0, s, all_pairs, n_all, ColumnOrder{q.bitmap, q.word_weight, q.ncol_at},
-                           words, X.d_totals, X.d_npairs + 1);
+        hipLaunchKernelGGL(k_pairs_note, dim3((uint32_t)std::min<uint64_t>(1024, (n_all + 255) / 256)), dim3(256), 0, s, all_pairs, n_all,
+                           X.gw, q.ncol_at, words, X.d_totals, X.d_npairs + 1);
+    hipLaunchKernelGGL(k_order_split, dim3(grid_for(words, 256, 512)), dim3(256), 0, s, (const unsigned long long*)X.gw, (uint64_t)words, q.bitmap,
+                       q.word_weight);
     const uint32_t nbw = (uint32_t)((words + kScanChunk - 1) / kScanChunk);
     hipLaunchKernelGGL(k_scan_reduce<false>, dim3(nbw), dim3(kScanThreads), 0, s, q.word_weight, (const uint32_t*)nullptr, (uint32_t)words, q.bsum_words);
     hipLaunchKernelGGL(k_scan_apply<false>, dim3(nbw), dim3(kScanThreads), 0, s, q.word_weight, (const uint32_t*)nullptr, (uint32_t)words, q.bsum_words,
@@ -561,21 +568,33 @@ int gndt_build_owned_device(gndt_handle* h, gndt_comm* c, const void* shard_xyz_
         RCCL_TRY(h, rccl().GroupEnd());
     }
     stamp(2);
-    // 3. the columns this rank owns, finished: the ordinary pipeline on the records
+    // 3. the columns this rank owns, finished: the ordinary pipeline on the records.  The column pairs and every rank's
+    //    (column count, "my build has to be re-run") message follow on the stream: ONE wait for the build and the counts.  If
+    //    some rank's build overflowed, that rank re-runs it and ALL ranks repeat the round (they all saw the same messages).
     if ((rc = build_records(h, X.own_recs, (size_t)n_own, total_points, s))) return rc;
+    if (!X.d_colmsg) HIP_TRY(h, hipMalloc(&X.d_colmsg, kColMsgWords * (size_t)kMaxRanks * sizeof(unsigned long long)));
+    if (!X.h_colmsg) HIP_TRY(h, hipHostMalloc(&X.h_colmsg, kColMsgWords * (size_t)kMaxRanks * sizeof(unsigned long long)));
     uint32_t ncols = 0;
-    if ((rc = owned_columns_launch(h, s, ncols))) return rc;            // (waits for the build: overflow re-runs happen here)
+    uint64_t m_max = 1;
+    for (int round = 0;; ++round) {
+        if ((rc = owned_columns_enqueue(h, s))) return rc;
+        hipLaunchKernelGGL(k_owned_status, dim3(1), dim3(1), 0, s, (const uint32_t*)X.d_npairs, (const PartCounters*)q.d_pc, (const Counters*)h->d_cnt,
+                           (unsigned long long)n_own, X.d_colmsg + kColMsgWords * me);
+        RCCL_TRY(h, rccl().AllGather(X.d_colmsg + kColMsgWords * me, X.d_colmsg, kColMsgWords, ncclUint64, c->nccl, s));
+        HIP_TRY(h, hipMemcpyAsync(X.h_colmsg, X.d_colmsg, kColMsgWords * (size_t)W * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+        if ((rc = partition_resolve(h))) return rc;                    // the wait; this rank's own overflow re-runs happen here
+        bool someone_failed = false;
+        m_max = 1;
+        for (int r = 0; r < W; ++r) {
+            someone_failed = someone_failed || X.h_colmsg[kColMsgWords * r + 1] != 0;
+            m_max = std::max<uint64_t>(m_max, X.h_colmsg[kColMsgWords * r]);
+        }
+        if (!someone_failed) break;
+        if (round >= 8) { h->err = "a rank's build keeps overflowing"; return GNDT_ERR_CAPACITY; }
+    }
+    ncols = h->h_cnt->num_columns;
     stamp(3);
     // 4. everybody's columns -> the global row of every local row
-    if (!X.d_counts) { if ((rc = grow_buf(h, X.d_counts, X.counts_cap, (uint64_t)kMaxRanks))) return rc; }
-    if (!X.h_counts) HIP_TRY(h, hipHostMalloc(&X.h_counts, 1024 * sizeof(unsigned long long)));
-    X.h_counts[me] = ncols;
-    HIP_TRY(h, hipMemcpyAsync(X.d_counts + me, X.h_counts + me, sizeof(unsigned long long), hipMemcpyHostToDevice, s));
-    RCCL_TRY(h, rccl().AllGather(X.d_counts + me, X.d_counts, 1, ncclUint64, c->nccl, s));
-    HIP_TRY(h, hipMemcpyAsync(X.h_counts, X.d_counts, (size_t)W * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
-    HIP_TRY(h, hipStreamSynchronize(s));
-    uint64_t m_max = 1;
-    for (int r = 0; r < W; ++r) m_max = std::max<uint64_t>(m_max, X.h_counts[r]);
     if (m_max > X.pairs_cap) {                          // (another rank owns more columns: a longer send buffer, contents kept)
         unsigned long long* bigger = nullptr;
         HIP_TRY(h, hipMalloc(&bigger, m_max * sizeof(unsigned long long)));
@@ -588,18 +607,20 @@ int gndt_build_owned_device(gndt_handle* h, gndt_comm* c, const void* shard_xyz_
     if ((rc = grow_buf(h, X.pairs_all, X.pairs_all_cap, m_max * (uint64_t)W))) return rc;
     RCCL_TRY(h, rccl().AllGather(X.pairs, X.pairs_all, (size_t)m_max, ncclUint64, c->nccl, s));
     if ((rc = global_rows_launch(h, X.pairs_all, m_max * (uint64_t)W, total_points, s))) return rc;
-    // slopes and owned points of the whole map
-    X.h_totals[2] = h->h_cnt->num_slopes; X.h_totals[3] = n_own;
-    HIP_TRY(h, hipMemcpyAsync(X.d_totals + 2, X.h_totals + 2, 2 * sizeof(unsigned long long), hipMemcpyHostToDevice, s));
-    RCCL_TRY(h, rccl().AllReduce(X.d_totals + 2, X.d_totals + 2, 2, ncclUint64, ncclSum, c->nccl, s));
     uint32_t bad = 0;
-    HIP_TRY(h, hipMemcpyAsync(X.h_totals, X.d_totals, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+    HIP_TRY(h, hipMemcpyAsync(X.h_totals, X.d_totals, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
     HIP_TRY(h, hipMemcpyAsync(&bad, X.d_npairs + 1, sizeof bad, hipMemcpyDeviceToHost, s));
     stamp(4);
     HIP_TRY(h, hipStreamSynchronize(s));
     if (bad) { h->err = std::to_string(bad) + " column pair(s) with an index beyond total_points"; return GNDT_ERR_INVALID; }
     if (split_rc) { h->err = split_err; return split_rc; }
+    if (h->h_cnt->err_key_range) {          // (a z level beyond the key range: found by the build; reported now, after the collectives)
+        h->err = std::to_string(h->h_cnt->err_key_range) + " point(s) outside the key range";
+        return GNDT_ERR_KEY_RANGE;
+    }
     if (global_row_dev) *global_row_dev = X.global_row;
+    X.h_totals[2] = 0;                                    // slopes of the whole map: every rank's share came with its column message
+    for (int r = 0; r < W; ++r) X.h_totals[2] += X.h_colmsg[kColMsgWords * r + 2];
     if (info) {
         float t[4] = {0, 0, 0, 0};
         for (int i = 0; i < 4; ++i) (void)hipEventElapsedTime(&t[i], ev[i], ev[i + 1]);

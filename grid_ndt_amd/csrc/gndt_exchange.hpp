@@ -201,46 +201,99 @@ static __global__ void __launch_bounds__(256) k_owner_pick(const uint32_t* __res
     }
 }
 
-// the columns of the local map: (first-seen index of the column, its node count), in any order
+// the columns of the local map: (first-seen index of the column, its node count), in any order.  A workgroup takes a chunk
+// of kColChunk rows: it counts the chunk's column heads, reserves their places with ONE memory-side atomic (a per-wave
+// atomic on the single counter word serialises: 26 k of them cost 0.3 ms on a 1.7 M-row map) and writes them out.
+constexpr uint32_t kColChunk = 4096;
 static __global__ void __launch_bounds__(256) k_owned_columns(const uint32_t* __restrict__ first_idx, const uint32_t* __restrict__ row_ncol,
-                                                              const Counters* __restrict__ cnt, unsigned long long* __restrict__ pairs,
+                                                              const Counters* __restrict__ cnt, const PartCounters* __restrict__ pc,
+                                                              unsigned long long* __restrict__ pairs,
                                                               uint32_t pairs_cap, uint32_t* __restrict__ n_pairs) {
+    if (pc->lds_overflow | pc->stage_overflow | pc->index_overflow | pc->part_overflow) return;   // the build is re-run: no rows yet
+    __shared__ uint32_t heads, base, cursor;
     const uint32_t n = cnt->num_nodes;
-    const uint32_t n_round = (n + 63u) & ~63u;
-    for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < n_round; r += gridDim.x * blockDim.x) {
-        const uint32_t nc = r < n ? row_ncol[r] : 0u;
-        const unsigned long long m = __ballot(nc != 0u);
-        if (!m) continue;
-        const int lane = threadIdx.x & 63, leader = (int)__builtin_ctzll(m);
-        uint32_t base = 0;
-        if (lane == leader) base = atomicAdd(n_pairs, (uint32_t)__popcll(m));
-        base = (uint32_t)__shfl((int)base, leader, 64);
-        if (nc) {
-            const uint32_t pos = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-            if (pos < pairs_cap) pairs[pos] = ((unsigned long long)first_idx[r] << 32) | nc;
+    const int lane = threadIdx.x & 63;
+    for (uint32_t c0 = blockIdx.x * kColChunk; c0 < n; c0 += gridDim.x * kColChunk) {
+        if (threadIdx.x == 0) { heads = 0; cursor = 0; }
+        __syncthreads();
+        uint32_t mine = 0;
+        for (uint32_t r = c0 + threadIdx.x; r < min(c0 + kColChunk, n); r += 256) mine += row_ncol[r] != 0u ? 1u : 0u;
+        for (int off = 32; off > 0; off >>= 1) mine += (uint32_t)__shfl_down((int)mine, off, 64);
+        if (lane == 0 && mine) atomicAdd(&heads, mine);
+        __syncthreads();
+        if (threadIdx.x == 0) base = heads ? atomicAdd(n_pairs, heads) : 0u;
+        __syncthreads();
+        for (uint32_t r0 = c0; r0 < min(c0 + kColChunk, n); r0 += 256) {          // (uniform trip count: whole waves reach the ballot)
+            const uint32_t r = r0 + threadIdx.x;
+            const uint32_t nc = r < n && r < c0 + kColChunk ? row_ncol[r] : 0u;
+            const unsigned long long m = __ballot(nc != 0u);
+            if (!m) continue;
+            uint32_t wbase = 0;
+            if (lane == 0) wbase = atomicAdd(&cursor, (uint32_t)__popcll(m));
+            wbase = (uint32_t)__shfl((int)wbase, 0, 64);
+            if (nc) {
+                const uint32_t pos = base + wbase + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                if (pos < pairs_cap) pairs[pos] = ((unsigned long long)first_idx[r] << 32) | nc;
+            }
         }
+        __syncthreads();
     }
+}
+
+// what a rank tells the others before the pairs travel: how many it has, and whether its build has to be re-run first
+// (and its share of the whole map's totals, so that no further collective is needed for them)
+constexpr int kColMsgWords = 4;
+static __global__ void k_owned_status(const uint32_t* __restrict__ n_pairs, const PartCounters* __restrict__ pc, const Counters* __restrict__ cnt,
+                                      unsigned long long owned_points, unsigned long long* __restrict__ msg) {
+    msg[0] = *n_pairs;
+    msg[1] = (pc->lds_overflow | pc->stage_overflow | pc->index_overflow | pc->part_overflow) ? 1ull : 0ull;
+    msg[2] = cnt->num_slopes;
+    msg[3] = owned_points;
 }
 
 static __global__ void __launch_bounds__(256) k_pairs_pad(unsigned long long* __restrict__ pairs, uint32_t have, uint32_t padded) {
     for (uint32_t i = have + blockIdx.x * blockDim.x + threadIdx.x; i < padded; i += gridDim.x * blockDim.x) pairs[i] = kNoPair;
 }
 
-// everybody's columns into the column-order arrays (cleared before)
-static __global__ void __launch_bounds__(256) k_pairs_note(const unsigned long long* __restrict__ pairs, uint64_t n, ColumnOrder O,
+// Everybody's columns into the column order of the WHOLE map.  A column costs ONE memory-side atomic here (they retire at
+// ~20 G/s chip-wide, and S3 has 4 M columns): bit and weight of its bitmap word are the two halves of one 64-bit word (a bit
+// is set once, so add = or), split into the arrays the prefix and the row kernels read afterwards.
+static __global__ void __launch_bounds__(256) k_order_clear(unsigned long long* __restrict__ gw, uint64_t words,
+                                                            unsigned long long* __restrict__ totals, uint32_t* __restrict__ bad) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < words; i += (uint64_t)gridDim.x * blockDim.x) gw[i] = 0ull;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { totals[0] = 0ull; totals[1] = 0ull; *bad = 0u; }
+}
+
+// node and column totals of the whole map are summed per workgroup first (one pair of memory-side atomics per workgroup)
+static __global__ void __launch_bounds__(256) k_pairs_note(const unsigned long long* __restrict__ pairs, uint64_t n,
+                                                           unsigned long long* __restrict__ gw, uint32_t* __restrict__ ncol_at,
                                                            uint64_t words, unsigned long long* __restrict__ totals, uint32_t* __restrict__ bad) {
+    __shared__ unsigned long long s_nodes, s_cols;
+    if (threadIdx.x == 0) { s_nodes = 0ull; s_cols = 0ull; }
+    __syncthreads();
     unsigned long long nodes = 0, cols = 0;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
         const unsigned long long pr = pairs[i];
         if (pr == kNoPair) continue;
         const uint32_t cf = (uint32_t)(pr >> 32), nc = (uint32_t)pr;
         if ((uint64_t)(cf >> 5) >= words) { atomicAdd(bad, 1u); continue; }
-        note_column(O, cf, nc);
+        atomicAdd(&gw[cf >> 5], ((unsigned long long)nc << 32) | (1ull << (cf & 31u)));
+        ncol_at[cf] = nc;
         nodes += nc; ++cols;
     }
     nodes = (unsigned long long)wave_sum((double)nodes);      // (exact: far below 2^53)
     cols = (unsigned long long)wave_sum((double)cols);
-    if ((threadIdx.x & 63) == 0 && cols) { atomicAdd(&totals[0], nodes); atomicAdd(&totals[1], cols); }
+    if ((threadIdx.x & 63) == 0 && cols) { atomicAdd(&s_nodes, nodes); atomicAdd(&s_cols, cols); }
+    __syncthreads();
+    if (threadIdx.x == 0 && s_cols) { atomicAdd(&totals[0], s_nodes); atomicAdd(&totals[1], s_cols); }
+}
+
+static __global__ void __launch_bounds__(256) k_order_split(const unsigned long long* __restrict__ gw, uint64_t words,
+                                                            uint32_t* __restrict__ bitmap, uint32_t* __restrict__ word_weight) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < words; i += (uint64_t)gridDim.x * blockDim.x) {
+        const unsigned long long v = gw[i];
+        bitmap[i] = (uint32_t)v; word_weight[i] = (uint32_t)(v >> 32);
+    }
 }
 
 // row of every local row in the map of the whole cloud: the column's position from the global column order, then the nodes

@@ -134,6 +134,8 @@ struct gndt_handle {
         gndt::Counters* d_split_cnt = nullptr;  gndt::Counters* h_split_cnt = nullptr;
         unsigned long long* pairs = nullptr; uint64_t pairs_cap = 0;  unsigned long long* pairs_all = nullptr; uint64_t pairs_all_cap = 0;
         uint32_t* d_npairs = nullptr;  uint32_t* global_row = nullptr; uint64_t global_row_cap = 0;
+        unsigned long long* gw = nullptr; uint64_t gw_cap = 0;                                   // bitmap word + weight, packed (k_pairs_note)
+        unsigned long long* d_colmsg = nullptr;  unsigned long long* h_colmsg = nullptr;         // [2 x ranks] column count, build failed
         unsigned long long* d_totals = nullptr;  unsigned long long* h_totals = nullptr;          // [4] nodes, columns, slopes, points
         uint64_t send_off[1025] = {};   // host: start of every owner's records in send_recs (after gndt_owner_split_device)
         // locality-aware ownership (gndt_exchange.hpp): this rank's sample message, everybody's, the block table

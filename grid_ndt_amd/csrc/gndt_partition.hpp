@@ -441,7 +441,6 @@ __global__ void __launch_bounds__(kTileThreads) __attribute__((amdgpu_waves_per_
     // in LDS and copied out (the kernel is latency-bound: ~70 % of a wave's life is spent parked on waits).
     const uint64_t ntiles = (n + (uint64_t)kTileThreads * PER - 1) / ((uint64_t)kTileThreads * PER);
     float nx[PER], ny[PER], nz[PER];
-    uint32_t nw[IDXW ? PER : 1];                   // IDXW: the input is 16-B records whose 4th word is the index word (taken as it is)
     auto load_tile = [&](uint64_t tile) {
         const uint64_t t0 = tile * (kTileThreads * PER);
         const float* __restrict__ base = xyz + t0 * STRIDE_FLOATS;            // uniform: the 64-bit arithmetic stays scalar
@@ -450,10 +449,7 @@ __global__ void __launch_bounds__(kTileThreads) __attribute__((amdgpu_waves_per_
         for (int j = 0; j < PER; ++j) {
             const uint32_t i = (uint32_t)(j * kTileThreads) + threadIdx.x;     // a wave holds 64 consecutive points
             nx[j] = 0.f; ny[j] = 0.f; nz[j] = 0.f;
-            if (i < have) {
-                const float* p = base + i * (uint32_t)STRIDE_FLOATS; nx[j] = p[0]; ny[j] = p[1]; nz[j] = p[2];
-                if constexpr (IDXW) nw[j] = __float_as_uint(p[3]);
-            }
+            if (i < have) { const float* p = base + i * (uint32_t)STRIDE_FLOATS; nx[j] = p[0]; ny[j] = p[1]; nz[j] = p[2]; }
         }
     };
     uint64_t tile = blockIdx.x;
@@ -462,9 +458,20 @@ __global__ void __launch_bounds__(kTileThreads) __attribute__((amdgpu_waves_per_
         const uint64_t t0 = tile * (kTileThreads * PER);
         const uint32_t rep = (uint32_t)(tile % R);
         float cx[PER], cy[PER], cz[PER];
+        // IDXW: the input is 16-B records whose 4th word is the index word (taken as it is).  It is not prefetched with the
+        // coordinates (eight more registers per tile in flight): its line arrived with them and is read when the tile is taken up.
         uint32_t cw[IDXW ? PER : 1];
 #pragma unroll
-        for (int j = 0; j < PER; ++j) { cx[j] = nx[j]; cy[j] = ny[j]; cz[j] = nz[j]; if constexpr (IDXW) cw[j] = nw[j]; }
+        for (int j = 0; j < PER; ++j) { cx[j] = nx[j]; cy[j] = ny[j]; cz[j] = nz[j]; }
+        if constexpr (IDXW) {
+            const float* __restrict__ base = xyz + t0 * STRIDE_FLOATS;
+            const uint32_t have = (uint32_t)min((uint64_t)(kTileThreads * PER), n - t0);
+#pragma unroll
+            for (int j = 0; j < PER; ++j) {
+                const uint32_t i = (uint32_t)(j * kTileThreads) + threadIdx.x;
+                cw[j] = i < have ? __float_as_uint(base[i * (uint32_t)STRIDE_FLOATS + 3]) : 0u;
+            }
+        }
         if (tile + gridDim.x < ntiles) load_tile(tile + gridDim.x);
         // All 512 points this wave holds in the tile bit-identical (a stretch of the converters' zero padding)?  Then they go
         // out as ONE record of weight 512 instead of eight of weight 64: the bucket that collects the padding gets 8x fewer.
