@@ -26,6 +26,12 @@
 
 namespace gndt {
 
+#ifndef GNDT_DIRECT_SUBSTAMPS
+#define GNDT_DIRECT_SUBSTAMPS 0      // diagnostic build: wave 0's waits inside the accumulate loop (bench.py --stamps: acc:0..3)
+#endif
+#ifndef GNDT_DIRECT_PREFETCH2
+#define GNDT_DIRECT_PREFETCH2 0
+#endif
 #ifndef GNDT_DIRECT_WAVES
 #define GNDT_DIRECT_WAVES 5      // waves per SIMD the register allocation aims at (512-slot variant): 5 = 96 VGPRs, no spills
 #endif
@@ -93,19 +99,42 @@ __device__ __forceinline__ void bucket_direct_one(BucketLds3<H>& L, const uint32
     // with one set of atomics.  The records of the next iteration are loaded while this one is keyed and accumulated;
     // out-of-range lanes re-read the bucket's last record instead of branching around the load.
     float4 nxt[U];
+#if GNDT_DIRECT_PREFETCH2
+    float4 nxt2[U];                                  // two iterations ahead (a bucket is ~3 iterations: the loads of all of them are in flight early)
+#endif
     if (lo < hi) {
 #pragma unroll
         for (int j = 0; j < U; ++j) nxt[j] = recs[min(lo + (uint32_t)(U * tid + j), hi - 1u)];
+#if GNDT_DIRECT_PREFETCH2
+#pragma unroll
+        for (int j = 0; j < U; ++j) nxt2[j] = recs[min(lo + (uint32_t)(U * T + U * tid + j), hi - 1u)];
+#endif
     }
+#if GNDT_DIRECT_SUBSTAMPS
+    unsigned long long st_acc[4] = {0ull, 0ull, 0ull, 0ull};     // diagnostics (dbg): wave 0's waits inside the accumulate loop
+#endif
     for (uint32_t base = lo; base < hi; base += (uint32_t)(U * T)) {
+#if GNDT_DIRECT_SUBSTAMPS
+        unsigned long long st0 = 0ull;
+        if (dbg) st0 = __builtin_amdgcn_s_memtime();
+#endif
         float4 rec[U];
         bool use[U];
 #pragma unroll
         for (int j = 0; j < U; ++j) { rec[j] = nxt[j]; use[j] = base + (uint32_t)(U * tid + j) < hi; }
+#if GNDT_DIRECT_PREFETCH2
+#pragma unroll
+        for (int j = 0; j < U; ++j) nxt[j] = nxt2[j];
+        if (base + (uint32_t)(2 * U * T) < hi) {   // uniform
+#pragma unroll
+            for (int j = 0; j < U; ++j) nxt2[j] = recs[min(base + (uint32_t)(2 * U * T + U * tid + j), hi - 1u)];
+        }
+#else
         if (base + (uint32_t)(U * T) < hi) {       // uniform
 #pragma unroll
             for (int j = 0; j < U; ++j) nxt[j] = recs[min(base + (uint32_t)(U * T + U * tid + j), hi - 1u)];
         }
+#endif
         PointKey k[U];
         uint32_t slot[U];
         unsigned long long pkey[U], k0[U];
@@ -120,6 +149,16 @@ __device__ __forceinline__ void bucket_direct_one(BucketLds3<H>& L, const uint32
         if (pair) use[1] = false;
 #pragma unroll
         for (int j = 0; j < U; ++j) k0[j] = L.key[slot[j]];
+#if GNDT_DIRECT_SUBSTAMPS
+        if (dbg) {                     // (a) records arrived and keyed, table reads issued
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const unsigned long long t = __builtin_amdgcn_s_memtime();
+            st_acc[0] += t - st0; st0 = t;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (b) the table reads are back (behind the previous iteration's atomics)
+            const unsigned long long t2 = __builtin_amdgcn_s_memtime();
+            st_acc[1] += t2 - st0; st0 = t2;
+        }
+#endif
         double c[U][9];
         uint32_t cn[U], cf[U];
 #pragma unroll
@@ -165,7 +204,18 @@ __device__ __forceinline__ void bucket_direct_one(BucketLds3<H>& L, const uint32
                 atomicMin(&L.first[s], cf[j]);
             }
         }
+#if GNDT_DIRECT_SUBSTAMPS
+        if (dbg) {                     // (c) contributions computed, atomics issued; (d) ... and retired
+            const unsigned long long t = __builtin_amdgcn_s_memtime();
+            st_acc[2] += t - st0; st0 = t;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            st_acc[3] += __builtin_amdgcn_s_memtime() - st0;
+        }
+#endif
     }
+#if GNDT_DIRECT_SUBSTAMPS
+    if (dbg && tid == 0) { for (int k = 0; k < 4; ++k) dbg[(size_t)bucket * 16 + 8 + k] = st_acc[k]; }
+#endif
     __syncthreads();
     GNDT_STAMP3(2);
     const uint32_t M = L.n_nodes;
