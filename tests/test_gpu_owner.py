@@ -188,3 +188,24 @@ def test_owner_build_with_torch_distributed_as_the_transport():
         assert np.array_equal(grow.cpu().numpy(), np.arange(out["num_nodes"]))
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n,W", [(1, 2), (7, 4), (300, 8), (5000, 3)])
+def test_owner_build_of_tiny_clouds_with_ranks_that_own_nothing(n, W):
+    """Fewer points than ranks, ranks whose shard or whose set of owned columns is empty, 16-byte input points, demand "true"."""
+    rng = np.random.default_rng(n)
+    cloud = np.concatenate([np.float32([[0.1, 0.2, 0.3]]), (rng.random((n, 3)) * [6, 6, 0.4]).astype(np.float32)], 0)
+    P = dict(grid_len=0.5, z_len=0.1, slope_interval=0.08, demand="true")
+    ref = parity.ref_from_cloud(cloud, P)
+    for locality in (False, True):
+        glob, info = owner_build_on_one_gpu(cloud, P, W, locality=locality)
+        parity.assert_parity(glob, ref, demand="true", adversarial=True)
+    # the same through padded 16-byte points (pcl::PointXYZ)
+    import torch
+    maps = _ranks(cloud, P, 1)
+    pts16 = torch.zeros((n, 4), dtype=torch.float32, device="cuda")
+    pts16[:, :3] = torch.from_numpy(cloud[1:]).cuda()
+    pts16[:, 3] = float("nan")                                    # the padding word is never read
+    recs, cnt = maps[0].owner_split("true", pts16, 0, n, 1)
+    maps[0].build_records("true", recs.clone(), n)
+    parity.assert_parity(maps[0].export(), ref, demand="true", adversarial=True)
