@@ -60,7 +60,7 @@ constexpr uint64_t kMaxBuckets = 32768;   // 4-byte LDS cursor per bucket in the
 // flags; no host wait.  Returns GNDT_OK, an error, or -1 when the partition path cannot hold this input.
 int partition_launch(gndt_handle* h, gndt_handle::Pending& P) {
     auto& q = h->part;
-    const size_t n = P.n, stride_bytes = P.stride;
+    const size_t n = P.n + P.n2, stride_bytes = P.stride;       // (n2: the second segment of a records build)
     hipStream_t s = P.s;
     const int attempt = P.attempt;
     uint64_t& nodes_est = P.nodes_est;
@@ -75,6 +75,7 @@ int partition_launch(gndt_handle* h, gndt_handle::Pending& P) {
     const uint32_t part_mode = P.records ? kPartModeRecords : 0u;
     const GridParams gp = P.gp;                        // as they were at launch (a retry must not pick up a new origin)
     const float* p = static_cast<const float*>(P.xyz);
+    const float* p2 = static_cast<const float*>(P.xyz2);
     // table size and bucket count for this attempt: 512-slot tables unless that needs too many buckets
     // attempt 0: 512-slot tables; an overflow first doubles the table (same estimate), then raises the estimate
     int bslots = env_slots ? env_slots : (attempt == 0 ? 512 : 1024);
@@ -151,16 +152,22 @@ int partition_launch(gndt_handle* h, gndt_handle::Pending& P) {
                            q.cursors, (uint32_t)(kMaxFan + 2 * B));
         HIP_TRY(h, hipGetLastError());
         mark(h, 1, s);
-        const uint32_t tiles1 = (uint32_t)((n + kTile1 - 1) / kTile1);
+        const uint32_t tiles1 = (uint32_t)((P.n + kTile1 - 1) / kTile1), tiles1b = (uint32_t)((P.n2 + kTile1 - 1) / kTile1);
         const uint32_t l1_wgs = tuning().l1_wgs;   // persistent workgroups (2 resident per CU)
         const bool wide = std::max(V, F2) > 256;           // LDS arrays for a fan-out of 512 (fewer resident tiles) only when needed
-        const dim3 g1(std::min<uint32_t>(tiles1, l1_wgs)), g2((uint32_t)((cap1 + kTile2 - 1) / kTile2), V);
+        const dim3 g1(std::max<uint32_t>(1, std::min<uint32_t>(tiles1, l1_wgs))), g1b(std::max<uint32_t>(1, std::min<uint32_t>(tiles1b, l1_wgs))),
+            g2((uint32_t)((cap1 + kTile2 - 1) / kTile2), V);
 #define GNDT_L1(SF_, FAN_)                                                                                                  \
     hipLaunchKernelGGL((k_part2_level1<SF_, FAN_>), g1, dim3(kTileThreads), 0, s, p, (uint64_t)n, P.first_base, gp, B, F1, F2_shift, \
                        R, cursor1, cap1, est2, q.recs1, h->d_cnt, q.d_pc, compress)
+        // records: the two segments one after the other into the same regions (the cursors carry on)
 #define GNDT_L1R(FAN_)                                                                                                      \
-    hipLaunchKernelGGL((k_part2_level1<4, FAN_, true>), g1, dim3(kTileThreads), 0, s, p, (uint64_t)n, P.first_base, gp, B, F1,   \
-                       F2_shift, R, cursor1, cap1, est2, q.recs1, h->d_cnt, q.d_pc, compress)
+    do {                                                                                                                    \
+        if (P.n) hipLaunchKernelGGL((k_part2_level1<4, FAN_, true>), g1, dim3(kTileThreads), 0, s, p, (uint64_t)P.n, P.first_base, gp, B, F1, \
+                                    F2_shift, R, cursor1, cap1, est2, q.recs1, h->d_cnt, q.d_pc, compress);                 \
+        if (P.n2) hipLaunchKernelGGL((k_part2_level1<4, FAN_, true>), g1b, dim3(kTileThreads), 0, s, p2, (uint64_t)P.n2, P.first_base, gp, B, \
+                                     F1, F2_shift, R, cursor1, cap1, est2, q.recs1, h->d_cnt, q.d_pc, compress);            \
+    } while (0)
         if (P.records) { if (wide) GNDT_L1R(512); else GNDT_L1R(256); }
         else if (stride_bytes == 12) { if (wide) GNDT_L1(3, 512); else GNDT_L1(3, 256); }
         else { if (wide) GNDT_L1(4, 512); else GNDT_L1(4, 256); }
@@ -183,6 +190,10 @@ int partition_launch(gndt_handle* h, gndt_handle::Pending& P) {
         mark(h, 4, s);
         range_lo = q.range_lo; range_hi = q.range_hi;
     } else {
+    if (P.n2) {                    // one array for the counting partition: the first segment goes into the room in front of the second
+        p = p2 - 4 * P.n;
+        if (P.n) HIP_TRY(h, hipMemcpyAsync(const_cast<float*>(p), P.xyz, P.n * 16, hipMemcpyDeviceToDevice, s));
+    }
     if ((rc = grow_buf(h, q.recs, q.rec_cap, n))) return rc;
     if ((rc = grow_buf(h, q.hist, q.hist_cap, (uint64_t)nwg * B))) return rc;
     if (B > q.bucket_cap) {
@@ -282,18 +293,22 @@ int partition_launch(gndt_handle* h, gndt_handle::Pending& P) {
 
 // Start a PARTITION build (attempt 0) and leave it pending.  `records`: the input is 16-B records {x, y, z, index word} whose
 // index words (point indices below `index_range`, weight flags included) are taken as they are (gndt_build_records_device).
-int partition_begin(gndt_handle* h, const void* xyz_dev, size_t n, size_t stride_bytes, hipStream_t s, bool records, uint64_t index_range) {
+int partition_begin(gndt_handle* h, const void* xyz_dev, size_t n, size_t stride_bytes, hipStream_t s, bool records, uint64_t index_range,
+                    const void* records2, size_t n2) {
     auto& q = h->part;
     if (stride_bytes != 12 && stride_bytes != 16) { h->err = "stride_bytes must be 12 or 16"; return GNDT_ERR_INVALID; }
     if (records && stride_bytes != 16) { h->err = "records are 16 bytes"; return GNDT_ERR_INVALID; }
+    if (n2 && !records) { h->err = "a second segment needs records"; return GNDT_ERR_INVALID; }
+    const size_t n_first = n;
+    n += n2;                           // (sizes below are those of the whole input)
     if (n >= 0x7FFFFFFFull || index_range >= 0x7FFFFFFFull) return -1;   // bit 31 of the record index word carries the weight flag: atomic path beyond 2^31 points
     int rc;
     if ((rc = ensure_words(h, ((index_range ? (size_t)index_range : n) + 31) / 32 + 1))) return rc;
     if ((rc = ensure_part_counters(h))) return rc;
     auto& P = h->pending;
     P = gndt_handle::Pending{};
-    P.xyz = xyz_dev; P.n = n; P.stride = stride_bytes; P.s = s; P.attempt = 0;
-    P.records = records; P.index_range = index_range;
+    P.xyz = xyz_dev; P.n = n_first; P.stride = stride_bytes; P.s = s; P.attempt = 0;
+    P.records = records; P.index_range = index_range; P.xyz2 = records2; P.n2 = n2;
     P.gp = grid_params(h);
     // What the last build of a cloud of this size needed (larger tables, a doubled estimate) is where this one starts: without
     // it every build of such a cloud would first fail with the small tables and be run twice.
@@ -358,7 +373,7 @@ int partition_resolve(gndt_handle* h) {
             // without a hint guesses n / 4 nodes: its failure says nothing about the cloud)
             const bool est_was_fine = P.est_reliable && P.est0 >= (uint64_t)h->h_cnt->num_nodes;
             q.good_slots = (P.bslots == 1024 && !est_was_fine) ? 0 : P.bslots;
-            q.good_est = P.nodes_est; q.good_n = P.n;
+            q.good_est = P.nodes_est; q.good_n = P.n + P.n2;
             if (!P.stats_only) {
                 h->results_valid = true;
                 ++h->result_serial;

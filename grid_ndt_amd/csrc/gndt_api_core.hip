@@ -243,6 +243,8 @@ void gndt_destroy(gndt_handle* h) {
         if (X.h_split_cnt) (void)hipHostFree(X.h_split_cnt);
         if (X.h_totals) (void)hipHostFree(X.h_totals);
         if (X.h_colmsg) (void)hipHostFree(X.h_colmsg);
+        if (X.h_bad) (void)hipHostFree(X.h_bad);
+        for (auto& e : X.ev) if (e) (void)hipEventDestroy(e);
     }
     if (h->xstream_ev) (void)hipEventDestroy(h->xstream_ev);
     if (h->d_sample) (void)hipFree(h->d_sample);

@@ -162,8 +162,8 @@ int gndt_build_global_device(gndt_handle* h, gndt_comm* c, const void* shard_xyz
     if (!c || !c->nccl) { h->err = "no communicator"; return GNDT_ERR_INVALID; }
     hipStream_t s = stream_of(h, hip_stream);
     auto& X = h->exch;
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
-    if (times) for (auto& e : ev) HIP_TRY(h, hipEventCreate(&e));
+    hipEvent_t* ev = X.ev;                     // (kept on the handle: an early error return leaks nothing)
+    if (times) for (int i = 0; i < 4; ++i) if (!ev[i]) HIP_TRY(h, hipEventCreate(&ev[i]));
     auto stamp = [&](int i) { if (times) (void)hipEventRecord(ev[i], s); };
     stamp(0);
     // 1. this rank's shard -> statistics of its occupied nodes (the partition pipeline's statistics epilogue)
@@ -242,7 +242,6 @@ int gndt_build_global_device(gndt_handle* h, gndt_comm* c, const void* shard_xyz
         times->shard_ms = a; times->exchange_ms = b; times->finalize_ms = d;
         times->local_nodes = m; times->global_nodes = C; times->ranks = (uint32_t)W;
         times->bytes_reduced = (uint64_t)C * (kExWidth * 8 + 4);
-        for (auto& e : ev) (void)hipEventDestroy(e);
     }
     return GNDT_OK;
 }
@@ -351,11 +350,12 @@ int owner_split_finish(gndt_handle* h, uint32_t W) {        // (after the stream
 }
 
 // the records this rank owns -> its map (launched, not awaited)
-int build_records(gndt_handle* h, const void* recs, size_t n, uint64_t total_points, hipStream_t s) {
+// (`recs2`: a second segment, preceded in its allocation by room for the first: gndt_handle::Pending)
+int build_records(gndt_handle* h, const void* recs, size_t n, uint64_t total_points, hipStream_t s, const void* recs2 = nullptr, size_t n2 = 0) {
     h->pending.active = false;
     { const int urc = use_stream(h, s); if (urc) return urc; }
     next_event_set(h);
-    const int rc = partition_begin(h, recs, n, 16, s, true, std::max<uint64_t>(total_points, 1));
+    const int rc = partition_begin(h, recs, n, 16, s, true, std::max<uint64_t>(total_points, 1), recs2, n2);
     if (rc == -1) { h->err = "the records do not fit the partition pipeline"; return GNDT_ERR_CAPACITY; }
     return rc;
 }
@@ -473,6 +473,14 @@ int gndt_build_records_device(gndt_handle* h, const void* records_dev, size_t n_
     return build_records(h, records_dev, n_records, total_points, stream_of(h, hip_stream));
 }
 
+int gndt_build_records2_device(gndt_handle* h, const void* first_dev, size_t n_first, void* second_dev, size_t n_second,
+                               uint64_t total_points, void* hip_stream) {
+    int rc = check_ready(h);
+    if (rc) return rc;
+    if ((!first_dev && n_first) || (!second_dev && n_second)) { h->err = "null input"; return GNDT_ERR_INVALID; }
+    return build_records(h, first_dev, n_first, total_points, stream_of(h, hip_stream), second_dev, n_second);
+}
+
 int gndt_owned_columns_device(gndt_handle* h, const uint64_t** pairs_dev, uint64_t* n_pairs, void* hip_stream) {
     int rc = check_ready(h);
     if (rc) return rc;
@@ -498,10 +506,11 @@ int gndt_owned_global_rows_device(gndt_handle* h, const uint64_t* all_pairs_dev,
     if (!h->results_valid || h->map_in_table) { h->err = "no finished PARTITION build on this handle"; return GNDT_ERR_INVALID; }
     auto& X = h->exch;
     if ((rc = global_rows_launch(h, reinterpret_cast<const unsigned long long*>(all_pairs_dev), n_all, total_points, s))) return rc;
-    uint32_t bad = 0;
+    if (!X.h_bad) HIP_TRY(h, hipHostMalloc(&X.h_bad, sizeof(uint32_t)));
     HIP_TRY(h, hipMemcpyAsync(X.h_totals, X.d_totals, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
-    HIP_TRY(h, hipMemcpyAsync(&bad, X.d_npairs + 1, sizeof bad, hipMemcpyDeviceToHost, s));
+    HIP_TRY(h, hipMemcpyAsync(X.h_bad, X.d_npairs + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     HIP_TRY(h, hipStreamSynchronize(s));
+    const uint32_t bad = *X.h_bad;
     if (bad) { h->err = std::to_string(bad) + " column pair(s) with an index beyond total_points"; return GNDT_ERR_INVALID; }
     *global_row_dev = X.global_row;
     if (global_nodes) *global_nodes = X.h_totals[0];
@@ -523,8 +532,8 @@ int gndt_build_owned_device(gndt_handle* h, gndt_comm* c, const void* shard_xyz_
     { const int urc = use_stream(h, s); if (urc) return urc; }
     auto& q = h->part;
     auto& X = h->exch;
-    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-    if (info) for (auto& e : ev) HIP_TRY(h, hipEventCreate(&e));
+    hipEvent_t* ev = X.ev;                     // (kept on the handle: an early error return leaks nothing)
+    if (info) for (int i = 0; i < 5; ++i) if (!ev[i]) HIP_TRY(h, hipEventCreate(&ev[i]));
     auto stamp = [&](int i) { if (info) (void)hipEventRecord(ev[i], s); };
     stamp(0);
     // 0. who owns what: everybody's samples (one fixed-size all-gather, no wait) -> the block table, identical on every rank
@@ -547,15 +556,16 @@ int gndt_build_owned_device(gndt_handle* h, gndt_comm* c, const void* shard_xyz_
     const int split_rc = owner_split_finish(h, (uint32_t)W);
     const std::string split_err = split_rc ? h->err : std::string();
     // 2. the runs themselves
+    // The run this rank keeps stays where the split left it: the build reads two segments (it, and what arrives).  own_recs
+    // holds [room for the kept run | the runs of the other ranks in rank order]; the room is only filled when the build
+    // takes the counting partition, which wants one array.
+    const uint64_t kept = X.send_off[me + 1] - X.send_off[me];
     std::vector<uint64_t> recv_off((size_t)W + 1, 0);
-    for (int r = 0; r < W; ++r) recv_off[r + 1] = recv_off[r] + X.h_matrix[(size_t)r * W + me];      // what rank r holds for me
+    recv_off[0] = kept;
+    for (int r = 0; r < W; ++r) recv_off[r + 1] = recv_off[r] + (r == me ? 0 : X.h_matrix[(size_t)r * W + me]);      // what rank r holds for me
     const uint64_t n_own = recv_off[W];
     if ((rc = grow_buf(h, X.own_recs, X.own_cap, std::max<uint64_t>(n_own, 1)))) return rc;
     uint64_t sent = 0, received = 0;
-    {
-        const uint64_t mine = X.send_off[me + 1] - X.send_off[me];
-        if (mine) HIP_TRY(h, hipMemcpyAsync(X.own_recs + recv_off[me], X.send_recs + X.send_off[me], mine * sizeof(float4), hipMemcpyDeviceToDevice, s));
-    }
     if (W > 1) {
         RCCL_TRY(h, rccl().GroupStart());
         for (int r = 0; r < W; ++r) {
@@ -571,7 +581,7 @@ int gndt_build_owned_device(gndt_handle* h, gndt_comm* c, const void* shard_xyz_
     // 3. the columns this rank owns, finished: the ordinary pipeline on the records.  The column pairs and every rank's
     //    (column count, "my build has to be re-run") message follow on the stream: ONE wait for the build and the counts.  If
     //    some rank's build overflowed, that rank re-runs it and ALL ranks repeat the round (they all saw the same messages).
-    if ((rc = build_records(h, X.own_recs, (size_t)n_own, total_points, s))) return rc;
+    if ((rc = build_records(h, X.send_recs + X.send_off[me], (size_t)kept, total_points, s, X.own_recs + kept, (size_t)(n_own - kept)))) return rc;
     if (!X.d_colmsg) HIP_TRY(h, hipMalloc(&X.d_colmsg, kColMsgWords * (size_t)kMaxRanks * sizeof(unsigned long long)));
     if (!X.h_colmsg) HIP_TRY(h, hipHostMalloc(&X.h_colmsg, kColMsgWords * (size_t)kMaxRanks * sizeof(unsigned long long)));
     uint32_t ncols = 0;
@@ -583,6 +593,7 @@ int gndt_build_owned_device(gndt_handle* h, gndt_comm* c, const void* shard_xyz_
         RCCL_TRY(h, rccl().AllGather(X.d_colmsg + kColMsgWords * me, X.d_colmsg, kColMsgWords, ncclUint64, c->nccl, s));
         HIP_TRY(h, hipMemcpyAsync(X.h_colmsg, X.d_colmsg, kColMsgWords * (size_t)W * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
         if ((rc = partition_resolve(h))) return rc;                    // the wait; this rank's own overflow re-runs happen here
+        HIP_TRY(h, hipStreamSynchronize(s));                           // (a repeated round finds the build resolved already: the messages still have to arrive)
         bool someone_failed = false;
         m_max = 1;
         for (int r = 0; r < W; ++r) {
@@ -607,11 +618,12 @@ int gndt_build_owned_device(gndt_handle* h, gndt_comm* c, const void* shard_xyz_
     if ((rc = grow_buf(h, X.pairs_all, X.pairs_all_cap, m_max * (uint64_t)W))) return rc;
     RCCL_TRY(h, rccl().AllGather(X.pairs, X.pairs_all, (size_t)m_max, ncclUint64, c->nccl, s));
     if ((rc = global_rows_launch(h, X.pairs_all, m_max * (uint64_t)W, total_points, s))) return rc;
-    uint32_t bad = 0;
+    if (!X.h_bad) HIP_TRY(h, hipHostMalloc(&X.h_bad, sizeof(uint32_t)));
     HIP_TRY(h, hipMemcpyAsync(X.h_totals, X.d_totals, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
-    HIP_TRY(h, hipMemcpyAsync(&bad, X.d_npairs + 1, sizeof bad, hipMemcpyDeviceToHost, s));
+    HIP_TRY(h, hipMemcpyAsync(X.h_bad, X.d_npairs + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     stamp(4);
     HIP_TRY(h, hipStreamSynchronize(s));
+    const uint32_t bad = *X.h_bad;
     if (bad) { h->err = std::to_string(bad) + " column pair(s) with an index beyond total_points"; return GNDT_ERR_INVALID; }
     if (split_rc) { h->err = split_err; return split_rc; }
     if (h->h_cnt->err_key_range) {          // (a z level beyond the key range: found by the build; reported now, after the collectives)
@@ -628,7 +640,6 @@ int gndt_build_owned_device(gndt_handle* h, gndt_comm* c, const void* shard_xyz_
         info->owned_points = n_own; info->local_nodes = h->h_cnt->num_nodes; info->local_columns = ncols;
         info->global_nodes = X.h_totals[0]; info->global_columns = X.h_totals[1]; info->global_slopes = X.h_totals[2];
         info->bytes_sent = sent; info->bytes_received = received; info->ranks = (uint32_t)W;
-        for (auto& e : ev) (void)hipEventDestroy(e);
     }
     return GNDT_OK;
 }

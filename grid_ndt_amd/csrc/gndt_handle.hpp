@@ -137,6 +137,8 @@ struct gndt_handle {
         unsigned long long* gw = nullptr; uint64_t gw_cap = 0;                                   // bitmap word + weight, packed (k_pairs_note)
         unsigned long long* d_colmsg = nullptr;  unsigned long long* h_colmsg = nullptr;         // [2 x ranks] column count, build failed
         unsigned long long* d_totals = nullptr;  unsigned long long* h_totals = nullptr;          // [4] nodes, columns, slopes, points
+        hipEvent_t ev[5] = {};          // stage stamps of the sharded builds (created once, reused)
+        uint32_t* h_bad = nullptr;      // pinned: the "pair beyond the index range" counter comes back here
         uint64_t send_off[1025] = {};   // host: start of every owner's records in send_recs (after gndt_owner_split_device)
         // locality-aware ownership (gndt_exchange.hpp): this rank's sample message, everybody's, the block table
         uint32_t* owner_msg = nullptr;  uint32_t* owner_msgs_all = nullptr; uint64_t owner_msgs_cap = 0;
@@ -175,6 +177,8 @@ struct gndt_handle {
         uint32_t first_base = 0;        // global index of xyz[0] (shards of a global cloud)
         bool records = false;           // the input is 16-B records {x, y, z, index word} (owner-partitioned build): the index
         uint64_t index_range = 0;       //   word is taken as it is; point indices then run over [0, index_range) (0: n)
+        const void* xyz2 = nullptr; size_t n2 = 0;   // records only: a second segment, PRECEDED in its allocation by room for the
+                                        //   first one (the exact partition reads one array: the first segment is copied in front)
     } pending;
 
     std::string err;
@@ -292,7 +296,8 @@ int locality_sample(gndt_handle* h, const void* xyz_dev, size_t n, size_t stride
 // ---- gndt_api_build.hip ----
 int launch_order_and_emit(gndt_handle* h, uint64_t words, int m0, hipStream_t s);
 int partition_launch(gndt_handle* h, gndt_handle::Pending& P);
-int partition_begin(gndt_handle* h, const void* xyz_dev, size_t n, size_t stride_bytes, hipStream_t s, bool records = false, uint64_t index_range = 0);
+int partition_begin(gndt_handle* h, const void* xyz_dev, size_t n, size_t stride_bytes, hipStream_t s, bool records = false, uint64_t index_range = 0,
+                    const void* records2 = nullptr, size_t n2 = 0);
 int partition_resolve(gndt_handle* h);
 // ---- gndt_api_cost.hip ----
 void free_cost(gndt_handle* h);

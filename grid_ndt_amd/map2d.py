@@ -331,6 +331,17 @@ class TwoDmap:
                                                       _stream_ptr(stream)))
         self._keep = records
 
+    def build_records2(self, demand, first, room_and_second, total_points, stream=None):
+        """build_records from two segments: `first` [a, 4] stays where it is; `room_and_second` [a + b, 4] holds the second
+        segment in its last b rows (the first a rows are room the small-build path fills)."""
+        self._ensure(demand)
+        a = int(first.shape[0])
+        b = int(room_and_second.shape[0]) - a
+        assert b >= 0 and first.is_contiguous() and room_and_second.is_contiguous()
+        self._check(self._L.gndt_build_records2_device(self._h, C.c_void_p(first.data_ptr()), a, C.c_void_p(room_and_second.data_ptr() + 16 * a), b,
+                                                       int(total_points), _stream_ptr(stream)))
+        self._keep = (first, room_and_second)
+
     def owned_columns(self, stream=None):
         """(first-seen index << 32 | node count) of every column of the local map: int64 device view."""
         import torch

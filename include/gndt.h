@@ -262,6 +262,11 @@ int gndt_owner_map_device(gndt_handle* h, const uint32_t* all_msgs_dev, uint32_t
 int gndt_owner_split_device(gndt_handle* h, const void* shard_xyz_dev, size_t n, size_t stride_bytes, uint64_t first_idx_base,
                             uint64_t total_points, uint32_t world, const void** records_dev, uint64_t* counts_host, void* hip_stream);
 int gndt_build_records_device(gndt_handle* h, const void* records_dev, size_t n_records, uint64_t total_points, void* hip_stream);
+/* The same from TWO segments, so that the run a rank keeps for itself need not be copied next to what it receives: the
+ * second segment must be preceded, in its own allocation, by room for the n_first records of the first (only small builds,
+ * which partition one array, fill that room). */
+int gndt_build_records2_device(gndt_handle* h, const void* first_dev, size_t n_first, void* second_dev, size_t n_second,
+                               uint64_t total_points, void* hip_stream);
 int gndt_owned_columns_device(gndt_handle* h, const uint64_t** pairs_dev, uint64_t* n_pairs, void* hip_stream);
 int gndt_owned_global_rows_device(gndt_handle* h, const uint64_t* all_pairs_dev, uint64_t n_all, uint64_t total_points,
                                   const uint32_t** global_row_dev, uint64_t* global_nodes, uint64_t* global_columns, void* hip_stream);

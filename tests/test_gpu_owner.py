@@ -209,3 +209,52 @@ def test_owner_build_of_tiny_clouds_with_ranks_that_own_nothing(n, W):
     recs, cnt = maps[0].owner_split("true", pts16, 0, n, 1)
     maps[0].build_records("true", recs.clone(), n)
     parity.assert_parity(maps[0].export(), ref, demand="true", adversarial=True)
+
+
+@pytest.mark.parametrize("n", [200_000, 3_000_000])
+def test_records_build_from_two_segments_equals_the_single_array_build(n):
+    """gndt_build_records2_device (what gndt_build_owned_device uses so that the run a rank keeps is not copied): small builds
+    (counting partition: the first segment is copied into the room) and large ones (two level-1 launches into the same regions)."""
+    import torch
+    cloud = scenes.terrain_cloud(n)
+    ref_m, one = parity.gpu_from_cloud(cloud, TERRAIN, on_device=True)
+    m = _ranks(cloud, TERRAIN, 1)[0]
+    pts = torch.from_numpy(np.ascontiguousarray(cloud[1:])).cuda()
+    recs, cnt = m.owner_split("slope", pts, 0, pts.shape[0], 1)
+    recs = recs.clone()
+    for a in (0, 1, recs.shape[0] // 3, recs.shape[0] - 1, recs.shape[0]):
+        first = recs[:a].clone()
+        room_and_second = torch.empty_like(recs)
+        room_and_second[a:] = recs[a:]
+        room_and_second[:a] = float("nan")                        # (never read unless filled by the build itself)
+        m.build_records2("slope", first, room_and_second, pts.shape[0])
+        out = m.export()
+        for k in ("sx", "sy", "sz", "count", "first_idx", "flags"):
+            assert np.array_equal(out[k], one[k]), (a, k)
+        scale = np.abs(one["cov"]).max(axis=1, keepdims=True) + 1e-30
+        assert (np.abs(out["cov"] - one["cov"]) / scale).max() < 1e-5
+
+
+def test_owner_build_whose_local_build_has_to_be_re_run():
+    """A first build without a hint guesses n / 4 nodes; this cloud has more than twice that, so the build inside
+    gndt_build_owned_device overflows, is re-run by the rank that owns it, and the column round is repeated (every rank would
+    repeat it: they all read the "has to be re-run" word of every rank's message)."""
+    import torch
+    from grid_ndt_amd.dist import Communicator
+    rng = np.random.default_rng(5)
+    n = 4_000_000
+    cloud = np.concatenate([np.float32([[0.0, 0.0, 0.0]]),
+                            np.stack([rng.random(n) * 200 - 100, rng.random(n) * 200 - 100, rng.random(n) * 2 - 1], 1).astype(np.float32)], 0)
+    P = dict(grid_len=0.5, z_len=0.1, slope_interval=0.08, demand="slope")
+    _, one = parity.gpu_from_cloud(cloud, P, on_device=True)
+    assert one["num_nodes"] > n // 2
+    comm = Communicator.single()
+    m = _ranks(cloud, P, 1)[0]
+    pts = torch.from_numpy(np.ascontiguousarray(cloud[1:])).cuda()
+    grow, info = m.build_owned(comm, "slope", pts, 0, n)
+    assert m.retry_count() >= 1
+    out = m.export()
+    for k in ("sx", "sy", "sz", "count", "first_idx", "flags"):
+        assert np.array_equal(out[k], one[k]), k
+    assert info["global_nodes"] == one["num_nodes"] and info["global_columns"] == one["num_columns"]
+    assert np.array_equal(grow.cpu().numpy(), np.arange(out["num_nodes"]))
