@@ -210,7 +210,7 @@ def lib():
     L.gndt_owner_sample_device.argtypes = [H, vp, C.c_size_t, C.c_size_t, C.POINTER(vp), C.POINTER(u64), vp]
     L.gndt_owner_map_device.argtypes = [H, vp, C.c_uint32, vp]
     L.gndt_owner_sample_device.restype = L.gndt_owner_map_device.restype = C.c_int
-    L.gndt_owner_split_device.argtypes = [H, vp, C.c_size_t, C.c_size_t, u64, u64, C.c_uint32, C.POINTER(vp), C.POINTER(u64), vp]
+    L.gndt_owner_split_device.argtypes = [H, vp, C.c_size_t, C.c_size_t, u64, u64, C.c_uint32, C.POINTER(vp), C.POINTER(u64), C.POINTER(u64), vp]
     L.gndt_build_records_device.argtypes = [H, vp, C.c_size_t, u64, vp]
     L.gndt_build_records2_device.argtypes = [H, vp, C.c_size_t, vp, C.c_size_t, u64, vp]
     L.gndt_build_records2_device.restype = C.c_int

@@ -159,14 +159,14 @@ int partition_launch(gndt_handle* h, gndt_handle::Pending& P) {
             g2((uint32_t)((cap1 + kTile2 - 1) / kTile2), V);
 #define GNDT_L1(SF_, FAN_)                                                                                                  \
     hipLaunchKernelGGL((k_part2_level1<SF_, FAN_>), g1, dim3(kTileThreads), 0, s, p, (uint64_t)n, P.first_base, gp, B, F1, F2_shift, \
-                       R, cursor1, cap1, est2, q.recs1, h->d_cnt, q.d_pc, compress)
+                       R, cursor1, cap1, est2, q.recs1, h->d_cnt, q.d_pc, compress, OwnerMap{nullptr, nullptr, 0u})
         // records: the two segments one after the other into the same regions (the cursors carry on)
 #define GNDT_L1R(FAN_)                                                                                                      \
     do {                                                                                                                    \
         if (P.n) hipLaunchKernelGGL((k_part2_level1<4, FAN_, true>), g1, dim3(kTileThreads), 0, s, p, (uint64_t)P.n, P.first_base, gp, B, F1, \
-                                    F2_shift, R, cursor1, cap1, est2, q.recs1, h->d_cnt, q.d_pc, compress);                 \
+                                    F2_shift, R, cursor1, cap1, est2, q.recs1, h->d_cnt, q.d_pc, compress, OwnerMap{nullptr, nullptr, 0u}); \
         if (P.n2) hipLaunchKernelGGL((k_part2_level1<4, FAN_, true>), g1b, dim3(kTileThreads), 0, s, p2, (uint64_t)P.n2, P.first_base, gp, B, \
-                                     F1, F2_shift, R, cursor1, cap1, est2, q.recs1, h->d_cnt, q.d_pc, compress);            \
+                                     F1, F2_shift, R, cursor1, cap1, est2, q.recs1, h->d_cnt, q.d_pc, compress, OwnerMap{nullptr, nullptr, 0u}); \
     } while (0)
         if (P.records) { if (wide) GNDT_L1R(512); else GNDT_L1R(256); }
         else if (stride_bytes == 12) { if (wide) GNDT_L1(3, 512); else GNDT_L1(3, 256); }

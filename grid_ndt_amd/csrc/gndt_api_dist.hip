@@ -314,34 +314,60 @@ int owner_split_launch(gndt_handle* h, const void* xyz, size_t n, size_t stride_
         HIP_TRY(h, hipMalloc(&q.bucket_base, ((size_t)W + 1) * 4));
         q.bucket_cap = W;
     }
-    if ((rc = grow_buf(h, X.send_recs, X.send_cap, std::max<uint64_t>(n, 1)))) return rc;
     const GridParams gp = grid_params(h);
     const uint32_t compress = total_points < (uint64_t)kWeightIndexLimit ? 1u : 0u;
     const float* p = static_cast<const float*>(xyz);
-    const size_t lds = (size_t)W * 4;
     // the block table all ranks made from the same samples (owner_map_launch), if it is for this many ranks; else hash ownership
     const OwnerMap M = (X.owner_map_world == W && X.bkey) ? OwnerMap{X.bkey, X.bown, kOwnerSlots - 1u} : OwnerMap{nullptr, nullptr, 0u};
-    if (stride_bytes == 12)
-        hipLaunchKernelGGL(k_part_hist<3>, dim3(nwg), dim3(kPartThreads), lds, s, p, (uint64_t)n, gp, W, q.hist, X.d_split_cnt, compress, kPartModeOwner, M);
-    else
-        hipLaunchKernelGGL(k_part_hist<4>, dim3(nwg), dim3(kPartThreads), lds, s, p, (uint64_t)n, gp, W, q.hist, X.d_split_cnt, compress, kPartModeOwner, M);
-    hipLaunchKernelGGL(k_part_offsets, dim3((W + 31) / 32), dim3(256), 0, s, q.hist, q.totals, W, nwg);
-    if (stride_bytes == 12)
-        hipLaunchKernelGGL(k_part_scatter<3>, dim3(nwg), dim3(kPartThreads), lds, s, p, (uint64_t)n, (uint32_t)first_base, gp, W, q.hist, q.totals,
-                           q.bucket_base, X.send_recs, compress, kPartModeOwner, M);
-    else
-        hipLaunchKernelGGL(k_part_scatter<4>, dim3(nwg), dim3(kPartThreads), lds, s, p, (uint64_t)n, (uint32_t)first_base, gp, W, q.hist, q.totals,
-                           q.bucket_base, X.send_recs, compress, kPartModeOwner, M);
-    HIP_TRY(h, hipGetLastError());
-    uint32_t* h_base = X.h_matrix + (size_t)kMaxRanks * kMaxRanks;
-    HIP_TRY(h, hipMemcpyAsync(h_base, q.bucket_base, ((size_t)W + 1) * 4, hipMemcpyDeviceToHost, s));
+    // ONE pass: level 1 of the partition pipeline with the owner as digit (k_part2_level1<.., OWNER>): owner r's run starts at
+    // r * cap, every run could take the whole shard.  (W x shard records of address space: beyond 2^32, or with more ranks than
+    // the tile sort's fan-out, the two-pass counting partition packs the runs instead.)
+    constexpr uint64_t kTile1 = (uint64_t)kTileThreads * kTilePer1;
+    const uint64_t cap = (uint64_t)n + kTile1;
+    X.split_one_pass = W <= 256 && cap * W < 0xFFFFFFFFull && n >= (1u << 16);
+    if (X.split_one_pass) {
+        if ((rc = grow_buf(h, X.send_recs, X.send_cap, cap * W))) return rc;
+        HIP_TRY(h, hipMemsetAsync(q.totals, 0, (size_t)W * 4, s));          // the runs' cursors = what every owner gets
+        const uint32_t tiles = (uint32_t)((n + kTile1 - 1) / kTile1);
+        const dim3 g1(std::max<uint32_t>(1, std::min<uint32_t>(tiles, tuning().l1_wgs)));
+        if (stride_bytes == 12)
+            hipLaunchKernelGGL((k_part2_level1<3, 256, false, true>), g1, dim3(kTileThreads), 0, s, p, (uint64_t)n, (uint32_t)first_base, gp, W, W, 0u, 1u,
+                               q.totals, (uint32_t)cap, (uint32_t*)nullptr, X.send_recs, X.d_split_cnt, q.d_pc, compress, M);
+        else
+            hipLaunchKernelGGL((k_part2_level1<4, 256, false, true>), g1, dim3(kTileThreads), 0, s, p, (uint64_t)n, (uint32_t)first_base, gp, W, W, 0u, 1u,
+                               q.totals, (uint32_t)cap, (uint32_t*)nullptr, X.send_recs, X.d_split_cnt, q.d_pc, compress, M);
+        HIP_TRY(h, hipGetLastError());
+        X.split_cap = cap;
+        uint32_t* h_base = X.h_matrix + (size_t)kMaxRanks * kMaxRanks;
+        HIP_TRY(h, hipMemcpyAsync(h_base, q.totals, (size_t)W * 4, hipMemcpyDeviceToHost, s));
+    } else {
+        if ((rc = grow_buf(h, X.send_recs, X.send_cap, std::max<uint64_t>(n, 1)))) return rc;
+        const size_t lds = (size_t)W * 4;
+        if (stride_bytes == 12)
+            hipLaunchKernelGGL(k_part_hist<3>, dim3(nwg), dim3(kPartThreads), lds, s, p, (uint64_t)n, gp, W, q.hist, X.d_split_cnt, compress, kPartModeOwner, M);
+        else
+            hipLaunchKernelGGL(k_part_hist<4>, dim3(nwg), dim3(kPartThreads), lds, s, p, (uint64_t)n, gp, W, q.hist, X.d_split_cnt, compress, kPartModeOwner, M);
+        hipLaunchKernelGGL(k_part_offsets, dim3((W + 31) / 32), dim3(256), 0, s, q.hist, q.totals, W, nwg);
+        if (stride_bytes == 12)
+            hipLaunchKernelGGL(k_part_scatter<3>, dim3(nwg), dim3(kPartThreads), lds, s, p, (uint64_t)n, (uint32_t)first_base, gp, W, q.hist, q.totals,
+                               q.bucket_base, X.send_recs, compress, kPartModeOwner, M);
+        else
+            hipLaunchKernelGGL(k_part_scatter<4>, dim3(nwg), dim3(kPartThreads), lds, s, p, (uint64_t)n, (uint32_t)first_base, gp, W, q.hist, q.totals,
+                               q.bucket_base, X.send_recs, compress, kPartModeOwner, M);
+        HIP_TRY(h, hipGetLastError());
+        uint32_t* h_base = X.h_matrix + (size_t)kMaxRanks * kMaxRanks;
+        HIP_TRY(h, hipMemcpyAsync(h_base, q.bucket_base, ((size_t)W + 1) * 4, hipMemcpyDeviceToHost, s));
+    }
     HIP_TRY(h, hipMemcpyAsync(X.h_split_cnt, X.d_split_cnt, sizeof(Counters), hipMemcpyDeviceToHost, s));
     return GNDT_OK;
 }
 int owner_split_finish(gndt_handle* h, uint32_t W) {        // (after the stream has been waited for)
     auto& X = h->exch;
     const uint32_t* h_base = X.h_matrix + (size_t)kMaxRanks * kMaxRanks;
-    for (uint32_t r = 0; r <= W; ++r) X.send_off[r] = h_base[r];
+    for (uint32_t r = 0; r < W; ++r) {
+        if (X.split_one_pass) { X.send_off[r] = (uint64_t)r * X.split_cap; X.send_cnt[r] = h_base[r]; }
+        else { X.send_off[r] = h_base[r]; X.send_cnt[r] = h_base[r + 1] - h_base[r]; }
+    }
     if (X.h_split_cnt->err_key_range) {
         h->err = std::to_string(X.h_split_cnt->err_key_range) + " point(s) outside the key range";
         return GNDT_ERR_KEY_RANGE;
@@ -451,17 +477,18 @@ int gndt_owner_map_device(gndt_handle* h, const uint32_t* all_msgs_dev, uint32_t
 }
 
 int gndt_owner_split_device(gndt_handle* h, const void* shard_xyz_dev, size_t n, size_t stride_bytes, uint64_t first_idx_base,
-                            uint64_t total_points, uint32_t world, const void** records_dev, uint64_t* counts_host, void* hip_stream) {
+                            uint64_t total_points, uint32_t world, const void** records_dev, uint64_t* counts_host, uint64_t* offsets_host,
+                            void* hip_stream) {
     int rc = check_ready(h);
     if (rc) return rc;
-    if (!records_dev || !counts_host || (!shard_xyz_dev && n)) { h->err = "null argument"; return GNDT_ERR_INVALID; }
+    if (!records_dev || !counts_host || !offsets_host || (!shard_xyz_dev && n)) { h->err = "null argument"; return GNDT_ERR_INVALID; }
     hipStream_t s = stream_of(h, hip_stream);
     h->pending.active = false;
     { const int urc = use_stream(h, s); if (urc) return urc; }
     if ((rc = owner_split_launch(h, shard_xyz_dev, n, stride_bytes, first_idx_base, total_points, world, s))) return rc;
     HIP_TRY(h, hipStreamSynchronize(s));
     if ((rc = owner_split_finish(h, world))) return rc;
-    for (uint32_t r = 0; r < world; ++r) counts_host[r] = h->exch.send_off[r + 1] - h->exch.send_off[r];
+    for (uint32_t r = 0; r < world; ++r) { counts_host[r] = h->exch.send_cnt[r]; offsets_host[r] = h->exch.send_off[r]; }
     *records_dev = h->exch.send_recs;
     return GNDT_OK;
 }
@@ -559,7 +586,7 @@ int gndt_build_owned_device(gndt_handle* h, gndt_comm* c, const void* shard_xyz_
     // The run this rank keeps stays where the split left it: the build reads two segments (it, and what arrives).  own_recs
     // holds [room for the kept run | the runs of the other ranks in rank order]; the room is only filled when the build
     // takes the counting partition, which wants one array.
-    const uint64_t kept = X.send_off[me + 1] - X.send_off[me];
+    const uint64_t kept = X.send_cnt[me];
     std::vector<uint64_t> recv_off((size_t)W + 1, 0);
     recv_off[0] = kept;
     for (int r = 0; r < W; ++r) recv_off[r + 1] = recv_off[r] + (r == me ? 0 : X.h_matrix[(size_t)r * W + me]);      // what rank r holds for me
@@ -570,7 +597,7 @@ int gndt_build_owned_device(gndt_handle* h, gndt_comm* c, const void* shard_xyz_
         RCCL_TRY(h, rccl().GroupStart());
         for (int r = 0; r < W; ++r) {
             if (r == me) continue;
-            const uint64_t out = X.send_off[r + 1] - X.send_off[r], in = recv_off[r + 1] - recv_off[r];
+            const uint64_t out = X.send_cnt[r], in = recv_off[r + 1] - recv_off[r];
             if (out) RCCL_TRY(h, rccl().Send(X.send_recs + X.send_off[r], (size_t)out * 4, ncclFloat, r, c->nccl, s));
             if (in) RCCL_TRY(h, rccl().Recv(X.own_recs + recv_off[r], (size_t)in * 4, ncclFloat, r, c->nccl, s));
             sent += out * sizeof(float4); received += in * sizeof(float4);

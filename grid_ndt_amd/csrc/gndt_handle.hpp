@@ -139,7 +139,8 @@ struct gndt_handle {
         unsigned long long* d_totals = nullptr;  unsigned long long* h_totals = nullptr;          // [4] nodes, columns, slopes, points
         hipEvent_t ev[5] = {};          // stage stamps of the sharded builds (created once, reused)
         uint32_t* h_bad = nullptr;      // pinned: the "pair beyond the index range" counter comes back here
-        uint64_t send_off[1025] = {};   // host: start of every owner's records in send_recs (after gndt_owner_split_device)
+        uint64_t send_off[1025] = {}, send_cnt[1025] = {};   // host: start and length of every owner's run in send_recs (after the split)
+        bool split_one_pass = false;  uint64_t split_cap = 0;   // one-pass split: run r at r * split_cap
         // locality-aware ownership (gndt_exchange.hpp): this rank's sample message, everybody's, the block table
         uint32_t* owner_msg = nullptr;  uint32_t* owner_msgs_all = nullptr; uint64_t owner_msgs_cap = 0;
         uint32_t* bkey = nullptr;  uint32_t* bcnt = nullptr; uint64_t bcnt_cap = 0;  uint8_t* bown = nullptr;  uint32_t* d_owner_full = nullptr;

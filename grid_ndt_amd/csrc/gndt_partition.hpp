@@ -428,13 +428,16 @@ __device__ __forceinline__ void tile_partition(TileLds<PER, FAN>& L, const float
 // level 1: the cloud -> coarse regions.  One tile per workgroup.  A coarse region can be split into R sub-regions
 // with their own cursors (tile t fills sub-region t % R) to spread the reservations of thousands of tiles over
 // more words (same-address atomics serialise at the memory side); with 4096-point tiles R = 1 measured best.
-template <int STRIDE_FLOATS, int FAN, bool IDXW = false>
+// OWNER: the same kernel as the split of a sharded cloud by column owner (gndt_api_dist.hip): the digit is the owner rank of the
+// point's column among B ranks (region c at c * cap1, nothing sampled), everything else — the pipelined tile loads, the folding
+// of identical points into weighted records, the LDS sort and the coalesced copy-out — is what level 1 does anyway.
+template <int STRIDE_FLOATS, int FAN, bool IDXW = false, bool OWNER = false>
 __global__ void __launch_bounds__(kTileThreads) __attribute__((amdgpu_waves_per_eu(4, 4))) k_part2_level1(const float* __restrict__ xyz, uint64_t n, uint32_t first_base,
                                                                GridParams P, uint32_t B, uint32_t F1, uint32_t F2_shift, uint32_t R,
                                                                uint32_t* __restrict__ cursor1, uint32_t cap1,
                                                                uint32_t* __restrict__ est2,
                                                                float4* __restrict__ recs1, Counters* __restrict__ cnt,
-                                                               PartCounters* __restrict__ pc, uint32_t compress) {
+                                                               PartCounters* __restrict__ pc, uint32_t compress, OwnerMap M) {
     constexpr int PER = kTilePer1;
     __shared__ TileLds<PER, FAN> L;
     // Persistent workgroups, software-pipelined: the loads of tile t+1 are in flight while tile t is keyed, sorted
@@ -500,18 +503,22 @@ __global__ void __launch_bounds__(kTileThreads) __attribute__((amdgpu_waves_per_
             const bool same = !IDXW && (all8 || (compress && wave_all_identical(px, py, pz, use)));   // 64 identical points -> one weighted record
             dig[j] = 0xFFFFFFFFu;
             if (use && (!same || ((threadIdx.x & 63) == 0 && (!all8 || j == 0)))) {
-                const uint32_t b = bucket_of(column_hash(sx, sy), B);
-                dig[j] = (b >> F2_shift) * R + rep;                                  // F2 is a power of two
-                // One record in kSampleEvery votes for its bucket (k_part2_layout sizes the buckets' regions from the
-                // votes).  Chosen by a hash of the point index: a fixed stride would alias with the scan pattern of a
-                // spinning LiDAR (the same azimuths every ring) and with the lane-0 records of compressed waves.
-                if ((((uint32_t)i * 0x9E3779B1u) >> 26) == 0u) atomicAdd(&est2[b], 1u);
+                if constexpr (OWNER) {
+                    dig[j] = owner_lookup(M, sx, sy, B);
+                } else {
+                    const uint32_t b = bucket_of(column_hash(sx, sy), B);
+                    dig[j] = (b >> F2_shift) * R + rep;                              // F2 is a power of two
+                    // One record in kSampleEvery votes for its bucket (k_part2_layout sizes the buckets' regions from the
+                    // votes).  Chosen by a hash of the point index: a fixed stride would alias with the scan pattern of a
+                    // spinning LiDAR (the same azimuths every ring) and with the lane-0 records of compressed waves.
+                    if ((((uint32_t)i * 0x9E3779B1u) >> 26) == 0u) atomicAdd(&est2[b], 1u);
+                }
                 uint32_t idx = (first_base + (uint32_t)i) | (same ? (all8 ? (kWeight64Flag | kWeight512Flag) : kWeight64Flag) : 0u);
                 if constexpr (IDXW) idx = cw[j];                                   // (the host passes compress = 0 with records)
                 r[j] = make_float4(px, py, pz, __uint_as_float(idx));
             }
         }
-        tile_partition<PER, FAN>(L, r, dig, F1 * R, cursor1, cap1, 0ull, (uint64_t)cap1, nullptr, nullptr, recs1, pc);
+        tile_partition<PER, FAN>(L, r, dig, OWNER ? B : F1 * R, cursor1, cap1, 0ull, (uint64_t)cap1, nullptr, nullptr, recs1, pc);
         __syncthreads();                                   // the tile's LDS image is reused by the next iteration
     }
 }

@@ -157,33 +157,30 @@ def owner_of_columns(sx, sy, world):
     return out
 
 
-def exchange_records(records, counts, group=None):
-    """records [m, 4] (any 4-byte dtype) grouped by owner rank, counts[r] of them for rank r  ->  the records this rank owns:
-    the runs every rank holds for it, in rank order.  Sizes first (all-gather), then one send / receive per peer."""
+def exchange_records(runs, group=None):
+    """runs[r]: the [c_r, 4] records (any 4-byte dtype) this rank holds for rank r  ->  the records this rank owns: the runs
+    every rank holds for it, in rank order.  Sizes first (all-gather), then one send / receive per peer."""
     world, rank = dist.get_world_size(group), dist.get_rank(group)
-    dev = records.device
-    mine = torch.tensor(list(counts), dtype=torch.int64, device=dev)
+    dev = runs[0].device
+    mine = torch.tensor([int(r.shape[0]) for r in runs], dtype=torch.int64, device=dev)
     table = [torch.zeros_like(mine) for _ in range(world)]
     dist.all_gather(table, mine, group=group)
     incoming = [int(table[r][rank]) for r in range(world)]                 # what rank r holds for this rank
-    off = [0]
-    for c in counts:
-        off.append(off[-1] + int(c))
-    bits = records.view(torch.int32)                                       # index words are bit patterns, never numbers
+    bits = [r.view(torch.int32) for r in runs]                             # index words are bit patterns, never numbers
     got = [torch.empty((incoming[r], 4), dtype=torch.int32, device=dev) for r in range(world)]
-    got[rank].copy_(bits[off[rank]:off[rank + 1]])
+    got[rank].copy_(bits[rank])
     ops = []
     for r in range(world):
         if r == rank:
             continue
-        if off[r + 1] > off[r]:
-            ops.append(dist.P2POp(dist.isend, bits[off[r]:off[r + 1]].contiguous(), r, group))
+        if bits[r].shape[0]:
+            ops.append(dist.P2POp(dist.isend, bits[r].contiguous(), r, group))
         if incoming[r]:
             ops.append(dist.P2POp(dist.irecv, got[r], r, group))
     if ops:
         for w in dist.batch_isend_irecv(ops):
             w.wait()
-    return torch.cat(got, 0).contiguous().view(records.dtype)
+    return torch.cat(got, 0).contiguous().view(runs[0].dtype)
 
 
 def gather_column_pairs(pairs, group=None):
@@ -210,8 +207,8 @@ def build_owned_map(m, demand, shard, first_idx_base, total_points, group=None, 
         msgs = [torch.empty_like(msg) for _ in range(world)]
         dist.all_gather(msgs, msg, group=group)
         m.owner_map(torch.cat(msgs).contiguous(), world, stream)
-    recs, counts = m.owner_split(demand, shard, first_idx_base, total_points, world, stream)
-    own = exchange_records(recs, counts, group)
+    runs = m.owner_split(demand, shard, first_idx_base, total_points, world, stream)
+    own = exchange_records(runs, group)
     m.build_records(demand, own, total_points, stream)
     allp = gather_column_pairs(m.owned_columns(stream).clone(), group)
     return m.owned_global_rows(allp, total_points, stream)

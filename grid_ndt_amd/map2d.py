@@ -307,20 +307,20 @@ class TwoDmap:
 
     def owner_split(self, demand, points, first_idx_base, total_points, world, stream=None):
         """This rank's contiguous range of the cloud -> its points as 16-B records grouped by owner rank.
-        Returns (records [n, 4] float32 device view, counts per owner)."""
+        Returns the list of runs, one [count, 4] float32 device view per owner rank."""
         self._ensure(demand)
         ptr, n, stride, on_dev, keep = self._as_input(points)
         if not on_dev:
             raise GndtError(1, "owner_split takes device memory")
         recs = C.c_void_p()
         counts = (C.c_uint64 * int(world))()
+        offsets = (C.c_uint64 * int(world))()
         self._check(self._L.gndt_owner_split_device(self._h, C.c_void_p(ptr), n, stride, int(first_idx_base), int(total_points), int(world),
-                                                    C.byref(recs), counts, _stream_ptr(stream)))
+                                                    C.byref(recs), counts, offsets, _stream_ptr(stream)))
         self._keep = keep
         import torch
-        cnt = [int(c) for c in counts]
-        total = sum(cnt)
-        return self._dev_view(recs.value or 0, total * 16, torch.float32, (total, 4)), cnt
+        base = recs.value or 0
+        return [self._dev_view(base + 16 * int(o), int(c) * 16, torch.float32, (int(c), 4)) for c, o in zip(counts, offsets)]
 
     def build_records(self, demand, records, total_points, stream=None):
         """The records this rank owns ([m, 4] float32 on the device: x, y, z, index word) -> its part of the map."""

@@ -230,8 +230,9 @@ int gndt_build_global_device(gndt_handle* h, gndt_comm* c, const void* shard_xyz
  *
  * gndt_build_owned_device does all of it over RCCL.  The four steps are also exported one by one for hosts that bring their
  * own transport (MPI, a ROS bridge) and for the single-GPU tests that play W ranks on one device:
- *   gndt_owner_split_device    shard -> records grouped by owner; counts_host[world] and the device pointer of the runs
- *                              (valid until the next call on the handle); waits for the stream
+ *   gndt_owner_split_device    shard -> records grouped by owner: rank r's run is counts_host[r] records of 16 bytes starting
+ *                              offsets_host[r] records into *records_dev (the runs need not be adjacent; valid until the
+ *                              next call on the handle); waits for the stream
  *   gndt_build_records_device  the records a rank owns (runs of all ranks, concatenated in any order) -> its map; like
  *                              gndt_build_device it is launched, not awaited.  total_points = binned points of the whole cloud
  *   gndt_owned_columns_device  (first-seen index << 32 | node count) per column of the local map; waits
@@ -260,7 +261,8 @@ int gndt_owner_sample_device(gndt_handle* h, const void* shard_xyz_dev, size_t n
                              uint64_t* msg_words, void* hip_stream);
 int gndt_owner_map_device(gndt_handle* h, const uint32_t* all_msgs_dev, uint32_t world, void* hip_stream);
 int gndt_owner_split_device(gndt_handle* h, const void* shard_xyz_dev, size_t n, size_t stride_bytes, uint64_t first_idx_base,
-                            uint64_t total_points, uint32_t world, const void** records_dev, uint64_t* counts_host, void* hip_stream);
+                            uint64_t total_points, uint32_t world, const void** records_dev, uint64_t* counts_host,
+                            uint64_t* offsets_host, void* hip_stream);
 int gndt_build_records_device(gndt_handle* h, const void* records_dev, size_t n_records, uint64_t total_points, void* hip_stream);
 /* The same from TWO segments, so that the run a rank keeps for itself need not be copied next to what it receives: the
  * second segment must be preceded, in its own allocation, by room for the n_first records of the first (only small builds,

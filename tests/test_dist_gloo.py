@@ -102,8 +102,8 @@ def _owner_worker(rank, world, port, cut, q):
     recs = np.zeros((shard.shape[0], 4), np.float32)
     recs[:, :3] = shard[order, :3]
     recs[:, 3] = (np.arange(lo, hi, dtype=np.uint32)[order]).view(np.float32)
-    counts = np.bincount(owner, minlength=world).tolist()
-    own = exchange_records(torch.from_numpy(recs), counts).numpy()
+    off = np.concatenate([[0], np.cumsum(np.bincount(owner, minlength=world))])
+    own = exchange_records([torch.from_numpy(recs[off[r]:off[r + 1]]) for r in range(world)]).numpy()
     idx = np.ascontiguousarray(own[:, 3]).view(np.uint32).astype(np.int64)
     # every point of a column this rank owns is here, and nothing else
     sx2, sy2 = he.point_columns(own, origin, P["grid_len"], P["z_len"])

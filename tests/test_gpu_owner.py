@@ -43,12 +43,11 @@ def owner_build_on_one_gpu(cloud, P, W, bounds=None, strategy=0, locality=False)
     pieces = [[None] * W for _ in range(W)]
     kept = 0
     for r in range(W):
-        recs, cnt = maps[r].owner_split(demand, pts[bounds[r]:bounds[r + 1]], bounds[r], n, W)
-        off = np.concatenate([[0], np.cumsum(cnt)]).astype(np.int64)
-        assert recs.shape[0] == off[-1] <= bounds[r + 1] - bounds[r]          # (weighted records fold identical points)
+        runs = maps[r].owner_split(demand, pts[bounds[r]:bounds[r + 1]], bounds[r], n, W)
+        assert len(runs) == W and sum(int(x.shape[0]) for x in runs) <= bounds[r + 1] - bounds[r]   # (weighted records fold identical points)
         for o in range(W):
-            pieces[r][o] = recs[off[o]:off[o + 1]].clone()
-        kept += cnt[r]
+            pieces[r][o] = runs[o].clone()
+        kept += int(runs[r].shape[0])
     owned_points = []
     for o in range(W):
         own = torch.cat([pieces[r][o] for r in range(W)], 0).contiguous()
@@ -206,7 +205,7 @@ def test_owner_build_of_tiny_clouds_with_ranks_that_own_nothing(n, W):
     pts16 = torch.zeros((n, 4), dtype=torch.float32, device="cuda")
     pts16[:, :3] = torch.from_numpy(cloud[1:]).cuda()
     pts16[:, 3] = float("nan")                                    # the padding word is never read
-    recs, cnt = maps[0].owner_split("true", pts16, 0, n, 1)
+    recs = maps[0].owner_split("true", pts16, 0, n, 1)[0]
     maps[0].build_records("true", recs.clone(), n)
     parity.assert_parity(maps[0].export(), ref, demand="true", adversarial=True)
 
@@ -220,8 +219,7 @@ def test_records_build_from_two_segments_equals_the_single_array_build(n):
     ref_m, one = parity.gpu_from_cloud(cloud, TERRAIN, on_device=True)
     m = _ranks(cloud, TERRAIN, 1)[0]
     pts = torch.from_numpy(np.ascontiguousarray(cloud[1:])).cuda()
-    recs, cnt = m.owner_split("slope", pts, 0, pts.shape[0], 1)
-    recs = recs.clone()
+    recs = m.owner_split("slope", pts, 0, pts.shape[0], 1)[0].clone()
     for a in (0, 1, recs.shape[0] // 3, recs.shape[0] - 1, recs.shape[0]):
         first = recs[:a].clone()
         room_and_second = torch.empty_like(recs)
