@@ -46,7 +46,11 @@ uint64_t buckets_for(uint64_t n, uint64_t nodes, int slots, int load_pct) {
     if (pts_target) return std::max<uint64_t>(n / (uint64_t)pts_target, 16);
     // k_bucket_owner takes a bucket in ONE chunk of kOwnerChunk records when it can: mean 1600 leaves 3 sigma of the
     // column-granular spread of a hash partition (a fuller bucket simply takes a second chunk)
-    const uint64_t per_bucket = slots >= 1024 ? 6400 : (tuning().bucket_kernel == 4 ? (slots == 256 ? 800 : 1600) : 2800);
+    // Clouds of up to a few million points do not fill the chip with 2800-point buckets (200 k points: 71 workgroups for 256
+    // CUs): down to 700 points per bucket below a million points, measured 5-13 % faster there (campus / bridge / terrain / uniform
+    // clouds of 0.1-1 M points) and slower from 2 M points on.
+    const uint64_t small_cloud = std::min<uint64_t>(2800, std::max<uint64_t>(700, n / 1024));
+    const uint64_t per_bucket = slots >= 1024 ? 6400 : (tuning().bucket_kernel == 4 ? (slots == 256 ? 800 : 1600) : small_cloud);
     // (k_bucket_owner: two lanes own a node, so a 512-thread workgroup holds 256 nodes: average load 1/4 of that table)
     const uint64_t node_room = (slots < 1024 && tuning().bucket_kernel == 4) ? (uint64_t)slots * load_pct * 2 / 3 : (uint64_t)slots * load_pct;
     const uint64_t want = std::max<uint64_t>(n / per_bucket, (nodes * 100) / node_room);
