@@ -98,9 +98,19 @@ int partition_launch(gndt_handle* h, gndt_handle::Pending& P) {
         if (!env_slots && Bw > kMaxBuckets) { bslots = 1024; Bw = buckets_for(n, nodes_est, bslots, q.load_pct); }
         if (Bw > kMaxBuckets) return -1;                   // too many nodes for one partition level: atomic path
     }
+    // (a cloud just above kMaxFan buckets of the small-cloud size still fits kMaxFan larger ones, if its nodes do)
+    if (!two && tuning().one_level && q.one_level_ok && h->P.strategy != GNDT_STRATEGY_PARTITION_EXACT && Bw > (uint64_t)kMaxFan &&
+        n <= (uint64_t)kMaxFan * 2800 && (nodes_est * 100) / ((uint64_t)bslots * q.load_pct) <= (uint64_t)kMaxFan)
+        Bw = kMaxFan;
     const uint32_t B = (uint32_t)Bw;
+    // Small clouds (at most kMaxFan buckets): ONE tile-sort level writes the buckets themselves, each with a fixed room of 4 x
+    // the mean fill — a third of the counting partition's time (no histogram pass, no offsets pass, coalesced copy-out).  A
+    // bucket that overflows its room sends the build (and this handle from then on) to the counting partition.
+    const bool one = !two && tuning().one_level && q.one_level_ok && h->P.strategy != GNDT_STRATEGY_PARTITION_EXACT && B <= (uint32_t)kMaxFan &&
+                     n >= (1u << 14);
     P.two_level = two;
-    h->last_strategy = two ? GNDT_STRATEGY_PARTITION : GNDT_STRATEGY_PARTITION_EXACT;
+    P.one_level = one;
+    h->last_strategy = two ? GNDT_STRATEGY_PARTITION : (one ? GNDT_STRATEGY_PARTITION_ONE_LEVEL : GNDT_STRATEGY_PARTITION_EXACT);
     stage_want = std::max<uint64_t>(stage_want, nodes_est + nodes_est / 8);
     if (P.stats_only) {
         if ((rc = ensure_stats_buffers(h, stage_want))) return rc;
@@ -193,6 +203,57 @@ int partition_launch(gndt_handle* h, gndt_handle::Pending& P) {
         HIP_TRY(h, hipGetLastError());
         mark(h, 4, s);
         range_lo = q.range_lo; range_hi = q.range_hi;
+    } else if (one) {
+        constexpr uint64_t kTile1 = (uint64_t)kTileThreads * kTilePer1;
+        const uint64_t mean = n / B + 1;
+        const uint32_t cap1 = (uint32_t)std::max<uint64_t>(4 * mean, mean + 4096);
+        if ((rc = grow_buf(h, q.recs1, q.rec1_cap, (uint64_t)B * cap1))) return rc;
+        if (B > q.cur_cap) {
+            for (uint32_t** a : {&q.cursors, &q.range_lo, &q.range_hi, &q.range_cap}) { if (*a) (void)hipFree(*a); *a = nullptr; }
+            q.cur_cap = 0;
+            const uint64_t c = (uint64_t)B + B / 4;
+            HIP_TRY(h, hipMalloc(&q.cursors, ((size_t)kMaxFan + 2 * c) * 4));
+            HIP_TRY(h, hipMalloc(&q.range_lo, c * 4));
+            HIP_TRY(h, hipMalloc(&q.range_hi, c * 4));
+            HIP_TRY(h, hipMalloc(&q.range_cap, c * 4));
+            q.cur_cap = c;
+        }
+        uint32_t* cursor1 = q.cursors;                     // [B <= kMaxFan] the buckets' fills
+        uint32_t* est2 = q.cursors + kMaxFan;              // (the kernel's sample votes: not used here, but counted)
+        const uint32_t F1 = B, F2_shift = 0, R = 1;
+        mark(h, 0, s);
+        if (h->table_dirty) { if ((rc = do_reset(h, s))) return rc; }
+        h->results_valid = false;
+        hipLaunchKernelGGL(k_part_clear, dim3(grid_for(words, 256, 512)), dim3(256), 0, s, h->d_cnt, q.d_pc, q.bitmap, q.word_weight, (uint64_t)words,
+                           q.cursors, (uint32_t)(kMaxFan + B));
+        HIP_TRY(h, hipGetLastError());
+        mark(h, 1, s);
+        const uint32_t tiles1 = (uint32_t)((P.n + kTile1 - 1) / kTile1), tiles1b = (uint32_t)((P.n2 + kTile1 - 1) / kTile1);
+        const uint32_t l1_wgs = tuning().l1_wgs;
+        const bool wide = B > 256;
+        const dim3 g1(std::max<uint32_t>(1, std::min<uint32_t>(tiles1, l1_wgs))), g1b(std::max<uint32_t>(1, std::min<uint32_t>(tiles1b, l1_wgs)));
+#define GNDT_L1(SF_, FAN_)                                                                                                  \
+    hipLaunchKernelGGL((k_part2_level1<SF_, FAN_>), g1, dim3(kTileThreads), 0, s, p, (uint64_t)n, P.first_base, gp, B, F1, F2_shift, \
+                       R, cursor1, cap1, est2, q.recs1, h->d_cnt, q.d_pc, compress, OwnerMap{nullptr, nullptr, 0u})
+#define GNDT_L1R(FAN_)                                                                                                      \
+    do {                                                                                                                    \
+        if (P.n) hipLaunchKernelGGL((k_part2_level1<4, FAN_, true>), g1, dim3(kTileThreads), 0, s, p, (uint64_t)P.n, P.first_base, gp, B, F1, \
+                                    F2_shift, R, cursor1, cap1, est2, q.recs1, h->d_cnt, q.d_pc, compress, OwnerMap{nullptr, nullptr, 0u}); \
+        if (P.n2) hipLaunchKernelGGL((k_part2_level1<4, FAN_, true>), g1b, dim3(kTileThreads), 0, s, p2, (uint64_t)P.n2, P.first_base, gp, B, \
+                                     F1, F2_shift, R, cursor1, cap1, est2, q.recs1, h->d_cnt, q.d_pc, compress, OwnerMap{nullptr, nullptr, 0u}); \
+    } while (0)
+        if (P.records) { if (wide) GNDT_L1R(512); else GNDT_L1R(256); }
+        else if (stride_bytes == 12) { if (wide) GNDT_L1(3, 512); else GNDT_L1(3, 256); }
+        else { if (wide) GNDT_L1(4, 512); else GNDT_L1(4, 256); }
+#undef GNDT_L1
+#undef GNDT_L1R
+        HIP_TRY(h, hipGetLastError());
+        mark(h, 2, s);
+        mark(h, 3, s);
+        hipLaunchKernelGGL(k_part1_ranges, dim3(grid_for(B, 256, 64)), dim3(256), 0, s, (const uint32_t*)cursor1, cap1, B, q.range_lo, q.range_hi);
+        HIP_TRY(h, hipGetLastError());
+        mark(h, 4, s);
+        range_lo = q.range_lo; range_hi = q.range_hi;
     } else {
     if (P.n2) {                    // one array for the counting partition: the first segment goes into the room in front of the second
         p = p2 - 4 * P.n;
@@ -242,7 +303,7 @@ int partition_launch(gndt_handle* h, gndt_handle::Pending& P) {
     mark(h, 4, s);
     range_lo = q.bucket_base; range_hi = q.bucket_base + 1;
     }
-    bucket_recs = q.recs;
+    bucket_recs = (two || !one) ? q.recs : q.recs1;
     if (tuning().stamps && q.dbg_buckets < B) {
         if (q.dbg) (void)hipFree(q.dbg);
         q.dbg = nullptr; q.dbg_buckets = 0;
@@ -359,7 +420,8 @@ int partition_resolve(gndt_handle* h) {
                             "staging overflow %u -> re-run\n", P.n, P.attempt, P.bslots, (unsigned long long)P.nodes_est, q.h_pc->part_overflow,
                     q.h_pc->lds_overflow, q.h_pc->stage_overflow);
         if (q.h_pc->part_overflow) {                           // a region of the two-level partition was too small: same table
-            ++q.two_level_failures;                            // size and estimate again (level-1 regions sized from the fullest
+            if (P.one_level) q.one_level_ok = false;           // (one-level: a bucket outgrew its fixed room: counting partition from now on)
+            else ++q.two_level_failures;                       // size and estimate again (level-1 regions sized from the fullest
             --P.attempt;                                       // one seen; after two failures the exact counting partition)
             again = true;
         } else if (q.h_pc->lds_overflow) {                            // some bucket holds too many nodes for its LDS table:

@@ -27,6 +27,7 @@ Tuning parse_tuning() {
     if (getenv("GNDT_TILE_RATIO")) t.tile_ratio = atof(getenv("GNDT_TILE_RATIO"));
     t.update_tile = geti("GNDT_UPDATE_TILE", t.update_tile);
     t.owner_locality = geti("GNDT_OWNER_LOCALITY", t.owner_locality);
+    t.one_level = geti("GNDT_ONE_LEVEL", t.one_level);
     t.stamps = getenv("GNDT_STAMPS") != nullptr;
     t.verbose = getenv("GNDT_VERBOSE") != nullptr;
     return t;

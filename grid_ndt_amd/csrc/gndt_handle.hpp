@@ -88,6 +88,7 @@ struct gndt_handle {
         uint64_t rec1_cap = 0;     float4* recs1 = nullptr;
         uint64_t cur_cap = 0;      uint32_t *cursors = nullptr, *range_lo = nullptr, *range_hi = nullptr, *range_cap = nullptr;
         int two_level_failures = 0;   // builds whose regions overflowed although sized from the sample
+        bool one_level_ok = true;  // cleared when a bucket of the one-level tile partition (small clouds) overflowed its fixed room
         bool two_level_ok = true;  // cleared when the regions a cloud needs are too large: exact path from then on
         double fill1_ratio = 0.0;   // fullest level-1 region / mean seen on this handle (0 = unknown)
         uint64_t hist_cap = 0;     uint32_t* hist = nullptr;
@@ -171,6 +172,7 @@ struct gndt_handle {
         uint64_t nodes_est = 0, stage_want = 0, est0 = 0;   // est0: the estimate the first attempt used
         bool est_reliable = false;      //   ... and whether it came from a hint / an earlier build rather than the n / 4 guess
         bool two_level = false;         // this attempt used the two-level partition
+        bool one_level = false;         //   ... the one-level tile partition (small clouds)
         double mean1 = 0.0;             // its mean level-1 region fill (to turn the fullest region into a ratio)
         bool stats_only = false;        // gndt_shard_stats_device: statistics out, no labels / ordering / rows
         gndt::GridParams gp{};          // origin and grid parameters AS THEY WERE when the build was launched: a retry
@@ -201,6 +203,7 @@ struct Tuning {
     uint32_t bucket_wgs = 0xFFFFFFFFu;   // GNDT_BUCKET_WGS   persistent bucket workgroups (default: one per bucket)
     double tile_ratio = 48.0;    // GNDT_TILE_RATIO     AUTO takes strategy TILE from this many points per partial on (sampled; the
                                  //                     measured crossover, profiles/r02_tile_calibration.json)
+    int one_level = 1;           // GNDT_ONE_LEVEL      small clouds: level 1 writes the buckets directly (0: counting partition)
     int owner_locality = 1;      // GNDT_OWNER_LOCALITY owner-partitioned build: sampled block ownership (1) or hash ownership only (0)
     int update_tile = -1;        // GNDT_UPDATE_TILE    incremental updates through the tile kernel: 1 always, 0 never, -1 = by strategy
     bool stamps = false;         // GNDT_STAMPS=1       in-kernel phase stamps of the bucket kernel

@@ -604,6 +604,15 @@ static __global__ void __launch_bounds__(256) k_part2_ranges(const uint32_t* __r
     if (threadIdx.x == 0 && m1) atomicMax(&pc->max_fill1, m1);
 }
 
+// one-level tile partition (small clouds: level 1 writes the buckets themselves, bucket b at b * cap1): the buckets' ranges
+static __global__ void __launch_bounds__(256) k_part1_ranges(const uint32_t* __restrict__ cursor1, uint32_t cap1, uint32_t B,
+                                                             uint32_t* __restrict__ lo, uint32_t* __restrict__ hi) {
+    for (uint32_t b = blockIdx.x * blockDim.x + threadIdx.x; b < B; b += gridDim.x * blockDim.x) {
+        lo[b] = b * cap1;
+        hi[b] = b * cap1 + min(cursor1[b], cap1);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // pass 3: one workgroup per bucket
 // ---------------------------------------------------------------------------------------------

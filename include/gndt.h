@@ -59,6 +59,8 @@ enum {
                                      two-level partition without counting passes and fall back to the exact one */
     GNDT_STRATEGY_PARTITION_EXACT = 3,      /* always the single-level counting partition (histogram + offsets + scatter) */
     GNDT_STRATEGY_PARTITION_TWO_LEVEL = 4,  /* the two-level partition whatever the size (PARTITION picks it from 2^20 points) */
+    GNDT_STRATEGY_PARTITION_ONE_LEVEL = 6,  /* (reported by gndt_last_strategy only) small clouds: one tile-sort level writes the
+                                             * buckets directly; PARTITION / AUTO pick it when the cloud needs at most 512 buckets */
     GNDT_STRATEGY_TILE = 5        /* one pass for clouds that keep their scan order: contiguous ranges of the cloud, node table
                                      privatised in LDS per workgroup, ONE partial per distinct node and flush into the HBM node
                                      table (gndt_tile.hpp).  AUTO takes it when a sample of the cloud shows enough points per
@@ -365,7 +367,7 @@ void gndt_unpack_key(uint64_t key, int32_t* sx, int32_t* sy, int32_t* sz);
  * (bucket_build / accumulate): two events per build instead of eleven. */
 int gndt_set_profiling(gndt_handle* h, int enable);
 int gndt_get_phase_times(gndt_handle* h, double ms_out[GNDT_NUM_PHASES]);
-/* GNDT_STRATEGY_ATOMIC, _PARTITION (two-level) or _PARTITION_EXACT: what the last build actually ran (AUTO resolves,
+/* GNDT_STRATEGY_ATOMIC, _PARTITION (two-level), _PARTITION_ONE_LEVEL, _PARTITION_EXACT or _TILE: what the last build actually ran (AUTO resolves,
  * and PARTITION falls back to ATOMIC when a bucket does not fit in LDS). */
 /* The measurement AUTO bases that choice on, for logs and tuning: `tiles` tiles of 2048 consecutive points spread over the
  * cloud; *points_per_partial = points looked at / distinct nodes met per tile.  Waits for the result. */

@@ -356,8 +356,8 @@ def test_sharded_cloud_statistics_merge_to_the_global_map(strategy, scene):
         m.setInterval(P["slope_interval"])
         m.setCloudFirst(cloud[0])
         st = m.shard_stats(P["demand"], body[cuts[r]:cuts[r + 1]], first_idx_base=cuts[r])
-        expect = 1 if strategy == 1 else (2 if cuts[r + 1] - cuts[r] >= (1 << 20) else 3)
-        assert m.last_strategy() == expect, (r, m.last_strategy())
+        expect = (1,) if strategy == 1 else ((2,) if cuts[r + 1] - cuts[r] >= (1 << 20) else (3, 6))   # (6: one-level tile partition)
+        assert m.last_strategy() in expect, (r, m.last_strategy())
         parts.append({k: v.clone() for k, v in st.items()})
         assert int(parts[-1]["count"].sum().item()) == cuts[r + 1] - cuts[r]
     keys = torch.cat([p["key"] for p in parts])
@@ -642,3 +642,39 @@ def test_remove_whole_frames_equals_the_build_without_them():
     for f in (5, 4):
         m.del2DMap("slope", torch.from_numpy(frames[f * ppf:(f + 1) * ppf]).cuda())
     parity.assert_parity(m.export(), parity.ref_from_cloud(frames[:4 * ppf], P))
+
+
+def test_small_clouds_take_the_one_level_tile_partition_and_fall_back_when_a_bucket_outgrows_its_room():
+    """Clouds that need at most 512 buckets: level 1 writes the buckets themselves (strategy 6 reported), every bucket with room
+    for 4 x the mean.  A cloud with one very hot column overflows that room: the build is re-run on the counting partition and the
+    handle stays there."""
+    import torch
+    import grid_ndt_amd as g
+    for name in ("campus_200k", "bridge_ground"):
+        cloud, P, ref = _case(name)
+        m, out = parity.gpu_from_cloud(cloud, P, on_device=True, strategy=2)
+        parity.assert_parity(out, ref)
+        assert m.last_strategy() == 6, (name, m.last_strategy())
+        # 16-byte points through the same path
+        m2 = g.TwoDmap(P["grid_len"], P["z_len"], strategy=2)
+        m2.setInterval(P["slope_interval"]); m2.setCloudFirst(cloud[0])
+        p16 = torch.zeros((cloud.shape[0] - 1, 4), dtype=torch.float32, device="cuda")
+        p16[:, :3] = torch.from_numpy(cloud[1:]).cuda()
+        m2.create2DMap(P["demand"], p16)
+        parity.assert_parity(m2.export(), ref)
+        assert m2.last_strategy() == 6
+    rng = np.random.default_rng(3)
+    n = 300_000
+    xyz = np.stack([rng.random(n) * 60 - 30, rng.random(n) * 60 - 30, 0.02 * rng.normal(size=n)], 1)
+    hot = rng.random(n) < 0.5
+    xyz[hot, 0] = 1.26 + 0.01 * rng.random(hot.sum()); xyz[hot, 1] = 4.03 + 0.01 * rng.random(hot.sum()); xyz[hot, 2] = rng.random(hot.sum()) * 3.0
+    cloud = np.concatenate([np.float32([[0.0, 0.0, 0.0]]), xyz.astype(np.float32)], 0)
+    P = dict(grid_len=0.5, z_len=0.1, slope_interval=0.08, demand="slope")
+    ref = parity.ref_from_cloud(cloud, P)
+    m, out = parity.gpu_from_cloud(cloud, P, on_device=True, strategy=2)
+    parity.assert_parity(out, ref, adversarial=True)
+    assert m.last_strategy() == 3 and m.retry_count() >= 1
+    before = m.retry_count()
+    m.create2DMap("slope", torch.from_numpy(cloud[1:]).cuda())
+    parity.assert_parity(m.export(), ref, adversarial=True)
+    assert m.last_strategy() == 3 and m.retry_count() == before          # (no second attempt at the one-level path)
