@@ -9,7 +9,8 @@ namespace gndt_host {
 constexpr int kOwnerChunk = 2560;       // records per chunk of k_bucket_owner (40 KB of LDS)
 
 // prefix of the per-word column weights -> row of every staged node -> SoA rows (marks m0+1 .. m0+5)
-int launch_order_and_emit(gndt_handle* h, uint64_t words, int m0, hipStream_t s) {
+// `grouped`: the staging rows of a column are adjacent (k_bucket_direct): the destination pass works per column
+int launch_order_and_emit(gndt_handle* h, uint64_t words, int m0, hipStream_t s, bool grouped) {
     auto& q = h->part;
     const uint32_t nbw = (uint32_t)((words + kScanChunk - 1) / kScanChunk);
     hipLaunchKernelGGL(k_scan_reduce<false>, dim3(nbw), dim3(kScanThreads), 0, s, q.word_weight, (const uint32_t*)nullptr,
@@ -20,8 +21,12 @@ int launch_order_and_emit(gndt_handle* h, uint64_t words, int m0, hipStream_t s)
     mark(h, m0 + 1, s);
     mark(h, m0 + 2, s);       // (the column-rank and column-scan passes of earlier versions: phases kept for the ABI, empty)
     mark(h, m0 + 3, s);
-    hipLaunchKernelGGL(k_order_dest, dim3(grid_for(q.stage_cap)), dim3(kBlock), 0, s, q.ord_cf, q.ord_idx, q.bitmap, q.word_base,
-                       q.ncol_at, q.inv, h->d_cnt, q.d_pc);
+    if (grouped)
+        hipLaunchKernelGGL(k_order_dest_columns, dim3(grid_for(q.stage_cap)), dim3(kBlock), 0, s, q.ord_cf, q.ord_idx, q.bitmap, q.word_base,
+                           q.ncol_at, q.inv, h->d_cnt, q.d_pc);
+    else
+        hipLaunchKernelGGL(k_order_dest, dim3(grid_for(q.stage_cap)), dim3(kBlock), 0, s, q.ord_cf, q.ord_idx, q.bitmap, q.word_base,
+                           q.ncol_at, q.inv, h->d_cnt, q.d_pc);
     HIP_TRY(h, hipGetLastError());
     mark(h, m0 + 4, s);
     hipLaunchKernelGGL(k_emit_rows, dim3(grid_for(q.stage_cap)), dim3(kBlock), 0, s, q.stage, q.inv, h->out, q.row_ncol, h->d_cnt,
@@ -319,6 +324,7 @@ int partition_launch(gndt_handle* h, gndt_handle::Pending& P) {
     const ColumnOrder order{q.bitmap, q.word_weight, q.ncol_at};
     const StatsOut stats_out{h->st_key, h->st_sums, h->st_count, h->st_first};
     unsigned long long* dbg = tuning().stamps ? q.dbg : nullptr;
+    bool grouped = false;               // k_bucket_direct stages a column's rows next to each other
     if (tuning().bucket_kernel == 4 && bslots != 1024) {
         // k_bucket_owner (gndt_bucket4.hpp): nodes owned by threads, statistics in registers
 #define GNDT_LAUNCH_OWNER(T_, CH_, S_)                                                                                              \
@@ -328,6 +334,7 @@ int partition_launch(gndt_handle* h, gndt_handle::Pending& P) {
         else { if (P.stats_only) GNDT_LAUNCH_OWNER(512, kOwnerChunk, true); else GNDT_LAUNCH_OWNER(512, kOwnerChunk, false); }
 #undef GNDT_LAUNCH_OWNER
     } else if (tuning().bucket_kernel != 2) {
+        grouped = true;
         // k_bucket_direct (gndt_bucket3.hpp): 512-slot tables with three workgroups per CU, 1024-slot tables on a retry
 #define GNDT_LAUNCH_DIRECT(T_, H_, S_)                                                                                          \
     hipLaunchKernelGGL((k_bucket_direct<T_, H_, S_>), bgrid, dim3(T_), 0, s, bucket_recs, range_lo, range_hi, B, gp, q.stage,    \
@@ -349,7 +356,7 @@ int partition_launch(gndt_handle* h, gndt_handle::Pending& P) {
     }
     HIP_TRY(h, hipGetLastError());
     mark(h, 5, s);
-    if (!P.stats_only && (rc = launch_order_and_emit(h, words, 5, s))) return rc;
+    if (!P.stats_only && (rc = launch_order_and_emit(h, words, 5, s, grouped))) return rc;
     HIP_TRY(h, hipMemcpyAsync(q.h_pc, q.d_pc, sizeof(PartCounters), hipMemcpyDeviceToHost, s));
     HIP_TRY(h, hipMemcpyAsync(h->h_cnt, h->d_cnt, sizeof(Counters), hipMemcpyDeviceToHost, s));
     P.bslots = bslots;

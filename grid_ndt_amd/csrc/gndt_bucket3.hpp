@@ -48,6 +48,8 @@ struct BucketLds3 {           // 52.0 KB at H = 512: three workgroups per CU
     uint32_t next[H];           //   key is the key of ANY node on its list, so no separate column keys are kept
     uint16_t list[H];           // the occupied slots, compacted
     uint16_t cslot[H];          // column slot of the node in this slot
+    uint32_t ccnt[H];           // nodes of the column in this column slot, then the column's first row inside the bucket (exclusive prefix)
+    uint32_t wtot[16];          // (the prefix's wave totals)
     uint32_t n_nodes, n_cols, n_slopes, n_list, stage_base, overflow, err_range, pad;
 };
 constexpr uint32_t kNoNode = 0xFFFFFFFFu;
@@ -85,6 +87,7 @@ __device__ __forceinline__ void bucket_direct_one(BucketLds3<H>& L, const uint32
         for (int j = 0; j < 9; ++j) L.sum[j][s] = 0.0;
         L.cnt[s] = 0; L.first[s] = 0xFFFFFFFFu;
         L.chead[s] = kNoNode;
+        L.ccnt[s] = 0;
     }
     if (tid == 0) { L.n_nodes = 0; L.n_cols = 0; L.n_slopes = 0; L.n_list = 0; L.stage_base = 0; L.overflow = 0; L.err_range = 0; }
     __syncthreads();
@@ -279,10 +282,26 @@ __device__ __forceinline__ void bucket_direct_one(BucketLds3<H>& L, const uint32
             c = (c + 1) & (uint32_t)(H - 1);
         }
         L.cslot[s] = (uint16_t)c;
+        atomicAdd(&L.ccnt[c], 1u);
     }
     __syncthreads();
-    GNDT_STAMP3(3);
     if (tid == 0) atomicAdd(&cnt->num_columns, L.n_cols);
+    // The rows of a column are staged NEXT TO EACH OTHER, in first-seen order: the column's first row inside the bucket is the
+    // exclusive prefix of the column sizes over the column slots (one slot per thread).  The ordering pass then works per column
+    // (one lookup of the column's place instead of one per node) and the emit pass gathers runs of rows.
+    {
+        static_assert(T == H, "one column slot per thread");
+        const uint32_t v = L.ccnt[tid];
+        uint32_t incl = v;
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)incl, o, 64); if (lane >= o) incl += t; }
+        if (lane == 63) L.wtot[tid >> 6] = incl;
+        __syncthreads();
+        uint32_t base = incl - v;
+        for (int w = 0; w < (tid >> 6); ++w) base += L.wtot[w];
+        L.ccnt[tid] = base;
+        __syncthreads();
+    }
+    GNDT_STAMP3(3);
 
     // ---- rows: slope label (OcNode::isSlope, map2D.h:66-108), index in column, column size and first-seen index by
     //      walking the column's short list; mean + fp64 scatter -> staging row ----
@@ -331,10 +350,10 @@ __device__ __forceinline__ void bucket_direct_one(BucketLds3<H>& L, const uint32
             node_moments(row.count, sums, c, row.mean, row.scatter);
         }
         row.col_first = cf; row.idx_in_col = icol; row.ncol = ncol;
-        const uint32_t dst = sbase + i;
+        const uint32_t dst = sbase + L.ccnt[L.cslot[s]] + icol;
         stage[dst] = row;
         ord_cf[dst] = cf;
-        ord_idx[dst] = icol;
+        ord_idx[dst] = icol ? icol : (kOrdHeadFlag | ncol);       // (a column's first row carries the column's size)
         if (icol == 0) note_column(O, cf, ncol);
     }
     // counters: aggregated in LDS, ONE memory-side atomic per bucket and counter

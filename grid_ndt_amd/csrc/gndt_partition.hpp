@@ -725,6 +725,28 @@ __global__ void __launch_bounds__(kScanThreads) k_scan_apply(const uint32_t* __r
 // ---------------------------------------------------------------------------------------------
 // ordering
 // ---------------------------------------------------------------------------------------------
+// Staging rows grouped by column (k_bucket_direct): a column's rows are adjacent and in first-seen order, its first row's
+// ord_idx is kOrdHeadFlag | column size.  One lookup of the column's place, then its rows in a run.
+constexpr uint32_t kOrdHeadFlag = 0x80000000u;
+static __global__ void __launch_bounds__(kBlock) k_order_dest_columns(const uint32_t* __restrict__ ord_cf, const uint32_t* __restrict__ ord_idx,
+                                                                      const uint32_t* __restrict__ bitmap, const uint32_t* __restrict__ word_base,
+                                                                      const uint32_t* __restrict__ ncol_at, uint32_t* __restrict__ inv,
+                                                                      const Counters* __restrict__ cnt, const PartCounters* __restrict__ pc) {
+    if (pc->lds_overflow | pc->stage_overflow | pc->index_overflow | pc->part_overflow) return;
+    const uint32_t n = cnt->num_nodes;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const uint32_t v = ord_idx[i];
+        if (!(v & kOrdHeadFlag)) continue;
+        const uint32_t nc = v & ~kOrdHeadFlag;
+        const uint32_t cf = ord_cf[i];
+        const uint32_t w = cf >> 5;
+        uint32_t m = bitmap[w] & ((1u << (cf & 31u)) - 1u);       // columns first seen earlier inside the same word (rare)
+        uint32_t row = word_base[w];
+        while (m) { row += ncol_at[(w << 5) + (uint32_t)__builtin_ctz(m)]; m &= m - 1u; }
+        for (uint32_t k = 0; k < nc; ++k) inv[row + k] = i + k;
+    }
+}
+
 // destination row of every staged node (see ColumnOrder), as the inverse permutation the emit kernel gathers by
 static __global__ void __launch_bounds__(kBlock) k_order_dest(const uint32_t* __restrict__ ord_cf, const uint32_t* __restrict__ ord_idx,
                                                        const uint32_t* __restrict__ bitmap, const uint32_t* __restrict__ word_base,
