@@ -43,9 +43,10 @@ struct BucketLds3 {           // 52.0 KB at H = 512: three workgroups per CU
     uint32_t cnt[H];
     uint32_t first[H];
     // per-node phases
-    float mean_z[H];
+    uint4 walk[H];              // what a walk over a column's node list reads of a node, in ONE 16-byte load: first-seen index, z level,
+                                //   fp32 mean z (0 below min_points), next node of the column
     uint32_t chead[H];          // column table: head of the column's node list (a node slot), kNoNode = free.  The column's
-    uint32_t next[H];           //   key is the key of ANY node on its list, so no separate column keys are kept
+                                //   key is the key of ANY node on its list, so no separate column keys are kept
     uint16_t list[H];           // the occupied slots, compacted
     uint16_t cslot[H];          // column slot of the node in this slot
     uint32_t ccnt[H];           // nodes of the column in this column slot, then the column's first row inside the bucket (exclusive prefix)
@@ -269,19 +270,21 @@ __device__ __forceinline__ void bucket_direct_one(BucketLds3<H>& L, const uint32
         int sx, sy, sz;
         unpack_key(key, sx, sy, sz);
         const uint32_t n = L.cnt[s];
-        L.mean_z[s] = (n >= (uint32_t)P.min_points) ? node_mean_z(n, L.sum[2][s], axis_centre(sz, P.oz, P.z_len)) : 0.f;
+        const float mz = (n >= (uint32_t)P.min_points) ? node_mean_z(n, L.sum[2][s], axis_centre(sz, P.oz, P.z_len)) : 0.f;
+        uint32_t nx = kNoNode;
         const uint64_t ck = column_key(key);
         uint32_t c = ((column_hash(sx, sy) * 0x85EBCA77u) >> 12) & (uint32_t)(H - 1);
         for (int probe = 0; probe < H; ++probe) {            // (terminates: the table has more slots than nodes)
             uint32_t head = L.chead[c];
             if (head == kNoNode) {
                 head = atomicCAS(&L.chead[c], kNoNode, s);
-                if (head == kNoNode) { L.next[s] = kNoNode; atomicAdd(&L.n_cols, 1u); break; }      // first node of a new column
+                if (head == kNoNode) { atomicAdd(&L.n_cols, 1u); break; }                           // first node of a new column
             }
-            if (column_key(L.key[head]) == ck) { L.next[s] = atomicExch(&L.chead[c], s); break; }   // push in front
+            if (column_key(L.key[head]) == ck) { nx = atomicExch(&L.chead[c], s); break; }          // push in front
             c = (c + 1) & (uint32_t)(H - 1);
         }
         L.cslot[s] = (uint16_t)c;
+        L.walk[s] = make_uint4(L.first[s], (uint32_t)sz, __float_as_uint(mz), nx);
         atomicAdd(&L.ccnt[c], 1u);
     }
     __syncthreads();
@@ -295,11 +298,11 @@ __device__ __forceinline__ void bucket_direct_one(BucketLds3<H>& L, const uint32
         uint32_t incl = v;
         for (int o = 1; o < 64; o <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)incl, o, 64); if (lane >= o) incl += t; }
         if (lane == 63) L.wtot[tid >> 6] = incl;
-        __syncthreads();
+        lds_barrier();
         uint32_t base = incl - v;
         for (int w = 0; w < (tid >> 6); ++w) base += L.wtot[w];
         L.ccnt[tid] = base;
-        __syncthreads();
+        lds_barrier();
     }
     GNDT_STAMP3(3);
 
@@ -313,23 +316,25 @@ __device__ __forceinline__ void bucket_direct_one(BucketLds3<H>& L, const uint32
         int sx, sy, sz;
         unpack_key(key, sx, sy, sz);
         const int za = level_above(sz), zb = level_below(sz);
-        const float cz = L.mean_z[s];
+        const float cz = __uint_as_float(L.walk[s].z);
         const uint32_t my_n = L.cnt[s];
         uint32_t icol = 0, ncol = 0, cf = 0xFFFFFFFFu;
         bool up = false, down = false;
-        for (uint32_t t = L.chead[L.cslot[s]]; t != kNoNode; t = L.next[t]) {
-            const uint32_t tf = L.first[t];
+        for (uint32_t t = L.chead[L.cslot[s]]; t != kNoNode;) {
+            const uint4 r = L.walk[t];                      // {first-seen, z level, mean z or 0, next}
+            const uint32_t tf = r.x;
             ++ncol;
             cf = min(cf, tf);
-            if (t == s) continue;
-            icol += (tf < my_first) ? 1u : 0u;
-            const int tz = (int)(L.key[t] & 0x3FFFFFu) - (1 << 21);
-            if (tz == za || tz == zb) {
-                const bool visited = tf < my_first && L.cnt[t] >= (uint32_t)P.min_points;
-                const float oz2 = visited ? L.mean_z[t] : 0.f;
-                const bool far = fabsf(oz2 - cz) > P.slope_interval;
-                if (tz == za) up = up || far; else down = down || far;
+            if (t != s) {
+                icol += (tf < my_first) ? 1u : 0u;
+                const int tz = (int)r.y;
+                if (tz == za || tz == zb) {
+                    const float oz2 = (tf < my_first) ? __uint_as_float(r.z) : 0.f;     // "visited": seen earlier AND has statistics
+                    const bool far = fabsf(oz2 - cz) > P.slope_interval;
+                    if (tz == za) up = up || far; else down = down || far;
+                }
             }
+            t = r.w;
         }
         uint32_t fl = (my_n >= (uint32_t)P.min_points) ? 1u : 0u;
         if (fl) {
