@@ -43,13 +43,15 @@ struct BucketLds3 {           // 52.0 KB at H = 512: three workgroups per CU
     uint32_t cnt[H];
     uint32_t first[H];
     // per-node phases
-    uint4 walk[H];              // what a walk over a column's node list reads of a node, in ONE 16-byte load: first-seen index, z level,
-                                //   fp32 mean z (0 below min_points), next node of the column
-    uint32_t chead[H];          // column table: head of the column's node list (a node slot), kNoNode = free.  The column's
-                                //   key is the key of ANY node on its list, so no separate column keys are kept
+    uint4 colnodes[H];          // the nodes of every column as an ARRAY (column c at ccnt[c] >> 16): what a node's look at its column
+                                //   needs of the others in one 16-byte load each, with independent addresses (loads pipeline; a linked
+                                //   list chased one LDS round trip per node): first-seen index, z level, fp32 mean z (0 below min_points)
+    float mz[H];                // (kept from the column phase until the arrays are filled)
+    uint16_t kcol[H];           // the node's arrival number in its column
+    uint32_t chead[H];          // column table: a node of the column (its key is the column's key: no separate column keys), kNoNode = free
     uint16_t list[H];           // the occupied slots, compacted
     uint16_t cslot[H];          // column slot of the node in this slot
-    uint32_t ccnt[H];           // nodes of the column in this column slot, then the column's first row inside the bucket (exclusive prefix)
+    uint32_t ccnt[H];           // nodes of the column in this column slot; after the prefix (first row inside the bucket) << 16 | nodes
     uint32_t wtot[16];          // (the prefix's wave totals)
     uint32_t n_nodes, n_cols, n_slopes, n_list, stage_base, overflow, err_range, pad;
 };
@@ -263,15 +265,14 @@ __device__ __forceinline__ void bucket_direct_one(BucketLds3<H>& L, const uint32
         return;
     }
 
-    // ---- columns: every node joins the list of its column; fp32 mean-z of the nodes that have statistics ----
+    // ---- columns: every node finds the slot of its column and takes a number in it; fp32 mean-z of the nodes that have statistics ----
     for (uint32_t i = tid; i < M; i += T) {
         const uint32_t s = L.list[i];
         const uint64_t key = L.key[s];
         int sx, sy, sz;
         unpack_key(key, sx, sy, sz);
         const uint32_t n = L.cnt[s];
-        const float mz = (n >= (uint32_t)P.min_points) ? node_mean_z(n, L.sum[2][s], axis_centre(sz, P.oz, P.z_len)) : 0.f;
-        uint32_t nx = kNoNode;
+        L.mz[s] = (n >= (uint32_t)P.min_points) ? node_mean_z(n, L.sum[2][s], axis_centre(sz, P.oz, P.z_len)) : 0.f;
         const uint64_t ck = column_key(key);
         uint32_t c = ((column_hash(sx, sy) * 0x85EBCA77u) >> 12) & (uint32_t)(H - 1);
         for (int probe = 0; probe < H; ++probe) {            // (terminates: the table has more slots than nodes)
@@ -280,18 +281,18 @@ __device__ __forceinline__ void bucket_direct_one(BucketLds3<H>& L, const uint32
                 head = atomicCAS(&L.chead[c], kNoNode, s);
                 if (head == kNoNode) { atomicAdd(&L.n_cols, 1u); break; }                           // first node of a new column
             }
-            if (column_key(L.key[head]) == ck) { nx = atomicExch(&L.chead[c], s); break; }          // push in front
+            if (column_key(L.key[head]) == ck) break;
             c = (c + 1) & (uint32_t)(H - 1);
         }
         L.cslot[s] = (uint16_t)c;
-        L.walk[s] = make_uint4(L.first[s], (uint32_t)sz, __float_as_uint(mz), nx);
-        atomicAdd(&L.ccnt[c], 1u);
+        L.kcol[s] = (uint16_t)atomicAdd(&L.ccnt[c], 1u);
     }
     __syncthreads();
     if (tid == 0) atomicAdd(&cnt->num_columns, L.n_cols);
     // The rows of a column are staged NEXT TO EACH OTHER, in first-seen order: the column's first row inside the bucket is the
     // exclusive prefix of the column sizes over the column slots (one slot per thread).  The ordering pass then works per column
-    // (one lookup of the column's place instead of one per node) and the emit pass gathers runs of rows.
+    // (one lookup of the column's place instead of one per node) and the emit pass gathers runs of rows.  The same prefix
+    // places the columns' node arrays.
     {
         static_assert(T == H, "one column slot per thread");
         const uint32_t v = L.ccnt[tid];
@@ -301,9 +302,15 @@ __device__ __forceinline__ void bucket_direct_one(BucketLds3<H>& L, const uint32
         lds_barrier();
         uint32_t base = incl - v;
         for (int w = 0; w < (tid >> 6); ++w) base += L.wtot[w];
-        L.ccnt[tid] = base;
+        L.ccnt[tid] = (base << 16) | v;
         lds_barrier();
     }
+    for (uint32_t i = tid; i < M; i += T) {
+        const uint32_t s = L.list[i];
+        const int sz = (int)(L.key[s] & 0x3FFFFFu) - (1 << 21);
+        L.colnodes[(L.ccnt[L.cslot[s]] >> 16) + L.kcol[s]] = make_uint4(L.first[s], (uint32_t)sz, __float_as_uint(L.mz[s]), s);
+    }
+    lds_barrier();
     GNDT_STAMP3(3);
 
     // ---- rows: slope label (OcNode::isSlope, map2D.h:66-108), index in column, column size and first-seen index by
@@ -316,26 +323,34 @@ __device__ __forceinline__ void bucket_direct_one(BucketLds3<H>& L, const uint32
         int sx, sy, sz;
         unpack_key(key, sx, sy, sz);
         const int za = level_above(sz), zb = level_below(sz);
-        const float cz = __uint_as_float(L.walk[s].z);
+        const float cz = L.mz[s];
         const uint32_t my_n = L.cnt[s];
         uint32_t icol = 0, ncol = 0, cf = 0xFFFFFFFFu;
         bool up = false, down = false;
-        for (uint32_t t = L.chead[L.cslot[s]]; t != kNoNode;) {
-            const uint4 r = L.walk[t];                      // {first-seen, z level, mean z or 0, next}
-            const uint32_t tf = r.x;
-            ++ncol;
-            cf = min(cf, tf);
-            if (t != s) {
-                icol += (tf < my_first) ? 1u : 0u;
-                const int tz = (int)r.y;
-                if (tz == za || tz == zb) {
-                    const float oz2 = (tf < my_first) ? __uint_as_float(r.z) : 0.f;     // "visited": seen earlier AND has statistics
-                    const bool far = fabsf(oz2 - cz) > P.slope_interval;
-                    if (tz == za) up = up || far; else down = down || far;
+        const uint32_t cinfo = L.ccnt[L.cslot[s]];
+        const uint32_t cbase = cinfo >> 16;
+        ncol = cinfo & 0xFFFFu;
+        for (uint32_t k0 = 0; k0 < ncol; k0 += 4) {         // four independent loads in flight, then their four nodes
+            uint4 rr[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) rr[j] = L.colnodes[cbase + min(k0 + (uint32_t)j, ncol - 1u)];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint4 r = rr[j];                      // {first-seen, z level, mean z or 0, node slot}
+                const uint32_t tf = r.x;
+                if (k0 + (uint32_t)j < ncol && tf != my_first) {     // (first-seen indices of distinct nodes are distinct points)
+                    cf = min(cf, tf);
+                    icol += (tf < my_first) ? 1u : 0u;
+                    const int tz = (int)r.y;
+                    if (tz == za || tz == zb) {
+                        const float oz2 = (tf < my_first) ? __uint_as_float(r.z) : 0.f;     // "visited": seen earlier AND has statistics
+                        const bool far = fabsf(oz2 - cz) > P.slope_interval;
+                        if (tz == za) up = up || far; else down = down || far;
+                    }
                 }
             }
-            t = r.w;
         }
+        cf = min(cf, my_first);
         uint32_t fl = (my_n >= (uint32_t)P.min_points) ? 1u : 0u;
         if (fl) {
             bool slope = true;
@@ -355,7 +370,7 @@ __device__ __forceinline__ void bucket_direct_one(BucketLds3<H>& L, const uint32
             node_moments(row.count, sums, c, row.mean, row.scatter);
         }
         row.col_first = cf; row.idx_in_col = icol; row.ncol = ncol;
-        const uint32_t dst = sbase + L.ccnt[L.cslot[s]] + icol;
+        const uint32_t dst = sbase + cbase + icol;
         stage[dst] = row;
         ord_cf[dst] = cf;
         ord_idx[dst] = icol ? icol : (kOrdHeadFlag | ncol);       // (a column's first row carries the column's size)
