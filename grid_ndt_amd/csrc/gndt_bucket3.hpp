@@ -52,8 +52,7 @@ struct BucketLds3 {           // 52.0 KB at H = 512: three workgroups per CU
     uint16_t list[H];           // the occupied slots, compacted
     uint16_t cslot[H];          // column slot of the node in this slot
     uint32_t ccnt[H];           // nodes of the column in this column slot; after the prefix (first row inside the bucket) << 16 | nodes
-    uint32_t wtot[16];          // (the prefix's wave totals)
-    uint32_t n_nodes, n_cols, n_slopes, n_list, stage_base, overflow, err_range, pad;
+    uint32_t n_nodes, n_cols, n_slopes, n_list, stage_base, overflow, err_range, row_cursor;
 };
 constexpr uint32_t kNoNode = 0xFFFFFFFFu;
 
@@ -92,7 +91,7 @@ __device__ __forceinline__ void bucket_direct_one(BucketLds3<H>& L, const uint32
         L.chead[s] = kNoNode;
         L.ccnt[s] = 0;
     }
-    if (tid == 0) { L.n_nodes = 0; L.n_cols = 0; L.n_slopes = 0; L.n_list = 0; L.stage_base = 0; L.overflow = 0; L.err_range = 0; }
+    if (tid == 0) { L.n_nodes = 0; L.n_cols = 0; L.n_slopes = 0; L.n_list = 0; L.stage_base = 0; L.overflow = 0; L.err_range = 0; L.row_cursor = 0; }
     __syncthreads();
     GNDT_STAMP3(1);
 
@@ -289,22 +288,14 @@ __device__ __forceinline__ void bucket_direct_one(BucketLds3<H>& L, const uint32
     }
     __syncthreads();
     if (tid == 0) atomicAdd(&cnt->num_columns, L.n_cols);
-    // The rows of a column are staged NEXT TO EACH OTHER, in first-seen order: the column's first row inside the bucket is the
-    // exclusive prefix of the column sizes over the column slots (one slot per thread).  The ordering pass then works per column
-    // (one lookup of the column's place instead of one per node) and the emit pass gathers runs of rows.  The same prefix
-    // places the columns' node arrays.
-    {
-        static_assert(T == H, "one column slot per thread");
-        const uint32_t v = L.ccnt[tid];
-        uint32_t incl = v;
-        for (int o = 1; o < 64; o <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)incl, o, 64); if (lane >= o) incl += t; }
-        if (lane == 63) L.wtot[tid >> 6] = incl;
-        lds_barrier();
-        uint32_t base = incl - v;
-        for (int w = 0; w < (tid >> 6); ++w) base += L.wtot[w];
-        L.ccnt[tid] = (base << 16) | v;
-        lds_barrier();
+    // The rows of a column are staged NEXT TO EACH OTHER, in first-seen order: every column reserves its rows inside the bucket.
+    // The ordering pass then works per column (one lookup of the column's place instead of one per node) and the emit pass
+    // gathers runs of rows.  The same reservation places the columns' node arrays.
+    for (int c = tid; c < H; c += T) {              // (one LDS atomic per column: the columns' order inside the bucket is free)
+        const uint32_t v = L.ccnt[c];
+        if (v) L.ccnt[c] = (atomicAdd(&L.row_cursor, v) << 16) | v;
     }
+    lds_barrier();
     for (uint32_t i = tid; i < M; i += T) {
         const uint32_t s = L.list[i];
         const int sz = (int)(L.key[s] & 0x3FFFFFu) - (1 << 21);
