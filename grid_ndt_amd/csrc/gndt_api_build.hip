@@ -335,7 +335,7 @@ int partition_launch(gndt_handle* h, gndt_handle::Pending& P) {
 #undef GNDT_LAUNCH_OWNER
     } else if (tuning().bucket_kernel != 2) {
         grouped = true;
-        // k_bucket_direct (gndt_bucket3.hpp): 512-slot tables with three workgroups per CU, 1024-slot tables on a retry
+        // k_bucket_direct (gndt_bucket3.hpp): 512-slot tables with two workgroups per CU, 1024-slot tables on a retry
 #define GNDT_LAUNCH_DIRECT(T_, H_, S_)                                                                                          \
     hipLaunchKernelGGL((k_bucket_direct<T_, H_, S_>), bgrid, dim3(T_), 0, s, bucket_recs, range_lo, range_hi, B, gp, q.stage,    \
                        (uint32_t)(S_ ? h->st_cap : q.stage_cap), q.ord_cf, q.ord_idx, order, h->d_cnt, q.d_pc, dbg, stats_out)

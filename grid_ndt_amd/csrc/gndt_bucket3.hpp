@@ -9,10 +9,13 @@
 //       record -> key (divide-free exact index, gndt_math.hpp) -> LDS node table slot (first probe hits ~always)
 //              -> v = p - centre(node) in fp64 -> 9 x ds_add_f64 + count + first-seen straight into the table
 //   then, on the finished table
-//       compact the occupied slots (wave ballots), so that the per-node phases run on dense lanes
-//       columns : column table + per-column linked list of nodes, fp32 mean-z
-//       rows    : slope label and index in column by walking the short list; mean + fp64 scatter -> 96-B staging row,
-//                 written WHOLE by one lane (a row written in two parts by two lanes cost twice the bytes at the memory side)
+//       compact the occupied slots (wave ballots), so that the per-node phases run on dense lanes (measured: iterating the
+//                 half-empty table instead saves the pass and a barrier but makes the row phase 10-25 % slower)
+//       columns : column table; every node takes a number in its column, every column reserves its rows inside the bucket
+//                 and gets an ARRAY of 16-byte node records (first-seen, z level, fp32 mean z)
+//       rows    : slope label and index in column from a scan of the column's array; mean + fp64 scatter -> 96-B staging row,
+//                 written WHOLE by one lane (a row written in two parts by two lanes cost twice the bytes at the memory side),
+//                 a column's rows next to each other in first-seen order
 //
 // ~120 instructions per point, bounded by the LDS atomic unit (ds_add_f64: ~2.5 lanes per clock and CU) instead of
 // by instruction issue.  Hot buckets need no special casing (no chunk image to overflow); 64 identical consecutive
@@ -37,7 +40,7 @@ namespace gndt {
 #endif
 
 template <int H>
-struct BucketLds3 {           // 52.0 KB at H = 512: three workgroups per CU
+struct BucketLds3 {           // 61 KB at H = 512: two workgroups per CU
     unsigned long long key[H];
     double sum[9][H];
     uint32_t cnt[H];
@@ -375,8 +378,8 @@ __device__ __forceinline__ void bucket_direct_one(BucketLds3<H>& L, const uint32
 #undef GNDT_STAMP3
 }
 
-// Bucket b, b + gridDim.x, ...  With 512-slot tables three 512-thread workgroups share a CU (52 KB of LDS each): six waves
-// per SIMD, i.e. at most 80 VGPRs; the 1024-slot variant (retries) runs one 1024-thread workgroup per CU.
+// Bucket b, b + gridDim.x, ...  With 512-slot tables two 512-thread workgroups share a CU (61 KB of LDS each, four waves per
+// SIMD); the 1024-slot variant (retries, node-heavy clouds) runs one 1024-thread workgroup per CU.
 template <int T, int H, bool STATS = false>
 __global__ void __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(H <= 512 ? GNDT_DIRECT_WAVES : 4, H <= 512 ? GNDT_DIRECT_WAVES : 4))) k_bucket_direct(const float4* __restrict__ recs, const uint32_t* __restrict__ range_lo,
                                                      const uint32_t* __restrict__ range_hi, uint32_t num_buckets, GridParams P,
