@@ -256,3 +256,34 @@ def test_owner_build_whose_local_build_has_to_be_re_run():
         assert np.array_equal(out[k], one[k]), k
     assert info["global_nodes"] == one["num_nodes"] and info["global_columns"] == one["num_columns"]
     assert np.array_equal(grow.cpu().numpy(), np.arange(out["num_nodes"]))
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_owner_build_fuzz_against_the_single_gpu_build(seed):
+    """Random world sizes, shard boundaries (empty shards included), cloud kinds and sizes on either side of the one-pass
+    split / one-level / two-level thresholds, with and without the sampled block ownership: the assembled map is the
+    single-GPU map, row for row."""
+    rng = np.random.default_rng(4000 + seed)
+    W = int(rng.integers(1, 9))
+    kind = ("terrain", "campus", "uniform", "site")[seed % 4]
+    n = int(rng.choice([3_000, 70_000, 400_000, 1_300_000, 2_600_000]))
+    if kind == "terrain":
+        cloud, P = scenes.terrain_cloud(n), TERRAIN
+    elif kind == "campus":
+        cloud, P = scenes.campus_frame(n), scenes.CAMPUS_PARAMS
+    elif kind == "uniform":
+        cloud, P = scenes.uniform_box(n), dict(grid_len=0.5, z_len=0.5, slope_interval=0.08, demand="slope")
+    else:
+        cloud, P = scenes.site_two_storey(n), dict(grid_len=0.1, z_len=0.1, slope_interval=0.08, demand="slope")
+    nb = cloud.shape[0] - 1
+    cuts = np.sort(rng.integers(0, nb + 1, size=W - 1)).tolist()
+    bounds = [0] + cuts + [nb]
+    _, one = parity.gpu_from_cloud(cloud, P, on_device=True)
+    glob, info = owner_build_on_one_gpu(cloud, P, W, bounds=bounds, locality=bool(seed & 1))
+    print("W", W, kind, n, "bounds", bounds, "owned", info["owned_points"])
+    for k in ("sx", "sy", "sz", "count", "first_idx", "flags"):
+        assert np.array_equal(glob[k], one[k]), k
+    assert (glob["num_nodes"], glob["num_columns"], glob["num_slopes"]) == (one["num_nodes"], one["num_columns"], one["num_slopes"])
+    scale = np.abs(one["cov"]).max(axis=1, keepdims=True) + 1e-30
+    assert (np.abs(glob["cov"] - one["cov"]) / scale).max() < 1e-5
+    assert np.allclose(glob["mean"], one["mean"], rtol=0, atol=2e-6)
