@@ -202,6 +202,8 @@ def lib():
     L.gndt_comm_unique_id.argtypes = [C.c_char_p]
     L.gndt_comm_create.argtypes = [C.c_char_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(vp)]
     L.gndt_comm_destroy.argtypes = [vp]
+    L.gndt_comm_create_threads.argtypes = [C.c_int32, C.c_int32, C.POINTER(vp)]
+    L.gndt_comm_create_threads.restype = C.c_int
     L.gndt_comm_destroy.restype = None
     L.gndt_comm_last_error.restype = C.c_char_p
     L.gndt_build_global_device.argtypes = [H, vp, vp, C.c_size_t, C.c_size_t, u64, u64, C.POINTER(ExchangeTimes), vp]

@@ -5,14 +5,38 @@
 
 #include <rocprim/rocprim.hpp>
 
+#include <condition_variable>
+#include <memory>
+#include <mutex>
 #include <vector>
 
 using namespace gndt;
 using namespace gndt_host;
 
+// Ranks that are THREADS of one process (gndt_comm_create_threads): the collectives of the owner-partitioned build as device
+// copies between the ranks' buffers, with a host barrier on either side.  One GPU can then play a whole node — the tests run
+// gndt_build_owned_device itself with 2 .. 8 ranks on the single-GPU box — and a process that drives several handles from
+// several threads needs no RCCL.
+struct ThreadGroup {
+    int world = 1;
+    std::mutex m;
+    std::condition_variable cv;
+    int arrived = 0;
+    uint64_t generation = 0;
+    std::vector<const void*> send;                  // per rank: what it publishes for the collective in flight
+    std::vector<const uint64_t*> off, cnt;          // exchange: byte offset / byte count of the run for every destination
+    void barrier() {
+        std::unique_lock<std::mutex> lk(m);
+        const uint64_t g = generation;
+        if (++arrived == world) { arrived = 0; ++generation; cv.notify_all(); }
+        else cv.wait(lk, [&] { return generation != g; });
+    }
+};
+
 struct gndt_comm {
     ncclComm_t nccl = nullptr;
     int rank = 0, world = 1, device = 0;
+    std::shared_ptr<ThreadGroup> threads;           // set: the ranks are threads of this process, nccl is not used
 };
 
 namespace {
@@ -26,6 +50,58 @@ thread_local std::string g_comm_error;
             return GNDT_ERR_HIP;                                                                         \
         }                                                                                                \
     } while (0)
+
+ncclDataType_t nccl_type_of(size_t elem_bytes) { return elem_bytes == 8 ? ncclUint64 : ncclUint32; }
+
+// every rank's `count` elements of `elem_bytes` (4 or 8) -> all of them, in rank order, on every rank
+int comm_all_gather(gndt_handle* h, gndt_comm* c, const void* send, void* recv, size_t count, size_t elem_bytes, hipStream_t s) {
+    if (!c->threads) {
+        RCCL_TRY(h, rccl().AllGather(send, recv, count, nccl_type_of(elem_bytes), c->nccl, s));
+        return GNDT_OK;
+    }
+    ThreadGroup& G = *c->threads;
+    const size_t bytes = count * elem_bytes;
+    HIP_TRY(h, hipStreamSynchronize(s));                       // what this rank publishes is complete
+    G.send[c->rank] = send;
+    G.barrier();
+    for (int q = 0; q < c->world; ++q) {
+        void* dst = static_cast<char*>(recv) + (size_t)q * bytes;
+        if (bytes && dst != G.send[q]) HIP_TRY(h, hipMemcpyAsync(dst, G.send[q], bytes, hipMemcpyDeviceToDevice, s));
+    }
+    HIP_TRY(h, hipStreamSynchronize(s));
+    G.barrier();                                               // everybody has read: the buffers may change again
+    return GNDT_OK;
+}
+
+// all-to-all of runs: rank r sends cnt_bytes[q] bytes at send_base + off_bytes[q] to every q != r and receives the run every
+// q holds for it at recv_base + recv_off_bytes[q] (recv_cnt_bytes[q] bytes: the same number the sender counted)
+int comm_exchange(gndt_handle* h, gndt_comm* c, const char* send_base, const uint64_t* off_bytes, const uint64_t* cnt_bytes,
+                  char* recv_base, const uint64_t* recv_off_bytes, const uint64_t* recv_cnt_bytes, hipStream_t s) {
+    const int W = c->world, me = c->rank;
+    if (!c->threads) {
+        RCCL_TRY(h, rccl().GroupStart());
+        for (int r = 0; r < W; ++r) {
+            if (r == me) continue;
+            if (cnt_bytes[r]) RCCL_TRY(h, rccl().Send(send_base + off_bytes[r], (size_t)(cnt_bytes[r] / 4), ncclFloat, r, c->nccl, s));
+            if (recv_cnt_bytes[r]) RCCL_TRY(h, rccl().Recv(recv_base + recv_off_bytes[r], (size_t)(recv_cnt_bytes[r] / 4), ncclFloat, r, c->nccl, s));
+        }
+        RCCL_TRY(h, rccl().GroupEnd());
+        return GNDT_OK;
+    }
+    ThreadGroup& G = *c->threads;
+    HIP_TRY(h, hipStreamSynchronize(s));
+    G.send[me] = send_base; G.off[me] = off_bytes; G.cnt[me] = cnt_bytes;
+    G.barrier();
+    for (int q = 0; q < W; ++q) {
+        if (q == me || !recv_cnt_bytes[q]) continue;
+        if (G.cnt[q][me] != recv_cnt_bytes[q]) { h->err = "exchange: the sender's count differs from the receiver's"; return GNDT_ERR_INVALID; }
+        HIP_TRY(h, hipMemcpyAsync(recv_base + recv_off_bytes[q], static_cast<const char*>(G.send[q]) + G.off[q][me], recv_cnt_bytes[q],
+                                  hipMemcpyDeviceToDevice, s));
+    }
+    HIP_TRY(h, hipStreamSynchronize(s));
+    G.barrier();
+    return GNDT_OK;
+}
 }  // namespace
 
 extern "C" {
@@ -149,6 +225,19 @@ int gndt_comm_create(const char id[GNDT_COMM_ID_BYTES], int32_t rank, int32_t wo
     return GNDT_OK;
 }
 
+int gndt_comm_create_threads(int32_t world, int32_t device_id, gndt_comm** out) {
+    if (!out || world < 1 || world > 1024) { g_comm_error = "bad argument"; return GNDT_ERR_INVALID; }
+    auto G = std::make_shared<ThreadGroup>();
+    G->world = world;
+    G->send.assign((size_t)world, nullptr); G->off.assign((size_t)world, nullptr); G->cnt.assign((size_t)world, nullptr);
+    for (int r = 0; r < world; ++r) {
+        out[r] = new (std::nothrow) gndt_comm;
+        if (!out[r]) { for (int q = 0; q < r; ++q) delete out[q]; return GNDT_ERR_NOMEM; }
+        out[r]->rank = r; out[r]->world = world; out[r]->device = device_id; out[r]->threads = G;
+    }
+    return GNDT_OK;
+}
+
 void gndt_comm_destroy(gndt_comm* c) {
     if (!c) return;
     if (c->nccl && rccl().ok()) (void)rccl().CommDestroy(c->nccl);
@@ -159,7 +248,7 @@ int gndt_build_global_device(gndt_handle* h, gndt_comm* c, const void* shard_xyz
                              uint64_t first_idx_base, uint64_t total_points, gndt_exchange_times* times, void* hip_stream) {
     int rc = check_ready(h);
     if (rc) return rc;
-    if (!c || !c->nccl) { h->err = "no communicator"; return GNDT_ERR_INVALID; }
+    if (!c || !c->nccl) { h->err = c && c->threads ? "gndt_build_global_device needs an RCCL communicator" : "no communicator"; return GNDT_ERR_INVALID; }
     hipStream_t s = stream_of(h, hip_stream);
     auto& X = h->exch;
     hipEvent_t* ev = X.ev;                     // (kept on the handle: an early error return leaks nothing)
@@ -550,10 +639,10 @@ int gndt_build_owned_device(gndt_handle* h, gndt_comm* c, const void* shard_xyz_
                             gndt_owned_info* info, void* hip_stream) {
     int rc = check_ready(h);
     if (rc) return rc;
-    if (!c || !c->nccl) { h->err = "no communicator"; return GNDT_ERR_INVALID; }
+    if (!c || (!c->nccl && !c->threads)) { h->err = "no communicator"; return GNDT_ERR_INVALID; }
     if (!shard_xyz_dev && n) { h->err = "null input"; return GNDT_ERR_INVALID; }
     const int W = c->world, me = c->rank;
-    if (W > 1 && !rccl().p2p()) { h->err = "this RCCL has no ncclSend / ncclRecv"; return GNDT_ERR_NO_DEVICE; }
+    if (W > 1 && !c->threads && !rccl().p2p()) { h->err = "this RCCL has no ncclSend / ncclRecv"; return GNDT_ERR_NO_DEVICE; }
     hipStream_t s = stream_of(h, hip_stream);
     h->pending.active = false;
     { const int urc = use_stream(h, s); if (urc) return urc; }
@@ -568,14 +657,14 @@ int gndt_build_owned_device(gndt_handle* h, gndt_comm* c, const void* shard_xyz_
     if (W > 1 && W <= (int)kOwnerMapMaxRanks && tuning().owner_locality) {
         if ((rc = owner_sample_launch(h, shard_xyz_dev, n, stride_bytes, s))) return rc;
         if ((rc = grow_buf(h, X.owner_msgs_all, X.owner_msgs_cap, (uint64_t)kOwnerMsgWords * W))) return rc;
-        RCCL_TRY(h, rccl().AllGather(X.owner_msg, X.owner_msgs_all, (size_t)kOwnerMsgWords, ncclUint32, c->nccl, s));
+        if ((rc = comm_all_gather(h, c, X.owner_msg, X.owner_msgs_all, (size_t)kOwnerMsgWords, 4, s))) return rc;
         if ((rc = owner_map_launch(h, X.owner_msgs_all, (uint32_t)W, s))) return rc;
     }
     // 1. split by owner; who sends how much to whom (W x W counts) follows on the stream: ONE wait for both
     if ((rc = grow_buf(h, X.d_matrix, X.matrix_cap, (uint64_t)W * W))) return rc;
     if ((rc = owner_split_launch(h, shard_xyz_dev, n, stride_bytes, first_idx_base, total_points, (uint32_t)W, s))) return rc;
     stamp(1);
-    RCCL_TRY(h, rccl().AllGather(q.totals, X.d_matrix, (size_t)W, ncclUint32, c->nccl, s));
+    if ((rc = comm_all_gather(h, c, q.totals, X.d_matrix, (size_t)W, 4, s))) return rc;
     HIP_TRY(h, hipMemcpyAsync(X.h_matrix, X.d_matrix, (size_t)W * W * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     HIP_TRY(h, hipStreamSynchronize(s));
     // (points outside the key range were dropped by the split: the other ranks are already on their way into the exchange, so
@@ -594,15 +683,14 @@ int gndt_build_owned_device(gndt_handle* h, gndt_comm* c, const void* shard_xyz_
     if ((rc = grow_buf(h, X.own_recs, X.own_cap, std::max<uint64_t>(n_own, 1)))) return rc;
     uint64_t sent = 0, received = 0;
     if (W > 1) {
-        RCCL_TRY(h, rccl().GroupStart());
+        std::vector<uint64_t> so((size_t)W), sc((size_t)W), ro((size_t)W), rcnt((size_t)W);
         for (int r = 0; r < W; ++r) {
-            if (r == me) continue;
-            const uint64_t out = X.send_cnt[r], in = recv_off[r + 1] - recv_off[r];
-            if (out) RCCL_TRY(h, rccl().Send(X.send_recs + X.send_off[r], (size_t)out * 4, ncclFloat, r, c->nccl, s));
-            if (in) RCCL_TRY(h, rccl().Recv(X.own_recs + recv_off[r], (size_t)in * 4, ncclFloat, r, c->nccl, s));
-            sent += out * sizeof(float4); received += in * sizeof(float4);
+            so[r] = X.send_off[r] * sizeof(float4); sc[r] = r == me ? 0 : X.send_cnt[r] * sizeof(float4);
+            ro[r] = recv_off[r] * sizeof(float4); rcnt[r] = r == me ? 0 : (recv_off[r + 1] - recv_off[r]) * sizeof(float4);
+            sent += sc[r]; received += rcnt[r];
         }
-        RCCL_TRY(h, rccl().GroupEnd());
+        if ((rc = comm_exchange(h, c, reinterpret_cast<const char*>(X.send_recs), so.data(), sc.data(), reinterpret_cast<char*>(X.own_recs), ro.data(),
+                                rcnt.data(), s))) return rc;
     }
     stamp(2);
     // 3. the columns this rank owns, finished: the ordinary pipeline on the records.  The column pairs and every rank's
@@ -617,7 +705,7 @@ int gndt_build_owned_device(gndt_handle* h, gndt_comm* c, const void* shard_xyz_
         if ((rc = owned_columns_enqueue(h, s))) return rc;
         hipLaunchKernelGGL(k_owned_status, dim3(1), dim3(1), 0, s, (const uint32_t*)X.d_npairs, (const PartCounters*)q.d_pc, (const Counters*)h->d_cnt,
                            (unsigned long long)n_own, X.d_colmsg + kColMsgWords * me);
-        RCCL_TRY(h, rccl().AllGather(X.d_colmsg + kColMsgWords * me, X.d_colmsg, kColMsgWords, ncclUint64, c->nccl, s));
+        if ((rc = comm_all_gather(h, c, X.d_colmsg + kColMsgWords * me, X.d_colmsg, kColMsgWords, 8, s))) return rc;
         HIP_TRY(h, hipMemcpyAsync(X.h_colmsg, X.d_colmsg, kColMsgWords * (size_t)W * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
         if ((rc = partition_resolve(h))) return rc;                    // the wait; this rank's own overflow re-runs happen here
         HIP_TRY(h, hipStreamSynchronize(s));                           // (a repeated round finds the build resolved already: the messages still have to arrive)
@@ -643,7 +731,7 @@ int gndt_build_owned_device(gndt_handle* h, gndt_comm* c, const void* shard_xyz_
     }
     hipLaunchKernelGGL(k_pairs_pad, dim3(grid_for(m_max)), dim3(256), 0, s, X.pairs, ncols, (uint32_t)m_max);
     if ((rc = grow_buf(h, X.pairs_all, X.pairs_all_cap, m_max * (uint64_t)W))) return rc;
-    RCCL_TRY(h, rccl().AllGather(X.pairs, X.pairs_all, (size_t)m_max, ncclUint64, c->nccl, s));
+    if ((rc = comm_all_gather(h, c, X.pairs, X.pairs_all, (size_t)m_max, 8, s))) return rc;
     if ((rc = global_rows_launch(h, X.pairs_all, m_max * (uint64_t)W, total_points, s))) return rc;
     if (!X.h_bad) HIP_TRY(h, hipHostMalloc(&X.h_bad, sizeof(uint32_t)));
     HIP_TRY(h, hipMemcpyAsync(X.h_totals, X.d_totals, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));

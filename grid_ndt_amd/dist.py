@@ -61,6 +61,22 @@ class Communicator:
         self.handle, self.rank, self.world = h, 0, 1
         return self
 
+    @classmethod
+    def threads(cls, world, device=0):
+        """`world` communicators whose ranks are threads of THIS process (gndt_comm_create_threads): one per calling thread."""
+        from . import _lib
+        L = _lib.lib()
+        arr = (C.c_void_p * int(world))()
+        rc = L.gndt_comm_create_threads(int(world), int(device), arr)
+        if rc:
+            raise _lib.GndtError(rc, (L.gndt_comm_last_error() or b"").decode())
+        out = []
+        for r in range(int(world)):
+            self = cls.__new__(cls)
+            self._L, self.handle, self.rank, self.world = L, C.c_void_p(arr[r]), r, int(world)
+            out.append(self)
+        return out
+
     def close(self):
         if self.handle:
             self._L.gndt_comm_destroy(self.handle)

@@ -211,6 +211,11 @@ typedef struct {
 } gndt_exchange_times;
 int gndt_comm_unique_id(char id_out[GNDT_COMM_ID_BYTES]);
 int gndt_comm_create(const char id[GNDT_COMM_ID_BYTES], int32_t rank, int32_t world, int32_t device_id, gndt_comm** out);
+/* `world` communicators whose ranks are THREADS of this process (one handle and one calling thread per rank, any devices
+ * that can copy to each other — normally one): gndt_build_owned_device then hands the runs over with device copies and host
+ * barriers instead of RCCL.  One GPU can play a whole node (the tests do), and a process that drives several handles from
+ * several threads needs no RCCL.  Every rank must make every call; destroy each communicator. */
+int gndt_comm_create_threads(int32_t world, int32_t device_id, gndt_comm** out /* [world] */);
 void gndt_comm_destroy(gndt_comm* c);
 const char* gndt_comm_last_error(void);
 /* first_idx_base = index of shard[0] in the whole cloud's binned points; total_points = binned points of the whole cloud.

@@ -287,3 +287,80 @@ def test_owner_build_fuzz_against_the_single_gpu_build(seed):
     scale = np.abs(one["cov"]).max(axis=1, keepdims=True) + 1e-30
     assert (np.abs(glob["cov"] - one["cov"]) / scale).max() < 1e-5
     assert np.allclose(glob["mean"], one["mean"], rtol=0, atol=2e-6)
+
+
+def owner_build_with_threads(cloud, P, W, bounds=None):
+    """gndt_build_owned_device ITSELF with W ranks: the ranks are W threads of this process on the one GPU, their communicators
+    a thread group (gndt_comm_create_threads: device copies + host barriers where RCCL would send and receive)."""
+    import threading
+    import torch
+    from grid_ndt_amd.dist import Communicator
+    maps = _ranks(cloud, P, W)
+    comms = Communicator.threads(W)
+    pts = torch.from_numpy(np.ascontiguousarray(cloud[1:])).cuda()
+    n = int(pts.shape[0])
+    bounds = bounds or [n * r // W for r in range(W + 1)]
+    res, errs = [None] * W, []
+
+    def rank(r):
+        try:
+            torch.cuda.set_device(0)
+            s = torch.cuda.Stream()
+            with torch.cuda.stream(s):
+                grow, info = maps[r].build_owned(comms[r], P.get("demand", "slope"), pts[bounds[r]:bounds[r + 1]], bounds[r], n, s)
+                res[r] = (maps[r].export(), grow.cpu().numpy().astype(np.int64), info)
+        except Exception as e:                         # (a rank that dies leaves the others at a barrier: report, do not hang the suite)
+            errs.append((r, repr(e)))
+            os._exit(3)
+
+    import os
+    th = [threading.Thread(target=rank, args=(r,)) for r in range(W)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=300)
+        assert not t.is_alive(), "a rank is stuck"
+    assert not errs, errs
+    for c in comms:
+        c.close()
+    N, K = res[0][2]["global_nodes"], res[0][2]["global_columns"]
+    glob = {k: np.zeros((N,) + v.shape[1:], v.dtype) for k, v in res[0][0].items() if isinstance(v, np.ndarray)}
+    seen = np.zeros(N, bool)
+    for out, grow, info in res:
+        assert (info["global_nodes"], info["global_columns"], info["ranks"]) == (N, K, W)
+        assert not seen[grow].any()
+        seen[grow] = True
+        for k in glob:
+            glob[k][grow] = out[k]
+    assert seen.all()
+    glob.update(num_nodes=N, num_columns=K, num_slopes=res[0][2]["global_slopes"])
+    return glob, [r[2] for r in res]
+
+
+@pytest.mark.parametrize("W", [2, 3, 4, 8])
+def test_the_owner_build_itself_with_several_ranks_on_one_gpu(W):
+    """Every rank runs gndt_build_owned_device (ownership from the all-gathered samples, one-pass split, all-to-all, two-segment
+    build, column round, global rows); the assembled map is the oracle's.  Only RCCL itself is replaced (thread-group
+    communicators)."""
+    cloud, P = scenes.terrain_cloud(1_200_000), TERRAIN
+    ref = parity.ref_from_cloud(cloud, P)
+    glob, infos = owner_build_with_threads(cloud, P, W)
+    parity.assert_parity(glob, ref)
+    assert glob["num_slopes"] == int(np.count_nonzero(ref["flags"] & 2))
+    sent = sum(i["bytes_sent"] for i in infos)
+    assert sent == sum(i["bytes_received"] for i in infos) and sent > 0
+    kept = 1.0 - sent / 16.0 / sum(i["owned_points"] for i in infos)
+    print("W", W, "kept", round(kept, 3), "owned", [i["owned_points"] for i in infos])
+    assert kept > 0.5                                                          # locality-aware ownership was in force
+
+
+def test_the_owner_build_itself_with_ranks_that_get_little_or_nothing():
+    cloud, P = scenes.bridge_ground(), scenes.BRIDGE_PARAMS
+    n = cloud.shape[0] - 1
+    ref = parity.ref_from_cloud(cloud, P)
+    glob, infos = owner_build_with_threads(cloud, P, 4, bounds=[0, 1000, 1000, n - 70_000, n])
+    parity.assert_parity(glob, ref)
+    cloud = scenes.campus_frame(30)                                            # fewer points than there are columns to go round
+    ref = parity.ref_from_cloud(cloud, scenes.CAMPUS_PARAMS)
+    glob, infos = owner_build_with_threads(cloud, scenes.CAMPUS_PARAMS, 5)
+    parity.assert_parity(glob, ref, adversarial=True)
