@@ -364,3 +364,19 @@ def test_the_owner_build_itself_with_ranks_that_get_little_or_nothing():
     ref = parity.ref_from_cloud(cloud, scenes.CAMPUS_PARAMS)
     glob, infos = owner_build_with_threads(cloud, scenes.CAMPUS_PARAMS, 5)
     parity.assert_parity(glob, ref, adversarial=True)
+
+
+def test_the_owner_build_itself_repeats_the_column_round_when_a_rank_re_runs_its_build():
+    """First builds without a hint guess n / 4 nodes; this cloud has more than half as many nodes as points, so both ranks' local
+    builds overflow inside the collective sequence: each re-runs its own, and BOTH repeat the column round (they read the same
+    "has to be re-run" words)."""
+    rng = np.random.default_rng(6)
+    n = 3_000_000
+    cloud = np.concatenate([np.float32([[0.0, 0.0, 0.0]]),
+                            np.stack([rng.random(n) * 200 - 100, rng.random(n) * 200 - 100, rng.random(n) * 2 - 1], 1).astype(np.float32)], 0)
+    P = dict(grid_len=0.5, z_len=0.1, slope_interval=0.08, demand="slope")
+    _, one = parity.gpu_from_cloud(cloud, P, on_device=True)
+    glob, infos = owner_build_with_threads(cloud, P, 2)
+    for k in ("sx", "sy", "sz", "count", "first_idx", "flags"):
+        assert np.array_equal(glob[k], one[k]), k
+    assert glob["num_nodes"] == one["num_nodes"] > n // 2
