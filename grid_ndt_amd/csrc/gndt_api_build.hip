@@ -1,12 +1,10 @@
-// gndt_api_build.hip — strategy PARTITION (gndt_partition.hpp, gndt_bucket.hpp): launch, pending-build resolution, gndt_build*.
+// gndt_api_build.hip — strategy PARTITION (gndt_partition.hpp, gndt_bucket3.hpp): launch, pending-build resolution, gndt_build*.
 #include "gndt_handle.hpp"
-#include "gndt_bucket4.hpp"
+#include "gndt_bucket3.hpp"
 using namespace gndt;
 using namespace gndt_host;
 
 namespace gndt_host {
-
-constexpr int kOwnerChunk = 2560;       // records per chunk of k_bucket_owner (40 KB of LDS)
 
 // prefix of the per-word column weights -> row of every staged node -> SoA rows (marks m0+1 .. m0+5)
 // `grouped`: the staging rows of a column are adjacent (k_bucket_direct): the destination pass works per column
@@ -49,15 +47,12 @@ namespace {
 uint64_t buckets_for(uint64_t n, uint64_t nodes, int slots, int load_pct) {
     const int pts_target = tuning().bucket_points;
     if (pts_target) return std::max<uint64_t>(n / (uint64_t)pts_target, 16);
-    // k_bucket_owner takes a bucket in ONE chunk of kOwnerChunk records when it can: mean 1600 leaves 3 sigma of the
-    // column-granular spread of a hash partition (a fuller bucket simply takes a second chunk)
     // Clouds of up to a few million points do not fill the chip with 2800-point buckets (200 k points: 71 workgroups for 256
     // CUs): down to 700 points per bucket below a million points, measured 5-13 % faster there (campus / bridge / terrain / uniform
     // clouds of 0.1-1 M points) and slower from 2 M points on.
     const uint64_t small_cloud = std::min<uint64_t>(2800, std::max<uint64_t>(700, n / 1024));
-    const uint64_t per_bucket = slots >= 1024 ? 6400 : (tuning().bucket_kernel == 4 ? (slots == 256 ? 800 : 1600) : small_cloud);
-    // (k_bucket_owner: two lanes own a node, so a 512-thread workgroup holds 256 nodes: average load 1/4 of that table)
-    const uint64_t node_room = (slots < 1024 && tuning().bucket_kernel == 4) ? (uint64_t)slots * load_pct * 2 / 3 : (uint64_t)slots * load_pct;
+    const uint64_t per_bucket = slots >= 1024 ? 6400 : small_cloud;
+    const uint64_t node_room = (uint64_t)slots * load_pct;
     const uint64_t want = std::max<uint64_t>(n / per_bucket, (nodes * 100) / node_room);
     return std::max<uint64_t>(want, 16);
 }
@@ -324,17 +319,8 @@ int partition_launch(gndt_handle* h, gndt_handle::Pending& P) {
     const ColumnOrder order{q.bitmap, q.word_weight, q.ncol_at};
     const StatsOut stats_out{h->st_key, h->st_sums, h->st_count, h->st_first};
     unsigned long long* dbg = tuning().stamps ? q.dbg : nullptr;
-    bool grouped = false;               // k_bucket_direct stages a column's rows next to each other
-    if (tuning().bucket_kernel == 4 && bslots != 1024) {
-        // k_bucket_owner (gndt_bucket4.hpp): nodes owned by threads, statistics in registers
-#define GNDT_LAUNCH_OWNER(T_, CH_, S_)                                                                                              \
-    hipLaunchKernelGGL((k_bucket_owner<T_, T_, CH_, S_>), bgrid, dim3(T_), 0, s, bucket_recs, range_lo, range_hi, B, gp, q.stage,  \
-                       (uint32_t)(S_ ? h->st_cap : q.stage_cap), q.ord_cf, q.ord_idx, order, h->d_cnt, q.d_pc, dbg, stats_out)
-        if (bslots == 256) { if (P.stats_only) GNDT_LAUNCH_OWNER(256, 1280, true); else GNDT_LAUNCH_OWNER(256, 1280, false); }
-        else { if (P.stats_only) GNDT_LAUNCH_OWNER(512, kOwnerChunk, true); else GNDT_LAUNCH_OWNER(512, kOwnerChunk, false); }
-#undef GNDT_LAUNCH_OWNER
-    } else if (tuning().bucket_kernel != 2) {
-        grouped = true;
+    const bool grouped = true;          // k_bucket_direct stages a column's rows next to each other
+    {
         // k_bucket_direct (gndt_bucket3.hpp): 512-slot tables with two workgroups per CU, 1024-slot tables on a retry
 #define GNDT_LAUNCH_DIRECT(T_, H_, S_)                                                                                          \
     hipLaunchKernelGGL((k_bucket_direct<T_, H_, S_>), bgrid, dim3(T_), 0, s, bucket_recs, range_lo, range_hi, B, gp, q.stage,    \
@@ -342,17 +328,6 @@ int partition_launch(gndt_handle* h, gndt_handle::Pending& P) {
         if (bslots == 1024) { if (P.stats_only) GNDT_LAUNCH_DIRECT(1024, 1024, true); else GNDT_LAUNCH_DIRECT(1024, 1024, false); }
         else { if (P.stats_only) GNDT_LAUNCH_DIRECT(512, 512, true); else GNDT_LAUNCH_DIRECT(512, 512, false); }
 #undef GNDT_LAUNCH_DIRECT
-    } else {
-#define GNDT_LAUNCH_BUCKET2(T_, H_, CH_, S_)                                                                           \
-    hipLaunchKernelGGL((k_bucket_build2<T_, H_, CH_, S_>), bgrid, dim3(T_), 0, s, bucket_recs, range_lo, range_hi, B, gp, q.stage, \
-                       (uint32_t)(S_ ? h->st_cap : q.stage_cap), q.ord_cf, q.ord_idx, order, h->d_cnt, q.d_pc, dbg, stats_out)
-            if (P.stats_only) {
-                if (bslots == 1024) GNDT_LAUNCH_BUCKET2(512, 1024, 3584, true);
-                else GNDT_LAUNCH_BUCKET2(512, 512, 1536, true);
-            }
-            else if (bslots == 1024) GNDT_LAUNCH_BUCKET2(512, 1024, 3584, false);
-            else GNDT_LAUNCH_BUCKET2(512, 512, 1536, false);
-#undef GNDT_LAUNCH_BUCKET2
     }
     HIP_TRY(h, hipGetLastError());
     mark(h, 5, s);

@@ -17,7 +17,6 @@ Tuning parse_tuning() {
     auto geti = [](const char* k, int d) { const char* v = getenv(k); return v ? atoi(v) : d; };
     t.bucket_load = geti("GNDT_BUCKET_LOAD", t.bucket_load);
     t.bucket_points = geti("GNDT_BUCKET_POINTS", t.bucket_points);
-    t.bucket_kernel = geti("GNDT_BUCKET_KERNEL", t.bucket_kernel);
     t.bucket_slots = geti("GNDT_BUCKET_SLOTS", t.bucket_slots);
     t.part_wgs = geti("GNDT_PART_WGS", t.part_wgs);
     t.two_level = geti("GNDT_TWO_LEVEL", t.two_level);

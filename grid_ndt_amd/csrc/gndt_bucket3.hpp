@@ -25,19 +25,21 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#include "gndt_bucket.hpp"
+#include "gndt_partition.hpp"
 
 namespace gndt {
 
-#ifndef GNDT_DIRECT_SUBSTAMPS
-#define GNDT_DIRECT_SUBSTAMPS 0      // diagnostic build: wave 0's waits inside the accumulate loop (bench.py --stamps: acc:0..3)
-#endif
-#ifndef GNDT_DIRECT_PREFETCH2
-#define GNDT_DIRECT_PREFETCH2 0
-#endif
 #ifndef GNDT_DIRECT_WAVES
 #define GNDT_DIRECT_WAVES 5      // waves per SIMD the register allocation aims at (512-slot variant): 5 = 96 VGPRs, no spills
 #endif
+
+// Compact per-node statistics (the gndt_stats layout): what a shard of a multi-GPU build hands to the exchange.
+// STATS = false: the bucket's nodes leave as staging rows (labels, moments) for the ordering + emit kernels.
+// STATS = true : they leave as additive statistics (key, 9 sums, count, first index) and nothing else is done:
+//                the shard's contribution to a global map (gndt_shard_stats_device).
+struct StatsOut {
+    uint64_t* key; double* sums; uint32_t* count; uint32_t* first;
+};
 
 template <int H>
 struct BucketLds3 {           // 61 KB at H = 512: two workgroups per CU
@@ -62,6 +64,66 @@ constexpr uint32_t kNoNode = 0xFFFFFFFFu;
 // Workgroup barrier that orders LDS traffic ONLY (__syncthreads() also waits for the wave's global stores): the phases of
 // the bucket kernels hand over LDS contents, their global stores are read by later kernels.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// ---- probing the node table: windows of kProbeWindow consecutive slots per round trip, all of a thread's records together ----
+// A wave waits for its slowest lane, and every probe of the one-slot-at-a-time loop (lds_find_or_insert) is a dependent LDS
+// round trip.  At the usual load (0.4) linear probing displaces a fifth of the nodes, the worst one of a bucket by ~9 slots;
+// among the 128 records a wave holds, some lane always needs most of that, so the loop ran ~9 round trips per record and
+// iteration: HALF of the accumulate phase (profiles/r03_bucket_ablation.txt).  Here a lane reads kProbeWindow slots at once
+// (independent loads, one wait), the thread's U records probe in the same rounds, and the order of the slots tried — hence
+// the table that results — is exactly linear probing's: the first slot of the sequence that holds the key or is empty.
+#ifndef GNDT_PROBE_WINDOW
+#define GNDT_PROBE_WINDOW 4
+#endif
+constexpr int kProbeWindow = GNDT_PROBE_WINDOW;
+// pos[j]: where record j's probe sequence stands (updated); done[j]: settled (slot in pos[j]); returns false on a full table.
+// One round = one window read and at most ONE compare-and-swap per record, the records' operations issued together: the
+// first slot of the window that holds the key settles the record, the first EMPTY one before that is claimed; a claim lost
+// to another key continues behind that slot.
+template <int H, int U, typename KeyArray>
+__device__ __forceinline__ bool lds_probe_insert(KeyArray& keys, uint32_t (&pos)[U], bool (&done)[U], const unsigned long long (&key)[U],
+                                                 uint32_t* n_new) {
+    for (int round = 0; round < 2 * H; ++round) {        // (every round settles a record or moves it at least one slot on)
+        bool all_done = true;
+#pragma unroll
+        for (int j = 0; j < U; ++j) all_done = all_done && done[j];
+        if (all_done) return true;
+        unsigned long long kk[U][kProbeWindow];
+#pragma unroll
+        for (int j = 0; j < U; ++j)
+#pragma unroll
+            for (int i = 0; i < kProbeWindow; ++i) kk[j][i] = keys[(pos[j] + (uint32_t)i) & (uint32_t)(H - 1)];
+        int at[U];                 // first slot of the window that holds the key or is empty (kProbeWindow: none)
+        bool claim[U];             //   ... it is empty: claim it
+        unsigned long long old[U];
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            at[j] = kProbeWindow; claim[j] = false;
+#pragma unroll
+            for (int i = kProbeWindow - 1; i >= 0; --i) {
+                const bool hit = kk[j][i] == key[j], empty = kk[j][i] == kEmptyKey;
+                if (hit || empty) { at[j] = i; claim[j] = empty; }
+            }
+            claim[j] = claim[j] && !done[j];
+        }
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            old[j] = 0ull;
+            if (claim[j]) old[j] = atomicCAS(&keys[(pos[j] + (uint32_t)at[j]) & (uint32_t)(H - 1)], (unsigned long long)kEmptyKey, key[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            if (done[j]) continue;
+            const uint32_t s = (pos[j] + (uint32_t)at[j]) & (uint32_t)(H - 1);
+            if (at[j] == kProbeWindow) { pos[j] = s; continue; }                        // nothing here: next window
+            if (!claim[j]) { pos[j] = s; done[j] = true; continue; }                    // the key is there
+            if (old[j] == kEmptyKey) { atomicAdd(n_new, 1u); pos[j] = s; done[j] = true; continue; }   // a new node
+            if (old[j] == key[j]) { pos[j] = s; done[j] = true; continue; }             // another lane inserted it meanwhile
+            pos[j] = (s + 1u) & (uint32_t)(H - 1);                                      // taken by another key: go on behind it
+        }
+    }
+    return false;
+}
 
 // slot of a node inside its bucket's table.  The bucket is chosen by the TOP bits of the column hash (bucket_of), so its
 // low bits are still uniform inside a bucket; the z level is spread over them with a full-rate 24-bit multiply.
@@ -106,46 +168,29 @@ __device__ __forceinline__ void bucket_direct_one(BucketLds3<H>& L, const uint32
     // same node: the pair is then added as ONE contribution, and a wave whose 128 records all fall into one node adds them
     // with one set of atomics.  The records of the next iteration are loaded while this one is keyed and accumulated;
     // out-of-range lanes re-read the bucket's last record instead of branching around the load.
-    float4 nxt[U];
-#if GNDT_DIRECT_PREFETCH2
-    float4 nxt2[U];                                  // two iterations ahead (a bucket is ~3 iterations: the loads of all of them are in flight early)
+#ifdef GNDT_DIRECT_SUBSTAMPS      // diagnostic build: wave 0's clock at the stages of the loop, every stage drained before it is read
+    unsigned long long st_acc[4] = {0ull, 0ull, 0ull, 0ull}, st0 = __builtin_amdgcn_s_memtime();
+#define GNDT_SUB(k) do { if (dbg) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_acc[k] += t_ - st0; st0 = t_; } } while (0)
+#else
+#define GNDT_SUB(k) do { } while (0)
 #endif
+    float4 nxt[U];
     if (lo < hi) {
 #pragma unroll
         for (int j = 0; j < U; ++j) nxt[j] = recs[min(lo + (uint32_t)(U * tid + j), hi - 1u)];
-#if GNDT_DIRECT_PREFETCH2
-#pragma unroll
-        for (int j = 0; j < U; ++j) nxt2[j] = recs[min(lo + (uint32_t)(U * T + U * tid + j), hi - 1u)];
-#endif
     }
-#if GNDT_DIRECT_SUBSTAMPS
-    unsigned long long st_acc[4] = {0ull, 0ull, 0ull, 0ull};     // diagnostics (dbg): wave 0's waits inside the accumulate loop
-#endif
     for (uint32_t base = lo; base < hi; base += (uint32_t)(U * T)) {
-#if GNDT_DIRECT_SUBSTAMPS
-        unsigned long long st0 = 0ull;
-        if (dbg) st0 = __builtin_amdgcn_s_memtime();
-#endif
         float4 rec[U];
         bool use[U];
 #pragma unroll
         for (int j = 0; j < U; ++j) { rec[j] = nxt[j]; use[j] = base + (uint32_t)(U * tid + j) < hi; }
-#if GNDT_DIRECT_PREFETCH2
-#pragma unroll
-        for (int j = 0; j < U; ++j) nxt[j] = nxt2[j];
-        if (base + (uint32_t)(2 * U * T) < hi) {   // uniform
-#pragma unroll
-            for (int j = 0; j < U; ++j) nxt2[j] = recs[min(base + (uint32_t)(2 * U * T + U * tid + j), hi - 1u)];
-        }
-#else
         if (base + (uint32_t)(U * T) < hi) {       // uniform
 #pragma unroll
             for (int j = 0; j < U; ++j) nxt[j] = recs[min(base + (uint32_t)(U * T + U * tid + j), hi - 1u)];
         }
-#endif
         PointKey k[U];
         uint32_t slot[U];
-        unsigned long long pkey[U], k0[U];
+        unsigned long long pkey[U];
 #pragma unroll
         for (int j = 0; j < U; ++j) {
             k[j] = point_key_fast(rec[j].x, rec[j].y, rec[j].z, P.ox, P.oy, P.oz, P.grid_len, P.z_len, P.inv_grid, P.inv_z);
@@ -155,18 +200,12 @@ __device__ __forceinline__ void bucket_direct_one(BucketLds3<H>& L, const uint32
         }
         const bool pair = use[0] && use[1] && pkey[0] == pkey[1];      // both records in one node: one contribution
         if (pair) use[1] = false;
+        // a wave whose records all sit in ONE node (dense cells, the zero padding): summed across the wave, one lane adds
+        const bool one_node = __all(pair) && __all(pkey[0] == __shfl(pkey[0], 0, 64));
+        if (one_node) use[0] = lane == 0;
+        unsigned long long k0[U];
 #pragma unroll
         for (int j = 0; j < U; ++j) k0[j] = L.key[slot[j]];
-#if GNDT_DIRECT_SUBSTAMPS
-        if (dbg) {                     // (a) records arrived and keyed, table reads issued
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            const unsigned long long t = __builtin_amdgcn_s_memtime();
-            st_acc[0] += t - st0; st0 = t;
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (b) the table reads are back (behind the previous iteration's atomics)
-            const unsigned long long t2 = __builtin_amdgcn_s_memtime();
-            st_acc[1] += t2 - st0; st0 = t2;
-        }
-#endif
         double c[U][9];
         uint32_t cn[U], cf[U];
 #pragma unroll
@@ -189,21 +228,27 @@ __device__ __forceinline__ void bucket_direct_one(BucketLds3<H>& L, const uint32
             for (int q = 0; q < 9; ++q) c[0][q] += c[1][q];
             cn[0] += cn[1]; cf[0] = min(cf[0], cf[1]);
         }
-        // a wave whose records all sit in ONE node (dense cells, the zero padding): sum across the wave, one lane adds
-        if (__all(pair) && __all(pkey[0] == __shfl(pkey[0], 0, 64))) {
+        if (one_node) {
 #pragma unroll
             for (int q = 0; q < 9; ++q) c[0][q] = wave_sum(c[0][q]);          // (lane 0 holds the total)
             for (int off = 32; off > 0; off >>= 1) { cn[0] += (uint32_t)__shfl_down((int)cn[0], off, 64); cf[0] = min(cf[0], (uint32_t)__shfl_down((int)cf[0], off, 64)); }
-            use[0] = lane == 0;
         }
+        GNDT_SUB(0);
+        {   // first probe missed (new node, or a node linear probing displaced): all of the thread's records probe together
+            bool done[U];
+#pragma unroll
+            for (int j = 0; j < U; ++j) done[j] = !use[j] || k0[j] == pkey[j];
+            if (!lds_probe_insert<H, U>(L.key, slot, done, pkey, &L.n_nodes)) {
+                L.overflow = 1;
+#pragma unroll
+                for (int j = 0; j < U; ++j) if (!done[j]) { use[j] = false; slot[j] = 0; }
+            }
+        }
+        GNDT_SUB(base == lo ? 1 : 2);
 #pragma unroll
         for (int j = 0; j < U; ++j) {
-            uint32_t s = slot[j];
-            bool u = use[j];
-            if (u && k0[j] != pkey[j]) {                               // first probe missed: new node or a collision
-                s = lds_find_or_insert<H>(L.key, slot[j], pkey[j], &L.n_nodes);
-                if (s >= (uint32_t)H) { L.overflow = 1; u = false; }
-            }
+            const uint32_t s = slot[j];
+            const bool u = use[j];
             if (u) {
                 atomicAdd(&L.sum[0][s], c[j][0]); atomicAdd(&L.sum[1][s], c[j][1]); atomicAdd(&L.sum[2][s], c[j][2]);
                 atomicAdd(&L.sum[3][s], c[j][3]); atomicAdd(&L.sum[4][s], c[j][4]); atomicAdd(&L.sum[5][s], c[j][5]);
@@ -212,16 +257,9 @@ __device__ __forceinline__ void bucket_direct_one(BucketLds3<H>& L, const uint32
                 atomicMin(&L.first[s], cf[j]);
             }
         }
-#if GNDT_DIRECT_SUBSTAMPS
-        if (dbg) {                     // (c) contributions computed, atomics issued; (d) ... and retired
-            const unsigned long long t = __builtin_amdgcn_s_memtime();
-            st_acc[2] += t - st0; st0 = t;
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            st_acc[3] += __builtin_amdgcn_s_memtime() - st0;
-        }
-#endif
+        GNDT_SUB(3);
     }
-#if GNDT_DIRECT_SUBSTAMPS
+#ifdef GNDT_DIRECT_SUBSTAMPS
     if (dbg && tid == 0) { for (int k = 0; k < 4; ++k) dbg[(size_t)bucket * 16 + 8 + k] = st_acc[k]; }
 #endif
     __syncthreads();

@@ -194,8 +194,7 @@ using namespace gndt;
 struct Tuning {
     int bucket_load = 60;        // GNDT_BUCKET_LOAD    average LDS-table load (percent) that sizes the bucket count
     int bucket_points = 0;       // GNDT_BUCKET_POINTS  points per bucket (0 = derived)
-    int bucket_kernel = 3;       // GNDT_BUCKET_KERNEL  3 = k_bucket_direct (default), 4 = k_bucket_owner, 2 = k_bucket_build2 (A/B measurements)
-    int bucket_slots = 0;        // GNDT_BUCKET_SLOTS   k_bucket_build2 variant (0 = 512, 1024 on retry)
+    int bucket_slots = 0;        // GNDT_BUCKET_SLOTS   LDS table of the first attempt (0 = 512, 1024 on a retry)
     int part_wgs = 256;          // GNDT_PART_WGS       workgroups of the exact counting partition
     int two_level = -1;          // GNDT_TWO_LEVEL      0 = never use the two-level partition
     int l1_rep = 1;              // GNDT_L1_REP         level-1 cursor replicas
@@ -223,7 +222,7 @@ void tuning_force_stamps(bool on);   // bench.py --stamps flips this after the t
 
 inline void mark(gndt_handle* h, int i, hipStream_t s) {
     if (!h->prof || !h->ev[h->ev_set][i]) return;
-    if (h->prof == 2) {   // k_bucket_build2 sits between marks 4 and 5, k_accumulate between 1 and 2
+    if (h->prof == 2) {   // the bucket kernel sits between marks 4 and 5, k_accumulate between 1 and 2
         const int lo = h->last_strategy != GNDT_STRATEGY_ATOMIC ? 4 : 1;
         if (i != lo && i != lo + 1) return;
     }

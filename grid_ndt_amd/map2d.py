@@ -396,8 +396,7 @@ class TwoDmap:
     # kernels that stream the cloud 12 B/point, the bucket kernel 12 B/point + 76 B/node, node kernels 76 B/node
     KERNEL_OF_PHASE = {"accumulate": "k_accumulate", "hist": "k_part_hist", "scatter": "k_part_scatter",
                        "level1": "k_part2_level1", "level2": "k_part2_level2",
-                       # GNDT_BUCKET_KERNEL picks the bucket kernel (gndt_api_build.hip); k_bucket_direct unless told otherwise
-                       "bucket_build": {"2": "k_bucket_build2", "4": "k_bucket_owner"}.get(os.environ.get("GNDT_BUCKET_KERNEL", ""), "k_bucket_direct"),
+                       "bucket_build": "k_bucket_direct",
                        "columns": "k_tab_columns", "rows": "k_tab_rows", "emit": "k_emit_rows"}
     POINT_PHASES = ("accumulate", "hist", "scatter", "level1", "level2")
     POINT_AND_NODE_PHASES = ("bucket_build",)
@@ -439,7 +438,6 @@ class TwoDmap:
         arr = (C.c_double * 10)()
         nb = C.c_uint32()
         self._check(self._L.gndt_debug_bucket_phases(self._h, arr, C.byref(nb)))
-        # (k_bucket_owner fills [0..3] and the four accumulate sub-phases classify / scan / scatter / reduce in [6..9])
         names = ("clear", "accumulate", "columns", "rows", "-", "-", "acc:0", "acc:1", "acc:2", "acc:3")
         return dict(zip(names, list(arr))), nb.value
 
