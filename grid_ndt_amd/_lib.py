@@ -15,7 +15,7 @@ SOURCES = ["gndt_api_core.hip", "gndt_api_table.hip", "gndt_api_build.hip", "gnd
 HEADERS = ["gndt_handle.hpp", "gndt_kernels.hpp", "gndt_table.hpp", "gndt_cost.hpp", "gndt_pack.hpp", "gndt_partition.hpp", "gndt_bucket3.hpp", "gndt_tile.hpp", "gndt_exchange.hpp", "gndt_math.hpp", os.path.join(_ROOT, "include", "gndt.h")]
 
 GNDT_OK = 0
-ERR_NAMES = {0: "OK", 1: "INVALID", 2: "NO_DEVICE", 3: "HIP", 4: "KEY_RANGE", 5: "CAPACITY", 6: "NOMEM"}
+ERR_NAMES = {0: "OK", 1: "INVALID", 2: "NO_DEVICE", 3: "HIP", 4: "KEY_RANGE", 5: "CAPACITY", 6: "NOMEM", 7: "PEER"}
 
 
 class GndtError(RuntimeError):
@@ -219,6 +219,11 @@ def lib():
     L.gndt_owned_columns_device.argtypes = [H, C.POINTER(vp), C.POINTER(u64), vp]
     L.gndt_owned_global_rows_device.argtypes = [H, vp, u64, u64, C.POINTER(vp), C.POINTER(u64), C.POINTER(u64), vp]
     L.gndt_build_owned_device.argtypes = [H, vp, vp, C.c_size_t, C.c_size_t, u64, u64, C.POINTER(vp), C.POINTER(OwnedInfo), vp]
+    L.gndt_gather_owned_map_device.argtypes = [H, vp, C.c_int32, vp]
+    L.gndt_owned_pack_rows_device.argtypes = [H, C.POINTER(vp), C.POINTER(u64), vp]
+    L.gndt_adopt_rows_device.argtypes = [H, vp, u64, u64, u64, u64, vp]
+    for name in ("gndt_gather_owned_map_device", "gndt_owned_pack_rows_device", "gndt_adopt_rows_device"):
+        getattr(L, name).restype = C.c_int
     for name in ("gndt_comm_unique_id", "gndt_comm_create", "gndt_build_global_device", "gndt_owner_split_device",
                  "gndt_build_records_device", "gndt_owned_columns_device", "gndt_owned_global_rows_device", "gndt_build_owned_device"):
         getattr(L, name).restype = C.c_int

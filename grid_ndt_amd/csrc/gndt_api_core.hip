@@ -101,16 +101,18 @@ void free_part(gndt_handle* h) {
 int ensure_stage(gndt_handle* h, uint64_t nodes) {
     auto& q = h->part;
     if (nodes <= q.stage_cap) return GNDT_OK;
-    void* ptrs[] = {q.stage, q.ord_cf, q.ord_idx, q.inv, q.row_ncol};
+    void* ptrs[] = {q.stage, q.ord_cf, q.ord_idx, q.inv};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
-    q.stage = nullptr; q.ord_cf = q.ord_idx = q.inv = q.row_ncol = nullptr;
+    q.stage = nullptr; q.ord_cf = q.ord_idx = q.inv = nullptr;
     q.stage_cap = 0;
     HIP_TRY(h, hipMalloc(&q.stage, nodes * sizeof(StageRow)));
-    uint32_t** arrs[] = {&q.ord_cf, &q.ord_idx, &q.inv, &q.row_ncol};
+    uint32_t** arrs[] = {&q.ord_cf, &q.ord_idx, &q.inv};
     for (auto a : arrs) HIP_TRY(h, hipMalloc(a, nodes * 4));
     q.stage_cap = nodes;
-    return GNDT_OK;
+    // (the column index of the result rows has its own capacity: an adopted map — gndt_adopt_rows_device — can be larger than
+    // anything this handle staged)
+    return grow_buf(h, q.row_ncol, q.row_ncol_cap, nodes);
 }
 
 // Bucket count: ~4096 points per bucket, and few enough nodes per bucket for the LDS table
@@ -236,7 +238,7 @@ void gndt_destroy(gndt_handle* h) {
         auto& X = h->exch;
         void* xp[] = {X.d_counts, X.keys_in, X.keys_all, X.keys_sorted, X.canon, X.d_unique, X.d_missing, X.scratch, X.packed, X.pfirst, X.r_sums, X.r_count,
                       X.send_recs, X.own_recs, X.d_matrix, X.d_split_cnt, X.pairs, X.pairs_all, X.d_npairs, X.global_row, X.d_totals,
-                      X.owner_msg, X.owner_msgs_all, X.bkey, X.bcnt, X.bown, X.d_owner_full, X.d_colmsg, X.gw};
+                      X.owner_msg, X.owner_msgs_all, X.bkey, X.bcnt, X.bown, X.d_owner_full, X.d_colmsg, X.gw, X.grec, X.grec_all, X.d_tally, X.d_status};
         for (void* p : xp) if (p) (void)hipFree(p);
         if (X.h_counts) (void)hipHostFree(X.h_counts);
         if (X.h_matrix) (void)hipHostFree(X.h_matrix);
@@ -244,6 +246,7 @@ void gndt_destroy(gndt_handle* h) {
         if (X.h_totals) (void)hipHostFree(X.h_totals);
         if (X.h_colmsg) (void)hipHostFree(X.h_colmsg);
         if (X.h_bad) (void)hipHostFree(X.h_bad);
+        if (X.h_tally) (void)hipHostFree(X.h_tally);
         for (auto& e : X.ev) if (e) (void)hipEventDestroy(e);
     }
     if (h->xstream_ev) (void)hipEventDestroy(h->xstream_ev);

@@ -25,6 +25,7 @@ struct ThreadGroup {
     uint64_t generation = 0;
     std::vector<const void*> send;                  // per rank: what it publishes for the collective in flight
     std::vector<const uint64_t*> off, cnt;          // exchange: byte offset / byte count of the run for every destination
+    std::vector<int> ok;                            // per rank: it reached the collective in good order (0: its buffers are not to be read)
     void barrier() {
         std::unique_lock<std::mutex> lk(m);
         const uint64_t g = generation;
@@ -53,7 +54,10 @@ thread_local std::string g_comm_error;
 
 ncclDataType_t nccl_type_of(size_t elem_bytes) { return elem_bytes == 8 ? ncclUint64 : ncclUint32; }
 
-// every rank's `count` elements of `elem_bytes` (4 or 8) -> all of them, in rank order, on every rank
+// every rank's `count` elements of `elem_bytes` (4 or 8) -> all of them, in rank order, on every rank.
+// Thread ranks: a rank never returns between the two barriers of a collective (the others would wait for it for ever, and read
+// buffers it has freed): what goes wrong in between is recorded, the second barrier is passed, then it is reported — and a
+// rank that arrives in trouble says so (ThreadGroup::ok), which every rank sees and reports as GNDT_ERR_PEER.
 int comm_all_gather(gndt_handle* h, gndt_comm* c, const void* send, void* recv, size_t count, size_t elem_bytes, hipStream_t s) {
     if (!c->threads) {
         RCCL_TRY(h, rccl().AllGather(send, recv, count, nccl_type_of(elem_bytes), c->nccl, s));
@@ -61,16 +65,24 @@ int comm_all_gather(gndt_handle* h, gndt_comm* c, const void* send, void* recv, 
     }
     ThreadGroup& G = *c->threads;
     const size_t bytes = count * elem_bytes;
-    HIP_TRY(h, hipStreamSynchronize(s));                       // what this rank publishes is complete
-    G.send[c->rank] = send;
+    int rc = GNDT_OK;
+    if (hipStreamSynchronize(s) != hipSuccess) { h->err = "hipStreamSynchronize failed before a collective"; rc = GNDT_ERR_HIP; }   // what this rank publishes is complete
+    G.send[c->rank] = send; G.ok[c->rank] = rc == GNDT_OK;
     G.barrier();
-    for (int q = 0; q < c->world; ++q) {
-        void* dst = static_cast<char*>(recv) + (size_t)q * bytes;
-        if (bytes && dst != G.send[q]) HIP_TRY(h, hipMemcpyAsync(dst, G.send[q], bytes, hipMemcpyDeviceToDevice, s));
+    bool peers_ok = true;
+    for (int q = 0; q < c->world; ++q) peers_ok = peers_ok && G.ok[q];
+    if (rc == GNDT_OK && peers_ok) {
+        for (int q = 0; q < c->world && rc == GNDT_OK; ++q) {
+            void* dst = static_cast<char*>(recv) + (size_t)q * bytes;
+            if (bytes && dst != G.send[q] && hipMemcpyAsync(dst, G.send[q], bytes, hipMemcpyDeviceToDevice, s) != hipSuccess) {
+                h->err = "hipMemcpyAsync failed inside a collective"; rc = GNDT_ERR_HIP;
+            }
+        }
+        if (hipStreamSynchronize(s) != hipSuccess && rc == GNDT_OK) { h->err = "hipStreamSynchronize failed inside a collective"; rc = GNDT_ERR_HIP; }
     }
-    HIP_TRY(h, hipStreamSynchronize(s));
     G.barrier();                                               // everybody has read: the buffers may change again
-    return GNDT_OK;
+    if (rc == GNDT_OK && !peers_ok) { h->err = "another rank failed on its way into a collective"; rc = GNDT_ERR_PEER; }
+    return rc;
 }
 
 // all-to-all of runs: rank r sends cnt_bytes[q] bytes at send_base + off_bytes[q] to every q != r and receives the run every
@@ -89,18 +101,24 @@ int comm_exchange(gndt_handle* h, gndt_comm* c, const char* send_base, const uin
         return GNDT_OK;
     }
     ThreadGroup& G = *c->threads;
-    HIP_TRY(h, hipStreamSynchronize(s));
-    G.send[me] = send_base; G.off[me] = off_bytes; G.cnt[me] = cnt_bytes;
+    int rc = GNDT_OK;
+    if (hipStreamSynchronize(s) != hipSuccess) { h->err = "hipStreamSynchronize failed before a collective"; rc = GNDT_ERR_HIP; }
+    G.send[me] = send_base; G.off[me] = off_bytes; G.cnt[me] = cnt_bytes; G.ok[me] = rc == GNDT_OK;
     G.barrier();
-    for (int q = 0; q < W; ++q) {
-        if (q == me || !recv_cnt_bytes[q]) continue;
-        if (G.cnt[q][me] != recv_cnt_bytes[q]) { h->err = "exchange: the sender's count differs from the receiver's"; return GNDT_ERR_INVALID; }
-        HIP_TRY(h, hipMemcpyAsync(recv_base + recv_off_bytes[q], static_cast<const char*>(G.send[q]) + G.off[q][me], recv_cnt_bytes[q],
-                                  hipMemcpyDeviceToDevice, s));
+    bool peers_ok = true;
+    for (int q = 0; q < W; ++q) peers_ok = peers_ok && G.ok[q];
+    if (rc == GNDT_OK && peers_ok) {
+        for (int q = 0; q < W && rc == GNDT_OK; ++q) {
+            if (q == me || !recv_cnt_bytes[q]) continue;
+            if (G.cnt[q][me] != recv_cnt_bytes[q]) { h->err = "exchange: the sender's count differs from the receiver's"; rc = GNDT_ERR_INVALID; break; }
+            if (hipMemcpyAsync(recv_base + recv_off_bytes[q], static_cast<const char*>(G.send[q]) + G.off[q][me], recv_cnt_bytes[q],
+                               hipMemcpyDeviceToDevice, s) != hipSuccess) { h->err = "hipMemcpyAsync failed inside a collective"; rc = GNDT_ERR_HIP; }
+        }
+        if (hipStreamSynchronize(s) != hipSuccess && rc == GNDT_OK) { h->err = "hipStreamSynchronize failed inside a collective"; rc = GNDT_ERR_HIP; }
     }
-    HIP_TRY(h, hipStreamSynchronize(s));
-    G.barrier();
-    return GNDT_OK;
+    G.barrier();                                               // (the senders' offset / count vectors are read until here)
+    if (rc == GNDT_OK && !peers_ok) { h->err = "another rank failed on its way into a collective"; rc = GNDT_ERR_PEER; }
+    return rc;
 }
 }  // namespace
 
@@ -230,6 +248,7 @@ int gndt_comm_create_threads(int32_t world, int32_t device_id, gndt_comm** out) 
     auto G = std::make_shared<ThreadGroup>();
     G->world = world;
     G->send.assign((size_t)world, nullptr); G->off.assign((size_t)world, nullptr); G->cnt.assign((size_t)world, nullptr);
+    G->ok.assign((size_t)world, 1);
     for (int r = 0; r < world; ++r) {
         out[r] = new (std::nothrow) gndt_comm;
         if (!out[r]) { for (int q = 0; q < r; ++q) delete out[q]; return GNDT_ERR_NOMEM; }
@@ -255,22 +274,31 @@ int gndt_build_global_device(gndt_handle* h, gndt_comm* c, const void* shard_xyz
     if (times) for (int i = 0; i < 4; ++i) if (!ev[i]) HIP_TRY(h, hipEventCreate(&ev[i]));
     auto stamp = [&](int i) { if (times) (void)hipEventRecord(ev[i], s); };
     stamp(0);
-    // 1. this rank's shard -> statistics of its occupied nodes (the partition pipeline's statistics epilogue)
-    gndt_stats st;
-    rc = gndt_shard_stats_device(h, shard_xyz_dev, n, stride_bytes, first_idx_base, &st, hip_stream);
-    if (rc) return rc;
+    // 1. this rank's shard -> statistics of its occupied nodes (the partition pipeline's statistics epilogue).  A failure here (a
+    //    point outside the key range, a capacity error) does not end the call: the other ranks are on their way into the
+    //    collectives, so this rank's code travels with its node count and ALL ranks leave together after the first all-gather.
+    gndt_stats st{};
+    const int shard_rc = gndt_shard_stats_device(h, shard_xyz_dev, n, stride_bytes, first_idx_base, &st, hip_stream);
+    const std::string shard_err = shard_rc ? h->err : std::string();
     stamp(1);
-    const uint32_t m = (uint32_t)st.num_nodes;
-    // 2. node counts of every rank (one tiny all-gather; the host needs them to size the key exchange)
+    const uint32_t m = shard_rc ? 0u : (uint32_t)st.num_nodes;
+    // 2. node counts of every rank (one tiny all-gather; the host needs them to size the key exchange), status in the top byte
     const int W = c->world;
+    if (W > 1024) { h->err = "more than 1024 ranks"; return GNDT_ERR_INVALID; }
     if ((rc = grow_buf(h, X.d_counts, X.counts_cap, (uint64_t)W))) return rc;
     if (!X.h_counts) HIP_TRY(h, hipHostMalloc(&X.h_counts, 1024 * sizeof(unsigned long long)));
-    if (W > 1024) { h->err = "more than 1024 ranks"; return GNDT_ERR_INVALID; }
-    X.h_counts[c->rank] = m;
+    X.h_counts[c->rank] = (unsigned long long)m | ((unsigned long long)(shard_rc & 0xFF) << 56);
     HIP_TRY(h, hipMemcpyAsync(X.d_counts + c->rank, X.h_counts + c->rank, sizeof(unsigned long long), hipMemcpyHostToDevice, s));
     RCCL_TRY(h, rccl().AllGather(X.d_counts + c->rank, X.d_counts, 1, ncclUint64, c->nccl, s));
     HIP_TRY(h, hipMemcpyAsync(X.h_counts, X.d_counts, (size_t)W * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
     HIP_TRY(h, hipStreamSynchronize(s));
+    for (int r = 0; r < W; ++r) {
+        const int code = (int)(X.h_counts[r] >> 56);
+        if (!code) continue;
+        if (shard_rc) { h->err = shard_err; return shard_rc; }
+        h->err = "rank " + std::to_string(r) + " could not build its shard (error " + std::to_string(code) + "): the global build was abandoned by all ranks";
+        return GNDT_ERR_PEER;
+    }
     uint64_t m_max = 1;
     for (int r = 0; r < W; ++r) m_max = std::max<uint64_t>(m_max, X.h_counts[r]);
     // 3. every rank's keys, padded to the longest list -> sorted unique union = canonical node order (identical on all ranks)
@@ -324,8 +352,17 @@ int gndt_build_global_device(gndt_handle* h, gndt_comm* c, const void* shard_xyz
     rc = gndt_finalize_stats_device(h, &red, total_points, hip_stream);
     if (rc) return rc;
     stamp(3);
+    // a key of this rank that the canonical union does not hold would have lost its statistics silently (k_exchange_scatter counts them)
+    if (!X.h_bad) HIP_TRY(h, hipHostMalloc(&X.h_bad, sizeof(uint32_t)));
+    HIP_TRY(h, hipMemcpyAsync(X.h_bad, X.d_missing, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(h, hipStreamSynchronize(s));
+    if (*X.h_bad) {
+        const uint32_t lost = *X.h_bad;
+        HIP_TRY(h, hipMemsetAsync(X.d_missing, 0, sizeof(uint32_t), s));
+        h->err = std::to_string(lost) + " node(s) of this rank are missing from the union of the ranks' keys";
+        return GNDT_ERR_INVALID;
+    }
     if (times) {
-        HIP_TRY(h, hipStreamSynchronize(s));
         float a = 0, b = 0, d = 0;
         (void)hipEventElapsedTime(&a, ev[0], ev[1]); (void)hipEventElapsedTime(&b, ev[1], ev[2]); (void)hipEventElapsedTime(&d, ev[2], ev[3]);
         times->shard_ms = a; times->exchange_ms = b; times->finalize_ms = d;
@@ -391,7 +428,7 @@ int owner_split_launch(gndt_handle* h, const void* xyz, size_t n, size_t stride_
     if ((rc = ensure_part_counters(h))) return rc;
     if (!X.d_split_cnt) HIP_TRY(h, hipMalloc(&X.d_split_cnt, sizeof(Counters)));
     if (!X.h_split_cnt) HIP_TRY(h, hipHostMalloc(&X.h_split_cnt, sizeof(Counters)));
-    if (!X.h_matrix) HIP_TRY(h, hipHostMalloc(&X.h_matrix, ((size_t)kMaxRanks * kMaxRanks + kMaxRanks + 1) * sizeof(uint32_t)));
+    if (!X.h_matrix) HIP_TRY(h, hipHostMalloc(&X.h_matrix, ((size_t)kMaxRanks * (kMaxRanks + 1) + kMaxRanks + 1) * sizeof(uint32_t)));
     HIP_TRY(h, hipMemsetAsync(X.d_split_cnt, 0, sizeof(Counters), s));
     const uint32_t nwg = (uint32_t)std::min<uint64_t>((uint64_t)tuning().part_wgs, std::max<uint64_t>(1, n / 8192));
     if ((rc = grow_buf(h, q.hist, q.hist_cap, (uint64_t)nwg * W))) return rc;
@@ -407,7 +444,7 @@ int owner_split_launch(gndt_handle* h, const void* xyz, size_t n, size_t stride_
     const uint32_t compress = total_points < (uint64_t)kWeightIndexLimit ? 1u : 0u;
     const float* p = static_cast<const float*>(xyz);
     // the block table all ranks made from the same samples (owner_map_launch), if it is for this many ranks; else hash ownership
-    const OwnerMap M = (X.owner_map_world == W && X.bkey) ? OwnerMap{X.bkey, X.bown, kOwnerSlots - 1u} : OwnerMap{nullptr, nullptr, 0u};
+    const OwnerMap M = (X.owner_map_world == W && X.bkey) ? OwnerMap{X.bkey, X.bown, kOwnerSlots - 1u, X.d_owner_full} : OwnerMap{nullptr, nullptr, 0u, nullptr};
     // ONE pass: level 1 of the partition pipeline with the owner as digit (k_part2_level1<.., OWNER>): owner r's run starts at
     // r * cap, every run could take the whole shard.  (W x shard records of address space: beyond 2^32, or with more ranks than
     // the tile sort's fan-out, the two-pass counting partition packs the runs instead.)
@@ -427,7 +464,7 @@ int owner_split_launch(gndt_handle* h, const void* xyz, size_t n, size_t stride_
                                q.totals, (uint32_t)cap, (uint32_t*)nullptr, X.send_recs, X.d_split_cnt, q.d_pc, compress, M);
         HIP_TRY(h, hipGetLastError());
         X.split_cap = cap;
-        uint32_t* h_base = X.h_matrix + (size_t)kMaxRanks * kMaxRanks;
+        uint32_t* h_base = X.h_matrix + (size_t)kMaxRanks * (kMaxRanks + 1);
         HIP_TRY(h, hipMemcpyAsync(h_base, q.totals, (size_t)W * 4, hipMemcpyDeviceToHost, s));
     } else {
         if ((rc = grow_buf(h, X.send_recs, X.send_cap, std::max<uint64_t>(n, 1)))) return rc;
@@ -444,7 +481,7 @@ int owner_split_launch(gndt_handle* h, const void* xyz, size_t n, size_t stride_
             hipLaunchKernelGGL(k_part_scatter<4>, dim3(nwg), dim3(kPartThreads), lds, s, p, (uint64_t)n, (uint32_t)first_base, gp, W, q.hist, q.totals,
                                q.bucket_base, X.send_recs, compress, kPartModeOwner, M);
         HIP_TRY(h, hipGetLastError());
-        uint32_t* h_base = X.h_matrix + (size_t)kMaxRanks * kMaxRanks;
+        uint32_t* h_base = X.h_matrix + (size_t)kMaxRanks * (kMaxRanks + 1);
         HIP_TRY(h, hipMemcpyAsync(h_base, q.bucket_base, ((size_t)W + 1) * 4, hipMemcpyDeviceToHost, s));
     }
     HIP_TRY(h, hipMemcpyAsync(X.h_split_cnt, X.d_split_cnt, sizeof(Counters), hipMemcpyDeviceToHost, s));
@@ -452,7 +489,7 @@ int owner_split_launch(gndt_handle* h, const void* xyz, size_t n, size_t stride_
 }
 int owner_split_finish(gndt_handle* h, uint32_t W) {        // (after the stream has been waited for)
     auto& X = h->exch;
-    const uint32_t* h_base = X.h_matrix + (size_t)kMaxRanks * kMaxRanks;
+    const uint32_t* h_base = X.h_matrix + (size_t)kMaxRanks * (kMaxRanks + 1);
     for (uint32_t r = 0; r < W; ++r) {
         if (X.split_one_pass) { X.send_off[r] = (uint64_t)r * X.split_cap; X.send_cnt[r] = h_base[r]; }
         else { X.send_off[r] = h_base[r]; X.send_cnt[r] = h_base[r + 1] - h_base[r]; }
@@ -631,6 +668,7 @@ int gndt_owned_global_rows_device(gndt_handle* h, const uint64_t* all_pairs_dev,
     *global_row_dev = X.global_row;
     if (global_nodes) *global_nodes = X.h_totals[0];
     if (global_columns) *global_columns = X.h_totals[1];
+    X.owned_serial = h->result_serial; X.owned_world = 0;      // (gndt_owned_pack_rows_device may follow; the gather needs gndt_build_owned_device)
     return GNDT_OK;
 }
 
@@ -640,37 +678,68 @@ int gndt_build_owned_device(gndt_handle* h, gndt_comm* c, const void* shard_xyz_
     int rc = check_ready(h);
     if (rc) return rc;
     if (!c || (!c->nccl && !c->threads)) { h->err = "no communicator"; return GNDT_ERR_INVALID; }
-    if (!shard_xyz_dev && n) { h->err = "null input"; return GNDT_ERR_INVALID; }
     const int W = c->world, me = c->rank;
+    if (W > (int)kMaxRanks) { h->err = "world must be 1..1024"; return GNDT_ERR_INVALID; }
     if (W > 1 && !c->threads && !rccl().p2p()) { h->err = "this RCCL has no ncclSend / ncclRecv"; return GNDT_ERR_NO_DEVICE; }
     hipStream_t s = stream_of(h, hip_stream);
     h->pending.active = false;
     { const int urc = use_stream(h, s); if (urc) return urc; }
     auto& q = h->part;
     auto& X = h->exch;
+    X.owned_serial = 0;
     hipEvent_t* ev = X.ev;                     // (kept on the handle: an early error return leaks nothing)
     if (info) for (int i = 0; i < 5; ++i) if (!ev[i]) HIP_TRY(h, hipEventCreate(&ev[i]));
     auto stamp = [&](int i) { if (info) (void)hipEventRecord(ev[i], s); };
+    // ---- errors and collectives ----
+    // The ranks meet in five collectives.  A rank that fails on its own (bad input, a point outside the key range, a build
+    // that does not fit) must not simply return: the others would wait for it in the next collective.  Its error code
+    // travels instead — with its row of the send-count matrix, then with its column message — and every rank that sees a
+    // non-zero code leaves at that point: the failing rank with its own error, the others with GNDT_ERR_PEER.  What
+    // cannot be reported this way is fatal for the group, as the loss of a rank is: a failing collective itself, and running
+    // out of memory for the buffers allocated here, before the first collective, or between two collectives.
+    int err = GNDT_OK;                         // this rank's first error; the protocol goes on with empty contributions
+    std::string err_msg;
+    auto note = [&](int code) { if (code && !err) { err = code; err_msg = h->err; } return code == GNDT_OK; };
+    auto leave = [&]() { h->err = err_msg; return err; };
+    auto peer_failed = [&](int r, unsigned long long code) {
+        h->err = "rank " + std::to_string(r) + " reported error " + std::to_string(code) + ": the owner-partitioned build was abandoned by all ranks";
+        return GNDT_ERR_PEER;
+    };
+    const uint32_t RW = (uint32_t)W + 1u;      // a rank's row of the matrix: W send counts and its status word
+    if ((rc = grow_buf(h, X.d_matrix, X.matrix_cap, (uint64_t)W * RW))) return rc;
+    if (!X.h_matrix) HIP_TRY(h, hipHostMalloc(&X.h_matrix, ((size_t)kMaxRanks * (kMaxRanks + 1) + kMaxRanks + 1) * sizeof(uint32_t)));
+    if (!X.d_colmsg) HIP_TRY(h, hipMalloc(&X.d_colmsg, kColMsgWords * (size_t)kMaxRanks * sizeof(unsigned long long)));
+    if (!X.h_colmsg) HIP_TRY(h, hipHostMalloc(&X.h_colmsg, kColMsgWords * ((size_t)kMaxRanks + 1) * sizeof(unsigned long long)));
+    if (!X.d_split_cnt) HIP_TRY(h, hipMalloc(&X.d_split_cnt, sizeof(Counters)));
+    if (!shard_xyz_dev && n) { h->err = "null input"; note(GNDT_ERR_INVALID); }
     stamp(0);
     // 0. who owns what: everybody's samples (one fixed-size all-gather, no wait) -> the block table, identical on every rank
     X.owner_map_world = 0;
     if (W > 1 && W <= (int)kOwnerMapMaxRanks && tuning().owner_locality) {
-        if ((rc = owner_sample_launch(h, shard_xyz_dev, n, stride_bytes, s))) return rc;
+        if (!X.owner_msg) HIP_TRY(h, hipMalloc(&X.owner_msg, (size_t)kOwnerMsgWords * 4));
         if ((rc = grow_buf(h, X.owner_msgs_all, X.owner_msgs_cap, (uint64_t)kOwnerMsgWords * W))) return rc;
+        if (err || !note(owner_sample_launch(h, shard_xyz_dev, n, stride_bytes, s)))
+            HIP_TRY(h, hipMemsetAsync(X.owner_msg, 0xFF, (size_t)kOwnerMsgWords * 4, s));      // (no samples; nobody will use the table)
         if ((rc = comm_all_gather(h, c, X.owner_msg, X.owner_msgs_all, (size_t)kOwnerMsgWords, 4, s))) return rc;
-        if ((rc = owner_map_launch(h, X.owner_msgs_all, (uint32_t)W, s))) return rc;
+        if (!err) note(owner_map_launch(h, X.owner_msgs_all, (uint32_t)W, s));
     }
-    // 1. split by owner; who sends how much to whom (W x W counts) follows on the stream: ONE wait for both
-    if ((rc = grow_buf(h, X.d_matrix, X.matrix_cap, (uint64_t)W * W))) return rc;
-    if ((rc = owner_split_launch(h, shard_xyz_dev, n, stride_bytes, first_idx_base, total_points, (uint32_t)W, s))) return rc;
+    // 1. split by owner; who sends how much to whom (W x W counts, and every rank's status word) follows on the stream
+    if (!err) note(owner_split_launch(h, shard_xyz_dev, n, stride_bytes, first_idx_base, total_points, (uint32_t)W, s));
     stamp(1);
-    if ((rc = comm_all_gather(h, c, q.totals, X.d_matrix, (size_t)W, 4, s))) return rc;
-    HIP_TRY(h, hipMemcpyAsync(X.h_matrix, X.d_matrix, (size_t)W * W * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    uint32_t* my_row = X.d_matrix + (size_t)me * RW;
+    if (!err) HIP_TRY(h, hipMemcpyAsync(my_row, q.totals, (size_t)W * 4, hipMemcpyDeviceToDevice, s));
+    else HIP_TRY(h, hipMemsetAsync(my_row, 0, (size_t)W * 4, s));
+    hipLaunchKernelGGL(k_split_status, dim3(1), dim3(1), 0, s, (const Counters*)(err ? nullptr : X.d_split_cnt), (uint32_t)err, (uint32_t)GNDT_ERR_KEY_RANGE,
+                       my_row + W);
+    if ((rc = comm_all_gather(h, c, my_row, X.d_matrix, (size_t)RW, 4, s))) return rc;
+    HIP_TRY(h, hipMemcpyAsync(X.h_matrix, X.d_matrix, (size_t)W * RW * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     HIP_TRY(h, hipStreamSynchronize(s));
-    // (points outside the key range were dropped by the split: the other ranks are already on their way into the exchange, so
-    // this rank takes part in it to the end and reports the error then)
-    const int split_rc = owner_split_finish(h, (uint32_t)W);
-    const std::string split_err = split_rc ? h->err : std::string();
+    if (!err) note(owner_split_finish(h, (uint32_t)W));        // (points outside the key range: the same verdict the status word carries)
+    for (int r = 0; r < W; ++r) {
+        const uint32_t code = X.h_matrix[(size_t)r * RW + W];
+        if (code) return err ? leave() : peer_failed(r, code);
+    }
+    if (err) return leave();                                   // (cannot happen: this rank's own status word was zero)
     // 2. the runs themselves
     // The run this rank keeps stays where the split left it: the build reads two segments (it, and what arrives).  own_recs
     // holds [room for the kept run | the runs of the other ranks in rank order]; the room is only filled when the build
@@ -678,7 +747,7 @@ int gndt_build_owned_device(gndt_handle* h, gndt_comm* c, const void* shard_xyz_
     const uint64_t kept = X.send_cnt[me];
     std::vector<uint64_t> recv_off((size_t)W + 1, 0);
     recv_off[0] = kept;
-    for (int r = 0; r < W; ++r) recv_off[r + 1] = recv_off[r] + (r == me ? 0 : X.h_matrix[(size_t)r * W + me]);      // what rank r holds for me
+    for (int r = 0; r < W; ++r) recv_off[r + 1] = recv_off[r] + (r == me ? 0 : X.h_matrix[(size_t)r * RW + me]);      // what rank r holds for me
     const uint64_t n_own = recv_off[W];
     if ((rc = grow_buf(h, X.own_recs, X.own_cap, std::max<uint64_t>(n_own, 1)))) return rc;
     uint64_t sent = 0, received = 0;
@@ -694,44 +763,61 @@ int gndt_build_owned_device(gndt_handle* h, gndt_comm* c, const void* shard_xyz_
     }
     stamp(2);
     // 3. the columns this rank owns, finished: the ordinary pipeline on the records.  The column pairs and every rank's
-    //    (column count, "my build has to be re-run") message follow on the stream: ONE wait for the build and the counts.  If
-    //    some rank's build overflowed, that rank re-runs it and ALL ranks repeat the round (they all saw the same messages).
-    if ((rc = build_records(h, X.send_recs + X.send_off[me], (size_t)kept, total_points, s, X.own_recs + kept, (size_t)(n_own - kept)))) return rc;
-    if (!X.d_colmsg) HIP_TRY(h, hipMalloc(&X.d_colmsg, kColMsgWords * (size_t)kMaxRanks * sizeof(unsigned long long)));
-    if (!X.h_colmsg) HIP_TRY(h, hipHostMalloc(&X.h_colmsg, kColMsgWords * (size_t)kMaxRanks * sizeof(unsigned long long)));
+    //    message (column count, "my build has to be re-run", status) follow on the stream: ONE wait for the build and the
+    //    messages.  If some rank's build overflowed, that rank re-runs it and ALL ranks repeat the round (they all saw the same
+    //    messages); a rank that cannot go on says so in its message and all ranks leave.
+    note(build_records(h, X.send_recs + X.send_off[me], (size_t)kept, total_points, s, X.own_recs + kept, (size_t)(n_own - kept)));
+    unsigned long long* my_msg_host = X.h_colmsg + kColMsgWords * (size_t)kMaxRanks;       // (pinned: what a failed rank sends)
     uint32_t ncols = 0;
     uint64_t m_max = 1;
+    bool peers_know = false;                   // this rank's error has been seen by everybody
     for (int round = 0;; ++round) {
-        if ((rc = owned_columns_enqueue(h, s))) return rc;
-        hipLaunchKernelGGL(k_owned_status, dim3(1), dim3(1), 0, s, (const uint32_t*)X.d_npairs, (const PartCounters*)q.d_pc, (const Counters*)h->d_cnt,
-                           (unsigned long long)n_own, X.d_colmsg + kColMsgWords * me);
+        if (!err) note(owned_columns_enqueue(h, s));
+        if (!err) {
+            hipLaunchKernelGGL(k_owned_status, dim3(1), dim3(1), 0, s, (const uint32_t*)X.d_npairs, (const PartCounters*)q.d_pc, (const Counters*)h->d_cnt,
+                               (unsigned long long)n_own, X.d_colmsg + kColMsgWords * me);
+        } else {
+            for (int k = 0; k < kColMsgWords; ++k) my_msg_host[k] = 0ull;
+            my_msg_host[4] = (unsigned long long)err;
+            HIP_TRY(h, hipMemcpyAsync(X.d_colmsg + kColMsgWords * me, my_msg_host, kColMsgWords * sizeof(unsigned long long), hipMemcpyHostToDevice, s));
+            peers_know = true;
+        }
         if ((rc = comm_all_gather(h, c, X.d_colmsg + kColMsgWords * me, X.d_colmsg, kColMsgWords, 8, s))) return rc;
         HIP_TRY(h, hipMemcpyAsync(X.h_colmsg, X.d_colmsg, kColMsgWords * (size_t)W * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
-        if ((rc = partition_resolve(h))) return rc;                    // the wait; this rank's own overflow re-runs happen here
+        if (!err) note(partition_resolve(h));                          // the wait; this rank's own overflow re-runs happen here
         HIP_TRY(h, hipStreamSynchronize(s));                           // (a repeated round finds the build resolved already: the messages still have to arrive)
         bool someone_failed = false;
         m_max = 1;
         for (int r = 0; r < W; ++r) {
+            const unsigned long long code = X.h_colmsg[kColMsgWords * r + 4];
+            if (code) return err ? leave() : peer_failed(r, code);
             someone_failed = someone_failed || X.h_colmsg[kColMsgWords * r + 1] != 0;
             m_max = std::max<uint64_t>(m_max, X.h_colmsg[kColMsgWords * r]);
         }
-        if (!someone_failed) break;
-        if (round >= 8) { h->err = "a rank's build keeps overflowing"; return GNDT_ERR_CAPACITY; }
+        if (err && !peers_know && !someone_failed) break;      // the build failed AFTER this round's message said it was fine: the
+                                                               //   others go on to the pairs; this rank joins that collective empty-handed
+        if (!someone_failed && !err) break;
+        if (round >= 8 && !err) { h->err = "a rank's build keeps overflowing"; note(GNDT_ERR_CAPACITY); }
     }
-    ncols = h->h_cnt->num_columns;
+    if (!err) ncols = h->h_cnt->num_columns;
     stamp(3);
     // 4. everybody's columns -> the global row of every local row
     if (m_max > X.pairs_cap) {                          // (another rank owns more columns: a longer send buffer, contents kept)
         unsigned long long* bigger = nullptr;
         HIP_TRY(h, hipMalloc(&bigger, m_max * sizeof(unsigned long long)));
-        if (ncols) HIP_TRY(h, hipMemcpyAsync(bigger, X.pairs, (size_t)ncols * sizeof(unsigned long long), hipMemcpyDeviceToDevice, s));
+        if (ncols && X.pairs) HIP_TRY(h, hipMemcpyAsync(bigger, X.pairs, (size_t)ncols * sizeof(unsigned long long), hipMemcpyDeviceToDevice, s));
         HIP_TRY(h, hipStreamSynchronize(s));
-        (void)hipFree(X.pairs);
+        if (X.pairs) (void)hipFree(X.pairs);
         X.pairs = bigger; X.pairs_cap = m_max;
     }
     hipLaunchKernelGGL(k_pairs_pad, dim3(grid_for(m_max)), dim3(256), 0, s, X.pairs, ncols, (uint32_t)m_max);
+    if (err) {      // this rank's columns will be missing from everybody's order: a pair no map can hold makes the other ranks fail too
+        my_msg_host[0] = kPoisonPair;
+        HIP_TRY(h, hipMemcpyAsync(X.pairs, my_msg_host, sizeof(unsigned long long), hipMemcpyHostToDevice, s));
+    }
     if ((rc = grow_buf(h, X.pairs_all, X.pairs_all_cap, m_max * (uint64_t)W))) return rc;
     if ((rc = comm_all_gather(h, c, X.pairs, X.pairs_all, (size_t)m_max, 8, s))) return rc;
+    if (err) return leave();                            // (no collective follows: the others finish without this rank)
     if ((rc = global_rows_launch(h, X.pairs_all, m_max * (uint64_t)W, total_points, s))) return rc;
     if (!X.h_bad) HIP_TRY(h, hipHostMalloc(&X.h_bad, sizeof(uint32_t)));
     HIP_TRY(h, hipMemcpyAsync(X.h_totals, X.d_totals, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
@@ -739,15 +825,15 @@ int gndt_build_owned_device(gndt_handle* h, gndt_comm* c, const void* shard_xyz_
     stamp(4);
     HIP_TRY(h, hipStreamSynchronize(s));
     const uint32_t bad = *X.h_bad;
-    if (bad) { h->err = std::to_string(bad) + " column pair(s) with an index beyond total_points"; return GNDT_ERR_INVALID; }
-    if (split_rc) { h->err = split_err; return split_rc; }
-    if (h->h_cnt->err_key_range) {          // (a z level beyond the key range: found by the build; reported now, after the collectives)
+    if (bad) { h->err = std::to_string(bad) + " column pair(s) with an index beyond total_points (a rank whose build failed late sends one on purpose)"; return GNDT_ERR_PEER; }
+    if (h->h_cnt->err_key_range) {          // (a z level beyond the key range: found by the build; no collective follows)
         h->err = std::to_string(h->h_cnt->err_key_range) + " point(s) outside the key range";
         return GNDT_ERR_KEY_RANGE;
     }
     if (global_row_dev) *global_row_dev = X.global_row;
     X.h_totals[2] = 0;                                    // slopes of the whole map: every rank's share came with its column message
     for (int r = 0; r < W; ++r) X.h_totals[2] += X.h_colmsg[kColMsgWords * r + 2];
+    X.owned_serial = h->result_serial; X.owned_world = (uint32_t)W;
     if (info) {
         float t[4] = {0, 0, 0, 0};
         for (int i = 0; i < 4; ++i) (void)hipEventElapsedTime(&t[i], ev[i], ev[i + 1]);
@@ -757,6 +843,123 @@ int gndt_build_owned_device(gndt_handle* h, gndt_comm* c, const void* shard_xyz_
         info->bytes_sent = sent; info->bytes_received = received; info->ranks = (uint32_t)W;
     }
     return GNDT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// the assembled map: the ranks' rows gathered and scattered by their global row
+// ---------------------------------------------------------------------------------------------
+int gndt_owned_pack_rows_device(gndt_handle* h, const uint32_t** rows_dev, uint64_t* n_rows, void* hip_stream) {
+    int rc = check_ready(h);
+    if (rc) return rc;
+    if (!rows_dev || !n_rows) { h->err = "null argument"; return GNDT_ERR_INVALID; }
+    auto& X = h->exch;
+    if ((rc = partition_resolve(h))) return rc;
+    if (!h->results_valid || !X.owned_serial || X.owned_serial != h->result_serial) {
+        h->err = "no owner-partitioned build on this handle (gndt_build_owned_device / gndt_owned_global_rows_device come first)";
+        return GNDT_ERR_INVALID;
+    }
+    hipStream_t s = stream_of(h, hip_stream);
+    { const int urc = use_stream(h, s); if (urc) return urc; }
+    const uint64_t nl = h->h_cnt->num_nodes;
+    if ((rc = grow_buf(h, X.grec, X.grec_cap, std::max<uint64_t>(nl, 1) * kPackedRowWords))) return rc;
+    if (nl) hipLaunchKernelGGL(k_rows_pack, dim3(grid_for(nl)), dim3(256), 0, s, h->out, (const uint32_t*)h->part.row_ncol, (const uint32_t*)X.global_row,
+                               (uint32_t)nl, (uint32_t)nl, X.grec);
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipStreamSynchronize(s));
+    *rows_dev = X.grec; *n_rows = nl;
+    return GNDT_OK;
+}
+
+int gndt_adopt_rows_device(gndt_handle* h, const uint32_t* rows_dev, uint64_t n_rows, uint64_t total_nodes, uint64_t total_columns,
+                           uint64_t total_slopes, void* hip_stream) {
+    int rc = check_ready(h);
+    if (rc) return rc;
+    if ((!rows_dev && n_rows) || total_nodes >= 0xFFFFFFFFull) { h->err = "bad argument"; return GNDT_ERR_INVALID; }
+    auto& X = h->exch;
+    if (rows_dev == X.grec) { h->err = "the rows to adopt must not be this handle's own pack buffer alone: pass everybody's rows"; return GNDT_ERR_INVALID; }
+    hipStream_t s = stream_of(h, hip_stream);
+    h->pending.active = false;
+    { const int urc = use_stream(h, s); if (urc) return urc; }
+    HIP_TRY(h, hipStreamSynchronize(s));                      // (the result arrays may be re-allocated: nothing may still read them)
+    if ((rc = ensure_out(h, std::max<uint64_t>(total_nodes, 1)))) return rc;
+    if ((rc = grow_buf(h, h->part.row_ncol, h->part.row_ncol_cap, std::max<uint64_t>(total_nodes, 1)))) return rc;
+    if (!X.d_tally) HIP_TRY(h, hipMalloc(&X.d_tally, 2 * sizeof(uint32_t)));
+    if (!X.h_tally) HIP_TRY(h, hipHostMalloc(&X.h_tally, 2 * sizeof(uint32_t)));
+    HIP_TRY(h, hipMemsetAsync(X.d_tally, 0, 2 * sizeof(uint32_t), s));
+    h->results_valid = false;
+    if (n_rows) hipLaunchKernelGGL(k_rows_adopt, dim3(grid_for(n_rows)), dim3(256), 0, s, rows_dev, (uint64_t)n_rows, (uint32_t)total_nodes, h->out,
+                                   h->part.row_ncol, X.d_tally);
+    HIP_TRY(h, hipGetLastError());
+    // the handle's counters now describe the adopted map (gndt_sync / gndt_export* / gndt_compute_cost read them)
+    h->h_cnt->num_nodes = (uint32_t)total_nodes; h->h_cnt->num_columns = (uint32_t)total_columns; h->h_cnt->num_slopes = (uint32_t)total_slopes;
+    h->h_cnt->err_key_range = 0; h->h_cnt->err_table_full = 0;
+    HIP_TRY(h, hipMemcpyAsync(h->d_cnt, h->h_cnt, sizeof(Counters), hipMemcpyHostToDevice, s));
+    HIP_TRY(h, hipMemcpyAsync(X.h_tally, X.d_tally, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(h, hipStreamSynchronize(s));
+    if (X.h_tally[1] || X.h_tally[0] != total_nodes) {
+        h->err = "adopted " + std::to_string(X.h_tally[0]) + " row(s) for a map of " + std::to_string(total_nodes) + " (" + std::to_string(X.h_tally[1]) +
+                 " beyond it): the rows of some rank are missing or belong to another build";
+        return GNDT_ERR_INVALID;
+    }
+    if (h->part.h_pc) { h->part.h_pc->stage_overflow = 0; h->part.h_pc->index_overflow = 0; }
+    h->results_valid = true;
+    ++h->result_serial;
+    h->map_in_table = false; h->incr_ok = false;      // (the node table, if any, no longer describes the rows)
+    h->last_stream = s;
+    X.owned_serial = 0;
+    return GNDT_OK;
+}
+
+int gndt_gather_owned_map_device(gndt_handle* h, gndt_comm* c, int32_t root, void* hip_stream) {
+    int rc = check_ready(h);
+    if (rc) return rc;
+    if (!c || (!c->nccl && !c->threads)) { h->err = "no communicator"; return GNDT_ERR_INVALID; }
+    const int W = c->world, me = c->rank;
+    if (root >= W) { h->err = "root outside the communicator"; return GNDT_ERR_INVALID; }
+    auto& X = h->exch;
+    // (Everything checked here is the same on all ranks after a successful gndt_build_owned_device with this communicator, so
+    // either all ranks return or none does.)
+    if (!h->results_valid || !X.owned_serial || X.owned_serial != h->result_serial || X.owned_world != (uint32_t)W) {
+        h->err = "gndt_gather_owned_map_device follows a successful gndt_build_owned_device on the same communicator";
+        return GNDT_ERR_INVALID;
+    }
+    hipStream_t s = stream_of(h, hip_stream);
+    { const int urc = use_stream(h, s); if (urc) return urc; }
+    const uint64_t N = X.h_totals[0], K = X.h_totals[1], S = X.h_totals[2];
+    std::vector<uint64_t> rows_of((size_t)W);
+    uint64_t m_max = 1, sum = 0;
+    for (int r = 0; r < W; ++r) { rows_of[r] = X.h_colmsg[kColMsgWords * r + 5]; m_max = std::max(m_max, rows_of[r]); sum += rows_of[r]; }
+    const uint64_t nl = rows_of[me];
+    if (sum != N || nl != h->h_cnt->num_nodes) { h->err = "the ranks' row counts do not add up to the map"; return GNDT_ERR_INVALID; }
+    const bool all = root < 0;
+    // this rank's rows, packed (padded to the longest list for the fixed-size all-gather)
+    const uint64_t padded = all ? m_max : std::max<uint64_t>(nl, 1);
+    if ((rc = grow_buf(h, X.grec, X.grec_cap, padded * kPackedRowWords))) return rc;
+    hipLaunchKernelGGL(k_rows_pack, dim3(grid_for(padded)), dim3(256), 0, s, h->out, (const uint32_t*)h->part.row_ncol, (const uint32_t*)X.global_row,
+                       (uint32_t)nl, (uint32_t)(all ? padded : nl), X.grec);
+    HIP_TRY(h, hipGetLastError());
+    uint64_t n_recv = 0;
+    if (all) {
+        n_recv = m_max * (uint64_t)W;
+        if ((rc = grow_buf(h, X.grec_all, X.grec_all_cap, n_recv * kPackedRowWords))) return rc;
+        if ((rc = comm_all_gather(h, c, X.grec, X.grec_all, (size_t)(m_max * kPackedRowWords), 4, s))) return rc;
+    } else {
+        // to ONE rank: the all-to-all primitive with a single receiver (ncclSend / ncclRecv in one group)
+        std::vector<uint64_t> so((size_t)W, 0), sc((size_t)W, 0), ro((size_t)W, 0), rcnt((size_t)W, 0);
+        if (me == root) {
+            uint64_t off = 0;
+            for (int r = 0; r < W; ++r) { ro[r] = off * kPackedRowWords * 4; rcnt[r] = r == me ? 0 : rows_of[r] * kPackedRowWords * 4; off += rows_of[r]; }
+            n_recv = N;
+            if ((rc = grow_buf(h, X.grec_all, X.grec_all_cap, std::max<uint64_t>(N, 1) * kPackedRowWords))) return rc;
+            if (nl) HIP_TRY(h, hipMemcpyAsync(X.grec_all + ro[me] / 4, X.grec, nl * kPackedRowWords * 4, hipMemcpyDeviceToDevice, s));
+        } else {
+            sc[root] = nl * kPackedRowWords * 4;
+        }
+        if (W > 1 && (rc = comm_exchange(h, c, reinterpret_cast<const char*>(X.grec), so.data(), sc.data(), reinterpret_cast<char*>(X.grec_all), ro.data(),
+                                          rcnt.data(), s))) return rc;
+        if (me != root) { HIP_TRY(h, hipStreamSynchronize(s)); return GNDT_OK; }     // (this rank keeps the columns it owns)
+    }
+    return gndt_adopt_rows_device(h, X.grec_all, n_recv, N, K, S, hip_stream);
 }
 
 }  // extern "C"

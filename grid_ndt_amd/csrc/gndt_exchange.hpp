@@ -127,6 +127,7 @@ static __global__ void k_exchange_pad(uint64_t* __restrict__ buf, uint32_t have,
 // against 84 B per node of the global map through a ring all-reduce for the statistics exchange above.
 // ---------------------------------------------------------------------------------------------
 constexpr unsigned long long kNoPair = 0xFFFFFFFFFFFFFFFFull;
+constexpr unsigned long long kPoisonPair = 0xFFFFFFFE00000001ull;    // first-seen index beyond any cloud: k_pairs_note counts it as bad
 
 // ---- who owns which column: locality first ----
 // A contiguous range of a scan-ordered cloud covers a patch of ground, so most points of a 32 x 32-column block (6.4 m at
@@ -242,13 +243,23 @@ static __global__ void __launch_bounds__(256) k_owned_columns(const uint32_t* __
 
 // what a rank tells the others before the pairs travel: how many it has, and whether its build has to be re-run first
 // (and its share of the whole map's totals, so that no further collective is needed for them)
-constexpr int kColMsgWords = 4;
+// [4]: a status code — non-zero means this rank cannot go on (its error code, include/gndt.h): every rank reads everybody's
+// word after the all-gather and they all leave the sequence together (nobody is left waiting in the next collective);
+// [5]: rows of this rank's map (what gndt_gather_owned_map_device moves).
+constexpr int kColMsgWords = 6;
 static __global__ void k_owned_status(const uint32_t* __restrict__ n_pairs, const PartCounters* __restrict__ pc, const Counters* __restrict__ cnt,
                                       unsigned long long owned_points, unsigned long long* __restrict__ msg) {
     msg[0] = *n_pairs;
     msg[1] = (pc->lds_overflow | pc->stage_overflow | pc->index_overflow | pc->part_overflow) ? 1ull : 0ull;
     msg[2] = cnt->num_slopes;
     msg[3] = owned_points;
+    msg[4] = 0ull;
+    msg[5] = cnt->num_nodes;
+}
+// the status word that travels with a rank's row of the W x W send-count matrix: the host's code if it has one, else what the
+// split found on the device (points outside the key range)
+static __global__ void k_split_status(const Counters* __restrict__ split_cnt, uint32_t host_code, uint32_t key_range_code, uint32_t* __restrict__ word) {
+    *word = host_code ? host_code : ((split_cnt && split_cnt->err_key_range) ? key_range_code : 0u);
 }
 
 static __global__ void __launch_bounds__(256) k_pairs_pad(unsigned long long* __restrict__ pairs, uint32_t have, uint32_t padded) {
@@ -312,6 +323,47 @@ static __global__ void __launch_bounds__(256) k_global_rows(const uint32_t* __re
         while (m) { row += ncol_at[(w << 5) + (uint32_t)__builtin_ctz(m)]; m &= m - 1u; }
         for (uint32_t i = 0; i < nc; ++i) global_row[r + i] = row + i;
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// The assembled map (gndt_gather_owned_map_device): a rank's result rows travel as packed records of kPackedRowWords 32-bit
+// words — the 76-byte row of gndt_cells (sx, sy, sz, count, first_idx, mean[3], cov[6], rough, normal[3], flags: 19 words),
+// the column index the cost map reads (row_ncol) and the row's place in the map of the whole cloud — and are scattered by
+// that place into the result arrays of the handle that adopts them.
+// ---------------------------------------------------------------------------------------------
+constexpr uint32_t kPackedRowWords = 21, kNoRow = 0xFFFFFFFFu;
+static __global__ void __launch_bounds__(256) k_rows_pack(OutView o, const uint32_t* __restrict__ row_ncol, const uint32_t* __restrict__ global_row,
+                                                          uint32_t n, uint32_t padded, uint32_t* __restrict__ rows) {
+    for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < padded; r += gridDim.x * blockDim.x) {
+        uint32_t* w = rows + (size_t)r * kPackedRowWords;
+        if (r >= n) { w[20] = kNoRow; continue; }                   // (padding of a fixed-size all-gather)
+        w[0] = (uint32_t)o.sx[r]; w[1] = (uint32_t)o.sy[r]; w[2] = (uint32_t)o.sz[r]; w[3] = o.count[r]; w[4] = o.first_idx[r];
+        for (int k = 0; k < 3; ++k) w[5 + k] = __float_as_uint(o.mean[3 * (size_t)r + k]);
+        for (int k = 0; k < 6; ++k) w[8 + k] = __float_as_uint(o.cov[6 * (size_t)r + k]);
+        w[14] = __float_as_uint(o.rough[r]);
+        for (int k = 0; k < 3; ++k) w[15 + k] = __float_as_uint(o.normal[3 * (size_t)r + k]);
+        w[18] = o.flags[r]; w[19] = row_ncol[r]; w[20] = global_row[r];
+    }
+}
+// tally[0] = rows written, tally[1] = rows whose place lies beyond the map
+static __global__ void __launch_bounds__(256) k_rows_adopt(const uint32_t* __restrict__ rows, uint64_t n, uint32_t total, OutView o,
+                                                           uint32_t* __restrict__ row_ncol, uint32_t* __restrict__ tally) {
+    uint32_t wrote = 0, bad = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t* w = rows + i * kPackedRowWords;
+        const uint32_t r = w[20];
+        if (r == kNoRow) continue;
+        if (r >= total) { ++bad; continue; }
+        o.sx[r] = (int32_t)w[0]; o.sy[r] = (int32_t)w[1]; o.sz[r] = (int32_t)w[2]; o.count[r] = w[3]; o.first_idx[r] = w[4];
+        for (int k = 0; k < 3; ++k) o.mean[3 * (size_t)r + k] = __uint_as_float(w[5 + k]);
+        for (int k = 0; k < 6; ++k) o.cov[6 * (size_t)r + k] = __uint_as_float(w[8 + k]);
+        o.rough[r] = __uint_as_float(w[14]);
+        for (int k = 0; k < 3; ++k) o.normal[3 * (size_t)r + k] = __uint_as_float(w[15 + k]);
+        o.flags[r] = w[18]; row_ncol[r] = w[19];
+        ++wrote;
+    }
+    for (int off = 32; off > 0; off >>= 1) { wrote += (uint32_t)__shfl_down((int)wrote, off, 64); bad += (uint32_t)__shfl_down((int)bad, off, 64); }
+    if ((threadIdx.x & 63) == 0) { if (wrote) atomicAdd(&tally[0], wrote); if (bad) atomicAdd(&tally[1], bad); }
 }
 
 }  // namespace gndt

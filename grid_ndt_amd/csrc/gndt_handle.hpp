@@ -94,7 +94,8 @@ struct gndt_handle {
         uint64_t hist_cap = 0;     uint32_t* hist = nullptr;
         uint32_t bucket_cap = 0;   uint32_t* totals = nullptr; uint32_t* bucket_base = nullptr;
         uint64_t stage_cap = 0;    StageRow* stage = nullptr;
-        uint32_t *ord_cf = nullptr, *ord_idx = nullptr, *inv = nullptr, *row_ncol = nullptr;
+        uint32_t *ord_cf = nullptr, *ord_idx = nullptr, *inv = nullptr;
+        uint32_t* row_ncol = nullptr; uint64_t row_ncol_cap = 0;     // per result row: its column's node count on the column's first row, else 0
         // column order (gndt_partition.hpp ColumnOrder): per bitmap word, and per point index for ncol_at
         uint64_t words_init = 0;   // bitmap / word_weight words the table path's column order has initialised
         uint64_t word_cap = 0;     uint32_t *bitmap = nullptr, *word_weight = nullptr, *word_base = nullptr, *bsum_words = nullptr,
@@ -142,6 +143,11 @@ struct gndt_handle {
         uint32_t* h_bad = nullptr;      // pinned: the "pair beyond the index range" counter comes back here
         uint64_t send_off[1025] = {}, send_cnt[1025] = {};   // host: start and length of every owner's run in send_recs (after the split)
         bool split_one_pass = false;  uint64_t split_cap = 0;   // one-pass split: run r at r * split_cap
+        // the assembled map (gndt_gather_owned_map_device): this rank's rows packed for travel, everybody's rows, the adopt tally
+        uint32_t* grec = nullptr; uint64_t grec_cap = 0;  uint32_t* grec_all = nullptr; uint64_t grec_all_cap = 0;
+        uint32_t* d_tally = nullptr;  uint32_t* h_tally = nullptr;
+        uint64_t owned_serial = 0;  uint32_t owned_world = 0;   // result_serial / ranks of the owned build global_row describes (0: none)
+        uint32_t* d_status = nullptr;                           // scratch word for the status kernels
         // locality-aware ownership (gndt_exchange.hpp): this rank's sample message, everybody's, the block table
         uint32_t* owner_msg = nullptr;  uint32_t* owner_msgs_all = nullptr; uint64_t owner_msgs_cap = 0;
         uint32_t* bkey = nullptr;  uint32_t* bcnt = nullptr; uint64_t bcnt_cap = 0;  uint8_t* bown = nullptr;  uint32_t* d_owner_full = nullptr;

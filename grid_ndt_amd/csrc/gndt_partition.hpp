@@ -108,13 +108,15 @@ struct OwnerMap {
     const uint32_t* bkey;    // open addressing: block + 1, 0 = empty; nullptr = no map (hash ownership only)
     const uint8_t* bown;     // owner rank of the block in that slot, 0xFF = hash ownership
     uint32_t mask;
+    const uint32_t* full;    // != 0 on the device: the block table could not hold every sampled block (k_owner_vote) and is NOT
+                             //   used — the same on every rank, since they all vote the same samples into tables of one size
 };
 __host__ __device__ __forceinline__ uint32_t owner_block(int sx, int sy) {      // 12 + 12 bits
     return ((((uint32_t)(sx + 65536) & 0x3FFFFu) >> 5) << 12) | (((uint32_t)(sy + 65536) & 0x3FFFFu) >> 5);
 }
 __host__ __device__ __forceinline__ uint32_t owner_block_slot(uint32_t key) { key *= 0x9E3779B1u; return key ^ (key >> 15); }
 __device__ __forceinline__ uint32_t owner_lookup(const OwnerMap& M, int sx, int sy, uint32_t W) {
-    if (M.bkey) {
+    if (M.bkey && !(M.full && *M.full)) {
         const uint32_t key = owner_block(sx, sy) + 1u;
         uint32_t s = owner_block_slot(key) & M.mask;
         for (uint32_t probe = 0; probe <= M.mask; ++probe) {

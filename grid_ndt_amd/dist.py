@@ -228,3 +228,39 @@ def build_owned_map(m, demand, shard, first_idx_base, total_points, group=None, 
     m.build_records(demand, own, total_points, stream)
     allp = gather_column_pairs(m.owned_columns(stream).clone(), group)
     return m.owned_global_rows(allp, total_points, stream)
+
+
+def gather_packed_rows(rows, group=None, root=-1):
+    """Packed result rows ([n, 21] int32: gndt_owned_pack_rows_device, last word = the row's place in the map of the whole cloud)
+    of every rank -> all of them on rank `root` (root < 0: on every rank); other ranks get None.  Padding records of the
+    fixed-size all-gather carry -1 in their last word, which gndt_adopt_rows_device skips."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    n = torch.tensor([rows.shape[0]], dtype=torch.int64, device=rows.device)
+    sizes = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(sizes, n, group=group)
+    sizes = [int(x) for x in sizes]
+    if root < 0:
+        m = max(1, max(sizes))
+        padded = torch.full((m, rows.shape[1]), -1, dtype=torch.int32, device=rows.device)
+        padded[:rows.shape[0]] = rows
+        out = [torch.empty_like(padded) for _ in range(world)]
+        dist.all_gather(out, padded, group=group)
+        return torch.cat(out)
+    if rank == root:
+        got = [torch.empty((sizes[r], rows.shape[1]), dtype=torch.int32, device=rows.device) for r in range(world)]
+        got[rank].copy_(rows)
+        ops = [dist.P2POp(dist.irecv, got[r], r, group) for r in range(world) if r != rank and sizes[r]]
+    else:
+        ops = [dist.P2POp(dist.isend, rows.contiguous(), root, group)] if rows.shape[0] else []
+    if ops:
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+    return torch.cat(got) if rank == root else None
+
+
+def gather_owned_map(m, totals, group=None, root=-1, stream=None):
+    """build_owned_map's result assembled: `totals` = (nodes, columns, slopes) of the whole map.  On `root` (or every rank) `m`
+    then holds the map of the whole cloud."""
+    rows = gather_packed_rows(m.owned_pack_rows(stream).clone(), group, root)
+    if rows is not None:
+        m.adopt_rows(rows, totals[0], totals[1], totals[2], stream)

@@ -374,6 +374,25 @@ class TwoDmap:
         d = {k: (float(getattr(info, k)) if k.endswith("_ms") else int(getattr(info, k))) for k, _ in OwnedInfo._fields_}
         return self._dev_view(p.value or 0, d["local_nodes"] * 4, torch.int32, (d["local_nodes"],)), d
 
+    def gather_owned(self, comm, root=-1, stream=None):
+        """After build_owned: the rows of all ranks gathered on rank `root` (root < 0: on every rank) and scattered by their
+        global row — this map then IS the map of the whole cloud (export(), computeCost(), ... as after a single-GPU build).
+        Every rank of the communicator calls it; ranks other than `root` keep the columns they own."""
+        self._check(self._L.gndt_gather_owned_map_device(self._h, comm.handle, int(root), _stream_ptr(stream)))
+
+    def owned_pack_rows(self, stream=None):
+        """This rank's rows as packed records [n, 21] int32 (device view, valid until the next call): for hosts with their own transport."""
+        import torch
+        p, n = C.c_void_p(), C.c_uint64()
+        self._check(self._L.gndt_owned_pack_rows_device(self._h, C.byref(p), C.byref(n), _stream_ptr(stream)))
+        return self._dev_view(p.value or 0, n.value * 21 * 4, torch.int32, (n.value, 21))
+
+    def adopt_rows(self, rows, total_nodes, total_columns, total_slopes, stream=None):
+        """Packed records of any number of ranks ([m, 21] int32 on the device; padding records skipped) -> this map's rows."""
+        rows = rows.contiguous()
+        self._check(self._L.gndt_adopt_rows_device(self._h, C.c_void_p(rows.data_ptr()), int(rows.shape[0]), int(total_nodes), int(total_columns),
+                                                   int(total_slopes), _stream_ptr(stream)))
+
     def finalize_stats(self, key, sums, count, first_idx, total_points, stream=None):
         """Merged statistics of the whole cloud (unique nodes sorted by key) -> the map."""
         st = Stats(int(key.shape[0]), key.data_ptr(), sums.data_ptr(), count.data_ptr(), first_idx.data_ptr())

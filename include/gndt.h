@@ -39,7 +39,9 @@ enum {
     GNDT_ERR_HIP = 3,          /* a HIP runtime call failed; see gndt_last_error */
     GNDT_ERR_KEY_RANGE = 4,    /* |nx| or |ny| > 65535 (countMorton wraps, Stopwatch.h:102-110) or |nz| >= 2^21 */
     GNDT_ERR_CAPACITY = 5,     /* node table full and growth disabled */
-    GNDT_ERR_NOMEM = 6
+    GNDT_ERR_NOMEM = 6,
+    GNDT_ERR_PEER = 7          /* sharded builds: another rank of the communicator reported a failure; every rank left the
+                                  collective sequence at the same point (this rank's own input was fine) */
 };
 
 enum { GNDT_DEMAND_SLOPE = 0, GNDT_DEMAND_TRUE = 1 };   /* create2DMap(demand), map2D.h:630, 644 */
@@ -282,6 +284,31 @@ int gndt_owned_global_rows_device(gndt_handle* h, const uint64_t* all_pairs_dev,
 int gndt_build_owned_device(gndt_handle* h, gndt_comm* c, const void* shard_xyz_dev, size_t n, size_t stride_bytes,
                             uint64_t first_idx_base, uint64_t total_points, const uint32_t** global_row_dev,
                             gndt_owned_info* info, void* hip_stream);
+/* Errors inside the collective sequence of gndt_build_owned_device / gndt_build_global_device: a rank that fails on its own
+ * (bad input, a point outside the key range, a build that does not fit) still takes part in the collectives that follow, its
+ * error code travelling with the messages that are exchanged anyway; every rank that sees a non-zero code leaves at the same
+ * point — the failing rank with its own error, the others with GNDT_ERR_PEER — so no rank is left waiting.  Not reportable
+ * this way, hence fatal for the group like the loss of a rank: a failing collective, and memory exhaustion for the exchange
+ * buffers themselves.
+ *
+ * ---- one map for the consumers (src/receiver.cpp:171-175 runs computeCost and the planner on ONE map)
+ * After gndt_build_owned_device the map is sharded by column owner.  gndt_gather_owned_map_device moves the finished rows —
+ * 84 bytes each: the 76-byte row of gndt_cells, the column index the cost map uses, and the row's place in the map of the
+ * whole cloud — to rank `root` (ncclSend / ncclRecv) or, with root < 0, to every rank (one padded all-gather), and scatters
+ * them by that place into the handle's result arrays: the handle then HOLDS THE WHOLE MAP, in the reference's order, and
+ * gndt_sync / gndt_export* / gndt_compute_cost / gndt_compat::TwoDmap work on it as after a single-GPU build.  Ranks other
+ * than `root` keep the columns they own.  All ranks of the communicator call it, after a successful gndt_build_owned_device.
+ * For hosts with their own transport the two device steps are exported:
+ *   gndt_owned_pack_rows_device   this rank's rows as packed records (GNDT_PACKED_ROW_WORDS 32-bit words each; device pointer
+ *                                 valid until the next call on the handle)
+ *   gndt_adopt_rows_device        packed records of ANY number of ranks (padding records, last word 0xFFFFFFFF, are skipped)
+ *                                 -> the handle's result rows; fails with GNDT_ERR_INVALID unless exactly total_nodes rows
+ *                                 arrive. */
+#define GNDT_PACKED_ROW_WORDS 21
+int gndt_gather_owned_map_device(gndt_handle* h, gndt_comm* c, int32_t root, void* hip_stream);
+int gndt_owned_pack_rows_device(gndt_handle* h, const uint32_t** rows_dev, uint64_t* n_rows, void* hip_stream);
+int gndt_adopt_rows_device(gndt_handle* h, const uint32_t* rows_dev, uint64_t n_rows, uint64_t total_nodes, uint64_t total_columns,
+                           uint64_t total_slopes, void* hip_stream);
 
 /* ---- cost map over the finished grid -------------------------------------
  * gndt_compute_cost replaces TwoDmap::computeCost (include/map2D.h:1285-1397; called at receiver.cpp:171

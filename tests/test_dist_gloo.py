@@ -85,6 +85,39 @@ def _global_rows(all_pairs, head, ncol, local):
     return rows, int(base[-1]), int(p.size)
 
 
+_ROW_FIELDS = (("sx", 1), ("sy", 1), ("sz", 1), ("count", 1), ("first_idx", 1), ("mean", 3), ("cov", 6), ("rough", 1), ("normal", 3), ("flags", 1))
+
+
+def _pack_rows(local, rows):
+    """What k_rows_pack writes: the 19 words of a result row, the column index (node count on a column's first row) and the global row."""
+    n = local["sx"].shape[0]
+    out = np.zeros((n, 21), np.int32)
+    w = 0
+    for name, k in _ROW_FIELDS:
+        out[:, w:w + k] = np.ascontiguousarray(local[name]).reshape(n, k).view(np.int32)
+        w += k
+    _, head, ncol = _column_pairs(local)
+    out[head, 19] = ncol.astype(np.int32)
+    out[:, 20] = rows.astype(np.int32)
+    return out
+
+
+def _adopt_rows(packed, total):
+    """What k_rows_adopt does with everybody's records."""
+    keep = packed[packed[:, 20] != -1]
+    assert keep.shape[0] == total and np.array_equal(np.sort(keep[:, 20]), np.arange(total))
+    order = np.argsort(keep[:, 20], kind="stable")
+    keep = keep[order]
+    out, w = {}, 0
+    for name, k in _ROW_FIELDS:
+        col = np.ascontiguousarray(keep[:, w:w + k])
+        dt = np.float32 if name in ("mean", "cov", "rough", "normal") else (np.uint32 if name in ("count", "first_idx", "flags") else np.int32)
+        out[name] = col.view(dt).reshape((total, k) if k > 1 else (total,))
+        w += k
+    out["row_ncol"] = keep[:, 19].copy()
+    return out
+
+
 def _owner_worker(rank, world, port, cut, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -115,7 +148,17 @@ def _owner_worker(rank, world, port, cut, q):
     pairs, head, ncol = _column_pairs(local)
     allp = gather_column_pairs(torch.from_numpy(pairs)).numpy()
     rows, n_glob, k_glob = _global_rows(allp, head, ncol, local)
-    q.put((rank, local, rows, n_glob, k_glob, int(own.shape[0])))
+    # step 5 (gndt_owned_pack_rows_device -> transport -> gndt_adopt_rows_device): the rows travel as packed records and are
+    # scattered by their place in the map of the whole cloud; to every rank, and to rank 1 alone
+    from grid_ndt_amd.dist import gather_packed_rows
+    packed = _pack_rows(local, rows)
+    everywhere = _adopt_rows(gather_packed_rows(torch.from_numpy(packed), root=-1).numpy(), n_glob)
+    at_one = gather_packed_rows(torch.from_numpy(packed), root=1)
+    assert (at_one is None) == (rank != 1)
+    if rank == 1:
+        again = _adopt_rows(at_one.numpy(), n_glob)
+        assert all(np.array_equal(everywhere[k], again[k]) for k in everywhere)
+    q.put((rank, local, rows, n_glob, k_glob, int(own.shape[0]), everywhere))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -147,3 +190,9 @@ def test_two_rank_owner_partitioned_build_assembles_the_oracle_map():
     assert seen.all()
     glob.update(num_nodes=N, num_columns=K, num_slopes=sum(res[r][0]["num_slopes"] for r in range(world)))
     parity.assert_parity(glob, ref)
+    # the map every rank assembled from the packed rows is that same map, and its column index marks every column's first row
+    for r in range(world):
+        got = res[r][5]
+        for k in ("sx", "sy", "sz", "count", "first_idx", "flags", "mean", "cov", "rough", "normal"):
+            assert np.array_equal(got[k], glob[k].reshape(got[k].shape)), (r, k)
+        assert int(np.count_nonzero(got["row_ncol"])) == K and int(got["row_ncol"].sum()) == N

@@ -380,3 +380,125 @@ def test_the_owner_build_itself_repeats_the_column_round_when_a_rank_re_runs_its
     for k in ("sx", "sy", "sz", "count", "first_idx", "flags"):
         assert np.array_equal(glob[k], one[k]), k
     assert glob["num_nodes"] == one["num_nodes"] > n // 2
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the assembled map (gndt_gather_owned_map_device): the consumers get ONE map
+# ---------------------------------------------------------------------------------------------------------------------
+def _threads(W, body):
+    """Run body(r) on W threads (one per thread-group rank); returns the list of results, re-raises the first failure."""
+    import threading
+    res, errs = [None] * W, []
+
+    def run(r):
+        try:
+            res[r] = body(r)
+        except BaseException as e:            # noqa: BLE001 — collected and re-raised on the test's thread
+            errs.append((r, e))
+
+    th = [threading.Thread(target=run, args=(r,)) for r in range(W)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=300)
+        assert not t.is_alive(), "a rank is stuck"
+    return res, errs
+
+
+@pytest.mark.parametrize("W,root", [(2, 0), (4, 2), (8, -1), (3, -1)])
+def test_gathered_owner_build_is_the_single_gpu_map_and_floods_like_it(W, root):
+    """All ranks build their columns, the rows travel to `root` (or to everybody) and are scattered by their global row: that
+    handle's export is the single-GPU export row for row, and gndt_compute_cost on it gives the single-GPU flood bit for bit."""
+    import torch
+    from grid_ndt_amd.dist import Communicator
+    cloud, P = scenes.drivable_site(400_000), scenes.COST_PARAMS
+    goal = np.asarray(scenes.DRIVABLE_GOAL, np.float32)
+    m1, one = parity.gpu_from_cloud(cloud, P, on_device=True)
+    st1 = m1.computeCost(goal)
+    c1 = m1.cost_export()
+    h1, s1 = c1["h"], c1["state"]
+    assert st1["rc"] == 0 and st1["traversable"] > 100
+    maps, comms = _ranks(cloud, P, W), Communicator.threads(W)
+    pts = torch.from_numpy(np.ascontiguousarray(cloud[1:])).cuda()
+    n = int(pts.shape[0])
+    bounds = [n * r // W for r in range(W + 1)]
+
+    def rank(r):
+        torch.cuda.set_device(0)
+        s = torch.cuda.Stream()
+        with torch.cuda.stream(s):
+            grow, info = maps[r].build_owned(comms[r], P["demand"], pts[bounds[r]:bounds[r + 1]], bounds[r], n, s)
+            local_nodes = info["local_nodes"]
+            maps[r].gather_owned(comms[r], root, s)
+            out = maps[r].export()
+            cost = None
+            if root < 0 or r == root:
+                st = maps[r].computeCost(goal, stream=s)
+                ce = maps[r].cost_export()
+                cost = (st, ce["h"], ce["state"])
+            return out, local_nodes, info, cost
+
+    res, errs = _threads(W, rank)
+    assert not errs, errs
+    for r in range(W):
+        out, local_nodes, info, cost = res[r]
+        if root >= 0 and r != root:
+            assert out["num_nodes"] == local_nodes                 # the other ranks keep the columns they own
+            continue
+        assert (out["num_nodes"], out["num_columns"], out["num_slopes"]) == (one["num_nodes"], one["num_columns"], one["num_slopes"])
+        for k in ("sx", "sy", "sz", "count", "first_idx", "flags"):
+            assert np.array_equal(out[k], one[k]), (r, k)
+        scale = np.abs(one["cov"]).max(axis=1, keepdims=True) + 1e-30
+        assert (np.abs(out["cov"] - one["cov"]) / scale).max() < 1e-5
+        assert np.allclose(out["mean"], one["mean"], rtol=0, atol=2e-6)
+        st, h, state = cost
+        assert st["rc"] == 0 and st["traversable"] == st1["traversable"] and st["closed"] == st1["closed"]
+        assert np.array_equal(state, s1)
+        # h is a sum of fp32 distances between fp32 means: identical wherever the means are bit-identical (different summation
+        # order of the fp64 statistics can move a mean by an ulp)
+        same = np.all(out["mean"] == one["mean"], axis=1)
+        assert same.mean() > 0.99
+        assert np.allclose(h, h1, rtol=1e-5, atol=1e-5)
+    for c in comms:
+        c.close()
+
+
+def test_a_failing_rank_takes_every_rank_out_of_the_owner_build_together():
+    """One rank's shard holds a point outside the key range.  Nobody hangs: that rank reports KEY_RANGE, the others PEER, all
+    at the same collective; the same communicators and handles then build a clean cloud."""
+    import torch
+    from grid_ndt_amd._lib import GndtError
+    from grid_ndt_amd.dist import Communicator
+    W = 4
+    cloud, P = scenes.campus_frame(120_000), scenes.CAMPUS_PARAMS
+    bad = cloud.copy()
+    bad[70_000, 0] = 5.0e4                                        # |nx| = 1e5 cells of 0.5 m: beyond 65535
+    maps, comms = _ranks(cloud, P, W), Communicator.threads(W)
+    n = cloud.shape[0] - 1
+    bounds = [n * r // W for r in range(W + 1)]
+    culprit = next(r for r in range(W) if bounds[r] <= 70_000 - 1 < bounds[r + 1])
+
+    def attempt(src):
+        pts = torch.from_numpy(np.ascontiguousarray(src[1:])).cuda()
+
+        def rank(r):
+            torch.cuda.set_device(0)
+            s = torch.cuda.Stream()
+            with torch.cuda.stream(s):
+                try:
+                    grow, info = maps[r].build_owned(comms[r], P["demand"], pts[bounds[r]:bounds[r + 1]], bounds[r], n, s)
+                    return ("ok", info["global_nodes"])
+                except GndtError as e:
+                    return ("err", e.code)
+        res, errs = _threads(W, rank)
+        assert not errs, errs
+        return res
+
+    res = attempt(bad)
+    for r in range(W):
+        assert res[r] == ("err", 4 if r == culprit else 7), (r, res)
+    ref = parity.ref_from_cloud(cloud, P)
+    res = attempt(cloud)
+    assert all(x == ("ok", ref["num_nodes"]) for x in res), res
+    for c in comms:
+        c.close()
