@@ -26,6 +26,7 @@ Tuning parse_tuning() {
     if (getenv("GNDT_TILE_RATIO")) t.tile_ratio = atof(getenv("GNDT_TILE_RATIO"));
     t.update_tile = geti("GNDT_UPDATE_TILE", t.update_tile);
     t.owner_locality = geti("GNDT_OWNER_LOCALITY", t.owner_locality);
+    t.owner_sliced_rows = geti("GNDT_OWNER_SLICED", t.owner_sliced_rows);
     t.one_level = geti("GNDT_ONE_LEVEL", t.one_level);
     t.stamps = getenv("GNDT_STAMPS") != nullptr;
     t.verbose = getenv("GNDT_VERBOSE") != nullptr;
@@ -238,7 +239,7 @@ void gndt_destroy(gndt_handle* h) {
         auto& X = h->exch;
         void* xp[] = {X.d_counts, X.keys_in, X.keys_all, X.keys_sorted, X.canon, X.d_unique, X.d_missing, X.scratch, X.packed, X.pfirst, X.r_sums, X.r_count,
                       X.send_recs, X.own_recs, X.d_matrix, X.d_split_cnt, X.pairs, X.pairs_all, X.d_npairs, X.global_row, X.d_totals,
-                      X.owner_msg, X.owner_msgs_all, X.bkey, X.bcnt, X.bown, X.d_owner_full, X.d_colmsg, X.gw, X.grec, X.grec_all, X.d_tally, X.d_status};
+                      X.owner_msg, X.owner_msgs_all, X.bkey, X.bcnt, X.bown, X.d_owner_full, X.d_colmsg, X.gw, X.grec, X.grec_all, X.d_tally, X.d_status, X.row_of_pair, X.place_all, X.place_mine, X.d_slice};
         for (void* p : xp) if (p) (void)hipFree(p);
         if (X.h_counts) (void)hipHostFree(X.h_counts);
         if (X.h_matrix) (void)hipHostFree(X.h_matrix);

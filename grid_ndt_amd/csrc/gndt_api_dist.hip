@@ -120,6 +120,39 @@ int comm_exchange(gndt_handle* h, gndt_comm* c, const char* send_base, const uin
     if (rc == GNDT_OK && !peers_ok) { h->err = "another rank failed on its way into a collective"; rc = GNDT_ERR_PEER; }
     return rc;
 }
+
+// sum over the ranks of `send` ([W x count] u32), every rank keeping its own segment of `count` elements in `recv`
+int comm_reduce_scatter_u32(gndt_handle* h, gndt_comm* c, const uint32_t* send, uint32_t* recv, size_t count, hipStream_t s) {
+    const int W = c->world, me = c->rank;
+    if (!c->threads) {
+        if (rccl().ReduceScatter) {
+            RCCL_TRY(h, rccl().ReduceScatter(send, recv, count, ncclUint32, ncclSum, c->nccl, s));
+        } else {                                     // (same result through the collective every RCCL has; the array is small)
+            RCCL_TRY(h, rccl().AllReduce(send, const_cast<uint32_t*>(send), count * (size_t)W, ncclUint32, ncclSum, c->nccl, s));
+            HIP_TRY(h, hipMemcpyAsync(recv, send + (size_t)me * count, count * 4, hipMemcpyDeviceToDevice, s));
+        }
+        return GNDT_OK;
+    }
+    ThreadGroup& G = *c->threads;
+    int rc = GNDT_OK;
+    if (hipStreamSynchronize(s) != hipSuccess) { h->err = "hipStreamSynchronize failed before a collective"; rc = GNDT_ERR_HIP; }
+    G.send[me] = send; G.ok[me] = rc == GNDT_OK;
+    G.barrier();
+    bool peers_ok = true;
+    for (int q = 0; q < W; ++q) peers_ok = peers_ok && G.ok[q];
+    if (rc == GNDT_OK && peers_ok && count) {
+        for (int q = 0; q < W && rc == GNDT_OK; ++q) {
+            const uint32_t* src = static_cast<const uint32_t*>(G.send[q]) + (size_t)me * count;
+            if (q == 0) { if (hipMemcpyAsync(recv, src, count * 4, hipMemcpyDeviceToDevice, s) != hipSuccess) rc = GNDT_ERR_HIP; }
+            else hipLaunchKernelGGL(k_add_u32, dim3(grid_for(count)), dim3(256), 0, s, recv, src, (uint64_t)count);
+        }
+        if (hipStreamSynchronize(s) != hipSuccess && rc == GNDT_OK) rc = GNDT_ERR_HIP;
+        if (rc) h->err = "a device copy failed inside a collective";
+    }
+    G.barrier();
+    if (rc == GNDT_OK && !peers_ok) { h->err = "another rank failed on its way into a collective"; rc = GNDT_ERR_PEER; }
+    return rc;
+}
 }  // namespace
 
 extern "C" {
@@ -520,11 +553,12 @@ int owned_columns_enqueue(gndt_handle* h, hipStream_t s) {
     auto& X = h->exch;
     int rc;
     if ((rc = grow_buf(h, X.pairs, X.pairs_cap, std::max<uint64_t>(q.stage_cap, 1)))) return rc;
+    if ((rc = grow_buf(h, X.row_of_pair, X.row_of_pair_cap, X.pairs_cap))) return rc;
     if (!X.d_npairs) HIP_TRY(h, hipMalloc(&X.d_npairs, 2 * sizeof(uint32_t)));
     HIP_TRY(h, hipMemsetAsync(X.d_npairs, 0, 2 * sizeof(uint32_t), s));
     const uint32_t col_wgs = (uint32_t)std::min<uint64_t>(2048, (std::max<uint64_t>(q.stage_cap, 1) + kColChunk - 1) / kColChunk);
     hipLaunchKernelGGL(k_owned_columns, dim3(col_wgs), dim3(256), 0, s, h->out.first_idx, q.row_ncol,
-                       h->d_cnt, q.d_pc, X.pairs, (uint32_t)X.pairs_cap, X.d_npairs);
+                       h->d_cnt, q.d_pc, X.pairs, (uint32_t)X.pairs_cap, X.d_npairs, X.row_of_pair);
     HIP_TRY(h, hipGetLastError());
     return GNDT_OK;
 }
@@ -562,6 +596,54 @@ int global_rows_launch(gndt_handle* h, const unsigned long long* all_pairs, uint
                        q.word_base);
     hipLaunchKernelGGL(k_global_rows, dim3(grid_for(std::max<uint64_t>(h->h_cnt->num_nodes, 1))), dim3(256), 0, s, h->out.first_idx, q.row_ncol, h->d_cnt,
                        q.bitmap, q.word_base, q.ncol_at, X.global_row);
+    HIP_TRY(h, hipGetLastError());
+    return GNDT_OK;
+}
+
+
+// The same for gndt_build_owned_device, sliced over the ranks (gndt_exchange.hpp "the same, sliced"): rank t orders the columns
+// first seen in its slice of the index range; two more small collectives instead of W times the atomics.  X.pairs holds this
+// rank's pairs padded to m_max, all_pairs everybody's (rank r at r * m_max).
+// `own_rows`: false for a rank whose build failed after its peers went on: it only plays its part in the collectives.
+int global_rows_sliced(gndt_handle* h, gndt_comm* c, const unsigned long long* all_pairs, uint64_t m_max, uint64_t total_points, hipStream_t s,
+                       bool own_rows = true) {
+    auto& q = h->part;
+    auto& X = h->exch;
+    const uint32_t W = (uint32_t)c->world, me = (uint32_t)c->rank;
+    int rc;
+    const uint64_t words = (std::max<uint64_t>(total_points, 1) + 31) / 32 + 1;
+    if (words > q.word_cap) { h->err = "total_points differs from the build's"; return GNDT_ERR_INVALID; }
+    const uint64_t slice_words = (words + W - 1) / W;
+    const uint64_t lo = std::min<uint64_t>(words, (uint64_t)me * slice_words), hi = std::min<uint64_t>(words, lo + slice_words);
+    const uint64_t n_all = m_max * W;
+    if (!X.d_totals) HIP_TRY(h, hipMalloc(&X.d_totals, 4 * sizeof(unsigned long long)));
+    if (!X.h_totals) HIP_TRY(h, hipHostMalloc(&X.h_totals, 4 * sizeof(unsigned long long)));
+    if (!X.d_slice) HIP_TRY(h, hipMalloc(&X.d_slice, (2 + 3 * (size_t)kMaxRanks) * sizeof(unsigned long long)));
+    unsigned long long *mine = X.d_slice, *all = X.d_slice + 2, *rows = X.d_slice + 2 + 2 * (size_t)kMaxRanks;
+    if ((rc = grow_buf(h, X.global_row, X.global_row_cap, own_rows ? std::max<uint64_t>(h->h_cnt->num_nodes, 1) : 1))) return rc;
+    if ((rc = grow_buf(h, X.gw, X.gw_cap, std::max<uint64_t>(slice_words, 1)))) return rc;
+    if ((rc = grow_buf(h, X.place_all, X.place_all_cap, std::max<uint64_t>(n_all, 1)))) return rc;
+    if ((rc = grow_buf(h, X.place_mine, X.place_mine_cap, std::max<uint64_t>(m_max, 1)))) return rc;
+    // (the local order is finished — rows emitted —: its arrays now take this rank's slice of the column order of the WHOLE map)
+    hipLaunchKernelGGL(k_order_clear, dim3(grid_for(slice_words, 256, 512)), dim3(256), 0, s, X.gw, (uint64_t)(hi - lo), mine, X.d_npairs + 1);
+    hipLaunchKernelGGL(k_pairs_note_slice, dim3((uint32_t)std::min<uint64_t>(1024, (n_all + 255) / 256)), dim3(256), 0, s, all_pairs, n_all, words, lo, hi,
+                       X.gw, q.ncol_at, mine, X.d_npairs + 1);
+    hipLaunchKernelGGL(k_order_split, dim3(grid_for(slice_words, 256, 512)), dim3(256), 0, s, (const unsigned long long*)X.gw, (uint64_t)(hi - lo), q.bitmap,
+                       q.word_weight);
+    const uint32_t nbw = (uint32_t)std::max<uint64_t>(1, ((hi - lo) + kScanChunk - 1) / kScanChunk);
+    hipLaunchKernelGGL(k_scan_reduce<false>, dim3(nbw), dim3(kScanThreads), 0, s, q.word_weight, (const uint32_t*)nullptr, (uint32_t)(hi - lo), q.bsum_words);
+    hipLaunchKernelGGL(k_scan_apply<false>, dim3(nbw), dim3(kScanThreads), 0, s, q.word_weight, (const uint32_t*)nullptr, (uint32_t)(hi - lo), q.bsum_words,
+                       q.word_base);
+    hipLaunchKernelGGL(k_pair_places, dim3((uint32_t)std::min<uint64_t>(2048, (n_all + 255) / 256)), dim3(256), 0, s, all_pairs, n_all, lo, hi,
+                       (const uint32_t*)q.bitmap, (const uint32_t*)q.word_base, (const uint32_t*)q.ncol_at, X.place_all);
+    HIP_TRY(h, hipGetLastError());
+    // everybody's slice totals (rank t's pair at all + 2 t), and every rank's own places
+    HIP_TRY(h, hipMemcpyAsync(all + 2 * (size_t)me, mine, 2 * sizeof(unsigned long long), hipMemcpyDeviceToDevice, s));
+    if ((rc = comm_all_gather(h, c, all + 2 * (size_t)me, all, 2, 8, s))) return rc;
+    if ((rc = comm_reduce_scatter_u32(h, c, X.place_all, X.place_mine, (size_t)m_max, s))) return rc;
+    hipLaunchKernelGGL(k_slice_rows, dim3(1), dim3(1), 0, s, (const unsigned long long*)all, W, rows, X.d_totals);
+    if (own_rows) hipLaunchKernelGGL(k_global_rows_sliced, dim3(grid_for(m_max)), dim3(256), 0, s, (const unsigned long long*)X.pairs, (const uint32_t*)X.row_of_pair,
+                       (const uint32_t*)X.place_mine, (uint32_t)m_max, slice_words, (const unsigned long long*)rows, X.global_row);
     HIP_TRY(h, hipGetLastError());
     return GNDT_OK;
 }
@@ -817,8 +899,13 @@ int gndt_build_owned_device(gndt_handle* h, gndt_comm* c, const void* shard_xyz_
     }
     if ((rc = grow_buf(h, X.pairs_all, X.pairs_all_cap, m_max * (uint64_t)W))) return rc;
     if ((rc = comm_all_gather(h, c, X.pairs, X.pairs_all, (size_t)m_max, 8, s))) return rc;
-    if (err) return leave();                            // (no collective follows: the others finish without this rank)
-    if ((rc = global_rows_launch(h, X.pairs_all, m_max * (uint64_t)W, total_points, s))) return rc;
+    const bool sliced = W > 1 && tuning().owner_sliced_rows != 0;
+    if (err) {      // the others finish without this rank's columns — and notice, by its poison pair — once it has played its part
+        if (sliced && (rc = global_rows_sliced(h, c, X.pairs_all, m_max, total_points, s, false))) return rc;
+        return leave();
+    }
+    if (sliced) { if ((rc = global_rows_sliced(h, c, X.pairs_all, m_max, total_points, s))) return rc; }
+    else if ((rc = global_rows_launch(h, X.pairs_all, m_max * (uint64_t)W, total_points, s))) return rc;
     if (!X.h_bad) HIP_TRY(h, hipHostMalloc(&X.h_bad, sizeof(uint32_t)));
     HIP_TRY(h, hipMemcpyAsync(X.h_totals, X.d_totals, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
     HIP_TRY(h, hipMemcpyAsync(X.h_bad, X.d_npairs + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, s));

@@ -29,6 +29,7 @@ struct RcclApi {
     decltype(&ncclCommDestroy) CommDestroy = nullptr;
     decltype(&ncclAllGather) AllGather = nullptr;
     decltype(&ncclAllReduce) AllReduce = nullptr;
+    decltype(&ncclReduceScatter) ReduceScatter = nullptr;      // (optional: an all-reduce of the whole array does the same job)
     decltype(&ncclSend) Send = nullptr;
     decltype(&ncclRecv) Recv = nullptr;
     decltype(&ncclGroupStart) GroupStart = nullptr;
@@ -58,6 +59,7 @@ inline const RcclApi& rccl() {
             a.CommDestroy = (decltype(a.CommDestroy))dlsym(a.lib, "ncclCommDestroy");
             a.AllGather = (decltype(a.AllGather))dlsym(a.lib, "ncclAllGather");
             a.AllReduce = (decltype(a.AllReduce))dlsym(a.lib, "ncclAllReduce");
+            a.ReduceScatter = (decltype(a.ReduceScatter))dlsym(a.lib, "ncclReduceScatter");
             a.GetErrorString = (decltype(a.GetErrorString))dlsym(a.lib, "ncclGetErrorString");
             a.Send = (decltype(a.Send))dlsym(a.lib, "ncclSend");
             a.Recv = (decltype(a.Recv))dlsym(a.lib, "ncclRecv");
@@ -209,7 +211,8 @@ constexpr uint32_t kColChunk = 4096;
 static __global__ void __launch_bounds__(256) k_owned_columns(const uint32_t* __restrict__ first_idx, const uint32_t* __restrict__ row_ncol,
                                                               const Counters* __restrict__ cnt, const PartCounters* __restrict__ pc,
                                                               unsigned long long* __restrict__ pairs,
-                                                              uint32_t pairs_cap, uint32_t* __restrict__ n_pairs) {
+                                                              uint32_t pairs_cap, uint32_t* __restrict__ n_pairs,
+                                                              uint32_t* __restrict__ row_of_pair /* nullable: the column's first row */) {
     if (pc->lds_overflow | pc->stage_overflow | pc->index_overflow | pc->part_overflow) return;   // the build is re-run: no rows yet
     __shared__ uint32_t heads, base, cursor;
     const uint32_t n = cnt->num_nodes;
@@ -234,7 +237,7 @@ static __global__ void __launch_bounds__(256) k_owned_columns(const uint32_t* __
             wbase = (uint32_t)__shfl((int)wbase, 0, 64);
             if (nc) {
                 const uint32_t pos = base + wbase + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-                if (pos < pairs_cap) pairs[pos] = ((unsigned long long)first_idx[r] << 32) | nc;
+                if (pos < pairs_cap) { pairs[pos] = ((unsigned long long)first_idx[r] << 32) | nc; if (row_of_pair) row_of_pair[pos] = r; }
             }
         }
         __syncthreads();
@@ -297,6 +300,80 @@ static __global__ void __launch_bounds__(256) k_pairs_note(const unsigned long l
     if ((threadIdx.x & 63) == 0 && cols) { atomicAdd(&s_nodes, nodes); atomicAdd(&s_cols, cols); }
     __syncthreads();
     if (threadIdx.x == 0 && s_cols) { atomicAdd(&totals[0], s_nodes); atomicAdd(&totals[1], s_cols); }
+}
+
+// ---- the same, sliced: rank t orders only the columns whose first-seen index falls into ITS slice of the index range ----
+// With every rank noting all columns the ordering costs W times the memory-side atomics of the single-GPU build (S3: 4 M
+// columns; profiles/r02_owner_threads.json: 0.8 -> 2.2 ms from 2 to 8 ranks).  Here rank t owns the bitmap words
+// [t * slice_words, (t + 1) * slice_words): it notes the pairs of that slice (1 / W of the atomics), takes the prefix inside
+// it, and writes for every pair of the slice — whoever owns the column — the place of the column RELATIVE to the slice.
+// A sum reduce-scatter over the ranks hands every rank the places of its own pairs (each is non-zero on one rank at most), an
+// all-gather of the W slice totals turns them into rows of the whole map.
+static __global__ void __launch_bounds__(256) k_pairs_note_slice(const unsigned long long* __restrict__ pairs, uint64_t n, uint64_t words,
+                                                                 uint64_t lo_word, uint64_t hi_word, unsigned long long* __restrict__ gw,
+                                                                 uint32_t* __restrict__ ncol_at, unsigned long long* __restrict__ slice_tot,
+                                                                 uint32_t* __restrict__ bad) {
+    __shared__ unsigned long long s_nodes, s_cols;
+    if (threadIdx.x == 0) { s_nodes = 0ull; s_cols = 0ull; }
+    __syncthreads();
+    unsigned long long nodes = 0, cols = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const unsigned long long pr = pairs[i];
+        if (pr == kNoPair) continue;
+        const uint32_t cf = (uint32_t)(pr >> 32), nc = (uint32_t)pr;
+        const uint64_t w = cf >> 5;
+        if (w >= words) { atomicAdd(bad, 1u); continue; }         // (every rank sees every pair: they all count it)
+        if (w < lo_word || w >= hi_word) continue;
+        atomicAdd(&gw[w - lo_word], ((unsigned long long)nc << 32) | (1ull << (cf & 31u)));
+        ncol_at[cf] = nc;
+        nodes += nc; ++cols;
+    }
+    nodes = (unsigned long long)wave_sum((double)nodes);
+    cols = (unsigned long long)wave_sum((double)cols);
+    if ((threadIdx.x & 63) == 0 && cols) { atomicAdd(&s_nodes, nodes); atomicAdd(&s_cols, cols); }
+    __syncthreads();
+    if (threadIdx.x == 0 && s_cols) { atomicAdd(&slice_tot[0], s_nodes); atomicAdd(&slice_tot[1], s_cols); }
+}
+// place of every pair of the slice relative to the slice's first row (0 for the pairs of other slices)
+static __global__ void __launch_bounds__(256) k_pair_places(const unsigned long long* __restrict__ pairs, uint64_t n, uint64_t lo_word, uint64_t hi_word,
+                                                            const uint32_t* __restrict__ bitmap, const uint32_t* __restrict__ word_base,
+                                                            const uint32_t* __restrict__ ncol_at, uint32_t* __restrict__ place) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const unsigned long long pr = pairs[i];
+        uint32_t out = 0u;
+        if (pr != kNoPair) {
+            const uint32_t cf = (uint32_t)(pr >> 32);
+            const uint64_t w = cf >> 5;
+            if (w >= lo_word && w < hi_word) {
+                uint32_t m = bitmap[w - lo_word] & ((1u << (cf & 31u)) - 1u);
+                out = word_base[w - lo_word];
+                while (m) { out += ncol_at[((uint32_t)w << 5) + (uint32_t)__builtin_ctz(m)]; m &= m - 1u; }
+            }
+        }
+        place[i] = out;
+    }
+}
+// everybody's slice totals {nodes, columns} -> the first row of every slice (slice_row[t]) and the totals of the whole map
+static __global__ void k_slice_rows(const unsigned long long* __restrict__ slice_tot_all, uint32_t W, unsigned long long* __restrict__ slice_row,
+                                    unsigned long long* __restrict__ totals) {
+    unsigned long long nodes = 0, cols = 0;
+    for (uint32_t t = 0; t < W; ++t) { slice_row[t] = nodes; nodes += slice_tot_all[2 * t]; cols += slice_tot_all[2 * t + 1]; }
+    totals[0] = nodes; totals[1] = cols;
+}
+// this rank's pairs, their places and the slices' first rows -> the row of every local row in the map of the whole cloud
+static __global__ void __launch_bounds__(256) k_global_rows_sliced(const unsigned long long* __restrict__ pairs, const uint32_t* __restrict__ row_of_pair,
+                                                                   const uint32_t* __restrict__ place, uint32_t n_pairs, uint64_t slice_words,
+                                                                   const unsigned long long* __restrict__ slice_row, uint32_t* __restrict__ global_row) {
+    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n_pairs; j += gridDim.x * blockDim.x) {
+        const unsigned long long pr = pairs[j];
+        if (pr == kNoPair) continue;
+        const uint32_t cf = (uint32_t)(pr >> 32), nc = (uint32_t)pr, r = row_of_pair[j];
+        const uint32_t row = (uint32_t)slice_row[(cf >> 5) / slice_words] + place[j];
+        for (uint32_t i = 0; i < nc; ++i) global_row[r + i] = row + i;
+    }
+}
+static __global__ void __launch_bounds__(256) k_add_u32(uint32_t* __restrict__ dst, const uint32_t* __restrict__ src, uint64_t n) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) dst[i] += src[i];
 }
 
 static __global__ void __launch_bounds__(256) k_order_split(const unsigned long long* __restrict__ gw, uint64_t words,

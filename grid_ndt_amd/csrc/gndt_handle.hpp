@@ -148,6 +148,9 @@ struct gndt_handle {
         uint32_t* d_tally = nullptr;  uint32_t* h_tally = nullptr;
         uint64_t owned_serial = 0;  uint32_t owned_world = 0;   // result_serial / ranks of the owned build global_row describes (0: none)
         uint32_t* d_status = nullptr;                           // scratch word for the status kernels
+        // sliced global rows: the first row of every pair of this rank, everybody's pair places, this rank's, slice totals / rows
+        uint32_t* row_of_pair = nullptr; uint64_t row_of_pair_cap = 0;  uint32_t* place_all = nullptr; uint64_t place_all_cap = 0;
+        uint32_t* place_mine = nullptr; uint64_t place_mine_cap = 0;  unsigned long long* d_slice = nullptr;   // [2 mine | 2W all | W rows]
         // locality-aware ownership (gndt_exchange.hpp): this rank's sample message, everybody's, the block table
         uint32_t* owner_msg = nullptr;  uint32_t* owner_msgs_all = nullptr; uint64_t owner_msgs_cap = 0;
         uint32_t* bkey = nullptr;  uint32_t* bcnt = nullptr; uint64_t bcnt_cap = 0;  uint8_t* bown = nullptr;  uint32_t* d_owner_full = nullptr;
@@ -209,6 +212,7 @@ struct Tuning {
     double tile_ratio = 48.0;    // GNDT_TILE_RATIO     AUTO takes strategy TILE from this many points per partial on (sampled; the
                                  //                     measured crossover, profiles/r02_tile_calibration.json)
     int one_level = 1;           // GNDT_ONE_LEVEL      small clouds: level 1 writes the buckets directly (0: counting partition)
+    int owner_sliced_rows = 1;   // GNDT_OWNER_SLICED   owner-partitioned build: every rank orders a slice of the index range (1) or all columns (0)
     int owner_locality = 1;      // GNDT_OWNER_LOCALITY owner-partitioned build: sampled block ownership (1) or hash ownership only (0)
     int update_tile = -1;        // GNDT_UPDATE_TILE    incremental updates through the tile kernel: 1 always, 0 never, -1 = by strategy
     bool stamps = false;         // GNDT_STAMPS=1       in-kernel phase stamps of the bucket kernel
