@@ -69,20 +69,35 @@ def parse():
                     help="diagnostic: after the timed run, one extra build with in-kernel phase stamps (stderr)")
     ap.add_argument("--nodes-hint", type=int, default=-1, help="max_nodes_hint (-1 = the workload's default)")
     ap.add_argument("--graph", action="store_true", help="S4: replay one captured update per frame (hipGraph) instead of eager launches")
+    ap.add_argument("--no-anchor", action="store_true", help="N>1: skip the single-GPU build of the same cloud on rank 0 (single_gpu_anchor)")
+    ap.add_argument("--no-modes", action="store_true", help="N>1, --mode owner: skip the three extra steps of --mode global (modes block)")
+    ap.add_argument("--watchdog", type=int, default=900, help="seconds a stage (warm-up + timed loop, gather, anchor, modes) may take before "
+                                                             "the rank exits non-zero: a hung collective must not hang the job")
+    ap.add_argument("--force-multi-extras", action="store_true",
+                    help="testing on a one-GPU box (under torchrun with ONE rank): run the anchor / gather / modes stages of the N > 1 line all the same")
     ap.add_argument("--launch-check", action="store_true",
                     help="CPU-only check of the self-launch path: the ranks rendezvous over gloo, shard a small cloud "
                          "exactly as the timed run would, and rank 0 prints what every rank got")
     return ap.parse_args()
 
 
+# what the N > 1 line carries beside the N = 1 keys (tests/test_bench_launcher.py)
+MULTI_GPU_KEYS = ("single_gpu_anchor", "speedup_vs_single_gpu", "gather_ms", "modes", "exchange")
+
+
+def watchdog(seconds):
+    """Arms (seconds > 0) or disarms the stage watchdog: a C thread of the interpreter that dumps the tracebacks and _exit(1)s
+    the rank — also while the main thread sits in a collective inside libgndt or RCCL.  torchrun then ends the other ranks."""
+    import faulthandler
+    faulthandler.cancel_dump_traceback_later()
+    if seconds > 0:
+        faulthandler.dump_traceback_later(seconds, exit=True)
+
+
 def self_launch(a):
-    """`python bench.py --gpus N` without a launcher: start the ranks as a child job.  The parent never touches the
-    GPU (device_count does not initialise it on this image); it only relays the child's exit code."""
-    import torch
-    have = torch.cuda.device_count()
-    if have < a.gpus and not a.launch_check:
-        print(f"bench.py: --gpus {a.gpus} but only {have} GPU(s) visible", file=sys.stderr)
-        return 2
+    """`python bench.py --gpus N` without a launcher: start the ranks as a child job.  The parent never touches the GPU — it
+    does not even count the devices (without amdsmi that goes through hipGetDeviceCount and initialises the runtime): a rank
+    that finds no device of its own says so and exits non-zero; the parent only relays the child job's exit code."""
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
@@ -122,6 +137,17 @@ def make_cloud(name, nb, rank, world, global_mode):
         lo, hi = 1 + rank * nb // world, 1 + (rank + 1) * nb // world
         return origin, np.ascontiguousarray(cloud[lo:hi]), lo - 1, nb
     return origin, np.ascontiguousarray(cloud[1:]), 0, nb * world
+
+
+def shard_and_anchor(name, nb, rank, world, one_cloud, want_anchor):
+    """make_cloud for this rank; with `want_anchor` rank 0 generates the WHOLE cloud once (the single-GPU anchor builds it) and
+    takes its shard out of it.  -> (origin, shard, first index, job points, whole cloud on rank 0 or None)."""
+    if want_anchor and rank == 0:
+        origin, full, _, job = make_cloud(name, nb, 0, 1, True)
+        hi = nb // world
+        return origin, np.ascontiguousarray(full[:hi]), 0, job, full
+    origin, pts, base, job = make_cloud(name, nb, rank, world, one_cloud)
+    return origin, pts, base, job, None
 
 
 def cpu_baseline(origin, pts, P, sample):
@@ -186,13 +212,22 @@ def launch_check(a, rank, world):
     wname = a.workload or ("S3" if world > 1 else "S2")
     mode = a.mode or ("owner" if world > 1 else "single")
     total = a.points or 300_000
-    origin, pts, base, job = make_cloud(wname, total, rank, world, mode in ("global", "owner"))
+    one_cloud = mode in ("global", "owner")
+    origin, pts, base, job, anchor = shard_and_anchor(wname, total, rank, world, one_cloud, want_anchor=one_cloud and world > 1 and not a.no_anchor)
     mine = torch.tensor([base, pts.shape[0], job], dtype=torch.int64)
     got = [torch.zeros_like(mine) for _ in range(world)]
     dist.all_gather(got, mine)
     if rank == 0:
-        print(json.dumps({"launch_check": True, "n_gpus": world, "workload": wname, "mode": mode,
-                          "shards": [[int(v) for v in g] for g in got], "origin": [float(v) for v in origin]}))
+        out = {"launch_check": True, "n_gpus": world, "workload": wname, "mode": mode,
+               "shards": [[int(v) for v in g] for g in got], "origin": [float(v) for v in origin]}
+        if one_cloud and world > 1:       # what the timed run adds to its line, and the cloud rank 0 builds alone for the anchor
+            out["multi_gpu_keys"] = [k for k in MULTI_GPU_KEYS if not (k == "single_gpu_anchor" and a.no_anchor)
+                                     and not (k == "speedup_vs_single_gpu" and a.no_anchor) and not (k == "gather_ms" and mode != "owner")
+                                     and not (k == "modes" and (mode != "owner" or a.no_modes))]
+            out["anchor_points"] = None if anchor is None else int(anchor.shape[0])
+            out["anchor_is_the_ranks_cloud"] = None if anchor is None else bool(
+                np.array_equal(anchor[base:base + pts.shape[0]], pts) and anchor.shape[0] == job)
+        print(json.dumps(out))
     dist.destroy_process_group()
 
 
@@ -269,6 +304,7 @@ def run_stream(a):
 
 def main():
     a = parse()
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # before anything initialises HIP / HSA in this process
     if a.workload == "S4":
         return run_stream(a)
     if a.gpus > 1 and "RANK" not in os.environ:
@@ -285,11 +321,14 @@ def main():
     if world != a.gpus:
         print(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}", file=sys.stderr)
         sys.exit(2)
+    if local >= torch.cuda.device_count():
+        print(f"bench.py: rank {rank} wants GPU {local} but only {torch.cuda.device_count()} visible", file=sys.stderr)
+        sys.exit(2)
     torch.cuda.set_device(local)
     mode = a.mode or ("owner" if world > 1 else "single")
     use_dist = world > 1 or ("RANK" in os.environ and mode in ("global", "owner"))   # torchrun with one rank exercises the exchange too
     if use_dist:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        watchdog(a.watchdog)
         dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
     global_mode = use_dist and mode in ("global", "owner")      # ONE cloud sharded over the ranks
     owner_mode = use_dist and mode == "owner"
@@ -302,8 +341,12 @@ def main():
     hint = W["hint"] if a.nodes_hint < 0 else a.nodes_hint
     P = dict(grid_len=W["grid_len"], z_len=W["z_len"], slope_interval=0.08, demand="slope")
     t_gen = time.perf_counter()
-    origin, host_pts, first_base, job_points = make_cloud(wname, total, rank, world, global_mode)
+    several = world > 1 or a.force_multi_extras
+    want_anchor = global_mode and several and not a.no_anchor
+    watchdog(0)
+    origin, host_pts, first_base, job_points, anchor_host = shard_and_anchor(wname, total, rank, world, global_mode, want_anchor)
     t_gen = time.perf_counter() - t_gen
+    watchdog(a.watchdog)
     n = host_pts.shape[0]
     dev = torch.device(f"cuda:{local}")
     torch.cuda.synchronize()
@@ -368,8 +411,13 @@ def main():
     # warm-up builds have taught the handle this cloud's sizes; if the last timed build still had to be re-run, the ones
     # before it ran short as well and the timing is not that of complete builds.
     retries_timed = m.retry_count() - retries_before
+    if use_dist:                         # a re-run on ANY rank invalidates the step time
+        rt = torch.tensor([retries_timed], dtype=torch.int64, device=dev)
+        dist.all_reduce(rt, op=dist.ReduceOp.SUM)
+        retries_timed = int(rt.item())
     if retries_timed and rank == 0:
-        print(f"bench.py: WARNING {retries_timed} build re-run(s) inside the timed region: the step time is not valid", file=sys.stderr)
+        print(f"bench.py: ERROR {retries_timed} build re-run(s) inside the timed region: the step time is not that of complete builds "
+              "(the line is printed with \"valid\": false and the exit code is 3)", file=sys.stderr)
     if global_mode:                       # stage times from a few extra, untimed steps (their events make the call wait)
         exch.clear()
         for _ in range(3):
@@ -389,10 +437,83 @@ def main():
     dt = float(t.item())
     nodes, cols, slopes = m.sync()
     n_local = n
+    multi = {}
     if owner_mode:                       # the handle holds this rank's columns; the map of the whole cloud has:
         n_local = int(exch_timed.get("owned_points", n))
         local_nodes = nodes
         nodes, cols, slopes = int(exch_timed["global_nodes"]), int(exch_timed["global_columns"]), int(exch_timed["global_slopes"])
+        # ---- ONE map for the consumers (untimed by `value`): the rows of all ranks gathered on rank 0 and scattered by global row ----
+        watchdog(a.watchdog)
+        g_ms = []
+        for _ in range(3):
+            step()
+            m.sync()
+            torch.cuda.synchronize()
+            dist.barrier()
+            t1 = time.perf_counter()
+            m.gather_owned(comm, 0, stream)
+            torch.cuda.synchronize()
+            g_ms.append((time.perf_counter() - t1) * 1e3)
+        tg = torch.tensor([float(np.median(g_ms))], dtype=torch.float64, device=dev)
+        dist.all_reduce(tg, op=dist.ReduceOp.MAX)
+        multi["gather_ms"] = {"value": round(float(tg.item()), 4), "rows": int(nodes), "bytes_per_row": 84,
+                              "what": "gndt_gather_owned_map_device to rank 0 (ncclSend / ncclRecv of the packed rows + scatter by global row), "
+                                      "median of 3, max over ranks; after it rank 0's handle holds the whole map"}
+        if rank == 0:
+            an, ac, asl = m.sync()
+            multi["gather_ms"]["assembled_map_matches_totals"] = bool((an, ac, asl) == (nodes, cols, slopes))
+    if global_mode and several and owner_mode and not a.no_modes:
+        # ---- BASELINE configs[2] names the "cell-stat all-reduce": the same cloud through --mode global, three steps ----
+        watchdog(a.watchdog)
+        from grid_ndt_amd._lib import GndtError
+        try:
+            mg = new_map(hint)
+            mg.build_global(comm, "slope", pts, first_base, job_points, stream)
+            mg.sync()
+            torch.cuda.synchronize()
+            dist.barrier()
+            t1 = time.perf_counter()
+            for _ in range(3):
+                mg.build_global(comm, "slope", pts, first_base, job_points, stream)
+            gn, _, _ = mg.sync()
+            torch.cuda.synchronize()
+            tgl = torch.tensor([(time.perf_counter() - t1) / 3 * 1e3], dtype=torch.float64, device=dev)
+            dist.all_reduce(tgl, op=dist.ReduceOp.MAX)
+            multi["modes"] = {"owner": {"ms_per_step": round(dt / a.steps * 1e3, 4)},
+                              "global": {"ms_per_step": round(float(tgl.item()), 4), "nodes": int(gn), "steps": 3,
+                                         "what": "gndt_build_global_device: key all-gather + packed sum / min all-reduce of the per-node statistics, "
+                                                 "the whole map finalised on every rank"}}
+            del mg
+        except GndtError as e:           # (every rank gets an error at the same collective: gndt.h, GNDT_ERR_PEER)
+            multi["modes"] = {"owner": {"ms_per_step": round(dt / a.steps * 1e3, 4)}, "global": {"error": str(e)}}
+    if want_anchor:
+        # ---- the same cloud built by rank 0 ALONE: the N = 1 point of the scaling series, measured in this very run ----
+        watchdog(max(a.watchdog, 1800))
+        dist.barrier()
+        if rank == 0:
+            full = torch.from_numpy(anchor_host).to(dev)
+            ma = new_map(hint)
+            for _ in range(2):
+                ma.create2DMap("slope", full, stream)
+                ma.sync()
+            r0 = ma.retry_count()
+            asteps = max(3, min(a.steps, 10))
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(asteps):
+                ma.create2DMap("slope", full, stream)
+            an, ac, asl = ma.sync()
+            torch.cuda.synchronize()
+            a_ms = (time.perf_counter() - t1) / asteps * 1e3
+            multi["single_gpu_anchor"] = {"ms_per_step": round(a_ms, 4), "Mpoints_per_s": round(job_points / a_ms / 1e3, 3), "steps": asteps,
+                                          "points_total": int(full.shape[0]), "nodes": int(an), "columns": int(ac), "slopes": int(asl),
+                                          "retries_in_timed_region": int(ma.retry_count() - r0),
+                                          "same_map_as_the_ranks": bool((an, ac, asl) == (nodes, cols, slopes)),
+                                          "what": "gndt_build_device of the WHOLE cloud on rank 0's GPU while the other ranks wait (not part of `value`)"}
+            multi["speedup_vs_single_gpu"] = round(a_ms / (dt / a.steps * 1e3), 4)
+            del full, ma
+        dist.barrier()
+    watchdog(0)
 
     # ---- extras (untimed, rank 0 of a single-GPU run): what a 10 Hz callback sees, the no-hint path, PCIe legs ----
     extras = {}
@@ -472,6 +593,9 @@ def main():
             "phase_ms": phases,
             "retries_in_timed_region": int(retries_timed),
         }
+        if retries_timed:
+            out["valid"] = False
+        out.update(multi)
         if global_mode:
             out["exchange"] = {k: (round(v, 4) if isinstance(v, float) else v) for k, v in exch_timed.items()}
             out["exchange"]["ranks"] = world
@@ -500,6 +624,8 @@ def main():
         print(json.dumps(out))
     if use_dist:
         dist.destroy_process_group()
+    if retries_timed:
+        sys.exit(3)
 
 
 if __name__ == "__main__":

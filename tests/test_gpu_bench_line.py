@@ -1,0 +1,28 @@
+"""GPU tier: the N > 1 line of bench.py, produced on the one-GPU box by a torchrun-style rank of a world of ONE (RCCL communicator of
+one rank inside libgndt) with --force-multi-extras: owner-partitioned steps, the gather to rank 0, the three --mode global steps
+and the single-GPU anchor of the same cloud all run, and the anchor must be the very map the ranks built."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_multi_gpu_line_carries_anchor_gather_and_modes():
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29731")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--mode", "owner", "--workload", "S3", "--points", "3000000",
+                        "--steps", "4", "--warmup", "2", "--force-multi-extras", "--no-cpu-baseline"], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(line) == 1, r.stdout[-2000:]
+    d = json.loads(line[0])
+    assert d["config"]["multi_gpu_mode"] == "owner" and d["retries_in_timed_region"] == 0 and "valid" not in d
+    a = d["single_gpu_anchor"]
+    assert a["same_map_as_the_ranks"] and a["points_total"] == d["config"]["points_total"] == 3000000 and a["nodes"] == d["config"]["nodes"]
+    assert a["retries_in_timed_region"] == 0 and d["speedup_vs_single_gpu"] > 0
+    assert d["gather_ms"]["value"] > 0 and d["gather_ms"]["assembled_map_matches_totals"] and d["gather_ms"]["rows"] == d["config"]["nodes"]
+    assert d["modes"]["global"]["nodes"] == d["config"]["nodes"] and d["modes"]["global"]["ms_per_step"] > 0
