@@ -348,6 +348,7 @@ constexpr int kTilePer1 = 8;       // level 1: 4096 records per tile (68 KB of L
 #define GNDT_TILE_PER2 4
 #endif
 constexpr int kTilePer2 = GNDT_TILE_PER2;       // level 2: 2048 records per tile (34 KB): four tiles resident per CU
+static_assert(kTilePer1 * 64 == 512, "kWeight512Flag: a wave's share of a level-1 tile is the 512 points a weighted record can stand for");
 constexpr int kMaxFan = 512;               // fan-out per level: up to 512 x 512 buckets
 constexpr uint32_t kSampleEvery = 64;      // level 1 samples one record in 64 to size the buckets' regions (the hash test below is >> 26)
 

@@ -59,7 +59,7 @@ def test_single_points_and_tiny_clouds():
         ref = parity.ref_from_cloud(cloud, P)
         for strategy in (1, 3, 4):
             _, out = parity.gpu_from_cloud(cloud, P, on_device=True, strategy=strategy)
-            parity.assert_parity(out, ref, adversarial=True)
+            parity.assert_parity(out, ref)                    # (random points: the share caps of tests/parity.py stay in force)
 
 
 @pytest.mark.parametrize("kind", ["pole", "identical", "two_hot_columns"])
@@ -84,7 +84,10 @@ def test_degenerate_large_clouds_fall_through_the_partition_paths(kind):
     ref = parity.ref_from_cloud(cloud, P)
     for strategy in (0, 4):
         m, out = parity.gpu_from_cloud(cloud, P, on_device=True, strategy=strategy)
-        parity.assert_parity(out, ref, adversarial=True)
+        # The share caps of tests/parity.py stay in force except for the pole: ~330 points per node at |z| up to 200 m, where the
+        # fp32-sequential oracle itself is more than 5e-6 off the exact scatter on 53 of the 4000 nodes (1.3 %; cap 0.1 %) — the
+        # widening FACTOR stays capped for it as well.
+        parity.assert_parity(out, ref, adversarial=(kind == "pole"))
 
 
 
@@ -98,4 +101,4 @@ def test_min_points_other_than_the_reference_constant(min_points):
     assert ((ref["flags"] & 1) != 0).sum() != ((parity.ref_from_cloud(cloud, dict(P, min_points=3))["flags"] & 1) != 0).sum()
     for strategy in (1, 3, 4):
         _, out = parity.gpu_from_cloud(cloud, P, on_device=True, strategy=strategy)
-        parity.assert_parity(out, ref, adversarial=True)
+        parity.assert_parity(out, ref, adversarial=True)       # (_cloud: lattice points and their float neighbours)
