@@ -1,0 +1,152 @@
+"""GPU tier: BASELINE.json configs[2] and configs[4] at FULL size on one GPU — S3, 100 M LiDAR-ordered terrain points at 0.2 m,
+and S5, the 20 M-point two-storey site at 0.1 m whose last 3 M points sit at (0,0,0).  The oracle does not finish such clouds in
+seconds, so the checks are the size-independent ones the domain offers (every point binned once, unique keys, reference order
+monotone, labels consistent with counts), a sample of nodes against an independent numpy fp64 recomputation (mean, scatter,
+lambda_min) and, on a 16 M-point prefix, strategy PARTITION == strategy ATOMIC row for row."""
+import numpy as np
+import pytest
+
+from grid_ndt_amd import scenes
+
+pytestmark = pytest.mark.gpu
+
+
+def _keys_of_points(cloud, gl, zl):
+    """transMortonXYZ's integer form for every binned point (map2D.h:950-976), in numpy fp32 like the reference."""
+    o = cloud[0]
+    out = []
+    for ax, ln in ((0, gl), (1, gl), (2, zl)):
+        d = cloud[1:, ax] - o[ax]
+        n = np.maximum(1, np.ceil(np.abs(d) / np.float32(ln))).astype(np.int32)
+        out.append(np.where(cloud[1:, ax] > o[ax], n, -n))
+    return out
+
+
+def _pack(sx, sy, sz):
+    return ((sx.astype(np.int64) + (1 << 20)) << 43) | ((sy.astype(np.int64) + (1 << 20)) << 22) | (sz.astype(np.int64) + (1 << 21))
+
+
+def _structure_checks(out, n):
+    assert int(out["count"].astype(np.int64).sum()) == n                         # every point binned once
+    keys = _pack(out["sx"], out["sy"], out["sz"])
+    assert np.unique(keys).size == out["num_nodes"]                              # one row per node
+    f = out["first_idx"].astype(np.int64)
+    assert np.unique(f).size == f.size and f.min() == 0 and f.max() < n
+    col = (out["sx"].astype(np.int64) << 32) ^ (out["sy"].astype(np.int64) & 0xFFFFFFFF)
+    new_col = np.concatenate([[True], col[1:] != col[:-1]])
+    assert int(new_col.sum()) == out["num_columns"] == np.unique(col).size       # a column's rows are contiguous
+    assert np.all(np.diff(f[new_col]) > 0)                                       # columns in first-seen order (morton_list)
+    assert np.all(np.diff(f)[~new_col[1:]] > 0)                                  # nodes of a column in first-seen order
+    has = (out["flags"] & 1) != 0
+    assert np.array_equal(has, out["count"] >= 3)                                # MINPOINTSIZE (map2D.h:28)
+    assert not np.any(out["flags"][~has] & 6) and int(np.count_nonzero(out["flags"] & 2)) == out["num_slopes"]
+    assert np.all(out["mean"][~has] == 0) and np.all(out["cov"][~has] == 0)
+    return keys, has
+
+
+def _sample_check(cloud, out, keys, has, gl, zl, picks=200, seed=0, max_count=20000):
+    """`picks` random nodes with statistics against numpy fp64 (two-pass mean / scatter, eigvalsh)."""
+    rng = np.random.default_rng(seed)
+    cand = np.flatnonzero(has & (out["count"] <= max_count))
+    pick = rng.choice(cand, picks, replace=False)
+    pk = _pack(*_keys_of_points(cloud, gl, zl))
+    sel = np.flatnonzero(np.isin(pk, keys[pick]))
+    order = np.argsort(pk[sel], kind="stable")
+    sel = sel[order]
+    grp_keys, starts = np.unique(pk[sel], return_index=True)
+    assert grp_keys.size == picks
+    ends = np.concatenate([starts[1:], [sel.size]])
+    row_of = {int(k): int(i) for k, i in zip(keys[pick], pick)}
+    body = cloud[1:]
+    for k, a, b in zip(grp_keys, starts, ends):
+        i = row_of[int(k)]
+        idx = sel[a:b]
+        assert idx.size == out["count"][i] and idx.min() == out["first_idx"][i]
+        p = body[idx].astype(np.float64)
+        mu = p.mean(0)
+        S = (p - mu).T @ (p - mu)
+        ut = np.array([S[0, 0], S[0, 1], S[0, 2], S[1, 1], S[1, 2], S[2, 2]])
+        assert np.abs(out["cov"][i] - ut).max() <= 1e-5 * np.abs(ut).max() + 1e-12
+        assert np.abs(out["mean"][i] - mu).max() <= 1e-5 * max(1.0, np.abs(mu).max())
+        if out["flags"][i] & 2:
+            ev = np.linalg.eigvalsh(S)
+            lam = 0.0 if (out["rough"][i] == np.float32(0.01) and ev[0] < 1e-3) else float(out["rough"][i])
+            assert abs(lam - ev[0]) <= 1e-5 * np.trace(S) + 1e-12
+
+
+@pytest.fixture(scope="module")
+def terrain_100m():
+    return scenes.terrain_cloud(100_000_000)
+
+
+def test_full_size_terrain_100M(terrain_100m):
+    import torch
+    import grid_ndt_amd as g
+    cloud = terrain_100m
+    n = cloud.shape[0] - 1
+    m = g.TwoDmap(0.2, 0.2)
+    m.setInterval(0.08)
+    m.setCloudFirst(cloud[0])
+    t = torch.from_numpy(cloud[1:]).cuda()
+    m.create2DMap("slope", t)
+    out = m.export()
+    assert m.last_strategy() == 2 and out["num_nodes"] > 8_000_000 and out["num_columns"] > 3_000_000
+    before = m.retry_count()
+    m.create2DMap("slope", t)                       # steady state: what the first build learnt is enough
+    n2, k2, s2 = m.sync()
+    assert m.retry_count() == before and (n2, k2, s2) == (out["num_nodes"], out["num_columns"], out["num_slopes"])
+    keys, has = _structure_checks(out, n)
+    _sample_check(cloud, out, keys, has, 0.2, 0.2)
+    # a 16 M-point prefix: the LDS-resident pipeline and the HBM node table agree row for row
+    pre = t[:16_000_000]
+    res = []
+    for strategy in (2, 1):
+        ms = g.TwoDmap(0.2, 0.2, strategy=strategy)
+        ms.setInterval(0.08)
+        ms.setCloudFirst(cloud[0])
+        ms.create2DMap("slope", pre)
+        res.append(ms.export())
+        assert ms.last_strategy() == strategy
+        del ms
+    a, b = res
+    for k in ("sx", "sy", "sz", "count", "first_idx", "flags"):
+        assert np.array_equal(a[k], b[k]), k
+    scale = np.abs(b["cov"]).max(axis=1, keepdims=True) + 1e-30
+    assert (np.abs(a["cov"] - b["cov"]) / scale).max() < 1e-5 and np.abs(a["mean"] - b["mean"]).max() < 1e-5
+
+
+def test_full_size_site_20M_with_its_three_million_point_origin_node():
+    import torch
+    import grid_ndt_amd as g
+    cloud = scenes.site_two_storey(20_000_000)
+    n = cloud.shape[0] - 1
+    zeros = int(np.count_nonzero(np.all(cloud[1:] == 0, axis=1)))
+    assert zeros == 3_000_000
+    m = g.TwoDmap(0.1, 0.1)
+    m.setInterval(0.08)
+    m.setCloudFirst(cloud[0])
+    t = torch.from_numpy(cloud[1:]).cuda()
+    # The first build of a handle guesses n / 4 nodes (many, small buckets); the second knows the node count, takes fewer
+    # buckets, and this cloud's tall wall columns (56 levels) then overflow some 512-slot tables: it is re-run ONCE with
+    # 1024-slot tables, which the handle remembers (DESIGN §4.1 "Robustness and steady state").  From the third build on
+    # nothing is re-run: that is the steady state bench.py times after its warm-up.
+    for _ in range(2):
+        m.create2DMap("slope", t)
+        m.sync()
+    assert m.retry_count() <= 2
+    before = m.retry_count()
+    for _ in range(2):
+        m.create2DMap("slope", t)
+        m.sync()
+    assert m.retry_count() == before
+    out = m.export()
+    keys, has = _structure_checks(out, n)
+    # the padding node: every (0,0,0) point, first seen where the padding starts, scatter EXACTLY zero, mean exactly the point
+    sx, sy, sz = _keys_of_points(np.concatenate([cloud[:1], np.zeros((1, 3), np.float32)], 0), 0.1, 0.1)
+    i = int(np.flatnonzero(keys == _pack(sx, sy, sz)[0])[0])
+    assert out["count"][i] >= zeros and out["first_idx"][i] <= n - zeros
+    others = np.flatnonzero((_pack(*_keys_of_points(cloud[: n - zeros + 1], 0.1, 0.1)) == keys[i]))
+    assert out["count"][i] == zeros + others.size
+    if others.size == 0:
+        assert np.all(out["cov"][i] == 0) and np.all(out["mean"][i] == 0) and out["rough"][i] == np.float32(0.01)
+    _sample_check(cloud, out, keys, has, 0.1, 0.1, seed=1)
