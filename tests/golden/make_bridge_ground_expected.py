@@ -11,6 +11,16 @@ computed HERE with numpy only — independent of oracle/*.cpp and of libgndt —
   A.5  slope label with the reference's visiting-order rule, evaluated on the fp64 means; `label_margin` is how far the
        closest threshold decision of the node was from flipping (labels are only compared where it exceeds 1e-5)
 
+Round 3 — the fp32 half, so that the oracle's stand-in for PCL is pinned by something that is not the oracle:
+  A.3' mean32 / scatter32: what pcl::compute3DCentroid and pcl::computeCovarianceMatrix (call sites include/map2D.h:621-622)
+       compute on a dense cloud — the points of a node in ARRIVAL order, running sums in fp32 (numpy.cumsum with dtype
+       float32 adds strictly left to right), centroid = sum / float(n), then the six products of the fp32 differences, again
+       summed in fp32 in arrival order, not divided by n.
+  A.5' flags32: the same visiting-order rule evaluated on the fp32 centroids with fp32 arithmetic (what the reference's
+       OcNode::isSlope sees, map2D.h:66-108): compared EVERYWHERE, no margin mask.
+and a second scene that is not lattice data: the campus stand-in of BASELINE configs[0] at 100 000 points
+(tests/golden/campus_100k_expected.npz: keys, counts, the fp32 fields and labels only, to keep the fixture small).
+
 Run from the repository root:  python tests/golden/make_bridge_ground_expected.py
 """
 import os
@@ -22,10 +32,26 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 
 
-def main():
-    from grid_ndt_amd import scenes
-    cloud = scenes.bridge_ground()
-    P = scenes.BRIDGE_PARAMS
+def fp32_sequential(pts, inv, cnt, has):
+    """mean32 [N,3] and scatter32 [N,6] per node, PCL's dense path: fp32 running sums in arrival order."""
+    order = np.argsort(inv, kind="stable")                  # points grouped by node, arrival order kept inside a node
+    starts = np.concatenate([[0], np.cumsum(cnt)])
+    mean32 = np.zeros((cnt.size, 3), np.float32)
+    S32 = np.zeros((cnt.size, 6), np.float32)
+    pairs = ((0, 0), (0, 1), (0, 2), (1, 1), (1, 2), (2, 2))
+    for k in np.flatnonzero(has):
+        p = pts[order[starts[k]:starts[k + 1]]]              # fp32 [n, 3]
+        # (PCL's accumulators start at +0: adding +0 turns a sum of nothing but -0 terms into +0 and changes nothing else)
+        tot = np.cumsum(p, axis=0, dtype=np.float32)[-1] + np.float32(0.0)
+        m = tot / np.float32(p.shape[0])                     # fp32 divide
+        mean32[k] = m
+        d = p - m                                            # fp32
+        for j, (a, b) in enumerate(pairs):
+            S32[k, j] = np.cumsum(d[:, a] * d[:, b], dtype=np.float32)[-1] + np.float32(0.0)
+    return mean32, S32
+
+
+def evaluate(cloud, P, with_fp64=True):
     o = cloud[0].astype(np.float32)
     pts = cloud[1:]
     lens = np.float32([P["grid_len"], P["grid_len"], P["z_len"]])
@@ -92,13 +118,50 @@ def main():
             flags[i] |= 2
             if down:
                 flags[i] |= 4
-    out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "bridge_ground_expected.npz")
-    np.savez_compressed(out, sx=sx[order].astype(np.int32), sy=sy[order].astype(np.int32), sz=sz[order].astype(np.int32),
-                        count=cnt[order].astype(np.uint32), first_idx=first[order].astype(np.uint32), mean64=mean[order],
-                        scatter64=S[order], lambda_min64=lam[order], flags=flags[order],
-                        label_margin=np.minimum(margin[order], 1e9).astype(np.float32),
-                        num_columns=np.int64(ucol.size), params=np.float64([P["grid_len"], P["z_len"], P["slope_interval"]]))
-    print(out, os.path.getsize(out), "bytes;", uk.size, "nodes,", ucol.size, "columns,", int(np.count_nonzero(flags & 2)), "slopes")
+    # ---- the fp32 half: PCL's dense path and the reference's own label arithmetic ----
+    mean32, S32 = fp32_sequential(pts, inv, cnt, has)
+    flags32 = has.astype(np.uint32)
+    iv32 = np.float32(P["slope_interval"])
+    for i in order:
+        if not has[i]:
+            continue
+        z = int(sz[i])
+        up = down = False
+        for target, is_up in (((1 if z == -1 else z + 1), True), ((-1 if z == 1 else z - 1), False)):
+            j = where.get(int((sx[i] + (1 << 20)) << 43 | (sy[i] + (1 << 20)) << 22 | (target + (1 << 21))))
+            if j is None:
+                continue
+            visited = first[j] < first[i] and has[j]
+            oz = mean32[j, 2] if visited else np.float32(0.0)
+            if np.abs(np.float32(oz - mean32[i, 2])) > iv32:
+                if is_up:
+                    up = True
+                else:
+                    down = True
+        if not up:
+            flags32[i] |= 2
+            if down:
+                flags32[i] |= 4
+    res = dict(sx=sx[order].astype(np.int32), sy=sy[order].astype(np.int32), sz=sz[order].astype(np.int32),
+               count=cnt[order].astype(np.uint32), first_idx=first[order].astype(np.uint32),
+               mean32=mean32[order], scatter32=S32[order], flags32=flags32[order],
+               num_columns=np.int64(ucol.size), params=np.float64([P["grid_len"], P["z_len"], P["slope_interval"]]))
+    if with_fp64:
+        res.update(mean64=mean[order], scatter64=S[order], lambda_min64=lam[order], flags=flags[order],
+                   label_margin=np.minimum(margin[order], 1e9).astype(np.float32))
+    return res
+
+
+def main():
+    from grid_ndt_amd import scenes
+    here = os.path.dirname(os.path.abspath(__file__))
+    for name, cloud, P, full in (("bridge_ground_expected.npz", scenes.bridge_ground(), scenes.BRIDGE_PARAMS, True),
+                                 ("campus_100k_expected.npz", scenes.campus_frame(100_000), scenes.CAMPUS_PARAMS, False)):
+        res = evaluate(cloud, P, with_fp64=full)
+        out = os.path.join(here, name)
+        np.savez_compressed(out, **res)
+        print(out, os.path.getsize(out), "bytes;", res["sx"].size, "nodes,", int(res["num_columns"]), "columns,",
+              int(np.count_nonzero(res["flags32"] & 2)), "slopes (fp32 labels)")
 
 
 if __name__ == "__main__":

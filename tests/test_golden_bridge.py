@@ -9,6 +9,27 @@ import pytest
 from tests import parity, scenes
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "bridge_ground_expected.npz")
+GOLD_CAMPUS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "campus_100k_expected.npz")
+
+
+def check_fp32_half(got, gold_path, what, bit_exact_statistics):
+    """Round 3: the golden's fp32 half (PCL's dense path restated with numpy float32 running sums in arrival order, labels from
+    the fp32 centroids).  The oracle must reproduce mean / scatter BIT FOR BIT and every label; the HIP path — fp64 cell-local
+    sums — must give every label and the fp32 values within the north_star tolerance."""
+    g = np.load(gold_path)
+    n = g["sx"].shape[0]
+    assert int(got["num_nodes"]) == n and int(got["num_columns"]) == int(g["num_columns"]), what
+    for k in ("sx", "sy", "sz", "count", "first_idx"):
+        assert np.array_equal(np.asarray(got[k]).astype(np.int64), g[k].astype(np.int64)), (what, k)
+    assert np.array_equal(np.asarray(got["flags"]).astype(np.int64) & 7, g["flags32"].astype(np.int64)), (what, "labels, all nodes")
+    mean, cov = np.asarray(got["mean"], np.float32), np.asarray(got["cov"], np.float32)
+    if bit_exact_statistics:
+        assert np.array_equal(mean.view(np.uint32), g["mean32"].view(np.uint32)), (what, "fp32 centroid bits")
+        assert np.array_equal(cov.view(np.uint32), g["scatter32"].view(np.uint32)), (what, "fp32 scatter bits")
+    else:
+        has = (g["flags32"] & 1) != 0
+        assert np.abs(mean[has].astype(np.float64) - g["mean32"][has]).max() <= 1e-5 * max(1.0, float(np.abs(g["mean32"]).max())), what
+    return {"nodes": n, "labels_checked": n, "bit_exact_statistics": bool(bit_exact_statistics)}
 
 
 def check_against_golden(got, what):
@@ -52,6 +73,15 @@ def test_oracle_reproduces_the_numpy_golden():
     print(check_against_golden(ref, "oracle mode 0"))
 
 
+def test_oracle_fp32_statistics_and_labels_are_bit_identical_to_the_numpy_float32_restatement():
+    """The oracle's stand-in for pcl::compute3DCentroid / computeCovarianceMatrix (map2D.h:621-622) and for OcNode::isSlope's
+    fp32 comparisons, pinned by a restatement that shares no code with it: on the reference's own scene and on a non-lattice one."""
+    for gold, cloud, P in ((GOLD, scenes.bridge_ground(), scenes.BRIDGE_PARAMS), (GOLD_CAMPUS, scenes.campus_frame(100_000), scenes.CAMPUS_PARAMS)):
+        for mode in (0, 1, 2):
+            ref = parity.ref_from_cloud(cloud, P, mode=mode, threads=3 if mode == 2 else 0)
+            print(check_fp32_half(ref, gold, f"oracle mode {mode}", True))
+
+
 def test_kernel_arithmetic_on_the_host_reproduces_the_numpy_golden():
     from tests import host_emulation as he
     P = scenes.BRIDGE_PARAMS
@@ -64,3 +94,6 @@ def test_kernel_arithmetic_on_the_host_reproduces_the_numpy_golden():
 def test_hip_path_reproduces_the_numpy_golden(strategy):
     _, out = parity.gpu_from_cloud(scenes.bridge_ground(), scenes.BRIDGE_PARAMS, strategy=strategy)
     print(check_against_golden(out, f"libgndt strategy {strategy}"))
+    print(check_fp32_half(out, GOLD, f"libgndt strategy {strategy}", False))
+    _, out = parity.gpu_from_cloud(scenes.campus_frame(100_000), scenes.CAMPUS_PARAMS, strategy=strategy)
+    print(check_fp32_half(out, GOLD_CAMPUS, f"libgndt strategy {strategy}, campus", False))
