@@ -8,13 +8,17 @@ namespace gndt_host {
 
 // prefix of the per-word column weights -> row of every staged node -> SoA rows (marks m0+1 .. m0+5)
 // `grouped`: the staging rows of a column are adjacent (k_bucket_direct): the destination pass works per column
-int launch_order_and_emit(gndt_handle* h, uint64_t words, int m0, hipStream_t s, bool grouped) {
+int launch_order_and_emit(gndt_handle* h, uint64_t words, int m0, hipStream_t s, bool grouped, bool counters_to_host) {
     auto& q = h->part;
-    const uint32_t nbw = (uint32_t)((words + kScanChunk - 1) / kScanChunk);
-    hipLaunchKernelGGL(k_scan_reduce<false>, dim3(nbw), dim3(kScanThreads), 0, s, q.word_weight, (const uint32_t*)nullptr,
-                       (uint32_t)words, q.bsum_words);
-    hipLaunchKernelGGL(k_scan_apply<false>, dim3(nbw), dim3(kScanThreads), 0, s, q.word_weight, (const uint32_t*)nullptr,
-                       (uint32_t)words, q.bsum_words, q.word_base);
+    if (words <= kScanSmallMax) {
+        hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(1024), 0, s, (const uint32_t*)q.word_weight, (uint32_t)words, q.word_base);
+    } else {
+        const uint32_t nbw = (uint32_t)((words + kScanChunk - 1) / kScanChunk);
+        hipLaunchKernelGGL(k_scan_reduce<false>, dim3(nbw), dim3(kScanThreads), 0, s, q.word_weight, (const uint32_t*)nullptr,
+                           (uint32_t)words, q.bsum_words);
+        hipLaunchKernelGGL(k_scan_apply<false>, dim3(nbw), dim3(kScanThreads), 0, s, q.word_weight, (const uint32_t*)nullptr,
+                           (uint32_t)words, q.bsum_words, q.word_base);
+    }
     HIP_TRY(h, hipGetLastError());
     mark(h, m0 + 1, s);
     mark(h, m0 + 2, s);       // (the column-rank and column-scan passes of earlier versions: phases kept for the ABI, empty)
@@ -28,7 +32,7 @@ int launch_order_and_emit(gndt_handle* h, uint64_t words, int m0, hipStream_t s,
     HIP_TRY(h, hipGetLastError());
     mark(h, m0 + 4, s);
     hipLaunchKernelGGL(k_emit_rows, dim3(grid_for(q.stage_cap)), dim3(kBlock), 0, s, q.stage, q.inv, h->out, q.row_ncol, h->d_cnt,
-                       q.d_pc);
+                       q.d_pc, counters_to_host ? h->h_cnt : (Counters*)nullptr, counters_to_host ? q.h_pc : (PartCounters*)nullptr);
     HIP_TRY(h, hipGetLastError());
     mark(h, m0 + 5, s);
     return GNDT_OK;
@@ -83,7 +87,8 @@ int partition_launch(gndt_handle* h, gndt_handle::Pending& P) {
     // table size and bucket count for this attempt: 512-slot tables unless that needs too many buckets
     // attempt 0: 512-slot tables; an overflow first doubles the table (same estimate), then raises the estimate
     int bslots = env_slots ? env_slots : (attempt == 0 ? 512 : 1024);
-    uint64_t Bw = buckets_for(n, nodes_est, bslots, q.load_pct);
+    const int load_pct = P.load_pct ? P.load_pct : q.load_pct;
+    uint64_t Bw = buckets_for(n, nodes_est, bslots, load_pct);
     // Two-level partition (no counting passes) for large builds; the exact single-level counting partition for small
     // ones, when asked for (GNDT_STRATEGY_PARTITION_EXACT), and after a region overflowed once on this handle.
     const int env_two = tuning().two_level;
@@ -91,16 +96,16 @@ int partition_launch(gndt_handle* h, gndt_handle::Pending& P) {
                (n >= (1u << 20) || h->P.strategy == GNDT_STRATEGY_PARTITION_TWO_LEVEL);
     if (env_two == 0 || n == 0) two = false;
     if (two && Bw > (uint64_t)kMaxFan * kMaxFan) {         // more buckets than two levels address: larger tables, fewer buckets
-        if (!env_slots) { bslots = 1024; Bw = buckets_for(n, nodes_est, bslots, q.load_pct); }
+        if (!env_slots) { bslots = 1024; Bw = buckets_for(n, nodes_est, bslots, load_pct); }
         if (Bw > (uint64_t)kMaxFan * kMaxFan) two = false;
     }
     if (!two) {
-        if (!env_slots && Bw > kMaxBuckets) { bslots = 1024; Bw = buckets_for(n, nodes_est, bslots, q.load_pct); }
+        if (!env_slots && Bw > kMaxBuckets) { bslots = 1024; Bw = buckets_for(n, nodes_est, bslots, load_pct); }
         if (Bw > kMaxBuckets) return -1;                   // too many nodes for one partition level: atomic path
     }
     // (a cloud just above kMaxFan buckets of the small-cloud size still fits kMaxFan larger ones, if its nodes do)
     if (!two && tuning().one_level && q.one_level_ok && h->P.strategy != GNDT_STRATEGY_PARTITION_EXACT && Bw > (uint64_t)kMaxFan &&
-        n <= (uint64_t)kMaxFan * 2800 && (nodes_est * 100) / ((uint64_t)bslots * q.load_pct) <= (uint64_t)kMaxFan)
+        n <= (uint64_t)kMaxFan * 2800 && (nodes_est * 100) / ((uint64_t)bslots * load_pct) <= (uint64_t)kMaxFan)
         Bw = kMaxFan;
     const uint32_t B = (uint32_t)Bw;
     // Small clouds (at most kMaxFan buckets): ONE tile-sort level writes the buckets themselves, each with a fixed room of 4 x
@@ -118,8 +123,7 @@ int partition_launch(gndt_handle* h, gndt_handle::Pending& P) {
         if ((rc = ensure_stage(h, stage_want))) return rc;
         if ((rc = ensure_out(h, q.stage_cap))) return rc;
     }
-    const uint32_t* range_lo = nullptr;
-    const uint32_t* range_hi = nullptr;
+    BucketRanges ranges{nullptr, nullptr, nullptr, 0u};
     const float4* bucket_recs = nullptr;
     if (two) {
         uint32_t F2_shift = 1;                             // fan-out ~ sqrt(B) per level, F2 a power of two, both <= kMaxFan
@@ -198,11 +202,9 @@ int partition_launch(gndt_handle* h, gndt_handle::Pending& P) {
         else
             hipLaunchKernelGGL(k_part2_level2<256>, g2, dim3(kTileThreads), 0, s, q.recs1, cursor1, cap1, R, gp, B, F2, cursor2,
                                q.range_lo, q.range_cap, q.recs, q.d_pc);
-        hipLaunchKernelGGL(k_part2_ranges, dim3(grid_for(B, 256, 64)), dim3(256), 0, s, cursor1, V, cursor2, q.range_cap, B, q.range_lo,
-                           q.range_hi, q.d_pc);
         HIP_TRY(h, hipGetLastError());
         mark(h, 4, s);
-        range_lo = q.range_lo; range_hi = q.range_hi;
+        ranges = BucketRanges{q.range_lo, q.range_cap, cursor2, 0u};
     } else if (one) {
         constexpr uint64_t kTile1 = (uint64_t)kTileThreads * kTilePer1;
         const uint64_t mean = n / B + 1;
@@ -250,10 +252,8 @@ int partition_launch(gndt_handle* h, gndt_handle::Pending& P) {
         HIP_TRY(h, hipGetLastError());
         mark(h, 2, s);
         mark(h, 3, s);
-        hipLaunchKernelGGL(k_part1_ranges, dim3(grid_for(B, 256, 64)), dim3(256), 0, s, (const uint32_t*)cursor1, cap1, B, q.range_lo, q.range_hi);
-        HIP_TRY(h, hipGetLastError());
         mark(h, 4, s);
-        range_lo = q.range_lo; range_hi = q.range_hi;
+        ranges = BucketRanges{nullptr, nullptr, cursor1, cap1};
     } else {
     if (P.n2) {                    // one array for the counting partition: the first segment goes into the room in front of the second
         p = p2 - 4 * P.n;
@@ -301,7 +301,7 @@ int partition_launch(gndt_handle* h, gndt_handle::Pending& P) {
                            q.totals, q.bucket_base, q.recs, compress, part_mode, OwnerMap{nullptr, nullptr, 0u});
     HIP_TRY(h, hipGetLastError());
     mark(h, 4, s);
-    range_lo = q.bucket_base; range_hi = q.bucket_base + 1;
+    ranges = BucketRanges{q.bucket_base, nullptr, nullptr, 0u};
     }
     bucket_recs = (two || !one) ? q.recs : q.recs1;
     if (tuning().stamps && q.dbg_buckets < B) {
@@ -323,7 +323,7 @@ int partition_launch(gndt_handle* h, gndt_handle::Pending& P) {
     {
         // k_bucket_direct (gndt_bucket3.hpp): 512-slot tables with two workgroups per CU, 1024-slot tables on a retry
 #define GNDT_LAUNCH_DIRECT(T_, H_, S_)                                                                                          \
-    hipLaunchKernelGGL((k_bucket_direct<T_, H_, S_>), bgrid, dim3(T_), 0, s, bucket_recs, range_lo, range_hi, B, gp, q.stage,    \
+    hipLaunchKernelGGL((k_bucket_direct<T_, H_, S_>), bgrid, dim3(T_), 0, s, bucket_recs, ranges, B, gp, q.stage,    \
                        (uint32_t)(S_ ? h->st_cap : q.stage_cap), q.ord_cf, q.ord_idx, order, h->d_cnt, q.d_pc, dbg, stats_out)
         if (bslots == 1024) { if (P.stats_only) GNDT_LAUNCH_DIRECT(1024, 1024, true); else GNDT_LAUNCH_DIRECT(1024, 1024, false); }
         else { if (P.stats_only) GNDT_LAUNCH_DIRECT(512, 512, true); else GNDT_LAUNCH_DIRECT(512, 512, false); }
@@ -331,9 +331,12 @@ int partition_launch(gndt_handle* h, gndt_handle::Pending& P) {
     }
     HIP_TRY(h, hipGetLastError());
     mark(h, 5, s);
-    if (!P.stats_only && (rc = launch_order_and_emit(h, words, 5, s, grouped))) return rc;
-    HIP_TRY(h, hipMemcpyAsync(q.h_pc, q.d_pc, sizeof(PartCounters), hipMemcpyDeviceToHost, s));
-    HIP_TRY(h, hipMemcpyAsync(h->h_cnt, h->d_cnt, sizeof(Counters), hipMemcpyDeviceToHost, s));
+    // (the counters and overflow flags come back with the last kernel: k_emit_rows stores them into the host's pinned mirrors)
+    if (!P.stats_only && (rc = launch_order_and_emit(h, words, 5, s, grouped, true))) return rc;
+    if (P.stats_only) {
+        HIP_TRY(h, hipMemcpyAsync(q.h_pc, q.d_pc, sizeof(PartCounters), hipMemcpyDeviceToHost, s));
+        HIP_TRY(h, hipMemcpyAsync(h->h_cnt, h->d_cnt, sizeof(Counters), hipMemcpyDeviceToHost, s));
+    }
     P.bslots = bslots;
     return GNDT_OK;
 }
@@ -361,6 +364,7 @@ int partition_begin(gndt_handle* h, const void* xyz_dev, size_t n, size_t stride
     // it every build of such a cloud would first fail with the small tables and be run twice.
     const bool similar = q.good_n && n <= 2 * q.good_n && 2 * n >= q.good_n;
     if (similar && q.good_slots == 1024) P.attempt = 1;
+    if (similar && q.good_load) P.load_pct = q.good_load;        // (a small cloud that needed a lower table load)
     // expected node count: the caller's hint, else what the previous build of this handle found, else n/4
     P.nodes_est = h->P.max_nodes_hint ? h->P.max_nodes_hint : (q.nodes_learned ? q.nodes_learned : std::max<uint64_t>(n / 4, 1024));
     P.est_reliable = h->P.max_nodes_hint != 0 || q.nodes_learned != 0;      // (not the n / 4 guess of a first build)
@@ -409,7 +413,12 @@ int partition_resolve(gndt_handle* h) {
         } else if (q.h_pc->lds_overflow) {                            // some bucket holds too many nodes for its LDS table:
             // (Lowering the average table load instead — more, smaller buckets — was measured: 1.19 ms against 0.80 ms with the
             // 1024-slot tables on the 3 M-node variant of the bench scene, and it does not help a hot column at all.)
-            if (P.attempt >= 1 || env_slots) P.nodes_est *= 2;   // (attempt 0 -> 1 only switches to the 1024-slot table)
+            // Small clouds are the exception: a 200 k-point frame fills 1024-slot tables (one workgroup per CU) with ~140
+            // buckets for 256 CUs; more 512-slot buckets keep the chip busy, so they first get a lower table load.
+            if (P.bslots == 512 && !env_slots && P.n + P.n2 <= (1u << 20) && (P.load_pct ? P.load_pct : q.load_pct) > 35) {
+                P.load_pct = 35;
+                --P.attempt;                                     // (stay on the 512-slot tables)
+            } else if (P.attempt >= 1 || env_slots) P.nodes_est *= 2;   // (attempt 0 -> 1 only switches to the 1024-slot table)
             again = true;
         } else if (q.h_pc->stage_overflow) {                   // num_nodes kept counting: it is the true total
             P.stage_want = (uint64_t)h->h_cnt->num_nodes + h->h_cnt->num_nodes / 8 + 1024;
@@ -421,7 +430,7 @@ int partition_resolve(gndt_handle* h) {
             // without a hint guesses n / 4 nodes: its failure says nothing about the cloud)
             const bool est_was_fine = P.est_reliable && P.est0 >= (uint64_t)h->h_cnt->num_nodes;
             q.good_slots = (P.bslots == 1024 && !est_was_fine) ? 0 : P.bslots;
-            q.good_est = P.nodes_est; q.good_n = P.n + P.n2;
+            q.good_est = P.nodes_est; q.good_n = P.n + P.n2; q.good_load = P.load_pct;
             if (!P.stats_only) {
                 h->results_valid = true;
                 ++h->result_serial;

@@ -419,16 +419,16 @@ __device__ __forceinline__ void bucket_direct_one(BucketLds3<H>& L, const uint32
 // Bucket b, b + gridDim.x, ...  With 512-slot tables two 512-thread workgroups share a CU (61 KB of LDS each, four waves per
 // SIMD); the 1024-slot variant (retries, node-heavy clouds) runs one 1024-thread workgroup per CU.
 template <int T, int H, bool STATS = false>
-__global__ void __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(H <= 512 ? GNDT_DIRECT_WAVES : 4, H <= 512 ? GNDT_DIRECT_WAVES : 4))) k_bucket_direct(const float4* __restrict__ recs, const uint32_t* __restrict__ range_lo,
-                                                     const uint32_t* __restrict__ range_hi, uint32_t num_buckets, GridParams P,
+__global__ void __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(H <= 512 ? GNDT_DIRECT_WAVES : 4, H <= 512 ? GNDT_DIRECT_WAVES : 4))) k_bucket_direct(const float4* __restrict__ recs, BucketRanges ranges, uint32_t num_buckets, GridParams P,
                                                      StageRow* __restrict__ stage, uint32_t stage_cap,
                                                      uint32_t* __restrict__ ord_cf, uint32_t* __restrict__ ord_idx, ColumnOrder O,
                                                      Counters* __restrict__ cnt, PartCounters* __restrict__ pc,
                                                      unsigned long long* __restrict__ dbg, StatsOut so) {
     __shared__ BucketLds3<H> L;
     for (uint32_t bucket = blockIdx.x; bucket < num_buckets; bucket += gridDim.x) {
-        bucket_direct_one<T, H, STATS>(L, bucket, recs, range_lo[bucket], range_hi[bucket], P, stage, stage_cap, ord_cf, ord_idx, O,
-                                       cnt, pc, dbg, so);
+        uint32_t lo, hi;
+        bucket_range(ranges, bucket, lo, hi);
+        bucket_direct_one<T, H, STATS>(L, bucket, recs, lo, hi, P, stage, stage_cap, ord_cf, ord_idx, O, cnt, pc, dbg, so);
         lds_barrier();          // the LDS tables are re-initialised by the next bucket
     }
 }

@@ -106,6 +106,7 @@ struct gndt_handle {
         uint32_t last_buckets = 0;
         uint64_t nodes_learned = 0;   // node count of the last successful PARTITION build (+20 %)
         int good_slots = 0; uint64_t good_est = 0, good_n = 0;   // table size / estimate that worked last time
+        int good_load = 0;          //   ... and the table load (percent) if it had to be lowered (0: the default)
         int load_pct = 60;          // average LDS-table load (percent) the bucket count aims at
         uint64_t retries_total = 0; // builds re-run because a table / region / staging area was too small (gndt_debug_retry_count)
     } part;
@@ -178,6 +179,7 @@ struct gndt_handle {
         const void* xyz = nullptr; size_t n = 0, stride = 0;
         hipStream_t s = nullptr;
         int attempt = 0, bslots = 0;
+        int load_pct = 0;               // average LDS-table load this build aims at (0: the handle's default)
         uint64_t nodes_est = 0, stage_want = 0, est0 = 0;   // est0: the estimate the first attempt used
         bool est_reliable = false;      //   ... and whether it came from a hint / an earlier build rather than the n / 4 guess
         bool two_level = false;         // this attempt used the two-level partition
@@ -307,7 +309,7 @@ int do_reset(gndt_handle* h, hipStream_t s);
 int build_atomic(gndt_handle* h, const void* xyz_dev, size_t n, size_t stride_bytes, hipStream_t s, bool tile = false);
 int locality_sample(gndt_handle* h, const void* xyz_dev, size_t n, size_t stride_bytes, uint32_t tiles, double* ratio, hipStream_t s);
 // ---- gndt_api_build.hip ----
-int launch_order_and_emit(gndt_handle* h, uint64_t words, int m0, hipStream_t s, bool grouped = false);
+int launch_order_and_emit(gndt_handle* h, uint64_t words, int m0, hipStream_t s, bool grouped = false, bool counters_to_host = false);
 int partition_launch(gndt_handle* h, gndt_handle::Pending& P);
 int partition_begin(gndt_handle* h, const void* xyz_dev, size_t n, size_t stride_bytes, hipStream_t s, bool records = false, uint64_t index_range = 0,
                     const void* records2 = nullptr, size_t n2 = 0);

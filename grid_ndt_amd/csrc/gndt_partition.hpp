@@ -565,8 +565,10 @@ __global__ void __launch_bounds__(kTileThreads) k_part2_level2(const float4* __r
                                                                PartCounters* __restrict__ pc) {
     constexpr int PER = kTilePer2;
     __shared__ TileLds<PER, FAN> L;
-    if (pc->part_overflow) return;                       // level 1 or the layout already gave up: the build is re-run
     const uint32_t v = blockIdx.y, c = v / R;
+    // the fullest level-1 region (true count, also beyond its capacity: the host sizes a retry from it)
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicMax(&pc->max_fill1, cursor1[v]);
+    if (pc->part_overflow) return;                       // level 1 or the layout already gave up: the build is re-run
     const uint32_t have = min(cursor1[v], cap1);
     const uint32_t t0 = blockIdx.x * (kTileThreads * PER);
     if (t0 >= have) return;
@@ -589,31 +591,20 @@ __global__ void __launch_bounds__(kTileThreads) k_part2_level2(const float4* __r
     tile_partition<PER, FAN>(L, r, dig, nd, cursor2 + b0, 0u, 0ull, 0ull, lo + b0, cap + b0, recs2, pc);
 }
 
-// the fine buckets' record ranges for the bucket kernel (lo[] is the layout's base), and the fullest level-1 region
-static __global__ void __launch_bounds__(256) k_part2_ranges(const uint32_t* __restrict__ cursor1, uint32_t V,
-                                                      const uint32_t* __restrict__ cursor2, const uint32_t* __restrict__ cap,
-                                                      uint32_t B, const uint32_t* __restrict__ lo, uint32_t* __restrict__ hi,
-                                                      PartCounters* __restrict__ pc) {
-    __shared__ uint32_t m1;
-    if (threadIdx.x == 0) m1 = 0;
-    __syncthreads();
-    uint32_t a = 0;
-    for (uint32_t b = blockIdx.x * blockDim.x + threadIdx.x; b < max(B, V); b += gridDim.x * blockDim.x) {
-        if (b < B) hi[b] = lo[b] + min(cursor2[b], cap[b]);
-        if (b < V) a = max(a, cursor1[b]);
-    }
-    if (a) atomicMax(&m1, a);
-    __syncthreads();
-    if (threadIdx.x == 0 && m1) atomicMax(&pc->max_fill1, m1);
-}
-
-// one-level tile partition (small clouds: level 1 writes the buckets themselves, bucket b at b * cap1): the buckets' ranges
-static __global__ void __launch_bounds__(256) k_part1_ranges(const uint32_t* __restrict__ cursor1, uint32_t cap1, uint32_t B,
-                                                             uint32_t* __restrict__ lo, uint32_t* __restrict__ hi) {
-    for (uint32_t b = blockIdx.x * blockDim.x + threadIdx.x; b < B; b += gridDim.x * blockDim.x) {
-        lo[b] = b * cap1;
-        hi[b] = b * cap1 + min(cursor1[b], cap1);
-    }
+// Where bucket b's records are, for the bucket kernel (no kernel of its own: two or three loads per bucket).
+//   exact counting partition : [base[b], base[b + 1])                                  (fill == nullptr)
+//   two-level partition      : lo[b] + [0, min(fill[b], cap[b]))   lo / cap from k_part2_layout, fill = the level-2 cursors
+//   one-level tile partition : b * stride + [0, min(fill[b], stride))                  (lo == nullptr; fill = the level-1 cursors)
+struct BucketRanges {
+    const uint32_t* lo;
+    const uint32_t* cap;
+    const uint32_t* fill;
+    uint32_t stride;
+};
+__device__ __forceinline__ void bucket_range(const BucketRanges& R, uint32_t b, uint32_t& lo, uint32_t& hi) {
+    if (!R.fill) { lo = R.lo[b]; hi = R.lo[b + 1]; }
+    else if (R.lo) { lo = R.lo[b]; hi = lo + min(R.fill[b], R.cap[b]); }
+    else { lo = b * R.stride; hi = lo + min(R.fill[b], R.stride); }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -725,6 +716,24 @@ __global__ void __launch_bounds__(kScanThreads) k_scan_apply(const uint32_t* __r
     }
 }
 
+// the same prefix in ONE launch of one workgroup, for short arrays (small clouds: two launches cost more than the scan)
+constexpr uint32_t kScanSmallMax = 1u << 16;
+static __global__ void __launch_bounds__(1024) k_scan_small(const uint32_t* __restrict__ in, uint32_t n, uint32_t* __restrict__ out) {
+    __shared__ uint32_t ws[16];
+    const uint32_t per = (n + 1023u) / 1024u;
+    const uint32_t i0 = threadIdx.x * per;
+    uint32_t s = 0;
+    for (uint32_t j = 0; j < per; ++j) if (i0 + j < n) s += in[i0 + j];
+    uint32_t incl = s;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int off = 1; off < 64; off <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)incl, off, 64); if (lane >= off) incl += t; }
+    if (lane == 63) ws[wave] = incl;
+    __syncthreads();
+    uint32_t run = incl - s;
+    for (int w = 0; w < wave; ++w) run += ws[w];
+    for (uint32_t j = 0; j < per; ++j) if (i0 + j < n) { const uint32_t v = in[i0 + j]; out[i0 + j] = run; run += v; }
+}
+
 // ---------------------------------------------------------------------------------------------
 // ordering
 // ---------------------------------------------------------------------------------------------
@@ -768,9 +777,17 @@ static __global__ void __launch_bounds__(kBlock) k_order_dest(const uint32_t* __
 }
 
 // staging rows -> SoA result rows in reference order
+// host_cnt / host_pc (nullable): the host's pinned mirrors of the counters and overflow flags.  Both are final when this —
+// the last kernel of a PARTITION build — starts, so one lane stores them straight into host memory: two copy commands less
+// behind every build (4.5 us each on the stream of a 70 us small-frame build).
 static __global__ void __launch_bounds__(kBlock) k_emit_rows(const StageRow* __restrict__ stage, const uint32_t* __restrict__ inv,
                                                       OutView out, uint32_t* __restrict__ row_ncol,
-                                                      const Counters* __restrict__ cnt, const PartCounters* __restrict__ pc) {
+                                                      const Counters* __restrict__ cnt, const PartCounters* __restrict__ pc,
+                                                      Counters* __restrict__ host_cnt, PartCounters* __restrict__ host_pc) {
+    if (blockIdx.x == 0 && threadIdx.x < 2) {
+        if (threadIdx.x == 0 && host_cnt) *host_cnt = *cnt;
+        if (threadIdx.x == 1 && host_pc) *host_pc = *pc;
+    }
     if (pc->lds_overflow | pc->stage_overflow | pc->index_overflow | pc->part_overflow) return;
     const uint32_t n = cnt->num_nodes;
     for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x) {
