@@ -47,6 +47,7 @@
 #include <vector>
 #ifdef _OPENMP
 #include <omp.h>
+#include <memory>
 #include <parallel/algorithm>
 #endif
 
@@ -307,9 +308,12 @@ Grid* build_int_keys(const float* xyz, size_t n, size_t stride, const float o[3]
     if (threads < 1) threads = 1;
     const size_t T = static_cast<size_t>(threads);
     double t0 = now_s();
-    std::vector<uint64_t> keys(n);
-    std::vector<Key> kk(n);
-    std::vector<uint16_t> owner(n);
+    // (Arrays of n elements are allocated WITHOUT a value-initialising pass: a std::vector would be zero-filled by this one
+    // thread — 340 MB at 10 M points, a third of the "division" time on a 128-core box — and every page would then sit on
+    // this thread's memory node.  Left uninitialised, a page is first touched by the thread of the loop that fills it.)
+    std::unique_ptr<uint64_t[]> keys(new uint64_t[n]);
+    std::unique_ptr<Key[]> kk(new Key[n]);
+    std::unique_ptr<uint16_t[]> owner(new uint16_t[n]);
 #pragma omp parallel for num_threads(threads) schedule(static)
     for (long long i = 0; i < static_cast<long long>(n); ++i) {
         const float* p = xyz + static_cast<size_t>(i) * stride;
@@ -320,7 +324,7 @@ Grid* build_int_keys(const float* xyz, size_t n, size_t stride, const float o[3]
     }
     // stable counting sort of the indices by owner: cnt[chunk][owner] -> offsets -> perm
     std::vector<size_t> cnt(T * T, 0), start(T + 1, 0);
-    std::vector<uint32_t> perm(n);
+    std::unique_ptr<uint32_t[]> perm(new uint32_t[n]);
 #pragma omp parallel num_threads(threads)
     {
 #ifdef _OPENMP
