@@ -630,7 +630,7 @@ def main():
             ref = parity.ref_from_cloud(small, P)
             _, o = parity.gpu_from_cloud(small, P, device=local)
             out["check"] = parity.compare(o, ref)["ok"]
-        if a.stamps and m.last_strategy() in (2, 3):
+        if a.stamps and m.last_strategy() in (2, 3, 4, 6):
             m.enable_stamps(True)
             m.create2DMap("slope", pts, stream)
             cyc, nb = m.debug_bucket_phases()

@@ -117,6 +117,9 @@ def build_native(force=False, verbose=False):
         obj = os.path.splitext(src)[0] + ".o"
         cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-c",
                "-Wno-unused-command-line-argument", "-Wno-unused-function", "-Wno-pass-failed", "-fno-slp-vectorize",
+               # the code objects keep their dynamic symbols (kernel names) only: rocPRIM's ~500 instantiations in gndt_api_dist
+               # carried 1.4 MB of .symtab / .strtab
+               "-Xoffload-linker", "--strip-all",
                "-I", os.path.join(_ROOT, "include"), "-I", _CSRC, "-o", obj, src] + os.environ.get("GNDT_EXTRA_CXXFLAGS", "").split()
         if verbose:
             print(" ".join(cmd))
@@ -127,7 +130,7 @@ def build_native(force=False, verbose=False):
             raise subprocess.CalledProcessError(pr.returncode, cmd)
     libdir = _hip_runtime_dir()
     link = ["g++", "-shared", "-o", LIB_PATH] + objs + ["-L", libdir, "-l:libamdhip64.so", "-Wl,-rpath," + libdir,
-                                                         "-Wl,--no-undefined", "-lpthread", "-ldl"]
+                                                         "-Wl,--no-undefined", "-Wl,--strip-all", "-lpthread", "-ldl"]
     if verbose:
         print(" ".join(link))
     subprocess.check_call(link)
