@@ -117,9 +117,9 @@ def build_native(force=False, verbose=False):
         obj = os.path.splitext(src)[0] + ".o"
         cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-c",
                "-Wno-unused-command-line-argument", "-Wno-unused-function", "-Wno-pass-failed", "-fno-slp-vectorize",
-               # the code objects keep their dynamic symbols (kernel names) only: rocPRIM's ~500 instantiations in gndt_api_dist
-               # carried 1.4 MB of .symtab / .strtab
-               "-Xoffload-linker", "--strip-all",
+               # the code objects drop their local symbols (rocPRIM's ~500 instantiations in gndt_api_dist carried 1 MB of them).
+               # NOT --strip-all: the HIP runtime segfaults on a code object without .symtab (measured on the MI355X box)
+               "-Xoffload-linker", "--discard-all",
                "-I", os.path.join(_ROOT, "include"), "-I", _CSRC, "-o", obj, src] + os.environ.get("GNDT_EXTRA_CXXFLAGS", "").split()
         if verbose:
             print(" ".join(cmd))

@@ -46,7 +46,7 @@ namespace {
 // workgroup and bucket) and the bucket kernel (fixed costs per bucket): as many points per bucket as two chunks of
 // the bucket kernel take (2800 leaves room for the spread of a hash partition), unless the LDS node table says
 // otherwise: average load <= 0.5 of `slots` against an estimate that already carries a 20 % margin, i.e. ~0.42 of
-// the slots really used, ~5 sigma of the column count below the overflow limit of 0.78.  (An overflow is not an
+// the slots really used, far below the overflow limit (a table holds `slots` nodes).  (An overflow is not an
 // error: the build is re-run with the larger table / more buckets.)
 uint64_t buckets_for(uint64_t n, uint64_t nodes, int slots, int load_pct) {
     const int pts_target = tuning().bucket_points;

@@ -116,8 +116,6 @@ int ensure_stage(gndt_handle* h, uint64_t nodes) {
     return grow_buf(h, q.row_ncol, q.row_ncol_cap, nodes);
 }
 
-// Bucket count: ~4096 points per bucket, and few enough nodes per bucket for the LDS table
-// (average load <= 0.4 of `slots`: the overflow limit of 0.78 is then ~6 sigma of the column count away).
 int ensure_words(gndt_handle* h, uint64_t words) {
     auto& q = h->part;
     if (words <= q.word_cap) return GNDT_OK;

@@ -1,26 +1,23 @@
-// gndt_bucket3.hpp — k_bucket_direct: one workgroup per bucket, third generation.
-//
-// k_bucket_build2 (gndt_bucket.hpp) sorts every chunk of a bucket by node inside LDS so that runs of one node can be
-// summed in registers.  Counted on the ISA it spends ~270 vector + ~170 scalar instructions per point in four
-// barrier-separated phases per chunk (rank atomics, scan, scatter, re-read, run logic) and is issue-bound in those
-// phases: 242 us for the 10 M-point bench scene.  This kernel does the obvious thing instead, made cheap:
+// gndt_bucket3.hpp — k_bucket_direct: one workgroup per bucket.
 //
 //   accumulate (no barrier, no chunking: every wave streams its share of the bucket's records)
-//       record -> key (divide-free exact index, gndt_math.hpp) -> LDS node table slot (first probe hits ~always)
-//              -> v = p - centre(node) in fp64 -> 9 x ds_add_f64 + count + first-seen straight into the table
-//   then, on the finished table
-//       compact the occupied slots (wave ballots), so that the per-node phases run on dense lanes (measured: iterating the
-//                 half-empty table instead saves the pass and a barrier but makes the row phase 10-25 % slower)
+//       record -> key (divide-free exact index, gndt_math.hpp) -> number of its node (LDS index -> dense node arrays)
+//              -> v = p - centre(node) in fp64 -> 9 x ds_add_f64 + count + first-seen straight into the node's sums
+//   then, on the finished table (nodes are numbered in arrival order: the phases run over 0 .. n_nodes - 1, no compaction)
 //       columns : column table; every node takes a number in its column, every column reserves its rows inside the bucket
 //                 and gets an ARRAY of 16-byte node records (first-seen, z level, fp32 mean z)
 //       rows    : slope label and index in column from a scan of the column's array; mean + fp64 scatter -> 96-B staging row,
 //                 written WHOLE by one lane (a row written in two parts by two lanes cost twice the bytes at the memory side),
 //                 a column's rows next to each other in first-seen order
 //
-// ~120 instructions per point, bounded by the LDS atomic unit (ds_add_f64: ~2.5 lanes per clock and CU) instead of
-// by instruction issue.  Hot buckets need no special casing (no chunk image to overflow); 64 identical consecutive
-// points still arrive as ONE weighted record (gndt_partition.hpp).  Semantics are those of k_bucket_build2 (same
-// gndt_math.hpp arithmetic, same order-free label rule); tests run every strategy against the oracle.
+// What bounds it (profiles/r03_bucket_ablation.txt): ~350 vector instructions per point at four waves per SIMD — the issue
+// port is busy all the time — with the LDS pipeline about half busy behind it (dependent LDS round trips queue behind the
+// other waves' fp64 atomics, ~1 k cycles each under load).  More work in flight per thread (1 .. 4 records) changes nothing;
+// what was tried against the probing cost (windows of slots, deferred probing, a second home slot, this index) and against
+// the atomics (fixed point, integer atomics, bank binning) is listed there.  An earlier generation sorted every chunk of a
+// bucket by node in LDS and summed runs in registers (~440 instructions per point, 242 us on the bench scene); a "thread pair
+// owns a node" variant needed the same sort (238-256 us).  Hot buckets need no special casing; 64 or 512 identical consecutive
+// points arrive as ONE weighted record (gndt_partition.hpp).  Tests run every strategy against the oracle.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -30,7 +27,7 @@
 namespace gndt {
 
 #ifndef GNDT_DIRECT_WAVES
-#define GNDT_DIRECT_WAVES 5      // waves per SIMD the register allocation aims at (512-slot variant): 5 = 96 VGPRs, no spills
+#define GNDT_DIRECT_WAVES 4      // waves per SIMD (two 512-thread workgroups per CU): 128 VGPRs, no spills
 #endif
 
 // Compact per-node statistics (the gndt_stats layout): what a shard of a multi-GPU build hands to the exchange.
@@ -42,7 +39,11 @@ struct StatsOut {
 };
 
 template <int H>
-struct BucketLds3 {           // 61 KB at H = 512: two workgroups per CU
+struct BucketLds3 {           // 70 KB at H = 512: two workgroups per CU
+    // Node table in two parts.  `idx` is an open-addressing INDEX of 4 H words (at most a quarter full): the hash of a node's
+    // key leads to the number of the node.  Nodes are numbered in the order they arrive, so keys and statistics sit in DENSE
+    // arrays: the per-node phases run over 0 .. n_nodes - 1 with no compaction pass, and a table holds H nodes, not 0.78 H.
+    uint32_t idx[4 * H];
     unsigned long long key[H];
     double sum[9][H];
     uint32_t cnt[H];
@@ -54,10 +55,9 @@ struct BucketLds3 {           // 61 KB at H = 512: two workgroups per CU
     float mz[H];                // (kept from the column phase until the arrays are filled)
     uint16_t kcol[H];           // the node's arrival number in its column
     uint32_t chead[H];          // column table: a node of the column (its key is the column's key: no separate column keys), kNoNode = free
-    uint16_t list[H];           // the occupied slots, compacted
-    uint16_t cslot[H];          // column slot of the node in this slot
+    uint16_t cslot[H];          // column slot of the node
     uint32_t ccnt[H];           // nodes of the column in this column slot; after the prefix (first row inside the bucket) << 16 | nodes
-    uint32_t n_nodes, n_cols, n_slopes, n_list, stage_base, overflow, err_range, row_cursor;
+    uint32_t n_nodes, n_cols, n_slopes, stage_base, overflow, err_range, row_cursor;
 };
 constexpr uint32_t kNoNode = 0xFFFFFFFFu;
 
@@ -65,64 +65,80 @@ constexpr uint32_t kNoNode = 0xFFFFFFFFu;
 // the bucket kernels hand over LDS contents, their global stores are read by later kernels.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-// ---- probing the node table: windows of kProbeWindow consecutive slots per round trip, all of a thread's records together ----
-// A wave waits for its slowest lane, and every probe of the one-slot-at-a-time loop (lds_find_or_insert) is a dependent LDS
-// round trip.  At the usual load (0.4) linear probing displaces a fifth of the nodes, the worst one of a bucket by ~9 slots;
-// among the 128 records a wave holds, some lane always needs most of that, so the loop ran ~9 round trips per record and
-// iteration: HALF of the accumulate phase (profiles/r03_bucket_ablation.txt).  Here a lane reads kProbeWindow slots at once
-// (independent loads, one wait), the thread's U records probe in the same rounds, and the order of the slots tried — hence
-// the table that results — is exactly linear probing's: the first slot of the sequence that holds the key or is empty.
-#ifndef GNDT_PROBE_WINDOW
-#define GNDT_PROBE_WINDOW 4
-#endif
-constexpr int kProbeWindow = GNDT_PROBE_WINDOW;
-// pos[j]: where record j's probe sequence stands (updated); done[j]: settled (slot in pos[j]); returns false on a full table.
-// One round = one window read and at most ONE compare-and-swap per record, the records' operations issued together: the
-// first slot of the window that holds the key settles the record, the first EMPTY one before that is claimed; a claim lost
-// to another key continues behind that slot.
-template <int H, int U, typename KeyArray>
-__device__ __forceinline__ bool lds_probe_insert(KeyArray& keys, uint32_t (&pos)[U], bool (&done)[U], const unsigned long long (&key)[U],
-                                                 uint32_t* n_new) {
-    for (int round = 0; round < 2 * H; ++round) {        // (every round settles a record or moves it at least one slot on)
+// ---- finding a node: the index ----
+// idx[h] is kIdxEmpty, the number of a node, kIdxLock (a lane has claimed the word and is about to publish the number of a NEW
+// node) or kIdxFull (the table ran out of node numbers: the build is re-run).  At a load of at most 1/4 — usually 1/10 — a key
+// that does not sit where its hash points is rare and never far away, so the loop is one 4-byte read and one 8-byte key read per
+// step, ~12 instructions: the round-2 table probed 64-bit keys in place at a load of 0.4, where a fifth of the nodes is
+// displaced by up to ~9 slots and, with 128 records per wave, every wave walked that far in every iteration (windows of four
+// slots per round trip: ~100 instructions per round, three rounds; profiles/r03_bucket_ablation.txt).
+constexpr uint32_t kIdxEmpty = 0xFFFFFFFFu, kIdxLock = 0xFFFFFFFEu, kIdxFull = 0xFFFFFFFDu;
+// h[j]: where record j's search stands (updated); id[j]: the node number once done[j].  Records of a lane search together.
+// A record whose table is full gets id = 0 and use = false.
+template <int H, int U, typename Lds>
+__device__ __forceinline__ void lds_index_find_or_insert(Lds& L, uint32_t (&h)[U], uint32_t (&id)[U], bool (&use)[U],
+                                                         const unsigned long long (&key)[U]) {
+    constexpr uint32_t kMask = 4u * (uint32_t)H - 1u;
+    bool done[U];
+#pragma unroll
+    for (int j = 0; j < U; ++j) { done[j] = !use[j]; id[j] = 0u; }
+    for (int round = 0; round < 16 * H; ++round) {      // (a step settles a record, moves it one word on, or waits for a publication)
         bool all_done = true;
 #pragma unroll
         for (int j = 0; j < U; ++j) all_done = all_done && done[j];
-        if (all_done) return true;
-        unsigned long long kk[U][kProbeWindow];
+        if (__all(all_done)) return;                     // (the wave leaves together: the wave-wide operations below see all of its lanes)
+        uint32_t e[U];
 #pragma unroll
-        for (int j = 0; j < U; ++j)
-#pragma unroll
-            for (int i = 0; i < kProbeWindow; ++i) kk[j][i] = keys[(pos[j] + (uint32_t)i) & (uint32_t)(H - 1)];
-        int at[U];                 // first slot of the window that holds the key or is empty (kProbeWindow: none)
-        bool claim[U];             //   ... it is empty: claim it
-        unsigned long long old[U];
+        for (int j = 0; j < U; ++j) e[j] = __hip_atomic_load(&L.idx[h[j]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        // empty words are claimed (the records' operations issued together: one wait each for the compare-and-swaps, the
+        // node numbers — ONE addition per wave — and nothing for the writes)
+        bool won[U];
+        bool any_won = false;
 #pragma unroll
         for (int j = 0; j < U; ++j) {
-            at[j] = kProbeWindow; claim[j] = false;
+            won[j] = false;
+            if (!done[j] && e[j] == kIdxEmpty) e[j] = atomicCAS(&L.idx[h[j]], kIdxEmpty, kIdxLock), won[j] = true;
+        }
 #pragma unroll
-            for (int i = kProbeWindow - 1; i >= 0; --i) {
-                const bool hit = kk[j][i] == key[j], empty = kk[j][i] == kEmptyKey;
-                if (hit || empty) { at[j] = i; claim[j] = empty; }
+        for (int j = 0; j < U; ++j) { won[j] = won[j] && e[j] == kIdxEmpty; any_won = any_won || won[j]; }
+        if (__any(any_won)) {
+            unsigned long long m[U];
+            uint32_t total = 0;
+#pragma unroll
+            for (int j = 0; j < U; ++j) { m[j] = __ballot(won[j]); total += (uint32_t)__popcll(m[j]); }
+            uint32_t n0 = 0;
+            if ((threadIdx.x & 63) == 0) n0 = atomicAdd(&L.n_nodes, total);
+            n0 = (uint32_t)__shfl((int)n0, 0, 64);
+            const unsigned long long below = (1ull << (threadIdx.x & 63)) - 1ull;
+#pragma unroll
+            for (int j = 0; j < U; ++j) {
+                const uint32_t n = n0 + (uint32_t)__popcll(m[j] & below);
+                n0 += (uint32_t)__popcll(m[j]);
+                if (!won[j]) continue;
+                if (n < (uint32_t)H) {
+                    L.key[n] = key[j];
+                    __hip_atomic_store(&L.idx[h[j]], n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // (LDS operations of a wave execute in order: the key is there first)
+                    id[j] = n;
+                } else {
+                    __hip_atomic_store(&L.idx[h[j]], kIdxFull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    L.overflow = 1; use[j] = false;
+                }
+                done[j] = true;
             }
-            claim[j] = claim[j] && !done[j];
         }
+        unsigned long long k[U];
+#pragma unroll
+        for (int j = 0; j < U; ++j) k[j] = L.key[(!done[j] && e[j] < (uint32_t)H) ? e[j] : 0u];
 #pragma unroll
         for (int j = 0; j < U; ++j) {
-            old[j] = 0ull;
-            if (claim[j]) old[j] = atomicCAS(&keys[(pos[j] + (uint32_t)at[j]) & (uint32_t)(H - 1)], (unsigned long long)kEmptyKey, key[j]);
-        }
-#pragma unroll
-        for (int j = 0; j < U; ++j) {
-            if (done[j]) continue;
-            const uint32_t s = (pos[j] + (uint32_t)at[j]) & (uint32_t)(H - 1);
-            if (at[j] == kProbeWindow) { pos[j] = s; continue; }                        // nothing here: next window
-            if (!claim[j]) { pos[j] = s; done[j] = true; continue; }                    // the key is there
-            if (old[j] == kEmptyKey) { atomicAdd(n_new, 1u); pos[j] = s; done[j] = true; continue; }   // a new node
-            if (old[j] == key[j]) { pos[j] = s; done[j] = true; continue; }             // another lane inserted it meanwhile
-            pos[j] = (s + 1u) & (uint32_t)(H - 1);                                      // taken by another key: go on behind it
+            if (done[j] || e[j] == kIdxLock) continue;                     // (a number is about to appear there: look again)
+            if (e[j] == kIdxFull) { use[j] = false; done[j] = true; continue; }
+            if (k[j] == key[j]) { id[j] = e[j]; done[j] = true; continue; }
+            h[j] = (h[j] + 1u) & kMask;
         }
     }
-    return false;
+#pragma unroll
+    for (int j = 0; j < U; ++j) if (!done[j]) { L.overflow = 1; use[j] = false; }
 }
 
 // slot of a node inside its bucket's table.  The bucket is chosen by the TOP bits of the column hash (bucket_of), so its
@@ -141,22 +157,22 @@ __device__ __forceinline__ void bucket_direct_one(BucketLds3<H>& L, const uint32
                                                   const ColumnOrder& O, Counters* __restrict__ cnt,
                                                   PartCounters* __restrict__ pc, unsigned long long* __restrict__ dbg,
                                                   const StatsOut& so) {
-    static_assert(H <= 65535, "slot indices are kept in 16 bits");
-    constexpr int kFill = (H * 25) / 32;
+    static_assert(H <= 65535, "node numbers are kept in 16 bits");
     constexpr int U = 2;                           // records in flight per thread
     const int tid = threadIdx.x;
     const int lane = tid & 63;
 #define GNDT_STAMP3(k) do { if (dbg && tid == 0) dbg[(size_t)bucket * 16 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
     GNDT_STAMP3(0);
     for (int s = tid; s < H; s += T) {
-        L.key[s] = kEmptyKey;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) L.idx[4 * s + j] = kIdxEmpty;
 #pragma unroll
         for (int j = 0; j < 9; ++j) L.sum[j][s] = 0.0;
         L.cnt[s] = 0; L.first[s] = 0xFFFFFFFFu;
         L.chead[s] = kNoNode;
         L.ccnt[s] = 0;
     }
-    if (tid == 0) { L.n_nodes = 0; L.n_cols = 0; L.n_slopes = 0; L.n_list = 0; L.stage_base = 0; L.overflow = 0; L.err_range = 0; L.row_cursor = 0; }
+    if (tid == 0) { L.n_nodes = 0; L.n_cols = 0; L.n_slopes = 0; L.stage_base = 0; L.overflow = 0; L.err_range = 0; L.row_cursor = 0; }
     __syncthreads();
     GNDT_STAMP3(1);
 
@@ -182,7 +198,7 @@ __device__ __forceinline__ void bucket_direct_one(BucketLds3<H>& L, const uint32
     for (uint32_t base = lo; base < hi; base += (uint32_t)(U * T)) {
         // A table beyond its fill limit is given up at once: the build is re-run with more room anyway, and probing a nearly
         // full table costs hundreds of rounds per record (a cloud whose tables ALL overflow kept this kernel busy for 18-37 ms).
-        if (__builtin_amdgcn_readfirstlane((int)L.n_nodes) > kFill) break;
+        if (__builtin_amdgcn_readfirstlane((int)L.n_nodes) > H) break;
         float4 rec[U];
         bool use[U];
 #pragma unroll
@@ -198,7 +214,7 @@ __device__ __forceinline__ void bucket_direct_one(BucketLds3<H>& L, const uint32
         for (int j = 0; j < U; ++j) {
             k[j] = point_key_fast(rec[j].x, rec[j].y, rec[j].z, P.ox, P.oy, P.oz, P.grid_len, P.z_len, P.inv_grid, P.inv_z);
             pkey[j] = pack_key(k[j].sx, k[j].sy, k[j].sz);
-            slot[j] = node_slot3(column_hash(k[j].sx, k[j].sy), k[j].sz) & (uint32_t)(H - 1);
+            slot[j] = node_slot3(column_hash(k[j].sx, k[j].sy), k[j].sz) & (4u * (uint32_t)H - 1u);      // (where the search starts in the index)
             if (use[j] && !k[j].ok) { atomicAdd(&L.err_range, 1u); use[j] = false; }   // |nz| beyond the key range (x, y: the partition)
         }
         const bool pair = use[0] && use[1] && pkey[0] == pkey[1];      // both records in one node: one contribution
@@ -206,9 +222,6 @@ __device__ __forceinline__ void bucket_direct_one(BucketLds3<H>& L, const uint32
         // a wave whose records all sit in ONE node (dense cells, the zero padding): summed across the wave, one lane adds
         const bool one_node = __all(pair) && __all(pkey[0] == __shfl(pkey[0], 0, 64));
         if (one_node) use[0] = lane == 0;
-        unsigned long long k0[U];
-#pragma unroll
-        for (int j = 0; j < U; ++j) k0[j] = L.key[slot[j]];
         double c[U][9];
         uint32_t cn[U], cf[U];
 #pragma unroll
@@ -237,20 +250,12 @@ __device__ __forceinline__ void bucket_direct_one(BucketLds3<H>& L, const uint32
             for (int off = 32; off > 0; off >>= 1) { cn[0] += (uint32_t)__shfl_down((int)cn[0], off, 64); cf[0] = min(cf[0], (uint32_t)__shfl_down((int)cf[0], off, 64)); }
         }
         GNDT_SUB(0);
-        {   // first probe missed (new node, or a node linear probing displaced): all of the thread's records probe together
-            bool done[U];
-#pragma unroll
-            for (int j = 0; j < U; ++j) done[j] = !use[j] || k0[j] == pkey[j];
-            if (!lds_probe_insert<H, U>(L.key, slot, done, pkey, &L.n_nodes)) {
-                L.overflow = 1;
-#pragma unroll
-                for (int j = 0; j < U; ++j) if (!done[j]) { use[j] = false; slot[j] = 0; }
-            }
-        }
+        uint32_t node[U];
+        lds_index_find_or_insert<H, U>(L, slot, node, use, pkey);
         GNDT_SUB(base == lo ? 1 : 2);
 #pragma unroll
         for (int j = 0; j < U; ++j) {
-            const uint32_t s = slot[j];
+            const uint32_t s = node[j];
             const bool u = use[j];
             if (u) {
                 atomicAdd(&L.sum[0][s], c[j][0]); atomicAdd(&L.sum[1][s], c[j][1]); atomicAdd(&L.sum[2][s], c[j][2]);
@@ -268,7 +273,7 @@ __device__ __forceinline__ void bucket_direct_one(BucketLds3<H>& L, const uint32
     __syncthreads();
     GNDT_STAMP3(2);
     const uint32_t M = L.n_nodes;
-    if (L.overflow || M > (uint32_t)kFill) {     // uniform
+    if (L.overflow || M > (uint32_t)H) {         // uniform
         if (tid == 0) atomicAdd(&pc->lds_overflow, 1u);
         return;
     }
@@ -277,16 +282,6 @@ __device__ __forceinline__ void bucket_direct_one(BucketLds3<H>& L, const uint32
     if (tid == T - 1) stage_base_reg = atomicAdd(&cnt->num_nodes, M);
     if (tid == 0 && L.err_range) atomicAdd(&cnt->err_key_range, L.err_range);
 
-    // ---- compact the occupied slots: the per-node phases then run on dense lanes (M of H slots are in use) ----
-    for (int s0 = 0; s0 < H; s0 += T) {
-        const int s = s0 + tid;
-        const bool occ = s < H && L.key[s] != kEmptyKey;
-        const unsigned long long m = __ballot(occ);
-        uint32_t wbase = 0;
-        if (lane == 0 && m) wbase = atomicAdd(&L.n_list, (uint32_t)__popcll(m));
-        wbase = (uint32_t)__shfl((int)wbase, 0, 64);
-        if (occ) L.list[wbase + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)s;
-    }
     if (tid == T - 1) L.stage_base = stage_base_reg;
     __syncthreads();
     const uint32_t sbase = L.stage_base;
@@ -297,7 +292,7 @@ __device__ __forceinline__ void bucket_direct_one(BucketLds3<H>& L, const uint32
 
     if constexpr (STATS) {
         for (uint32_t i = tid; i < M; i += T) {
-            const uint32_t s = L.list[i];
+            const uint32_t s = i;
             const uint32_t dst = sbase + i;
             so.key[dst] = L.key[s];
 #pragma unroll
@@ -310,7 +305,7 @@ __device__ __forceinline__ void bucket_direct_one(BucketLds3<H>& L, const uint32
 
     // ---- columns: every node finds the slot of its column and takes a number in it; fp32 mean-z of the nodes that have statistics ----
     for (uint32_t i = tid; i < M; i += T) {
-        const uint32_t s = L.list[i];
+        const uint32_t s = i;
         const uint64_t key = L.key[s];
         int sx, sy, sz;
         unpack_key(key, sx, sy, sz);
@@ -341,7 +336,7 @@ __device__ __forceinline__ void bucket_direct_one(BucketLds3<H>& L, const uint32
     }
     lds_barrier();
     for (uint32_t i = tid; i < M; i += T) {
-        const uint32_t s = L.list[i];
+        const uint32_t s = i;
         const int sz = (int)(L.key[s] & 0x3FFFFFu) - (1 << 21);
         L.colnodes[(L.ccnt[L.cslot[s]] >> 16) + L.kcol[s]] = make_uint4(L.first[s], (uint32_t)sz, __float_as_uint(L.mz[s]), s);
     }
@@ -352,7 +347,7 @@ __device__ __forceinline__ void bucket_direct_one(BucketLds3<H>& L, const uint32
     //      walking the column's short list; mean + fp64 scatter -> staging row ----
     uint32_t my_slopes = 0;
     for (uint32_t i = tid; i < M; i += T) {
-        const uint32_t s = L.list[i];
+        const uint32_t s = i;
         const uint64_t key = L.key[s];
         const uint32_t my_first = L.first[s];
         int sx, sy, sz;

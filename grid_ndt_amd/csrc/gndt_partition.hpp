@@ -2,9 +2,8 @@
 //
 // The atomic path (gndt_kernels.hpp) spends its time in ~11 memory-side atomics per point (MI355X
 // executes device-scope atomics at the memory side, ~20 G requests/s chip-wide).  Here the points are
-// first partitioned by COLUMN hash into B buckets with a counting partition (two streaming passes), so
-// that one workgroup owns every node of its bucket's columns and can keep their statistics, the slope
-// labels and the in-bucket ordering in LDS:
+// first partitioned by COLUMN hash into B buckets, so that one workgroup owns every node of its bucket's
+// columns and can keep their statistics, the slope labels and the in-bucket ordering in LDS:
 //
 //   partition, large builds: two levels through LDS tile sorts, no counting passes (see "Two-level partition" below)
 //   k_part2_level1   points -> {x,y,z,idx} records grouped by coarse region        reads 12, writes 16 B/pt
@@ -14,12 +13,11 @@
 //   k_part_hist      points -> bucket histogram per workgroup                      reads 12 B/pt
 //   k_part_offsets   per-bucket exclusive scan over workgroups (+ bucket totals)
 //   k_part_scatter   points -> {x,y,z,idx} records grouped by bucket               reads 12, writes 16 B/pt
-//   k_bucket_build2  (gndt_bucket.hpp) one workgroup per bucket: LDS node table, sort-based accumulation,
-//                    column lists, slope labels, mean + fp64 scatter -> 128-B staging rows
-//                                                                                   reads 16 B/pt, writes 128 B/node
+//   k_bucket_direct  (gndt_bucket3.hpp) one workgroup per bucket: LDS node table, fp64 LDS atomics, column arrays,
+//                    slope labels, mean + fp64 scatter -> 96-B staging rows         reads 16 B/pt, writes 96 + 8 B/node
 //   k_scan_*         prefix of the per-word column weights (ColumnOrder)
 //   k_order_*        destination row of every node (reference order), inverse permutation
-//   k_emit_rows      staging rows -> SoA result in reference order                 reads 128, writes 76 B/node
+//   k_emit_rows      staging rows -> SoA result in reference order                 reads 96 + 4, writes 80 B/node
 //
 // Reference semantics are the ones of gndt_kernels.hpp (same gndt_math.hpp arithmetic); only the data
 // movement differs.  Anything that does not fit (LDS table overflow, staging overflow, a partition region) raises
@@ -36,8 +34,8 @@
 namespace gndt {
 
 constexpr int kPartThreads = 1024;   // k_part_hist / k_part_scatter
-// k_bucket_build is a template on <threads, LDS node-table slots>; a bucket holding more than
-// 0.78 * slots distinct nodes overflows (the host then re-runs on the atomic path).
+// k_bucket_direct (gndt_bucket3.hpp) is a template on <threads, LDS node-table slots>; a bucket holding more distinct nodes
+// than slots overflows (the host then re-runs the build with larger tables, in the end on the atomic path).
 constexpr int kScanChunk = 2048;     // elements per block in the two-level scans
 constexpr int kScanThreads = 256;
 
