@@ -117,7 +117,7 @@ __device__ __forceinline__ void lds_index_find_or_insert(Lds& L, uint32_t (&h)[U
                 if (!won[j]) continue;
                 if (n < (uint32_t)H) {
                     L.key[n] = key[j];
-                    __hip_atomic_store(&L.idx[h[j]], n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // (LDS operations of a wave execute in order: the key is there first)
+                    __hip_atomic_store(&L.idx[h[j]], n, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);   // (release: the key is written before the number can be seen)
                     id[j] = n;
                 } else {
                     __hip_atomic_store(&L.idx[h[j]], kIdxFull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);

@@ -341,12 +341,18 @@ __global__ void __launch_bounds__(kPartThreads) k_part_scatter(const float* __re
 // Record order inside a bucket depends on the order in which tiles reserve; nothing downstream depends on it.
 // ---------------------------------------------------------------------------------------------
 constexpr int kTileThreads = 512;
-constexpr int kTilePer1 = 8;       // level 1: 4096 records per tile (68 KB of LDS); smaller tiles measured slower here
+#ifndef GNDT_TILE_PER1
+#define GNDT_TILE_PER1 8
+#endif
+#ifndef GNDT_L1_WAVES
+#define GNDT_L1_WAVES 4
+#endif
+constexpr int kTilePer1 = GNDT_TILE_PER1;       // level 1: 4096 records per tile (68 KB of LDS); smaller tiles measured slower here
 #ifndef GNDT_TILE_PER2
 #define GNDT_TILE_PER2 4
 #endif
 constexpr int kTilePer2 = GNDT_TILE_PER2;       // level 2: 2048 records per tile (34 KB): four tiles resident per CU
-static_assert(kTilePer1 * 64 == 512, "kWeight512Flag: a wave's share of a level-1 tile is the 512 points a weighted record can stand for");
+constexpr bool kWeight512Ok = kTilePer1 * 64 == 512;   // kWeight512Flag: a wave's share of a level-1 tile is the 512 points a weighted record can stand for
 constexpr int kMaxFan = 512;               // fan-out per level: up to 512 x 512 buckets
 constexpr uint32_t kSampleEvery = 64;      // level 1 samples one record in 64 to size the buckets' regions (the hash test below is >> 26)
 
@@ -433,7 +439,7 @@ __device__ __forceinline__ void tile_partition(TileLds<PER, FAN>& L, const float
 // point's column among B ranks (region c at c * cap1, nothing sampled), everything else — the pipelined tile loads, the folding
 // of identical points into weighted records, the LDS sort and the coalesced copy-out — is what level 1 does anyway.
 template <int STRIDE_FLOATS, int FAN, bool IDXW = false, bool OWNER = false>
-__global__ void __launch_bounds__(kTileThreads) __attribute__((amdgpu_waves_per_eu(4, 4))) k_part2_level1(const float* __restrict__ xyz, uint64_t n, uint32_t first_base,
+__global__ void __launch_bounds__(kTileThreads) __attribute__((amdgpu_waves_per_eu(GNDT_L1_WAVES, GNDT_L1_WAVES))) k_part2_level1(const float* __restrict__ xyz, uint64_t n, uint32_t first_base,
                                                                GridParams P, uint32_t B, uint32_t F1, uint32_t F2_shift, uint32_t R,
                                                                uint32_t* __restrict__ cursor1, uint32_t cap1,
                                                                uint32_t* __restrict__ est2,
@@ -479,7 +485,7 @@ __global__ void __launch_bounds__(kTileThreads) __attribute__((amdgpu_waves_per_
         if (tile + gridDim.x < ntiles) load_tile(tile + gridDim.x);
         // All 512 points this wave holds in the tile bit-identical (a stretch of the converters' zero padding)?  Then they go
         // out as ONE record of weight 512 instead of eight of weight 64: the bucket that collects the padding gets 8x fewer.
-        bool all8 = !IDXW && compress != 0u && t0 + (uint64_t)kTileThreads * PER <= n;
+        bool all8 = kWeight512Ok && !IDXW && compress != 0u && t0 + (uint64_t)kTileThreads * PER <= n;
         if constexpr (!IDXW) {
             const uint32_t fx = (uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(cx[0])),
                            fy = (uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(cy[0])),
