@@ -77,8 +77,9 @@ namespace {
 int grow_table(gndt_handle* h, uint32_t new_cap, hipStream_t s);
 
 // `base_from_device`: first_idx base = the device-side stream position (incremental updates)
+// `defer_advance`: the device-side stream position is advanced by the finalisation that follows (k_emit_rows), not here
 int do_accumulate(gndt_handle* h, const void* xyz_dev, size_t n, size_t stride_bytes, uint64_t first_base,
-                  int base_from_device, hipStream_t s, int mark = 0, bool tile = false) {
+                  int base_from_device, hipStream_t s, int mark = 0, bool tile = false, bool defer_advance = false) {
     if (stride_bytes != 12 && stride_bytes != 16) { h->err = "stride_bytes must be 12 or 16"; return GNDT_ERR_INVALID; }
     if (first_base + n >= 0xFFFFFFFFull) { h->err = "point index exceeds 32 bits"; return GNDT_ERR_INVALID; }
     if (n == 0) return GNDT_OK;
@@ -105,7 +106,7 @@ int do_accumulate(gndt_handle* h, const void* xyz_dev, size_t n, size_t stride_b
                            h->touch_epoch, h->touched, mark, h->d_cnt);
     HIP_TRY(h, hipGetLastError());
     if (!mark) h->incr_ok = false;                    // nodes changed without being listed: the next finalisation redoes every column
-    if (base_from_device) {
+    if (base_from_device && !defer_advance) {
         hipLaunchKernelGGL(k_advance_stream, dim3(1), dim3(64), 0, s, h->d_cnt, (uint32_t)n);
         HIP_TRY(h, hipGetLastError());
     }
@@ -117,7 +118,8 @@ int do_accumulate(gndt_handle* h, const void* xyz_dev, size_t n, size_t stride_b
 
 // columns -> labels + staging rows -> ordering -> emit.  Everything is sized on the device; nothing waits for
 // the host, so accumulate + finalize can be captured in a hipGraph once the buffers exist.
-int do_finalize(gndt_handle* h, hipStream_t s, bool incremental = false, uint64_t touched_bound = 0) {
+// `advance`: points by which the device-side stream position moves at the end of this finalisation (gndt_update_device)
+int do_finalize(gndt_handle* h, hipStream_t s, bool incremental = false, uint64_t touched_bound = 0, uint32_t advance = 0) {
     auto& q = h->part;
     int rc;
     // host-side upper bounds only: rows <= slots/2 at a healthy load; points seen so far (or the caller's hint)
@@ -162,11 +164,9 @@ int do_finalize(gndt_handle* h, hipStream_t s, bool incremental = false, uint64_
         q.words_init = words;
     }
     mark(h, 4, s);
-    if ((rc = launch_order_and_emit(h, words, 4, s))) return rc;
-    hipLaunchKernelGGL(k_tab_end, dim3(1), dim3(64), 0, s, h->d_cnt);
-    HIP_TRY(h, hipGetLastError());
-    HIP_TRY(h, hipMemcpyAsync(q.h_pc, q.d_pc, sizeof(PartCounters), hipMemcpyDeviceToHost, s));
-    HIP_TRY(h, hipMemcpyAsync(h->h_cnt, h->d_cnt, sizeof(Counters), hipMemcpyDeviceToHost, s));
+    // (k_emit_rows, the last kernel, also stores the counters and flags into the host's pinned mirrors and does the end-of-frame
+    //  bookkeeping: no copy commands and no one-thread launches behind a frame)
+    if ((rc = launch_order_and_emit(h, words, 4, s, false, true, true, advance))) return rc;
     h->results_valid = true;
     ++h->result_serial;
     h->last_stream = s;
@@ -352,10 +352,10 @@ int gndt_update_device(gndt_handle* h, const void* xyz_dev, size_t n, size_t str
     const bool incr = h->incr_ok;
     bool tile = n >= 4096 && (h->P.strategy == GNDT_STRATEGY_TILE || (h->P.strategy == GNDT_STRATEGY_AUTO && h->tile_choice == 1));
     if (tuning().update_tile >= 0) tile = n >= 4096 && tuning().update_tile == 1;
-    rc = do_accumulate(h, xyz_dev, n, stride_bytes, h->stream_pos, 1, s, incr ? 1 : 0, tile);
+    rc = do_accumulate(h, xyz_dev, n, stride_bytes, h->stream_pos, 1, s, incr ? 1 : 0, tile, /*defer_advance=*/true);
     if (rc) return rc;
     h->stream_pos += n;
-    return do_finalize(h, s, incr, n);
+    return do_finalize(h, s, incr, n, (uint32_t)n);
 }
 
 int gndt_update(gndt_handle* h, const void* xyz_host, size_t n, size_t stride_bytes) {

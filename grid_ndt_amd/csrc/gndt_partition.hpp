@@ -787,10 +787,20 @@ static __global__ void __launch_bounds__(kBlock) k_order_dest(const uint32_t* __
 static __global__ void __launch_bounds__(kBlock) k_emit_rows(const StageRow* __restrict__ stage, const uint32_t* __restrict__ inv,
                                                       OutView out, uint32_t* __restrict__ row_ncol,
                                                       const Counters* __restrict__ cnt, const PartCounters* __restrict__ pc,
-                                                      Counters* __restrict__ host_cnt, PartCounters* __restrict__ host_pc) {
+                                                      Counters* __restrict__ host_cnt, PartCounters* __restrict__ host_pc,
+                                                      Counters* tab_cnt, uint32_t advance) {
     if (blockIdx.x == 0 && threadIdx.x < 2) {
         if (threadIdx.x == 0 && host_cnt) *host_cnt = *cnt;
         if (threadIdx.x == 1 && host_pc) *host_pc = *pc;
+        // Table path (gndt_update*): the end-of-frame bookkeeping rides here as well — how many nodes own a column entry, the
+        // next epoch, the stream position of the next frame — instead of two one-thread launches per frame.  None of these
+        // fields is read by this kernel or mirrored for the host (which keeps its own stream position).
+        if (threadIdx.x == 0 && tab_cnt) {
+            tab_cnt->prev_nodes = tab_cnt->num_nodes;
+            tab_cnt->n_touched = 0; tab_cnt->n_tcols = 0; tab_cnt->n_work = 0;
+            tab_cnt->epoch = tab_cnt->epoch + 1u;
+            tab_cnt->stream_pos += advance;
+        }
     }
     if (pc->lds_overflow | pc->stage_overflow | pc->index_overflow | pc->part_overflow) return;
     const uint32_t n = cnt->num_nodes;

@@ -7,7 +7,7 @@
 //   k_tab_rows      per node: slope label (OcNode::isSlope, map2D.h:66-108) and index in column by walking the
 //                   column's list; mean + fp64 scatter -> 128-B staging row; bit per column-first index
 //   then the partition path's ordering (k_scan_*, k_order_*) and k_emit_rows (gndt_partition.hpp)
-//   k_tab_end       remember how many nodes now own a column entry; next epoch
+//   (k_emit_rows also does the end-of-frame bookkeeping: how many nodes now own a column entry, next epoch, stream position)
 //
 // Incremental updates (gndt_update_device; SURVEY §8(f) rank 2: "per-frame re-labelling of touched columns"): the staging
 // rows, the per-node order keys and the column order (bitmap, word weights) persist between finalisations, k_accumulate
@@ -161,13 +161,6 @@ static __global__ void __launch_bounds__(kBlock) k_tab_rows(TableView T, GridPar
     }
 }
 
-static __global__ void k_tab_end(Counters* cnt) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        cnt->prev_nodes = cnt->num_nodes;
-        cnt->n_touched = 0; cnt->n_tcols = 0; cnt->n_work = 0;
-        cnt->epoch = cnt->epoch + 1u;
-    }
-}
 
 // Incremental finalisation, step 1: the nodes the frame touched.
 static __global__ void __launch_bounds__(kBlock) k_tab_touch(TableView T, GridParams P, Counters* __restrict__ cnt,
