@@ -257,18 +257,40 @@ __global__ void __launch_bounds__(kBlock) k_accumulate(const float* __restrict__
                     atomicMin(&a->first, pmin);
                 }
             }
-        } else if (ok) {
-            bool inserted;
-            uint32_t slot = find_or_insert(keys, cap_mask, key, inserted);
-            if (slot > cap_mask) { atomicAdd(&cnt->err_table_full, 1u); inserted = false; }
-            append_new_nodes(inserted, slot, node_slot, index_of_slot, cnt);
-            if (slot <= cap_mask) {
-                if (mark) mark_touched(slot, epoch, touch_epoch, touched, cnt);
-                NodeAcc* a = acc + slot;
+        } else {
+            // Neighbouring lanes of one node are added as ONE contribution (a segmented reduction over the runs of equal keys in
+            // the wave): a spinning LiDAR stays in a 0.2 m voxel for a few azimuth steps — 43 % of the points of a 131 k-point
+            // terrain frame have their predecessor's key, 64 lanes hold 36 runs — and every run saved is 11 memory-side atomics
+            // and a table probe, which is all this kernel waits for.  (Order of the fp64 additions: as unordered as before.)
+            const int lane = threadIdx.x & 63;
+            const uint32_t klo = (uint32_t)key, khi = (uint32_t)(key >> 32);
+            const uint32_t plo = (uint32_t)__shfl_up((int)klo, 1, 64), phi = (uint32_t)__shfl_up((int)khi, 1, 64);
+            const bool head = lane == 0 || plo != klo || phi != khi;
+            const unsigned long long hm = __ballot(head);
+            const uint32_t rid = (uint32_t)__popcll(hm & (~0ull >> (63 - lane)));          // runs that start at or before this lane
+            uint32_t run_n = ok ? 1u : 0u, pmin = pidx;
 #pragma unroll
-                for (int j = 0; j < 9; ++j) unsafeAtomicAdd(&a->s[j], q[j]);
-                atomicAdd(&a->count, 1u);
-                atomicMin(&a->first, pidx);
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t rid_o = (uint32_t)__shfl_down((int)rid, off, 64);      // (every lane takes part: a shuffle reads nothing from a lane that sits it out)
+                const bool take = lane + off < 64 && rid_o == rid;                   // (runs are contiguous)
+#pragma unroll
+                for (int j = 0; j < 9; ++j) { const double o = __shfl_down(q[j], off, 64); if (take) q[j] += o; }
+                const uint32_t on = (uint32_t)__shfl_down((int)run_n, off, 64), op = (uint32_t)__shfl_down((int)pmin, off, 64);
+                if (take) { run_n += on; pmin = min(pmin, op); }
+            }
+            if (ok && head) {                              // the run's first lane holds its total
+                bool inserted;
+                uint32_t slot = find_or_insert(keys, cap_mask, key, inserted);
+                if (slot > cap_mask) { atomicAdd(&cnt->err_table_full, 1u); inserted = false; }
+                append_new_nodes(inserted, slot, node_slot, index_of_slot, cnt);
+                if (slot <= cap_mask) {
+                    if (mark) mark_touched(slot, epoch, touch_epoch, touched, cnt);
+                    NodeAcc* a = acc + slot;
+#pragma unroll
+                    for (int j = 0; j < 9; ++j) unsafeAtomicAdd(&a->s[j], q[j]);
+                    atomicAdd(&a->count, run_n);
+                    atomicMin(&a->first, pmin);
+                }
             }
         }
     }
