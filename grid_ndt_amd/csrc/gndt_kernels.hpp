@@ -258,12 +258,30 @@ __global__ void __launch_bounds__(kBlock) k_accumulate(const float* __restrict__
                 }
             }
         } else {
-            // Neighbouring lanes of one node are added as ONE contribution (a segmented reduction over the runs of equal keys in
-            // the wave): a spinning LiDAR stays in a 0.2 m voxel for a few azimuth steps — 43 % of the points of a 131 k-point
-            // terrain frame have their predecessor's key, 64 lanes hold 36 runs — and every run saved is 11 memory-side atomics
-            // and a table probe, which is all this kernel waits for.  (Order of the fp64 additions: as unordered as before.)
+            // The lanes of a wave that hold the same node are added as ONE contribution: the wave sorts its keys (a bitonic
+            // network over (key, lane) in registers), gathers the contributions into that order and reduces every run of equal
+            // keys onto its first lane.  A spinning LiDAR stays in a 0.2 m voxel for a few azimuth steps and comes back to it
+            // after a step next door: the 64 points of a wave of a 131 k-point terrain frame fall into 26 nodes (36 runs before
+            // sorting), and every node saved is 11 memory-side atomics and a table probe — which is all this kernel waits for;
+            // the ~600 extra vector instructions per wave are free.  (Order of the fp64 additions: as unordered as before.)
             const int lane = threadIdx.x & 63;
-            const uint32_t klo = (uint32_t)key, khi = (uint32_t)(key >> 32);
+            uint32_t klo = (uint32_t)key, khi = (uint32_t)(key >> 32), src = (uint32_t)lane;
+#pragma unroll
+            for (int kk = 2; kk <= 64; kk <<= 1) {
+#pragma unroll
+                for (int jj = kk >> 1; jj > 0; jj >>= 1) {
+                    const uint32_t olo = (uint32_t)__shfl_xor((int)klo, jj, 64), ohi = (uint32_t)__shfl_xor((int)khi, jj, 64),
+                                   osrc = (uint32_t)__shfl_xor((int)src, jj, 64);
+                    const bool mine_less = khi < ohi || (khi == ohi && (klo < olo || (klo == olo && src < osrc)));
+                    const bool keep_min = ((lane & jj) == 0) == ((lane & kk) == 0);
+                    if (keep_min != mine_less) { klo = olo; khi = ohi; src = osrc; }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 9; ++j) q[j] = __shfl(q[j], (int)src, 64);
+            pidx = (uint32_t)__shfl((int)pidx, (int)src, 64);
+            ok = __shfl((int)ok, (int)src, 64) != 0;
+            key = ((uint64_t)khi << 32) | (uint64_t)klo;
             const uint32_t plo = (uint32_t)__shfl_up((int)klo, 1, 64), phi = (uint32_t)__shfl_up((int)khi, 1, 64);
             const bool head = lane == 0 || plo != klo || phi != khi;
             const unsigned long long hm = __ballot(head);
