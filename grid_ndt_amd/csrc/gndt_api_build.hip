@@ -8,7 +8,8 @@ namespace gndt_host {
 
 // prefix of the per-word column weights -> row of every staged node -> SoA rows (marks m0+1 .. m0+5)
 // `grouped`: the staging rows of a column are adjacent (k_bucket_direct): the destination pass works per column
-int launch_order_and_emit(gndt_handle* h, uint64_t words, int m0, hipStream_t s, bool grouped, bool counters_to_host, bool tab_end, uint32_t advance) {
+int launch_order_and_emit(gndt_handle* h, uint64_t words, int m0, hipStream_t s, bool grouped, bool counters_to_host, bool tab_end, uint32_t advance,
+                          bool partial) {
     auto& q = h->part;
     if (words <= kScanSmallMax) {
         hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(1024), 0, s, (const uint32_t*)q.word_weight, (uint32_t)words, q.word_base);
@@ -28,12 +29,13 @@ int launch_order_and_emit(gndt_handle* h, uint64_t words, int m0, hipStream_t s,
                            q.ncol_at, q.inv, h->d_cnt, q.d_pc);
     else
         hipLaunchKernelGGL(k_order_dest, dim3(grid_for(q.stage_cap)), dim3(kBlock), 0, s, q.ord_cf, q.ord_idx, q.bitmap, q.word_base,
-                           q.ncol_at, q.inv, h->d_cnt, q.d_pc);
+                           q.ncol_at, q.inv, h->d_cnt, q.d_pc, tab_end ? q.row_of : (uint32_t*)nullptr, partial ? 1u : 0u);
     HIP_TRY(h, hipGetLastError());
     mark(h, m0 + 4, s);
     hipLaunchKernelGGL(k_emit_rows, dim3(grid_for(q.stage_cap)), dim3(kBlock), 0, s, q.stage, q.inv, h->out, q.row_ncol, h->d_cnt,
                        q.d_pc, counters_to_host ? h->h_cnt : (Counters*)nullptr, counters_to_host ? q.h_pc : (PartCounters*)nullptr,
-                       tab_end ? h->d_cnt : (Counters*)nullptr, advance);
+                       tab_end ? h->d_cnt : (Counters*)nullptr, advance,
+                       partial ? EmitPartial{q.word_base, q.row_of, h->touched} : EmitPartial{nullptr, nullptr, nullptr});
     HIP_TRY(h, hipGetLastError());
     mark(h, m0 + 5, s);
     return GNDT_OK;

@@ -91,7 +91,7 @@ int check_ready(gndt_handle* h) {
 
 void free_part(gndt_handle* h) {
     auto& q = h->part;
-    void* ptrs[] = {q.recs, q.recs1, q.cursors, q.range_lo, q.range_hi, q.range_cap, q.hist, q.totals, q.bucket_base, q.stage, q.ord_cf, q.ord_idx, q.inv, q.row_ncol,
+    void* ptrs[] = {q.recs, q.recs1, q.cursors, q.range_lo, q.range_hi, q.range_cap, q.hist, q.totals, q.bucket_base, q.stage, q.ord_cf, q.ord_idx, q.inv, q.row_of, q.row_ncol,
                     q.bitmap, q.word_weight, q.word_base, q.bsum_words, q.ncol_at, q.d_pc, q.dbg};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -102,13 +102,13 @@ void free_part(gndt_handle* h) {
 int ensure_stage(gndt_handle* h, uint64_t nodes) {
     auto& q = h->part;
     if (nodes <= q.stage_cap) return GNDT_OK;
-    void* ptrs[] = {q.stage, q.ord_cf, q.ord_idx, q.inv};
+    void* ptrs[] = {q.stage, q.ord_cf, q.ord_idx, q.inv, q.row_of};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
-    q.stage = nullptr; q.ord_cf = q.ord_idx = q.inv = nullptr;
+    q.stage = nullptr; q.ord_cf = q.ord_idx = q.inv = q.row_of = nullptr;
     q.stage_cap = 0;
     HIP_TRY(h, hipMalloc(&q.stage, nodes * sizeof(StageRow)));
-    uint32_t** arrs[] = {&q.ord_cf, &q.ord_idx, &q.inv};
+    uint32_t** arrs[] = {&q.ord_cf, &q.ord_idx, &q.inv, &q.row_of};
     for (auto a : arrs) HIP_TRY(h, hipMalloc(a, nodes * 4));
     q.stage_cap = nodes;
     // (the column index of the result rows has its own capacity: an adopted map — gndt_adopt_rows_device — can be larger than

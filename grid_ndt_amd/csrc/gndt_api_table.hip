@@ -166,7 +166,7 @@ int do_finalize(gndt_handle* h, hipStream_t s, bool incremental = false, uint64_
     mark(h, 4, s);
     // (k_emit_rows, the last kernel, also stores the counters and flags into the host's pinned mirrors and does the end-of-frame
     //  bookkeeping: no copy commands and no one-thread launches behind a frame)
-    if ((rc = launch_order_and_emit(h, words, 4, s, false, true, true, advance))) return rc;
+    if ((rc = launch_order_and_emit(h, words, 4, s, false, true, true, advance, incremental))) return rc;
     h->results_valid = true;
     ++h->result_serial;
     h->last_stream = s;

@@ -95,6 +95,7 @@ struct gndt_handle {
         uint32_t bucket_cap = 0;   uint32_t* totals = nullptr; uint32_t* bucket_base = nullptr;
         uint64_t stage_cap = 0;    StageRow* stage = nullptr;
         uint32_t *ord_cf = nullptr, *ord_idx = nullptr, *inv = nullptr;
+        uint32_t* row_of = nullptr;        // [stage_cap] row of every staged node (table path: the incremental finalisation emits in place)
         uint32_t* row_ncol = nullptr; uint64_t row_ncol_cap = 0;     // per result row: its column's node count on the column's first row, else 0
         // column order (gndt_partition.hpp ColumnOrder): per bitmap word, and per point index for ncol_at
         uint64_t words_init = 0;   // bitmap / word_weight words the table path's column order has initialised
@@ -310,8 +311,10 @@ int build_atomic(gndt_handle* h, const void* xyz_dev, size_t n, size_t stride_by
 int locality_sample(gndt_handle* h, const void* xyz_dev, size_t n, size_t stride_bytes, uint32_t tiles, double* ratio, hipStream_t s);
 // ---- gndt_api_build.hip ----
 // tab_end: the table path's end-of-frame bookkeeping (k_tab_end + `advance` points of stream position) done by k_emit_rows
+// partial: incremental finalisation — only rows from the first changed column on are placed and gathered again, touched rows in
+//          front of it are emitted where they are (k_order_dest / k_emit_rows, gndt_partition.hpp)
 int launch_order_and_emit(gndt_handle* h, uint64_t words, int m0, hipStream_t s, bool grouped = false, bool counters_to_host = false,
-                          bool tab_end = false, uint32_t advance = 0);
+                          bool tab_end = false, uint32_t advance = 0, bool partial = false);
 int partition_launch(gndt_handle* h, gndt_handle::Pending& P);
 int partition_begin(gndt_handle* h, const void* xyz_dev, size_t n, size_t stride_bytes, hipStream_t s, bool records = false, uint64_t index_range = 0,
                     const void* records2 = nullptr, size_t n2 = 0);

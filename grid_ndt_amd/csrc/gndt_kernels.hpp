@@ -48,7 +48,8 @@ struct Counters {
     uint32_t n_work;          // nodes of those columns (list: reuses touched[])
     uint32_t n_dead;          // gndt_remove*: nodes whose last point was taken away (dropped by the compaction that follows)
     uint32_t err_remove;      // gndt_remove*: points whose node does not exist or is already empty
-    uint32_t pad;
+    uint32_t first_word;      // incremental finalisation: first bitmap word whose column order changed in this frame (a column
+                              //   gained a node or is new); rows of columns in front of it keep their places.  0xFFFFFFFF: none
 };
 
 struct GridParams {

@@ -764,19 +764,25 @@ static __global__ void __launch_bounds__(kBlock) k_order_dest_columns(const uint
 }
 
 // destination row of every staged node (see ColumnOrder), as the inverse permutation the emit kernel gathers by
+// `row_of` (nullable): the row of every staged node, kept for the incremental finalisation.  `partial`: only the nodes of columns
+// from bitmap word cnt->first_word on are placed again — nothing in front of that word moved in this frame (gndt_table.hpp).
 static __global__ void __launch_bounds__(kBlock) k_order_dest(const uint32_t* __restrict__ ord_cf, const uint32_t* __restrict__ ord_idx,
                                                        const uint32_t* __restrict__ bitmap, const uint32_t* __restrict__ word_base,
                                                        const uint32_t* __restrict__ ncol_at, uint32_t* __restrict__ inv,
-                                                       const Counters* __restrict__ cnt, const PartCounters* __restrict__ pc) {
+                                                       const Counters* __restrict__ cnt, const PartCounters* __restrict__ pc,
+                                                       uint32_t* __restrict__ row_of, uint32_t partial) {
     if (pc->lds_overflow | pc->stage_overflow | pc->index_overflow | pc->part_overflow) return;   // the host re-runs the build; staged rows are incomplete
     const uint32_t n = cnt->num_nodes;
+    const uint32_t w0 = partial ? cnt->first_word : 0u;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const uint32_t cf = ord_cf[i];
         const uint32_t w = cf >> 5;
+        if (w < w0) continue;
         uint32_t m = bitmap[w] & ((1u << (cf & 31u)) - 1u);       // columns first seen earlier inside the same word (rare)
         uint32_t row = word_base[w] + ord_idx[i];
         while (m) { row += ncol_at[(w << 5) + (uint32_t)__builtin_ctz(m)]; m &= m - 1u; }
         inv[row] = i;
+        if (row_of) row_of[i] = row;
     }
 }
 
@@ -784,37 +790,58 @@ static __global__ void __launch_bounds__(kBlock) k_order_dest(const uint32_t* __
 // host_cnt / host_pc (nullable): the host's pinned mirrors of the counters and overflow flags.  Both are final when this —
 // the last kernel of a PARTITION build — starts, so one lane stores them straight into host memory: two copy commands less
 // behind every build (4.5 us each on the stream of a 70 us small-frame build).
+__device__ __forceinline__ void emit_one_row(const StageRow& row, uint32_t r, const OutView& out, uint32_t* __restrict__ row_ncol) {
+    out.sx[r] = row.sx; out.sy[r] = row.sy; out.sz[r] = row.sz;
+    out.count[r] = row.count; out.first_idx[r] = row.first; out.flags[r] = row.flags;
+    row_ncol[r] = row.idx_in_col == 0u ? row.ncol : 0u;        // the consumers' column index (gndt_cost.hpp)
+    float rough = 0.f, normal[3] = {0.f, 0.f, 0.f};
+    if (row.flags & 1u) node_rough_normal(row.scatter, rough, normal);
+    for (int k = 0; k < 3; ++k) { out.mean[3 * r + k] = row.mean[k]; out.normal[3 * r + k] = normal[k]; }
+    for (int k = 0; k < 6; ++k) out.cov[6 * r + k] = (float)row.scatter[k];
+    out.rough[r] = rough;
+}
+
+// Incremental finalisation (gndt_update*): what k_emit_rows needs to emit only what changed.  Rows in front of
+// word_base[first_word] did not move in this frame; of those, the ones whose node a frame touched (work list `touched`, rows
+// `row_of`) are written again in place, everything from that row on is gathered as usual.
+struct EmitPartial {
+    const uint32_t* word_base;   // nullptr: emit every row
+    const uint32_t* row_of;
+    const uint32_t* touched;
+};
+
 static __global__ void __launch_bounds__(kBlock) k_emit_rows(const StageRow* __restrict__ stage, const uint32_t* __restrict__ inv,
                                                       OutView out, uint32_t* __restrict__ row_ncol,
                                                       const Counters* __restrict__ cnt, const PartCounters* __restrict__ pc,
                                                       Counters* __restrict__ host_cnt, PartCounters* __restrict__ host_pc,
-                                                      Counters* tab_cnt, uint32_t advance) {
+                                                      Counters* tab_cnt, uint32_t advance, EmitPartial part) {
     if (blockIdx.x == 0 && threadIdx.x < 2) {
         if (threadIdx.x == 0 && host_cnt) *host_cnt = *cnt;
         if (threadIdx.x == 1 && host_pc) *host_pc = *pc;
         // Table path (gndt_update*): the end-of-frame bookkeeping rides here as well — how many nodes own a column entry, the
         // next epoch, the stream position of the next frame — instead of two one-thread launches per frame.  None of these
-        // fields is read by this kernel or mirrored for the host (which keeps its own stream position).
+        // fields is read by this kernel or mirrored for the host (which keeps its own stream position); n_work and first_word,
+        // which this kernel does read, are reset by the first kernel of the next finalisation.
         if (threadIdx.x == 0 && tab_cnt) {
             tab_cnt->prev_nodes = tab_cnt->num_nodes;
-            tab_cnt->n_touched = 0; tab_cnt->n_tcols = 0; tab_cnt->n_work = 0;
+            tab_cnt->n_touched = 0; tab_cnt->n_tcols = 0;
             tab_cnt->epoch = tab_cnt->epoch + 1u;
             tab_cnt->stream_pos += advance;
         }
     }
     if (pc->lds_overflow | pc->stage_overflow | pc->index_overflow | pc->part_overflow) return;
     const uint32_t n = cnt->num_nodes;
-    for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x) {
-        const StageRow row = stage[inv[r]];
-        out.sx[r] = row.sx; out.sy[r] = row.sy; out.sz[r] = row.sz;
-        out.count[r] = row.count; out.first_idx[r] = row.first; out.flags[r] = row.flags;
-        row_ncol[r] = row.idx_in_col == 0u ? row.ncol : 0u;        // the consumers' column index (gndt_cost.hpp)
-        float rough = 0.f, normal[3] = {0.f, 0.f, 0.f};
-        if (row.flags & 1u) node_rough_normal(row.scatter, rough, normal);
-        for (int k = 0; k < 3; ++k) { out.mean[3 * r + k] = row.mean[k]; out.normal[3 * r + k] = normal[k]; }
-        for (int k = 0; k < 6; ++k) out.cov[6 * r + k] = (float)row.scatter[k];
-        out.rough[r] = rough;
+    uint32_t r0 = 0;
+    if (part.word_base) {
+        const uint32_t w0 = cnt->first_word;
+        r0 = w0 == 0xFFFFFFFFu ? n : part.word_base[w0];
+        const uint32_t nw = cnt->n_work;
+        for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < nw; j += gridDim.x * blockDim.x) {
+            const uint32_t t = part.touched[j], r = part.row_of[t];
+            if (r < r0) emit_one_row(stage[t], r, out, row_ncol);          // touched, but where it was
+        }
     }
+    for (uint32_t r = r0 + blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x) emit_one_row(stage[inv[r]], r, out, row_ncol);
 }
 
 }  // namespace gndt

@@ -97,7 +97,7 @@ static __global__ void __launch_bounds__(kBlock) k_tab_begin(TableView T, Counte
                                                       uint32_t* __restrict__ bitmap, uint32_t* __restrict__ word_weight,
                                                       uint64_t words) {
     const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, gsz = (uint64_t)gridDim.x * blockDim.x;
-    if (gid == 0) { cnt->num_columns = 0; cnt->num_slopes = 0; pc->lds_overflow = 0; pc->stage_overflow = 0; pc->index_overflow = 0; pc->part_overflow = 0; }
+    if (gid == 0) { cnt->num_columns = 0; cnt->num_slopes = 0; pc->lds_overflow = 0; pc->stage_overflow = 0; pc->index_overflow = 0; pc->part_overflow = 0; cnt->first_word = 0u; cnt->n_work = 0u; }
     for (uint64_t i = gid; i < words; i += gsz) { bitmap[i] = 0u; word_weight[i] = 0u; }
     const uint32_t np = cnt->prev_nodes;
     for (uint64_t i = gid; i < np; i += gsz) {
@@ -168,7 +168,7 @@ static __global__ void __launch_bounds__(kBlock) k_tab_touch(TableView T, GridPa
     const uint32_t n = cnt->n_touched, np = cnt->prev_nodes, epoch = cnt->epoch;
     // (stage_overflow and index_overflow stay set once raised: an incremental finalisation builds on the rows and the
     //  column order of the previous ones, so a frame that could not be recorded invalidates the map until a reset)
-    if (blockIdx.x == 0 && threadIdx.x == 0) { pc->lds_overflow = 0; pc->part_overflow = 0; }
+    if (blockIdx.x == 0 && threadIdx.x == 0) { pc->lds_overflow = 0; pc->part_overflow = 0; cnt->first_word = 0xFFFFFFFFu; cnt->n_work = 0u; }   // (both are next used by later kernels)
     const uint32_t n_round = (n + 63u) & ~63u;                 // whole waves for the aggregated list append
     for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n_round; j += gridDim.x * blockDim.x) {
         bool first = false;
@@ -232,9 +232,10 @@ static __global__ void __launch_bounds__(kBlock) k_tab_rows_touched(TableView T,
                                                              uint32_t* __restrict__ ord_idx, ColumnOrder O, uint64_t words,
                                                              Counters* __restrict__ cnt, PartCounters* __restrict__ pc) {
     __shared__ int s_slopes;
-    __shared__ uint32_t s_cols;
-    if (threadIdx.x == 0) { s_slopes = 0; s_cols = 0; }
+    __shared__ uint32_t s_cols, s_w0;
+    if (threadIdx.x == 0) { s_slopes = 0; s_cols = 0; s_w0 = 0xFFFFFFFFu; }
     __syncthreads();
+    uint32_t my_w0 = 0xFFFFFFFFu;                   // first bitmap word whose columns changed size (one memory-side atomic per block)
     const uint32_t nw = cnt->n_work, np = cnt->prev_nodes;
     if (cnt->num_nodes > stage_cap) { if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&pc->stage_overflow, cnt->num_nodes); return; }
     int my_slopes = 0;
@@ -255,16 +256,18 @@ static __global__ void __launch_bounds__(kBlock) k_tab_rows_touched(TableView T,
             const bool had = (O.bitmap[w] & bit) != 0u;
             const uint32_t old_n = had ? O.ncol_at[cf] : 0u;
             if (!had) { atomicOr(&O.bitmap[w], bit); ++my_cols; }
-            if (row.ncol != old_n) atomicAdd(&O.word_weight[w], row.ncol - old_n);
+            if (row.ncol != old_n) { atomicAdd(&O.word_weight[w], row.ncol - old_n); my_w0 = min(my_w0, w); }   // rows from this word on move
             O.ncol_at[cf] = row.ncol;
         }
     }
     if (my_slopes) atomicAdd(&s_slopes, my_slopes);
     if (my_cols) atomicAdd(&s_cols, my_cols);
+    if (my_w0 != 0xFFFFFFFFu) atomicMin(&s_w0, my_w0);
     __syncthreads();
     if (threadIdx.x == 0) {
         if (s_slopes) atomicAdd(&cnt->num_slopes, (uint32_t)s_slopes);     // two's complement: also subtracts
         if (s_cols) atomicAdd(&cnt->num_columns, s_cols);
+        if (s_w0 != 0xFFFFFFFFu) atomicMin(&cnt->first_word, s_w0);
     }
 }
 
