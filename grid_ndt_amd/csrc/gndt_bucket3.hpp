@@ -117,7 +117,10 @@ __device__ __forceinline__ void lds_index_find_or_insert(Lds& L, uint32_t (&h)[U
                 if (!won[j]) continue;
                 if (n < (uint32_t)H) {
                     L.key[n] = key[j];
-                    __hip_atomic_store(&L.idx[h[j]], n, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);   // (release: the key is written before the number can be seen)
+                    // The key must be in place before the number can be seen.  The LDS executes a wave's operations in order, so
+                    // only the COMPILER has to be kept from swapping the two stores: a signal fence, no s_waitcnt.
+                    __atomic_signal_fence(__ATOMIC_SEQ_CST);
+                    __hip_atomic_store(&L.idx[h[j]], n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     id[j] = n;
                 } else {
                     __hip_atomic_store(&L.idx[h[j]], kIdxFull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);

@@ -838,10 +838,13 @@ static __global__ void __launch_bounds__(kBlock) k_emit_rows(const StageRow* __r
         const uint32_t nw = cnt->n_work;
         for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < nw; j += gridDim.x * blockDim.x) {
             const uint32_t t = part.touched[j], r = part.row_of[t];
-            if (r < r0) emit_one_row(stage[t], r, out, row_ncol);          // touched, but where it was
+            if (r < r0) { const StageRow row = stage[t]; emit_one_row(row, r, out, row_ncol); }          // touched, but where it was
         }
     }
-    for (uint32_t r = r0 + blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x) emit_one_row(stage[inv[r]], r, out, row_ncol);
+    for (uint32_t r = r0 + blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x) {
+        const StageRow row = stage[inv[r]];             // (the 96-byte row in one piece: six 16-byte loads)
+        emit_one_row(row, r, out, row_ncol);
+    }
 }
 
 }  // namespace gndt
