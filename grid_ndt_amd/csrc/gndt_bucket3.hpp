@@ -76,12 +76,13 @@ constexpr uint32_t kIdxEmpty = 0xFFFFFFFFu, kIdxLock = 0xFFFFFFFEu, kIdxFull = 0
 // h[j]: where record j's search stands (updated); id[j]: the node number once done[j].  Records of a lane search together.
 // A record whose table is full gets id = 0 and use = false.
 template <int H, int U, typename Lds>
+// settled[j]: record j's node number is already in id[j] (the caller's early look at the index found it).
 __device__ __forceinline__ void lds_index_find_or_insert(Lds& L, uint32_t (&h)[U], uint32_t (&id)[U], bool (&use)[U],
-                                                         const unsigned long long (&key)[U]) {
+                                                         const unsigned long long (&key)[U], const bool (&settled)[U]) {
     constexpr uint32_t kMask = 4u * (uint32_t)H - 1u;
     bool done[U];
 #pragma unroll
-    for (int j = 0; j < U; ++j) { done[j] = !use[j]; id[j] = 0u; }
+    for (int j = 0; j < U; ++j) { done[j] = !use[j] || settled[j]; if (!settled[j]) id[j] = 0u; }
     for (int round = 0; round < 16 * H; ++round) {      // (a step settles a record, moves it one word on, or waits for a publication)
         bool all_done = true;
 #pragma unroll
@@ -220,6 +221,11 @@ __device__ __forceinline__ void bucket_direct_one(BucketLds3<H>& L, const uint32
             slot[j] = node_slot3(column_hash(k[j].sx, k[j].sy), k[j].sz) & (4u * (uint32_t)H - 1u);      // (where the search starts in the index)
             if (use[j] && !k[j].ok) { atomicAdd(&L.err_range, 1u); use[j] = false; }   // |nz| beyond the key range (x, y: the partition)
         }
+        // an early look at the index: the word the hash points at is requested now, the key it leads to after the arithmetic below —
+        // by the time the search proper starts, the usual case (the node exists where the hash says) is already answered
+        uint32_t e0[U];
+#pragma unroll
+        for (int j = 0; j < U; ++j) e0[j] = __hip_atomic_load(&L.idx[slot[j]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         const bool pair = use[0] && use[1] && pkey[0] == pkey[1];      // both records in one node: one contribution
         if (pair) use[1] = false;
         // a wave whose records all sit in ONE node (dense cells, the zero padding): summed across the wave, one lane adds
@@ -242,6 +248,9 @@ __device__ __forceinline__ void bucket_direct_one(BucketLds3<H>& L, const uint32
             cn[j] = wn;
             cf[j] = record_index(iw);
         }
+        unsigned long long k0[U];
+#pragma unroll
+        for (int j = 0; j < U; ++j) k0[j] = L.key[e0[j] < (uint32_t)H ? e0[j] : 0u];
         if (pair) {
 #pragma unroll
             for (int q = 0; q < 9; ++q) c[0][q] += c[1][q];
@@ -254,7 +263,15 @@ __device__ __forceinline__ void bucket_direct_one(BucketLds3<H>& L, const uint32
         }
         GNDT_SUB(0);
         uint32_t node[U];
-        lds_index_find_or_insert<H, U>(L, slot, node, use, pkey);
+        bool settled[U];
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            const bool named = e0[j] < (uint32_t)H;
+            settled[j] = use[j] && named && k0[j] == pkey[j];
+            node[j] = e0[j];
+            if (use[j] && named && !settled[j]) slot[j] = (slot[j] + 1u) & (4u * (uint32_t)H - 1u);     // another node lives there: go on behind it
+        }
+        lds_index_find_or_insert<H, U>(L, slot, node, use, pkey, settled);
         GNDT_SUB(base == lo ? 1 : 2);
 #pragma unroll
         for (int j = 0; j < U; ++j) {
