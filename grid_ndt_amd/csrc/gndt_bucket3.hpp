@@ -10,8 +10,9 @@
 //                 written WHOLE by one lane (a row written in two parts by two lanes cost twice the bytes at the memory side),
 //                 a column's rows next to each other in first-seen order
 //
-// What bounds it (profiles/r03_bucket_ablation.txt): ~350 vector instructions per point at four waves per SIMD — the issue
-// port is busy all the time — with the LDS pipeline about half busy behind it (dependent LDS round trips queue behind the
+// What bounds it (profiles/r03_bucket_ablation.txt, r03_c_sq.txt): ~350 vector instructions and ~15 LDS operations per point at
+// four waves per SIMD — the vector port is ~56 % busy, the LDS pipeline about half, and the waves spend the rest waiting on
+// each other (dependent LDS round trips queue behind the
 // other waves' fp64 atomics, ~1 k cycles each under load).  More work in flight per thread (1 .. 4 records) changes nothing;
 // what was tried against the probing cost (windows of slots, deferred probing, a second home slot, this index) and against
 // the atomics (fixed point, integer atomics, bank binning) is listed there.  An earlier generation sorted every chunk of a
