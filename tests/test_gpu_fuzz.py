@@ -102,3 +102,41 @@ def test_min_points_other_than_the_reference_constant(min_points):
     for strategy in (1, 3, 4):
         _, out = parity.gpu_from_cloud(cloud, P, on_device=True, strategy=strategy)
         parity.assert_parity(out, ref, adversarial=True)       # (_cloud: lattice points and their float neighbours)
+
+
+@pytest.mark.parametrize("pattern", ["abab", "runs", "abcabc_plus_padding"])
+def test_interleaved_nodes_inside_a_wave(pattern):
+    """Strategy ATOMIC merges the lanes of a wave that hold the same node before it touches the table (a bitonic sort of the
+    wave's keys, then a run reduction): clouds whose consecutive points alternate between a few nodes, with lengths that are
+    not multiples of 64, dead lanes at the end and a padding run in the middle — as a build and as a stream of uneven updates."""
+    rng = np.random.default_rng(7)
+    P = dict(grid_len=0.5, z_len=0.1, slope_interval=0.08, demand="slope")
+    centres = np.float32([[1.25, 2.25, 0.05], [1.25, 2.25, 0.15], [3.75, -1.25, 0.05], [1.75, 2.25, 0.05], [-2.25, 0.75, 0.25]])
+    n = 64 * 37 + 29
+    if pattern == "abab":
+        which = np.arange(n) % 2
+    elif pattern == "runs":
+        which = np.repeat(rng.integers(0, 5, size=n // 3 + 1), rng.integers(1, 7, size=n // 3 + 1))[:n]
+    else:
+        which = np.arange(n) % 3
+    body = centres[which] + (rng.random((n, 3)).astype(np.float32) - 0.5) * np.float32([0.4, 0.4, 0.08])
+    if pattern == "abcabc_plus_padding":
+        body = np.concatenate([body[:1000], np.zeros((200, 3), np.float32), body[1000:]], 0)
+    cloud = np.concatenate([np.float32([[0.1, 0.2, 0.3]]), body], 0)
+    ref = parity.ref_from_cloud(cloud, P)
+    _, out = parity.gpu_from_cloud(cloud, P, on_device=True, strategy=1)
+    parity.assert_parity(out, ref)
+    # the same points as a stream of uneven frames (gndt_update_device: the table path's incremental finalisation)
+    import torch
+    import grid_ndt_amd as g
+    m = g.TwoDmap(P["grid_len"], P["z_len"], strategy=1)
+    m.setInterval(P["slope_interval"])
+    m.setCloudFirst(cloud[0])
+    pos = 1
+    for step in (700, 1, 63, 64, 65, 900, 10 ** 9):
+        chunk = cloud[pos:pos + step]
+        if chunk.shape[0] == 0:
+            break
+        m.change2DMap(P["demand"], torch.from_numpy(np.ascontiguousarray(chunk)).cuda())
+        pos += chunk.shape[0]
+    parity.assert_parity(m.export(), ref)
