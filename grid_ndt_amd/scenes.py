@@ -178,6 +178,9 @@ def terrain_frames(n_poses, first_pose=0, seed=0x5EED0003, half=200.0, lane=14.0
     return out
 
 
+TERRAIN_PARAMS = dict(grid_len=0.2, z_len=0.2, slope_interval=0.08, demand="slope")   # BASELINE configs[2] / [3]: 0.2 m cubic voxels
+
+
 def terrain_cloud(n, seed=0x5EED0003, **kw):
     """S3: the first n points of the pose stream."""
     ppf = kw.get("points_per_frame", FRAME_POINTS)

@@ -19,7 +19,8 @@ Round 3 — the fp32 half, so that the oracle's stand-in for PCL is pinned by so
   A.5' flags32: the same visiting-order rule evaluated on the fp32 centroids with fp32 arithmetic (what the reference's
        OcNode::isSlope sees, map2D.h:66-108): compared EVERYWHERE, no margin mask.
 and a second scene that is not lattice data: the campus stand-in of BASELINE configs[0] at 100 000 points
-(tests/golden/campus_100k_expected.npz: keys, counts, the fp32 fields and labels only, to keep the fixture small).
+(tests/golden/campus_100k_expected.npz: keys, counts, the fp32 fields and labels only, to keep the fixture small), and a
+third that is one scan-ordered LiDAR frame of the S3 / S4 terrain (tests/golden/terrain_frame_expected.npz, same fields).
 
 Run from the repository root:  python tests/golden/make_bridge_ground_expected.py
 """
@@ -156,7 +157,10 @@ def main():
     from grid_ndt_amd import scenes
     here = os.path.dirname(os.path.abspath(__file__))
     for name, cloud, P, full in (("bridge_ground_expected.npz", scenes.bridge_ground(), scenes.BRIDGE_PARAMS, True),
-                                 ("campus_100k_expected.npz", scenes.campus_frame(100_000), scenes.CAMPUS_PARAMS, False)):
+                                 ("campus_100k_expected.npz", scenes.campus_frame(100_000), scenes.CAMPUS_PARAMS, False),
+                                 # one scan-ordered LiDAR frame of the S3 / S4 terrain (131 072 points, vegetation: columns of
+                                 # several levels, so the up / down comparisons of isSlope are exercised on most columns)
+                                 ("terrain_frame_expected.npz", scenes.terrain_frames(1, 5), scenes.TERRAIN_PARAMS, False)):
         res = evaluate(cloud, P, with_fp64=full)
         out = os.path.join(here, name)
         np.savez_compressed(out, **res)

@@ -10,6 +10,7 @@ from tests import parity, scenes
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "bridge_ground_expected.npz")
 GOLD_CAMPUS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "campus_100k_expected.npz")
+GOLD_TERRAIN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "terrain_frame_expected.npz")
 
 
 def check_fp32_half(got, gold_path, what, bit_exact_statistics):
@@ -76,7 +77,8 @@ def test_oracle_reproduces_the_numpy_golden():
 def test_oracle_fp32_statistics_and_labels_are_bit_identical_to_the_numpy_float32_restatement():
     """The oracle's stand-in for pcl::compute3DCentroid / computeCovarianceMatrix (map2D.h:621-622) and for OcNode::isSlope's
     fp32 comparisons, pinned by a restatement that shares no code with it: on the reference's own scene and on a non-lattice one."""
-    for gold, cloud, P in ((GOLD, scenes.bridge_ground(), scenes.BRIDGE_PARAMS), (GOLD_CAMPUS, scenes.campus_frame(100_000), scenes.CAMPUS_PARAMS)):
+    for gold, cloud, P in ((GOLD, scenes.bridge_ground(), scenes.BRIDGE_PARAMS), (GOLD_CAMPUS, scenes.campus_frame(100_000), scenes.CAMPUS_PARAMS),
+                           (GOLD_TERRAIN, scenes.terrain_frames(1, 5), scenes.TERRAIN_PARAMS)):
         for mode in (0, 1, 2):
             ref = parity.ref_from_cloud(cloud, P, mode=mode, threads=3 if mode == 2 else 0)
             print(check_fp32_half(ref, gold, f"oracle mode {mode}", True))
@@ -97,3 +99,5 @@ def test_hip_path_reproduces_the_numpy_golden(strategy):
     print(check_fp32_half(out, GOLD, f"libgndt strategy {strategy}", False))
     _, out = parity.gpu_from_cloud(scenes.campus_frame(100_000), scenes.CAMPUS_PARAMS, strategy=strategy)
     print(check_fp32_half(out, GOLD_CAMPUS, f"libgndt strategy {strategy}, campus", False))
+    _, out = parity.gpu_from_cloud(scenes.terrain_frames(1, 5), scenes.TERRAIN_PARAMS, strategy=strategy)
+    print(check_fp32_half(out, GOLD_TERRAIN, f"libgndt strategy {strategy}, terrain frame", False))
