@@ -9,12 +9,12 @@ namespace gndt_host {
 
 void free_table(gndt_handle* h) {
     void* ptrs[] = {h->keys, h->acc, h->col_keys, h->col_first, h->aux, h->node_slot, h->col_slot_of_node,
-                    h->col_cnt, h->col_head, h->node_next, h->index_of_slot, h->touch_epoch, h->col_epoch, h->touched,
+                    h->col_cnt, h->col_head, h->node_next, h->ninfo, h->index_of_slot, h->touch_epoch, h->col_epoch, h->touched,
                     h->touched_cols};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     h->keys = nullptr; h->acc = nullptr; h->col_keys = nullptr; h->col_first = nullptr; h->aux = nullptr;
-    h->node_slot = nullptr; h->col_slot_of_node = nullptr; h->col_cnt = nullptr; h->col_head = nullptr; h->node_next = nullptr;
+    h->node_slot = nullptr; h->col_slot_of_node = nullptr; h->col_cnt = nullptr; h->col_head = nullptr; h->node_next = nullptr; h->ninfo = nullptr;
     h->index_of_slot = h->touch_epoch = h->col_epoch = h->touched = h->touched_cols = nullptr;
     h->incr_ok = false;
     h->cap = 0;
@@ -33,6 +33,7 @@ int alloc_table(gndt_handle* h, uint32_t cap, hipStream_t s) {
     HIP_TRY(h, hipMalloc(&h->node_slot, (size_t)cap * sizeof(uint32_t)));
     HIP_TRY(h, hipMalloc(&h->col_slot_of_node, (size_t)cap * sizeof(uint32_t)));
     HIP_TRY(h, hipMalloc(&h->node_next, (size_t)cap * sizeof(uint32_t)));
+    HIP_TRY(h, hipMalloc(&h->ninfo, (size_t)cap * sizeof(NodeInfo)));
     for (uint32_t** a : {&h->index_of_slot, &h->touch_epoch, &h->col_epoch, &h->touched, &h->touched_cols})
         HIP_TRY(h, hipMalloc(a, (size_t)cap * sizeof(uint32_t)));
     h->cap = cap;
@@ -48,7 +49,7 @@ TableView table_view(const gndt_handle* h) {
     TableView T;
     T.keys = h->keys; T.acc = h->acc; T.aux = h->aux; T.col_keys = h->col_keys; T.col_first = h->col_first;
     T.col_cnt = h->col_cnt; T.col_head = h->col_head; T.node_slot = h->node_slot; T.col_slot_of_node = h->col_slot_of_node;
-    T.node_next = h->node_next; T.cap_mask = h->cap - 1;
+    T.node_next = h->node_next; T.ninfo = static_cast<NodeInfo*>(h->ninfo); T.cap_mask = h->cap - 1;
     T.index_of_slot = h->index_of_slot; T.touch_epoch = h->touch_epoch; T.col_epoch = h->col_epoch;
     T.touched = h->touched; T.touched_cols = h->touched_cols;
     return T;

@@ -48,6 +48,7 @@ struct gndt_handle {
     uint32_t* col_cnt = nullptr;
     uint32_t* col_head = nullptr;
     uint32_t* node_next = nullptr;
+    void* ninfo = nullptr;          // gndt::NodeInfo[cap]: per node {first-seen, z level, mean z, flags} for the column walks (gndt_table.hpp)
     // incremental updates: slot -> node index, touch marks, the lists of touched nodes / columns
     uint32_t *index_of_slot = nullptr, *touch_epoch = nullptr, *col_epoch = nullptr, *touched = nullptr, *touched_cols = nullptr;
     bool incr_ok = false;       // the persistent staging rows / order of the table path describe the current map

@@ -25,8 +25,16 @@
 
 namespace gndt {
 
+// What a node's look at its column needs of the OTHER nodes, by node index in one 16-byte load: a walk over a column's list
+// then costs one dependent load per step (the next pointer) with this record beside it, instead of node -> slot -> {first-seen
+// index, key, mean z} two levels deep (the touched-column pass of a 131 k-point frame: 40 -> ~25 us).  Written whenever the
+// node's SlotAux is (k_tab_columns, k_tab_touch); first-seen index and z level never change once the node exists.
+struct alignas(16) NodeInfo {
+    uint32_t first; int32_t sz; float mean_z; uint32_t flags;
+};
+
 struct TableView {
-    uint64_t* keys; NodeAcc* acc; SlotAux* aux;
+    uint64_t* keys; NodeAcc* acc; SlotAux* aux; NodeInfo* ninfo;
     uint64_t* col_keys; uint32_t* col_first; uint32_t* col_cnt; uint32_t* col_head;
     uint32_t* node_slot; uint32_t* col_slot_of_node; uint32_t* node_next;
     uint32_t* index_of_slot; uint32_t* touch_epoch; uint32_t* col_epoch;      // incremental updates
@@ -65,12 +73,11 @@ __device__ __forceinline__ void tab_make_row(const TableView& T, const GridParam
     bool up = false, down = false;
     for (uint32_t t = T.col_head[cs]; t != 0xFFFFFFFFu; t = T.node_next[t]) {
         if (t == i) continue;
-        const uint32_t ts = T.node_slot[t];
-        const uint32_t tf = T.acc[ts].first;
+        const NodeInfo tx = T.ninfo[t];
+        const uint32_t tf = tx.first;
         icol += (tf < a.first) ? 1u : 0u;
-        const int tz = (int)(T.keys[ts] & 0x3FFFFFu) - (1 << 21);
+        const int tz = tx.sz;
         if (tz == za || tz == zb) {
-            const SlotAux tx = T.aux[ts];
             const bool visited = tf < a.first && (tx.flags & 1u);
             const float oz = visited ? tx.mean_z : 0.f;
             const bool far = fabsf(oz - cz) > P.slope_interval;
@@ -119,6 +126,7 @@ static __global__ void __launch_bounds__(kBlock) k_tab_columns(TableView T, Grid
         x.flags = 0u; x.mean_z = 0.f;
         if (a.count >= (uint32_t)P.min_points) { x.mean_z = node_mean_z(a.count, a.s[2], axis_centre(sz, P.oz, P.z_len)); x.flags = 1u; }
         T.aux[s] = x;
+        T.ninfo[i] = NodeInfo{a.first, sz, x.mean_z, x.flags};
         const uint32_t cs = tab_column_slot(T, column_key(key));
         T.col_slot_of_node[i] = cs;
         atomicMin(&T.col_first[cs], a.first);
@@ -183,6 +191,7 @@ static __global__ void __launch_bounds__(kBlock) k_tab_touch(TableView T, GridPa
             x.flags = 0u; x.mean_z = 0.f;
             if (a.count >= (uint32_t)P.min_points) { x.mean_z = node_mean_z(a.count, a.s[2], axis_centre(sz, P.oz, P.z_len)); x.flags = 1u; }
             T.aux[s] = x;
+            T.ninfo[i] = NodeInfo{a.first, sz, x.mean_z, x.flags};
             if (i >= np) {                                     // a node born in this frame joins its column
                 cs = tab_column_slot(T, column_key(key));
                 T.col_slot_of_node[i] = cs;
