@@ -211,6 +211,8 @@ __global__ void __launch_bounds__(kBlock) k_accumulate(const float* __restrict__
                                                        uint32_t* __restrict__ node_slot, uint32_t* __restrict__ index_of_slot,
                                                        uint32_t* __restrict__ touch_epoch, uint32_t* __restrict__ touched,
                                                        int mark, Counters* __restrict__ cnt) {
+    __shared__ double s_q[kBlock / 64][64 * 9];          // per wave: the leading lanes' nine sums, transposed for the atomics
+    __shared__ uint32_t s_slot[kBlock / 64][64];
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     const uint32_t epoch = cnt->epoch;
     const uint64_t n_round = (n + 63) & ~63ull;   // keep waves converged for the wave-uniform test
@@ -297,20 +299,41 @@ __global__ void __launch_bounds__(kBlock) k_accumulate(const float* __restrict__
                 const uint32_t on = (uint32_t)__shfl_down((int)run_n, off, 64), op = (uint32_t)__shfl_down((int)pmin, off, 64);
                 if (take) { run_n += on; pmin = min(pmin, op); }
             }
-            if (ok && head) {                              // the run's first lane holds its total
+            // The runs' first lanes hold the totals.  Their nine fp64 sums are not added lane by lane (nine instructions whose
+            // lanes each hit a different node: every lane its own 64-byte request at the memory side) but TRANSPOSED through
+            // LDS: consecutive lanes take consecutive sums of one node, so an instruction's 64 lanes cover seven nodes' 72
+            // contiguous bytes each — a few requests instead of dozens (MI355X_MICROARCH, global float atomics: the memory
+            // side is paid per 64-byte segment an instruction touches, not per lane).
+            const bool lead = ok && head;
+            const unsigned long long lm = __ballot(lead);
+            const uint32_t n_lead = (uint32_t)__popcll(lm);
+            const uint32_t li = (uint32_t)__popcll(lm & ((1ull << lane) - 1ull));     // this lane's place among the leading lanes
+            double* const wq = &s_q[threadIdx.x >> 6][0];
+            uint32_t* const wslot = &s_slot[threadIdx.x >> 6][0];
+            if (lead) {
                 bool inserted;
                 uint32_t slot = find_or_insert(keys, cap_mask, key, inserted);
                 if (slot > cap_mask) { atomicAdd(&cnt->err_table_full, 1u); inserted = false; }
                 append_new_nodes(inserted, slot, node_slot, index_of_slot, cnt);
+                wslot[li] = slot <= cap_mask ? slot : 0xFFFFFFFFu;
                 if (slot <= cap_mask) {
                     if (mark) mark_touched(slot, epoch, touch_epoch, touched, cnt);
-                    NodeAcc* a = acc + slot;
 #pragma unroll
-                    for (int j = 0; j < 9; ++j) unsafeAtomicAdd(&a->s[j], q[j]);
+                    for (int j = 0; j < 9; ++j) wq[li * 9 + j] = q[j];
+                    NodeAcc* a = acc + slot;
                     atomicAdd(&a->count, run_n);
                     atomicMin(&a->first, pmin);
                 }
             }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     // (the wave's LDS writes before its LDS reads below)
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            for (uint32_t e = (uint32_t)lane; e < n_lead * 9u; e += 64u) {
+                const uint32_t hi = (e * 7282u) >> 16;                  // e / 9 for e < 576
+                const uint32_t sl = wslot[hi];
+                if (sl != 0xFFFFFFFFu) unsafeAtomicAdd(&acc[sl].s[e - hi * 9u], wq[e]);
+            }
+            __builtin_amdgcn_wave_barrier();                             // (the next iteration writes the same LDS)
         }
     }
 }
