@@ -213,9 +213,10 @@ __global__ void __launch_bounds__(kBlock) k_accumulate(const float* __restrict__
                                                        int mark, Counters* __restrict__ cnt) {
     __shared__ double s_q[kBlock / 64][64 * 9];          // per wave: the leading lanes' nine sums, transposed for the atomics
     __shared__ uint32_t s_slot[kBlock / 64][64];
+    __shared__ uint32_t s_app[2][kBlock / 64 + 1];       // list appends of the block: per wave counts, then the block's base
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     const uint32_t epoch = cnt->epoch;
-    const uint64_t n_round = (n + 63) & ~63ull;   // keep waves converged for the wave-uniform test
+    const uint64_t n_round = (n + kBlock - 1) / kBlock * kBlock;   // whole BLOCKS: the waves of a block stay together (block barriers below)
     const uint32_t base = base_from_device ? cnt->stream_pos : first_base;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_round; i += stride) {
         const bool live = i < n;
@@ -241,6 +242,9 @@ __global__ void __launch_bounds__(kBlock) k_accumulate(const float* __restrict__
         const uint64_t key0 = ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(key >> 32)) << 32) |
                               (uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)key);
         const bool uniform = __all(ok && key == key0);
+        // what this lane appends to the lists at the end of the iteration: a node it created, a node it is the first to touch
+        uint32_t app_slot = 0;
+        bool app_new = false, app_touch = false;
         if (uniform) {
 #pragma unroll
             for (int j = 0; j < 9; ++j) q[j] = wave_sum(q[j]);
@@ -251,8 +255,8 @@ __global__ void __launch_bounds__(kBlock) k_accumulate(const float* __restrict__
                 uint32_t slot = find_or_insert(keys, cap_mask, key, inserted);
                 if (slot > cap_mask) { atomicAdd(&cnt->err_table_full, 1u); }
                 else {
-                    if (inserted) { const uint32_t idx = atomicAdd(&cnt->num_nodes, 1u); node_slot[idx] = slot; index_of_slot[slot] = idx; }
-                    if (mark && atomicExch(&touch_epoch[slot], epoch) != epoch) touched[atomicAdd(&cnt->n_touched, 1u)] = slot;
+                    app_slot = slot; app_new = inserted;
+                    app_touch = mark && atomicExch(&touch_epoch[slot], epoch) != epoch;
                     NodeAcc* a = acc + slot;
 #pragma unroll
                     for (int j = 0; j < 9; ++j) unsafeAtomicAdd(&a->s[j], q[j]);
@@ -314,10 +318,10 @@ __global__ void __launch_bounds__(kBlock) k_accumulate(const float* __restrict__
                 bool inserted;
                 uint32_t slot = find_or_insert(keys, cap_mask, key, inserted);
                 if (slot > cap_mask) { atomicAdd(&cnt->err_table_full, 1u); inserted = false; }
-                append_new_nodes(inserted, slot, node_slot, index_of_slot, cnt);
                 wslot[li] = slot <= cap_mask ? slot : 0xFFFFFFFFu;
                 if (slot <= cap_mask) {
-                    if (mark) mark_touched(slot, epoch, touch_epoch, touched, cnt);
+                    app_slot = slot; app_new = inserted;
+                    app_touch = mark && atomicExch(&touch_epoch[slot], epoch) != epoch;
 #pragma unroll
                     for (int j = 0; j < 9; ++j) wq[li * 9 + j] = q[j];
                     NodeAcc* a = acc + slot;
@@ -334,6 +338,33 @@ __global__ void __launch_bounds__(kBlock) k_accumulate(const float* __restrict__
                 if (sl != 0xFFFFFFFFu) unsafeAtomicAdd(&acc[sl].s[e - hi * 9u], wq[e]);
             }
             __builtin_amdgcn_wave_barrier();                             // (the next iteration writes the same LDS)
+        }
+        // ---- the two lists (new nodes, touched nodes): ONE counter atomic per BLOCK and list.  A counter is one word, and
+        // same-address atomics retire at ~90 per microsecond: one per wave — 2 048 for a 131 k-point frame — kept this kernel
+        // busy for 20 of its 60 us.
+        {
+            const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+            const unsigned long long m_new = __ballot(app_new), m_touch = __ballot(app_touch);
+            if (lane == 0) { s_app[0][wave] = (uint32_t)__popcll(m_new); s_app[1][wave] = (uint32_t)__popcll(m_touch); }
+            __syncthreads();
+            if (threadIdx.x < 2) {
+                uint32_t total = 0;
+                for (int w = 0; w < kBlock / 64; ++w) total += s_app[threadIdx.x][w];
+                uint32_t b = 0;
+                if (total) b = atomicAdd(threadIdx.x == 0 ? &cnt->num_nodes : &cnt->n_touched, total);
+                s_app[threadIdx.x][kBlock / 64] = b;
+            }
+            __syncthreads();
+            uint32_t b_new = s_app[0][kBlock / 64], b_touch = s_app[1][kBlock / 64];
+            for (int w = 0; w < wave; ++w) { b_new += s_app[0][w]; b_touch += s_app[1][w]; }
+            const unsigned long long below = (1ull << lane) - 1ull;
+            if (app_new) {
+                const uint32_t idx = b_new + (uint32_t)__popcll(m_new & below);
+                node_slot[idx] = app_slot;
+                index_of_slot[app_slot] = idx;
+            }
+            if (app_touch) touched[b_touch + (uint32_t)__popcll(m_touch & below)] = app_slot;
+            __syncthreads();                                             // (s_app is written again by the next iteration)
         }
     }
 }
