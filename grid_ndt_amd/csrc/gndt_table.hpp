@@ -170,6 +170,27 @@ static __global__ void __launch_bounds__(kBlock) k_tab_rows(TableView T, GridPar
 }
 
 
+// Room for `mine` entries of this lane in a list whose length is *counter: ONE counter atomic per block (a counter is one
+// word; same-address atomics retire at ~90 per microsecond at the memory side, so one per wave is felt in kernels this
+// short).  Every thread of the block calls it, the same number of times.  s: kBlock / 64 + 1 words of LDS.
+__device__ __forceinline__ uint32_t block_list_reserve(uint32_t mine, uint32_t* __restrict__ counter, uint32_t* s) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t incl = mine;
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)incl, o, 64); if (lane >= o) incl += t; }
+    if (lane == 63) s[wave] = incl;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t total = 0;
+        for (int w = 0; w < kBlock / 64; ++w) total += s[w];
+        s[kBlock / 64] = total ? atomicAdd(counter, total) : 0u;
+    }
+    __syncthreads();
+    uint32_t base = s[kBlock / 64] + incl - mine;
+    for (int w = 0; w < wave; ++w) base += s[w];
+    __syncthreads();                                   // (s is written again by the next call)
+    return base;
+}
+
 // Incremental finalisation, step 1: the nodes the frame touched.
 static __global__ void __launch_bounds__(kBlock) k_tab_touch(TableView T, GridParams P, Counters* __restrict__ cnt,
                                                       PartCounters* __restrict__ pc) {
@@ -177,7 +198,8 @@ static __global__ void __launch_bounds__(kBlock) k_tab_touch(TableView T, GridPa
     // (stage_overflow and index_overflow stay set once raised: an incremental finalisation builds on the rows and the
     //  column order of the previous ones, so a frame that could not be recorded invalidates the map until a reset)
     if (blockIdx.x == 0 && threadIdx.x == 0) { pc->lds_overflow = 0; pc->part_overflow = 0; cnt->first_word = 0xFFFFFFFFu; cnt->n_work = 0u; }   // (both are next used by later kernels)
-    const uint32_t n_round = (n + 63u) & ~63u;                 // whole waves for the aggregated list append
+    __shared__ uint32_t s_res[kBlock / 64 + 1];
+    const uint32_t n_round = (n + (uint32_t)kBlock - 1u) / (uint32_t)kBlock * (uint32_t)kBlock;   // whole blocks for the aggregated list append
     for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n_round; j += gridDim.x * blockDim.x) {
         bool first = false;
         uint32_t cs = 0;
@@ -203,32 +225,21 @@ static __global__ void __launch_bounds__(kBlock) k_tab_touch(TableView T, GridPa
             }
             first = atomicExch(&T.col_epoch[cs], epoch) != epoch;
         }
-        const unsigned long long m = __ballot(first);
-        if (m) {
-            const int lane = threadIdx.x & 63, leader = (int)__builtin_ctzll(m);
-            uint32_t base = 0;
-            if (lane == leader) base = atomicAdd(&cnt->n_tcols, (uint32_t)__popcll(m));
-            base = (uint32_t)__shfl((int)base, leader, 64);
-            if (first) T.touched_cols[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = cs;
-        }
+        const uint32_t at = block_list_reserve(first ? 1u : 0u, &cnt->n_tcols, s_res);
+        if (first) T.touched_cols[at] = cs;
     }
 }
 
 // Incremental finalisation, step 2: the nodes of the touched columns, as a flat work list (it reuses touched[], which
-// step 1 has consumed).  A wave adds up its columns' node counts and reserves the space with one atomic.
+// step 1 has consumed).  A block adds up its columns' node counts and reserves the space with one atomic.
 static __global__ void __launch_bounds__(kBlock) k_tab_expand(TableView T, Counters* __restrict__ cnt) {
+    __shared__ uint32_t s_res[kBlock / 64 + 1];
     const uint32_t nc = cnt->n_tcols;
-    const uint32_t nc_round = (nc + 63u) & ~63u;
+    const uint32_t nc_round = (nc + (uint32_t)kBlock - 1u) / (uint32_t)kBlock * (uint32_t)kBlock;
     for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < nc_round; c += gridDim.x * blockDim.x) {
         uint32_t cs = 0, n = 0;
         if (c < nc) { cs = T.touched_cols[c]; n = T.col_cnt[cs]; }
-        uint32_t incl = n;
-        const int lane = threadIdx.x & 63;
-        for (int o = 1; o < 64; o <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)incl, o, 64); if (lane >= o) incl += t; }
-        const uint32_t total = (uint32_t)__shfl((int)incl, 63, 64);
-        uint32_t base = 0;
-        if (lane == 63 && total) base = atomicAdd(&cnt->n_work, total);
-        base = (uint32_t)__shfl((int)base, 63, 64) + incl - n;
+        uint32_t base = block_list_reserve(n, &cnt->n_work, s_res);
         if (c < nc)
             for (uint32_t t = T.col_head[cs]; t != 0xFFFFFFFFu; t = T.node_next[t]) T.touched[base++] = t;
     }
