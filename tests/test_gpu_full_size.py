@@ -150,3 +150,42 @@ def test_full_size_site_20M_with_its_three_million_point_origin_node():
     if others.size == 0:
         assert np.all(out["cov"][i] == 0) and np.all(out["mean"][i] == 0) and out["rough"][i] == np.float32(0.01)
     _sample_check(cloud, out, keys, has, 0.1, 0.1, seed=1)
+
+
+def test_full_length_stream_equals_one_build():
+    """BASELINE configs[3] at full length: 100 frames x 131 072 points added one by one (gndt_update_device: wave-level merge of
+    the accumulate kernel, touched-column relabelling, partial destination / emit) against ONE build of the same 13.1 M points by
+    the partition pipeline: the same nodes in the same order with the same counts, first-seen indices and labels, and the same
+    moments up to the order of the fp64 additions.  (update(F1..Fk) == build(F1 || ... || Fk).)"""
+    import torch
+    import grid_ndt_amd as g
+    nframes, ppf = 100, scenes.FRAME_POINTS
+    frames = scenes.terrain_frames(nframes, 0)
+    P = scenes.TERRAIN_PARAMS
+    dev = torch.from_numpy(frames).cuda()
+    m = g.TwoDmap(P["grid_len"], P["z_len"], strategy=1, max_nodes_hint=4_000_000, max_points_hint=nframes * ppf)
+    m.setInterval(P["slope_interval"])
+    m.setCloudFirst(frames[0])
+    for f in range(nframes):                       # (frame 0 includes point 0: the origin is also a point of the stream, as in bench.py)
+        m.change2DMap(P["demand"], dev[f * ppf:(f + 1) * ppf])
+        if f in (0, 1, 17, 63):
+            m.sync()                               # a few frames awaited, the rest enqueued back to back
+    s = m.export()
+    b = g.TwoDmap(P["grid_len"], P["z_len"], strategy=2)
+    b.setInterval(P["slope_interval"])
+    b.setCloudFirst(frames[0])
+    b.create2DMap(P["demand"], dev)
+    o = b.export()
+    assert s["num_nodes"] == o["num_nodes"] and s["num_columns"] == o["num_columns"] and s["num_slopes"] == o["num_slopes"]
+    for k in ("sx", "sy", "sz", "count", "first_idx"):
+        assert np.array_equal(s[k], o[k]), k
+    assert np.array_equal(s["flags"] & 7, o["flags"] & 7)
+    assert int(s["count"].astype(np.int64).sum()) == nframes * ppf
+    has = (o["flags"] & 1) != 0
+    assert np.abs(s["mean"][has].astype(np.float64) - o["mean"][has]).max() <= 1e-5 * max(1.0, float(np.abs(o["mean"]).max()))
+    scale = np.abs(o["cov"][has]).max(axis=1, keepdims=True).astype(np.float64)
+    assert (np.abs(s["cov"][has].astype(np.float64) - o["cov"][has]) <= 1e-5 * scale + 1e-12).all()
+    # lambda_min: {0 -> 0.01 (map2D.h:131-132), +-tiny} are one class (tests/parity.py): compared where it is clear of that class
+    sep = has & (o["rough"] > 1e-4) & (o["rough"] != np.float32(0.01)) & (s["rough"] != np.float32(0.01))
+    trace = (o["cov"][:, 0] + o["cov"][:, 3] + o["cov"][:, 5]).astype(np.float64)
+    assert (np.abs(s["rough"][sep].astype(np.float64) - o["rough"][sep]) <= 1e-5 * trace[sep] + 1e-7).all()
