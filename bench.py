@@ -248,7 +248,7 @@ def launch_check(a, rank, world):
 
 def run_stream(a):
     """--workload S4: a step is ONE frame of 131072 points added to the map (gndt_update_device: accumulate into the HBM node
-    table, relabel the touched columns, re-order and re-emit the rows).  `value` counts the timed frames' points against the
+    table, relabel the touched columns, re-order and re-emit the rows behind the first column that changed size).  `value` counts the timed frames' points against the
     wall time of the back-to-back loop; the per-frame latency (launch -> results ready) is measured in a second, synchronised
     pass over the same frames."""
     import torch
@@ -303,7 +303,7 @@ def run_stream(a):
     _, lat, _, _ = run(True)
     lat = np.sort(np.array(lat))
     ms_step = dt / a.steps * 1e3
-    path_bytes = BYTES_PER_POINT * ppf + BYTES_PER_NODE * nodes      # a frame re-emits the whole map's rows
+    path_bytes = BYTES_PER_POINT * ppf + BYTES_PER_NODE * nodes      # (upper bound: a frame re-emits the rows behind the first column that changed size, most of the map)
     out = {"metric": "NDT grid-build throughput (bin + mean/cov + eigen + labels + ordering)", "value": round(ppf / (dt / a.steps) / 1e6, 3),
            "unit": "Mpoints/s", "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_step, 4), "higher_is_better": True,
            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "io_dtype": "f32", "data": "synthetic",

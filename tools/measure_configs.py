@@ -114,7 +114,7 @@ def main():
 
     out["S4_streaming_128k_frames"] = {"frames": a.frames, "points_per_frame": ppf, "budget_ms": 100.0,
                                        "eager": stream(False), "hip_graph_replay": stream(True),
-                                       "note": "host-timed around one frame incl. the device sync; touched columns relabelled, ordering + emit over the whole map"}
+                                       "note": "host-timed around one frame incl. the device sync; touched columns relabelled, rows placed and emitted again from the first column that changed size on"}
     del dev_frames
 
     # S5 stand-in: two-storey site, 15 % of the points at (0,0,0) (the converters' pre-allocated clouds)
