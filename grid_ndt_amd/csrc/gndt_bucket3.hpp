@@ -27,6 +27,9 @@
 
 namespace gndt {
 
+#ifndef GNDT_TALL_COLUMN
+#define GNDT_TALL_COLUMN 24      // columns of more nodes than this find their z neighbours through the index (rows phase; 8 / 16 / 24 / 32 measured: S5 gains from 16 on, S2's 20-node columns lose below)
+#endif
 #ifndef GNDT_DIRECT_WAVES
 #define GNDT_DIRECT_WAVES 4      // waves per SIMD (two 512-thread workgroups per CU): 128 VGPRs, no spills
 #endif
@@ -144,6 +147,19 @@ __device__ __forceinline__ void lds_index_find_or_insert(Lds& L, uint32_t (&h)[U
     }
 #pragma unroll
     for (int j = 0; j < U; ++j) if (!done[j]) { L.overflow = 1; use[j] = false; }
+}
+
+// Look a key up in the finished index (no insertion): the node's number, or kIdxEmpty.
+template <int H, typename Lds>
+__device__ __forceinline__ uint32_t lds_index_find(const Lds& L, uint32_t h, unsigned long long key) {
+    constexpr uint32_t kMask = 4u * (uint32_t)H - 1u;
+    for (int probe = 0; probe < 4 * H; ++probe) {
+        const uint32_t e = L.idx[h];
+        if (e >= (uint32_t)H) return kIdxEmpty;          // (empty: the key is not in the table; lock / full marks do not outlive the accumulate phase of a table that is kept)
+        if (L.key[e] == key) return e;
+        h = (h + 1u) & kMask;
+    }
+    return kIdxEmpty;
 }
 
 // slot of a node inside its bucket's table.  The bucket is chosen by the TOP bits of the column hash (bucket_of), so its
@@ -381,6 +397,31 @@ __device__ __forceinline__ void bucket_direct_one(BucketLds3<H>& L, const uint32
         const uint32_t cinfo = L.ccnt[L.cslot[s]];
         const uint32_t cbase = cinfo >> 16;
         ncol = cinfo & 0xFFFFu;
+        // Tall columns (walls: dozens of levels) look their two z neighbours up in the node index — two short probes — and walk
+        // the column only for what needs every node of it (index in column, the column's first-seen index): three instructions
+        // per node instead of ten.  Short columns find the neighbours during the walk, as before.
+        const bool tall = ncol > (uint32_t)GNDT_TALL_COLUMN;
+        if (tall) {
+            const uint32_t colh = column_hash(sx, sy);
+#pragma unroll
+            for (int side = 0; side < 2; ++side) {
+                const int tz = side == 0 ? za : zb;
+                const uint32_t t = lds_index_find<H>(L, node_slot3(colh, tz) & (4u * (uint32_t)H - 1u), pack_key(sx, sy, tz));
+                if (t != kIdxEmpty) {
+                    const float oz2 = (L.first[t] < my_first) ? L.mz[t] : 0.f;            // "visited": seen earlier AND has statistics
+                    const bool far = fabsf(oz2 - cz) > P.slope_interval;
+                    if (side == 0) up = far; else down = far;
+                }
+            }
+            for (uint32_t k0 = 0; k0 < ncol; k0 += 4) {
+                uint32_t tf[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) tf[j] = L.colnodes[cbase + min(k0 + (uint32_t)j, ncol - 1u)].x;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (k0 + (uint32_t)j < ncol) { cf = min(cf, tf[j]); icol += (tf[j] < my_first) ? 1u : 0u; }
+            }
+        } else
         for (uint32_t k0 = 0; k0 < ncol; k0 += 4) {         // four independent loads in flight, then their four nodes
             uint4 rr[4];
 #pragma unroll
