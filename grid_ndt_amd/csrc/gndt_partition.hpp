@@ -841,9 +841,44 @@ static __global__ void __launch_bounds__(kBlock) k_emit_rows(const StageRow* __r
             if (r < r0) { const StageRow row = stage[t]; emit_one_row(row, r, out, row_ncol); }          // touched, but where it was
         }
     }
-    for (uint32_t r = r0 + blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x) {
-        const StageRow row = stage[inv[r]];             // (the 96-byte row in one piece: six 16-byte loads)
-        emit_one_row(row, r, out, row_ncol);
+    // A wave takes 64 consecutive rows.  mean / normal ([n][3]) and cov ([n][6]) are written TRANSPOSED through LDS: every store
+    // instruction then covers 256 contiguous bytes instead of 64 four-byte pieces 12 or 24 bytes apart (twelve instructions that
+    // touched 6-12 lines each: the kernel spent half its time stalled at issue behind them).
+    __shared__ float s_t[kBlock / 64][64 * 12];
+    const int lane = threadIdx.x & 63;
+    float* const wm = &s_t[threadIdx.x >> 6][0];       // [64][3] mean
+    float* const wn = wm + 64 * 3;                      // [64][3] normal
+    float* const wc = wm + 64 * 6;                      // [64][6] cov
+    for (uint32_t rb = r0 + blockIdx.x * blockDim.x + (threadIdx.x & ~63u); rb < n; rb += gridDim.x * blockDim.x) {   // (wave-uniform)
+        const uint32_t r = rb + (uint32_t)lane;
+        if (r < n) {
+            const StageRow row = stage[inv[r]];         // (the 96-byte row in one piece: six 16-byte loads)
+            out.sx[r] = row.sx; out.sy[r] = row.sy; out.sz[r] = row.sz;
+            out.count[r] = row.count; out.first_idx[r] = row.first; out.flags[r] = row.flags;
+            row_ncol[r] = row.idx_in_col == 0u ? row.ncol : 0u;
+            float rough = 0.f, normal[3] = {0.f, 0.f, 0.f};
+            if (row.flags & 1u) node_rough_normal(row.scatter, rough, normal);
+            out.rough[r] = rough;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { wm[lane * 3 + k] = row.mean[k]; wn[lane * 3 + k] = normal[k]; }
+#pragma unroll
+            for (int k = 0; k < 6; ++k) wc[lane * 6 + k] = (float)row.scatter[k];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const uint32_t rows_here = min(64u, n - rb);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const uint32_t e = (uint32_t)(k * 64 + lane);
+            if (e < rows_here * 3u) { out.mean[3 * (size_t)rb + e] = wm[e]; out.normal[3 * (size_t)rb + e] = wn[e]; }
+        }
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const uint32_t e = (uint32_t)(k * 64 + lane);
+            if (e < rows_here * 6u) out.cov[6 * (size_t)rb + e] = wc[e];
+        }
+        __builtin_amdgcn_wave_barrier();                // (the next iteration writes the same LDS)
     }
 }
 
