@@ -421,7 +421,13 @@ int partition_resolve(gndt_handle* h) {
             if (P.bslots == 512 && !env_slots && P.n + P.n2 <= (1u << 20) && (P.load_pct ? P.load_pct : q.load_pct) > 35) {
                 P.load_pct = 35;
                 --P.attempt;                                     // (stay on the 512-slot tables)
-            } else if (P.attempt >= 1 || env_slots) P.nodes_est *= 2;   // (attempt 0 -> 1 only switches to the 1024-slot table)
+            } else if (P.attempt >= 1 || env_slots) {            // (attempt 0 -> 1 only switches to the 1024-slot table)
+                // More buckets: by 1.4x while only a few tables overflow (a cloud of tall columns — 10 M points at z = 0.1 m: one
+                // table in 5 500 — runs 15 % faster on 7 700 buckets than on the 11 000 a doubling gave it: fewer, fuller buckets
+                // amortise the per-bucket phases), doubling when many do.
+                const bool few = q.h_pc->lds_overflow * 64u <= q.last_buckets;
+                P.nodes_est = few ? P.nodes_est + (P.nodes_est * 2) / 5 : P.nodes_est * 2;
+            }
             again = true;
         } else if (q.h_pc->stage_overflow) {                   // num_nodes kept counting: it is the true total
             P.stage_want = (uint64_t)h->h_cnt->num_nodes + h->h_cnt->num_nodes / 8 + 1024;
