@@ -417,8 +417,11 @@ int partition_resolve(gndt_handle* h) {
             // (Lowering the average table load instead — more, smaller buckets — was measured: 1.19 ms against 0.80 ms with the
             // 1024-slot tables on the 3 M-node variant of the bench scene, and it does not help a hot column at all.)
             // Small clouds are the exception: a 200 k-point frame fills 1024-slot tables (one workgroup per CU) with ~140
-            // buckets for 256 CUs; more 512-slot buckets keep the chip busy, so they first get a lower table load.
-            if (P.bslots == 512 && !env_slots && P.n + P.n2 <= (1u << 20) && (P.load_pct ? P.load_pct : q.load_pct) > 35) {
+            // buckets for 256 CUs; more 512-slot buckets keep the chip busy, so they first get a lower table load — as long as
+            // the 1024-slot tables would leave CUs idle (under 384 buckets): a million points with half a million nodes get
+            // 1 000 of them, and 3 600 tiny 512-slot buckets instead cost 30-45 % (size sweep, round 3).
+            const uint64_t b1024 = buckets_for(P.n + P.n2, P.nodes_est, 1024, P.load_pct ? P.load_pct : q.load_pct);
+            if (P.bslots == 512 && !env_slots && P.n + P.n2 <= (1u << 20) && b1024 < 384 && (P.load_pct ? P.load_pct : q.load_pct) > 35) {
                 P.load_pct = 35;
                 --P.attempt;                                     // (stay on the 512-slot tables)
             } else if (P.attempt >= 1 || env_slots) {            // (attempt 0 -> 1 only switches to the 1024-slot table)

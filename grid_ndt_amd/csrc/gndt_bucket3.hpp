@@ -240,9 +240,11 @@ __device__ __forceinline__ void bucket_direct_one(BucketLds3<H>& L, const uint32
         }
         // an early look at the index: the word the hash points at is requested now, the key it leads to after the arithmetic below —
         // by the time the search proper starts, the usual case (the node exists where the hash says) is already answered
+        // (512-slot variant only: the 1024-slot one, a single 1024-thread workgroup per CU, has no registers to spare for it)
+        constexpr bool kEarly = H <= 512;
         uint32_t e0[U];
 #pragma unroll
-        for (int j = 0; j < U; ++j) e0[j] = __hip_atomic_load(&L.idx[slot[j]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        for (int j = 0; j < U; ++j) e0[j] = kEarly ? __hip_atomic_load(&L.idx[slot[j]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : kIdxEmpty;
         const bool pair = use[0] && use[1] && pkey[0] == pkey[1];      // both records in one node: one contribution
         if (pair) use[1] = false;
         // a wave whose records all sit in ONE node (dense cells, the zero padding): summed across the wave, one lane adds
@@ -267,7 +269,7 @@ __device__ __forceinline__ void bucket_direct_one(BucketLds3<H>& L, const uint32
         }
         unsigned long long k0[U];
 #pragma unroll
-        for (int j = 0; j < U; ++j) k0[j] = L.key[e0[j] < (uint32_t)H ? e0[j] : 0u];
+        for (int j = 0; j < U; ++j) k0[j] = kEarly ? L.key[e0[j] < (uint32_t)H ? e0[j] : 0u] : 0ull;
         if (pair) {
 #pragma unroll
             for (int q = 0; q < 9; ++q) c[0][q] += c[1][q];
