@@ -92,6 +92,14 @@ int partition_launch(gndt_handle* h, gndt_handle::Pending& P) {
     int bslots = env_slots ? env_slots : (attempt == 0 ? 512 : 1024);
     const int load_pct = P.load_pct ? P.load_pct : q.load_pct;
     uint64_t Bw = buckets_for(n, nodes_est, bslots, load_pct);
+    // Clouds with few points per node (a million points in half a million nodes): the NODES size the bucket count, and 512-slot
+    // tables — which since round 3 hold 512 nodes and no longer overflow on such clouds — would get buckets of a few hundred
+    // points, all per-bucket overhead (size sweep: 0.217 against 0.186 ms).  Below 900 points per bucket the 1024-slot tables
+    // are taken from the start, if they still fill the chip.
+    if (!env_slots && attempt == 0 && P.est_reliable && n / std::max<uint64_t>(Bw, 1) < 900) {
+        const uint64_t b1024 = buckets_for(n, nodes_est, 1024, load_pct);
+        if (b1024 >= 384) { bslots = 1024; Bw = b1024; }
+    }
     // Two-level partition (no counting passes) for large builds; the exact single-level counting partition for small
     // ones, when asked for (GNDT_STRATEGY_PARTITION_EXACT), and after a region overflowed once on this handle.
     const int env_two = tuning().two_level;
