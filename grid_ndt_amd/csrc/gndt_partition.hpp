@@ -721,7 +721,7 @@ __global__ void __launch_bounds__(kScanThreads) k_scan_apply(const uint32_t* __r
 }
 
 // the same prefix in ONE launch of one workgroup, for short arrays (small clouds: two launches cost more than the scan)
-constexpr uint32_t kScanSmallMax = 1u << 16;
+constexpr uint32_t kScanSmallMax = 1u << 13;      // (7.7 us at 6 k words and linear in them: 52 us at 31 k, where the two-launch scan takes 10)
 static __global__ void __launch_bounds__(1024) k_scan_small(const uint32_t* __restrict__ in, uint32_t n, uint32_t* __restrict__ out) {
     __shared__ uint32_t ws[16];
     const uint32_t per = (n + 1023u) / 1024u;
