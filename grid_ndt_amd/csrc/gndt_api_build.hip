@@ -491,9 +491,14 @@ int gndt_build_device(gndt_handle* h, const void* xyz_dev, size_t n, size_t stri
         // table carries many points per node.  That ratio is MEASURED on a sample of this cloud (64 tiles of 2048
         // consecutive points, ~20 us + one host wait); the answer is kept for the handle and re-measured when the cloud
         // size changes by a quarter or after 64 builds.
-        if (n >= (1u << 18)) {
-            const bool stale = h->tile_choice < 0 || ++h->tile_choice_age >= 64 ||
-                               n > h->tile_choice_n + h->tile_choice_n / 4 || n + n / 4 < h->tile_choice_n;
+        if (n >= (1u << 16)) {             // (a 200 k-point depth-camera frame at 0.5 m cells: 400 points per node, TILE 0.088 ms against PARTITION 0.145)
+            // (the sample ends in a host wait, which a stream under graph capture cannot take: a captured build keeps the
+            //  handle's last answer, PARTITION if there is none yet)
+            hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+            (void)hipStreamIsCapturing(s, &cap);
+            const bool stale = cap == hipStreamCaptureStatusNone &&
+                               (h->tile_choice < 0 || ++h->tile_choice_age >= 64 ||
+                                n > h->tile_choice_n + h->tile_choice_n / 4 || n + n / 4 < h->tile_choice_n);
             if (stale) {
                 double ratio = 0.0;
                 rc = locality_sample(h, xyz_dev, n, stride_bytes, 64, &ratio, s);

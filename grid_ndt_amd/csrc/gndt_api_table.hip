@@ -267,6 +267,12 @@ int build_atomic(gndt_handle* h, const void* xyz_dev, size_t n, size_t stride_by
         HIP_TRY(h, hipGetLastError());
         rc = do_finalize(h, s);
         if (rc) return rc;
+        // A build being captured into a hipGraph cannot wait: it is recorded once, for the table the eager builds before it
+        // settled on, and a replay whose cloud outgrows that table says so at gndt_sync (GNDT_ERR_CAPACITY), as a captured
+        // gndt_update does.
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        (void)hipStreamIsCapturing(s, &cap);
+        if (cap != hipStreamCaptureStatusNone) return GNDT_OK;
         // a build returns with its results ready: wait once and look at the device-side flags
         HIP_TRY(h, hipStreamSynchronize(s));
         if (!h->h_cnt->err_table_full && !h->part.h_pc->stage_overflow) {

@@ -281,3 +281,27 @@ def with_stride4(cloud):
     out = np.ones((cloud.shape[0], 4), np.float32)
     out[:, :3] = cloud
     return out
+
+
+# --------------------------------------------------------------------------------------------------
+# S1 (second stand-in): one depth-camera frame — what BASELINE configs[0]'s freiburg2 .pcd files are (an organised 640 x 480
+# cloud of an office, NaN pixels removed, row-major order kept).  At the reference's launch cells (0.5 / 0.1 m) such a frame
+# has a few hundred nodes of hundreds of points each: the regime of dense cells and hot columns, unlike the campus raster above.
+# --------------------------------------------------------------------------------------------------
+DEPTH_PARAMS = dict(grid_len=0.5, z_len=0.1, slope_interval=0.08, demand="slope")  # parameters.txt:46-51
+
+
+def depth_frame(seed=0x5EED0006, holes=0.3):
+    rng = np.random.default_rng(seed)
+    W, H = 640, 480
+    u, v = np.meshgrid(np.arange(W), np.arange(H))
+    dx, dy = (u - 319.5) / 525.0, (v - 239.5) / 525.0               # pinhole, looking along +y (x right, z up)
+    below = dy > 1e-3
+    t_floor = np.where(below, 1.2 / np.maximum(dy, 1e-3), np.inf)   # floor 1.2 m under the camera
+    t_desk = np.where(below, 0.5 / np.maximum(dy, 1e-3), np.inf)    # a desk top 0.5 m under it, 1 .. 2 m away, 1.6 m wide
+    t_desk = np.where((t_desk > 1.0) & (t_desk < 2.0) & (np.abs(dx * t_desk) < 0.8), t_desk, np.inf)
+    t = np.minimum(np.minimum(t_floor, 3.5), t_desk)                 # back wall at 3.5 m
+    t = t * (1.0 + 0.002 * rng.standard_normal(t.shape))
+    pts = np.stack([dx * t, t, -dy * t], -1).reshape(-1, 3).astype(np.float32)
+    keep = rng.random(pts.shape[0]) > holes                          # invalid pixels dropped, order kept
+    return np.ascontiguousarray(pts[keep])

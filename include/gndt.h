@@ -133,7 +133,10 @@ int gndt_build(gndt_handle* h, const void* xyz_host, size_t n, size_t stride_byt
  * the next call that needs the result (gndt_sync, gndt_export*, gndt_compute_cost, ...), which waits for the
  * stream and, if a table or region was too small, re-runs the build with more room — so `xyz_dev` must stay valid
  * and unchanged until then (a later gndt_build* / gndt_reset on the handle abandons the pending build instead).
- * Strategy ATOMIC waits for the stream once before returning. */
+ * Strategies ATOMIC and TILE wait for the stream once before returning (and grow the table themselves) — except on a stream
+ * under hipGraph capture, where they are recorded once for the table as it stands and a replay that outgrows it reports
+ * GNDT_ERR_CAPACITY at gndt_sync.  AUTO picks per cloud (ATOMIC below 65 536 points; above, TILE when a sample of the
+ * cloud shows dense scan-ordered cells, PARTITION otherwise); under capture it keeps the choice of the last eager build. */
 int gndt_build_device(gndt_handle* h, const void* xyz_dev, size_t n, size_t stride_bytes, void* hip_stream);
 
 /* Incremental add (the intent of changeCallback/change2DMap, receiver.cpp:179-212, map2D.h:672-822;

@@ -61,6 +61,23 @@ def test_parity_device_input(name, strategy):
     assert ran == {1: 1, 3: 3, 4: 2, 5: 5}[strategy], (name, ran)
 
 
+@pytest.mark.parametrize("cells", [(0.5, 0.1), (0.1, 0.05)], ids=["launch_cells", "fine_cells"])
+def test_depth_camera_frame_every_strategy(cells):
+    """One organised 640 x 480 depth frame (what BASELINE configs[0]'s .pcd files are): hundreds of points per node and hot
+    columns at the launch cells.  Every strategy gives the oracle's map (a forced two-level build may end on the exact
+    partition here: one region holds a third of the frame); AUTO measures the locality and takes TILE at the launch cells."""
+    cloud = scenes.depth_frame()
+    P = dict(scenes.DEPTH_PARAMS, grid_len=cells[0], z_len=cells[1])
+    ref = parity.ref_from_cloud(cloud, P)
+    for strategy in (0, 1, 2, 3, 4, 5):
+        m, out = parity.gpu_from_cloud(cloud, P, on_device=True, strategy=strategy)
+        parity.assert_parity(out, ref)
+        ran = m.last_strategy()
+        print(cells, "strategy", strategy, "ran", m.STRATEGY_NAMES[ran], "nodes", int(ref["num_nodes"]))
+        if strategy == 0 and cells[0] == 0.5:
+            assert ran == 5, ran
+
+
 def test_partition_with_node_hint_handles_dense_node_sets():
     """With max_nodes_hint the bucket count follows the node count, so node-heavy clouds stay on the LDS path."""
     for name in ("uniform_300k_cubic", "uniform_300k_z01", "site_zero_padded"):
@@ -497,6 +514,33 @@ def test_partition_build_replayed_from_a_hip_graph():
         cloud = np.concatenate([origin[None, :], clouds[k][1:]], 0)
         ref = parity.ref_from_cloud(cloud, dict(grid_len=0.5, z_len=0.5, slope_interval=0.08, demand="slope"))
         parity.assert_parity(m.export(), ref)
+
+
+def test_auto_build_captured_when_its_locality_answer_is_due_for_renewal():
+    """AUTO re-measures a cloud's locality every 64 builds, with a host wait.  A build captured into a hipGraph at that
+    moment keeps the answer the handle has instead of waiting inside the capture."""
+    import torch
+    import grid_ndt_amd as g
+    cloud = scenes.depth_frame()
+    P = scenes.DEPTH_PARAMS
+    ref = parity.ref_from_cloud(cloud, P)
+    buf = torch.from_numpy(np.ascontiguousarray(cloud[1:])).cuda()
+    m = g.TwoDmap(P["grid_len"], P["z_len"])
+    m.setInterval(P["slope_interval"])
+    m.setCloudFirst(cloud[0])
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        for _ in range(63):                                     # the 64th build would measure again
+            m.create2DMap("slope", buf, s)
+            m.sync()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=s):
+            for _ in range(3):
+                m.create2DMap("slope", buf, s)
+        graph.replay()
+        s.synchronize()
+    parity.assert_parity(m.export(), ref)
+    assert m.last_strategy() == 5
 
 
 def test_long_stream_incremental_finalisation_equals_batch_builds():

@@ -17,7 +17,8 @@ def main():
     from grid_ndt_amd import scenes
     out = {}
     for name, cloud, P in (("S1_campus_200k", scenes.campus_frame(200_000), scenes.CAMPUS_PARAMS),
-                           ("S1_bridge_ground", scenes.bridge_ground(), scenes.BRIDGE_PARAMS)):
+                           ("S1_bridge_ground", scenes.bridge_ground(), scenes.BRIDGE_PARAMS),
+                           ("S1_depth_frame", scenes.depth_frame(), scenes.DEPTH_PARAMS)):
         pts = torch.from_numpy(np.ascontiguousarray(cloud[1:])).cuda()
         m = g.TwoDmap(P["grid_len"], P["z_len"])
         m.setInterval(P["slope_interval"])
