@@ -380,9 +380,14 @@ def main():
     stream = torch.cuda.current_stream()
     exch = {}
     comm = None
+    one_cloud = global_mode                     # the ranks hold contiguous index ranges of ONE cloud (stays true if the mode steps down)
+    comm_error = None
     if global_mode:
         from grid_ndt_amd import dist as gdist
-        comm = gdist.Communicator(local)        # libgndt's own RCCL communicator: the exchange runs inside the library
+        try:
+            comm = gdist.Communicator(local)    # libgndt's own RCCL communicator: the exchange runs inside the library
+        except Exception as e:                  # (reported and agreed on below: every rank steps down together)
+            comm_error = f"{type(e).__name__}: {e}"
 
     def step(mm=None, timed=False):
         mm = mm or m
@@ -401,6 +406,37 @@ def main():
         else:
             mm.create2DMap("slope", pts, stream)
 
+    # ---- N > 1: one untimed build through the exchange before anything is measured.  If the library's RCCL path reports an
+    # error (every rank gets one at the same collective: gndt.h, GNDT_ERR_PEER), all ranks agree on it over torch.distributed
+    # and step down together: owner -> global -> the shards built with no exchange at all (said so in the line, never silent).
+    # A rank that hangs instead is ended by the watchdog. ----
+    fallback = []
+    if global_mode and several:
+        from grid_ndt_amd._lib import GndtError
+        while global_mode:
+            err = comm_error
+            try:
+                if mode in os.environ.get("GNDT_BENCH_FAIL_MODES", "").split(","):     # tests only: the step-down itself
+                    raise RuntimeError(f"injected failure of --mode {mode} (GNDT_BENCH_FAIL_MODES)")
+                if err is None:
+                    step()
+                    m.sync()
+            except (GndtError, RuntimeError) as e:
+                err = f"{type(e).__name__}: {e}"
+            okt = torch.tensor([0 if err else 1], dtype=torch.int32, device=dev)
+            dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+            if int(okt.item()):
+                break
+            fallback.append({"mode": mode, "error": err or "another rank reported an error"})
+            if rank == 0:
+                print(f"bench.py: --mode {mode} failed on its first build ({fallback[-1]['error']}): stepping down", file=sys.stderr)
+            mode = "global" if (mode == "owner" and comm is not None) else "shards_without_exchange"
+            owner_mode = False
+            global_mode = mode == "global"
+            if not global_mode:                 # each rank's shard as a map of its own: origin and indices stay those of the one cloud
+                want_anchor = False
+            exch.clear()
+            m = new_map(hint)
     for _ in range(a.warmup):
         step()
         m.sync()                     # every warm-up build is resolved: what it teaches the handle (node count, table size a
@@ -453,6 +489,13 @@ def main():
     nodes, cols, slopes = m.sync()
     n_local = n
     multi = {}
+    if fallback:
+        multi["fallback"] = fallback
+    rank0_nodes = nodes
+    if mode == "shards_without_exchange":      # one map per rank: the totals are sums (nodes of columns two shards share count twice)
+        tot = torch.tensor([nodes, cols, slopes], dtype=torch.int64, device=dev)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        nodes, cols, slopes = (int(v) for v in tot.tolist())
     if owner_mode:                       # the handle holds this rank's columns; the map of the whole cloud has:
         n_local = int(exch_timed.get("owned_points", n))
         local_nodes = nodes
@@ -575,7 +618,7 @@ def main():
         dom = max(cand, key=cand.get) if cand else None
         acc_ms = live.get(dom, cand.get(dom, float("nan"))) if dom else float("nan")
         timed_live = dom in live
-        k_nodes = local_nodes if owner_mode else nodes       # what ONE launch of the kernel on rank 0 processed
+        k_nodes = local_nodes if owner_mode else rank0_nodes    # what ONE launch of the kernel on rank 0 processed
         if dom in m.POINT_PHASES:
             alg_bytes = BYTES_PER_POINT * n_local
         elif dom in m.POINT_AND_NODE_PHASES:
@@ -591,7 +634,7 @@ def main():
             "metric": "NDT grid-build throughput (bin + mean/cov + eigen + labels + ordering)",
             "value": round(value, 3), "unit": "Mpoints/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(ms_step, 4), "higher_is_better": True,
-            "scaling": "strong" if global_mode else "weak", "vs_baseline": None,
+            "scaling": "strong" if one_cloud else "weak", "vs_baseline": None,
             "dtype": "f64", "io_dtype": "f32", "data": "synthetic",
             "config": {"workload": W["desc"] + (f", {total} points" if total != W["points"] else ""),
                        "points_total": int(job_points), "points_per_gpu": int(n), "nodes": int(nodes), "columns": int(cols),

@@ -26,3 +26,18 @@ def test_multi_gpu_line_carries_anchor_gather_and_modes():
     assert a["retries_in_timed_region"] == 0 and d["speedup_vs_single_gpu"] > 0
     assert d["gather_ms"]["value"] > 0 and d["gather_ms"]["assembled_map_matches_totals"] and d["gather_ms"]["rows"] == d["config"]["nodes"]
     assert d["modes"]["global"]["nodes"] == d["config"]["nodes"] and d["modes"]["global"]["ms_per_step"] > 0
+
+
+@pytest.mark.parametrize("fail,ends_on", [("owner", "global"), ("owner,global", "shards_without_exchange")])
+def test_multi_gpu_line_steps_down_when_the_exchange_reports_an_error(fail, ends_on):
+    """An error of the library's exchange on the first, untimed build (injected here) is agreed on by all ranks, named in the line, and
+    the measurement goes on in the next mode instead of ending without a line."""
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29733", GNDT_BENCH_FAIL_MODES=fail)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--mode", "owner", "--workload", "S3", "--points", "2000000",
+                        "--steps", "3", "--warmup", "2", "--force-multi-extras", "--no-cpu-baseline"], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert d["config"]["multi_gpu_mode"] == ends_on and [f["mode"] for f in d["fallback"]] == fail.split(",")
+    assert all("injected failure" in f["error"] for f in d["fallback"])
+    assert d["config"]["points_total"] == 2000000 and d["config"]["nodes"] > 0 and d["value"] > 0 and d["scaling"] == "strong"
+    assert "gather_ms" not in d and "modes" not in d
