@@ -337,7 +337,7 @@ int partition_launch(gndt_handle* h, gndt_handle::Pending& P) {
     hipLaunchKernelGGL((k_bucket_direct<T_, H_, S_>), bgrid, dim3(T_), 0, s, bucket_recs, ranges, B, gp, q.stage,    \
                        (uint32_t)(S_ ? h->st_cap : q.stage_cap), q.ord_cf, q.ord_idx, order, h->d_cnt, q.d_pc, dbg, stats_out)
         if (bslots == 1024) { if (P.stats_only) GNDT_LAUNCH_DIRECT(1024, 1024, true); else GNDT_LAUNCH_DIRECT(1024, 1024, false); }
-        else { if (P.stats_only) GNDT_LAUNCH_DIRECT(512, 512, true); else GNDT_LAUNCH_DIRECT(512, 512, false); }
+        else { if (P.stats_only) GNDT_LAUNCH_DIRECT(GNDT_DIRECT_THREADS, 512, true); else GNDT_LAUNCH_DIRECT(GNDT_DIRECT_THREADS, 512, false); }
 #undef GNDT_LAUNCH_DIRECT
     }
     HIP_TRY(h, hipGetLastError());

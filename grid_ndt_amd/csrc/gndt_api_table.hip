@@ -58,12 +58,11 @@ TableView table_view(const gndt_handle* h) {
 }  // namespace
 
 int do_reset(gndt_handle* h, hipStream_t s) {
-    if (h->cap && h->table_dirty) {
+    if (h->cap && h->table_dirty)       // (its last workgroup zeroes the counters)
         hipLaunchKernelGGL(k_clear_used, dim3(grid_for(h->cap / 8)), dim3(kBlock), 0, s, h->keys, h->acc, h->col_keys,
                            h->col_first, h->col_cnt, h->col_head, h->node_slot, h->col_slot_of_node, h->d_cnt);
-        HIP_TRY(h, hipGetLastError());
-    }
-    hipLaunchKernelGGL(k_zero_counters, dim3(1), dim3(64), 0, s, h->d_cnt);
+    else
+        hipLaunchKernelGGL(k_zero_counters, dim3(1), dim3(64), 0, s, h->d_cnt);
     HIP_TRY(h, hipGetLastError());
     h->table_dirty = false;
     h->results_valid = false;
@@ -120,7 +119,8 @@ int do_accumulate(gndt_handle* h, const void* xyz_dev, size_t n, size_t stride_b
 // columns -> labels + staging rows -> ordering -> emit.  Everything is sized on the device; nothing waits for
 // the host, so accumulate + finalize can be captured in a hipGraph once the buffers exist.
 // `advance`: points by which the device-side stream position moves at the end of this finalisation (gndt_update_device)
-int do_finalize(gndt_handle* h, hipStream_t s, bool incremental = false, uint64_t touched_bound = 0, uint32_t advance = 0) {
+// `raise_to`: the stream position is at least this from here on (a batch build: its point count)
+int do_finalize(gndt_handle* h, hipStream_t s, bool incremental = false, uint64_t touched_bound = 0, uint32_t advance = 0, uint32_t raise_to = 0) {
     auto& q = h->part;
     int rc;
     // host-side upper bounds only: rows <= slots/2 at a healthy load; points seen so far (or the caller's hint)
@@ -155,7 +155,7 @@ int do_finalize(gndt_handle* h, hipStream_t s, bool incremental = false, uint64_
         HIP_TRY(h, hipGetLastError());
     } else {
         hipLaunchKernelGGL(k_tab_begin, dim3(grid_for(std::max<uint64_t>(words, h->cap / 4), kBlock, 1024)), dim3(kBlock), 0, s, T,
-                           h->d_cnt, q.d_pc, q.bitmap, q.word_weight, (uint64_t)words);
+                           h->d_cnt, q.d_pc, q.bitmap, q.word_weight, (uint64_t)words, raise_to);
         hipLaunchKernelGGL(k_tab_columns, dim3(grid_for(rows_bound)), dim3(kBlock), 0, s, T, gp, h->d_cnt);
         HIP_TRY(h, hipGetLastError());
         mark(h, 3, s);
@@ -263,9 +263,7 @@ int build_atomic(gndt_handle* h, const void* xyz_dev, size_t n, size_t stride_by
         rc = do_accumulate(h, xyz_dev, n, stride_bytes, 0, 0, s, 0, tile);
         if (rc) return rc;
         h->stream_pos = n;
-        hipLaunchKernelGGL(k_raise_stream, dim3(1), dim3(64), 0, s, h->d_cnt, (uint32_t)n);
-        HIP_TRY(h, hipGetLastError());
-        rc = do_finalize(h, s);
+        rc = do_finalize(h, s, false, 0, 0, (uint32_t)n);        // (the device-side stream position is raised by its first kernel)
         if (rc) return rc;
         // A build being captured into a hipGraph cannot wait: it is recorded once, for the table the eager builds before it
         // settled on, and a replay whose cloud outgrows that table says so at gndt_sync (GNDT_ERR_CAPACITY), as a captured

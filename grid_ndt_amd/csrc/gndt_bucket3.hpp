@@ -33,6 +33,12 @@ namespace gndt {
 #ifndef GNDT_DIRECT_WAVES
 #define GNDT_DIRECT_WAVES 4      // waves per SIMD (two 512-thread workgroups per CU): 128 VGPRs, no spills
 #endif
+#ifndef GNDT_DIRECT_THREADS
+#define GNDT_DIRECT_THREADS 512  // threads of a workgroup with a 512-slot table
+#endif
+#ifndef GNDT_DIRECT_U
+#define GNDT_DIRECT_U 2          // records per thread and iteration (512-slot table)
+#endif
 
 // Compact per-node statistics (the gndt_stats layout): what a shard of a multi-GPU build hands to the exchange.
 // STATS = false: the bucket's nodes leave as staging rows (labels, moments) for the ordering + emit kernels.
@@ -179,7 +185,7 @@ __device__ __forceinline__ void bucket_direct_one(BucketLds3<H>& L, const uint32
                                                   PartCounters* __restrict__ pc, unsigned long long* __restrict__ dbg,
                                                   const StatsOut& so) {
     static_assert(H <= 65535, "node numbers are kept in 16 bits");
-    constexpr int U = 2;                           // records in flight per thread
+    constexpr int U = H <= 512 ? GNDT_DIRECT_U : 2;    // records in flight per thread
     const int tid = threadIdx.x;
     const int lane = tid & 63;
 #define GNDT_STAMP3(k) do { if (dbg && tid == 0) dbg[(size_t)bucket * 16 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
@@ -245,10 +251,10 @@ __device__ __forceinline__ void bucket_direct_one(BucketLds3<H>& L, const uint32
         uint32_t e0[U];
 #pragma unroll
         for (int j = 0; j < U; ++j) e0[j] = kEarly ? __hip_atomic_load(&L.idx[slot[j]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : kIdxEmpty;
-        const bool pair = use[0] && use[1] && pkey[0] == pkey[1];      // both records in one node: one contribution
-        if (pair) use[1] = false;
+        const bool pair = U >= 2 && use[0] && use[U - 1] && pkey[0] == pkey[U - 1];      // both records in one node: one contribution
+        if (pair) use[U - 1] = false;
         // a wave whose records all sit in ONE node (dense cells, the zero padding): summed across the wave, one lane adds
-        const bool one_node = __all(pair) && __all(pkey[0] == __shfl(pkey[0], 0, 64));
+        const bool one_node = __all(U >= 2 ? pair : use[0]) && __all(pkey[0] == __shfl(pkey[0], 0, 64));
         if (one_node) use[0] = lane == 0;
         double c[U][9];
         uint32_t cn[U], cf[U];
@@ -272,8 +278,8 @@ __device__ __forceinline__ void bucket_direct_one(BucketLds3<H>& L, const uint32
         for (int j = 0; j < U; ++j) k0[j] = kEarly ? L.key[e0[j] < (uint32_t)H ? e0[j] : 0u] : 0ull;
         if (pair) {
 #pragma unroll
-            for (int q = 0; q < 9; ++q) c[0][q] += c[1][q];
-            cn[0] += cn[1]; cf[0] = min(cf[0], cf[1]);
+            for (int q = 0; q < 9; ++q) c[0][q] += c[U - 1][q];
+            cn[0] += cn[U - 1]; cf[0] = min(cf[0], cf[U - 1]);
         }
         if (one_node) {
 #pragma unroll

@@ -50,6 +50,7 @@ struct Counters {
     uint32_t err_remove;      // gndt_remove*: points whose node does not exist or is already empty
     uint32_t first_word;      // incremental finalisation: first bitmap word whose column order changed in this frame (a column
                               //   gained a node or is new); rows of columns in front of it keep their places.  0xFFFFFFFF: none
+    uint32_t ticket;          // k_clear_used: workgroups that are done (the last one zeroes the counters); 0 between kernels
 };
 
 struct GridParams {
@@ -164,9 +165,15 @@ static __global__ void k_clear_all(uint64_t* keys, NodeAcc* acc, uint64_t* col_k
 
 // k_clear_used: empty the map by visiting only its occupied slots (O(C), not O(cap)).  Nodes that went through a
 // finalize (i < prev_nodes) also own a column-table entry.
+static __device__ __forceinline__ void zero_counters(Counters* c) {
+    c->num_nodes = 0; c->num_columns = 0; c->num_slopes = 0; c->err_key_range = 0; c->err_table_full = 0;
+    c->stream_pos = 0; c->prev_nodes = 0; c->n_touched = 0; c->n_tcols = 0; c->n_work = 0; c->n_dead = 0; c->err_remove = 0;
+    c->epoch = c->epoch + 1u;                     // stale touch marks of the previous map can never match again
+}
+
 static __global__ void k_clear_used(uint64_t* keys, NodeAcc* acc, uint64_t* col_keys, uint32_t* col_first, uint32_t* col_cnt,
                              uint32_t* col_head, const uint32_t* node_slot, const uint32_t* col_slot_of_node,
-                             const Counters* cur) {
+                             Counters* cur) {
     const uint32_t n = cur->num_nodes, np = cur->prev_nodes;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const uint32_t slot = node_slot[i];
@@ -183,15 +190,18 @@ static __global__ void k_clear_used(uint64_t* keys, NodeAcc* acc, uint64_t* col_
             col_head[cs] = 0xFFFFFFFFu;
         }
     }
+    // The counters go to zero in the same launch (a one-thread kernel behind this one cost a small build ~5 us): every thread
+    // has read them above; the workgroup that takes the last ticket knows that all the others have, too.
+    __syncthreads();
+    if (threadIdx.x == 0 && atomicAdd(&cur->ticket, 1u) == gridDim.x - 1u) {
+        zero_counters(cur);
+        cur->ticket = 0u;
+    }
 }
 
 // all counters to zero (after the clear that read them)
 static __global__ void k_zero_counters(Counters* c) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        c->num_nodes = 0; c->num_columns = 0; c->num_slopes = 0; c->err_key_range = 0; c->err_table_full = 0;
-        c->stream_pos = 0; c->prev_nodes = 0; c->n_touched = 0; c->n_tcols = 0; c->n_work = 0; c->n_dead = 0; c->err_remove = 0;
-        c->epoch = c->epoch + 1u;                     // stale touch marks of the previous map can never match again
-    }
+    if (threadIdx.x == 0 && blockIdx.x == 0) zero_counters(c);
 }
 
 // ---------------------------------------------------------------------------------------------

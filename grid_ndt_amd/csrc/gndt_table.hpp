@@ -102,8 +102,9 @@ __device__ __forceinline__ void tab_make_row(const TableView& T, const GridParam
 
 static __global__ void __launch_bounds__(kBlock) k_tab_begin(TableView T, Counters* __restrict__ cnt, PartCounters* __restrict__ pc,
                                                       uint32_t* __restrict__ bitmap, uint32_t* __restrict__ word_weight,
-                                                      uint64_t words) {
+                                                      uint64_t words, uint32_t raise_to) {
     const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, gsz = (uint64_t)gridDim.x * blockDim.x;
+    if (gid == 0 && raise_to) cnt->stream_pos = max(cnt->stream_pos, raise_to);
     if (gid == 0) { cnt->num_columns = 0; cnt->num_slopes = 0; pc->lds_overflow = 0; pc->stage_overflow = 0; pc->index_overflow = 0; pc->part_overflow = 0; cnt->first_word = 0u; cnt->n_work = 0u; }
     for (uint64_t i = gid; i < words; i += gsz) { bitmap[i] = 0u; word_weight[i] = 0u; }
     const uint32_t np = cnt->prev_nodes;
