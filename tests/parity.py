@@ -18,12 +18,56 @@ MAX_WIDENING = 10.0           # ... and none by more than this factor over 1e-5
 MAX_UNRESOLVED_FRACTION = 1e-3   # nodes whose scatter lies below the input resolution floor
 
 
-def compare(gpu, ref, demand="slope", adversarial=False):
+LABEL_MARGIN = 1e-5   # dense clouds only (see compare): a label may differ where |dz| is this close to the slope interval, plus what
+                      # the fp32 oracle's own centroids of the two nodes are off the fp64 ones
+
+
+def _labels_within_margin(gpu, ref, rows, interval, min_points, margin):
+    """OcNode::isSlope (map2D.h:66-108) decides on |mean_z(neighbour) - mean_z(node)| > interval, with the neighbour's centroid
+    as it is at call time: fitted if the neighbour comes EARLIER in the column and has min_points, zero otherwise.  -> for each
+    of `rows`: is one of the node's decision quantities, evaluated on the fp64 means, within `margin` of the interval?"""
+    sx, sy, sz = ref["sx"], ref["sy"], ref["sz"]
+    z = ref["mean64"][:, 2]
+    zerr = np.abs(ref["mean"][:, 2].astype(np.float64) - z)          # the fp32 oracle's own error on every node
+    cnt = ref["count"].astype(np.int64)
+    n = sx.shape[0]
+    new_col = np.ones(n, bool)
+    new_col[1:] = (sx[1:] != sx[:-1]) | (sy[1:] != sy[:-1])
+    start = np.flatnonzero(new_col)
+    col_of = np.cumsum(new_col) - 1
+    end = np.append(start[1:], n)
+    ok = np.zeros(len(rows), bool)
+    for k, i in enumerate(rows):
+        a, b = int(start[col_of[i]]), int(end[col_of[i]])
+        zadd, zminus = int(sz[i]) + 1, int(sz[i]) - 1
+        if sz[i] == -1:
+            zadd = 1
+        elif sz[i] == 1:
+            zminus = -1
+        for o in range(a, b):
+            if sz[o] == zadd or sz[o] == zminus:
+                fitted = o < i and cnt[o] >= min_points
+                zo = z[o] if fitted else 0.0
+                if abs(abs(zo - z[i]) - interval) <= margin + zerr[i] + (zerr[o] if fitted else 0.0):
+                    ok[k] = True
+                    break
+    return ok
+
+
+def compare(gpu, ref, demand="slope", adversarial=False, dense=False, interval=0.08, min_points=3):
     """-> report dict; report['ok'] is the conjunction of all gates.  `adversarial`: the cloud was BUILT to sit at the input
     resolution (lattice points and their float neighbours, tests/test_gpu_fuzz.py): the share of unresolvable nodes is then
     not capped, nor is the share of nodes on which the fp32 oracle itself is more than 1e-5 off (the factor stays capped;
-    every other gate stays)."""
+    every other gate stays).
+    `dense` (tools/fuzz_campaign.py: random clouds with hundreds to thousands of points per node): the reference's sequential
+    fp32 sums are then themselves 1e-5 .. 1e-4 off the exact centroid, which no other summation order reproduces.  The mean is
+    held to 1e-5 of the fp64 TRUTH and, against the fp32 oracle, to twice the oracle's own error; a slope / down label may differ
+    only on a node one of whose decision quantities |dz| lies within LABEL_MARGIN + the fp32 oracle's own error on the two centroids
+    of the interval (every other node: exact); the eigen gates run on the nodes both sides call slopes; the covariance is held to
+    the fp64 truth (the caps on how far the fp32 oracle's own scatter may be off are lifted: it is 1e-2 off on such nodes)."""
     rep = {"ok": True, "fail": []}
+    if dense:
+        adversarial = True
 
     def fail(msg):
         rep["ok"] = False
@@ -50,14 +94,22 @@ def compare(gpu, ref, demand="slope", adversarial=False):
     if not np.array_equal(gpu["first_idx"].astype(np.int64), ref["first_idx"].astype(np.int64)):
         fail("first_idx mismatch")
     gf, rf = gpu["flags"].astype(np.int64), ref["flags"].astype(np.int64)
+    tolerated = np.zeros(n, bool)
+    if dense and demand == "slope":
+        rows = np.flatnonzero((gf & 6) != (rf & 6))
+        if rows.size and rows.size <= 20000:
+            tolerated[rows] = _labels_within_margin(gpu, ref, rows, float(interval), int(min_points), LABEL_MARGIN)
+        rep["labels_within_margin"] = int(np.count_nonzero(tolerated))
     for bit, name in ((1, "has_stats"), (2, "slope"), (4, "down")):
-        d = np.count_nonzero((gf & bit) != (rf & bit))
+        d = np.count_nonzero(((gf & bit) != (rf & bit)) & ~tolerated)
         rep[f"label_mismatch_{name}"] = int(d)
         if d:
             fail(f"{name} label differs on {d} nodes")
     rep["num_slopes"] = int(np.count_nonzero(rf & 2))
-    if "num_slopes" in gpu and int(gpu["num_slopes"]) != rep["num_slopes"]:
-        fail(f"num_slopes {gpu['num_slopes']} != {rep['num_slopes']}")
+    if "num_slopes" in gpu:
+        want = rep["num_slopes"] + int(np.count_nonzero(((gf & 2) != 0) & tolerated)) - int(np.count_nonzero(((rf & 2) != 0) & tolerated))
+        if int(gpu["num_slopes"]) != want:
+            fail(f"num_slopes {gpu['num_slopes']} != {want}")
 
     has = (rf & 1) != 0
     if not has.any():
@@ -65,7 +117,17 @@ def compare(gpu, ref, demand="slope", adversarial=False):
     gm, rm = gpu["mean"][has].astype(np.float64), ref["mean"][has].astype(np.float64)
     e_mean = np.abs(gm - rm) / np.maximum(1.0, np.abs(rm))
     rep["mean_err"] = float(e_mean.max())
-    if rep["mean_err"] > TOL_MEAN:
+    if dense:
+        tm = ref["mean64"][has]
+        e_truth = np.abs(gm - tm) / np.maximum(1.0, np.abs(tm))
+        self_err = np.abs(rm - tm) / np.maximum(1.0, np.abs(tm))
+        rep["mean_err_truth"] = float(e_truth.max())
+        rep["ref_fp32_mean_self_err"] = float(self_err.max())
+        if rep["mean_err_truth"] > TOL_MEAN:
+            fail(f"mean error vs fp64 truth {rep['mean_err_truth']:.3e} > {TOL_MEAN}")
+        if np.any(e_mean > np.maximum(TOL_MEAN, 2.0 * self_err)):
+            fail(f"mean error {rep['mean_err']:.3e} beyond twice the fp32 oracle's own error")
+    elif rep["mean_err"] > TOL_MEAN:
         fail(f"mean error {rep['mean_err']:.3e} > {TOL_MEAN}")
     # nodes without stats must stay zero (OcNode keeps its zero-initialised centroid, map2D.h:54-55)
     if np.any(gpu["mean"][~has] != 0) or np.any(gpu["cov"][~has] != 0):
@@ -104,7 +166,7 @@ def compare(gpu, ref, demand="slope", adversarial=False):
     n_has = int(np.count_nonzero(has))
     if not adversarial and np.count_nonzero(widened) > max(1, int(MAX_WIDENED_FRACTION * n_has)):
         fail(f"{int(np.count_nonzero(widened))} of {n_has} nodes need a widened covariance allowance (cap {MAX_WIDENED_FRACTION:g})")
-    if rep["cov_widening_max"] > MAX_WIDENING:
+    if rep["cov_widening_max"] > MAX_WIDENING and not dense:
         fail(f"covariance allowance widened {rep['cov_widening_max']:.1f}x on some node (cap {MAX_WIDENING:g}x)")
     if np.any(d32 > np.maximum(allow32 * scale, 2.0 * floor + np.abs(rc32 - rc64).max(axis=1))):
         fail(f"cov error vs fp32 oracle {float((e32 / allow32).max()):.2f}x allowance (max {rep['cov_err']:.3e})")
@@ -123,6 +185,8 @@ def compare(gpu, ref, demand="slope", adversarial=False):
 
     # eigen results exist where the reference created a Slope
     sl = (rf & 2) != 0
+    if dense:
+        sl = sl & ((gf & 2) != 0)
     if sl.any():
         tr = (ref["cov64"][sl][:, 0] + ref["cov64"][sl][:, 3] + ref["cov64"][sl][:, 5])
         g_rough = gpu["rough"][sl].astype(np.float64)

@@ -140,3 +140,14 @@ def test_interleaved_nodes_inside_a_wave(pattern):
         m.change2DMap(P["demand"], torch.from_numpy(np.ascontiguousarray(chunk)).cuda())
         pos += chunk.shape[0]
     parity.assert_parity(m.export(), ref)
+
+
+@pytest.mark.parametrize("seed", [11, 12])
+def test_one_handle_builds_a_sequence_of_unrelated_clouds(seed):
+    """tools/fuzz_campaign.py in small: handles of random strategy / cells / hint, each building 2-5 unrelated clouds of random
+    structure and size (what a handle learnt from the last cloud is wrong for the next), some as update streams; every map
+    against the oracle under the dense-cloud gates of tests/parity.py.  (The long run: profiles/r03_fuzz_campaign.json.)"""
+    from tools import fuzz_campaign
+    stats = fuzz_campaign.run(seconds=120.0, seed=seed, max_points=400_000, max_handles=20)
+    assert not stats["failures"], stats["failures"]
+    assert stats["builds"] >= 40
