@@ -176,7 +176,8 @@ GNDT_HD int pick_min_eigen(const double e[3]) {
 //   2. fp32 trigonometric closed form for a start value (relative error ~1e-6 whatever the clustering);
 //   3. fp64 Newton on det(A - x I) started just LEFT of the estimate: for a cubic with real roots the
 //      iterates rise monotonically to the smallest root (quadratic when it is separated; when roots
-//      cluster the start value is already inside the tolerance);
+//      cluster the start value is already inside the tolerance — or, if it landed right of them, the
+//      iteration starts again from just left of zero);
 //   4. eigenvector = largest cross product of two rows of (A - x I); rank-deficient fall-backs below.
 // c = xx,xy,xz,yy,yz,zz.  Returns lambda (>= 0 up to rounding) and a unit vector.
 GNDT_HD void min_eigenpair_sym3(const double c[6], double& lambda, double v[3]) {
@@ -208,11 +209,26 @@ GNDT_HD void min_eigenpair_sym3(const double c[6], double& lambda, double v[3]) 
         lam = (double)(q + 2.0f * p * cosf(phi + 2.0943951023931953f)) - 1e-5;
     }
     // separated root: 2-4 iterations (quadratic); double/triple root: halves the error each time
+    bool restarted = false;
+    double prev = 1e300;
     for (int it = 0; it < 26; ++it) {
         const double f = ((c2 - lam) * lam - c1) * lam + c0;
         const double fp = (2.0 * c2 - 3.0 * lam) * lam - c1;
-        if (!(fp < 0.0)) break;                    // past the first critical point: roots coincide to ~1e-5
+        if (!(fp < 0.0)) {
+            // Beyond the cubic's first critical point.  On the way up from the left that means the roots coincide to rounding;
+            // at the START it means the fp32 value itself was too high: with two clustered small roots (one scan line in a
+            // cell: rank-1 scatter) acos() is taken near 1 and the estimate is up to ~1e-4 off, more than the 1e-5 it is
+            // moved left by.  A scatter matrix has no root below zero: start again from just left of it (linear convergence
+            // towards a double root: 26 halvings of 1e-5 .. 1e-4).
+            if (it == 0 && !restarted) { restarted = true; lam = -1e-5; it = -1; continue; }
+            break;
+        }
         const double step = f / fp;
+        // Left of the smallest of three real roots a Newton step is 1 / Sum 1 / (root_i - x): it shrinks from one iteration to
+        // the next.  A step LARGER than the last one is rounding noise (f and f' both vanish at a double root: 3e-17 / 2e-12
+        // threw the iterate 1e-5 to the right of a double root at zero) and is not taken.
+        if (fabs(step) > prev) break;
+        prev = fabs(step);
         lam -= step;
         if (fabs(step) <= 1e-15) break;
     }
@@ -226,7 +242,9 @@ GNDT_HD void min_eigenpair_sym3(const double c[6], double& lambda, double v[3]) 
     double vx = x0, vy = y0, vz = z0, nn = n0;
     if (n1 > nn) { vx = x1; vy = y1; vz = z1; nn = n1; }
     if (n2 > nn) { vx = x2; vy = y2; vz = z2; nn = n2; }
-    if (nn > 1e-26) {
+    // (the cross products carry ~1e-16 of absolute rounding: below |cross| = 1e-8 the direction they give is worse than what the
+    //  rank-one fall-back gives — any vector orthogonal to the dominant row is then an eigenvector to ~1e-8)
+    if (nn > 1e-16) {
         const double k = 1.0 / sqrt(nn);
         v[0] = vx * k; v[1] = vy * k; v[2] = vz * k;
         return;

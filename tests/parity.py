@@ -204,6 +204,7 @@ def compare(gpu, ref, demand="slope", adversarial=False, dense=False, interval=0
         fl = ref["count"][sl].astype(np.float64) * (2.0 ** -23 * pm) ** 2      # same input-resolution floor as above
         if np.any(d > np.maximum(TOL_ROUGH * tr, fl)):
             fail(f"rough error {rep['rough_err']:.3e} > {TOL_ROUGH}")
+            rep["rough_worst_node"] = int(np.flatnonzero(sl)[int(np.argmax(d / np.maximum(TOL_ROUGH * tr, fl)))])
         if np.any(d[~okz] > 1e-9):
             fail("rough on zero-trace nodes")
         # the reference's own rule: rough is never exactly 0

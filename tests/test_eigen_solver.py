@@ -96,3 +96,22 @@ def test_matches_in_repo_jacobi():
     vv = np.zeros((S.shape[0], 9))
     he.shim().shim_jacobi(C.c_void_p(S.ctypes.data), C.c_uint64(S.shape[0]), C.c_void_p(ev.ctypes.data), C.c_void_p(vv.ctypes.data))
     assert np.abs(lam - ev.min(1)).max() <= 1e-9 * np.abs(ev).max()
+
+
+def test_oblique_lines_two_clustered_small_eigenvalues():
+    """Points of one scan line in a cell: rank-1 scatter in a general direction, the two small eigenvalues 1e-6 .. 1e-18 of the large
+    one.  The fp32 start value is then up to ~1e-4 off (acos near 1) and used to land beyond the cubic's first critical point, where
+    the Newton loop stopped at once and returned the start value (found by tools/fuzz_campaign.py: 3 nearly collinear points,
+    lambda_min 2e-6 instead of 0 at trace 0.13)."""
+    rng = np.random.default_rng(4)
+    for npts in (3, 5, 40):
+        for thick in (1e-3, 1e-5, 1e-7, 1e-9, 0.0):
+            p = rng.uniform(-0.25, 0.25, (6000, npts, 3))
+            p[:, :, 1:] *= thick
+            R = np.linalg.qr(rng.normal(size=(6000, 3, 3)))[0]
+            _check(_scatter(np.einsum("nij,nkj->nki", R, p)), f"oblique_line{npts}_{thick}")
+    # the campaign's node itself
+    S = np.array([[0.04515270355572436, 0.052456556703911396, -0.033486629652467556, 0.06094187334398763, -0.038903391133923534, 0.02483471148358755]])
+    S = S * (1 + 1e-16 * rng.standard_normal((5000, 6)))
+    lam, _ = _solve(S)
+    assert np.abs(lam).max() <= 2e-6 * 0.131, np.abs(lam).max()

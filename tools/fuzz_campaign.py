@@ -132,7 +132,14 @@ def run(seconds=600.0, seed=1, max_points=3_000_000, max_handles=0):
                 stats["worst_cov_err_truth"] = max(stats.get("worst_cov_err_truth", 0.0), rep.get("cov_err_truth", 0.0))
                 stats["nodes"] = stats.get("nodes", 0) + int(rep.get("num_nodes", 0))
                 if not rep["ok"]:
-                    stats["failures"].append(dict(desc, ran=ran, fail=rep["fail"][:5]))
+                    f = dict(desc, ran=ran, fail=rep["fail"][:5])
+                    if "rough_worst_node" in rep:
+                        i = rep["rough_worst_node"]
+                        f["node"] = dict(i=i, key=[int(ref[k][i]) for k in ("sx", "sy", "sz")], count=int(ref["count"][i]),
+                                         cov64=ref["cov64"][i].tolist(), cov_gpu=out["cov"][i].astype(float).tolist(), cov_ref32=ref["cov"][i].astype(float).tolist(),
+                                         evals64=ref["evals64"][i].tolist(), rough_gpu=float(out["rough"][i]), rough_ref=float(ref["rough"][i]),
+                                         mean64=ref["mean64"][i].tolist(), flags_gpu=int(out["flags"][i]), flags_ref=int(ref["flags"][i]))
+                    stats["failures"].append(f)
                     break
                 del dev, out, ref
         except Exception as e:            # an error code from the library is a failure of the campaign, too
