@@ -465,8 +465,8 @@ int partition_resolve(gndt_handle* h) {
         if (rc == GNDT_OK) continue;
         P.active = false;
         if (rc != -1 || P.stats_only) return rc;   // (a statistics-only run reports -1: its caller falls back)
-        if (P.records) { h->err = "the records do not fit the partition pipeline (too many nodes per bucket)"; return GNDT_ERR_CAPACITY; }
         // does not fit the LDS-resident pipeline (too many nodes per bucket): same result via the atomic path
+        if (P.records) { const gndt_handle::Pending rec = P; return build_atomic(h, nullptr, 0, 16, rec.s, false, &rec); }   // (a copy: the build resets h->pending)
         return build_atomic(h, P.xyz, P.n, P.stride, P.s);
     }
 }

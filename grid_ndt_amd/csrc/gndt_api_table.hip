@@ -79,13 +79,17 @@ int grow_table(gndt_handle* h, uint32_t new_cap, hipStream_t s);
 // `base_from_device`: first_idx base = the device-side stream position (incremental updates)
 // `defer_advance`: the device-side stream position is advanced by the finalisation that follows (k_emit_rows), not here
 int do_accumulate(gndt_handle* h, const void* xyz_dev, size_t n, size_t stride_bytes, uint64_t first_base,
-                  int base_from_device, hipStream_t s, int mark = 0, bool tile = false, bool defer_advance = false) {
+                  int base_from_device, hipStream_t s, int mark = 0, bool tile = false, bool defer_advance = false, bool records = false) {
     if (stride_bytes != 12 && stride_bytes != 16) { h->err = "stride_bytes must be 12 or 16"; return GNDT_ERR_INVALID; }
-    if (first_base + n >= 0xFFFFFFFFull) { h->err = "point index exceeds 32 bits"; return GNDT_ERR_INVALID; }
+    if (records && stride_bytes != 16) { h->err = "records are 16 bytes"; return GNDT_ERR_INVALID; }
+    if (!records && first_base + n >= 0xFFFFFFFFull) { h->err = "point index exceeds 32 bits"; return GNDT_ERR_INVALID; }
     if (n == 0) return GNDT_OK;
     const float* p = static_cast<const float*>(xyz_dev);
     const int blocks = grid_for(n, kBlock, 256 * 16);
-    if (tile) {
+    if (records) {       // {x, y, z, index word}: indices and weights as the records carry them (first_base is not used)
+        hipLaunchKernelGGL((k_accumulate<4, true>), dim3(blocks), dim3(kBlock), 0, s, p, (uint64_t)n, 0u, 0, grid_params(h), h->keys, h->acc,
+                           h->cap - 1, h->node_slot, h->index_of_slot, h->touch_epoch, h->touched, mark, h->d_cnt);
+    } else if (tile) {
         // strategy TILE: contiguous ranges, LDS-privatised partials (gndt_tile.hpp); two resident workgroups per CU
         const int wgs = (int)std::min<uint64_t>(512, (n + kTileCheck - 1) / kTileCheck);
         if (stride_bytes == 12)
@@ -248,11 +252,17 @@ int locality_sample(gndt_handle* h, const void* xyz_dev, size_t n, size_t stride
     return GNDT_OK;
 }
 
-int build_atomic(gndt_handle* h, const void* xyz_dev, size_t n, size_t stride_bytes, hipStream_t s, bool tile) {
+// `rec`: the input is the records of a pending owner-partitioned build (two segments, indices over [0, index_range)) that did
+// not fit the partition pipeline: the same map through the node table.  The table is only the means here: the handle ends as
+// after a PARTITION build (rows, order arrays; no additive state to update).
+int build_atomic(gndt_handle* h, const void* xyz_dev, size_t n, size_t stride_bytes, hipStream_t s, bool tile, const gndt_handle::Pending* rec) {
     int rc;
     h->last_strategy = tile ? GNDT_STRATEGY_TILE : GNDT_STRATEGY_ATOMIC;
     h->map_in_table = true;
-    uint64_t expect = h->P.max_nodes_hint ? h->P.max_nodes_hint : std::max<uint64_t>(1024, n / 4);
+    const uint64_t n_all = rec ? rec->n + rec->n2 : n;
+    const uint64_t reach = rec ? (rec->index_range ? rec->index_range : n_all) : n;      // the point indices run below this
+    if (reach >= 0xFFFFFFFFull) { h->err = "point index exceeds 32 bits"; return GNDT_ERR_INVALID; }
+    uint64_t expect = h->P.max_nodes_hint ? h->P.max_nodes_hint : std::max<uint64_t>(1024, n_all / 4);
     for (int attempt = 0; attempt < 8; ++attempt) {
         const uint32_t want = cap_for_nodes(expect);
         if (h->cap < want) { rc = alloc_table(h, want, s); if (rc) return rc; }
@@ -260,10 +270,15 @@ int build_atomic(gndt_handle* h, const void* xyz_dev, size_t n, size_t stride_by
         rc = do_reset(h, s);
         if (rc) return rc;
         mark(h, 1, s);
-        rc = do_accumulate(h, xyz_dev, n, stride_bytes, 0, 0, s, 0, tile);
+        if (rec) {
+            rc = do_accumulate(h, rec->xyz, rec->n, 16, 0, 0, s, 0, false, false, true);
+            if (!rc) rc = do_accumulate(h, rec->xyz2, rec->n2, 16, 0, 0, s, 0, false, false, true);
+        } else {
+            rc = do_accumulate(h, xyz_dev, n, stride_bytes, 0, 0, s, 0, tile);
+        }
         if (rc) return rc;
-        h->stream_pos = n;
-        rc = do_finalize(h, s, false, 0, 0, (uint32_t)n);        // (the device-side stream position is raised by its first kernel)
+        h->stream_pos = reach;
+        rc = do_finalize(h, s, false, 0, 0, (uint32_t)reach);    // (the device-side stream position is raised by its first kernel)
         if (rc) return rc;
         // A build being captured into a hipGraph cannot wait: it is recorded once, for the table the eager builds before it
         // settled on, and a replay whose cloud outgrows that table says so at gndt_sync (GNDT_ERR_CAPACITY), as a captured
@@ -276,6 +291,7 @@ int build_atomic(gndt_handle* h, const void* xyz_dev, size_t n, size_t stride_by
         if (!h->h_cnt->err_table_full && !h->part.h_pc->stage_overflow) {
             // what a later PARTITION build of a similar cloud should expect (a first build without a hint guesses n / 4)
             h->part.nodes_learned = (uint64_t)h->h_cnt->num_nodes + h->h_cnt->num_nodes / 5;
+            if (rec) { h->map_in_table = false; h->incr_ok = false; }
             return GNDT_OK;
         }
         // table (or staging) overflowed: the build starts from empty, so simply redo it in a larger table

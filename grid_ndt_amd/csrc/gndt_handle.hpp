@@ -308,7 +308,8 @@ void free_part(gndt_handle* h);
 void free_table(gndt_handle* h);
 int alloc_table(gndt_handle* h, uint32_t cap, hipStream_t s);
 int do_reset(gndt_handle* h, hipStream_t s);
-int build_atomic(gndt_handle* h, const void* xyz_dev, size_t n, size_t stride_bytes, hipStream_t s, bool tile = false);
+int build_atomic(gndt_handle* h, const void* xyz_dev, size_t n, size_t stride_bytes, hipStream_t s, bool tile = false,
+                 const gndt_handle::Pending* rec = nullptr);
 int locality_sample(gndt_handle* h, const void* xyz_dev, size_t n, size_t stride_bytes, uint32_t tiles, double* ratio, hipStream_t s);
 // ---- gndt_api_build.hip ----
 // tab_end: the table path's end-of-frame bookkeeping (k_tab_end + `advance` points of stream position) done by k_emit_rows

@@ -204,6 +204,14 @@ static __global__ void k_zero_counters(Counters* c) {
     if (threadIdx.x == 0 && blockIdx.x == 0) zero_counters(c);
 }
 
+// A record's index word.  Bit 31: the record stands for 64 identical consecutive points (one wave of the partition pass:
+// the (0,0,0) padding of the reference's own clouds); with bit 30 as well for 512 of them (all eight groups a
+// wave handles in a tile).  Weighted records keep the index of their FIRST point in the low 30 bits; clouds of 2^30 points
+// or more are simply not compressed.
+constexpr uint32_t kWeight64Flag = 0x80000000u, kWeight512Flag = 0x40000000u, kWeightIndexLimit = 0x40000000u;
+__host__ __device__ __forceinline__ uint32_t record_weight(uint32_t iw) { return (iw & kWeight64Flag) ? ((iw & kWeight512Flag) ? 512u : 64u) : 1u; }
+__host__ __device__ __forceinline__ uint32_t record_index(uint32_t iw) { return (iw & kWeight64Flag) ? (iw & (kWeightIndexLimit - 1u)) : iw; }
+
 // ---------------------------------------------------------------------------------------------
 // k_accumulate (strategy ATOMIC): one point per thread-iteration
 //   uniformDivision (src/receiver.cpp:41-93) + transMortonXYZ (include/map2D.h:950-976), with the
@@ -214,7 +222,9 @@ static __global__ void k_zero_counters(Counters* c) {
 // first_idx of point i = first_base + i, or cnt->stream_pos + i when `base_from_device` (incremental updates:
 // the base then lives on the device, so a captured graph can be replayed frame after frame).
 // ---------------------------------------------------------------------------------------------
-template <int STRIDE_FLOATS>
+// REC: the input is 16-B records {x, y, z, index word} (the owner-partitioned build of a sharded cloud, when the records do not
+// fit the partition pipeline): the point index and the weight come from the word.
+template <int STRIDE_FLOATS, bool REC = false>
 __global__ void __launch_bounds__(kBlock) k_accumulate(const float* __restrict__ xyz, uint64_t n, uint32_t first_base,
                                                        int base_from_device, GridParams P, uint64_t* __restrict__ keys,
                                                        NodeAcc* __restrict__ acc, uint32_t cap_mask,
@@ -230,11 +240,15 @@ __global__ void __launch_bounds__(kBlock) k_accumulate(const float* __restrict__
     const uint32_t base = base_from_device ? cnt->stream_pos : first_base;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_round; i += stride) {
         const bool live = i < n;
+        static_assert(!REC || STRIDE_FLOATS == 4, "records are 16 bytes");
         float px = 0.f, py = 0.f, pz = 0.f;
+        uint32_t word = 0u;
         if (live) {
             const float* p = xyz + i * STRIDE_FLOATS;
             px = p[0]; py = p[1]; pz = p[2];
+            if constexpr (REC) word = __float_as_uint(p[3]);
         }
+        const uint32_t wn = REC ? record_weight(word) : 1u;       // (64 or 512 identical points in one record: exact, powers of two)
         PointKey k = point_key(px, py, pz, P.ox, P.oy, P.oz, P.grid_len, P.z_len);
         bool ok = live && k.ok;
         if (live && !k.ok) atomicAdd(&cnt->err_key_range, 1u);
@@ -246,7 +260,11 @@ __global__ void __launch_bounds__(kBlock) k_accumulate(const float* __restrict__
             v[2] = (double)pz - axis_centre(k.sz, P.oz, P.z_len);
         }
         double q[9] = {v[0], v[1], v[2], v[0] * v[0], v[0] * v[1], v[0] * v[2], v[1] * v[1], v[1] * v[2], v[2] * v[2]};
-        uint32_t pidx = base + (uint32_t)i;
+        if constexpr (REC) {
+#pragma unroll
+            for (int j = 0; j < 9; ++j) q[j] *= (double)wn;
+        }
+        uint32_t pidx = REC ? record_index(word) : base + (uint32_t)i;
 
         // wave-uniform key?  (all 64 lanes live, ok and equal)
         const uint64_t key0 = ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(key >> 32)) << 32) |
@@ -258,8 +276,11 @@ __global__ void __launch_bounds__(kBlock) k_accumulate(const float* __restrict__
         if (uniform) {
 #pragma unroll
             for (int j = 0; j < 9; ++j) q[j] = wave_sum(q[j]);
-            uint32_t pmin = pidx;
-            for (int off = 32; off > 0; off >>= 1) pmin = min(pmin, (uint32_t)__shfl_down((int)pmin, off, 64));
+            uint32_t pmin = pidx, wsum = wn;
+            for (int off = 32; off > 0; off >>= 1) {
+                pmin = min(pmin, (uint32_t)__shfl_down((int)pmin, off, 64));
+                if constexpr (REC) wsum += (uint32_t)__shfl_down((int)wsum, off, 64);
+            }
             if ((threadIdx.x & 63) == 0) {
                 bool inserted;
                 uint32_t slot = find_or_insert(keys, cap_mask, key, inserted);
@@ -270,7 +291,7 @@ __global__ void __launch_bounds__(kBlock) k_accumulate(const float* __restrict__
                     NodeAcc* a = acc + slot;
 #pragma unroll
                     for (int j = 0; j < 9; ++j) unsafeAtomicAdd(&a->s[j], q[j]);
-                    atomicAdd(&a->count, 64u);
+                    atomicAdd(&a->count, REC ? wsum : 64u);
                     atomicMin(&a->first, pmin);
                 }
             }
@@ -303,7 +324,9 @@ __global__ void __launch_bounds__(kBlock) k_accumulate(const float* __restrict__
             const bool head = lane == 0 || plo != klo || phi != khi;
             const unsigned long long hm = __ballot(head);
             const uint32_t rid = (uint32_t)__popcll(hm & (~0ull >> (63 - lane)));          // runs that start at or before this lane
-            uint32_t run_n = ok ? 1u : 0u, pmin = pidx;
+            uint32_t wn_s = wn;
+            if constexpr (REC) wn_s = (uint32_t)__shfl((int)wn, (int)src, 64);
+            uint32_t run_n = ok ? wn_s : 0u, pmin = pidx;
 #pragma unroll
             for (int off = 1; off < 64; off <<= 1) {
                 const uint32_t rid_o = (uint32_t)__shfl_down((int)rid, off, 64);      // (every lane takes part: a shuffle reads nothing from a lane that sits it out)

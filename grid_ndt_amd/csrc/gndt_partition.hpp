@@ -154,13 +154,7 @@ __device__ __forceinline__ void column_of_point(float px, float py, const GridPa
     sy = axis_from_ceil(cy, py, P.oy, ok, kMaxXY);
 }
 
-// A record's index word.  Bit 31: the record stands for 64 identical consecutive points (one wave of the partition pass:
-// the (0,0,0) padding of the reference's own clouds); with bit 30 as well for 512 of them (all eight groups a
-// wave handles in a tile).  Weighted records keep the index of their FIRST point in the low 30 bits; clouds of 2^30 points
-// or more are simply not compressed.
-constexpr uint32_t kWeight64Flag = 0x80000000u, kWeight512Flag = 0x40000000u, kWeightIndexLimit = 0x40000000u;
-__host__ __device__ __forceinline__ uint32_t record_weight(uint32_t iw) { return (iw & kWeight64Flag) ? ((iw & kWeight512Flag) ? 512u : 64u) : 1u; }
-__host__ __device__ __forceinline__ uint32_t record_index(uint32_t iw) { return (iw & kWeight64Flag) ? (iw & (kWeightIndexLimit - 1u)) : iw; }
+// (a record's index word — weight flags, record_weight, record_index —: gndt_kernels.hpp, next to k_accumulate, which reads records too)
 
 // true (wave-uniformly) iff all 64 lanes are `use` and hold bit-identical coordinates
 __device__ __forceinline__ bool wave_all_identical(float px, float py, float pz, bool use) {

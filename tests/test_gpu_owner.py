@@ -311,6 +311,8 @@ def owner_build_with_threads(cloud, P, W, bounds=None):
                 res[r] = (maps[r].export(), grow.cpu().numpy().astype(np.int64), info)
         except Exception as e:                         # (a rank that dies leaves the others at a barrier: report, do not hang the suite)
             errs.append((r, repr(e)))
+            import sys
+            print(f"owner_build_with_threads: rank {r} of {W} failed: {e!r} (bounds {bounds})", file=sys.stderr, flush=True)
             os._exit(3)
 
     import os
@@ -385,6 +387,27 @@ def test_the_owner_build_itself_repeats_the_column_round_when_a_rank_re_runs_its
 # ---------------------------------------------------------------------------------------------------------------------
 # the assembled map (gndt_gather_owned_map_device): the consumers get ONE map
 # ---------------------------------------------------------------------------------------------------------------------
+def test_the_owner_build_of_a_cloud_whose_records_do_not_fit_the_partition_pipeline():
+    """One column with ~4000 z levels: every node of it belongs to ONE bucket, more than any LDS table holds.  A single-GPU build
+    then takes the node table in HBM; the owner's build from records used to give up with GNDT_ERR_CAPACITY (found by
+    tools/fuzz_owner.py) and now does the same: k_accumulate reads the records (index words and weights as they are)."""
+    rng = np.random.default_rng(21)
+    n = 300_000
+    xyz = np.stack([0.3 + 0.1 * rng.random(n), -0.7 + 0.1 * rng.random(n), rng.random(n) * 400.0 - 200.0], 1).astype(np.float32)
+    xyz[1000:1000 + 640] = xyz[1000]                      # ten waves of identical points: weighted records through the fallback
+    ground = np.stack([rng.random(n) * 40 - 20, rng.random(n) * 40 - 20, 0.02 * rng.normal(size=n)], 1).astype(np.float32)
+    cloud = np.concatenate([xyz[:1], xyz, ground], 0)
+    P = dict(grid_len=0.5, z_len=0.1, slope_interval=0.08, demand="slope")
+    _, one = parity.gpu_from_cloud(cloud, P, on_device=True)
+    ref = parity.ref_from_cloud(cloud, P)
+    for W in (1, 3):
+        glob, infos = owner_build_with_threads(cloud, P, W)
+        rep = parity.compare(glob, ref, dense=True)            # (the pole's nodes: 30 points each at |z| up to 200 m — the fp32 oracle's own
+        assert rep["ok"], rep["fail"]                           #  scatter is 1e-3 off there: held to the fp64 truth, labels to the margin)
+        for k in ("sx", "sy", "sz", "count", "first_idx", "flags"):
+            assert np.array_equal(glob[k], one[k]), (W, k)
+
+
 def _threads(W, body):
     """Run body(r) on W threads (one per thread-group rank); returns the list of results, re-raises the first failure."""
     import threading
