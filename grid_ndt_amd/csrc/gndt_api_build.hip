@@ -319,7 +319,7 @@ int partition_launch(gndt_handle* h, gndt_handle::Pending& P) {
         if (q.dbg) (void)hipFree(q.dbg);
         q.dbg = nullptr; q.dbg_buckets = 0;
         HIP_TRY(h, hipMalloc(&q.dbg, (size_t)B * 16 * sizeof(unsigned long long)));
-        HIP_TRY(h, hipMemset(q.dbg, 0, (size_t)B * 16 * sizeof(unsigned long long)));
+        { const int zrc = zero_device_now(h, q.dbg, (size_t)B * 16 * sizeof(unsigned long long)); if (zrc) return zrc; }
         q.dbg_buckets = B;
     }
     q.last_buckets = B;

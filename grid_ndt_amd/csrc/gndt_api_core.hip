@@ -131,12 +131,23 @@ int ensure_words(gndt_handle* h, uint64_t words) {
     return GNDT_OK;
 }
 
+// Zero a fresh allocation and WAIT for it.  hipMemset() is not that: it fills on the null stream, which is not ordered with the
+// non-blocking streams the builds run on, and it returns before the fill has run when the GPU is busy — the zeros then land
+// seconds of GPU work later, e.g. on the overflow flags a first build has just raised (round 3: a shard built by one of six
+// host threads on a shared GPU lost its "region overflow" flag in 3 % of the runs and with it the points that did not fit;
+// tools/fuzz_owner.py).  Filled on the handle's own stream and awaited, nothing can follow it.
+int zero_device_now(gndt_handle* h, void* p, size_t bytes) {
+    HIP_TRY(h, hipMemsetAsync(p, 0, bytes, h->own_stream));
+    HIP_TRY(h, hipStreamSynchronize(h->own_stream));
+    return GNDT_OK;
+}
+
 int ensure_part_counters(gndt_handle* h) {
     auto& q = h->part;
     if (q.d_pc) return GNDT_OK;
     HIP_TRY(h, hipMalloc(&q.d_pc, sizeof(PartCounters)));
     HIP_TRY(h, hipHostMalloc(&q.h_pc, sizeof(PartCounters)));
-    HIP_TRY(h, hipMemset(q.d_pc, 0, sizeof(PartCounters)));
+    { const int rc = zero_device_now(h, q.d_pc, sizeof(PartCounters)); if (rc) return rc; }
     memset(q.h_pc, 0, sizeof(PartCounters));
     return GNDT_OK;
 }
@@ -203,7 +214,8 @@ int gndt_create(const gndt_params* params, gndt_handle** out) {
     if ((e = hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking)) != hipSuccess) return fail("hipStreamCreate", e);
     if ((e = hipMalloc(&h->d_cnt, sizeof(Counters))) != hipSuccess) return fail("hipMalloc", e);
     if ((e = hipHostMalloc(&h->h_cnt, sizeof(Counters))) != hipSuccess) return fail("hipHostMalloc", e);
-    if ((e = hipMemset(h->d_cnt, 0, sizeof(Counters))) != hipSuccess) return fail("hipMemset", e);
+    if ((e = hipMemsetAsync(h->d_cnt, 0, sizeof(Counters), h->own_stream)) != hipSuccess) return fail("hipMemsetAsync", e);   // (not hipMemset: zero_device_now)
+    if ((e = hipStreamSynchronize(h->own_stream)) != hipSuccess) return fail("hipStreamSynchronize", e);
     memset(h->h_cnt, 0, sizeof(Counters));
     h->last_stream = h->own_stream;
     if (params->max_nodes_hint) {
@@ -235,7 +247,7 @@ void gndt_destroy(gndt_handle* h) {
     if (h->h_cnt) (void)hipHostFree(h->h_cnt);
     {
         auto& X = h->exch;
-        void* xp[] = {X.d_counts, X.keys_in, X.keys_all, X.keys_sorted, X.canon, X.d_unique, X.d_missing, X.scratch, X.packed, X.pfirst, X.r_sums, X.r_count,
+        void* xp[] = {X.d_counts, X.keys_in, X.keys_all, X.keys_sorted, X.canon, X.d_unique, X.d_missing, X.scratch, X.packed, X.pfirst, X.r_sums, X.r_count, X.red_tmp,
                       X.send_recs, X.own_recs, X.d_matrix, X.d_split_cnt, X.pairs, X.pairs_all, X.d_npairs, X.global_row, X.d_totals,
                       X.owner_msg, X.owner_msgs_all, X.bkey, X.bcnt, X.bown, X.d_owner_full, X.d_colmsg, X.gw, X.grec, X.grec_all, X.d_tally, X.d_status, X.row_of_pair, X.place_all, X.place_mine, X.d_slice};
         for (void* p : xp) if (p) (void)hipFree(p);

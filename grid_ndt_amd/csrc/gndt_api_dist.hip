@@ -153,6 +153,38 @@ int comm_reduce_scatter_u32(gndt_handle* h, gndt_comm* c, const uint32_t* send, 
     if (rc == GNDT_OK && !peers_ok) { h->err = "another rank failed on its way into a collective"; rc = GNDT_ERR_PEER; }
     return rc;
 }
+// in-place all-reduce of `count` doubles (sum; the ranks add in rank order: every rank gets the same bits) or u32 (min)
+int comm_all_reduce(gndt_handle* h, gndt_comm* c, void* buf, size_t count, bool f64_sum, hipStream_t s) {
+    if (!c->threads) {
+        if (f64_sum) RCCL_TRY(h, rccl().AllReduce(buf, buf, count, ncclDouble, ncclSum, c->nccl, s));
+        else RCCL_TRY(h, rccl().AllReduce(buf, buf, count, ncclUint32, ncclMin, c->nccl, s));
+        return GNDT_OK;
+    }
+    ThreadGroup& G = *c->threads;
+    auto& X = h->exch;
+    const int W = c->world, me = c->rank;
+    const size_t bytes = count * (f64_sum ? 8 : 4);
+    int rc = grow_buf(h, X.red_tmp, X.red_tmp_cap, (uint64_t)(bytes + 7) / 8 + 1);      // (before the first barrier: nobody waits yet)
+    if (rc == GNDT_OK && hipStreamSynchronize(s) != hipSuccess) { h->err = "hipStreamSynchronize failed before a collective"; rc = GNDT_ERR_HIP; }
+    G.send[me] = buf; G.ok[me] = rc == GNDT_OK;
+    G.barrier();
+    bool peers_ok = true;
+    for (int q = 0; q < W; ++q) peers_ok = peers_ok && G.ok[q];
+    const bool go = rc == GNDT_OK && peers_ok && count;
+    if (go) {
+        for (int q = 0; q < W && rc == GNDT_OK; ++q) {
+            if (q == 0) { if (hipMemcpyAsync(X.red_tmp, G.send[0], bytes, hipMemcpyDeviceToDevice, s) != hipSuccess) rc = GNDT_ERR_HIP; }
+            else if (f64_sum) hipLaunchKernelGGL(k_add_f64, dim3(grid_for(count)), dim3(256), 0, s, X.red_tmp, static_cast<const double*>(G.send[q]), (uint64_t)count);
+            else hipLaunchKernelGGL(k_min_u32, dim3(grid_for(count)), dim3(256), 0, s, reinterpret_cast<uint32_t*>(X.red_tmp), static_cast<const uint32_t*>(G.send[q]), (uint64_t)count);
+        }
+        if (hipStreamSynchronize(s) != hipSuccess && rc == GNDT_OK) rc = GNDT_ERR_HIP;
+        if (rc) h->err = "a device copy failed inside a collective";
+    }
+    G.barrier();                                               // everybody has read everybody's contribution: the result may go in place
+    if (go && rc == GNDT_OK && hipMemcpyAsync(buf, X.red_tmp, bytes, hipMemcpyDeviceToDevice, s) != hipSuccess) { h->err = "hipMemcpyAsync failed after a collective"; rc = GNDT_ERR_HIP; }
+    if (rc == GNDT_OK && !peers_ok) { h->err = "another rank failed on its way into a collective"; rc = GNDT_ERR_PEER; }
+    return rc;
+}
 }  // namespace
 
 extern "C" {
@@ -300,7 +332,7 @@ int gndt_build_global_device(gndt_handle* h, gndt_comm* c, const void* shard_xyz
                              uint64_t first_idx_base, uint64_t total_points, gndt_exchange_times* times, void* hip_stream) {
     int rc = check_ready(h);
     if (rc) return rc;
-    if (!c || !c->nccl) { h->err = c && c->threads ? "gndt_build_global_device needs an RCCL communicator" : "no communicator"; return GNDT_ERR_INVALID; }
+    if (!c || (!c->nccl && !c->threads)) { h->err = "no communicator"; return GNDT_ERR_INVALID; }
     hipStream_t s = stream_of(h, hip_stream);
     auto& X = h->exch;
     hipEvent_t* ev = X.ev;                     // (kept on the handle: an early error return leaks nothing)
@@ -322,7 +354,7 @@ int gndt_build_global_device(gndt_handle* h, gndt_comm* c, const void* shard_xyz
     if (!X.h_counts) HIP_TRY(h, hipHostMalloc(&X.h_counts, 1024 * sizeof(unsigned long long)));
     X.h_counts[c->rank] = (unsigned long long)m | ((unsigned long long)(shard_rc & 0xFF) << 56);
     HIP_TRY(h, hipMemcpyAsync(X.d_counts + c->rank, X.h_counts + c->rank, sizeof(unsigned long long), hipMemcpyHostToDevice, s));
-    RCCL_TRY(h, rccl().AllGather(X.d_counts + c->rank, X.d_counts, 1, ncclUint64, c->nccl, s));
+    if ((rc = comm_all_gather(h, c, X.d_counts + c->rank, X.d_counts, 1, 8, s))) return rc;
     HIP_TRY(h, hipMemcpyAsync(X.h_counts, X.d_counts, (size_t)W * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
     HIP_TRY(h, hipStreamSynchronize(s));
     for (int r = 0; r < W; ++r) {
@@ -344,7 +376,7 @@ int gndt_build_global_device(gndt_handle* h, gndt_comm* c, const void* shard_xyz
     if (!X.d_unique) HIP_TRY(h, hipMalloc(&X.d_unique, sizeof(unsigned int)));
     if (m) HIP_TRY(h, hipMemcpyAsync(X.keys_in, st.key, (size_t)m * 8, hipMemcpyDeviceToDevice, s));
     hipLaunchKernelGGL(k_exchange_pad, dim3(grid_for(m_max)), dim3(256), 0, s, X.keys_in, m, (uint32_t)m_max);
-    RCCL_TRY(h, rccl().AllGather(X.keys_in, X.keys_all, m_max, ncclUint64, c->nccl, s));
+    if ((rc = comm_all_gather(h, c, X.keys_in, X.keys_all, (size_t)m_max, 8, s))) return rc;
     size_t tmp = 0, tmp2 = 0;
     HIP_TRY(h, rocprim::radix_sort_keys(nullptr, tmp, X.keys_all, X.keys_sorted, (size_t)all, 0, 64, s));
     HIP_TRY(h, rocprim::unique(nullptr, tmp2, X.keys_sorted, X.canon, X.d_unique, (size_t)all, rocprim::equal_to<uint64_t>(), s));
@@ -373,8 +405,8 @@ int gndt_build_global_device(gndt_handle* h, gndt_comm* c, const void* shard_xyz
                                   (const uint32_t*)st.count, (const uint32_t*)st.first_idx, m, (const uint64_t*)X.canon, C, X.packed,
                                   X.pfirst, X.d_missing);
         HIP_TRY(h, hipGetLastError());
-        RCCL_TRY(h, rccl().AllReduce(X.packed, X.packed, (size_t)C * kExWidth, ncclDouble, ncclSum, c->nccl, s));
-        RCCL_TRY(h, rccl().AllReduce(X.pfirst, X.pfirst, (size_t)C, ncclUint32, ncclMin, c->nccl, s));
+        if ((rc = comm_all_reduce(h, c, X.packed, (size_t)C * kExWidth, true, s))) return rc;
+        if ((rc = comm_all_reduce(h, c, X.pfirst, (size_t)C, false, s))) return rc;
         hipLaunchKernelGGL(k_exchange_unpack, dim3(grid_for(C)), dim3(256), 0, s, (const double*)X.packed, C, X.r_sums, X.r_count);
         HIP_TRY(h, hipGetLastError());
     }

@@ -372,6 +372,12 @@ static __global__ void __launch_bounds__(256) k_global_rows_sliced(const unsigne
         for (uint32_t i = 0; i < nc; ++i) global_row[r + i] = row + i;
     }
 }
+static __global__ void __launch_bounds__(256) k_add_f64(double* __restrict__ dst, const double* __restrict__ src, uint64_t n) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) dst[i] += src[i];
+}
+static __global__ void __launch_bounds__(256) k_min_u32(uint32_t* __restrict__ dst, const uint32_t* __restrict__ src, uint64_t n) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) dst[i] = min(dst[i], src[i]);
+}
 static __global__ void __launch_bounds__(256) k_add_u32(uint32_t* __restrict__ dst, const uint32_t* __restrict__ src, uint64_t n) {
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) dst[i] += src[i];
 }

@@ -132,6 +132,7 @@ struct gndt_handle {
         char* scratch = nullptr; uint64_t scratch_cap = 0;
         double* packed = nullptr; uint64_t packed_cap = 0;  uint32_t* pfirst = nullptr; uint64_t pfirst_cap = 0;
         double* r_sums = nullptr; uint64_t r_sums_cap = 0;  uint32_t* r_count = nullptr; uint64_t r_count_cap = 0;
+        double* red_tmp = nullptr; uint64_t red_tmp_cap = 0;      // thread ranks: where an in-place all-reduce is summed up
         // owner-partitioned build (gndt_build_owned_device): records grouped by owner, the records this rank owns, its
         // columns as (first-seen index, node count) pairs, everybody's pairs, the global row of every local row
         float4* send_recs = nullptr; uint64_t send_cap = 0;  float4* own_recs = nullptr; uint64_t own_cap = 0;
@@ -308,6 +309,7 @@ void free_part(gndt_handle* h);
 void free_table(gndt_handle* h);
 int alloc_table(gndt_handle* h, uint32_t cap, hipStream_t s);
 int do_reset(gndt_handle* h, hipStream_t s);
+int zero_device_now(gndt_handle* h, void* p, size_t bytes);
 int build_atomic(gndt_handle* h, const void* xyz_dev, size_t n, size_t stride_bytes, hipStream_t s, bool tile = false,
                  const gndt_handle::Pending* rec = nullptr);
 int locality_sample(gndt_handle* h, const void* xyz_dev, size_t n, size_t stride_bytes, uint32_t tiles, double* ratio, hipStream_t s);
