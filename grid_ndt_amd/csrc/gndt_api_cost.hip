@@ -37,7 +37,10 @@ int gndt_compute_cost(gndt_handle* h, const float goal_xyz[3], const gndt_robot*
     if (!c.d_cc) {
         HIP_TRY(h, hipMalloc(&c.d_cc, sizeof(CostCounters)));
         HIP_TRY(h, hipHostMalloc(&c.h_cc, sizeof(CostCounters)));
-        HIP_TRY(h, hipMalloc(&c.ring, (size_t)kCostBlocks * kCostThreads * kRingCap * sizeof(uint32_t)));
+    }
+    if (!c.ring) {
+        HIP_TRY(h, hipMalloc(&c.ring, (size_t)kCostBlocks * (kCostThreads / 4) * kRingCap * sizeof(uint32_t)));    // (one checker per quad of lanes)
+        c.ring_cap = kRingCap;
     }
     if (n > c.node_cap) {
         for (uint32_t** a : {&c.h_bits, &c.pushed, &c.state, &c.f[0], &c.f[1], &c.nbr}) { if (*a) (void)hipFree(*a); *a = nullptr; }
@@ -69,6 +72,8 @@ int gndt_compute_cost(gndt_handle* h, const float goal_xyz[3], const gndt_robot*
     // the goal's key through the same codec the build uses (transMortonXYZ, map2D.h:1293)
     const PointKey gk = point_key(goal_xyz[0], goal_xyz[1], goal_xyz[2], h->origin[0], h->origin[1], h->origin[2],
                                   h->P.grid_len, h->P.z_len);
+  for (;;) {                  // (again with a larger ring scratch if a collision ring did not fit)
+    V.nbr = nullptr;
     hipLaunchKernelGGL(k_cost_clear, dim3(grid_for(std::max<uint64_t>(n, c.ctab_size))), dim3(256), 0, s, c.h_bits, c.pushed,
                        c.state, (uint32_t)n, c.ctab_key, c.ctab_size, c.d_cc);
     if (K)
@@ -87,7 +92,7 @@ int gndt_compute_cost(gndt_handle* h, const float goal_xyz[3], const gndt_robot*
     for (;;) {
         for (int b = 0; b < kCostBatch; ++b, ++level)
             hipLaunchKernelGGL(k_cost_level, dim3(kCostBlocks), dim3(kCostThreads), 0, s, V, R, c.ring_n, level, c.h_bits,
-                               c.pushed, c.state, c.f[level & 1u], c.f[(level + 1u) & 1u], c.ring, c.d_cc);
+                               c.pushed, c.state, c.f[level & 1u], c.f[(level + 1u) & 1u], c.ring, c.ring_cap, c.d_cc);
         HIP_TRY(h, hipGetLastError());
         HIP_TRY(h, hipMemcpyAsync(c.h_cc, c.d_cc, sizeof(CostCounters), hipMemcpyDeviceToHost, s));
         HIP_TRY(h, hipStreamSynchronize(s));
@@ -99,9 +104,21 @@ int gndt_compute_cost(gndt_handle* h, const float goal_xyz[3], const gndt_robot*
         return GNDT_ERR_KEY_RANGE;
     }
     if (c.h_cc->ring_overflow) {
-        h->err = "cost map: a collision ring holds more than " + std::to_string(kRingCap) + " slopes (robot radius too large for this grid)";
-        return GNDT_ERR_CAPACITY;
+        // CollisionCheck's ring is a std::list in the reference (map2D.h:351-411): any size.  Here it is scratch of a fixed size per
+        // checker, grown fourfold and the flood run again when a ring did not fit (the check is quadratic in the ring: large robots on
+        // fine grids are slow in the reference, too).
+        if (c.ring_cap >= kRingCapMax) {
+            h->err = "cost map: a collision ring holds more than " + std::to_string(kRingCapMax) + " slopes (robot radius too large for this grid)";
+            return GNDT_ERR_CAPACITY;
+        }
+        (void)hipFree(c.ring);
+        c.ring = nullptr;
+        c.ring_cap = std::min(c.ring_cap * 4, kRingCapMax);
+        HIP_TRY(h, hipMalloc(&c.ring, (size_t)kCostBlocks * (kCostThreads / 4) * (size_t)c.ring_cap * sizeof(uint32_t)));
+        continue;
     }
+    break;
+  }
     c.serial = h->result_serial;
     return GNDT_OK;
 }

@@ -41,7 +41,8 @@ struct Robot {   // include/robot.h:12, 38-46
 
 constexpr int kCostMaxXY = 32767;        // mortonToXY decodes only up to here (Stopwatch.h:171-189)
 constexpr uint32_t kNoColumn = 0xFFFFFFFFu;
-constexpr int kRingCap = 256;            // slopes a collision ring may hold (per thread scratch)
+constexpr int kRingCap = 256;            // slopes a collision ring may hold at first (per checker scratch); the host doubles it when a
+constexpr int kRingCapMax = 1 << 15;     //   ring does not fit (a 1.3 m robot on 0.1 m cells: 27 x 27 columns) up to this
 
 struct CostView {
     // result rows in reference order (gndt_cells)
@@ -147,9 +148,9 @@ GNDT_HD void neighbour_columns(const CostView& V, uint32_t row, uint32_t col[4])
     col[3] = ctab_find(V, step_skip0(sx, -1), sy);
 }
 
-// CollisionCheck (map2D.h:351-411) and CollisionCheck3D (:414-474).  `ring` is scratch for kRingCap rows.
+// CollisionCheck (map2D.h:351-411) and CollisionCheck3D (:414-474).  `ring` is scratch for `ring_cap` rows.
 // Returns 1 = collide, 0 = free, -1 = the ring did not fit the scratch.
-GNDT_HD int cost_collide(const CostView& V, const Robot& R, uint32_t slope, int ring_n, uint32_t* ring) {
+GNDT_HD int cost_collide(const CostView& V, const Robot& R, uint32_t slope, int ring_n, uint32_t* ring, int ring_cap = kRingCap) {
     GNDT_FP_STRICT
     if (row_up(V, slope)) return 1;
     const float mz = V.mean[3 * slope + 2];
@@ -170,7 +171,7 @@ GNDT_HD int cost_collide(const CostView& V, const Robot& R, uint32_t slope, int 
                     bool seen = false;
                     for (int j = 0; j < n_all; ++j) seen = seen || (ring[j] == t);
                     if (seen) continue;
-                    if (n_all >= kRingCap) return -1;
+                    if (n_all >= ring_cap) return -1;
                     ring[n_all++] = t;
                 }
             }
@@ -332,7 +333,7 @@ static __global__ void k_cost_goal(CostView V, int gx, int gy, int gz, uint32_t*
 static __global__ void __launch_bounds__(64) k_cost_level(CostView V, Robot R, int ring_n, uint32_t level, uint32_t* __restrict__ h_bits,
                                                    uint32_t* __restrict__ pushed, uint32_t* __restrict__ state,
                                                    const uint32_t* __restrict__ f_in, uint32_t* __restrict__ f_out,
-                                                   uint32_t* __restrict__ ring_scratch, CostCounters* __restrict__ cc) {
+                                                   uint32_t* __restrict__ ring_scratch, int ring_cap, CostCounters* __restrict__ cc) {
     const uint32_t n_in = cc->frontier[level % 3u];
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         cc->frontier[(level + 2u) % 3u] = 0u;          // the counter two layers ahead (was the previous layer's input)
@@ -353,7 +354,7 @@ static __global__ void __launch_bounds__(64) k_cost_level(CostView V, Robot R, i
         const bool live = i < n_in;
         const uint32_t q = live ? f_in[i] : 0u;
         int hit = 0;
-        if (live && dir == 0u) hit = cost_collide(V, R, q, ring_n, ring_scratch + (size_t)quad * kRingCap);
+        if (live && dir == 0u) hit = cost_collide(V, R, q, ring_n, ring_scratch + (size_t)quad * (size_t)ring_cap, ring_cap);
         hit = __shfl(hit, leader, 64);
         constexpr uint32_t kKeep = 4;                  // pushes a lane keeps for the wave's append (more go out one by one)
         uint32_t mine[kKeep] = {0u, 0u, 0u, 0u}, np = 0;

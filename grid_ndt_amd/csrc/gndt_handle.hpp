@@ -116,7 +116,7 @@ struct gndt_handle {
     struct Cost {
         uint64_t node_cap = 0;     uint32_t *h_bits = nullptr, *pushed = nullptr, *state = nullptr, *f[2] = {nullptr, nullptr};
         uint32_t ctab_size = 0;    uint64_t* ctab_key = nullptr; uint32_t* ctab_val = nullptr;
-        uint32_t* ring = nullptr;
+        uint32_t* ring = nullptr; int ring_cap = 0;
         uint32_t* nbr = nullptr;       // [4 * node_cap] neighbour columns of every row
         CostCounters* d_cc = nullptr;
         CostCounters* h_cc = nullptr;   // pinned

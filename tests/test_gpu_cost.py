@@ -86,3 +86,17 @@ def test_cost_map_on_a_large_terrain():
     g0 = cells["mean"][np.nonzero(got["h"] == 0)[0][0]].astype(np.float64)
     d = np.sqrt(((cells["mean"].astype(np.float64) - g0) ** 2).sum(1))
     assert (got["h"][reached] >= d[reached] * (1 - 1e-5)).all()
+
+
+def test_cost_map_with_collision_rings_beyond_the_first_scratch():
+    """A 1.3 m robot on 0.1 m cells: CollisionCheck's ring covers 27 x 27 columns, thousands of slopes — a std::list in the
+    reference (map2D.h:351-411), here a scratch of 256 rows per checker that is grown and the flood run again when a ring does
+    not fit (it used to end with GNDT_ERR_CAPACITY; found by tools/fuzz_cost.py).  Same flood as the oracle's, bit for bit."""
+    cloud = scenes.drivable_site(600_000, half=6.0)                # ~40 points per 0.1 m cell
+    P = dict(scenes.COST_PARAMS, grid_len=0.1, z_len=0.05)
+    m = _build(cloud, P, "slope", 0)
+    st, got = _check(m, cloud, P, scenes.DRIVABLE_GOAL, "slope", {"radius": 1.3})
+    print("flood", st)
+    assert st["rc"] == 0 and st["traversable"] + st["closed"] > 100
+    st, got = _check(m, cloud, P, scenes.DRIVABLE_GOAL, "slope", {"radius": 0.25})      # (the larger scratch stays: smaller rings fit)
+    assert st["rc"] == 0

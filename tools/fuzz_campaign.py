@@ -149,13 +149,47 @@ def run(seconds=600.0, seed=1, max_points=3_000_000, max_handles=0):
     return stats
 
 
+def run_threads(seconds, seed, max_points, threads):
+    """`threads` campaigns at once, each on its own torch stream with its own handles and random sequence: the GPU is shared, so
+    anything that is not ordered on the handle's stream (a null-stream fill, a buffer freed under a kernel) gets its chance."""
+    import threading
+    import torch
+    res = [None] * threads
+
+    def body(k):
+        torch.cuda.set_device(0)
+        with torch.cuda.stream(torch.cuda.Stream()):
+            res[k] = run(seconds, seed * 1000 + k, max_points)
+
+    th = [threading.Thread(target=body, args=(k,)) for k in range(threads)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    total = {"threads": threads, "failures": []}
+    for r in res:
+        for key, v in (r or {"failures": [{"error": "a campaign thread died"}]}).items():
+            if key == "failures":
+                total["failures"] += v
+            elif isinstance(v, dict):
+                d = total.setdefault(key, {})
+                for kk, vv in v.items():
+                    d[kk] = d.get(kk, 0) + vv
+            elif key.startswith("worst") or key == "seconds":
+                total[key] = max(total.get(key, 0), v)
+            else:
+                total[key] = total.get(key, 0) + v
+    return total
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=600.0)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--max-points", type=int, default=3_000_000)
+    ap.add_argument("--threads", type=int, default=1, help="independent campaigns at once, sharing the GPU")
     a = ap.parse_args()
-    stats = run(a.seconds, a.seed, a.max_points)
+    stats = run_threads(a.seconds, a.seed, a.max_points, a.threads) if a.threads > 1 else run(a.seconds, a.seed, a.max_points)
     print(json.dumps(stats, indent=1))
     sys.exit(1 if stats["failures"] else 0)
 
