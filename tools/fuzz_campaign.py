@@ -95,20 +95,32 @@ def run(seconds=600.0, seed=1, max_points=3_000_000, max_handles=0):
         cells = CELLS[int(rng.integers(0, len(CELLS)))]
         strategy = int(rng.choice([0, 0, 1, 2, 2, 3, 4, 5]))
         demand = "true" if rng.random() < 0.15 else "slope"
-        P = dict(grid_len=cells[0], z_len=cells[1], slope_interval=0.08, demand=demand)
+        interval = float(rng.choice([0.08, 0.08, 0.05, 0.2]))
+        min_points = int(rng.choice([3, 3, 1, 2, 5]))
+        P = dict(grid_len=cells[0], z_len=cells[1], slope_interval=interval, demand=demand, min_points=min_points)
         hint_kind = int(rng.integers(0, 3))          # none / far too low / generous
         hint = [0, 500, 4_000_000][hint_kind]
-        m = g.TwoDmap(cells[0], cells[1], max_nodes_hint=hint, strategy=strategy)
-        m.setInterval(0.08)
+        m = g.TwoDmap(cells[0], cells[1], max_nodes_hint=hint, strategy=strategy, min_points=min_points)
+        m.setInterval(interval)
         stats["handles"] += 1
         desc = None
         try:
             for step in range(int(rng.integers(2, 6))):
                 n = int(np.exp(rng.uniform(np.log(200), np.log(a.max_points))))
                 cloud, adv = make_cloud(rng, n, cells)
-                desc = dict(trial=trial, step=step, seed=a.seed, cells=cells, strategy=strategy, hint=hint, demand=demand, points=int(cloud.shape[0] - 1))
-                dev = torch.from_numpy(np.ascontiguousarray(cloud[1:])).cuda()
-                streamed = strategy == 1 and hint != 500 and rng.random() < 0.4 and cloud.shape[0] > 10     # (a stream does not outgrow a hint: documented)
+                if rng.random() < 0.15:              # a few points far out, up to ~60 000 cells from the origin (the key range ends at 65 535)
+                    k = int(rng.integers(1, 50))
+                    far = cloud[0] + (rng.random((k, 3)) * 2 - 1) * np.float32([60000 * cells[0], 60000 * cells[0], 3000 * cells[1]])
+                    at = rng.integers(1, cloud.shape[0], k)
+                    cloud[at] = far.astype(np.float32)
+                layout = int(rng.integers(0, 4))     # device [n,3] / device PointXYZ records [n,4] / host [n,3] / host [n,4]
+                desc = dict(trial=trial, step=step, seed=a.seed, cells=cells, strategy=strategy, hint=hint, demand=demand, points=int(cloud.shape[0] - 1),
+                            interval=interval, min_points=min_points, layout=layout)
+                body = np.ascontiguousarray(cloud[1:])
+                if layout in (1, 3):
+                    body = np.ascontiguousarray(np.concatenate([body, np.ones((body.shape[0], 1), np.float32)], 1))
+                dev = torch.from_numpy(body).cuda() if layout < 2 else body
+                streamed = strategy == 1 and hint != 500 and layout < 2 and rng.random() < 0.4 and cloud.shape[0] > 10     # (a stream does not outgrow a hint: documented)
                 m.setCloudFirst(cloud[0])
                 if streamed:                        # the same cloud as an update stream of uneven frames from an empty map
                     m.reset(demand)
@@ -123,7 +135,7 @@ def run(seconds=600.0, seed=1, max_points=3_000_000, max_handles=0):
                 ran = m.STRATEGY_NAMES.get(m.last_strategy(), str(m.last_strategy()))
                 stats["by_strategy_ran"][ran] = stats["by_strategy_ran"].get(ran, 0) + 1
                 ref = parity.ref_from_cloud(cloud, P, mode=2)
-                rep = parity.compare(out, ref, demand, adversarial=adv, dense=True, interval=0.08)
+                rep = parity.compare(out, ref, demand, adversarial=adv, dense=True, interval=interval, min_points=min_points)
                 stats["builds"] += 1
                 stats["points"] += int(cloud.shape[0] - 1)
                 for k in ("labels_within_margin",):
