@@ -93,7 +93,7 @@ def run(seconds=600.0, seed=1, max_points=3_000_000, max_handles=0):
     while time.time() < t_end and len(stats["failures"]) < 5 and (not max_handles or trial < max_handles):
         trial += 1
         cells = CELLS[int(rng.integers(0, len(CELLS)))]
-        strategy = int(rng.choice([0, 0, 1, 2, 2, 3, 4, 5]))
+        strategy = int(rng.choice([0, 0, 1, 1, 2, 2, 3, 4, 5]))
         demand = "true" if rng.random() < 0.15 else "slope"
         interval = float(rng.choice([0.08, 0.08, 0.05, 0.2]))
         min_points = int(rng.choice([3, 3, 1, 2, 5]))
@@ -120,14 +120,22 @@ def run(seconds=600.0, seed=1, max_points=3_000_000, max_handles=0):
                 if layout in (1, 3):
                     body = np.ascontiguousarray(np.concatenate([body, np.ones((body.shape[0], 1), np.float32)], 1))
                 dev = torch.from_numpy(body).cuda() if layout < 2 else body
-                streamed = strategy == 1 and hint != 500 and layout < 2 and rng.random() < 0.4 and cloud.shape[0] > 10     # (a stream does not outgrow a hint: documented)
+                streamed = strategy == 1 and hint != 500 and layout < 2 and rng.random() < 0.6 and cloud.shape[0] > 10     # (a stream does not outgrow a hint: documented)
                 m.setCloudFirst(cloud[0])
                 if streamed:                        # the same cloud as an update stream of uneven frames from an empty map
                     m.reset(demand)
-                    cuts = np.unique(np.concatenate([[0, dev.shape[0]], rng.integers(0, dev.shape[0], int(rng.integers(1, 6)))]))
-                    for lo, hi in zip(cuts[:-1], cuts[1:]):
+                    cuts = np.unique(np.concatenate([[0, dev.shape[0]], rng.integers(0, dev.shape[0], int(rng.integers(1, 40)))]))
+                    check_at = int(rng.integers(1, len(cuts)))              # one checkpoint inside the stream, then the end
+                    for fi, (lo, hi) in enumerate(zip(cuts[:-1], cuts[1:])):
                         m.change2DMap(demand, dev[int(lo):int(hi)])
                         stats["updates"] += 1
+                        if fi + 1 == check_at and fi + 1 < len(cuts) - 1:
+                            part = cloud[:int(hi) + 1]
+                            rp = parity.compare(m.export(), parity.ref_from_cloud(part, P, mode=2), demand, adversarial=adv, dense=True,
+                                                interval=interval, min_points=min_points)
+                            stats["checkpoints"] = stats.get("checkpoints", 0) + 1
+                            if not rp["ok"]:
+                                stats["failures"].append(dict(desc, at_frame=fi + 1, frames=int(len(cuts) - 1), fail=rp["fail"][:5]))
                     desc["streamed_frames"] = int(len(cuts) - 1)
                 else:
                     m.create2DMap(demand, dev)
