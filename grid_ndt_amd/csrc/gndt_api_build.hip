@@ -90,7 +90,12 @@ int partition_launch(gndt_handle* h, gndt_handle::Pending& P) {
     // table size and bucket count for this attempt: 512-slot tables unless that needs too many buckets
     // attempt 0: 512-slot tables; an overflow first doubles the table (same estimate), then raises the estimate
     int bslots = env_slots ? env_slots : (attempt == 0 ? 512 : 1024);
-    const int load_pct = P.load_pct ? P.load_pct : q.load_pct;
+    // Node-heavy clouds (a few points per node) get their bucket count from the NODES: estimate / (slots x load).  From 2 M points
+    // on any such count fills the chip, and fuller tables with fewer buckets are faster (size sweep, round 3: load 75 against 60
+    // gains 3-11 % on 3-30 M-point clouds of 0.05-0.2 m voxels, S2z 0.84 -> 0.79 ms, S3 32 M 1.50 -> 1.47; a million points lose
+    // 4-13 % with it: fewer buckets than CUs want).  The estimate carries a 20 % margin, so 75 % is ~62 % of the slots really used.
+    int load_pct = P.load_pct ? P.load_pct : q.load_pct;
+    if (!P.load_pct && n >= (1u << 21)) load_pct = std::max(load_pct, tuning().bucket_load_large);
     uint64_t Bw = buckets_for(n, nodes_est, bslots, load_pct);
     // Clouds with few points per node (a million points in half a million nodes): the NODES size the bucket count, and 512-slot
     // tables — which since round 3 hold 512 nodes and no longer overflow on such clouds — would get buckets of a few hundred

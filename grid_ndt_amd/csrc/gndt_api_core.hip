@@ -16,6 +16,7 @@ Tuning parse_tuning() {
     Tuning t;
     auto geti = [](const char* k, int d) { const char* v = getenv(k); return v ? atoi(v) : d; };
     t.bucket_load = geti("GNDT_BUCKET_LOAD", t.bucket_load);
+    t.bucket_load_large = geti("GNDT_BUCKET_LOAD_LARGE", getenv("GNDT_BUCKET_LOAD") ? t.bucket_load : t.bucket_load_large);   // (one knob set: both follow it)
     t.bucket_points = geti("GNDT_BUCKET_POINTS", t.bucket_points);
     t.bucket_slots = geti("GNDT_BUCKET_SLOTS", t.bucket_slots);
     t.part_wgs = geti("GNDT_PART_WGS", t.part_wgs);

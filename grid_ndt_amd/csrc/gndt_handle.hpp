@@ -207,6 +207,7 @@ using namespace gndt;
 // Diagnostic / tuning knobs from the environment, parsed ONCE per process (DESIGN.md "Diagnostic and tuning knobs").
 struct Tuning {
     int bucket_load = 60;        // GNDT_BUCKET_LOAD    average LDS-table load (percent) that sizes the bucket count
+    int bucket_load_large = 75;  // GNDT_BUCKET_LOAD_LARGE  the same from 2 M points on (the chip is full either way: fuller tables, fewer buckets)
     int bucket_points = 0;       // GNDT_BUCKET_POINTS  points per bucket (0 = derived)
     int bucket_slots = 0;        // GNDT_BUCKET_SLOTS   LDS table of the first attempt (0 = 512, 1024 on a retry)
     int part_wgs = 256;          // GNDT_PART_WGS       workgroups of the exact counting partition
