@@ -148,6 +148,7 @@ def run(seconds=600.0, seed=1, max_points=3_000_000, max_handles=0):
                 stats["points"] += int(cloud.shape[0] - 1)
                 for k in ("labels_within_margin",):
                     stats[k] = stats.get(k, 0) + int(rep.get(k, 0))
+                stats["labels_on_the_margin"] = stats.get("labels_on_the_margin", 0) + int(rep.get("labels_on_the_margin", 0))
                 stats["worst_mean_err_truth"] = max(stats.get("worst_mean_err_truth", 0.0), rep.get("mean_err_truth", 0.0))
                 stats["worst_cov_err_truth"] = max(stats.get("worst_cov_err_truth", 0.0), rep.get("cov_err_truth", 0.0))
                 stats["nodes"] = stats.get("nodes", 0) + int(rep.get("num_nodes", 0))
