@@ -400,6 +400,27 @@ int partition_begin(gndt_handle* h, const void* xyz_dev, size_t n, size_t stride
     return GNDT_OK;
 }
 
+// A PARTITION build captured in a hipGraph is replayed without the host: nobody starts a pending build, nobody looks at its flags.
+// They come home all the same (k_emit_rows stores them into the pinned mirrors), so the call that waits for the stream can see
+// that the build it finds on the device — necessarily a replay of the last one resolved here, while the handle's serial is still
+// that build's — ran out of room in an LDS table, a partition region or the staging rows.  It cannot be run again here as a
+// build the host launched would be: more room means new buffers, and the graph holds the old ones.  So it is REPORTED
+// (GNDT_ERR_CAPACITY, what a captured gndt_update does): the caller builds that cloud eagerly and captures again.  Without this
+// such a replay came back SHORT and unreported (tools/fuzz_graph.py, round 3).  Called with the stream idle.
+int partition_recheck_after_replay(gndt_handle* h) {
+    auto& P = h->pending;
+    auto& q = h->part;
+    if (P.active || !P.done_serial || P.done_serial != h->result_serial || P.stats_only || P.records || h->map_in_table || !h->results_valid ||
+        !q.h_pc)
+        return GNDT_OK;
+    if (!(q.h_pc->part_overflow | q.h_pc->lds_overflow | q.h_pc->stage_overflow)) return GNDT_OK;
+    h->results_valid = false;
+    h->err = "a build replayed from a hipGraph ran out of room (LDS tables " + std::to_string(q.h_pc->lds_overflow) + ", partition regions " +
+             std::to_string(q.h_pc->part_overflow) + ", staging rows " + std::to_string(q.h_pc->stage_overflow) +
+             "): the capture is sized for the cloud it was recorded on — build this cloud eagerly (gndt_build_device + gndt_sync), then capture again";
+    return GNDT_ERR_CAPACITY;
+}
+
 // Wait for the pending build and look at its flags; re-run it with more room while they ask for it (the input
 // must still be valid: it is the caller's until gndt_sync / gndt_export returns).
 int partition_resolve(gndt_handle* h) {
@@ -459,6 +480,7 @@ int partition_resolve(gndt_handle* h) {
             if (!P.stats_only) {
                 h->results_valid = true;
                 ++h->result_serial;
+                P.done_serial = h->result_serial;
             }
             h->table_dirty = false;
             P.active = false;

@@ -299,6 +299,7 @@ int gndt_sync(gndt_handle* h, uint64_t* num_nodes, uint64_t* num_columns, uint64
     HIP_TRY(h, hipSetDevice(h->device));
     { const int prc = partition_resolve(h); if (prc) return prc; }
     HIP_TRY(h, hipStreamSynchronize(h->last_stream));
+    { const int rrc = partition_recheck_after_replay(h); if (rrc) return rrc; }      // (a replayed build that ran out of room says so)
     if (h->results_valid) {
         h->res_nodes = h->h_cnt->num_nodes;
         h->res_columns = h->h_cnt->num_columns;

@@ -189,6 +189,8 @@ struct gndt_handle {
         bool one_level = false;         //   ... the one-level tile partition (small clouds)
         double mean1 = 0.0;             // its mean level-1 region fill (to turn the fullest region into a ratio)
         bool stats_only = false;        // gndt_shard_stats_device: statistics out, no labels / ordering / rows
+        uint64_t done_serial = 0;       // result_serial when this build was resolved: while the handle still shows that serial, the map
+                                        //   on the device can only have been replaced by a REPLAY of this build (hipGraph)
         gndt::GridParams gp{};          // origin and grid parameters AS THEY WERE when the build was launched: a retry
                                         // re-runs the same build even if the handle's origin has moved on since
         uint32_t first_base = 0;        // global index of xyz[0] (shards of a global cloud)
@@ -311,6 +313,7 @@ void free_table(gndt_handle* h);
 int alloc_table(gndt_handle* h, uint32_t cap, hipStream_t s);
 int do_reset(gndt_handle* h, hipStream_t s);
 int zero_device_now(gndt_handle* h, void* p, size_t bytes);
+int partition_recheck_after_replay(gndt_handle* h);
 int build_atomic(gndt_handle* h, const void* xyz_dev, size_t n, size_t stride_bytes, hipStream_t s, bool tile = false,
                  const gndt_handle::Pending* rec = nullptr);
 int locality_sample(gndt_handle* h, const void* xyz_dev, size_t n, size_t stride_bytes, uint32_t tiles, double* ratio, hipStream_t s);

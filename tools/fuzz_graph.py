@@ -1,0 +1,130 @@
+#!/usr/bin/env python3
+"""Randomised campaign for builds and updates replayed from a hipGraph: two eager builds of a random cloud, the build captured,
+then the graph replayed on other random clouds of the same size and kind written into the same device buffer; a stream of equal
+frames through a captured gndt_update.  Every map against the oracle (dense-cloud gates).  A replay whose cloud outgrows what
+the capture was recorded for must say so (GNDT_ERR_CAPACITY at gndt_sync, or a re-run inside it) — never return a short map.
+Test infrastructure.      python3 tools/fuzz_graph.py [--seconds 200] [--seed 1]   -> JSON summary; exit 1 on a failure"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seconds", type=float, default=200.0)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--max-points", type=int, default=2_000_000)
+    a = ap.parse_args()
+    import torch
+    import grid_ndt_amd as g
+    from grid_ndt_amd._lib import GndtError
+    from tests import parity
+    from tools.fuzz_campaign import CELLS, make_cloud
+    g.build_native()
+    rng = np.random.default_rng(a.seed)
+    t_end = time.time() + a.seconds
+    stats = {"graphs": 0, "replays": 0, "capacity_reported": 0, "update_graphs": 0, "update_replays": 0, "failures": []}
+    while time.time() < t_end and len(stats["failures"]) < 3:
+        cells = CELLS[int(rng.integers(0, len(CELLS)))]
+        P = dict(grid_len=cells[0], z_len=cells[1], slope_interval=0.08, demand="slope")
+        n = int(np.exp(rng.uniform(np.log(3000), np.log(a.max_points))))
+        strategy = int(rng.choice([0, 1, 2, 4, 5]))
+        sub = np.random.default_rng(int(rng.integers(1 << 30)))
+
+        def cloud_of(seed_state):
+            r = np.random.default_rng(seed_state)
+            c, adv = make_cloud(r, n, cells)
+            return c[:n + 1] if c.shape[0] > n + 1 else np.concatenate([c, np.repeat(c[-1:], n + 1 - c.shape[0], 0)], 0), adv
+
+        kind_seed = int(sub.integers(1 << 30))
+        base, adv = cloud_of(kind_seed)
+        desc = dict(seed=a.seed, graph=stats["graphs"], cells=cells, points=n, strategy=strategy)
+        if os.environ.get("FUZZ_TRACE"):
+            print("case", desc, file=sys.stderr, flush=True)
+        try:
+            s = torch.cuda.Stream()
+            with torch.cuda.stream(s):
+                buf = torch.from_numpy(np.ascontiguousarray(base[1:])).cuda()
+                if rng.random() < 0.7:
+                    # ---- a whole build, captured ----
+                    m = g.TwoDmap(cells[0], cells[1], strategy=strategy, max_nodes_hint=int(rng.choice([0, 3_000_000])), max_points_hint=n + 1)
+                    m.setInterval(0.08)
+                    m.setCloudFirst(base[0])
+                    for _ in range(2):
+                        m.create2DMap("slope", buf, s)
+                        m.sync()
+                    graph = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(graph, stream=s):
+                        m.create2DMap("slope", buf, s)
+                    stats["graphs"] += 1
+                    for k in range(int(rng.integers(1, 4))):
+                        other, adv2 = cloud_of(kind_seed + 1 + k) if rng.random() < 0.8 else cloud_of(int(sub.integers(1 << 30)))
+                        other[0] = base[0]                       # (the origin stays the handle's)
+                        buf.copy_(torch.from_numpy(np.ascontiguousarray(other[1:])))
+                        if os.environ.get("FUZZ_TRACE"):
+                            print("  replay", k, m.STRATEGY_NAMES.get(m.last_strategy()), file=sys.stderr, flush=True)
+                        graph.replay()
+                        s.synchronize()
+                        stats["replays"] += 1
+                        try:
+                            out = m.export()
+                        except GndtError as e:
+                            if e.code == 5:        # GNDT_ERR_CAPACITY: said so, as documented
+                                stats["capacity_reported"] += 1
+                                break
+                            raise
+                        rep = parity.compare(out, parity.ref_from_cloud(other, P, mode=2), "slope", adversarial=adv or adv2, dense=True)
+                        if not rep["ok"]:
+                            stats["failures"].append(dict(desc, replay=k, fail=rep["fail"][:4]))
+                            break
+                else:
+                    # ---- a stream of equal frames through a captured update ----
+                    frames = int(rng.integers(3, 9))
+                    per = max(64, n // frames)
+                    m = g.TwoDmap(cells[0], cells[1], strategy=1, max_nodes_hint=min(per * frames + 1024, 4_000_000), max_points_hint=per * frames + 64)
+                    m.setInterval(0.08)
+                    m.setCloudFirst(base[0])
+                    m.reset("slope")
+                    fb = torch.empty((per, 3), dtype=torch.float32, device="cuda")
+                    body = base[1:1 + per * frames]
+                    if body.shape[0] < per * frames:
+                        continue
+                    fb.copy_(torch.from_numpy(np.ascontiguousarray(body[:per])))
+                    m.change2DMap("slope", fb, s)            # one eager frame: every buffer exists
+                    m.sync()
+                    graph = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(graph, stream=s):
+                        m.change2DMap("slope", fb, s)
+                    stats["update_graphs"] += 1
+                    for k in range(1, frames):
+                        fb.copy_(torch.from_numpy(np.ascontiguousarray(body[k * per:(k + 1) * per])))
+                        if os.environ.get("FUZZ_TRACE"):
+                            print("  update replay", k, per, file=sys.stderr, flush=True)
+                        graph.replay()
+                        s.synchronize()
+                        stats["update_replays"] += 1
+                    try:
+                        out = m.export()
+                    except GndtError as e:
+                        if e.code == 5:
+                            stats["capacity_reported"] += 1
+                            continue
+                        raise
+                    part = np.concatenate([base[:1], body], 0)
+                    rep = parity.compare(out, parity.ref_from_cloud(part, P, mode=2), "slope", adversarial=adv, dense=True)
+                    if not rep["ok"]:
+                        stats["failures"].append(dict(desc, frames=frames, per=per, fail=rep["fail"][:4]))
+        except Exception as e:
+            stats["failures"].append(dict(desc, error=f"{type(e).__name__}: {e}"))
+    print(json.dumps(stats, indent=1))
+    sys.exit(1 if stats["failures"] else 0)
+
+
+if __name__ == "__main__":
+    main()
