@@ -390,6 +390,11 @@ int partition_begin(gndt_handle* h, const void* xyz_dev, size_t n, size_t stride
                                                                        : std::max<uint64_t>(4096, n / 4));
     const int prev_strategy = h->last_strategy;
     h->last_strategy = GNDT_STRATEGY_PARTITION;
+    {
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        (void)hipStreamIsCapturing(s, &cap);
+        P.captured = cap != hipStreamCaptureStatusNone;
+    }
     rc = partition_launch(h, P);
     if (rc) { h->last_strategy = prev_strategy; return rc; }
     P.active = true;
@@ -469,6 +474,17 @@ int partition_resolve(gndt_handle* h) {
         } else if (q.h_pc->stage_overflow) {                   // num_nodes kept counting: it is the true total
             P.stage_want = (uint64_t)h->h_cnt->num_nodes + h->h_cnt->num_nodes / 8 + 1024;
             again = true;
+        }
+        if (again && P.captured) {
+            // The build was recorded into a hipGraph and what ran was its first replay.  Running it again here with more room would
+            // re-allocate the buffers the graph holds (round 3: exactly that happened — the re-run gave the right map and the NEXT
+            // replay wrote through freed pointers: a GPU memory fault; tools/fuzz_graph.py).  Reported instead, like a later replay.
+            P.active = false;
+            h->results_valid = false;
+            h->err = "a build replayed from a hipGraph ran out of room (LDS tables " + std::to_string(q.h_pc->lds_overflow) + ", partition regions " +
+                     std::to_string(q.h_pc->part_overflow) + ", staging rows " + std::to_string(q.h_pc->stage_overflow) +
+                     "): the capture is sized for the cloud it was recorded on — build this cloud eagerly (gndt_build_device + gndt_sync), then capture again";
+            return GNDT_ERR_CAPACITY;
         }
         if (!again) {
             q.nodes_learned = (uint64_t)h->h_cnt->num_nodes + h->h_cnt->num_nodes / 5;

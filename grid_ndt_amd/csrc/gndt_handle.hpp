@@ -189,6 +189,8 @@ struct gndt_handle {
         bool one_level = false;         //   ... the one-level tile partition (small clouds)
         double mean1 = 0.0;             // its mean level-1 region fill (to turn the fullest region into a ratio)
         bool stats_only = false;        // gndt_shard_stats_device: statistics out, no labels / ordering / rows
+        bool captured = false;          // launched on a stream under hipGraph capture: it runs when the graph is replayed, with the
+                                        //   buffers it was recorded with — never re-run here with more room (new buffers: the graph holds the old)
         uint64_t done_serial = 0;       // result_serial when this build was resolved: while the handle still shows that serial, the map
                                         //   on the device can only have been replaced by a REPLAY of this build (hipGraph)
         gndt::GridParams gp{};          // origin and grid parameters AS THEY WERE when the build was launched: a retry

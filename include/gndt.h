@@ -135,7 +135,7 @@ int gndt_build(gndt_handle* h, const void* xyz_host, size_t n, size_t stride_byt
  * and unchanged until then (a later gndt_build* / gndt_reset on the handle abandons the pending build instead).
  * A PARTITION build captured in a hipGraph and replayed is not watched by the host: if the replayed cloud needs more room than
  * the captured one (LDS tables, partition regions, staging rows), gndt_sync reports GNDT_ERR_CAPACITY — build that cloud
- * eagerly, then capture again (DESIGN.md 4.4 names the one open problem with replays on clouds of a different structure).
+ * eagerly, then capture again.
  * Strategies ATOMIC and TILE wait for the stream once before returning (and grow the table themselves) — except on a stream
  * under hipGraph capture, where they are recorded once for the table as it stands and a replay that outgrows it reports
  * GNDT_ERR_CAPACITY at gndt_sync.  AUTO picks per cloud (ATOMIC below 65 536 points; above, TILE when a sample of the
