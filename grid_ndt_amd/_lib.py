@@ -202,6 +202,10 @@ def lib():
     L.gndt_debug_retry_count.restype = C.c_int
     L.gndt_debug_enable_stamps.argtypes = [C.c_int]
     L.gndt_debug_enable_stamps.restype = C.c_int
+    L.gndt_debug_set_fp_bits.argtypes = [C.c_int]
+    L.gndt_debug_set_fp_bits.restype = C.c_int
+    L.gndt_debug_fp_clashes.argtypes = [H, C.POINTER(u64)]
+    L.gndt_debug_fp_clashes.restype = C.c_int
     L.gndt_comm_unique_id.argtypes = [C.c_char_p]
     L.gndt_comm_create.argtypes = [C.c_char_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(vp)]
     L.gndt_comm_destroy.argtypes = [vp]

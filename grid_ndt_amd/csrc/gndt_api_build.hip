@@ -336,11 +336,12 @@ int partition_launch(gndt_handle* h, gndt_handle::Pending& P) {
     const StatsOut stats_out{h->st_key, h->st_sums, h->st_count, h->st_first};
     unsigned long long* dbg = tuning().stamps ? q.dbg : nullptr;
     const bool grouped = true;          // k_bucket_direct stages a column's rows next to each other
+    const uint32_t fp_mask = (1u << tuning().fp_bits) - 1u;
     {
         // k_bucket_direct (gndt_bucket3.hpp): 512-slot tables with two workgroups per CU, 1024-slot tables on a retry
 #define GNDT_LAUNCH_DIRECT(T_, H_, S_)                                                                                          \
     hipLaunchKernelGGL((k_bucket_direct<T_, H_, S_>), bgrid, dim3(T_), 0, s, bucket_recs, ranges, B, gp, q.stage,    \
-                       (uint32_t)(S_ ? h->st_cap : q.stage_cap), q.ord_cf, q.ord_idx, order, h->d_cnt, q.d_pc, dbg, stats_out)
+                       (uint32_t)(S_ ? h->st_cap : q.stage_cap), q.ord_cf, q.ord_idx, order, h->d_cnt, q.d_pc, dbg, stats_out, fp_mask)
         if (bslots == 1024) { if (P.stats_only) GNDT_LAUNCH_DIRECT(1024, 1024, true); else GNDT_LAUNCH_DIRECT(1024, 1024, false); }
         else { if (P.stats_only) GNDT_LAUNCH_DIRECT(GNDT_DIRECT_THREADS, 512, true); else GNDT_LAUNCH_DIRECT(GNDT_DIRECT_THREADS, 512, false); }
 #undef GNDT_LAUNCH_DIRECT
@@ -582,6 +583,14 @@ int gndt_debug_retry_count(gndt_handle* h, uint64_t* retries) {
 }
 
 int gndt_debug_enable_stamps(int on) { tuning_force_stamps(on != 0); return GNDT_OK; }
+
+int gndt_debug_set_fp_bits(int bits) { tuning_force_fp_bits(bits); return GNDT_OK; }
+
+int gndt_debug_fp_clashes(gndt_handle* h, uint64_t* buckets) {
+    if (!h || !buckets) return GNDT_ERR_INVALID;
+    *buckets = h->part.h_pc ? h->part.h_pc->fp_clashes : 0;
+    return GNDT_OK;
+}
 
 int gndt_debug_bucket_phases(gndt_handle* h, double cycles_out[10], uint32_t* buckets_out) {
     if (!h || !cycles_out) return GNDT_ERR_INVALID;

@@ -29,6 +29,7 @@ Tuning parse_tuning() {
     t.owner_locality = geti("GNDT_OWNER_LOCALITY", t.owner_locality);
     t.owner_sliced_rows = geti("GNDT_OWNER_SLICED", t.owner_sliced_rows);
     t.one_level = geti("GNDT_ONE_LEVEL", t.one_level);
+    t.fp_bits = std::min(21, std::max(0, geti("GNDT_FP_BITS", t.fp_bits)));
     t.stamps = getenv("GNDT_STAMPS") != nullptr;
     t.verbose = getenv("GNDT_VERBOSE") != nullptr;
     return t;
@@ -37,6 +38,7 @@ Tuning& tuning_storage() { static Tuning t = parse_tuning(); return t; }
 }  // namespace
 const Tuning& tuning() { return tuning_storage(); }
 void tuning_force_stamps(bool on) { tuning_storage().stamps = on; }
+void tuning_force_fp_bits(int bits) { tuning_storage().fp_bits = std::min(21, std::max(0, bits)); }
 
 int ensure_out(gndt_handle* h, uint64_t n) {
     if (n <= h->out_cap) return GNDT_OK;

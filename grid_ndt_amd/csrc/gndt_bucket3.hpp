@@ -51,9 +51,10 @@ struct StatsOut {
 template <int H>
 struct BucketLds3 {           // 70 KB at H = 512: two workgroups per CU
     // Node table in two parts.  `idx` is an open-addressing INDEX of 4 H words (at most a quarter full): the hash of a node's
-    // key leads to the number of the node.  Nodes are numbered in the order they arrive, so keys and statistics sit in DENSE
-    // arrays: the per-node phases run over 0 .. n_nodes - 1 with no compaction pass, and a table holds H nodes, not 0.78 H.
-    uint32_t idx[4 * H];
+    // key leads to a word holding a FINGERPRINT of the key and the number of the node.  Nodes are numbered in the order they
+    // arrive, so keys and statistics sit in DENSE arrays: the per-node phases run over 0 .. n_nodes - 1 with no compaction
+    // pass, and a table holds H nodes, not 0.78 H.
+    alignas(16) uint32_t idx[4 * H];
     unsigned long long key[H];
     double sum[9][H];
     uint32_t cnt[H];
@@ -68,104 +69,200 @@ struct BucketLds3 {           // 70 KB at H = 512: two workgroups per CU
     uint16_t cslot[H];          // column slot of the node
     uint32_t ccnt[H];           // nodes of the column in this column slot; after the prefix (first row inside the bucket) << 16 | nodes
     uint32_t n_nodes, n_cols, n_slopes, stage_base, overflow, err_range, row_cursor;
+    uint32_t clash;             // records whose fingerprint named another node (they went on with the key itself)
 };
-constexpr uint32_t kNoNode = 0xFFFFFFFFu;
-
 // Workgroup barrier that orders LDS traffic ONLY (__syncthreads() also waits for the wave's global stores): the phases of
 // the bucket kernels hand over LDS contents, their global stores are read by later kernels.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // ---- finding a node: the index ----
-// idx[h] is kIdxEmpty, the number of a node, kIdxLock (a lane has claimed the word and is about to publish the number of a NEW
-// node) or kIdxFull (the table ran out of node numbers: the build is re-run).  At a load of at most 1/4 — usually 1/10 — a key
-// that does not sit where its hash points is rare and never far away, so the loop is one 4-byte read and one 8-byte key read per
-// step, ~12 instructions: the round-2 table probed 64-bit keys in place at a load of 0.4, where a fifth of the nodes is
-// displaced by up to ~9 slots and, with 128 records per wave, every wave walked that far in every iteration (windows of four
-// slots per round trip: ~100 instructions per round, three rounds; profiles/r03_bucket_ablation.txt).
-constexpr uint32_t kIdxEmpty = 0xFFFFFFFFu, kIdxLock = 0xFFFFFFFEu, kIdxFull = 0xFFFFFFFDu;
-// h[j]: where record j's search stands (updated); id[j]: the node number once done[j].  Records of a lane search together.
-// A record whose table is full gets id = 0 and use = false.
+// The index is H WINDOWS of four words.  A word is (fingerprint << 11) | nf: nf = 0 only in the EMPTY word (0); 1 .. 1024 = node
+// number + 1; kNfPending = a lane has claimed the word and is about to publish the number of a NEW node; kNfFull = the table ran
+// out of node numbers (the build is re-run).  The fingerprint is 21 bits of a second hash of the node key (never 0).  A node lives
+// in the window its hash points at (any of its four words), or — that window full when it arrived — in the next one.
+// ONE 16-byte read therefore answers "which node is this record's, and what is its number" for (nearly) every record of a wave:
+// round 3's plain index took two DEPENDENT round trips per step (the word, then the 8-byte key it names; ~1 k cycles each under
+// load, profiles/r03_bucket_ablation.txt) and a step per displaced slot, and with 128 records per wave some lane always needed
+// three or four steps.  Here a window overflows with probability ~2e-4 (Poisson, 0.5 nodes per window) and a second step is rare.
+// A fingerprint NAMES the node; the key confirms it: two keys that meet in a window share their fingerprint with probability
+// 2^-21, so the key array is still read — once per record, requested after the search and looked at after the record's atomics
+// have been issued.  A mismatch raises BucketLds3::clash: the bucket's table is cleared and filled again by accumulate_exact,
+// which confirms every step with the key (~1 bucket in 10^4; tests narrow the fingerprint to force it in every bucket).
+constexpr uint32_t kFpShift = 11u, kNfMask = 0x7FFu, kNfPending = 0x7FFu, kNfFull = 0x7FEu;
+constexpr uint32_t kNoNode = 0xFFFFFFFFu;
+__device__ __forceinline__ uint32_t node_fp_word(uint32_t colh, int sz, uint32_t fp_mask) {
+    uint32_t f = __umul24(colh >> 8, 0x6F4F2Bu) ^ __umul24((uint32_t)sz & 0xFFFFFFu, 0xA24BAFu) ^ (colh << 13);
+    f ^= f >> 9;
+    f = (f >> 3) & fp_mask;                          // (fp_mask = 2^21 - 1 unless a test narrows it)
+    return max(f, 1u) << kFpShift;
+}
+// the window of slot h (h & 3 = where a new node of this key looks for room first: spreads the claims of a window's keys)
+template <typename Lds>
+__device__ __forceinline__ uint4 lds_index_window(const Lds& L, uint32_t h) {
+    asm volatile("" ::: "memory");                    // (other lanes write the index: every look is a new read)
+    return *reinterpret_cast<const uint4*>(&L.idx[h & ~3u]);
+}
+// the word of window W that carries fingerprint fpw (0 if none does)
+__device__ __forceinline__ uint32_t window_match(const uint4& W, uint32_t fpw) {
+    uint32_t e = 0u;
+    if ((W.w & ~kNfMask) == fpw) e = W.w;
+    if ((W.z & ~kNfMask) == fpw) e = W.z;
+    if ((W.y & ~kNfMask) == fpw) e = W.y;
+    if ((W.x & ~kNfMask) == fpw) e = W.x;
+    return e;
+}
+// first empty word of window W at or (cyclically) after position p0; 4 if the window is full
+__device__ __forceinline__ uint32_t window_room(const uint4& W, uint32_t p0) {
+    const uint32_t em = (W.x == 0u ? 1u : 0u) | (W.y == 0u ? 2u : 0u) | (W.z == 0u ? 4u : 0u) | (W.w == 0u ? 8u : 0u);
+    if (em == 0u) return 4u;
+    const uint32_t rot = ((em | (em << 4)) >> p0) & 0xFu;
+    return (p0 + (uint32_t)__builtin_ctz(rot)) & 3u;
+}
+
+// The wave's lanes that claimed an empty word (`won`, the word at hw[j]) take node numbers — ONE addition per wave for all U
+// records — and publish key and number.  id[j] / done[j] are set for the winners; a winner that finds the numbers used up marks
+// the word kNfFull.
 template <int H, int U, typename Lds>
-// settled[j]: record j's node number is already in id[j] (the caller's early look at the index found it).
-__device__ __forceinline__ void lds_index_find_or_insert(Lds& L, uint32_t (&h)[U], uint32_t (&id)[U], bool (&use)[U],
-                                                         const unsigned long long (&key)[U], const bool (&settled)[U]) {
+__device__ __forceinline__ void lds_index_publish(Lds& L, const uint32_t (&hw)[U], const uint32_t (&fpw)[U], const unsigned long long (&key)[U],
+                                                  const bool (&won)[U], uint32_t (&id)[U], bool (&use)[U], bool (&done)[U]) {
+    unsigned long long m[U];
+    uint32_t total = 0;
+#pragma unroll
+    for (int j = 0; j < U; ++j) { m[j] = __ballot(won[j]); total += (uint32_t)__popcll(m[j]); }
+    if (total == 0u) return;                          // (wave-uniform)
+    uint32_t n0 = 0;
+    if ((threadIdx.x & 63) == 0) n0 = atomicAdd(&L.n_nodes, total);
+    n0 = (uint32_t)__shfl((int)n0, 0, 64);
+    const unsigned long long below = (1ull << (threadIdx.x & 63)) - 1ull;
+#pragma unroll
+    for (int j = 0; j < U; ++j) {
+        const uint32_t n = n0 + (uint32_t)__popcll(m[j] & below);
+        n0 += (uint32_t)__popcll(m[j]);
+        if (!won[j]) continue;
+        if (n < (uint32_t)H) {
+            L.key[n] = key[j];
+            // The key must be in place before the number can be seen.  The LDS executes a wave's operations in order, so
+            // only the COMPILER has to be kept from swapping the two stores: a signal fence, no s_waitcnt.
+            __atomic_signal_fence(__ATOMIC_SEQ_CST);
+            __hip_atomic_store(&L.idx[hw[j]], fpw[j] | (n + 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            id[j] = n;
+        } else {
+            __hip_atomic_store(&L.idx[hw[j]], fpw[j] | kNfFull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            L.overflow = 1; use[j] = false;
+        }
+        done[j] = true;
+    }
+}
+
+// h[j]: where record j's search stands (updated); W[j]: the window it saw there (the caller's early look); id[j]: the node number
+// once the search is over — NAMED by a fingerprint, to be confirmed by the caller with the key.  Records of a lane search
+// together.  A record whose table is full gets use = false.  The usual case — every record of the wave finds its node in the
+// window the hash points at — is settled by the early look without another LDS operation; only a wave that has to make room
+// for a new node goes through the claim (compare-and-swap, numbers, publication).
+template <int H, int U, typename Lds>
+__device__ __forceinline__ void lds_index_find_or_insert(Lds& L, uint32_t (&h)[U], uint4 (&W)[U], uint32_t (&id)[U], bool (&use)[U],
+                                                         const uint32_t (&fpw)[U], const unsigned long long (&key)[U]) {
     constexpr uint32_t kMask = 4u * (uint32_t)H - 1u;
     bool done[U];
 #pragma unroll
-    for (int j = 0; j < U; ++j) { done[j] = !use[j] || settled[j]; if (!settled[j]) id[j] = 0u; }
-    for (int round = 0; round < 16 * H; ++round) {      // (a step settles a record, moves it one word on, or waits for a publication)
-        bool all_done = true;
-#pragma unroll
-        for (int j = 0; j < U; ++j) all_done = all_done && done[j];
-        if (__all(all_done)) return;                     // (the wave leaves together: the wave-wide operations below see all of its lanes)
-        uint32_t e[U];
-#pragma unroll
-        for (int j = 0; j < U; ++j) e[j] = __hip_atomic_load(&L.idx[h[j]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        // empty words are claimed (the records' operations issued together: one wait each for the compare-and-swaps, the
-        // node numbers — ONE addition per wave — and nothing for the writes)
-        bool won[U];
-        bool any_won = false;
+    for (int j = 0; j < U; ++j) { done[j] = !use[j]; id[j] = 0u; }
+    for (int round = 0; round < 16 * H; ++round) {      // (a step settles a record, claims a word for it, moves it one window on, or waits for a publication)
+        bool need = false, all_done = true;
 #pragma unroll
         for (int j = 0; j < U; ++j) {
-            won[j] = false;
-            if (!done[j] && e[j] == kIdxEmpty) e[j] = atomicCAS(&L.idx[h[j]], kIdxEmpty, kIdxLock), won[j] = true;
+            if (done[j]) continue;
+            const uint32_t e = window_match(W[j], fpw[j]);
+            const uint32_t nf = e & kNfMask;
+            if (e == 0u) need = true;                     // not in this window: claim a word of it, or go on if it is full
+            else if (nf < kNfFull) { id[j] = nf - 1u; done[j] = true; }
+            else if (nf == kNfFull) { use[j] = false; done[j] = true; }
+            // (kNfPending: the number is about to appear there — look again)
         }
-#pragma unroll
-        for (int j = 0; j < U; ++j) { won[j] = won[j] && e[j] == kIdxEmpty; any_won = any_won || won[j]; }
-        if (__any(any_won)) {
-            unsigned long long m[U];
-            uint32_t total = 0;
-#pragma unroll
-            for (int j = 0; j < U; ++j) { m[j] = __ballot(won[j]); total += (uint32_t)__popcll(m[j]); }
-            uint32_t n0 = 0;
-            if ((threadIdx.x & 63) == 0) n0 = atomicAdd(&L.n_nodes, total);
-            n0 = (uint32_t)__shfl((int)n0, 0, 64);
-            const unsigned long long below = (1ull << (threadIdx.x & 63)) - 1ull;
+        if (__any(need)) {
+            bool won[U];
+            uint32_t hw[U], old[U];
 #pragma unroll
             for (int j = 0; j < U; ++j) {
-                const uint32_t n = n0 + (uint32_t)__popcll(m[j] & below);
-                n0 += (uint32_t)__popcll(m[j]);
-                if (!won[j]) continue;
-                if (n < (uint32_t)H) {
-                    L.key[n] = key[j];
-                    // The key must be in place before the number can be seen.  The LDS executes a wave's operations in order, so
-                    // only the COMPILER has to be kept from swapping the two stores: a signal fence, no s_waitcnt.
-                    __atomic_signal_fence(__ATOMIC_SEQ_CST);
-                    __hip_atomic_store(&L.idx[h[j]], n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    id[j] = n;
-                } else {
-                    __hip_atomic_store(&L.idx[h[j]], kIdxFull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    L.overflow = 1; use[j] = false;
+                won[j] = false; old[j] = 1u; hw[j] = 0u;
+                if (!done[j] && window_match(W[j], fpw[j]) == 0u) {
+                    const uint32_t p = window_room(W[j], h[j] & 3u);
+                    if (p < 4u) { hw[j] = (h[j] & ~3u) | p; won[j] = true; old[j] = atomicCAS(&L.idx[hw[j]], 0u, fpw[j] | kNfPending); }
+                    else h[j] = (h[j] + 4u) & kMask;          // the window is full: its neighbour
                 }
-                done[j] = true;
             }
-        }
-        unsigned long long k[U];
 #pragma unroll
-        for (int j = 0; j < U; ++j) k[j] = L.key[(!done[j] && e[j] < (uint32_t)H) ? e[j] : 0u];
-#pragma unroll
-        for (int j = 0; j < U; ++j) {
-            if (done[j] || e[j] == kIdxLock) continue;                     // (a number is about to appear there: look again)
-            if (e[j] == kIdxFull) { use[j] = false; done[j] = true; continue; }
-            if (k[j] == key[j]) { id[j] = e[j]; done[j] = true; continue; }
-            h[j] = (h[j] + 1u) & kMask;
+            for (int j = 0; j < U; ++j) won[j] = won[j] && old[j] == 0u;      // (a loser looks at the window again: it may hold its own node now)
+            lds_index_publish<H, U>(L, hw, fpw, key, won, id, use, done);
         }
+#pragma unroll
+        for (int j = 0; j < U; ++j) all_done = all_done && done[j];
+        if (__all(all_done)) return;                     // (the wave leaves together: the wave-wide operations above see all of its lanes)
+#pragma unroll
+        for (int j = 0; j < U; ++j) W[j] = lds_index_window(L, h[j]);
     }
 #pragma unroll
     for (int j = 0; j < U; ++j) if (!done[j]) { L.overflow = 1; use[j] = false; }
 }
 
-// Look a key up in the finished index (no insertion): the node's number, or kIdxEmpty.
+// The same search with every step confirmed by the 8-byte key, one record per lane: what accumulate_exact does for the bucket
+// whose fingerprints clashed.  Called by whole waves (`active` per lane).  Returns the node's number, or kNoNode (table full).
 template <int H, typename Lds>
-__device__ __forceinline__ uint32_t lds_index_find(const Lds& L, uint32_t h, unsigned long long key) {
+__device__ __forceinline__ uint32_t lds_index_find_or_insert_exact(Lds& L, uint32_t h, const uint32_t fpw, const unsigned long long key, const bool active) {
     constexpr uint32_t kMask = 4u * (uint32_t)H - 1u;
-    for (int probe = 0; probe < 4 * H; ++probe) {
-        const uint32_t e = L.idx[h];
-        if (e >= (uint32_t)H) return kIdxEmpty;          // (empty: the key is not in the table; lock / full marks do not outlive the accumulate phase of a table that is kept)
-        if (L.key[e] == key) return e;
-        h = (h + 1u) & kMask;
+    uint32_t node = kNoNode;
+    bool done = !active;
+    for (int round = 0; round < 16 * H; ++round) {
+        if (__all(done)) break;
+        if (done) continue;
+        const uint4 W = lds_index_window(L, h);
+        const uint32_t w4[4] = {W.x, W.y, W.z, W.w};
+        bool wait = false;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t e = w4[i], nf = e & kNfMask;
+            if (done || e == 0u || (e & ~kNfMask) != fpw) continue;
+            if (nf == kNfPending) wait = true;            // (may be this key: look again once the number is there)
+            else if (nf != kNfFull && L.key[nf - 1u] == key) { node = nf - 1u; done = true; }
+        }
+        if (done || wait) continue;
+        const uint32_t p = window_room(W, h & 3u);
+        if (p == 4u) { h = (h + 4u) & kMask; continue; }
+        const uint32_t hw = (h & ~3u) | p;
+        if (atomicCAS(&L.idx[hw], 0u, fpw | kNfPending) != 0u) continue;      // (somebody else took the word: look again)
+        const uint32_t n = atomicAdd(&L.n_nodes, 1u);
+        if (n < (uint32_t)H) {
+            L.key[n] = key;
+            __atomic_signal_fence(__ATOMIC_SEQ_CST);
+            __hip_atomic_store(&L.idx[hw], fpw | (n + 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            node = n;
+        } else {
+            __hip_atomic_store(&L.idx[hw], fpw | kNfFull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            L.overflow = 1;
+        }
+        done = true;
     }
-    return kIdxEmpty;
+    if (!done) L.overflow = 1;
+    return node;
+}
+
+// Look a key up in the finished index (no insertion): the node's number, or kNoNode.
+template <int H, typename Lds>
+__device__ __forceinline__ uint32_t lds_index_find(const Lds& L, uint32_t h, const uint32_t fpw, const unsigned long long key) {
+    constexpr uint32_t kMask = 4u * (uint32_t)H - 1u;
+    for (int probe = 0; probe < H; ++probe) {
+        const uint4 W = *reinterpret_cast<const uint4*>(&L.idx[h & ~3u]);
+        const uint32_t w4[4] = {W.x, W.y, W.z, W.w};
+        bool room = false;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t e = w4[i], n = (e & kNfMask) - 1u;
+            if (e == 0u) room = true;
+            else if ((e & ~kNfMask) == fpw && n < (uint32_t)H && L.key[n] == key) return n;
+        }
+        if (room) return kNoNode;                         // (a window with room left never sent a node on to its neighbour)
+        h = (h + 4u) & kMask;
+    }
+    return kNoNode;
 }
 
 // slot of a node inside its bucket's table.  The bucket is chosen by the TOP bits of the column hash (bucket_of), so its
@@ -176,6 +273,52 @@ __device__ __forceinline__ uint32_t node_slot3(uint32_t colh, int sz) {
     return g;
 }
 
+template <int T, int H, typename Lds>
+__device__ __forceinline__ void bucket_tables_init(Lds& L) {
+    const int tid = threadIdx.x;
+    for (int s = tid; s < H; s += T) {
+        *reinterpret_cast<uint4*>(&L.idx[4 * s]) = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+        for (int j = 0; j < 9; ++j) L.sum[j][s] = 0.0;
+        L.cnt[s] = 0; L.first[s] = 0xFFFFFFFFu;
+        L.chead[s] = kNoNode;
+        L.ccnt[s] = 0;
+    }
+    if (tid == 0) { L.n_nodes = 0; L.n_cols = 0; L.n_slopes = 0; L.stage_base = 0; L.overflow = 0; L.err_range = 0; L.row_cursor = 0; L.clash = 0; }
+}
+
+// The accumulate phase once more for a bucket whose fingerprints clashed: one record per thread and step, every step of the
+// search confirmed by the key.  Plain and slow on purpose — it runs for about one bucket in 10^4.
+template <int T, int H, typename Lds>
+__device__ __forceinline__ void accumulate_exact(Lds& L, const float4* __restrict__ recs, const uint32_t lo, const uint32_t hi,
+                                                 const GridParams& P, const uint32_t fp_mask) {
+    const double hx = 0.5 * (double)P.grid_len, hz = 0.5 * (double)P.z_len;
+    const double ox = (double)P.ox, oy = (double)P.oy, oz = (double)P.oz;
+    for (uint32_t base = lo; base < hi; base += (uint32_t)T) {
+        if (__builtin_amdgcn_readfirstlane((int)L.overflow)) break;
+        const uint32_t i = base + threadIdx.x;
+        bool use = i < hi;
+        const float4 rec = recs[min(i, hi - 1u)];
+        const PointKey k = point_key_fast(rec.x, rec.y, rec.z, P.ox, P.oy, P.oz, P.grid_len, P.z_len, P.inv_grid, P.inv_z);
+        const unsigned long long pkey = pack_key(k.sx, k.sy, k.sz);
+        const uint32_t colh = column_hash(k.sx, k.sy);
+        if (use && !k.ok) { atomicAdd(&L.err_range, 1u); use = false; }
+        const uint32_t s = lds_index_find_or_insert_exact<H>(L, node_slot3(colh, k.sz) & (4u * (uint32_t)H - 1u), node_fp_word(colh, k.sz, fp_mask), pkey, use);
+        if (!use || s == kNoNode) continue;
+        const uint32_t iw = __float_as_uint(rec.w);
+        const double v0 = (double)rec.x - fma((double)(2 * k.sx - (k.sx > 0 ? 1 : -1)), hx, ox);
+        const double v1 = (double)rec.y - fma((double)(2 * k.sy - (k.sy > 0 ? 1 : -1)), hx, oy);
+        const double v2 = (double)rec.z - fma((double)(2 * k.sz - (k.sz > 0 ? 1 : -1)), hz, oz);
+        const double wf = (double)record_weight(iw);
+        const double w0 = wf * v0, w1 = wf * v1, w2 = wf * v2;
+        atomicAdd(&L.sum[0][s], w0); atomicAdd(&L.sum[1][s], w1); atomicAdd(&L.sum[2][s], w2);
+        atomicAdd(&L.sum[3][s], w0 * v0); atomicAdd(&L.sum[4][s], w0 * v1); atomicAdd(&L.sum[5][s], w0 * v2);
+        atomicAdd(&L.sum[6][s], w1 * v1); atomicAdd(&L.sum[7][s], w1 * v2); atomicAdd(&L.sum[8][s], w2 * v2);
+        atomicAdd(&L.cnt[s], record_weight(iw));
+        atomicMin(&L.first[s], record_index(iw));
+    }
+}
+
 template <int T, int H, bool STATS>
 __device__ __forceinline__ void bucket_direct_one(BucketLds3<H>& L, const uint32_t bucket, const float4* __restrict__ recs,
                                                   const uint32_t lo, const uint32_t hi, const GridParams& P,
@@ -183,23 +326,14 @@ __device__ __forceinline__ void bucket_direct_one(BucketLds3<H>& L, const uint32
                                                   uint32_t* __restrict__ ord_cf, uint32_t* __restrict__ ord_idx,
                                                   const ColumnOrder& O, Counters* __restrict__ cnt,
                                                   PartCounters* __restrict__ pc, unsigned long long* __restrict__ dbg,
-                                                  const StatsOut& so) {
+                                                  const StatsOut& so, const uint32_t fp_mask) {
     static_assert(H <= 65535, "node numbers are kept in 16 bits");
     constexpr int U = H <= 512 ? GNDT_DIRECT_U : 2;    // records in flight per thread
     const int tid = threadIdx.x;
     const int lane = tid & 63;
 #define GNDT_STAMP3(k) do { if (dbg && tid == 0) dbg[(size_t)bucket * 16 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
     GNDT_STAMP3(0);
-    for (int s = tid; s < H; s += T) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) L.idx[4 * s + j] = kIdxEmpty;
-#pragma unroll
-        for (int j = 0; j < 9; ++j) L.sum[j][s] = 0.0;
-        L.cnt[s] = 0; L.first[s] = 0xFFFFFFFFu;
-        L.chead[s] = kNoNode;
-        L.ccnt[s] = 0;
-    }
-    if (tid == 0) { L.n_nodes = 0; L.n_cols = 0; L.n_slopes = 0; L.stage_base = 0; L.overflow = 0; L.err_range = 0; L.row_cursor = 0; }
+    bucket_tables_init<T, H>(L);
     __syncthreads();
     GNDT_STAMP3(1);
 
@@ -235,22 +369,22 @@ __device__ __forceinline__ void bucket_direct_one(BucketLds3<H>& L, const uint32
             for (int j = 0; j < U; ++j) nxt[j] = recs[min(base + (uint32_t)(U * T + U * tid + j), hi - 1u)];
         }
         PointKey k[U];
-        uint32_t slot[U];
+        uint32_t slot[U], fpw[U];
         unsigned long long pkey[U];
 #pragma unroll
         for (int j = 0; j < U; ++j) {
             k[j] = point_key_fast(rec[j].x, rec[j].y, rec[j].z, P.ox, P.oy, P.oz, P.grid_len, P.z_len, P.inv_grid, P.inv_z);
             pkey[j] = pack_key(k[j].sx, k[j].sy, k[j].sz);
-            slot[j] = node_slot3(column_hash(k[j].sx, k[j].sy), k[j].sz) & (4u * (uint32_t)H - 1u);      // (where the search starts in the index)
+            const uint32_t colh = column_hash(k[j].sx, k[j].sy);
+            slot[j] = node_slot3(colh, k[j].sz) & (4u * (uint32_t)H - 1u);      // (where the search starts in the index)
+            fpw[j] = node_fp_word(colh, k[j].sz, fp_mask);
             if (use[j] && !k[j].ok) { atomicAdd(&L.err_range, 1u); use[j] = false; }   // |nz| beyond the key range (x, y: the partition)
         }
-        // an early look at the index: the word the hash points at is requested now, the key it leads to after the arithmetic below —
-        // by the time the search proper starts, the usual case (the node exists where the hash says) is already answered
-        // (512-slot variant only: the 1024-slot one, a single 1024-thread workgroup per CU, has no registers to spare for it)
-        constexpr bool kEarly = H <= 512;
-        uint32_t e0[U];
+        // an early look at the index: the window the hash points at is requested now and looked at after the arithmetic below — the
+        // usual case (the node is there: a word carries its fingerprint and its number) costs no wait at all
+        uint4 W0[U];
 #pragma unroll
-        for (int j = 0; j < U; ++j) e0[j] = kEarly ? __hip_atomic_load(&L.idx[slot[j]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : kIdxEmpty;
+        for (int j = 0; j < U; ++j) W0[j] = lds_index_window(L, slot[j]);
         const bool pair = U >= 2 && use[0] && use[U - 1] && pkey[0] == pkey[U - 1];      // both records in one node: one contribution
         if (pair) use[U - 1] = false;
         // a wave whose records all sit in ONE node (dense cells, the zero padding): summed across the wave, one lane adds
@@ -273,9 +407,6 @@ __device__ __forceinline__ void bucket_direct_one(BucketLds3<H>& L, const uint32
             cn[j] = wn;
             cf[j] = record_index(iw);
         }
-        unsigned long long k0[U];
-#pragma unroll
-        for (int j = 0; j < U; ++j) k0[j] = kEarly ? L.key[e0[j] < (uint32_t)H ? e0[j] : 0u] : 0ull;
         if (pair) {
 #pragma unroll
             for (int q = 0; q < 9; ++q) c[0][q] += c[U - 1][q];
@@ -288,15 +419,11 @@ __device__ __forceinline__ void bucket_direct_one(BucketLds3<H>& L, const uint32
         }
         GNDT_SUB(0);
         uint32_t node[U];
-        bool settled[U];
+        lds_index_find_or_insert<H, U>(L, slot, W0, node, use, fpw, pkey);
+        // the fingerprint NAMED the node; the key confirms it: requested now, looked at when the atomics are on their way
+        unsigned long long kv[U];
 #pragma unroll
-        for (int j = 0; j < U; ++j) {
-            const bool named = e0[j] < (uint32_t)H;
-            settled[j] = use[j] && named && k0[j] == pkey[j];
-            node[j] = e0[j];
-            if (use[j] && named && !settled[j]) slot[j] = (slot[j] + 1u) & (4u * (uint32_t)H - 1u);     // another node lives there: go on behind it
-        }
-        lds_index_find_or_insert<H, U>(L, slot, node, use, pkey, settled);
+        for (int j = 0; j < U; ++j) kv[j] = L.key[use[j] ? node[j] : 0u];
         GNDT_SUB(base == lo ? 1 : 2);
 #pragma unroll
         for (int j = 0; j < U; ++j) {
@@ -310,12 +437,23 @@ __device__ __forceinline__ void bucket_direct_one(BucketLds3<H>& L, const uint32
                 atomicMin(&L.first[s], cf[j]);
             }
         }
+#pragma unroll
+        for (int j = 0; j < U; ++j)
+            if (use[j] && kv[j] != pkey[j]) L.clash = 1;       // the sums just went to ANOTHER node: this table is given up (below)
         GNDT_SUB(3);
     }
 #ifdef GNDT_DIRECT_SUBSTAMPS
     if (dbg && tid == 0) { for (int k = 0; k < 4; ++k) dbg[(size_t)bucket * 16 + 8 + k] = st_acc[k]; }
 #endif
     __syncthreads();
+    if (L.clash && !L.overflow) {            // uniform; ~1 bucket in 10^4: a fingerprint named the wrong node and the sums went there
+        __syncthreads();                     // (everybody has read the flags)
+        bucket_tables_init<T, H>(L);
+        __syncthreads();
+        accumulate_exact<T, H>(L, recs, lo, hi, P, fp_mask);
+        if (tid == 0) atomicAdd(&pc->fp_clashes, 1u);
+        __syncthreads();
+    }
     GNDT_STAMP3(2);
     const uint32_t M = L.n_nodes;
     if (L.overflow || M > (uint32_t)H) {         // uniform
@@ -414,8 +552,8 @@ __device__ __forceinline__ void bucket_direct_one(BucketLds3<H>& L, const uint32
 #pragma unroll
             for (int side = 0; side < 2; ++side) {
                 const int tz = side == 0 ? za : zb;
-                const uint32_t t = lds_index_find<H>(L, node_slot3(colh, tz) & (4u * (uint32_t)H - 1u), pack_key(sx, sy, tz));
-                if (t != kIdxEmpty) {
+                const uint32_t t = lds_index_find<H>(L, node_slot3(colh, tz) & (4u * (uint32_t)H - 1u), node_fp_word(colh, tz, fp_mask), pack_key(sx, sy, tz));
+                if (t != kNoNode) {
                     const float oz2 = (L.first[t] < my_first) ? L.mz[t] : 0.f;            // "visited": seen earlier AND has statistics
                     const bool far = fabsf(oz2 - cz) > P.slope_interval;
                     if (side == 0) up = far; else down = far;
@@ -491,12 +629,12 @@ __global__ void __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(H <= 512
                                                      StageRow* __restrict__ stage, uint32_t stage_cap,
                                                      uint32_t* __restrict__ ord_cf, uint32_t* __restrict__ ord_idx, ColumnOrder O,
                                                      Counters* __restrict__ cnt, PartCounters* __restrict__ pc,
-                                                     unsigned long long* __restrict__ dbg, StatsOut so) {
+                                                     unsigned long long* __restrict__ dbg, StatsOut so, uint32_t fp_mask) {
     __shared__ BucketLds3<H> L;
     for (uint32_t bucket = blockIdx.x; bucket < num_buckets; bucket += gridDim.x) {
         uint32_t lo, hi;
         bucket_range(ranges, bucket, lo, hi);
-        bucket_direct_one<T, H, STATS>(L, bucket, recs, lo, hi, P, stage, stage_cap, ord_cf, ord_idx, O, cnt, pc, dbg, so);
+        bucket_direct_one<T, H, STATS>(L, bucket, recs, lo, hi, P, stage, stage_cap, ord_cf, ord_idx, O, cnt, pc, dbg, so, fp_mask);
         lds_barrier();          // the LDS tables are re-initialised by the next bucket
     }
 }

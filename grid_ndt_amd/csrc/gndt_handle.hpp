@@ -225,11 +225,13 @@ struct Tuning {
     int owner_sliced_rows = 1;   // GNDT_OWNER_SLICED   owner-partitioned build: every rank orders a slice of the index range (1) or all columns (0)
     int owner_locality = 1;      // GNDT_OWNER_LOCALITY owner-partitioned build: sampled block ownership (1) or hash ownership only (0)
     int update_tile = -1;        // GNDT_UPDATE_TILE    incremental updates through the tile kernel: 1 always, 0 never, -1 = by strategy
+    int fp_bits = 21;            // GNDT_FP_BITS        bits of the bucket kernel's index fingerprint (tests narrow it to force clashes)
     bool stamps = false;         // GNDT_STAMPS=1       in-kernel phase stamps of the bucket kernel
     bool verbose = false;        // GNDT_VERBOSE=1      stderr line per resolved two-level build
 };
 const Tuning& tuning();
 void tuning_force_stamps(bool on);   // bench.py --stamps flips this after the timed run
+void tuning_force_fp_bits(int bits); // tests: narrow the fingerprint so that clashes happen
 
 #define HIP_TRY(h, expr)                                                                                 \
     do {                                                                                                 \

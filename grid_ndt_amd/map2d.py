@@ -452,6 +452,15 @@ class TwoDmap:
     def enable_stamps(self, on=True):
         self._L.gndt_debug_enable_stamps(int(bool(on)))
 
+    def set_fp_bits(self, bits):
+        """Narrow the bucket kernel's index fingerprint (process-wide; tests: forces its exact second pass)."""
+        self._L.gndt_debug_set_fp_bits(int(bits))
+
+    def fp_clashes(self):
+        r = C.c_uint64()
+        self._check(self._L.gndt_debug_fp_clashes(self._h, C.byref(r)))
+        return int(r.value)
+
     def debug_bucket_phases(self):
         """Mean shader cycles per bucket of k_bucket_build's phases (needs GNDT_STAMPS=1 in the environment)."""
         arr = (C.c_double * 10)()

@@ -423,6 +423,12 @@ int gndt_debug_bucket_phases(gndt_handle* h, double cycles_out[10], uint32_t* bu
 int gndt_debug_retry_count(gndt_handle* h, uint64_t* retries);
 /* Switch the stamps on or off for the builds that follow (the environment is only read once per process). */
 int gndt_debug_enable_stamps(int on);
+/* The bucket kernel finds a node through a 21-bit fingerprint of its key and confirms it with the key itself; a bucket in
+ * which a fingerprint named the wrong node (~1 in 10^4) is accumulated a second time with every probe confirmed.  Tests narrow
+ * the fingerprint (0 .. 21 bits, process-wide, for the builds that follow) so that this happens in every bucket;
+ * gndt_debug_fp_clashes: buckets of the last resolved PARTITION build that took the second pass. */
+int gndt_debug_set_fp_bits(int bits);
+int gndt_debug_fp_clashes(gndt_handle* h, uint64_t* buckets);
 
 /* Library / device information for logs: returns 0 and fills what it can. */
 int gndt_device_info(int32_t device_id, char name_out[128], int32_t* compute_units, uint64_t* hbm_bytes);

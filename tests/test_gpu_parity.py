@@ -61,6 +61,29 @@ def test_parity_device_input(name, strategy):
     assert ran == {1: 1, 3: 3, 4: 2, 5: 5}[strategy], (name, ran)
 
 
+@pytest.mark.parametrize("bits", [0, 2, 6])
+def test_fingerprint_clash_takes_the_exact_second_pass(bits):
+    """The bucket kernel names a node by a 21-bit fingerprint of its key and confirms it with the key (gndt_bucket3.hpp); a bucket
+    where the fingerprint named the wrong node (~1 in 10^4) is accumulated again with every probe confirmed by the key.  With the
+    fingerprint narrowed to 0 / 2 / 6 bits that happens in (nearly) every bucket: the map must still be the oracle's."""
+    import grid_ndt_amd as g
+    try:
+        for name in ("campus_200k", "uniform_300k_z01", "site_zero_padded", "bridge_ground"):
+            cloud, P, ref = _case(name)
+            from grid_ndt_amd import _lib
+            _lib.lib().gndt_debug_set_fp_bits(bits)
+            for strategy in (3, 4):
+                m, out = parity.gpu_from_cloud(cloud, P, on_device=True, strategy=strategy)
+                parity.assert_parity(out, ref)
+                clashes = m.fp_clashes()
+                print(name, "bits", bits, "strategy", strategy, "buckets redone", clashes)
+                if bits <= 2:
+                    assert clashes > 0, (name, bits, strategy)
+    finally:
+        from grid_ndt_amd import _lib
+        _lib.lib().gndt_debug_set_fp_bits(21)
+
+
 @pytest.mark.parametrize("cells", [(0.5, 0.1), (0.1, 0.05)], ids=["launch_cells", "fine_cells"])
 def test_depth_camera_frame_every_strategy(cells):
     """One organised 640 x 480 depth frame (what BASELINE configs[0]'s .pcd files are): hundreds of points per node and hot
