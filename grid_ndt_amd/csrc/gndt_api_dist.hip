@@ -523,10 +523,12 @@ int owner_split_launch(gndt_handle* h, const void* xyz, size_t n, size_t stride_
         const dim3 g1(std::max<uint32_t>(1, std::min<uint32_t>(tiles, tuning().l1_wgs)));
         if (stride_bytes == 12)
             hipLaunchKernelGGL((k_part2_level1<3, 256, false, true>), g1, dim3(kTileThreads), 0, s, p, (uint64_t)n, (uint32_t)first_base, gp, W, W, 0u, 1u,
-                               q.totals, (uint32_t)cap, (uint32_t*)nullptr, X.send_recs, X.d_split_cnt, q.d_pc, compress, M);
+                               q.totals, (uint32_t)cap, (uint32_t*)nullptr, X.send_recs, X.d_split_cnt, q.d_pc, compress, M, (uint32_t*)nullptr,
+                               (uint32_t*)nullptr, 0ull);
         else
             hipLaunchKernelGGL((k_part2_level1<4, 256, false, true>), g1, dim3(kTileThreads), 0, s, p, (uint64_t)n, (uint32_t)first_base, gp, W, W, 0u, 1u,
-                               q.totals, (uint32_t)cap, (uint32_t*)nullptr, X.send_recs, X.d_split_cnt, q.d_pc, compress, M);
+                               q.totals, (uint32_t)cap, (uint32_t*)nullptr, X.send_recs, X.d_split_cnt, q.d_pc, compress, M, (uint32_t*)nullptr,
+                               (uint32_t*)nullptr, 0ull);
         HIP_TRY(h, hipGetLastError());
         X.split_cap = cap;
         uint32_t* h_base = X.h_matrix + (size_t)kMaxRanks * (kMaxRanks + 1);
@@ -952,7 +954,7 @@ int gndt_build_owned_device(gndt_handle* h, gndt_comm* c, const void* shard_xyz_
     if (global_row_dev) *global_row_dev = X.global_row;
     X.h_totals[2] = 0;                                    // slopes of the whole map: every rank's share came with its column message
     for (int r = 0; r < W; ++r) X.h_totals[2] += X.h_colmsg[kColMsgWords * r + 2];
-    X.owned_serial = h->result_serial; X.owned_world = (uint32_t)W;
+    X.owned_serial = h->result_serial; X.owned_world = (uint32_t)W; X.gathered = false;
     if (info) {
         float t[4] = {0, 0, 0, 0};
         for (int i = 0; i < 4; ++i) (void)hipEventElapsedTime(&t[i], ev[i], ev[i + 1]);
@@ -1036,12 +1038,15 @@ int gndt_gather_owned_map_device(gndt_handle* h, gndt_comm* c, int32_t root, voi
     const int W = c->world, me = c->rank;
     if (root >= W) { h->err = "root outside the communicator"; return GNDT_ERR_INVALID; }
     auto& X = h->exch;
-    // (Everything checked here is the same on all ranks after a successful gndt_build_owned_device with this communicator, so
-    // either all ranks return or none does.)
-    if (!h->results_valid || !X.owned_serial || X.owned_serial != h->result_serial || X.owned_world != (uint32_t)W) {
-        h->err = "gndt_gather_owned_map_device follows a successful gndt_build_owned_device on the same communicator";
+    // Everything checked here is the same on all ranks after a successful gndt_build_owned_device with this communicator, so
+    // either all ranks return or none does — ONCE per owned build: the root's handle holds the whole map afterwards (its owned
+    // rows are gone), so every rank, root or not, refuses a second gather of the same build here, before any collective.
+    // (Round 3 let the non-root ranks into the exchange of a second call while the old root had already returned: a hang.)
+    if (!h->results_valid || !X.owned_serial || X.owned_serial != h->result_serial || X.owned_world != (uint32_t)W || X.gathered) {
+        h->err = "gndt_gather_owned_map_device follows a successful gndt_build_owned_device on the same communicator, once per build";
         return GNDT_ERR_INVALID;
     }
+    X.gathered = true;
     hipStream_t s = stream_of(h, hip_stream);
     { const int urc = use_stream(h, s); if (urc) return urc; }
     const uint64_t N = X.h_totals[0], K = X.h_totals[1], S = X.h_totals[2];

@@ -151,6 +151,7 @@ struct gndt_handle {
         uint32_t* grec = nullptr; uint64_t grec_cap = 0;  uint32_t* grec_all = nullptr; uint64_t grec_all_cap = 0;
         uint32_t* d_tally = nullptr;  uint32_t* h_tally = nullptr;
         uint64_t owned_serial = 0;  uint32_t owned_world = 0;   // result_serial / ranks of the owned build global_row describes (0: none)
+        bool gathered = false;                                  // gndt_gather_owned_map_device has run for that build (every rank: once per build)
         uint32_t* d_status = nullptr;                           // scratch word for the status kernels
         // sliced global rows: the first row of every pair of this rank, everybody's pair places, this rank's, slice totals / rows
         uint32_t* row_of_pair = nullptr; uint64_t row_of_pair_cap = 0;  uint32_t* place_all = nullptr; uint64_t place_all_cap = 0;
@@ -191,6 +192,7 @@ struct gndt_handle {
         bool stats_only = false;        // gndt_shard_stats_device: statistics out, no labels / ordering / rows
         bool captured = false;          // launched on a stream under hipGraph capture: it runs when the graph is replayed, with the
                                         //   buffers it was recorded with — never re-run here with more room (new buffers: the graph holds the old)
+        bool replay_failed = false;     // the last replay of this build ran out of room (results_valid is false because of that, and only that)
         uint64_t done_serial = 0;       // result_serial when this build was resolved: while the handle still shows that serial, the map
                                         //   on the device can only have been replaced by a REPLAY of this build (hipGraph)
         gndt::GridParams gp{};          // origin and grid parameters AS THEY WERE when the build was launched: a retry

@@ -46,7 +46,8 @@ struct PartCounters {
     uint32_t part_overflow;    // two-level partition: reservations beyond a region's fixed capacity
     uint32_t max_fill1;        // two-level partition: fullest level-1 region (true count, also beyond its capacity: the
     uint32_t fp_clashes;       //   host sizes the retry from it); buckets done a second time because a fingerprint named the
-    uint32_t pad[2];           //   wrong node (gndt_bucket3.hpp; diagnostic)
+    uint32_t l1_ticket;        //   wrong node (gndt_bucket3.hpp; diagnostic); level-1 workgroups that are done (the last one lays
+    uint32_t pad;              //   out the buckets' regions; 0 between kernels)
 };
 
 struct alignas(16) StageRow {   // 96 bytes, gathered whole by k_emit_rows (round 1 padded it to 128: a quarter of the node traffic)
@@ -182,7 +183,7 @@ static __global__ void __launch_bounds__(256) k_part_clear(Counters* __restrict_
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         cnt->num_nodes = 0; cnt->num_columns = 0; cnt->num_slopes = 0; cnt->err_key_range = 0; cnt->err_table_full = 0;
         pc->lds_overflow = 0; pc->stage_overflow = 0; pc->index_overflow = 0; pc->part_overflow = 0;
-        pc->max_fill1 = 0; pc->fp_clashes = 0;
+        pc->max_fill1 = 0; pc->fp_clashes = 0; pc->l1_ticket = 0;
     }
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < words; i += (uint64_t)gridDim.x * blockDim.x) { bitmap[i] = 0u; word_weight[i] = 0u; }
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_cursors; i += gridDim.x * blockDim.x) cursors[i] = 0u;   // two-level partition
@@ -427,6 +428,45 @@ __device__ __forceinline__ void tile_partition(TileLds<PER, FAN>& L, const float
     }
 }
 
+// Region of every bucket from the sample level 1 took: capacity = 2 x the estimate + 2048 records.  (A bucket of c records
+// has c/64 +- sqrt(c/64) votes; it overflows if c > 2 x 64 x votes + 2048, which for c = 2000..5000 is 6 sigma or more away
+// and never happens below 2048: with 50 000 buckets, 1.6x + 1024 still overflowed a handful per build.)  LiDAR clouds' hot
+// columns simply get the room they need.  base = exclusive prefix.  Run by ONE workgroup of kTileThreads threads — the last
+// level-1 workgroup to finish (round 4: a launch of its own cost 6 us of a 0.38 ms build); writes lo[] (= base) and cap[].
+struct LayoutLds { uint32_t wsum[16]; uint32_t carry; uint32_t last; };
+template <int T>
+__device__ __forceinline__ void part2_layout(LayoutLds& S, const uint32_t* est2, uint32_t B, uint32_t* __restrict__ lo,
+                                             uint32_t* __restrict__ cap, uint64_t rec_capacity, PartCounters* __restrict__ pc) {
+    // A thread takes a contiguous run of buckets, kRun at a time with all of their loads in flight at once (one memory
+    // round trip per batch instead of one per element: the launch this replaces walked B / 1024 dependent rounds, 6 us).
+    constexpr uint32_t kRun = 8;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) S.carry = 0;
+    __syncthreads();
+    for (uint32_t b0 = 0; b0 < B; b0 += (uint32_t)T * kRun) {
+        const uint32_t mine = b0 + (uint32_t)tid * kRun;
+        uint32_t c[kRun], s = 0;
+#pragma unroll
+        for (uint32_t j = 0; j < kRun; ++j)      // (the votes were added by other workgroups with memory-side atomics: read them there as well)
+            c[j] = mine + j < B ? (uint32_t)((uint64_t)__hip_atomic_load(&est2[mine + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) * kSampleEvery * 2) + 2048u : 0u;
+#pragma unroll
+        for (uint32_t j = 0; j < kRun; ++j) s += c[j];
+        uint32_t incl = s;
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)incl, o, 64); if (lane >= o) incl += t; }
+        if (lane == 63) S.wsum[wave] = incl;
+        __syncthreads();
+        uint32_t run = S.carry + incl - s;
+        for (int w = 0; w < wave; ++w) run += S.wsum[w];
+#pragma unroll
+        for (uint32_t j = 0; j < kRun; ++j)
+            if (mine + j < B) { cap[mine + j] = c[j]; lo[mine + j] = run; run += c[j]; }
+        __syncthreads();
+        if (tid == T - 1) S.carry = run;
+        __syncthreads();
+    }
+    if (tid == 0 && (uint64_t)S.carry > rec_capacity) atomicAdd(&pc->part_overflow, 1u);
+}
+
 // level 1: the cloud -> coarse regions.  One tile per workgroup.  A coarse region can be split into R sub-regions
 // with their own cursors (tile t fills sub-region t % R) to spread the reservations of thousands of tiles over
 // more words (same-address atomics serialise at the memory side); with 4096-point tiles R = 1 measured best.
@@ -439,7 +479,8 @@ __global__ void __launch_bounds__(kTileThreads) __attribute__((amdgpu_waves_per_
                                                                uint32_t* __restrict__ cursor1, uint32_t cap1,
                                                                uint32_t* __restrict__ est2,
                                                                float4* __restrict__ recs1, Counters* __restrict__ cnt,
-                                                               PartCounters* __restrict__ pc, uint32_t compress, OwnerMap M) {
+                                                               PartCounters* __restrict__ pc, uint32_t compress, OwnerMap M,
+                                                               uint32_t* __restrict__ lay_lo, uint32_t* __restrict__ lay_cap, uint64_t rec_capacity) {
     constexpr int PER = kTilePer1;
     __shared__ TileLds<PER, FAN> L;
     // Persistent workgroups, software-pipelined: the loads of tile t+1 are in flight while tile t is keyed, sorted
@@ -523,36 +564,24 @@ __global__ void __launch_bounds__(kTileThreads) __attribute__((amdgpu_waves_per_
         tile_partition<PER, FAN>(L, r, dig, OWNER ? B : F1 * R, cursor1, cap1, 0ull, (uint64_t)cap1, nullptr, nullptr, recs1, pc);
         __syncthreads();                                   // the tile's LDS image is reused by the next iteration
     }
-}
-
-// Region of every bucket from the sample level 1 took: capacity = 2 x the estimate + 2048 records.  (A bucket of c records
-// has c/64 +- sqrt(c/64) votes; it overflows if c > 2 x 64 x votes + 2048, which for c = 2000..5000 is 6 sigma or more away
-// and never happens below 2048: with 50 000 buckets, 1.6x + 1024 still overflowed a handful per build.)  LiDAR clouds' hot
-// columns simply get the room they need.  base = exclusive prefix.  One workgroup; writes lo[] (= base) and cap[].
-static __global__ void __launch_bounds__(1024) k_part2_layout(const uint32_t* __restrict__ est2, uint32_t B, uint32_t* __restrict__ lo,
-                                                       uint32_t* __restrict__ cap, uint64_t rec_capacity,
-                                                       PartCounters* __restrict__ pc) {
-    __shared__ uint32_t wsum[16];
-    __shared__ uint32_t carry;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid == 0) carry = 0;
-    __syncthreads();
-    for (uint32_t b0 = 0; b0 < B; b0 += 1024) {
-        const uint32_t b = b0 + tid;
-        uint32_t c = 0;
-        if (b < B) { c = (uint32_t)((uint64_t)est2[b] * kSampleEvery * 2) + 2048u; cap[b] = c; }
-        uint32_t incl = c;
-        for (int o = 1; o < 64; o <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)incl, o, 64); if (lane >= o) incl += t; }
-        if (lane == 63) wsum[wave] = incl;
-        __syncthreads();
-        uint32_t base = carry + incl - c;
-        for (int w = 0; w < wave; ++w) base += wsum[w];
-        if (b < B) lo[b] = base;
-        __syncthreads();
-        if (tid == 1023) carry = base + c;
-        __syncthreads();
+    // Two-level partition: the LAST workgroup to get here lays out the buckets' regions for level 2 from everybody's votes
+    // (lay_lo == nullptr: one-level partition / owner split / not the last launch over a segmented input: nothing to lay out).
+    if constexpr (!OWNER) {
+        if (lay_lo) {                                      // uniform
+            LayoutLds& S = *reinterpret_cast<LayoutLds*>(&L);      // (the tile image is dead)
+            // This workgroup's votes are memory-side atomics: once they are acknowledged (vmcnt) they are where the last workgroup
+            // will read them, also memory-side.  NOT __threadfence(): an agent-scope release writes the L2 back — the records this
+            // kernel has just written — and cost 0.3 ms per build when every workgroup did it.
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (threadIdx.x == 0) S.last = atomicAdd(&pc->l1_ticket, 1u) == gridDim.x - 1u ? 1u : 0u;
+            __syncthreads();
+            if (S.last) {
+                part2_layout<kTileThreads>(S, est2, B, lay_lo, lay_cap, rec_capacity, pc);
+                if (threadIdx.x == 0) pc->l1_ticket = 0u;
+            }
+        }
     }
-    if (tid == 0 && (uint64_t)carry > rec_capacity) atomicAdd(&pc->part_overflow, 1u);
 }
 
 // level 2: sub-region blockIdx.y (of coarse region blockIdx.y / R), tile blockIdx.x of it -> that region's fine buckets
@@ -807,9 +836,10 @@ struct EmitPartial {
 
 static __global__ void __launch_bounds__(kBlock) k_emit_rows(const StageRow* __restrict__ stage, const uint32_t* __restrict__ inv,
                                                       OutView out, uint32_t* __restrict__ row_ncol,
-                                                      const Counters* __restrict__ cnt, const PartCounters* __restrict__ pc,
+                                                      const Counters* cnt, const PartCounters* __restrict__ pc,
                                                       Counters* __restrict__ host_cnt, PartCounters* __restrict__ host_pc,
                                                       Counters* tab_cnt, uint32_t advance, EmitPartial part) {
+    // (cnt is NOT __restrict__: on the table path tab_cnt points at the same object and lane 0 writes through it below)
     if (blockIdx.x == 0 && threadIdx.x < 2) {
         if (threadIdx.x == 0 && host_cnt) *host_cnt = *cnt;
         if (threadIdx.x == 1 && host_pc) *host_pc = *pc;

@@ -303,7 +303,8 @@ int gndt_build_owned_device(gndt_handle* h, gndt_comm* c, const void* shard_xyz_
  * whole cloud — to rank `root` (ncclSend / ncclRecv) or, with root < 0, to every rank (one padded all-gather), and scatters
  * them by that place into the handle's result arrays: the handle then HOLDS THE WHOLE MAP, in the reference's order, and
  * gndt_sync / gndt_export* / gndt_compute_cost / gndt_compat::TwoDmap work on it as after a single-GPU build.  Ranks other
- * than `root` keep the columns they own.  All ranks of the communicator call it, after a successful gndt_build_owned_device.
+ * than `root` keep the columns they own.  All ranks of the communicator call it, after a successful gndt_build_owned_device,
+ * ONCE per build (a second call fails with GNDT_ERR_INVALID on every rank, before any collective).
  * For hosts with their own transport the two device steps are exported:
  *   gndt_owned_pack_rows_device   this rank's rows as packed records (GNDT_PACKED_ROW_WORDS 32-bit words each; device pointer
  *                                 valid until the next call on the handle)

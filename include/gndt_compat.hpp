@@ -14,10 +14,14 @@
 // reference would instead include its own map2D.h and use gndt_compat::materialise_into() as a template
 // over its types.
 #pragma once
+#include <algorithm>
 #include <cfloat>
+#include <chrono>
 #include <cmath>
 #include <cstdint>
 #include <cstdlib>
+#include <cstring>
+#include <deque>
 #include <list>
 #include <map>
 #include <string>
@@ -97,53 +101,109 @@ inline std::string column_key(int32_t sx, int32_t sy) {
     return std::string(1, q) + buf;
 }
 
+// Where the element objects of one materialised map live: three allocations instead of three per node (round 3: 1.1-3.7 us per
+// node went into `new` + tree inserts — 96 ms for an 80 k-node frame behind a 0.06 ms build).  The reference allocates every
+// object with `new` and never frees it (src/receiver.cpp:62,85; map2D.h:598,632,648); a map filled through an arena is freed
+// with the arena instead, and row_slope[i] is the Slope of result row i (nullptr: not a slope) for whoever writes per-row
+// values back (apply_cost_into).
+template <class Node, class SlopeT, class CellT>
+struct MapArena {
+    std::vector<Node> nodes;
+    std::vector<SlopeT> slopes;
+    std::vector<CellT> cells;
+    std::vector<SlopeT*> row_slope;
+    void clear() { nodes.clear(); slopes.clear(); cells.clear(); row_slope.clear(); }
+};
+
+namespace detail {
+struct ColumnRun { uint64_t k_hi, k_lo; uint32_t first, count; };      // key characters packed big-endian: numeric order == std::string order
+inline void pack_key_chars(const std::string& k, uint64_t& hi, uint64_t& lo) {
+    unsigned char b[16] = {0};
+    std::memcpy(b, k.data(), k.size() < 16 ? k.size() : 16);
+    hi = 0; lo = 0;
+    for (int i = 0; i < 8; ++i) { hi = (hi << 8) | b[i]; lo = (lo << 8) | b[8 + i]; }
+}
+}  // namespace detail
+
 // Rebuild the reference containers from an export.  `Map` needs map_xy / morton_list / map_cell members of
-// the reference's shapes; Node/SlopeT/CellT are its element types.  Objects are allocated with `new`
+// the reference's shapes; Node/SlopeT/CellT are its element types.  Without an arena the objects are allocated with `new`
 // and owned by the caller, as in the reference (src/receiver.cpp:62,85; map2D.h:598,632,648).
+// Rows arrive grouped by column, columns in first-seen order (= morton_list order).  The ordered containers are filled in KEY
+// order — the columns' keys are sorted once (as packed integers) and every element goes in with the end() hint, an O(1) insert
+// with no string compares — which yields exactly the containers node-by-node insertion builds: std::map order is the key
+// order, equal keys of map_xy keep their insertion (= row) order, morton_list is filled in row order.
 template <class Map, class Node, class SlopeT, class CellT>
-void materialise_into(const gndt_cells& c, Map& out) {
-    std::string cur_key;
-    CellT* cell = nullptr;
-    int32_t cur_sx = 0, cur_sy = 0;
-    for (uint64_t i = 0; i < c.num_nodes; ++i) {
-        if (i == 0 || c.sx[i] != cur_sx || c.sy[i] != cur_sy) {      // rows are grouped by column, in morton_list order
-            cur_sx = c.sx[i]; cur_sy = c.sy[i];
-            cur_key = column_key(cur_sx, cur_sy);
-            out.morton_list.push_back(cur_key);                       // receiver.cpp:70
-            cell = new CellT(cur_key);                                // map2D.h:598-599
-            out.map_cell.insert(typename decltype(out.map_cell)::value_type(cur_key, cell));
+void materialise_into(const gndt_cells& c, Map& out, MapArena<Node, SlopeT, CellT>* arena = nullptr) {
+    const uint64_t n = c.num_nodes;
+    std::vector<detail::ColumnRun> cols;
+    std::vector<std::string> keys;
+    cols.reserve(c.num_columns ? c.num_columns : n / 2 + 1);
+    keys.reserve(cols.capacity());
+    uint64_t n_slopes = 0;
+    for (uint64_t i = 0; i < n; ++i) {
+        if (i == 0 || c.sx[i] != c.sx[i - 1] || c.sy[i] != c.sy[i - 1]) {
+            keys.push_back(column_key(c.sx[i], c.sy[i]));
+            detail::ColumnRun r{0, 0, (uint32_t)i, 0};
+            detail::pack_key_chars(keys.back(), r.k_hi, r.k_lo);
+            cols.push_back(r);
+            out.morton_list.push_back(keys.back());                   // receiver.cpp:70
         }
-        Node* node = new Node();
-        node->morton = cur_key;
-        node->z = c.sz[i];
-        node->count = c.count[i];
-        const bool has = (c.flags[i] & GNDT_FLAG_HAS_STATS) != 0;
-        if (has) {                                                    // map2D.h:621-625
-            node->N = (int)c.count[i];
-            for (int k = 0; k < 3; ++k) node->xyz_centroid(k) = c.mean[3 * i + k];
-            const float* u = c.cov + 6 * i;                           // xx,xy,xz,yy,yz,zz
-            node->covariance_matrix(0, 0) = u[0]; node->covariance_matrix(0, 1) = u[1]; node->covariance_matrix(0, 2) = u[2];
-            node->covariance_matrix(1, 0) = u[1]; node->covariance_matrix(1, 1) = u[3]; node->covariance_matrix(1, 2) = u[4];
-            node->covariance_matrix(2, 0) = u[2]; node->covariance_matrix(2, 1) = u[4]; node->covariance_matrix(2, 2) = u[5];
-        }
-        node->_isSlope = (c.flags[i] & GNDT_FLAG_SLOPE) != 0;
-        out.map_xy.insert(typename decltype(out.map_xy)::value_type(cur_key, node));   // equal keys keep insertion order
-        if (c.flags[i] & GNDT_FLAG_SLOPE) {                           // map2D.h:632-642 / 648-658
-            SlopeT* s = new SlopeT();
-            s->morton_xy = cur_key;
-            s->morton_z = c.sz[i];
-            s->down = (c.flags[i] & GNDT_FLAG_DOWN) != 0;
-            s->h = s->g = s->f = FLT_MAX;
-            for (int k = 0; k < 3; ++k) { s->mean(k) = c.mean[3 * i + k]; s->normal(k) = c.normal[3 * i + k]; }
-            s->father = nullptr;
-            s->rough = c.rough[i];
-            cell->map_slope.insert(std::make_pair((int)c.sz[i], s));
+        ++cols.back().count;
+        if (c.flags[i] & GNDT_FLAG_SLOPE) ++n_slopes;
+    }
+    if (arena) {
+        arena->clear();
+        arena->nodes.reserve(n); arena->slopes.reserve(n_slopes); arena->cells.reserve(cols.size());
+        arena->row_slope.assign(n, nullptr);
+    }
+    std::vector<uint32_t> order(cols.size());
+    for (uint32_t k = 0; k < order.size(); ++k) order[k] = k;
+    std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
+        return cols[a].k_hi != cols[b].k_hi ? cols[a].k_hi < cols[b].k_hi : cols[a].k_lo < cols[b].k_lo;
+    });
+    for (const uint32_t k : order) {
+        const std::string& key = keys[k];
+        CellT* cell;
+        if (arena) { arena->cells.emplace_back(key); cell = &arena->cells.back(); }
+        else cell = new CellT(key);                                   // map2D.h:598-599
+        out.map_cell.emplace_hint(out.map_cell.end(), key, cell);
+        for (uint64_t i = cols[k].first, e = (uint64_t)cols[k].first + cols[k].count; i < e; ++i) {
+            Node* node;
+            if (arena) { arena->nodes.emplace_back(); node = &arena->nodes.back(); }
+            else node = new Node();
+            node->morton = key;
+            node->z = c.sz[i];
+            node->count = c.count[i];
+            if (c.flags[i] & GNDT_FLAG_HAS_STATS) {                    // map2D.h:621-625
+                node->N = (int)c.count[i];
+                for (int q = 0; q < 3; ++q) node->xyz_centroid(q) = c.mean[3 * i + q];
+                const float* u = c.cov + 6 * i;                       // xx,xy,xz,yy,yz,zz
+                node->covariance_matrix(0, 0) = u[0]; node->covariance_matrix(0, 1) = u[1]; node->covariance_matrix(0, 2) = u[2];
+                node->covariance_matrix(1, 0) = u[1]; node->covariance_matrix(1, 1) = u[3]; node->covariance_matrix(1, 2) = u[4];
+                node->covariance_matrix(2, 0) = u[2]; node->covariance_matrix(2, 1) = u[4]; node->covariance_matrix(2, 2) = u[5];
+            }
+            node->_isSlope = (c.flags[i] & GNDT_FLAG_SLOPE) != 0;
+            out.map_xy.emplace_hint(out.map_xy.end(), key, node);     // equal keys keep insertion order
+            if (c.flags[i] & GNDT_FLAG_SLOPE) {                       // map2D.h:632-642 / 648-658
+                SlopeT* sl;
+                if (arena) { arena->slopes.emplace_back(); sl = &arena->slopes.back(); arena->row_slope[i] = sl; }
+                else sl = new SlopeT();
+                sl->morton_xy = key;
+                sl->morton_z = c.sz[i];
+                sl->down = (c.flags[i] & GNDT_FLAG_DOWN) != 0;
+                sl->h = sl->g = sl->f = FLT_MAX;
+                for (int q = 0; q < 3; ++q) { sl->mean(q) = c.mean[3 * i + q]; sl->normal(q) = c.normal[3 * i + q]; }
+                sl->father = nullptr;
+                sl->rough = c.rough[i];
+                cell->map_slope.insert(std::make_pair((int)c.sz[i], sl));
+            }
         }
     }
 }
 
 // Write the flood's h (gndt_cost_export, one value per result row) into the Slope objects of containers that
 // were materialised from the same export: what computeCost leaves behind in Slope::h (map2D.h:1301, 1329, 1340).
+// With the arena's row_slope it is one pass over the rows; without, the slopes are looked up by key.
 template <class Map>
 void apply_cost_into(const gndt_cells& c, const float* h, Map& out) {
     int32_t cur_sx = 0, cur_sy = 0;
@@ -157,6 +217,11 @@ void apply_cost_into(const gndt_cells& c, const float* h, Map& out) {
         auto it = cell->second->map_slope.find((int)c.sz[i]);
         if (it != cell->second->map_slope.end()) it->second->h = h[i];
     }
+}
+template <class SlopeT>
+void apply_cost_rows(const std::vector<SlopeT*>& row_slope, const float* h) {
+    for (size_t i = 0; i < row_slope.size(); ++i)
+        if (row_slope[i]) row_slope[i]->h = h[i];
 }
 
 // include/robot.h:12-46 (ROS-free; setPos/setGoal take the parsed vectors)
@@ -189,7 +254,78 @@ class TwoDmap {
     std::string last_error;
     CellsHost host;                     // the export the containers were built from (rows <-> Slope objects)
     gndt_cost_stats cost_stats{};
+    MapArena<OcNode, Slope, Cell> arena;   // the containers' objects (eager mode)
+    // lazy mode (create2DMap(..., lazy = true)): no containers; the consumers are served from the export by row index
+    bool lazy_mode = false;
+    struct ColumnSlot { int32_t sx, sy; uint32_t first, count; };     // count == 0: free
+    std::vector<ColumnSlot> col_index;                                  // open addressing, power-of-two size
+    std::deque<Slope> lazy_pool;                                        // Slope objects made on demand (stable addresses)
+    std::vector<Slope*> lazy_row_slope;                                 // row -> its Slope once somebody asked for it
+    std::vector<float> cost_h;                                          // the last flood's h per row (empty: none yet)
+    static uint32_t col_hash(int32_t sx, int32_t sy) {
+        uint32_t h = (uint32_t)sx * 0x9E3779B1u ^ (uint32_t)sy * 0x85EBCA77u;
+        return h ^ (h >> 15);
+    }
+    void build_column_index() {
+        const gndt_cells& c = host.view;
+        size_t cap = 16;
+        while (cap < 2 * (size_t)(c.num_columns ? c.num_columns : c.num_nodes) + 2) cap <<= 1;
+        col_index.assign(cap, ColumnSlot{0, 0, 0, 0});
+        for (uint64_t i = 0; i < c.num_nodes;) {
+            uint64_t e = i + 1;
+            while (e < c.num_nodes && c.sx[e] == c.sx[i] && c.sy[e] == c.sy[i]) ++e;
+            size_t p = col_hash(c.sx[i], c.sy[i]) & (cap - 1);
+            while (col_index[p].count) p = (p + 1) & (cap - 1);
+            col_index[p] = ColumnSlot{c.sx[i], c.sy[i], (uint32_t)i, (uint32_t)(e - i)};
+            i = e;
+        }
+    }
+    const ColumnSlot* find_column(int32_t sx, int32_t sy) const {
+        if (col_index.empty()) return nullptr;
+        const size_t cap = col_index.size();
+        for (size_t p = col_hash(sx, sy) & (cap - 1); col_index[p].count; p = (p + 1) & (cap - 1))
+            if (col_index[p].sx == sx && col_index[p].sy == sy) return &col_index[p];
+        return nullptr;
+    }
+    Slope* lazy_slope(uint32_t row) {
+        if (lazy_row_slope[row]) return lazy_row_slope[row];
+        const gndt_cells& c = host.view;
+        lazy_pool.emplace_back();
+        Slope* sl = &lazy_pool.back();
+        sl->morton_xy = column_key(c.sx[row], c.sy[row]);
+        sl->morton_z = c.sz[row];
+        sl->down = (c.flags[row] & GNDT_FLAG_DOWN) != 0;
+        for (int q = 0; q < 3; ++q) { sl->mean(q) = c.mean[3 * row + q]; sl->normal(q) = c.normal[3 * row + q]; }
+        sl->rough = c.rough[row];
+        if (!cost_h.empty()) sl->h = cost_h[row];
+        lazy_row_slope[row] = sl;
+        return sl;
+    }
+    static bool key_to_column(const std::string& key, int32_t& sx, int32_t& sy) {
+        if (key.size() < 2) return false;
+        int32_t x = 0, y = 0;
+        gndt_morton_to_xy((int32_t)std::atoi(key.c_str() + 1), &x, &y);
+        const char q = key[0];
+        sx = (q == 'A' || q == 'B') ? x : -x;
+        sy = (q == 'A' || q == 'C') ? y : -y;
+        return q >= 'A' && q <= 'D';
+    }
+    bool finish_build(bool lazy) {
+        const auto t0 = std::chrono::steady_clock::now();
+        clear();
+        lazy_mode = lazy;
+        if (lazy) {
+            build_column_index();
+            lazy_row_slope.assign(host.view.num_nodes, nullptr);
+        } else {
+            materialise_into<TwoDmap, OcNode, Slope, Cell>(host.view, *this, &arena);
+        }
+        timing.containers_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        return true;
+    }
 public:
+    // where the last create2DMap* spent its time on the host side of the seam (tools/host_path.cpp, bench.py "host_path")
+    struct Timing { double build_ms = 0, export_ms = 0, containers_ms = 0; } timing;
     std::multimap<std::string, OcNode*> map_xy;
     std::list<std::string> morton_list;
     std::list<std::string> changeMorton_list, delMorton_list;   // unused by the build path; kept for shape
@@ -224,20 +360,46 @@ public:
     // Replaces `for (i = 1 .. n-1) uniformDivision(points[i], false); map2D.create2DMap(demand);`
     // (src/receiver.cpp:150-160).  `xyz` = host pointer to point 1 (point 0 was given to setCloudFirst),
     // n = number of points to bin, stride_bytes = 12 or 16 (pcl::PointXYZ).
-    bool create2DMap(const std::string& demand, const void* xyz, size_t n, size_t stride_bytes) {
+    // lazy = true: the reference's containers (map_xy, morton_list, map_cell) are NOT filled — rebuilding them costs 100-1000x
+    // the GPU build (one heap node per tree entry) — and the consumers of this header (computeCost, AccessibleNeighbors,
+    // findSlope, AstarPlanar) are served from the exported rows instead, Slope objects being made only for the rows the
+    // planner touches.  Code that walks the containers itself needs lazy = false.
+    bool create2DMap(const std::string& demand, const void* xyz, size_t n, size_t stride_bytes, bool lazy = false) {
         const int d = (demand == "true") ? GNDT_DEMAND_TRUE : GNDT_DEMAND_SLOPE;
         if (!ensure_handle(d)) return false;
+        const auto t0 = std::chrono::steady_clock::now();
         int rc = gndt_set_origin(handle, cloudFirst.d);
         if (rc == GNDT_OK) rc = gndt_build(handle, xyz, n, stride_bytes);
         uint64_t nodes = 0, cols = 0, slopes = 0;
         if (rc == GNDT_OK) rc = gndt_sync(handle, &nodes, &cols, &slopes);
         if (rc != GNDT_OK) { last_error = gndt_last_error(handle); return false; }   // "wrong" (map2D.h:602-604)
+        const auto t1 = std::chrono::steady_clock::now();
         host.resize(nodes);
         rc = gndt_export(handle, &host.view);
         if (rc != GNDT_OK) { last_error = gndt_last_error(handle); return false; }
-        clear();
-        materialise_into<TwoDmap, OcNode, Slope, Cell>(host.view, *this);
-        return true;
+        const auto t2 = std::chrono::steady_clock::now();
+        timing.build_ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
+        timing.export_ms = std::chrono::duration<double, std::milli>(t2 - t1).count();
+        return finish_build(lazy);
+    }
+    bool isLazy() const { return lazy_mode; }
+
+    // map_cell.find(morton_xy)->second->map_slope.find(morton_z) (map2D.h:1294-1299, GlobalPlan.h:58-64) in either mode
+    Slope* findSlope(const std::string& morton_xy, int morton_z) {
+        if (!lazy_mode) {
+            auto it = map_cell.find(morton_xy);
+            if (it == map_cell.end()) return nullptr;
+            auto ss = it->second->map_slope.find(morton_z);
+            return ss == it->second->map_slope.end() ? nullptr : ss->second;
+        }
+        int32_t sx, sy;
+        if (!key_to_column(morton_xy, sx, sy)) return nullptr;
+        const ColumnSlot* col = find_column(sx, sy);
+        if (!col) return nullptr;
+        const gndt_cells& c = host.view;
+        for (uint32_t r = col->first; r < col->first + col->count; ++r)
+            if (c.sz[r] == morton_z && (c.flags[r] & GNDT_FLAG_SLOPE)) return lazy_slope(r);
+        return nullptr;
     }
 
     // Replaces TwoDmap::computeCost (include/map2D.h:1285-1397; receiver.cpp:171): the flood runs on the GPU over the
@@ -251,7 +413,13 @@ public:
         std::vector<float> h(host.view.num_nodes);
         if (rc == GNDT_OK) rc = gndt_cost_export(handle, h.data(), nullptr, &cost_stats);
         if (rc != GNDT_OK) { last_error = gndt_last_error(handle); return false; }
-        if (cost_stats.goal_status == 0) apply_cost_into(host.view, h.data(), *this);
+        if (cost_stats.goal_status == 0) {
+            if (lazy_mode) {                            // slopes made from now on take their h from here; the ones that exist are updated
+                cost_h.swap(h);
+                for (size_t i = 0; i < lazy_row_slope.size(); ++i) if (lazy_row_slope[i]) lazy_row_slope[i]->h = cost_h[i];
+            } else if (arena.row_slope.size() == host.view.num_nodes) apply_cost_rows(arena.row_slope, h.data());
+            else apply_cost_into(host.view, h.data(), *this);
+        }
         return true;
     }
     const gndt_cost_stats& costStats() const { return cost_stats; }
@@ -279,6 +447,17 @@ public:
         int zadd = s->morton_z + 1;
         if (s->morton_z == -1) zadd = 1;
         bool zup = false;
+        if (lazy_mode) {                                   // the column's nodes in row (= map_xy insertion) order; no statistics: centroid 0
+            int32_t sx, sy;
+            const ColumnSlot* col = key_to_column(s->morton_xy, sx, sy) ? find_column(sx, sy) : nullptr;
+            const gndt_cells& c = host.view;
+            for (uint32_t r = col ? col->first : 0; col && r < col->first + col->count && !zup; ++r) {
+                const float cz = (c.flags[r] & GNDT_FLAG_HAS_STATS) ? c.mean[3 * r + 2] : 0.f;
+                if (zadd == c.sz[r] && std::fabs(cz - s->mean(2)) > slope_interval) zup = true;
+            }
+            s->up = zup;
+            return zup;
+        }
         for (auto it = map_xy.find(s->morton_xy); it != map_xy.end() && it->first == s->morton_xy && !zup; ++it)
             if (zadd == it->second->z && std::fabs(it->second->xyz_centroid(2) - s->mean(2)) > slope_interval) zup = true;
         s->up = zup;
@@ -296,18 +475,32 @@ public:
         const int sx = (q == 'A' || q == 'B') ? x : -x, sy = (q == 'A' || q == 'C') ? y : -y;
         auto step = [](int v, int d) { int r = v + d; if (r == 0) r += d; return r; };   // no cell 0 (map2D.h:226-255)
         const int nb[4][2] = {{sx, step(sy, -1)}, {sx, step(sy, +1)}, {step(sx, +1), sy}, {step(sx, -1), sy}};
+        auto visit = [&](Slope* s) {
+            if (comand == 3) { list.push_back(s); return; }
+            if (comand == 4) s->up = countUp(s);
+            if (s->up) return;
+            if (s->rough <= robot.getRough() && countAngle(s->normal, slope->normal) <= robot.getAngle() &&
+                std::fabs(s->mean(2) - slope->mean(2)) <= robot.getReachableHeight())
+                list.push_back(s);
+        };
         for (const auto& c : nb) {
+            if (lazy_mode) {                               // the cell's slopes in ascending z, as map_slope iterates them
+                const ColumnSlot* col = find_column(c[0], c[1]);
+                if (!col) continue;
+                uint32_t rows[64];
+                std::vector<uint32_t> more;
+                uint32_t m = 0;
+                for (uint32_t r = col->first; r < col->first + col->count; ++r)
+                    if (host.view.flags[r] & GNDT_FLAG_SLOPE) { if (m < 64) rows[m] = r; else more.push_back(r); ++m; }
+                if (!more.empty()) { more.insert(more.begin(), rows, rows + 64); }
+                uint32_t* rr = more.empty() ? rows : more.data();
+                std::sort(rr, rr + m, [&](uint32_t a, uint32_t b) { return host.view.sz[a] < host.view.sz[b]; });
+                for (uint32_t k = 0; k < m; ++k) visit(lazy_slope(rr[k]));
+                continue;
+            }
             auto mit = map_cell.find(column_key(c[0], c[1]));
             if (mit == map_cell.end()) continue;
-            for (auto& kv : mit->second->map_slope) {
-                Slope* s = kv.second;
-                if (comand == 3) { list.push_back(s); continue; }
-                if (comand == 4) s->up = countUp(s);
-                if (s->up) continue;
-                if (s->rough <= robot.getRough() && countAngle(s->normal, slope->normal) <= robot.getAngle() &&
-                    std::fabs(s->mean(2) - slope->mean(2)) <= robot.getReachableHeight())
-                    list.push_back(s);
-            }
+            for (auto& kv : mit->second->map_slope) visit(kv.second);
         }
         return list;
     }
@@ -315,7 +508,7 @@ public:
     // The whole of chatterCallback's front half (src/receiver.cpp:140-160) from a raw cloud: records as a PointCloud2 /
     // .pcd payload lays them out -> NaN rows dropped on the device (publisher.cpp:24-26), origin := the first valid
     // point (receiver.cpp:145), division + create2DMap of the rest.
-    bool create2DMapFromRaw(const std::string& demand, const void* raw, size_t n, const gndt_point_layout& layout) {
+    bool create2DMapFromRaw(const std::string& demand, const void* raw, size_t n, const gndt_point_layout& layout, bool lazy = false) {
         const int d = (demand == "true") ? GNDT_DEMAND_TRUE : GNDT_DEMAND_SLOPE;
         if (!ensure_handle(d)) return false;
         int rc = gndt_build_cloud(handle, raw, n, &layout);
@@ -326,18 +519,32 @@ public:
         host.resize(nodes);
         rc = gndt_export(handle, &host.view);
         if (rc != GNDT_OK) { last_error = gndt_last_error(handle); return false; }
-        clear();
-        materialise_into<TwoDmap, OcNode, Slope, Cell>(host.view, *this);
-        return true;
+        return finish_build(lazy);
     }
 
-    void clear() {
-        for (auto& kv : map_xy) delete kv.second;
-        for (auto& kv : map_cell) {
-            for (auto& s : kv.second->map_slope) delete s.second;
-            delete kv.second;
+    // Fill the containers from an export made elsewhere (tests, the sharded build's gathered map): eager mode.
+    void adopt(const gndt_cells& c) {
+        clear();
+        lazy_mode = false;
+        if (c.sx == host.view.sx && c.num_nodes == host.view.num_nodes) {      // this map's own export: nothing to copy
+            materialise_into<TwoDmap, OcNode, Slope, Cell>(host.view, *this, &arena);
+            return;
         }
+        const uint64_t k_cols = c.num_columns, k_slopes = c.num_slopes;
+        host.resize(c.num_nodes);
+        host.view.num_columns = k_cols; host.view.num_slopes = k_slopes;
+        const size_t n = c.num_nodes;
+        std::memcpy(host.sx.data(), c.sx, 4 * n); std::memcpy(host.sy.data(), c.sy, 4 * n); std::memcpy(host.sz.data(), c.sz, 4 * n);
+        std::memcpy(host.count.data(), c.count, 4 * n); std::memcpy(host.first_idx.data(), c.first_idx, 4 * n);
+        std::memcpy(host.flags.data(), c.flags, 4 * n); std::memcpy(host.mean.data(), c.mean, 12 * n);
+        std::memcpy(host.cov.data(), c.cov, 24 * n); std::memcpy(host.rough.data(), c.rough, 4 * n); std::memcpy(host.normal.data(), c.normal, 12 * n);
+        materialise_into<TwoDmap, OcNode, Slope, Cell>(host.view, *this, &arena);
+    }
+
+    void clear() {                                         // (the objects live in the arena / the lazy pool, not in `new`s of their own)
         map_xy.clear(); map_cell.clear(); morton_list.clear();
+        arena.clear();
+        col_index.clear(); lazy_pool.clear(); lazy_row_slope.clear(); cost_h.clear();
     }
 
 private:
@@ -356,10 +563,7 @@ private:
     }
 };
 
-inline void materialise(const gndt_cells& c, TwoDmap& out) {
-    out.clear();
-    materialise_into<TwoDmap, OcNode, Slope, Cell>(c, out);
-}
+inline void materialise(const gndt_cells& c, TwoDmap& out) { out.adopt(c); }
 
 // include/GlobalPlan.h:15-166 — the A* planner that consumes Slope::h, restated against these containers with the
 // reference's own quirks kept: the open queue is a multimap on f; isContaninedOpen only looks at the entries whose
@@ -392,13 +596,11 @@ public:
         bool route = false;
         map2D.transMortonXYZ(start, morton_xy, morton_z);
         map2D.transMortonXYZ(goal, g_xy, g_z);
-        auto it = map2D.map_cell.find(morton_xy);
-        if (it == map2D.map_cell.end()) return false;
-        auto ss = it->second->map_slope.find(morton_z);
-        if (ss == it->second->map_slope.end()) return false;
-        ss->second->g = 0;
-        ss->second->f = ss->second->g + ss->second->h;
-        open_queue.insert(std::make_pair(ss->second->f, ss->second));
+        Slope* first = map2D.findSlope(morton_xy, morton_z);         // (map_cell.find / map_slope.find, GlobalPlan.h:58-64)
+        if (!first) return false;
+        first->g = 0;
+        first->f = first->g + first->h;
+        open_queue.insert(std::make_pair(first->f, first));
         const float comand = (demand == "true") ? 4.f : 2.5f;
         while (!open_queue.empty()) {
             auto it_open = open_queue.begin();

@@ -42,12 +42,12 @@
 #include <cstring>
 #include <list>
 #include <map>
+#include <memory>
 #include <string>
 #include <unordered_map>
 #include <vector>
 #ifdef _OPENMP
 #include <omp.h>
-#include <memory>
 #include <parallel/algorithm>
 #endif
 

@@ -486,6 +486,42 @@ def test_gathered_owner_build_is_the_single_gpu_map_and_floods_like_it(W, root):
         c.close()
 
 
+def test_a_second_gather_of_the_same_build_is_refused_on_every_rank():
+    """After a rooted gather the root's handle holds the whole map and no longer its owned rows.  A second gather of the same build
+    is refused on EVERY rank before any collective (round 3: the old root returned and the others waited in the exchange for ever);
+    a new owned build makes the gather legal again."""
+    import torch
+    from grid_ndt_amd._lib import GndtError
+    from grid_ndt_amd.dist import Communicator
+    W = 3
+    cloud, P = scenes.campus_frame(90_000), scenes.CAMPUS_PARAMS
+    maps, comms = _ranks(cloud, P, W), Communicator.threads(W)
+    pts = torch.from_numpy(np.ascontiguousarray(cloud[1:])).cuda()
+    n = int(pts.shape[0])
+    bounds = [n * r // W for r in range(W + 1)]
+
+    def rank(r):
+        torch.cuda.set_device(0)
+        s = torch.cuda.Stream()
+        codes = []
+        with torch.cuda.stream(s):
+            for root in (0, 1):
+                maps[r].build_owned(comms[r], P["demand"], pts[bounds[r]:bounds[r + 1]], bounds[r], n, s)
+                maps[r].gather_owned(comms[r], root, s)
+                try:
+                    maps[r].gather_owned(comms[r], (root + 1) % W, s)
+                    codes.append(0)
+                except GndtError as e:
+                    codes.append(e.code)
+        return codes
+
+    res, errs = _threads(W, rank)
+    assert not errs, errs
+    assert all(c == [1, 1] for c in res), res          # GNDT_ERR_INVALID everywhere, twice; nobody hung
+    for c in comms:
+        c.close()
+
+
 def test_a_failing_rank_takes_every_rank_out_of_the_owner_build_together():
     """One rank's shard holds a point outside the key range.  Nobody hangs: that rank reports KEY_RANGE, the others PEER, all
     at the same collective; the same communicators and handles then build a clean cloud."""

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Run on the MI355X box (gpurun): kernel-trace statistics and the two PMC passes of the bench workload.
 #   tools/collect_profiles.sh <tag>     -> gpurun_out/<tag>_{kernel_stats.csv,pmc.json,bench.json}
-case " $* " in *" --gpus "*) echo "$0: single-process runs only: rocprofv3 has initialised the GPU before bench.py starts, and bench.py --gpus N would start torchrun from that process" >&2; exit 2;; esac
+. "$(dirname "$0")/_single_process_guard.sh"
 set -e
 tag=${1:-prof}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"

@@ -2,6 +2,7 @@
 # PC sampling of the bench workload on the GPU box (rocprofv3 beta feature; stochastic = hardware sampling with stall reasons).
 #   tools/pc_sample.sh <tag> [bench args...]   -> gpurun_out/<tag>_pcsamp/
 tag=$1; shift
+. "$(dirname "$0")/_single_process_guard.sh"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 out=gpurun_out/${tag}_pcsamp
 rm -rf $out; mkdir -p $out

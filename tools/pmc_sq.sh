@@ -1,7 +1,7 @@
 #!/bin/bash
 # SQ counters per kernel for one bench.py invocation (run on the GPU box):  tools/pmc_sq.sh <tag> [bench args...]
 # Two passes of 8 SQ counters each (rocprofv3 --pmc only, no tracing beside it), summarised per kernel name.
-case " $* " in *" --gpus "*) echo "$0: single-process runs only: rocprofv3 has initialised the GPU before bench.py starts, and bench.py --gpus N would start torchrun from that process" >&2; exit 2;; esac
+. "$(dirname "$0")/_single_process_guard.sh"
 tag=$1; shift
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 out=gpurun_out
