@@ -63,6 +63,8 @@ def parse():
                          "by owner) or 'global' (statistics all-reduced, whole map on every rank) — or independent per-rank maps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the single-build latency / no-hint / H2D-D2H measurements")
+    ap.add_argument("--no-configs", action="store_true", help="skip the `configs` block (the other BASELINE.json configurations, untimed by `value`) "
+                                                              "and the `host_path` block (the seam's host side, stage by stage)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="points of the CPU baseline's sample (0 = the whole workload, capped at 10 M)")
     ap.add_argument("--check", action="store_true", help="also check a 300 k-point build against the oracle")
     ap.add_argument("--stamps", action="store_true",
@@ -190,6 +192,151 @@ def cpu_baseline(origin, pts, P, sample):
             "same_code_one_core": {"value": round(sample / (d1 + c1) / 1e6, 4), "unit": "Mpoints/s", "cores": 1},
             "as_shipped_serial": {"value": round(n_ser / dt0 / 1e6, 4), "unit": "Mpoints/s", "cores": 1,
                                   "sample": f"first {n_ser} points, oracle mode 0 (strings + multimap, as the reference runs)"}}
+
+
+def _timed_builds(g, torch, cloud, P, steps, hint=0, strategy=0, demand="slope"):
+    """ms per back-to-back build of `cloud` (device-resident) on a warmed-up handle + what a FRESH handle's first build costs."""
+    pts = torch.from_numpy(np.ascontiguousarray(cloud[1:])).cuda()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    m = g.TwoDmap(P["grid_len"], P["z_len"], max_nodes_hint=hint, strategy=strategy)
+    m.setInterval(P["slope_interval"])
+    m.setCloudFirst(cloud[0])
+    m.create2DMap(demand, pts)
+    m.sync()
+    first_ms = (time.perf_counter() - t0) * 1e3
+    first_retries = m.retry_count()
+    for _ in range(3):
+        m.create2DMap(demand, pts)
+        m.sync()
+    torch.cuda.synchronize()
+    r0 = m.retry_count()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        m.create2DMap(demand, pts)
+    nodes, cols, slopes = m.sync()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    n = cloud.shape[0] - 1
+    return {"points": int(n), "nodes": int(nodes), "ms_per_build": round(dt * 1e3, 4), "Mpoints_per_s": round(n / dt / 1e6, 1),
+            "strategy": m.STRATEGY_NAMES[m.last_strategy()], "path_frac": round((12 * n + 76 * nodes) / dt / (HBM_PEAK_GBS * 1e9), 5),
+            "retries": int(m.retry_count() - r0), "steps": steps,
+            "first_build_ms": round(first_ms, 3), "first_build_re_runs": int(first_retries)}
+
+
+def _stream_latency(g, torch, frames, ppf, nframes, graph_mode):
+    """S4: one gndt_update per 131 072-point frame; per-frame latency (launch -> device idle) and the back-to-back rate."""
+    dev_frames = [torch.from_numpy(frames[f * ppf:(f + 1) * ppf]).cuda() for f in range(nframes)]
+    m = g.TwoDmap(0.2, 0.2, strategy=1, max_nodes_hint=4_000_000, max_points_hint=nframes * ppf)
+    m.setInterval(0.08)
+    m.setCloudFirst(frames[0])
+    buf = torch.empty(ppf, 3, dtype=torch.float32, device="cuda")
+    buf.copy_(dev_frames[0])
+    m.change2DMap("slope", buf)
+    m.sync()
+    graph = None
+    if graph_mode:
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            m.change2DMap("slope", buf)
+    lat = []
+    half = nframes // 2
+    torch.cuda.synchronize()
+    for f in range(1, half):                       # first half: one awaited frame at a time
+        buf.copy_(dev_frames[f])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        graph.replay() if graph else m.change2DMap("slope", buf)
+        torch.cuda.synchronize()
+        lat.append((time.perf_counter() - t0) * 1e3)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for f in range(half, nframes):                 # second half: back to back
+        buf.copy_(dev_frames[f])
+        graph.replay() if graph else m.change2DMap("slope", buf)
+    torch.cuda.synchronize()                      # (a replayed graph runs on torch's stream, not on the one it was captured on, which is all m.sync() waits for)
+    b2b = (time.perf_counter() - t0) / (nframes - half) * 1e3
+    nodes, _, _ = m.sync()
+    lat = np.sort(np.array(lat[2:]))
+    return {"p50_ms": round(float(np.percentile(lat, 50)), 4), "p99_ms": round(float(np.percentile(lat, 99)), 4),
+            "back_to_back_ms_per_frame": round(b2b, 4), "nodes_at_the_end": int(nodes)}
+
+
+def measure_configs(g, torch, s2_cloud_host):
+    """The BASELINE.json configurations other than the bench line, each on ONE GPU, untimed by `value`:
+    configs[0] S1 (campus stand-in, the reference's own bridge_ground scene, an organised depth frame), configs[1]'s launch-default
+    z variant, configs[2] / [4] at a size whose generation fits the default run (said in the key), configs[3] S4 eager and replayed."""
+    from grid_ndt_amd import scenes
+    out = {}
+    out["S1_campus_200k"] = _timed_builds(g, torch, scenes.campus_frame(200_001), scenes.CAMPUS_PARAMS, steps=30)
+    out["S1_bridge_ground_360k"] = _timed_builds(g, torch, scenes.bridge_ground(), scenes.BRIDGE_PARAMS, steps=30)
+    out["S1_depth_frame_215k"] = _timed_builds(g, torch, scenes.depth_frame(), scenes.DEPTH_PARAMS, steps=30)
+    if s2_cloud_host is not None:
+        out["S2_first_build"] = {k: v for k, v in _timed_builds(g, torch, s2_cloud_host, dict(grid_len=0.5, z_len=0.5, slope_interval=0.08), steps=3).items()
+                                 if k in ("first_build_ms", "first_build_re_runs", "points", "nodes")}
+        out["S2z_10M_z01"] = _timed_builds(g, torch, s2_cloud_host, dict(grid_len=0.5, z_len=0.1, slope_interval=0.08), steps=10, hint=3_400_000)
+    r = _timed_builds(g, torch, scenes.terrain_cloud(8_000_001), dict(grid_len=0.2, z_len=0.2, slope_interval=0.08), steps=10)
+    r["note"] = "8 M of configs[2]'s 100 M points (scene generation time); the full size on one GPU: bench.py --workload S3 --points 100000000"
+    out["S3_terrain_8M"] = r
+    r = _timed_builds(g, torch, scenes.site_two_storey(5_000_001), dict(grid_len=0.1, z_len=0.1, slope_interval=0.08), steps=10)
+    r["note"] = "5 M of configs[4]'s 20 M points, 15 % of them at (0,0,0); the full size: bench.py --workload S5"
+    out["S5_site_5M"] = r
+    nframes, ppf = 48, scenes.FRAME_POINTS
+    frames = scenes.terrain_frames(nframes, 0)
+    out["S4_stream_131k_frames"] = {"frames": nframes, "budget_ms": 100.0, "eager": _stream_latency(g, torch, frames, ppf, nframes, False),
+                                    "hip_graph_replay": _stream_latency(g, torch, frames, ppf, nframes, True)}
+    return out
+
+
+def build_host_path_tool():
+    """tools/host_path (C++: gndt_compat.hpp over the C ABI), built in-tree like the examples."""
+    from grid_ndt_amd import _lib
+    exe = os.path.join(ROOT, "tools", "host_path")
+    src = exe + ".cpp"
+    deps = [src, os.path.join(ROOT, "include", "gndt_compat.hpp"), os.path.join(ROOT, "include", "gndt.h"), _lib.LIB_PATH]
+    if not os.path.exists(exe) or any(os.path.getmtime(d) > os.path.getmtime(exe) for d in deps):
+        csrc = os.path.dirname(_lib.LIB_PATH)
+        hip = _lib._hip_runtime_dir()
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-D__HIP_PLATFORM_AMD__", "-I", os.path.join(ROOT, "include"), "-I", "/opt/rocm/include",
+                               "-o", exe, src, "-L", csrc, "-l:libgndt.so", "-L", hip, "-l:libamdhip64.so", f"-Wl,-rpath,{csrc}", f"-Wl,-rpath,{hip}"])
+    return exe
+
+
+def measure_host_path():
+    """The HOST side of the seam (src/receiver.cpp:140-175) for configs[0]-sized clouds, stage by stage, through the C++ mirror of
+    the reference's API (include/gndt_compat.hpp): host cloud -> gndt_build + gndt_sync -> gndt_export_host -> containers ->
+    computeCost -> findRoute, eager (containers rebuilt) and lazy (consumers served from the exported rows), beside what the
+    oracle's as-shipped restatement of the reference's two loops takes on this box.  A child process: plain C++, no torch."""
+    import tempfile
+    from grid_ndt_amd import scenes
+    from oracle import oracle
+    exe = build_host_path_tool()
+    out = {}
+    site = scenes.drivable_site(400_000)
+    start = (-20.0, 10.0, float(0.35 * np.sin(-20.0 / 7.0) + 0.25 * np.cos(10.0 / 5.0)))
+    cases = (("S1_campus_200k", scenes.campus_frame(200_001), scenes.CAMPUS_PARAMS, (10.0, -10.0, 0.7), (30.0, -30.0, 0.4)),
+             ("S1_bridge_ground_360k", scenes.bridge_ground(), scenes.BRIDGE_PARAMS, (9.5, 3.0, 1.0), (9.5, 3.0, 3.0)),      # parameters.txt:53-59
+             ("drivable_site_400k", site, scenes.COST_PARAMS, scenes.DRIVABLE_GOAL, start))
+    with tempfile.TemporaryDirectory() as td:
+        for name, cloud, P, goal, st in cases:
+            fn = os.path.join(td, name + ".f32")
+            np.ascontiguousarray(cloud, np.float32).tofile(fn)
+            cmd = [exe, fn, str(cloud.shape[0]), repr(P["grid_len"]), repr(P["z_len"]), repr(P["slope_interval"]), P.get("demand", "slope")] + \
+                  [repr(float(v)) for v in goal] + [repr(float(v)) for v in st] + ["0.25", "7"]
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+            try:
+                rec = json.loads(r.stdout.strip().splitlines()[-1])
+            except Exception:
+                rec = {"error": (r.stdout + r.stderr)[-300:]}
+            t0 = time.perf_counter()
+            ro = oracle.build_grid(cloud, P["grid_len"], P["z_len"], P["slope_interval"], P.get("demand", "slope"), mode=oracle.MODE_AS_SHIPPED, export=False)
+            rec["oracle_as_shipped_ms"] = {"division": round(ro["t_division"] * 1e3, 1), "calculate": round(ro["t_calculate"] * 1e3, 1),
+                                           "what": "the reference's two loops (receiver.cpp:150-160) as restated by the oracle, 1 core, this box"}
+            out[name] = rec
+    out["what"] = ("tools/host_path.cpp: medians of 7 (ms); build_sync = gndt_build from a pageable host buffer + gndt_sync; export = gndt_export_host "
+                   "(pinned mirror); containers = materialise_into (eager) or the column index (lazy); never part of `value`")
+    return out
+
 
 
 def committed_traffic(kernel_substr):
@@ -605,6 +752,33 @@ def main():
         extras["h2d_cloud_ms"] = round(t_h2d * 1e3, 3)
         extras["pcie_note"] = "pageable host memory, torch copy; never part of `value`"
         del res
+        # host buffer -> map on the device through the C ABI (gndt_build = stage + build, then gndt_sync): pageable and pinned
+        hb = {}
+        for label, arr in (("pageable", host_pts), ("pinned", torch.from_numpy(host_pts).pin_memory())):
+            for _ in range(2):
+                m.create2DMap("slope", arr)
+                m.sync()
+            ts = []
+            for _ in range(5):
+                t1 = time.perf_counter()
+                m.create2DMap("slope", arr)
+                m.sync()
+                ts.append((time.perf_counter() - t1) * 1e3)
+            hb[label + "_ms"] = round(float(np.median(ts)), 3)
+        hb["what"] = "gndt_build from a HOST buffer (H2D staging + build) + gndt_sync, median of 5; PCIe-inclusive, never `value`"
+        extras["host_build"] = hb
+    if world == 1 and not a.no_configs and not global_mode and rank == 0:
+        watchdog(0)
+        s2_host = np.concatenate([origin[None, :], host_pts], 0) if wname == "S2" and total == WORKLOADS["S2"]["points"] else None
+        del pts
+        torch.cuda.empty_cache()
+        extras["configs"] = measure_configs(g, torch, s2_host)
+        del s2_host
+        try:
+            extras["host_path"] = measure_host_path()
+        except Exception as e:            # (a missing g++ must not cost the bench line)
+            extras["host_path"] = {"error": f"{type(e).__name__}: {e}"}
+        pts = torch.from_numpy(host_pts).to(dev)
 
     if rank == 0:
         ms_step = dt / a.steps * 1e3

@@ -173,6 +173,10 @@ def lib():
     L.gndt_sync.argtypes = [H, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64)]
     L.gndt_export_device.argtypes = [H, C.POINTER(Cells)]
     L.gndt_export.argtypes = [H, C.POINTER(Cells)]
+    L.gndt_export_host.argtypes = [H, C.POINTER(Cells)]
+    L.gndt_reserve.argtypes = [H, u64, u64]
+    L.gndt_reserve.restype = C.c_int
+    L.gndt_export_host.restype = C.c_int
     L.gndt_stats_export_device.argtypes = [H, C.POINTER(Stats), vp]
     L.gndt_stats_merge_device.argtypes = [H, C.POINTER(Stats), vp]
     L.gndt_shard_stats_device.argtypes = [H, vp, C.c_size_t, C.c_size_t, u64, C.POINTER(Stats), vp]

@@ -170,6 +170,7 @@ int partition_launch(gndt_handle* h, gndt_handle::Pending& P) {
         if ((rc = grow_buf(h, q.recs1, q.rec1_cap, (uint64_t)V * cap1))) return rc;
         if ((rc = grow_buf(h, q.recs, q.rec_cap, recs_want))) return rc;
         if (B > q.cur_cap) {
+            GNDT_NO_CAPTURE(h, "the partition cursors");
             for (uint32_t** a : {&q.cursors, &q.range_lo, &q.range_hi, &q.range_cap}) { if (*a) (void)hipFree(*a); *a = nullptr; }
             q.cur_cap = 0;
             const uint64_t c = (uint64_t)B + B / 4;
@@ -232,6 +233,7 @@ int partition_launch(gndt_handle* h, gndt_handle::Pending& P) {
         const uint32_t cap1 = (uint32_t)std::max<uint64_t>(4 * mean, mean + 4096);
         if ((rc = grow_buf(h, q.recs1, q.rec1_cap, (uint64_t)B * cap1))) return rc;
         if (B > q.cur_cap) {
+            GNDT_NO_CAPTURE(h, "the partition cursors");
             for (uint32_t** a : {&q.cursors, &q.range_lo, &q.range_hi, &q.range_cap}) { if (*a) (void)hipFree(*a); *a = nullptr; }
             q.cur_cap = 0;
             const uint64_t c = (uint64_t)B + B / 4;
@@ -286,6 +288,7 @@ int partition_launch(gndt_handle* h, gndt_handle::Pending& P) {
     if ((rc = grow_buf(h, q.recs, q.rec_cap, n))) return rc;
     if ((rc = grow_buf(h, q.hist, q.hist_cap, (uint64_t)nwg * B))) return rc;
     if (B > q.bucket_cap) {
+        GNDT_NO_CAPTURE(h, "the bucket totals");
         if (q.totals) (void)hipFree(q.totals);
         if (q.bucket_base) (void)hipFree(q.bucket_base);
         q.totals = q.bucket_base = nullptr; q.bucket_cap = 0;
@@ -329,6 +332,7 @@ int partition_launch(gndt_handle* h, gndt_handle::Pending& P) {
     }
     bucket_recs = (two || !one) ? q.recs : q.recs1;
     if (tuning().stamps && q.dbg_buckets < B) {
+        GNDT_NO_CAPTURE(h, "the stamp buffer");
         if (q.dbg) (void)hipFree(q.dbg);
         q.dbg = nullptr; q.dbg_buckets = 0;
         HIP_TRY(h, hipMalloc(&q.dbg, (size_t)B * 16 * sizeof(unsigned long long)));
@@ -589,6 +593,71 @@ int gndt_build(gndt_handle* h, const void* xyz_host, size_t n, size_t stride_byt
     rc = gndt_build_device(h, h->stage, n, stride_bytes, h->own_stream);
     if (rc) return rc;
     return gndt_sync(h, nullptr, nullptr, nullptr);
+}
+
+// Every buffer a build of up to max_points points and max_nodes nodes can ask for, whatever the strategy and whatever a re-run
+// would want (both LDS table sizes, the lowest table load, node estimates up to twice max_nodes; level-1 regions at their 4 n
+// ceiling; the exact partition's histogram; the node table of strategies ATOMIC / TILE; staging rows, result rows, order arrays).
+// After it a build of that size allocates nothing: it can be captured into a hipGraph without an eager warm-up, and a replay
+// never finds its buffers moved (7.7 % of round 3's captures were refused — root cause: ONE capture in
+// which a buffer had to grow; hipFree / hipMalloc on a capturing stream invalidates the capture and HIP then refuses every later
+// capture of the process).
+int gndt_reserve(gndt_handle* h, uint64_t max_points, uint64_t max_nodes) {
+    if (!h) return GNDT_ERR_INVALID;
+    HIP_TRY(h, hipSetDevice(h->device));
+    h->capturing = false;
+    if (max_points == 0) { h->err = "gndt_reserve: max_points must be > 0"; return GNDT_ERR_INVALID; }
+    if (max_points >= 0x7FFFFFFFull) { h->err = "gndt_reserve: more than 2^31 points"; return GNDT_ERR_INVALID; }
+    if (h->pending.active) { const int prc = partition_resolve(h); if (prc) return prc; }
+    HIP_TRY(h, hipStreamSynchronize(h->last_stream));              // (buffers may move: nothing may still use them)
+    const uint64_t n = max_points;
+    if (!max_nodes) max_nodes = std::max<uint64_t>(n / 4, 1024);
+    max_nodes = std::max<uint64_t>(max_nodes, h->P.max_nodes_hint);      // (the hint is what sizes the first attempt of every build)
+    auto& q = h->part;
+    int rc;
+    if ((rc = ensure_words(h, (std::max<uint64_t>(n, h->P.max_points_hint) + 31) / 32 + 1))) return rc;
+    if ((rc = ensure_part_counters(h))) return rc;
+    // rows: what a PARTITION build stages (estimate + 1/8, after two 1.4x raises) and what the table path bounds by its slots
+    const uint64_t est_hi = 2 * max_nodes;
+    const uint64_t rows = std::max<uint64_t>(std::max<uint64_t>(est_hi + est_hi / 8 + 1024, (uint64_t)cap_for_nodes(max_nodes) / 2 + 1),
+                                             4096 + n / 4 + n / 32);      // (a build without a hint stages max(4096, n / 4) rows at least)
+    if ((rc = ensure_stage(h, rows))) return rc;
+    if ((rc = ensure_out(h, q.stage_cap))) return rc;
+    // bucket count: the largest any attempt can ask for
+    uint64_t Bmax = 16;
+    for (int slots : {512, 1024})
+        for (int load : {35, 60, 75}) Bmax = std::max(Bmax, buckets_for(n, est_hi, slots, load));
+    Bmax = std::min<uint64_t>(Bmax, (uint64_t)kMaxFan * kMaxFan);
+    if (Bmax > q.cur_cap) {
+        for (uint32_t** a : {&q.cursors, &q.range_lo, &q.range_hi, &q.range_cap}) { if (*a) (void)hipFree(*a); *a = nullptr; }
+        q.cur_cap = 0;
+        const uint64_t c = Bmax + Bmax / 4;
+        HIP_TRY(h, hipMalloc(&q.cursors, ((size_t)kMaxFan + 2 * c) * 4));
+        HIP_TRY(h, hipMalloc(&q.range_lo, c * 4));
+        HIP_TRY(h, hipMalloc(&q.range_hi, c * 4));
+        HIP_TRY(h, hipMalloc(&q.range_cap, c * 4));
+        q.cur_cap = c;
+    }
+    constexpr uint64_t kTile1 = (uint64_t)kTileThreads * kTilePer1;
+    if ((rc = grow_buf(h, q.recs, q.rec_cap, 2 * n + n / 8 + 2048ull * Bmax + 4096))) return rc;                    // two-level (covers the exact partition's n)
+    if ((rc = grow_buf(h, q.recs1, q.rec1_cap, 4 * n + (1u << 24) + (uint64_t)kMaxFan * (4096 + 2 * kTile1)))) return rc;   // level-1 regions at their ceiling / one-level rooms
+    const uint64_t Bexact = std::min<uint64_t>(Bmax, kMaxBuckets);
+    if ((rc = grow_buf(h, q.hist, q.hist_cap, (uint64_t)tuning().part_wgs * Bexact))) return rc;
+    if (Bexact > q.bucket_cap) {
+        if (q.totals) (void)hipFree(q.totals);
+        if (q.bucket_base) (void)hipFree(q.bucket_base);
+        q.totals = q.bucket_base = nullptr; q.bucket_cap = 0;
+        HIP_TRY(h, hipMalloc(&q.totals, (size_t)Bexact * 4));
+        HIP_TRY(h, hipMalloc(&q.bucket_base, ((size_t)Bexact + 1) * 4));
+        q.bucket_cap = (uint32_t)Bexact;
+    }
+    // strategies ATOMIC / TILE (and gndt_update*): the node table
+    if ((rc = reserve_table(h, std::max<uint64_t>(max_nodes, std::max<uint64_t>(1024, n / 4)), h->own_stream))) return rc;
+    HIP_TRY(h, hipStreamSynchronize(h->own_stream));
+    // (rows_bound of a table-path finalisation follows the table: cap / 2 + 1)
+    if ((rc = ensure_stage(h, std::max<uint64_t>(1024, h->cap / 2 + 1)))) return rc;
+    if ((rc = ensure_out(h, q.stage_cap))) return rc;
+    return GNDT_OK;
 }
 
 int gndt_debug_retry_count(gndt_handle* h, uint64_t* retries) {

@@ -42,6 +42,7 @@ void tuning_force_fp_bits(int bits) { tuning_storage().fp_bits = std::min(21, st
 
 int ensure_out(gndt_handle* h, uint64_t n) {
     if (n <= h->out_cap) return GNDT_OK;
+    GNDT_NO_CAPTURE(h, "the result arrays");
     void* ptrs[] = {h->out.sx, h->out.sy, h->out.sz, h->out.count, h->out.first_idx, h->out.mean, h->out.cov,
                     h->out.rough, h->out.normal, h->out.flags};
     for (void* p : ptrs)
@@ -65,6 +66,7 @@ int ensure_out(gndt_handle* h, uint64_t n) {
 
 int ensure_stats_buffers(gndt_handle* h, uint64_t n) {
     if (n <= h->st_cap) return GNDT_OK;
+    GNDT_NO_CAPTURE(h, "the statistics buffers");
     void* ptrs[] = {h->st_key, h->st_sums, h->st_count, h->st_first};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -80,6 +82,7 @@ int ensure_stats_buffers(gndt_handle* h, uint64_t n) {
 
 // read the device counters (synchronises the stream)
 int fetch_counters(gndt_handle* h, hipStream_t s) {
+    GNDT_NO_CAPTURE(h, "the device counters");
     HIP_TRY(h, hipMemcpyAsync(h->h_cnt, h->d_cnt, sizeof(Counters), hipMemcpyDeviceToHost, s));
     HIP_TRY(h, hipStreamSynchronize(s));
     return GNDT_OK;
@@ -87,6 +90,7 @@ int fetch_counters(gndt_handle* h, hipStream_t s) {
 
 int check_ready(gndt_handle* h) {
     if (!h) return GNDT_ERR_INVALID;
+    h->capturing = false;              // (use_stream, which every call that enqueues work makes next, sets it for the call's stream)
     if (!h->origin_set) { h->err = "gndt_set_origin must be called first (setCloudFirst, receiver.cpp:145)"; return GNDT_ERR_INVALID; }
     HIP_TRY(h, hipSetDevice(h->device));
     return GNDT_OK;
@@ -105,6 +109,7 @@ void free_part(gndt_handle* h) {
 int ensure_stage(gndt_handle* h, uint64_t nodes) {
     auto& q = h->part;
     if (nodes <= q.stage_cap) return GNDT_OK;
+    GNDT_NO_CAPTURE(h, "the staging rows");
     void* ptrs[] = {q.stage, q.ord_cf, q.ord_idx, q.inv, q.row_of};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -122,6 +127,7 @@ int ensure_stage(gndt_handle* h, uint64_t nodes) {
 int ensure_words(gndt_handle* h, uint64_t words) {
     auto& q = h->part;
     if (words <= q.word_cap) return GNDT_OK;
+    GNDT_NO_CAPTURE(h, "the column-order bitmap (raise gndt_params.max_points_hint)");
     for (uint32_t** a : {&q.bitmap, &q.word_weight, &q.word_base, &q.bsum_words, &q.ncol_at}) { if (*a) (void)hipFree(*a); *a = nullptr; }
     q.word_cap = 0;
     words += words / 4;
@@ -140,6 +146,7 @@ int ensure_words(gndt_handle* h, uint64_t words) {
 // host threads on a shared GPU lost its "region overflow" flag in 3 % of the runs and with it the points that did not fit;
 // tools/fuzz_owner.py).  Filled on the handle's own stream and awaited, nothing can follow it.
 int zero_device_now(gndt_handle* h, void* p, size_t bytes) {
+    GNDT_NO_CAPTURE(h, "a fresh buffer");
     HIP_TRY(h, hipMemsetAsync(p, 0, bytes, h->own_stream));
     HIP_TRY(h, hipStreamSynchronize(h->own_stream));
     return GNDT_OK;
@@ -148,6 +155,7 @@ int zero_device_now(gndt_handle* h, void* p, size_t bytes) {
 int ensure_part_counters(gndt_handle* h) {
     auto& q = h->part;
     if (q.d_pc) return GNDT_OK;
+    GNDT_NO_CAPTURE(h, "the partition counters");
     HIP_TRY(h, hipMalloc(&q.d_pc, sizeof(PartCounters)));
     HIP_TRY(h, hipHostMalloc(&q.h_pc, sizeof(PartCounters)));
     { const int rc = zero_device_now(h, q.d_pc, sizeof(PartCounters)); if (rc) return rc; }
@@ -155,15 +163,48 @@ int ensure_part_counters(gndt_handle* h) {
     return GNDT_OK;
 }
 
+// Host input -> the handle's device staging buffer, asynchronously on stream s.
+//   pinned host memory (hipHostMalloc / hipHostRegister, e.g. a pinned torch tensor): ONE async copy, the DMA engine's rate;
+//   pageable memory, large: the cloud goes through two pinned bounce buffers of 8 MB — the CPU fills one while the DMA engine
+//     empties the other, and the build's kernels queue behind the last chunk — instead of the runtime's own pageable path
+//     (a 120 MB cloud: 150 ms measured through torch in round 3);
+//   pageable, small (a LiDAR frame): the runtime's path, which is fast for a few MB.
 int stage_host_input(gndt_handle* h, const void* xyz_host, size_t n, size_t stride_bytes, hipStream_t s) {
     const size_t bytes = n * stride_bytes;
     if (bytes > h->stage_bytes) {
+        GNDT_NO_CAPTURE(h, "the host-input staging buffer");
         if (h->stage) (void)hipFree(h->stage);
         h->stage = nullptr; h->stage_bytes = 0;
         HIP_TRY(h, hipMalloc(&h->stage, bytes + 64));
         h->stage_bytes = bytes;
     }
-    if (bytes) HIP_TRY(h, hipMemcpyAsync(h->stage, xyz_host, bytes, hipMemcpyHostToDevice, s));
+    if (!bytes) return GNDT_OK;
+    constexpr size_t kChunk = 8u << 20;
+    bool pinned = false;
+    {
+        hipPointerAttribute_t a{};
+        if (hipPointerGetAttributes(&a, xyz_host) == hipSuccess) pinned = a.type == hipMemoryTypeHost;
+        else (void)hipGetLastError();                        // (plain malloc memory: "invalid value" on some runtimes — not an error here)
+    }
+    if (pinned || bytes < 2 * kChunk) {
+        HIP_TRY(h, hipMemcpyAsync(h->stage, xyz_host, bytes, hipMemcpyHostToDevice, s));
+        return GNDT_OK;
+    }
+    for (int b = 0; b < 2; ++b) {
+        if (!h->bounce[b]) HIP_TRY(h, hipHostMalloc(&h->bounce[b], kChunk));
+        if (!h->bounce_ev[b]) HIP_TRY(h, hipEventCreateWithFlags(&h->bounce_ev[b], hipEventDisableTiming));
+    }
+    const char* src = static_cast<const char*>(xyz_host);
+    char* dst = static_cast<char*>(h->stage);
+    size_t i = 0;
+    for (size_t off = 0; off < bytes; off += kChunk, ++i) {
+        const int b = (int)(i & 1);
+        const size_t len = std::min(kChunk, bytes - off);
+        if (i >= 2) HIP_TRY(h, hipEventSynchronize(h->bounce_ev[b]));      // the copy that last used this buffer has left it
+        memcpy(h->bounce[b], src + off, len);
+        HIP_TRY(h, hipMemcpyAsync(dst + off, h->bounce[b], len, hipMemcpyHostToDevice, s));
+        HIP_TRY(h, hipEventRecord(h->bounce_ev[b], s));
+    }
     return GNDT_OK;
 }
 
@@ -173,6 +214,7 @@ int stage_host_input(gndt_handle* h, const void* xyz_host, size_t n, size_t stri
 int use_stream(gndt_handle* h, hipStream_t s) {
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     (void)hipStreamIsCapturing(s, &cap);
+    h->capturing = cap != hipStreamCaptureStatusNone;
     // (a stream under graph capture cannot wait for un-captured work: the caller orders the capture itself)
     if (h->last_stream != s && cap == hipStreamCaptureStatusNone) {     // (last_stream is always a stream: own_stream from gndt_create on)
         if (!h->xstream_ev) HIP_TRY(h, hipEventCreateWithFlags(&h->xstream_ev, hipEventDisableTiming));
@@ -264,6 +306,8 @@ void gndt_destroy(gndt_handle* h) {
         for (auto& e : X.ev) if (e) (void)hipEventDestroy(e);
     }
     if (h->xstream_ev) (void)hipEventDestroy(h->xstream_ev);
+    if (h->exp_host) (void)hipHostFree(h->exp_host);
+    for (int b = 0; b < 2; ++b) { if (h->bounce[b]) (void)hipHostFree(h->bounce[b]); if (h->bounce_ev[b]) (void)hipEventDestroy(h->bounce_ev[b]); }
     if (h->d_sample) (void)hipFree(h->d_sample);
     if (h->h_sample) (void)hipHostFree(h->h_sample);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
@@ -355,6 +399,39 @@ int gndt_export(gndt_handle* h, gndt_cells* o) {
         {o->rough, h->out.rough, 4}, {o->normal, h->out.normal, 12}, {o->flags, h->out.flags, 4}};
     for (auto& c : copies)
         if (c.dst && n) HIP_TRY(h, hipMemcpy(c.dst, c.src, n * c.elem, hipMemcpyDeviceToHost));
+    return GNDT_OK;
+}
+
+int gndt_export_host(gndt_handle* h, gndt_cells* o) {
+    if (!h || !o) return GNDT_ERR_INVALID;
+    { const int prc = partition_resolve(h); if (prc) return prc; }
+    if (!h->results_valid) { h->err = "no finished build to export"; return GNDT_ERR_INVALID; }
+    int rc = gndt_sync(h, nullptr, nullptr, nullptr);
+    if (rc) return rc;
+    const uint64_t n = h->res_nodes;
+    const uint64_t rows = std::max<uint64_t>(n, 1);
+    if (rows > h->exp_rows) {
+        if (h->exp_host) (void)hipHostFree(h->exp_host);
+        h->exp_host = nullptr; h->exp_rows = 0;
+        const uint64_t want = rows + rows / 4;
+        HIP_TRY(h, hipHostMalloc(&h->exp_host, want * 76 + 256));
+        h->exp_rows = want;
+    }
+    // ten arrays, one after the other in the pinned mirror (every one of them 4-byte elements: no alignment gaps needed)
+    char* base = static_cast<char*>(h->exp_host);
+    const uint64_t cap = h->exp_rows;
+    struct { const void* src; size_t elem; void** dst; } copies[] = {
+        {h->out.sx, 4, (void**)&o->sx}, {h->out.sy, 4, (void**)&o->sy}, {h->out.sz, 4, (void**)&o->sz}, {h->out.count, 4, (void**)&o->count},
+        {h->out.first_idx, 4, (void**)&o->first_idx}, {h->out.mean, 12, (void**)&o->mean}, {h->out.cov, 24, (void**)&o->cov},
+        {h->out.rough, 4, (void**)&o->rough}, {h->out.normal, 12, (void**)&o->normal}, {h->out.flags, 4, (void**)&o->flags}};
+    size_t off = 0;
+    for (auto& c : copies) {
+        *c.dst = base + off;
+        if (n) HIP_TRY(h, hipMemcpyAsync(base + off, c.src, n * c.elem, hipMemcpyDeviceToHost, h->last_stream));
+        off += cap * c.elem;
+    }
+    HIP_TRY(h, hipStreamSynchronize(h->last_stream));
+    o->num_nodes = n; o->num_columns = h->res_columns; o->num_slopes = h->res_slopes;
     return GNDT_OK;
 }
 

@@ -22,6 +22,7 @@ void free_table(gndt_handle* h) {
 
 // A fresh, empty table of `cap` slots.  The device counters are NOT touched: the caller decides (reset vs growth).
 int alloc_table(gndt_handle* h, uint32_t cap, hipStream_t s) {
+    GNDT_NO_CAPTURE(h, "the node table");
     free_table(h);
     HIP_TRY(h, hipMalloc(&h->keys, (size_t)cap * sizeof(uint64_t)));
     HIP_TRY(h, hipMalloc(&h->acc, (size_t)cap * sizeof(NodeAcc)));
@@ -58,7 +59,11 @@ TableView table_view(const gndt_handle* h) {
 }  // namespace
 
 int do_reset(gndt_handle* h, hipStream_t s) {
-    if (h->cap && h->table_dirty)       // (its last workgroup zeroes the counters)
+    // A reset recorded into a hipGraph must be the one that CLEARS: at capture time a fresh table is clean and the cheap variant
+    // would be recorded, but the second replay finds the first one's nodes in it (round 4: a build captured on a reserved fresh
+    // handle came back from its second replay with only the nodes the first cloud did not have).  On a clean table the clearing
+    // kernel finds an empty node list and only zeroes the counters.
+    if (h->cap && (h->table_dirty || h->capturing))       // (its last workgroup zeroes the counters)
         hipLaunchKernelGGL(k_clear_used, dim3(grid_for(h->cap / 8)), dim3(kBlock), 0, s, h->keys, h->acc, h->col_keys,
                            h->col_first, h->col_cnt, h->col_head, h->node_slot, h->col_slot_of_node, h->d_cnt);
     else
@@ -231,11 +236,19 @@ int grow_table(gndt_handle* h, uint32_t new_cap, hipStream_t s) {
 
 }  // namespace
 
+// gndt_reserve: a node table for `nodes` nodes (what a table that holds a map already is grown to, its contents kept)
+int reserve_table(gndt_handle* h, uint64_t nodes, hipStream_t s) {
+    const uint32_t want = cap_for_nodes(nodes);
+    if (h->cap >= want) return GNDT_OK;
+    return (h->cap && h->table_dirty) ? grow_table(h, want, s) : alloc_table(h, want, s);
+}
+
 // strategy ATOMIC from empty; waits for the result (the retry on a full table needs the device-side flags)
 int locality_sample(gndt_handle* h, const void* xyz_dev, size_t n, size_t stride_bytes, uint32_t tiles, double* ratio, hipStream_t s) {
     if (stride_bytes != 12 && stride_bytes != 16) { h->err = "stride_bytes must be 12 or 16"; return GNDT_ERR_INVALID; }
     *ratio = 0.0;
     if (n == 0 || tiles == 0) return GNDT_OK;
+    GNDT_NO_CAPTURE(h, "the locality sample");
     if (!h->d_sample) {
         HIP_TRY(h, hipMalloc(&h->d_sample, 2 * sizeof(unsigned long long)));
         HIP_TRY(h, hipHostMalloc(&h->h_sample, 2 * sizeof(unsigned long long)));

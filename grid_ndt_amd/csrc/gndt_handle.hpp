@@ -34,6 +34,8 @@ struct gndt_handle {
     hipStream_t own_stream = nullptr;
     hipStream_t last_stream = nullptr;
     hipEvent_t xstream_ev = nullptr;   // orders work on a new stream behind what the previous one still runs (use_stream)
+    bool capturing = false;            // the stream of the call in progress is under hipGraph capture (use_stream): nothing may allocate,
+                                       //   free or wait — such a call would not only fail, it INVALIDATES the capture (GNDT_NO_CAPTURE)
 
     // node table
     uint32_t cap = 0;  // slots, power of two
@@ -72,6 +74,9 @@ struct gndt_handle {
     // staging for host input
     void* stage = nullptr;
     size_t stage_bytes = 0;
+    void* exp_host = nullptr;  uint64_t exp_rows = 0;   // gndt_export_host: pinned mirror of the result arrays
+    void* bounce[2] = {nullptr, nullptr};          // pinned bounce buffers for large pageable inputs (stage_host_input)
+    hipEvent_t bounce_ev[2] = {nullptr, nullptr};
     // gndt_build_cloud: packed xyz of the unpacked, NaN-stripped cloud; pinned word for the valid count
     float* packed = nullptr;
     uint64_t packed_cap = 0;
@@ -244,6 +249,19 @@ void tuning_force_fp_bits(int bits); // tests: narrow the fingerprint so that cl
         }                                                                                                \
     } while (0)
 
+// Allocating, freeing or waiting while a stream of the process is being captured makes HIP refuse the call AND invalidate the
+// capture (hipErrorStreamCaptureInvalidated at hipStreamEndCapture; round 3's fuzz: one such capture and every later capture of
+// the process was refused).  Code that is about to do one of these asks first and reports GNDT_ERR_CAPACITY — a clean error the
+// caller answers with gndt_reserve() (or an eager build of the same size) before capturing.
+#define GNDT_NO_CAPTURE(h, what)                                                                                              \
+    do {                                                                                                                      \
+        if ((h)->capturing) {                                                                                                 \
+            (h)->err = std::string(what) + " must be (re)allocated or waited for, which a stream under hipGraph capture cannot do: "  \
+                       "call gndt_reserve(max_points, max_nodes) — or build a cloud of this size eagerly — before capturing";  \
+            return GNDT_ERR_CAPACITY;                                                                                         \
+        }                                                                                                                     \
+    } while (0)
+
 inline void mark(gndt_handle* h, int i, hipStream_t s) {
     if (!h->prof || !h->ev[h->ev_set][i]) return;
     if (h->prof == 2) {   // the bucket kernel sits between marks 4 and 5, k_accumulate between 1 and 2
@@ -296,6 +314,7 @@ inline hipStream_t stream_of(gndt_handle* h, void* hip_stream) {
 template <typename T>
 int grow_buf(gndt_handle* h, T*& p, uint64_t& cap, uint64_t want) {
     if (want <= cap) return GNDT_OK;
+    GNDT_NO_CAPTURE(h, "a work buffer");
     if (p) (void)hipFree(p);
     p = nullptr; cap = 0;
     HIP_TRY(h, hipMalloc(&p, want * sizeof(T)));
@@ -320,6 +339,7 @@ int alloc_table(gndt_handle* h, uint32_t cap, hipStream_t s);
 int do_reset(gndt_handle* h, hipStream_t s);
 int zero_device_now(gndt_handle* h, void* p, size_t bytes);
 int partition_recheck_after_replay(gndt_handle* h);
+int reserve_table(gndt_handle* h, uint64_t nodes, hipStream_t s);
 int build_atomic(gndt_handle* h, const void* xyz_dev, size_t n, size_t stride_bytes, hipStream_t s, bool tile = false,
                  const gndt_handle::Pending* rec = nullptr);
 int locality_sample(gndt_handle* h, const void* xyz_dev, size_t n, size_t stride_bytes, uint32_t tiles, double* ratio, hipStream_t s);

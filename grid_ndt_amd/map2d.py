@@ -452,6 +452,11 @@ class TwoDmap:
     def enable_stamps(self, on=True):
         self._L.gndt_debug_enable_stamps(int(bool(on)))
 
+    def reserve(self, max_points, max_nodes=0, demand="slope"):
+        """gndt_reserve: every buffer a build of this size can need, allocated now (capture a build on a fresh handle afterwards)."""
+        self._ensure(demand, need_origin=False)
+        self._check(self._L.gndt_reserve(self._h, int(max_points), int(max_nodes)))
+
     def set_fp_bits(self, bits):
         """Narrow the bucket kernel's index fingerprint (process-wide; tests: forces its exact second pass)."""
         self._L.gndt_debug_set_fp_bits(int(bits))

@@ -141,6 +141,12 @@ int gndt_build(gndt_handle* h, const void* xyz_host, size_t n, size_t stride_byt
  * GNDT_ERR_CAPACITY at gndt_sync.  AUTO picks per cloud (ATOMIC below 65 536 points; above, TILE when a sample of the
  * cloud shows dense scan-ordered cells, PARTITION otherwise); under capture it keeps the choice of the last eager build. */
 int gndt_build_device(gndt_handle* h, const void* xyz_dev, size_t n, size_t stride_bytes, void* hip_stream);
+/* Allocate NOW every buffer a build / update of up to max_points points and max_nodes nodes (0: max_points / 4) can ask for,
+ * whatever the strategy and whatever a re-run with more room would want.  After it such a build allocates nothing: it can be
+ * captured into a hipGraph on a FRESH handle (no eager warm-up), and no replay finds its buffers moved.  Without it a captured
+ * call that has to grow a buffer fails with GNDT_ERR_CAPACITY before touching the allocator (allocating on a capturing stream
+ * would invalidate the capture — and, on this runtime, every later capture of the process).  Waits for the handle's stream. */
+int gndt_reserve(gndt_handle* h, uint64_t max_points, uint64_t max_nodes);
 
 /* Incremental add (the intent of changeCallback/change2DMap, receiver.cpp:179-212, map2D.h:672-822;
  * semantics defined in SURVEY.md Appendix A.7): after update(F1) .. update(Fk) the map equals
@@ -184,6 +190,10 @@ int gndt_sync(gndt_handle* h, uint64_t* num_nodes, uint64_t* num_columns, uint64
 int gndt_export_device(gndt_handle* h, gndt_cells* out);
 /* Copies into caller-allocated host arrays sized from gndt_sync's num_nodes (NULL arrays skipped). */
 int gndt_export(gndt_handle* h, gndt_cells* out_host);
+/* The same rows in host memory the HANDLE owns (pinned, one D2H pass, no copy into caller arrays): the pointers stored in *out
+ * stay valid until the next gndt_export_host / gndt_destroy on the handle.  What gndt_compat::TwoDmap reads the map from
+ * (the reference's containers are filled from it, or — lazy mode — the consumers are served from it directly). */
+int gndt_export_host(gndt_handle* h, gndt_cells* out);
 
 /* ---- statistics exchange (multi-GPU; additive over any partition of the points) --------------- */
 /* Device-resident compact list of this handle's occupied nodes. */

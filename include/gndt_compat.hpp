@@ -374,8 +374,8 @@ public:
         if (rc == GNDT_OK) rc = gndt_sync(handle, &nodes, &cols, &slopes);
         if (rc != GNDT_OK) { last_error = gndt_last_error(handle); return false; }   // "wrong" (map2D.h:602-604)
         const auto t1 = std::chrono::steady_clock::now();
-        host.resize(nodes);
-        rc = gndt_export(handle, &host.view);
+        host.resize(0);                                  // (the rows are read where gndt_export_host puts them: the handle's pinned mirror)
+        rc = gndt_export_host(handle, &host.view);
         if (rc != GNDT_OK) { last_error = gndt_last_error(handle); return false; }
         const auto t2 = std::chrono::steady_clock::now();
         timing.build_ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
@@ -516,8 +516,8 @@ public:
         if (rc == GNDT_OK) rc = gndt_sync(handle, &nodes, &cols, &slopes);
         if (rc == GNDT_OK) rc = gndt_get_origin(handle, cloudFirst.d);
         if (rc != GNDT_OK) { last_error = gndt_last_error(handle); return false; }
-        host.resize(nodes);
-        rc = gndt_export(handle, &host.view);
+        host.resize(0);
+        rc = gndt_export_host(handle, &host.view);
         if (rc != GNDT_OK) { last_error = gndt_last_error(handle); return false; }
         return finish_build(lazy);
     }

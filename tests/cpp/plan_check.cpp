@@ -140,6 +140,35 @@ int main(int argc, char** argv) {
     AstarPlanar planner(robot.getPosition(), robot.getGoal());
     CHECK(planner.findRoute(B, robot, demand) == !ref.path.empty(), "route found / not found differs");
     if (same_route(planner.global_path, ref, ex, "gpu")) return 1;
-    std::printf("libgndt computeCost + A* == oracle OK slopes=%zu steps=%zu\n", slopes, ref.path.size());
+    // ---- the same through the LAZY mode: no containers, the consumers served from the exported rows ----
+    TwoDmap L(gl, zl);
+    L.setInterval(iv);
+    L.setCloudFirst(Vector3f{{cloud[0], cloud[1], cloud[2]}});
+    CHECK(L.create2DMap(demand, cloud.data() + 3, n - 1, 12, true), "lazy create2DMap failed: %s", L.lastError().c_str());
+    CHECK(L.isLazy() && L.map_cell.empty() && L.map_xy.empty() && L.morton_list.empty(), "lazy mode filled the containers");
+    RobotSphere robot2(radius, vstart, vgoal);
+    CHECK(L.computeCost(robot2.getGoal(), robot2, demand), "lazy computeCost failed: %s", L.lastError().c_str());
+    AstarPlanar planner2(robot2.getPosition(), robot2.getGoal());
+    CHECK(planner2.findRoute(L, robot2, demand) == !ref.path.empty(), "lazy: route found / not found differs");
+    if (same_route(planner2.global_path, ref, ex, "lazy")) return 1;
+    {
+        size_t k = 0;
+        for (const Slope* s : planner2.global_path) {
+            const int32_t row = ref.path[k++];
+            CHECK(std::memcmp(&s->h, &ref.h[row], 4) == 0, "lazy: h of step %zu differs", k - 1);
+        }
+        // field for field what the rows L was built from hold (two builds of one cloud agree in keys and order, and in the fp32
+        // values up to the last bit: the order of the fp64 LDS additions is not fixed — so L's slopes are held to L's own rows)
+        const gndt_cells& lx = L.exported();
+        CHECK(lx.num_nodes == ex.num_nodes, "lazy build has %llu rows, eager %llu", (unsigned long long)lx.num_nodes, (unsigned long long)ex.num_nodes);
+        k = 0;
+        for (const Slope* s : planner2.global_path) {
+            const int32_t row = ref.path[k++];
+            CHECK(lx.sx[row] == ex.sx[row] && lx.sy[row] == ex.sy[row] && lx.sz[row] == ex.sz[row], "row %d: keys differ between two builds", row);
+            CHECK(s->rough == lx.rough[row] && s->mean(2) == lx.mean[3 * row + 2] && s->normal(0) == lx.normal[3 * row] &&
+                      s->down == ((lx.flags[row] & GNDT_FLAG_DOWN) != 0), "lazy slope of row %d differs from its row", row);
+        }
+    }
+    std::printf("libgndt computeCost + A* == oracle OK slopes=%zu steps=%zu (eager and lazy)\n", slopes, ref.path.size());
     return 0;
 }

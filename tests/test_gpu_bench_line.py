@@ -41,3 +41,31 @@ def test_multi_gpu_line_steps_down_when_the_exchange_reports_an_error(fail, ends
     assert all("injected failure" in f["error"] for f in d["fallback"])
     assert d["config"]["points_total"] == 2000000 and d["config"]["nodes"] > 0 and d["value"] > 0 and d["scaling"] == "strong"
     assert "gather_ms" not in d and "modes" not in d
+
+
+def test_single_gpu_line_carries_every_config_and_the_host_path():
+    """The N = 1 line (what the driver records): S2 as `value`, and — untimed by it — the other BASELINE.json configurations
+    (`configs`: S1 campus / bridge_ground / depth frame, S2z, S3, S5, S4 eager and replayed, first builds), the host side of the seam
+    stage by stage (`host_path`, eager and lazy) and the host-buffer build (`host_build`)."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "5", "--warmup", "2", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert d["retries_in_timed_region"] == 0 and d["config"]["points_total"] == 10_000_000
+    c = d["configs"]
+    for k in ("S1_campus_200k", "S1_bridge_ground_360k", "S1_depth_frame_215k", "S2z_10M_z01", "S3_terrain_8M", "S5_site_5M"):
+        assert c[k]["ms_per_build"] > 0 and c[k]["retries"] == 0 and 0 < c[k]["path_frac"] < 1 and c[k]["first_build_ms"] > 0, (k, c[k])
+    assert c["S2_first_build"]["first_build_ms"] > 0
+    for k in ("eager", "hip_graph_replay"):
+        s4 = c["S4_stream_131k_frames"][k]
+        assert 0 < s4["p50_ms"] <= s4["p99_ms"] < 100.0 and s4["back_to_back_ms_per_frame"] > 0
+    hp = d["host_path"]
+    for k in ("S1_campus_200k", "S1_bridge_ground_360k", "drivable_site_400k"):
+        assert "error" not in hp[k], hp[k]
+        for mode in ("eager", "lazy"):
+            assert hp[k][mode]["total_ms"] > 0 and hp[k][mode]["build_sync_ms"] > 0
+        assert hp[k]["lazy"]["containers_ms"] < hp[k]["eager"]["containers_ms"]
+        assert hp[k]["oracle_as_shipped_ms"]["division"] > 0
+    site = hp["drivable_site_400k"]
+    assert site["eager"]["route_found"] and site["lazy"]["route_found"] and site["eager"]["route_steps"] == site["lazy"]["route_steps"] > 2
+    assert d["host_build"]["pageable_ms"] > 0 and d["host_build"]["pinned_ms"] > 0

@@ -61,6 +61,50 @@ def test_parity_device_input(name, strategy):
     assert ran == {1: 1, 3: 3, 4: 2, 5: 5}[strategy], (name, ran)
 
 
+@pytest.mark.parametrize("strategy", [0, 1, 2, 3, 4, 5], ids=["auto", "atomic", "partition", "partition_exact", "partition_two_level", "tile"])
+def test_build_captured_on_a_reserved_fresh_handle(strategy):
+    """gndt_reserve sizes every buffer a build of that size can ask for, so the FIRST build of a handle can be recorded into a
+    hipGraph (no eager warm-up) and replayed on other clouds of that size: nothing allocates under capture (which would invalidate
+    it), no replay finds a buffer moved.  Without the reservation the same capture is refused cleanly (GNDT_ERR_CAPACITY)."""
+    import torch
+    import grid_ndt_amd as g
+    from grid_ndt_amd._lib import GndtError
+    n = 150_000
+    P = scenes.CAMPUS_PARAMS
+    clouds = [scenes.campus_frame(n + 1, seed=0x5EED0001 + k) for k in range(3)]
+    for c in clouds[1:]:
+        c[0] = clouds[0][0]                                   # (the origin stays the handle's)
+    refs = [parity.ref_from_cloud(c, P) for c in clouds]
+    hint = int(max(r["num_nodes"] for r in refs) * 1.25)
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        buf = torch.from_numpy(np.ascontiguousarray(clouds[0][1:])).cuda()
+        # not reserved: refused before the allocator is touched, and the process can still capture afterwards
+        m0 = g.TwoDmap(P["grid_len"], P["z_len"], strategy=strategy, max_nodes_hint=hint, max_points_hint=n + 1)
+        m0.setInterval(P["slope_interval"])
+        m0.setCloudFirst(clouds[0][0])
+        m0._ensure(P["demand"])                                # (the handle itself is created outside the capture)
+        gr = torch.cuda.CUDAGraph()
+        with pytest.raises(GndtError) as ei:
+            with torch.cuda.graph(gr, stream=s):
+                m0.create2DMap(P["demand"], buf, s)
+        assert ei.value.code == 5 and "gndt_reserve" in str(ei.value)
+        del m0, gr
+        m = g.TwoDmap(P["grid_len"], P["z_len"], strategy=strategy, max_nodes_hint=hint, max_points_hint=n + 1)
+        m.setInterval(P["slope_interval"])
+        m.setCloudFirst(clouds[0][0])
+        m.reserve(n + 1, hint, P["demand"])
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=s):
+            m.create2DMap(P["demand"], buf, s)
+        for c, ref in zip(clouds, refs):
+            buf.copy_(torch.from_numpy(np.ascontiguousarray(c[1:])))
+            graph.replay()
+            s.synchronize()
+            parity.assert_parity(m.export(), ref)
+    print("strategy", strategy, "ran", m.STRATEGY_NAMES[m.last_strategy()])
+
+
 @pytest.mark.parametrize("bits", [0, 2, 6])
 def test_fingerprint_clash_takes_the_exact_second_pass(bits):
     """The bucket kernel names a node by a 21-bit fingerprint of its key and confirms it with the key (gndt_bucket3.hpp); a bucket

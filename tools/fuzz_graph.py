@@ -56,12 +56,30 @@ def main():
                     m = g.TwoDmap(cells[0], cells[1], strategy=strategy, max_nodes_hint=int(rng.choice([0, 3_000_000])), max_points_hint=n + 1)
                     m.setInterval(0.08)
                     m.setCloudFirst(base[0])
-                    for _ in range(2):
-                        m.create2DMap("slope", buf, s)
-                        m.sync()
-                    graph = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(graph, stream=s):
-                        m.create2DMap("slope", buf, s)
+                    fresh = rng.random() < 0.3
+                    if fresh:                  # a FRESH handle: gndt_reserve instead of eager warm-up builds
+                        m.reserve(n + 1, 0)
+                        stats["fresh_captures"] = stats.get("fresh_captures", 0) + 1
+                    else:
+                        for _ in range(2):
+                            m.create2DMap("slope", buf, s)
+                            m.sync()
+
+                    def capture():
+                        gr = torch.cuda.CUDAGraph()
+                        with torch.cuda.graph(gr, stream=s):
+                            m.create2DMap("slope", buf, s)
+                        return gr
+                    try:
+                        graph = capture()
+                    except GndtError as e:     # a buffer would have had to grow under capture: said so BEFORE touching the allocator
+                        if e.code != 5:
+                            raise
+                        stats["capture_asked_for_reserve"] = stats.get("capture_asked_for_reserve", 0) + 1
+                        if len(stats.setdefault("reserve_examples", [])) < 4:
+                            stats["reserve_examples"].append(dict(desc, error=str(e)[:300]))
+                        m.reserve(n + 1, 0)
+                        graph = capture()
                     stats["graphs"] += 1
                     for k in range(int(rng.integers(1, 4))):
                         other, adv2 = cloud_of(kind_seed + 1 + k) if rng.random() < 0.8 else cloud_of(int(sub.integers(1 << 30)))
@@ -125,6 +143,8 @@ def main():
                 # a clean refusal at capture time (seen with ATOMIC builds, 3 of 363 graphs; not root-caused in round 3): the caller
                 # builds eagerly instead — counted, not a wrong map
                 stats["capture_refused"] = stats.get("capture_refused", 0) + 1
+                if len(stats.setdefault("capture_refused_examples", [])) < 6:
+                    stats["capture_refused_examples"].append(dict(desc, error=str(e)[:400]))
                 torch.cuda.synchronize()
                 continue
             stats["failures"].append(dict(desc, error=f"{type(e).__name__}: {e}"))
