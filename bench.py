@@ -84,7 +84,7 @@ def parse():
 
 
 # what the N > 1 line carries beside the N = 1 keys (tests/test_bench_launcher.py)
-MULTI_GPU_KEYS = ("single_gpu_anchor", "speedup_vs_single_gpu", "gather_ms", "modes", "exchange")
+MULTI_GPU_KEYS = ("single_gpu_anchor", "speedup_vs_single_gpu", "gather_ms", "modes", "exchange", "comm_selftest")
 
 
 def watchdog(seconds):
@@ -558,6 +558,16 @@ def main():
     # and step down together: owner -> global -> the shards built with no exchange at all (said so in the line, never silent).
     # A rank that hangs instead is ended by the watchdog. ----
     fallback = []
+    selftest = None
+    if global_mode and comm is not None:
+        # one verified round of every collective libgndt's exchange uses, before anything is built on it: the first multi-rank run
+        # of a node is otherwise also the first test of the transport (reported per primitive; a wrong answer is an error below)
+        from grid_ndt_amd._lib import GndtError
+        try:
+            selftest = m.comm_selftest(comm, stream)
+        except GndtError as e:
+            selftest = {"error": str(e)}
+            comm_error = comm_error or f"communicator self-test: {e}"
     if global_mode and several:
         from grid_ndt_amd._lib import GndtError
         while global_mode:
@@ -636,6 +646,8 @@ def main():
     nodes, cols, slopes = m.sync()
     n_local = n
     multi = {}
+    if selftest is not None:
+        multi["comm_selftest"] = selftest
     if fallback:
         multi["fallback"] = fallback
     rank0_nodes = nodes

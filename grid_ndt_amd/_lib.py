@@ -65,6 +65,11 @@ class ExchangeTimes(C.Structure):
                 ("local_nodes", C.c_uint64), ("global_nodes", C.c_uint64), ("bytes_reduced", C.c_uint64)]
 
 
+class CommSelftest(C.Structure):
+    _fields_ = [("all_gather_ms", C.c_float), ("exchange_ms", C.c_float), ("reduce_scatter_ms", C.c_float), ("all_reduce_ms", C.c_float),
+                ("ok_mask", C.c_uint32), ("ranks", C.c_uint32)]
+
+
 class OwnedInfo(C.Structure):
     _fields_ = [("owned_points", C.c_uint64), ("local_nodes", C.c_uint64), ("local_columns", C.c_uint64),
                 ("global_nodes", C.c_uint64), ("global_columns", C.c_uint64), ("global_slopes", C.c_uint64),
@@ -217,6 +222,8 @@ def lib():
     L.gndt_comm_create_threads.restype = C.c_int
     L.gndt_comm_destroy.restype = None
     L.gndt_comm_last_error.restype = C.c_char_p
+    L.gndt_comm_selftest.argtypes = [H, vp, C.POINTER(CommSelftest), vp]
+    L.gndt_comm_selftest.restype = C.c_int
     L.gndt_build_global_device.argtypes = [H, vp, vp, C.c_size_t, C.c_size_t, u64, u64, C.POINTER(ExchangeTimes), vp]
     L.gndt_owner_of_columns.argtypes = [vp, vp, C.c_size_t, C.c_uint32, vp]
     L.gndt_owner_of_columns.restype = C.c_int

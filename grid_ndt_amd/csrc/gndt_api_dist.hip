@@ -5,6 +5,7 @@
 
 #include <rocprim/rocprim.hpp>
 
+#include <chrono>
 #include <condition_variable>
 #include <memory>
 #include <mutex>
@@ -91,13 +92,21 @@ int comm_exchange(gndt_handle* h, gndt_comm* c, const char* send_base, const uin
                   char* recv_base, const uint64_t* recv_off_bytes, const uint64_t* recv_cnt_bytes, hipStream_t s) {
     const int W = c->world, me = c->rank;
     if (!c->threads) {
+        // A failing Send / Recv must not leave the group open (round 3 returned from inside it: the communicator was then stuck
+        // in a group for good): the first error is kept, nothing more is added, the group is CLOSED, then the error is reported.
         RCCL_TRY(h, rccl().GroupStart());
-        for (int r = 0; r < W; ++r) {
+        ncclResult_t first = ncclSuccess;
+        const char* what = "";
+        for (int r = 0; r < W && first == ncclSuccess; ++r) {
             if (r == me) continue;
-            if (cnt_bytes[r]) RCCL_TRY(h, rccl().Send(send_base + off_bytes[r], (size_t)(cnt_bytes[r] / 4), ncclFloat, r, c->nccl, s));
-            if (recv_cnt_bytes[r]) RCCL_TRY(h, rccl().Recv(recv_base + recv_off_bytes[r], (size_t)(recv_cnt_bytes[r] / 4), ncclFloat, r, c->nccl, s));
+            if (cnt_bytes[r]) { first = rccl().Send(send_base + off_bytes[r], (size_t)(cnt_bytes[r] / 4), ncclFloat, r, c->nccl, s); what = "ncclSend"; }
+            if (first == ncclSuccess && recv_cnt_bytes[r]) {
+                first = rccl().Recv(recv_base + recv_off_bytes[r], (size_t)(recv_cnt_bytes[r] / 4), ncclFloat, r, c->nccl, s); what = "ncclRecv";
+            }
         }
-        RCCL_TRY(h, rccl().GroupEnd());
+        const ncclResult_t ended = rccl().GroupEnd();
+        if (first != ncclSuccess) { h->err = std::string(what) + " inside the exchange: " + rccl().GetErrorString(first); return GNDT_ERR_HIP; }
+        if (ended != ncclSuccess) { h->err = std::string("ncclGroupEnd: ") + rccl().GetErrorString(ended); return GNDT_ERR_HIP; }
         return GNDT_OK;
     }
     ThreadGroup& G = *c->threads;
@@ -1084,6 +1093,100 @@ int gndt_gather_owned_map_device(gndt_handle* h, gndt_comm* c, int32_t root, voi
         if (me != root) { HIP_TRY(h, hipStreamSynchronize(s)); return GNDT_OK; }     // (this rank keeps the columns it owns)
     }
     return gndt_adopt_rows_device(h, X.grec_all, n_recv, N, K, S, hip_stream);
+}
+
+// One tiny round of every collective the sharded builds use, each verified against what it must produce: the first multi-rank run
+// of a node is otherwise also the first test of libgndt's RCCL path (this pool has one-GPU boxes: rounds 1-3 never saw two RCCL
+// ranks).  All ranks call it; every rank checks its own results.  bench.py --gpus N runs it before the first build.
+int gndt_comm_selftest(gndt_handle* h, gndt_comm* c, gndt_comm_selftest_report* out, void* hip_stream) {
+    if (!h || !c || !out) return GNDT_ERR_INVALID;
+    if (!c->nccl && !c->threads) { h->err = "no communicator"; return GNDT_ERR_INVALID; }
+    HIP_TRY(h, hipSetDevice(h->device));
+    h->capturing = false;
+    hipStream_t s = stream_of(h, hip_stream);
+    const int W = c->world, me = c->rank;
+    *out = gndt_comm_selftest_report{};
+    out->ranks = (uint32_t)W;
+    constexpr size_t kN = 256;                         // elements per rank and primitive
+    const size_t words = (size_t)W * kN * 2 + 64;
+    uint32_t *d_send = nullptr, *d_recv = nullptr;
+    HIP_TRY(h, hipMalloc(&d_send, words * 4));
+    HIP_TRY(h, hipMalloc(&d_recv, words * 4));
+    std::vector<uint32_t> hs(words), hr(words);
+    int rc = GNDT_OK;
+    auto wall = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    auto up = [&](size_t nwords) { return hipMemcpyAsync(d_send, hs.data(), nwords * 4, hipMemcpyHostToDevice, s) == hipSuccess; };
+    auto down = [&](size_t nwords) { return hipMemcpyAsync(hr.data(), d_recv, nwords * 4, hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess; };
+    std::string bad;
+    // 1. all-gather (u32)
+    if (rc == GNDT_OK) {
+        for (size_t i = 0; i < kN; ++i) hs[i] = (uint32_t)(me * 1000 + i);
+        const double t0 = wall();
+        if (!up(kN)) rc = GNDT_ERR_HIP;
+        if (rc == GNDT_OK) rc = comm_all_gather(h, c, d_send, d_recv, kN, 4, s);
+        if (rc == GNDT_OK && !down((size_t)W * kN)) rc = GNDT_ERR_HIP;
+        out->all_gather_ms = (float)(wall() - t0);
+        bool ok = rc == GNDT_OK;
+        for (int q = 0; ok && q < W; ++q) for (size_t i = 0; i < kN; ++i) if (hr[(size_t)q * kN + i] != (uint32_t)(q * 1000 + i)) { ok = false; break; }
+        if (ok) out->ok_mask |= 1u; else if (rc == GNDT_OK) bad += " all-gather";
+    }
+    // 2. all-to-all of runs (ncclSend / ncclRecv in one group): rank r sends 64 words r * 100 + q + i to every q
+    if (rc == GNDT_OK) {
+        constexpr size_t kRun = 64;
+        std::vector<uint64_t> so((size_t)W), sc((size_t)W), ro((size_t)W), rcv((size_t)W);
+        for (int q = 0; q < W; ++q) {
+            so[q] = (uint64_t)q * kRun * 4; sc[q] = q == me ? 0 : kRun * 4; ro[q] = (uint64_t)q * kRun * 4; rcv[q] = q == me ? 0 : kRun * 4;
+            for (size_t i = 0; i < kRun; ++i) hs[(size_t)q * kRun + i] = (uint32_t)(me * 100 + q + i * 7);
+        }
+        const double t0 = wall();
+        if (!up((size_t)W * kRun)) rc = GNDT_ERR_HIP;
+        if (rc == GNDT_OK && hipMemsetAsync(d_recv, 0, (size_t)W * kRun * 4, s) != hipSuccess) rc = GNDT_ERR_HIP;
+        if (rc == GNDT_OK && W > 1) rc = comm_exchange(h, c, reinterpret_cast<const char*>(d_send), so.data(), sc.data(), reinterpret_cast<char*>(d_recv), ro.data(), rcv.data(), s);
+        if (rc == GNDT_OK && !down((size_t)W * kRun)) rc = GNDT_ERR_HIP;
+        out->exchange_ms = (float)(wall() - t0);
+        bool ok = rc == GNDT_OK;
+        for (int q = 0; ok && q < W; ++q) { if (q == me) continue; for (size_t i = 0; i < kRun; ++i) if (hr[(size_t)q * kRun + i] != (uint32_t)(q * 100 + me + i * 7)) { ok = false; break; } }
+        if (ok) out->ok_mask |= 2u; else if (rc == GNDT_OK) bad += " send/recv";
+    }
+    // 3. reduce-scatter (u32 sum)
+    if (rc == GNDT_OK) {
+        for (int q = 0; q < W; ++q) for (size_t i = 0; i < kN; ++i) hs[(size_t)q * kN + i] = (uint32_t)(me + 1 + q * 3 + i);
+        const double t0 = wall();
+        if (!up((size_t)W * kN)) rc = GNDT_ERR_HIP;
+        if (rc == GNDT_OK) rc = comm_reduce_scatter_u32(h, c, d_send, d_recv, kN, s);
+        if (rc == GNDT_OK && !down(kN)) rc = GNDT_ERR_HIP;
+        out->reduce_scatter_ms = (float)(wall() - t0);
+        bool ok = rc == GNDT_OK;
+        const uint32_t ranks_sum = (uint32_t)(W * (W + 1) / 2);
+        for (size_t i = 0; ok && i < kN; ++i) if (hr[i] != ranks_sum + (uint32_t)W * (uint32_t)(me * 3 + i)) ok = false;
+        if (ok) out->ok_mask |= 4u; else if (rc == GNDT_OK) bad += " reduce-scatter";
+    }
+    // 4. all-reduce: f64 sum and u32 min, in place
+    if (rc == GNDT_OK) {
+        double* hd = reinterpret_cast<double*>(hs.data());
+        for (size_t i = 0; i < kN; ++i) hd[i] = 0.5 * (me + 1) + (double)i;
+        const double t0 = wall();
+        if (!up(2 * kN)) rc = GNDT_ERR_HIP;
+        if (rc == GNDT_OK) rc = comm_all_reduce(h, c, d_send, kN, true, s);
+        if (rc == GNDT_OK && (hipMemcpyAsync(hr.data(), d_send, 2 * kN * 4, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)) rc = GNDT_ERR_HIP;
+        bool ok = rc == GNDT_OK;
+        const double* rd = reinterpret_cast<const double*>(hr.data());
+        for (size_t i = 0; ok && i < kN; ++i) if (rd[i] != 0.5 * (W * (W + 1) / 2) + (double)W * (double)i) ok = false;
+        if (rc == GNDT_OK) {
+            for (size_t i = 0; i < kN; ++i) hs[i] = (uint32_t)(1000 - me + i);
+            if (!up(kN)) rc = GNDT_ERR_HIP;
+            if (rc == GNDT_OK) rc = comm_all_reduce(h, c, d_send, kN, false, s);
+            if (rc == GNDT_OK && (hipMemcpyAsync(hr.data(), d_send, kN * 4, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)) rc = GNDT_ERR_HIP;
+            for (size_t i = 0; ok && rc == GNDT_OK && i < kN; ++i) if (hr[i] != (uint32_t)(1000 - (W - 1) + i)) ok = false;
+        }
+        out->all_reduce_ms = (float)(wall() - t0);
+        if (ok && rc == GNDT_OK) out->ok_mask |= 8u; else if (rc == GNDT_OK) bad += " all-reduce";
+    }
+    (void)hipFree(d_send);
+    (void)hipFree(d_recv);
+    if (rc) return rc;
+    if (out->ok_mask != 15u) { h->err = "communicator self-test: wrong result from" + bad + " on rank " + std::to_string(me); return GNDT_ERR_PEER; }
+    return GNDT_OK;
 }
 
 }  // extern "C"

@@ -380,6 +380,16 @@ class TwoDmap:
         Every rank of the communicator calls it; ranks other than `root` keep the columns they own."""
         self._check(self._L.gndt_gather_owned_map_device(self._h, comm.handle, int(root), _stream_ptr(stream)))
 
+    def comm_selftest(self, comm, stream=None, demand="slope"):
+        """gndt_comm_selftest: one verified round of every collective the sharded builds use (all ranks call it together)."""
+        from ._lib import CommSelftest
+        self._ensure(demand, need_origin=False)
+        rep = CommSelftest()
+        self._check(self._L.gndt_comm_selftest(self._h, comm.handle, C.byref(rep), _stream_ptr(stream)))
+        return {"ok_mask": int(rep.ok_mask), "ranks": int(rep.ranks), "all_gather_ms": round(float(rep.all_gather_ms), 3),
+                "exchange_ms": round(float(rep.exchange_ms), 3), "reduce_scatter_ms": round(float(rep.reduce_scatter_ms), 3),
+                "all_reduce_ms": round(float(rep.all_reduce_ms), 3)}
+
     def owned_pack_rows(self, stream=None):
         """This rank's rows as packed records [n, 21] int32 (device view, valid until the next call): for hosts with their own transport."""
         import torch

@@ -236,6 +236,16 @@ int gndt_comm_create(const char id[GNDT_COMM_ID_BYTES], int32_t rank, int32_t wo
 int gndt_comm_create_threads(int32_t world, int32_t device_id, gndt_comm** out /* [world] */);
 void gndt_comm_destroy(gndt_comm* c);
 const char* gndt_comm_last_error(void);
+/* One tiny, VERIFIED round of every collective the sharded builds use — all-gather, the all-to-all of runs (ncclSend / ncclRecv in
+ * one group), reduce-scatter, all-reduce (f64 sum, u32 min) — on communicator `c`, all ranks calling together.  ok_mask: bit 0
+ * all-gather, 1 send/recv, 2 reduce-scatter, 3 all-reduce; times include the host copies that carry the test data.  Returns GNDT_OK
+ * only if every primitive gave the right answer on this rank (GNDT_ERR_PEER and gndt_last_error(h) name the wrong one).  Run it
+ * once before the first sharded build of a job: that build is otherwise the first test of the transport. */
+typedef struct {
+    float all_gather_ms, exchange_ms, reduce_scatter_ms, all_reduce_ms;
+    uint32_t ok_mask, ranks;
+} gndt_comm_selftest_report;
+int gndt_comm_selftest(gndt_handle* h, gndt_comm* c, gndt_comm_selftest_report* out, void* hip_stream);
 /* first_idx_base = index of shard[0] in the whole cloud's binned points; total_points = binned points of the whole cloud.
  * `times` may be NULL (it makes the call wait for the stream). */
 int gndt_build_global_device(gndt_handle* h, gndt_comm* c, const void* shard_xyz_dev, size_t n, size_t stride_bytes,

@@ -27,13 +27,13 @@ def test_self_launch_two_ranks_shards_the_default_multi_gpu_workload():
     assert j0 == j1 == 300000                     # point 0 is the origin and is not binned (receiver.cpp:145, 150)
     assert b0 == 0 and b1 == n0 and n0 + n1 == 300000   # contiguous index ranges that tile the binned points
     # the N > 1 line's extra keys, and the cloud rank 0 builds alone for the single-GPU anchor: the very cloud the ranks share
-    assert out["multi_gpu_keys"] == ["single_gpu_anchor", "speedup_vs_single_gpu", "gather_ms", "modes", "exchange"]
+    assert out["multi_gpu_keys"] == ["single_gpu_anchor", "speedup_vs_single_gpu", "gather_ms", "modes", "exchange", "comm_selftest"]
     assert out["anchor_points"] == 300000 and out["anchor_is_the_ranks_cloud"] is True
 
 
 def test_self_launch_global_mode_without_anchor():
     out = _run(["--gpus", "2", "--launch-check", "--points", "100000", "--mode", "global", "--no-anchor"])
-    assert out["mode"] == "global" and out["multi_gpu_keys"] == ["exchange"] and out["anchor_points"] is None
+    assert out["mode"] == "global" and out["multi_gpu_keys"] == ["exchange", "comm_selftest"] and out["anchor_points"] is None
 
 
 def test_self_launch_replicas_mode_gives_each_rank_its_own_cloud():

@@ -26,6 +26,7 @@ def test_multi_gpu_line_carries_anchor_gather_and_modes():
     assert a["retries_in_timed_region"] == 0 and d["speedup_vs_single_gpu"] > 0
     assert d["gather_ms"]["value"] > 0 and d["gather_ms"]["assembled_map_matches_totals"] and d["gather_ms"]["rows"] == d["config"]["nodes"]
     assert d["modes"]["global"]["nodes"] == d["config"]["nodes"] and d["modes"]["global"]["ms_per_step"] > 0
+    assert d["comm_selftest"]["ok_mask"] == 15 and d["comm_selftest"]["ranks"] == 1      # (RCCL itself, one rank: every primitive verified)
 
 
 @pytest.mark.parametrize("fail,ends_on", [("owner", "global"), ("owner,global", "shards_without_exchange")])

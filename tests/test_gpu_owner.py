@@ -486,6 +486,29 @@ def test_gathered_owner_build_is_the_single_gpu_map_and_floods_like_it(W, root):
         c.close()
 
 
+@pytest.mark.parametrize("W", [1, 2, 5, 8])
+def test_communicator_selftest_verifies_every_collective(W):
+    """gndt_comm_selftest: all-gather, send/recv all-to-all, reduce-scatter, all-reduce (f64 sum, u32 min), each checked against what
+    it must produce — on thread ranks (device copies) here, on RCCL with one rank in tests/test_gpu_bench_line.py, and by
+    bench.py --gpus N before its first build on a real node."""
+    import torch
+    from grid_ndt_amd.dist import Communicator
+    cloud, P = scenes.campus_frame(5000), scenes.CAMPUS_PARAMS
+    maps, comms = _ranks(cloud, P, W), Communicator.threads(W)
+
+    def rank(r):
+        torch.cuda.set_device(0)
+        s = torch.cuda.Stream()
+        with torch.cuda.stream(s):
+            return maps[r].comm_selftest(comms[r], s)
+
+    res, errs = _threads(W, rank)
+    assert not errs, errs
+    assert all(rep["ok_mask"] == 15 and rep["ranks"] == W for rep in res), res
+    for c in comms:
+        c.close()
+
+
 def test_a_second_gather_of_the_same_build_is_refused_on_every_rank():
     """After a rooted gather the root's handle holds the whole map and no longer its owned rows.  A second gather of the same build
     is refused on EVERY rank before any collective (round 3: the old root returned and the others waited in the exchange for ever);
