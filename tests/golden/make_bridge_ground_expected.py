@@ -53,6 +53,7 @@ def fp32_sequential(pts, inv, cnt, has):
 
 
 def evaluate(cloud, P, with_fp64=True):
+    demand_true = P.get("demand", "slope") == "true"
     o = cloud[0].astype(np.float32)
     pts = cloud[1:]
     lens = np.float32([P["grid_len"], P["grid_len"], P["z_len"]])
@@ -115,7 +116,9 @@ def evaluate(cloud, P, with_fp64=True):
                     up = True
                 else:
                     down = True
-        if not up:
+        if demand_true:                                   # map2D.h:644-659: always a Slope, `down` left as constructed (false)
+            flags[i] |= 2
+        elif not up:
             flags[i] |= 2
             if down:
                 flags[i] |= 4
@@ -139,7 +142,9 @@ def evaluate(cloud, P, with_fp64=True):
                     up = True
                 else:
                     down = True
-        if not up:
+        if demand_true:
+            flags32[i] |= 2
+        elif not up:
             flags32[i] |= 2
             if down:
                 flags32[i] |= 4
@@ -160,7 +165,13 @@ def main():
                                  ("campus_100k_expected.npz", scenes.campus_frame(100_000), scenes.CAMPUS_PARAMS, False),
                                  # one scan-ordered LiDAR frame of the S3 / S4 terrain (131 072 points, vegetation: columns of
                                  # several levels, so the up / down comparisons of isSlope are exercised on most columns)
-                                 ("terrain_frame_expected.npz", scenes.terrain_frames(1, 5), scenes.TERRAIN_PARAMS, False)):
+                                 ("terrain_frame_expected.npz", scenes.terrain_frames(1, 5), scenes.TERRAIN_PARAMS, False),
+                                 # round 4: demand "true" (every node with statistics becomes a Slope, `down` never assigned,
+                                 # map2D.h:644-659) on a terrain cloud at the launch z resolution ...
+                                 ("terrain_true_expected.npz", scenes.terrain_cloud(120_000), dict(grid_len=0.2, z_len=0.1, slope_interval=0.08, demand="true"), False),
+                                 # ... and the two-storey site with the converters' (0,0,0) padding (15 % of the points in ONE node:
+                                 # its fp32 running sums are the reference's own worst case), 0.1 m cubic cells
+                                 ("site_zero_padded_expected.npz", scenes.site_two_storey(150_000), dict(grid_len=0.1, z_len=0.1, slope_interval=0.08, demand="slope"), False)):
         res = evaluate(cloud, P, with_fp64=full)
         out = os.path.join(here, name)
         np.savez_compressed(out, **res)

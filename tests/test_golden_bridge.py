@@ -11,6 +11,18 @@ from tests import parity, scenes
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "bridge_ground_expected.npz")
 GOLD_CAMPUS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "campus_100k_expected.npz")
 GOLD_TERRAIN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "terrain_frame_expected.npz")
+GOLD_TRUE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "terrain_true_expected.npz")
+GOLD_SITE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "site_zero_padded_expected.npz")
+TRUE_PARAMS = dict(grid_len=0.2, z_len=0.1, slope_interval=0.08, demand="true")
+SITE_PARAMS = dict(grid_len=0.1, z_len=0.1, slope_interval=0.08, demand="slope")
+
+
+def fp32_cases():
+    """(golden, cloud, parameters) of every numpy-only fp32 golden: the reference's scene, a non-lattice frame, a LiDAR frame,
+    demand "true" (round 4) and the zero-padded site (round 4: 15 % of the points in one node)."""
+    return ((GOLD, scenes.bridge_ground(), scenes.BRIDGE_PARAMS), (GOLD_CAMPUS, scenes.campus_frame(100_000), scenes.CAMPUS_PARAMS),
+            (GOLD_TERRAIN, scenes.terrain_frames(1, 5), scenes.TERRAIN_PARAMS), (GOLD_TRUE, scenes.terrain_cloud(120_000), TRUE_PARAMS),
+            (GOLD_SITE, scenes.site_two_storey(150_000), SITE_PARAMS))
 
 
 def check_fp32_half(got, gold_path, what, bit_exact_statistics):
@@ -77,8 +89,7 @@ def test_oracle_reproduces_the_numpy_golden():
 def test_oracle_fp32_statistics_and_labels_are_bit_identical_to_the_numpy_float32_restatement():
     """The oracle's stand-in for pcl::compute3DCentroid / computeCovarianceMatrix (map2D.h:621-622) and for OcNode::isSlope's
     fp32 comparisons, pinned by a restatement that shares no code with it: on the reference's own scene and on a non-lattice one."""
-    for gold, cloud, P in ((GOLD, scenes.bridge_ground(), scenes.BRIDGE_PARAMS), (GOLD_CAMPUS, scenes.campus_frame(100_000), scenes.CAMPUS_PARAMS),
-                           (GOLD_TERRAIN, scenes.terrain_frames(1, 5), scenes.TERRAIN_PARAMS)):
+    for gold, cloud, P in fp32_cases():
         for mode in (0, 1, 2):
             ref = parity.ref_from_cloud(cloud, P, mode=mode, threads=3 if mode == 2 else 0)
             print(check_fp32_half(ref, gold, f"oracle mode {mode}", True))
@@ -101,3 +112,13 @@ def test_hip_path_reproduces_the_numpy_golden(strategy):
     print(check_fp32_half(out, GOLD_CAMPUS, f"libgndt strategy {strategy}, campus", False))
     _, out = parity.gpu_from_cloud(scenes.terrain_frames(1, 5), scenes.TERRAIN_PARAMS, strategy=strategy)
     print(check_fp32_half(out, GOLD_TERRAIN, f"libgndt strategy {strategy}, terrain frame", False))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("strategy", [0, 1, 3, 4], ids=["auto", "atomic", "partition_exact", "partition_two_level"])
+def test_hip_path_reproduces_the_true_demand_and_zero_padded_goldens(strategy):
+    """Round 4: every label of the numpy-only goldens for demand "true" and for the zero-padded site, exactly — no dense-cloud gate,
+    no margin mask — and the centroids within the north_star tolerance."""
+    for gold, cloud, P in fp32_cases()[3:]:
+        _, out = parity.gpu_from_cloud(cloud, P, strategy=strategy)
+        print(check_fp32_half(out, gold, f"libgndt strategy {strategy}, {os.path.basename(gold)}", False))

@@ -151,3 +151,10 @@ def test_one_handle_builds_a_sequence_of_unrelated_clouds(seed):
     stats = fuzz_campaign.run(seconds=120.0, seed=seed, max_points=400_000, max_handles=12)
     assert not stats["failures"], stats["failures"]
     assert stats["builds"] >= 24
+    # The dense gate lets a slope / down label differ from the fp32 oracle's where it is the label the reference's rule gives on the
+    # EXACT centroids (tests/parity.py).  That exception is reported and capped: more than 1e-5 of the nodes passing on it would mean
+    # the gate, not the reference's fp32 rounding, is doing the work (the long campaign: 1 520 of 208 M nodes).
+    share = stats.get("labels_within_margin", 0) / max(1, stats.get("nodes", 1))
+    print("labels that differ from the fp32 oracle and equal the rule on exact centroids:", stats.get("labels_within_margin", 0), "of",
+          stats.get("nodes", 0), "nodes; decided within 1e-5 of the interval:", stats.get("labels_on_the_margin", 0))
+    assert share <= 1e-5, (stats.get("labels_within_margin"), stats.get("nodes"))
