@@ -64,9 +64,7 @@ struct BucketLds3 {           // 70 KB at H = 512: two workgroups per CU
                                 //   needs of the others in one 16-byte load each, with independent addresses (loads pipeline; a linked
                                 //   list chased one LDS round trip per node): first-seen index, z level, fp32 mean z (0 below min_points)
     float mz[H];                // (kept from the column phase until the arrays are filled)
-    uint16_t kcol[H];           // the node's arrival number in its column
     uint32_t chead[H];          // column table: a node of the column (its key is the column's key: no separate column keys), kNoNode = free
-    uint16_t cslot[H];          // column slot of the node
     uint32_t ccnt[H];           // nodes of the column in this column slot; after the prefix (first row inside the bucket) << 16 | nodes
     uint32_t n_nodes, n_cols, n_slopes, stage_base, overflow, err_range, row_cursor;
     uint32_t clash;             // records whose fingerprint named another node (they went on with the key itself)
@@ -486,29 +484,39 @@ __device__ __forceinline__ void bucket_direct_one(BucketLds3<H>& L, const uint32
         return;
     }
 
+    // ---- per-node phases: ONE node per thread (a table holds at most H = T nodes), so what a node learns in one phase — its
+    //      key, count, first-seen index, mean z, column slot, number in its column — stays in REGISTERS across the barriers
+    //      (round 3 kept it in LDS arrays: three more dependent round trips, each behind the other workgroup's fp64 atomics) ----
+    static_assert(H <= T, "one node per thread");
+    const bool live = (uint32_t)tid < M;
+    const uint32_t s = (uint32_t)tid;
+    uint64_t key = 0;
+    int sx = 0, sy = 0, sz = 0;
+    uint32_t my_n = 0, my_first = 0xFFFFFFFFu, col = 0, kc = 0;
+    float cz = 0.f;
     // ---- columns: every node finds the slot of its column and takes a number in it; fp32 mean-z of the nodes that have statistics ----
-    for (uint32_t i = tid; i < M; i += T) {
-        const uint32_t s = i;
-        const uint64_t key = L.key[s];
-        int sx, sy, sz;
+    if (live) {
+        key = L.key[s];
+        my_n = L.cnt[s];
+        my_first = L.first[s];
+        const double sum_z = L.sum[2][s];
         unpack_key(key, sx, sy, sz);
-        const uint32_t n = L.cnt[s];
-        L.mz[s] = (n >= (uint32_t)P.min_points) ? node_mean_z(n, L.sum[2][s], axis_centre(sz, P.oz, P.z_len)) : 0.f;
+        cz = (my_n >= (uint32_t)P.min_points) ? node_mean_z(my_n, sum_z, axis_centre(sz, P.oz, P.z_len)) : 0.f;
+        L.mz[s] = cz;                                         // (tall columns look their z neighbours up by node number)
         const uint64_t ck = column_key(key);
-        uint32_t c = ((column_hash(sx, sy) * 0x85EBCA77u) >> 12) & (uint32_t)(H - 1);
+        col = ((column_hash(sx, sy) * 0x85EBCA77u) >> 12) & (uint32_t)(H - 1);
         for (int probe = 0; probe < H; ++probe) {            // (terminates: the table has more slots than nodes)
-            uint32_t head = L.chead[c];
+            uint32_t head = L.chead[col];
             if (head == kNoNode) {
-                head = atomicCAS(&L.chead[c], kNoNode, s);
+                head = atomicCAS(&L.chead[col], kNoNode, s);
                 if (head == kNoNode) { atomicAdd(&L.n_cols, 1u); break; }                           // first node of a new column
             }
             if (column_key(L.key[head]) == ck) break;
-            c = (c + 1) & (uint32_t)(H - 1);
+            col = (col + 1) & (uint32_t)(H - 1);
         }
-        L.cslot[s] = (uint16_t)c;
-        L.kcol[s] = (uint16_t)atomicAdd(&L.ccnt[c], 1u);
+        kc = atomicAdd(&L.ccnt[col], 1u);
     }
-    __syncthreads();
+    lds_barrier();
     if (tid == 0) atomicAdd(&cnt->num_columns, L.n_cols);
     // The rows of a column are staged NEXT TO EACH OTHER, in first-seen order: every column reserves its rows inside the bucket.
     // The ordering pass then works per column (one lookup of the column's place instead of one per node) and the emit pass
@@ -518,10 +526,10 @@ __device__ __forceinline__ void bucket_direct_one(BucketLds3<H>& L, const uint32
         if (v) L.ccnt[c] = (atomicAdd(&L.row_cursor, v) << 16) | v;
     }
     lds_barrier();
-    for (uint32_t i = tid; i < M; i += T) {
-        const uint32_t s = i;
-        const int sz = (int)(L.key[s] & 0x3FFFFFu) - (1 << 21);
-        L.colnodes[(L.ccnt[L.cslot[s]] >> 16) + L.kcol[s]] = make_uint4(L.first[s], (uint32_t)sz, __float_as_uint(L.mz[s]), s);
+    uint32_t cinfo = 0;
+    if (live) {
+        cinfo = L.ccnt[col];
+        L.colnodes[(cinfo >> 16) + kc] = make_uint4(my_first, (uint32_t)sz, __float_as_uint(cz), s);
     }
     lds_barrier();
     GNDT_STAMP3(3);
@@ -529,20 +537,16 @@ __device__ __forceinline__ void bucket_direct_one(BucketLds3<H>& L, const uint32
     // ---- rows: slope label (OcNode::isSlope, map2D.h:66-108), index in column, column size and first-seen index by
     //      walking the column's short list; mean + fp64 scatter -> staging row ----
     uint32_t my_slopes = 0;
-    for (uint32_t i = tid; i < M; i += T) {
-        const uint32_t s = i;
-        const uint64_t key = L.key[s];
-        const uint32_t my_first = L.first[s];
-        int sx, sy, sz;
-        unpack_key(key, sx, sy, sz);
+    if (live) {
         const int za = level_above(sz), zb = level_below(sz);
-        const float cz = L.mz[s];
-        const uint32_t my_n = L.cnt[s];
-        uint32_t icol = 0, ncol = 0, cf = 0xFFFFFFFFu;
+        uint32_t icol = 0, cf = 0xFFFFFFFFu;
         bool up = false, down = false;
-        const uint32_t cinfo = L.ccnt[L.cslot[s]];
         const uint32_t cbase = cinfo >> 16;
-        ncol = cinfo & 0xFFFFu;
+        const uint32_t ncol = cinfo & 0xFFFFu;
+        uint32_t fl = (my_n >= (uint32_t)P.min_points) ? 1u : 0u;
+        double sums[9];                                        // (requested now: they arrive while the column is walked)
+#pragma unroll
+        for (int j = 0; j < 9; ++j) sums[j] = L.sum[j][fl ? s : 0u];
         // Tall columns (walls: dozens of levels) look their two z neighbours up in the node index — two short probes — and walk
         // the column only for what needs every node of it (index in column, the column's first-seen index): three instructions
         // per node instead of ten.  Short columns find the neighbours during the walk, as before.
@@ -589,7 +593,6 @@ __device__ __forceinline__ void bucket_direct_one(BucketLds3<H>& L, const uint32
             }
         }
         cf = min(cf, my_first);
-        uint32_t fl = (my_n >= (uint32_t)P.min_points) ? 1u : 0u;
         if (fl) {
             bool slope = true;
             if (P.demand == 0) slope = !up; else down = false;
@@ -601,9 +604,6 @@ __device__ __forceinline__ void bucket_direct_one(BucketLds3<H>& L, const uint32
         for (int k = 0; k < 3; ++k) row.mean[k] = 0.f;
         for (int k = 0; k < 6; ++k) row.scatter[k] = 0.0;
         if (fl & 1u) {
-            double sums[9];
-#pragma unroll
-            for (int j = 0; j < 9; ++j) sums[j] = L.sum[j][s];
             const double c[3] = {axis_centre(sx, P.ox, P.grid_len), axis_centre(sy, P.oy, P.grid_len), axis_centre(sz, P.oz, P.z_len)};
             node_moments(row.count, sums, c, row.mean, row.scatter);
         }

@@ -77,6 +77,15 @@ def trans_morton_xyz(origin, grid_len, z_len, p):
 MODE_AS_SHIPPED, MODE_INT_SERIAL, MODE_INT_OPENMP = 0, 1, 2
 
 
+EIGEN_JACOBI, EIGEN_GENERAL_QR = 0, 1
+
+
+def set_eigen_solver(which):
+    """The fp32 eigen-solve the oracle uses for OcNode::countRoughNormal (map2D.h:110-133): EIGEN_JACOBI (default: cyclic Jacobi on the
+    symmetric scatter) or EIGEN_GENERAL_QR (Hessenberg + shifted QR + back-substitution: the route Eigen::EigenSolver takes)."""
+    lib().oracle_set_eigen_solver(int(which))
+
+
 def build_grid(cloud, grid_len, z_len, slope_interval, demand="slope", min_points=3, mode=MODE_AS_SHIPPED,
                threads=0, export=True, truth=None):
     """Run the reference path on `cloud` ([N, 3|4] float32, point 0 = origin and is not binned:

@@ -40,6 +40,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <limits>
 #include <list>
 #include <map>
 #include <memory>
@@ -123,6 +124,217 @@ void jacobi3(const T c[6], T evals[3], T evecs[3][3]) {
     }
 }
 
+// ---- general real eigen-solver of a 3x3 (what Eigen::EigenSolver<Matrix3f> runs, map2D.h:111-113) ----
+// The reference does NOT call a symmetric solver: EigenSolver reduces the matrix to Hessenberg form with a Householder reflector,
+// runs shifted (Francis) QR iterations to the real Schur form while accumulating the transformations, finds the eigenvectors of
+// the triangular factor by back-substitution and transforms them back — the EISPACK orthes / hqr2 route (Wilkinson & Reinsch;
+// published in JAMA, which Eigen's RealSchur and EigenSolver::doComputeEigenvectors cite as their source).  Restated here in the
+// working precision T (fp32 for the reference's Matrix3f).  pseudoEigenvalueMatrix's diagonal = evals in the order the QR
+// iteration deflates them (NOT sorted); pseudoEigenvectors' columns = evecs, NOT normalised (the consumers only use directions,
+// map2D.h:477-482).  A 2x2 block whose discriminant rounds negative (two eigenvalues equal to working precision: Eigen would
+// report a complex pair and the reference would read the block's diagonal) is given as a double eigenvalue with the Schur vectors.
+// Eigen is un-vendored and un-versioned in the reference: this pins nothing — it bounds how much the choice of
+// solver can matter (tests/test_oracle_eigensolver.py compares it with the Jacobi restatement on every fixed scene).
+template <typename T>
+void general_qr3(const T c[6], T evals[3], T evecs[3][3]) {
+    constexpr int nn = 3;
+    T H[3][3] = {{c[0], c[1], c[2]}, {c[1], c[3], c[4]}, {c[2], c[4], c[5]}};
+    T V[3][3], ort[3] = {0, 0, 0}, d[3] = {0, 0, 0}, e[3] = {0, 0, 0};
+    (void)e;                                            // (the imaginary parts: always zero on this path)
+    const int low = 0, high = nn - 1;
+    // orthes: Householder reduction to Hessenberg form
+    for (int m = low + 1; m <= high - 1; ++m) {
+        T scale = 0;
+        for (int i = m; i <= high; ++i) scale += std::fabs(H[i][m - 1]);
+        if (scale != T(0)) {
+            T h = 0;
+            for (int i = high; i >= m; --i) { ort[i] = H[i][m - 1] / scale; h += ort[i] * ort[i]; }
+            T g = std::sqrt(h);
+            if (ort[m] > 0) g = -g;
+            h -= ort[m] * g;
+            ort[m] -= g;
+            for (int j = m; j < nn; ++j) {
+                T f = 0;
+                for (int i = high; i >= m; --i) f += ort[i] * H[i][j];
+                f /= h;
+                for (int i = m; i <= high; ++i) H[i][j] -= f * ort[i];
+            }
+            for (int i = 0; i <= high; ++i) {
+                T f = 0;
+                for (int j = high; j >= m; --j) f += ort[j] * H[i][j];
+                f /= h;
+                for (int j = m; j <= high; ++j) H[i][j] -= f * ort[j];
+            }
+            ort[m] = scale * ort[m];
+            H[m][m - 1] = scale * g;
+        }
+    }
+    for (int i = 0; i < nn; ++i) for (int j = 0; j < nn; ++j) V[i][j] = i == j ? T(1) : T(0);
+    for (int m = high - 1; m >= low + 1; --m) {
+        if (H[m][m - 1] != T(0)) {
+            for (int i = m + 1; i <= high; ++i) ort[i] = H[i][m - 1];
+            for (int j = m; j <= high; ++j) {
+                T g = 0;
+                for (int i = m; i <= high; ++i) g += ort[i] * V[i][j];
+                g = (g / ort[m]) / H[m][m - 1];
+                for (int i = m; i <= high; ++i) V[i][j] += g * ort[i];
+            }
+        }
+    }
+    // hqr2: Francis double-shift QR to the real Schur form
+    int n = nn - 1;
+    const T eps = std::numeric_limits<T>::epsilon();
+    T exshift = 0, p = 0, q = 0, r = 0, s = 0, z = 0, t, w, x, y;
+    T norm = 0;
+    for (int i = 0; i < nn; ++i)
+        for (int j = std::max(i - 1, 0); j < nn; ++j) norm += std::fabs(H[i][j]);
+    int iter = 0, total = 0;
+    if (norm == T(0)) n = low - 1;                      // (the zero matrix is its own Schur form: Eigen's RealSchur skips the iteration too)
+    while (n >= low && total < 40 * nn) {
+        int l = n;
+        while (l > low) {
+            s = std::fabs(H[l - 1][l - 1]) + std::fabs(H[l][l]);
+            if (s == T(0)) s = norm;
+            if (std::fabs(H[l][l - 1]) <= eps * s) break;   // (<=, as Eigen's RealSchur tests it: an exact zero always deflates)
+            --l;
+        }
+        if (l == n) {                                   // one root found
+            H[n][n] += exshift;
+            d[n] = H[n][n]; e[n] = 0;
+            --n; iter = 0;
+        } else if (l == n - 1) {                        // two roots found
+            w = H[n][n - 1] * H[n - 1][n];
+            p = (H[n - 1][n - 1] - H[n][n]) / T(2);
+            q = p * p + w;
+            z = std::sqrt(std::fabs(q));
+            H[n][n] += exshift;
+            H[n - 1][n - 1] += exshift;
+            x = H[n][n];
+            if (q >= 0) {                               // real pair
+                z = p >= 0 ? p + z : p - z;
+                d[n - 1] = x + z;
+                d[n] = d[n - 1];
+                if (z != T(0)) d[n] = x - w / z;
+                e[n - 1] = 0; e[n] = 0;
+                x = H[n][n - 1];
+                s = std::fabs(x) + std::fabs(z);
+                p = x / s; q = z / s;
+                r = std::sqrt(p * p + q * q);
+                p /= r; q /= r;
+                for (int j = n - 1; j < nn; ++j) { z = H[n - 1][j]; H[n - 1][j] = q * z + p * H[n][j]; H[n][j] = q * H[n][j] - p * z; }
+                for (int i = 0; i <= n; ++i) { z = H[i][n - 1]; H[i][n - 1] = q * z + p * H[i][n]; H[i][n] = q * H[i][n] - p * z; }
+                for (int i = low; i <= high; ++i) { z = V[i][n - 1]; V[i][n - 1] = q * z + p * V[i][n]; V[i][n] = q * V[i][n] - p * z; }
+            } else {                                    // discriminant rounded negative: a double eigenvalue to working precision
+                d[n - 1] = x + p; d[n] = x + p;
+                e[n - 1] = 0; e[n] = 0;
+                H[n][n - 1] = 0;                        // (the block is taken as diagonal: its Schur vectors stand for the eigenvectors)
+                H[n - 1][n - 1] = d[n - 1]; H[n][n] = d[n];
+            }
+            n -= 2; iter = 0;
+        } else {                                        // no convergence yet
+            x = H[n][n]; y = 0; w = 0;
+            if (l < n) { y = H[n - 1][n - 1]; w = H[n][n - 1] * H[n - 1][n]; }
+            if (iter == 10) {                           // Wilkinson's original ad hoc shift
+                exshift += x;
+                for (int i = low; i <= n; ++i) H[i][i] -= x;
+                s = std::fabs(H[n][n - 1]) + std::fabs(H[n - 1][n - 2]);
+                x = y = T(0.75) * s;
+                w = T(-0.4375) * s * s;
+            }
+            if (iter == 30) {                           // MATLAB's ad hoc shift
+                s = (y - x) / T(2);
+                s = s * s + w;
+                if (s > 0) {
+                    s = std::sqrt(s);
+                    if (y < x) s = -s;
+                    s = x - w / ((y - x) / T(2) + s);
+                    for (int i = low; i <= n; ++i) H[i][i] -= s;
+                    exshift += s;
+                    x = y = w = T(0.964);
+                }
+            }
+            ++iter; ++total;
+            int m = n - 2;
+            while (m >= l) {
+                z = H[m][m];
+                r = x - z; s = y - z;
+                p = (r * s - w) / H[m + 1][m] + H[m][m + 1];
+                q = H[m + 1][m + 1] - z - r - s;
+                r = H[m + 2][m + 1];
+                s = std::fabs(p) + std::fabs(q) + std::fabs(r);
+                p /= s; q /= s; r /= s;
+                if (m == l) break;
+                if (std::fabs(H[m][m - 1]) * (std::fabs(q) + std::fabs(r)) <
+                    eps * (std::fabs(p) * (std::fabs(H[m - 1][m - 1]) + std::fabs(z) + std::fabs(H[m + 1][m + 1])))) break;
+                --m;
+            }
+            for (int i = m + 2; i <= n; ++i) { H[i][i - 2] = 0; if (i > m + 2) H[i][i - 3] = 0; }
+            for (int k = m; k <= n - 1; ++k) {          // double QR step on rows l:n, columns m:n
+                const bool notlast = k != n - 1;
+                if (k != m) {
+                    p = H[k][k - 1]; q = H[k + 1][k - 1];
+                    r = notlast ? H[k + 2][k - 1] : T(0);
+                    x = std::fabs(p) + std::fabs(q) + std::fabs(r);
+                    if (x == T(0)) continue;
+                    p /= x; q /= x; r /= x;
+                }
+                s = std::sqrt(p * p + q * q + r * r);
+                if (p < 0) s = -s;
+                if (s != T(0)) {
+                    if (k != m) H[k][k - 1] = -s * x;
+                    else if (l != m) H[k][k - 1] = -H[k][k - 1];
+                    p += s; x = p / s; y = q / s; z = r / s; q /= p; r /= p;
+                    for (int j = k; j < nn; ++j) {
+                        p = H[k][j] + q * H[k + 1][j];
+                        if (notlast) { p += r * H[k + 2][j]; H[k + 2][j] -= p * z; }
+                        H[k][j] -= p * x;
+                        H[k + 1][j] -= p * y;
+                    }
+                    for (int i = 0; i <= std::min(n, k + 3); ++i) {
+                        p = x * H[i][k] + y * H[i][k + 1];
+                        if (notlast) { p += z * H[i][k + 2]; H[i][k + 2] -= p * r; }
+                        H[i][k] -= p;
+                        H[i][k + 1] -= p * q;
+                    }
+                    for (int i = low; i <= high; ++i) {
+                        p = x * V[i][k] + y * V[i][k + 1];
+                        if (notlast) { p += z * V[i][k + 2]; V[i][k + 2] -= p * r; }
+                        V[i][k] -= p;
+                        V[i][k + 1] -= p * q;
+                    }
+                }
+            }
+        }
+    }
+    if (norm == T(0)) { for (int i = 0; i < nn; ++i) d[i] = 0; }
+    while (n >= low) { d[n] = H[n][n] + exshift; e[n] = 0; --n; }      // (iteration limit: what is on the diagonal)
+    // back-substitution: eigenvectors of the (quasi-)triangular factor, all roots real here
+    if (norm != T(0)) {
+        for (n = nn - 1; n >= 0; --n) {
+            p = d[n];
+            H[n][n] = 1;
+            for (int i = n - 1; i >= 0; --i) {
+                w = H[i][i] - p;
+                r = 0;
+                for (int j = i + 1; j <= n; ++j) r += H[i][j] * H[j][n];
+                H[i][n] = w != T(0) ? -r / w : -r / (eps * norm);
+                t = std::fabs(H[i][n]);
+                if ((eps * t) * t > 1) for (int j = i; j <= n; ++j) H[j][n] /= t;     // overflow control
+            }
+        }
+        for (int j = nn - 1; j >= low; --j)             // back transformation to the eigenvectors of the original matrix
+            for (int i = low; i <= high; ++i) {
+                z = 0;
+                for (int k = low; k <= std::min(j, high); ++k) z += V[i][k] * H[k][j];
+                V[i][j] = z;
+            }
+    }
+    for (int i = 0; i < 3; ++i) {
+        evals[i] = d[i];
+        for (int k = 0; k < 3; ++k) evecs[k][i] = V[k][i];
+    }
+}
+
 // map2D.h:114-130: index of the chosen eigenvalue; ties go to the higher index.
 template <typename T>
 inline int pick_min(const T e[3]) {
@@ -175,9 +387,11 @@ void fit_node(Node& nd, const float* xyz, size_t stride, const Params& P) {
     for (int k = 0; k < 6; ++k) nd.cov64[k] = d[k];
 }
 
+int g_eigen_solver = 0;      // 0: cyclic Jacobi (symmetric); 1: Hessenberg + shifted QR + back-substitution, EigenSolver's route
 void eigen_node(Node& nd) {  // OcNode::countRoughNormal, map2D.h:110-133
     float ev[3], vec[3][3];
-    jacobi3<float>(nd.cov, ev, vec);
+    if (g_eigen_solver == 1) general_qr3<float>(nd.cov, ev, vec);
+    else jacobi3<float>(nd.cov, ev, vec);
     int j = pick_min(ev);
     nd.rough = ev[j];
     for (int k = 0; k < 3; ++k) { nd.normal[k] = vec[k][j]; nd.evals[k] = ev[k]; }
@@ -447,6 +661,7 @@ Grid* build_int_keys(const float* xyz, size_t n, size_t stride, const float o[3]
 extern "C" {
 
 void oracle_set_truth(int on) { g_with_truth = on != 0; }
+void oracle_set_eigen_solver(int which) { g_eigen_solver = which == 1 ? 1 : 0; }
 
 // ---- key codec entry points ---------------------------------------------------------------------
 int oracle_count_morton(int a, int b, char* out, int cap) {
