@@ -60,7 +60,10 @@ uint64_t buckets_for(uint64_t n, uint64_t nodes, int slots, int load_pct) {
     // Clouds of up to a few million points do not fill the chip with 2800-point buckets (200 k points: 71 workgroups for 256
     // CUs): down to 700 points per bucket below a million points, measured 5-13 % faster there (campus / bridge / terrain / uniform
     // clouds of 0.1-1 M points) and slower from 2 M points on.
-    const uint64_t small_cloud = std::min<uint64_t>(2800, std::max<uint64_t>(700, n / 1024));
+    // Round 4: 3600 (was 2800) for clouds that fill the chip either way — with the fingerprint index a bucket's accumulate phase
+    // is shorter and the per-bucket phases weigh more: bench scene 2000 / 2400 / 2800 / 3072 / 3600 / 4000 points per bucket:
+    // 0.418 / 0.399 / 0.393 / 0.383 / 0.372 / 0.385 ms per build (node-heavy clouds get their bucket count from the nodes, below).
+    const uint64_t small_cloud = std::min<uint64_t>(3600, std::max<uint64_t>(700, n / 1024));
     const uint64_t per_bucket = slots >= 1024 ? 6400 : small_cloud;
     const uint64_t node_room = (uint64_t)slots * load_pct;
     const uint64_t want = std::max<uint64_t>(n / per_bucket, (nodes * 100) / node_room);
