@@ -19,15 +19,11 @@ Tuning parse_tuning() {
     t.bucket_load_large = geti("GNDT_BUCKET_LOAD_LARGE", getenv("GNDT_BUCKET_LOAD") ? t.bucket_load : t.bucket_load_large);   // (one knob set: both follow it)
     t.bucket_points = geti("GNDT_BUCKET_POINTS", t.bucket_points);
     t.bucket_slots = geti("GNDT_BUCKET_SLOTS", t.bucket_slots);
-    t.part_wgs = geti("GNDT_PART_WGS", t.part_wgs);
     t.two_level = geti("GNDT_TWO_LEVEL", t.two_level);
-    t.l1_rep = geti("GNDT_L1_REP", t.l1_rep);
     t.l1_wgs = (uint32_t)geti("GNDT_L1_WGS", (int)t.l1_wgs);
     if (getenv("GNDT_BUCKET_WGS")) t.bucket_wgs = (uint32_t)atoi(getenv("GNDT_BUCKET_WGS"));
     if (getenv("GNDT_TILE_RATIO")) t.tile_ratio = atof(getenv("GNDT_TILE_RATIO"));
-    t.update_tile = geti("GNDT_UPDATE_TILE", t.update_tile);
     t.owner_locality = geti("GNDT_OWNER_LOCALITY", t.owner_locality);
-    t.owner_sliced_rows = geti("GNDT_OWNER_SLICED", t.owner_sliced_rows);
     t.one_level = geti("GNDT_ONE_LEVEL", t.one_level);
     t.fp_bits = std::min(21, std::max(0, geti("GNDT_FP_BITS", t.fp_bits)));
     t.stamps = getenv("GNDT_STAMPS") != nullptr;

@@ -504,7 +504,7 @@ int owner_split_launch(gndt_handle* h, const void* xyz, size_t n, size_t stride_
     if (!X.h_split_cnt) HIP_TRY(h, hipHostMalloc(&X.h_split_cnt, sizeof(Counters)));
     if (!X.h_matrix) HIP_TRY(h, hipHostMalloc(&X.h_matrix, ((size_t)kMaxRanks * (kMaxRanks + 1) + kMaxRanks + 1) * sizeof(uint32_t)));
     HIP_TRY(h, hipMemsetAsync(X.d_split_cnt, 0, sizeof(Counters), s));
-    const uint32_t nwg = (uint32_t)std::min<uint64_t>((uint64_t)tuning().part_wgs, std::max<uint64_t>(1, n / 8192));
+    const uint32_t nwg = (uint32_t)std::min<uint64_t>((uint64_t)kPartWgs, std::max<uint64_t>(1, n / 8192));
     if ((rc = grow_buf(h, q.hist, q.hist_cap, (uint64_t)nwg * W))) return rc;
     if (W > q.bucket_cap) {
         if (q.totals) (void)hipFree(q.totals);
@@ -942,7 +942,7 @@ int gndt_build_owned_device(gndt_handle* h, gndt_comm* c, const void* shard_xyz_
     }
     if ((rc = grow_buf(h, X.pairs_all, X.pairs_all_cap, m_max * (uint64_t)W))) return rc;
     if ((rc = comm_all_gather(h, c, X.pairs, X.pairs_all, (size_t)m_max, 8, s))) return rc;
-    const bool sliced = W > 1 && tuning().owner_sliced_rows != 0;
+    const bool sliced = W > 1;
     if (err) {      // the others finish without this rank's columns — and notice, by its poison pair — once it has played its part
         if (sliced && (rc = global_rows_sliced(h, c, X.pairs_all, m_max, total_points, s, false))) return rc;
         return leave();

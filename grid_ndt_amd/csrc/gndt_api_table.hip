@@ -385,7 +385,6 @@ int gndt_update_device(gndt_handle* h, const void* xyz_dev, size_t n, size_t str
     // still cover the whole map: rows move when a column in front of them grows).
     const bool incr = h->incr_ok;
     bool tile = n >= 4096 && (h->P.strategy == GNDT_STRATEGY_TILE || (h->P.strategy == GNDT_STRATEGY_AUTO && h->tile_choice == 1));
-    if (tuning().update_tile >= 0) tile = n >= 4096 && tuning().update_tile == 1;
     rc = do_accumulate(h, xyz_dev, n, stride_bytes, h->stream_pos, 1, s, incr ? 1 : 0, tile, /*defer_advance=*/true);
     if (rc) return rc;
     h->stream_pos += n;

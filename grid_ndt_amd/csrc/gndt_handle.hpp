@@ -216,22 +216,21 @@ namespace gndt_host {
 using namespace gndt;
 
 // Diagnostic / tuning knobs from the environment, parsed ONCE per process (DESIGN.md "Diagnostic and tuning knobs").
+// (Folded into constants in round 4, each after losing its A/B: level-1 cursor replicas (1), workgroups of the counting partition
+//  (256), incremental updates through the tile kernel (by strategy), every rank ordering all columns instead of its slice (no).)
+constexpr int kPartWgs = 256;    // workgroups of the exact counting partition
 struct Tuning {
     int bucket_load = 60;        // GNDT_BUCKET_LOAD    average LDS-table load (percent) that sizes the bucket count
     int bucket_load_large = 75;  // GNDT_BUCKET_LOAD_LARGE  the same from 2 M points on (the chip is full either way: fuller tables, fewer buckets)
     int bucket_points = 0;       // GNDT_BUCKET_POINTS  points per bucket (0 = derived)
     int bucket_slots = 0;        // GNDT_BUCKET_SLOTS   LDS table of the first attempt (0 = 512, 1024 on a retry)
-    int part_wgs = 256;          // GNDT_PART_WGS       workgroups of the exact counting partition
     int two_level = -1;          // GNDT_TWO_LEVEL      0 = never use the two-level partition
-    int l1_rep = 1;              // GNDT_L1_REP         level-1 cursor replicas
     uint32_t l1_wgs = 1024;      // GNDT_L1_WGS         persistent level-1 workgroups
     uint32_t bucket_wgs = 0xFFFFFFFFu;   // GNDT_BUCKET_WGS   persistent bucket workgroups (default: one per bucket)
     double tile_ratio = 48.0;    // GNDT_TILE_RATIO     AUTO takes strategy TILE from this many points per partial on (sampled; the
                                  //                     measured crossover, profiles/r02_tile_calibration.json)
     int one_level = 1;           // GNDT_ONE_LEVEL      small clouds: level 1 writes the buckets directly (0: counting partition)
-    int owner_sliced_rows = 1;   // GNDT_OWNER_SLICED   owner-partitioned build: every rank orders a slice of the index range (1) or all columns (0)
     int owner_locality = 1;      // GNDT_OWNER_LOCALITY owner-partitioned build: sampled block ownership (1) or hash ownership only (0)
-    int update_tile = -1;        // GNDT_UPDATE_TILE    incremental updates through the tile kernel: 1 always, 0 never, -1 = by strategy
     int fp_bits = 21;            // GNDT_FP_BITS        bits of the bucket kernel's index fingerprint (tests narrow it to force clashes)
     bool stamps = false;         // GNDT_STAMPS=1       in-kernel phase stamps of the bucket kernel
     bool verbose = false;        // GNDT_VERBOSE=1      stderr line per resolved two-level build

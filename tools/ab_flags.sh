@@ -2,7 +2,7 @@
 for F in "$@"; do
   GNDT_EXTRA_CXXFLAGS="$F" python3 -c "import grid_ndt_amd as g; g.build_native(force=True)" > /dev/null 2>&1
   for W in "S2" "S3 --points 32000000"; do
-    python3 bench.py --workload $W --steps 10 --no-cpu-baseline --no-extras 2>/dev/null | python3 -c "
+    python3 bench.py --workload $W --steps 10 --no-cpu-baseline --no-extras --no-configs 2>/dev/null | python3 -c "
 import sys,json
 for l in sys.stdin:
     if l.startswith('{'):

@@ -2,7 +2,7 @@
 WL=${WL:-"S2"}
 for E in "$@"; do
   echo "$WL" | tr '|' '\n' | while read W; do
-    env $E python3 bench.py --workload $W --steps 10 --no-cpu-baseline --no-extras --stamps 2>&1 | python3 -c "
+    env $E python3 bench.py --workload $W --steps 10 --no-cpu-baseline --no-extras --no-configs --stamps 2>&1 | python3 -c "
 import sys,json
 for l in sys.stdin:
     if l.startswith('{'):

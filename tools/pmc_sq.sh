@@ -10,7 +10,7 @@ P2="SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_LDS_BANK_CONFLICT 
 i=1
 for P in "$P1" "$P2"; do
   rm -rf $out/${tag}_sq$i
-  rocprofv3 --pmc $P --output-format csv -d $out/${tag}_sq$i -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras "$@" > $out/${tag}_sq$i.log 2>&1
+  rocprofv3 --pmc $P --output-format csv -d $out/${tag}_sq$i -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras --no-configs "$@" > $out/${tag}_sq$i.log 2>&1
   i=$((i+1))
 done
 python3 - "$out/${tag}_sq1" "$out/${tag}_sq2" <<'PY' | tee $out/${tag}_sq.txt
