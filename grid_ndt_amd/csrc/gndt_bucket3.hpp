@@ -458,20 +458,22 @@ __device__ __forceinline__ void bucket_direct_one(BucketLds3<H>& L, const uint32
         if (tid == 0) atomicAdd(&pc->lds_overflow, 1u);
         return;
     }
-    // Reserve the staging rows now: the memory-side atomic's round trip hides behind the per-node phases.
+    // Reserve the staging rows now.  The memory-side atomic's round trip (~3 us) hides behind the column phases: its answer stays in
+    // the register of the thread that asked and is handed to the workgroup only at the barrier in front of the rows phase, where it is
+    // first needed.  (Rounds 1-3 said the same in this comment and then waited for the answer at the very next barrier — ~5 k cycles per
+    // bucket that the stamps booked under "columns"; on a small frame, one workgroup per CU, nothing else ran meanwhile.)
     uint32_t stage_base_reg = 0;
     if (tid == T - 1) stage_base_reg = atomicAdd(&cnt->num_nodes, M);
     if (tid == 0 && L.err_range) atomicAdd(&cnt->err_key_range, L.err_range);
 
-    if (tid == T - 1) L.stage_base = stage_base_reg;
-    __syncthreads();
-    const uint32_t sbase = L.stage_base;
-    if (sbase + M > stage_cap) {                   // uniform
-        if (tid == 0) atomicAdd(&pc->stage_overflow, M);
-        return;
-    }
-
     if constexpr (STATS) {
+        if (tid == T - 1) L.stage_base = stage_base_reg;
+        __syncthreads();
+        const uint32_t sbase = L.stage_base;
+        if (sbase + M > stage_cap) {                   // uniform
+            if (tid == 0) atomicAdd(&pc->stage_overflow, M);
+            return;
+        }
         for (uint32_t i = tid; i < M; i += T) {
             const uint32_t s = i;
             const uint32_t dst = sbase + i;
@@ -531,8 +533,14 @@ __device__ __forceinline__ void bucket_direct_one(BucketLds3<H>& L, const uint32
         cinfo = L.ccnt[col];
         L.colnodes[(cinfo >> 16) + kc] = make_uint4(my_first, (uint32_t)sz, __float_as_uint(cz), s);
     }
+    if (tid == T - 1) L.stage_base = stage_base_reg;      // (the reservation's answer: waited for here, by one thread)
     lds_barrier();
     GNDT_STAMP3(3);
+    const uint32_t sbase = L.stage_base;
+    if (sbase + M > stage_cap) {                   // uniform: the staging rows ran out, the build is re-run with more
+        if (tid == 0) atomicAdd(&pc->stage_overflow, M);
+        return;
+    }
 
     // ---- rows: slope label (OcNode::isSlope, map2D.h:66-108), index in column, column size and first-seen index by
     //      walking the column's short list; mean + fp64 scatter -> staging row ----
