@@ -342,6 +342,17 @@ int gndt_sync(gndt_handle* h, uint64_t* num_nodes, uint64_t* num_columns, uint64
     { const int prc = partition_resolve(h); if (prc) return prc; }
     HIP_TRY(h, hipStreamSynchronize(h->last_stream));
     { const int rrc = partition_recheck_after_replay(h); if (rrc) return rrc; }      // (a replayed build that ran out of room says so)
+    if (h->results_valid && h->small_used && h->part.h_pc && h->part.h_pc->small_fallback) {
+        // the one-workgroup finalisation (k_small_finalize) met a map that is not small and wrote nothing
+        if (h->small_captured) {
+            h->results_valid = false;
+            h->err = "a build replayed from a hipGraph has more nodes than the small-map finalisation it was captured with can hold: "
+                     "build this cloud eagerly (gndt_build_device + gndt_sync), then capture again";
+            return GNDT_ERR_CAPACITY;
+        }
+        const int frc = table_refinalize(h);
+        if (frc) return frc;
+    }
     if (h->results_valid) {
         h->res_nodes = h->h_cnt->num_nodes;
         h->res_columns = h->h_cnt->num_columns;

@@ -147,6 +147,23 @@ int do_finalize(gndt_handle* h, hipStream_t s, bool incremental = false, uint64_
     const GridParams gp = grid_params(h);
     const ColumnOrder O{q.bitmap, q.word_weight, q.ncol_at};
     mark(h, 2, s);
+    // Small maps — a few hundred nodes: a depth-camera frame at the launch cells — are finalised by ONE workgroup in ONE launch
+    // (k_small_finalize) instead of the six kernels below.  The host goes by what the last resolved build of this handle had; a
+    // map that turns out larger raises PartCounters::small_fallback and gndt_sync runs the regular path (table_refinalize).
+    h->small_used = false;
+    if (!incremental && advance == 0 && h->small_ok && h->table_nodes_seen && h->table_nodes_seen <= 900u) {
+        hipLaunchKernelGGL(k_small_finalize, dim3(1), dim3(kSmallMapNodes), 0, s, T, gp, h->out, q.row_ncol, h->d_cnt, q.d_pc, h->h_cnt, q.h_pc,
+                           raise_to, (uint32_t)std::min<uint64_t>(h->out_cap, 0xFFFFFFFFull));
+        HIP_TRY(h, hipGetLastError());
+        for (int i = 3; i <= 9; ++i) mark(h, i, s);
+        h->small_used = true;
+        h->small_captured = h->capturing;
+        h->results_valid = true;
+        ++h->result_serial;
+        h->last_stream = s;
+        h->incr_ok = false;                  // (no staging rows, no order arrays: an update after this takes the full path)
+        return GNDT_OK;
+    }
     if (incremental) {
         if (words > q.words_init) {                        // the stream grew past the words the order has seen: they start empty
             HIP_TRY(h, hipMemsetAsync(q.bitmap + q.words_init, 0, (words - q.words_init) * 4, s));
@@ -243,6 +260,16 @@ int reserve_table(gndt_handle* h, uint64_t nodes, hipStream_t s) {
     return (h->cap && h->table_dirty) ? grow_table(h, want, s) : alloc_table(h, want, s);
 }
 
+// gndt_sync found PartCounters::small_fallback after an eager finalisation: the same table through the regular kernels
+int table_refinalize(gndt_handle* h) {
+    h->small_ok = false;
+    hipStream_t s = h->last_stream;
+    int rc = do_finalize(h, s, false, 0, 0, (uint32_t)std::min<uint64_t>(h->stream_pos, 0xFFFFFFFEull));
+    if (rc) return rc;
+    HIP_TRY(h, hipStreamSynchronize(s));
+    return GNDT_OK;
+}
+
 // strategy ATOMIC from empty; waits for the result (the retry on a full table needs the device-side flags)
 int locality_sample(gndt_handle* h, const void* xyz_dev, size_t n, size_t stride_bytes, uint32_t tiles, double* ratio, hipStream_t s) {
     if (stride_bytes != 12 && stride_bytes != 16) { h->err = "stride_bytes must be 12 or 16"; return GNDT_ERR_INVALID; }
@@ -301,7 +328,15 @@ int build_atomic(gndt_handle* h, const void* xyz_dev, size_t n, size_t stride_by
         if (cap != hipStreamCaptureStatusNone) return GNDT_OK;
         // a build returns with its results ready: wait once and look at the device-side flags
         HIP_TRY(h, hipStreamSynchronize(s));
+        if (h->small_used && h->part.h_pc->small_fallback) {      // not a small map after all: the regular finalisation of the same table
+            h->small_ok = false;
+            rc = do_finalize(h, s, false, 0, 0, (uint32_t)reach);
+            if (rc) return rc;
+            HIP_TRY(h, hipStreamSynchronize(s));
+        }
         if (!h->h_cnt->err_table_full && !h->part.h_pc->stage_overflow) {
+            h->table_nodes_seen = h->h_cnt->num_nodes;
+            if (h->table_nodes_seen <= 900u) h->small_ok = true;       // (small again: the next build may take the short way)
             // what a later PARTITION build of a similar cloud should expect (a first build without a hint guesses n / 4)
             h->part.nodes_learned = (uint64_t)h->h_cnt->num_nodes + h->h_cnt->num_nodes / 5;
             if (rec) { h->map_in_table = false; h->incr_ok = false; }

@@ -86,6 +86,9 @@ struct gndt_handle {
     uint64_t stream_pos = 0;    // points accumulated since the last reset (host mirror of the device-side first_idx base)
     uint64_t nodes_bound = 0;   // host-side upper bound of the nodes in the table (no sync needed to size buffers)
     bool table_dirty = false;   // table holds nodes
+    // small maps (k_small_finalize, gndt_table.hpp): the node count the last resolved table-path build had; cleared when the
+    // one-workgroup finalisation met a map that was not small; whether its last launch was recorded under hipGraph capture
+    uint32_t table_nodes_seen = 0;  bool small_ok = true;  bool small_captured = false;  bool small_used = false;
 
     // strategy PARTITION buffers (gndt_partition.hpp)
     struct Part {
@@ -339,6 +342,7 @@ int do_reset(gndt_handle* h, hipStream_t s);
 int zero_device_now(gndt_handle* h, void* p, size_t bytes);
 int partition_recheck_after_replay(gndt_handle* h);
 int reserve_table(gndt_handle* h, uint64_t nodes, hipStream_t s);
+int table_refinalize(gndt_handle* h);      // the regular finalisation after the small-map one gave up (gndt_sync)
 int build_atomic(gndt_handle* h, const void* xyz_dev, size_t n, size_t stride_bytes, hipStream_t s, bool tile = false,
                  const gndt_handle::Pending* rec = nullptr);
 int locality_sample(gndt_handle* h, const void* xyz_dev, size_t n, size_t stride_bytes, uint32_t tiles, double* ratio, hipStream_t s);

@@ -47,7 +47,7 @@ struct PartCounters {
     uint32_t max_fill1;        // two-level partition: fullest level-1 region (true count, also beyond its capacity: the
     uint32_t fp_clashes;       //   host sizes the retry from it); buckets done a second time because a fingerprint named the
     uint32_t l1_ticket;        //   wrong node (gndt_bucket3.hpp; diagnostic); level-1 workgroups that are done (the last one lays
-    uint32_t pad;              //   out the buckets' regions; 0 between kernels)
+    uint32_t small_fallback;   //   out the buckets' regions; 0 between kernels); k_small_finalize met more nodes than it has threads
 };
 
 struct alignas(16) StageRow {   // 96 bytes, gathered whole by k_emit_rows (round 1 padded it to 128: a quarter of the node traffic)
@@ -183,7 +183,7 @@ static __global__ void __launch_bounds__(256) k_part_clear(Counters* __restrict_
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         cnt->num_nodes = 0; cnt->num_columns = 0; cnt->num_slopes = 0; cnt->err_key_range = 0; cnt->err_table_full = 0;
         pc->lds_overflow = 0; pc->stage_overflow = 0; pc->index_overflow = 0; pc->part_overflow = 0;
-        pc->max_fill1 = 0; pc->fp_clashes = 0; pc->l1_ticket = 0;
+        pc->max_fill1 = 0; pc->fp_clashes = 0; pc->l1_ticket = 0; pc->small_fallback = 0;
     }
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < words; i += (uint64_t)gridDim.x * blockDim.x) { bitmap[i] = 0u; word_weight[i] = 0u; }
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_cursors; i += gridDim.x * blockDim.x) cursors[i] = 0u;   // two-level partition

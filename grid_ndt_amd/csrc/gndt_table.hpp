@@ -105,7 +105,7 @@ static __global__ void __launch_bounds__(kBlock) k_tab_begin(TableView T, Counte
                                                       uint64_t words, uint32_t raise_to) {
     const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, gsz = (uint64_t)gridDim.x * blockDim.x;
     if (gid == 0 && raise_to) cnt->stream_pos = max(cnt->stream_pos, raise_to);
-    if (gid == 0) { cnt->num_columns = 0; cnt->num_slopes = 0; pc->lds_overflow = 0; pc->stage_overflow = 0; pc->index_overflow = 0; pc->part_overflow = 0; cnt->first_word = 0u; cnt->n_work = 0u; }
+    if (gid == 0) { cnt->num_columns = 0; cnt->num_slopes = 0; pc->lds_overflow = 0; pc->stage_overflow = 0; pc->index_overflow = 0; pc->part_overflow = 0; pc->small_fallback = 0; cnt->first_word = 0u; cnt->n_work = 0u; }
     for (uint64_t i = gid; i < words; i += gsz) { bitmap[i] = 0u; word_weight[i] = 0u; }
     const uint32_t np = cnt->prev_nodes;
     for (uint64_t i = gid; i < np; i += gsz) {
@@ -170,6 +170,189 @@ static __global__ void __launch_bounds__(kBlock) k_tab_rows(TableView T, GridPar
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Small maps: the whole finalisation in ONE workgroup (round 4).
+// A depth-camera frame at the launch cells — what BASELINE configs[0]'s .pcd files are — has a few hundred nodes; taking them
+// through k_tab_begin / k_tab_columns / k_tab_rows / the scan / the destination pass / k_emit_rows costs six launches of 4-20 us
+// each for work that fits one workgroup's LDS.  Here thread i IS node i (at most kSmallMapNodes of them): columns are found in an
+// LDS table and sorted by their first-seen index (a bitonic sort of at most 1024 keys), the node counts in that order are scanned
+// into first rows, a column's nodes are put next to each other, and every node walks its own column once for its index in the
+// column and its two z neighbours — then writes its result row where it belongs.  (A first version compared every node with
+// every other node of the map: 562^2 pairs on ONE compute unit took 0.1 ms, slower than the six launches it replaced.)  No staging rows, no order arrays, no bitmap: the incremental finalisation of gndt_update* cannot
+// continue from such a map and takes its full path (the host clears gndt_handle::incr_ok).
+// More nodes than the workgroup has threads: PartCounters::small_fallback is raised, nothing is written, the host runs the
+// regular kernels (an eager build does so at once; a replayed hipGraph reports GNDT_ERR_CAPACITY like any other overflow).
+// ---------------------------------------------------------------------------------------------
+constexpr int kSmallMapNodes = 1024;
+constexpr int kSmallColSlots = 2048;
+struct SmallMapLds {
+    uint4 colnodes[kSmallMapNodes];             // the nodes of every column next to each other: {first-seen index, z level, fp32 mean z, -}
+    unsigned long long ckey[kSmallColSlots];    // column table: key (kEmptyKey = free)
+    uint32_t ccf[kSmallColSlots];               //   first-seen index of the column (min over its nodes); later: nodes placed so far
+    uint32_t ccnt[kSmallColSlots];              //   nodes of the column; later: (first row << 16) | nodes
+    unsigned long long sortk[kSmallMapNodes];   // the occupied columns as (first-seen index << 16 | slot), sorted: position = rank
+    uint32_t by_rank[kSmallMapNodes];           // node count of the column of rank r -> exclusive prefix = its first row
+    uint32_t wsum[kSmallMapNodes / 64];
+    uint32_t n_cols, n_slopes;
+};
+
+static __global__ void __launch_bounds__(kSmallMapNodes) k_small_finalize(TableView T, GridParams P, OutView out, uint32_t* __restrict__ row_ncol,
+                                                                   Counters* cnt, PartCounters* __restrict__ pc, Counters* __restrict__ host_cnt,
+                                                                   PartCounters* __restrict__ host_pc, uint32_t raise_to, uint32_t out_cap) {
+    __shared__ SmallMapLds L;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t n = cnt->num_nodes;
+    if (n > (uint32_t)kSmallMapNodes || n > out_cap) {          // uniform: not a small map after all
+        if (tid == 0) {
+            pc->small_fallback = 1u;
+            if (host_cnt) *host_cnt = *cnt;
+            if (host_pc) *host_pc = *pc;
+        }
+        return;
+    }
+    for (int c = tid; c < kSmallColSlots; c += kSmallMapNodes) { L.ckey[c] = kEmptyKey; L.ccf[c] = 0xFFFFFFFFu; L.ccnt[c] = 0u; }
+    L.sortk[tid] = ~0ull;
+    if (tid == 0) { L.n_cols = 0; L.n_slopes = 0; }
+    __syncthreads();
+    // ---- the node, its column ----
+    const bool live = (uint32_t)tid < n;
+    uint64_t key = 0;
+    NodeAcc a;
+    for (int k = 0; k < 9; ++k) a.s[k] = 0.0;
+    a.count = 0; a.first = 0xFFFFFFFFu;
+    int sx = 0, sy = 0, sz = 0;
+    float cz = 0.f;
+    uint32_t col = 0, fl = 0;
+    if (live) {
+        const uint32_t slot = T.node_slot[tid];
+        key = T.keys[slot];
+        a = T.acc[slot];
+        unpack_key(key, sx, sy, sz);
+        if (a.count >= (uint32_t)P.min_points) { cz = node_mean_z(a.count, a.s[2], axis_centre(sz, P.oz, P.z_len)); fl = 1u; }
+        const unsigned long long ck = column_key(key);
+        col = (uint32_t)mix64(ck) & (uint32_t)(kSmallColSlots - 1);
+        for (int probe = 0; probe < kSmallColSlots; ++probe) {      // (terminates: twice as many slots as nodes)
+            const unsigned long long k = L.ckey[col];
+            if (k == ck) break;
+            if (k == kEmptyKey) {
+                const unsigned long long old = atomicCAS(&L.ckey[col], (unsigned long long)kEmptyKey, ck);
+                if (old == kEmptyKey || old == ck) break;
+            }
+            col = (col + 1) & (uint32_t)(kSmallColSlots - 1);
+        }
+        atomicMin(&L.ccf[col], a.first);
+        atomicAdd(&L.ccnt[col], 1u);
+    }
+    __syncthreads();
+    // ---- the occupied columns, compacted as sort keys (thread = column slot, two passes over the table) ----
+    for (int c = tid; c < kSmallColSlots; c += kSmallMapNodes) {
+        const bool occ = L.ccnt[c] != 0u;
+        const unsigned long long m = __ballot(occ);
+        uint32_t base = 0;
+        if (lane == 0 && m) base = atomicAdd(&L.n_cols, (uint32_t)__popcll(m));
+        base = (uint32_t)__shfl((int)base, 0, 64);
+        if (occ) L.sortk[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = ((unsigned long long)L.ccf[c] << 16) | (unsigned long long)c;
+    }
+    __syncthreads();
+    const uint32_t K = L.n_cols;
+    // ---- columns in first-seen order (first-seen indices of distinct columns are distinct points).  Few columns: every column
+    //      counts the columns seen before it (K^2 / K threads, all reading the same word at a time: LDS broadcasts) and moves to
+    //      that place; many: a bitonic sort of the keys, padded to the next power of two (the padding sorts to the end) ----
+    if (K <= 256u) {
+        unsigned long long mine = ~0ull;
+        uint32_t rank = 0;
+        if ((uint32_t)tid < K) {
+            mine = L.sortk[tid];
+            for (uint32_t j = 0; j < K; ++j) rank += (L.sortk[j] < mine) ? 1u : 0u;
+        }
+        __syncthreads();
+        if ((uint32_t)tid < K) L.sortk[rank] = mine;
+        __syncthreads();
+    } else {
+        uint32_t N2 = 512;
+        while (N2 < K) N2 <<= 1;
+        for (uint32_t k = 2; k <= N2; k <<= 1) {
+            for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+                const uint32_t ixj = (uint32_t)tid ^ j;
+                if (ixj > (uint32_t)tid && ixj < N2) {
+                    const unsigned long long x = L.sortk[tid], y = L.sortk[ixj];
+                    const bool up = ((uint32_t)tid & k) == 0;
+                    if ((x > y) == up) { L.sortk[tid] = y; L.sortk[ixj] = x; }
+                }
+                __syncthreads();
+            }
+        }
+    }
+    // ---- the node counts in rank order, scanned: the first row of every column ----
+    uint32_t my_cslot = 0, my_ccnt = 0;
+    if ((uint32_t)tid < K) { my_cslot = (uint32_t)(L.sortk[tid] & 0xFFFFull); my_ccnt = L.ccnt[my_cslot]; }
+    {
+        const uint32_t v = my_ccnt;
+        uint32_t incl = v;
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)incl, o, 64); if (lane >= o) incl += t; }
+        if (lane == 63) L.wsum[wave] = incl;
+        __syncthreads();
+        uint32_t base = incl - v;
+        for (int w = 0; w < wave; ++w) base += L.wsum[w];
+        if ((uint32_t)tid < K) { L.ccnt[my_cslot] = (base << 16) | my_ccnt; L.ccf[my_cslot] = 0u; }      // first row | nodes (both fit 16 bits); nodes placed: 0
+    }
+    __syncthreads();
+    // ---- a column's nodes next to each other (the order inside the array is free), then every node looks at its own column ----
+    uint32_t cinfo = 0;
+    if (live) {
+        cinfo = L.ccnt[col];
+        const uint32_t k = atomicAdd(&L.ccf[col], 1u);
+        L.colnodes[(cinfo >> 16) + k] = make_uint4(a.first, (uint32_t)sz, __float_as_uint(cz), 0u);
+    }
+    __syncthreads();
+    if (live) {
+        const int za = level_above(sz), zb = level_below(sz);
+        const uint32_t cbase = cinfo >> 16, ncol = cinfo & 0xFFFFu;
+        uint32_t icol = 0;
+        bool up = false, down = false;
+        for (uint32_t j = 0; j < ncol; ++j) {
+            const uint4 o = L.colnodes[cbase + j];       // {first-seen, z level, mean z}
+            if (o.x == a.first) continue;                // (this node itself: first-seen indices of distinct nodes are distinct points)
+            icol += (o.x < a.first) ? 1u : 0u;
+            const int tz = (int)o.y;
+            if (tz == za || tz == zb) {
+                const float oz = (o.x < a.first) ? __uint_as_float(o.z) : 0.f;        // "visited": seen earlier AND has statistics
+                const bool far = fabsf(oz - cz) > P.slope_interval;
+                if (tz == za) up = up || far; else down = down || far;
+            }
+        }
+        if (fl & 1u) {
+            bool slope = true;
+            if (P.demand == 0) slope = !up; else down = false;
+            if (slope) { fl |= 2u; if (down) fl |= 4u; atomicAdd(&L.n_slopes, 1u); }
+        }
+        const uint32_t r = cbase + icol;
+        out.sx[r] = sx; out.sy[r] = sy; out.sz[r] = sz;
+        out.count[r] = a.count; out.first_idx[r] = a.first; out.flags[r] = fl;
+        row_ncol[r] = icol == 0u ? ncol : 0u;
+        float mean[3] = {0.f, 0.f, 0.f}, rough = 0.f, normal[3] = {0.f, 0.f, 0.f};
+        double S[6] = {0, 0, 0, 0, 0, 0};
+        if (fl & 1u) {
+            const double c[3] = {axis_centre(sx, P.ox, P.grid_len), axis_centre(sy, P.oy, P.grid_len), axis_centre(sz, P.oz, P.z_len)};
+            node_moments(a.count, a.s, c, mean, S);
+            node_rough_normal(S, rough, normal);
+        }
+        out.rough[r] = rough;
+        for (int k = 0; k < 3; ++k) { out.mean[3 * r + k] = mean[k]; out.normal[3 * r + k] = normal[k]; }
+        for (int k = 0; k < 6; ++k) out.cov[6 * r + k] = (float)S[k];
+    }
+    __syncthreads();
+    if (tid == 0) {
+        cnt->num_columns = K; cnt->num_slopes = L.n_slopes;
+        if (raise_to) cnt->stream_pos = max(cnt->stream_pos, raise_to);
+        cnt->n_touched = 0; cnt->n_tcols = 0; cnt->n_work = 0; cnt->first_word = 0u;
+        cnt->epoch = cnt->epoch + 1u;                      // (prev_nodes stays 0: no node owns an entry of the HBM column table)
+        pc->lds_overflow = 0; pc->stage_overflow = 0; pc->index_overflow = 0; pc->part_overflow = 0; pc->small_fallback = 0;
+        if (host_cnt) *host_cnt = *cnt;
+        if (host_pc) *host_pc = *pc;
+    }
+}
 
 // Room for `mine` entries of this lane in a list whose length is *counter: ONE counter atomic per block (a counter is one
 // word; same-address atomics retire at ~90 per microsecond at the memory side, so one per wave is felt in kernels this

@@ -145,6 +145,77 @@ def test_depth_camera_frame_every_strategy(cells):
             assert ran == 5, ran
 
 
+@pytest.mark.parametrize("strategy", [0, 1, 5], ids=["auto", "atomic", "tile"])
+def test_small_maps_are_finalised_by_one_workgroup_and_larger_ones_fall_back(strategy):
+    """A map of a few hundred nodes (a depth-camera frame at the launch cells) is finalised by ONE workgroup in one launch
+    (k_small_finalize) from the handle's second build on; a cloud with more nodes than that kernel has threads raises its fallback
+    flag and is finalised by the regular kernels — eagerly at gndt_sync, as GNDT_ERR_CAPACITY for a replayed hipGraph."""
+    import torch
+    import grid_ndt_amd as g
+    from grid_ndt_amd._lib import GndtError
+    frame, P = scenes.depth_frame(), scenes.DEPTH_PARAMS
+    n = frame.shape[0] - 1
+    big = scenes.campus_frame(n + 1)                           # same point count, ~70 k nodes
+    big[0] = frame[0]
+    ref_small, ref_big = parity.ref_from_cloud(frame, P), parity.ref_from_cloud(big, P)
+    assert ref_small["num_nodes"] < 900 < ref_big["num_nodes"]
+    m = g.TwoDmap(P["grid_len"], P["z_len"], strategy=strategy)
+    m.setInterval(P["slope_interval"])
+    m.setCloudFirst(frame[0])
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        buf = torch.from_numpy(np.ascontiguousarray(frame[1:])).cuda()
+        for k in range(3):                                     # build 0: the regular kernels; 1, 2: one workgroup
+            m.create2DMap(P["demand"], buf, s)
+            parity.assert_parity(m.export(), ref_small)
+        ran = m.last_strategy()
+        if ran in (1, 5):                                      # (AUTO may have taken TILE or ATOMIC; PARTITION has no small path)
+            buf.copy_(torch.from_numpy(np.ascontiguousarray(big[1:])))
+            m.create2DMap(P["demand"], buf, s)                 # not small: the fallback inside the build
+            parity.assert_parity(m.export(), ref_big)
+            buf.copy_(torch.from_numpy(np.ascontiguousarray(frame[1:])))
+            for k in range(2):
+                m.create2DMap(P["demand"], buf, s)
+                parity.assert_parity(m.export(), ref_small)
+            # captured with the small finalisation, replayed on the small frame and on the big cloud
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=s):
+                m.create2DMap(P["demand"], buf, s)
+            graph.replay()
+            s.synchronize()
+            parity.assert_parity(m.export(), ref_small)
+            buf.copy_(torch.from_numpy(np.ascontiguousarray(big[1:])))
+            graph.replay()
+            s.synchronize()
+            with pytest.raises(GndtError) as ei:
+                m.export()
+            assert ei.value.code == 5
+    print("strategy", strategy, "ran", m.STRATEGY_NAMES[ran])
+
+
+@pytest.mark.parametrize("n_pts,spread", [(700, 40.0), (1200, 3.0), (1000, 0.9)], ids=["700_columns", "few_hundred_columns", "one_tall_stack"])
+def test_small_map_finalisation_orders_many_and_few_columns(n_pts, spread):
+    """k_small_finalize sorts the columns by first-seen index — by counting for up to 256 columns, by a bitonic sort above — and walks
+    every column once: sparse clouds (one node per column, ~700 columns), clouds of a few hundred columns with several levels each,
+    and a single stack of levels, all from the second build of a handle on (the first goes through the regular kernels)."""
+    import torch
+    import grid_ndt_amd as g
+    rng = np.random.default_rng(n_pts)
+    body = (rng.random((n_pts, 3)) - 0.5).astype(np.float32) * np.float32([spread, spread, 3.0])
+    cloud = np.concatenate([np.float32([[0.01, 0.02, 0.03]]), body], 0)
+    P = dict(grid_len=0.5, z_len=0.1, slope_interval=0.08, demand="slope")
+    ref = parity.ref_from_cloud(cloud, P)
+    assert ref["num_nodes"] <= 900
+    m = g.TwoDmap(P["grid_len"], P["z_len"], strategy=1)
+    m.setInterval(P["slope_interval"])
+    m.setCloudFirst(cloud[0])
+    dev = torch.from_numpy(np.ascontiguousarray(cloud[1:])).cuda()
+    for k in range(3):
+        m.create2DMap(P["demand"], dev)
+        parity.assert_parity(m.export(), ref)
+    print("nodes", int(ref["num_nodes"]), "columns", int(ref["num_columns"]))
+
+
 def test_partition_with_node_hint_handles_dense_node_sets():
     """With max_nodes_hint the bucket count follows the node count, so node-heavy clouds stay on the LDS path."""
     for name in ("uniform_300k_cubic", "uniform_300k_z01", "site_zero_padded"):
