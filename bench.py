@@ -224,13 +224,15 @@ def _timed_builds(g, torch, cloud, P, steps, hint=0, strategy=0, demand="slope")
             "first_build_ms": round(first_ms, 3), "first_build_re_runs": int(first_retries)}
 
 
-def _stream_latency(g, torch, frames, ppf, nframes, graph_mode):
+def _stream_latency(g, torch, frames, ppf, nframes, graph_mode, deferred=False):
     """S4: one gndt_update per 131 072-point frame; per-frame latency (launch -> device idle) and the back-to-back rate."""
     dev_frames = [torch.from_numpy(frames[f * ppf:(f + 1) * ppf]).cuda() for f in range(nframes)]
     m = g.TwoDmap(0.2, 0.2, strategy=1, max_nodes_hint=4_000_000, max_points_hint=nframes * ppf)
     m.setInterval(0.08)
     m.setCloudFirst(frames[0])
     buf = torch.empty(ppf, 3, dtype=torch.float32, device="cuda")
+    if deferred:
+        m.set_deferred_emit(True)
     buf.copy_(dev_frames[0])
     m.change2DMap("slope", buf)
     m.sync()
@@ -256,10 +258,17 @@ def _stream_latency(g, torch, frames, ppf, nframes, graph_mode):
         graph.replay() if graph else m.change2DMap("slope", buf)
     torch.cuda.synchronize()                      # (a replayed graph runs on torch's stream, not on the one it was captured on, which is all m.sync() waits for)
     b2b = (time.perf_counter() - t0) / (nframes - half) * 1e3
+    t0 = time.perf_counter()
     nodes, _, _ = m.sync()
+    read_ms = (time.perf_counter() - t0) * 1e3
     lat = np.sort(np.array(lat[2:]))
-    return {"p50_ms": round(float(np.percentile(lat, 50)), 4), "p99_ms": round(float(np.percentile(lat, 99)), 4),
-            "back_to_back_ms_per_frame": round(b2b, 4), "nodes_at_the_end": int(nodes)}
+    out = {"p50_ms": round(float(np.percentile(lat, 50)), 4), "p99_ms": round(float(np.percentile(lat, 99)), 4),
+           "back_to_back_ms_per_frame": round(b2b, 4), "nodes_at_the_end": int(nodes)}
+    if deferred:
+        out["read_ms"] = round(read_ms, 4)
+        out["what"] = ("gndt_set_deferred_emit: a frame relabels the touched columns and stops; read_ms = the gndt_sync that orders and emits "
+                       "the dense rows for all the frames since the last read")
+    return out
 
 
 def measure_configs(g, torch, s2_cloud_host):
@@ -284,7 +293,9 @@ def measure_configs(g, torch, s2_cloud_host):
     nframes, ppf = 48, scenes.FRAME_POINTS
     frames = scenes.terrain_frames(nframes, 0)
     out["S4_stream_131k_frames"] = {"frames": nframes, "budget_ms": 100.0, "eager": _stream_latency(g, torch, frames, ppf, nframes, False),
-                                    "hip_graph_replay": _stream_latency(g, torch, frames, ppf, nframes, True)}
+                                    "hip_graph_replay": _stream_latency(g, torch, frames, ppf, nframes, True),
+                                    "deferred_emit": _stream_latency(g, torch, frames, ppf, nframes, False, deferred=True),
+                                    "deferred_emit_replayed": _stream_latency(g, torch, frames, ppf, nframes, True, deferred=True)}
     return out
 
 

@@ -180,6 +180,8 @@ def lib():
     L.gndt_export.argtypes = [H, C.POINTER(Cells)]
     L.gndt_export_host.argtypes = [H, C.POINTER(Cells)]
     L.gndt_reserve.argtypes = [H, u64, u64]
+    L.gndt_set_deferred_emit.argtypes = [H, C.c_int]
+    L.gndt_set_deferred_emit.restype = C.c_int
     L.gndt_reserve.restype = C.c_int
     L.gndt_export_host.restype = C.c_int
     L.gndt_stats_export_device.argtypes = [H, C.POINTER(Stats), vp]

@@ -342,6 +342,10 @@ int gndt_sync(gndt_handle* h, uint64_t* num_nodes, uint64_t* num_columns, uint64
     { const int prc = partition_resolve(h); if (prc) return prc; }
     HIP_TRY(h, hipStreamSynchronize(h->last_stream));
     { const int rrc = partition_recheck_after_replay(h); if (rrc) return rrc; }      // (a replayed build that ran out of room says so)
+    if (h->results_valid && (h->emit_pending || h->deferred_captured) && h->map_in_table) {      // deferred-emit mode: the rows are produced now, for all the frames since the last read
+        const int erc = table_emit_pending(h);
+        if (erc) return erc;
+    }
     if (h->results_valid && h->small_used && h->part.h_pc && h->part.h_pc->small_fallback) {
         // the one-workgroup finalisation (k_small_finalize) met a map that is not small and wrote nothing
         if (h->small_captured) {

@@ -191,9 +191,27 @@ int do_finalize(gndt_handle* h, hipStream_t s, bool incremental = false, uint64_
         q.words_init = words;
     }
     mark(h, 4, s);
+    if (h->defer_emit && incremental) {
+        // Deferred-emit mode: the frame ends here — touched columns relabelled, their staging rows and the column order up to date,
+        // the bookkeeping done by a one-thread launch.  The ordering + emit pass (O(map): rows move when a column in front of them
+        // grows) runs when somebody reads the map (gndt_sync -> table_emit_pending).  A frame costs O(touched).
+        hipLaunchKernelGGL(k_tab_end, dim3(1), dim3(64), 0, s, h->d_cnt, (const PartCounters*)q.d_pc, h->h_cnt, q.h_pc, advance);
+        HIP_TRY(h, hipGetLastError());
+        for (int i = 5; i <= 9; ++i) mark(h, i, s);
+        h->emit_pending = true;
+        h->deferred_captured = h->capturing;
+        h->pending_words = std::max(h->pending_words, words);
+        h->results_valid = true;
+        ++h->result_serial;
+        h->last_stream = s;
+        h->incr_ok = true;
+        return GNDT_OK;
+    }
     // (k_emit_rows, the last kernel, also stores the counters and flags into the host's pinned mirrors and does the end-of-frame
     //  bookkeeping: no copy commands and no one-thread launches behind a frame)
-    if ((rc = launch_order_and_emit(h, words, 4, s, false, true, true, advance, incremental))) return rc;
+    // (rows left un-emitted by deferred frames: everything is placed and emitted again, not only what this frame moved)
+    if ((rc = launch_order_and_emit(h, words, 4, s, false, true, true, advance, incremental && !h->emit_pending && !h->deferred_captured))) return rc;
+    h->emit_pending = false; h->pending_words = 0; h->deferred_captured = false;
     h->results_valid = true;
     ++h->result_serial;
     h->last_stream = s;
@@ -258,6 +276,20 @@ int reserve_table(gndt_handle* h, uint64_t nodes, hipStream_t s) {
     const uint32_t want = cap_for_nodes(nodes);
     if (h->cap >= want) return GNDT_OK;
     return (h->cap && h->table_dirty) ? grow_table(h, want, s) : alloc_table(h, want, s);
+}
+
+// gndt_sync on a handle in deferred-emit mode: the ordering + emit pass over the whole map, once, for all the frames since the last read
+int table_emit_pending(gndt_handle* h) {
+    if (!h->emit_pending && !h->deferred_captured) return GNDT_OK;
+    hipStream_t s = h->last_stream;
+    const uint64_t words = std::max<uint64_t>(h->pending_words, 1);
+    int rc = launch_order_and_emit(h, words, 4, s, false, true, true, 0u, false);     // (advance 0: the frames did their own bookkeeping)
+    if (rc) return rc;
+    HIP_TRY(h, hipStreamSynchronize(s));
+    h->emit_pending = false;
+    if (!h->deferred_captured) h->pending_words = 0;      // (a captured frame may be replayed again: the next read emits again)
+    ++h->result_serial;                                   // (a cost map of the stale rows is stale, too)
+    return GNDT_OK;
 }
 
 // gndt_sync found PartCounters::small_fallback after an eager finalisation: the same table through the regular kernels
@@ -424,6 +456,12 @@ int gndt_update_device(gndt_handle* h, const void* xyz_dev, size_t n, size_t str
     if (rc) return rc;
     h->stream_pos += n;
     return do_finalize(h, s, incr, n, (uint32_t)n);
+}
+
+int gndt_set_deferred_emit(gndt_handle* h, int on) {
+    if (!h) return GNDT_ERR_INVALID;
+    h->defer_emit = on != 0;
+    return GNDT_OK;
 }
 
 int gndt_update(gndt_handle* h, const void* xyz_host, size_t n, size_t stride_bytes) {

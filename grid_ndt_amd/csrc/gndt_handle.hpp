@@ -89,6 +89,10 @@ struct gndt_handle {
     // small maps (k_small_finalize, gndt_table.hpp): the node count the last resolved table-path build had; cleared when the
     // one-workgroup finalisation met a map that was not small; whether its last launch was recorded under hipGraph capture
     uint32_t table_nodes_seen = 0;  bool small_ok = true;  bool small_captured = false;  bool small_used = false;
+    // deferred-emit mode (gndt_set_deferred_emit): gndt_update* relabels the touched columns and stops; the rows in the reference's
+    // dense order are produced by the next call that READS the map.  emit_pending: frames have been added since the rows were emitted
+    bool defer_emit = false;  bool emit_pending = false;  uint64_t pending_words = 0;
+    bool deferred_captured = false;    // the last deferred frame was recorded under hipGraph capture: replays add frames the host does not see
 
     // strategy PARTITION buffers (gndt_partition.hpp)
     struct Part {
@@ -343,6 +347,7 @@ int zero_device_now(gndt_handle* h, void* p, size_t bytes);
 int partition_recheck_after_replay(gndt_handle* h);
 int reserve_table(gndt_handle* h, uint64_t nodes, hipStream_t s);
 int table_refinalize(gndt_handle* h);      // the regular finalisation after the small-map one gave up (gndt_sync)
+int table_emit_pending(gndt_handle* h);    // deferred-emit mode: the ordering + emit pass the frames since the last read left out (gndt_sync)
 int build_atomic(gndt_handle* h, const void* xyz_dev, size_t n, size_t stride_bytes, hipStream_t s, bool tile = false,
                  const gndt_handle::Pending* rec = nullptr);
 int locality_sample(gndt_handle* h, const void* xyz_dev, size_t n, size_t stride_bytes, uint32_t tiles, double* ratio, hipStream_t s);

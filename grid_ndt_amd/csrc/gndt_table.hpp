@@ -354,6 +354,19 @@ static __global__ void __launch_bounds__(kSmallMapNodes) k_small_finalize(TableV
     }
 }
 
+// The end-of-frame bookkeeping k_emit_rows does for the table path, as a launch of its own: what a frame of a handle in
+// deferred-emit mode (gndt_set_deferred_emit) ends with instead of the ordering and the emit pass.
+static __global__ void k_tab_end(Counters* cnt, const PartCounters* __restrict__ pc, Counters* __restrict__ host_cnt, PartCounters* __restrict__ host_pc,
+                          uint32_t advance) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    cnt->prev_nodes = cnt->num_nodes;
+    cnt->n_touched = 0; cnt->n_tcols = 0;
+    cnt->epoch = cnt->epoch + 1u;
+    cnt->stream_pos += advance;
+    if (host_cnt) *host_cnt = *cnt;
+    if (host_pc) *host_pc = *pc;
+}
+
 // Room for `mine` entries of this lane in a list whose length is *counter: ONE counter atomic per block (a counter is one
 // word; same-address atomics retire at ~90 per microsecond at the memory side, so one per wave is felt in kernels this
 // short).  Every thread of the block calls it, the same number of times.  s: kBlock / 64 + 1 words of LDS.

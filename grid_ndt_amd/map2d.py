@@ -467,6 +467,11 @@ class TwoDmap:
         self._ensure(demand, need_origin=False)
         self._check(self._L.gndt_reserve(self._h, int(max_points), int(max_nodes)))
 
+    def set_deferred_emit(self, on=True, demand="slope"):
+        """gndt_set_deferred_emit: updates relabel the touched columns only; the dense rows are produced when the map is read."""
+        self._ensure(demand)
+        self._check(self._L.gndt_set_deferred_emit(self._h, int(bool(on))))
+
     def set_fp_bits(self, bits):
         """Narrow the bucket kernel's index fingerprint (process-wide; tests: forces its exact second pass)."""
         self._L.gndt_debug_set_fp_bits(int(bits))

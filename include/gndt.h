@@ -158,6 +158,12 @@ int gndt_reserve(gndt_handle* h, uint64_t max_points, uint64_t max_nodes);
  * a 10 Hz, 131 072-point stream); the next update then fails with GNDT_ERR_INVALID instead of wrapping. */
 int gndt_update(gndt_handle* h, const void* xyz_host, size_t n, size_t stride_bytes);
 int gndt_update_device(gndt_handle* h, const void* xyz_dev, size_t n, size_t stride_bytes, void* hip_stream);
+/* Stream-friendly mode (off by default).  The dense rows in the reference's order move whenever a column in front of them grows, so
+ * producing them costs O(map) per frame however little the frame touched.  With deferred emit on, gndt_update* relabels the touched
+ * columns and stops — O(touched) — and the rows are ordered and emitted by the next call that READS the map (gndt_sync,
+ * gndt_export*, gndt_compute_cost): a node that integrates frames at 10 Hz and plans once a second pays for the dense form once a
+ * second.  Results are those of the default mode (tests: a 100-frame stream equals one build of its points in both). */
+int gndt_set_deferred_emit(gndt_handle* h, int on);
 
 /* Incremental delete: the intent of del2DMap (include/map2D.h:826-915; its caller delCallback is commented out at
  * src/receiver.cpp:214-248, and the shipped merge formula is inconsistent: SURVEY row a10), DEFINED here as the inverse of

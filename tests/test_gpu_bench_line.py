@@ -57,6 +57,8 @@ def test_single_gpu_line_carries_every_config_and_the_host_path():
     for k in ("S1_campus_200k", "S1_bridge_ground_360k", "S1_depth_frame_215k", "S2z_10M_z01", "S3_terrain_8M", "S5_site_5M"):
         assert c[k]["ms_per_build"] > 0 and c[k]["retries"] == 0 and 0 < c[k]["path_frac"] < 1 and c[k]["first_build_ms"] > 0, (k, c[k])
     assert c["S2_first_build"]["first_build_ms"] > 0
+    assert c["S4_stream_131k_frames"]["deferred_emit"]["back_to_back_ms_per_frame"] < c["S4_stream_131k_frames"]["eager"]["back_to_back_ms_per_frame"]
+    assert c["S4_stream_131k_frames"]["deferred_emit"]["nodes_at_the_end"] == c["S4_stream_131k_frames"]["eager"]["nodes_at_the_end"]
     for k in ("eager", "hip_graph_replay"):
         s4 = c["S4_stream_131k_frames"][k]
         assert 0 < s4["p50_ms"] <= s4["p99_ms"] < 100.0 and s4["back_to_back_ms_per_frame"] > 0

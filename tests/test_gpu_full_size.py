@@ -152,7 +152,8 @@ def test_full_size_site_20M_with_its_three_million_point_origin_node():
     _sample_check(cloud, out, keys, has, 0.1, 0.1, seed=1)
 
 
-def test_full_length_stream_equals_one_build():
+@pytest.mark.parametrize("deferred", [False, True], ids=["dense_rows_every_frame", "deferred_emit"])
+def test_full_length_stream_equals_one_build(deferred):
     """BASELINE configs[3] at full length: 100 frames x 131 072 points added one by one (gndt_update_device: wave-level merge of
     the accumulate kernel, touched-column relabelling, partial destination / emit) against ONE build of the same 13.1 M points by
     the partition pipeline: the same nodes in the same order with the same counts, first-seen indices and labels, and the same
@@ -166,10 +167,15 @@ def test_full_length_stream_equals_one_build():
     m = g.TwoDmap(P["grid_len"], P["z_len"], strategy=1, max_nodes_hint=4_000_000, max_points_hint=nframes * ppf)
     m.setInterval(P["slope_interval"])
     m.setCloudFirst(frames[0])
+    if deferred:                                   # gndt_set_deferred_emit: frames stop after relabelling; the rows are produced at the reads below
+        m.set_deferred_emit(True, P["demand"])
     for f in range(nframes):                       # (frame 0 includes point 0: the origin is also a point of the stream, as in bench.py)
         m.change2DMap(P["demand"], dev[f * ppf:(f + 1) * ppf])
         if f in (0, 1, 17, 63):
-            m.sync()                               # a few frames awaited, the rest enqueued back to back
+            m.sync()                               # a few frames awaited (and, deferred, their rows emitted), the rest enqueued back to back
+        if deferred and f == 40:
+            mid = m.export()                       # a read in the middle of the stream: the map of the first 41 frames
+            assert int(mid["count"].astype(np.int64).sum()) == 41 * ppf
     s = m.export()
     b = g.TwoDmap(P["grid_len"], P["z_len"], strategy=2)
     b.setInterval(P["slope_interval"])

@@ -309,6 +309,45 @@ def test_update_replayed_from_a_hip_graph_equals_batch_build():
         m.sync()
 
 
+def test_deferred_emit_stream_eager_and_replayed_equals_batch_build():
+    """gndt_set_deferred_emit: frames stop after relabelling the touched columns; a read in the middle and at the end of the stream gives
+    the oracle's map of the points so far — frames launched eagerly, then the same stream with ONE captured update replayed per
+    frame (the host cannot see replays: every read of such a handle emits)."""
+    import torch
+    import grid_ndt_amd as g
+    nf, ppf = 7, 30000
+    frames = scenes.terrain_frames(nf, first_pose=3, points_per_frame=ppf)
+    cloud = np.concatenate([frames[:1], frames], 0)
+    ref_all = parity.ref_from_cloud(cloud, TERRAIN)
+    ref_mid = parity.ref_from_cloud(cloud[:1 + 4 * ppf], TERRAIN)
+    host = [torch.from_numpy(frames[f * ppf:(f + 1) * ppf]).cuda() for f in range(nf)]
+    for graph_mode in (False, True):
+        m = g.TwoDmap(TERRAIN["grid_len"], TERRAIN["z_len"], strategy=1, max_nodes_hint=200000, max_points_hint=nf * ppf)
+        m.setInterval(TERRAIN["slope_interval"])
+        m.setCloudFirst(cloud[0])
+        m.set_deferred_emit(True)
+        buf = torch.empty(ppf, 3, dtype=torch.float32, device="cuda")
+        buf.copy_(host[0])
+        m.change2DMap("slope", buf)          # the first frame is a full finalisation in either mode
+        m.sync()
+        graph = None
+        if graph_mode:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                m.change2DMap("slope", buf)
+        for f in range(1, nf):
+            buf.copy_(host[f])
+            graph.replay() if graph else m.change2DMap("slope", buf)
+            if f == 3:
+                torch.cuda.synchronize()
+                parity.assert_parity(m.export(), ref_mid)      # frames 0 .. 3
+        torch.cuda.synchronize()
+        parity.assert_parity(m.export(), ref_all)
+        parity.assert_parity(m.export(), ref_all)              # a second read changes nothing
+        m.set_deferred_emit(False)                             # back to dense rows every frame: one more (empty-handed) check of the switch
+        del m
+
+
 def test_split_accumulate_finalize_and_stats_roundtrip():
     """accumulate(shard A) + accumulate(shard B) == build(A||B); stats export -> merge into a second
     handle reproduces the same map (the multi-GPU exchange primitive)."""
