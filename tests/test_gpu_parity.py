@@ -241,6 +241,27 @@ def test_parity_host_input_and_pointxyz_stride():
             assert np.array_equal(o[k], out12[k])
 
 
+def test_large_pageable_host_input_goes_through_the_bounce_buffers():
+    """gndt_build from a pageable host buffer of more than 16 MB is staged through two pinned 8 MB bounce buffers (the CPU fills one
+    while the DMA engine empties the other); from pinned memory it is one async copy.  Both give the device build's map, row for row."""
+    import torch
+    cloud = scenes.terrain_cloud(1_500_000)                   # 18 MB of packed xyz: three bounce chunks, the last one short
+    P = TERRAIN
+    m_dev, dev = parity.gpu_from_cloud(cloud, P, on_device=True)
+    _, pageable = parity.gpu_from_cloud(cloud, P, on_device=False)
+    import grid_ndt_amd as g
+    m = g.TwoDmap(P["grid_len"], P["z_len"])
+    m.setInterval(P["slope_interval"])
+    m.setCloudFirst(cloud[0])
+    m.create2DMap(P["demand"], torch.from_numpy(np.ascontiguousarray(cloud[1:])).pin_memory())
+    pinned = m.export()
+    for o in (pageable, pinned):
+        assert o["num_nodes"] == dev["num_nodes"] and o["num_columns"] == dev["num_columns"] and o["num_slopes"] == dev["num_slopes"]
+        for k in ("sx", "sy", "sz", "count", "first_idx", "flags"):
+            assert np.array_equal(o[k], dev[k]), k
+    parity.assert_parity(pageable, parity.ref_from_cloud(cloud, P, mode=2))
+
+
 def test_rebuild_is_idempotent_and_clears_previous_map():
     import torch
     import grid_ndt_amd as g
