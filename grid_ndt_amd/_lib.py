@@ -42,7 +42,7 @@ class Robot(C.Structure):
 
 
 class CostStats(C.Structure):
-    _fields_ = [("goal_status", C.c_int32), ("ring", C.c_uint32), ("levels", C.c_uint32), ("reserved", C.c_uint32),
+    _fields_ = [("goal_status", C.c_int32), ("ring", C.c_uint32), ("levels", C.c_uint32), ("ring_store", C.c_uint32),
                 ("traversable", C.c_uint64), ("closed", C.c_uint64), ("check_pushes", C.c_uint64)]
 
 

@@ -16,11 +16,17 @@ void free_cost(gndt_handle* h) {
 }
 
 
+static int env_int(const char* name, int otherwise) {
+    const char* v = std::getenv(name);
+    return v ? std::atoi(v) : otherwise;
+}
+
 }  // namespace gndt_host
 
 extern "C" {
 
 constexpr int kCostBlocks = 128, kCostThreads = 64, kCostBatch = 32;
+constexpr int kCostWaves = 512;      // wavefronts of a layer launch whose slopes are checked by a whole wavefront each (rings in global scratch)
 
 int gndt_compute_cost(gndt_handle* h, const float goal_xyz[3], const gndt_robot* robot, void* hip_stream) {
     int rc = check_ready(h);
@@ -38,10 +44,10 @@ int gndt_compute_cost(gndt_handle* h, const float goal_xyz[3], const gndt_robot*
         HIP_TRY(h, hipMalloc(&c.d_cc, sizeof(CostCounters)));
         HIP_TRY(h, hipHostMalloc(&c.h_cc, sizeof(CostCounters)));
     }
-    if (!c.ring) {
-        HIP_TRY(h, hipMalloc(&c.ring, (size_t)kCostBlocks * (kCostThreads / 4) * kRingCap * sizeof(uint32_t)));    // (one checker per quad of lanes)
-        c.ring_cap = kRingCap;
-    }
+    // rings of up to lds_cap slopes stay in LDS; larger ones go to global scratch, ring_cap slopes per checker at first
+    // (GNDT_COST_RING_LDS / GNDT_COST_RING_FIRST: smaller numbers for the tests of exactly these steps)
+    const int lds_cap = std::max(1, std::min(kTeamRingCap, env_int("GNDT_COST_RING_LDS", kTeamRingCap)));
+    if (c.ring_cap == 0) c.ring_cap = (int)pow2_ceil((uint64_t)std::max(16, std::min(kRingCapMax, env_int("GNDT_COST_RING_FIRST", 8 * kTeamRingCap))));
     if (n > c.node_cap) {
         for (uint32_t** a : {&c.h_bits, &c.pushed, &c.state, &c.f[0], &c.f[1], &c.nbr}) { if (*a) (void)hipFree(*a); *a = nullptr; }
         c.node_cap = 0;
@@ -88,11 +94,33 @@ int gndt_compute_cost(gndt_handle* h, const float goal_xyz[3], const gndt_robot*
     HIP_TRY(h, hipGetLastError());
     // One launch per layer.  The layer count is only known on the device, so layers are enqueued in batches and
     // the frontier size of the next layer is read back after each batch (empty layers are no-ops).
+    // Who checks a slope for collisions (gndt_cost.hpp): without a ring one lane; with a ring a team of 16 and the ring in LDS, or —
+    // once a ring of that depth has not fitted on this handle — a whole wavefront per slope with ring and set in global scratch,
+    // which is only allocated then.  GNDT_COST_RING_IN_LDS=0 sends every ring the second way (tests).
+    const bool lds_off = env_int("GNDT_COST_RING_IN_LDS", 1) == 0;
+    const int mode = c.ring_n == 0 ? 0 : (c.ring_n < c.team_ring_limit && !lds_off) ? 1 : 2;
+    c.ring_store = mode;
+    if (mode == 2 && c.ring_alloc < c.ring_cap) {
+        if (c.ring) (void)hipFree(c.ring);
+        c.ring = nullptr; c.ring_alloc = 0;
+        const size_t words = (size_t)kCostWaves * 3u * (size_t)c.ring_cap;                       // (ring + a set twice as large, per wavefront)
+        HIP_TRY(h, hipMalloc(&c.ring, words * sizeof(uint32_t)));
+        HIP_TRY(h, hipMemsetAsync(c.ring, 0xFF, words * sizeof(uint32_t), s));                   // (sets are empty at rest)
+        c.ring_alloc = c.ring_cap;
+    }
     uint32_t level = 0;
     for (;;) {
-        for (int b = 0; b < kCostBatch; ++b, ++level)
-            hipLaunchKernelGGL(k_cost_level, dim3(kCostBlocks), dim3(kCostThreads), 0, s, V, R, c.ring_n, level, c.h_bits,
-                               c.pushed, c.state, c.f[level & 1u], c.f[(level + 1u) & 1u], c.ring, c.ring_cap, c.d_cc);
+        for (int b = 0; b < kCostBatch; ++b, ++level) {
+            if (mode == 1)
+                hipLaunchKernelGGL(k_cost_level<16>, dim3(kCostBlocks * 4), dim3(kCostThreads), 0, s, V, R, c.ring_n, level, c.h_bits,
+                                   c.pushed, c.state, c.f[level & 1u], c.f[(level + 1u) & 1u], (uint32_t*)nullptr, (uint32_t)lds_cap, c.d_cc);
+            else if (mode == 2)
+                hipLaunchKernelGGL(k_cost_level<64>, dim3(kCostWaves), dim3(kCostThreads), 0, s, V, R, c.ring_n, level, c.h_bits,
+                                   c.pushed, c.state, c.f[level & 1u], c.f[(level + 1u) & 1u], c.ring, (uint32_t)c.ring_cap, c.d_cc);
+            else
+                hipLaunchKernelGGL(k_cost_level<4>, dim3(kCostBlocks), dim3(kCostThreads), 0, s, V, R, 0, level, c.h_bits,
+                                   c.pushed, c.state, c.f[level & 1u], c.f[(level + 1u) & 1u], (uint32_t*)nullptr, 1u, c.d_cc);
+        }
         HIP_TRY(h, hipGetLastError());
         HIP_TRY(h, hipMemcpyAsync(c.h_cc, c.d_cc, sizeof(CostCounters), hipMemcpyDeviceToHost, s));
         HIP_TRY(h, hipStreamSynchronize(s));
@@ -104,17 +132,14 @@ int gndt_compute_cost(gndt_handle* h, const float goal_xyz[3], const gndt_robot*
         return GNDT_ERR_KEY_RANGE;
     }
     if (c.h_cc->ring_overflow) {
-        // CollisionCheck's ring is a std::list in the reference (map2D.h:351-411): any size.  Here it is scratch of a fixed size per
-        // checker, grown fourfold and the flood run again when a ring did not fit (the check is quadratic in the ring: large robots on
-        // fine grids are slow in the reference, too).
+        // CollisionCheck's ring is a std::list in the reference (map2D.h:351-411): any size.  Here it is storage of a fixed size per
+        // checker, made four times larger and the flood run again when a ring did not fit.
+        if (mode == 1) { c.team_ring_limit = c.ring_n; continue; }     // (this handle's maps hold rings of this depth that do not fit LDS)
         if (c.ring_cap >= kRingCapMax) {
             h->err = "cost map: a collision ring holds more than " + std::to_string(kRingCapMax) + " slopes (robot radius too large for this grid)";
             return GNDT_ERR_CAPACITY;
         }
-        (void)hipFree(c.ring);
-        c.ring = nullptr;
         c.ring_cap = std::min(c.ring_cap * 4, kRingCapMax);
-        HIP_TRY(h, hipMalloc(&c.ring, (size_t)kCostBlocks * (kCostThreads / 4) * (size_t)c.ring_cap * sizeof(uint32_t)));
         continue;
     }
     break;
@@ -131,7 +156,7 @@ static int cost_ready(gndt_handle* h, gndt_cost_stats* st) {
     }
     if (st) {
         const CostCounters* cc = h->cost.h_cc;
-        st->goal_status = cc->goal_status; st->ring = (uint32_t)h->cost.ring_n; st->levels = cc->levels; st->reserved = 0;
+        st->goal_status = cc->goal_status; st->ring = (uint32_t)h->cost.ring_n; st->levels = cc->levels; st->ring_store = (uint32_t)h->cost.ring_store;
         st->traversable = cc->traversable; st->closed = cc->closed; st->check_pushes = cc->check_pushes;
     }
     return GNDT_OK;

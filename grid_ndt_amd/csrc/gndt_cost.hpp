@@ -41,8 +41,9 @@ struct Robot {   // include/robot.h:12, 38-46
 
 constexpr int kCostMaxXY = 32767;        // mortonToXY decodes only up to here (Stopwatch.h:171-189)
 constexpr uint32_t kNoColumn = 0xFFFFFFFFu;
-constexpr int kRingCap = 256;            // slopes a collision ring may hold at first (per checker scratch); the host doubles it when a
-constexpr int kRingCapMax = 1 << 15;     //   ring does not fit (a 1.3 m robot on 0.1 m cells: 27 x 27 columns) up to this
+constexpr int kRingCap = 256;            // slopes a serial checker's ring holds in the host shim (tests/host_math_shim.cpp)
+constexpr int kRingCapMax = 1 << 17;     // the device grows a checker's scratch fourfold when a ring does not fit (a 1.3 m robot on
+                                         //   0.1 m cells: 27 x 27 columns, every level of them with demand "true") up to this
 
 struct CostView {
     // result rows in reference order (gndt_cells)
@@ -328,37 +329,219 @@ static __global__ void k_cost_goal(CostView V, int gx, int gy, int gz, uint32_t*
     }
 }
 
-// one layer of the flood: collision check, then expansion, of every slope in the layer.  Four lanes share a slope
-// (one per neighbour cell): layers are short, so the kernel is latency-bound and the serial work per lane counts.
+// ---------------------------------------------------------------------------------------------
+// CollisionCheck by a TEAM of lanes (round 4).  The ring of a slope is a SET: layer d + 1 = the slopes, not seen before, that pass
+// the gates from SOME slope of layer d, and the verdict asks whether ANY member is too high (map2D.h:384-392) — nothing depends on
+// the order the reference's list happens to hold them in.  So the (slope of the layer, neighbour cell) pairs of a ring layer are
+// spread over the team's lanes, a member is claimed with one compare-and-swap in a hash set in LDS (which is also the "seen" test the
+// serial walk spends a scan of the whole ring on), and the list itself is only appended to.  A serial checker's time is a chain of
+// ~5 dependent memory round trips per neighbour cell, 20 cells for a ring of depth 2; the team pays the chain once per ring layer.
+// (bridge_ground at its own parameters, 182 layers: 28.5 ms of flood with one lane per checker — 2.5 x the reference's own loop on
+// one CPU core.)  All lanes of a team are lanes of ONE wavefront: they run in lockstep, and LDS serves a wavefront's requests in
+// order, so what a lane wrote before team_sync() is what every lane reads after it.
+// ---------------------------------------------------------------------------------------------
+constexpr int kTeamRingCap = 1024;       // slopes a team's ring holds in LDS; a ring that does not fit is a whole wavefront's, in global scratch
+constexpr int kTeamSetSize = 2048;       // (power of two, 2 x the ring)
+constexpr uint32_t kSetEmpty = 0xFFFFFFFFu;
+
+struct TeamCtl {
+    uint32_t n;                          // ring members
+    uint32_t flags;                      // 1 = collide, 2 = the ring does not fit
+};
+
+__device__ __forceinline__ void team_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Where a team keeps its ring (the list) and its set (open addressing over row numbers, kSetEmpty at rest: every check removes what
+// it added).  In LDS: plain accesses, in order for the wavefront.
+struct alignas(16) TeamLds {
+    uint32_t ring[kTeamRingCap];
+    alignas(16) uint32_t set[kTeamSetSize];
+};
+struct RingInLds {
+    TeamLds* L;
+    uint32_t ring_cap;                   // <= kTeamRingCap
+    __device__ __forceinline__ uint32_t cap() const { return ring_cap; }
+    __device__ __forceinline__ uint32_t mask() const { return (uint32_t)(kTeamSetSize - 1); }
+    __device__ __forceinline__ uint32_t get(uint32_t i) const { return L->ring[i]; }
+    __device__ __forceinline__ void put(uint32_t i, uint32_t t) const { L->ring[i] = t; }
+    __device__ __forceinline__ uint32_t cas(uint32_t s, uint32_t t) const { return atomicCAS(&L->set[s], kSetEmpty, t); }
+    __device__ __forceinline__ uint32_t peek(uint32_t s) const { return __atomic_load_n(&L->set[s], __ATOMIC_RELAXED); }
+    __device__ __forceinline__ void wipe(uint32_t s) const { L->set[s] = kSetEmpty; }
+    __device__ __forceinline__ void sync() const { team_sync(); }
+};
+// In global memory: every access is a device-scope atomic (served by the L2, past the CU's cache, which a wavefront's own stores do
+// not update), and a sync waits for the wavefront's stores to have arrived there before the lanes go on.
+struct RingInGlobal {
+    uint32_t *ring, *set;
+    uint32_t ring_cap, set_mask;
+    __device__ __forceinline__ uint32_t cap() const { return ring_cap; }
+    __device__ __forceinline__ uint32_t mask() const { return set_mask; }
+    __device__ __forceinline__ uint32_t get(uint32_t i) const { return __hip_atomic_load(&ring[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    __device__ __forceinline__ void put(uint32_t i, uint32_t t) const { __hip_atomic_store(&ring[i], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    __device__ __forceinline__ uint32_t cas(uint32_t s, uint32_t t) const { return atomicCAS(&set[s], kSetEmpty, t); }
+    __device__ __forceinline__ uint32_t peek(uint32_t s) const { return __hip_atomic_load(&set[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    __device__ __forceinline__ void wipe(uint32_t s) const { __hip_atomic_store(&set[s], kSetEmpty, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    __device__ __forceinline__ void sync() const { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); team_sync(); }
+};
+
+__device__ __forceinline__ uint32_t team_set_home(uint32_t t, uint32_t mask) { return ((t * 0x9E3779B1u) >> 11) & mask; }
+
+// true: t was not a member and is one now
+template <typename Store>
+__device__ __forceinline__ bool team_set_claim(const Store& S, uint32_t t) {
+    uint32_t s = team_set_home(t, S.mask());
+    for (;;) {
+        const uint32_t old = S.cas(s, t);
+        if (old == kSetEmpty) return true;
+        if (old == t) return false;
+        s = (s + 1u) & S.mask();
+    }
+}
+
+// (every member is removed by exactly one lane, so a walk only ever passes slots that hold, or held, OTHER members)
+template <typename Store>
+__device__ __forceinline__ void team_set_release(const Store& S, uint32_t t) {
+    uint32_t s = team_set_home(t, S.mask());
+    while (S.peek(s) != t) s = (s + 1u) & S.mask();
+    S.wipe(s);
+}
+
+// Same verdict as cost_collide(): 1 collide, 0 free, -1 the ring holds more than S.cap() slopes.  Called by all T lanes of a team
+// (tl = 0 .. T-1) with the same arguments; returns the same value in all of them.  C is the team's control block in LDS.
+template <int T, typename Store>
+__device__ int cost_collide_team(const CostView& V, const Robot& R, uint32_t slope, int ring_n, const Store& S, TeamCtl& C, uint32_t tl) {
+    GNDT_FP_STRICT
+    if (row_up(V, slope)) return 1;
+    const float mz = V.mean[3 * slope + 2];
+    if (tl == 0u) { S.put(0u, slope); C.n = 1u; C.flags = 0u; (void)team_set_claim(S, slope); }
+    S.sync();
+    uint32_t now_b = 0u, now_e = 1u;
+    for (int depth = 0; depth < ring_n; ++depth) {
+        const uint32_t items = (now_e - now_b) * 4u;
+        for (uint32_t w = tl; w < items; w += (uint32_t)T) {
+            const uint32_t cur = S.get(now_b + (w >> 2)), k = w & 3u;
+            uint32_t c;
+            if (V.nbr) c = V.nbr[4 * (size_t)cur + k];
+            else {
+                const int sx = V.sx[cur], sy = V.sy[cur];
+                c = k == 0u ? ctab_find(V, sx, step_skip0(sy, -1)) : k == 1u ? ctab_find(V, sx, step_skip0(sy, +1))
+                  : k == 2u ? ctab_find(V, step_skip0(sx, +1), sy) : ctab_find(V, step_skip0(sx, -1), sy);
+            }
+            if (c == kNoColumn) continue;
+            const uint32_t e = c + V.row_ncol[c];
+            for (uint32_t t = c; t < e; ++t) {
+                if (!row_has_slope(V, t)) continue;
+                if (!V.demand_true && !cost_gates(V, R, t, V.normal + 3 * cur, V.mean + 3 * cur)) continue;
+                if (__atomic_load_n(&C.flags, __ATOMIC_RELAXED) & 2u) break;        // (the set must not fill up either)
+                if (!team_set_claim(S, t)) continue;
+                const uint32_t pos = atomicAdd(&C.n, 1u);
+                if (pos < S.cap()) S.put(pos, t);
+                else atomicOr(&C.flags, 2u);
+            }
+        }
+        S.sync();
+        if (C.flags & 2u) break;
+        now_b = now_e;
+        now_e = C.n;
+        if (now_b == now_e) break;                     // an empty ring layer: the deeper ones are empty, too
+    }
+    int res = 0;
+    const bool overflow = (C.flags & 2u) != 0u;
+    const uint32_t n_all = overflow ? 0u : C.n;
+    if (overflow) res = -1;
+    else {
+        for (uint32_t j = tl; j < n_all; j += (uint32_t)T) {
+            const uint32_t m = S.get(j);
+            const float tz = V.mean[3 * m + 2];
+            bool hit = tz < mz && row_up(V, m);
+            // map2D.h:388 / :451: `((a < b) + 2*r)` only asks for a non-zero number
+            const float odd = (float)(tz < mz ? 1 : 0) + 2.f * R.r;
+            hit = hit || (tz > mz && odd != 0.f && (tz - mz > R.reach));
+            if (hit) atomicOr(&C.flags, 1u);
+        }
+        team_sync();
+        if (C.flags & 1u) res = 1;
+        else {
+            // the next slope above in the same cell (map_slope is ascending in z); the same loads in every lane of the team
+            const uint32_t c = ctab_find(V, V.sx[slope], V.sy[slope]);
+            if (c != kNoColumn) {
+                const uint32_t e = c + V.row_ncol[c];
+                const int myz = V.sz[slope];
+                uint32_t next = kNoColumn;
+                int next_z = 0;
+                for (uint32_t t = c; t < e; ++t) {
+                    if (!row_has_slope(V, t) || V.sz[t] <= myz) continue;
+                    if (next == kNoColumn || V.sz[t] < next_z) { next = t; next_z = V.sz[t]; }
+                }
+                if (next != kNoColumn) {
+                    const float nz = V.mean[3 * next + 2];
+                    if ((nz < mz + 2.f * R.r) && (nz - mz > R.reach)) res = 1;
+                }
+            }
+        }
+    }
+    // leave the set empty for the team's next slope
+    if (overflow) { for (uint32_t j = tl; j <= S.mask(); j += (uint32_t)T) S.wipe(j); }
+    else          { for (uint32_t j = tl; j < n_all; j += (uint32_t)T) team_set_release(S, S.get(j)); }
+    S.sync();
+    return res;
+}
+
+// one layer of the flood: collision check, then expansion, of every slope in the layer.  T lanes share a slope: 4 (one per neighbour
+// cell of the expansion; the collision check without a ring is one lane's), 16 (rings that fit LDS: the check is the team's, the
+// expansion its first four lanes') or 64 (rings that do not: ring and set in `scratch`, 3 * ring_cap words per wavefront, set part
+// kSetEmpty at rest).  Layers are short, so the kernel is latency-bound and the serial work per lane counts.
+template <int T>
 static __global__ void __launch_bounds__(64) k_cost_level(CostView V, Robot R, int ring_n, uint32_t level, uint32_t* __restrict__ h_bits,
                                                    uint32_t* __restrict__ pushed, uint32_t* __restrict__ state,
                                                    const uint32_t* __restrict__ f_in, uint32_t* __restrict__ f_out,
-                                                   uint32_t* __restrict__ ring_scratch, int ring_cap, CostCounters* __restrict__ cc) {
+                                                   uint32_t* scratch, uint32_t ring_cap, CostCounters* __restrict__ cc) {
+    constexpr uint32_t kPerWave = 64u / (uint32_t)T;   // slopes a wave takes at a time
+    __shared__ uint32_t s_one[T == 4 ? 16 : 1];        // a checker without a ring still lists the slope itself
+    __shared__ TeamLds s_team[T == 16 ? kPerWave : 1];
+    __shared__ TeamCtl s_ctl[kPerWave];
     const uint32_t n_in = cc->frontier[level % 3u];
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         cc->frontier[(level + 2u) % 3u] = 0u;          // the counter two layers ahead (was the previous layer's input)
         if (n_in) cc->levels = level + 1u;
     }
-    if (n_in == 0u) return;
+    if (blockIdx.x * kPerWave >= n_in) return;         // (also: n_in == 0)
     uint32_t* out_count = &cc->frontier[(level + 1u) % 3u];
     const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t quad = tid >> 2, dir = tid & 3u, quads = (gridDim.x * blockDim.x) >> 2;
-    const int lane = (int)(threadIdx.x & 63u), leader = lane & ~3;
+    const uint32_t dir = tid % (uint32_t)T, teams = (gridDim.x * blockDim.x) / (uint32_t)T;
+    const int lane = (int)(threadIdx.x & 63u), leader = lane & ~(T - 1);
+    if constexpr (T == 16) {
+        for (uint32_t j = threadIdx.x; j < kPerWave * (uint32_t)(kTeamSetSize / 4); j += blockDim.x)
+            reinterpret_cast<uint4*>(s_team[j / (uint32_t)(kTeamSetSize / 4)].set)[j % (uint32_t)(kTeamSetSize / 4)] =
+                make_uint4(kSetEmpty, kSetEmpty, kSetEmpty, kSetEmpty);
+        __syncthreads();
+    }
     uint32_t trav = 0, closed = 0, checks = 0;
-    // The loop is wave-uniform (a wave's 16 quads take 16 consecutive slopes of the layer, lanes past the end sit idle), so that
-    // the slopes a wave pushes are appended with ONE atomic on the layer's counter: the counter is one word, same-address atomics
+    // The loop is wave-uniform (a wave's teams take consecutive slopes of the layer, lanes past the end sit idle), so that the
+    // slopes a wave pushes are appended with ONE atomic on the layer's counter: the counter is one word, same-address atomics
     // retire at ~90 per microsecond at the memory side, and a layer of a few hundred slopes used to add one per pushed slope
     // and three more per expanded slope (the statistics below) — most of a layer's 13-18 us.
-    for (uint32_t i0 = (tid >> 6) * 16u; i0 < n_in; i0 += quads) {
-        const uint32_t i = i0 + ((uint32_t)lane >> 2);
+    for (uint32_t i0 = (tid >> 6) * kPerWave; i0 < n_in; i0 += teams) {
+        const uint32_t i = i0 + (uint32_t)lane / (uint32_t)T;
         const bool live = i < n_in;
         const uint32_t q = live ? f_in[i] : 0u;
         int hit = 0;
-        if (live && dir == 0u) hit = cost_collide(V, R, q, ring_n, ring_scratch + (size_t)quad * (size_t)ring_cap, ring_cap);
-        hit = __shfl(hit, leader, 64);
+        if constexpr (T == 16) {
+            if (live) hit = cost_collide_team<T>(V, R, q, ring_n, RingInLds{&s_team[(uint32_t)lane / (uint32_t)T], ring_cap}, s_ctl[(uint32_t)lane / (uint32_t)T], dir);
+        } else if constexpr (T == 64) {
+            uint32_t* mine = scratch + (size_t)blockIdx.x * 3u * (size_t)ring_cap;
+            if (live) hit = cost_collide_team<T>(V, R, q, ring_n, RingInGlobal{mine, mine + ring_cap, ring_cap, 2u * ring_cap - 1u}, s_ctl[0], dir);
+        } else {
+            if (live && dir == 0u) hit = cost_collide(V, R, q, 0, &s_one[threadIdx.x >> 2], 1);
+            hit = __shfl(hit, leader, 64);
+        }
         constexpr uint32_t kKeep = 4;                  // pushes a lane keeps for the wave's append (more go out one by one)
         uint32_t mine[kKeep] = {0u, 0u, 0u, 0u}, np = 0;
-        if (live) {
+        if (live && dir < 4u) {
             if (hit < 0) { if (dir == 0u) atomicAdd(&cc->ring_overflow, 1u); }
             else if (hit) {
                 if (dir == 0u) {

@@ -508,7 +508,7 @@ class TwoDmap:
     @staticmethod
     def _cost_stats(st):
         return {"rc": int(st.goal_status), "ring": int(st.ring), "levels": int(st.levels), "traversable": int(st.traversable),
-                "closed": int(st.closed), "check_pushes": int(st.check_pushes)}
+                "closed": int(st.closed), "check_pushes": int(st.check_pushes), "ring_store": int(st.ring_store)}
 
     def cost_export(self):
         """Host copy of Slope::h (fp32, FLT_MAX = unreached) and the flood state per result row."""

@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--seconds", type=float, default=300.0)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--max-points", type=int, default=600_000)
+    ap.add_argument("--trace", action="store_true", help="print every flood's description to stderr before it runs (to find one that hangs)")
     a = ap.parse_args()
     import torch
     import grid_ndt_amd as g
@@ -49,6 +50,8 @@ def main():
                      "max_angle_deg": float(rng.choice([15.0, 20.0, 30.0, 45.0]))}
             desc = dict(seed=a.seed, map=stats["maps"], cells=cells, demand=demand, points=int(cloud.shape[0] - 1), nodes=int(grid["num_nodes"]),
                         goal=[float(v) for v in goal], robot=robot)
+            if a.trace:
+                print(json.dumps(desc), file=sys.stderr, flush=True)
             try:
                 st = m.computeCost(goal, robot=robot)
                 got = m.cost_export()
