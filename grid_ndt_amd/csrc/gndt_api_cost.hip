@@ -53,7 +53,7 @@ int gndt_compute_cost(gndt_handle* h, const float goal_xyz[3], const gndt_robot*
         c.node_cap = 0;
         const uint64_t cap = std::max<uint64_t>(1024, n + n / 8);
         for (uint32_t** a : {&c.h_bits, &c.pushed, &c.state, &c.f[0], &c.f[1]}) HIP_TRY(h, hipMalloc(a, cap * 4));
-        HIP_TRY(h, hipMalloc(&c.nbr, cap * 16));
+        HIP_TRY(h, hipMalloc(&c.nbr, cap * 24));      // (4 neighbour columns + own column + slope above, per row)
         c.node_cap = cap;
     }
     const uint32_t tsize = pow2_ceil(std::max<uint64_t>(1024, 2 * K));
@@ -79,15 +79,16 @@ int gndt_compute_cost(gndt_handle* h, const float goal_xyz[3], const gndt_robot*
     const PointKey gk = point_key(goal_xyz[0], goal_xyz[1], goal_xyz[2], h->origin[0], h->origin[1], h->origin[2],
                                   h->P.grid_len, h->P.z_len);
   for (;;) {                  // (again with a larger ring scratch if a collision ring did not fit)
-    V.nbr = nullptr;
+    V.nbr = nullptr; V.self = nullptr;
     hipLaunchKernelGGL(k_cost_clear, dim3(grid_for(std::max<uint64_t>(n, c.ctab_size))), dim3(256), 0, s, c.h_bits, c.pushed,
                        c.state, (uint32_t)n, c.ctab_key, c.ctab_size, c.d_cc);
     if (K)
         hipLaunchKernelGGL(k_cost_columns, dim3(grid_for(n)), dim3(256), 0, s, h->out.sx, h->out.sy, h->part.row_ncol,
                            (uint32_t)n, c.ctab_key, c.ctab_val, c.ctab_size - 1, c.d_cc);
     if (K) {
-        hipLaunchKernelGGL(k_cost_neighbours, dim3(grid_for(4 * n)), dim3(256), 0, s, V, (uint32_t)n, c.nbr);   // (probes: V.nbr is null)
+        hipLaunchKernelGGL(k_cost_neighbours, dim3(grid_for(4 * n)), dim3(256), 0, s, V, (uint32_t)n, c.nbr, c.nbr + 4 * c.node_cap);   // (probes: V.nbr, V.self are null)
         V.nbr = c.nbr;
+        V.self = c.nbr + 4 * c.node_cap;
     }
     if (gk.ok && K)
         hipLaunchKernelGGL(k_cost_goal, dim3(1), dim3(64), 0, s, V, gk.sx, gk.sy, gk.sz, c.h_bits, c.pushed, c.f[0], c.d_cc);

@@ -61,6 +61,9 @@ struct CostView {
     const uint32_t* nbr;
     float slope_interval;
     int demand_true;
+    // optional, like nbr: self[2 * row] = first row of the row's OWN column, self[2 * row + 1] = the next slope above the row in its
+    // cell (map_slope is ascending in z) or kNoColumn — what every collision check asks first, found once per flood
+    const uint32_t* self = nullptr;
 };
 
 GNDT_HD uint64_t column_pack(int sx, int sy) { return pack_key(sx, sy, 0); }
@@ -111,12 +114,30 @@ GNDT_HD float cost_travel(const float* cur, const float* des) {
 
 GNDT_HD bool row_has_slope(const CostView& V, uint32_t row) { return (V.flags[row] & 2u) != 0u; }
 
+GNDT_HD uint32_t row_column(const CostView& V, uint32_t row) { return V.self ? V.self[2 * (size_t)row] : ctab_find(V, V.sx[row], V.sy[row]); }
+
+// the next slope above `row` in its cell, or kNoColumn
+GNDT_HD uint32_t row_next_above(const CostView& V, uint32_t row) {
+    if (V.self) return V.self[2 * (size_t)row + 1];
+    const uint32_t c = ctab_find(V, V.sx[row], V.sy[row]);
+    if (c == kNoColumn) return kNoColumn;
+    const uint32_t e = c + V.row_ncol[c];
+    const int myz = V.sz[row];
+    uint32_t next = kNoColumn;
+    int next_z = 0;
+    for (uint32_t t = c; t < e; ++t) {
+        if (!row_has_slope(V, t) || V.sz[t] <= myz) continue;
+        if (next == kNoColumn || V.sz[t] < next_z) { next = t; next_z = V.sz[t]; }
+    }
+    return next;
+}
+
 // Slope::countUp (map2D.h:147-177): a node one level up in the column whose centroid z differs by more than the
 // interval; centroids of nodes without statistics are zero.  Only demand "true" evaluates it (lazily); with
 // demand "slope" Slope::up is never assigned and stays false (map2D.h:636).
 GNDT_HD bool row_up(const CostView& V, uint32_t row) {
     if (!V.demand_true) return false;
-    const uint32_t c = ctab_find(V, V.sx[row], V.sy[row]);
+    const uint32_t c = row_column(V, row);
     if (c == kNoColumn) return false;
     const int zadd = level_above(V.sz[row]);
     const float mz = V.mean[3 * row + 2];
@@ -188,16 +209,7 @@ GNDT_HD int cost_collide(const CostView& V, const Robot& R, uint32_t slope, int 
         if (tz > mz && odd != 0.f && (tz - mz > R.reach)) return 1;
     }
     // the next slope above in the same cell (map_slope is ascending in z)
-    const uint32_t c = ctab_find(V, V.sx[slope], V.sy[slope]);
-    if (c == kNoColumn) return 0;
-    const uint32_t b = c, e = c + V.row_ncol[c];
-    const int myz = V.sz[slope];
-    uint32_t next = kNoColumn;
-    int next_z = 0;
-    for (uint32_t t = b; t < e; ++t) {
-        if (!row_has_slope(V, t) || V.sz[t] <= myz) continue;
-        if (next == kNoColumn || V.sz[t] < next_z) { next = t; next_z = V.sz[t]; }
-    }
+    const uint32_t next = row_next_above(V, slope);
     if (next != kNoColumn) {
         const float nz = V.mean[3 * next + 2];
         if ((nz < mz + 2.f * R.r) && (nz - mz > R.reach)) return 1;
@@ -297,11 +309,15 @@ static __global__ void __launch_bounds__(256) k_cost_columns(const int32_t* __re
     }
 }
 
-// the four neighbour columns of every row, once per flood (the layers then follow plain indices)
-static __global__ void __launch_bounds__(256) k_cost_neighbours(CostView V, uint32_t num_rows, uint32_t* __restrict__ nbr) {
+// the four neighbour columns of every row, its own column and the slope above it, once per flood (the layers then follow plain indices)
+static __global__ void __launch_bounds__(256) k_cost_neighbours(CostView V, uint32_t num_rows, uint32_t* __restrict__ nbr, uint32_t* __restrict__ self) {
     for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < 4u * num_rows; t += gridDim.x * blockDim.x) {
         const uint32_t row = t >> 2, k = t & 3u;
         const int sx = V.sx[row], sy = V.sy[row];
+        if (k == 0u) {                                  // (V.self is null here: both go through the hash table)
+            self[2 * (size_t)row] = ctab_find(V, sx, sy);
+            self[2 * (size_t)row + 1] = row_next_above(V, row);
+        }
         nbr[t] = k == 0 ? ctab_find(V, sx, step_skip0(sy, -1))
                : k == 1 ? ctab_find(V, sx, step_skip0(sy, +1))
                : k == 2 ? ctab_find(V, step_skip0(sx, +1), sy)
@@ -467,20 +483,10 @@ __device__ int cost_collide_team(const CostView& V, const Robot& R, uint32_t slo
         if (C.flags & 1u) res = 1;
         else {
             // the next slope above in the same cell (map_slope is ascending in z); the same loads in every lane of the team
-            const uint32_t c = ctab_find(V, V.sx[slope], V.sy[slope]);
-            if (c != kNoColumn) {
-                const uint32_t e = c + V.row_ncol[c];
-                const int myz = V.sz[slope];
-                uint32_t next = kNoColumn;
-                int next_z = 0;
-                for (uint32_t t = c; t < e; ++t) {
-                    if (!row_has_slope(V, t) || V.sz[t] <= myz) continue;
-                    if (next == kNoColumn || V.sz[t] < next_z) { next = t; next_z = V.sz[t]; }
-                }
-                if (next != kNoColumn) {
-                    const float nz = V.mean[3 * next + 2];
-                    if ((nz < mz + 2.f * R.r) && (nz - mz > R.reach)) res = 1;
-                }
+            const uint32_t next = row_next_above(V, slope);
+            if (next != kNoColumn) {
+                const float nz = V.mean[3 * next + 2];
+                if ((nz < mz + 2.f * R.r) && (nz - mz > R.reach)) res = 1;
             }
         }
     }
