@@ -8,7 +8,7 @@ namespace gndt_host {
 
 void free_cost(gndt_handle* h) {
     auto& c = h->cost;
-    void* ptrs[] = {c.h_bits, c.pushed, c.state, c.f[0], c.f[1], c.ctab_key, c.ctab_val, c.ring, c.nbr, c.d_cc};
+    void* ptrs[] = {c.h_bits, c.state, c.f[0], c.f[1], c.ctab_key, c.ctab_val, c.ring, c.nbr, c.d_cc};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (c.h_cc) (void)hipHostFree(c.h_cc);
@@ -49,11 +49,11 @@ int gndt_compute_cost(gndt_handle* h, const float goal_xyz[3], const gndt_robot*
     const int lds_cap = std::max(1, std::min(kTeamRingCap, env_int("GNDT_COST_RING_LDS", kTeamRingCap)));
     if (c.ring_cap == 0) c.ring_cap = (int)pow2_ceil((uint64_t)std::max(16, std::min(kRingCapMax, env_int("GNDT_COST_RING_FIRST", 8 * kTeamRingCap))));
     if (n > c.node_cap) {
-        for (uint32_t** a : {&c.h_bits, &c.pushed, &c.state, &c.f[0], &c.f[1], &c.nbr}) { if (*a) (void)hipFree(*a); *a = nullptr; }
+        for (uint32_t** a : {&c.h_bits, &c.state, &c.f[0], &c.f[1], &c.nbr}) { if (*a) (void)hipFree(*a); *a = nullptr; }
         c.node_cap = 0;
         const uint64_t cap = std::max<uint64_t>(1024, n + n / 8);
-        for (uint32_t** a : {&c.h_bits, &c.pushed, &c.state, &c.f[0], &c.f[1]}) HIP_TRY(h, hipMalloc(a, cap * 4));
-        HIP_TRY(h, hipMalloc(&c.nbr, cap * 24));      // (4 neighbour columns + own column + slope above, per row)
+        for (uint32_t** a : {&c.h_bits, &c.state, &c.f[0], &c.f[1]}) HIP_TRY(h, hipMalloc(a, cap * 4));
+        HIP_TRY(h, hipMalloc(&c.nbr, cap * 40));      // (4 neighbour columns with their sizes + own column + verdict on the slope above, per row)
         c.node_cap = cap;
     }
     const uint32_t tsize = pow2_ceil(std::max<uint64_t>(1024, 2 * K));
@@ -80,21 +80,19 @@ int gndt_compute_cost(gndt_handle* h, const float goal_xyz[3], const gndt_robot*
                                   h->P.grid_len, h->P.z_len);
   for (;;) {                  // (again with a larger ring scratch if a collision ring did not fit)
     V.nbr = nullptr; V.self = nullptr;
-    hipLaunchKernelGGL(k_cost_clear, dim3(grid_for(std::max<uint64_t>(n, c.ctab_size))), dim3(256), 0, s, c.h_bits, c.pushed,
+    hipLaunchKernelGGL(k_cost_clear, dim3(grid_for(std::max<uint64_t>(n, c.ctab_size))), dim3(256), 0, s, c.h_bits,
                        c.state, (uint32_t)n, c.ctab_key, c.ctab_size, c.d_cc);
     if (K)
         hipLaunchKernelGGL(k_cost_columns, dim3(grid_for(n)), dim3(256), 0, s, h->out.sx, h->out.sy, h->part.row_ncol,
                            (uint32_t)n, c.ctab_key, c.ctab_val, c.ctab_size - 1, c.d_cc);
     if (K) {
-        hipLaunchKernelGGL(k_cost_neighbours, dim3(grid_for(4 * n)), dim3(256), 0, s, V, (uint32_t)n, c.nbr, c.nbr + 4 * c.node_cap);   // (probes: V.nbr, V.self are null)
+        hipLaunchKernelGGL(k_cost_neighbours, dim3(grid_for(4 * n)), dim3(256), 0, s, V, R, (uint32_t)n, c.nbr, c.nbr + 8 * c.node_cap);   // (probes: V.nbr, V.self are null)
         V.nbr = c.nbr;
-        V.self = c.nbr + 4 * c.node_cap;
+        V.self = c.nbr + 8 * c.node_cap;
     }
     if (gk.ok && K)
-        hipLaunchKernelGGL(k_cost_goal, dim3(1), dim3(64), 0, s, V, gk.sx, gk.sy, gk.sz, c.h_bits, c.pushed, c.f[0], c.d_cc);
+        hipLaunchKernelGGL(k_cost_goal, dim3(1), dim3(64), 0, s, V, gk.sx, gk.sy, gk.sz, c.h_bits, c.f[0], c.d_cc);
     HIP_TRY(h, hipGetLastError());
-    // One launch per layer.  The layer count is only known on the device, so layers are enqueued in batches and
-    // the frontier size of the next layer is read back after each batch (empty layers are no-ops).
     // Who checks a slope for collisions (gndt_cost.hpp): without a ring one lane; with a ring a team of 16 and the ring in LDS, or —
     // once a ring of that depth has not fitted on this handle — a whole wavefront per slope with ring and set in global scratch,
     // which is only allocated then.  GNDT_COST_RING_IN_LDS=0 sends every ring the second way (tests).
@@ -109,23 +107,35 @@ int gndt_compute_cost(gndt_handle* h, const float goal_xyz[3], const gndt_robot*
         HIP_TRY(h, hipMemsetAsync(c.ring, 0xFF, words * sizeof(uint32_t), s));                   // (sets are empty at rest)
         c.ring_alloc = c.ring_cap;
     }
-    uint32_t level = 0;
+    // A batch on the stream: without collision rings the one-workgroup kernel (as many narrow layers as it meets, gndt_cost.hpp), then
+    // one-layer launches (any width; no-ops once the flood has ended) — 8 while the layers are narrow, 32 when the last answer showed a
+    // wide one.  How many layers the one-workgroup kernel walked is only known on the device (cc->wg_layers); the host asks after
+    // every batch whether the flood has ended.  GNDT_COST_WG=0: one-layer launches only.
+    const bool wg = mode == 0 && env_int("GNDT_COST_WG", 1) != 0;
+    bool narrow = true;
+    uint32_t launched = 0;                                   // one-layer launches enqueued so far
     for (;;) {
-        for (int b = 0; b < kCostBatch; ++b, ++level) {
+        if (wg)
+            hipLaunchKernelGGL(k_cost_flood_wg, dim3(1), dim3(kWgThreads), 0, s, V, R, c.h_bits, c.state, c.f[0], c.f[1], c.d_cc, kWgFrontier, 1u << 20,
+                               launched);
+        for (int b = 0, nb = wg && narrow ? 8 : kCostBatch; b < nb; ++b, ++launched) {
             if (mode == 1)
-                hipLaunchKernelGGL(k_cost_level<16>, dim3(kCostBlocks * 4), dim3(kCostThreads), 0, s, V, R, c.ring_n, level, c.h_bits,
-                                   c.pushed, c.state, c.f[level & 1u], c.f[(level + 1u) & 1u], (uint32_t*)nullptr, (uint32_t)lds_cap, c.d_cc);
+                hipLaunchKernelGGL(k_cost_level<16>, dim3(kCostBlocks * 4), dim3(kCostThreads), 0, s, V, R, c.ring_n, c.h_bits,
+                                   c.state, c.f[0], c.f[1], (uint32_t*)nullptr, (uint32_t)lds_cap, c.d_cc, launched);
             else if (mode == 2)
-                hipLaunchKernelGGL(k_cost_level<64>, dim3(kCostWaves), dim3(kCostThreads), 0, s, V, R, c.ring_n, level, c.h_bits,
-                                   c.pushed, c.state, c.f[level & 1u], c.f[(level + 1u) & 1u], c.ring, (uint32_t)c.ring_cap, c.d_cc);
+                hipLaunchKernelGGL(k_cost_level<64>, dim3(kCostWaves), dim3(kCostThreads), 0, s, V, R, c.ring_n, c.h_bits,
+                                   c.state, c.f[0], c.f[1], c.ring, (uint32_t)c.ring_cap, c.d_cc, launched);
             else
-                hipLaunchKernelGGL(k_cost_level<4>, dim3(kCostBlocks), dim3(kCostThreads), 0, s, V, R, 0, level, c.h_bits,
-                                   c.pushed, c.state, c.f[level & 1u], c.f[(level + 1u) & 1u], (uint32_t*)nullptr, 1u, c.d_cc);
+                hipLaunchKernelGGL(k_cost_level<4>, dim3(kCostBlocks), dim3(kCostThreads), 0, s, V, R, 0, c.h_bits,
+                                   c.state, c.f[0], c.f[1], (uint32_t*)nullptr, 1u, c.d_cc, launched);
         }
         HIP_TRY(h, hipGetLastError());
         HIP_TRY(h, hipMemcpyAsync(c.h_cc, c.d_cc, sizeof(CostCounters), hipMemcpyDeviceToHost, s));
         HIP_TRY(h, hipStreamSynchronize(s));
-        if (c.h_cc->frontier[level % 3u] == 0u) break;
+        const uint32_t level = launched + c.h_cc->wg_layers;
+        const uint32_t left = c.h_cc->frontier[level % 3u];
+        if (left == 0u) break;
+        narrow = left <= kWgFrontier;
         if (level > (1u << 24)) { h->err = "cost flood did not terminate"; return GNDT_ERR_HIP; }
     }
     if (c.h_cc->range_error) {
@@ -145,6 +155,11 @@ int gndt_compute_cost(gndt_handle* h, const float goal_xyz[3], const gndt_robot*
     }
     break;
   }
+    if (n) {        // what no relaxation reached keeps the FLT_MAX it was created with (gndt_cost.hpp: kUnreachedBits)
+        hipLaunchKernelGGL(k_cost_finish, dim3(grid_for(n)), dim3(256), 0, s, c.h_bits, (uint32_t)n);
+        HIP_TRY(h, hipGetLastError());
+        HIP_TRY(h, hipStreamSynchronize(s));
+    }
     c.serial = h->result_serial;
     return GNDT_OK;
 }

@@ -56,13 +56,15 @@ struct CostView {
     const uint64_t* ctab_key;
     const uint32_t* ctab_val;
     uint32_t ctab_mask;
-    // optional: nbr[4 * row + k] = first row of the row's k-th neighbour column (left, right, forward, back) or kNoColumn,
-    // precomputed for every row so that the per-layer kernels do not probe the hash table (null: probe)
+    // optional: nbr[8 * row + 2 * k] = first row of the row's k-th neighbour column (left, right, forward, back) or kNoColumn,
+    // nbr[8 * row + 2 * k + 1] = the nodes of that column (one 8-byte load names the rows to look at), precomputed for every row so
+    // that the per-layer kernels neither probe the hash table nor read row_ncol (null: probe)
     const uint32_t* nbr;
     float slope_interval;
     int demand_true;
-    // optional, like nbr: self[2 * row] = first row of the row's OWN column, self[2 * row + 1] = the next slope above the row in its
-    // cell (map_slope is ascending in z) or kNoColumn — what every collision check asks first, found once per flood
+    // optional, like nbr: self[2 * row] = first row of the row's OWN column, self[2 * row + 1] = 1 if the next slope above the row in
+    // its cell (map_slope is ascending in z) is in the robot's way (map2D.h:394-410) — what every collision check asks, answered once
+    // per flood (for that flood's robot)
     const uint32_t* self = nullptr;
 };
 
@@ -116,20 +118,23 @@ GNDT_HD bool row_has_slope(const CostView& V, uint32_t row) { return (V.flags[ro
 
 GNDT_HD uint32_t row_column(const CostView& V, uint32_t row) { return V.self ? V.self[2 * (size_t)row] : ctab_find(V, V.sx[row], V.sy[row]); }
 
-// the next slope above `row` in its cell, or kNoColumn
-GNDT_HD uint32_t row_next_above(const CostView& V, uint32_t row) {
-    if (V.self) return V.self[2 * (size_t)row + 1];
+// Is the next slope above `row` in its cell in the robot's way?  (CollisionCheck's last test, map2D.h:394-410 / :457-473.)
+GNDT_HD bool row_above_hits(const CostView& V, const Robot& R, uint32_t row) {
+    GNDT_FP_STRICT
+    if (V.self) return V.self[2 * (size_t)row + 1] != 0u;
     const uint32_t c = ctab_find(V, V.sx[row], V.sy[row]);
-    if (c == kNoColumn) return kNoColumn;
+    if (c == kNoColumn) return false;
     const uint32_t e = c + V.row_ncol[c];
     const int myz = V.sz[row];
     uint32_t next = kNoColumn;
     int next_z = 0;
     for (uint32_t t = c; t < e; ++t) {
-        if (!row_has_slope(V, t) || V.sz[t] <= myz) continue;
+        if (!((V.flags[t] & 2u) != 0u) || V.sz[t] <= myz) continue;
         if (next == kNoColumn || V.sz[t] < next_z) { next = t; next_z = V.sz[t]; }
     }
-    return next;
+    if (next == kNoColumn) return false;
+    const float mz = V.mean[3 * row + 2], nz = V.mean[3 * next + 2];
+    return (nz < mz + 2.f * R.r) && (nz - mz > R.reach);
 }
 
 // Slope::countUp (map2D.h:147-177): a node one level up in the column whose centroid z differs by more than the
@@ -157,17 +162,21 @@ GNDT_HD bool cost_gates(const CostView& V, const Robot& R, uint32_t s, const flo
     return fabsf(V.mean[3 * s + 2] - mean[2]) <= R.reach;
 }
 
-// The four neighbour columns in the reference's order: left, right, forward, back (map2D.h:540-546).
-GNDT_HD void neighbour_columns(const CostView& V, uint32_t row, uint32_t col[4]) {
+// The k-th neighbour column in the reference's order — left, right, forward, back (map2D.h:540-546): its first row and node count.
+GNDT_HD void neighbour_column(const CostView& V, uint32_t row, uint32_t k, uint32_t& c, uint32_t& ncol) {
     if (V.nbr) {
-        for (int k = 0; k < 4; ++k) col[k] = V.nbr[4 * (size_t)row + k];
+#if defined(__HIP_DEVICE_COMPILE__)
+        const uint2 e = reinterpret_cast<const uint2*>(V.nbr)[4 * (size_t)row + k];
+        c = e.x; ncol = e.y;
+#else
+        c = V.nbr[8 * (size_t)row + 2 * k]; ncol = V.nbr[8 * (size_t)row + 2 * k + 1];
+#endif
         return;
     }
     const int sx = V.sx[row], sy = V.sy[row];
-    col[0] = ctab_find(V, sx, step_skip0(sy, -1));
-    col[1] = ctab_find(V, sx, step_skip0(sy, +1));
-    col[2] = ctab_find(V, step_skip0(sx, +1), sy);
-    col[3] = ctab_find(V, step_skip0(sx, -1), sy);
+    c = k == 0u ? ctab_find(V, sx, step_skip0(sy, -1)) : k == 1u ? ctab_find(V, sx, step_skip0(sy, +1))
+      : k == 2u ? ctab_find(V, step_skip0(sx, +1), sy) : ctab_find(V, step_skip0(sx, -1), sy);
+    ncol = c == kNoColumn ? 0u : V.row_ncol[c];
 }
 
 // CollisionCheck (map2D.h:351-411) and CollisionCheck3D (:414-474).  `ring` is scratch for `ring_cap` rows.
@@ -181,11 +190,11 @@ GNDT_HD int cost_collide(const CostView& V, const Robot& R, uint32_t slope, int 
     for (int depth = 0; depth < ring_n; ++depth) {
         for (int i = now_b; i < now_e; ++i) {
             const uint32_t cur = ring[i];
-            uint32_t col[4];
-            neighbour_columns(V, cur, col);
-            for (int k = 0; k < 4; ++k) {
-                if (col[k] == kNoColumn) continue;
-                const uint32_t b = col[k], e = b + V.row_ncol[b];
+            for (uint32_t k = 0; k < 4u; ++k) {
+                uint32_t b, ncol;
+                neighbour_column(V, cur, k, b, ncol);
+                if (b == kNoColumn) continue;
+                const uint32_t e = b + ncol;
                 for (uint32_t t = b; t < e; ++t) {
                     if (!row_has_slope(V, t)) continue;
                     // comand 3 (3D ring): every slope of the cell; comand 2.5: up == false and the three gates
@@ -209,12 +218,7 @@ GNDT_HD int cost_collide(const CostView& V, const Robot& R, uint32_t slope, int 
         if (tz > mz && odd != 0.f && (tz - mz > R.reach)) return 1;
     }
     // the next slope above in the same cell (map_slope is ascending in z)
-    const uint32_t next = row_next_above(V, slope);
-    if (next != kNoColumn) {
-        const float nz = V.mean[3 * next + 2];
-        if ((nz < mz + 2.f * R.r) && (nz - mz > R.reach)) return 1;
-    }
-    return 0;
+    return row_above_hits(V, R, slope) ? 1 : 0;
 }
 
 // int n = (ceil(2*r/gridLen) - 1) / 2  in fp32, truncated (map2D.h:1310)
@@ -230,29 +234,35 @@ GNDT_HD float bits_float(uint32_t u) { union { float f; uint32_t u; } v; v.u = u
 // Expansion of one popped slope (map2D.h:1312-1345 / 1346-1378) towards ONE of its four neighbour cells
 // (0 left, 1 right, 2 forward, 3 back): calls relax(neighbour_row, candidate_h) for every accessible slope of that
 // cell and returns the number of checkList pushes.
+// (nq, mq: normal and centroid of q; c, ncol: its neighbour column in this direction — read by the caller, on the device together
+//  with everything else that only needs q)
 template <typename Relax>
-GNDT_HD uint32_t cost_expand_dir(const CostView& V, const Robot& R, uint32_t q, float hq, int dir, Relax relax) {
+GNDT_HD uint32_t cost_expand_column(const CostView& V, const Robot& R, float hq, const float* nq, const float* mq, uint32_t c, uint32_t ncol, Relax relax) {
     GNDT_FP_STRICT
-    uint32_t c;
-    if (V.nbr) {
-        c = V.nbr[4 * (size_t)q + dir];
-    } else {
-        const int sx = V.sx[q], sy = V.sy[q];
-        c = dir == 0 ? ctab_find(V, sx, step_skip0(sy, -1))
-          : dir == 1 ? ctab_find(V, sx, step_skip0(sy, +1))
-          : dir == 2 ? ctab_find(V, step_skip0(sx, +1), sy)
-                     : ctab_find(V, step_skip0(sx, -1), sy);
-    }
     if (c == kNoColumn) return 0u;
     uint32_t checks = 0;
-    const uint32_t b = c, e = c + V.row_ncol[c];
-    for (uint32_t t = b; t < e; ++t) {
-        if (!row_has_slope(V, t)) continue;
+    for (uint32_t t = c; t < c + ncol; ++t) {
+        // everything the gates may ask of the row, requested at once (one round trip instead of one per gate; here — a slope's few
+        // neighbour rows, most of which pass — that is a gain, 7.8 against 8.4 us per layer; in the rings' loop it is a loss)
+        const uint32_t fl = V.flags[t];
+        const float rg = V.rough[t];
+        const float tn[3] = {V.normal[3 * t], V.normal[3 * t + 1], V.normal[3 * t + 2]};
+        const float tm[3] = {V.mean[3 * t], V.mean[3 * t + 1], V.mean[3 * t + 2]};
+        if (!(fl & 2u)) continue;
         ++checks;                                   // checkList.push_back (up is false / not consulted)
-        if (!cost_gates(V, R, t, V.normal + 3 * q, V.mean + 3 * q)) continue;
-        relax(t, hq + cost_travel(V.mean + 3 * q, V.mean + 3 * t));
+        // the three gates of countReachable (map2D.h:271-274): roughness, angle between normals, height difference
+        if (!(rg <= R.rough)) continue;
+        if (!(cost_angle(tn, nq) <= R.angle)) continue;
+        if (!(fabsf(tm[2] - mq[2]) <= R.reach)) continue;
+        relax(t, hq + cost_travel(mq, tm));
     }
     return checks;
+}
+template <typename Relax>
+GNDT_HD uint32_t cost_expand_dir(const CostView& V, const Robot& R, uint32_t q, float hq, int dir, Relax relax) {
+    uint32_t c, ncol;
+    neighbour_column(V, q, (uint32_t)dir, c, ncol);
+    return cost_expand_column(V, R, hq, V.normal + 3 * q, V.mean + 3 * q, c, ncol, relax);
 }
 
 template <typename Relax>
@@ -274,19 +284,33 @@ struct CostCounters {
     uint32_t levels;          // layers that held at least one slope
     uint32_t pad;
     unsigned long long check_pushes;
+    uint32_t wg_layers;       // layers walked by the one-workgroup kernel so far: a kernel's layer = the one-layer launches the host
+                              //   has enqueued before it (an argument) + this
 };
 
-static __global__ void __launch_bounds__(256) k_cost_clear(uint32_t* __restrict__ h_bits, uint32_t* __restrict__ pushed,
-                                                    uint32_t* __restrict__ state, uint32_t n, uint64_t* __restrict__ ctab_key,
-                                                    uint32_t ctab_size, CostCounters* __restrict__ cc) {
+// While a flood runs, h of a slope that no relaxation has reached yet is this marker (above every float, FLT_MAX included): the
+// relaxation that finds it is the slope's first and queues it — what the reference's three-list membership test decides
+// (map2D.h:1331-1336: a slope is queued once) — with the atomic min itself, no second flag.  Closed slopes hold FLT_MAX
+// (map2D.h:1340), so later relaxations of them never see the marker.  k_cost_finish turns what is left of it into FLT_MAX.
+constexpr uint32_t kUnreachedBits = 0x7F800000u;
+constexpr uint32_t kFltMaxBits = 0x7F7FFFFFu;
+
+static __global__ void __launch_bounds__(256) k_cost_clear(uint32_t* __restrict__ h_bits, uint32_t* __restrict__ state, uint32_t n,
+                                                    uint64_t* __restrict__ ctab_key, uint32_t ctab_size, CostCounters* __restrict__ cc) {
     const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x, gsz = gridDim.x * blockDim.x;
-    for (uint32_t i = gid; i < n; i += gsz) { h_bits[i] = 0x7F7FFFFFu; pushed[i] = 0u; state[i] = 0u; }
+    for (uint32_t i = gid; i < n; i += gsz) { h_bits[i] = kUnreachedBits; state[i] = 0u; }
     for (uint32_t i = gid; i < ctab_size; i += gsz) ctab_key[i] = kEmptyKey;
     if (gid == 0) {
         cc->frontier[0] = cc->frontier[1] = cc->frontier[2] = 0u;
         cc->traversable = cc->closed = cc->ring_overflow = cc->range_error = 0u;
         cc->goal_status = 1; cc->levels = 0u; cc->check_pushes = 0ull;
+        cc->wg_layers = 0u;
     }
+}
+
+static __global__ void __launch_bounds__(256) k_cost_finish(uint32_t* __restrict__ h_bits, uint32_t n) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+        if (h_bits[i] == kUnreachedBits) h_bits[i] = kFltMaxBits;          // Slope::h = FLT_MAX (map2D.h:636, 652)
 }
 
 // first row of every column -> hash table entry keyed by the column's (sx, sy)
@@ -309,25 +333,25 @@ static __global__ void __launch_bounds__(256) k_cost_columns(const int32_t* __re
     }
 }
 
-// the four neighbour columns of every row, its own column and the slope above it, once per flood (the layers then follow plain indices)
-static __global__ void __launch_bounds__(256) k_cost_neighbours(CostView V, uint32_t num_rows, uint32_t* __restrict__ nbr, uint32_t* __restrict__ self) {
+// the four neighbour columns of every row (first row, node count), its own column and the verdict on the slope above it, once per
+// flood (the layers then follow plain indices)
+static __global__ void __launch_bounds__(256) k_cost_neighbours(CostView V, Robot R, uint32_t num_rows, uint32_t* __restrict__ nbr, uint32_t* __restrict__ self) {
     for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < 4u * num_rows; t += gridDim.x * blockDim.x) {
         const uint32_t row = t >> 2, k = t & 3u;
-        const int sx = V.sx[row], sy = V.sy[row];
-        if (k == 0u) {                                  // (V.self is null here: both go through the hash table)
-            self[2 * (size_t)row] = ctab_find(V, sx, sy);
-            self[2 * (size_t)row + 1] = row_next_above(V, row);
+        uint32_t c, ncol;
+        neighbour_column(V, row, k, c, ncol);            // (V.nbr, V.self are null here: everything goes through the hash table)
+        nbr[2 * (size_t)t] = c;
+        nbr[2 * (size_t)t + 1] = ncol;
+        if (k == 0u) {
+            self[2 * (size_t)row] = ctab_find(V, V.sx[row], V.sy[row]);
+            self[2 * (size_t)row + 1] = row_above_hits(V, R, row) ? 1u : 0u;
         }
-        nbr[t] = k == 0 ? ctab_find(V, sx, step_skip0(sy, -1))
-               : k == 1 ? ctab_find(V, sx, step_skip0(sy, +1))
-               : k == 2 ? ctab_find(V, step_skip0(sx, +1), sy)
-                        : ctab_find(V, step_skip0(sx, -1), sy);
     }
 }
 
 // goal lookup (map2D.h:1294-1307): the slope of the goal's cell at the goal's level gets h = 0 and is queued
-static __global__ void k_cost_goal(CostView V, int gx, int gy, int gz, uint32_t* __restrict__ h_bits, uint32_t* __restrict__ pushed,
-                            uint32_t* __restrict__ frontier0, CostCounters* __restrict__ cc) {
+static __global__ void k_cost_goal(CostView V, int gx, int gy, int gz, uint32_t* __restrict__ h_bits, uint32_t* __restrict__ frontier0,
+                            CostCounters* __restrict__ cc) {
     if (blockIdx.x != 0 || threadIdx.x != 0) return;
     const uint32_t c = ctab_find(V, gx, gy);
     if (c == kNoColumn) { cc->goal_status = 1; return; }
@@ -336,7 +360,6 @@ static __global__ void k_cost_goal(CostView V, int gx, int gy, int gz, uint32_t*
     for (uint32_t t = b; t < e; ++t) {
         if (V.sz[t] == gz && row_has_slope(V, t)) {
             h_bits[t] = 0u;
-            pushed[t] = 1u;
             frontier0[0] = t;
             cc->frontier[0] = 1u;
             cc->goal_status = 0;
@@ -378,15 +401,15 @@ struct alignas(16) TeamLds {
     alignas(16) uint32_t set[kTeamSetSize];
 };
 struct RingInLds {
-    TeamLds* L;
-    uint32_t ring_cap;                   // <= kTeamRingCap
+    uint32_t *ring, *set;
+    uint32_t ring_cap, set_mask;         // set_mask + 1 = a power of two >= 2 * ring_cap
     __device__ __forceinline__ uint32_t cap() const { return ring_cap; }
-    __device__ __forceinline__ uint32_t mask() const { return (uint32_t)(kTeamSetSize - 1); }
-    __device__ __forceinline__ uint32_t get(uint32_t i) const { return L->ring[i]; }
-    __device__ __forceinline__ void put(uint32_t i, uint32_t t) const { L->ring[i] = t; }
-    __device__ __forceinline__ uint32_t cas(uint32_t s, uint32_t t) const { return atomicCAS(&L->set[s], kSetEmpty, t); }
-    __device__ __forceinline__ uint32_t peek(uint32_t s) const { return __atomic_load_n(&L->set[s], __ATOMIC_RELAXED); }
-    __device__ __forceinline__ void wipe(uint32_t s) const { L->set[s] = kSetEmpty; }
+    __device__ __forceinline__ uint32_t mask() const { return set_mask; }
+    __device__ __forceinline__ uint32_t get(uint32_t i) const { return ring[i]; }
+    __device__ __forceinline__ void put(uint32_t i, uint32_t t) const { ring[i] = t; }
+    __device__ __forceinline__ uint32_t cas(uint32_t s, uint32_t t) const { return atomicCAS(&set[s], kSetEmpty, t); }
+    __device__ __forceinline__ uint32_t peek(uint32_t s) const { return __atomic_load_n(&set[s], __ATOMIC_RELAXED); }
+    __device__ __forceinline__ void wipe(uint32_t s) const { set[s] = kSetEmpty; }
     __device__ __forceinline__ void sync() const { team_sync(); }
 };
 // In global memory: every access is a device-scope atomic (served by the L2, past the CU's cache, which a wavefront's own stores do
@@ -440,18 +463,25 @@ __device__ int cost_collide_team(const CostView& V, const Robot& R, uint32_t slo
         const uint32_t items = (now_e - now_b) * 4u;
         for (uint32_t w = tl; w < items; w += (uint32_t)T) {
             const uint32_t cur = S.get(now_b + (w >> 2)), k = w & 3u;
-            uint32_t c;
-            if (V.nbr) c = V.nbr[4 * (size_t)cur + k];
-            else {
-                const int sx = V.sx[cur], sy = V.sy[cur];
-                c = k == 0u ? ctab_find(V, sx, step_skip0(sy, -1)) : k == 1u ? ctab_find(V, sx, step_skip0(sy, +1))
-                  : k == 2u ? ctab_find(V, step_skip0(sx, +1), sy) : ctab_find(V, step_skip0(sx, -1), sy);
-            }
+            uint32_t c, ncol;
+            neighbour_column(V, cur, k, c, ncol);
+            // (normal and centroid of the ring slope the gates compare with: requested with the neighbour column, not after it)
+            const float cn[3] = {V.normal[3 * cur], V.normal[3 * cur + 1], V.normal[3 * cur + 2]};
+            const float cmz = V.mean[3 * cur + 2];
             if (c == kNoColumn) continue;
-            const uint32_t e = c + V.row_ncol[c];
-            for (uint32_t t = c; t < e; ++t) {
-                if (!row_has_slope(V, t)) continue;
-                if (!V.demand_true && !cost_gates(V, R, t, V.normal + 3 * cur, V.mean + 3 * cur)) continue;
+            for (uint32_t t = c; t < c + ncol; ++t) {
+                // One gate at a time, each value asked for only by the lanes still in: requesting the row's values together (one round
+                // trip instead of three) was measured on bridge_ground — 35.7 us per layer against 28.1: most rows fail an early
+                // gate, and what bounds a layer is the number of scattered requests, not their latency.
+                const uint32_t fl = V.flags[t];
+                if (!(fl & 2u)) continue;
+                if (!V.demand_true) {
+                    // the three gates of countReachable (map2D.h:271-274)
+                    if (!(V.rough[t] <= R.rough)) continue;
+                    const float tn[3] = {V.normal[3 * t], V.normal[3 * t + 1], V.normal[3 * t + 2]};
+                    if (!(cost_angle(tn, cn) <= R.angle)) continue;
+                    if (!(fabsf(V.mean[3 * t + 2] - cmz) <= R.reach)) continue;
+                }                                        // (comand 3, the 3D ring: every slope of the cell)
                 if (__atomic_load_n(&C.flags, __ATOMIC_RELAXED) & 2u) break;        // (the set must not fill up either)
                 if (!team_set_claim(S, t)) continue;
                 const uint32_t pos = atomicAdd(&C.n, 1u);
@@ -482,12 +512,8 @@ __device__ int cost_collide_team(const CostView& V, const Robot& R, uint32_t slo
         team_sync();
         if (C.flags & 1u) res = 1;
         else {
-            // the next slope above in the same cell (map_slope is ascending in z); the same loads in every lane of the team
-            const uint32_t next = row_next_above(V, slope);
-            if (next != kNoColumn) {
-                const float nz = V.mean[3 * next + 2];
-                if ((nz < mz + 2.f * R.r) && (nz - mz > R.reach)) res = 1;
-            }
+            // the next slope above in the same cell (map_slope is ascending in z)
+            if (row_above_hits(V, R, slope)) res = 1;
         }
     }
     // leave the set empty for the team's next slope
@@ -497,75 +523,76 @@ __device__ int cost_collide_team(const CostView& V, const Robot& R, uint32_t slo
     return res;
 }
 
-// one layer of the flood: collision check, then expansion, of every slope in the layer.  T lanes share a slope: 4 (one per neighbour
+// One layer of the flood: collision check, then expansion, of every slope in the layer.  T lanes share a slope: 4 (one per neighbour
 // cell of the expansion; the collision check without a ring is one lane's), 16 (rings that fit LDS: the check is the team's, the
-// expansion its first four lanes') or 64 (rings that do not: ring and set in `scratch`, 3 * ring_cap words per wavefront, set part
-// kSetEmpty at rest).  Layers are short, so the kernel is latency-bound and the serial work per lane counts.
-template <int T>
-static __global__ void __launch_bounds__(64) k_cost_level(CostView V, Robot R, int ring_n, uint32_t level, uint32_t* __restrict__ h_bits,
-                                                   uint32_t* __restrict__ pushed, uint32_t* __restrict__ state,
-                                                   const uint32_t* __restrict__ f_in, uint32_t* __restrict__ f_out,
-                                                   uint32_t* scratch, uint32_t ring_cap, CostCounters* __restrict__ cc) {
-    constexpr uint32_t kPerWave = 64u / (uint32_t)T;   // slopes a wave takes at a time
-    __shared__ uint32_t s_one[T == 4 ? 16 : 1];        // a checker without a ring still lists the slope itself
-    __shared__ TeamLds s_team[T == 16 ? kPerWave : 1];
-    __shared__ TeamCtl s_ctl[kPerWave];
-    const uint32_t n_in = cc->frontier[level % 3u];
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        cc->frontier[(level + 2u) % 3u] = 0u;          // the counter two layers ahead (was the previous layer's input)
-        if (n_in) cc->levels = level + 1u;
-    }
-    if (blockIdx.x * kPerWave >= n_in) return;         // (also: n_in == 0)
-    uint32_t* out_count = &cc->frontier[(level + 1u) % 3u];
-    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t dir = tid % (uint32_t)T, teams = (gridDim.x * blockDim.x) / (uint32_t)T;
+// expansion its first four lanes') or 64 (rings that do not: ring and set in global scratch).  Layers are short, so the work is
+// latency-bound and the serial work per lane counts.  The body is shared by the one-layer launch (k_cost_level: every workgroup a
+// wavefront, any layer size) and the one-workgroup kernel that walks many layers per launch (k_cost_flood_wg, WG = true, T = 4: h,
+// which other wavefronts of the workgroup changed one barrier ago, is read past the CU's cache; the frontier is in LDS).
+struct LayerStats { uint32_t trav, closed, checks; };
+
+// f_in: the layer's slopes (WG: in LDS).  f_out: the next layer's, in global memory — and, WG, its first f_lds_cap entries in LDS
+// as well (f_out_lds), where the workgroup's next layer reads them.
+template <int T, bool WG, typename Store>
+__device__ __forceinline__ void cost_layer(const CostView& V, const Robot& R, int ring_n, uint32_t n_in, uint32_t first, uint32_t stride,
+                                           uint32_t* __restrict__ h_bits, uint32_t* __restrict__ state,
+                                           const uint32_t* f_in, uint32_t* __restrict__ f_out, uint32_t* f_out_lds, uint32_t f_lds_cap,
+                                           uint32_t* out_count, const Store& S, TeamCtl* C, uint32_t* one, uint32_t* overflow_count,
+                                           LayerStats& st) {
     const int lane = (int)(threadIdx.x & 63u), leader = lane & ~(T - 1);
-    if constexpr (T == 16) {
-        for (uint32_t j = threadIdx.x; j < kPerWave * (uint32_t)(kTeamSetSize / 4); j += blockDim.x)
-            reinterpret_cast<uint4*>(s_team[j / (uint32_t)(kTeamSetSize / 4)].set)[j % (uint32_t)(kTeamSetSize / 4)] =
-                make_uint4(kSetEmpty, kSetEmpty, kSetEmpty, kSetEmpty);
-        __syncthreads();
-    }
-    uint32_t trav = 0, closed = 0, checks = 0;
+    const uint32_t dir = threadIdx.x % (uint32_t)T;
     // The loop is wave-uniform (a wave's teams take consecutive slopes of the layer, lanes past the end sit idle), so that the
     // slopes a wave pushes are appended with ONE atomic on the layer's counter: the counter is one word, same-address atomics
     // retire at ~90 per microsecond at the memory side, and a layer of a few hundred slopes used to add one per pushed slope
-    // and three more per expanded slope (the statistics below) — most of a layer's 13-18 us.
-    for (uint32_t i0 = (tid >> 6) * kPerWave; i0 < n_in; i0 += teams) {
+    // and three more per expanded slope (the statistics) — most of a layer's 13-18 us.
+    for (uint32_t i0 = first; i0 < n_in; i0 += stride) {
         const uint32_t i = i0 + (uint32_t)lane / (uint32_t)T;
         const bool live = i < n_in;
         const uint32_t q = live ? f_in[i] : 0u;
+        // what the expansion needs of q itself, requested before the collision check instead of after it
+        uint32_t hq_bits = 0u, nc = kNoColumn, nc_rows = 0u, above = 0u;
+        float nq[3] = {0.f, 0.f, 0.f}, mq[3] = {0.f, 0.f, 0.f};
+        if (live && dir < 4u) {
+            hq_bits = WG ? __hip_atomic_load(&h_bits[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : h_bits[q];
+            for (int k = 0; k < 3; ++k) { nq[k] = V.normal[3 * q + k]; mq[k] = V.mean[3 * q + k]; }
+            neighbour_column(V, q, dir, nc, nc_rows);
+            if (T == 4 && V.self) above = V.self[2 * (size_t)q + 1];
+        }
         int hit = 0;
-        if constexpr (T == 16) {
-            if (live) hit = cost_collide_team<T>(V, R, q, ring_n, RingInLds{&s_team[(uint32_t)lane / (uint32_t)T], ring_cap}, s_ctl[(uint32_t)lane / (uint32_t)T], dir);
-        } else if constexpr (T == 64) {
-            uint32_t* mine = scratch + (size_t)blockIdx.x * 3u * (size_t)ring_cap;
-            if (live) hit = cost_collide_team<T>(V, R, q, ring_n, RingInGlobal{mine, mine + ring_cap, ring_cap, 2u * ring_cap - 1u}, s_ctl[0], dir);
+        if constexpr (T >= 16) {
+            if (live) hit = cost_collide_team<T>(V, R, q, ring_n, S, *C, dir);
         } else {
-            if (live && dir == 0u) hit = cost_collide(V, R, q, 0, &s_one[threadIdx.x >> 2], 1);
+            // Without a ring the list holds the slope itself, which is not above itself: the check is Slope::up (demand "true"
+            // only; "slope" leaves it false, map2D.h:636) and the slope above in the same cell, answered per row before the flood.
+            if (V.self && !V.demand_true) hit = (int)above;
+            else if (live && dir == 0u) hit = cost_collide(V, R, q, 0, one, 1);
             hit = __shfl(hit, leader, 64);
         }
         constexpr uint32_t kKeep = 4;                  // pushes a lane keeps for the wave's append (more go out one by one)
         uint32_t mine[kKeep] = {0u, 0u, 0u, 0u}, np = 0;
+        bool closed_one = false;
         if (live && dir < 4u) {
-            if (hit < 0) { if (dir == 0u) atomicAdd(&cc->ring_overflow, 1u); }
+            if (hit < 0) { if (dir == 0u) atomicAdd(overflow_count, 1u); }
             else if (hit) {
                 if (dir == 0u) {
-                    h_bits[q] = 0x7F7FFFFFu;          // Q.front()->h = FLT_MAX (map2D.h:1340)
+                    h_bits[q] = kFltMaxBits;          // Q.front()->h = FLT_MAX (map2D.h:1340)
                     state[q] = 2u;
-                    ++closed;
+                    ++st.closed;
+                    closed_one = true;
                 }
             } else {
-                if (dir == 0u) { state[q] = 1u; ++trav; }
-                const float hq = bits_float(h_bits[q]);
-                checks += cost_expand_dir(V, R, q, hq, (int)dir, [&](uint32_t t, float cand) {
+                if (dir == 0u) { state[q] = 1u; ++st.trav; }
+                st.checks += cost_expand_column(V, R, bits_float(hq_bits), nq, mq, nc, nc_rows, [&](uint32_t t, float cand) {
                     const uint32_t cb = float_bits(cand);
-                    const uint32_t old = atomicMin(&h_bits[t], cb);
-                    if (old > cb && atomicCAS(&pushed[t], 0u, 1u) == 0u) {
-                        if (np == 0u) mine[0] = t; else if (np == 1u) mine[1] = t; else if (np == 2u) mine[2] = t; else if (np == 3u) mine[3] = t;
-                        else f_out[atomicAdd(out_count, 1u)] = t;
-                        ++np;
+                    if (cb >= kFltMaxBits) return;     // (not below the FLT_MAX every h starts from: no improvement, map2D.h:1329)
+                    if (atomicMin(&h_bits[t], cb) != kUnreachedBits) return;          // (not the slope's first relaxation: it is queued already)
+                    if (np < kKeep) { if (np == 0u) mine[0] = t; else if (np == 1u) mine[1] = t; else if (np == 2u) mine[2] = t; else mine[3] = t; }
+                    else {
+                        const uint32_t pos = atomicAdd(out_count, 1u);
+                        f_out[pos] = t;
+                        if (WG && pos < f_lds_cap) f_out_lds[pos] = t;
                     }
+                    ++np;
                 });
             }
         }
@@ -577,21 +604,124 @@ static __global__ void __launch_bounds__(64) k_cost_level(CostView V, Robot R, i
             uint32_t base = 0;
             if (lane == 63) base = atomicAdd(out_count, total);
             base = (uint32_t)__shfl((int)base, 63, 64) + incl - kept;
-            if (kept > 0u) f_out[base] = mine[0];
-            if (kept > 1u) f_out[base + 1u] = mine[1];
-            if (kept > 2u) f_out[base + 2u] = mine[2];
-            if (kept > 3u) f_out[base + 3u] = mine[3];
+            for (uint32_t k = 0; k < kKeep; ++k) {
+                if (k < kept) {
+                    const uint32_t t = k == 0u ? mine[0] : k == 1u ? mine[1] : k == 2u ? mine[2] : mine[3];
+                    f_out[base + k] = t;
+                    if (WG && base + k < f_lds_cap) f_out_lds[base + k] = t;
+                }
+            }
         }
+        // WG: the FLT_MAX of a closed slope must have arrived before another wavefront's atomic min on the same word, one barrier on
+        if (WG && __any(closed_one)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-    // the layer's statistics: one atomic per wave and counter
+}
+
+// the statistics of a wave: one atomic per counter
+__device__ __forceinline__ void cost_flush_stats(LayerStats st, CostCounters* __restrict__ cc) {
     for (int o = 32; o > 0; o >>= 1) {
-        trav += (uint32_t)__shfl_down((int)trav, o, 64); closed += (uint32_t)__shfl_down((int)closed, o, 64);
-        checks += (uint32_t)__shfl_down((int)checks, o, 64);
+        st.trav += (uint32_t)__shfl_down((int)st.trav, o, 64); st.closed += (uint32_t)__shfl_down((int)st.closed, o, 64);
+        st.checks += (uint32_t)__shfl_down((int)st.checks, o, 64);
     }
-    if (lane == 0) {
-        if (trav) atomicAdd(&cc->traversable, trav);
-        if (closed) atomicAdd(&cc->closed, closed);
-        if (checks) atomicAdd(&cc->check_pushes, (unsigned long long)checks);
+    if ((threadIdx.x & 63u) == 0u) {
+        if (st.trav) atomicAdd(&cc->traversable, st.trav);
+        if (st.closed) atomicAdd(&cc->closed, st.closed);
+        if (st.checks) atomicAdd(&cc->check_pushes, (unsigned long long)st.checks);
+    }
+}
+
+// ONE layer, any size: a launch of single-wavefront workgroups.  The layer's number is `launched` — the one-layer launches enqueued
+// before this one — plus the layers the one-workgroup kernel has walked (cc->wg_layers; the host does not know how far that got).
+// T = 64: `scratch` holds 3 * ring_cap words per workgroup (ring + set, the set kSetEmpty at rest).
+template <int T>
+static __global__ void __launch_bounds__(64) k_cost_level(CostView V, Robot R, int ring_n, uint32_t* __restrict__ h_bits,
+                                                   uint32_t* __restrict__ state,
+                                                   uint32_t* __restrict__ f0, uint32_t* __restrict__ f1,
+                                                   uint32_t* scratch, uint32_t ring_cap, CostCounters* __restrict__ cc, uint32_t launched) {
+    constexpr uint32_t kPerWave = 64u / (uint32_t)T;   // slopes a wave takes at a time
+    __shared__ uint32_t s_one[T == 4 ? 16 : 1];        // a checker without a ring still lists the slope itself
+    __shared__ TeamLds s_team[T == 16 ? kPerWave : 1];
+    __shared__ TeamCtl s_ctl[kPerWave];
+    const uint32_t level = launched + cc->wg_layers;
+    const uint32_t n_in = cc->frontier[level % 3u];
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        cc->frontier[(level + 2u) % 3u] = 0u;          // the counter two layers ahead (was the previous layer's input)
+        if (n_in) cc->levels = level + 1u;
+    }
+    if (blockIdx.x * kPerWave < n_in) {                // (uniform; false for every workgroup when the flood has ended)
+        if constexpr (T == 16) {
+            for (uint32_t j = threadIdx.x; j < kPerWave * (uint32_t)(kTeamSetSize / 4); j += blockDim.x)
+                reinterpret_cast<uint4*>(s_team[j / (uint32_t)(kTeamSetSize / 4)].set)[j % (uint32_t)(kTeamSetSize / 4)] =
+                    make_uint4(kSetEmpty, kSetEmpty, kSetEmpty, kSetEmpty);
+            __syncthreads();
+        }
+        const uint32_t* f_in = (level & 1u) ? f1 : f0;
+        uint32_t* f_out = (level & 1u) ? f0 : f1;
+        uint32_t* out_count = &cc->frontier[(level + 1u) % 3u];
+        const uint32_t team = threadIdx.x / (uint32_t)T;
+        LayerStats st{0u, 0u, 0u};
+        if constexpr (T == 16) {
+            cost_layer<T, false>(V, R, ring_n, n_in, blockIdx.x * kPerWave, gridDim.x * kPerWave, h_bits, state, f_in, f_out, nullptr, 0u, out_count,
+                                 RingInLds{s_team[team].ring, s_team[team].set, ring_cap, (uint32_t)(kTeamSetSize - 1)}, &s_ctl[team], nullptr,
+                                 &cc->ring_overflow, st);
+        } else if constexpr (T == 64) {
+            uint32_t* mine = scratch + (size_t)blockIdx.x * 3u * (size_t)ring_cap;
+            cost_layer<T, false>(V, R, ring_n, n_in, blockIdx.x * kPerWave, gridDim.x * kPerWave, h_bits, state, f_in, f_out, nullptr, 0u, out_count,
+                                 RingInGlobal{mine, mine + ring_cap, ring_cap, 2u * ring_cap - 1u}, &s_ctl[0], nullptr, &cc->ring_overflow, st);
+        } else {
+            cost_layer<T, false>(V, R, 0, n_in, blockIdx.x * kPerWave, gridDim.x * kPerWave, h_bits, state, f_in, f_out, nullptr, 0u, out_count,
+                                 RingInLds{nullptr, nullptr, 0u, 0u}, nullptr, &s_one[team], &cc->ring_overflow, st);
+        }
+        cost_flush_stats(st, cc);
+    }
+}
+
+// MANY layers per launch, while they are narrow: one workgroup of 16 wavefronts walks layer after layer with ONE workgroup barrier
+// between them instead of a launch, the frontier and its counters in LDS.  It stops at a layer wider than max_frontier (<= kWgFrontier;
+// the one-layer launches that follow it on the stream take it from there: cc->wg_layers, cc->frontier, the frontier arrays in global
+// memory are kept complete), when the flood has ended, or after max_layers.  Floods without collision rings only: with rings a team of
+// 16 lanes checks a slope, a workgroup holds 64 teams, and the same kernel over them was no faster than the one-layer launches
+// (bridge_ground: 7.0 ms either way), which spread a layer's teams over the whole chip.
+// Measured (profiles/r04_cost_map.json): 6.6 us per layer on the site, 7.8 on the 8 M-point terrain; one-layer launches 8.5 / 10.5.
+constexpr int kWgThreads = 1024;
+constexpr uint32_t kWgFrontier = 4u * (uint32_t)(kWgThreads / 4);      // four rounds of the workgroup's quads
+
+static __global__ void __launch_bounds__(kWgThreads) k_cost_flood_wg(CostView V, Robot R, uint32_t* __restrict__ h_bits,
+                                                              uint32_t* __restrict__ state, uint32_t* f0, uint32_t* f1,
+                                                              CostCounters* __restrict__ cc, uint32_t max_frontier, uint32_t max_layers,
+                                                              uint32_t launched) {
+    constexpr uint32_t kTeams = (uint32_t)kWgThreads / 4u;
+    __shared__ uint32_t s_one[kTeams];
+    __shared__ uint32_t s_count[3];
+    __shared__ uint32_t s_f[2][kWgFrontier];
+    uint32_t level = launched + cc->wg_layers;
+    uint32_t n_in = cc->frontier[level % 3u];
+    max_frontier = min(max_frontier, kWgFrontier);
+    if (n_in == 0u || n_in > max_frontier) return;     // (uniform) nothing for this kernel to do: cc stays as it is
+    {
+        const uint32_t* f_first = (level & 1u) ? f1 : f0;
+        for (uint32_t j = threadIdx.x; j < n_in; j += blockDim.x) s_f[level & 1u][j] = f_first[j];
+        if (threadIdx.x < 3u) s_count[threadIdx.x] = 0u;
+    }
+    __syncthreads();
+    LayerStats st{0u, 0u, 0u};
+    uint32_t done = 0;
+    for (; done < max_layers && n_in != 0u && n_in <= max_frontier; ++done) {
+        if (threadIdx.x == 0) s_count[(level + 2u) % 3u] = 0u;        // (the layer after next's; nobody looks at it during this layer)
+        cost_layer<4, true>(V, R, 0, n_in, (threadIdx.x >> 6) * 16u, kTeams, h_bits, state, s_f[level & 1u], (level & 1u) ? f0 : f1,
+                            s_f[(level + 1u) & 1u], kWgFrontier, &s_count[(level + 1u) % 3u], RingInLds{nullptr, nullptr, 0u, 0u}, nullptr,
+                            &s_one[threadIdx.x >> 2], &cc->ring_overflow, st);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // (LDS only: the frontier's global copy is for later kernels)
+        ++level;
+        n_in = s_count[level % 3u];
+    }
+    cost_flush_stats(st, cc);
+    if (threadIdx.x == 0) {
+        cc->wg_layers = level - launched;
+        cc->frontier[level % 3u] = n_in;
+        cc->frontier[(level + 1u) % 3u] = 0u;
+        cc->frontier[(level + 2u) % 3u] = 0u;
+        if (done) cc->levels = level;                  // (every layer walked here held at least one slope)
     }
 }
 #endif  // __HIPCC__

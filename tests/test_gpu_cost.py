@@ -167,3 +167,16 @@ def test_cost_map_with_rings_of_thousands_of_slopes_in_3d():
         _check(m, cloud, P, goal, "true", {"radius": 0.25})
     # (the first goal has a node right above it and collides before any ring is listed; the topmost slope lists 13 columns of ~110)
     assert st["ring_store"] == 2
+
+
+@pytest.mark.parametrize("demand", ["slope", "true"])
+def test_cost_map_by_one_layer_launches_only(demand, monkeypatch):
+    """GNDT_COST_WG=0: no one-workgroup kernel walking the narrow layers, every layer its own launch (what wide layers get anyway).
+    Same flood."""
+    cloud = scenes.drivable_site()
+    P = scenes.COST_PARAMS
+    m = _build(cloud, P, demand, 0)
+    monkeypatch.setenv("GNDT_COST_WG", "0")
+    for radius in (0.25, 0.6):
+        st, _ = _check(m, cloud, P, scenes.DRIVABLE_GOAL, demand, {"radius": radius})
+        assert st["traversable"] > 8000 and st["levels"] > 50
