@@ -8,7 +8,7 @@ namespace gndt_host {
 
 void free_cost(gndt_handle* h) {
     auto& c = h->cost;
-    void* ptrs[] = {c.h_bits, c.state, c.f[0], c.f[1], c.ctab_key, c.ctab_val, c.ring, c.nbr, c.d_cc};
+    void* ptrs[] = {c.h_bits, c.state, c.f[0], c.f[1], c.ctab_key, c.ctab_val, c.nbr, c.d_cc};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (c.h_cc) (void)hipHostFree(c.h_cc);
@@ -26,7 +26,6 @@ static int env_int(const char* name, int otherwise) {
 extern "C" {
 
 constexpr int kCostBlocks = 128, kCostThreads = 64, kCostBatch = 32;
-constexpr int kCostWaves = 512;      // wavefronts of a layer launch whose slopes are checked by a whole wavefront each (rings in global scratch)
 
 int gndt_compute_cost(gndt_handle* h, const float goal_xyz[3], const gndt_robot* robot, void* hip_stream) {
     int rc = check_ready(h);
@@ -44,16 +43,14 @@ int gndt_compute_cost(gndt_handle* h, const float goal_xyz[3], const gndt_robot*
         HIP_TRY(h, hipMalloc(&c.d_cc, sizeof(CostCounters)));
         HIP_TRY(h, hipHostMalloc(&c.h_cc, sizeof(CostCounters)));
     }
-    // rings of up to lds_cap slopes stay in LDS; larger ones go to global scratch, ring_cap slopes per checker at first
-    // (GNDT_COST_RING_LDS / GNDT_COST_RING_FIRST: smaller numbers for the tests of exactly these steps)
-    const int lds_cap = std::max(1, std::min(kTeamRingCap, env_int("GNDT_COST_RING_LDS", kTeamRingCap)));
-    if (c.ring_cap == 0) c.ring_cap = (int)pow2_ceil((uint64_t)std::max(16, std::min(kRingCapMax, env_int("GNDT_COST_RING_FIRST", 8 * kTeamRingCap))));
     if (n > c.node_cap) {
         for (uint32_t** a : {&c.h_bits, &c.state, &c.f[0], &c.f[1], &c.nbr}) { if (*a) (void)hipFree(*a); *a = nullptr; }
         c.node_cap = 0;
         const uint64_t cap = std::max<uint64_t>(1024, n + n / 8);
         for (uint32_t** a : {&c.h_bits, &c.state, &c.f[0], &c.f[1]}) HIP_TRY(h, hipMalloc(a, cap * 4));
-        HIP_TRY(h, hipMalloc(&c.nbr, cap * 40));      // (4 neighbour columns with their sizes + own column + verdict on the slope above, per row)
+        // per row: 4 neighbour columns with their sizes (32 B), own column + collision verdict (8), the ring's step masks (16) and
+        // two pairs of extremes for its rounds (16)
+        HIP_TRY(h, hipMalloc(&c.nbr, cap * 72));
         c.node_cap = cap;
     }
     const uint32_t tsize = pow2_ceil(std::max<uint64_t>(1024, 2 * K));
@@ -73,62 +70,47 @@ int gndt_compute_cost(gndt_handle* h, const float goal_xyz[3], const gndt_robot*
     V.mean = h->out.mean; V.normal = h->out.normal; V.rough = h->out.rough; V.flags = h->out.flags;
     V.row_ncol = h->part.row_ncol;
     V.ctab_key = c.ctab_key; V.ctab_val = c.ctab_val; V.ctab_mask = c.ctab_size - 1;
-    V.nbr = nullptr;
+    V.nbr = nullptr; V.self = nullptr;
     V.slope_interval = h->P.slope_interval; V.demand_true = h->P.demand == GNDT_DEMAND_TRUE ? 1 : 0;
     // the goal's key through the same codec the build uses (transMortonXYZ, map2D.h:1293)
     const PointKey gk = point_key(goal_xyz[0], goal_xyz[1], goal_xyz[2], h->origin[0], h->origin[1], h->origin[2],
                                   h->P.grid_len, h->P.z_len);
-  for (;;) {                  // (again with a larger ring scratch if a collision ring did not fit)
-    V.nbr = nullptr; V.self = nullptr;
     hipLaunchKernelGGL(k_cost_clear, dim3(grid_for(std::max<uint64_t>(n, c.ctab_size))), dim3(256), 0, s, c.h_bits,
                        c.state, (uint32_t)n, c.ctab_key, c.ctab_size, c.d_cc);
-    if (K)
+    if (K) {
         hipLaunchKernelGGL(k_cost_columns, dim3(grid_for(n)), dim3(256), 0, s, h->out.sx, h->out.sy, h->part.row_ncol,
                            (uint32_t)n, c.ctab_key, c.ctab_val, c.ctab_size - 1, c.d_cc);
-    if (K) {
-        hipLaunchKernelGGL(k_cost_neighbours, dim3(grid_for(4 * n)), dim3(256), 0, s, V, R, (uint32_t)n, c.nbr, c.nbr + 8 * c.node_cap);   // (probes: V.nbr, V.self are null)
+        // the per-flood tables (gndt_cost.hpp): neighbour columns, own column, and CollisionCheck's verdict for every slope — with a
+        // robot wider than a cell after ring_n rounds of "the extreme over my steps" over the whole map instead of a ring per slope
+        uint32_t* self = c.nbr + 8 * c.node_cap;
+        uint32_t* step = c.nbr + 10 * c.node_cap;
+        float* ext = reinterpret_cast<float*>(c.nbr + 14 * c.node_cap);            // hi[2], lo[2]: node_cap floats each
+        float* hi[2] = {ext, ext + c.node_cap};
+        float* lo[2] = {ext + 2 * c.node_cap, ext + 3 * c.node_cap};
+        hipLaunchKernelGGL(k_cost_neighbours, dim3(grid_for(4 * n)), dim3(256), 0, s, V, R, (uint32_t)n, c.ring_n, c.nbr, self, step, hi[0], lo[0]);   // (probes: V.nbr, V.self are null)
         V.nbr = c.nbr;
-        V.self = c.nbr + 8 * c.node_cap;
+        V.self = self;
+        for (int d = 0; d < c.ring_n; ++d)
+            hipLaunchKernelGGL(k_cost_ring_round, dim3(grid_for(4 * n)), dim3(256), 0, s, V, R, (uint32_t)n, step, hi[d & 1], hi[(d + 1) & 1],
+                               lo[d & 1], lo[(d + 1) & 1], self, d == c.ring_n - 1 ? 1 : 0);
     }
+    c.ring_store = c.ring_n > 0 ? 1 : 0;
     if (gk.ok && K)
         hipLaunchKernelGGL(k_cost_goal, dim3(1), dim3(64), 0, s, V, gk.sx, gk.sy, gk.sz, c.h_bits, c.f[0], c.d_cc);
     HIP_TRY(h, hipGetLastError());
-    // Who checks a slope for collisions (gndt_cost.hpp): without a ring one lane; with a ring a team of 16 and the ring in LDS, or —
-    // once a ring of that depth has not fitted on this handle — a whole wavefront per slope with ring and set in global scratch,
-    // which is only allocated then.  GNDT_COST_RING_IN_LDS=0 sends every ring the second way (tests).
-    const bool lds_off = env_int("GNDT_COST_RING_IN_LDS", 1) == 0;
-    const int mode = c.ring_n == 0 ? 0 : (c.ring_n < c.team_ring_limit && !lds_off) ? 1 : 2;
-    c.ring_store = mode;
-    if (mode == 2 && c.ring_alloc < c.ring_cap) {
-        if (c.ring) (void)hipFree(c.ring);
-        c.ring = nullptr; c.ring_alloc = 0;
-        const size_t words = (size_t)kCostWaves * 3u * (size_t)c.ring_cap;                       // (ring + a set twice as large, per wavefront)
-        HIP_TRY(h, hipMalloc(&c.ring, words * sizeof(uint32_t)));
-        HIP_TRY(h, hipMemsetAsync(c.ring, 0xFF, words * sizeof(uint32_t), s));                   // (sets are empty at rest)
-        c.ring_alloc = c.ring_cap;
-    }
-    // A batch on the stream: without collision rings the one-workgroup kernel (as many narrow layers as it meets, gndt_cost.hpp), then
-    // one-layer launches (any width; no-ops once the flood has ended) — 8 while the layers are narrow, 32 when the last answer showed a
-    // wide one.  How many layers the one-workgroup kernel walked is only known on the device (cc->wg_layers); the host asks after
-    // every batch whether the flood has ended.  GNDT_COST_WG=0: one-layer launches only.
-    const bool wg = mode == 0 && env_int("GNDT_COST_WG", 1) != 0;
+    // A batch on the stream: the one-workgroup kernel (as many narrow layers as it meets, gndt_cost.hpp), then one-layer launches
+    // (any width; no-ops once the flood has ended) — 8 while the layers are narrow, 32 when the last answer showed a wide one.  How
+    // many layers the one-workgroup kernel walked is only known on the device (cc->wg_layers); the host asks after every batch
+    // whether the flood has ended.  GNDT_COST_WG=0: one-layer launches only.
+    const bool wg = env_int("GNDT_COST_WG", 1) != 0;
     bool narrow = true;
     uint32_t launched = 0;                                   // one-layer launches enqueued so far
     for (;;) {
         if (wg)
             hipLaunchKernelGGL(k_cost_flood_wg, dim3(1), dim3(kWgThreads), 0, s, V, R, c.h_bits, c.state, c.f[0], c.f[1], c.d_cc, kWgFrontier, 1u << 20,
                                launched);
-        for (int b = 0, nb = wg && narrow ? 8 : kCostBatch; b < nb; ++b, ++launched) {
-            if (mode == 1)
-                hipLaunchKernelGGL(k_cost_level<16>, dim3(kCostBlocks * 4), dim3(kCostThreads), 0, s, V, R, c.ring_n, c.h_bits,
-                                   c.state, c.f[0], c.f[1], (uint32_t*)nullptr, (uint32_t)lds_cap, c.d_cc, launched);
-            else if (mode == 2)
-                hipLaunchKernelGGL(k_cost_level<64>, dim3(kCostWaves), dim3(kCostThreads), 0, s, V, R, c.ring_n, c.h_bits,
-                                   c.state, c.f[0], c.f[1], c.ring, (uint32_t)c.ring_cap, c.d_cc, launched);
-            else
-                hipLaunchKernelGGL(k_cost_level<4>, dim3(kCostBlocks), dim3(kCostThreads), 0, s, V, R, 0, c.h_bits,
-                                   c.state, c.f[0], c.f[1], (uint32_t*)nullptr, 1u, c.d_cc, launched);
-        }
+        for (int b = 0, nb = wg && narrow ? 8 : kCostBatch; b < nb; ++b, ++launched)
+            hipLaunchKernelGGL(k_cost_level, dim3(kCostBlocks), dim3(kCostThreads), 0, s, V, R, c.h_bits, c.state, c.f[0], c.f[1], c.d_cc, launched);
         HIP_TRY(h, hipGetLastError());
         HIP_TRY(h, hipMemcpyAsync(c.h_cc, c.d_cc, sizeof(CostCounters), hipMemcpyDeviceToHost, s));
         HIP_TRY(h, hipStreamSynchronize(s));
@@ -142,19 +124,6 @@ int gndt_compute_cost(gndt_handle* h, const float goal_xyz[3], const gndt_robot*
         h->err = "cost map: column indices beyond 32767 (mortonToXY decodes no further, Stopwatch.h:171-189)";
         return GNDT_ERR_KEY_RANGE;
     }
-    if (c.h_cc->ring_overflow) {
-        // CollisionCheck's ring is a std::list in the reference (map2D.h:351-411): any size.  Here it is storage of a fixed size per
-        // checker, made four times larger and the flood run again when a ring did not fit.
-        if (mode == 1) { c.team_ring_limit = c.ring_n; continue; }     // (this handle's maps hold rings of this depth that do not fit LDS)
-        if (c.ring_cap >= kRingCapMax) {
-            h->err = "cost map: a collision ring holds more than " + std::to_string(kRingCapMax) + " slopes (robot radius too large for this grid)";
-            return GNDT_ERR_CAPACITY;
-        }
-        c.ring_cap = std::min(c.ring_cap * 4, kRingCapMax);
-        continue;
-    }
-    break;
-  }
     if (n) {        // what no relaxation reached keeps the FLT_MAX it was created with (gndt_cost.hpp: kUnreachedBits)
         hipLaunchKernelGGL(k_cost_finish, dim3(grid_for(n)), dim3(256), 0, s, c.h_bits, (uint32_t)n);
         HIP_TRY(h, hipGetLastError());

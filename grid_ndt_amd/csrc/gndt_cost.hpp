@@ -41,9 +41,7 @@ struct Robot {   // include/robot.h:12, 38-46
 
 constexpr int kCostMaxXY = 32767;        // mortonToXY decodes only up to here (Stopwatch.h:171-189)
 constexpr uint32_t kNoColumn = 0xFFFFFFFFu;
-constexpr int kRingCap = 256;            // slopes a serial checker's ring holds in the host shim (tests/host_math_shim.cpp)
-constexpr int kRingCapMax = 1 << 17;     // the device grows a checker's scratch fourfold when a ring does not fit (a 1.3 m robot on
-                                         //   0.1 m cells: 27 x 27 columns, every level of them with demand "true") up to this
+constexpr int kRingCap = 256;            // slopes the ring of the serial walk holds in the host shim (tests/host_math_shim.cpp)
 
 struct CostView {
     // result rows in reference order (gndt_cells)
@@ -272,6 +270,73 @@ GNDT_HD uint32_t cost_expand(const CostView& V, const Robot& R, uint32_t q, floa
     return checks;
 }
 
+// ---------------------------------------------------------------------------------------------
+// CollisionCheck without walking rings (round 4).  The ring of a slope q (map2D.h:351-411 / 414-474) is the set R_n(q) of slopes
+// within n steps of q, a step going from a slope to a slope of one of its four neighbour cells that passes the gates seen from it
+// (comand 2.5) or to any slope there (comand 3), and the verdict asks whether SOME member lies more than the robot's reach above q
+// — or, comand 3, has `up` set and lies below q.  Both are questions about an extreme over the set, and the set is a union:
+//     R_n(q) = {q}  +  the R_(n-1)(p) of q's steps p          =>          max z over R_n(q) = max(z(q), max over p of [max z over R_(n-1)(p)])
+// so n rounds of "take the extreme over your steps" over ALL slopes of the map at once — the steps of a slope a bit mask per
+// neighbour cell, computed once — give every slope's answer, exactly (the verdict's fp32 subtraction is monotone in the member's z,
+// so the highest member decides).  The flood then reads one word per slope.  A ring is never listed: no capacity, no retry, and
+// the cost does not grow with the ring's size (27 x 27 cells of a 1.3 m robot on 0.1 m cells: 13 rounds).
+// The walk itself is kept above (cost_collide) as the statement of what is computed; the CPU tier checks these rounds against it
+// for every slope of random maps (tests/test_cost_map.py), and runs it against the oracle.
+// ---------------------------------------------------------------------------------------------
+constexpr uint32_t kStepRows = 32;       // rows of a neighbour cell that fit its step mask; taller cells: the gates again in every round
+
+// may the ring step from slope `row` to row t of a neighbour cell?
+GNDT_HD bool ring_step_ok(const CostView& V, const Robot& R, uint32_t row, uint32_t t) {
+    if (!(V.flags[t] & 2u)) return false;
+    if (V.demand_true) return true;                    // comand 3 (3D ring): every slope of the cell
+    return cost_gates(V, R, t, V.normal + 3 * row, V.mean + 3 * row);
+}
+
+// the steps of slope `row` into its k-th neighbour cell (first row c, ncol rows): bit j = row c + j, for the first kStepRows rows
+GNDT_HD uint32_t ring_step_mask(const CostView& V, const Robot& R, uint32_t row, uint32_t c, uint32_t ncol) {
+    uint32_t m = 0u;
+    if (c == kNoColumn) return m;
+    for (uint32_t j = 0; j < ncol && j < kStepRows; ++j) m |= ring_step_ok(V, R, row, c + j) ? 1u << j : 0u;
+    return m;
+}
+
+// round 0 of a slope's extremes: the slope itself.  hi: the highest centroid in the ring; lo: the lowest of the members whose `up`
+// is set (comand 3 consults it: map2D.h:447), FLT_MAX while there is none
+GNDT_HD void ring_round0(const CostView& V, uint32_t row, bool up, float& hi, float& lo) {
+    hi = V.mean[3 * row + 2];
+    lo = up ? V.mean[3 * row + 2] : FLT_MAX;
+}
+
+// one round, one neighbour cell: the extremes over the steps of `row` into it
+GNDT_HD void ring_round_cell(const CostView& V, const Robot& R, uint32_t row, uint32_t c, uint32_t ncol, uint32_t mask,
+                             const float* hi_in, const float* lo_in, float& hi, float& lo) {
+    if (c == kNoColumn) return;
+    while (mask) {
+        uint32_t j = 0;
+        while (!((mask >> j) & 1u)) ++j;
+        mask &= mask - 1u;
+        hi = fmaxf(hi, hi_in[c + j]);
+        if (V.demand_true) lo = fminf(lo, lo_in[c + j]);
+    }
+    for (uint32_t j = kStepRows; j < ncol; ++j) {      // (a cell of more than kStepRows nodes)
+        if (!ring_step_ok(V, R, row, c + j)) continue;
+        hi = fmaxf(hi, hi_in[c + j]);
+        if (V.demand_true) lo = fminf(lo, lo_in[c + j]);
+    }
+}
+
+// map2D.h:384-392 / 447-455 over the whole ring at once: a member with `up` below the slope (comand 3; lo is FLT_MAX otherwise), or a
+// member more than the reach above it (`(a < b) + 2 r` only asks for a non-zero number, and r > 0 where there is a ring)
+GNDT_HD bool ring_verdict(const CostView& V, const Robot& R, uint32_t row, float hi, float lo) {
+    GNDT_FP_STRICT
+    const float mz = V.mean[3 * row + 2];
+    return (V.demand_true && lo < mz) || (hi > mz && (hi - mz > R.reach));
+}
+
+// what of CollisionCheck does not need the ring: Slope::up of the slope itself (comand 3, map2D.h:417) and the next slope above it
+// in its cell (:394-410)
+GNDT_HD bool ring_free_verdict(const CostView& V, const Robot& R, uint32_t row, bool up) { return up || row_above_hits(V, R, row); }
+
 #if defined(__HIPCC__)
 // ---------------------------------------------------------------------------------------------
 // kernels
@@ -279,7 +344,7 @@ GNDT_HD uint32_t cost_expand(const CostView& V, const Robot& R, uint32_t q, floa
 struct CostCounters {
     uint32_t frontier[3];     // sizes of the frontier of level L (index L % 3)
     uint32_t traversable, closed;
-    uint32_t ring_overflow, range_error;
+    uint32_t pad0, range_error;
     int32_t goal_status;      // 0 flood started, 1 no cell at the goal, 2 no slope at the goal's level
     uint32_t levels;          // layers that held at least one slope
     uint32_t pad;
@@ -302,7 +367,7 @@ static __global__ void __launch_bounds__(256) k_cost_clear(uint32_t* __restrict_
     for (uint32_t i = gid; i < ctab_size; i += gsz) ctab_key[i] = kEmptyKey;
     if (gid == 0) {
         cc->frontier[0] = cc->frontier[1] = cc->frontier[2] = 0u;
-        cc->traversable = cc->closed = cc->ring_overflow = cc->range_error = 0u;
+        cc->traversable = cc->closed = cc->pad0 = cc->range_error = 0u;
         cc->goal_status = 1; cc->levels = 0u; cc->check_pushes = 0ull;
         cc->wg_layers = 0u;
     }
@@ -333,18 +398,60 @@ static __global__ void __launch_bounds__(256) k_cost_columns(const int32_t* __re
     }
 }
 
-// the four neighbour columns of every row (first row, node count), its own column and the verdict on the slope above it, once per
-// flood (the layers then follow plain indices)
-static __global__ void __launch_bounds__(256) k_cost_neighbours(CostView V, Robot R, uint32_t num_rows, uint32_t* __restrict__ nbr, uint32_t* __restrict__ self) {
+// ---------------------------------------------------------------------------------------------
+// Per-flood tables: a row's neighbour columns, its own column, and the collision verdict of every slope ("CollisionCheck without
+// walking rings" above).
+// ---------------------------------------------------------------------------------------------
+// nbr / self for every row; and, for floods with rings, the step masks of every slope and round 0 of the extremes
+static __global__ void __launch_bounds__(256) k_cost_neighbours(CostView V, Robot R, uint32_t num_rows, int ring_n, uint32_t* __restrict__ nbr,
+                                                         uint32_t* __restrict__ self, uint32_t* __restrict__ step, float* __restrict__ hi0,
+                                                         float* __restrict__ lo0) {
     for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < 4u * num_rows; t += gridDim.x * blockDim.x) {
         const uint32_t row = t >> 2, k = t & 3u;
         uint32_t c, ncol;
         neighbour_column(V, row, k, c, ncol);            // (V.nbr, V.self are null here: everything goes through the hash table)
         nbr[2 * (size_t)t] = c;
         nbr[2 * (size_t)t + 1] = ncol;
+        const bool slope = row_has_slope(V, row);
+        if (ring_n > 0) step[t] = slope ? ring_step_mask(V, R, row, c, ncol) : 0u;
         if (k == 0u) {
             self[2 * (size_t)row] = ctab_find(V, V.sx[row], V.sy[row]);
-            self[2 * (size_t)row + 1] = row_above_hits(V, R, row) ? 1u : 0u;
+            const bool up = slope && row_up(V, row);
+            self[2 * (size_t)row + 1] = slope && ring_free_verdict(V, R, row, up) ? 1u : 0u;
+            if (ring_n > 0 && slope) {
+                float hi, lo;
+                ring_round0(V, row, up, hi, lo);
+                hi0[row] = hi;
+                if (V.demand_true) lo0[row] = lo;
+            }
+        }
+    }
+}
+
+// one round for every slope, four lanes per slope (one per neighbour cell); the last round adds the verdict to self[2 q + 1]
+static __global__ void __launch_bounds__(256) k_cost_ring_round(CostView V, Robot R, uint32_t num_rows, const uint32_t* __restrict__ step,
+                                                         const float* __restrict__ hi_in, float* __restrict__ hi_out,
+                                                         const float* __restrict__ lo_in, float* __restrict__ lo_out,
+                                                         uint32_t* __restrict__ self, int last) {
+    for (uint32_t t0 = blockIdx.x * blockDim.x; t0 < 4u * num_rows; t0 += gridDim.x * blockDim.x) {     // (uniform: the quad exchanges below)
+        const uint32_t t = t0 + threadIdx.x;
+        const bool live = t < 4u * num_rows;
+        const uint32_t row = live ? t >> 2 : 0u, k = t & 3u;
+        const bool slope = live && row_has_slope(V, row);
+        float hi = -FLT_MAX, lo = FLT_MAX;
+        if (slope) {
+            uint32_t c, ncol;
+            neighbour_column(V, row, k, c, ncol);
+            ring_round_cell(V, R, row, c, ncol, step[t], hi_in, lo_in, hi, lo);
+        }
+        hi = fmaxf(hi, __shfl_xor(hi, 1, 64)); hi = fmaxf(hi, __shfl_xor(hi, 2, 64));
+        lo = fminf(lo, __shfl_xor(lo, 1, 64)); lo = fminf(lo, __shfl_xor(lo, 2, 64));
+        if (slope && k == 0u) {
+            hi = fmaxf(hi, hi_in[row]);                // (R_d(q) holds R_(d-1)(q): q itself and everything found so far)
+            if (V.demand_true) lo = fminf(lo, lo_in[row]);
+            hi_out[row] = hi;
+            if (V.demand_true) lo_out[row] = lo;
+            if (last && ring_verdict(V, R, row, hi, lo)) self[2 * (size_t)row + 1] = 1u;
         }
     }
 }
@@ -368,212 +475,44 @@ static __global__ void k_cost_goal(CostView V, int gx, int gy, int gz, uint32_t*
     }
 }
 
-// ---------------------------------------------------------------------------------------------
-// CollisionCheck by a TEAM of lanes (round 4).  The ring of a slope is a SET: layer d + 1 = the slopes, not seen before, that pass
-// the gates from SOME slope of layer d, and the verdict asks whether ANY member is too high (map2D.h:384-392) — nothing depends on
-// the order the reference's list happens to hold them in.  So the (slope of the layer, neighbour cell) pairs of a ring layer are
-// spread over the team's lanes, a member is claimed with one compare-and-swap in a hash set in LDS (which is also the "seen" test the
-// serial walk spends a scan of the whole ring on), and the list itself is only appended to.  A serial checker's time is a chain of
-// ~5 dependent memory round trips per neighbour cell, 20 cells for a ring of depth 2; the team pays the chain once per ring layer.
-// (bridge_ground at its own parameters, 182 layers: 28.5 ms of flood with one lane per checker — 2.5 x the reference's own loop on
-// one CPU core.)  All lanes of a team are lanes of ONE wavefront: they run in lockstep, and LDS serves a wavefront's requests in
-// order, so what a lane wrote before team_sync() is what every lane reads after it.
-// ---------------------------------------------------------------------------------------------
-constexpr int kTeamRingCap = 1024;       // slopes a team's ring holds in LDS; a ring that does not fit is a whole wavefront's, in global scratch
-constexpr int kTeamSetSize = 2048;       // (power of two, 2 x the ring)
-constexpr uint32_t kSetEmpty = 0xFFFFFFFFu;
-
-struct TeamCtl {
-    uint32_t n;                          // ring members
-    uint32_t flags;                      // 1 = collide, 2 = the ring does not fit
-};
-
-__device__ __forceinline__ void team_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-// Where a team keeps its ring (the list) and its set (open addressing over row numbers, kSetEmpty at rest: every check removes what
-// it added).  In LDS: plain accesses, in order for the wavefront.
-struct alignas(16) TeamLds {
-    uint32_t ring[kTeamRingCap];
-    alignas(16) uint32_t set[kTeamSetSize];
-};
-struct RingInLds {
-    uint32_t *ring, *set;
-    uint32_t ring_cap, set_mask;         // set_mask + 1 = a power of two >= 2 * ring_cap
-    __device__ __forceinline__ uint32_t cap() const { return ring_cap; }
-    __device__ __forceinline__ uint32_t mask() const { return set_mask; }
-    __device__ __forceinline__ uint32_t get(uint32_t i) const { return ring[i]; }
-    __device__ __forceinline__ void put(uint32_t i, uint32_t t) const { ring[i] = t; }
-    __device__ __forceinline__ uint32_t cas(uint32_t s, uint32_t t) const { return atomicCAS(&set[s], kSetEmpty, t); }
-    __device__ __forceinline__ uint32_t peek(uint32_t s) const { return __atomic_load_n(&set[s], __ATOMIC_RELAXED); }
-    __device__ __forceinline__ void wipe(uint32_t s) const { set[s] = kSetEmpty; }
-    __device__ __forceinline__ void sync() const { team_sync(); }
-};
-// In global memory: every access is a device-scope atomic (served by the L2, past the CU's cache, which a wavefront's own stores do
-// not update), and a sync waits for the wavefront's stores to have arrived there before the lanes go on.
-struct RingInGlobal {
-    uint32_t *ring, *set;
-    uint32_t ring_cap, set_mask;
-    __device__ __forceinline__ uint32_t cap() const { return ring_cap; }
-    __device__ __forceinline__ uint32_t mask() const { return set_mask; }
-    __device__ __forceinline__ uint32_t get(uint32_t i) const { return __hip_atomic_load(&ring[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-    __device__ __forceinline__ void put(uint32_t i, uint32_t t) const { __hip_atomic_store(&ring[i], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-    __device__ __forceinline__ uint32_t cas(uint32_t s, uint32_t t) const { return atomicCAS(&set[s], kSetEmpty, t); }
-    __device__ __forceinline__ uint32_t peek(uint32_t s) const { return __hip_atomic_load(&set[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-    __device__ __forceinline__ void wipe(uint32_t s) const { __hip_atomic_store(&set[s], kSetEmpty, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-    __device__ __forceinline__ void sync() const { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); team_sync(); }
-};
-
-__device__ __forceinline__ uint32_t team_set_home(uint32_t t, uint32_t mask) { return ((t * 0x9E3779B1u) >> 11) & mask; }
-
-// true: t was not a member and is one now
-template <typename Store>
-__device__ __forceinline__ bool team_set_claim(const Store& S, uint32_t t) {
-    uint32_t s = team_set_home(t, S.mask());
-    for (;;) {
-        const uint32_t old = S.cas(s, t);
-        if (old == kSetEmpty) return true;
-        if (old == t) return false;
-        s = (s + 1u) & S.mask();
-    }
-}
-
-// (every member is removed by exactly one lane, so a walk only ever passes slots that hold, or held, OTHER members)
-template <typename Store>
-__device__ __forceinline__ void team_set_release(const Store& S, uint32_t t) {
-    uint32_t s = team_set_home(t, S.mask());
-    while (S.peek(s) != t) s = (s + 1u) & S.mask();
-    S.wipe(s);
-}
-
-// Same verdict as cost_collide(): 1 collide, 0 free, -1 the ring holds more than S.cap() slopes.  Called by all T lanes of a team
-// (tl = 0 .. T-1) with the same arguments; returns the same value in all of them.  C is the team's control block in LDS.
-template <int T, typename Store>
-__device__ int cost_collide_team(const CostView& V, const Robot& R, uint32_t slope, int ring_n, const Store& S, TeamCtl& C, uint32_t tl) {
-    GNDT_FP_STRICT
-    if (row_up(V, slope)) return 1;
-    const float mz = V.mean[3 * slope + 2];
-    if (tl == 0u) { S.put(0u, slope); C.n = 1u; C.flags = 0u; (void)team_set_claim(S, slope); }
-    S.sync();
-    uint32_t now_b = 0u, now_e = 1u;
-    for (int depth = 0; depth < ring_n; ++depth) {
-        const uint32_t items = (now_e - now_b) * 4u;
-        for (uint32_t w = tl; w < items; w += (uint32_t)T) {
-            const uint32_t cur = S.get(now_b + (w >> 2)), k = w & 3u;
-            uint32_t c, ncol;
-            neighbour_column(V, cur, k, c, ncol);
-            // (normal and centroid of the ring slope the gates compare with: requested with the neighbour column, not after it)
-            const float cn[3] = {V.normal[3 * cur], V.normal[3 * cur + 1], V.normal[3 * cur + 2]};
-            const float cmz = V.mean[3 * cur + 2];
-            if (c == kNoColumn) continue;
-            for (uint32_t t = c; t < c + ncol; ++t) {
-                // One gate at a time, each value asked for only by the lanes still in: requesting the row's values together (one round
-                // trip instead of three) was measured on bridge_ground — 35.7 us per layer against 28.1: most rows fail an early
-                // gate, and what bounds a layer is the number of scattered requests, not their latency.
-                const uint32_t fl = V.flags[t];
-                if (!(fl & 2u)) continue;
-                if (!V.demand_true) {
-                    // the three gates of countReachable (map2D.h:271-274)
-                    if (!(V.rough[t] <= R.rough)) continue;
-                    const float tn[3] = {V.normal[3 * t], V.normal[3 * t + 1], V.normal[3 * t + 2]};
-                    if (!(cost_angle(tn, cn) <= R.angle)) continue;
-                    if (!(fabsf(V.mean[3 * t + 2] - cmz) <= R.reach)) continue;
-                }                                        // (comand 3, the 3D ring: every slope of the cell)
-                if (__atomic_load_n(&C.flags, __ATOMIC_RELAXED) & 2u) break;        // (the set must not fill up either)
-                if (!team_set_claim(S, t)) continue;
-                const uint32_t pos = atomicAdd(&C.n, 1u);
-                if (pos < S.cap()) S.put(pos, t);
-                else atomicOr(&C.flags, 2u);
-            }
-        }
-        S.sync();
-        if (C.flags & 2u) break;
-        now_b = now_e;
-        now_e = C.n;
-        if (now_b == now_e) break;                     // an empty ring layer: the deeper ones are empty, too
-    }
-    int res = 0;
-    const bool overflow = (C.flags & 2u) != 0u;
-    const uint32_t n_all = overflow ? 0u : C.n;
-    if (overflow) res = -1;
-    else {
-        for (uint32_t j = tl; j < n_all; j += (uint32_t)T) {
-            const uint32_t m = S.get(j);
-            const float tz = V.mean[3 * m + 2];
-            bool hit = tz < mz && row_up(V, m);
-            // map2D.h:388 / :451: `((a < b) + 2*r)` only asks for a non-zero number
-            const float odd = (float)(tz < mz ? 1 : 0) + 2.f * R.r;
-            hit = hit || (tz > mz && odd != 0.f && (tz - mz > R.reach));
-            if (hit) atomicOr(&C.flags, 1u);
-        }
-        team_sync();
-        if (C.flags & 1u) res = 1;
-        else {
-            // the next slope above in the same cell (map_slope is ascending in z)
-            if (row_above_hits(V, R, slope)) res = 1;
-        }
-    }
-    // leave the set empty for the team's next slope
-    if (overflow) { for (uint32_t j = tl; j <= S.mask(); j += (uint32_t)T) S.wipe(j); }
-    else          { for (uint32_t j = tl; j < n_all; j += (uint32_t)T) team_set_release(S, S.get(j)); }
-    S.sync();
-    return res;
-}
-
-// One layer of the flood: collision check, then expansion, of every slope in the layer.  T lanes share a slope: 4 (one per neighbour
-// cell of the expansion; the collision check without a ring is one lane's), 16 (rings that fit LDS: the check is the team's, the
-// expansion its first four lanes') or 64 (rings that do not: ring and set in global scratch).  Layers are short, so the work is
-// latency-bound and the serial work per lane counts.  The body is shared by the one-layer launch (k_cost_level: every workgroup a
-// wavefront, any layer size) and the one-workgroup kernel that walks many layers per launch (k_cost_flood_wg, WG = true, T = 4: h,
-// which other wavefronts of the workgroup changed one barrier ago, is read past the CU's cache; the frontier is in LDS).
+// One layer of the flood: verdict, then expansion, of every slope in the layer.  Four lanes share a slope, one per neighbour cell;
+// layers are short, so the work is latency-bound and the dependent round trips per lane count: what only needs the slope — its
+// verdict, h, normal, centroid, the neighbour column with its node count — is requested together, then the neighbour cell's rows
+// with all their fields, then the atomic min.  The body is shared by the one-layer launch (k_cost_level: every workgroup a
+// wavefront, any layer size) and the one-workgroup kernel that walks many layers per launch (k_cost_flood_wg, WG = true: h, which
+// other wavefronts of the workgroup changed one barrier ago, is read past the CU's cache; the frontier is in LDS).
 struct LayerStats { uint32_t trav, closed, checks; };
 
 // f_in: the layer's slopes (WG: in LDS).  f_out: the next layer's, in global memory — and, WG, its first f_lds_cap entries in LDS
 // as well (f_out_lds), where the workgroup's next layer reads them.
-template <int T, bool WG, typename Store>
-__device__ __forceinline__ void cost_layer(const CostView& V, const Robot& R, int ring_n, uint32_t n_in, uint32_t first, uint32_t stride,
+template <bool WG>
+__device__ __forceinline__ void cost_layer(const CostView& V, const Robot& R, uint32_t n_in, uint32_t first, uint32_t stride,
                                            uint32_t* __restrict__ h_bits, uint32_t* __restrict__ state,
                                            const uint32_t* f_in, uint32_t* __restrict__ f_out, uint32_t* f_out_lds, uint32_t f_lds_cap,
-                                           uint32_t* out_count, const Store& S, TeamCtl* C, uint32_t* one, uint32_t* overflow_count,
-                                           LayerStats& st) {
-    const int lane = (int)(threadIdx.x & 63u), leader = lane & ~(T - 1);
-    const uint32_t dir = threadIdx.x % (uint32_t)T;
-    // The loop is wave-uniform (a wave's teams take consecutive slopes of the layer, lanes past the end sit idle), so that the
+                                           uint32_t* out_count, LayerStats& st) {
+    const int lane = (int)(threadIdx.x & 63u);
+    const uint32_t dir = threadIdx.x & 3u;
+    // The loop is wave-uniform (a wave's quads take 16 consecutive slopes of the layer, lanes past the end sit idle), so that the
     // slopes a wave pushes are appended with ONE atomic on the layer's counter: the counter is one word, same-address atomics
     // retire at ~90 per microsecond at the memory side, and a layer of a few hundred slopes used to add one per pushed slope
     // and three more per expanded slope (the statistics) — most of a layer's 13-18 us.
     for (uint32_t i0 = first; i0 < n_in; i0 += stride) {
-        const uint32_t i = i0 + (uint32_t)lane / (uint32_t)T;
+        const uint32_t i = i0 + ((uint32_t)lane >> 2);
         const bool live = i < n_in;
         const uint32_t q = live ? f_in[i] : 0u;
-        // what the expansion needs of q itself, requested before the collision check instead of after it
-        uint32_t hq_bits = 0u, nc = kNoColumn, nc_rows = 0u, above = 0u;
+        uint32_t hq_bits = 0u, nc = kNoColumn, nc_rows = 0u, hit = 0u;
         float nq[3] = {0.f, 0.f, 0.f}, mq[3] = {0.f, 0.f, 0.f};
-        if (live && dir < 4u) {
+        if (live) {
+            hit = V.self[2 * (size_t)q + 1];           // CollisionCheck's verdict, found for every slope before the flood
             hq_bits = WG ? __hip_atomic_load(&h_bits[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : h_bits[q];
             for (int k = 0; k < 3; ++k) { nq[k] = V.normal[3 * q + k]; mq[k] = V.mean[3 * q + k]; }
             neighbour_column(V, q, dir, nc, nc_rows);
-            if (T == 4 && V.self) above = V.self[2 * (size_t)q + 1];
-        }
-        int hit = 0;
-        if constexpr (T >= 16) {
-            if (live) hit = cost_collide_team<T>(V, R, q, ring_n, S, *C, dir);
-        } else {
-            // Without a ring the list holds the slope itself, which is not above itself: the check is Slope::up (demand "true"
-            // only; "slope" leaves it false, map2D.h:636) and the slope above in the same cell, answered per row before the flood.
-            if (V.self && !V.demand_true) hit = (int)above;
-            else if (live && dir == 0u) hit = cost_collide(V, R, q, 0, one, 1);
-            hit = __shfl(hit, leader, 64);
         }
         constexpr uint32_t kKeep = 4;                  // pushes a lane keeps for the wave's append (more go out one by one)
         uint32_t mine[kKeep] = {0u, 0u, 0u, 0u}, np = 0;
         bool closed_one = false;
-        if (live && dir < 4u) {
-            if (hit < 0) { if (dir == 0u) atomicAdd(overflow_count, 1u); }
-            else if (hit) {
+        if (live) {
+            if (hit) {
                 if (dir == 0u) {
                     h_bits[q] = kFltMaxBits;          // Q.front()->h = FLT_MAX (map2D.h:1340)
                     state[q] = 2u;
@@ -632,57 +571,27 @@ __device__ __forceinline__ void cost_flush_stats(LayerStats st, CostCounters* __
 
 // ONE layer, any size: a launch of single-wavefront workgroups.  The layer's number is `launched` — the one-layer launches enqueued
 // before this one — plus the layers the one-workgroup kernel has walked (cc->wg_layers; the host does not know how far that got).
-// T = 64: `scratch` holds 3 * ring_cap words per workgroup (ring + set, the set kSetEmpty at rest).
-template <int T>
-static __global__ void __launch_bounds__(64) k_cost_level(CostView V, Robot R, int ring_n, uint32_t* __restrict__ h_bits,
-                                                   uint32_t* __restrict__ state,
-                                                   uint32_t* __restrict__ f0, uint32_t* __restrict__ f1,
-                                                   uint32_t* scratch, uint32_t ring_cap, CostCounters* __restrict__ cc, uint32_t launched) {
-    constexpr uint32_t kPerWave = 64u / (uint32_t)T;   // slopes a wave takes at a time
-    __shared__ uint32_t s_one[T == 4 ? 16 : 1];        // a checker without a ring still lists the slope itself
-    __shared__ TeamLds s_team[T == 16 ? kPerWave : 1];
-    __shared__ TeamCtl s_ctl[kPerWave];
+static __global__ void __launch_bounds__(64) k_cost_level(CostView V, Robot R, uint32_t* __restrict__ h_bits, uint32_t* __restrict__ state,
+                                                   uint32_t* __restrict__ f0, uint32_t* __restrict__ f1, CostCounters* __restrict__ cc,
+                                                   uint32_t launched) {
     const uint32_t level = launched + cc->wg_layers;
     const uint32_t n_in = cc->frontier[level % 3u];
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         cc->frontier[(level + 2u) % 3u] = 0u;          // the counter two layers ahead (was the previous layer's input)
         if (n_in) cc->levels = level + 1u;
     }
-    if (blockIdx.x * kPerWave < n_in) {                // (uniform; false for every workgroup when the flood has ended)
-        if constexpr (T == 16) {
-            for (uint32_t j = threadIdx.x; j < kPerWave * (uint32_t)(kTeamSetSize / 4); j += blockDim.x)
-                reinterpret_cast<uint4*>(s_team[j / (uint32_t)(kTeamSetSize / 4)].set)[j % (uint32_t)(kTeamSetSize / 4)] =
-                    make_uint4(kSetEmpty, kSetEmpty, kSetEmpty, kSetEmpty);
-            __syncthreads();
-        }
-        const uint32_t* f_in = (level & 1u) ? f1 : f0;
-        uint32_t* f_out = (level & 1u) ? f0 : f1;
-        uint32_t* out_count = &cc->frontier[(level + 1u) % 3u];
-        const uint32_t team = threadIdx.x / (uint32_t)T;
-        LayerStats st{0u, 0u, 0u};
-        if constexpr (T == 16) {
-            cost_layer<T, false>(V, R, ring_n, n_in, blockIdx.x * kPerWave, gridDim.x * kPerWave, h_bits, state, f_in, f_out, nullptr, 0u, out_count,
-                                 RingInLds{s_team[team].ring, s_team[team].set, ring_cap, (uint32_t)(kTeamSetSize - 1)}, &s_ctl[team], nullptr,
-                                 &cc->ring_overflow, st);
-        } else if constexpr (T == 64) {
-            uint32_t* mine = scratch + (size_t)blockIdx.x * 3u * (size_t)ring_cap;
-            cost_layer<T, false>(V, R, ring_n, n_in, blockIdx.x * kPerWave, gridDim.x * kPerWave, h_bits, state, f_in, f_out, nullptr, 0u, out_count,
-                                 RingInGlobal{mine, mine + ring_cap, ring_cap, 2u * ring_cap - 1u}, &s_ctl[0], nullptr, &cc->ring_overflow, st);
-        } else {
-            cost_layer<T, false>(V, R, 0, n_in, blockIdx.x * kPerWave, gridDim.x * kPerWave, h_bits, state, f_in, f_out, nullptr, 0u, out_count,
-                                 RingInLds{nullptr, nullptr, 0u, 0u}, nullptr, &s_one[team], &cc->ring_overflow, st);
-        }
-        cost_flush_stats(st, cc);
-    }
+    if (blockIdx.x * 16u >= n_in) return;              // (uniform; every workgroup once the flood has ended)
+    LayerStats st{0u, 0u, 0u};
+    cost_layer<false>(V, R, n_in, blockIdx.x * 16u, gridDim.x * 16u, h_bits, state, (level & 1u) ? f1 : f0, (level & 1u) ? f0 : f1, nullptr, 0u,
+                      &cc->frontier[(level + 1u) % 3u], st);
+    cost_flush_stats(st, cc);
 }
 
 // MANY layers per launch, while they are narrow: one workgroup of 16 wavefronts walks layer after layer with ONE workgroup barrier
 // between them instead of a launch, the frontier and its counters in LDS.  It stops at a layer wider than max_frontier (<= kWgFrontier;
 // the one-layer launches that follow it on the stream take it from there: cc->wg_layers, cc->frontier, the frontier arrays in global
-// memory are kept complete), when the flood has ended, or after max_layers.  Floods without collision rings only: with rings a team of
-// 16 lanes checks a slope, a workgroup holds 64 teams, and the same kernel over them was no faster than the one-layer launches
-// (bridge_ground: 7.0 ms either way), which spread a layer's teams over the whole chip.
-// Measured (profiles/r04_cost_map.json): 6.6 us per layer on the site, 7.8 on the 8 M-point terrain; one-layer launches 8.5 / 10.5.
+// memory are kept complete), when the flood has ended, or after max_layers.
+// Measured (profiles/r04_cost_map.json): 6.5 us per layer on the site, 7.9 on the 8 M-point terrain; one-layer launches 7.9 / 10.5.
 constexpr int kWgThreads = 1024;
 constexpr uint32_t kWgFrontier = 4u * (uint32_t)(kWgThreads / 4);      // four rounds of the workgroup's quads
 
@@ -690,8 +599,6 @@ static __global__ void __launch_bounds__(kWgThreads) k_cost_flood_wg(CostView V,
                                                               uint32_t* __restrict__ state, uint32_t* f0, uint32_t* f1,
                                                               CostCounters* __restrict__ cc, uint32_t max_frontier, uint32_t max_layers,
                                                               uint32_t launched) {
-    constexpr uint32_t kTeams = (uint32_t)kWgThreads / 4u;
-    __shared__ uint32_t s_one[kTeams];
     __shared__ uint32_t s_count[3];
     __shared__ uint32_t s_f[2][kWgFrontier];
     uint32_t level = launched + cc->wg_layers;
@@ -708,9 +615,8 @@ static __global__ void __launch_bounds__(kWgThreads) k_cost_flood_wg(CostView V,
     uint32_t done = 0;
     for (; done < max_layers && n_in != 0u && n_in <= max_frontier; ++done) {
         if (threadIdx.x == 0) s_count[(level + 2u) % 3u] = 0u;        // (the layer after next's; nobody looks at it during this layer)
-        cost_layer<4, true>(V, R, 0, n_in, (threadIdx.x >> 6) * 16u, kTeams, h_bits, state, s_f[level & 1u], (level & 1u) ? f0 : f1,
-                            s_f[(level + 1u) & 1u], kWgFrontier, &s_count[(level + 1u) % 3u], RingInLds{nullptr, nullptr, 0u, 0u}, nullptr,
-                            &s_one[threadIdx.x >> 2], &cc->ring_overflow, st);
+        cost_layer<true>(V, R, n_in, (threadIdx.x >> 6) * 16u, (uint32_t)kWgThreads / 4u, h_bits, state, s_f[level & 1u], (level & 1u) ? f0 : f1,
+                         s_f[(level + 1u) & 1u], kWgFrontier, &s_count[(level + 1u) % 3u], st);
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // (LDS only: the frontier's global copy is for later kernels)
         ++level;
         n_in = s_count[level % 3u];

@@ -128,9 +128,7 @@ struct gndt_handle {
     struct Cost {
         uint64_t node_cap = 0;     uint32_t *h_bits = nullptr, *state = nullptr, *f[2] = {nullptr, nullptr};
         uint32_t ctab_size = 0;    uint64_t* ctab_key = nullptr; uint32_t* ctab_val = nullptr;
-        uint32_t* ring = nullptr; int ring_cap = 0, ring_alloc = 0;   // rings in global scratch: slopes a ring may hold; what the scratch was sized for
-        int team_ring_limit = 1 << 30;                                  // ring depths from here on did not fit a team's LDS ring on this handle
-        uint32_t* nbr = nullptr;       // [8 * node_cap] neighbour columns of every row (first row, nodes), then [2 * node_cap] its own column and the verdict on the slope above it
+        uint32_t* nbr = nullptr;       // per-flood tables, node_cap rows each: neighbour columns (8 words), own column + collision verdict (2), ring step masks (4), ring extremes (4)
         CostCounters* d_cc = nullptr;
         CostCounters* h_cc = nullptr;   // pinned
         uint64_t serial = 0;            // result_serial the flood was computed for (0 = none)

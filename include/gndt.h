@@ -364,8 +364,8 @@ typedef struct gndt_cost_stats {
                                 goal's level ("Goal position wrong", map2D.h:1304-1306) */
     uint32_t ring;           /* n = (ceil(2r/gridLen)-1)/2, the collision ring depth (map2D.h:1310) */
     uint32_t levels;         /* layers of the flood */
-    uint32_t ring_store;     /* where the collision rings of this flood were kept: 0 no ring, 1 LDS (a team of 16 lanes per slope),
-                                2 global scratch (a wavefront per slope; rings of more than 1024 slopes) */
+    uint32_t ring_store;     /* 0: no collision ring (robot no wider than a cell); 1: the rings' verdicts came from `ring` rounds of
+                                neighbour propagation over the whole map before the flood (no ring is listed, no capacity) */
     uint64_t traversable;    /* traversability.size() (map2D.h:1382) */
     uint64_t closed;         /* slopes closed by a collision */
     uint64_t check_pushes;   /* checkList.size() (map2D.h:1383) */

@@ -169,3 +169,26 @@ def cost_levelsync(cells, grid_len, slope_interval, goal_key, demand="slope", ro
                      h.ctypes.data, state.ctypes.data, stats.ctypes.data)
     return {"rc": rc, "h": h, "state": state, "traversable": int(stats[0]), "closed": int(stats[1]),
             "check_pushes": int(stats[2]), "ring": int(stats[3]), "levels": int(stats[4]), "ring_overflow": int(stats[5])}
+
+
+def collide_all(cells, grid_len, slope_interval, demand="slope", robot=None, ring_cap=1 << 16):
+    """CollisionCheck for every slope of `cells`, by the walk over the ring (cost_collide: the restatement of map2D.h:351-474) and by
+    the rounds over the whole map the device runs instead (gndt_cost.hpp).  Returns (ring depth, walk, rounds): uint8 arrays, 1
+    collide / 0 free / 255 not a slope (walk 2: the ring did not fit ring_cap)."""
+    rb = dict(radius=0.25, reachable_height=0.15, max_rough=100.0, max_angle_deg=30.0)
+    rb.update(robot or {})
+    n = int(len(cells["sx"]))
+    arr = {k: np.ascontiguousarray(cells[k], dtype=t) for k, t in
+           (("sx", np.int32), ("sy", np.int32), ("sz", np.int32), ("mean", np.float32), ("normal", np.float32),
+            ("rough", np.float32), ("flags", np.uint32))}
+    walk = np.zeros(n, np.uint8)
+    rounds = np.zeros(n, np.uint8)
+    r4 = (C.c_float * 4)(float(rb["radius"]), float(rb["reachable_height"]), float(rb["max_rough"]), float(rb["max_angle_deg"]))
+    L = shim()
+    L.shim_collide_all.restype = C.c_int
+    L.shim_collide_all.argtypes = [C.c_uint64] + [C.c_void_p] * 7 + [C.c_float, C.c_int, C.c_float, C.POINTER(C.c_float), C.c_int,
+                                   C.c_void_p, C.c_void_p]
+    dem = {"slope": 0, "true": 1}[demand] if isinstance(demand, str) else int(demand)
+    ring = L.shim_collide_all(n, *[arr[k].ctypes.data for k in ("sx", "sy", "sz", "mean", "normal", "rough", "flags")],
+                              float(slope_interval), dem, float(grid_len), r4, int(ring_cap), walk.ctypes.data, rounds.ctypes.data)
+    return ring, walk, rounds

@@ -117,3 +117,65 @@ extern "C" int shim_cost(uint64_t n, const int32_t* sx, const int32_t* sy, const
     stats[0] = trav; stats[1] = closed; stats[2] = checks; stats[3] = ring_n; stats[4] = levels; stats[5] = overflow;
     return goal_status;
 }
+
+
+// CollisionCheck for EVERY slope of a grid, twice: the walk over the ring (cost_collide, the restatement of map2D.h:351-474) and the
+// rounds over the whole map the device runs instead (gndt_cost.hpp, "CollisionCheck without walking rings").  walk / rounds: 1 collide,
+// 0 free, 255 not a slope (walk: 2 = the walk's ring scratch of ring_cap slopes did not fit).
+extern "C" int shim_collide_all(uint64_t n, const int32_t* sx, const int32_t* sy, const int32_t* sz, const float* mean,
+                                const float* normal, const float* rough, const uint32_t* flags, float slope_interval,
+                                int demand_true, float grid_len, const float robot4[4], int ring_cap, uint8_t* walk, uint8_t* rounds) {
+    using namespace gndt;
+    std::vector<uint32_t> col_base, row_ncol(n ? n : 1, 0u);
+    for (uint64_t i = 0; i < n; ++i) {
+        if (i == 0 || sx[i] != sx[i - 1] || sy[i] != sy[i - 1]) col_base.push_back((uint32_t)i);
+        ++row_ncol[col_base.back()];
+    }
+    uint32_t tsize = 1024;
+    while (tsize < 2 * col_base.size()) tsize <<= 1;
+    std::vector<uint64_t> tkey(tsize, kEmptyKey);
+    std::vector<uint32_t> tval(tsize, 0);
+    for (uint32_t c = 0; c < col_base.size(); ++c) {
+        const uint64_t key = column_pack(sx[col_base[c]], sy[col_base[c]]);
+        uint32_t s = (uint32_t)mix64(key) & (tsize - 1);
+        while (tkey[s] != kEmptyKey) s = (s + 1) & (tsize - 1);
+        tkey[s] = key; tval[s] = col_base[c];
+    }
+    CostView V{sx, sy, sz, mean, normal, rough, flags, row_ncol.data(), tkey.data(), tval.data(), tsize - 1, nullptr,
+               slope_interval, demand_true};
+    Robot R{robot4[0], robot4[1], robot4[2], robot4[3]};
+    const int ring_n = cost_ring_depth(R.r, grid_len);
+    std::vector<uint32_t> ring((size_t)ring_cap);
+    for (uint64_t q = 0; q < n; ++q) {
+        if (!row_has_slope(V, (uint32_t)q)) { walk[q] = 255; continue; }
+        const int hit = cost_collide(V, R, (uint32_t)q, ring_n, ring.data(), ring_cap);
+        walk[q] = hit < 0 ? 2 : (uint8_t)hit;
+    }
+    // the rounds, as k_cost_neighbours / k_cost_ring_round run them
+    std::vector<uint32_t> nc(4 * n), nr(4 * n), step(4 * n, 0u);
+    std::vector<float> hi[2] = {std::vector<float>(n, 0.f), std::vector<float>(n, 0.f)}, lo[2] = {std::vector<float>(n, 0.f), std::vector<float>(n, 0.f)};
+    std::vector<uint8_t> verdict(n, 0);
+    for (uint64_t q = 0; q < n; ++q) {
+        const bool slope = row_has_slope(V, (uint32_t)q);
+        for (uint32_t k = 0; k < 4; ++k) {
+            neighbour_column(V, (uint32_t)q, k, nc[4 * q + k], nr[4 * q + k]);
+            if (ring_n > 0 && slope) step[4 * q + k] = ring_step_mask(V, R, (uint32_t)q, nc[4 * q + k], nr[4 * q + k]);
+        }
+        const bool up = slope && row_up(V, (uint32_t)q);
+        verdict[q] = slope && ring_free_verdict(V, R, (uint32_t)q, up) ? 1 : 0;
+        if (ring_n > 0 && slope) ring_round0(V, (uint32_t)q, up, hi[0][q], lo[0][q]);
+    }
+    for (int d = 0; d < ring_n; ++d) {
+        const std::vector<float>&hin = hi[d & 1], &lin = lo[d & 1];
+        std::vector<float>&hout = hi[(d + 1) & 1], &lout = lo[(d + 1) & 1];
+        for (uint64_t q = 0; q < n; ++q) {
+            if (!row_has_slope(V, (uint32_t)q)) continue;
+            float h = hin[q], l = lin[q];
+            for (uint32_t k = 0; k < 4; ++k) ring_round_cell(V, R, (uint32_t)q, nc[4 * q + k], nr[4 * q + k], step[4 * q + k], hin.data(), lin.data(), h, l);
+            hout[q] = h; lout[q] = l;
+            if (d == ring_n - 1 && ring_verdict(V, R, (uint32_t)q, h, l)) verdict[q] = 1;
+        }
+    }
+    for (uint64_t q = 0; q < n; ++q) rounds[q] = row_has_slope(V, (uint32_t)q) ? verdict[q] : 255;
+    return ring_n;
+}

@@ -163,3 +163,43 @@ def test_flood_properties_on_the_site():
     assert (h[reached] >= d[reached] * (1 - 1e-5)).all()
     assert (st[~reached] != 1).all() and (h[st == 0] == FLT_MAX).sum() == (st == 0).sum() - ((st == 0) & reached).sum()
     assert ((ref["flags"] & 2) == 0)[reached].sum() == 0
+
+
+def _random_grid(rng, cols, levels, fill, bumpy):
+    """A grid in reference order (columns contiguous, ascending z inside a column) with random occupancy: `levels` z levels of
+    1 m, centroids jittered inside their level, normals tilted up to ~40 degrees, most nodes slopes."""
+    rows = []
+    for sx in range(1, cols + 1):
+        for sy in range(1, cols + 1):
+            for sz in range(1, levels + 1):
+                if rng.random() > fill:
+                    continue
+                z = (sz - 1) + float(rng.random()) * (1.0 if bumpy else 0.12)
+                tilt = rng.normal(0, 0.35 if bumpy else 0.05, 2)
+                nrm = np.array([tilt[0], tilt[1], 1.0]) / np.sqrt(tilt[0] ** 2 + tilt[1] ** 2 + 1.0)
+                rows.append((sx, sy, sz, (centre(sx), centre(sy), z), tuple(nrm), rng.random() < 0.85))
+    return make_cells(rows)
+
+
+@pytest.mark.parametrize("demand", ["slope", "true"])
+def test_ring_verdicts_by_rounds_over_the_map_equal_the_walk_for_every_slope(demand):
+    """The device never lists a collision ring: ring-depth rounds of "the extreme over my steps" over all slopes at once give every
+    slope's verdict (gndt_cost.hpp, "CollisionCheck without walking rings").  Here both run on the host, for EVERY slope of random
+    grids — flat and bumpy, sparse and full, cells of up to 48 nodes (a step mask holds 32), ring depths 0 to 4, both demands —
+    and must agree slope for slope."""
+    rng = np.random.default_rng(7 if demand == "slope" else 8)
+    total = collided = 0
+    for trial in range(14):
+        cols = int(rng.integers(5, 11))
+        levels = int(rng.choice([1, 2, 6, 48]))
+        cells = _random_grid(rng, cols, levels, float(rng.choice([0.35, 0.7, 1.0])) if levels > 1 else 0.9, bool(rng.integers(0, 2)))
+        if len(cells["sx"]) == 0:
+            continue
+        for radius in (0.25, 0.8, 1.6, 2.4, 4.4):              # 1 m cells: ring depths 0, 0/1, 1, 2, 4
+            robot = {"radius": radius, "reachable_height": float(rng.choice([0.15, 0.4, 1.1]))}
+            ring, walk, rounds = he.collide_all(cells, 1.0, 0.08, demand=demand, robot=robot)
+            assert (walk != 2).all()
+            np.testing.assert_array_equal(rounds, walk, err_msg=f"trial {trial} levels {levels} ring {ring} {robot}")
+            total += int((walk != 255).sum())
+            collided += int((walk == 1).sum())
+    assert total > 20000 and 0.02 * total < collided < 0.98 * total, (total, collided)
