@@ -102,22 +102,28 @@ int gndt_compute_cost(gndt_handle* h, const float goal_xyz[3], const gndt_robot*
     // (any width; no-ops once the flood has ended) — 8 while the layers are narrow, 32 when the last answer showed a wide one.  How
     // many layers the one-workgroup kernel walked is only known on the device (cc->wg_layers); the host asks after every batch
     // whether the flood has ended.  GNDT_COST_WG=0: one-layer launches only.
+    // (One workgroup takes ~5.6 us + 8 ns per slope for a layer, a one-layer launch 8-10 us whatever the width — site, terrain and a
+    //  200 m open site with layers of thousands, profiles/r04_cost_map.json: the workgroup keeps the layers of up to kWgNarrow slopes.)
+    constexpr uint32_t kWgNarrow = 320;
     const bool wg = env_int("GNDT_COST_WG", 1) != 0;
     bool narrow = true;
     uint32_t launched = 0;                                   // one-layer launches enqueued so far
+    uint32_t blocks = kCostBlocks;                           // wavefronts of a one-layer launch (16 slopes at a time each): twice the last
+                                                             //   layer seen, so that a wide layer is one pass
     for (;;) {
         if (wg)
-            hipLaunchKernelGGL(k_cost_flood_wg, dim3(1), dim3(kWgThreads), 0, s, V, R, c.h_bits, c.state, c.f[0], c.f[1], c.d_cc, kWgFrontier, 1u << 20,
+            hipLaunchKernelGGL(k_cost_flood_wg, dim3(1), dim3(kWgThreads), 0, s, V, R, c.h_bits, c.state, c.f[0], c.f[1], c.d_cc, kWgNarrow, 1u << 20,
                                launched);
         for (int b = 0, nb = wg && narrow ? 8 : kCostBatch; b < nb; ++b, ++launched)
-            hipLaunchKernelGGL(k_cost_level, dim3(kCostBlocks), dim3(kCostThreads), 0, s, V, R, c.h_bits, c.state, c.f[0], c.f[1], c.d_cc, launched);
+            hipLaunchKernelGGL(k_cost_level, dim3(blocks), dim3(kCostThreads), 0, s, V, R, c.h_bits, c.state, c.f[0], c.f[1], c.d_cc, launched);
         HIP_TRY(h, hipGetLastError());
         HIP_TRY(h, hipMemcpyAsync(c.h_cc, c.d_cc, sizeof(CostCounters), hipMemcpyDeviceToHost, s));
         HIP_TRY(h, hipStreamSynchronize(s));
         const uint32_t level = launched + c.h_cc->wg_layers;
         const uint32_t left = c.h_cc->frontier[level % 3u];
         if (left == 0u) break;
-        narrow = left <= kWgFrontier;
+        narrow = left <= kWgNarrow;
+        blocks = (uint32_t)std::min<uint64_t>(16384, std::max<uint64_t>(kCostBlocks, pow2_ceil((uint64_t)left / 8 + 1)));
         if (level > (1u << 24)) { h->err = "cost flood did not terminate"; return GNDT_ERR_HIP; }
     }
     if (c.h_cc->range_error) {

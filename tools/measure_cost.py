@@ -64,6 +64,8 @@ def main():
     P = dict(grid_len=0.5, z_len=0.25, slope_interval=0.08)
     one("terrain_2M", scenes.terrain_cloud(2_000_000), P, None, True)
     one(f"terrain_{a.points // 1_000_000}M", scenes.terrain_cloud(a.points), P, None, False)
+    # wide layers: an open site of 200 x 200 m on 0.25 m cells (hundreds of thousands of slopes, layers of thousands)
+    one("open_site_6M", scenes.drivable_site(6_000_000, half=100.0), dict(grid_len=0.25, z_len=0.25, slope_interval=0.08), scenes.DRIVABLE_GOAL, False)
     print(json.dumps(out, indent=1))
 
 
