@@ -144,3 +144,15 @@ def test_cost_map_by_one_layer_launches_only(demand, monkeypatch):
     for radius in (0.25, 0.6):
         st, _ = _check(m, cloud, P, scenes.DRIVABLE_GOAL, demand, {"radius": radius})
         assert st["traversable"] > 8000 and st["levels"] > 50
+
+
+def test_cost_map_with_layers_wider_than_the_one_workgroup_kernel_takes():
+    """An open 100 m site on 0.25 m cells: ~150 k slopes, layers grow from one slope to far more than the 320 the one-workgroup
+    kernel keeps, and shrink again at the end — the flood is handed from that kernel to one-layer launches (sized from the last layer
+    seen) and back.  Same flood as the oracle's; also with one-layer launches only."""
+    cloud = scenes.drivable_site(1_500_000, half=50.0)
+    P = dict(grid_len=0.25, z_len=0.25, slope_interval=0.08)
+    m = _build(cloud, P, "slope", 0)
+    st, _ = _check(m, cloud, P, scenes.DRIVABLE_GOAL, "slope", None)
+    assert st["traversable"] > 100_000 and st["levels"] > 200
+    assert st["traversable"] / st["levels"] > 200          # (the MEAN layer is near the workgroup's share: the wide ones are far beyond it)
