@@ -99,9 +99,10 @@ int gndt_compute_cost(gndt_handle* h, const float goal_xyz[3], const gndt_robot*
         hipLaunchKernelGGL(k_cost_goal, dim3(1), dim3(64), 0, s, V, gk.sx, gk.sy, gk.sz, c.h_bits, c.f[0], c.d_cc);
     HIP_TRY(h, hipGetLastError());
     // A batch on the stream: the one-workgroup kernel (as many narrow layers as it meets, gndt_cost.hpp), then one-layer launches
-    // (any width; no-ops once the flood has ended) — 8 while the layers are narrow, 32 when the last answer showed a wide one.  How
-    // many layers the one-workgroup kernel walked is only known on the device (cc->wg_layers); the host asks after every batch
-    // whether the flood has ended.  GNDT_COST_WG=0: one-layer launches only.
+    // (any width; no-ops once the flood has ended) — 8 while the layers are narrow, 32 when the last answer showed a wide one
+    // (batches growing to 128 while the layers stay wide were measured on the 807-layer open site: no gain).  How many layers the
+    // one-workgroup kernel walked is only known on the device (cc->wg_layers); the host asks after every batch whether the flood
+    // has ended.  GNDT_COST_WG=0: one-layer launches only.
     // (One workgroup takes ~5.6 us + 8 ns per slope for a layer, a one-layer launch 8-10 us whatever the width — site, terrain and a
     //  200 m open site with layers of thousands, profiles/r04_cost_map.json: the workgroup keeps the layers of up to kWgNarrow slopes.)
     constexpr uint32_t kWgNarrow = 320;

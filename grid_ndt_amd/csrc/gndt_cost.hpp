@@ -15,8 +15,10 @@
 // not propagated (map2D.h:1331-1336: it is pushed only while in none of the three lists).  Therefore
 //   h_pop(p)  = min over expanded q in layer k-1 with p accessible from q of  h_pop(q) + d(q,p)
 //   h_final(p) = min(h_pop(p) or FLT_MAX if p collided, the same expression over layer k+1)
-// and every one of these minima is over a SET, so one kernel launch per layer with an atomic min on the fp32
-// bit pattern (h >= 0) reproduces h bit for bit, whatever the order of the threads.
+// and every one of these minima is over a SET, so a layer worked on by any number of threads in any order, with an
+// atomic min on the fp32 bit pattern (h >= 0), reproduces h bit for bit — one launch per layer, or one workgroup
+// walking layer after layer with a barrier between them (k_cost_level / k_cost_flood_wg at the bottom).  CollisionCheck's
+// verdict is found for every slope before the flood ("CollisionCheck without walking rings" below).
 //
 // The per-slope logic is host-callable so that the CPU-only test tier runs the same code level by level
 // (tests/host_math_shim.cpp); the kernels are at the bottom.
