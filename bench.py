@@ -350,6 +350,49 @@ def measure_host_path():
 
 
 
+def measure_cost_flood(g, torch):
+    """The immediate consumer of the grid (SURVEY.md §8(f) rank 1): gndt_compute_cost — TwoDmap::computeCost, include/map2D.h:1285-1397,
+    with CollisionCheck :351-474 — on three finished grids, each checked against the oracle's flag-based restatement of the reference's
+    FIFO flood run on the same exported grid (h and state bit for bit).  Untimed by `value`."""
+    from grid_ndt_amd import scenes
+    from oracle import oracle
+    out = {}
+    cases = (("drivable_site_400k", scenes.drivable_site(400_000), scenes.COST_PARAMS, scenes.DRIVABLE_GOAL, None),
+             ("bridge_ground_360k_own_parameters", scenes.bridge_ground(), scenes.BRIDGE_PARAMS, (9.5, 3.0, 1.0), {"radius": 0.25}),   # parameters.txt:53-59
+             ("terrain_2M", scenes.terrain_cloud(2_000_000), dict(grid_len=0.5, z_len=0.25, slope_interval=0.08), None, None))
+    for name, cloud, P, goal, robot in cases:
+        demand = P.get("demand", "slope")
+        m = g.TwoDmap(P["grid_len"], P["z_len"])
+        m.setInterval(P["slope_interval"])
+        m.setCloudFirst(cloud[0])
+        m.create2DMap(demand, torch.from_numpy(np.ascontiguousarray(cloud[1:])).cuda())
+        cells = m.export()
+        if goal is None:
+            rows = np.nonzero((cells["flags"] & 2) != 0)[0]
+            goal = cells["mean"][rows[len(rows) // 3]]
+        st = m.computeCost(goal, robot=robot)
+        ts = []
+        for _ in range(5):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            st = m.computeCost(goal, robot=robot)
+            ts.append((time.perf_counter() - t0) * 1e3)
+        got = m.cost_export()
+        t0 = time.perf_counter()
+        ref = oracle.compute_cost(cells, cloud[0], P["grid_len"], P["z_len"], P["slope_interval"], goal, demand=demand, robot=robot, mode=oracle.COST_FLAGS)
+        cpu_ms = (time.perf_counter() - t0) * 1e3
+        ms = float(np.median(ts))
+        out[name] = {"points": int(cloud.shape[0] - 1), "nodes": int(cells["num_nodes"]), "slopes": int(cells["num_slopes"]),
+                     "ring_depth": int(st["ring"]), "layers": int(st["levels"]), "traversable": int(st["traversable"]), "closed": int(st["closed"]),
+                     "gpu_ms": round(ms, 3), "us_per_layer": round(ms * 1e3 / max(int(st["levels"]), 1), 2),
+                     "cpu_oracle_flags_ms": round(cpu_ms, 1),
+                     "h_bit_exact": bool((got["h"] == ref["h"]).all()), "state_exact": bool((got["state"] == ref["state"]).all())}
+        del m
+    out["what"] = ("gndt_compute_cost (host call to host return, median of 5) on the grid of the build before it; cpu_oracle_flags_ms = the "
+                   "oracle's flag-based restatement of the reference's FIFO flood, one core of this box; never part of `value`")
+    return out
+
+
 def committed_traffic(kernel_substr):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes — only when that profile
     was taken from THIS source tree (hash of the kernel sources stored in the profile); otherwise null."""
@@ -801,6 +844,10 @@ def main():
             extras["host_path"] = measure_host_path()
         except Exception as e:            # (a missing g++ must not cost the bench line)
             extras["host_path"] = {"error": f"{type(e).__name__}: {e}"}
+        try:
+            extras["cost_flood"] = measure_cost_flood(g, torch)
+        except Exception as e:
+            extras["cost_flood"] = {"error": f"{type(e).__name__}: {e}"}
         pts = torch.from_numpy(host_pts).to(dev)
 
     if rank == 0:

@@ -47,7 +47,7 @@ def test_multi_gpu_line_steps_down_when_the_exchange_reports_an_error(fail, ends
 def test_single_gpu_line_carries_every_config_and_the_host_path():
     """The N = 1 line (what the driver records): S2 as `value`, and — untimed by it — the other BASELINE.json configurations
     (`configs`: S1 campus / bridge_ground / depth frame, S2z, S3, S5, S4 eager and replayed, first builds), the host side of the seam
-    stage by stage (`host_path`, eager and lazy) and the host-buffer build (`host_build`)."""
+    stage by stage (`host_path`, eager and lazy), the host-buffer build (`host_build`) and the cost flood on three grids (`cost_flood`)."""
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "5", "--warmup", "2", "--no-cpu-baseline"],
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
@@ -72,3 +72,7 @@ def test_single_gpu_line_carries_every_config_and_the_host_path():
     site = hp["drivable_site_400k"]
     assert site["eager"]["route_found"] and site["lazy"]["route_found"] and site["eager"]["route_steps"] == site["lazy"]["route_steps"] > 2
     assert d["host_build"]["pageable_ms"] > 0 and d["host_build"]["pinned_ms"] > 0
+    cf = d["cost_flood"]                      # the grid's immediate consumer (computeCost), each flood checked against the oracle's
+    for k in ("drivable_site_400k", "bridge_ground_360k_own_parameters", "terrain_2M"):
+        assert cf[k]["h_bit_exact"] and cf[k]["state_exact"] and cf[k]["layers"] > 10 and cf[k]["gpu_ms"] > 0, (k, cf[k])
+    assert cf["bridge_ground_360k_own_parameters"]["ring_depth"] == 2 and cf["drivable_site_400k"]["ring_depth"] == 0
