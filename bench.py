@@ -385,11 +385,14 @@ def measure_cost_flood(g, torch):
         out[name] = {"points": int(cloud.shape[0] - 1), "nodes": int(cells["num_nodes"]), "slopes": int(cells["num_slopes"]),
                      "ring_depth": int(st["ring"]), "layers": int(st["levels"]), "traversable": int(st["traversable"]), "closed": int(st["closed"]),
                      "gpu_ms": round(ms, 3), "us_per_layer": round(ms * 1e3 / max(int(st["levels"]), 1), 2),
-                     "cpu_oracle_flags_ms": round(cpu_ms, 1),
+                     # this block's cpu_baseline leg: the oracle's flood, timed beside the GPU's and used as its checker
+                     "cpu_baseline": {"value": round(cpu_ms, 1), "unit": "ms", "cores": 1, "kind": "port",
+                                      "sample": "the whole flood on the same exported grid, oracle/cost_cpu.cpp (flag-based restatement of map2D.h:1285-1397)"},
                      "h_bit_exact": bool((got["h"] == ref["h"]).all()), "state_exact": bool((got["state"] == ref["state"]).all())}
         del m
-    out["what"] = ("gndt_compute_cost (host call to host return, median of 5) on the grid of the build before it; cpu_oracle_flags_ms = the "
-                   "oracle's flag-based restatement of the reference's FIFO flood, one core of this box; never part of `value`")
+    out["what"] = ("gndt_compute_cost (host call to host return, median of 5) on the grid of the build before it; cpu_baseline = the "
+                   "oracle's flag-based restatement of the reference's FIFO flood, one core of this box, which also checks the GPU's h and state; "
+                   "never part of `value`")
     return out
 
 
