@@ -186,7 +186,8 @@ int partition_launch(gndt_handle* h, gndt_handle::Pending& P) {
         uint32_t* cursor2 = q.cursors + kMaxFan;
         uint32_t* est2 = cursor2 + B;
         mark(h, 0, s);
-        if (h->table_dirty) { if ((rc = do_reset(h, s))) return rc; }
+        // (a build recorded into a hipGraph always records the reset: its replays must not depend on what the table held at capture time)
+        if (h->table_dirty || h->capturing) { if ((rc = do_reset(h, s))) return rc; }
         h->results_valid = false;
         hipLaunchKernelGGL(k_part_clear, dim3(grid_for(words, 256, 512)), dim3(256), 0, s, h->d_cnt, q.d_pc, q.bitmap, q.word_weight, (uint64_t)words,
                            q.cursors, (uint32_t)(kMaxFan + 2 * B));
@@ -249,7 +250,8 @@ int partition_launch(gndt_handle* h, gndt_handle::Pending& P) {
         uint32_t* est2 = q.cursors + kMaxFan;              // (the kernel's sample votes: not used here, but counted)
         const uint32_t F1 = B, F2_shift = 0, R = 1;
         mark(h, 0, s);
-        if (h->table_dirty) { if ((rc = do_reset(h, s))) return rc; }
+        // (a build recorded into a hipGraph always records the reset: its replays must not depend on what the table held at capture time)
+        if (h->table_dirty || h->capturing) { if ((rc = do_reset(h, s))) return rc; }
         h->results_valid = false;
         hipLaunchKernelGGL(k_part_clear, dim3(grid_for(words, 256, 512)), dim3(256), 0, s, h->d_cnt, q.d_pc, q.bitmap, q.word_weight, (uint64_t)words,
                            q.cursors, (uint32_t)(kMaxFan + B));
@@ -300,7 +302,7 @@ int partition_launch(gndt_handle* h, gndt_handle::Pending& P) {
     }
     mark(h, 0, s);
     // the HBM node table is not used by this strategy, but a previous atomic build may sit in it
-    if (h->table_dirty) { if ((rc = do_reset(h, s))) return rc; }
+    if (h->table_dirty || h->capturing) { if ((rc = do_reset(h, s))) return rc; }     // (as above: a captured build always records the reset)
     h->results_valid = false;
     hipLaunchKernelGGL(k_part_clear, dim3(grid_for(words, 256, 512)), dim3(256), 0, s, h->d_cnt, q.d_pc, q.bitmap, q.word_weight, (uint64_t)words,
                        (uint32_t*)nullptr, 0u);

@@ -51,6 +51,11 @@ struct Counters {
     uint32_t first_word;      // incremental finalisation: first bitmap word whose column order changed in this frame (a column
                               //   gained a node or is new); rows of columns in front of it keep their places.  0xFFFFFFFF: none
     uint32_t ticket;          // k_clear_used: workgroups that are done (the last one zeroes the counters); 0 between kernels
+    uint32_t part_owned;      // 1 while num_nodes counts a PARTITION build's staged rows (set by k_part_clear) and NOT the node list of
+                              //   the table, which is empty then (every partition build resets a dirty table first; a captured one
+                              //   always records the reset): k_clear_used must not walk node_slot[0 .. num_nodes) — past the list the
+                              //   slots are whatever the allocation held (round 4, tools/fuzz_graph.py --seed 6: the second replay of a
+                              //   PARTITION build captured after an ATOMIC fallback cleared "slots" read from there — a GPU memory fault)
 };
 
 struct GridParams {
@@ -169,12 +174,14 @@ static __device__ __forceinline__ void zero_counters(Counters* c) {
     c->num_nodes = 0; c->num_columns = 0; c->num_slopes = 0; c->err_key_range = 0; c->err_table_full = 0;
     c->stream_pos = 0; c->prev_nodes = 0; c->n_touched = 0; c->n_tcols = 0; c->n_work = 0; c->n_dead = 0; c->err_remove = 0;
     c->epoch = c->epoch + 1u;                     // stale touch marks of the previous map can never match again
+    c->part_owned = 0u;                           // (num_nodes is the table's node list again, empty)
 }
 
 static __global__ void k_clear_used(uint64_t* keys, NodeAcc* acc, uint64_t* col_keys, uint32_t* col_first, uint32_t* col_cnt,
                              uint32_t* col_head, const uint32_t* node_slot, const uint32_t* col_slot_of_node,
                              Counters* cur) {
-    const uint32_t n = cur->num_nodes, np = cur->prev_nodes;
+    const bool listed = cur->part_owned == 0u;    // (else: the counters are a PARTITION build's and the table is empty)
+    const uint32_t n = listed ? cur->num_nodes : 0u, np = listed ? cur->prev_nodes : 0u;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const uint32_t slot = node_slot[i];
         keys[slot] = kEmptyKey;

@@ -182,6 +182,7 @@ static __global__ void __launch_bounds__(256) k_part_clear(Counters* __restrict_
                                                     uint64_t words, uint32_t* __restrict__ cursors, uint32_t n_cursors) {
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         cnt->num_nodes = 0; cnt->num_columns = 0; cnt->num_slopes = 0; cnt->err_key_range = 0; cnt->err_table_full = 0;
+        cnt->part_owned = 1u;                        // (num_nodes counts staged rows from here on, not the table's node list)
         pc->lds_overflow = 0; pc->stage_overflow = 0; pc->index_overflow = 0; pc->part_overflow = 0;
         pc->max_fill1 = 0; pc->fp_clashes = 0; pc->l1_ticket = 0; pc->small_fallback = 0;
     }

@@ -61,6 +61,55 @@ def test_parity_device_input(name, strategy):
     assert ran == {1: 1, 3: 3, 4: 2, 5: 5}[strategy], (name, ran)
 
 
+def test_partition_build_captured_after_an_atomic_fallback_is_replayed_again_and_again():
+    """A PARTITION build recorded into a hipGraph right after the handle's eager builds ended on the ATOMIC fallback (columns of
+    ~2000 nodes: no LDS table holds them) carries the reset of that table.  The SECOND replay used to walk the table's node list with
+    the first replay's node count — the counters are shared, the list is not — and cleared "slots" read from beyond the list: wild
+    writes, a GPU memory fault in a process whose allocations held garbage there (tools/fuzz_graph.py --seed 6, round 4).  The
+    counters now say whose they are (Counters::part_owned).  Several replays, maps with more nodes than the fallback's, each against
+    the oracle; then the handle goes back to the fallback eagerly."""
+    import torch
+    import grid_ndt_amd as g
+    n = 140_000
+    P = dict(grid_len=0.1, z_len=0.05, slope_interval=0.08, demand="slope")
+    rng = np.random.default_rng(5)
+    tall = np.empty((n + 1, 3), np.float32)                    # 25 columns of 0.1 m, 100 m tall: ~2000 levels each
+    tall[:, 0:2] = 1.0 + rng.random((n + 1, 2)) * 0.5
+    tall[:, 2] = rng.random(n + 1) * 100.0
+    flat = []
+    for k in range(3):                                         # benign clouds of the same size, more nodes than `tall` has columns
+        c = np.empty((n + 1, 3), np.float32)
+        c[:, 0:2] = 1.0 + rng.random((n + 1, 2)) * (24.0 + k)      # ~52-58 k nodes: more than the fallback's list, within the capture's tables
+        c[:, 2] = 0.01 + rng.random(n + 1) * 0.03
+        c[0] = tall[0]
+        flat.append(c)
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        buf = torch.from_numpy(np.ascontiguousarray(tall[1:])).cuda()
+        m = g.TwoDmap(P["grid_len"], P["z_len"], strategy=4, max_points_hint=n + 1)
+        m.setInterval(P["slope_interval"])
+        m.setCloudFirst(tall[0])
+        ref_tall = parity.ref_from_cloud(tall, P, mode=2)
+        for _ in range(2):
+            m.create2DMap("slope", buf, s)
+            out = m.export()
+            assert m.STRATEGY_NAMES[m.last_strategy()] == "atomic"           # (the partition attempts all overflowed)
+            assert parity.compare(out, ref_tall, "slope", dense=True)["ok"]
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=s):
+            m.create2DMap("slope", buf, s)
+        for c in flat + flat[::-1]:
+            buf.copy_(torch.from_numpy(np.ascontiguousarray(c[1:])))
+            graph.replay()
+            s.synchronize()
+            out = m.export()
+            rep = parity.compare(out, parity.ref_from_cloud(c, P, mode=2), "slope", dense=True)
+            assert rep["ok"], rep["fail"][:3]
+        buf.copy_(torch.from_numpy(np.ascontiguousarray(tall[1:])))
+        m.create2DMap("slope", buf, s)
+        assert parity.compare(m.export(), ref_tall, "slope", dense=True)["ok"]
+
+
 @pytest.mark.parametrize("strategy", [0, 1, 2, 3, 4, 5], ids=["auto", "atomic", "partition", "partition_exact", "partition_two_level", "tile"])
 def test_build_captured_on_a_reserved_fresh_handle(strategy):
     """gndt_reserve sizes every buffer a build of that size can ask for, so the FIRST build of a handle can be recorded into a

@@ -87,7 +87,13 @@ def main():
                         buf.copy_(torch.from_numpy(np.ascontiguousarray(other[1:])))
                         if os.environ.get("FUZZ_TRACE"):
                             print("  replay", k, m.STRATEGY_NAMES.get(m.last_strategy()), file=sys.stderr, flush=True)
-                        graph.replay()
+                        if os.environ.get("FUZZ_DUMP"):          # (to find the cloud of a replay that kills the process: the last file written)
+                            np.savez(os.environ["FUZZ_DUMP"] + f".{k}", base=base, other=other, cells=np.float32(cells), strategy=strategy, replay=k,
+                                     hint=int(m._params_hint) if hasattr(m, "_params_hint") else -1, fresh=int(fresh))
+                        if os.environ.get("FUZZ_EAGER"):         # (diagnosis: the same sequence of clouds through eager builds instead of replays)
+                            m.create2DMap("slope", buf, s)
+                        else:
+                            graph.replay()
                         s.synchronize()
                         stats["replays"] += 1
                         try:
