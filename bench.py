@@ -194,6 +194,33 @@ def cpu_baseline(origin, pts, P, sample):
                                   "sample": f"first {n_ser} points, oracle mode 0 (strings + multimap, as the reference runs)"}}
 
 
+def full_size_parity(m, torch, origin, host_pts, P, pts, stream, dense=False):
+    """EVERY node of the workload's map against the oracle (OpenMP port, all host threads, exported with its fp64 truth): keys,
+    counts, first-seen order and labels exact, mean / covariance / lambda_min / normal under the gates of tests/parity.py.
+    The oracle is the checker here, untimed and outside `value`; a failure makes the bench exit non-zero."""
+    from oracle import oracle
+    from tests import parity
+    t0 = time.perf_counter()
+    cloud = np.ascontiguousarray(np.concatenate([origin[None, :], host_pts], 0))
+    ref = oracle.build_grid(cloud, P["grid_len"], P["z_len"], P["slope_interval"], P.get("demand", "slope"), mode=oracle.MODE_INT_OPENMP,
+                            threads=oracle.max_threads(), export=True)
+    del cloud
+    t_ref = time.perf_counter() - t0
+    m.create2DMap(P.get("demand", "slope"), pts, stream)
+    got = m.export()
+    rep = parity.compare(got, ref, P.get("demand", "slope"), dense=dense, interval=P["slope_interval"])
+    keep = ("ok", "num_nodes", "label_mismatch_has_stats", "label_mismatch_slope", "label_mismatch_down", "labels_within_margin",
+            "labels_on_the_margin", "mean_err", "cov_err", "cov_err_truth", "rough_err", "normal_err", "normals_checked",
+            "cov_nodes_over_1e-5_vs_fp32", "cov_widening_max", "cov_nodes_below_input_resolution", "fail")
+    out = {k: rep[k] for k in keep if k in rep}
+    out["labels_within_margin"] = int(rep.get("labels_within_margin", 0))      # (0 unless the dense gate is on: labels are exact)
+    out["dense_gate"] = bool(dense)
+    out["oracle_s"] = round(t_ref, 2)
+    out["what"] = ("parity.compare(gndt export, oracle mode 2 export) over ALL nodes of this workload: keys / counts / first-seen order / "
+                   "labels exact; covariance <= 1e-5 max|C| vs the fp32-sequential restatement and <= 2e-6 vs fp64 truth")
+    return out
+
+
 def _timed_builds(g, torch, cloud, P, steps, hint=0, strategy=0, demand="slope"):
     """ms per back-to-back build of `cloud` (device-resident) on a warmed-up handle + what a FRESH handle's first build costs."""
     pts = torch.from_numpy(np.ascontiguousarray(cloud[1:])).cuda()
@@ -853,6 +880,7 @@ def main():
             extras["cost_flood"] = {"error": f"{type(e).__name__}: {e}"}
         pts = torch.from_numpy(host_pts).to(dev)
 
+    parity_failed = False
     if rank == 0:
         ms_step = dt / a.steps * 1e3
         value = job_points / (dt / a.steps) / 1e6
@@ -911,6 +939,9 @@ def main():
         if not a.no_cpu_baseline and world == 1:
             sample = a.cpu_sample or min(n, 10_000_000)
             out["cpu_baseline"] = cpu_baseline(origin, host_pts, P, min(sample, n))
+            if min(sample, n) >= n and not global_mode:      # the whole workload fits the CPU leg: check the whole map, too
+                out["parity_full_size"] = full_size_parity(m, torch, origin, host_pts, P, pts, stream, dense=(wname == "S5"))
+                parity_failed = not out["parity_full_size"]["ok"]
         elif world == 1:
             out["cpu_baseline"] = None
         if a.check:
@@ -931,6 +962,9 @@ def main():
         dist.destroy_process_group()
     if retries_timed:
         sys.exit(3)
+    if parity_failed:
+        print("bench.py: ERROR the full-size map differs from the oracle's (parity_full_size.fail)", file=sys.stderr)
+        sys.exit(4)
 
 
 if __name__ == "__main__":

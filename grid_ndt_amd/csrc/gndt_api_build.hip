@@ -163,13 +163,21 @@ int partition_launch(gndt_handle* h, gndt_handle::Pending& P) {
         const double r1 = std::max(2.0, q.fill1_ratio * 1.25);
         const uint64_t cap1w = (uint64_t)(r1 * (double)(n / V)) + 2 * kTile1;
         const uint64_t recs_want = 2 * (uint64_t)n + n / 8 + 2048ull * B + 4096;     // 2 n + 2048 B, and sampling slack
-        if ((uint64_t)V * cap1w > 4 * (uint64_t)n + (1u << 24) || recs_want >= 0xF0000000ull || q.two_level_failures >= 2) {
+        if ((!(tuning().l1_inplace != 0 && R == 1) && (uint64_t)V * cap1w > 4 * (uint64_t)n + (1u << 24)) || recs_want >= 0xF0000000ull ||
+            q.two_level_failures >= 2) {
             q.two_level_ok = false;
             return partition_launch(h, P);                 // (re-enters on the exact path)
         }
         const uint32_t cap1 = (uint32_t)cap1w;
-        P.mean1 = (double)(n / V);
-        if ((rc = grow_buf(h, q.recs1, q.rec1_cap, (uint64_t)V * cap1))) return rc;
+        // Level 1 in place (round 5, gndt_partition.hpp tile_partition_inplace): no regions, no reservations, n record slots
+        const bool inplace = tuning().l1_inplace != 0 && R == 1;
+        const uint32_t tiles_a = (uint32_t)((P.n + kTile1 - 1) / kTile1), tiles_b = (uint32_t)((P.n2 + kTile1 - 1) / kTile1);
+        const uint32_t tiles_all = P.records ? tiles_a + tiles_b : (uint32_t)((n + kTile1 - 1) / kTile1);
+        P.mean1 = inplace ? 0.0 : (double)(n / V);
+        if (inplace) {
+            if ((rc = grow_buf(h, q.recs1, q.rec1_cap, (uint64_t)tiles_all * kTile1))) return rc;
+            if ((rc = grow_buf(h, q.tab1, q.tab1_cap, (uint64_t)tiles_all * (F1 + 1) + 8))) return rc;
+        } else if ((rc = grow_buf(h, q.recs1, q.rec1_cap, (uint64_t)V * cap1))) return rc;
         if ((rc = grow_buf(h, q.recs, q.rec_cap, recs_want))) return rc;
         if (B > q.cur_cap) {
             GNDT_NO_CAPTURE(h, "the partition cursors");
@@ -199,29 +207,49 @@ int partition_launch(gndt_handle* h, gndt_handle::Pending& P) {
         const dim3 g1(std::max<uint32_t>(1, std::min<uint32_t>(tiles1, l1_wgs))), g1b(std::max<uint32_t>(1, std::min<uint32_t>(tiles1b, l1_wgs))),
             g2((uint32_t)((cap1 + kTile2 - 1) / kTile2), V);
         // (the last level-1 workgroup to finish lays out the buckets' regions: range_lo / range_cap)
-#define GNDT_L1(SF_, FAN_)                                                                                                  \
-    hipLaunchKernelGGL((k_part2_level1<SF_, FAN_>), g1, dim3(kTileThreads), 0, s, p, (uint64_t)n, P.first_base, gp, B, F1, F2_shift, \
+#define GNDT_L1(SF_, FAN_, INP_)                                                                                            \
+    hipLaunchKernelGGL((k_part2_level1<SF_, FAN_, false, false, INP_>), g1, dim3(kTileThreads), 0, s, p, (uint64_t)n, P.first_base, gp, B, F1, F2_shift, \
                        R, cursor1, cap1, est2, q.recs1, h->d_cnt, q.d_pc, compress, OwnerMap{nullptr, nullptr, 0u}, q.range_lo,     \
-                       q.range_cap, (uint64_t)q.rec_cap)
+                       q.range_cap, (uint64_t)q.rec_cap, q.tab1, 0u)
         // records: the two segments one after the other into the same regions (the cursors carry on; the last launch lays out)
-#define GNDT_L1R(FAN_)                                                                                                      \
+#define GNDT_L1R(FAN_, INP_)                                                                                                \
     do {                                                                                                                    \
-        if (P.n) hipLaunchKernelGGL((k_part2_level1<4, FAN_, true>), g1, dim3(kTileThreads), 0, s, p, (uint64_t)P.n, P.first_base, gp, B, F1, \
+        if (P.n) hipLaunchKernelGGL((k_part2_level1<4, FAN_, true, false, INP_>), g1, dim3(kTileThreads), 0, s, p, (uint64_t)P.n, P.first_base, gp, B, F1, \
                                     F2_shift, R, cursor1, cap1, est2, q.recs1, h->d_cnt, q.d_pc, compress, OwnerMap{nullptr, nullptr, 0u}, \
-                                    P.n2 ? (uint32_t*)nullptr : q.range_lo, q.range_cap, (uint64_t)q.rec_cap);               \
-        if (P.n2) hipLaunchKernelGGL((k_part2_level1<4, FAN_, true>), g1b, dim3(kTileThreads), 0, s, p2, (uint64_t)P.n2, P.first_base, gp, B, \
+                                    P.n2 ? (uint32_t*)nullptr : q.range_lo, q.range_cap, (uint64_t)q.rec_cap, q.tab1, 0u);   \
+        if (P.n2) hipLaunchKernelGGL((k_part2_level1<4, FAN_, true, false, INP_>), g1b, dim3(kTileThreads), 0, s, p2, (uint64_t)P.n2, P.first_base, gp, B, \
                                      F1, F2_shift, R, cursor1, cap1, est2, q.recs1, h->d_cnt, q.d_pc, compress, OwnerMap{nullptr, nullptr, 0u}, \
-                                     q.range_lo, q.range_cap, (uint64_t)q.rec_cap);                                          \
+                                     q.range_lo, q.range_cap, (uint64_t)q.rec_cap, q.tab1, tiles_a);                         \
     } while (0)
-        if (P.records) { if (wide) GNDT_L1R(512); else GNDT_L1R(256); }
-        else if (stride_bytes == 12) { if (wide) GNDT_L1(3, 512); else GNDT_L1(3, 256); }
-        else { if (wide) GNDT_L1(4, 512); else GNDT_L1(4, 256); }
+        if (inplace) {
+            if (P.records) { if (wide) GNDT_L1R(512, true); else GNDT_L1R(256, true); }
+            else if (stride_bytes == 12) { if (wide) GNDT_L1(3, 512, true); else GNDT_L1(3, 256, true); }
+            else { if (wide) GNDT_L1(4, 512, true); else GNDT_L1(4, 256, true); }
+        } else {
+            if (P.records) { if (wide) GNDT_L1R(512, false); else GNDT_L1R(256, false); }
+            else if (stride_bytes == 12) { if (wide) GNDT_L1(3, 512, false); else GNDT_L1(3, 256, false); }
+            else { if (wide) GNDT_L1(4, 512, false); else GNDT_L1(4, 256, false); }
+        }
 #undef GNDT_L1
 #undef GNDT_L1R
         HIP_TRY(h, hipGetLastError());
         mark(h, 2, s);
         mark(h, 3, s);
-        if (wide)
+        if (inplace) {
+            // a chunk = G consecutive level-1 tiles whose segments of one region fill a level-2 tile to l2_fill_pct on a balanced cloud
+            const uint32_t G = (uint32_t)std::min<uint64_t>(kGatherMaxG, std::max<uint64_t>(1, (uint64_t)tuning().l2_fill_pct * kTile2 * F1 / (100 * kTile1)));
+            uint32_t steps = 0;
+            while ((1u << steps) < G) ++steps;
+            const uint32_t rf = tuning().l2_region_fast ? 1u : 0u;
+            const uint32_t nchunks = (tiles_all + G - 1) / G;
+            const dim3 g2g((uint32_t)std::min<uint64_t>((uint64_t)nchunks * F1, tuning().l2_wgs));      // persistent: four resident per CU
+            if (wide)
+                hipLaunchKernelGGL(k_part2_level2_gather<512>, g2g, dim3(kTileThreads), 0, s, (const float4*)q.recs1, (const uint16_t*)q.tab1, tiles_all, F1, G,
+                                   steps, gp, B, F2, cursor2, q.range_lo, q.range_cap, q.recs, q.d_pc, rf, nchunks);
+            else
+                hipLaunchKernelGGL(k_part2_level2_gather<256>, g2g, dim3(kTileThreads), 0, s, (const float4*)q.recs1, (const uint16_t*)q.tab1, tiles_all, F1, G,
+                                   steps, gp, B, F2, cursor2, q.range_lo, q.range_cap, q.recs, q.d_pc, rf, nchunks);
+        } else if (wide)
             hipLaunchKernelGGL(k_part2_level2<512>, g2, dim3(kTileThreads), 0, s, q.recs1, cursor1, cap1, R, gp, B, F2, cursor2,
                                q.range_lo, q.range_cap, q.recs, q.d_pc);
         else
@@ -353,11 +381,14 @@ int partition_launch(gndt_handle* h, gndt_handle::Pending& P) {
     unsigned long long* dbg = tuning().stamps ? q.dbg : nullptr;
     const bool grouped = true;          // k_bucket_direct stages a column's rows next to each other
     const uint32_t fp_mask = (1u << tuning().fp_bits) - 1u;
+    // record pairs interleaved over the waves (gndt_bucket3.hpp) unless the last build of this handle counted next to no adjacent
+    // records of one node: on by default — a cloud with locality gains 11-14 % of its bucket kernel, one without loses 2 %
+    const uint32_t interleave = tuning().interleave >= 0 ? (uint32_t)(tuning().interleave != 0) : (q.pair_ratio < 0.0 || q.pair_ratio > 0.02 ? 1u : 0u);
     {
         // k_bucket_direct (gndt_bucket3.hpp): 512-slot tables with two workgroups per CU, 1024-slot tables on a retry
 #define GNDT_LAUNCH_DIRECT(T_, H_, S_)                                                                                          \
     hipLaunchKernelGGL((k_bucket_direct<T_, H_, S_>), bgrid, dim3(T_), 0, s, bucket_recs, ranges, B, gp, q.stage,    \
-                       (uint32_t)(S_ ? h->st_cap : q.stage_cap), q.ord_cf, q.ord_idx, order, h->d_cnt, q.d_pc, dbg, stats_out, fp_mask)
+                       (uint32_t)(S_ ? h->st_cap : q.stage_cap), q.ord_cf, q.ord_idx, order, h->d_cnt, q.d_pc, dbg, stats_out, fp_mask, interleave)
         if (bslots == 1024) { if (P.stats_only) GNDT_LAUNCH_DIRECT(1024, 1024, true); else GNDT_LAUNCH_DIRECT(1024, 1024, false); }
         else { if (P.stats_only) GNDT_LAUNCH_DIRECT(GNDT_DIRECT_THREADS, 512, true); else GNDT_LAUNCH_DIRECT(GNDT_DIRECT_THREADS, 512, false); }
 #undef GNDT_LAUNCH_DIRECT
@@ -519,6 +550,7 @@ int partition_resolve(gndt_handle* h) {
         }
         if (!again) {
             q.nodes_learned = (uint64_t)h->h_cnt->num_nodes + h->h_cnt->num_nodes / 5;
+            if (P.n + P.n2) q.pair_ratio = 2.0 * (double)q.h_pc->pairs / (double)(P.n + P.n2);
             // the larger tables are remembered only if the small ones failed although the estimate was adequate (a first build
             // without a hint guesses n / 4 nodes: its failure says nothing about the cloud)
             const bool est_was_fine = P.est_reliable && P.est0 >= (uint64_t)h->h_cnt->num_nodes;
@@ -652,6 +684,7 @@ int gndt_reserve(gndt_handle* h, uint64_t max_points, uint64_t max_nodes) {
     constexpr uint64_t kTile1 = (uint64_t)kTileThreads * kTilePer1;
     if ((rc = grow_buf(h, q.recs, q.rec_cap, 2 * n + n / 8 + 2048ull * Bmax + 4096))) return rc;                    // two-level (covers the exact partition's n)
     if ((rc = grow_buf(h, q.recs1, q.rec1_cap, 4 * n + (1u << 24) + (uint64_t)kMaxFan * (4096 + 2 * kTile1)))) return rc;   // level-1 regions at their ceiling / one-level rooms
+    if ((rc = grow_buf(h, q.tab1, q.tab1_cap, (n / kTile1 + 4) * (uint64_t)(kMaxFan + 1) + 8))) return rc;                   // level 1 in place: the tiles' digit offsets
     const uint64_t Bexact = std::min<uint64_t>(Bmax, kMaxBuckets);
     if ((rc = grow_buf(h, q.hist, q.hist_cap, (uint64_t)kPartWgs * Bexact))) return rc;
     if (Bexact > q.bucket_cap) {

@@ -21,6 +21,11 @@ Tuning parse_tuning() {
     t.bucket_slots = geti("GNDT_BUCKET_SLOTS", t.bucket_slots);
     t.two_level = geti("GNDT_TWO_LEVEL", t.two_level);
     t.l1_wgs = (uint32_t)geti("GNDT_L1_WGS", (int)t.l1_wgs);
+    t.l1_inplace = geti("GNDT_L1_INPLACE", t.l1_inplace);
+    t.interleave = geti("GNDT_INTERLEAVE", t.interleave);
+    t.l2_region_fast = geti("GNDT_L2_ORDER", t.l2_region_fast);
+    t.l2_wgs = (uint32_t)std::max(1, geti("GNDT_L2_WGS", (int)t.l2_wgs));
+    t.l2_fill_pct = std::min(100, std::max(10, geti("GNDT_L2_FILL", t.l2_fill_pct)));
     if (getenv("GNDT_BUCKET_WGS")) t.bucket_wgs = (uint32_t)atoi(getenv("GNDT_BUCKET_WGS"));
     if (getenv("GNDT_TILE_RATIO")) t.tile_ratio = atof(getenv("GNDT_TILE_RATIO"));
     t.owner_locality = geti("GNDT_OWNER_LOCALITY", t.owner_locality);
@@ -94,7 +99,7 @@ int check_ready(gndt_handle* h) {
 
 void free_part(gndt_handle* h) {
     auto& q = h->part;
-    void* ptrs[] = {q.recs, q.recs1, q.cursors, q.range_lo, q.range_hi, q.range_cap, q.hist, q.totals, q.bucket_base, q.stage, q.ord_cf, q.ord_idx, q.inv, q.row_of, q.row_ncol,
+    void* ptrs[] = {q.recs, q.recs1, q.tab1, q.cursors, q.range_lo, q.range_hi, q.range_cap, q.hist, q.totals, q.bucket_base, q.stage, q.ord_cf, q.ord_idx, q.inv, q.row_of, q.row_ncol,
                     q.bitmap, q.word_weight, q.word_base, q.bsum_words, q.ncol_at, q.d_pc, q.dbg};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -186,6 +191,7 @@ int stage_host_input(gndt_handle* h, const void* xyz_host, size_t n, size_t stri
         HIP_TRY(h, hipMemcpyAsync(h->stage, xyz_host, bytes, hipMemcpyHostToDevice, s));
         return GNDT_OK;
     }
+    GNDT_NO_CAPTURE(h, "the pinned bounce buffers of a pageable host input");     // (allocated lazily and waited on below)
     for (int b = 0; b < 2; ++b) {
         if (!h->bounce[b]) HIP_TRY(h, hipHostMalloc(&h->bounce[b], kChunk));
         if (!h->bounce_ev[b]) HIP_TRY(h, hipEventCreateWithFlags(&h->bounce_ev[b], hipEventDisableTiming));
@@ -196,7 +202,9 @@ int stage_host_input(gndt_handle* h, const void* xyz_host, size_t n, size_t stri
     for (size_t off = 0; off < bytes; off += kChunk, ++i) {
         const int b = (int)(i & 1);
         const size_t len = std::min(kChunk, bytes - off);
-        if (i >= 2) HIP_TRY(h, hipEventSynchronize(h->bounce_ev[b]));      // the copy that last used this buffer has left it
+        // the copy that last used this buffer has left it — also the PREVIOUS call's (a call that failed between staging and its
+        // sync leaves its copies in flight; an event never recorded is complete)
+        HIP_TRY(h, hipEventSynchronize(h->bounce_ev[b]));
         memcpy(h->bounce[b], src + off, len);
         HIP_TRY(h, hipMemcpyAsync(dst + off, h->bounce[b], len, hipMemcpyHostToDevice, s));
         HIP_TRY(h, hipEventRecord(h->bounce_ev[b], s));

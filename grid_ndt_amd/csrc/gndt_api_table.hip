@@ -74,6 +74,8 @@ int do_reset(gndt_handle* h, hipStream_t s) {
     h->stream_pos = 0;
     h->nodes_bound = 0;
     h->incr_ok = false;
+    // (deferred-emit frames that nobody read belong to the map that has just been cleared)
+    h->emit_pending = false; h->pending_words = 0; h->deferred_captured = false;
     return GNDT_OK;
 }
 
@@ -151,7 +153,9 @@ int do_finalize(gndt_handle* h, hipStream_t s, bool incremental = false, uint64_
     // (k_small_finalize) instead of the six kernels below.  The host goes by what the last resolved build of this handle had; a
     // map that turns out larger raises PartCounters::small_fallback and gndt_sync runs the regular path (table_refinalize).
     h->small_used = false;
-    if (!incremental && advance == 0 && h->small_ok && h->table_nodes_seen && h->table_nodes_seen <= 900u) {
+    // (not while deferred frames wait for their rows: the read that follows would run the ordering pass over staging rows and
+    //  order arrays this kernel does not write, and overwrite its rows)
+    if (!incremental && advance == 0 && h->small_ok && h->table_nodes_seen && h->table_nodes_seen <= 900u && !h->emit_pending && !h->deferred_captured) {
         hipLaunchKernelGGL(k_small_finalize, dim3(1), dim3(kSmallMapNodes), 0, s, T, gp, h->out, q.row_ncol, h->d_cnt, q.d_pc, h->h_cnt, q.h_pc,
                            raise_to, (uint32_t)std::min<uint64_t>(h->out_cap, 0xFFFFFFFFull));
         HIP_TRY(h, hipGetLastError());
@@ -199,7 +203,10 @@ int do_finalize(gndt_handle* h, hipStream_t s, bool incremental = false, uint64_
         HIP_TRY(h, hipGetLastError());
         for (int i = 5; i <= 9; ++i) mark(h, i, s);
         h->emit_pending = true;
-        h->deferred_captured = h->capturing;
+        // STICKY: a deferred frame recorded into a hipGraph may be replayed at any time later, unseen by the host, so every read from
+        // here on emits — an eager frame in between must not clear it (replay, eager frame, sync, replay, export returned
+        // stale rows with GNDT_OK).  Cleared by a reset and by gndt_set_deferred_emit(0).
+        h->deferred_captured = h->deferred_captured || h->capturing;
         h->pending_words = std::max(h->pending_words, words);
         h->results_valid = true;
         ++h->result_serial;
@@ -211,7 +218,8 @@ int do_finalize(gndt_handle* h, hipStream_t s, bool incremental = false, uint64_
     //  bookkeeping: no copy commands and no one-thread launches behind a frame)
     // (rows left un-emitted by deferred frames: everything is placed and emitted again, not only what this frame moved)
     if ((rc = launch_order_and_emit(h, words, 4, s, false, true, true, advance, incremental && !h->emit_pending && !h->deferred_captured))) return rc;
-    h->emit_pending = false; h->pending_words = 0; h->deferred_captured = false;
+    h->emit_pending = false;
+    h->pending_words = h->deferred_captured ? std::max(h->pending_words, words) : 0;      // (a captured deferred frame may still be replayed: reads keep emitting)
     h->results_valid = true;
     ++h->result_serial;
     h->last_stream = s;
@@ -461,6 +469,10 @@ int gndt_update_device(gndt_handle* h, const void* xyz_dev, size_t n, size_t str
 int gndt_set_deferred_emit(gndt_handle* h, int on) {
     if (!h) return GNDT_ERR_INVALID;
     h->defer_emit = on != 0;
+    if (!on && h->deferred_captured) {      // frames a graph replayed since the last read get their rows at the next read; after that, none are deferred
+        h->emit_pending = true;
+        h->deferred_captured = false;
+    }
     return GNDT_OK;
 }
 

@@ -68,6 +68,7 @@ struct BucketLds3 {           // 70 KB at H = 512: two workgroups per CU
     uint32_t ccnt[H];           // nodes of the column in this column slot; after the prefix (first row inside the bucket) << 16 | nodes
     uint32_t n_nodes, n_cols, n_slopes, stage_base, overflow, err_range, row_cursor;
     uint32_t clash;             // records whose fingerprint named another node (they went on with the key itself)
+    uint32_t n_pairs;           // lanes whose two adjacent records fell into one node (what the host reads the cloud's locality from)
 };
 // Workgroup barrier that orders LDS traffic ONLY (__syncthreads() also waits for the wave's global stores): the phases of
 // the bucket kernels hand over LDS contents, their global stores are read by later kernels.
@@ -282,7 +283,7 @@ __device__ __forceinline__ void bucket_tables_init(Lds& L) {
         L.chead[s] = kNoNode;
         L.ccnt[s] = 0;
     }
-    if (tid == 0) { L.n_nodes = 0; L.n_cols = 0; L.n_slopes = 0; L.stage_base = 0; L.overflow = 0; L.err_range = 0; L.row_cursor = 0; L.clash = 0; }
+    if (tid == 0) { L.n_nodes = 0; L.n_cols = 0; L.n_slopes = 0; L.stage_base = 0; L.overflow = 0; L.err_range = 0; L.row_cursor = 0; L.clash = 0; L.n_pairs = 0; }
 }
 
 // The accumulate phase once more for a bucket whose fingerprints clashed: one record per thread and step, every step of the
@@ -324,7 +325,7 @@ __device__ __forceinline__ void bucket_direct_one(BucketLds3<H>& L, const uint32
                                                   uint32_t* __restrict__ ord_cf, uint32_t* __restrict__ ord_idx,
                                                   const ColumnOrder& O, Counters* __restrict__ cnt,
                                                   PartCounters* __restrict__ pc, unsigned long long* __restrict__ dbg,
-                                                  const StatsOut& so, const uint32_t fp_mask) {
+                                                  const StatsOut& so, const uint32_t fp_mask, const uint32_t interleave) {
     static_assert(H <= 65535, "node numbers are kept in 16 bits");
     constexpr int U = H <= 512 ? GNDT_DIRECT_U : 2;    // records in flight per thread
     const int tid = threadIdx.x;
@@ -349,10 +350,19 @@ __device__ __forceinline__ void bucket_direct_one(BucketLds3<H>& L, const uint32
 #else
 #define GNDT_SUB(k) do { } while (0)
 #endif
+    // Which records a lane takes.  `interleave`: the lanes of ONE wave hold record pairs T / 64 pairs apart, the pairs in between go
+    // to the other waves.  Clouds with locality keep their order inside a bucket, so records next to each other in the stream
+    // belong to the same node more often than not (S3 / S5: half of all records follow one of their own node, a window of 128
+    // records holds ~35 nodes); with consecutive pairs in consecutive lanes those meet inside ONE LDS atomic instruction, which
+    // then serialises on the address: bucket kernel S3 32 M 681 -> 584 us, S5 355 -> 316 us (round 5).  A cloud without locality
+    // (the bench scene) gains nothing and pays ~2 % for loads that cover 64 half-used lines each (the other waves take the other
+    // halves), so the host turns it off once a build has counted (PartCounters::pairs) that adjacent records rarely share a node.
+    const int ptid = interleave ? lane * (T / 64) + (tid >> 6) : tid;
+    uint32_t npairs = 0;                                    // (wave-uniform) lanes whose two records fell into one node
     float4 nxt[U];
     if (lo < hi) {
 #pragma unroll
-        for (int j = 0; j < U; ++j) nxt[j] = recs[min(lo + (uint32_t)(U * tid + j), hi - 1u)];
+        for (int j = 0; j < U; ++j) nxt[j] = recs[min(lo + (uint32_t)(U * ptid + j), hi - 1u)];
     }
     for (uint32_t base = lo; base < hi; base += (uint32_t)(U * T)) {
         // A table beyond its fill limit is given up at once: the build is re-run with more room anyway, and probing a nearly
@@ -361,10 +371,10 @@ __device__ __forceinline__ void bucket_direct_one(BucketLds3<H>& L, const uint32
         float4 rec[U];
         bool use[U];
 #pragma unroll
-        for (int j = 0; j < U; ++j) { rec[j] = nxt[j]; use[j] = base + (uint32_t)(U * tid + j) < hi; }
+        for (int j = 0; j < U; ++j) { rec[j] = nxt[j]; use[j] = base + (uint32_t)(U * ptid + j) < hi; }
         if (base + (uint32_t)(U * T) < hi) {       // uniform
 #pragma unroll
-            for (int j = 0; j < U; ++j) nxt[j] = recs[min(base + (uint32_t)(U * T + U * tid + j), hi - 1u)];
+            for (int j = 0; j < U; ++j) nxt[j] = recs[min(base + (uint32_t)(U * T + U * ptid + j), hi - 1u)];
         }
         PointKey k[U];
         uint32_t slot[U], fpw[U];
@@ -385,6 +395,7 @@ __device__ __forceinline__ void bucket_direct_one(BucketLds3<H>& L, const uint32
         for (int j = 0; j < U; ++j) W0[j] = lds_index_window(L, slot[j]);
         const bool pair = U >= 2 && use[0] && use[U - 1] && pkey[0] == pkey[U - 1];      // both records in one node: one contribution
         if (pair) use[U - 1] = false;
+        npairs += (uint32_t)__popcll(__ballot(pair));
         // a wave whose records all sit in ONE node (dense cells, the zero padding): summed across the wave, one lane adds
         const bool one_node = __all(U >= 2 ? pair : use[0]) && __all(pkey[0] == __shfl(pkey[0], 0, 64));
         if (one_node) use[0] = lane == 0;
@@ -443,6 +454,7 @@ __device__ __forceinline__ void bucket_direct_one(BucketLds3<H>& L, const uint32
 #ifdef GNDT_DIRECT_SUBSTAMPS
     if (dbg && tid == 0) { for (int k = 0; k < 4; ++k) dbg[(size_t)bucket * 16 + 8 + k] = st_acc[k]; }
 #endif
+    if (lane == 0 && npairs) atomicAdd(&L.n_pairs, npairs);
     __syncthreads();
     if (L.clash && !L.overflow) {            // uniform; ~1 bucket in 10^4: a fingerprint named the wrong node and the sums went there
         __syncthreads();                     // (everybody has read the flags)
@@ -465,6 +477,7 @@ __device__ __forceinline__ void bucket_direct_one(BucketLds3<H>& L, const uint32
     uint32_t stage_base_reg = 0;
     if (tid == T - 1) stage_base_reg = atomicAdd(&cnt->num_nodes, M);
     if (tid == 0 && L.err_range) atomicAdd(&cnt->err_key_range, L.err_range);
+    if (tid == 64 && L.n_pairs) atomicAdd(&pc->pairs, L.n_pairs);
 
     if constexpr (STATS) {
         if (tid == T - 1) L.stage_base = stage_base_reg;
@@ -637,12 +650,12 @@ __global__ void __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(H <= 512
                                                      StageRow* __restrict__ stage, uint32_t stage_cap,
                                                      uint32_t* __restrict__ ord_cf, uint32_t* __restrict__ ord_idx, ColumnOrder O,
                                                      Counters* __restrict__ cnt, PartCounters* __restrict__ pc,
-                                                     unsigned long long* __restrict__ dbg, StatsOut so, uint32_t fp_mask) {
+                                                     unsigned long long* __restrict__ dbg, StatsOut so, uint32_t fp_mask, uint32_t interleave) {
     __shared__ BucketLds3<H> L;
     for (uint32_t bucket = blockIdx.x; bucket < num_buckets; bucket += gridDim.x) {
         uint32_t lo, hi;
         bucket_range(ranges, bucket, lo, hi);
-        bucket_direct_one<T, H, STATS>(L, bucket, recs, lo, hi, P, stage, stage_cap, ord_cf, ord_idx, O, cnt, pc, dbg, so, fp_mask);
+        bucket_direct_one<T, H, STATS>(L, bucket, recs, lo, hi, P, stage, stage_cap, ord_cf, ord_idx, O, cnt, pc, dbg, so, fp_mask, interleave);
         lds_barrier();          // the LDS tables are re-initialised by the next bucket
     }
 }

@@ -99,6 +99,7 @@ struct gndt_handle {
         uint64_t rec_cap = 0;      float4* recs = nullptr;
         // two-level partition: level-1 regions, cursors of both levels, record ranges of the fine buckets
         uint64_t rec1_cap = 0;     float4* recs1 = nullptr;
+        uint64_t tab1_cap = 0;     uint16_t* tab1 = nullptr;     // level 1 in place: digit offsets of every tile ([tiles][F1 + 1])
         uint64_t cur_cap = 0;      uint32_t *cursors = nullptr, *range_lo = nullptr, *range_hi = nullptr, *range_cap = nullptr;
         int two_level_failures = 0;   // builds whose regions overflowed although sized from the sample
         bool one_level_ok = true;  // cleared when a bucket of the one-level tile partition (small clouds) overflowed its fixed room
@@ -122,6 +123,7 @@ struct gndt_handle {
         int good_slots = 0; uint64_t good_est = 0, good_n = 0;   // table size / estimate that worked last time
         int good_load = 0;          //   ... and the table load (percent) if it had to be lowered (0: the default)
         int load_pct = 60;          // average LDS-table load (percent) the bucket count aims at
+        double pair_ratio = -1.0;   // share of the last resolved build's records that sat next to one of their own node inside a bucket (< 0: unknown)
         uint64_t retries_total = 0; // builds re-run because a table / region / staging area was too small (gndt_debug_retry_count)
     } part;
     // cost-map flood over the finished grid (gndt_cost.hpp)
@@ -232,6 +234,11 @@ struct Tuning {
     int bucket_slots = 0;        // GNDT_BUCKET_SLOTS   LDS table of the first attempt (0 = 512, 1024 on a retry)
     int two_level = -1;          // GNDT_TWO_LEVEL      0 = never use the two-level partition
     uint32_t l1_wgs = 1024;      // GNDT_L1_WGS         persistent level-1 workgroups
+    int interleave = -1;         // GNDT_INTERLEAVE     bucket kernel: record pairs interleaved over the waves (1), consecutive (0), by the last build's locality (-1)
+    int l1_inplace = 0;          // GNDT_L1_INPLACE     two-level partition: level 1 writes sorted tiles in place, level 2 gathers segments (0: reserved regions)
+    uint32_t l2_wgs = 1024;      // GNDT_L2_WGS         persistent workgroups of the gathering level 2
+    int l2_region_fast = 1;      // GNDT_L2_ORDER       gathering level 2: concurrent workgroups share tiles (1) or a region (0)
+    int l2_fill_pct = 85;        // GNDT_L2_FILL        ... and how full a level-2 tile the segments of a chunk are meant to make (percent)
     uint32_t bucket_wgs = 0xFFFFFFFFu;   // GNDT_BUCKET_WGS   persistent bucket workgroups (default: one per bucket)
     double tile_ratio = 48.0;    // GNDT_TILE_RATIO     AUTO takes strategy TILE from this many points per partial on (sampled; the
                                  //                     measured crossover, profiles/r02_tile_calibration.json)
@@ -260,6 +267,11 @@ void tuning_force_fp_bits(int bits); // tests: narrow the fingerprint so that cl
 // caller answers with gndt_reserve() (or an eager build of the same size) before capturing.
 #define GNDT_NO_CAPTURE(h, what)                                                                                              \
     do {                                                                                                                      \
+        {   /* asked of the stream itself: entry points that enqueue nothing (gndt_sync, gndt_export*) do not pass use_stream, and a flag left by the last captured call would refuse them */ \
+            hipStreamCaptureStatus c__ = hipStreamCaptureStatusNone;                                                          \
+            (void)hipStreamIsCapturing((h)->last_stream, &c__);                                                               \
+            (h)->capturing = c__ != hipStreamCaptureStatusNone;                                                               \
+        }                                                                                                                     \
         if ((h)->capturing) {                                                                                                 \
             (h)->err = std::string(what) + " must be (re)allocated or waited for, which a stream under hipGraph capture cannot do: "  \
                        "call gndt_reserve(max_points, max_nodes) — or build a cloud of this size eagerly — before capturing";  \

@@ -1,6 +1,7 @@
 """GPU tier: BASELINE.json configs[2] and configs[4] at FULL size on one GPU — S3, 100 M LiDAR-ordered terrain points at 0.2 m,
-and S5, the 20 M-point two-storey site at 0.1 m whose last 3 M points sit at (0,0,0).  The oracle does not finish such clouds in
-seconds, so the checks are the size-independent ones the domain offers (every point binned once, unique keys, reference order
+and S5, the 20 M-point two-storey site at 0.1 m whose last 3 M points sit at (0,0,0) — and configs[1], the 10 M-point bench scene.
+Round 5: every node of each of these maps is compared with the oracle's OpenMP port (it finishes them in seconds on the GPU box's
+host cores), labels exact; beside it stay the size-independent checks the domain offers (every point binned once, unique keys, reference order
 monotone, labels consistent with counts), a sample of nodes against an independent numpy fp64 recomputation (mean, scatter,
 lambda_min) and, on a 16 M-point prefix, strategy PARTITION == strategy ATOMIC row for row."""
 import numpy as np
@@ -74,6 +75,41 @@ def _sample_check(cloud, out, keys, has, gl, zl, picks=200, seed=0, max_count=20
             assert abs(lam - ev[0]) <= 1e-5 * np.trace(S) + 1e-12
 
 
+def _oracle_check(cloud, out, gl, zl, dense=False, interval=0.08, label_cap=8e-5):
+    """EVERY node of a full-size map against the oracle (OpenMP port of the reference path, all host threads, with its fp64 truth):
+    keys / counts / first-seen order / labels exact, moments and eigen results under the gates of tests/parity.py (VERDICT r4
+    item 2: until round 5 the driver-run tier compared full-size maps by structure and 200 sampled nodes only).
+    `dense`: the cloud has nodes of 10^5 .. 10^6 points, on which the reference's sequential fp32 sums are themselves percent off."""
+    from oracle import oracle
+    from tests import parity
+    ref = oracle.build_grid(cloud, gl, zl, interval, "slope", mode=oracle.MODE_INT_OPENMP, threads=oracle.max_threads(), export=True)
+    rep = parity.compare(out, ref, "slope", dense=dense, interval=interval)
+    assert rep["ok"], "full-size parity failed: " + "; ".join(rep["fail"])
+    if dense:      # the dense gate's label exception, reported and capped as in tests/test_gpu_fuzz.py
+        assert rep.get("labels_within_margin", 0) <= label_cap * rep["num_nodes"] + 2, rep
+    else:
+        assert rep["label_mismatch_slope"] == rep["label_mismatch_down"] == rep["label_mismatch_has_stats"] == 0
+    return rep
+
+
+def test_full_size_uniform_10M_every_node_against_the_oracle():
+    """BASELINE configs[1] — the configuration the metric is quoted on — with ALL of its 796 k nodes compared with the oracle."""
+    import torch
+    import grid_ndt_amd as g
+    cloud = scenes.uniform_box(10_000_000)
+    m = g.TwoDmap(0.5, 0.5, max_nodes_hint=1 << 20)
+    m.setInterval(0.08)
+    m.setCloudFirst(cloud[0])
+    t = torch.from_numpy(cloud[1:]).cuda()
+    for _ in range(2):                          # (the second build is the steady-state one bench.py times)
+        m.create2DMap("slope", t)
+        m.sync()
+    out = m.export()
+    assert m.last_strategy() == 2
+    rep = _oracle_check(cloud, out, 0.5, 0.5)
+    print("S2 10M vs oracle:", {k: rep[k] for k in ("num_nodes", "cov_err", "cov_err_truth", "rough_err", "normal_err") if k in rep})
+
+
 @pytest.fixture(scope="module")
 def terrain_100m():
     return scenes.terrain_cloud(100_000_000)
@@ -97,6 +133,13 @@ def test_full_size_terrain_100M(terrain_100m):
     assert m.retry_count() == before and (n2, k2, s2) == (out["num_nodes"], out["num_columns"], out["num_slopes"])
     keys, has = _structure_checks(out, n)
     _sample_check(cloud, out, keys, has, 0.2, 0.2)
+    # All 10.9 M nodes.  Keys / counts / order / has_stats exact.  Slope / down labels: round 5's first run of this comparison found
+    # 2 of the 10.9 M that differ from the fp32-sequential oracle — nodes whose |mean-z difference| sits within an fp32 rounding of the
+    # interval, where the reference's own answer depends on the ORDER of its fp32 additions.  They are held to the dense gate's
+    # rule (the label the reference's rule gives on the exact centroids, or a decision within 1e-5 of the interval) and capped at
+    # one node in a million; everything else is exact.
+    rep = _oracle_check(cloud, out, 0.2, 0.2, dense=True, label_cap=1e-6)
+    print("S3 100M vs oracle:", {k: rep[k] for k in ("num_nodes", "labels_within_margin", "labels_on_the_margin", "cov_err_truth", "rough_err", "normal_err") if k in rep})
     # a 16 M-point prefix: the LDS-resident pipeline and the HBM node table agree row for row
     pre = t[:16_000_000]
     res = []
@@ -150,6 +193,10 @@ def test_full_size_site_20M_with_its_three_million_point_origin_node():
     if others.size == 0:
         assert np.all(out["cov"][i] == 0) and np.all(out["mean"][i] == 0) and out["rough"][i] == np.float32(0.01)
     _sample_check(cloud, out, keys, has, 0.1, 0.1, seed=1)
+    # every node against the oracle; the dense gate only because of the 3 M-point padding node and the near-sensor cells (its label
+    # exception is capped inside)
+    rep = _oracle_check(cloud, out, 0.1, 0.1, dense=True)
+    print("S5 20M vs oracle:", {k: rep[k] for k in ("num_nodes", "labels_within_margin", "labels_on_the_margin", "cov_err_truth", "rough_err") if k in rep})
 
 
 @pytest.mark.parametrize("deferred", [False, True], ids=["dense_rows_every_frame", "deferred_emit"])

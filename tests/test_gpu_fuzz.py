@@ -152,9 +152,12 @@ def test_one_handle_builds_a_sequence_of_unrelated_clouds(seed):
     assert not stats["failures"], stats["failures"]
     assert stats["builds"] >= 24
     # The dense gate lets a slope / down label differ from the fp32 oracle's where it is the label the reference's rule gives on the
-    # EXACT centroids (tests/parity.py).  That exception is reported and capped: more than 1e-5 of the nodes passing on it would mean
-    # the gate, not the reference's fp32 rounding, is doing the work (long campaigns: 1 520 of 208 M, 1 068 of 104 M nodes).
+    # EXACT centroids (tests/parity.py).  That exception is reported and capped at 8e-5 of the nodes (the long campaigns measured
+    # 1.0e-5 of 104 M nodes and 5.9e-5 of 617 M with denser clouds, profiles/r04_fuzz_campaign*.json; ADVICE r4: the assertion said
+    # 1e-4 under a comment that said 1e-5): more would mean the gate, not the reference's fp32 rounding, is doing the work.
     share = stats.get("labels_within_margin", 0) / max(1, stats.get("nodes", 1))
     print("labels that differ from the fp32 oracle and equal the rule on exact centroids:", stats.get("labels_within_margin", 0), "of",
           stats.get("nodes", 0), "nodes; decided within 1e-5 of the interval:", stats.get("labels_on_the_margin", 0))
-    assert share <= 1e-4, (stats.get("labels_within_margin"), stats.get("nodes"))     # (round 4's campaigns: 1.0e-5 of 104 M nodes, 4.1e-5 of 617 M with denser clouds)
+    assert share <= 8e-5, (stats.get("labels_within_margin"), stats.get("nodes"))
+    # (about a third of them are decided within 1e-5 of the interval on the exact centroids — 8 930 of 27 436 in the long campaign —; the
+    #  rest are dense nodes whose SEQUENTIAL fp32 mean in the oracle is further than that from the exact mean: reported, not asserted)

@@ -418,6 +418,43 @@ def test_deferred_emit_stream_eager_and_replayed_equals_batch_build():
         del m
 
 
+def test_deferred_emit_replay_eager_frame_sync_replay_export():
+    """a deferred gndt_update recorded into a hipGraph, then — on the same handle — a replay, an EAGER frame,
+    a read, another replay and an export.  The eager frame used to clear the handle's "a captured deferred frame exists" flag,
+    so the read after the last replay skipped the ordering + emit pass and returned the new node count over stale rows with
+    GNDT_OK.  The flag is sticky now: every read of such a handle emits."""
+    import torch
+    import grid_ndt_amd as g
+    nf, ppf = 6, 30000
+    frames = scenes.terrain_frames(nf, first_pose=3, points_per_frame=ppf)
+    cloud = np.concatenate([frames[:1], frames], 0)
+    host = [torch.from_numpy(frames[f * ppf:(f + 1) * ppf]).cuda() for f in range(nf)]
+    m = g.TwoDmap(TERRAIN["grid_len"], TERRAIN["z_len"], strategy=1, max_nodes_hint=200000, max_points_hint=nf * ppf)
+    m.setInterval(TERRAIN["slope_interval"])
+    m.setCloudFirst(cloud[0])
+    m.set_deferred_emit(True)
+    buf = torch.empty(ppf, 3, dtype=torch.float32, device="cuda")
+    buf.copy_(host[0])
+    m.change2DMap("slope", buf)              # frame 0: full finalisation
+    m.sync()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        m.change2DMap("slope", buf)          # (recorded, not run)
+    buf.copy_(host[1]); graph.replay()       # frame 1: replay
+    torch.cuda.synchronize()
+    buf.copy_(host[2]); m.change2DMap("slope", buf)      # frame 2: eager
+    m.sync()                                              # a read in between
+    parity.assert_parity(m.export(), parity.ref_from_cloud(cloud[:1 + 3 * ppf], TERRAIN))
+    buf.copy_(host[3]); graph.replay()       # frame 3: replay, unseen by the host
+    torch.cuda.synchronize()
+    parity.assert_parity(m.export(), parity.ref_from_cloud(cloud[:1 + 4 * ppf], TERRAIN))
+    buf.copy_(host[4]); graph.replay()
+    buf.copy_(host[5]); m.change2DMap("slope", buf)
+    torch.cuda.synchronize()
+    parity.assert_parity(m.export(), parity.ref_from_cloud(cloud, TERRAIN))
+    del m
+
+
 def test_split_accumulate_finalize_and_stats_roundtrip():
     """accumulate(shard A) + accumulate(shard B) == build(A||B); stats export -> merge into a second
     handle reproduces the same map (the multi-GPU exchange primitive)."""
