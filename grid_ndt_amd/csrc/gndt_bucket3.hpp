@@ -89,12 +89,6 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 // which confirms every step with the key (~1 bucket in 10^4; tests narrow the fingerprint to force it in every bucket).
 constexpr uint32_t kFpShift = 11u, kNfMask = 0x7FFu, kNfPending = 0x7FFu, kNfFull = 0x7FEu;
 constexpr uint32_t kNoNode = 0xFFFFFFFFu;
-__device__ __forceinline__ uint32_t node_fp_word(uint32_t colh, int sz, uint32_t fp_mask) {
-    uint32_t f = __umul24(colh >> 8, 0x6F4F2Bu) ^ __umul24((uint32_t)sz & 0xFFFFFFu, 0xA24BAFu) ^ (colh << 13);
-    f ^= f >> 9;
-    f = (f >> 3) & fp_mask;                          // (fp_mask = 2^21 - 1 unless a test narrows it)
-    return max(f, 1u) << kFpShift;
-}
 // the window of slot h (h & 3 = where a new node of this key looks for room first: spreads the claims of a window's keys)
 template <typename Lds>
 __device__ __forceinline__ uint4 lds_index_window(const Lds& L, uint32_t h) {
@@ -272,6 +266,36 @@ __device__ __forceinline__ uint32_t node_slot3(uint32_t colh, int sz) {
     return g;
 }
 
+// Where a node's search starts in the index (low 11 bits of `slot`, masked by the caller) and its fingerprint word, from ONE short
+// chain over the key (round 5; the bucket kernel is bound by vector-instruction issue, so every instruction per record counts):
+// three full-rate 24-bit multiply-adds, a fold, and one more 24-bit multiply each for the slot and for the fingerprint — 13
+// instructions where column hash + node_slot3 + node_fp_word took 27 and a quarter-rate 32-bit multiply.  The two outputs come from
+// different halves of the folded word (a single 24-bit product carries 24 bits of entropy for 9 window + 21 fingerprint bits:
+// measured 6-15 fingerprint clashes per build; with the second product 0-1, like the old chain).  Windows with more than four nodes,
+// share of all windows, old chain | this one: bench scene 3.7e-3 | 3.2e-4, S3 6.3e-4 | 4.8e-4, S5 1.5e-3 | 6.4e-4.
+__device__ __forceinline__ void node_index_hash(int sx, int sy, int sz, uint32_t fp_mask, uint32_t& slot, uint32_t& fpw) {
+    const uint32_t a = (uint32_t)(sx + 65536), b = (uint32_t)(sy + 65536);      // (|sx|, |sy| <= 65535: 18 bits; the multiplies read 24)
+    uint32_t t = __umul24(a, 0x9E3779u) + __umul24(b, 0x85EBCBu) + __umul24((uint32_t)sz, 0xC2B2AFu);
+    t ^= t >> 15;
+    uint32_t u = __umul24(t, 0x6D2B79u);
+    const uint32_t f = __umul24(t >> 8, 0xA24BAFu);
+    u ^= u >> 13;
+    slot = u;
+    fpw = max((f >> 11) & fp_mask, 1u) << kFpShift;                              // (fp_mask = 2^21 - 1 unless a test narrows it)
+}
+
+// One axis of a record's key and of its offset from the node's centre, from c = ceilf(|p - o| / len) however obtained: the signed
+// index s (axis_from_ceil's) and v = p - (o + (2 s -+ 1) half_len) (axis_centre's, the same single fma).  Spelled for the
+// instruction count: clamp by one median-of-three, 2 c - 1 and the sign in fp32 (exact: c <= 2^21), no integer detour.
+__device__ __forceinline__ void axis_index_offset(float p, float o, float c, float limit, double half_len, double o64, bool& ok, int& s, double& v) {
+    ok = ok && (c <= limit);                                         // (NaN: false — the record is dropped and counted)
+    const float cc = __builtin_amdgcn_fmed3f(c, 1.0f, limit);       // 0 -> 1, beyond the key range -> the limit (ok is false then)
+    const float k = fmaf(cc, 2.0f, -1.0f);
+    const bool pos = p > o;                                          // (strict, as the reference: p == o and p = -0 go to the negative side)
+    s = (int)(pos ? cc : -cc);
+    v = (double)p - fma((double)(pos ? k : -k), half_len, o64);
+}
+
 template <int T, int H, typename Lds>
 __device__ __forceinline__ void bucket_tables_init(Lds& L) {
     const int tid = threadIdx.x;
@@ -300,9 +324,10 @@ __device__ __forceinline__ void accumulate_exact(Lds& L, const float4* __restric
         const float4 rec = recs[min(i, hi - 1u)];
         const PointKey k = point_key_fast(rec.x, rec.y, rec.z, P.ox, P.oy, P.oz, P.grid_len, P.z_len, P.inv_grid, P.inv_z);
         const unsigned long long pkey = pack_key(k.sx, k.sy, k.sz);
-        const uint32_t colh = column_hash(k.sx, k.sy);
+        uint32_t hs, hf;
+        node_index_hash(k.sx, k.sy, k.sz, fp_mask, hs, hf);
         if (use && !k.ok) { atomicAdd(&L.err_range, 1u); use = false; }
-        const uint32_t s = lds_index_find_or_insert_exact<H>(L, node_slot3(colh, k.sz) & (4u * (uint32_t)H - 1u), node_fp_word(colh, k.sz, fp_mask), pkey, use);
+        const uint32_t s = lds_index_find_or_insert_exact<H>(L, hs & (4u * (uint32_t)H - 1u), hf, pkey, use);
         if (!use || s == kNoNode) continue;
         const uint32_t iw = __float_as_uint(rec.w);
         const double v0 = (double)rec.x - fma((double)(2 * k.sx - (k.sx > 0 ? 1 : -1)), hx, ox);
@@ -376,17 +401,30 @@ __device__ __forceinline__ void bucket_direct_one(BucketLds3<H>& L, const uint32
 #pragma unroll
             for (int j = 0; j < U; ++j) nxt[j] = recs[min(base + (uint32_t)(U * T + U * ptid + j), hi - 1u)];
         }
-        PointKey k[U];
         uint32_t slot[U], fpw[U];
         unsigned long long pkey[U];
+        double v0[U], v1[U], v2[U];                   // the record's offset from its node's centre
 #pragma unroll
         for (int j = 0; j < U; ++j) {
-            k[j] = point_key_fast(rec[j].x, rec[j].y, rec[j].z, P.ox, P.oy, P.oz, P.grid_len, P.z_len, P.inv_grid, P.inv_z);
-            pkey[j] = pack_key(k[j].sx, k[j].sy, k[j].sz);
-            const uint32_t colh = column_hash(k[j].sx, k[j].sy);
-            slot[j] = node_slot3(colh, k[j].sz) & (4u * (uint32_t)H - 1u);      // (where the search starts in the index)
-            fpw[j] = node_fp_word(colh, k[j].sz, fp_mask);
-            if (use[j] && !k[j].ok) { atomicAdd(&L.err_range, 1u); use[j] = false; }   // |nz| beyond the key range (x, y: the partition)
+            // point_key_fast + pack_key + axis_centre, fused (same values bit for bit; ~40 vector instructions fewer per record)
+            bool und = false;
+            float cx = axis_ceil_try(rec[j].x, P.ox, P.inv_grid, und);
+            float cy = axis_ceil_try(rec[j].y, P.oy, P.inv_grid, und);
+            float cz = axis_ceil_try(rec[j].z, P.oz, P.inv_z, und);
+            if (und) {                                 // (rare: within ~2 ulp of a cell border the reference's own divide decides)
+                cx = ceilf(fabsf(rec[j].x - P.ox) / P.grid_len);
+                cy = ceilf(fabsf(rec[j].y - P.oy) / P.grid_len);
+                cz = ceilf(fabsf(rec[j].z - P.oz) / P.z_len);
+            }
+            bool ok = true;
+            int sx, sy, sz;
+            axis_index_offset(rec[j].x, P.ox, cx, (float)kMaxXY, hx, ox, ok, sx, v0[j]);
+            axis_index_offset(rec[j].y, P.oy, cy, (float)kMaxXY, hx, oy, ok, sy, v1[j]);
+            axis_index_offset(rec[j].z, P.oz, cz, (float)kMaxZ, hz, oz, ok, sz, v2[j]);
+            pkey[j] = pack_key(sx, sy, sz);
+            node_index_hash(sx, sy, sz, fp_mask, slot[j], fpw[j]);
+            slot[j] &= 4u * (uint32_t)H - 1u;                                     // (where the search starts in the index)
+            if (use[j] && !ok) { atomicAdd(&L.err_range, 1u); use[j] = false; }   // |nz| beyond the key range (x, y: the partition)
         }
         // an early look at the index: the window the hash points at is requested now and looked at after the arithmetic below — the
         // usual case (the node is there: a word carries its fingerprint and its number) costs no wait at all
@@ -401,20 +439,25 @@ __device__ __forceinline__ void bucket_direct_one(BucketLds3<H>& L, const uint32
         if (one_node) use[0] = lane == 0;
         double c[U][9];
         uint32_t cn[U], cf[U];
+        // weighted records (64 or 512 identical points in one: the converters' zero padding) exist in few clouds and, there, in few
+        // waves: a wave without one skips the decoding and the three multiplications by the weight (x 1.0 is exact: same sums)
+        bool any_weight = false;
+#pragma unroll
+        for (int j = 0; j < U; ++j) any_weight = any_weight || (__float_as_uint(rec[j].w) & kWeight64Flag) != 0u;
+        any_weight = __any(any_weight) != 0;
 #pragma unroll
         for (int j = 0; j < U; ++j) {
             const uint32_t iw = __float_as_uint(rec[j].w);
-            // v = p - centre(node): the centre is axis_centre(), spelled so that it costs one convert and one fma per axis
-            const double v0 = (double)rec[j].x - fma((double)(2 * k[j].sx - (k[j].sx > 0 ? 1 : -1)), hx, ox);
-            const double v1 = (double)rec[j].y - fma((double)(2 * k[j].sy - (k[j].sy > 0 ? 1 : -1)), hx, oy);
-            const double v2 = (double)rec[j].z - fma((double)(2 * k[j].sz - (k[j].sz > 0 ? 1 : -1)), hz, oz);
-            const uint32_t wn = record_weight(iw);                // 64 or 512 identical points in one record (exact: powers of two)
-            const double wf = (double)wn;
-            const double w0 = wf * v0, w1 = wf * v1, w2 = wf * v2;
+            double w0 = v0[j], w1 = v1[j], w2 = v2[j];
+            cn[j] = 1u; cf[j] = iw;
+            if (any_weight) {                                     // (wave-uniform)
+                cn[j] = record_weight(iw);                        // exact: powers of two
+                cf[j] = record_index(iw);
+                const double wf = (double)cn[j];
+                w0 = wf * v0[j]; w1 = wf * v1[j]; w2 = wf * v2[j];
+            }
             c[j][0] = w0; c[j][1] = w1; c[j][2] = w2;
-            c[j][3] = w0 * v0; c[j][4] = w0 * v1; c[j][5] = w0 * v2; c[j][6] = w1 * v1; c[j][7] = w1 * v2; c[j][8] = w2 * v2;
-            cn[j] = wn;
-            cf[j] = record_index(iw);
+            c[j][3] = w0 * v0[j]; c[j][4] = w0 * v1[j]; c[j][5] = w0 * v2[j]; c[j][6] = w1 * v1[j]; c[j][7] = w1 * v2[j]; c[j][8] = w2 * v2[j];
         }
         if (pair) {
 #pragma unroll
@@ -573,11 +616,12 @@ __device__ __forceinline__ void bucket_direct_one(BucketLds3<H>& L, const uint32
         // per node instead of ten.  Short columns find the neighbours during the walk, as before.
         const bool tall = ncol > (uint32_t)GNDT_TALL_COLUMN;
         if (tall) {
-            const uint32_t colh = column_hash(sx, sy);
 #pragma unroll
             for (int side = 0; side < 2; ++side) {
                 const int tz = side == 0 ? za : zb;
-                const uint32_t t = lds_index_find<H>(L, node_slot3(colh, tz) & (4u * (uint32_t)H - 1u), node_fp_word(colh, tz, fp_mask), pack_key(sx, sy, tz));
+                uint32_t hs, hf;
+                node_index_hash(sx, sy, tz, fp_mask, hs, hf);
+                const uint32_t t = lds_index_find<H>(L, hs & (4u * (uint32_t)H - 1u), hf, pack_key(sx, sy, tz));
                 if (t != kNoNode) {
                     const float oz2 = (L.first[t] < my_first) ? L.mz[t] : 0.f;            // "visited": seen earlier AND has statistics
                     const bool far = fabsf(oz2 - cz) > P.slope_interval;
