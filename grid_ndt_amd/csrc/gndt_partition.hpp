@@ -76,13 +76,15 @@ __device__ __forceinline__ void note_column(const ColumnOrder& O, uint32_t cf, u
     O.ncol_at[cf] = ncol;
 }
 
-// Hash of a column.  |sx|, |sy| <= 65535, so the biased indices fit 18 bits: two FULL-RATE 24-bit multiplies, one 32-bit
-// multiply (quarter rate on CDNA) and two xor-shifts.  Columns per bucket come out Poisson-distributed on lattices of
-// 160 k .. 4 M columns for 4096 .. 32768 buckets (checked offline against the five-multiply version this replaces).
+// Hash of a column.  |sx|, |sy| <= 65535, so the biased indices fit 18 bits: THREE full-rate 24-bit multiplies and two
+// xor-shifts (round 5: the middle one was a 32-bit multiply — quarter rate on CDNA, the cost of four instructions, paid per point
+// in level 1, level 2 and per node in the bucket kernel; the fold in front of it brings the word's top bits down into the 24 the
+// multiply reads).  Columns per bucket come out Poisson-distributed (variance / mean 0.79 .. 1.09) on full lattices of 4 M columns
+// and on the columns of the bench scenes for 44 .. 32768 buckets, as with the 32-bit multiply (0.73 .. 1.12; checked offline).
 __host__ __device__ __forceinline__ uint32_t column_hash(int sx, int sy) {
     const uint32_t a = (uint32_t)(sx + 65536) & 0x3FFFFu, b = (uint32_t)(sy + 65536) & 0x3FFFFu;
     uint32_t h = a * 0x9E3779u + b * 0x85EBCBu;         // (both operands < 2^24: v_mul_u32_u24)
-    h ^= h >> 15; h *= 0x2C1B3C6Du;
+    h ^= h >> 15; h = (h & 0xFFFFFFu) * 0x1B3C6Du;      // (again)
     h ^= h >> 13;
     return h;
 }
@@ -152,9 +154,12 @@ __device__ __forceinline__ void column_of_point(float px, float py, const GridPa
         cx = ceilf(fabsf(px - P.ox) / P.grid_len);
         cy = ceilf(fabsf(py - P.oy) / P.grid_len);
     }
-    ok = true;
-    sx = axis_from_ceil(cx, px, P.ox, ok, kMaxXY);
-    sy = axis_from_ceil(cy, py, P.oy, ok, kMaxXY);
+    ok = (cx <= (float)kMaxXY) && (cy <= (float)kMaxXY);      // (NaN: false)
+    // axis_from_ceil, spelled for the instruction count (these kernels issue vector instructions half of their time): clamp by one
+    // median-of-three (0 -> 1, beyond the key range -> the limit), the sign applied in fp32
+    const float ccx = __builtin_amdgcn_fmed3f(cx, 1.0f, (float)kMaxXY), ccy = __builtin_amdgcn_fmed3f(cy, 1.0f, (float)kMaxXY);
+    sx = (int)(px > P.ox ? ccx : -ccx);
+    sy = (int)(py > P.oy ? ccy : -ccy);
 }
 
 // (a record's index word — weight flags, record_weight, record_index —: gndt_kernels.hpp, next to k_accumulate, which reads records too)
@@ -550,7 +555,9 @@ __global__ void __launch_bounds__(kTileThreads) __attribute__((amdgpu_waves_per_
     if (tile < ntiles) load_tile(tile);
     for (; tile < ntiles; tile += gridDim.x) {
         const uint64_t t0 = tile * (kTileThreads * PER);
-        const uint32_t rep = (uint32_t)(tile % R);
+        const uint32_t rep = R > 1u ? (uint32_t)(tile % R) : 0u;
+        const uint32_t have_now = (uint32_t)min((uint64_t)(kTileThreads * PER), n - t0);     // points of this tile (32-bit compares below)
+        const uint32_t idx0 = first_base + (uint32_t)t0;
         float cx[PER], cy[PER], cz[PER];
         // IDXW: the input is 16-B records whose 4th word is the index word (taken as it is).  It is not prefetched with the
         // coordinates (eight more registers per tile in flight): its line arrived with them and is read when the tile is taken up.
@@ -583,8 +590,9 @@ __global__ void __launch_bounds__(kTileThreads) __attribute__((amdgpu_waves_per_
         uint32_t dig[PER];
 #pragma unroll
         for (int j = 0; j < PER; ++j) {
-            const uint64_t i = t0 + (uint64_t)j * kTileThreads + threadIdx.x;
-            const bool live = i < n;
+            const uint32_t il = (uint32_t)j * kTileThreads + threadIdx.x;              // (index inside the tile)
+            const uint32_t i = idx0 + il;                                              // first-seen index of the point
+            const bool live = il < have_now;
             const float px = cx[j], py = cy[j], pz = cz[j];
             int sx, sy;
             bool kok;
@@ -598,13 +606,13 @@ __global__ void __launch_bounds__(kTileThreads) __attribute__((amdgpu_waves_per_
                     dig[j] = owner_lookup(M, sx, sy, B);
                 } else {
                     const uint32_t b = bucket_of(column_hash(sx, sy), B);
-                    dig[j] = (b >> F2_shift) * R + rep;                              // F2 is a power of two
+                    dig[j] = (b >> F2_shift) + rep;                                  // F2 is a power of two (R == 1: no sub-regions, see above)
                     // One record in kSampleEvery votes for its bucket (k_part2_layout sizes the buckets' regions from the
                     // votes).  Chosen by a hash of the point index: a fixed stride would alias with the scan pattern of a
                     // spinning LiDAR (the same azimuths every ring) and with the lane-0 records of compressed waves.
-                    if ((((uint32_t)i * 0x9E3779B1u) >> 26) == 0u) atomicAdd(&est2[b], 1u);
+                    if ((((i & 0xFFFFFFu) * 0x9E3779u) >> 26) == 0u) atomicAdd(&est2[b], 1u);     // (a full-rate 24-bit multiply; the pattern repeats every 2^24 points)
                 }
-                uint32_t idx = (first_base + (uint32_t)i) | (same ? (all8 ? (kWeight64Flag | kWeight512Flag) : kWeight64Flag) : 0u);
+                uint32_t idx = i | (same ? (all8 ? (kWeight64Flag | kWeight512Flag) : kWeight64Flag) : 0u);
                 if constexpr (IDXW) idx = cw[j];                                   // (the host passes compress = 0 with records)
                 r[j] = make_float4(px, py, pz, __uint_as_float(idx));
             }
