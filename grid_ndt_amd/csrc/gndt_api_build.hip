@@ -73,6 +73,22 @@ constexpr uint64_t kMaxBuckets = 32768;   // 4-byte LDS cursor per bucket in the
 
 }  // namespace
 
+// cursors of both partition levels, the sample votes, the buckets' ranges and the bucket kernel's retry list, for B buckets
+int ensure_cursors(gndt_handle* h, uint64_t B) {
+    auto& q = h->part;
+    if (B <= q.cur_cap) return GNDT_OK;
+    GNDT_NO_CAPTURE(h, "the partition cursors");
+    for (uint32_t** a : {&q.cursors, &q.range_lo, &q.range_hi, &q.range_cap}) { if (*a) (void)hipFree(*a); *a = nullptr; }
+    q.cur_cap = 0;
+    const uint64_t c = B + B / 4;
+    HIP_TRY(h, hipMalloc(&q.cursors, ((size_t)kMaxFan + 2 * c) * 4));  // [kMaxFan] level 1, [c] level 2, [c] samples
+    HIP_TRY(h, hipMalloc(&q.range_lo, c * 4));
+    HIP_TRY(h, hipMalloc(&q.range_hi, c * 4));                        // (the retry list)
+    HIP_TRY(h, hipMalloc(&q.range_cap, c * 4));
+    q.cur_cap = c;
+    return GNDT_OK;
+}
+
 // One attempt of the PARTITION build: every launch plus the asynchronous read-back of the counters and overflow
 // flags; no host wait.  Returns GNDT_OK, an error, or -1 when the partition path cannot hold this input.
 int partition_launch(gndt_handle* h, gndt_handle::Pending& P) {
@@ -179,17 +195,7 @@ int partition_launch(gndt_handle* h, gndt_handle::Pending& P) {
             if ((rc = grow_buf(h, q.tab1, q.tab1_cap, (uint64_t)tiles_all * (F1 + 1) + 8))) return rc;
         } else if ((rc = grow_buf(h, q.recs1, q.rec1_cap, (uint64_t)V * cap1))) return rc;
         if ((rc = grow_buf(h, q.recs, q.rec_cap, recs_want))) return rc;
-        if (B > q.cur_cap) {
-            GNDT_NO_CAPTURE(h, "the partition cursors");
-            for (uint32_t** a : {&q.cursors, &q.range_lo, &q.range_hi, &q.range_cap}) { if (*a) (void)hipFree(*a); *a = nullptr; }
-            q.cur_cap = 0;
-            const uint64_t c = (uint64_t)B + B / 4;
-            HIP_TRY(h, hipMalloc(&q.cursors, ((size_t)kMaxFan + 2 * c) * 4));  // [kMaxFan] level 1, [c] level 2, [c] samples
-            HIP_TRY(h, hipMalloc(&q.range_lo, c * 4));
-            HIP_TRY(h, hipMalloc(&q.range_hi, c * 4));
-            HIP_TRY(h, hipMalloc(&q.range_cap, c * 4));
-            q.cur_cap = c;
-        }
+        if ((rc = ensure_cursors(h, B))) return rc;
         uint32_t* cursor1 = q.cursors;
         uint32_t* cursor2 = q.cursors + kMaxFan;
         uint32_t* est2 = cursor2 + B;
@@ -263,17 +269,7 @@ int partition_launch(gndt_handle* h, gndt_handle::Pending& P) {
         const uint64_t mean = n / B + 1;
         const uint32_t cap1 = (uint32_t)std::max<uint64_t>(4 * mean, mean + 4096);
         if ((rc = grow_buf(h, q.recs1, q.rec1_cap, (uint64_t)B * cap1))) return rc;
-        if (B > q.cur_cap) {
-            GNDT_NO_CAPTURE(h, "the partition cursors");
-            for (uint32_t** a : {&q.cursors, &q.range_lo, &q.range_hi, &q.range_cap}) { if (*a) (void)hipFree(*a); *a = nullptr; }
-            q.cur_cap = 0;
-            const uint64_t c = (uint64_t)B + B / 4;
-            HIP_TRY(h, hipMalloc(&q.cursors, ((size_t)kMaxFan + 2 * c) * 4));
-            HIP_TRY(h, hipMalloc(&q.range_lo, c * 4));
-            HIP_TRY(h, hipMalloc(&q.range_hi, c * 4));
-            HIP_TRY(h, hipMalloc(&q.range_cap, c * 4));
-            q.cur_cap = c;
-        }
+        if ((rc = ensure_cursors(h, B))) return rc;
         uint32_t* cursor1 = q.cursors;                     // [B <= kMaxFan] the buckets' fills
         uint32_t* est2 = q.cursors + kMaxFan;              // (the kernel's sample votes: not used here, but counted)
         const uint32_t F1 = B, F2_shift = 0, R = 1;
@@ -318,6 +314,7 @@ int partition_launch(gndt_handle* h, gndt_handle::Pending& P) {
         if (P.n) HIP_TRY(h, hipMemcpyAsync(const_cast<float*>(p), P.xyz, P.n * 16, hipMemcpyDeviceToDevice, s));
     }
     if ((rc = grow_buf(h, q.recs, q.rec_cap, n))) return rc;
+    if ((rc = ensure_cursors(h, B))) return rc;            // (for the bucket kernel's retry list)
     if ((rc = grow_buf(h, q.hist, q.hist_cap, (uint64_t)nwg * B))) return rc;
     if (B > q.bucket_cap) {
         GNDT_NO_CAPTURE(h, "the bucket totals");
@@ -386,11 +383,24 @@ int partition_launch(gndt_handle* h, gndt_handle::Pending& P) {
     const uint32_t interleave = tuning().interleave >= 0 ? (uint32_t)(tuning().interleave != 0) : (q.pair_ratio < 0.0 || q.pair_ratio > 0.02 ? 1u : 0u);
     {
         // k_bucket_direct (gndt_bucket3.hpp): 512-slot tables with two workgroups per CU, 1024-slot tables on a retry
-#define GNDT_LAUNCH_DIRECT(T_, H_, S_)                                                                                          \
-    hipLaunchKernelGGL((k_bucket_direct<T_, H_, S_>), bgrid, dim3(T_), 0, s, bucket_recs, ranges, B, gp, q.stage,    \
-                       (uint32_t)(S_ ? h->st_cap : q.stage_cap), q.ord_cf, q.ord_idx, order, h->d_cnt, q.d_pc, dbg, stats_out, fp_mask, interleave)
-        if (bslots == 1024) { if (P.stats_only) GNDT_LAUNCH_DIRECT(1024, 1024, true); else GNDT_LAUNCH_DIRECT(1024, 1024, false); }
-        else { if (P.stats_only) GNDT_LAUNCH_DIRECT(GNDT_DIRECT_THREADS, 512, true); else GNDT_LAUNCH_DIRECT(GNDT_DIRECT_THREADS, 512, false); }
+        // A bucket whose 512-slot table overflows (a few wall columns; the spread of a hash partition over tall columns) is queued and
+        // done again by a SECOND PASS with 1024-slot tables over the queued buckets only (round 5) — it used to send the whole build
+        // round again.  The pass is launched behind a handle's first builds, behind builds recorded into a hipGraph (a replay cannot
+        // be re-run) and for as long as the last build used it; a handle whose clouds never overflow does not pay for the launch.
+        const bool retry = bslots == 512 && tuning().retry_pass && (q.retry_pass || h->capturing);
+        uint32_t* const rlist = retry ? q.range_hi : (uint32_t*)nullptr;
+        P.retry_pass = retry;
+#define GNDT_LAUNCH_DIRECT(T_, H_, S_, GRID_, RL_, TODO_)                                                                       \
+    hipLaunchKernelGGL((k_bucket_direct<T_, H_, S_>), GRID_, dim3(T_), 0, s, bucket_recs, ranges, B, gp, q.stage,    \
+                       (uint32_t)(S_ ? h->st_cap : q.stage_cap), q.ord_cf, q.ord_idx, order, h->d_cnt, q.d_pc, dbg, stats_out, fp_mask, interleave, \
+                       RL_, TODO_)
+        if (bslots == 1024) { if (P.stats_only) GNDT_LAUNCH_DIRECT(1024, 1024, true, bgrid, (uint32_t*)nullptr, (const uint32_t*)nullptr); else GNDT_LAUNCH_DIRECT(1024, 1024, false, bgrid, (uint32_t*)nullptr, (const uint32_t*)nullptr); }
+        else { if (P.stats_only) GNDT_LAUNCH_DIRECT(GNDT_DIRECT_THREADS, 512, true, bgrid, rlist, (const uint32_t*)nullptr); else GNDT_LAUNCH_DIRECT(GNDT_DIRECT_THREADS, 512, false, bgrid, rlist, (const uint32_t*)nullptr); }
+        if (retry) {
+            const dim3 rgrid(std::min<uint32_t>(B, 256u));       // (one 1024-thread workgroup per CU; all of them leave at once when nothing is queued)
+            if (P.stats_only) GNDT_LAUNCH_DIRECT(1024, 1024, true, rgrid, (uint32_t*)nullptr, (const uint32_t*)rlist);
+            else GNDT_LAUNCH_DIRECT(1024, 1024, false, rgrid, (uint32_t*)nullptr, (const uint32_t*)rlist);
+        }
 #undef GNDT_LAUNCH_DIRECT
     }
     HIP_TRY(h, hipGetLastError());
@@ -402,6 +412,34 @@ int partition_launch(gndt_handle* h, gndt_handle::Pending& P) {
         HIP_TRY(h, hipMemcpyAsync(h->h_cnt, h->d_cnt, sizeof(Counters), hipMemcpyDeviceToHost, s));
     }
     P.bslots = bslots;
+    return GNDT_OK;
+}
+
+// Distinct nodes of a cloud, estimated in one pass (k_node_sketch, gndt_partition.hpp); waits for the answer.
+int sketch_nodes(gndt_handle* h, const void* xyz_dev, size_t n, size_t stride_bytes, hipStream_t s, uint64_t* estimate) {
+    *estimate = 0;
+    if (n == 0) return GNDT_OK;
+    GNDT_NO_CAPTURE(h, "the node-count sketch");
+    if (!h->d_sketch) {
+        HIP_TRY(h, hipMalloc(&h->d_sketch, (size_t)kSketchRegs * 4));
+        HIP_TRY(h, hipHostMalloc(&h->h_sketch, (size_t)kSketchRegs * 4));
+    }
+    HIP_TRY(h, hipMemsetAsync(h->d_sketch, 0, (size_t)kSketchRegs * 4, s));
+    const float* p = static_cast<const float*>(xyz_dev);
+    const uint32_t wgs = (uint32_t)std::min<uint64_t>(512, (n + 16383) / 16384);      // two resident per CU (64 KB of LDS each)
+    if (stride_bytes == 12) hipLaunchKernelGGL(k_node_sketch<3>, dim3(wgs), dim3(kSketchThreads), 0, s, p, (uint64_t)n, grid_params(h), h->d_sketch);
+    else hipLaunchKernelGGL(k_node_sketch<4>, dim3(wgs), dim3(kSketchThreads), 0, s, p, (uint64_t)n, grid_params(h), h->d_sketch);
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipMemcpyAsync(h->h_sketch, h->d_sketch, (size_t)kSketchRegs * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(h, hipStreamSynchronize(s));
+    // HyperLogLog (Flajolet et al. 2007): E = alpha m^2 / sum 2^-M[j]; linear counting while many registers are still empty
+    const double m = (double)kSketchRegs;
+    double sum = 0.0;
+    uint32_t zeros = 0;
+    for (int j = 0; j < kSketchRegs; ++j) { sum += std::ldexp(1.0, -(int)h->h_sketch[j]); zeros += h->h_sketch[j] == 0u; }
+    double e = 0.7213 / (1.0 + 1.079 / m) * m * m / sum;
+    if (e <= 2.5 * m && zeros) e = m * std::log(m / (double)zeros);
+    *estimate = (uint64_t)(e + 0.5);
     return GNDT_OK;
 }
 
@@ -439,10 +477,26 @@ int partition_begin(gndt_handle* h, const void* xyz_dev, size_t n, size_t stride
         first_guess = std::max<uint64_t>(1024, (uint64_t)((double)n / h->tile_ratio_seen * 1.15));
     P.nodes_est = h->P.max_nodes_hint ? h->P.max_nodes_hint : (q.nodes_learned ? q.nodes_learned : first_guess);
     P.est_reliable = h->P.max_nodes_hint != 0 || q.nodes_learned != 0;      // (not the n / 4 guess of a first build)
+    // A fresh handle without a hint: count the nodes instead of guessing them (one pass, a HyperLogLog sketch: ~0.8 % standard
+    // error; the estimate carries 6 % on top).  Not under hipGraph capture (the answer is awaited), not for records (their
+    // producer knows), not for small clouds (a re-run costs them less than the wait).
+    if (!P.est_reliable && !records && n >= (1u << 20) && tuning().sketch) {
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        (void)hipStreamIsCapturing(s, &cap);
+        if (cap == hipStreamCaptureStatusNone) {
+            uint64_t est = 0;
+            if ((rc = sketch_nodes(h, xyz_dev, n_first, stride_bytes, s, &est))) return rc;
+            if (est) {
+                P.nodes_est = std::max<uint64_t>(1024, est + est / 16);
+                P.est_reliable = true;
+                if (tuning().verbose) fprintf(stderr, "[gndt] node sketch: ~%llu nodes in %zu points\n", (unsigned long long)est, n);
+            }
+        }
+    }
     if (similar && q.good_slots == 1024) P.nodes_est = std::max<uint64_t>(P.nodes_est, q.good_est);   // (an estimate that had to be doubled)
     P.est0 = P.nodes_est;
     P.stage_want = std::max<uint64_t>(q.stage_cap, h->P.max_nodes_hint ? h->P.max_nodes_hint + h->P.max_nodes_hint / 8
-                                                                       : std::max<uint64_t>(4096, n / 4));
+                                                                       : std::max<uint64_t>(4096, P.est_reliable ? P.nodes_est + P.nodes_est / 8 : n / 4));
     const int prev_strategy = h->last_strategy;
     h->last_strategy = GNDT_STRATEGY_PARTITION;
     {
@@ -515,6 +569,8 @@ int partition_resolve(gndt_handle* h) {
             --P.attempt;                                       // one seen; after two failures the exact counting partition)
             again = true;
         } else if (q.h_pc->lds_overflow) {                            // some bucket holds too many nodes for its LDS table:
+            const bool without_retry = P.bslots == 512 && !P.retry_pass && tuning().retry_pass != 0 && !env_slots;
+            q.retry_pass = true;                                      // (from now on overflowing buckets of this handle's clouds are done again locally)
             // (Lowering the average table load instead — more, smaller buckets — was measured: 1.19 ms against 0.80 ms with the
             // 1024-slot tables on the 3 M-node variant of the bench scene, and it does not help a hot column at all.)
             // Small clouds are the exception: a 200 k-point frame fills 1024-slot tables (one workgroup per CU) with ~140
@@ -522,7 +578,9 @@ int partition_resolve(gndt_handle* h) {
             // the 1024-slot tables would leave CUs idle (under 384 buckets): a million points with half a million nodes get
             // 1 000 of them, and 3 600 tiny 512-slot buckets instead cost 30-45 % (size sweep, round 3).
             const uint64_t b1024 = buckets_for(P.n + P.n2, P.nodes_est, 1024, P.load_pct ? P.load_pct : q.load_pct);
-            if (P.bslots == 512 && !env_slots && P.n + P.n2 <= (1u << 20) && b1024 < 384 && (P.load_pct ? P.load_pct : q.load_pct) > 35) {
+            if (without_retry) {
+                --P.attempt;                                     // the same tables once more, this time with the second pass behind them
+            } else if (P.bslots == 512 && !env_slots && P.n + P.n2 <= (1u << 20) && b1024 < 384 && (P.load_pct ? P.load_pct : q.load_pct) > 35) {
                 P.load_pct = 35;
                 --P.attempt;                                     // (stay on the 512-slot tables)
             } else if (P.attempt >= 1 || env_slots) {            // (attempt 0 -> 1 only switches to the 1024-slot table)
@@ -550,6 +608,13 @@ int partition_resolve(gndt_handle* h) {
         }
         if (!again) {
             q.nodes_learned = (uint64_t)h->h_cnt->num_nodes + h->h_cnt->num_nodes / 5;
+            // the second pass stays on for as long as it has work (and comes back through the re-run below when it is missed);
+            // many queued buckets mean the tables are too full for this cloud's columns: the next build takes more, emptier ones
+            q.retry_seen = P.retry_pass ? q.h_pc->lds_retry : 0u;
+            if (P.retry_pass) q.retry_pass = q.h_pc->lds_retry != 0u;
+            if (P.retry_pass && (uint64_t)q.h_pc->lds_retry * 8u > q.last_buckets) q.nodes_learned += q.nodes_learned / 4;
+            if (tuning().verbose && P.retry_pass && q.h_pc->lds_retry)
+                fprintf(stderr, "[gndt] %u of %u buckets went through the 1024-slot second pass\n", q.h_pc->lds_retry, q.last_buckets);
             if (P.n + P.n2) q.pair_ratio = 2.0 * (double)q.h_pc->pairs / (double)(P.n + P.n2);
             // the larger tables are remembered only if the small ones failed although the estimate was adequate (a first build
             // without a hint guesses n / 4 nodes: its failure says nothing about the cloud)
@@ -671,16 +736,7 @@ int gndt_reserve(gndt_handle* h, uint64_t max_points, uint64_t max_nodes) {
     for (int slots : {512, 1024})
         for (int load : {35, 60, 75}) Bmax = std::max(Bmax, buckets_for(n, est_hi, slots, load));
     Bmax = std::min<uint64_t>(Bmax, (uint64_t)kMaxFan * kMaxFan);
-    if (Bmax > q.cur_cap) {
-        for (uint32_t** a : {&q.cursors, &q.range_lo, &q.range_hi, &q.range_cap}) { if (*a) (void)hipFree(*a); *a = nullptr; }
-        q.cur_cap = 0;
-        const uint64_t c = Bmax + Bmax / 4;
-        HIP_TRY(h, hipMalloc(&q.cursors, ((size_t)kMaxFan + 2 * c) * 4));
-        HIP_TRY(h, hipMalloc(&q.range_lo, c * 4));
-        HIP_TRY(h, hipMalloc(&q.range_hi, c * 4));
-        HIP_TRY(h, hipMalloc(&q.range_cap, c * 4));
-        q.cur_cap = c;
-    }
+    if ((rc = ensure_cursors(h, Bmax))) return rc;
     constexpr uint64_t kTile1 = (uint64_t)kTileThreads * kTilePer1;
     if ((rc = grow_buf(h, q.recs, q.rec_cap, 2 * n + n / 8 + 2048ull * Bmax + 4096))) return rc;                    // two-level (covers the exact partition's n)
     if ((rc = grow_buf(h, q.recs1, q.rec1_cap, 4 * n + (1u << 24) + (uint64_t)kMaxFan * (4096 + 2 * kTile1)))) return rc;   // level-1 regions at their ceiling / one-level rooms

@@ -23,6 +23,8 @@ Tuning parse_tuning() {
     t.l1_wgs = (uint32_t)geti("GNDT_L1_WGS", (int)t.l1_wgs);
     t.l1_inplace = geti("GNDT_L1_INPLACE", t.l1_inplace);
     t.interleave = geti("GNDT_INTERLEAVE", t.interleave);
+    t.sketch = geti("GNDT_SKETCH", t.sketch);
+    t.retry_pass = geti("GNDT_RETRY_PASS", t.retry_pass);
     t.l2_region_fast = geti("GNDT_L2_ORDER", t.l2_region_fast);
     t.l2_wgs = (uint32_t)std::max(1, geti("GNDT_L2_WGS", (int)t.l2_wgs));
     t.l2_fill_pct = std::min(100, std::max(10, geti("GNDT_L2_FILL", t.l2_fill_pct)));
@@ -312,6 +314,8 @@ void gndt_destroy(gndt_handle* h) {
     if (h->xstream_ev) (void)hipEventDestroy(h->xstream_ev);
     if (h->exp_host) (void)hipHostFree(h->exp_host);
     for (int b = 0; b < 2; ++b) { if (h->bounce[b]) (void)hipHostFree(h->bounce[b]); if (h->bounce_ev[b]) (void)hipEventDestroy(h->bounce_ev[b]); }
+    if (h->d_sketch) (void)hipFree(h->d_sketch);
+    if (h->h_sketch) (void)hipHostFree(h->h_sketch);
     if (h->d_sample) (void)hipFree(h->d_sample);
     if (h->h_sample) (void)hipHostFree(h->h_sample);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);

@@ -350,7 +350,8 @@ __device__ __forceinline__ void bucket_direct_one(BucketLds3<H>& L, const uint32
                                                   uint32_t* __restrict__ ord_cf, uint32_t* __restrict__ ord_idx,
                                                   const ColumnOrder& O, Counters* __restrict__ cnt,
                                                   PartCounters* __restrict__ pc, unsigned long long* __restrict__ dbg,
-                                                  const StatsOut& so, const uint32_t fp_mask, const uint32_t interleave) {
+                                                  const StatsOut& so, const uint32_t fp_mask, const uint32_t interleave,
+                                                  uint32_t* __restrict__ retry_list) {
     static_assert(H <= 65535, "node numbers are kept in 16 bits");
     constexpr int U = H <= 512 ? GNDT_DIRECT_U : 2;    // records in flight per thread
     const int tid = threadIdx.x;
@@ -510,7 +511,14 @@ __device__ __forceinline__ void bucket_direct_one(BucketLds3<H>& L, const uint32
     GNDT_STAMP3(2);
     const uint32_t M = L.n_nodes;
     if (L.overflow || M > (uint32_t)H) {         // uniform
-        if (tid == 0) atomicAdd(&pc->lds_overflow, 1u);
+        // More nodes than the table has numbers.  Nothing of this bucket has left the workgroup yet, so it can simply be done again:
+        // with a retry list (round 5) the bucket is queued for the second pass — the same kernel with 1024-slot tables over the
+        // listed buckets only — and the build goes on; without one (that second pass itself, or a build launched without it) the
+        // flag is raised and the host re-runs the whole build with more room, as before.
+        if (tid == 0) {
+            if (retry_list) retry_list[atomicAdd(&pc->lds_retry, 1u)] = bucket;
+            else atomicAdd(&pc->lds_overflow, 1u);
+        }
         return;
     }
     // Reserve the staging rows now.  The memory-side atomic's round trip (~3 us) hides behind the column phases: its answer stays in
@@ -694,12 +702,16 @@ __global__ void __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(H <= 512
                                                      StageRow* __restrict__ stage, uint32_t stage_cap,
                                                      uint32_t* __restrict__ ord_cf, uint32_t* __restrict__ ord_idx, ColumnOrder O,
                                                      Counters* __restrict__ cnt, PartCounters* __restrict__ pc,
-                                                     unsigned long long* __restrict__ dbg, StatsOut so, uint32_t fp_mask, uint32_t interleave) {
+                                                     unsigned long long* __restrict__ dbg, StatsOut so, uint32_t fp_mask, uint32_t interleave,
+                                                     uint32_t* __restrict__ retry_list, const uint32_t* __restrict__ todo_list) {
+    // todo_list: the second pass — the buckets a first pass queued (pc->lds_retry of them), instead of all num_buckets
     __shared__ BucketLds3<H> L;
-    for (uint32_t bucket = blockIdx.x; bucket < num_buckets; bucket += gridDim.x) {
+    const uint32_t count = todo_list ? min(pc->lds_retry, num_buckets) : num_buckets;
+    for (uint32_t i = blockIdx.x; i < count; i += gridDim.x) {
+        const uint32_t bucket = todo_list ? todo_list[i] : i;
         uint32_t lo, hi;
         bucket_range(ranges, bucket, lo, hi);
-        bucket_direct_one<T, H, STATS>(L, bucket, recs, lo, hi, P, stage, stage_cap, ord_cf, ord_idx, O, cnt, pc, dbg, so, fp_mask, interleave);
+        bucket_direct_one<T, H, STATS>(L, bucket, recs, lo, hi, P, stage, stage_cap, ord_cf, ord_idx, O, cnt, pc, dbg, so, fp_mask, interleave, retry_list);
         lds_barrier();          // the LDS tables are re-initialised by the next bucket
     }
 }

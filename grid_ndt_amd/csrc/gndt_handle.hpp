@@ -10,6 +10,7 @@
 // There is NO CPU fallback: without a HIP device every compute entry point fails with GNDT_ERR_NO_DEVICE.
 #pragma once
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -101,6 +102,9 @@ struct gndt_handle {
         uint64_t rec1_cap = 0;     float4* recs1 = nullptr;
         uint64_t tab1_cap = 0;     uint16_t* tab1 = nullptr;     // level 1 in place: digit offsets of every tile ([tiles][F1 + 1])
         uint64_t cur_cap = 0;      uint32_t *cursors = nullptr, *range_lo = nullptr, *range_hi = nullptr, *range_cap = nullptr;
+        // (range_hi doubles as the bucket kernel's retry list: buckets whose 512-slot table overflowed, done again with 1024 slots)
+        bool retry_pass = true;    // launch that second pass behind the bucket kernel (first builds, captured builds, clouds that needed it)
+        uint32_t retry_seen = 0;   // buckets the last resolved build sent through it
         int two_level_failures = 0;   // builds whose regions overflowed although sized from the sample
         bool one_level_ok = true;  // cleared when a bucket of the one-level tile partition (small clouds) overflowed its fixed room
         bool two_level_ok = true;  // cleared when the regions a cloud needs are too large: exact path from then on
@@ -179,6 +183,7 @@ struct gndt_handle {
     // strategy AUTO: what the locality sample said last time, for which cloud size, and how many builds ago
     int tile_choice = -1;  uint64_t tile_choice_n = 0;  int tile_choice_age = 0;  double tile_ratio_seen = 0.0;
     unsigned long long* d_sample = nullptr;  unsigned long long* h_sample = nullptr;   // k_tile_sample's two counters (pinned copy)
+    uint32_t* d_sketch = nullptr;  uint32_t* h_sketch = nullptr;                        // k_node_sketch's HyperLogLog registers (pinned copy)
     bool map_in_table = true;   // false after a PARTITION build: the HBM node table does not hold the map
 
     // optional phase timing (bench / profiling): events recorded on the launch stream
@@ -201,6 +206,7 @@ struct gndt_handle {
         bool est_reliable = false;      //   ... and whether it came from a hint / an earlier build rather than the n / 4 guess
         bool two_level = false;         // this attempt used the two-level partition
         bool one_level = false;         //   ... the one-level tile partition (small clouds)
+        bool retry_pass = false;        //   ... and the bucket kernel's second pass behind the first (overflowing 512-slot tables done again with 1024)
         double mean1 = 0.0;             // its mean level-1 region fill (to turn the fullest region into a ratio)
         bool stats_only = false;        // gndt_shard_stats_device: statistics out, no labels / ordering / rows
         bool captured = false;          // launched on a stream under hipGraph capture: it runs when the graph is replayed, with the
@@ -233,7 +239,9 @@ struct Tuning {
     int bucket_points = 0;       // GNDT_BUCKET_POINTS  points per bucket (0 = derived)
     int bucket_slots = 0;        // GNDT_BUCKET_SLOTS   LDS table of the first attempt (0 = 512, 1024 on a retry)
     int two_level = -1;          // GNDT_TWO_LEVEL      0 = never use the two-level partition
-    uint32_t l1_wgs = 1024;      // GNDT_L1_WGS         persistent level-1 workgroups
+    uint32_t l1_wgs = 2048;      // GNDT_L1_WGS         level-1 workgroups (512 are resident: 2048 of them, ~1.2 tiles each, measured 69 us against 75 with 1024 and 72 with 512 on the bench scene, round 5)
+    int retry_pass = 1;          // GNDT_RETRY_PASS     0: never launch the bucket kernel's second pass (an overflowing 512-slot table re-runs the build, as before round 5)
+    int sketch = 1;              // GNDT_SKETCH         a fresh handle without a hint counts its first cloud's nodes (HyperLogLog pass) instead of guessing n / 4
     int interleave = -1;         // GNDT_INTERLEAVE     bucket kernel: record pairs interleaved over the waves (1), consecutive (0), by the last build's locality (-1)
     int l1_inplace = 0;          // GNDT_L1_INPLACE     two-level partition: level 1 writes sorted tiles in place, level 2 gathers segments (0: reserved regions)
     uint32_t l2_wgs = 1024;      // GNDT_L2_WGS         persistent workgroups of the gathering level 2
@@ -347,6 +355,7 @@ int ensure_stats_buffers(gndt_handle* h, uint64_t n);
 int ensure_stage(gndt_handle* h, uint64_t nodes);
 int ensure_words(gndt_handle* h, uint64_t words);
 int ensure_part_counters(gndt_handle* h);
+int ensure_cursors(gndt_handle* h, uint64_t buckets);   // gndt_api_build.hip
 int fetch_counters(gndt_handle* h, hipStream_t s);   // read the device counters (synchronises the stream)
 int stage_host_input(gndt_handle* h, const void* xyz_host, size_t n, size_t stride_bytes, hipStream_t s);
 void free_part(gndt_handle* h);
@@ -362,6 +371,7 @@ int table_emit_pending(gndt_handle* h);    // deferred-emit mode: the ordering +
 int build_atomic(gndt_handle* h, const void* xyz_dev, size_t n, size_t stride_bytes, hipStream_t s, bool tile = false,
                  const gndt_handle::Pending* rec = nullptr);
 int locality_sample(gndt_handle* h, const void* xyz_dev, size_t n, size_t stride_bytes, uint32_t tiles, double* ratio, hipStream_t s);
+int sketch_nodes(gndt_handle* h, const void* xyz_dev, size_t n, size_t stride_bytes, hipStream_t s, uint64_t* estimate);   // HyperLogLog over the node keys (waits)
 // ---- gndt_api_build.hip ----
 // tab_end: the table path's end-of-frame bookkeeping (k_tab_end + `advance` points of stream position) done by k_emit_rows
 // partial: incremental finalisation — only rows from the first changed column on are placed and gathered again, touched rows in
