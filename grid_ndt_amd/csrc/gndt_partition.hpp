@@ -981,16 +981,33 @@ static __global__ void __launch_bounds__(kBlock) k_order_dest_columns(const uint
                                                                       const Counters* __restrict__ cnt, const PartCounters* __restrict__ pc) {
     if (pc->lds_overflow | pc->stage_overflow | pc->index_overflow | pc->part_overflow) return;
     const uint32_t n = cnt->num_nodes;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const uint32_t v = ord_idx[i];
-        if (!(v & kOrdHeadFlag)) continue;
-        const uint32_t nc = v & ~kOrdHeadFlag;
-        const uint32_t cf = ord_cf[i];
-        const uint32_t w = cf >> 5;
-        uint32_t m = bitmap[w] & ((1u << (cf & 31u)) - 1u);       // columns first seen earlier inside the same word (rare)
-        uint32_t row = word_base[w];
-        while (m) { row += ncol_at[(w << 5) + (uint32_t)__builtin_ctz(m)]; m &= m - 1u; }
-        for (uint32_t k = 0; k < nc; ++k) inv[row + k] = i + k;
+    // The grid is capped (grid_for), so on a large map a thread walks ~20 rows, and every row of a column head is three DEPENDENT
+    // memory round trips (order key, first-seen index, bitmap word + word base).  Round 5: four rows per step, each stage's loads
+    // issued for all four before any is used: 0.356 -> 0.329 ms on 100 M points, 0.124 -> 0.110 on 32 M.  (What bounds it then is the
+    // number of random accesses — 4.3 M columns over a 3.1 M-word index range; {bitmap word, word base} side by side in one 8-byte
+    // record took the pass to 0.309 ms and gave the 0.03 ms back in the scan that has to write the records: not kept.  Folding the
+    // pass into the scan — the bitmap walked in order, the gather list written front to back from one {nodes, first row} record
+    // per column — is 0.27 ms on that scene and 146 us instead of 30 on the bench scene, whose 160 k columns are all first seen
+    // within the first 31 k bitmap words: a handful of threads then place them all.  Not kept either.)
+    constexpr int K = 4;
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t i0 = blockIdx.x * blockDim.x + threadIdx.x; i0 < n; i0 += K * stride) {
+        uint32_t v[K], cf[K], bw[K], wb[K];
+#pragma unroll
+        for (int q = 0; q < K; ++q) { const uint32_t i = i0 + (uint32_t)q * stride; v[q] = i < n ? ord_idx[i] : 0u; }
+#pragma unroll
+        for (int q = 0; q < K; ++q) cf[q] = (v[q] & kOrdHeadFlag) ? ord_cf[i0 + (uint32_t)q * stride] : 0u;
+#pragma unroll
+        for (int q = 0; q < K; ++q) { bw[q] = 0u; wb[q] = 0u; if (v[q] & kOrdHeadFlag) { bw[q] = bitmap[cf[q] >> 5]; wb[q] = word_base[cf[q] >> 5]; } }
+#pragma unroll
+        for (int q = 0; q < K; ++q) {
+            if (!(v[q] & kOrdHeadFlag)) continue;
+            const uint32_t i = i0 + (uint32_t)q * stride, nc = v[q] & ~kOrdHeadFlag, w = cf[q] >> 5;
+            uint32_t m = bw[q] & ((1u << (cf[q] & 31u)) - 1u);    // columns first seen earlier inside the same word
+            uint32_t row = wb[q];
+            while (m) { row += ncol_at[(w << 5) + (uint32_t)__builtin_ctz(m)]; m &= m - 1u; }
+            for (uint32_t k = 0; k < nc; ++k) inv[row + k] = i + k;
+        }
     }
 }
 
@@ -1081,10 +1098,16 @@ static __global__ void __launch_bounds__(kBlock) k_emit_rows(const StageRow* __r
     float* const wm = &s_t[threadIdx.x >> 6][0];       // [64][3] mean
     float* const wn = wm + 64 * 3;                      // [64][3] normal
     float* const wc = wm + 64 * 6;                      // [64][6] cov
-    for (uint32_t rb = r0 + blockIdx.x * blockDim.x + (threadIdx.x & ~63u); rb < n; rb += gridDim.x * blockDim.x) {   // (wave-uniform)
+    // (the index of the NEXT iteration's staging row is requested one iteration ahead: on a large map a wave walks ~20 iterations of
+    //  two dependent round trips each — index, then row)
+    const uint32_t rb_first = r0 + blockIdx.x * blockDim.x + (threadIdx.x & ~63u);
+    uint32_t src_next = (rb_first + (uint32_t)lane) < n ? inv[rb_first + (uint32_t)lane] : 0u;
+    for (uint32_t rb = rb_first; rb < n; rb += gridDim.x * blockDim.x) {   // (wave-uniform)
         const uint32_t r = rb + (uint32_t)lane;
+        const uint32_t src = src_next;
+        { const uint32_t rn = r + gridDim.x * blockDim.x; src_next = rn < n ? inv[rn] : 0u; }
         if (r < n) {
-            const StageRow row = stage[inv[r]];         // (the 96-byte row in one piece: six 16-byte loads)
+            const StageRow row = stage[src];            // (the 96-byte row in one piece: six 16-byte loads)
             out.sx[r] = row.sx; out.sy[r] = row.sy; out.sz[r] = row.sz;
             out.count[r] = row.count; out.first_idx[r] = row.first; out.flags[r] = row.flags;
             row_ncol[r] = row.idx_in_col == 0u ? row.ncol : 0u;
