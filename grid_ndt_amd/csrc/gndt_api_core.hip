@@ -268,6 +268,9 @@ int gndt_create(const gndt_params* params, gndt_handle** out) {
     if ((e = hipMemsetAsync(h->d_cnt, 0, sizeof(Counters), h->own_stream)) != hipSuccess) return fail("hipMemsetAsync", e);   // (not hipMemset: zero_device_now)
     if ((e = hipStreamSynchronize(h->own_stream)) != hipSuccess) return fail("hipStreamSynchronize", e);
     memset(h->h_cnt, 0, sizeof(Counters));
+    // (the sharded builds' agreement words: 8 KB each — see Exchange::d_agree)
+    if ((e = hipMalloc(&h->exch.d_agree, (size_t)(1024 + 1) * sizeof(unsigned long long))) != hipSuccess) return fail("hipMalloc", e);
+    if ((e = hipHostMalloc(&h->exch.h_agree, (size_t)(1024 + 1) * sizeof(unsigned long long))) != hipSuccess) return fail("hipHostMalloc", e);
     h->last_stream = h->own_stream;
     if (params->max_nodes_hint) {
         int rc = alloc_table(h, cap_for_nodes(params->max_nodes_hint), h->own_stream);
@@ -308,6 +311,8 @@ void gndt_destroy(gndt_handle* h) {
         if (X.h_totals) (void)hipHostFree(X.h_totals);
         if (X.h_colmsg) (void)hipHostFree(X.h_colmsg);
         if (X.h_bad) (void)hipHostFree(X.h_bad);
+        if (X.d_agree) (void)hipFree(X.d_agree);
+        if (X.h_agree) (void)hipHostFree(X.h_agree);
         if (X.h_tally) (void)hipHostFree(X.h_tally);
         for (auto& e : X.ev) if (e) (void)hipEventDestroy(e);
     }

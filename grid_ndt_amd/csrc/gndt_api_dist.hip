@@ -38,6 +38,7 @@ struct ThreadGroup {
 struct gndt_comm {
     ncclComm_t nccl = nullptr;
     int rank = 0, world = 1, device = 0;
+    uint64_t owned_builds = 0;                      // owned builds all ranks of this communicator entered together (gndt_build_owned_device)
     std::shared_ptr<ThreadGroup> threads;           // set: the ranks are threads of this process, nccl is not used
 };
 
@@ -455,6 +456,7 @@ int gndt_build_global_device(gndt_handle* h, gndt_comm* c, const void* shard_xyz
 namespace {
 
 constexpr uint32_t kMaxRanks = 1024;
+constexpr size_t kMatrixHostWords = (size_t)kMaxRanks * (kMaxRanks + 2);     // a rank's row: W send counts, its status word, its receive capacity
 
 // kOwnerSamples evenly spaced points of the shard -> their blocks, with the shard size in front (X.owner_msg)
 int owner_sample_launch(gndt_handle* h, const void* xyz, size_t n, size_t stride_bytes, hipStream_t s) {
@@ -502,7 +504,7 @@ int owner_split_launch(gndt_handle* h, const void* xyz, size_t n, size_t stride_
     if ((rc = ensure_part_counters(h))) return rc;
     if (!X.d_split_cnt) HIP_TRY(h, hipMalloc(&X.d_split_cnt, sizeof(Counters)));
     if (!X.h_split_cnt) HIP_TRY(h, hipHostMalloc(&X.h_split_cnt, sizeof(Counters)));
-    if (!X.h_matrix) HIP_TRY(h, hipHostMalloc(&X.h_matrix, ((size_t)kMaxRanks * (kMaxRanks + 1) + kMaxRanks + 1) * sizeof(uint32_t)));
+    if (!X.h_matrix) HIP_TRY(h, hipHostMalloc(&X.h_matrix, (kMatrixHostWords + kMaxRanks + 1) * sizeof(uint32_t)));
     HIP_TRY(h, hipMemsetAsync(X.d_split_cnt, 0, sizeof(Counters), s));
     const uint32_t nwg = (uint32_t)std::min<uint64_t>((uint64_t)kPartWgs, std::max<uint64_t>(1, n / 8192));
     if ((rc = grow_buf(h, q.hist, q.hist_cap, (uint64_t)nwg * W))) return rc;
@@ -540,7 +542,7 @@ int owner_split_launch(gndt_handle* h, const void* xyz, size_t n, size_t stride_
                                (uint32_t*)nullptr, 0ull);
         HIP_TRY(h, hipGetLastError());
         X.split_cap = cap;
-        uint32_t* h_base = X.h_matrix + (size_t)kMaxRanks * (kMaxRanks + 1);
+        uint32_t* h_base = X.h_matrix + kMatrixHostWords;
         HIP_TRY(h, hipMemcpyAsync(h_base, q.totals, (size_t)W * 4, hipMemcpyDeviceToHost, s));
     } else {
         if ((rc = grow_buf(h, X.send_recs, X.send_cap, std::max<uint64_t>(n, 1)))) return rc;
@@ -557,7 +559,7 @@ int owner_split_launch(gndt_handle* h, const void* xyz, size_t n, size_t stride_
             hipLaunchKernelGGL(k_part_scatter<4>, dim3(nwg), dim3(kPartThreads), lds, s, p, (uint64_t)n, (uint32_t)first_base, gp, W, q.hist, q.totals,
                                q.bucket_base, X.send_recs, compress, kPartModeOwner, M);
         HIP_TRY(h, hipGetLastError());
-        uint32_t* h_base = X.h_matrix + (size_t)kMaxRanks * (kMaxRanks + 1);
+        uint32_t* h_base = X.h_matrix + kMatrixHostWords;
         HIP_TRY(h, hipMemcpyAsync(h_base, q.bucket_base, ((size_t)W + 1) * 4, hipMemcpyDeviceToHost, s));
     }
     HIP_TRY(h, hipMemcpyAsync(X.h_split_cnt, X.d_split_cnt, sizeof(Counters), hipMemcpyDeviceToHost, s));
@@ -565,7 +567,7 @@ int owner_split_launch(gndt_handle* h, const void* xyz, size_t n, size_t stride_
 }
 int owner_split_finish(gndt_handle* h, uint32_t W) {        // (after the stream has been waited for)
     auto& X = h->exch;
-    const uint32_t* h_base = X.h_matrix + (size_t)kMaxRanks * (kMaxRanks + 1);
+    const uint32_t* h_base = X.h_matrix + kMatrixHostWords;
     for (uint32_t r = 0; r < W; ++r) {
         if (X.split_one_pass) { X.send_off[r] = (uint64_t)r * X.split_cap; X.send_cnt[r] = h_base[r]; }
         else { X.send_off[r] = h_base[r]; X.send_cnt[r] = h_base[r + 1] - h_base[r]; }
@@ -797,6 +799,40 @@ int gndt_owned_global_rows_device(gndt_handle* h, const uint64_t* all_pairs_dev,
     return GNDT_OK;
 }
 
+namespace {
+// One status word of every rank to every rank (an all-gather of 8 bytes per rank through buffers that exist since gndt_create) and
+// the common verdict: GNDT_OK if all words are zero; a rank whose own word is not leaves with it (and its message), every other
+// rank with GNDT_ERR_PEER — all of them at this point, so that nobody is left waiting in the collective that would follow.
+int agree_on(gndt_handle* h, gndt_comm* c, hipStream_t s, int my_code, const std::string& my_msg) {
+    auto& X = h->exch;
+    const int W = c->world, me = c->rank;
+    X.h_agree[kMaxRanks] = (unsigned long long)my_code;
+    HIP_TRY(h, hipMemcpyAsync(X.d_agree + me, X.h_agree + kMaxRanks, sizeof(unsigned long long), hipMemcpyHostToDevice, s));
+    { const int arc = comm_all_gather(h, c, X.d_agree + me, X.d_agree, 1, 8, s); if (arc) return arc; }
+    HIP_TRY(h, hipMemcpyAsync(X.h_agree, X.d_agree, (size_t)W * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+    HIP_TRY(h, hipStreamSynchronize(s));
+    if (my_code) { h->err = my_msg; return my_code; }
+    for (int r = 0; r < W; ++r)
+        if (X.h_agree[r]) {
+            h->err = "rank " + std::to_string(r) + " reported error " + std::to_string(X.h_agree[r]) + ": abandoned by all ranks";
+            return GNDT_ERR_PEER;
+        }
+    return GNDT_OK;
+}
+bool injected_failure(gndt_handle* h, int site) {      // tests: gndt_debug_fail_next_alloc
+    if (h->exch.inject_site != site) return false;
+    h->exch.inject_site = 0;
+    h->err = "allocation failure injected at site " + std::to_string(site) + " (gndt_debug_fail_next_alloc)";
+    return true;
+}
+}  // namespace
+
+int gndt_debug_fail_next_alloc(gndt_handle* h, int site) {
+    if (!h || site < 0 || site > 4) return GNDT_ERR_INVALID;
+    h->exch.inject_site = site;
+    return GNDT_OK;
+}
+
 int gndt_build_owned_device(gndt_handle* h, gndt_comm* c, const void* shard_xyz_dev, size_t n, size_t stride_bytes,
                             uint64_t first_idx_base, uint64_t total_points, const uint32_t** global_row_dev,
                             gndt_owned_info* info, void* hip_stream) {
@@ -830,12 +866,39 @@ int gndt_build_owned_device(gndt_handle* h, gndt_comm* c, const void* shard_xyz_
         h->err = "rank " + std::to_string(r) + " reported error " + std::to_string(code) + ": the owner-partitioned build was abandoned by all ranks";
         return GNDT_ERR_PEER;
     };
-    const uint32_t RW = (uint32_t)W + 1u;      // a rank's row of the matrix: W send counts and its status word
-    if ((rc = grow_buf(h, X.d_matrix, X.matrix_cap, (uint64_t)W * RW))) return rc;
-    if (!X.h_matrix) HIP_TRY(h, hipHostMalloc(&X.h_matrix, ((size_t)kMaxRanks * (kMaxRanks + 1) + kMaxRanks + 1) * sizeof(uint32_t)));
-    if (!X.d_colmsg) HIP_TRY(h, hipMalloc(&X.d_colmsg, kColMsgWords * (size_t)kMaxRanks * sizeof(unsigned long long)));
-    if (!X.h_colmsg) HIP_TRY(h, hipHostMalloc(&X.h_colmsg, kColMsgWords * ((size_t)kMaxRanks + 1) * sizeof(unsigned long long)));
-    if (!X.d_split_cnt) HIP_TRY(h, hipMalloc(&X.d_split_cnt, sizeof(Counters)));
+    // ---- agreement rounds (round 5) ----
+    // Buffers whose size the ranks learn from each other (what arrives in the exchange, everybody's column pairs) are grown
+    // BETWEEN two collectives, and a rank that cannot grow one cannot take part in the collective that follows: returning there
+    // left its peers waiting in that collective for ever (missing 5).  So every rank publishes the CAPACITY it has
+    // with the message that tells the sizes (its row of the matrix, its column message); all ranks then know whether anybody has
+    // to grow anything.  If nobody has — the steady state — nothing is added.  If somebody has, he tries, and ALL ranks meet in
+    // one more tiny all-gather of status words (`agree`) before the collective that needs the buffer: a rank that failed
+    // leaves with its own error, the others with GNDT_ERR_PEER, together.  The words travel through buffers allocated with the
+    // handle (Exchange::d_agree), so a rank can say "I cannot go on" whatever else it failed to allocate.
+    auto agree = [&]() -> int { return agree_on(h, c, s, err, err_msg); };
+    auto injected = [&](int site) { return injected_failure(h, site); };
+    const uint32_t RW = (uint32_t)W + 2u;      // a rank's row of the matrix: W send counts, its status word, its receive capacity
+    // The fixed-size message buffers of this handle.  On a communicator's FIRST owned build every rank allocates them, and the
+    // ranks agree on the outcome before the first collective that uses them; later builds find them in place (a fresh handle on
+    // a used communicator is not covered: its failure here is fatal for the group, as the loss of a rank is).
+    {
+        auto small = [&]() -> int {
+            if (injected(4)) return GNDT_ERR_NOMEM;
+            int r2;
+            if ((r2 = grow_buf(h, X.d_matrix, X.matrix_cap, (uint64_t)W * RW))) return r2;
+            if (!X.h_matrix) HIP_TRY(h, hipHostMalloc(&X.h_matrix, (kMatrixHostWords + kMaxRanks + 1) * sizeof(uint32_t)));
+            if (!X.d_colmsg) HIP_TRY(h, hipMalloc(&X.d_colmsg, kColMsgWords * (size_t)kMaxRanks * sizeof(unsigned long long)));
+            if (!X.h_colmsg) HIP_TRY(h, hipHostMalloc(&X.h_colmsg, kColMsgWords * ((size_t)kMaxRanks + 1) * sizeof(unsigned long long)));
+            if (!X.d_split_cnt) HIP_TRY(h, hipMalloc(&X.d_split_cnt, sizeof(Counters)));
+            return GNDT_OK;
+        };
+        const int src = small();
+        if (c->owned_builds == 0 && W > 1) {
+            note(src);
+            if ((rc = agree())) return rc;
+        } else if (src) return src;
+        ++c->owned_builds;                     // (all ranks pass this point together, or none does)
+    }
     if (!shard_xyz_dev && n) { h->err = "null input"; note(GNDT_ERR_INVALID); }
     stamp(0);
     // 0. who owns what: everybody's samples (one fixed-size all-gather, no wait) -> the block table, identical on every rank
@@ -855,7 +918,7 @@ int gndt_build_owned_device(gndt_handle* h, gndt_comm* c, const void* shard_xyz_
     if (!err) HIP_TRY(h, hipMemcpyAsync(my_row, q.totals, (size_t)W * 4, hipMemcpyDeviceToDevice, s));
     else HIP_TRY(h, hipMemsetAsync(my_row, 0, (size_t)W * 4, s));
     hipLaunchKernelGGL(k_split_status, dim3(1), dim3(1), 0, s, (const Counters*)(err ? nullptr : X.d_split_cnt), (uint32_t)err, (uint32_t)GNDT_ERR_KEY_RANGE,
-                       my_row + W);
+                       my_row + W, (uint32_t)std::min<uint64_t>(X.own_cap, 0xFFFFFFFFull));
     if ((rc = comm_all_gather(h, c, my_row, X.d_matrix, (size_t)RW, 4, s))) return rc;
     HIP_TRY(h, hipMemcpyAsync(X.h_matrix, X.d_matrix, (size_t)W * RW * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     HIP_TRY(h, hipStreamSynchronize(s));
@@ -874,7 +937,23 @@ int gndt_build_owned_device(gndt_handle* h, gndt_comm* c, const void* shard_xyz_
     recv_off[0] = kept;
     for (int r = 0; r < W; ++r) recv_off[r + 1] = recv_off[r] + (r == me ? 0 : X.h_matrix[(size_t)r * RW + me]);      // what rank r holds for me
     const uint64_t n_own = recv_off[W];
-    if ((rc = grow_buf(h, X.own_recs, X.own_cap, std::max<uint64_t>(n_own, 1)))) return rc;
+    {   // does ANY rank have to grow its receive buffer?  (every rank computes every rank's answer from the same matrix)
+        bool somebody_grows = false;
+        for (int r = 0; r < W && !somebody_grows; ++r) {
+            uint64_t own_r = 0;
+            for (int q2 = 0; q2 < W; ++q2) own_r += X.h_matrix[(size_t)q2 * RW + r];
+            somebody_grows = std::max<uint64_t>(own_r, 1) > X.h_matrix[(size_t)r * RW + W + 1];
+        }
+        if (somebody_grows) {
+            if (std::max<uint64_t>(n_own, 1) > X.own_cap) {
+                // (room to spare: the next builds of a similar cloud find the buffer large enough and skip the agreement round)
+                if (injected(1)) note(GNDT_ERR_NOMEM);
+                else note(grow_buf(h, X.own_recs, X.own_cap, n_own + n_own / 8 + 1024));
+            }
+            if (W > 1 && (rc = agree())) return rc;
+            if (err) return leave();
+        }
+    }
     uint64_t sent = 0, received = 0;
     if (W > 1) {
         std::vector<uint64_t> so((size_t)W), sc((size_t)W), ro((size_t)W), rcnt((size_t)W);
@@ -900,7 +979,7 @@ int gndt_build_owned_device(gndt_handle* h, gndt_comm* c, const void* shard_xyz_
         if (!err) note(owned_columns_enqueue(h, s));
         if (!err) {
             hipLaunchKernelGGL(k_owned_status, dim3(1), dim3(1), 0, s, (const uint32_t*)X.d_npairs, (const PartCounters*)q.d_pc, (const Counters*)h->d_cnt,
-                               (unsigned long long)n_own, X.d_colmsg + kColMsgWords * me);
+                               (unsigned long long)n_own, X.d_colmsg + kColMsgWords * me, (unsigned long long)X.pairs_cap, (unsigned long long)X.pairs_all_cap);
         } else {
             for (int k = 0; k < kColMsgWords; ++k) my_msg_host[k] = 0ull;
             my_msg_host[4] = (unsigned long long)err;
@@ -927,20 +1006,46 @@ int gndt_build_owned_device(gndt_handle* h, gndt_comm* c, const void* shard_xyz_
     if (!err) ncols = h->h_cnt->num_columns;
     stamp(3);
     // 4. everybody's columns -> the global row of every local row
-    if (m_max > X.pairs_cap) {                          // (another rank owns more columns: a longer send buffer, contents kept)
-        unsigned long long* bigger = nullptr;
-        HIP_TRY(h, hipMalloc(&bigger, m_max * sizeof(unsigned long long)));
-        if (ncols && X.pairs) HIP_TRY(h, hipMemcpyAsync(bigger, X.pairs, (size_t)ncols * sizeof(unsigned long long), hipMemcpyDeviceToDevice, s));
-        HIP_TRY(h, hipStreamSynchronize(s));
-        if (X.pairs) (void)hipFree(X.pairs);
-        X.pairs = bigger; X.pairs_cap = m_max;
+    {   // the pair buffers: does ANY rank have to grow one?  (capacities as every rank's last column message told them)
+        bool somebody_grows = false;
+        for (int r = 0; r < W && !somebody_grows; ++r)
+            somebody_grows = m_max > X.h_colmsg[kColMsgWords * r + 6] || m_max * (uint64_t)W > X.h_colmsg[kColMsgWords * r + 7];
+        if (somebody_grows) {
+            // (err is 0 here, or the error of a build that failed AFTER this rank's last message: that one is told by the poison
+            //  pair below — its rank still needs the buffers to play its part — and only a failure to grow is agreed on here)
+            int grow_err = GNDT_OK;
+            const uint64_t want = m_max + m_max / 8 + 64;      // (room to spare: similar clouds skip the round next time)
+            if (injected(2)) grow_err = GNDT_ERR_NOMEM;
+            if (!grow_err && m_max > X.pairs_cap) {             // (another rank owns more columns: a longer send buffer, contents kept)
+                unsigned long long* bigger = nullptr;
+                if (hipMalloc(&bigger, want * sizeof(unsigned long long)) != hipSuccess) { (void)hipGetLastError(); h->err = "hipMalloc of the column-pair buffer failed"; grow_err = GNDT_ERR_NOMEM; }
+                else {
+                    if (!err && ncols && X.pairs) HIP_TRY(h, hipMemcpyAsync(bigger, X.pairs, (size_t)ncols * sizeof(unsigned long long), hipMemcpyDeviceToDevice, s));
+                    HIP_TRY(h, hipStreamSynchronize(s));
+                    if (X.pairs) (void)hipFree(X.pairs);
+                    X.pairs = bigger; X.pairs_cap = want;
+                }
+            }
+            if (!grow_err && m_max * (uint64_t)W > X.pairs_all_cap) grow_err = grow_buf(h, X.pairs_all, X.pairs_all_cap, want * (uint64_t)W);
+            if (grow_err) { err = grow_err; err_msg = h->err; }
+            if (W > 1) {
+                const int late = grow_err ? GNDT_OK : err;
+                if (!grow_err) err = GNDT_OK;
+                rc = agree();
+                if (!grow_err) err = late;
+                if (rc) return rc;
+            } else if (grow_err) return leave();
+        }
+    }
+    if (m_max > X.pairs_cap || m_max * (uint64_t)W > X.pairs_all_cap) {     // (cannot happen: the capacities the ranks agreed on)
+        h->err = "column-pair buffers smaller than the ranks agreed on";
+        return GNDT_ERR_INVALID;
     }
     hipLaunchKernelGGL(k_pairs_pad, dim3(grid_for(m_max)), dim3(256), 0, s, X.pairs, ncols, (uint32_t)m_max);
     if (err) {      // this rank's columns will be missing from everybody's order: a pair no map can hold makes the other ranks fail too
         my_msg_host[0] = kPoisonPair;
         HIP_TRY(h, hipMemcpyAsync(X.pairs, my_msg_host, sizeof(unsigned long long), hipMemcpyHostToDevice, s));
     }
-    if ((rc = grow_buf(h, X.pairs_all, X.pairs_all_cap, m_max * (uint64_t)W))) return rc;
     if ((rc = comm_all_gather(h, c, X.pairs, X.pairs_all, (size_t)m_max, 8, s))) return rc;
     const bool sliced = W > 1;
     if (err) {      // the others finish without this rank's columns — and notice, by its poison pair — once it has played its part
@@ -1067,7 +1172,19 @@ int gndt_gather_owned_map_device(gndt_handle* h, gndt_comm* c, int32_t root, voi
     const bool all = root < 0;
     // this rank's rows, packed (padded to the longest list for the fixed-size all-gather)
     const uint64_t padded = all ? m_max : std::max<uint64_t>(nl, 1);
-    if ((rc = grow_buf(h, X.grec, X.grec_cap, padded * kPackedRowWords))) return rc;
+    // The buffers the collective below needs, then ONE agreement round (round 5): a rank that cannot allocate them used to return
+    // here and leave the others waiting in the exchange.  (The gather runs once per assembled map, not per build: the round's
+    // tiny all-gather is paid every time instead of publishing capacities first.)
+    {
+        int gerr = GNDT_OK;
+        if (injected_failure(h, 3)) gerr = GNDT_ERR_NOMEM;
+        if (!gerr) gerr = grow_buf(h, X.grec, X.grec_cap, padded * kPackedRowWords);
+        if (!gerr && all) gerr = grow_buf(h, X.grec_all, X.grec_all_cap, m_max * (uint64_t)W * kPackedRowWords);
+        if (!gerr && !all && me == root) gerr = grow_buf(h, X.grec_all, X.grec_all_cap, std::max<uint64_t>(N, 1) * kPackedRowWords);
+        const std::string gmsg = h->err;
+        if (W > 1) rc = agree_on(h, c, s, gerr, gmsg); else rc = gerr;
+        if (rc) { X.gathered = false; return rc; }     // (all ranks leave here together: the same build may be gathered again)
+    }
     hipLaunchKernelGGL(k_rows_pack, dim3(grid_for(padded)), dim3(256), 0, s, h->out, (const uint32_t*)h->part.row_ncol, (const uint32_t*)X.global_row,
                        (uint32_t)nl, (uint32_t)(all ? padded : nl), X.grec);
     HIP_TRY(h, hipGetLastError());

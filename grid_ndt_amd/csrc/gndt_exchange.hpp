@@ -249,9 +249,14 @@ static __global__ void __launch_bounds__(256) k_owned_columns(const uint32_t* __
 // [4]: a status code — non-zero means this rank cannot go on (its error code, include/gndt.h): every rank reads everybody's
 // word after the all-gather and they all leave the sequence together (nobody is left waiting in the next collective);
 // [5]: rows of this rank's map (what gndt_gather_owned_map_device moves).
-constexpr int kColMsgWords = 6;
+// [6], [7]: the capacities (in pairs) of this rank's pair send buffer and of its buffer for everybody's pairs: with them every rank
+// knows whether ANY rank has to grow a buffer before the pairs travel, and only then do the ranks spend an agreement round on it.
+constexpr int kColMsgWords = 8;
 static __global__ void k_owned_status(const uint32_t* __restrict__ n_pairs, const PartCounters* __restrict__ pc, const Counters* __restrict__ cnt,
-                                      unsigned long long owned_points, unsigned long long* __restrict__ msg) {
+                                      unsigned long long owned_points, unsigned long long* __restrict__ msg, unsigned long long pairs_cap,
+                                      unsigned long long pairs_all_cap) {
+    msg[6] = pairs_cap;
+    msg[7] = pairs_all_cap;
     msg[0] = *n_pairs;
     msg[1] = (pc->lds_overflow | pc->stage_overflow | pc->index_overflow | pc->part_overflow) ? 1ull : 0ull;
     msg[2] = cnt->num_slopes;
@@ -261,8 +266,10 @@ static __global__ void k_owned_status(const uint32_t* __restrict__ n_pairs, cons
 }
 // the status word that travels with a rank's row of the W x W send-count matrix: the host's code if it has one, else what the
 // split found on the device (points outside the key range)
-static __global__ void k_split_status(const Counters* __restrict__ split_cnt, uint32_t host_code, uint32_t key_range_code, uint32_t* __restrict__ word) {
-    *word = host_code ? host_code : ((split_cnt && split_cnt->err_key_range) ? key_range_code : 0u);
+static __global__ void k_split_status(const Counters* __restrict__ split_cnt, uint32_t host_code, uint32_t key_range_code, uint32_t* __restrict__ word,
+                                      uint32_t receive_capacity) {
+    word[0] = host_code ? host_code : ((split_cnt && split_cnt->err_key_range) ? key_range_code : 0u);
+    word[1] = receive_capacity;      // (records this rank can take in the exchange without growing its buffer)
 }
 
 static __global__ void __launch_bounds__(256) k_pairs_pad(unsigned long long* __restrict__ pairs, uint32_t have, uint32_t padded) {

@@ -170,6 +170,10 @@ struct gndt_handle {
         uint64_t owned_serial = 0;  uint32_t owned_world = 0;   // result_serial / ranks of the owned build global_row describes (0: none)
         bool gathered = false;                                  // gndt_gather_owned_map_device has run for that build (every rank: once per build)
         uint32_t* d_status = nullptr;                           // scratch word for the status kernels
+        // agreement rounds (gndt_api_dist.hip `agree`): one word per rank, device and pinned; allocated with the handle, so that a
+        // rank can ALWAYS say "I cannot go on" — whatever else it failed to allocate
+        unsigned long long* d_agree = nullptr;  unsigned long long* h_agree = nullptr;
+        int inject_site = 0;                                    // tests: the allocation site that fails next (gndt_debug_fail_next_alloc)
         // sliced global rows: the first row of every pair of this rank, everybody's pair places, this rank's, slice totals / rows
         uint32_t* row_of_pair = nullptr; uint64_t row_of_pair_cap = 0;  uint32_t* place_all = nullptr; uint64_t place_all_cap = 0;
         uint32_t* place_mine = nullptr; uint64_t place_mine_cap = 0;  unsigned long long* d_slice = nullptr;   // [2 mine | 2W all | W rows]

@@ -359,6 +359,11 @@ class TwoDmap:
         n = self.sync()[0]
         return self._dev_view(p.value or 0, n * 4, torch.int32, (n,)), int(gn.value), int(gc.value)
 
+    def debug_fail_next_alloc(self, site, demand="slope"):
+        """Tests: the next allocation at `site` of the sharded builds fails once on this handle (include/gndt.h)."""
+        self._ensure(demand)             # (the handle is created lazily, with the demand)
+        self._check(self._L.gndt_debug_fail_next_alloc(self._h, int(site)))
+
     def build_owned(self, comm, demand, points, first_idx_base, total_points, stream=None):
         """Owner-partitioned build over RCCL (called from C++ inside libgndt): this rank's range of the cloud in, the columns
         this rank owns out (export()), plus the global row of each of its rows.  Returns (global_row view, info dict)."""

