@@ -38,7 +38,7 @@ int launch_order_and_emit(gndt_handle* h, uint64_t words, int m0, hipStream_t s,
     hipLaunchKernelGGL(k_emit_rows, dim3(grid_for(q.stage_cap)), dim3(kBlock), 0, s, q.stage, q.inv, h->out, q.row_ncol, h->d_cnt,
                        q.d_pc, counters_to_host ? h->h_cnt : (Counters*)nullptr, counters_to_host ? q.h_pc : (PartCounters*)nullptr,
                        tab_end ? h->d_cnt : (Counters*)nullptr, advance,
-                       partial ? EmitPartial{q.word_base, q.row_of, h->touched} : EmitPartial{nullptr, nullptr, nullptr});
+                       partial ? EmitPartial{q.word_base, q.row_of, h->touched} : EmitPartial{nullptr, nullptr, nullptr}, h->cur_capture_id);
     HIP_TRY(h, hipGetLastError());
     mark(h, m0 + 5, s);
     return GNDT_OK;
@@ -78,7 +78,7 @@ int ensure_cursors(gndt_handle* h, uint64_t B) {
     auto& q = h->part;
     if (B <= q.cur_cap) return GNDT_OK;
     GNDT_NO_CAPTURE(h, "the partition cursors");
-    for (uint32_t** a : {&q.cursors, &q.range_lo, &q.range_hi, &q.range_cap}) { if (*a) (void)hipFree(*a); *a = nullptr; }
+    for (uint32_t** a : {&q.cursors, &q.range_lo, &q.range_hi, &q.range_cap}) { release_device(h, *a); *a = nullptr; }
     q.cur_cap = 0;
     const uint64_t c = B + B / 4;
     HIP_TRY(h, hipMalloc(&q.cursors, ((size_t)kMaxFan + 2 * c) * 4));  // [kMaxFan] level 1, [c] level 2, [c] samples
@@ -179,21 +179,13 @@ int partition_launch(gndt_handle* h, gndt_handle::Pending& P) {
         const double r1 = std::max(2.0, q.fill1_ratio * 1.25);
         const uint64_t cap1w = (uint64_t)(r1 * (double)(n / V)) + 2 * kTile1;
         const uint64_t recs_want = 2 * (uint64_t)n + n / 8 + 2048ull * B + 4096;     // 2 n + 2048 B, and sampling slack
-        if ((!(tuning().l1_inplace != 0 && R == 1) && (uint64_t)V * cap1w > 4 * (uint64_t)n + (1u << 24)) || recs_want >= 0xF0000000ull ||
-            q.two_level_failures >= 2) {
+        if ((uint64_t)V * cap1w > 4 * (uint64_t)n + (1u << 24) || recs_want >= 0xF0000000ull || q.two_level_failures >= 2) {
             q.two_level_ok = false;
             return partition_launch(h, P);                 // (re-enters on the exact path)
         }
         const uint32_t cap1 = (uint32_t)cap1w;
-        // Level 1 in place (round 5, gndt_partition.hpp tile_partition_inplace): no regions, no reservations, n record slots
-        const bool inplace = tuning().l1_inplace != 0 && R == 1;
-        const uint32_t tiles_a = (uint32_t)((P.n + kTile1 - 1) / kTile1), tiles_b = (uint32_t)((P.n2 + kTile1 - 1) / kTile1);
-        const uint32_t tiles_all = P.records ? tiles_a + tiles_b : (uint32_t)((n + kTile1 - 1) / kTile1);
-        P.mean1 = inplace ? 0.0 : (double)(n / V);
-        if (inplace) {
-            if ((rc = grow_buf(h, q.recs1, q.rec1_cap, (uint64_t)tiles_all * kTile1))) return rc;
-            if ((rc = grow_buf(h, q.tab1, q.tab1_cap, (uint64_t)tiles_all * (F1 + 1) + 8))) return rc;
-        } else if ((rc = grow_buf(h, q.recs1, q.rec1_cap, (uint64_t)V * cap1))) return rc;
+        P.mean1 = (double)(n / V);
+        if ((rc = grow_buf(h, q.recs1, q.rec1_cap, (uint64_t)V * cap1))) return rc;
         if ((rc = grow_buf(h, q.recs, q.rec_cap, recs_want))) return rc;
         if ((rc = ensure_cursors(h, B))) return rc;
         uint32_t* cursor1 = q.cursors;
@@ -213,49 +205,29 @@ int partition_launch(gndt_handle* h, gndt_handle::Pending& P) {
         const dim3 g1(std::max<uint32_t>(1, std::min<uint32_t>(tiles1, l1_wgs))), g1b(std::max<uint32_t>(1, std::min<uint32_t>(tiles1b, l1_wgs))),
             g2((uint32_t)((cap1 + kTile2 - 1) / kTile2), V);
         // (the last level-1 workgroup to finish lays out the buckets' regions: range_lo / range_cap)
-#define GNDT_L1(SF_, FAN_, INP_)                                                                                            \
-    hipLaunchKernelGGL((k_part2_level1<SF_, FAN_, false, false, INP_>), g1, dim3(kTileThreads), 0, s, p, (uint64_t)n, P.first_base, gp, B, F1, F2_shift, \
+#define GNDT_L1(SF_, FAN_)                                                                                                  \
+    hipLaunchKernelGGL((k_part2_level1<SF_, FAN_>), g1, dim3(kTileThreads), 0, s, p, (uint64_t)n, P.first_base, gp, B, F1, F2_shift, \
                        R, cursor1, cap1, est2, q.recs1, h->d_cnt, q.d_pc, compress, OwnerMap{nullptr, nullptr, 0u}, q.range_lo,     \
-                       q.range_cap, (uint64_t)q.rec_cap, q.tab1, 0u)
+                       q.range_cap, (uint64_t)q.rec_cap)
         // records: the two segments one after the other into the same regions (the cursors carry on; the last launch lays out)
-#define GNDT_L1R(FAN_, INP_)                                                                                                \
+#define GNDT_L1R(FAN_)                                                                                                      \
     do {                                                                                                                    \
-        if (P.n) hipLaunchKernelGGL((k_part2_level1<4, FAN_, true, false, INP_>), g1, dim3(kTileThreads), 0, s, p, (uint64_t)P.n, P.first_base, gp, B, F1, \
+        if (P.n) hipLaunchKernelGGL((k_part2_level1<4, FAN_, true>), g1, dim3(kTileThreads), 0, s, p, (uint64_t)P.n, P.first_base, gp, B, F1, \
                                     F2_shift, R, cursor1, cap1, est2, q.recs1, h->d_cnt, q.d_pc, compress, OwnerMap{nullptr, nullptr, 0u}, \
-                                    P.n2 ? (uint32_t*)nullptr : q.range_lo, q.range_cap, (uint64_t)q.rec_cap, q.tab1, 0u);   \
-        if (P.n2) hipLaunchKernelGGL((k_part2_level1<4, FAN_, true, false, INP_>), g1b, dim3(kTileThreads), 0, s, p2, (uint64_t)P.n2, P.first_base, gp, B, \
+                                    P.n2 ? (uint32_t*)nullptr : q.range_lo, q.range_cap, (uint64_t)q.rec_cap);               \
+        if (P.n2) hipLaunchKernelGGL((k_part2_level1<4, FAN_, true>), g1b, dim3(kTileThreads), 0, s, p2, (uint64_t)P.n2, P.first_base, gp, B, \
                                      F1, F2_shift, R, cursor1, cap1, est2, q.recs1, h->d_cnt, q.d_pc, compress, OwnerMap{nullptr, nullptr, 0u}, \
-                                     q.range_lo, q.range_cap, (uint64_t)q.rec_cap, q.tab1, tiles_a);                         \
+                                     q.range_lo, q.range_cap, (uint64_t)q.rec_cap);                                          \
     } while (0)
-        if (inplace) {
-            if (P.records) { if (wide) GNDT_L1R(512, true); else GNDT_L1R(256, true); }
-            else if (stride_bytes == 12) { if (wide) GNDT_L1(3, 512, true); else GNDT_L1(3, 256, true); }
-            else { if (wide) GNDT_L1(4, 512, true); else GNDT_L1(4, 256, true); }
-        } else {
-            if (P.records) { if (wide) GNDT_L1R(512, false); else GNDT_L1R(256, false); }
-            else if (stride_bytes == 12) { if (wide) GNDT_L1(3, 512, false); else GNDT_L1(3, 256, false); }
-            else { if (wide) GNDT_L1(4, 512, false); else GNDT_L1(4, 256, false); }
-        }
+        if (P.records) { if (wide) GNDT_L1R(512); else GNDT_L1R(256); }
+        else if (stride_bytes == 12) { if (wide) GNDT_L1(3, 512); else GNDT_L1(3, 256); }
+        else { if (wide) GNDT_L1(4, 512); else GNDT_L1(4, 256); }
 #undef GNDT_L1
 #undef GNDT_L1R
         HIP_TRY(h, hipGetLastError());
         mark(h, 2, s);
         mark(h, 3, s);
-        if (inplace) {
-            // a chunk = G consecutive level-1 tiles whose segments of one region fill a level-2 tile to l2_fill_pct on a balanced cloud
-            const uint32_t G = (uint32_t)std::min<uint64_t>(kGatherMaxG, std::max<uint64_t>(1, (uint64_t)tuning().l2_fill_pct * kTile2 * F1 / (100 * kTile1)));
-            uint32_t steps = 0;
-            while ((1u << steps) < G) ++steps;
-            const uint32_t rf = tuning().l2_region_fast ? 1u : 0u;
-            const uint32_t nchunks = (tiles_all + G - 1) / G;
-            const dim3 g2g((uint32_t)std::min<uint64_t>((uint64_t)nchunks * F1, tuning().l2_wgs));      // persistent: four resident per CU
-            if (wide)
-                hipLaunchKernelGGL(k_part2_level2_gather<512>, g2g, dim3(kTileThreads), 0, s, (const float4*)q.recs1, (const uint16_t*)q.tab1, tiles_all, F1, G,
-                                   steps, gp, B, F2, cursor2, q.range_lo, q.range_cap, q.recs, q.d_pc, rf, nchunks);
-            else
-                hipLaunchKernelGGL(k_part2_level2_gather<256>, g2g, dim3(kTileThreads), 0, s, (const float4*)q.recs1, (const uint16_t*)q.tab1, tiles_all, F1, G,
-                                   steps, gp, B, F2, cursor2, q.range_lo, q.range_cap, q.recs, q.d_pc, rf, nchunks);
-        } else if (wide)
+        if (wide)
             hipLaunchKernelGGL(k_part2_level2<512>, g2, dim3(kTileThreads), 0, s, q.recs1, cursor1, cap1, R, gp, B, F2, cursor2,
                                q.range_lo, q.range_cap, q.recs, q.d_pc);
         else
@@ -318,8 +290,8 @@ int partition_launch(gndt_handle* h, gndt_handle::Pending& P) {
     if ((rc = grow_buf(h, q.hist, q.hist_cap, (uint64_t)nwg * B))) return rc;
     if (B > q.bucket_cap) {
         GNDT_NO_CAPTURE(h, "the bucket totals");
-        if (q.totals) (void)hipFree(q.totals);
-        if (q.bucket_base) (void)hipFree(q.bucket_base);
+        release_device(h, q.totals);
+        release_device(h, q.bucket_base);
         q.totals = q.bucket_base = nullptr; q.bucket_cap = 0;
         HIP_TRY(h, hipMalloc(&q.totals, (size_t)B * 4));
         HIP_TRY(h, hipMalloc(&q.bucket_base, ((size_t)B + 1) * 4));
@@ -503,9 +475,15 @@ int partition_begin(gndt_handle* h, const void* xyz_dev, size_t n, size_t stride
         hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
         (void)hipStreamIsCapturing(s, &cap);
         P.captured = cap != hipStreamCaptureStatusNone;
+        P.captured_gen = h->realloc_gen;
     }
     rc = partition_launch(h, P);
     if (rc) { h->last_strategy = prev_strategy; return rc; }
+    if (h->cur_capture_id) {                       // (recorded: what the replays of this call will have run, and with which buffers)
+        auto& rec = h->captures[h->cur_capture_id % 32];
+        rec.partition = true; rec.two_level = P.two_level; rec.one_level = P.one_level;
+        rec.realloc_gen = h->realloc_gen; rec.table_gen = h->table_gen;
+    }
     P.active = true;
     h->results_valid = false;
     h->map_in_table = false;
@@ -601,6 +579,13 @@ int partition_resolve(gndt_handle* h) {
             // replay wrote through freed pointers: a GPU memory fault; tools/fuzz_graph.py).  Reported instead, like a later replay.
             P.active = false;
             h->results_valid = false;
+            // (round 5: the capture itself is sound — only THIS cloud did not fit — so the handle is left as after any reported replay:
+            //  a later replay that fits is validated by partition_recheck_after_replay and can be exported.  Until then this first
+            //  failure left later, fitting replays "no finished build": DESIGN §8.7 of round 4.)
+            ++h->result_serial;
+            P.done_serial = h->result_serial;
+            P.replay_failed = true;
+            h->table_dirty = false;
             h->err = "a build replayed from a hipGraph ran out of room (LDS tables " + std::to_string(q.h_pc->lds_overflow) + ", partition regions " +
                      std::to_string(q.h_pc->part_overflow) + ", staging rows " + std::to_string(q.h_pc->stage_overflow) +
                      "): the capture is sized for the cloud it was recorded on — build this cloud eagerly (gndt_build_device + gndt_sync), then capture again";
@@ -740,12 +725,11 @@ int gndt_reserve(gndt_handle* h, uint64_t max_points, uint64_t max_nodes) {
     constexpr uint64_t kTile1 = (uint64_t)kTileThreads * kTilePer1;
     if ((rc = grow_buf(h, q.recs, q.rec_cap, 2 * n + n / 8 + 2048ull * Bmax + 4096))) return rc;                    // two-level (covers the exact partition's n)
     if ((rc = grow_buf(h, q.recs1, q.rec1_cap, 4 * n + (1u << 24) + (uint64_t)kMaxFan * (4096 + 2 * kTile1)))) return rc;   // level-1 regions at their ceiling / one-level rooms
-    if ((rc = grow_buf(h, q.tab1, q.tab1_cap, (n / kTile1 + 4) * (uint64_t)(kMaxFan + 1) + 8))) return rc;                   // level 1 in place: the tiles' digit offsets
     const uint64_t Bexact = std::min<uint64_t>(Bmax, kMaxBuckets);
     if ((rc = grow_buf(h, q.hist, q.hist_cap, (uint64_t)kPartWgs * Bexact))) return rc;
     if (Bexact > q.bucket_cap) {
-        if (q.totals) (void)hipFree(q.totals);
-        if (q.bucket_base) (void)hipFree(q.bucket_base);
+        release_device(h, q.totals);
+        release_device(h, q.bucket_base);
         q.totals = q.bucket_base = nullptr; q.bucket_cap = 0;
         HIP_TRY(h, hipMalloc(&q.totals, (size_t)Bexact * 4));
         HIP_TRY(h, hipMalloc(&q.bucket_base, ((size_t)Bexact + 1) * 4));

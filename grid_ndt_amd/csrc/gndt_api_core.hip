@@ -21,13 +21,9 @@ Tuning parse_tuning() {
     t.bucket_slots = geti("GNDT_BUCKET_SLOTS", t.bucket_slots);
     t.two_level = geti("GNDT_TWO_LEVEL", t.two_level);
     t.l1_wgs = (uint32_t)geti("GNDT_L1_WGS", (int)t.l1_wgs);
-    t.l1_inplace = geti("GNDT_L1_INPLACE", t.l1_inplace);
     t.interleave = geti("GNDT_INTERLEAVE", t.interleave);
     t.sketch = geti("GNDT_SKETCH", t.sketch);
     t.retry_pass = geti("GNDT_RETRY_PASS", t.retry_pass);
-    t.l2_region_fast = geti("GNDT_L2_ORDER", t.l2_region_fast);
-    t.l2_wgs = (uint32_t)std::max(1, geti("GNDT_L2_WGS", (int)t.l2_wgs));
-    t.l2_fill_pct = std::min(100, std::max(10, geti("GNDT_L2_FILL", t.l2_fill_pct)));
     if (getenv("GNDT_BUCKET_WGS")) t.bucket_wgs = (uint32_t)atoi(getenv("GNDT_BUCKET_WGS"));
     if (getenv("GNDT_TILE_RATIO")) t.tile_ratio = atof(getenv("GNDT_TILE_RATIO"));
     t.owner_locality = geti("GNDT_OWNER_LOCALITY", t.owner_locality);
@@ -48,8 +44,7 @@ int ensure_out(gndt_handle* h, uint64_t n) {
     GNDT_NO_CAPTURE(h, "the result arrays");
     void* ptrs[] = {h->out.sx, h->out.sy, h->out.sz, h->out.count, h->out.first_idx, h->out.mean, h->out.cov,
                     h->out.rough, h->out.normal, h->out.flags};
-    for (void* p : ptrs)
-        if (p) (void)hipFree(p);
+    for (void* p : ptrs) release_device(h, p);
     h->out = OutView{};
     h->out_cap = 0;
     uint64_t c = std::max<uint64_t>(1024, n + n / 8);
@@ -71,8 +66,7 @@ int ensure_stats_buffers(gndt_handle* h, uint64_t n) {
     if (n <= h->st_cap) return GNDT_OK;
     GNDT_NO_CAPTURE(h, "the statistics buffers");
     void* ptrs[] = {h->st_key, h->st_sums, h->st_count, h->st_first};
-    for (void* p : ptrs)
-        if (p) (void)hipFree(p);
+    for (void* p : ptrs) release_device(h, p);
     h->st_key = nullptr; h->st_sums = nullptr; h->st_count = nullptr; h->st_first = nullptr; h->st_cap = 0;
     uint64_t c = std::max<uint64_t>(1024, n + n / 8);
     HIP_TRY(h, hipMalloc(&h->st_key, c * 8));
@@ -101,7 +95,7 @@ int check_ready(gndt_handle* h) {
 
 void free_part(gndt_handle* h) {
     auto& q = h->part;
-    void* ptrs[] = {q.recs, q.recs1, q.tab1, q.cursors, q.range_lo, q.range_hi, q.range_cap, q.hist, q.totals, q.bucket_base, q.stage, q.ord_cf, q.ord_idx, q.inv, q.row_of, q.row_ncol,
+    void* ptrs[] = {q.recs, q.recs1, q.cursors, q.range_lo, q.range_hi, q.range_cap, q.hist, q.totals, q.bucket_base, q.stage, q.ord_cf, q.ord_idx, q.inv, q.row_of, q.row_ncol,
                     q.bitmap, q.word_weight, q.word_base, q.bsum_words, q.ncol_at, q.d_pc, q.dbg};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -114,8 +108,7 @@ int ensure_stage(gndt_handle* h, uint64_t nodes) {
     if (nodes <= q.stage_cap) return GNDT_OK;
     GNDT_NO_CAPTURE(h, "the staging rows");
     void* ptrs[] = {q.stage, q.ord_cf, q.ord_idx, q.inv, q.row_of};
-    for (void* p : ptrs)
-        if (p) (void)hipFree(p);
+    for (void* p : ptrs) release_device(h, p);
     q.stage = nullptr; q.ord_cf = q.ord_idx = q.inv = q.row_of = nullptr;
     q.stage_cap = 0;
     HIP_TRY(h, hipMalloc(&q.stage, nodes * sizeof(StageRow)));
@@ -131,7 +124,7 @@ int ensure_words(gndt_handle* h, uint64_t words) {
     auto& q = h->part;
     if (words <= q.word_cap) return GNDT_OK;
     GNDT_NO_CAPTURE(h, "the column-order bitmap (raise gndt_params.max_points_hint)");
-    for (uint32_t** a : {&q.bitmap, &q.word_weight, &q.word_base, &q.bsum_words, &q.ncol_at}) { if (*a) (void)hipFree(*a); *a = nullptr; }
+    for (uint32_t** a : {&q.bitmap, &q.word_weight, &q.word_base, &q.bsum_words, &q.ncol_at}) { release_device(h, *a); *a = nullptr; }
     q.word_cap = 0;
     words += words / 4;
     HIP_TRY(h, hipMalloc(&q.bitmap, words * 4));
@@ -221,6 +214,14 @@ int use_stream(gndt_handle* h, hipStream_t s) {
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     (void)hipStreamIsCapturing(s, &cap);
     h->capturing = cap != hipStreamCaptureStatusNone;
+    h->cur_capture_id = 0;
+    if (h->capturing) {
+        h->ever_captured = true;                         // (from now on outgrown buffers are retired, not freed: Handle::retired)
+        h->cur_capture_id = ++h->capture_seq;            // this recorded call (what it is, and with which buffers, is noted when it launches)
+        auto& rec = h->captures[h->cur_capture_id % 32];
+        rec = gndt_handle::CaptureRec{};
+        rec.id = h->cur_capture_id; rec.realloc_gen = h->realloc_gen; rec.table_gen = h->table_gen;
+    }
     // (a stream under graph capture cannot wait for un-captured work: the caller orders the capture itself)
     if (h->last_stream != s && cap == hipStreamCaptureStatusNone) {     // (last_stream is always a stream: own_stream from gndt_create on)
         if (!h->xstream_ev) HIP_TRY(h, hipEventCreateWithFlags(&h->xstream_ev, hipEventDisableTiming));
@@ -319,6 +320,7 @@ void gndt_destroy(gndt_handle* h) {
     if (h->xstream_ev) (void)hipEventDestroy(h->xstream_ev);
     if (h->exp_host) (void)hipHostFree(h->exp_host);
     for (int b = 0; b < 2; ++b) { if (h->bounce[b]) (void)hipHostFree(h->bounce[b]); if (h->bounce_ev[b]) (void)hipEventDestroy(h->bounce_ev[b]); }
+    for (void* p : h->retired) (void)hipFree(p);
     if (h->d_sketch) (void)hipFree(h->d_sketch);
     if (h->h_sketch) (void)hipHostFree(h->h_sketch);
     if (h->d_sample) (void)hipFree(h->d_sample);
@@ -353,19 +355,70 @@ int gndt_reset(gndt_handle* h, void* hip_stream) {
     h->last_strategy = GNDT_STRATEGY_ATOMIC;
     return do_reset(h, s);
 }
+// Called with the stream idle.  The flags' host mirror names the recorded call that produced it (PartCounters::capture_id; 0 = a
+// call the host launched).  A replay is work the host did not see: if its buffers have been reallocated since the recording, what
+// it wrote is not in the handle's buffers (GNDT_ERR_CAPACITY: capture again); if it is a PARTITION build and the host's last own
+// build went through the node table (or the other way round), the handle's idea of what it holds is brought in line first.
+static int replay_check(gndt_handle* h) {
+    auto& q = h->part;
+    if (!q.h_pc || h->pending.active) return GNDT_OK;
+    const uint32_t cid = q.h_pc->capture_id;
+    h->replay_seen = cid;
+    if (!cid) return GNDT_OK;
+    const auto& rec = h->captures[cid % 32];
+    const bool known = rec.id == cid;
+    const bool moved = !known || rec.realloc_gen != h->realloc_gen || (!rec.partition && rec.table_gen != h->table_gen);
+    if (moved) {
+        h->results_valid = false;
+        h->pending.replay_failed = true;
+        h->err = "a hipGraph replay ran after buffers of this handle had been reallocated (an eager call of another size since the recording): "
+                 "it wrote through the old pointers — run the call eagerly once (or gndt_reserve), then capture again";
+        return GNDT_ERR_CAPACITY;
+    }
+    // What the device holds is a finished run of the recorded call, with the handle's own buffers: it can be read again even if an
+    // earlier replay was reported (too many nodes for what was recorded: the flags are looked at again right after this, and say so
+    // again if THIS replay does not fit either).  Until round 5 one reported replay left every later one "no finished build".
+    if (rec.partition) { if (!h->results_valid) h->pending.replay_failed = true; }
+    else h->results_valid = true;
+    if (rec.partition && h->map_in_table) {            // a PARTITION build replayed after an eager table-path call
+        auto& P = h->pending;
+        h->map_in_table = false;
+        h->last_strategy = rec.two_level ? GNDT_STRATEGY_PARTITION : (rec.one_level ? GNDT_STRATEGY_PARTITION_ONE_LEVEL : GNDT_STRATEGY_PARTITION_EXACT);
+        h->incr_ok = false;
+        h->emit_pending = false;
+        h->results_valid = true;
+        ++h->result_serial;
+        P = gndt_handle::Pending{};                      // (what is known of the recorded build: enough for the flags' check that follows)
+        P.captured = true; P.two_level = rec.two_level; P.one_level = rec.one_level;
+        P.done_serial = h->result_serial;
+    } else if (!rec.partition && !h->map_in_table) {   // a table-path call replayed after an eager PARTITION build
+        h->map_in_table = true;
+        h->last_strategy = GNDT_STRATEGY_ATOMIC;
+        h->incr_ok = false;                              // (the next update relabels every column)
+        h->table_dirty = true;
+        h->results_valid = true;
+        ++h->result_serial;
+        h->pending.done_serial = 0;
+    }
+    return GNDT_OK;
+}
+
 int gndt_sync(gndt_handle* h, uint64_t* num_nodes, uint64_t* num_columns, uint64_t* num_slopes) {
     if (!h) return GNDT_ERR_INVALID;
     HIP_TRY(h, hipSetDevice(h->device));
     { const int prc = partition_resolve(h); if (prc) return prc; }
     HIP_TRY(h, hipStreamSynchronize(h->last_stream));
+    { const int crc = replay_check(h); if (crc) return crc; }                          // (what the device holds may be a replay the host did not see)
     { const int rrc = partition_recheck_after_replay(h); if (rrc) return rrc; }      // (a replayed build that ran out of room says so)
     if (h->results_valid && (h->emit_pending || h->deferred_captured) && h->map_in_table) {      // deferred-emit mode: the rows are produced now, for all the frames since the last read
         const int erc = table_emit_pending(h);
         if (erc) return erc;
     }
-    if (h->results_valid && h->small_used && h->part.h_pc && h->part.h_pc->small_fallback) {
+    // (asked of the DEVICE's flag and of the id in the mirror, not of what the host's last own call used: round 5, tools/fuzz_graph.py —
+    //  a recorded small-map build replayed on a larger cloud right after an eager full finalisation came back as a map of 0 columns)
+    if (h->results_valid && h->part.h_pc && h->part.h_pc->small_fallback && (h->small_used || h->replay_seen)) {
         // the one-workgroup finalisation (k_small_finalize) met a map that is not small and wrote nothing
-        if (h->small_captured) {
+        if (h->replay_seen || h->small_captured) {
             h->results_valid = false;
             h->err = "a build replayed from a hipGraph has more nodes than the small-map finalisation it was captured with can hold: "
                      "build this cloud eagerly (gndt_build_device + gndt_sync), then capture again";

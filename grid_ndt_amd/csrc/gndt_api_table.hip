@@ -11,8 +11,7 @@ void free_table(gndt_handle* h) {
     void* ptrs[] = {h->keys, h->acc, h->col_keys, h->col_first, h->aux, h->node_slot, h->col_slot_of_node,
                     h->col_cnt, h->col_head, h->node_next, h->ninfo, h->index_of_slot, h->touch_epoch, h->col_epoch, h->touched,
                     h->touched_cols};
-    for (void* p : ptrs)
-        if (p) (void)hipFree(p);
+    for (void* p : ptrs) release_device(h, p, false);
     h->keys = nullptr; h->acc = nullptr; h->col_keys = nullptr; h->col_first = nullptr; h->aux = nullptr;
     h->node_slot = nullptr; h->col_slot_of_node = nullptr; h->col_cnt = nullptr; h->col_head = nullptr; h->node_next = nullptr; h->ninfo = nullptr;
     h->index_of_slot = h->touch_epoch = h->col_epoch = h->touched = h->touched_cols = nullptr;
@@ -38,8 +37,9 @@ int alloc_table(gndt_handle* h, uint32_t cap, hipStream_t s) {
     for (uint32_t** a : {&h->index_of_slot, &h->touch_epoch, &h->col_epoch, &h->touched, &h->touched_cols})
         HIP_TRY(h, hipMalloc(a, (size_t)cap * sizeof(uint32_t)));
     h->cap = cap;
+    ++h->table_gen;
     hipLaunchKernelGGL(k_clear_all, dim3(grid_for(cap)), dim3(kBlock), 0, s, h->keys, h->acc, h->col_keys,
-                       h->col_first, h->col_cnt, h->col_head, h->touch_epoch, h->col_epoch, cap);
+                       h->col_first, h->col_cnt, h->col_head, h->touch_epoch, h->col_epoch, cap, h->d_cnt, h->table_gen);
     HIP_TRY(h, hipGetLastError());
     h->table_dirty = false;
     return GNDT_OK;
@@ -65,7 +65,7 @@ int do_reset(gndt_handle* h, hipStream_t s) {
     // kernel finds an empty node list and only zeroes the counters.
     if (h->cap && (h->table_dirty || h->capturing))       // (its last workgroup zeroes the counters)
         hipLaunchKernelGGL(k_clear_used, dim3(grid_for(h->cap / 8)), dim3(kBlock), 0, s, h->keys, h->acc, h->col_keys,
-                           h->col_first, h->col_cnt, h->col_head, h->node_slot, h->col_slot_of_node, h->d_cnt);
+                           h->col_first, h->col_cnt, h->col_head, h->node_slot, h->col_slot_of_node, h->d_cnt, h->cap, h->table_gen);
     else
         hipLaunchKernelGGL(k_zero_counters, dim3(1), dim3(64), 0, s, h->d_cnt);
     HIP_TRY(h, hipGetLastError());
@@ -148,6 +148,10 @@ int do_finalize(gndt_handle* h, hipStream_t s, bool incremental = false, uint64_
     const TableView T = table_view(h);
     const GridParams gp = grid_params(h);
     const ColumnOrder O{q.bitmap, q.word_weight, q.ncol_at};
+    if (h->cur_capture_id) {                       // (recorded: a table-path call, with the buffers as they are now)
+        auto& rec = h->captures[h->cur_capture_id % 32];
+        rec.partition = false; rec.realloc_gen = h->realloc_gen; rec.table_gen = h->table_gen;
+    }
     mark(h, 2, s);
     // Small maps — a few hundred nodes: a depth-camera frame at the launch cells — are finalised by ONE workgroup in ONE launch
     // (k_small_finalize) instead of the six kernels below.  The host goes by what the last resolved build of this handle had; a
@@ -157,7 +161,7 @@ int do_finalize(gndt_handle* h, hipStream_t s, bool incremental = false, uint64_
     //  order arrays this kernel does not write, and overwrite its rows)
     if (!incremental && advance == 0 && h->small_ok && h->table_nodes_seen && h->table_nodes_seen <= 900u && !h->emit_pending && !h->deferred_captured) {
         hipLaunchKernelGGL(k_small_finalize, dim3(1), dim3(kSmallMapNodes), 0, s, T, gp, h->out, q.row_ncol, h->d_cnt, q.d_pc, h->h_cnt, q.h_pc,
-                           raise_to, (uint32_t)std::min<uint64_t>(h->out_cap, 0xFFFFFFFFull));
+                           raise_to, (uint32_t)std::min<uint64_t>(h->out_cap, 0xFFFFFFFFull), h->cur_capture_id);
         HIP_TRY(h, hipGetLastError());
         for (int i = 3; i <= 9; ++i) mark(h, i, s);
         h->small_used = true;
@@ -199,7 +203,7 @@ int do_finalize(gndt_handle* h, hipStream_t s, bool incremental = false, uint64_
         // Deferred-emit mode: the frame ends here — touched columns relabelled, their staging rows and the column order up to date,
         // the bookkeeping done by a one-thread launch.  The ordering + emit pass (O(map): rows move when a column in front of them
         // grows) runs when somebody reads the map (gndt_sync -> table_emit_pending).  A frame costs O(touched).
-        hipLaunchKernelGGL(k_tab_end, dim3(1), dim3(64), 0, s, h->d_cnt, (const PartCounters*)q.d_pc, h->h_cnt, q.h_pc, advance);
+        hipLaunchKernelGGL(k_tab_end, dim3(1), dim3(64), 0, s, h->d_cnt, (const PartCounters*)q.d_pc, h->h_cnt, q.h_pc, advance, h->cur_capture_id);
         HIP_TRY(h, hipGetLastError());
         for (int i = 5; i <= 9; ++i) mark(h, i, s);
         h->emit_pending = true;

@@ -35,6 +35,22 @@ struct gndt_handle {
     hipStream_t own_stream = nullptr;
     hipStream_t last_stream = nullptr;
     hipEvent_t xstream_ev = nullptr;   // orders work on a new stream behind what the previous one still runs (use_stream)
+    // A build recorded into a hipGraph keeps the device pointers of its day.  Once a stream of this handle has been seen under
+    // capture, buffers that are outgrown are not freed but RETIRED (kept until gndt_destroy): a replay of the old graph then writes
+    // into memory that is still the handle's — its result is reported as stale (realloc_gen), but it cannot fault or corrupt
+    // someone else's allocation (round 5, tools/fuzz_graph.py: "write access to a read-only page" 60 s into the first seed that
+    // put eager table-family builds between the replays).
+    bool ever_captured = false;  std::vector<void*> retired;
+    uint32_t table_gen = 0;            // allocations of the node table so far (Counters::table_gen on the device)
+    // Calls recorded into a hipGraph: each gets an id that the last kernel of the recorded work stores into the host's mirror of the
+    // flags (PartCounters::capture_id) — so the call that next waits for the stream can tell that what it finds on the device is a
+    // REPLAY (the host saw none of it), of which recorded call, and whether that call's buffers are still the handle's.
+    struct CaptureRec { uint32_t id = 0; uint64_t realloc_gen = 0; uint32_t table_gen = 0; bool partition = false; bool two_level = false, one_level = false; };
+    CaptureRec captures[32];           // (a ring: a handle with more than 32 live graphs reports the oldest ones as stale)
+    uint32_t capture_seq = 0, cur_capture_id = 0;
+    uint32_t replay_seen = 0;          // the capture id the last gndt_sync found in the mirror (0: the host's own call)
+    uint64_t realloc_gen = 0;          // bumped whenever a device buffer of this handle is freed / reallocated: a build recorded into a hipGraph
+                                       //   before that writes through the old pointers when replayed — noticed and reported (Pending::captured_gen)
     bool capturing = false;            // the stream of the call in progress is under hipGraph capture (use_stream): nothing may allocate,
                                        //   free or wait — such a call would not only fail, it INVALIDATES the capture (GNDT_NO_CAPTURE)
 
@@ -100,7 +116,6 @@ struct gndt_handle {
         uint64_t rec_cap = 0;      float4* recs = nullptr;
         // two-level partition: level-1 regions, cursors of both levels, record ranges of the fine buckets
         uint64_t rec1_cap = 0;     float4* recs1 = nullptr;
-        uint64_t tab1_cap = 0;     uint16_t* tab1 = nullptr;     // level 1 in place: digit offsets of every tile ([tiles][F1 + 1])
         uint64_t cur_cap = 0;      uint32_t *cursors = nullptr, *range_lo = nullptr, *range_hi = nullptr, *range_cap = nullptr;
         // (range_hi doubles as the bucket kernel's retry list: buckets whose 512-slot table overflowed, done again with 1024 slots)
         bool retry_pass = true;    // launch that second pass behind the bucket kernel (first builds, captured builds, clouds that needed it)
@@ -213,6 +228,7 @@ struct gndt_handle {
         bool retry_pass = false;        //   ... and the bucket kernel's second pass behind the first (overflowing 512-slot tables done again with 1024)
         double mean1 = 0.0;             // its mean level-1 region fill (to turn the fullest region into a ratio)
         bool stats_only = false;        // gndt_shard_stats_device: statistics out, no labels / ordering / rows
+        uint64_t captured_gen = 0;      // Handle::realloc_gen when this build was recorded (captured builds only)
         bool captured = false;          // launched on a stream under hipGraph capture: it runs when the graph is replayed, with the
                                         //   buffers it was recorded with — never re-run here with more room (new buffers: the graph holds the old)
         bool replay_failed = false;     // the last replay of this build ran out of room (results_valid is false because of that, and only that)
@@ -247,10 +263,6 @@ struct Tuning {
     int retry_pass = 1;          // GNDT_RETRY_PASS     0: never launch the bucket kernel's second pass (an overflowing 512-slot table re-runs the build, as before round 5)
     int sketch = 1;              // GNDT_SKETCH         a fresh handle without a hint counts its first cloud's nodes (HyperLogLog pass) instead of guessing n / 4
     int interleave = -1;         // GNDT_INTERLEAVE     bucket kernel: record pairs interleaved over the waves (1), consecutive (0), by the last build's locality (-1)
-    int l1_inplace = 0;          // GNDT_L1_INPLACE     two-level partition: level 1 writes sorted tiles in place, level 2 gathers segments (0: reserved regions)
-    uint32_t l2_wgs = 1024;      // GNDT_L2_WGS         persistent workgroups of the gathering level 2
-    int l2_region_fast = 1;      // GNDT_L2_ORDER       gathering level 2: concurrent workgroups share tiles (1) or a region (0)
-    int l2_fill_pct = 85;        // GNDT_L2_FILL        ... and how full a level-2 tile the segments of a chunk are meant to make (percent)
     uint32_t bucket_wgs = 0xFFFFFFFFu;   // GNDT_BUCKET_WGS   persistent bucket workgroups (default: one per bucket)
     double tile_ratio = 48.0;    // GNDT_TILE_RATIO     AUTO takes strategy TILE from this many points per partial on (sampled; the
                                  //                     measured crossover, profiles/r02_tile_calibration.json)
@@ -340,11 +352,18 @@ inline hipStream_t stream_of(gndt_handle* h, void* hip_stream) {
     return (hipStream_t)hip_stream == hipStreamLegacy ? (hipStream_t) nullptr : (hipStream_t)hip_stream;
 }
 
+// a device buffer of the handle goes out of use (see Handle::retired)
+inline void release_device(gndt_handle* h, void* p, bool bump = true) {     // (bump = false: the node table, which has a generation of its own)
+    if (!p) return;
+    if (bump) ++h->realloc_gen;
+    if (h->ever_captured) h->retired.push_back(p); else (void)hipFree(p);
+}
+
 template <typename T>
 int grow_buf(gndt_handle* h, T*& p, uint64_t& cap, uint64_t want) {
     if (want <= cap) return GNDT_OK;
     GNDT_NO_CAPTURE(h, "a work buffer");
-    if (p) (void)hipFree(p);
+    release_device(h, p);
     p = nullptr; cap = 0;
     HIP_TRY(h, hipMalloc(&p, want * sizeof(T)));
     cap = want;

@@ -51,6 +51,13 @@ struct Counters {
     uint32_t first_word;      // incremental finalisation: first bitmap word whose column order changed in this frame (a column
                               //   gained a node or is new); rows of columns in front of it keep their places.  0xFFFFFFFF: none
     uint32_t ticket;          // k_clear_used: workgroups that are done (the last one zeroes the counters); 0 between kernels
+    uint32_t table_gen;       // which allocation of the node table the counters belong to (set by k_clear_all: once per allocation).
+                              //   A reset recorded into a hipGraph carries the generation of ITS day: replayed after the table has
+                              //   been reallocated it must not touch anything (its pointers are the old table's) ...
+    uint32_t table_unclean;   //   ... and cannot clear the table that took its place: it says so here, and the next reset that does
+                              //   hold the current table clears ALL of it instead of the listed slots (round 5, tools/fuzz_graph.py
+                              //   with eager table-path builds between the replays: a GPU memory fault — the recorded reset walked
+                              //   the old table's node list with the new table's node count)
     uint32_t part_owned;      // 1 while num_nodes counts a PARTITION build's staged rows (set by k_part_clear) and NOT the node list of
                               //   the table, which is empty then (every partition build resets a dirty table first; a captured one
                               //   always records the reset): k_clear_used must not walk node_slot[0 .. num_nodes) — past the list the
@@ -152,7 +159,8 @@ __device__ __forceinline__ double wave_sum(double v) {
 // k_clear_all: whole-table initialisation (once at create / after growth)
 // ---------------------------------------------------------------------------------------------
 static __global__ void k_clear_all(uint64_t* keys, NodeAcc* acc, uint64_t* col_keys, uint32_t* col_first, uint32_t* col_cnt,
-                            uint32_t* col_head, uint32_t* touch_epoch, uint32_t* col_epoch, uint32_t cap) {
+                            uint32_t* col_head, uint32_t* touch_epoch, uint32_t* col_epoch, uint32_t cap, Counters* cur, uint32_t gen) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) { cur->table_gen = gen; cur->table_unclean = 0u; }      // (a new table: this generation, clean)
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < cap; i += gridDim.x * blockDim.x) {
         keys[i] = kEmptyKey;
         col_keys[i] = kEmptyKey;
@@ -170,7 +178,10 @@ static __global__ void k_clear_all(uint64_t* keys, NodeAcc* acc, uint64_t* col_k
 
 // k_clear_used: empty the map by visiting only its occupied slots (O(C), not O(cap)).  Nodes that went through a
 // finalize (i < prev_nodes) also own a column-table entry.
-static __device__ __forceinline__ void zero_counters(Counters* c) {
+// `table_cleared`: the caller has emptied the CURRENT node table (or it was empty).  If it has not, and the counters describe a
+// table that holds nodes, the table stays behind unclean (see Counters::table_unclean).
+static __device__ __forceinline__ void zero_counters(Counters* c, bool table_cleared) {
+    if (!table_cleared && c->part_owned == 0u && c->num_nodes != 0u) c->table_unclean = 1u;
     c->num_nodes = 0; c->num_columns = 0; c->num_slopes = 0; c->err_key_range = 0; c->err_table_full = 0;
     c->stream_pos = 0; c->prev_nodes = 0; c->n_touched = 0; c->n_tcols = 0; c->n_work = 0; c->n_dead = 0; c->err_remove = 0;
     c->epoch = c->epoch + 1u;                     // stale touch marks of the previous map can never match again
@@ -179,11 +190,27 @@ static __device__ __forceinline__ void zero_counters(Counters* c) {
 
 static __global__ void k_clear_used(uint64_t* keys, NodeAcc* acc, uint64_t* col_keys, uint32_t* col_first, uint32_t* col_cnt,
                              uint32_t* col_head, const uint32_t* node_slot, const uint32_t* col_slot_of_node,
-                             Counters* cur) {
-    const bool listed = cur->part_owned == 0u;    // (else: the counters are a PARTITION build's and the table is empty)
-    const uint32_t n = listed ? cur->num_nodes : 0u, np = listed ? cur->prev_nodes : 0u;
+                             Counters* cur, uint32_t cap, uint32_t gen) {
+    const bool mine = cur->table_gen == gen;      // (else: recorded for a table that has been reallocated since — hands off)
+    const bool everything = mine && cur->table_unclean != 0u;      // a stale reset could not clear this table: all of it, now
+    const bool listed = mine && !everything && cur->part_owned == 0u;    // (part_owned: the counters are a PARTITION build's and the table is empty)
+    const uint32_t n = listed ? min(cur->num_nodes, cap) : 0u, np = listed ? cur->prev_nodes : 0u;
+    if (everything) {
+        for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < cap; i += gridDim.x * blockDim.x) {
+            keys[i] = kEmptyKey;
+            col_keys[i] = kEmptyKey;
+            col_first[i] = 0xFFFFFFFFu;
+            col_cnt[i] = 0u;
+            col_head[i] = 0xFFFFFFFFu;
+            NodeAcc a;
+            for (int k = 0; k < 9; ++k) a.s[k] = 0.0;
+            a.count = 0; a.first = 0xFFFFFFFFu;
+            acc[i] = a;
+        }
+    }
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const uint32_t slot = node_slot[i];
+        if (slot >= cap) continue;
         keys[slot] = kEmptyKey;
         NodeAcc a;
         for (int k = 0; k < 9; ++k) a.s[k] = 0.0;
@@ -191,6 +218,7 @@ static __global__ void k_clear_used(uint64_t* keys, NodeAcc* acc, uint64_t* col_
         acc[slot] = a;
         if (i < np) {
             const uint32_t cs = col_slot_of_node[i];   // nodes of one column write the same values: benign
+            if (cs >= cap) continue;
             col_keys[cs] = kEmptyKey;
             col_first[cs] = 0xFFFFFFFFu;
             col_cnt[cs] = 0u;
@@ -201,14 +229,15 @@ static __global__ void k_clear_used(uint64_t* keys, NodeAcc* acc, uint64_t* col_
     // has read them above; the workgroup that takes the last ticket knows that all the others have, too.
     __syncthreads();
     if (threadIdx.x == 0 && atomicAdd(&cur->ticket, 1u) == gridDim.x - 1u) {
-        zero_counters(cur);
+        zero_counters(cur, mine);
+        if (everything) cur->table_unclean = 0u;
         cur->ticket = 0u;
     }
 }
 
 // all counters to zero (after the clear that read them)
 static __global__ void k_zero_counters(Counters* c) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) zero_counters(c);
+    if (threadIdx.x == 0 && blockIdx.x == 0) zero_counters(c, false);      // (no table cleared: if the counters describe one that holds nodes, it is marked)
 }
 
 // A record's index word.  Bit 31: the record stands for 64 identical consecutive points (one wave of the partition pass:

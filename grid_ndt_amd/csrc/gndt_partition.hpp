@@ -49,6 +49,9 @@ struct PartCounters {
     uint32_t l1_ticket;        //   wrong node (gndt_bucket3.hpp; diagnostic); level-1 workgroups that are done (the last one lays
     uint32_t small_fallback;   //   out the buckets' regions; 0 between kernels); k_small_finalize met more nodes than it has threads
     uint32_t pairs;            // bucket kernel: lanes whose two ADJACENT records fell into one node (the cloud's locality inside its buckets)
+    uint32_t capture_id;       // HOST MIRROR ONLY: which recorded call produced what the mirrors hold (0: a call the host launched itself).
+                               //   Stored by the kernel that sends the counters home; the host compares it with what it knows of that
+                               //   capture (gndt_sync): a replay it did not see, buffers reallocated since the recording.
     uint32_t lds_retry;        // buckets whose 512-slot table overflowed and that wait for the second pass with 1024 slots (the retry list's length)
 };
 
@@ -371,6 +374,9 @@ __global__ void __launch_bounds__(kPartThreads) k_part_scatter(const float* __re
 // region c starts at c*cap1, fine bucket b at b*cap2; the fill comes from the cursors.  A region that would
 // overflow raises PartCounters::part_overflow and the host re-runs the build on the exact counting path.
 // Record order inside a bucket depends on the order in which tiles reserve; nothing downstream depends on it.
+// (Round 5 built level 1 WITHOUT reservations — sorted tiles written back in place, level 2 gathering one segment per tile — and
+//  took it out again: level 1 gains 6-19 us of 81, level 2 loses 19-33 of 65 to the per-record segment search, whatever its launch
+//  shape; profiles/r05_ablation.txt §1.)
 // ---------------------------------------------------------------------------------------------
 constexpr int kTileThreads = 512;
 #ifndef GNDT_TILE_PER1
@@ -464,49 +470,6 @@ __device__ __forceinline__ void tile_partition(TileLds<PER, FAN>& L, const float
     }
 }
 
-// Level 1 WITHOUT reservations (round 5): the tile, sorted by digit, is written back IN PLACE — tile t's records at
-// out[t * tile .. ) as one contiguous block, a purely sequential stream of full lines — together with the tile's digit offsets
-// (tab[t * (nd + 1) + d] = first sorted slot of digit d, tab[.. + nd] = records in the tile; 16 bits each: a tile holds 4096).
-// A region then is not a place in memory but a LIST OF SEGMENTS, one per tile, which level 2 gathers (k_part2_level2_gather).
-// What this removes: one returning memory-side atomic per tile and digit (same-address atomics serialise at ~90 per us), the
-// wait for it in front of the copy-out, the regions' fixed capacities with their overflow flag and re-run, and half of recs1
-// (n record slots instead of 2 n and more).  What it costs: level 2 reads segments of tile / F1 records (1.5 KB on the bench
-// scene) instead of a contiguous region, and finds a record's segment by a binary search in LDS.
-template <int PER, int FAN>
-__device__ __forceinline__ void tile_partition_inplace(TileLds<PER, FAN>& L, const float4 (&r)[PER], const uint32_t (&dig)[PER],
-                                                       uint32_t nd, float4* __restrict__ out_tile, uint16_t* __restrict__ tab_tile) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (uint32_t d = tid; d < nd; d += kTileThreads) L.hist[d] = 0u;
-    __syncthreads();
-    uint32_t rank[PER];
-#pragma unroll
-    for (int j = 0; j < PER; ++j) rank[j] = (dig[j] != 0xFFFFFFFFu) ? atomicAdd(&L.hist[dig[j]], 1u) : 0u;
-    __syncthreads();
-    const uint32_t c = (uint32_t)tid < nd ? L.hist[tid] : 0u;
-    uint32_t incl = c;
-    for (int o = 1; o < 64; o <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)incl, o, 64); if (lane >= o) incl += t; }
-    if (lane == 63) L.wave_tot[wave] = incl;
-    __syncthreads();
-    if ((uint32_t)tid < nd) {
-        uint32_t base = incl - c;
-        for (int w = 0; w < wave; ++w) base += L.wave_tot[w];
-        L.scan[tid] = base;
-        tab_tile[tid] = (uint16_t)base;
-        if ((uint32_t)tid == nd - 1) { L.scan[nd] = base + c; tab_tile[nd] = (uint16_t)(base + c); }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < PER; ++j)
-        if (dig[j] != 0xFFFFFFFFu) L.rec[L.scan[dig[j]] + rank[j]] = r[j];
-    __syncthreads();
-    const uint32_t total = L.scan[nd];
-#pragma unroll
-    for (int k = 0; k < PER; ++k) {                // consecutive lanes copy consecutive sorted slots to consecutive addresses
-        const uint32_t j = (uint32_t)k * kTileThreads + tid;
-        if (j < total) out_tile[j] = L.rec[j];
-    }
-}
-
 // Region of every bucket from the sample level 1 took: capacity = 2 x the estimate + 2048 records.  (A bucket of c records
 // has c/64 +- sqrt(c/64) votes; it overflows if c > 2 x 64 x votes + 2048, which for c = 2000..5000 is 6 sigma or more away
 // and never happens below 2048: with 50 000 buckets, 1.6x + 1024 still overflowed a handful per build.)  LiDAR clouds' hot
@@ -552,17 +515,14 @@ __device__ __forceinline__ void part2_layout(LayoutLds& S, const uint32_t* est2,
 // OWNER: the same kernel as the split of a sharded cloud by column owner (gndt_api_dist.hip): the digit is the owner rank of the
 // point's column among B ranks (region c at c * cap1, nothing sampled), everything else — the pipelined tile loads, the folding
 // of identical points into weighted records, the LDS sort and the coalesced copy-out — is what level 1 does anyway.
-// INPLACE: the sorted tile goes back where it came from (tile_partition_inplace; `tab` = the tiles' digit offsets, `tile_base` =
-// tiles written by an earlier launch over another segment of the same input); cursor1 / cap1 are not used.
-template <int STRIDE_FLOATS, int FAN, bool IDXW = false, bool OWNER = false, bool INPLACE = false>
+template <int STRIDE_FLOATS, int FAN, bool IDXW = false, bool OWNER = false>
 __global__ void __launch_bounds__(kTileThreads) __attribute__((amdgpu_waves_per_eu(GNDT_L1_WAVES, GNDT_L1_WAVES))) k_part2_level1(const float* __restrict__ xyz, uint64_t n, uint32_t first_base,
                                                                GridParams P, uint32_t B, uint32_t F1, uint32_t F2_shift, uint32_t R,
                                                                uint32_t* __restrict__ cursor1, uint32_t cap1,
                                                                uint32_t* __restrict__ est2,
                                                                float4* __restrict__ recs1, Counters* __restrict__ cnt,
                                                                PartCounters* __restrict__ pc, uint32_t compress, OwnerMap M,
-                                                               uint32_t* __restrict__ lay_lo, uint32_t* __restrict__ lay_cap, uint64_t rec_capacity,
-                                                               uint16_t* __restrict__ tab = nullptr, uint32_t tile_base = 0u) {
+                                                               uint32_t* __restrict__ lay_lo, uint32_t* __restrict__ lay_cap, uint64_t rec_capacity) {
     constexpr int PER = kTilePer1;
     __shared__ TileLds<PER, FAN> L;
     // Persistent workgroups, software-pipelined: the loads of tile t+1 are in flight while tile t is keyed, sorted
@@ -646,12 +606,7 @@ __global__ void __launch_bounds__(kTileThreads) __attribute__((amdgpu_waves_per_
                 r[j] = make_float4(px, py, pz, __uint_as_float(idx));
             }
         }
-        if constexpr (INPLACE) {
-            const uint64_t tg = (uint64_t)tile_base + tile;
-            tile_partition_inplace<PER, FAN>(L, r, dig, F1, recs1 + tg * (uint64_t)(kTileThreads * PER), tab + tg * (uint64_t)(F1 + 1u));
-        } else {
-            tile_partition<PER, FAN>(L, r, dig, OWNER ? B : F1 * R, cursor1, cap1, 0ull, (uint64_t)cap1, nullptr, nullptr, recs1, pc);
-        }
+        tile_partition<PER, FAN>(L, r, dig, OWNER ? B : F1 * R, cursor1, cap1, 0ull, (uint64_t)cap1, nullptr, nullptr, recs1, pc);
         __syncthreads();                                   // the tile's LDS image is reused by the next iteration
     }
     // Two-level partition: the LAST workgroup to get here lays out the buckets' regions for level 2 from everybody's votes
@@ -707,123 +662,6 @@ __global__ void __launch_bounds__(kTileThreads) k_part2_level2(const float4* __r
         }
     }
     tile_partition<PER, FAN>(L, r, dig, nd, cursor2 + b0, 0u, 0ull, 0ull, lo + b0, cap + b0, recs2, pc);
-}
-
-// level 2 over level 1's in-place tiles.  A work item = (chunk of G consecutive level-1 tiles, coarse region c): region c's segment
-// of each of the chunk's tiles — tile t holds it at sorted slots [tab[t][c], tab[t][c + 1]) — gathered and sorted into the region's
-// F2 buckets as k_part2_level2 does.  G is chosen so that an item's segments fill a tile of this kernel to ~85 % on a hash-balanced
-// cloud; an item that holds more (a LiDAR cloud's hot columns) is taken in several batches.
-// PERSISTENT and software-pipelined (the kernel is latency-bound: an item needs its table entries, then its records — two dependent
-// global round trips — before the sort can start; a first version with one workgroup per item ran 30 % slower than the contiguous
-// level 2 for that reason alone): while unit u is sorted in LDS and copied out, the records of unit u + 1 are in flight into
-// registers and the table entries of the item after that into two more.  A record's segment is found by a binary search over the
-// item's segment prefix in LDS (`steps` = ceil(log2(G)) rounds).
-constexpr int kGatherMaxG = 64;         // segments per item: one wave scans them
-#ifndef GNDT_L2G_WAVES
-#define GNDT_L2G_WAVES 8
-#endif
-template <int FAN>
-__global__ void __launch_bounds__(kTileThreads) __attribute__((amdgpu_waves_per_eu(GNDT_L2G_WAVES, GNDT_L2G_WAVES))) k_part2_level2_gather(const float4* __restrict__ recs1, const uint16_t* __restrict__ tab,
-                                                                      uint32_t ntiles, uint32_t F1, uint32_t G, uint32_t steps, GridParams P,
-                                                                      uint32_t B, uint32_t F2, uint32_t* __restrict__ cursor2,
-                                                                      const uint32_t* __restrict__ lo, const uint32_t* __restrict__ cap,
-                                                                      float4* __restrict__ recs2, PartCounters* __restrict__ pc, uint32_t region_fast,
-                                                                      uint32_t nchunks) {
-    constexpr int PER = kTilePer2;
-    constexpr uint32_t kTile1 = (uint32_t)kTileThreads * kTilePer1;
-    constexpr uint32_t kBatch = (uint32_t)kTileThreads * PER;
-    __shared__ TileLds<PER, FAN> L;
-    __shared__ uint32_t seg_pre[kGatherMaxG + 1];        // exclusive prefix of the segment lengths of the item being fetched
-    __shared__ uint32_t seg_src[kGatherMaxG];            // first record of every segment in recs1
-    if (pc->part_overflow) return;                       // the layout already gave up: the build is re-run
-    const int tid = threadIdx.x;
-    const uint32_t nitems = nchunks * F1;
-    // region_fast: workgroups that run at the same time take the SAME tiles' segments of different regions — between them they read
-    // a window of consecutive tiles front to back
-    auto region_of = [&](uint32_t w) { return region_fast ? w % F1 : w / nchunks; };
-    auto chunk_of = [&](uint32_t w) { return region_fast ? w / F1 : w % nchunks; };
-    // table entries of item tw, requested one item ahead (threads < G hold one segment each)
-    uint32_t tw = blockIdx.x, tl0 = 0, tl1 = 0;
-    auto load_tab = [&](uint32_t w) {
-        tl0 = 0; tl1 = 0;
-        if (w < nitems && (uint32_t)tid < G) {
-            const uint32_t t = chunk_of(w) * G + (uint32_t)tid;
-            if (t < ntiles) { const uint16_t* tt = tab + (uint64_t)t * (F1 + 1u) + region_of(w); tl0 = tt[0]; tl1 = tt[1]; }
-        }
-    };
-    load_tab(tw);
-    uint32_t sw = 0, sm = 0, sb = 0;                     // the item the segment arrays describe, its records, the next batch of it to fetch
-    bool have_cur = false;
-    float4 r[PER];
-    uint32_t cur_c = 0, cur_n = 0;                       // region and record count of the unit in r[]
-    for (;;) {
-        // ---- A: the next unit: its records' loads are issued here and land while the current unit is sorted ----
-        bool have_next = sb < sm;                        // (another batch of the same item)
-        while (!have_next && tw < nitems) {
-            if (tid < 64) {                              // (G <= 64: one wave scans the item's segments)
-                const uint32_t len = tl1 - tl0;
-                uint32_t incl = len;
-                for (int o = 1; o < 64; o <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)incl, o, 64); if (tid >= o) incl += t; }
-                if ((uint32_t)tid < G) { seg_pre[tid] = incl - len; seg_src[tid] = (chunk_of(tw) * G + (uint32_t)tid) * kTile1 + tl0; }
-                if ((uint32_t)tid == G - 1u) seg_pre[G] = incl;
-            }
-            __syncthreads();
-            sw = tw; sm = seg_pre[G]; sb = 0;
-            tw += gridDim.x;
-            load_tab(tw);                                // (the item after: its entries arrive during this unit's sort)
-            have_next = sm > 0;
-            if (!have_next) __syncthreads();             // (an empty item: the arrays are written again at once)
-        }
-        float4 nr[PER];
-        uint32_t next_n = 0, next_c = 0;
-        if (have_next) {
-            next_c = region_of(sw);
-            next_n = min(kBatch, sm - sb);
-            uint32_t sidx[PER];
-#pragma unroll
-            for (int j = 0; j < PER; ++j) {              // the searches of a thread's records side by side: their LDS reads overlap
-                // (slots beyond the item's records look for its last record: no branch around the load, and always a valid address)
-                const uint32_t i = min(sb + (uint32_t)j * kTileThreads + (uint32_t)tid, sm - 1u);
-                uint32_t a = 0, b = G;                   // seg_pre[a] <= i < seg_pre[b]
-                for (uint32_t k = 0; k < steps; ++k) {
-                    const uint32_t mid = (a + b) >> 1;
-                    const bool right = seg_pre[mid] <= i;
-                    a = right ? mid : a;
-                    b = right ? b : mid;
-                }
-                sidx[j] = a;
-            }
-#pragma unroll
-            for (int j = 0; j < PER; ++j) {
-                const uint32_t ic = min(sb + (uint32_t)j * kTileThreads + (uint32_t)tid, sm - 1u);
-                const uint32_t sj = sidx[j];
-                nr[j] = recs1[(uint64_t)seg_src[sj] + (ic - seg_pre[sj])];
-            }
-            sb += kBatch;
-        }
-        // ---- B: the current unit through the LDS tile sort ----
-        if (have_cur) {
-            const uint32_t b0 = cur_c * F2, nd = min(F2, B - b0);
-            uint32_t dig[PER];
-#pragma unroll
-            for (int j = 0; j < PER; ++j) {
-                dig[j] = 0xFFFFFFFFu;
-                if ((uint32_t)j * kTileThreads + (uint32_t)tid < cur_n) {
-                    int sx, sy;
-                    bool kok;
-                    column_of_point(r[j].x, r[j].y, P, sx, sy, kok);
-                    dig[j] = bucket_of(column_hash(sx, sy), B) - b0;
-                }
-            }
-            tile_partition<PER, FAN>(L, r, dig, nd, cursor2 + b0, 0u, 0ull, 0ull, lo + b0, cap + b0, recs2, pc);
-        }
-        __syncthreads();                                  // the tile image and the segment arrays may be written again
-        if (!have_next) break;
-#pragma unroll
-        for (int j = 0; j < PER; ++j) r[j] = nr[j];
-        cur_c = next_c; cur_n = next_n;
-        have_cur = true;
-    }
 }
 
 // Where bucket b's records are, for the bucket kernel (no kernel of its own: two or three loads per bucket).
@@ -1062,11 +900,11 @@ static __global__ void __launch_bounds__(kBlock) k_emit_rows(const StageRow* __r
                                                       OutView out, uint32_t* __restrict__ row_ncol,
                                                       const Counters* cnt, const PartCounters* __restrict__ pc,
                                                       Counters* __restrict__ host_cnt, PartCounters* __restrict__ host_pc,
-                                                      Counters* tab_cnt, uint32_t advance, EmitPartial part) {
+                                                      Counters* tab_cnt, uint32_t advance, EmitPartial part, uint32_t capture_id) {
     // (cnt is NOT __restrict__: on the table path tab_cnt points at the same object and lane 0 writes through it below)
     if (blockIdx.x == 0 && threadIdx.x < 2) {
         if (threadIdx.x == 0 && host_cnt) *host_cnt = *cnt;
-        if (threadIdx.x == 1 && host_pc) *host_pc = *pc;
+        if (threadIdx.x == 1 && host_pc) { *host_pc = *pc; host_pc->capture_id = capture_id; }
         // Table path (gndt_update*): the end-of-frame bookkeeping rides here as well — how many nodes own a column entry, the
         // next epoch, the stream position of the next frame — instead of two one-thread launches per frame.  None of these
         // fields is read by this kernel or mirrored for the host (which keeps its own stream position); n_work and first_word,

@@ -199,7 +199,8 @@ struct SmallMapLds {
 
 static __global__ void __launch_bounds__(kSmallMapNodes) k_small_finalize(TableView T, GridParams P, OutView out, uint32_t* __restrict__ row_ncol,
                                                                    Counters* cnt, PartCounters* __restrict__ pc, Counters* __restrict__ host_cnt,
-                                                                   PartCounters* __restrict__ host_pc, uint32_t raise_to, uint32_t out_cap) {
+                                                                   PartCounters* __restrict__ host_pc, uint32_t raise_to, uint32_t out_cap,
+                                                                   uint32_t capture_id) {
     __shared__ SmallMapLds L;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t n = cnt->num_nodes;
@@ -207,7 +208,7 @@ static __global__ void __launch_bounds__(kSmallMapNodes) k_small_finalize(TableV
         if (tid == 0) {
             pc->small_fallback = 1u;
             if (host_cnt) *host_cnt = *cnt;
-            if (host_pc) *host_pc = *pc;
+            if (host_pc) { *host_pc = *pc; host_pc->capture_id = capture_id; }
         }
         return;
     }
@@ -350,21 +351,21 @@ static __global__ void __launch_bounds__(kSmallMapNodes) k_small_finalize(TableV
         cnt->epoch = cnt->epoch + 1u;                      // (prev_nodes stays 0: no node owns an entry of the HBM column table)
         pc->lds_overflow = 0; pc->stage_overflow = 0; pc->index_overflow = 0; pc->part_overflow = 0; pc->small_fallback = 0;
         if (host_cnt) *host_cnt = *cnt;
-        if (host_pc) *host_pc = *pc;
+        if (host_pc) { *host_pc = *pc; host_pc->capture_id = capture_id; }
     }
 }
 
 // The end-of-frame bookkeeping k_emit_rows does for the table path, as a launch of its own: what a frame of a handle in
 // deferred-emit mode (gndt_set_deferred_emit) ends with instead of the ordering and the emit pass.
 static __global__ void k_tab_end(Counters* cnt, const PartCounters* __restrict__ pc, Counters* __restrict__ host_cnt, PartCounters* __restrict__ host_pc,
-                          uint32_t advance) {
+                          uint32_t advance, uint32_t capture_id) {
     if (blockIdx.x != 0 || threadIdx.x != 0) return;
     cnt->prev_nodes = cnt->num_nodes;
     cnt->n_touched = 0; cnt->n_tcols = 0;
     cnt->epoch = cnt->epoch + 1u;
     cnt->stream_pos += advance;
     if (host_cnt) *host_cnt = *cnt;
-    if (host_pc) *host_pc = *pc;
+    if (host_pc) { *host_pc = *pc; host_pc->capture_id = capture_id; }
 }
 
 // Room for `mine` entries of this lane in a list whose length is *counter: ONE counter atomic per block (a counter is one

@@ -154,6 +154,45 @@ def test_build_captured_on_a_reserved_fresh_handle(strategy):
     print("strategy", strategy, "ran", m.STRATEGY_NAMES[m.last_strategy()])
 
 
+def test_captured_build_overflow_then_fit_then_overflow():
+    """a PARTITION build recorded on a reserved handle and replayed on clouds that do NOT fit what was reserved
+    (more nodes than staging rows), then on one that does, then again on one that does not — starting with the overflow, which
+    until round 5 left every later, fitting replay "no finished build".  Every overflowing replay is reported (GNDT_ERR_CAPACITY),
+    every fitting one exports the oracle's map."""
+    import torch
+    import grid_ndt_amd as g
+    from grid_ndt_amd._lib import GndtError
+    n = 200_000
+    P = dict(grid_len=0.5, z_len=0.5, slope_interval=0.08, demand="slope")
+    small = scenes.uniform_box(n + 1, seed=0x5EED0101, half_xy=20.0)            # ~25 k nodes
+    big = scenes.uniform_box(n + 1, seed=0x5EED0102, half_xy=400.0)             # nearly every point its own node
+    big[0] = small[0]
+    ref_small = parity.ref_from_cloud(small, P)
+    assert ref_small["num_nodes"] < 40_000
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        buf = torch.from_numpy(np.ascontiguousarray(big[1:])).cuda()
+        m = g.TwoDmap(P["grid_len"], P["z_len"], strategy=2, max_nodes_hint=40_000, max_points_hint=n + 1)
+        m.setInterval(P["slope_interval"])
+        m.setCloudFirst(small[0])
+        m.reserve(n + 1, 40_000, P["demand"])
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=s):
+            m.create2DMap(P["demand"], buf, s)
+        for k, (cloud, fits) in enumerate([(big, False), (small, True), (small, True), (big, False), (big, False), (small, True)]):
+            buf.copy_(torch.from_numpy(np.ascontiguousarray(cloud[1:])))
+            graph.replay()
+            s.synchronize()
+            if fits:
+                parity.assert_parity(m.export(), ref_small)
+            else:
+                with pytest.raises(GndtError) as ei:
+                    m.sync()
+                assert ei.value.code == 5, (k, ei.value)
+                with pytest.raises(GndtError):
+                    m.export()
+
+
 @pytest.mark.parametrize("bits", [0, 2, 6])
 def test_fingerprint_clash_takes_the_exact_second_pass(bits):
     """The bucket kernel names a node by a 21-bit fingerprint of its key and confirms it with the key (gndt_bucket3.hpp); a bucket

@@ -20,6 +20,8 @@ def main():
     ap.add_argument("--seconds", type=float, default=200.0)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--max-points", type=int, default=2_000_000)
+    ap.add_argument("--no-interleave", dest="interleave", action="store_false",
+                    help="do not put eager table-family builds between the replays of captured PARTITION builds")
     a = ap.parse_args()
     import torch
     import grid_ndt_amd as g
@@ -44,7 +46,7 @@ def main():
 
         kind_seed = int(sub.integers(1 << 30))
         base, adv = cloud_of(kind_seed)
-        desc = dict(seed=a.seed, graph=stats["graphs"], cells=cells, points=n, strategy=strategy)
+        desc = dict(seed=a.seed, graph=stats["graphs"], cells=cells, points=n, strategy=strategy, kind_seed=kind_seed, events=[])
         if os.environ.get("FUZZ_TRACE"):
             print("case", desc, file=sys.stderr, flush=True)
         try:
@@ -53,10 +55,12 @@ def main():
                 buf = torch.from_numpy(np.ascontiguousarray(base[1:])).cuda()
                 if rng.random() < 0.7:
                     # ---- a whole build, captured ----
-                    m = g.TwoDmap(cells[0], cells[1], strategy=strategy, max_nodes_hint=int(rng.choice([0, 3_000_000])), max_points_hint=n + 1)
+                    hint = int(rng.choice([0, 3_000_000]))
+                    m = g.TwoDmap(cells[0], cells[1], strategy=strategy, max_nodes_hint=hint, max_points_hint=n + 1)
                     m.setInterval(0.08)
                     m.setCloudFirst(base[0])
                     fresh = rng.random() < 0.3
+                    desc.update(hint=hint, fresh=bool(fresh))
                     if fresh:                  # a FRESH handle: gndt_reserve instead of eager warm-up builds
                         m.reserve(n + 1, 0)
                         stats["fresh_captures"] = stats.get("fresh_captures", 0) + 1
@@ -65,11 +69,31 @@ def main():
                             m.create2DMap("slope", buf, s)
                             m.sync()
 
+                    def other_family():
+                        """An EAGER build through the node table (reset + accumulate + finalize: the ATOMIC family's kernels and
+                        counters, whatever the handle's strategy) on a slice of the buffer — between the replays of a captured
+                        PARTITION build, by construction (round 4 met the ATOMIC-fallback-then-capture memory fault only by chance)."""
+                        k = int(sub.integers(64, min(n, 60_000) + 1))
+                        desc["events"].append(("other", k))
+                        if os.environ.get("FUZZ_TRACE"):
+                            print("  other family build of", k, "points", file=sys.stderr, flush=True)
+                        m.reset("slope", s)
+                        m.accumulate("slope", buf[:k], first_idx_base=0, stream=s)
+                        m.finalize(stream=s)
+                        m.sync()
+                        stats["other_family_builds"] = stats.get("other_family_builds", 0) + 1
+                    interleave = a.interleave and strategy in (0, 2, 4)
+                    if interleave and not fresh and rng.random() < 0.5:
+                        other_family()             # (right in front of the capture)
+
                     def capture():
                         gr = torch.cuda.CUDAGraph()
                         with torch.cuda.graph(gr, stream=s):
                             m.create2DMap("slope", buf, s)
                         return gr
+                    desc["events"].append(("capture",))
+                    if os.environ.get("FUZZ_TRACE"):
+                        print("  capture (fresh)" if fresh else "  capture", file=sys.stderr, flush=True)
                     try:
                         graph = capture()
                     except GndtError as e:     # a buffer would have had to grow under capture: said so BEFORE touching the allocator
@@ -90,6 +114,9 @@ def main():
                         if os.environ.get("FUZZ_DUMP"):          # (to find the cloud of a replay that kills the process: the last file written)
                             np.savez(os.environ["FUZZ_DUMP"] + f".{k}", base=base, other=other, cells=np.float32(cells), strategy=strategy, replay=k,
                                      hint=int(m._params_hint) if hasattr(m, "_params_hint") else -1, fresh=int(fresh))
+                        desc["events"].append(("replay", k, m.STRATEGY_NAMES.get(m.last_strategy())))
+                        if interleave and rng.random() < 0.6:
+                            other_family()
                         if os.environ.get("FUZZ_EAGER"):         # (diagnosis: the same sequence of clouds through eager builds instead of replays)
                             m.create2DMap("slope", buf, s)
                         else:
@@ -99,9 +126,10 @@ def main():
                         try:
                             out = m.export()
                         except GndtError as e:
-                            if e.code == 5:        # GNDT_ERR_CAPACITY: said so, as documented
-                                stats["capacity_reported"] += 1
-                                break
+                            if e.code == 5:        # GNDT_ERR_CAPACITY: said so, as documented — and the replays go on: one that fits
+                                stats["capacity_reported"] += 1      # after one that did not must be exportable (round 5)
+                                stats["replays_after_a_report"] = stats.get("replays_after_a_report", 0) + (1 if k + 1 < 3 else 0)
+                                continue
                             raise
                         rep = parity.compare(out, parity.ref_from_cloud(other, P, mode=2), "slope", adversarial=adv or adv2, dense=True)
                         if not rep["ok"]:
