@@ -384,6 +384,7 @@ int partition_launch(gndt_handle* h, gndt_handle::Pending& P) {
         HIP_TRY(h, hipMemcpyAsync(h->h_cnt, h->d_cnt, sizeof(Counters), hipMemcpyDeviceToHost, s));
     }
     P.bslots = bslots;
+    if (!P.captured) { q.last_n = n; q.last_est = nodes_est; q.last_stage_want = stage_want; q.last_attempt = attempt; q.last_load = P.load_pct; }
     return GNDT_OK;
 }
 
@@ -476,6 +477,10 @@ int partition_begin(gndt_handle* h, const void* xyz_dev, size_t n, size_t stride
         (void)hipStreamIsCapturing(s, &cap);
         P.captured = cap != hipStreamCaptureStatusNone;
         P.captured_gen = h->realloc_gen;
+    }
+    if (P.captured && q.last_n == n && q.last_est) {      // (recorded: sized like the eager build of this cloud size before it)
+        P.nodes_est = q.last_est; P.est0 = q.last_est; P.attempt = q.last_attempt; P.load_pct = q.last_load;
+        P.stage_want = std::max<uint64_t>(q.stage_cap, q.last_stage_want);
     }
     rc = partition_launch(h, P);
     if (rc) { h->last_strategy = prev_strategy; return rc; }

@@ -13,22 +13,11 @@ namespace gndt_host {
 const Tuning& tuning_mut_ref();
 namespace {
 Tuning parse_tuning() {
+    // (Round 5: twelve knobs that had lost — or never had — an A/B are constants of gndt_host::Tuning now: table loads, points per
+    //  bucket, table slots, the partition levels, workgroup counts, owner locality, record interleaving, the node sketch, the bucket
+    //  kernel's second pass.  What is left is read once per process: two diagnostics and the one threshold a tool calibrates.)
     Tuning t;
-    auto geti = [](const char* k, int d) { const char* v = getenv(k); return v ? atoi(v) : d; };
-    t.bucket_load = geti("GNDT_BUCKET_LOAD", t.bucket_load);
-    t.bucket_load_large = geti("GNDT_BUCKET_LOAD_LARGE", getenv("GNDT_BUCKET_LOAD") ? t.bucket_load : t.bucket_load_large);   // (one knob set: both follow it)
-    t.bucket_points = geti("GNDT_BUCKET_POINTS", t.bucket_points);
-    t.bucket_slots = geti("GNDT_BUCKET_SLOTS", t.bucket_slots);
-    t.two_level = geti("GNDT_TWO_LEVEL", t.two_level);
-    t.l1_wgs = (uint32_t)geti("GNDT_L1_WGS", (int)t.l1_wgs);
-    t.interleave = geti("GNDT_INTERLEAVE", t.interleave);
-    t.sketch = geti("GNDT_SKETCH", t.sketch);
-    t.retry_pass = geti("GNDT_RETRY_PASS", t.retry_pass);
-    if (getenv("GNDT_BUCKET_WGS")) t.bucket_wgs = (uint32_t)atoi(getenv("GNDT_BUCKET_WGS"));
-    if (getenv("GNDT_TILE_RATIO")) t.tile_ratio = atof(getenv("GNDT_TILE_RATIO"));
-    t.owner_locality = geti("GNDT_OWNER_LOCALITY", t.owner_locality);
-    t.one_level = geti("GNDT_ONE_LEVEL", t.one_level);
-    t.fp_bits = std::min(21, std::max(0, geti("GNDT_FP_BITS", t.fp_bits)));
+    if (getenv("GNDT_TILE_RATIO")) t.tile_ratio = atof(getenv("GNDT_TILE_RATIO"));      // tools/calibrate_tile.py
     t.stamps = getenv("GNDT_STAMPS") != nullptr;
     t.verbose = getenv("GNDT_VERBOSE") != nullptr;
     return t;

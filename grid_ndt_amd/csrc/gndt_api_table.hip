@@ -63,7 +63,13 @@ int do_reset(gndt_handle* h, hipStream_t s) {
     // would be recorded, but the second replay finds the first one's nodes in it (round 4: a build captured on a reserved fresh
     // handle came back from its second replay with only the nodes the first cloud did not have).  On a clean table the clearing
     // kernel finds an empty node list and only zeroes the counters.
-    if (h->cap && (h->table_dirty || h->capturing))       // (its last workgroup zeroes the counters)
+    // ... and once a call of this handle has been recorded into a hipGraph the host's idea of the table (table_dirty) is only a
+    // guess — it is updated while a call is RECORDED, as if the kernels had run, and says nothing of replays — so the clearing
+    // kernel always runs and decides on the device: the listed slots if the counters are the table's, the whole table if a stale
+    // reset left it unclean, nothing if it is empty.  (Round 5, tools/fuzz_graph.py under -DGNDT_POISON: an eager reset right after
+    // a capture took the one-thread path, the points that followed met the nodes of the map before — a memory fault in a process
+    // that had freed and reallocated for a while, silently merged statistics in a fresh one.)
+    if (h->cap && (h->table_dirty || h->capturing || h->ever_captured))       // (its last workgroup zeroes the counters)
         hipLaunchKernelGGL(k_clear_used, dim3(grid_for(h->cap / 8)), dim3(kBlock), 0, s, h->keys, h->acc, h->col_keys,
                            h->col_first, h->col_cnt, h->col_head, h->node_slot, h->col_slot_of_node, h->d_cnt, h->cap, h->table_gen);
     else

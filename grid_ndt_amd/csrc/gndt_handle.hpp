@@ -21,6 +21,20 @@
 #include <hip/hip_runtime.h>
 
 #include "gndt.h"
+
+// Debug build (-DGNDT_POISON): every device allocation is filled with 0xA5 before it is handed out.  A fresh process gets zeroed
+// pages from hipMalloc, which hides reads of memory the library never initialised; a process that has freed and reallocated for a
+// while does not (tools/fuzz_graph.py found two such reads only after ~100 handles).  The tests run under this build as well.
+#ifdef GNDT_POISON
+namespace gndt_host {
+inline hipError_t poison_malloc(void** p, size_t bytes) {
+    const hipError_t e = (hipMalloc)(p, bytes);
+    if (e == hipSuccess && bytes) { (void)hipMemset(*p, 0xA5, bytes); (void)hipDeviceSynchronize(); }
+    return e;
+}
+}  // namespace gndt_host
+#define hipMalloc(p, bytes) gndt_host::poison_malloc((void**)(p), (bytes))
+#endif
 #include "gndt_kernels.hpp"
 #include "gndt_partition.hpp"
 #include "gndt_cost.hpp"
@@ -142,6 +156,10 @@ struct gndt_handle {
         int good_slots = 0; uint64_t good_est = 0, good_n = 0;   // table size / estimate that worked last time
         int good_load = 0;          //   ... and the table load (percent) if it had to be lowered (0: the default)
         int load_pct = 60;          // average LDS-table load (percent) the bucket count aims at
+        // how the last PARTITION attempt of this handle was sized: a build RECORDED into a hipGraph right after it is sized the same
+        // way (what the eager build allocated is then enough — what it has learnt since, e.g. "more buckets next time", would ask
+        // for buffers a capture cannot allocate)
+        uint64_t last_n = 0, last_est = 0, last_stage_want = 0;  int last_attempt = 0, last_load = 0;
         double pair_ratio = -1.0;   // share of the last resolved build's records that sat next to one of their own node inside a bucket (< 0: unknown)
         uint64_t retries_total = 0; // builds re-run because a table / region / staging area was too small (gndt_debug_retry_count)
     } part;
@@ -254,21 +272,23 @@ using namespace gndt;
 //  (256), incremental updates through the tile kernel (by strategy), every rank ordering all columns instead of its slice (no).)
 constexpr int kPartWgs = 256;    // workgroups of the exact counting partition
 struct Tuning {
-    int bucket_load = 60;        // GNDT_BUCKET_LOAD    average LDS-table load (percent) that sizes the bucket count
-    int bucket_load_large = 75;  // GNDT_BUCKET_LOAD_LARGE  the same from 2 M points on (the chip is full either way: fuller tables, fewer buckets)
-    int bucket_points = 0;       // GNDT_BUCKET_POINTS  points per bucket (0 = derived)
-    int bucket_slots = 0;        // GNDT_BUCKET_SLOTS   LDS table of the first attempt (0 = 512, 1024 on a retry)
-    int two_level = -1;          // GNDT_TWO_LEVEL      0 = never use the two-level partition
-    uint32_t l1_wgs = 2048;      // GNDT_L1_WGS         level-1 workgroups (512 are resident: 2048 of them, ~1.2 tiles each, measured 69 us against 75 with 1024 and 72 with 512 on the bench scene, round 5)
-    int retry_pass = 1;          // GNDT_RETRY_PASS     0: never launch the bucket kernel's second pass (an overflowing 512-slot table re-runs the build, as before round 5)
-    int sketch = 1;              // GNDT_SKETCH         a fresh handle without a hint counts its first cloud's nodes (HyperLogLog pass) instead of guessing n / 4
-    int interleave = -1;         // GNDT_INTERLEAVE     bucket kernel: record pairs interleaved over the waves (1), consecutive (0), by the last build's locality (-1)
-    uint32_t bucket_wgs = 0xFFFFFFFFu;   // GNDT_BUCKET_WGS   persistent bucket workgroups (default: one per bucket)
+    // constants (each with the measurement that set it) ...
+    int bucket_load = 60;        // average LDS-table load (percent) that sizes the bucket count
+    int bucket_load_large = 75;  // the same from 2 M points on (the chip is full either way: fuller tables, fewer buckets; 85 / 92 with the second pass behind them: noise, r05 §4)
+    int bucket_points = 0;       // points per bucket (0 = derived: 700 .. 3600 with the cloud's size)
+    int bucket_slots = 0;        // LDS table of the first attempt (0 = 512, 1024 on a retry)
+    int two_level = -1;          // 0 = never use the two-level partition
+    uint32_t l1_wgs = 2048;      // level-1 workgroups (512 are resident: 2048 of them, ~1.2 tiles each, 69 us against 75 with 1024 and 72 with 512 on the bench scene, r05 §5)
+    uint32_t bucket_wgs = 0xFFFFFFFFu;   // persistent bucket workgroups (default: one per bucket; 512 persistent ones measured +8 %)
+    int one_level = 1;           // small clouds: level 1 writes the buckets directly (0: counting partition)
+    int owner_locality = 1;      // owner-partitioned build: sampled block ownership (1) or hash ownership only (0)
+    int interleave = -1;         // bucket kernel: record pairs interleaved over the waves (1), consecutive (0), by the last build's locality (-1) (r05 §3)
+    int sketch = 1;              // a fresh handle without a hint counts its first cloud's nodes (HyperLogLog pass) instead of guessing n / 4
+    int retry_pass = 1;          // 0: never launch the bucket kernel's second pass (an overflowing 512-slot table re-runs the build, as before round 5)
+    int fp_bits = 21;            // bits of the bucket kernel's index fingerprint (tests narrow it through gndt_debug_set_fp_bits to force clashes)
+    // ... and what the environment can set (parsed ONCE per process)
     double tile_ratio = 48.0;    // GNDT_TILE_RATIO     AUTO takes strategy TILE from this many points per partial on (sampled; the
-                                 //                     measured crossover, profiles/r02_tile_calibration.json)
-    int one_level = 1;           // GNDT_ONE_LEVEL      small clouds: level 1 writes the buckets directly (0: counting partition)
-    int owner_locality = 1;      // GNDT_OWNER_LOCALITY owner-partitioned build: sampled block ownership (1) or hash ownership only (0)
-    int fp_bits = 21;            // GNDT_FP_BITS        bits of the bucket kernel's index fingerprint (tests narrow it to force clashes)
+                                 //                     measured crossover, profiles/r02_tile_calibration.json; tools/calibrate_tile.py sweeps it)
     bool stamps = false;         // GNDT_STAMPS=1       in-kernel phase stamps of the bucket kernel
     bool verbose = false;        // GNDT_VERBOSE=1      stderr line per resolved two-level build
 };

@@ -191,8 +191,13 @@ static __device__ __forceinline__ void zero_counters(Counters* c, bool table_cle
 static __global__ void k_clear_used(uint64_t* keys, NodeAcc* acc, uint64_t* col_keys, uint32_t* col_first, uint32_t* col_cnt,
                              uint32_t* col_head, const uint32_t* node_slot, const uint32_t* col_slot_of_node,
                              Counters* cur, uint32_t cap, uint32_t gen) {
-    const bool mine = cur->table_gen == gen;      // (else: recorded for a table that has been reallocated since — hands off)
-    const bool everything = mine && cur->table_unclean != 0u;      // a stale reset could not clear this table: all of it, now
+    // mine: these pointers are the handle's CURRENT table.  Else the reset was recorded for a table that has been reallocated since
+    // (the old arrays are retired, not freed: Handle::retired): the counters then describe the new table, not this one — nothing of
+    // them may be used as an index here.  The old table is cleared WHOLE instead, so that the recorded build that follows stays
+    // consistent within its own (old) buffers (with the nodes of the replay before left in it, its column lists ran in circles:
+    // a hang; the host reports such a replay as stale, but it must end).
+    const bool mine = cur->table_gen == gen;
+    const bool everything = !mine || cur->table_unclean != 0u;     // (unclean: a stale reset could not clear the current table: all of it, now)
     const bool listed = mine && !everything && cur->part_owned == 0u;    // (part_owned: the counters are a PARTITION build's and the table is empty)
     const uint32_t n = listed ? min(cur->num_nodes, cap) : 0u, np = listed ? cur->prev_nodes : 0u;
     if (everything) {
@@ -230,7 +235,7 @@ static __global__ void k_clear_used(uint64_t* keys, NodeAcc* acc, uint64_t* col_
     __syncthreads();
     if (threadIdx.x == 0 && atomicAdd(&cur->ticket, 1u) == gridDim.x - 1u) {
         zero_counters(cur, mine);
-        if (everything) cur->table_unclean = 0u;
+        if (mine && everything) cur->table_unclean = 0u;
         cur->ticket = 0u;
     }
 }
