@@ -217,6 +217,8 @@ def lib():
     L.gndt_debug_set_fp_bits.restype = C.c_int
     L.gndt_debug_fp_clashes.argtypes = [H, C.POINTER(u64)]
     L.gndt_debug_fp_clashes.restype = C.c_int
+    L.gndt_debug_second_pass_buckets.argtypes = [H, C.POINTER(u64)]
+    L.gndt_debug_second_pass_buckets.restype = C.c_int
     L.gndt_debug_fail_next_alloc.argtypes = [H, C.c_int]
     L.gndt_debug_fail_next_alloc.restype = C.c_int
     L.gndt_comm_unique_id.argtypes = [C.c_char_p]

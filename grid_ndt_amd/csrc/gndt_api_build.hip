@@ -755,6 +755,12 @@ int gndt_debug_retry_count(gndt_handle* h, uint64_t* retries) {
     return GNDT_OK;
 }
 
+int gndt_debug_second_pass_buckets(gndt_handle* h, uint64_t* buckets) {
+    if (!h || !buckets) return GNDT_ERR_INVALID;
+    *buckets = h->part.retry_seen;
+    return GNDT_OK;
+}
+
 int gndt_debug_enable_stamps(int on) { tuning_force_stamps(on != 0); return GNDT_OK; }
 
 int gndt_debug_set_fp_bits(int bits) { tuning_force_fp_bits(bits); return GNDT_OK; }

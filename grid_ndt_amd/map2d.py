@@ -359,6 +359,12 @@ class TwoDmap:
         n = self.sync()[0]
         return self._dev_view(p.value or 0, n * 4, torch.int32, (n,)), int(gn.value), int(gc.value)
 
+    def second_pass_buckets(self):
+        """Buckets of the last resolved PARTITION build that went through the bucket kernel's second pass (1024-slot tables)."""
+        r = C.c_uint64()
+        self._check(self._L.gndt_debug_second_pass_buckets(self._h, C.byref(r)))
+        return int(r.value)
+
     def debug_fail_next_alloc(self, site, demand="slope"):
         """Tests: the next allocation at `site` of the sharded builds fails once on this handle (include/gndt.h)."""
         self._ensure(demand)             # (the handle is created lazily, with the demand)

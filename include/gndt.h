@@ -457,6 +457,9 @@ int gndt_debug_enable_stamps(int on);
  * gndt_debug_fp_clashes: buckets of the last resolved PARTITION build that took the second pass. */
 int gndt_debug_set_fp_bits(int bits);
 int gndt_debug_fp_clashes(gndt_handle* h, uint64_t* buckets);
+/* Buckets of the last resolved PARTITION build whose 512-slot LDS table overflowed and that were done again by the bucket kernel's
+ * second pass (1024-slot tables, those buckets only) instead of the whole build being re-run (gndt_debug_retry_count). */
+int gndt_debug_second_pass_buckets(gndt_handle* h, uint64_t* buckets);
 /* Tests of the sharded builds: the next allocation at `site` on this handle fails once, as if the device were out of memory —
  * 1: the receive buffer of gndt_build_owned_device's exchange, 2: its column-pair buffers, 3: the buffers of
  * gndt_gather_owned_map_device, 4: the fixed-size message buffers of a communicator's first owned build (0: none).  Every rank

@@ -154,6 +154,36 @@ def test_build_captured_on_a_reserved_fresh_handle(strategy):
     print("strategy", strategy, "ran", m.STRATEGY_NAMES[m.last_strategy()])
 
 
+def test_overflowing_tables_take_the_second_pass_not_a_re_run():
+    """Columns of 20 z levels make the node count of a bucket jump by a column at a time: some 512-slot tables overflow whatever the
+    average load (here ~384 nodes per table with a spread of ~90).  Those buckets are done again by the bucket kernel's second pass
+    (1024 slots) — the build is NOT re-run, on a fresh handle without a hint either (whose node count comes from the HyperLogLog
+    pass) — and the map is the oracle's."""
+    import grid_ndt_amd as g
+    cloud = scenes.uniform_box(3_000_001, seed=0x5EED0301, half_xy=50.0, half_z=1.0)
+    P = dict(grid_len=0.5, z_len=0.1, slope_interval=0.08, demand="slope")
+    ref = parity.ref_from_cloud(cloud, P, mode=2)
+    m, out = parity.gpu_from_cloud(cloud, P, on_device=True, strategy=2)
+
+    def check(o):      # (800 k random nodes: one or two labels sit within an fp32 rounding of the interval — the dense gate's rule, capped)
+        rep = parity.compare(o, ref, "slope", dense=True, interval=P["slope_interval"])
+        assert rep["ok"], rep["fail"]
+        assert rep.get("labels_within_margin", 0) <= 4, rep
+    check(out)
+    assert m.last_strategy() == 2
+    assert m.retry_count() == 0, m.retry_count()
+    first = m.second_pass_buckets()
+    assert first > 0, "the scene was meant to overflow some tables"
+    import torch
+    t = torch.from_numpy(np.ascontiguousarray(cloud[1:])).cuda()
+    for _ in range(2):                                   # steady state: still no re-run, the pass stays on while it has work
+        m.create2DMap("slope", t)
+        m.sync()
+    assert m.retry_count() == 0
+    check(m.export())
+    print("buckets through the second pass: first build", first, "steady", m.second_pass_buckets())
+
+
 def test_captured_build_overflow_then_fit_then_overflow():
     """a PARTITION build recorded on a reserved handle and replayed on clouds that do NOT fit what was reserved
     (more nodes than staging rows), then on one that does, then again on one that does not — starting with the overflow, which
