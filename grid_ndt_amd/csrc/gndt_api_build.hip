@@ -352,7 +352,12 @@ int partition_launch(gndt_handle* h, gndt_handle::Pending& P) {
     const uint32_t fp_mask = (1u << tuning().fp_bits) - 1u;
     // record pairs interleaved over the waves (gndt_bucket3.hpp) unless the last build of this handle counted next to no adjacent
     // records of one node: on by default — a cloud with locality gains 11-14 % of its bucket kernel, one without loses 2 %
-    const uint32_t interleave = tuning().interleave >= 0 ? (uint32_t)(tuning().interleave != 0) : (q.pair_ratio < 0.0 || q.pair_ratio > 0.02 ? 1u : 0u);
+    // (which mapping a cloud with locality gets: 1 = pairs interleaved inside 512-pair blocks, 2 = a contiguous stretch per lane;
+    //  bucket kernel S3 32 M 595 | 585 us, S3 100 M 1.691 | 1.679 ms, S5 317 | 306 us: 2)
+#ifndef GNDT_LOCALITY_MODE
+#define GNDT_LOCALITY_MODE 2
+#endif
+    const uint32_t interleave = tuning().interleave >= 0 ? (uint32_t)tuning().interleave : (q.pair_ratio < 0.0 || q.pair_ratio > 0.02 ? (uint32_t)GNDT_LOCALITY_MODE : 0u);
     {
         // k_bucket_direct (gndt_bucket3.hpp): 512-slot tables with two workgroups per CU, 1024-slot tables on a retry
         // A bucket whose 512-slot table overflows (a few wall columns; the spread of a hash partition over tall columns) is queued and

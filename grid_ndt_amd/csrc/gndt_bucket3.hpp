@@ -383,24 +383,33 @@ __device__ __forceinline__ void bucket_direct_one(BucketLds3<H>& L, const uint32
     // then serialises on the address: bucket kernel S3 32 M 681 -> 584 us, S5 355 -> 316 us (round 5).  A cloud without locality
     // (the bench scene) gains nothing and pays ~2 % for loads that cover 64 half-used lines each (the other waves take the other
     // halves), so the host turns it off once a build has counted (PartCounters::pairs) that adjacent records rarely share a node.
-    const int ptid = interleave ? lane * (T / 64) + (tid >> 6) : tid;
+    // interleave == 2: every LANE owns a contiguous stretch of the bucket (the waves and the iterations walk through it), so the
+    // records of one wave instruction are a 64th of the bucket apart — also runs of more than 16 records of one node (near-sensor
+    // cells, the padding) stay in one lane and never meet inside an instruction.  All three mappings are
+    //     pair(it, wave, lane) = lane * A + it * B + wave * C
+    constexpr uint32_t W = (uint32_t)(T / 64);
+    const uint32_t n_rec = hi - lo, iters = (n_rec + (uint32_t)(U * T) - 1u) / (uint32_t)(U * T);
+    const uint32_t mapA = interleave == 0u ? 1u : (interleave == 1u ? W : iters * W), mapB = interleave == 2u ? W : (uint32_t)T,
+                   mapC = interleave == 0u ? 64u : 1u;
+    const uint32_t pair0 = (uint32_t)lane * mapA + (uint32_t)(tid >> 6) * mapC;      // this thread's pair in iteration 0
     uint32_t npairs = 0;                                    // (wave-uniform) lanes whose two records fell into one node
     float4 nxt[U];
     if (lo < hi) {
 #pragma unroll
-        for (int j = 0; j < U; ++j) nxt[j] = recs[min(lo + (uint32_t)(U * ptid + j), hi - 1u)];
+        for (int j = 0; j < U; ++j) nxt[j] = recs[min(lo + (uint32_t)U * pair0 + (uint32_t)j, hi - 1u)];
     }
-    for (uint32_t base = lo; base < hi; base += (uint32_t)(U * T)) {
+    for (uint32_t it = 0; it < iters; ++it) {
+        const uint32_t mine = lo + (uint32_t)U * (pair0 + it * mapB);       // this thread's first record of the iteration
         // A table beyond its fill limit is given up at once: the build is re-run with more room anyway, and probing a nearly
         // full table costs hundreds of rounds per record (a cloud whose tables ALL overflow kept this kernel busy for 18-37 ms).
         if (__builtin_amdgcn_readfirstlane((int)L.n_nodes) > H) break;
         float4 rec[U];
         bool use[U];
 #pragma unroll
-        for (int j = 0; j < U; ++j) { rec[j] = nxt[j]; use[j] = base + (uint32_t)(U * ptid + j) < hi; }
-        if (base + (uint32_t)(U * T) < hi) {       // uniform
+        for (int j = 0; j < U; ++j) { rec[j] = nxt[j]; use[j] = mine + (uint32_t)j < hi; }
+        if (it + 1u < iters) {                     // uniform
 #pragma unroll
-            for (int j = 0; j < U; ++j) nxt[j] = recs[min(base + (uint32_t)(U * T + U * ptid + j), hi - 1u)];
+            for (int j = 0; j < U; ++j) nxt[j] = recs[min(mine + (uint32_t)U * mapB + (uint32_t)j, hi - 1u)];
         }
         uint32_t slot[U], fpw[U];
         unsigned long long pkey[U];
@@ -477,7 +486,7 @@ __device__ __forceinline__ void bucket_direct_one(BucketLds3<H>& L, const uint32
         unsigned long long kv[U];
 #pragma unroll
         for (int j = 0; j < U; ++j) kv[j] = L.key[use[j] ? node[j] : 0u];
-        GNDT_SUB(base == lo ? 1 : 2);
+        GNDT_SUB(it == 0u ? 1 : 2);
 #pragma unroll
         for (int j = 0; j < U; ++j) {
             const uint32_t s = node[j];

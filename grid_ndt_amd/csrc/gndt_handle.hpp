@@ -282,7 +282,8 @@ struct Tuning {
     uint32_t bucket_wgs = 0xFFFFFFFFu;   // persistent bucket workgroups (default: one per bucket; 512 persistent ones measured +8 %)
     int one_level = 1;           // small clouds: level 1 writes the buckets directly (0: counting partition)
     int owner_locality = 1;      // owner-partitioned build: sampled block ownership (1) or hash ownership only (0)
-    int interleave = -1;         // bucket kernel: record pairs interleaved over the waves (1), consecutive (0), by the last build's locality (-1) (r05 §3)
+    int interleave = -1;         // bucket kernel: which records a lane takes — consecutive pairs (0), pairs interleaved over the waves (1), a contiguous
+                                 //   stretch of the bucket per lane (2) — or by the last build's locality (-1: 0 without, 2 with; r05 §3)
     int sketch = 1;              // a fresh handle without a hint counts its first cloud's nodes (HyperLogLog pass) instead of guessing n / 4
     int retry_pass = 1;          // 0: never launch the bucket kernel's second pass (an overflowing 512-slot table re-runs the build, as before round 5)
     int fp_bits = 21;            // bits of the bucket kernel's index fingerprint (tests narrow it through gndt_debug_set_fp_bits to force clashes)
