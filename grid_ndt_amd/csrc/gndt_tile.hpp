@@ -125,6 +125,14 @@ k_tile_accumulate(const float* __restrict__ xyz, uint64_t n, uint32_t first_base
     __syncthreads();
     const uint32_t epoch = cnt->epoch;
     const uint32_t base_idx = base_from_device ? cnt->stream_pos : first_base;
+    // Which points a lane takes: the lanes of one wave hold point pairs T / 64 pairs apart, the other waves the pairs in between
+    // (gndt_bucket3.hpp, round 5).  This kernel only runs on clouds whose neighbours in the stream share their node — a depth
+    // frame's rows —, where consecutive lanes sent the same address into one LDS atomic instruction: depth frame 0.059 -> 0.054 ms
+    // per build, 0.048 -> 0.042 replayed.
+#ifndef GNDT_TILE_INTERLEAVE
+#define GNDT_TILE_INTERLEAVE 1
+#endif
+    const uint32_t ptid = GNDT_TILE_INTERLEAVE ? (uint32_t)lane * (uint32_t)(T / 64) + (uint32_t)(tid >> 6) : (uint32_t)tid;
     // this workgroup's contiguous range, a multiple of kTileCheck points
     uint64_t per = (n + gridDim.x - 1) / gridDim.x;
     per = (per + kTileCheck - 1) / kTileCheck * kTileCheck;
@@ -139,7 +147,7 @@ k_tile_accumulate(const float* __restrict__ xyz, uint64_t n, uint32_t first_base
             bool use[2];
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                const uint32_t i = b + 2u * tid + j;
+                const uint32_t i = b + 2u * ptid + j;
                 use[j] = i < have;
                 const float* p = src + min(i, have - 1u) * (uint32_t)STRIDE_FLOATS;
                 px[j] = p[0]; py[j] = p[1]; pz[j] = p[2];
@@ -166,7 +174,7 @@ k_tile_accumulate(const float* __restrict__ xyz, uint64_t n, uint32_t first_base
                 c[j][0] = v0; c[j][1] = v1; c[j][2] = v2;
                 c[j][3] = v0 * v0; c[j][4] = v0 * v1; c[j][5] = v0 * v2; c[j][6] = v1 * v1; c[j][7] = v1 * v2; c[j][8] = v2 * v2;
                 cn[j] = 1u;
-                cf[j] = base_idx + (uint32_t)(t0 + b + 2u * tid + j);
+                cf[j] = base_idx + (uint32_t)(t0 + b + 2u * ptid + j);
             }
             if (pair) {
 #pragma unroll
