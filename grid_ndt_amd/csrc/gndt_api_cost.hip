@@ -8,7 +8,7 @@ namespace gndt_host {
 
 void free_cost(gndt_handle* h) {
     auto& c = h->cost;
-    void* ptrs[] = {c.h_bits, c.state, c.f[0], c.f[1], c.ctab_key, c.ctab_val, c.nbr, c.d_cc};
+    void* ptrs[] = {c.h_bits, c.state, c.f[0], c.f[1], c.ctab_key, c.ctab_val, c.nbr, c.edges, c.d_cc};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (c.h_cc) (void)hipHostFree(c.h_cc);
@@ -45,12 +45,15 @@ int gndt_compute_cost(gndt_handle* h, const float goal_xyz[3], const gndt_robot*
     }
     if (n > c.node_cap) {
         for (uint32_t** a : {&c.h_bits, &c.state, &c.f[0], &c.f[1], &c.nbr}) { if (*a) (void)hipFree(*a); *a = nullptr; }
+        if (c.edges) (void)hipFree(c.edges);
+        c.edges = nullptr;
         c.node_cap = 0;
         const uint64_t cap = std::max<uint64_t>(1024, n + n / 8);
         for (uint32_t** a : {&c.h_bits, &c.state, &c.f[0], &c.f[1]}) HIP_TRY(h, hipMalloc(a, cap * 4));
         // per row: 4 neighbour columns with their sizes (32 B), own column + collision verdict (8), the ring's step masks (16) and
         // two pairs of extremes for its rounds (16)
         HIP_TRY(h, hipMalloc(&c.nbr, cap * 72));
+        HIP_TRY(h, hipMalloc(&c.edges, cap * 4 * sizeof(CostEdge)));
         c.node_cap = cap;
     }
     const uint32_t tsize = pow2_ceil(std::max<uint64_t>(1024, 2 * K));
@@ -87,9 +90,10 @@ int gndt_compute_cost(gndt_handle* h, const float goal_xyz[3], const gndt_robot*
         float* ext = reinterpret_cast<float*>(c.nbr + 14 * c.node_cap);            // hi[2], lo[2]: node_cap floats each
         float* hi[2] = {ext, ext + c.node_cap};
         float* lo[2] = {ext + 2 * c.node_cap, ext + 3 * c.node_cap};
-        hipLaunchKernelGGL(k_cost_neighbours, dim3(grid_for(4 * n)), dim3(256), 0, s, V, R, (uint32_t)n, c.ring_n, c.nbr, self, step, hi[0], lo[0]);   // (probes: V.nbr, V.self are null)
+        hipLaunchKernelGGL(k_cost_neighbours, dim3(grid_for(4 * n)), dim3(256), 0, s, V, R, (uint32_t)n, c.ring_n, c.nbr, self, step, hi[0], lo[0], c.edges);   // (probes: V.nbr, V.self are null)
         V.nbr = c.nbr;
         V.self = self;
+        V.edges = c.edges;
         for (int d = 0; d < c.ring_n; ++d)
             hipLaunchKernelGGL(k_cost_ring_round, dim3(grid_for(4 * n)), dim3(256), 0, s, V, R, (uint32_t)n, step, hi[d & 1], hi[(d + 1) & 1],
                                lo[d & 1], lo[(d + 1) & 1], self, d == c.ring_n - 1 ? 1 : 0);
@@ -107,7 +111,7 @@ int gndt_compute_cost(gndt_handle* h, const float goal_xyz[3], const gndt_robot*
     //  200 m open site with layers of thousands, profiles/r04_cost_map.json: the workgroup keeps the layers of up to kWgNarrow slopes.)
     constexpr uint32_t kWgNarrow = 320;
     const bool wg = env_int("GNDT_COST_WG", 1) != 0;
-    bool narrow = true;
+    bool narrow = true, first_batch = true;
     uint32_t launched = 0;                                   // one-layer launches enqueued so far
     uint32_t blocks = kCostBlocks;                           // wavefronts of a one-layer launch (16 slopes at a time each): twice the last
                                                              //   layer seen, so that a wide layer is one pass
@@ -115,7 +119,9 @@ int gndt_compute_cost(gndt_handle* h, const float goal_xyz[3], const gndt_robot*
         if (wg)
             hipLaunchKernelGGL(k_cost_flood_wg, dim3(1), dim3(kWgThreads), 0, s, V, R, c.h_bits, c.state, c.f[0], c.f[1], c.d_cc, kWgNarrow, 1u << 20,
                                launched);
-        for (int b = 0, nb = wg && narrow ? 8 : kCostBatch; b < nb; ++b, ++launched)
+        // (a flood the one-workgroup kernel walks to its end — bridge_ground, the site — pays 4.6 us for every one-layer launch behind
+        //  it that finds nothing to do: two behind the first kernel, eight once a layer has been too wide for it)
+        for (int b = 0, nb = !wg ? kCostBatch : first_batch ? 2 : narrow ? 8 : kCostBatch; b < nb; ++b, ++launched)
             hipLaunchKernelGGL(k_cost_level, dim3(blocks), dim3(kCostThreads), 0, s, V, R, c.h_bits, c.state, c.f[0], c.f[1], c.d_cc, launched);
         HIP_TRY(h, hipGetLastError());
         HIP_TRY(h, hipMemcpyAsync(c.h_cc, c.d_cc, sizeof(CostCounters), hipMemcpyDeviceToHost, s));
@@ -123,16 +129,23 @@ int gndt_compute_cost(gndt_handle* h, const float goal_xyz[3], const gndt_robot*
         const uint32_t level = launched + c.h_cc->wg_layers;
         const uint32_t left = c.h_cc->frontier[level % 3u];
         if (left == 0u) break;
+        first_batch = false;
         narrow = left <= kWgNarrow;
         blocks = (uint32_t)std::min<uint64_t>(16384, std::max<uint64_t>(kCostBlocks, pow2_ceil((uint64_t)left / 8 + 1)));
         if (level > (1u << 24)) { h->err = "cost flood did not terminate"; return GNDT_ERR_HIP; }
     }
+#if defined(GNDT_COST_STAMPS)
+    std::fprintf(stderr, "[gndt cost stamps] layers in the one-workgroup kernel %llu; cycles per layer (wave 0): frontier read %.0f, loads %.0f, "
+                 "minima %.0f, append %.0f, barrier + count %.0f\n", c.h_cc->phase[5], (double)c.h_cc->phase[0] / std::max<double>(1, c.h_cc->phase[5]),
+                 (double)c.h_cc->phase[1] / std::max<double>(1, c.h_cc->phase[5]), (double)c.h_cc->phase[2] / std::max<double>(1, c.h_cc->phase[5]),
+                 (double)c.h_cc->phase[3] / std::max<double>(1, c.h_cc->phase[5]), (double)c.h_cc->phase[4] / std::max<double>(1, c.h_cc->phase[5]));
+#endif
     if (c.h_cc->range_error) {
         h->err = "cost map: column indices beyond 32767 (mortonToXY decodes no further, Stopwatch.h:171-189)";
         return GNDT_ERR_KEY_RANGE;
     }
     if (n) {        // what no relaxation reached keeps the FLT_MAX it was created with (gndt_cost.hpp: kUnreachedBits)
-        hipLaunchKernelGGL(k_cost_finish, dim3(grid_for(n)), dim3(256), 0, s, c.h_bits, (uint32_t)n);
+        hipLaunchKernelGGL(k_cost_finish, dim3(grid_for(n)), dim3(256), 0, s, c.h_bits, c.state, V.self, (uint32_t)n);
         HIP_TRY(h, hipGetLastError());
         HIP_TRY(h, hipStreamSynchronize(s));
     }

@@ -45,6 +45,18 @@ constexpr int kCostMaxXY = 32767;        // mortonToXY decodes only up to here (
 constexpr uint32_t kNoColumn = 0xFFFFFFFFu;
 constexpr int kRingCap = 256;            // slopes the ring of the serial walk holds in the host shim (tests/host_math_shim.cpp)
 
+// What a popped slope does to ONE of its four neighbour cells, found for every slope BEFORE the flood (round 5): neither the gates
+// (roughness, angle, height: map2D.h:271-274) nor TravelCost (:523-526) depend on h, so the layer-by-layer walk — short layers, one
+// dependent round trip after the other — only adds and takes minima.  Up to two accessible slopes of the cell are named here with
+// their travel cost (a cell rarely holds more within the robot's reach); kEdgeMore sends the flood through cost_expand_column.
+struct CostEdge {
+    uint32_t c;        // first row of the neighbour column (kNoColumn: none)
+    uint32_t info;     // bits 0-7 / 8-15: the accessible rows, as offsets from c; 16-17: how many of them (0..2); 18: kEdgeMore;
+                       //   20-31: the cell's checkList pushes (map2D.h:1320-1323: its slopes)
+    float d0, d1;      // TravelCost to them
+};
+constexpr uint32_t kEdgeMore = 1u << 18;
+
 struct CostView {
     // result rows in reference order (gndt_cells)
     const int32_t *sx, *sy, *sz;
@@ -66,6 +78,8 @@ struct CostView {
     // its cell (map_slope is ascending in z) is in the robot's way (map2D.h:394-410) — what every collision check asks, answered once
     // per flood (for that flood's robot)
     const uint32_t* self = nullptr;
+    // optional: edges[4 * row + k] of every row that holds a slope (see CostEdge)
+    const CostEdge* edges = nullptr;
 };
 
 GNDT_HD uint64_t column_pack(int sx, int sy) { return pack_key(sx, sy, 0); }
@@ -272,6 +286,45 @@ GNDT_HD uint32_t cost_expand(const CostView& V, const Robot& R, uint32_t q, floa
     return checks;
 }
 
+// The record of slope q's k-th neighbour cell (c, ncol: neighbour_column): the same loop as cost_expand_column, with the relaxation
+// left for the flood.
+GNDT_HD CostEdge cost_edge_record(const CostView& V, const Robot& R, uint32_t q, uint32_t c, uint32_t ncol) {
+    GNDT_FP_STRICT
+    CostEdge e{c, 0u, 0.f, 0.f};
+    if (c == kNoColumn) return e;
+    const float* nq = V.normal + 3 * (size_t)q;
+    const float* mq = V.mean + 3 * (size_t)q;
+    uint32_t checks = 0, np = 0, j0 = 0, j1 = 0;
+    bool more = false;
+    for (uint32_t j = 0; j < ncol; ++j) {
+        const uint32_t t = c + j;
+        if (!(V.flags[t] & 2u)) continue;
+        ++checks;
+        if (!(V.rough[t] <= R.rough)) continue;
+        if (!(cost_angle(V.normal + 3 * (size_t)t, nq) <= R.angle)) continue;
+        if (!(fabsf(V.mean[3 * (size_t)t + 2] - mq[2]) <= R.reach)) continue;
+        const float d = cost_travel(mq, V.mean + 3 * (size_t)t);
+        if (np == 0u && j < 256u) { j0 = j; e.d0 = d; }
+        else if (np == 1u && j < 256u) { j1 = j; e.d1 = d; }
+        else more = true;
+        ++np;
+    }
+    if (checks > 4095u) more = true;
+    e.info = more ? kEdgeMore : (j0 | (j1 << 8) | (np << 16) | (checks << 20));
+    return e;
+}
+
+// Expansion towards one neighbour cell from its record (the record must not carry kEdgeMore): relax(row, candidate h) as
+// cost_expand_column calls it, the cell's checkList pushes returned.
+template <typename Relax>
+GNDT_HD uint32_t cost_expand_record(const CostEdge& e, float hq, Relax relax) {
+    GNDT_FP_STRICT
+    const uint32_t n = (e.info >> 16) & 3u;
+    if (n > 0u) relax(e.c + (e.info & 0xFFu), hq + e.d0);
+    if (n > 1u) relax(e.c + ((e.info >> 8) & 0xFFu), hq + e.d1);
+    return e.info >> 20;
+}
+
 // ---------------------------------------------------------------------------------------------
 // CollisionCheck without walking rings (round 4).  The ring of a slope q (map2D.h:351-411 / 414-474) is the set R_n(q) of slopes
 // within n steps of q, a step going from a slope to a slope of one of its four neighbour cells that passes the gates seen from it
@@ -353,6 +406,9 @@ struct CostCounters {
     unsigned long long check_pushes;
     uint32_t wg_layers;       // layers walked by the one-workgroup kernel so far: a kernel's layer = the one-layer launches the host
                               //   has enqueued before it (an argument) + this
+#if defined(GNDT_COST_STAMPS)
+    unsigned long long phase[6];   // diagnostic build: cycles wave 0 of the one-workgroup kernel spent per phase of a layer, summed
+#endif
 };
 
 // While a flood runs, h of a slope that no relaxation has reached yet is this marker (above every float, FLT_MAX included): the
@@ -365,19 +421,30 @@ constexpr uint32_t kFltMaxBits = 0x7F7FFFFFu;
 static __global__ void __launch_bounds__(256) k_cost_clear(uint32_t* __restrict__ h_bits, uint32_t* __restrict__ state, uint32_t n,
                                                     uint64_t* __restrict__ ctab_key, uint32_t ctab_size, CostCounters* __restrict__ cc) {
     const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x, gsz = gridDim.x * blockDim.x;
-    for (uint32_t i = gid; i < n; i += gsz) { h_bits[i] = kUnreachedBits; state[i] = 0u; }
+    for (uint32_t i = gid; i < n; i += gsz) h_bits[i] = kUnreachedBits;
     for (uint32_t i = gid; i < ctab_size; i += gsz) ctab_key[i] = kEmptyKey;
     if (gid == 0) {
         cc->frontier[0] = cc->frontier[1] = cc->frontier[2] = 0u;
         cc->traversable = cc->closed = cc->pad0 = cc->range_error = 0u;
         cc->goal_status = 1; cc->levels = 0u; cc->check_pushes = 0ull;
         cc->wg_layers = 0u;
+#if defined(GNDT_COST_STAMPS)
+        for (int k = 0; k < 6; ++k) cc->phase[k] = 0ull;
+#endif
     }
 }
 
-static __global__ void __launch_bounds__(256) k_cost_finish(uint32_t* __restrict__ h_bits, uint32_t n) {
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
-        if (h_bits[i] == kUnreachedBits) h_bits[i] = kFltMaxBits;          // Slope::h = FLT_MAX (map2D.h:636, 652)
+// The end of a flood.  What no relaxation reached keeps the FLT_MAX it was created with (map2D.h:636, 652).  state: 1 = the slope was
+// expanded (the reference's traversableList), 2 = it collided (closeList), 0 = never queued — every slope whose h left the marker was
+// queued, hence popped before the flood ended, and what happened to it then is CollisionCheck's verdict, which self holds for every
+// slope (so the layers store no state: a store counts in vmcnt like a load, and a layer is a chain of waits).
+static __global__ void __launch_bounds__(256) k_cost_finish(uint32_t* __restrict__ h_bits, uint32_t* __restrict__ state,
+                                                     const uint32_t* __restrict__ self, uint32_t n) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const bool reached = h_bits[i] != kUnreachedBits;
+        if (!reached) h_bits[i] = kFltMaxBits;
+        state[i] = !reached ? 0u : (self && self[2 * (size_t)i + 1]) ? 2u : 1u;
+    }
 }
 
 // first row of every column -> hash table entry keyed by the column's (sx, sy)
@@ -407,7 +474,7 @@ static __global__ void __launch_bounds__(256) k_cost_columns(const int32_t* __re
 // nbr / self for every row; and, for floods with rings, the step masks of every slope and round 0 of the extremes
 static __global__ void __launch_bounds__(256) k_cost_neighbours(CostView V, Robot R, uint32_t num_rows, int ring_n, uint32_t* __restrict__ nbr,
                                                          uint32_t* __restrict__ self, uint32_t* __restrict__ step, float* __restrict__ hi0,
-                                                         float* __restrict__ lo0) {
+                                                         float* __restrict__ lo0, CostEdge* __restrict__ edges) {
     for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < 4u * num_rows; t += gridDim.x * blockDim.x) {
         const uint32_t row = t >> 2, k = t & 3u;
         uint32_t c, ncol;
@@ -416,6 +483,10 @@ static __global__ void __launch_bounds__(256) k_cost_neighbours(CostView V, Robo
         nbr[2 * (size_t)t + 1] = ncol;
         const bool slope = row_has_slope(V, row);
         if (ring_n > 0) step[t] = slope ? ring_step_mask(V, R, row, c, ncol) : 0u;
+        if (slope) {
+            const CostEdge e = cost_edge_record(V, R, row, c, ncol);
+            reinterpret_cast<uint4*>(edges)[t] = make_uint4(e.c, e.info, float_bits(e.d0), float_bits(e.d1));
+        }
         if (k == 0u) {
             self[2 * (size_t)row] = ctab_find(V, V.sx[row], V.sy[row]);
             const bool up = slope && row_up(V, row);
@@ -478,12 +549,20 @@ static __global__ void k_cost_goal(CostView V, int gx, int gy, int gz, uint32_t*
 }
 
 // One layer of the flood: verdict, then expansion, of every slope in the layer.  Four lanes share a slope, one per neighbour cell;
-// layers are short, so the work is latency-bound and the dependent round trips per lane count: what only needs the slope — its
-// verdict, h, normal, centroid, the neighbour column with its node count — is requested together, then the neighbour cell's rows
-// with all their fields, then the atomic min.  The body is shared by the one-layer launch (k_cost_level: every workgroup a
-// wavefront, any layer size) and the one-workgroup kernel that walks many layers per launch (k_cost_flood_wg, WG = true: h, which
-// other wavefronts of the workgroup changed one barrier ago, is read past the CU's cache; the frontier is in LDS).
+// layers are short, so the work is latency-bound and the dependent round trips per lane count.  Round 5: two of them — what only
+// needs the slope (its verdict, h, and the neighbour cell's CostEdge record, requested together), then the atomic minima on the
+// accessible slopes' h; the gates and the travel cost (two fp64 square roots, a division, an arc cosine per row of the cell: the
+// larger part of a layer's 13-20 k cycles until round 4) were worked out for every slope at once before the flood.  The body is
+// shared by the one-layer launch (k_cost_level: every workgroup a wavefront, any layer size) and the one-workgroup kernel that walks
+// many layers per launch (k_cost_flood_wg, WG = true: h, which other wavefronts of the workgroup changed one barrier ago, is read
+// past the CU's cache; the frontier is in LDS).
+#if defined(GNDT_COST_STAMPS)
+struct LayerStats { uint32_t trav, closed, checks; unsigned long long ph[6], last; };
+#define GNDT_COST_STAMP(k) do { const unsigned long long now_ = clock64(); st.ph[k] += now_ - st.last; st.last = now_; } while (0)
+#else
 struct LayerStats { uint32_t trav, closed, checks; };
+#define GNDT_COST_STAMP(k) do { } while (0)
+#endif
 
 // f_in: the layer's slopes (WG: in LDS).  f_out: the next layer's, in global memory — and, WG, its first f_lds_cap entries in LDS
 // as well (f_out_lds), where the workgroup's next layer reads them.
@@ -494,67 +573,94 @@ __device__ __forceinline__ void cost_layer(const CostView& V, const Robot& R, ui
                                            uint32_t* out_count, LayerStats& st) {
     const int lane = (int)(threadIdx.x & 63u);
     const uint32_t dir = threadIdx.x & 3u;
+    constexpr uint32_t kNone = 0xFFFFFFFFu;
     // The loop is wave-uniform (a wave's quads take 16 consecutive slopes of the layer, lanes past the end sit idle), so that the
     // slopes a wave pushes are appended with ONE atomic on the layer's counter: the counter is one word, same-address atomics
     // retire at ~90 per microsecond at the memory side, and a layer of a few hundred slopes used to add one per pushed slope
-    // and three more per expanded slope (the statistics) — most of a layer's 13-18 us.
+    // and three more per expanded slope (the statistics) — most of a layer's 13-18 us in round 3.
     for (uint32_t i0 = first; i0 < n_in; i0 += stride) {
         const uint32_t i = i0 + ((uint32_t)lane >> 2);
         const bool live = i < n_in;
         const uint32_t q = live ? f_in[i] : 0u;
-        uint32_t hq_bits = 0u, nc = kNoColumn, nc_rows = 0u, hit = 0u;
-        float nq[3] = {0.f, 0.f, 0.f}, mq[3] = {0.f, 0.f, 0.f};
+        GNDT_COST_STAMP(0);
+        uint32_t hq_bits = 0u, hit = 0u;
+        uint4 er = make_uint4(kNoColumn, 0u, 0u, 0u);
         if (live) {
             hit = V.self[2 * (size_t)q + 1];           // CollisionCheck's verdict, found for every slope before the flood
             hq_bits = WG ? __hip_atomic_load(&h_bits[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : h_bits[q];
-            for (int k = 0; k < 3; ++k) { nq[k] = V.normal[3 * q + k]; mq[k] = V.mean[3 * q + k]; }
-            neighbour_column(V, q, dir, nc, nc_rows);
+            er = reinterpret_cast<const uint4*>(V.edges)[4 * (size_t)q + dir];
+            // (all three in flight together: left alone, the compiler asks for the record only once the verdict is back)
+            asm volatile("" : "+v"(hit), "+v"(hq_bits), "+v"(er.x), "+v"(er.y), "+v"(er.z), "+v"(er.w));
         }
-        constexpr uint32_t kKeep = 4;                  // pushes a lane keeps for the wave's append (more go out one by one)
-        uint32_t mine[kKeep] = {0u, 0u, 0u, 0u}, np = 0;
+        GNDT_COST_STAMP(1);
+        uint32_t p0 = kNone, p1 = kNone;               // the slopes this lane queues (a third and later ones go out one by one)
         bool closed_one = false;
         if (live) {
             if (hit) {
                 if (dir == 0u) {
                     h_bits[q] = kFltMaxBits;          // Q.front()->h = FLT_MAX (map2D.h:1340)
-                    state[q] = 2u;
                     ++st.closed;
                     closed_one = true;
                 }
             } else {
-                if (dir == 0u) { state[q] = 1u; ++st.trav; }
-                st.checks += cost_expand_column(V, R, bits_float(hq_bits), nq, mq, nc, nc_rows, [&](uint32_t t, float cand) {
-                    const uint32_t cb = float_bits(cand);
-                    if (cb >= kFltMaxBits) return;     // (not below the FLT_MAX every h starts from: no improvement, map2D.h:1329)
-                    if (atomicMin(&h_bits[t], cb) != kUnreachedBits) return;          // (not the slope's first relaxation: it is queued already)
-                    if (np < kKeep) { if (np == 0u) mine[0] = t; else if (np == 1u) mine[1] = t; else if (np == 2u) mine[2] = t; else mine[3] = t; }
-                    else {
-                        const uint32_t pos = atomicAdd(out_count, 1u);
-                        f_out[pos] = t;
-                        if (WG && pos < f_lds_cap) f_out_lds[pos] = t;
-                    }
-                    ++np;
-                });
+                if (dir == 0u) ++st.trav;
+                const float hq = bits_float(hq_bits);
+                if (!(er.y & kEdgeMore)) {
+                    // cost_expand_record, both minima in flight together
+                    const uint32_t n = (er.y >> 16) & 3u;
+                    const uint32_t t0 = er.x + (er.y & 0xFFu), t1 = er.x + ((er.y >> 8) & 0xFFu);
+                    const uint32_t c0 = float_bits(hq + bits_float(er.z)), c1 = float_bits(hq + bits_float(er.w));
+                    // (a candidate not below the FLT_MAX every h starts from is no improvement, map2D.h:1329)
+                    const bool do0 = n > 0u && c0 < kFltMaxBits, do1 = n > 1u && c1 < kFltMaxBits;
+                    uint32_t o0 = 0u, o1 = 0u;
+                    if (do0) o0 = atomicMin(&h_bits[t0], c0);
+                    if (do1) o1 = atomicMin(&h_bits[t1], c1);
+                    asm volatile("" : "+v"(o0), "+v"(o1));             // (one wait for both, not one after each)
+                    if (do0 && o0 == kUnreachedBits) p0 = t0;          // (the slope's first relaxation queues it)
+                    if (do1 && o1 == kUnreachedBits) p1 = t1;
+                    st.checks += er.y >> 20;
+                } else {
+                    float nq[3], mq[3];
+                    for (int k = 0; k < 3; ++k) { nq[k] = V.normal[3 * (size_t)q + k]; mq[k] = V.mean[3 * (size_t)q + k]; }
+                    uint32_t nc, nc_rows;
+                    neighbour_column(V, q, dir, nc, nc_rows);
+                    st.checks += cost_expand_column(V, R, hq, nq, mq, nc, nc_rows, [&](uint32_t t, float cand) {
+                        const uint32_t cb = float_bits(cand);
+                        if (cb >= kFltMaxBits) return;
+                        if (atomicMin(&h_bits[t], cb) != kUnreachedBits) return;
+                        if (p0 == kNone) p0 = t;
+                        else if (p1 == kNone) p1 = t;
+                        else {
+                            const uint32_t pos = atomicAdd(out_count, 1u);
+                            f_out[pos] = t;
+                            if (WG && pos < f_lds_cap) f_out_lds[pos] = t;
+                        }
+                    });
+                }
             }
         }
-        const uint32_t kept = min(np, kKeep);
-        uint32_t incl = kept;
-        for (int o = 1; o < 64; o <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)incl, o, 64); if (lane >= o) incl += t; }
-        const uint32_t total = (uint32_t)__shfl((int)incl, 63, 64);
-        if (total) {                                   // (wave-uniform)
+        GNDT_COST_STAMP(2);
+        const unsigned long long b0 = __ballot(p0 != kNone), b1 = __ballot(p1 != kNone);
+        if (b0 | b1) {                                 // (wave-uniform)
+            const uint32_t n0 = (uint32_t)__popcll(b0), total = n0 + (uint32_t)__popcll(b1);
             uint32_t base = 0;
-            if (lane == 63) base = atomicAdd(out_count, total);
-            base = (uint32_t)__shfl((int)base, 63, 64) + incl - kept;
-            for (uint32_t k = 0; k < kKeep; ++k) {
-                if (k < kept) {
-                    const uint32_t t = k == 0u ? mine[0] : k == 1u ? mine[1] : k == 2u ? mine[2] : mine[3];
-                    f_out[base + k] = t;
-                    if (WG && base + k < f_lds_cap) f_out_lds[base + k] = t;
-                }
+            if (lane == 0) base = atomicAdd(out_count, total);
+            base = (uint32_t)__shfl((int)base, 0, 64);
+            const unsigned long long below = (1ull << lane) - 1ull;
+            if (p0 != kNone) {
+                const uint32_t pos = base + (uint32_t)__popcll(b0 & below);
+                f_out[pos] = p0;
+                if (WG && pos < f_lds_cap) f_out_lds[pos] = p0;
+            }
+            if (p1 != kNone) {
+                const uint32_t pos = base + n0 + (uint32_t)__popcll(b1 & below);
+                f_out[pos] = p1;
+                if (WG && pos < f_lds_cap) f_out_lds[pos] = p1;
             }
         }
         // WG: the FLT_MAX of a closed slope must have arrived before another wavefront's atomic min on the same word, one barrier on
         if (WG && __any(closed_one)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        GNDT_COST_STAMP(3);
     }
 }
 
@@ -583,7 +689,7 @@ static __global__ void __launch_bounds__(64) k_cost_level(CostView V, Robot R, u
         if (n_in) cc->levels = level + 1u;
     }
     if (blockIdx.x * 16u >= n_in) return;              // (uniform; every workgroup once the flood has ended)
-    LayerStats st{0u, 0u, 0u};
+    LayerStats st{};
     cost_layer<false>(V, R, n_in, blockIdx.x * 16u, gridDim.x * 16u, h_bits, state, (level & 1u) ? f1 : f0, (level & 1u) ? f0 : f1, nullptr, 0u,
                       &cc->frontier[(level + 1u) % 3u], st);
     cost_flush_stats(st, cc);
@@ -593,7 +699,10 @@ static __global__ void __launch_bounds__(64) k_cost_level(CostView V, Robot R, u
 // between them instead of a launch, the frontier and its counters in LDS.  It stops at a layer wider than max_frontier (<= kWgFrontier;
 // the one-layer launches that follow it on the stream take it from there: cc->wg_layers, cc->frontier, the frontier arrays in global
 // memory are kept complete), when the flood has ended, or after max_layers.
-// Measured (profiles/r04_cost_map.json): 6.5 us per layer on the site, 7.9 on the 8 M-point terrain; one-layer launches 7.9 / 10.5.
+// Measured (profiles/r05_cost_map.json): 2.9 us per layer on the site, 2.3 on the 8 M-point terrain (round 4, with the gates and the
+// travel cost inside the layers: 6.5 / 7.9); one-layer launches 5.9 / 5.9.  Where a layer's ~5 k cycles go (tools/cost_stamps.sh,
+// profiles/r05_cost_stamps.txt): its two returning round trips — the loads ~600, the atomic minima ~1 300 (tools/atomic_latency.hip:
+// a returning global atomic takes 1 230-1 560 cycles on an idle chip, a load 370-880) — and the barrier, i.e. the slowest wave's.
 constexpr int kWgThreads = 1024;
 constexpr uint32_t kWgFrontier = 4u * (uint32_t)(kWgThreads / 4);      // four rounds of the workgroup's quads
 
@@ -613,7 +722,10 @@ static __global__ void __launch_bounds__(kWgThreads) k_cost_flood_wg(CostView V,
         if (threadIdx.x < 3u) s_count[threadIdx.x] = 0u;
     }
     __syncthreads();
-    LayerStats st{0u, 0u, 0u};
+    LayerStats st{};
+#if defined(GNDT_COST_STAMPS)
+    st.last = clock64();
+#endif
     uint32_t done = 0;
     for (; done < max_layers && n_in != 0u && n_in <= max_frontier; ++done) {
         if (threadIdx.x == 0) s_count[(level + 2u) % 3u] = 0u;        // (the layer after next's; nobody looks at it during this layer)
@@ -622,7 +734,11 @@ static __global__ void __launch_bounds__(kWgThreads) k_cost_flood_wg(CostView V,
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // (LDS only: the frontier's global copy is for later kernels)
         ++level;
         n_in = s_count[level % 3u];
+        GNDT_COST_STAMP(4);
     }
+#if defined(GNDT_COST_STAMPS)
+    if (threadIdx.x == 0) { for (int k = 0; k < 5; ++k) cc->phase[k] += st.ph[k]; cc->phase[5] += done; }
+#endif
     cost_flush_stats(st, cc);
     if (threadIdx.x == 0) {
         cc->wg_layers = level - launched;

@@ -168,6 +168,7 @@ struct gndt_handle {
         uint64_t node_cap = 0;     uint32_t *h_bits = nullptr, *state = nullptr, *f[2] = {nullptr, nullptr};
         uint32_t ctab_size = 0;    uint64_t* ctab_key = nullptr; uint32_t* ctab_val = nullptr;
         uint32_t* nbr = nullptr;       // per-flood tables, node_cap rows each: neighbour columns (8 words), own column + collision verdict (2), ring step masks (4), ring extremes (4)
+        CostEdge* edges = nullptr;     // node_cap x 4 records: what a slope does to each of its neighbour cells (gndt_cost.hpp)
         CostCounters* d_cc = nullptr;
         CostCounters* h_cc = nullptr;   // pinned
         uint64_t serial = 0;            // result_serial the flood was computed for (0 = none)

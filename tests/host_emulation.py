@@ -157,7 +157,7 @@ def cost_levelsync(cells, grid_len, slope_interval, goal_key, demand="slope", ro
             ("rough", np.float32), ("flags", np.uint32))}
     h = np.zeros(n, np.float32)
     state = np.zeros(n, np.uint8)
-    stats = np.zeros(6, np.int64)
+    stats = np.zeros(8, np.int64)
     r4 = (C.c_float * 4)(float(rb["radius"]), float(rb["reachable_height"]), float(rb["max_rough"]), float(rb["max_angle_deg"]))
     L = shim()
     L.shim_cost.restype = C.c_int
@@ -168,7 +168,8 @@ def cost_levelsync(cells, grid_len, slope_interval, goal_key, demand="slope", ro
                      float(slope_interval), dem, float(grid_len), int(goal_key[0]), int(goal_key[1]), int(goal_key[2]), r4,
                      h.ctypes.data, state.ctypes.data, stats.ctypes.data)
     return {"rc": rc, "h": h, "state": state, "traversable": int(stats[0]), "closed": int(stats[1]),
-            "check_pushes": int(stats[2]), "ring": int(stats[3]), "levels": int(stats[4]), "ring_overflow": int(stats[5])}
+            "check_pushes": int(stats[2]), "ring": int(stats[3]), "levels": int(stats[4]), "ring_overflow": int(stats[5]),
+            "records": int(stats[6]), "records_more": int(stats[7])}
 
 
 def collide_all(cells, grid_len, slope_interval, demand="slope", robot=None, ring_cap=1 << 16):

@@ -59,13 +59,14 @@ extern "C" void shim_jacobi(const double* S, uint64_t n, double* evals, double* 
 }
 
 // ---- cost-map flood (grid_ndt_amd/csrc/gndt_cost.hpp): the per-slope logic the kernels run, driven level by
-// level on the host exactly as k_cost_level is launched layer after layer ----
+// level on the host exactly as k_cost_level is launched layer after layer: a slope's four CostEdge records (what k_cost_neighbours
+// writes for every slope before the flood), then the expansion from them ----
 #include <vector>
 #include "gndt_cost.hpp"
 extern "C" int shim_cost(uint64_t n, const int32_t* sx, const int32_t* sy, const int32_t* sz, const float* mean,
                          const float* normal, const float* rough, const uint32_t* flags, float slope_interval,
                          int demand_true, float grid_len, int gx, int gy, int gz, const float robot4[4], float* h_out,
-                         uint8_t* state_out, int64_t stats[6]) {
+                         uint8_t* state_out, int64_t stats[8]) {
     using namespace gndt;
     // columns are contiguous in the reference order
     std::vector<uint32_t> col_base, row_ncol(n ? n : 1, 0u);
@@ -88,7 +89,7 @@ extern "C" int shim_cost(uint64_t n, const int32_t* sx, const int32_t* sy, const
     Robot R{robot4[0], robot4[1], robot4[2], robot4[3]};
     const int ring_n = cost_ring_depth(R.r, grid_len);
     std::vector<uint32_t> hb(n, 0x7F7FFFFFu), pushed(n, 0), state(n, 0), frontier, next, ring(kRingCap);
-    int64_t trav = 0, closed = 0, checks = 0, levels = 0, overflow = 0;
+    int64_t trav = 0, closed = 0, checks = 0, levels = 0, overflow = 0, records = 0, records_more = 0;
     int goal_status = 1;
     const uint32_t gc = ctab_find(V, gx, gy);
     if (gc != kNoColumn) {
@@ -104,17 +105,30 @@ extern "C" int shim_cost(uint64_t n, const int32_t* sx, const int32_t* sy, const
             if (hit < 0) { ++overflow; continue; }
             if (hit) { hb[q] = 0x7F7FFFFFu; state[q] = 2; ++closed; continue; }
             state[q] = 1; ++trav;
-            checks += cost_expand(V, R, q, bits_float(hb[q]), [&](uint32_t t, float cand) {
+            auto relax = [&](uint32_t t, float cand) {
                 const uint32_t cb = float_bits(cand);
                 const uint32_t old = hb[t];
                 if (cb < old) hb[t] = cb;
                 if (old > cb && pushed[t] == 0) { pushed[t] = 1; next.push_back(t); }
-            });
+            };
+            for (uint32_t k = 0; k < 4u; ++k) {          // as cost_layer: the record, or the column itself where the record says so
+                uint32_t c, ncol;
+                neighbour_column(V, q, k, c, ncol);
+                const CostEdge e = cost_edge_record(V, R, q, c, ncol);
+                ++records;
+                if (e.info & kEdgeMore) {
+                    ++records_more;
+                    checks += cost_expand_column(V, R, bits_float(hb[q]), V.normal + 3 * (size_t)q, V.mean + 3 * (size_t)q, c, ncol, relax);
+                } else {
+                    checks += cost_expand_record(e, bits_float(hb[q]), relax);
+                }
+            }
         }
         frontier.swap(next);
     }
     for (uint64_t i = 0; i < n; ++i) { h_out[i] = bits_float(hb[i]); state_out[i] = (uint8_t)state[i]; }
     stats[0] = trav; stats[1] = closed; stats[2] = checks; stats[3] = ring_n; stats[4] = levels; stats[5] = overflow;
+    stats[6] = records; stats[7] = records_more;
     return goal_status;
 }
 

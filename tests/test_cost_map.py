@@ -203,3 +203,26 @@ def test_ring_verdicts_by_rounds_over_the_map_equal_the_walk_for_every_slope(dem
             total += int((walk != 255).sum())
             collided += int((walk == 1).sum())
     assert total > 20000 and 0.02 * total < collided < 0.98 * total, (total, collided)
+
+
+def test_a_cell_with_more_than_two_accessible_slopes_is_expanded_from_the_column_itself():
+    """CostEdge records (gndt_cost.hpp) name at most two accessible slopes of a neighbour cell; a cell with more (a staircase of
+    closely stacked slopes within the robot's reach) sends the flood through cost_expand_column.  Both give the FIFO oracle's h."""
+    rows = []
+    for x in range(1, 8):
+        for level, z in enumerate((0.10, 0.22, 0.34, 0.46), start=1):
+            rows.append((x, 1, level, (centre(x), 0.5, z), UP, True))
+    cells = make_cells(rows)
+    robot = {"radius": 0.25, "reachable_height": 0.5}
+    o = run_both(cells, (0.5, 0.5, 0.10), robot=robot)
+    assert o["rc"] == 0 and o["traversable"] + o["closed"] == len(rows)
+    e = he.cost_levelsync(cells, 1.0, 0.08, (1, 1, 1), robot=robot)
+    assert e["records_more"] > 0 and e["records"] > e["records_more"]
+    # and the site's records never need it at the reference's robot (two slopes of a cell within 0.15 m of height are rare)
+    cloud = scenes.drivable_site()
+    P = scenes.COST_PARAMS
+    ref = oracle.build_grid(cloud, P["grid_len"], P["z_len"], P["slope_interval"], mode=oracle.MODE_INT_SERIAL)
+    key, nx, ny, sz = oracle.trans_morton_xyz(cloud[0], P["grid_len"], P["z_len"], scenes.DRIVABLE_GOAL)
+    gk = (nx if key[0] in "AB" else -nx, ny if key[0] in "AC" else -ny, sz)
+    s = he.cost_levelsync(ref, P["grid_len"], P["slope_interval"], gk)
+    assert s["records"] > 30000 and s["records_more"] == 0

@@ -133,6 +133,36 @@ def test_cost_map_with_rings_of_thousands_of_slopes(demand):
         _check(m, cloud, P, goal, demand, {"radius": 0.25})
 
 
+def _sheets(n=300_000, seed=12, levels=24):
+    """Thin, slightly tilted sheets 0.1 m apart over 2 x 2 m: every cell of 0.1 m holds a stack of flat nodes."""
+    rng = np.random.default_rng(seed)
+    body = np.empty((n, 3), np.float32)
+    body[:, 0:2] = rng.random((n, 2)) * 2.0 + 0.5
+    k = rng.integers(0, levels, n)
+    body[:, 2] = k * 0.1 + 0.05 + rng.normal(0, 0.002, n) + 0.01 * body[:, 0]
+    return np.vstack([np.zeros((1, 3), np.float32), body]).astype(np.float32)
+
+
+@pytest.mark.parametrize("wg", ["1", "0"])
+def test_cost_map_where_a_cell_holds_more_accessible_slopes_than_a_record_names(wg, monkeypatch):
+    """Stacked sheets on 0.1 m cells and a robot that reaches 0.45 m up or down: a neighbour cell holds up to nine accessible slopes,
+    a CostEdge record (gndt_cost.hpp) names two — such cells (nine records in ten here) are expanded from their rows inside the layer
+    (kEdgeMore), next to cells expanded from their record.  Same flood as the oracle's, by the one-workgroup kernel and by one-layer
+    launches."""
+    cloud = _sheets()
+    P = dict(grid_len=0.1, z_len=0.1, slope_interval=0.12)       # (a node 0.1 m above does not take the slope away: map2D.h:66-108)
+    m = _build(cloud, P, "slope", 0)
+    cells = m.export()
+    rows = np.nonzero((cells["flags"] & 2) != 0)[0]
+    assert len(rows) > 4000
+    monkeypatch.setenv("GNDT_COST_WG", wg)
+    robot = {"radius": 0.04, "reachable_height": 0.45, "max_angle_deg": 30.0}
+    goal = cells["mean"][rows[len(rows) // 2]]
+    st, _ = _check(m, cloud, P, goal, "slope", robot)
+    assert st["rc"] == 0 and st["ring"] == 0 and st["traversable"] > 4000
+    assert st["check_pushes"] > 20 * st["traversable"]              # (tall cells: ~12 slopes in each of the four)
+
+
 @pytest.mark.parametrize("demand", ["slope", "true"])
 def test_cost_map_by_one_layer_launches_only(demand, monkeypatch):
     """GNDT_COST_WG=0: no one-workgroup kernel walking the narrow layers, every layer its own launch (what wide layers get anyway).
