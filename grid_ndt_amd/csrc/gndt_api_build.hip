@@ -11,7 +11,10 @@ namespace gndt_host {
 int launch_order_and_emit(gndt_handle* h, uint64_t words, int m0, hipStream_t s, bool grouped, bool counters_to_host, bool tab_end, uint32_t advance,
                           bool partial) {
     auto& q = h->part;
-    if (words <= kScanSmallMax) {
+    // (small clouds, staging rows grouped by column: the destination pass scans the word weights itself — gndt_partition.hpp)
+    const bool dest_scans = grouped && !partial && !tab_end && words <= kDestScanMax && tuning().dest_scans;
+    if (dest_scans) {
+    } else if (words <= kScanSmallMax) {
         hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(1024), 0, s, (const uint32_t*)q.word_weight, (uint32_t)words, q.word_base);
     } else {
         const uint32_t nbw = (uint32_t)((words + kScanChunk - 1) / kScanChunk);
@@ -27,9 +30,12 @@ int launch_order_and_emit(gndt_handle* h, uint64_t words, int m0, hipStream_t s,
     mark(h, m0 + 1, s);
     mark(h, m0 + 2, s);       // (the column-rank and column-scan passes of earlier versions: phases kept for the ABI, empty)
     mark(h, m0 + 3, s);
-    if (grouped)
-        hipLaunchKernelGGL(k_order_dest_columns, dim3(grid_for(q.stage_cap)), dim3(kBlock), 0, s, q.ord_cf, q.ord_idx, q.bitmap, q.word_base,
-                           q.ncol_at, q.inv, h->d_cnt, q.d_pc);
+    if (grouped && dest_scans)
+        hipLaunchKernelGGL(k_order_dest_columns<true>, dim3(grid_for(q.stage_cap)), dim3(kBlock), 0, s, q.ord_cf, q.ord_idx, q.bitmap, q.word_base,
+                           q.ncol_at, q.inv, h->d_cnt, q.d_pc, (const uint32_t*)q.word_weight, (uint32_t)words);
+    else if (grouped)
+        hipLaunchKernelGGL(k_order_dest_columns<false>, dim3(grid_for(q.stage_cap)), dim3(kBlock), 0, s, q.ord_cf, q.ord_idx, q.bitmap, q.word_base,
+                           q.ncol_at, q.inv, h->d_cnt, q.d_pc, (const uint32_t*)q.word_weight, (uint32_t)words);
     else
         hipLaunchKernelGGL(k_order_dest, dim3(grid_for(q.stage_cap)), dim3(kBlock), 0, s, q.ord_cf, q.ord_idx, q.bitmap, q.word_base,
                            q.ncol_at, q.inv, h->d_cnt, q.d_pc, tab_end ? q.row_of : (uint32_t*)nullptr, partial ? 1u : 0u);

@@ -813,12 +813,39 @@ static __global__ void __launch_bounds__(1024) k_scan_small(const uint32_t* __re
 // Staging rows grouped by column (k_bucket_direct): a column's rows are adjacent and in first-seen order, its first row's
 // ord_idx is kOrdHeadFlag | column size.  One lookup of the column's place, then its rows in a run.
 constexpr uint32_t kOrdHeadFlag = 0x80000000u;
+// SCAN (small clouds: the index range's bitmap words fit LDS): no scan launch in front of this kernel — every workgroup works the
+// prefix of the word weights out for itself, in LDS (word_weight, words), and looks the word bases up there; workgroup 0 leaves
+// them in word_base as the scan launches would have.  A 200 k-point frame is seven launches of 4-25 us each, two of them the scan.
+constexpr uint32_t kDestScanMax = 1u << 13;
+template <bool SCAN>
 static __global__ void __launch_bounds__(kBlock) k_order_dest_columns(const uint32_t* __restrict__ ord_cf, const uint32_t* __restrict__ ord_idx,
-                                                                      const uint32_t* __restrict__ bitmap, const uint32_t* __restrict__ word_base,
+                                                                      const uint32_t* __restrict__ bitmap, uint32_t* __restrict__ word_base,
                                                                       const uint32_t* __restrict__ ncol_at, uint32_t* __restrict__ inv,
-                                                                      const Counters* __restrict__ cnt, const PartCounters* __restrict__ pc) {
+                                                                      const Counters* __restrict__ cnt, const PartCounters* __restrict__ pc,
+                                                                      const uint32_t* __restrict__ word_weight, uint32_t words) {
     if (pc->lds_overflow | pc->stage_overflow | pc->index_overflow | pc->part_overflow) return;
     const uint32_t n = cnt->num_nodes;
+    __shared__ uint32_t s_base[SCAN ? kDestScanMax : 1];
+    __shared__ uint32_t s_wave[kBlock / 64];
+    if (SCAN) {
+        for (uint32_t j = threadIdx.x; j < words; j += kBlock) s_base[j] = word_weight[j];
+        __syncthreads();
+        // a thread's words are consecutive, an odd number of them (its neighbours' then start in other banks)
+        const uint32_t per = ((words + kBlock - 1u) / kBlock) | 1u;
+        const uint32_t j0 = min(threadIdx.x * per, words), j1 = min(j0 + per, words);
+        uint32_t sum = 0;
+        for (uint32_t j = j0; j < j1; ++j) sum += s_base[j];
+        uint32_t incl = sum;
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        for (int off = 1; off < 64; off <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)incl, off, 64); if (lane >= off) incl += t; }
+        if (lane == 63) s_wave[wave] = incl;
+        __syncthreads();
+        uint32_t run = incl - sum;
+        for (int w = 0; w < wave; ++w) run += s_wave[w];
+        for (uint32_t j = j0; j < j1; ++j) { const uint32_t v = s_base[j]; s_base[j] = run; run += v; }
+        __syncthreads();
+        if (blockIdx.x == 0) for (uint32_t j = threadIdx.x; j < words; j += kBlock) word_base[j] = s_base[j];
+    }
     // The grid is capped (grid_for), so on a large map a thread walks ~20 rows, and every row of a column head is three DEPENDENT
     // memory round trips (order key, first-seen index, bitmap word + word base).  Round 5: four rows per step, each stage's loads
     // issued for all four before any is used: 0.356 -> 0.329 ms on 100 M points, 0.124 -> 0.110 on 32 M.  (What bounds it then is the
@@ -836,7 +863,7 @@ static __global__ void __launch_bounds__(kBlock) k_order_dest_columns(const uint
 #pragma unroll
         for (int q = 0; q < K; ++q) cf[q] = (v[q] & kOrdHeadFlag) ? ord_cf[i0 + (uint32_t)q * stride] : 0u;
 #pragma unroll
-        for (int q = 0; q < K; ++q) { bw[q] = 0u; wb[q] = 0u; if (v[q] & kOrdHeadFlag) { bw[q] = bitmap[cf[q] >> 5]; wb[q] = word_base[cf[q] >> 5]; } }
+        for (int q = 0; q < K; ++q) { bw[q] = 0u; wb[q] = 0u; if (v[q] & kOrdHeadFlag) { bw[q] = bitmap[cf[q] >> 5]; wb[q] = SCAN ? s_base[cf[q] >> 5] : word_base[cf[q] >> 5]; } }
 #pragma unroll
         for (int q = 0; q < K; ++q) {
             if (!(v[q] & kOrdHeadFlag)) continue;
