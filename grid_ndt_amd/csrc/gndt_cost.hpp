@@ -422,7 +422,7 @@ static __global__ void __launch_bounds__(256) k_cost_clear(uint32_t* __restrict_
                                                     uint64_t* __restrict__ ctab_key, uint32_t ctab_size, CostCounters* __restrict__ cc) {
     const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x, gsz = gridDim.x * blockDim.x;
     for (uint32_t i = gid; i < n; i += gsz) h_bits[i] = kUnreachedBits;
-    for (uint32_t i = gid; i < ctab_size; i += gsz) ctab_key[i] = kEmptyKey;
+    for (uint32_t i = gid; i < ctab_size; i += gsz) ctab_key[i] = kEmptyKey;       // (ctab_size 0: the column index of the last flood is kept)
     if (gid == 0) {
         cc->frontier[0] = cc->frontier[1] = cc->frontier[2] = 0u;
         cc->traversable = cc->closed = cc->pad0 = cc->range_error = 0u;

@@ -172,6 +172,8 @@ struct gndt_handle {
         CostCounters* d_cc = nullptr;
         CostCounters* h_cc = nullptr;   // pinned
         uint64_t serial = 0;            // result_serial the flood was computed for (0 = none)
+        uint64_t tables_serial = 0;     // result_serial the per-map tables (column index, nbr / self / edges, ring verdicts) belong to (0 = none) ...
+        float tables_robot[4] = {0, 0, 0, 0};   // ... and the robot they were worked out for: the next goal on the same map reuses them
         int ring_n = 0, ring_store = 0;
     } cost;
     // statistics exchange of a sharded build (gndt_exchange.hpp, gndt_api_dist.hip)

@@ -163,6 +163,31 @@ def test_cost_map_where_a_cell_holds_more_accessible_slopes_than_a_record_names(
     assert st["check_pushes"] > 20 * st["traversable"]              # (tall cells: ~12 slopes in each of the four)
 
 
+def test_cost_map_for_goal_after_goal_on_one_map_then_on_the_next():
+    """What a flood needs of the map and the robot alone (column index, neighbour columns, CostEdge records, collision verdicts) is
+    kept for the next goal on the same map: goals, robots and maps in every order — each flood the oracle's, also right after the
+    robot changed (tables worked out again), after the map was rebuilt from another cloud, and back."""
+    import torch
+    cloud = scenes.drivable_site()
+    P = scenes.COST_PARAMS
+    m = _build(cloud, P, "slope", 0)
+    cells = m.export()
+    rows = np.nonzero((cells["flags"] & 2) != 0)[0]
+    goals = [scenes.DRIVABLE_GOAL] + [cells["mean"][rows[(7 * k + 3) * len(rows) // 40]] for k in range(4)]
+    wide, narrow = {"radius": 0.6}, {"radius": 0.25}
+    for goal, robot in ((goals[0], narrow), (goals[1], narrow), (goals[2], wide), (goals[3], wide), (goals[4], narrow), (goals[0], narrow)):
+        st, _ = _check(m, cloud, P, goal, "slope", robot)
+        assert st["rc"] == 0
+    # another map on the same handle (half of the cloud: other nodes, other rows), the same goal and robot as the last flood
+    half = np.ascontiguousarray(np.vstack([cloud[:1], cloud[1::2]]))
+    m.create2DMap("slope", torch.from_numpy(np.ascontiguousarray(half[1:])).cuda())
+    st, _ = _check(m, half, P, goals[0], "slope", narrow)
+    st2, _ = _check(m, half, P, goals[1], "slope", narrow)
+    m.create2DMap("slope", torch.from_numpy(np.ascontiguousarray(cloud[1:])).cuda())
+    st3, _ = _check(m, cloud, P, goals[1], "slope", narrow)
+    assert st3["traversable"] > 8000
+
+
 @pytest.mark.parametrize("demand", ["slope", "true"])
 def test_cost_map_by_one_layer_launches_only(demand, monkeypatch):
     """GNDT_COST_WG=0: no one-workgroup kernel walking the narrow layers, every layer its own launch (what wide layers get anyway).

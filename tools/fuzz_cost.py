@@ -42,12 +42,17 @@ def main():
         m.create2DMap(demand, torch.from_numpy(np.ascontiguousarray(cloud[1:])).cuda())
         grid = m.export()
         stats["maps"] += 1
-        for _ in range(int(rng.integers(1, 4))):
+        robot_before = None
+        for _ in range(int(rng.integers(1, 5))):
             goal = cloud[int(rng.integers(1, cloud.shape[0]))].astype(np.float32)
             if rng.random() < 0.1:
                 goal = goal + np.float32([500.0, 0.0, 0.0])          # off the map
-            robot = {"radius": float(rng.choice([0.2, 0.25, 0.6, 1.3])), "reachable_height": float(rng.choice([0.05, 0.1, 0.3, 0.7])),
-                     "max_angle_deg": float(rng.choice([15.0, 20.0, 30.0, 45.0]))}
+            if robot_before is None or rng.random() < 0.5:       # (half of the floods: the robot of the flood before — its tables are kept)
+                robot = {"radius": float(rng.choice([0.2, 0.25, 0.6, 1.3])), "reachable_height": float(rng.choice([0.05, 0.1, 0.3, 0.7])),
+                         "max_angle_deg": float(rng.choice([15.0, 20.0, 30.0, 45.0]))}
+            else:
+                robot = robot_before
+            robot_before = robot
             desc = dict(seed=a.seed, map=stats["maps"], cells=cells, demand=demand, points=int(cloud.shape[0] - 1), nodes=int(grid["num_nodes"]),
                         goal=[float(v) for v in goal], robot=robot)
             if a.trace:

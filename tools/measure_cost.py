@@ -38,6 +38,17 @@ def main():
             rows = np.nonzero((cells["flags"] & 2) != 0)[0]
             goal = cells["mean"][rows[len(rows) // 3]]
         st = m.computeCost(goal)
+        # the first flood on a NEW map works the per-map tables out (column index, neighbour columns, CostEdge records, collision
+        # verdicts); the floods for further goals on it keep them
+        pts = torch.from_numpy(np.ascontiguousarray(cloud[1:])).cuda()
+        first = []
+        for _ in range(3):
+            m.create2DMap("slope", pts)
+            m.sync()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            st = m.computeCost(goal)
+            first.append((time.perf_counter() - t0) * 1e3)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(a.steps):
@@ -50,7 +61,8 @@ def main():
         cpu_flags_s = time.perf_counter() - t0
         rec = {"points": int(cloud.shape[0] - 1), "nodes": int(cells["num_nodes"]), "slopes": int(cells["num_slopes"]),
                "traversable": st["traversable"], "closed": st["closed"], "levels": st["levels"], "ring": st["ring"],
-               "gpu_ms": round(gpu_ms, 3), "gpu_us_per_level": round(gpu_ms * 1e3 / max(st["levels"], 1), 2),
+               "gpu_ms": round(gpu_ms, 3), "gpu_first_flood_on_a_map_ms": round(sorted(first)[1], 3),
+               "gpu_us_per_level": round(gpu_ms * 1e3 / max(st["levels"], 1), 2),
                "gpu_Mslopes_per_s": round(st["traversable"] / gpu_ms / 1e3, 2),
                "cpu_oracle_flags_ms": round(cpu_flags_s * 1e3, 1),
                "parity_h_bit_exact": bool((got["h"] == ref["h"]).all()), "parity_state_exact": bool((got["state"] == ref["state"]).all())}
