@@ -278,7 +278,7 @@ def _stream_latency(g, torch, frames, ppf, nframes, graph_mode, deferred=False):
     graph = None
     if graph_mode:
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
+        with g.graph_capture(graph):
             m.change2DMap("slope", buf)
     lat = []
     half = nframes // 2
@@ -531,7 +531,7 @@ def run_stream(a):
         graph = None
         if a.graph:
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            with g.graph_capture(graph):
                 m.change2DMap("slope", buf)
         lat = []
         for f in range(1, a.warmup + 1):

@@ -259,13 +259,20 @@ int partition_launch(gndt_handle* h, gndt_handle::Pending& P) {
                            q.cursors, (uint32_t)(kMaxFan + B));
         HIP_TRY(h, hipGetLastError());
         mark(h, 1, s);
-        const uint32_t tiles1 = (uint32_t)((P.n + kTile1 - 1) / kTile1), tiles1b = (uint32_t)((P.n2 + kTile1 - 1) / kTile1);
+        // small clouds: 1024-point tiles (gndt_partition.hpp: kTilePerSmall), so that the frame is a launch of a few hundred workgroups
+        const bool small_tiles = !P.records && n < (1u << 20) && tuning().small_tiles;
+        const uint64_t tile1 = small_tiles ? (uint64_t)kTileThreads * kTilePerSmall : kTile1;
+        const uint32_t tiles1 = (uint32_t)((P.n + tile1 - 1) / tile1), tiles1b = (uint32_t)((P.n2 + tile1 - 1) / tile1);
         const uint32_t l1_wgs = tuning().l1_wgs;
         const bool wide = B > 256;
         const dim3 g1(std::max<uint32_t>(1, std::min<uint32_t>(tiles1, l1_wgs))), g1b(std::max<uint32_t>(1, std::min<uint32_t>(tiles1b, l1_wgs)));
 #define GNDT_L1(SF_, FAN_)                                                                                                  \
     hipLaunchKernelGGL((k_part2_level1<SF_, FAN_>), g1, dim3(kTileThreads), 0, s, p, (uint64_t)n, P.first_base, gp, B, F1, F2_shift, \
                        R, cursor1, cap1, est2, q.recs1, h->d_cnt, q.d_pc, compress, OwnerMap{nullptr, nullptr, 0u}, (uint32_t*)nullptr, \
+                       (uint32_t*)nullptr, 0ull)
+#define GNDT_L1S(SF_, FAN_)                                                                                                 \
+    hipLaunchKernelGGL((k_part2_level1<SF_, FAN_, false, false, kTilePerSmall>), g1, dim3(kTileThreads), 0, s, p, (uint64_t)n, P.first_base, gp, B, F1, \
+                       F2_shift, R, cursor1, cap1, est2, q.recs1, h->d_cnt, q.d_pc, compress, OwnerMap{nullptr, nullptr, 0u}, (uint32_t*)nullptr, \
                        (uint32_t*)nullptr, 0ull)
 #define GNDT_L1R(FAN_)                                                                                                      \
     do {                                                                                                                    \
@@ -276,10 +283,15 @@ int partition_launch(gndt_handle* h, gndt_handle::Pending& P) {
                                      F1, F2_shift, R, cursor1, cap1, est2, q.recs1, h->d_cnt, q.d_pc, compress, OwnerMap{nullptr, nullptr, 0u}, \
                                      (uint32_t*)nullptr, (uint32_t*)nullptr, 0ull);                                          \
     } while (0)
+        if (small_tiles) {
+            if (stride_bytes == 12) { if (wide) GNDT_L1S(3, 512); else GNDT_L1S(3, 256); }
+            else { if (wide) GNDT_L1S(4, 512); else GNDT_L1S(4, 256); }
+        } else
         if (P.records) { if (wide) GNDT_L1R(512); else GNDT_L1R(256); }
         else if (stride_bytes == 12) { if (wide) GNDT_L1(3, 512); else GNDT_L1(3, 256); }
         else { if (wide) GNDT_L1(4, 512); else GNDT_L1(4, 256); }
 #undef GNDT_L1
+#undef GNDT_L1S
 #undef GNDT_L1R
         HIP_TRY(h, hipGetLastError());
         mark(h, 2, s);

@@ -291,6 +291,8 @@ struct Tuning {
     int retry_pass = 1;          // 0: never launch the bucket kernel's second pass (an overflowing 512-slot table re-runs the build, as before round 5)
     int dest_scans = 1;          // small clouds: the destination pass scans the word weights itself instead of one or two scan launches in front of it
                                  //   (200 k-point campus frame 0.0549 -> 0.0535 ms, bridge_ground 0.0647 -> 0.0646: r05 ablation 6h)
+    int small_tiles = 1;         // one-level partition of < 1 M points: 1024-point level-1 tiles (a few hundred workgroups instead of a few dozen:
+                                 //   campus frame 0.0535 -> 0.0520 ms, bridge_ground 0.0648 -> 0.0608; r05 ablation 6i)
     int fp_bits = 21;            // bits of the bucket kernel's index fingerprint (tests narrow it through gndt_debug_set_fp_bits to force clashes)
     // ... and what the environment can set (parsed ONCE per process)
     double tile_ratio = 48.0;    // GNDT_TILE_RATIO     AUTO takes strategy TILE from this many points per partial on (sampled; the

@@ -515,7 +515,11 @@ __device__ __forceinline__ void part2_layout(LayoutLds& S, const uint32_t* est2,
 // OWNER: the same kernel as the split of a sharded cloud by column owner (gndt_api_dist.hip): the digit is the owner rank of the
 // point's column among B ranks (region c at c * cap1, nothing sampled), everything else — the pipelined tile loads, the folding
 // of identical points into weighted records, the LDS sort and the coalesced copy-out — is what level 1 does anyway.
-template <int STRIDE_FLOATS, int FAN, bool IDXW = false, bool OWNER = false>
+// PER1: points per thread and tile.  kTilePer1 (4096-point tiles) everywhere but on small clouds (the one-level partition of < 1 M
+// points), where kTilePerSmall makes 1024-point tiles: a 200 k-point frame is 49 tiles of 4096 — a fifth of the CUs busy for 11-14 us —
+// or 196 of 1024.  (A wave's share of such a tile is 128 points: no weight-512 records, the weight-64 ones stay.)
+constexpr int kTilePerSmall = 2;
+template <int STRIDE_FLOATS, int FAN, bool IDXW = false, bool OWNER = false, int PER1 = kTilePer1>
 __global__ void __launch_bounds__(kTileThreads) __attribute__((amdgpu_waves_per_eu(GNDT_L1_WAVES, GNDT_L1_WAVES))) k_part2_level1(const float* __restrict__ xyz, uint64_t n, uint32_t first_base,
                                                                GridParams P, uint32_t B, uint32_t F1, uint32_t F2_shift, uint32_t R,
                                                                uint32_t* __restrict__ cursor1, uint32_t cap1,
@@ -523,7 +527,7 @@ __global__ void __launch_bounds__(kTileThreads) __attribute__((amdgpu_waves_per_
                                                                float4* __restrict__ recs1, Counters* __restrict__ cnt,
                                                                PartCounters* __restrict__ pc, uint32_t compress, OwnerMap M,
                                                                uint32_t* __restrict__ lay_lo, uint32_t* __restrict__ lay_cap, uint64_t rec_capacity) {
-    constexpr int PER = kTilePer1;
+    constexpr int PER = PER1;
     __shared__ TileLds<PER, FAN> L;
     // Persistent workgroups, software-pipelined: the loads of tile t+1 are in flight while tile t is keyed, sorted
     // in LDS and copied out (the kernel is latency-bound: ~70 % of a wave's life is spent parked on waits).
@@ -565,7 +569,7 @@ __global__ void __launch_bounds__(kTileThreads) __attribute__((amdgpu_waves_per_
         if (tile + gridDim.x < ntiles) load_tile(tile + gridDim.x);
         // All 512 points this wave holds in the tile bit-identical (a stretch of the converters' zero padding)?  Then they go
         // out as ONE record of weight 512 instead of eight of weight 64: the bucket that collects the padding gets 8x fewer.
-        bool all8 = kWeight512Ok && !IDXW && compress != 0u && t0 + (uint64_t)kTileThreads * PER <= n;
+        bool all8 = kWeight512Ok && PER == kTilePer1 && !IDXW && compress != 0u && t0 + (uint64_t)kTileThreads * PER <= n;
         if constexpr (!IDXW) {
             const uint32_t fx = (uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(cx[0])),
                            fy = (uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(cy[0])),

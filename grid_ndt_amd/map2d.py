@@ -622,3 +622,30 @@ def read_pcd(path):
     finally:
         L.gndt_pcd_free(C.byref(p))
     return raw, int(p.layout.point_step), (int(p.layout.offset_x), int(p.layout.offset_y), int(p.layout.offset_z))
+
+
+import contextlib as _contextlib
+
+
+@_contextlib.contextmanager
+def graph_capture(graph, stream=None):
+    """`with torch.cuda.graph(graph, stream=stream)` with Python's cycle collector paused for the duration of the capture.
+    A collection that starts in the middle of a capture can run the destructor of ANOTHER object — a handle of an earlier test
+    (gndt_destroy: hipStreamSynchronize, hipFree), a torch tensor, an abandoned CUDAGraph — and in torch's (global) capture mode any
+    such call invalidates the capture; torch then aborts the process inside capture_end (seen once in the GPU tier, in a test that
+    had just had a capture refused on purpose).  Reference-counted destruction is not affected: do not drop handles inside the block."""
+    import gc
+    import torch
+    gc.collect()
+    was_enabled = gc.isenabled()
+    gc.disable()
+    try:
+        if stream is None:
+            with torch.cuda.graph(graph):
+                yield
+        else:
+            with torch.cuda.graph(graph, stream=stream):
+                yield
+    finally:
+        if was_enabled:
+            gc.enable()

@@ -96,7 +96,7 @@ def test_partition_build_captured_after_an_atomic_fallback_is_replayed_again_and
             assert m.STRATEGY_NAMES[m.last_strategy()] == "atomic"           # (the partition attempts all overflowed)
             assert parity.compare(out, ref_tall, "slope", dense=True)["ok"]
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph, stream=s):
+        with g.graph_capture(graph, s):
             m.create2DMap("slope", buf, s)
         for c in flat + flat[::-1]:
             buf.copy_(torch.from_numpy(np.ascontiguousarray(c[1:])))
@@ -135,7 +135,7 @@ def test_build_captured_on_a_reserved_fresh_handle(strategy):
         m0._ensure(P["demand"])                                # (the handle itself is created outside the capture)
         gr = torch.cuda.CUDAGraph()
         with pytest.raises(GndtError) as ei:
-            with torch.cuda.graph(gr, stream=s):
+            with g.graph_capture(gr, s):
                 m0.create2DMap(P["demand"], buf, s)
         assert ei.value.code == 5 and "gndt_reserve" in str(ei.value)
         del m0, gr
@@ -144,7 +144,7 @@ def test_build_captured_on_a_reserved_fresh_handle(strategy):
         m.setCloudFirst(clouds[0][0])
         m.reserve(n + 1, hint, P["demand"])
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph, stream=s):
+        with g.graph_capture(graph, s):
             m.create2DMap(P["demand"], buf, s)
         for c, ref in zip(clouds, refs):
             buf.copy_(torch.from_numpy(np.ascontiguousarray(c[1:])))
@@ -207,7 +207,7 @@ def test_captured_build_overflow_then_fit_then_overflow():
         m.setCloudFirst(small[0])
         m.reserve(n + 1, 40_000, P["demand"])
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph, stream=s):
+        with g.graph_capture(graph, s):
             m.create2DMap(P["demand"], buf, s)
         for k, (cloud, fits) in enumerate([(big, False), (small, True), (small, True), (big, False), (big, False), (small, True)]):
             buf.copy_(torch.from_numpy(np.ascontiguousarray(cloud[1:])))
@@ -297,7 +297,7 @@ def test_small_maps_are_finalised_by_one_workgroup_and_larger_ones_fall_back(str
                 parity.assert_parity(m.export(), ref_small)
             # captured with the small finalisation, replayed on the small frame and on the big cloud
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph, stream=s):
+            with g.graph_capture(graph, s):
                 m.create2DMap(P["demand"], buf, s)
             graph.replay()
             s.synchronize()
@@ -433,7 +433,7 @@ def test_update_replayed_from_a_hip_graph_equals_batch_build():
     m.change2DMap("slope", buf)          # eager first frame: allocates every buffer
     m.sync()
     graph = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(graph):
+    with g.graph_capture(graph):
         m.change2DMap("slope", buf)      # captured, not executed
     for f in range(1, nf):
         buf.copy_(host[f])
@@ -472,7 +472,7 @@ def test_deferred_emit_stream_eager_and_replayed_equals_batch_build():
         graph = None
         if graph_mode:
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            with g.graph_capture(graph):
                 m.change2DMap("slope", buf)
         for f in range(1, nf):
             buf.copy_(host[f])
@@ -507,7 +507,7 @@ def test_deferred_emit_replay_eager_frame_sync_replay_export():
     m.change2DMap("slope", buf)              # frame 0: full finalisation
     m.sync()
     graph = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(graph):
+    with g.graph_capture(graph):
         m.change2DMap("slope", buf)          # (recorded, not run)
     buf.copy_(host[1]); graph.replay()       # frame 1: replay
     torch.cuda.synchronize()
@@ -858,7 +858,7 @@ def test_partition_build_replayed_from_a_hip_graph():
         m.sync()
     assert m.last_strategy() == 2
     graph = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(graph):
+    with g.graph_capture(graph):
         m.create2DMap("slope", buf)
     for k in (1, 2):
         buf.copy_(torch.from_numpy(clouds[k][1:]))
@@ -887,7 +887,7 @@ def test_auto_build_captured_when_its_locality_answer_is_due_for_renewal():
             m.create2DMap("slope", buf, s)
             m.sync()
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph, stream=s):
+        with g.graph_capture(graph, s):
             for _ in range(3):
                 m.create2DMap("slope", buf, s)
         graph.replay()

@@ -88,7 +88,7 @@ def main():
 
                     def capture():
                         gr = torch.cuda.CUDAGraph()
-                        with torch.cuda.graph(gr, stream=s):
+                        with g.graph_capture(gr, s):
                             m.create2DMap("slope", buf, s)
                         return gr
                     desc["events"].append(("capture",))
@@ -151,7 +151,7 @@ def main():
                     m.change2DMap("slope", fb, s)            # one eager frame: every buffer exists
                     m.sync()
                     graph = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(graph, stream=s):
+                    with g.graph_capture(graph, s):
                         m.change2DMap("slope", fb, s)
                     stats["update_graphs"] += 1
                     for k in range(1, frames):

@@ -92,7 +92,7 @@ def main():
         graph = None
         if graph_mode:
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            with g.graph_capture(graph):
                 m.change2DMap("slope", buf)
         lat = []
         torch.cuda.synchronize()

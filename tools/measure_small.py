@@ -45,7 +45,7 @@ def main():
             m.create2DMap("slope", pts, s)
             m.sync()
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph, stream=s):
+            with g.graph_capture(graph, s):
                 m.create2DMap("slope", pts, s)
             for _ in range(3):
                 graph.replay()

@@ -29,7 +29,7 @@ with torch.cuda.stream(s):
             m.create2DMap("slope", buf, s)
             print("eager build of `base`", m.sync(), m.retry_count(), m.STRATEGY_NAMES.get(m.last_strategy()), flush=True)
         gr = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(gr, stream=s):
+        with g.graph_capture(gr, s):
             m.create2DMap("slope", buf, s)
         print("captured", flush=True)
         seq = [other, other] if mode == "graph" else ([first, other, first, other] if mode == "graph_pair" else [base, other, base, other])
