@@ -246,7 +246,12 @@ def _timed_builds(g, torch, cloud, P, steps, hint=0, strategy=0, demand="slope")
     dt = (time.perf_counter() - t0) / steps
     n = cloud.shape[0] - 1
     # ... and a second fresh handle, now that the process has launched every kernel this cloud needs once (first_build_ms above
-    # includes their first launches; this one is handle creation + allocations + the build: tools/first_build_breakdown.py)
+    # includes their first launches; this one is handle creation + allocations + the build: tools/first_build_breakdown.py).
+    # The first handle is dropped before it: a second stream ALIVE in the process costs a hardware queue once (5.6 ms), which is the
+    # process's, not a build's.
+    strategy_name = m.STRATEGY_NAMES[m.last_strategy()]
+    retries = int(m.retry_count() - r0)
+    del m
     t0 = time.perf_counter()
     m2 = g.TwoDmap(P["grid_len"], P["z_len"], max_nodes_hint=hint, strategy=strategy)
     m2.setInterval(P["slope_interval"])
@@ -258,8 +263,8 @@ def _timed_builds(g, torch, cloud, P, steps, hint=0, strategy=0, demand="slope")
     del m2
     return {"points": int(n), "nodes": int(nodes), "ms_per_build": round(dt * 1e3, 4), "Mpoints_per_s": round(n / dt / 1e6, 1),
             "first_build_second_handle_ms": round(second_ms, 3), "first_build_second_handle_re_runs": int(second_retries),
-            "strategy": m.STRATEGY_NAMES[m.last_strategy()], "path_frac": round((12 * n + 76 * nodes) / dt / (HBM_PEAK_GBS * 1e9), 5),
-            "retries": int(m.retry_count() - r0), "steps": steps,
+            "strategy": strategy_name, "path_frac": round((12 * n + 76 * nodes) / dt / (HBM_PEAK_GBS * 1e9), 5),
+            "retries": retries, "steps": steps,
             "first_build_ms": round(first_ms, 3), "first_build_re_runs": int(first_retries)}
 
 
