@@ -121,14 +121,22 @@ int gndt_compute_cost(gndt_handle* h, const float goal_xyz[3], const gndt_robot*
     //  200 m open site with layers of thousands, profiles/r04_cost_map.json: the workgroup keeps the layers of up to kWgNarrow slopes.)
     constexpr uint32_t kWgNarrow = 320;
     const bool wg = env_int("GNDT_COST_WG", 1) != 0;
+    // maps of up to kCostLdsRows rows: the one-workgroup kernel keeps h in LDS (144 KB of dynamic LDS have to be asked for once)
+    static const bool lds_h_granted = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cost_flood_wg<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                          (int)(kCostLdsRows * 4u)) == hipSuccess;
+    if (!lds_h_granted) (void)hipGetLastError();
+    const bool lds_h = lds_h_granted && n <= kCostLdsRows;
     bool narrow = true, first_batch = true;
     uint32_t launched = 0;                                   // one-layer launches enqueued so far
     uint32_t blocks = kCostBlocks;                           // wavefronts of a one-layer launch (16 slopes at a time each): twice the last
                                                              //   layer seen, so that a wide layer is one pass
     for (;;) {
-        if (wg)
-            hipLaunchKernelGGL(k_cost_flood_wg, dim3(1), dim3(kWgThreads), 0, s, V, R, c.h_bits, c.state, c.f[0], c.f[1], c.d_cc, kWgNarrow, 1u << 20,
-                               launched);
+        if (wg && lds_h)
+            hipLaunchKernelGGL(k_cost_flood_wg<true>, dim3(1), dim3(kWgThreads), (size_t)n * 4, s, V, R, c.h_bits, c.state, c.f[0], c.f[1], c.d_cc, kWgNarrow,
+                               1u << 20, launched, (uint32_t)n);
+        else if (wg)
+            hipLaunchKernelGGL(k_cost_flood_wg<false>, dim3(1), dim3(kWgThreads), 0, s, V, R, c.h_bits, c.state, c.f[0], c.f[1], c.d_cc, kWgNarrow,
+                               1u << 20, launched, (uint32_t)n);
         // (a flood the one-workgroup kernel walks to its end — bridge_ground, the site — pays 4.6 us for every one-layer launch behind
         //  it that finds nothing to do: two behind the first kernel, eight once a layer has been too wide for it)
         for (int b = 0, nb = !wg ? kCostBatch : first_batch ? 2 : narrow ? 8 : kCostBatch; b < nb; ++b, ++launched)

@@ -564,9 +564,20 @@ struct LayerStats { uint32_t trav, closed, checks; };
 #define GNDT_COST_STAMP(k) do { } while (0)
 #endif
 
+// atomic min on h: in global memory, or (LDSH) on the one-workgroup kernel's copy of h in LDS
+template <bool LDSH>
+__device__ __forceinline__ uint32_t cost_h_min(uint32_t* p, uint32_t v) {
+    if constexpr (LDSH)
+        return __hip_atomic_fetch_min((__attribute__((address_space(3))) uint32_t*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    else
+        return atomicMin(p, v);
+}
+
 // f_in: the layer's slopes (WG: in LDS).  f_out: the next layer's, in global memory — and, WG, its first f_lds_cap entries in LDS
 // as well (f_out_lds), where the workgroup's next layer reads them.
-template <bool WG>
+// LDSH (WG only): h_bits is the workgroup's copy of h in LDS (maps of up to kCostLdsRows rows): the minima are ds_min_rtn — ~130
+// cycles instead of the 1 230-1 560 of a returning global atomic, the longest link of a layer's chain.
+template <bool WG, bool LDSH = false>
 __device__ __forceinline__ void cost_layer(const CostView& V, const Robot& R, uint32_t n_in, uint32_t first, uint32_t stride,
                                            uint32_t* __restrict__ h_bits, uint32_t* __restrict__ state,
                                            const uint32_t* f_in, uint32_t* __restrict__ f_out, uint32_t* f_out_lds, uint32_t f_lds_cap,
@@ -587,7 +598,7 @@ __device__ __forceinline__ void cost_layer(const CostView& V, const Robot& R, ui
         uint4 er = make_uint4(kNoColumn, 0u, 0u, 0u);
         if (live) {
             hit = V.self[2 * (size_t)q + 1];           // CollisionCheck's verdict, found for every slope before the flood
-            hq_bits = WG ? __hip_atomic_load(&h_bits[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : h_bits[q];
+            hq_bits = LDSH ? h_bits[q] : WG ? __hip_atomic_load(&h_bits[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : h_bits[q];
             er = reinterpret_cast<const uint4*>(V.edges)[4 * (size_t)q + dir];
             // (all three in flight together: left alone, the compiler asks for the record only once the verdict is back)
             asm volatile("" : "+v"(hit), "+v"(hq_bits), "+v"(er.x), "+v"(er.y), "+v"(er.z), "+v"(er.w));
@@ -613,8 +624,8 @@ __device__ __forceinline__ void cost_layer(const CostView& V, const Robot& R, ui
                     // (a candidate not below the FLT_MAX every h starts from is no improvement, map2D.h:1329)
                     const bool do0 = n > 0u && c0 < kFltMaxBits, do1 = n > 1u && c1 < kFltMaxBits;
                     uint32_t o0 = 0u, o1 = 0u;
-                    if (do0) o0 = atomicMin(&h_bits[t0], c0);
-                    if (do1) o1 = atomicMin(&h_bits[t1], c1);
+                    if (do0) o0 = cost_h_min<LDSH>(&h_bits[t0], c0);
+                    if (do1) o1 = cost_h_min<LDSH>(&h_bits[t1], c1);
                     asm volatile("" : "+v"(o0), "+v"(o1));             // (one wait for both, not one after each)
                     if (do0 && o0 == kUnreachedBits) p0 = t0;          // (the slope's first relaxation queues it)
                     if (do1 && o1 == kUnreachedBits) p1 = t1;
@@ -627,7 +638,7 @@ __device__ __forceinline__ void cost_layer(const CostView& V, const Robot& R, ui
                     st.checks += cost_expand_column(V, R, hq, nq, mq, nc, nc_rows, [&](uint32_t t, float cand) {
                         const uint32_t cb = float_bits(cand);
                         if (cb >= kFltMaxBits) return;
-                        if (atomicMin(&h_bits[t], cb) != kUnreachedBits) return;
+                        if (cost_h_min<LDSH>(&h_bits[t], cb) != kUnreachedBits) return;
                         if (p0 == kNone) p0 = t;
                         else if (p1 == kNone) p1 = t;
                         else {
@@ -659,7 +670,7 @@ __device__ __forceinline__ void cost_layer(const CostView& V, const Robot& R, ui
             }
         }
         // WG: the FLT_MAX of a closed slope must have arrived before another wavefront's atomic min on the same word, one barrier on
-        if (WG && __any(closed_one)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (WG && !LDSH && __any(closed_one)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // (LDSH: the layer's barrier waits for LDS)
         GNDT_COST_STAMP(3);
     }
 }
@@ -706,12 +717,18 @@ static __global__ void __launch_bounds__(64) k_cost_level(CostView V, Robot R, u
 constexpr int kWgThreads = 1024;
 constexpr uint32_t kWgFrontier = 4u * (uint32_t)(kWgThreads / 4);      // four rounds of the workgroup's quads
 
+// LDSH: h of the WHOLE map in LDS for the time of the launch (n_rows <= kCostLdsRows: 144 KB of the CU's 160), read from h_bits at the
+// start and written back at the end — whatever runs behind this kernel on the stream finds h where it always is.
+constexpr uint32_t kCostLdsRows = 36u * 1024u;
+
+template <bool LDSH>
 static __global__ void __launch_bounds__(kWgThreads) k_cost_flood_wg(CostView V, Robot R, uint32_t* __restrict__ h_bits,
                                                               uint32_t* __restrict__ state, uint32_t* f0, uint32_t* f1,
                                                               CostCounters* __restrict__ cc, uint32_t max_frontier, uint32_t max_layers,
-                                                              uint32_t launched) {
+                                                              uint32_t launched, uint32_t n_rows) {
     __shared__ uint32_t s_count[3];
     __shared__ uint32_t s_f[2][kWgFrontier];
+    extern __shared__ uint32_t s_h[];                  // (LDSH: n_rows words)
     uint32_t level = launched + cc->wg_layers;
     uint32_t n_in = cc->frontier[level % 3u];
     max_frontier = min(max_frontier, kWgFrontier);
@@ -720,8 +737,10 @@ static __global__ void __launch_bounds__(kWgThreads) k_cost_flood_wg(CostView V,
         const uint32_t* f_first = (level & 1u) ? f1 : f0;
         for (uint32_t j = threadIdx.x; j < n_in; j += blockDim.x) s_f[level & 1u][j] = f_first[j];
         if (threadIdx.x < 3u) s_count[threadIdx.x] = 0u;
+        if constexpr (LDSH) for (uint32_t j = threadIdx.x; j < n_rows; j += blockDim.x) s_h[j] = h_bits[j];
     }
     __syncthreads();
+    uint32_t* const h_live = LDSH ? s_h : h_bits;
     LayerStats st{};
 #if defined(GNDT_COST_STAMPS)
     st.last = clock64();
@@ -729,8 +748,8 @@ static __global__ void __launch_bounds__(kWgThreads) k_cost_flood_wg(CostView V,
     uint32_t done = 0;
     for (; done < max_layers && n_in != 0u && n_in <= max_frontier; ++done) {
         if (threadIdx.x == 0) s_count[(level + 2u) % 3u] = 0u;        // (the layer after next's; nobody looks at it during this layer)
-        cost_layer<true>(V, R, n_in, (threadIdx.x >> 6) * 16u, (uint32_t)kWgThreads / 4u, h_bits, state, s_f[level & 1u], (level & 1u) ? f0 : f1,
-                         s_f[(level + 1u) & 1u], kWgFrontier, &s_count[(level + 1u) % 3u], st);
+        cost_layer<true, LDSH>(V, R, n_in, (threadIdx.x >> 6) * 16u, (uint32_t)kWgThreads / 4u, h_live, state, s_f[level & 1u], (level & 1u) ? f0 : f1,
+                               s_f[(level + 1u) & 1u], kWgFrontier, &s_count[(level + 1u) % 3u], st);
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // (LDS only: the frontier's global copy is for later kernels)
         ++level;
         n_in = s_count[level % 3u];
@@ -739,6 +758,7 @@ static __global__ void __launch_bounds__(kWgThreads) k_cost_flood_wg(CostView V,
 #if defined(GNDT_COST_STAMPS)
     if (threadIdx.x == 0) { for (int k = 0; k < 5; ++k) cc->phase[k] += st.ph[k]; cc->phase[5] += done; }
 #endif
+    if constexpr (LDSH) for (uint32_t j = threadIdx.x; j < n_rows; j += blockDim.x) h_bits[j] = s_h[j];
     cost_flush_stats(st, cc);
     if (threadIdx.x == 0) {
         cc->wg_layers = level - launched;
