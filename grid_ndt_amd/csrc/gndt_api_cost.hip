@@ -133,10 +133,10 @@ int gndt_compute_cost(gndt_handle* h, const float goal_xyz[3], const gndt_robot*
     for (;;) {
         if (wg && lds_h)
             hipLaunchKernelGGL(k_cost_flood_wg<true>, dim3(1), dim3(kWgThreads), (size_t)n * 4, s, V, R, c.h_bits, c.state, c.f[0], c.f[1], c.d_cc, kWgNarrow,
-                               1u << 20, launched, (uint32_t)n);
+                               1u << 20, launched, (uint32_t)n, 1);
         else if (wg)
             hipLaunchKernelGGL(k_cost_flood_wg<false>, dim3(1), dim3(kWgThreads), 0, s, V, R, c.h_bits, c.state, c.f[0], c.f[1], c.d_cc, kWgNarrow,
-                               1u << 20, launched, (uint32_t)n);
+                               1u << 20, launched, (uint32_t)n, 0);
         // (a flood the one-workgroup kernel walks to its end — bridge_ground, the site — pays 4.6 us for every one-layer launch behind
         //  it that finds nothing to do: two behind the first kernel, eight once a layer has been too wide for it)
         for (int b = 0, nb = !wg ? kCostBatch : first_batch ? 2 : narrow ? 8 : kCostBatch; b < nb; ++b, ++launched)

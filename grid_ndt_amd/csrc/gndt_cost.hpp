@@ -581,10 +581,20 @@ template <bool WG, bool LDSH = false>
 __device__ __forceinline__ void cost_layer(const CostView& V, const Robot& R, uint32_t n_in, uint32_t first, uint32_t stride,
                                            uint32_t* __restrict__ h_bits, uint32_t* __restrict__ state,
                                            const uint32_t* f_in, uint32_t* __restrict__ f_out, uint32_t* f_out_lds, uint32_t f_lds_cap,
-                                           uint32_t* out_count, LayerStats& st) {
+                                           uint32_t* out_count, LayerStats& st, uint32_t* dump = nullptr) {
     const int lane = (int)(threadIdx.x & 63u);
     const uint32_t dir = threadIdx.x & 3u;
     constexpr uint32_t kNone = 0xFFFFFFFFu;
+    // dump (LDSH): 64 words of LDS nobody reads.  A word of the record and of the verdict of every slope a lane queues is requested
+    // into it (LDS-DMA: no register waits for the data), so that the lines are on their way to the CU when the next layer asks.
+    auto touch = [&](uint32_t t) {
+        if constexpr (LDSH) {
+            if (dump) {
+                __builtin_amdgcn_global_load_lds(reinterpret_cast<const uint32_t*>(V.edges) + 16 * (size_t)t, (__attribute__((address_space(3))) uint32_t*)dump, 4, 0, 0);
+                __builtin_amdgcn_global_load_lds(V.self + 2 * (size_t)t + 1, (__attribute__((address_space(3))) uint32_t*)dump, 4, 0, 0);
+            }
+        }
+    };
     // The loop is wave-uniform (a wave's quads take 16 consecutive slopes of the layer, lanes past the end sit idle), so that the
     // slopes a wave pushes are appended with ONE atomic on the layer's counter: the counter is one word, same-address atomics
     // retire at ~90 per microsecond at the memory side, and a layer of a few hundred slopes used to add one per pushed slope
@@ -662,11 +672,13 @@ __device__ __forceinline__ void cost_layer(const CostView& V, const Robot& R, ui
                 const uint32_t pos = base + (uint32_t)__popcll(b0 & below);
                 f_out[pos] = p0;
                 if (WG && pos < f_lds_cap) f_out_lds[pos] = p0;
+                touch(p0);
             }
             if (p1 != kNone) {
                 const uint32_t pos = base + n0 + (uint32_t)__popcll(b1 & below);
                 f_out[pos] = p1;
                 if (WG && pos < f_lds_cap) f_out_lds[pos] = p1;
+                touch(p1);
             }
         }
         // WG: the FLT_MAX of a closed slope must have arrived before another wavefront's atomic min on the same word, one barrier on
@@ -725,8 +737,9 @@ template <bool LDSH>
 static __global__ void __launch_bounds__(kWgThreads) k_cost_flood_wg(CostView V, Robot R, uint32_t* __restrict__ h_bits,
                                                               uint32_t* __restrict__ state, uint32_t* f0, uint32_t* f1,
                                                               CostCounters* __restrict__ cc, uint32_t max_frontier, uint32_t max_layers,
-                                                              uint32_t launched, uint32_t n_rows) {
+                                                              uint32_t launched, uint32_t n_rows, int prefetch) {
     __shared__ uint32_t s_count[3];
+    __shared__ uint32_t s_dump[64];
     __shared__ uint32_t s_f[2][kWgFrontier];
     extern __shared__ uint32_t s_h[];                  // (LDSH: n_rows words)
     uint32_t level = launched + cc->wg_layers;
@@ -749,7 +762,7 @@ static __global__ void __launch_bounds__(kWgThreads) k_cost_flood_wg(CostView V,
     for (; done < max_layers && n_in != 0u && n_in <= max_frontier; ++done) {
         if (threadIdx.x == 0) s_count[(level + 2u) % 3u] = 0u;        // (the layer after next's; nobody looks at it during this layer)
         cost_layer<true, LDSH>(V, R, n_in, (threadIdx.x >> 6) * 16u, (uint32_t)kWgThreads / 4u, h_live, state, s_f[level & 1u], (level & 1u) ? f0 : f1,
-                               s_f[(level + 1u) & 1u], kWgFrontier, &s_count[(level + 1u) % 3u], st);
+                               s_f[(level + 1u) & 1u], kWgFrontier, &s_count[(level + 1u) % 3u], st, prefetch ? s_dump : nullptr);
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // (LDS only: the frontier's global copy is for later kernels)
         ++level;
         n_in = s_count[level % 3u];
