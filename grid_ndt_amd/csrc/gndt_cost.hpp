@@ -133,10 +133,9 @@ GNDT_HD bool row_has_slope(const CostView& V, uint32_t row) { return (V.flags[ro
 GNDT_HD uint32_t row_column(const CostView& V, uint32_t row) { return V.self ? V.self[2 * (size_t)row] : ctab_find(V, V.sx[row], V.sy[row]); }
 
 // Is the next slope above `row` in its cell in the robot's way?  (CollisionCheck's last test, map2D.h:394-410 / :457-473.)
-GNDT_HD bool row_above_hits(const CostView& V, const Robot& R, uint32_t row) {
+// c: the first row of the row's own column (kNoColumn: none).
+GNDT_HD bool row_above_hits_in(const CostView& V, const Robot& R, uint32_t row, uint32_t c) {
     GNDT_FP_STRICT
-    if (V.self) return V.self[2 * (size_t)row + 1] != 0u;
-    const uint32_t c = ctab_find(V, V.sx[row], V.sy[row]);
     if (c == kNoColumn) return false;
     const uint32_t e = c + V.row_ncol[c];
     const int myz = V.sz[row];
@@ -150,13 +149,16 @@ GNDT_HD bool row_above_hits(const CostView& V, const Robot& R, uint32_t row) {
     const float mz = V.mean[3 * row + 2], nz = V.mean[3 * next + 2];
     return (nz < mz + 2.f * R.r) && (nz - mz > R.reach);
 }
+GNDT_HD bool row_above_hits(const CostView& V, const Robot& R, uint32_t row) {
+    if (V.self) return V.self[2 * (size_t)row + 1] != 0u;
+    return row_above_hits_in(V, R, row, ctab_find(V, V.sx[row], V.sy[row]));
+}
 
 // Slope::countUp (map2D.h:147-177): a node one level up in the column whose centroid z differs by more than the
 // interval; centroids of nodes without statistics are zero.  Only demand "true" evaluates it (lazily); with
 // demand "slope" Slope::up is never assigned and stays false (map2D.h:636).
-GNDT_HD bool row_up(const CostView& V, uint32_t row) {
+GNDT_HD bool row_up_in(const CostView& V, uint32_t row, uint32_t c) {
     if (!V.demand_true) return false;
-    const uint32_t c = row_column(V, row);
     if (c == kNoColumn) return false;
     const int zadd = level_above(V.sz[row]);
     const float mz = V.mean[3 * row + 2];
@@ -167,6 +169,10 @@ GNDT_HD bool row_up(const CostView& V, uint32_t row) {
         if (fabsf(cz - mz) > V.slope_interval) return true;
     }
     return false;
+}
+GNDT_HD bool row_up(const CostView& V, uint32_t row) {
+    if (!V.demand_true) return false;
+    return row_up_in(V, row, row_column(V, row));
 }
 
 // the three gates of countReachable (map2D.h:271-274): roughness, angle between normals, height difference
@@ -288,10 +294,15 @@ GNDT_HD uint32_t cost_expand(const CostView& V, const Robot& R, uint32_t q, floa
 
 // The record of slope q's k-th neighbour cell (c, ncol: neighbour_column): the same loop as cost_expand_column, with the relaxation
 // left for the flood.
-GNDT_HD CostEdge cost_edge_record(const CostView& V, const Robot& R, uint32_t q, uint32_t c, uint32_t ncol) {
+// STEPS (floods with collision rings): also the ring's steps of q into the cell (ring_step_mask below: bit j = row c + j for the first
+// kStepRows rows) from the same walk — the ring asks the same three gates (comand 2.5) or takes every slope (comand 3).
+struct CostEdgeAndSteps { CostEdge e; uint32_t steps; };
+template <bool STEPS>
+GNDT_HD CostEdgeAndSteps cost_edge_walk(const CostView& V, const Robot& R, uint32_t q, uint32_t c, uint32_t ncol) {
     GNDT_FP_STRICT
     CostEdge e{c, 0u, 0.f, 0.f};
-    if (c == kNoColumn) return e;
+    uint32_t steps = 0u;
+    if (c == kNoColumn) return CostEdgeAndSteps{e, steps};
     const float* nq = V.normal + 3 * (size_t)q;
     const float* mq = V.mean + 3 * (size_t)q;
     uint32_t checks = 0, np = 0, j0 = 0, j1 = 0;
@@ -300,9 +311,11 @@ GNDT_HD CostEdge cost_edge_record(const CostView& V, const Robot& R, uint32_t q,
         const uint32_t t = c + j;
         if (!(V.flags[t] & 2u)) continue;
         ++checks;
+        if (STEPS && V.demand_true && j < 32u) steps |= 1u << j;
         if (!(V.rough[t] <= R.rough)) continue;
         if (!(cost_angle(V.normal + 3 * (size_t)t, nq) <= R.angle)) continue;
         if (!(fabsf(V.mean[3 * (size_t)t + 2] - mq[2]) <= R.reach)) continue;
+        if (STEPS && !V.demand_true && j < 32u) steps |= 1u << j;
         const float d = cost_travel(mq, V.mean + 3 * (size_t)t);
         if (np == 0u && j < 256u) { j0 = j; e.d0 = d; }
         else if (np == 1u && j < 256u) { j1 = j; e.d1 = d; }
@@ -311,7 +324,10 @@ GNDT_HD CostEdge cost_edge_record(const CostView& V, const Robot& R, uint32_t q,
     }
     if (checks > 4095u) more = true;
     e.info = more ? kEdgeMore : (j0 | (j1 << 8) | (np << 16) | (checks << 20));
-    return e;
+    return CostEdgeAndSteps{e, steps};
+}
+GNDT_HD CostEdge cost_edge_record(const CostView& V, const Robot& R, uint32_t q, uint32_t c, uint32_t ncol) {
+    return cost_edge_walk<false>(V, R, q, c, ncol).e;
 }
 
 // Expansion towards one neighbour cell from its record (the record must not carry kEdgeMore): relax(row, candidate h) as
@@ -482,15 +498,20 @@ static __global__ void __launch_bounds__(256) k_cost_neighbours(CostView V, Robo
         nbr[2 * (size_t)t] = c;
         nbr[2 * (size_t)t + 1] = ncol;
         const bool slope = row_has_slope(V, row);
-        if (ring_n > 0) step[t] = slope ? ring_step_mask(V, R, row, c, ncol) : 0u;
-        if (slope) {
-            const CostEdge e = cost_edge_record(V, R, row, c, ncol);
-            reinterpret_cast<uint4*>(edges)[t] = make_uint4(e.c, e.info, float_bits(e.d0), float_bits(e.d1));
+        uint32_t mask = 0u;
+        if (slope) {                                       // (one walk over the cell's rows for the record and the ring's steps)
+            const CostEdgeAndSteps w = ring_n > 0 ? cost_edge_walk<true>(V, R, row, c, ncol) : cost_edge_walk<false>(V, R, row, c, ncol);
+            mask = w.steps;
+            reinterpret_cast<uint4*>(edges)[t] = make_uint4(w.e.c, w.e.info, float_bits(w.e.d0), float_bits(w.e.d1));
         }
+        if (ring_n > 0) step[t] = mask;
         if (k == 0u) {
-            self[2 * (size_t)row] = ctab_find(V, V.sx[row], V.sy[row]);
-            const bool up = slope && row_up(V, row);
-            self[2 * (size_t)row + 1] = slope && ring_free_verdict(V, R, row, up) ? 1u : 0u;
+            // the row's own column without the hash table: a column's rows are adjacent and its first row is the one that names its size
+            uint32_t c_self = row;
+            while (V.row_ncol[c_self] == 0u && c_self > 0u) --c_self;
+            self[2 * (size_t)row] = c_self;
+            const bool up = slope && row_up_in(V, row, c_self);
+            self[2 * (size_t)row + 1] = slope && (up || row_above_hits_in(V, R, row, c_self)) ? 1u : 0u;
             if (ring_n > 0 && slope) {
                 float hi, lo;
                 ring_round0(V, row, up, hi, lo);
