@@ -52,3 +52,37 @@ def test_product_does_not_import_oracle():
                     if re.search(r"(from|import)\s+oracle|liboracle|ref_cpu", t):
                         bad.append(os.path.join(dp, f))
     assert not bad, bad
+
+
+def test_graph_capture_pauses_the_cycle_collector_and_gives_it_back(monkeypatch):
+    """grid_ndt_amd.graph_capture = torch.cuda.graph with Python's cycle collector paused: a collection that starts inside a capture
+    can run another object's destructor (a handle's gndt_destroy, a tensor's free), which invalidates the capture and makes torch
+    abort the process.  No GPU here: torch.cuda.graph is replaced by a recorder."""
+    import contextlib
+    import gc
+    import torch
+    import grid_ndt_amd as g
+    seen = {}
+
+    @contextlib.contextmanager
+    def fake_graph(graph, stream=None):
+        seen["enter"] = (graph, stream, gc.isenabled())
+        yield
+        seen["exit"] = gc.isenabled()
+
+    monkeypatch.setattr(torch.cuda, "graph", fake_graph)
+    assert gc.isenabled()
+    with g.graph_capture("G", "S"):
+        assert not gc.isenabled()
+    assert seen["enter"] == ("G", "S", False) and seen["exit"] is False and gc.isenabled()
+    with pytest.raises(RuntimeError):
+        with g.graph_capture("G"):
+            raise RuntimeError("a refused capture")
+    assert seen["enter"] == ("G", None, False) and gc.isenabled()
+    gc.disable()
+    try:
+        with g.graph_capture("G"):
+            pass
+        assert not gc.isenabled()          # (a caller that had it off keeps it off)
+    finally:
+        gc.enable()
