@@ -1,4 +1,6 @@
 // gndt_api_cost.hip — cost-map flood (TwoDmap::computeCost, include/map2D.h:1285-1397) over the finished grid.
+#include <atomic>
+
 #include "gndt_handle.hpp"
 
 using namespace gndt;
@@ -121,10 +123,20 @@ int gndt_compute_cost(gndt_handle* h, const float goal_xyz[3], const gndt_robot*
     //  200 m open site with layers of thousands, profiles/r04_cost_map.json: the workgroup keeps the layers of up to kWgNarrow slopes.)
     constexpr uint32_t kWgNarrow = 320;
     const bool wg = env_int("GNDT_COST_WG", 1) != 0;
-    // maps of up to kCostLdsRows rows: the one-workgroup kernel keeps h in LDS (144 KB of dynamic LDS have to be asked for once)
-    static const bool lds_h_granted = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cost_flood_wg<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                          (int)(kCostLdsRows * 4u)) == hipSuccess;
-    if (!lds_h_granted) (void)hipGetLastError();
+    // maps of up to kCostLdsRows rows: the one-workgroup kernel keeps h in LDS (144 KB of dynamic LDS have to be asked for once per
+    // device: the attribute belongs to the function ON the current device, which check_ready has made the handle's)
+    static std::atomic<int> lds_h_state[64];              // per device: 0 not asked yet, 1 granted, 2 refused
+    bool lds_h_granted = false;
+    if (h->device >= 0 && h->device < 64) {
+        int st = lds_h_state[h->device].load(std::memory_order_acquire);
+        if (st == 0) {
+            st = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cost_flood_wg<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)(kCostLdsRows * 4u)) == hipSuccess ? 1 : 2;
+            if (st == 2) (void)hipGetLastError();
+            lds_h_state[h->device].store(st, std::memory_order_release);
+        }
+        lds_h_granted = st == 1;
+    }
     const bool lds_h = lds_h_granted && n <= kCostLdsRows;
     bool narrow = true, first_batch = true;
     uint32_t launched = 0;                                   // one-layer launches enqueued so far
