@@ -169,14 +169,25 @@ extern "C" int shim_collide_all(uint64_t n, const int32_t* sx, const int32_t* sy
     std::vector<uint32_t> nc(4 * n), nr(4 * n), step(4 * n, 0u);
     std::vector<float> hi[2] = {std::vector<float>(n, 0.f), std::vector<float>(n, 0.f)}, lo[2] = {std::vector<float>(n, 0.f), std::vector<float>(n, 0.f)};
     std::vector<uint8_t> verdict(n, 0);
+    std::vector<uint8_t> differs(n, 0);      // the kernel's shortcuts against the plain statements (a slope where they differ reads 3 below)
     for (uint64_t q = 0; q < n; ++q) {
         const bool slope = row_has_slope(V, (uint32_t)q);
         for (uint32_t k = 0; k < 4; ++k) {
             neighbour_column(V, (uint32_t)q, k, nc[4 * q + k], nr[4 * q + k]);
-            if (ring_n > 0 && slope) step[4 * q + k] = ring_step_mask(V, R, (uint32_t)q, nc[4 * q + k], nr[4 * q + k]);
+            if (ring_n > 0 && slope) {
+                // k_cost_neighbours: the ring's steps come out of the walk that makes the CostEdge record
+                step[4 * q + k] = cost_edge_walk<true>(V, R, (uint32_t)q, nc[4 * q + k], nr[4 * q + k]).steps;
+                if (step[4 * q + k] != ring_step_mask(V, R, (uint32_t)q, nc[4 * q + k], nr[4 * q + k])) differs[q] = 1;
+            }
         }
-        const bool up = slope && row_up(V, (uint32_t)q);
-        verdict[q] = slope && ring_free_verdict(V, R, (uint32_t)q, up) ? 1 : 0;
+        // k_cost_neighbours: the row's own column by walking back to the row that names the column's size, not through the hash table
+        uint32_t c_self = (uint32_t)q;
+        while (row_ncol[c_self] == 0u && c_self > 0u) --c_self;
+        if (c_self != ctab_find(V, sx[q], sy[q])) differs[q] = 1;
+        const bool up = slope && row_up_in(V, (uint32_t)q, c_self);
+        if (up != (slope && row_up(V, (uint32_t)q))) differs[q] = 1;
+        verdict[q] = slope && (up || row_above_hits_in(V, R, (uint32_t)q, c_self)) ? 1 : 0;
+        if (verdict[q] != (slope && ring_free_verdict(V, R, (uint32_t)q, up) ? 1 : 0)) differs[q] = 1;
         if (ring_n > 0 && slope) ring_round0(V, (uint32_t)q, up, hi[0][q], lo[0][q]);
     }
     for (int d = 0; d < ring_n; ++d) {
@@ -190,6 +201,6 @@ extern "C" int shim_collide_all(uint64_t n, const int32_t* sx, const int32_t* sy
             if (d == ring_n - 1 && ring_verdict(V, R, (uint32_t)q, h, l)) verdict[q] = 1;
         }
     }
-    for (uint64_t q = 0; q < n; ++q) rounds[q] = row_has_slope(V, (uint32_t)q) ? verdict[q] : 255;
+    for (uint64_t q = 0; q < n; ++q) rounds[q] = differs[q] ? 3 : row_has_slope(V, (uint32_t)q) ? verdict[q] : 255;
     return ring_n;
 }
