@@ -20,20 +20,52 @@ def golden_rows():
 
 
 def test_golden_file_has_header_example():
-    assert (5, 7, 55, 5, 7) in golden_rows()   # Stopwatch.h:112-115, 166-170
+    rows = golden_rows()
+    assert (5, 7, 55, 5, 7) in rows   # Stopwatch.h:112-115, 166-170
+    # >= 1 000 rows — every pair of 1..64, powers of two +- 1, the 32 767 / 32 768 / 65 535 / 65 536 edges
+    assert len(rows) >= 1000
+    have = {(a, b) for a, b, _, _, _ in rows}
+    assert all((a, b) in have for a in range(1, 65) for b in range(1, 65))
+    assert all((v, v) in have and (v, 1) in have and (1, v) in have for v in (32767, 32768, 65535, 65536, 1023, 1025, 4097))
 
 
-@pytest.mark.parametrize("a,b,m,da,db", golden_rows())
+def test_golden_file_regenerates(tmp_path):
+    """The fixture is the output of tools/make_morton_golden.sh (the reference's Stopwatch.h compiled where it lies).  Where the
+    reference exists (the build container, never the GPU box) the recipe is re-run and must reproduce the committed file byte
+    for byte; elsewhere only the committed CSV is used."""
+    import subprocess
+    ref = os.environ.get("GNDT_REFERENCE", "/root/reference")
+    if not os.path.exists(os.path.join(ref, "include", "Stopwatch.h")):
+        pytest.skip("no reference tree here: the committed fixture is the pin")
+    out = tmp_path / "regen.csv"
+    script = os.path.join(os.path.dirname(os.path.dirname(__file__)), "tools", "make_morton_golden.sh")
+    subprocess.run(["bash", script, str(out)], check=True, capture_output=True, timeout=120)
+    assert out.read_bytes() == open(GOLD, "rb").read()
+
+
+# the rows SURVEY Appendix B lists, one test each (readable failures); the whole table in one loop below
+@pytest.mark.parametrize("a,b,m,da,db", golden_rows()[:29])
 def test_oracle_count_morton_golden(a, b, m, da, db):
     assert oracle.count_morton(a, b) == str(m)
     assert oracle.morton_to_xy(m) == (da, db)
 
 
-@pytest.mark.parametrize("a,b,m,da,db", golden_rows())
+@pytest.mark.parametrize("a,b,m,da,db", golden_rows()[:29])
 def test_gndt_codec_golden(native_lib, a, b, m, da, db):
     import grid_ndt_amd as g
     assert g.count_morton(a, b) == str(m)
     assert g.morton_to_xy(m) == (da, db)
+
+
+def test_oracle_count_morton_golden_all_rows():
+    bad = [(a, b) for a, b, m, da, db in golden_rows() if oracle.count_morton(a, b) != str(m) or oracle.morton_to_xy(m) != (da, db)]
+    assert not bad, bad[:10]
+
+
+def test_gndt_codec_golden_all_rows(native_lib):
+    import grid_ndt_amd as g
+    bad = [(a, b) for a, b, m, da, db in golden_rows() if g.count_morton(a, b) != str(m) or g.morton_to_xy(m) != (da, db)]
+    assert not bad, bad[:10]
 
 
 def test_codec_matches_oracle_exhaustive_small(native_lib):
