@@ -785,6 +785,7 @@ int gndt_debug_second_pass_buckets(gndt_handle* h, uint64_t* buckets) {
 }
 
 int gndt_debug_enable_stamps(int on) { tuning_force_stamps(on != 0); return GNDT_OK; }
+int gndt_debug_set_option(int option, double value) { return tuning_set_option(option, value); }
 
 int gndt_debug_set_fp_bits(int bits) { tuning_force_fp_bits(bits); return GNDT_OK; }
 
@@ -797,7 +798,7 @@ int gndt_debug_fp_clashes(gndt_handle* h, uint64_t* buckets) {
 int gndt_debug_bucket_phases(gndt_handle* h, double cycles_out[10], uint32_t* buckets_out) {
     if (!h || !cycles_out) return GNDT_ERR_INVALID;
     auto& q = h->part;
-    if (!q.dbg || !q.last_buckets) { h->err = "no stamps: set GNDT_STAMPS=1 (or call gndt_debug_enable_stamps) before a PARTITION build"; return GNDT_ERR_INVALID; }
+    if (!q.dbg || !q.last_buckets) { h->err = "no stamps: call gndt_debug_enable_stamps(1) before a PARTITION build"; return GNDT_ERR_INVALID; }
     HIP_TRY(h, hipSetDevice(h->device));
     HIP_TRY(h, hipStreamSynchronize(h->last_stream));
     std::vector<unsigned long long> t((size_t)q.last_buckets * 16);

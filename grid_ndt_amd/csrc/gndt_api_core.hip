@@ -12,21 +12,23 @@ namespace gndt_host {
 
 const Tuning& tuning_mut_ref();
 namespace {
-Tuning parse_tuning() {
-    // (Round 5: twelve knobs that had lost — or never had — an A/B are constants of gndt_host::Tuning now: table loads, points per
-    //  bucket, table slots, the partition levels, workgroup counts, owner locality, record interleaving, the node sketch, the bucket
-    //  kernel's second pass.  What is left is read once per process: two diagnostics and the one threshold a tool calibrates.)
-    Tuning t;
-    if (getenv("GNDT_TILE_RATIO")) t.tile_ratio = atof(getenv("GNDT_TILE_RATIO"));      // tools/calibrate_tile.py
-    t.stamps = getenv("GNDT_STAMPS") != nullptr;
-    t.verbose = getenv("GNDT_VERBOSE") != nullptr;
-    return t;
-}
-Tuning& tuning_storage() { static Tuning t = parse_tuning(); return t; }
+// (Round 5: twelve knobs that had lost — or never had — an A/B became constants of gndt_host::Tuning.  Round 6: the last
+//  environment reads are gone as well; the two diagnostics, AUTO's threshold and the flood's launch mode are set through
+//  gndt_debug_enable_stamps / gndt_debug_set_option, process-wide.)
+Tuning& tuning_storage() { static Tuning t; return t; }
 }  // namespace
 const Tuning& tuning() { return tuning_storage(); }
 void tuning_force_stamps(bool on) { tuning_storage().stamps = on; }
 void tuning_force_fp_bits(int bits) { tuning_storage().fp_bits = std::min(21, std::max(0, bits)); }
+int tuning_set_option(int option, double value) {
+    Tuning& t = tuning_storage();
+    switch (option) {
+        case GNDT_DEBUG_VERBOSE: t.verbose = value != 0.0; return GNDT_OK;
+        case GNDT_DEBUG_TILE_RATIO: if (!(value >= 1.0)) return GNDT_ERR_INVALID; t.tile_ratio = value; return GNDT_OK;
+        case GNDT_DEBUG_COST_ONE_WORKGROUP: t.cost_one_workgroup = value != 0.0; return GNDT_OK;
+        default: return GNDT_ERR_INVALID;
+    }
+}
 
 int ensure_out(gndt_handle* h, uint64_t n) {
     if (n <= h->out_cap) return GNDT_OK;

@@ -17,12 +17,6 @@ void free_cost(gndt_handle* h) {
     c = gndt_handle::Cost{};
 }
 
-
-static int env_int(const char* name, int otherwise) {
-    const char* v = std::getenv(name);
-    return v ? std::atoi(v) : otherwise;
-}
-
 }  // namespace gndt_host
 
 extern "C" {
@@ -118,11 +112,11 @@ int gndt_compute_cost(gndt_handle* h, const float goal_xyz[3], const gndt_robot*
     // (any width; no-ops once the flood has ended) — 8 while the layers are narrow, 32 when the last answer showed a wide one
     // (batches growing to 128 while the layers stay wide were measured on the 807-layer open site: no gain).  How many layers the
     // one-workgroup kernel walked is only known on the device (cc->wg_layers); the host asks after every batch whether the flood
-    // has ended.  GNDT_COST_WG=0: one-layer launches only.
+    // has ended.  gndt_debug_set_option(GNDT_DEBUG_COST_ONE_WORKGROUP, 0): one-layer launches only.
     // (One workgroup takes ~5.6 us + 8 ns per slope for a layer, a one-layer launch 8-10 us whatever the width — site, terrain and a
     //  200 m open site with layers of thousands, profiles/r04_cost_map.json: the workgroup keeps the layers of up to kWgNarrow slopes.)
     constexpr uint32_t kWgNarrow = 320;
-    const bool wg = env_int("GNDT_COST_WG", 1) != 0;
+    const bool wg = tuning().cost_one_workgroup;
     // maps of up to kCostLdsRows rows: the one-workgroup kernel keeps h in LDS (144 KB of dynamic LDS have to be asked for once per
     // device: the attribute belongs to the function ON the current device, which check_ready has made the handle's)
     static std::atomic<int> lds_h_state[64];              // per device: 0 not asked yet, 1 granted, 2 refused

@@ -150,7 +150,7 @@ struct gndt_handle {
                                             *ncol_at = nullptr;
         PartCounters* d_pc = nullptr;
         PartCounters* h_pc = nullptr;   // pinned
-        unsigned long long* dbg = nullptr;  uint32_t dbg_buckets = 0;   // diagnostic phase stamps (GNDT_STAMPS=1)
+        unsigned long long* dbg = nullptr;  uint32_t dbg_buckets = 0;   // diagnostic phase stamps (gndt_debug_enable_stamps)
         uint32_t last_buckets = 0;
         uint64_t nodes_learned = 0;   // node count of the last successful PARTITION build (+20 %)
         int good_slots = 0; uint64_t good_est = 0, good_n = 0;   // table size / estimate that worked last time
@@ -294,15 +294,17 @@ struct Tuning {
     int small_tiles = 1;         // one-level partition of < 1 M points: 1024-point level-1 tiles (a few hundred workgroups instead of a few dozen:
                                  //   campus frame 0.0535 -> 0.0520 ms, bridge_ground 0.0648 -> 0.0608; r05 ablation 6i)
     int fp_bits = 21;            // bits of the bucket kernel's index fingerprint (tests narrow it through gndt_debug_set_fp_bits to force clashes)
-    // ... and what the environment can set (parsed ONCE per process)
-    double tile_ratio = 48.0;    // GNDT_TILE_RATIO     AUTO takes strategy TILE from this many points per partial on (sampled; the
-                                 //                     measured crossover, profiles/r02_tile_calibration.json; tools/calibrate_tile.py sweeps it)
-    bool stamps = false;         // GNDT_STAMPS=1       in-kernel phase stamps of the bucket kernel
-    bool verbose = false;        // GNDT_VERBOSE=1      stderr line per resolved two-level build
+    // ... and what gndt_debug_set_option / gndt_debug_enable_stamps can set (process-wide; the library reads no environment variable)
+    double tile_ratio = 48.0;    // GNDT_DEBUG_TILE_RATIO   AUTO takes strategy TILE from this many points per partial on (sampled; the
+                                 //                         measured crossover, profiles/r02_tile_calibration.json; tools/calibrate_tile.py sweeps it)
+    bool stamps = false;         // gndt_debug_enable_stamps: in-kernel phase stamps of the bucket kernel
+    bool verbose = false;        // GNDT_DEBUG_VERBOSE      stderr line per resolved two-level build
+    bool cost_one_workgroup = true;   // GNDT_DEBUG_COST_ONE_WORKGROUP   0: every layer of the flood its own launch
 };
 const Tuning& tuning();
 void tuning_force_stamps(bool on);   // bench.py --stamps flips this after the timed run
 void tuning_force_fp_bits(int bits); // tests: narrow the fingerprint so that clashes happen
+int tuning_set_option(int option, double value);
 
 #define HIP_TRY(h, expr)                                                                                 \
     do {                                                                                                 \

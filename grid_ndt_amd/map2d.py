@@ -483,6 +483,15 @@ class TwoDmap:
         self._ensure(demand)
         self._check(self._L.gndt_set_deferred_emit(self._h, int(bool(on))))
 
+    DEBUG_VERBOSE, DEBUG_TILE_RATIO, DEBUG_COST_ONE_WORKGROUP = 1, 2, 3
+
+    @staticmethod
+    def set_debug_option(option, value):
+        """gndt_debug_set_option: process-wide diagnostics and thresholds (the library reads no environment variable)."""
+        rc = _lib.lib().gndt_debug_set_option(int(option), float(value))
+        if rc:
+            raise _lib.GndtError(rc, f"gndt_debug_set_option({option}, {value})")
+
     def set_fp_bits(self, bits):
         """Narrow the bucket kernel's index fingerprint (process-wide; tests: forces its exact second pass)."""
         self._L.gndt_debug_set_fp_bits(int(bits))
@@ -493,7 +502,7 @@ class TwoDmap:
         return int(r.value)
 
     def debug_bucket_phases(self):
-        """Mean shader cycles per bucket of k_bucket_build's phases (needs GNDT_STAMPS=1 in the environment)."""
+        """Mean shader cycles per bucket of k_bucket_build's phases (after enable_stamps())."""
         arr = (C.c_double * 10)()
         nb = C.c_uint32()
         self._check(self._L.gndt_debug_bucket_phases(self._h, arr, C.byref(nb)))

@@ -440,7 +440,7 @@ int gndt_get_phase_times(gndt_handle* h, double ms_out[GNDT_NUM_PHASES]);
 int gndt_locality_sample(gndt_handle* h, const void* xyz_dev, size_t n, size_t stride_bytes, uint32_t tiles, double* points_per_partial,
                          void* hip_stream);
 int gndt_last_strategy(const gndt_handle* h);
-/* Diagnostic (not for timed runs): with the environment variable GNDT_STAMPS=1 set, k_bucket_build
+/* Diagnostic (not for timed runs): after gndt_debug_enable_stamps(1) the bucket kernel
  * stamps the shader clock at its phase boundaries; this returns the mean cycles per bucket of
  * [0] clear [1] accumulate [2] columns [3] labels [4] order [5] emit, then the accumulate phase split into
  * [6] load wait [7] classify [8] scan+scatter [9] reduce (first chunk), and the bucket count. */
@@ -449,8 +449,20 @@ int gndt_debug_bucket_phases(gndt_handle* h, double cycles_out[10], uint32_t* bu
  * too small (each is a whole extra build).  A build is launched without waiting and its flags are only looked at by the call
  * that needs the result: a benchmark that enqueues builds back to back should check that this does not move. */
 int gndt_debug_retry_count(gndt_handle* h, uint64_t* retries);
-/* Switch the stamps on or off for the builds that follow (the environment is only read once per process). */
+/* Switch the stamps on or off for the builds that follow (process-wide). */
 int gndt_debug_enable_stamps(int on);
+/* The library reads NO environment variable: what used to be GNDT_VERBOSE / GNDT_TILE_RATIO / GNDT_COST_WG (rounds 1-5) is set
+ * here, process-wide, for the calls that follow.  Returns GNDT_ERR_INVALID for an unknown option or a value out of range.
+ *   GNDT_DEBUG_VERBOSE            value != 0: one stderr line per resolved partition build (fullest region, flags, re-runs, second
+ *                                 pass, node sketch) and per locality sample                                        default 0
+ *   GNDT_DEBUG_TILE_RATIO         points per partial from which strategy AUTO takes TILE (tools/calibrate_tile.py sweeps it);
+ *                                 value >= 1                                                                        default 48
+ *   GNDT_DEBUG_COST_ONE_WORKGROUP value == 0: gndt_compute_cost launches every layer on its own, the one-workgroup kernel that walks
+ *                                 the narrow layers is not used (tests run the flood both ways)                     default 1 */
+#define GNDT_DEBUG_VERBOSE 1
+#define GNDT_DEBUG_TILE_RATIO 2
+#define GNDT_DEBUG_COST_ONE_WORKGROUP 3
+int gndt_debug_set_option(int option, double value);
 /* The bucket kernel finds a node through a 21-bit fingerprint of its key and confirms it with the key itself; a bucket in
  * which a fingerprint named the wrong node (~1 in 10^4) is accumulated a second time with every probe confirmed.  Tests narrow
  * the fingerprint (0 .. 21 bits, process-wide, for the builds that follow) so that this happens in every bucket;

@@ -54,6 +54,25 @@ def test_product_does_not_import_oracle():
     assert not bad, bad
 
 
+def test_library_reads_no_environment_variable_and_options_are_calls(native_lib):
+    """VERDICT r5 housekeeping: the last getenv reads of the product library are gndt_debug_set_option fields."""
+    bad = []
+    for dp, _, fs in os.walk(os.path.join(ROOT, "grid_ndt_amd", "csrc")):
+        for f in fs:
+            if f.endswith((".hip", ".cpp", ".hpp", ".h")) and re.search(r"\bgetenv\s*\(", open(os.path.join(dp, f)).read()):
+                bad.append(f)
+    assert not bad, bad
+    import grid_ndt_amd as g
+    T = g.TwoDmap
+    for opt, val in ((T.DEBUG_VERBOSE, 1), (T.DEBUG_VERBOSE, 0), (T.DEBUG_TILE_RATIO, 32.0), (T.DEBUG_TILE_RATIO, 48.0),
+                     (T.DEBUG_COST_ONE_WORKGROUP, 0), (T.DEBUG_COST_ONE_WORKGROUP, 1)):
+        T.set_debug_option(opt, val)
+    for opt, val in ((0, 1), (99, 1), (T.DEBUG_TILE_RATIO, 0.5), (T.DEBUG_TILE_RATIO, float("nan"))):
+        with pytest.raises(g.GndtError) as e:
+            T.set_debug_option(opt, val)
+        assert e.value.code == 1   # GNDT_ERR_INVALID
+
+
 def test_graph_capture_pauses_the_cycle_collector_and_gives_it_back(monkeypatch):
     """grid_ndt_amd.graph_capture = torch.cuda.graph with Python's cycle collector paused: a collection that starts inside a capture
     can run another object's destructor (a handle's gndt_destroy, a tensor's free), which invalidates the capture and makes torch

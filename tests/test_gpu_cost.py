@@ -11,6 +11,16 @@ pytestmark = pytest.mark.gpu
 FLT_MAX = np.float32(3.4028234663852886e38)
 
 
+@pytest.fixture
+def cost_launch_mode():
+    """gndt_debug_set_option(GNDT_DEBUG_COST_ONE_WORKGROUP, .) for one test: the flood with or without the one-workgroup kernel."""
+    import grid_ndt_amd as g
+    def choose(one_workgroup):
+        g.TwoDmap.set_debug_option(g.TwoDmap.DEBUG_COST_ONE_WORKGROUP, 1 if one_workgroup else 0)
+    yield choose
+    choose(True)
+
+
 def _build(cloud, P, demand="slope", strategy=0):
     import torch
     import grid_ndt_amd as g
@@ -144,7 +154,7 @@ def _sheets(n=300_000, seed=12, levels=24):
 
 
 @pytest.mark.parametrize("wg", ["1", "0"])
-def test_cost_map_where_a_cell_holds_more_accessible_slopes_than_a_record_names(wg, monkeypatch):
+def test_cost_map_where_a_cell_holds_more_accessible_slopes_than_a_record_names(wg, cost_launch_mode):
     """Stacked sheets on 0.1 m cells and a robot that reaches 0.45 m up or down: a neighbour cell holds up to nine accessible slopes,
     a CostEdge record (gndt_cost.hpp) names two — such cells (nine records in ten here) are expanded from their rows inside the layer
     (kEdgeMore), next to cells expanded from their record.  Same flood as the oracle's, by the one-workgroup kernel and by one-layer
@@ -155,7 +165,7 @@ def test_cost_map_where_a_cell_holds_more_accessible_slopes_than_a_record_names(
     cells = m.export()
     rows = np.nonzero((cells["flags"] & 2) != 0)[0]
     assert len(rows) > 4000
-    monkeypatch.setenv("GNDT_COST_WG", wg)
+    cost_launch_mode(wg != "0")
     robot = {"radius": 0.04, "reachable_height": 0.45, "max_angle_deg": 30.0}
     goal = cells["mean"][rows[len(rows) // 2]]
     st, _ = _check(m, cloud, P, goal, "slope", robot)
@@ -189,13 +199,13 @@ def test_cost_map_for_goal_after_goal_on_one_map_then_on_the_next():
 
 
 @pytest.mark.parametrize("demand", ["slope", "true"])
-def test_cost_map_by_one_layer_launches_only(demand, monkeypatch):
-    """GNDT_COST_WG=0: no one-workgroup kernel walking the narrow layers, every layer its own launch (what wide layers get anyway).
+def test_cost_map_by_one_layer_launches_only(demand, cost_launch_mode):
+    """GNDT_DEBUG_COST_ONE_WORKGROUP = 0: no one-workgroup kernel walking the narrow layers, every layer its own launch (what wide layers get anyway).
     Same flood."""
     cloud = scenes.drivable_site()
     P = scenes.COST_PARAMS
     m = _build(cloud, P, demand, 0)
-    monkeypatch.setenv("GNDT_COST_WG", "0")
+    cost_launch_mode(False)
     for radius in (0.25, 0.6):
         st, _ = _check(m, cloud, P, scenes.DRIVABLE_GOAL, demand, {"radius": radius})
         assert st["traversable"] > 8000 and st["levels"] > 50

@@ -2,7 +2,7 @@
 python3 -m pytest tests -m gpu -x -q > gpurun_out/r02_t.log 2>&1; grep -n "passed\|failed\|Error" gpurun_out/r02_t.log | tail -3
 for ST in 5 2; do
  for W in "S1" "S3 --points 32000000" "S5"; do
-  GNDT_VERBOSE=1 python3 bench.py --workload $W --strategy $ST --steps 10 --no-cpu-baseline --no-extras 2>gpurun_out/tile.err | python3 -c "
+  python3 bench.py --workload $W --strategy $ST --steps 10 --no-cpu-baseline --no-extras 2>gpurun_out/tile.err | python3 -c "
 import sys,json
 for l in sys.stdin:
     if l.startswith('{'):

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Where does the one-pass TILE strategy beat the partition pipeline?  Dense raster clouds with a controlled number of
 consecutive points per node (run length), 4 M points each: sampled points-per-partial, ms per build for strategy TILE (5) and
-PARTITION (2).  The crossover sets GNDT_TILE_RATIO's default (gndt_handle.hpp).  Run on the GPU box; JSON to stdout."""
+PARTITION (2).  The crossover sets the default of GNDT_DEBUG_TILE_RATIO (gndt_handle.hpp; gndt_debug_set_option).  Run on the GPU box; JSON to stdout."""
 import json
 import os
 import sys

@@ -20,12 +20,15 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--points", type=int, default=8_000_000)
     ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--layer-launches-only", action="store_true", help="without the one-workgroup kernel (gndt_debug_set_option)")
     a = ap.parse_args()
     import torch
     import grid_ndt_amd as g
     from oracle import oracle
     from grid_ndt_amd import scenes
     g.build_native()
+    if a.layer_launches_only or os.environ.get("GNDT_COST_WG") == "0":       # (the variable is this TOOL's, for tools/ab_cost*.sh; the library reads none)
+        g.TwoDmap.set_debug_option(g.TwoDmap.DEBUG_COST_ONE_WORKGROUP, 0)
     out = {"device": g.device_info(0)}
 
     def one(name, cloud, P, goal, as_shipped):
