@@ -958,6 +958,11 @@ def main():
         }
         if retries_timed:
             out["valid"] = False
+        if mode == "shards_without_exchange" and one_cloud:
+            # The step-down of last resort changes the COMPUTATION (one map per rank, no global map of the one cloud): the line is
+            # kept so that the failure is visible, but it is not a measurement of the configuration.
+            out["valid"] = False
+            out["invalid_because"] = "multi_gpu_mode shards_without_exchange: each rank built a map of its own shard; the configuration asks for ONE map"
         out.update(multi)
         if global_mode:
             out["exchange"] = {k: (round(v, 4) if isinstance(v, float) else v) for k, v in exch_timed.items()}

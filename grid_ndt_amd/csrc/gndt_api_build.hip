@@ -352,7 +352,7 @@ int partition_launch(gndt_handle* h, gndt_handle::Pending& P) {
     bucket_recs = (two || !one) ? q.recs : q.recs1;
     if (tuning().stamps && q.dbg_buckets < B) {
         GNDT_NO_CAPTURE(h, "the stamp buffer");
-        if (q.dbg) (void)hipFree(q.dbg);
+        release_device(h, q.dbg);
         q.dbg = nullptr; q.dbg_buckets = 0;
         HIP_TRY(h, hipMalloc(&q.dbg, (size_t)B * 16 * sizeof(unsigned long long)));
         { const int zrc = zero_device_now(h, q.dbg, (size_t)B * 16 * sizeof(unsigned long long)); if (zrc) return zrc; }

@@ -160,7 +160,7 @@ int stage_host_input(gndt_handle* h, const void* xyz_host, size_t n, size_t stri
     const size_t bytes = n * stride_bytes;
     if (bytes > h->stage_bytes) {
         GNDT_NO_CAPTURE(h, "the host-input staging buffer");
-        if (h->stage) (void)hipFree(h->stage);
+        release_device(h, h->stage);          // (a recorded host-input build copies into it: retired, not freed, once a graph exists)
         h->stage = nullptr; h->stage_bytes = 0;
         HIP_TRY(h, hipMalloc(&h->stage, bytes + 64));
         h->stage_bytes = bytes;

@@ -509,8 +509,8 @@ int owner_split_launch(gndt_handle* h, const void* xyz, size_t n, size_t stride_
     const uint32_t nwg = (uint32_t)std::min<uint64_t>((uint64_t)kPartWgs, std::max<uint64_t>(1, n / 8192));
     if ((rc = grow_buf(h, q.hist, q.hist_cap, (uint64_t)nwg * W))) return rc;
     if (W > q.bucket_cap) {
-        if (q.totals) (void)hipFree(q.totals);
-        if (q.bucket_base) (void)hipFree(q.bucket_base);
+        release_device(h, q.totals);          // (shared with the exact partition, whose recorded builds write through them)
+        release_device(h, q.bucket_base);
         q.totals = q.bucket_base = nullptr; q.bucket_cap = 0;
         HIP_TRY(h, hipMalloc(&q.totals, (size_t)W * 4));
         HIP_TRY(h, hipMalloc(&q.bucket_base, ((size_t)W + 1) * 4));
@@ -1022,7 +1022,7 @@ int gndt_build_owned_device(gndt_handle* h, gndt_comm* c, const void* shard_xyz_
                 else {
                     if (!err && ncols && X.pairs) HIP_TRY(h, hipMemcpyAsync(bigger, X.pairs, (size_t)ncols * sizeof(unsigned long long), hipMemcpyDeviceToDevice, s));
                     HIP_TRY(h, hipStreamSynchronize(s));
-                    if (X.pairs) (void)hipFree(X.pairs);
+                    release_device(h, X.pairs);
                     X.pairs = bigger; X.pairs_cap = want;
                 }
             }

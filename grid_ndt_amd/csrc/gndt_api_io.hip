@@ -56,7 +56,7 @@ int gndt_build_cloud(gndt_handle* h, const void* raw_host, size_t n, const gndt_
     int rc = stage_host_input(h, raw_host, n, layout->point_step, h->own_stream);
     if (rc) return rc;
     if (n > h->packed_cap) {
-        if (h->packed) (void)hipFree(h->packed);
+        release_device(h, h->packed);
         h->packed = nullptr; h->packed_cap = 0;
         HIP_TRY(h, hipMalloc(&h->packed, n * 12));
         h->packed_cap = n;

@@ -393,6 +393,9 @@ template <typename T>
 int grow_buf(gndt_handle* h, T*& p, uint64_t& cap, uint64_t want) {
     if (want <= cap) return GNDT_OK;
     GNDT_NO_CAPTURE(h, "a work buffer");
+    // Once a graph has been recorded an outgrown buffer is kept until gndt_destroy (release_device): a handle whose eager clouds
+    // grow slowly would keep the sum of all earlier sizes.  Growing by half bounds what is retired to twice the final size.
+    if (h->ever_captured && cap) want = std::max<uint64_t>(want, cap + cap / 2);
     release_device(h, p);
     p = nullptr; cap = 0;
     HIP_TRY(h, hipMalloc(&p, want * sizeof(T)));

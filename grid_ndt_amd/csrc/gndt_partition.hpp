@@ -549,6 +549,7 @@ __global__ void __launch_bounds__(kTileThreads) __attribute__((amdgpu_waves_per_
     for (; tile < ntiles; tile += gridDim.x) {
         const uint64_t t0 = tile * (kTileThreads * PER);
         const uint32_t rep = R > 1u ? (uint32_t)(tile % R) : 0u;
+        const bool r_is_one = R <= 1u;                     // (uniform; what the host passes today: no multiply on the per-point chain)
         const uint32_t have_now = (uint32_t)min((uint64_t)(kTileThreads * PER), n - t0);     // points of this tile (32-bit compares below)
         const uint32_t idx0 = first_base + (uint32_t)t0;
         float cx[PER], cy[PER], cz[PER];
@@ -599,7 +600,7 @@ __global__ void __launch_bounds__(kTileThreads) __attribute__((amdgpu_waves_per_
                     dig[j] = owner_lookup(M, sx, sy, B);
                 } else {
                     const uint32_t b = bucket_of(column_hash(sx, sy), B);
-                    dig[j] = (b >> F2_shift) + rep;                                  // F2 is a power of two (R == 1: no sub-regions, see above)
+                    dig[j] = r_is_one ? (b >> F2_shift) : (b >> F2_shift) * R + rep;  // F2 is a power of two; sub-region rep of coarse region b >> F2_shift
                     // One record in kSampleEvery votes for its bucket (k_part2_layout sizes the buckets' regions from the
                     // votes).  Chosen by a hash of the point index: a fixed stride would alias with the scan pattern of a
                     // spinning LiDAR (the same azimuths every ring) and with the lane-0 records of compressed waves.

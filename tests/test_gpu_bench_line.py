@@ -42,6 +42,8 @@ def test_multi_gpu_line_steps_down_when_the_exchange_reports_an_error(fail, ends
     assert all("injected failure" in f["error"] for f in d["fallback"])
     assert d["config"]["points_total"] == 2000000 and d["config"]["nodes"] > 0 and d["value"] > 0 and d["scaling"] == "strong"
     assert "gather_ms" not in d and "modes" not in d
+    # a fallback that changes the computation is not a measurement of the configuration: the line says so
+    assert (d.get("valid") is False and "shards_without_exchange" in d["invalid_because"]) == (ends_on == "shards_without_exchange")
 
 
 def test_single_gpu_line_carries_every_config_and_the_host_path():
