@@ -213,6 +213,8 @@ def lib():
     L.gndt_debug_retry_count.restype = C.c_int
     L.gndt_debug_enable_stamps.argtypes = [C.c_int]
     L.gndt_debug_enable_stamps.restype = C.c_int
+    L.gndt_warmup.argtypes = [C.c_void_p, C.c_uint64]
+    L.gndt_warmup.restype = C.c_int
     L.gndt_debug_set_option.argtypes = [C.c_int, C.c_double]
     L.gndt_debug_set_option.restype = C.c_int
     L.gndt_debug_set_fp_bits.argtypes = [C.c_int]

@@ -229,7 +229,12 @@ extern "C" {
 
 const char* gndt_last_error(const gndt_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
 
-int gndt_create(const gndt_params* params, gndt_handle** out) {
+int gndt_create(const gndt_params* params, gndt_handle** out) { return gndt_host::create_handle(params, out, nullptr); }
+
+}  // extern "C"
+
+namespace gndt_host {
+int create_handle(const gndt_params* params, gndt_handle** out, hipStream_t borrowed_stream) {
     if (!params || !out) { g_create_error = "null argument"; return GNDT_ERR_INVALID; }
     *out = nullptr;
     if (!(params->grid_len > 0.f) || !(params->z_len > 0.f) || params->min_points < 1 ||
@@ -254,7 +259,8 @@ int gndt_create(const gndt_params* params, gndt_handle** out) {
         return GNDT_ERR_HIP;
     };
     if ((e = hipSetDevice(h->device)) != hipSuccess) return fail("hipSetDevice", e);
-    if ((e = hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking)) != hipSuccess) return fail("hipStreamCreate", e);
+    if (borrowed_stream) { h->own_stream = borrowed_stream; h->stream_borrowed = true; }
+    else if ((e = hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking)) != hipSuccess) return fail("hipStreamCreate", e);
     if ((e = hipMalloc(&h->d_cnt, sizeof(Counters))) != hipSuccess) return fail("hipMalloc", e);
     if ((e = hipHostMalloc(&h->h_cnt, sizeof(Counters))) != hipSuccess) return fail("hipHostMalloc", e);
     if ((e = hipMemsetAsync(h->d_cnt, 0, sizeof(Counters), h->own_stream)) != hipSuccess) return fail("hipMemsetAsync", e);   // (not hipMemset: zero_device_now)
@@ -273,6 +279,9 @@ int gndt_create(const gndt_params* params, gndt_handle** out) {
     *out = h;
     return GNDT_OK;
 }
+}  // namespace gndt_host
+
+extern "C" {
 
 void gndt_destroy(gndt_handle* h) {
     if (!h) return;
@@ -316,7 +325,7 @@ void gndt_destroy(gndt_handle* h) {
     if (h->h_sketch) (void)hipHostFree(h->h_sketch);
     if (h->d_sample) (void)hipFree(h->d_sample);
     if (h->h_sample) (void)hipHostFree(h->h_sample);
-    if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+    if (h->own_stream && !h->stream_borrowed) (void)hipStreamDestroy(h->own_stream);
     delete h;
 }
 

@@ -439,8 +439,10 @@ __device__ __forceinline__ void bucket_direct_one(BucketLds3<H>& L, const uint32
         // an early look at the index: the window the hash points at is requested now and looked at after the arithmetic below — the
         // usual case (the node is there: a word carries its fingerprint and its number) costs no wait at all
         uint4 W0[U];
+#ifndef GNDT_ABLATE_DIRECT
 #pragma unroll
         for (int j = 0; j < U; ++j) W0[j] = lds_index_window(L, slot[j]);
+#endif
         const bool pair = U >= 2 && use[0] && use[U - 1] && pkey[0] == pkey[U - 1];      // both records in one node: one contribution
         if (pair) use[U - 1] = false;
         npairs += (uint32_t)__popcll(__ballot(pair));
@@ -481,11 +483,16 @@ __device__ __forceinline__ void bucket_direct_one(BucketLds3<H>& L, const uint32
         }
         GNDT_SUB(0);
         uint32_t node[U];
+        unsigned long long kv[U];
+#ifdef GNDT_ABLATE_DIRECT      // TIMING ONLY (wrong map): the node's slot computed, not searched — the bound of a directly addressed table
+#pragma unroll
+        for (int j = 0; j < U; ++j) { node[j] = slot[j] >> 2; kv[j] = pkey[j]; }
+#else
         lds_index_find_or_insert<H, U>(L, slot, W0, node, use, fpw, pkey);
         // the fingerprint NAMED the node; the key confirms it: requested now, looked at when the atomics are on their way
-        unsigned long long kv[U];
 #pragma unroll
         for (int j = 0; j < U; ++j) kv[j] = L.key[use[j] ? node[j] : 0u];
+#endif
         GNDT_SUB(it == 0u ? 1 : 2);
 #pragma unroll
         for (int j = 0; j < U; ++j) {
@@ -518,6 +525,9 @@ __device__ __forceinline__ void bucket_direct_one(BucketLds3<H>& L, const uint32
         __syncthreads();
     }
     GNDT_STAMP3(2);
+#ifdef GNDT_ABLATE_NO_PHASES   // TIMING ONLY (no map): what the kernel costs without its per-node phases
+    return;
+#endif
     const uint32_t M = L.n_nodes;
     if (L.overflow || M > (uint32_t)H) {         // uniform
         // More nodes than the table has numbers.  Nothing of this bucket has left the workgroup yet, so it can simply be done again:

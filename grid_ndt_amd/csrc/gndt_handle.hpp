@@ -47,6 +47,7 @@ struct gndt_handle {
     bool origin_set = false;
     int device = 0;
     hipStream_t own_stream = nullptr;
+    bool stream_borrowed = false;      // gndt_warmup's temporary handles run on the stream of the handle they warm up (never destroyed by them)
     hipStream_t last_stream = nullptr;
     hipEvent_t xstream_ev = nullptr;   // orders work on a new stream behind what the previous one still runs (use_stream)
     // A build recorded into a hipGraph keeps the device pointers of its day.  Once a stream of this handle has been seen under
@@ -404,6 +405,7 @@ int grow_buf(gndt_handle* h, T*& p, uint64_t& cap, uint64_t want) {
 }
 
 // ---- gndt_api_core.hip: shared buffers ----
+int create_handle(const gndt_params* params, gndt_handle** out, hipStream_t borrowed_stream);   // gndt_create's body
 int check_ready(gndt_handle* h);
 int use_stream(gndt_handle* h, hipStream_t s);     // work moves to stream s: it waits for what the handle's last stream still runs
 int ensure_out(gndt_handle* h, uint64_t n);

@@ -478,6 +478,12 @@ class TwoDmap:
         self._ensure(demand, need_origin=False)
         self._check(self._L.gndt_reserve(self._h, int(max_points), int(max_nodes)))
 
+    def warmup(self, expected_points=0, demand="slope"):
+        """gndt_warmup: the kernels' code loaded (a temporary handle runs every strategy family once on a synthetic cloud of
+        `expected_points` points) and, with a size known, every buffer reserved — so that the FIRST build costs what the next one does."""
+        self._ensure(demand, need_origin=False)
+        self._check(self._L.gndt_warmup(self._h, int(expected_points)))
+
     def set_deferred_emit(self, on=True, demand="slope"):
         """gndt_set_deferred_emit: updates relabel the touched columns only; the dense rows are produced when the map is read."""
         self._ensure(demand)

@@ -147,6 +147,17 @@ int gndt_build_device(gndt_handle* h, const void* xyz_dev, size_t n, size_t stri
  * call that has to grow a buffer fails with GNDT_ERR_CAPACITY before touching the allocator (allocating on a capturing stream
  * would invalidate the capture — and, on this runtime, every later capture of the process).  Waits for the handle's stream. */
 int gndt_reserve(gndt_handle* h, uint64_t max_points, uint64_t max_nodes);
+/* The reference builds ONE map per process (receiver.cpp:137-160): what its user sees is the FIRST build of a process, not the
+ * steady state.  HIP resolves a kernel's code at its first launch and every buffer is allocated on first use; on a 200 k-point frame
+ * that made the first build 0.4-1.0 ms against 0.05 ms for the next one.  gndt_warmup takes both out of the first build:
+ *   1. it runs a synthetic cloud of `expected_points` points (0: params.max_points_hint, else 200 000; at most 4 M) through every
+ *      strategy family a build on this handle can take — AUTO's locality sample, the partition pipeline at that size, its exact
+ *      fallback, ATOMIC, TILE, an incremental update, the export and a cost flood — on a TEMPORARY handle with this handle's
+ *      parameters, device and stream, so that the kernels' code is loaded (process-wide, per device) and this handle's state
+ *      stays that of a fresh handle;
+ *   2. if params.max_points_hint (or expected_points) is set, it calls gndt_reserve(h, that, params.max_nodes_hint).
+ * Waits for the device.  Not under stream capture.  Costs 5-40 ms, once; calling it again is cheap (the code is loaded). */
+int gndt_warmup(gndt_handle* h, uint64_t expected_points);
 
 /* Incremental add (the intent of changeCallback/change2DMap, receiver.cpp:179-212, map2D.h:672-822;
  * semantics defined in SURVEY.md Appendix A.7): after update(F1) .. update(Fk) the map equals
