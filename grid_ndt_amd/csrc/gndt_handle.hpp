@@ -141,8 +141,13 @@ struct gndt_handle {
         double fill1_ratio = 0.0;   // fullest level-1 region / mean seen on this handle (0 = unknown)
         uint64_t hist_cap = 0;     uint32_t* hist = nullptr;
         uint32_t bucket_cap = 0;   uint32_t* totals = nullptr; uint32_t* bucket_base = nullptr;
-        uint64_t stage_cap = 0;    StageRow* stage = nullptr;
+        uint64_t stage_cap = 0;    StageRow* stage = nullptr;    // stage_cap: dense staging rows the order arrays below can hold ...
+        uint64_t stage_rows_cap = 0;                             // ... and how many StageRow records `stage` holds (the table / TILE / statistics paths;
+                                                                 //     the PARTITION strategies stage RawNode records in `raw` instead and never grow it)
         uint32_t *ord_cf = nullptr, *ord_idx = nullptr, *inv = nullptr;
+        uint2* lk = nullptr;               // [stage_cap] k_bucket_columns: {record << 3 | flags, order word} of every staging row (= record slot)
+        RawNode* raw = nullptr;  uint64_t raw_cap = 0;          // k_bucket_direct's nodes: bucket b at b * slots, second-pass buckets behind them
+        uint2* binfo = nullptr;            // [cur_cap] per bucket {first record, nodes}
         uint32_t* row_of = nullptr;        // [stage_cap] row of every staged node (table path: the incremental finalisation emits in place)
         uint32_t* row_ncol = nullptr; uint64_t row_ncol_cap = 0;     // per result row: its column's node count on the column's first row, else 0
         // column order (gndt_partition.hpp ColumnOrder): per bitmap word, and per point index for ncol_at
@@ -250,6 +255,7 @@ struct gndt_handle {
         bool retry_pass = false;        //   ... and the bucket kernel's second pass behind the first (overflowing 512-slot tables done again with 1024)
         double mean1 = 0.0;             // its mean level-1 region fill (to turn the fullest region into a ratio)
         bool stats_only = false;        // gndt_shard_stats_device: statistics out, no labels / ordering / rows
+        uint32_t raw_first = 0, raw_retry_room = 0;   // record slots of this attempt: buckets x table slots, and the second pass's buckets (1024 each)
         uint64_t captured_gen = 0;      // Handle::realloc_gen when this build was recorded (captured builds only)
         bool captured = false;          // launched on a stream under hipGraph capture: it runs when the graph is replayed, with the
                                         //   buffers it was recorded with — never re-run here with more room (new buffers: the graph holds the old)
@@ -410,7 +416,8 @@ int check_ready(gndt_handle* h);
 int use_stream(gndt_handle* h, hipStream_t s);     // work moves to stream s: it waits for what the handle's last stream still runs
 int ensure_out(gndt_handle* h, uint64_t n);
 int ensure_stats_buffers(gndt_handle* h, uint64_t n);
-int ensure_stage(gndt_handle* h, uint64_t nodes);
+int ensure_stage(gndt_handle* h, uint64_t nodes, bool rows = true);   // rows = false: the order arrays only (PARTITION: RawNode records, ensure_raw)
+int ensure_raw(gndt_handle* h, uint64_t records);
 int ensure_words(gndt_handle* h, uint64_t words);
 int ensure_part_counters(gndt_handle* h);
 int ensure_cursors(gndt_handle* h, uint64_t buckets);   // gndt_api_build.hip
@@ -434,6 +441,8 @@ int sketch_nodes(gndt_handle* h, const void* xyz_dev, size_t n, size_t stride_by
 // tab_end: the table path's end-of-frame bookkeeping (k_tab_end + `advance` points of stream position) done by k_emit_rows
 // partial: incremental finalisation — only rows from the first changed column on are placed and gathered again, touched rows in
 //          front of it are emitted where they are (k_order_dest / k_emit_rows, gndt_partition.hpp)
+// grouped: the staging rows are k_bucket_columns' (a column's rows adjacent; link words; RawNode records): the caller has set mark
+//          m0 + 1 behind that kernel, the scan's mark is m0 + 2
 int launch_order_and_emit(gndt_handle* h, uint64_t words, int m0, hipStream_t s, bool grouped = false, bool counters_to_host = false,
                           bool tab_end = false, uint32_t advance = 0, bool partial = false);
 int partition_launch(gndt_handle* h, gndt_handle::Pending& P);
