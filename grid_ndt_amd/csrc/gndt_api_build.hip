@@ -13,10 +13,6 @@ namespace gndt_host {
 int launch_order_and_emit(gndt_handle* h, uint64_t words, int m0, hipStream_t s, bool grouped, bool counters_to_host, bool tab_end, uint32_t advance,
                           bool partial) {
     auto& q = h->part;
-    const GridParams emit_gp = grouped ? h->pending.gp : GridParams{};      // (as they were when the pending build was launched)
-    // grouped: the staging rows are the bucket kernel's record slots (first pass, then the second pass's room)
-    const uint32_t raw_first = grouped ? h->pending.raw_first : 0u, raw_retry_room = grouped ? h->pending.raw_retry_room : 0u;
-    const uint64_t slots = grouped ? (uint64_t)raw_first + (uint64_t)raw_retry_room * 1024u : q.stage_cap;
     // (small clouds, staging rows grouped by column: the destination pass scans the word weights itself — gndt_partition.hpp)
     const bool dest_scans = grouped && !partial && !tab_end && words <= kDestScanMax && tuning().dest_scans;
     if (dest_scans) {
@@ -33,31 +29,29 @@ int launch_order_and_emit(gndt_handle* h, uint64_t words, int m0, hipStream_t s,
                            (uint32_t)words, q.bsum_words, q.word_base);
     }
     HIP_TRY(h, hipGetLastError());
-    if (!grouped) mark(h, m0 + 1, s);       // (grouped: the caller's, behind k_bucket_columns)
+    mark(h, m0 + 1, s);
     mark(h, m0 + 2, s);       // (the column-rank and column-scan passes of earlier versions: phases kept for the ABI, empty)
     mark(h, m0 + 3, s);
     if (grouped && dest_scans)
-        hipLaunchKernelGGL((k_order_dest_columns<true, true>), dim3(grid_for(slots)), dim3(kBlock), 0, s, q.ord_cf, q.ord_idx, q.bitmap, q.word_base,
-                           q.ncol_at, q.inv, h->d_cnt, q.d_pc, (const uint32_t*)q.word_weight, (uint32_t)words, raw_first, raw_retry_room);
+        hipLaunchKernelGGL(k_order_dest_columns<true>, dim3(grid_for(q.stage_cap)), dim3(kBlock), 0, s, q.ord_cf, q.ord_idx, q.bitmap, q.word_base,
+                           q.ncol_at, q.inv, h->d_cnt, q.d_pc, (const uint32_t*)q.word_weight, (uint32_t)words);
     else if (grouped)
-        hipLaunchKernelGGL((k_order_dest_columns<false, true>), dim3(grid_for(slots)), dim3(kBlock), 0, s, q.ord_cf, q.ord_idx, q.bitmap, q.word_base,
-                           q.ncol_at, q.inv, h->d_cnt, q.d_pc, (const uint32_t*)q.word_weight, (uint32_t)words, raw_first, raw_retry_room);
+        hipLaunchKernelGGL(k_order_dest_columns<false>, dim3(grid_for(q.stage_cap)), dim3(kBlock), 0, s, q.ord_cf, q.ord_idx, q.bitmap, q.word_base,
+                           q.ncol_at, q.inv, h->d_cnt, q.d_pc, (const uint32_t*)q.word_weight, (uint32_t)words);
     else
         hipLaunchKernelGGL(k_order_dest, dim3(grid_for(q.stage_cap)), dim3(kBlock), 0, s, q.ord_cf, q.ord_idx, q.bitmap, q.word_base,
                            q.ncol_at, q.inv, h->d_cnt, q.d_pc, tab_end ? q.row_of : (uint32_t*)nullptr, partial ? 1u : 0u);
     HIP_TRY(h, hipGetLastError());
     mark(h, m0 + 4, s);
-    if (grouped)       // (RawNode records gathered by link word: moments and eigen-solve in the emit pass)
-        hipLaunchKernelGGL(k_emit_rows<true>, dim3(grid_for(std::min<uint64_t>(h->out_cap, slots))), dim3(kBlock), 0, s, reinterpret_cast<const StageRow*>(q.raw), q.inv, h->out, q.row_ncol, h->d_cnt,
+    if (grouped)       // (the PARTITION strategies' RawNode rows: moments and eigen-solve in the emit pass)
+        hipLaunchKernelGGL(k_emit_rows<true>, dim3(grid_for(q.stage_cap)), dim3(kBlock), 0, s, reinterpret_cast<const StageRow*>(q.raw), q.inv, h->out, q.row_ncol, h->d_cnt,
                            q.d_pc, counters_to_host ? h->h_cnt : (Counters*)nullptr, counters_to_host ? q.h_pc : (PartCounters*)nullptr,
-                           (Counters*)nullptr, 0u, EmitPartial{nullptr, nullptr, nullptr}, h->cur_capture_id, emit_gp, (const uint2*)q.lk,
-                           (uint32_t)std::min<uint64_t>(std::min<uint64_t>(h->out_cap, q.row_ncol_cap), 0xFFFFFFFFull));
+                           (Counters*)nullptr, 0u, EmitPartial{nullptr, nullptr, nullptr}, h->cur_capture_id, h->pending.gp);
     else
     hipLaunchKernelGGL(k_emit_rows<false>, dim3(grid_for(q.stage_cap)), dim3(kBlock), 0, s, q.stage, q.inv, h->out, q.row_ncol, h->d_cnt,
                        q.d_pc, counters_to_host ? h->h_cnt : (Counters*)nullptr, counters_to_host ? q.h_pc : (PartCounters*)nullptr,
                        tab_end ? h->d_cnt : (Counters*)nullptr, advance,
-                       partial ? EmitPartial{q.word_base, q.row_of, h->touched} : EmitPartial{nullptr, nullptr, nullptr}, h->cur_capture_id, GridParams{},
-                       (const uint2*)nullptr, 0u);
+                       partial ? EmitPartial{q.word_base, q.row_of, h->touched} : EmitPartial{nullptr, nullptr, nullptr}, h->cur_capture_id, GridParams{});
     HIP_TRY(h, hipGetLastError());
     mark(h, m0 + 5, s);
     return GNDT_OK;
@@ -98,10 +92,8 @@ int ensure_cursors(gndt_handle* h, uint64_t B) {
     if (B <= q.cur_cap) return GNDT_OK;
     GNDT_NO_CAPTURE(h, "the partition cursors");
     for (uint32_t** a : {&q.cursors, &q.range_lo, &q.range_hi, &q.range_cap}) { release_device(h, *a); *a = nullptr; }
-    release_device(h, q.binfo); q.binfo = nullptr;
     q.cur_cap = 0;
     const uint64_t c = B + B / 4;
-    HIP_TRY(h, hipMalloc(&q.binfo, c * sizeof(uint2)));
     HIP_TRY(h, hipMalloc(&q.cursors, ((size_t)kMaxFan + 2 * c) * 4));  // [kMaxFan] level 1, [c] level 2, [c] samples
     HIP_TRY(h, hipMalloc(&q.range_lo, c * 4));
     HIP_TRY(h, hipMalloc(&q.range_hi, c * 4));                        // (the retry list)
@@ -176,24 +168,12 @@ int partition_launch(gndt_handle* h, gndt_handle::Pending& P) {
     P.one_level = one;
     h->last_strategy = two ? GNDT_STRATEGY_PARTITION : (one ? GNDT_STRATEGY_PARTITION_ONE_LEVEL : GNDT_STRATEGY_PARTITION_EXACT);
     stage_want = std::max<uint64_t>(stage_want, nodes_est + nodes_est / 8);
-    // The bucket kernel leaves its nodes as RawNode records at places that need no reservation: bucket b owns bslots records from
-    // b * bslots on; the buckets of the second pass (1024-slot tables) follow behind, as many as an eighth of the buckets (more
-    // overflowing tables than that re-run the build with 1024-slot tables for all, as any overflow did before round 5).
-    const uint64_t raw_first = (uint64_t)B * (uint64_t)bslots;
-    const uint64_t raw_retry_room = bslots == 512 ? std::max<uint64_t>(64, B / 8) : 0;
-    const uint64_t raw_want = raw_first + raw_retry_room * 1024;
-    if (raw_want >= kMaxRawNodes) return -1;               // (a link word names a record in 29 bits: atomic path beyond)
-    P.raw_first = (uint32_t)raw_first; P.raw_retry_room = (uint32_t)raw_retry_room;
     if (P.stats_only) {
         if ((rc = ensure_stats_buffers(h, stage_want))) return rc;
     } else {
-        // staging rows = record slots (k_bucket_columns): the order arrays cover them all; the result arrays hold what the build expects
-        // (+ 1/8) — a map of more rows than that is reported by the emit pass (stage_overflow) and the build re-run with the true count
-        if ((rc = ensure_stage(h, std::max<uint64_t>(stage_want, raw_want), false))) return rc;
-        if ((rc = ensure_out(h, stage_want))) return rc;
-        if ((rc = grow_buf(h, q.row_ncol, q.row_ncol_cap, stage_want))) return rc;
-        if ((rc = ensure_raw(h, raw_want))) return rc;
-        if ((rc = ensure_cursors(h, B))) return rc;         // (binfo; the two-level and one-level paths ask again with the same B)
+        if ((rc = ensure_stage(h, stage_want, false))) return rc;       // (the order arrays; the rows are RawNode records)
+        if ((rc = ensure_raw(h, q.stage_cap))) return rc;
+        if ((rc = ensure_out(h, q.stage_cap))) return rc;
     }
     BucketRanges ranges{nullptr, nullptr, nullptr, 0u};
     const float4* bucket_recs = nullptr;
@@ -393,7 +373,6 @@ int partition_launch(gndt_handle* h, gndt_handle::Pending& P) {
     const dim3 bgrid(std::min<uint32_t>(B, bucket_wgs));
     const ColumnOrder order{q.bitmap, q.word_weight, q.ncol_at};
     const StatsOut stats_out{h->st_key, h->st_sums, h->st_count, h->st_first};
-    (void)order;
     unsigned long long* dbg = tuning().stamps ? q.dbg : nullptr;
     const bool grouped = true;          // k_bucket_direct stages a column's rows next to each other
     const uint32_t fp_mask = (1u << tuning().fp_bits) - 1u;
@@ -414,11 +393,17 @@ int partition_launch(gndt_handle* h, gndt_handle::Pending& P) {
         const bool retry = bslots == 512 && tuning().retry_pass && (q.retry_pass || h->capturing);
         uint32_t* const rlist = retry ? q.range_hi : (uint32_t*)nullptr;
         P.retry_pass = retry;
+        // one record per thread at three workgroups per CU for clouds without locality (interleave == 0: the last build counted next
+        // to no adjacent records of one node), two records at two workgroups per CU — with the pair folding — for the others
+        const bool wide = (interleave == 0u || tuning().bucket_three_wgs == 2) && !P.stats_only && tuning().bucket_three_wgs;
 #define GNDT_LAUNCH_DIRECT(T_, H_, S_, GRID_, RL_, TODO_)                                                                       \
-    hipLaunchKernelGGL((k_bucket_direct<T_, H_, S_>), GRID_, dim3(T_), 0, s, bucket_recs, ranges, B, gp, q.raw, (uint32_t)raw_first,    \
-                       (uint32_t)(S_ ? h->st_cap : raw_want), q.binfo, h->d_cnt, q.d_pc, dbg, stats_out, fp_mask, interleave, \
+    hipLaunchKernelGGL((k_bucket_direct<T_, H_, S_>), GRID_, dim3(T_), 0, s, bucket_recs, ranges, B, gp, q.raw,    \
+                       (uint32_t)(S_ ? h->st_cap : q.stage_cap), q.ord_cf, q.ord_idx, order, h->d_cnt, q.d_pc, dbg, stats_out, fp_mask, interleave, \
                        RL_, TODO_)
         if (bslots == 1024) { if (P.stats_only) GNDT_LAUNCH_DIRECT(1024, 1024, true, bgrid, (uint32_t*)nullptr, (const uint32_t*)nullptr); else GNDT_LAUNCH_DIRECT(1024, 1024, false, bgrid, (uint32_t*)nullptr, (const uint32_t*)nullptr); }
+        else if (wide)
+            hipLaunchKernelGGL((k_bucket_direct<GNDT_DIRECT_THREADS, 512, false, 1, 6>), bgrid, dim3(GNDT_DIRECT_THREADS), 0, s, bucket_recs, ranges, B, gp, q.raw,
+                               (uint32_t)q.stage_cap, q.ord_cf, q.ord_idx, order, h->d_cnt, q.d_pc, dbg, stats_out, fp_mask, interleave, rlist, (const uint32_t*)nullptr);
         else { if (P.stats_only) GNDT_LAUNCH_DIRECT(GNDT_DIRECT_THREADS, 512, true, bgrid, rlist, (const uint32_t*)nullptr); else GNDT_LAUNCH_DIRECT(GNDT_DIRECT_THREADS, 512, false, bgrid, rlist, (const uint32_t*)nullptr); }
         if (retry) {
             const dim3 rgrid(std::min<uint32_t>(B, 256u));       // (one 1024-thread workgroup per CU; all of them leave at once when nothing is queued)
@@ -426,23 +411,9 @@ int partition_launch(gndt_handle* h, gndt_handle::Pending& P) {
             else GNDT_LAUNCH_DIRECT(1024, 1024, false, rgrid, (uint32_t*)nullptr, (const uint32_t*)rlist);
         }
 #undef GNDT_LAUNCH_DIRECT
-        HIP_TRY(h, hipGetLastError());
-        mark(h, 5, s);
-        // the columns of every bucket, the slope labels, the order keys (gndt_bucket3.hpp k_bucket_columns): one workgroup per bucket,
-        // four resident per CU; the buckets of the second pass by a launch of the 1024-node instantiation over the retry list
-        if (!P.stats_only) {
-            const uint32_t cwgs = std::min<uint32_t>(B, 256u * 4u);       // persistent, four per CU (gndt_bucket3.hpp)
-#define GNDT_LAUNCH_COLUMNS(T_, H_, GRID_, TODO_)                                                                                \
-    hipLaunchKernelGGL((k_bucket_columns<T_, H_>), GRID_, dim3(T_), 0, s, (const RawNode*)q.raw, (const uint2*)q.binfo, B, gp,  \
-                       q.ord_cf, q.ord_idx, q.lk, order, q.d_pc, TODO_, (uint32_t)raw_first, (uint32_t)raw_want, dbg)
-            if (bslots == 1024) GNDT_LAUNCH_COLUMNS(1024, 1024, dim3(cwgs), (const uint32_t*)nullptr);
-            else GNDT_LAUNCH_COLUMNS(512, 512, dim3(cwgs), (const uint32_t*)nullptr);
-            if (retry) GNDT_LAUNCH_COLUMNS(1024, 1024, dim3(std::min<uint32_t>(B, 256u)), (const uint32_t*)rlist);
-#undef GNDT_LAUNCH_COLUMNS
-            HIP_TRY(h, hipGetLastError());
-            mark(h, 6, s);
-        }
     }
+    HIP_TRY(h, hipGetLastError());
+    mark(h, 5, s);
     // (the counters and overflow flags come back with the last kernel: k_emit_rows stores them into the host's pinned mirrors)
     if (!P.stats_only && (rc = launch_order_and_emit(h, words, 5, s, grouped, true))) return rc;
     if (P.stats_only) {
@@ -643,7 +614,7 @@ int partition_resolve(gndt_handle* h) {
         } else if (q.h_pc->stage_overflow) {                   // num_nodes kept counting: it is the true total
             const uint64_t true_nodes = h->h_cnt->num_nodes;
             const uint64_t want = true_nodes + true_nodes / 8 + 1024;
-            // More rows than the result arrays held is not a failure of the TABLES: the same attempt once more, with room for what
+            // More rows than the staging arrays held is not a failure of the TABLES: the same attempt once more, with room for what
             // was counted — and with the count as the node estimate where the estimate fell short of it (round 6: a first build that
             // guessed n / 4 nodes for a cloud of n / 2 went on to 1024-slot tables with the same wrong estimate and ran a third time)
             if (want > P.stage_want) --P.attempt;
@@ -730,16 +701,28 @@ int gndt_build_device(gndt_handle* h, const void* xyz_dev, size_t n, size_t stri
             //  handle's last answer, PARTITION if there is none yet)
             hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
             (void)hipStreamIsCapturing(s, &cap);
-            const bool stale = cap == hipStreamCaptureStatusNone &&
+            auto adopt = [&](double ratio, uint64_t n_of) {
+                h->tile_choice = ratio >= tuning().tile_ratio ? 1 : 0;
+                h->tile_choice_n = n_of; h->tile_choice_age = 0; h->tile_ratio_seen = ratio;
+                if (tuning().verbose) fprintf(stderr, "[gndt] locality sample: %.1f points per partial -> %s\n", ratio, h->tile_choice ? "TILE" : "PARTITION");
+            };
+            // (the answer of a sample an earlier build did not wait for, if it is there by now)
+            { double r0 = 0.0; if (h->sample_pending && locality_sample_take(h, false, &r0)) adopt(r0, h->sample_n); }
+            const bool stale = cap == hipStreamCaptureStatusNone && !h->sample_pending &&
                                (h->tile_choice < 0 || ++h->tile_choice_age >= 64 ||
                                 n > h->tile_choice_n + h->tile_choice_n / 4 || n + n / 4 < h->tile_choice_n);
             if (stale) {
-                double ratio = 0.0;
-                rc = locality_sample(h, xyz_dev, n, stride_bytes, 64, &ratio, s);
+                // A handle that already has room for whatever this cloud turns out to be (gndt_reserve / gndt_warmup, or earlier builds:
+                // staging rows for n / 2 nodes) does not WAIT for the sample — ~50 us of a first build that takes 90: the kernel and its
+                // copy ride in front of this build, which takes the handle's last choice (PARTITION on a fresh handle: never wrong, at
+                // worst 0.09 ms slower than TILE on a 200 k-point depth frame), and the next build finds the answer.  A fresh handle
+                // without room waits as before: the answer also sizes its first tables (partition_begin), and its allocations cost more.
+                // (A handle whose node estimate does not come from the sample — a hint, an earlier build — never needs to wait either.)
+                const bool defer = (h->part.stage_cap >= n / 2 && h->part.stage_cap > 0) || h->part.nodes_learned != 0 || h->P.max_nodes_hint != 0;
+                rc = locality_sample_begin(h, xyz_dev, n, stride_bytes, 64, s);
                 if (rc) return rc;
-                h->tile_choice = ratio >= tuning().tile_ratio ? 1 : 0;
-                h->tile_choice_n = n; h->tile_choice_age = 0; h->tile_ratio_seen = ratio;
-                if (tuning().verbose) fprintf(stderr, "[gndt] locality sample: %.1f points per partial -> %s\n", ratio, h->tile_choice ? "TILE" : "PARTITION");
+                if (!defer) { double ratio = 0.0; if (locality_sample_take(h, true, &ratio)) adopt(ratio, n); }
+                else if (h->tile_choice < 0) { h->tile_choice = 0; h->tile_choice_n = n; h->tile_choice_age = 0; }   // (PARTITION until the answer is in)
             }
             if (h->tile_choice == 1) strategy = GNDT_STRATEGY_TILE;
         }
@@ -792,22 +775,14 @@ int gndt_reserve(gndt_handle* h, uint64_t max_points, uint64_t max_nodes) {
     const uint64_t est_hi = 2 * max_nodes;
     const uint64_t rows = std::max<uint64_t>(std::max<uint64_t>(est_hi + est_hi / 8 + 1024, (uint64_t)cap_for_nodes(max_nodes) / 2 + 1),
                                              4096 + n / 4 + n / 32);      // (a build without a hint stages max(4096, n / 4) rows at least)
+    if ((rc = ensure_stage(h, rows))) return rc;
+    if ((rc = ensure_raw(h, q.stage_cap))) return rc;           // (the PARTITION strategies' staging rows)
+    if ((rc = ensure_out(h, q.stage_cap))) return rc;
     // bucket count: the largest any attempt can ask for
-    uint64_t Bmax = 16, raw_max = 0;
+    uint64_t Bmax = 16;
     for (int slots : {512, 1024})
-        for (int load : {35, 60, 75}) {
-            const uint64_t b = std::min<uint64_t>(buckets_for(n, est_hi, slots, load), (uint64_t)kMaxFan * kMaxFan);
-            Bmax = std::max(Bmax, b);
-            raw_max = std::max(raw_max, b * (uint64_t)slots + (slots == 512 ? std::max<uint64_t>(64, b / 8) * 1024 : 0));
-        }
+        for (int load : {35, 60, 75}) Bmax = std::max(Bmax, buckets_for(n, est_hi, slots, load));
     Bmax = std::min<uint64_t>(Bmax, (uint64_t)kMaxFan * kMaxFan);
-    raw_max = std::min<uint64_t>(raw_max, kMaxRawNodes - 1);
-    if ((rc = ensure_raw(h, raw_max))) return rc;      // the bucket kernel's node records
-    // (the order arrays cover the record slots of a PARTITION build — staging row = record slot — and the StageRow records of the
-    //  table / TILE paths are as many as the arrays address: ensure_stage)
-    if ((rc = ensure_stage(h, std::max<uint64_t>(rows, raw_max)))) return rc;
-    if ((rc = ensure_out(h, rows))) return rc;
-    if ((rc = grow_buf(h, q.row_ncol, q.row_ncol_cap, rows))) return rc;
     if ((rc = ensure_cursors(h, Bmax))) return rc;
     constexpr uint64_t kTile1 = (uint64_t)kTileThreads * kTilePer1;
     if ((rc = grow_buf(h, q.recs, q.rec_cap, 2 * n + n / 8 + 2048ull * Bmax + 4096))) return rc;                    // two-level (covers the exact partition's n)
@@ -827,6 +802,7 @@ int gndt_reserve(gndt_handle* h, uint64_t max_points, uint64_t max_nodes) {
     HIP_TRY(h, hipStreamSynchronize(h->own_stream));
     // (rows_bound of a table-path finalisation follows the table: cap / 2 + 1)
     if ((rc = ensure_stage(h, std::max<uint64_t>(1024, h->cap / 2 + 1)))) return rc;
+    if ((rc = ensure_raw(h, q.stage_cap))) return rc;
     if ((rc = ensure_out(h, q.stage_cap))) return rc;
     return GNDT_OK;
 }

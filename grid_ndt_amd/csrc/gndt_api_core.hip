@@ -86,8 +86,7 @@ int check_ready(gndt_handle* h) {
 
 void free_part(gndt_handle* h) {
     auto& q = h->part;
-    void* ptrs[] = {q.recs, q.recs1, q.cursors, q.range_lo, q.range_hi, q.range_cap, q.hist, q.totals, q.bucket_base, q.stage, q.ord_cf, q.ord_idx, q.inv, q.row_of, q.row_ncol,
-                    q.lk, q.raw, q.binfo,
+    void* ptrs[] = {q.recs, q.recs1, q.cursors, q.range_lo, q.range_hi, q.range_cap, q.hist, q.totals, q.bucket_base, q.stage, q.ord_cf, q.ord_idx, q.inv, q.row_of, q.row_ncol, q.raw,
                     q.bitmap, q.word_weight, q.word_base, q.bsum_words, q.ncol_at, q.d_pc, q.dbg};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -99,13 +98,12 @@ int ensure_stage(gndt_handle* h, uint64_t nodes, bool rows) {
     auto& q = h->part;
     if (nodes > q.stage_cap) {
         GNDT_NO_CAPTURE(h, "the staging rows");
-        void* ptrs[] = {q.ord_cf, q.ord_idx, q.inv, q.row_of, q.lk};
+        void* ptrs[] = {q.ord_cf, q.ord_idx, q.inv, q.row_of};
         for (void* p : ptrs) release_device(h, p);
-        q.ord_cf = q.ord_idx = q.inv = q.row_of = nullptr; q.lk = nullptr;
+        q.ord_cf = q.ord_idx = q.inv = q.row_of = nullptr;
         q.stage_cap = 0;
         uint32_t** arrs[] = {&q.ord_cf, &q.ord_idx, &q.inv, &q.row_of};
         for (auto a : arrs) HIP_TRY(h, hipMalloc(a, nodes * 4));
-        HIP_TRY(h, hipMalloc(&q.lk, nodes * sizeof(uint2)));
         q.stage_cap = nodes;
         // (the column index of the result rows has its own capacity: an adopted map — gndt_adopt_rows_device — can be larger than
         // anything this handle staged)
@@ -113,7 +111,7 @@ int ensure_stage(gndt_handle* h, uint64_t nodes, bool rows) {
         if (rc) return rc;
     }
     // StageRow records: as many as the order arrays address (the kernels that fill them are given stage_cap as their bound), but
-    // only for the paths that stage such rows — a PARTITION build leaves RawNode records in `raw` (ensure_raw)
+    // only for the paths that stage such rows — a PARTITION build stages RawNode records (ensure_raw)
     if (rows && q.stage_rows_cap < q.stage_cap) {
         GNDT_NO_CAPTURE(h, "the staging rows");
         release_device(h, q.stage);
@@ -124,15 +122,16 @@ int ensure_stage(gndt_handle* h, uint64_t nodes, bool rows) {
     return GNDT_OK;
 }
 
+// the PARTITION strategies' staging rows (RawNode): as many as the order arrays address
 int ensure_raw(gndt_handle* h, uint64_t records) {
     auto& q = h->part;
+    records = std::max<uint64_t>(records, q.stage_cap);
     if (records <= q.raw_cap) return GNDT_OK;
-    GNDT_NO_CAPTURE(h, "the bucket kernel's node records");
+    GNDT_NO_CAPTURE(h, "the bucket kernel's staging rows");
     release_device(h, q.raw);
     q.raw = nullptr; q.raw_cap = 0;
-    const uint64_t want = records + records / 8;
-    HIP_TRY(h, hipMalloc(&q.raw, want * sizeof(RawNode)));
-    q.raw_cap = want;
+    HIP_TRY(h, hipMalloc(&q.raw, records * sizeof(RawNode)));
+    q.raw_cap = records;
     return GNDT_OK;
 }
 
@@ -168,9 +167,9 @@ int ensure_part_counters(gndt_handle* h) {
     auto& q = h->part;
     if (q.d_pc) return GNDT_OK;
     GNDT_NO_CAPTURE(h, "the partition counters");
-    HIP_TRY(h, hipMalloc(&q.d_pc, kPartCountersBytes));          // (the counters and, behind them, the sub-counters: gndt_partition.hpp)
+    HIP_TRY(h, hipMalloc(&q.d_pc, sizeof(PartCounters)));
     HIP_TRY(h, hipHostMalloc(&q.h_pc, sizeof(PartCounters)));
-    { const int rc = zero_device_now(h, q.d_pc, kPartCountersBytes); if (rc) return rc; }
+    { const int rc = zero_device_now(h, q.d_pc, sizeof(PartCounters)); if (rc) return rc; }
     memset(q.h_pc, 0, sizeof(PartCounters));
     return GNDT_OK;
 }
@@ -348,6 +347,7 @@ void gndt_destroy(gndt_handle* h) {
     for (void* p : h->retired) (void)hipFree(p);
     if (h->d_sketch) (void)hipFree(h->d_sketch);
     if (h->h_sketch) (void)hipHostFree(h->h_sketch);
+    if (h->sample_ev) (void)hipEventDestroy(h->sample_ev);
     if (h->d_sample) (void)hipFree(h->d_sample);
     if (h->h_sample) (void)hipHostFree(h->h_sample);
     if (h->own_stream && !h->stream_borrowed) (void)hipStreamDestroy(h->own_stream);

@@ -321,15 +321,16 @@ int table_refinalize(gndt_handle* h) {
 }
 
 // strategy ATOMIC from empty; waits for the result (the retry on a full table needs the device-side flags)
-int locality_sample(gndt_handle* h, const void* xyz_dev, size_t n, size_t stride_bytes, uint32_t tiles, double* ratio, hipStream_t s) {
+int locality_sample_begin(gndt_handle* h, const void* xyz_dev, size_t n, size_t stride_bytes, uint32_t tiles, hipStream_t s) {
     if (stride_bytes != 12 && stride_bytes != 16) { h->err = "stride_bytes must be 12 or 16"; return GNDT_ERR_INVALID; }
-    *ratio = 0.0;
+    h->sample_pending = false;
     if (n == 0 || tiles == 0) return GNDT_OK;
     GNDT_NO_CAPTURE(h, "the locality sample");
     if (!h->d_sample) {
         HIP_TRY(h, hipMalloc(&h->d_sample, 2 * sizeof(unsigned long long)));
         HIP_TRY(h, hipHostMalloc(&h->h_sample, 2 * sizeof(unsigned long long)));
     }
+    if (!h->sample_ev) HIP_TRY(h, hipEventCreateWithFlags(&h->sample_ev, hipEventDisableTiming));
     tiles = (uint32_t)std::min<uint64_t>(tiles, (n + kTileCheck - 1) / kTileCheck);
     HIP_TRY(h, hipMemsetAsync(h->d_sample, 0, 2 * sizeof(unsigned long long), s));
     const float* p = static_cast<const float*>(xyz_dev);
@@ -337,8 +338,29 @@ int locality_sample(gndt_handle* h, const void* xyz_dev, size_t n, size_t stride
     else hipLaunchKernelGGL(k_tile_sample<4>, dim3(tiles), dim3(kTileT), 0, s, p, (uint64_t)n, grid_params(h), tiles, h->d_sample);
     HIP_TRY(h, hipGetLastError());
     HIP_TRY(h, hipMemcpyAsync(h->h_sample, h->d_sample, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
-    HIP_TRY(h, hipStreamSynchronize(s));
+    HIP_TRY(h, hipEventRecord(h->sample_ev, s));
+    h->sample_pending = true;
+    h->sample_n = n;
+    return GNDT_OK;
+}
+
+bool locality_sample_take(gndt_handle* h, bool wait, double* ratio) {
+    if (!h->sample_pending) return false;
+    if (wait) { if (hipEventSynchronize(h->sample_ev) != hipSuccess) { (void)hipGetLastError(); h->sample_pending = false; return false; } }
+    else {
+        const hipError_t e = hipEventQuery(h->sample_ev);
+        if (e != hipSuccess) { (void)hipGetLastError(); return false; }       // (not there yet: ask again later)
+    }
+    h->sample_pending = false;
     *ratio = h->h_sample[1] ? (double)h->h_sample[0] / (double)h->h_sample[1] : (double)h->h_sample[0];
+    return true;
+}
+
+int locality_sample(gndt_handle* h, const void* xyz_dev, size_t n, size_t stride_bytes, uint32_t tiles, double* ratio, hipStream_t s) {
+    *ratio = 0.0;
+    const int rc = locality_sample_begin(h, xyz_dev, n, stride_bytes, tiles, s);
+    if (rc) return rc;
+    (void)locality_sample_take(h, true, ratio);
     return GNDT_OK;
 }
 

@@ -48,21 +48,37 @@ struct StatsOut {
     uint64_t* key; double* sums; uint32_t* count; uint32_t* first;
 };
 
+// What the per-node phases need in LDS.  Round 6: it lives in the space of the nine sums, which every node's thread has taken into
+// registers by then — 53 KB per workgroup instead of 70: THREE workgroups per CU (with one record per thread and iteration the
+// accumulate loop fits the 80 registers that takes), and a workgroup in its phases leaves two, not one, accumulating beside it.
 template <int H>
-struct BucketLds3 {           // 53 KB at H = 512 (round 6: the per-node phases and their arrays moved to k_bucket_columns)
+struct PhaseLds3 {
+    uint4 colnodes[H];          // the nodes of every column as an ARRAY (column c at ccnt[c] >> 16): what a node's look at its column
+                                //   needs of the others in one 16-byte load each, with independent addresses (loads pipeline; a linked
+                                //   list chased one LDS round trip per node): first-seen index, z level, fp32 mean z (0 below min_points)
+    float mz[H];                // (tall columns look their z neighbours up by node number)
+    uint32_t chead[H];          // column table: a node of the column (its key is the column's key: no separate column keys), kNoNode = free
+    uint32_t ccnt[H];           // nodes of the column in this column slot; after the prefix (first row inside the bucket) << 16 | nodes
+};
+template <int H>
+struct BucketLds3 {           // 53 KB at H = 512
     // Node table in two parts.  `idx` is an open-addressing INDEX of 4 H words (at most a quarter full): the hash of a node's
     // key leads to a word holding a FINGERPRINT of the key and the number of the node.  Nodes are numbered in the order they
     // arrive, so keys and statistics sit in DENSE arrays: the per-node phases run over 0 .. n_nodes - 1 with no compaction
     // pass, and a table holds H nodes, not 0.78 H.
     alignas(16) uint32_t idx[4 * H];
     unsigned long long key[H];
-    double sum[9][H];
+    union {
+        double sum[9][H];       // accumulate phase
+        PhaseLds3<H> ph;        // per-node phases (the sums are in registers then)
+    };
     uint32_t cnt[H];
     uint32_t first[H];
-    uint32_t n_nodes, stage_base, overflow, err_range;
+    uint32_t n_nodes, n_cols, n_slopes, stage_base, overflow, err_range, row_cursor;
     uint32_t clash;             // records whose fingerprint named another node (they went on with the key itself)
     uint32_t n_pairs;           // lanes whose two adjacent records fell into one node (what the host reads the cloud's locality from)
 };
+static_assert(sizeof(PhaseLds3<512>) <= sizeof(double) * 9 * 512, "the phase arrays fit the space of the sums");
 // Workgroup barrier that orders LDS traffic ONLY (__syncthreads() also waits for the wave's global stores): the phases of
 // the bucket kernels hand over LDS contents, their global stores are read by later kernels.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
@@ -298,7 +314,7 @@ __device__ __forceinline__ void bucket_tables_init(Lds& L) {
         for (int j = 0; j < 9; ++j) L.sum[j][s] = 0.0;
         L.cnt[s] = 0; L.first[s] = 0xFFFFFFFFu;
     }
-    if (tid == 0) { L.n_nodes = 0; L.stage_base = 0; L.overflow = 0; L.err_range = 0; L.clash = 0; L.n_pairs = 0; }
+    if (tid == 0) { L.n_nodes = 0; L.n_cols = 0; L.n_slopes = 0; L.stage_base = 0; L.overflow = 0; L.err_range = 0; L.row_cursor = 0; L.clash = 0; L.n_pairs = 0; }
 }
 
 // The accumulate phase once more for a bucket whose fingerprints clashed: one record per thread and step, every step of the
@@ -334,16 +350,17 @@ __device__ __forceinline__ void accumulate_exact(Lds& L, const float4* __restric
     }
 }
 
-template <int T, int H, bool STATS>
+template <int T, int H, bool STATS, int UREC>
 __device__ __forceinline__ void bucket_direct_one(BucketLds3<H>& L, const uint32_t bucket, const float4* __restrict__ recs,
                                                   const uint32_t lo, const uint32_t hi, const GridParams& P,
-                                                  RawNode* __restrict__ raw, const uint32_t raw_base, const uint32_t raw_cap,
-                                                  uint2* __restrict__ binfo, Counters* __restrict__ cnt,
+                                                  RawNode* __restrict__ stage, uint32_t stage_cap,
+                                                  uint32_t* __restrict__ ord_cf, uint32_t* __restrict__ ord_idx,
+                                                  const ColumnOrder& O, Counters* __restrict__ cnt,
                                                   PartCounters* __restrict__ pc, unsigned long long* __restrict__ dbg,
                                                   const StatsOut& so, const uint32_t fp_mask, const uint32_t interleave,
                                                   uint32_t* __restrict__ retry_list) {
     static_assert(H <= 65535, "node numbers are kept in 16 bits");
-    constexpr int U = H <= 512 ? GNDT_DIRECT_U : 2;    // records in flight per thread
+    constexpr int U = UREC;                            // records per thread and iteration
     const int tid = threadIdx.x;
     const int lane = tid & 63;
 #define GNDT_STAMP3(k) do { if (dbg && tid == 0) dbg[(size_t)bucket * 16 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
@@ -515,6 +532,9 @@ __device__ __forceinline__ void bucket_direct_one(BucketLds3<H>& L, const uint32
         __syncthreads();
     }
     GNDT_STAMP3(2);
+#ifdef GNDT_ABLATE_NO_PHASES   // TIMING ONLY (no map): what the kernel costs without its per-node phases
+    return;
+#endif
     const uint32_t M = L.n_nodes;
     if (L.overflow || M > (uint32_t)H) {         // uniform
         // More nodes than the table has numbers.  Nothing of this bucket has left the workgroup yet, so it can simply be done again:
@@ -524,19 +544,23 @@ __device__ __forceinline__ void bucket_direct_one(BucketLds3<H>& L, const uint32
         if (tid == 0) {
             if (retry_list) retry_list[atomicAdd(&pc->lds_retry, 1u)] = bucket;
             else atomicAdd(&pc->lds_overflow, 1u);
-            if (!STATS) binfo[bucket] = make_uint2(0u, 0u);        // (nothing of this bucket yet: the second pass fills it in, or the build is re-run)
         }
         return;
     }
+    // Reserve the staging rows now.  The memory-side atomic's round trip (~3 us) hides behind the column phases: its answer stays in
+    // the register of the thread that asked and is handed to the workgroup only at the barrier in front of the rows phase, where it is
+    // first needed.  (Rounds 1-3 said the same in this comment and then waited for the answer at the very next barrier — ~5 k cycles per
+    // bucket that the stamps booked under "columns"; on a small frame, one workgroup per CU, nothing else ran meanwhile.)
+    uint32_t stage_base_reg = 0;
+    if (tid == T - 1) stage_base_reg = atomicAdd(&cnt->num_nodes, M);
     if (tid == 0 && L.err_range) atomicAdd(&cnt->err_key_range, L.err_range);
     if (tid == 64 && L.n_pairs) atomicAdd(&pc->pairs, L.n_pairs);
 
     if constexpr (STATS) {
-        // the shard's additive statistics, densely: one memory-side reservation per bucket (its round trip is this path's to pay)
-        if (tid == T - 1) L.stage_base = atomicAdd(&cnt->num_nodes, M);
+        if (tid == T - 1) L.stage_base = stage_base_reg;
         __syncthreads();
         const uint32_t sbase = L.stage_base;
-        if (sbase + M > raw_cap) {                     // uniform
+        if (sbase + M > stage_cap) {                   // uniform
             if (tid == 0) atomicAdd(&pc->stage_overflow, M);
             return;
         }
@@ -550,39 +574,170 @@ __device__ __forceinline__ void bucket_direct_one(BucketLds3<H>& L, const uint32
             so.first[dst] = L.first[s];
         }
         return;
-    } else {
-        // ---- the bucket's nodes leave as they are: key, count, first-seen index and the nine fp64 sums, one 96-byte record each, at
-        //      a place that needs NO reservation (bucket b owns records b * H ..; a second-pass bucket its place behind them) ----
-        // Rounds 1-5 went on, in this kernel, to the columns of the bucket, the slope labels and the moments ("per-node phases":
-        // one node per thread, eight dependent LDS round trips, each queued behind the OTHER resident workgroup's fp64 atomics).
-        // Measured in round 6 (profiles/r06_ablation.txt): those phases were 25 % of this kernel on the bench scene (38 of 153 us),
-        // 32 % on a 200 k-point frame, and FULLY exposed — the accumulate phase of the other workgroup does not speed up while this
-        // one waits; a third workgroup per CU had no room (70 KB of LDS each).  They now run in k_bucket_columns: four workgroups of
-        // it fit a CU, its LDS round trips queue behind nothing, and the moments + eigen-solve are k_emit_rows' (chip-wide).
-        for (uint32_t i = tid; i < M; i += T) {
-            RawNode r;
-            r.key = L.key[i]; r.count = L.cnt[i]; r.first = L.first[i];
-#pragma unroll
-            for (int j = 0; j < 9; ++j) r.sum[j] = L.sum[j][i];
-            r.pad[0] = 0u; r.pad[1] = 0u;
-            raw[(size_t)raw_base + i] = r;
-        }
-        if (tid == 0) { binfo[bucket] = make_uint2(raw_base, M); if (M) atomicAdd(&cnt->num_nodes, M); }      // (nobody waits for the sum: one per bucket, spread over the kernel's run)
     }
+
+    // ---- per-node phases: ONE node per thread (a table holds at most H = T nodes), so what a node learns in one phase — its
+    //      key, count, first-seen index, mean z, column slot, number in its column — stays in REGISTERS across the barriers
+    //      (round 3 kept it in LDS arrays: three more dependent round trips, each behind the other workgroups' fp64 atomics) ----
+    // Round 6: so do its nine SUMS.  Every thread takes its node's statistics out of the table first; from the barrier behind that
+    // on, the space of the sums holds the phases' own arrays (BucketLds3::ph), and the node leaves as a RawNode record — statistics
+    // as they are; mean, scatter and eigen-solve are k_emit_rows' — written whole by its thread, a column's rows next to each other.
+    static_assert(H <= T, "one node per thread");
+    const bool live = (uint32_t)tid < M;
+    const uint32_t s = (uint32_t)tid;            // (node s in thread s.  Transposed over the live waves — the levels of a column arrive together
+                                                 //  and would otherwise meet in one LDS atomic on the column's counter — measured in round 5: no change,
+                                                 //  columns 4.9 k / 7.0 k cycles per bucket on S2 / S3 either way: these phases are round trips, not conflicts)
+    uint64_t key = 0;
+    int sx = 0, sy = 0, sz = 0;
+    uint32_t my_n = 0, my_first = 0xFFFFFFFFu, col = 0, kc = 0;
+    float cz = 0.f;
+    double sums[9] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    if (live) {
+        key = L.key[s];
+        my_n = L.cnt[s];
+        my_first = L.first[s];
+#pragma unroll
+        for (int j = 0; j < 9; ++j) sums[j] = L.sum[j][s];
+    }
+    lds_barrier();                               // (every sum is in a register: their space is the phases' from here on)
+    for (int c = tid; c < H; c += T) { L.ph.chead[c] = kNoNode; L.ph.ccnt[c] = 0u; }
+    if (tid == 0) { L.n_cols = 0; L.n_slopes = 0; L.row_cursor = 0; }
+    if (live) {
+        unpack_key(key, sx, sy, sz);
+        cz = (my_n >= (uint32_t)P.min_points) ? node_mean_z(my_n, sums[2], axis_centre(sz, P.oz, P.z_len)) : 0.f;
+        L.ph.mz[s] = cz;                                      // (tall columns look their z neighbours up by node number)
+    }
+    lds_barrier();
+    // ---- columns: every node finds the slot of its column and takes a number in it ----
+    if (live) {
+        const uint64_t ck = column_key(key);
+        col = ((column_hash(sx, sy) * 0x85EBCA77u) >> 12) & (uint32_t)(H - 1);
+        for (int probe = 0; probe < H; ++probe) {            // (terminates: the table has more slots than nodes)
+            uint32_t head = L.ph.chead[col];
+            if (head == kNoNode) {
+                head = atomicCAS(&L.ph.chead[col], kNoNode, s);
+                if (head == kNoNode) { atomicAdd(&L.n_cols, 1u); break; }                           // first node of a new column
+            }
+            if (column_key(L.key[head]) == ck) break;
+            col = (col + 1) & (uint32_t)(H - 1);
+        }
+        kc = atomicAdd(&L.ph.ccnt[col], 1u);
+    }
+    lds_barrier();
+    if (tid == 0) atomicAdd(&cnt->num_columns, L.n_cols);
+    // The rows of a column are staged NEXT TO EACH OTHER, in first-seen order: every column reserves its rows inside the bucket.
+    // The ordering pass then works per column (one lookup of the column's place instead of one per node) and the emit pass
+    // gathers runs of rows.  The same reservation places the columns' node arrays.
+    for (int c = tid; c < H; c += T) {              // (one LDS atomic per column: the columns' order inside the bucket is free)
+        const uint32_t v = L.ph.ccnt[c];
+        if (v) L.ph.ccnt[c] = (atomicAdd(&L.row_cursor, v) << 16) | v;
+    }
+    lds_barrier();
+    uint32_t cinfo = 0;
+    if (live) {
+        cinfo = L.ph.ccnt[col];
+        L.ph.colnodes[(cinfo >> 16) + kc] = make_uint4(my_first, (uint32_t)sz, __float_as_uint(cz), s);
+    }
+    if (tid == T - 1) L.stage_base = stage_base_reg;      // (the reservation's answer: waited for here, by one thread)
+    lds_barrier();
     GNDT_STAMP3(3);
+    const uint32_t sbase = L.stage_base;
+    if (sbase + M > stage_cap) {                   // uniform: the staging rows ran out, the build is re-run with more
+        if (tid == 0) atomicAdd(&pc->stage_overflow, M);
+        return;
+    }
+
+    // ---- rows: slope label (OcNode::isSlope, map2D.h:66-108), index in column, column size and first-seen index by
+    //      walking the column's short array; the node's record ----
+    uint32_t my_slopes = 0;
+    if (live) {
+        const int za = level_above(sz), zb = level_below(sz);
+        uint32_t icol = 0, cf = 0xFFFFFFFFu;
+        bool up = false, down = false;
+        const uint32_t cbase = cinfo >> 16;
+        const uint32_t ncol = cinfo & 0xFFFFu;
+        uint32_t fl = (my_n >= (uint32_t)P.min_points) ? 1u : 0u;
+        // Tall columns (walls: dozens of levels) look their two z neighbours up in the node index — two short probes — and walk
+        // the column only for what needs every node of it (index in column, the column's first-seen index): three instructions
+        // per node instead of ten.  Short columns find the neighbours during the walk, as before.
+        const bool tall = ncol > (uint32_t)GNDT_TALL_COLUMN;
+        if (tall) {
+#pragma unroll
+            for (int side = 0; side < 2; ++side) {
+                const int tz = side == 0 ? za : zb;
+                uint32_t hs, hf;
+                node_index_hash(sx, sy, tz, fp_mask, hs, hf);
+                const uint32_t t = lds_index_find<H>(L, hs & (4u * (uint32_t)H - 1u), hf, pack_key(sx, sy, tz));
+                if (t != kNoNode) {
+                    const float oz2 = (L.first[t] < my_first) ? L.ph.mz[t] : 0.f;            // "visited": seen earlier AND has statistics
+                    const bool far = fabsf(oz2 - cz) > P.slope_interval;
+                    if (side == 0) up = far; else down = far;
+                }
+            }
+            for (uint32_t k0 = 0; k0 < ncol; k0 += 4) {
+                uint32_t tf[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) tf[j] = L.ph.colnodes[cbase + min(k0 + (uint32_t)j, ncol - 1u)].x;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (k0 + (uint32_t)j < ncol) { cf = min(cf, tf[j]); icol += (tf[j] < my_first) ? 1u : 0u; }
+            }
+        } else
+        for (uint32_t k0 = 0; k0 < ncol; k0 += 4) {         // four independent loads in flight, then their four nodes
+            uint4 rr[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) rr[j] = L.ph.colnodes[cbase + min(k0 + (uint32_t)j, ncol - 1u)];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint4 r = rr[j];                      // {first-seen, z level, mean z or 0, node slot}
+                const uint32_t tf = r.x;
+                if (k0 + (uint32_t)j < ncol && tf != my_first) {     // (first-seen indices of distinct nodes are distinct points)
+                    cf = min(cf, tf);
+                    icol += (tf < my_first) ? 1u : 0u;
+                    const int tz = (int)r.y;
+                    if (tz == za || tz == zb) {
+                        const float oz2 = (tf < my_first) ? __uint_as_float(r.z) : 0.f;     // "visited": seen earlier AND has statistics
+                        const bool far = fabsf(oz2 - cz) > P.slope_interval;
+                        if (tz == za) up = up || far; else down = down || far;
+                    }
+                }
+            }
+        }
+        cf = min(cf, my_first);
+        if (fl) {
+            bool slope = true;
+            if (P.demand == 0) slope = !up; else down = false;
+            if (slope) { fl |= 2u; if (down) fl |= 4u; ++my_slopes; }
+        }
+        RawNode row;
+        row.key = key; row.count = my_n; row.first = my_first;
+#pragma unroll
+        for (int j = 0; j < 9; ++j) row.sum[j] = sums[j];
+        row.info = fl | (icol << 3);
+        row.ncol = ncol;
+        const uint32_t dst = sbase + cbase + icol;
+        stage[dst] = row;
+        ord_cf[dst] = cf;
+        ord_idx[dst] = icol ? icol : (kOrdHeadFlag | ncol);       // (a column's first row carries the column's size)
+        if (icol == 0) note_column(O, cf, ncol);
+    }
+    // counters: aggregated in LDS, ONE memory-side atomic per bucket and counter
+    if (my_slopes) atomicAdd(&L.n_slopes, my_slopes);
+    lds_barrier();
+    if (tid == 0 && L.n_slopes) atomicAdd(&cnt->num_slopes, L.n_slopes);
     GNDT_STAMP3(4);
 #undef GNDT_STAMP3
 }
 
-// Bucket b, b + gridDim.x, ...  With 512-slot tables two 512-thread workgroups share a CU (four waves per SIMD); the 1024-slot
-// variant (second pass, node-heavy clouds) runs one 1024-thread workgroup per CU.
-// raw / binfo (STATS = false): the bucket's nodes as RawNode records and {first record, nodes} per bucket.  A first-pass bucket b
-// owns records b * H .. b * H + H - 1; the i-th bucket of the second pass (todo_list) the H records from raw_tail + i * H on —
-// raw_cap bounds both (a second pass with more buckets than the host left room for raises lds_overflow: the build is re-run).
-// STATS = true: raw_cap is the capacity of the statistics arrays.
-template <int T, int H, bool STATS = false>
-__global__ void __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(H <= 512 ? GNDT_DIRECT_WAVES : 4, H <= 512 ? GNDT_DIRECT_WAVES : 4))) k_bucket_direct(const float4* __restrict__ recs, BucketRanges ranges, uint32_t num_buckets, GridParams P,
-                                                     RawNode* __restrict__ raw, uint32_t raw_tail, uint32_t raw_cap, uint2* __restrict__ binfo,
+// Bucket b, b + gridDim.x, ...  With 512-slot tables two 512-thread workgroups share a CU (61 KB of LDS each, four waves per
+// SIMD); the 1024-slot variant (retries, node-heavy clouds) runs one 1024-thread workgroup per CU.
+// UREC / WAVES (512-slot tables): two records per thread and iteration at four waves per SIMD (128 registers, two workgroups per CU:
+// adjacent records of one node are added as ONE contribution — what clouds with locality live on), or one record at six waves per
+// SIMD (80 registers, THREE workgroups per CU): the host takes the second for clouds whose neighbouring records rarely share a node.
+template <int T, int H, bool STATS = false, int UREC = 2, int WAVES = 4>
+__global__ void __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) k_bucket_direct(const float4* __restrict__ recs, BucketRanges ranges, uint32_t num_buckets, GridParams P,
+                                                     RawNode* __restrict__ stage, uint32_t stage_cap,
+                                                     uint32_t* __restrict__ ord_cf, uint32_t* __restrict__ ord_idx, ColumnOrder O,
                                                      Counters* __restrict__ cnt, PartCounters* __restrict__ pc,
                                                      unsigned long long* __restrict__ dbg, StatsOut so, uint32_t fp_mask, uint32_t interleave,
                                                      uint32_t* __restrict__ retry_list, const uint32_t* __restrict__ todo_list) {
@@ -591,253 +746,10 @@ __global__ void __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(H <= 512
     const uint32_t count = todo_list ? min(pc->lds_retry, num_buckets) : num_buckets;
     for (uint32_t i = blockIdx.x; i < count; i += gridDim.x) {
         const uint32_t bucket = todo_list ? todo_list[i] : i;
-        const uint32_t raw_base = (todo_list ? raw_tail : 0u) + i * (uint32_t)H;
-        if (!STATS && raw_base + (uint32_t)H > raw_cap) {          // (uniform) no room left for this second-pass bucket's records
-            if (threadIdx.x == 0) { atomicAdd(&pc->lds_overflow, 1u); binfo[bucket] = make_uint2(0u, 0u); }
-            continue;
-        }
         uint32_t lo, hi;
         bucket_range(ranges, bucket, lo, hi);
-        bucket_direct_one<T, H, STATS>(L, bucket, recs, lo, hi, P, raw, raw_base, raw_cap, binfo, cnt, pc, dbg, so, fp_mask, interleave, retry_list);
+        bucket_direct_one<T, H, STATS, UREC>(L, bucket, recs, lo, hi, P, stage, stage_cap, ord_cf, ord_idx, O, cnt, pc, dbg, so, fp_mask, interleave, retry_list);
         lds_barrier();          // the LDS tables are re-initialised by the next bucket
-    }
-}
-
-// ------------------------------------------------------------------------------------------------------------------------------
-// k_bucket_columns: the columns of a bucket, the slope labels, the order keys — what k_bucket_direct did after its accumulate phase
-// until round 5, as a kernel of its own (one workgroup per bucket, ONE node per thread, its state in registers across the barriers).
-//
-//   load     : key, count, first-seen index and sum v_z of the bucket's nodes (32 of a record's 96 bytes)
-//   columns  : keyless column table (a slot holds a node of the column); every node takes a number in its column; every column
-//              reserves its rows inside the bucket and gets an ARRAY of 16-byte records {first-seen, z level, fp32 mean z, node}
-//   rows     : slope label (OcNode::isSlope, map2D.h:66-108) and index in column from one walk of the column's array (columns of
-//              more than GNDT_TALL_COLUMN nodes find their two z neighbours through a hash of the bucket's nodes instead)
-//   out      : a column's rows NEXT TO EACH OTHER, in first-seen order, INSIDE THE BUCKET'S OWN RECORD SLOTS (staging row = record slot:
-//              nothing is reserved, no returning atomic): ord_cf (the column's first-seen index), ord_idx (the order word the ordering
-//              pass places by), lk = {record << 3 | flags, order word} — what k_emit_rows gathers by — and the column's vote in the
-//              bitmap / word weights (note_column).  Slots of the bucket that hold no node get the order word 0.  Column and slope counts go to
-//              one of 64 sub-counters (a first version added them to the three words of Counters: 8 331 atomics on one line, 92 us).
-//
-// 24 KB of LDS at H = 512: four 512-thread workgroups per CU — the dependent LDS round trips of these phases (eight of them) queue
-// behind nothing here, where inside k_bucket_direct each waited for the other workgroup's bursts of fp64 atomics (~1 k cycles).
-template <int H>
-struct ColumnsLds {
-    unsigned long long key[H];
-    uint4 colnodes[H];          // the nodes of every column as an ARRAY (column c at ccnt[c] >> 16): {first-seen, z level, mean z or 0, node}
-    float mz[H];                // (tall columns look their z neighbours up by node number)
-    uint32_t first[H];
-    uint32_t chead[H];          // column table: a node of the column (its key is the column's key: no separate column keys), kNoNode = free
-    uint32_t ccnt[H];           // nodes of the column in this column slot; after the prefix (first row inside the bucket) << 16 | nodes
-    uint32_t nidx[2 * H];       // tall columns only: open-addressing index of the bucket's nodes (node + 1; 0 = free)
-    uint32_t n_cols, n_slopes, row_cursor, any_tall;
-};
-
-__device__ __forceinline__ uint32_t columns_node_slot(int sx, int sy, int sz, uint32_t mask) {
-    uint32_t slot, fpw;
-    node_index_hash(sx, sy, sz, 0x1FFFFFu, slot, fpw);
-    return (slot ^ (fpw >> 13)) & mask;
-}
-
-template <int T, int H>
-__global__ void __launch_bounds__(T) k_bucket_columns(const RawNode* __restrict__ raw, const uint2* __restrict__ binfo, uint32_t num_buckets, GridParams P,
-                                                      uint32_t* __restrict__ ord_cf, uint32_t* __restrict__ ord_idx, uint2* __restrict__ lk, ColumnOrder O,
-                                                      PartCounters* __restrict__ pc, const uint32_t* __restrict__ todo_list, uint32_t raw_tail, uint32_t raw_cap,
-                                                      unsigned long long* __restrict__ dbg) {
-    // todo_list: the buckets of the bucket kernel's second pass (the i-th one's H record slots start at raw_tail + i * H); without it:
-    // every bucket b with its slots b * H .. — also the ones that hold nothing (an empty bucket, one the second pass took over):
-    // their slots get the order word 0
-    static_assert(H <= T, "one node per thread");
-    static_assert(H <= 65535, "rows inside a bucket are kept in 16 bits");
-    __shared__ ColumnsLds<H> L;
-    const int tid = threadIdx.x;
-    const uint32_t count = todo_list ? min(pc->lds_retry, num_buckets) : num_buckets;
-    if (pc->lds_overflow | pc->part_overflow) return;          // (the build is re-run: nothing of it is read)
-    // Persistent workgroups (four per CU), software-pipelined: a bucket's part of this kernel is a chain of latencies — its entry and
-    // records from memory (~2 us), eight LDS round trips, the stores — so the NEXT bucket's loads are in flight while this one is
-    // worked on (round 6: one workgroup per bucket took 32 us for the bench scene's 2 777 buckets, ~10 us each whatever their number).
-    // The records are asked for without waiting for the bucket's node count: slots beyond it hold nothing and are not looked at.
-    const uint32_t tail0 = todo_list ? raw_tail : 0u;
-    uint2 info_n = make_uint2(0xFFFFFFFFu, 0u);
-    uint4 head_n = make_uint4(0u, 0u, 0u, 0u);
-    double sumz_n = 0.0;
-    uint32_t bucket_n = 0;
-    auto prefetch = [&](uint32_t b_i) {
-        bucket_n = todo_list ? todo_list[b_i] : b_i;
-        const uint32_t b_base = tail0 + b_i * (uint32_t)H;
-        info_n = make_uint2(0xFFFFFFFFu, 0u);
-        if (b_base + (uint32_t)H <= raw_cap) {                   // (uniform; beyond: the bucket kernel has raised lds_overflow for this bucket)
-            // (a vector load, although the address is uniform: a scalar load would be waited for by the next LDS barrier — lgkmcnt —
-            //  and the point of asking early is not to wait)
-            const uint2* pb = binfo + bucket_n;
-            asm volatile("" : "+v"(pb));
-            info_n = *pb;
-            if (tid < H) {
-                const RawNode* __restrict__ r = raw + (size_t)b_base + (uint32_t)tid;
-                head_n = *reinterpret_cast<const uint4*>(r);                  // {key lo, key hi, count, first}
-                sumz_n = r->sum[2];
-            }
-        }
-    };
-    uint32_t bi = blockIdx.x;
-    if (bi < count) prefetch(bi);
-    for (; bi < count; bi += gridDim.x) {
-        const uint32_t bucket = bucket_n;
-        const uint32_t base = tail0 + bi * (uint32_t)H;          // this bucket's H slots
-        const uint2 info = info_n;
-        const uint4 head = head_n;
-        const double sum_z = sumz_n;
-        if (bi + gridDim.x < count) prefetch(bi + gridDim.x);    // (uniform)
-#define GNDT_CSTAMP(k) do { if (dbg && tid == 0) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); if (k) dbg[(size_t)bucket * 16 + 7 + (k)] = t_ - cst; cst = t_; } } while (0)
-        unsigned long long cst = 0;
-        GNDT_CSTAMP(0);
-        if (info.x == 0xFFFFFFFFu && info.y == 0u) continue;    // (no room for this second-pass bucket: see above)
-        const uint32_t M = info.x == base ? info.y : 0u;        // (another base: the second pass took the bucket over — nothing here)
-        if (M == 0u) {                                          // uniform
-            for (int c = tid; c < H; c += T) { lk[base + (uint32_t)c] = make_uint2(0u, 0u); ord_idx[base + (uint32_t)c] = 0u; }
-            continue;
-        }
-        const bool live = (uint32_t)tid < M;
-        const uint32_t s = (uint32_t)tid;
-        uint64_t key = 0;
-        int sx = 0, sy = 0, sz = 0;
-        uint32_t my_n = 0, my_first = 0xFFFFFFFFu, col = 0, kc = 0;
-        float cz = 0.f;
-        for (int c = tid; c < H; c += T) { L.chead[c] = kNoNode; L.ccnt[c] = 0u; L.nidx[c] = 0u; L.nidx[c + H] = 0u; }
-        if (tid == 0) { L.n_cols = 0; L.n_slopes = 0; L.row_cursor = 0; L.any_tall = 0; }
-        if (live) {
-            key = (uint64_t)head.x | ((uint64_t)head.y << 32);
-            my_n = head.z; my_first = head.w;
-            unpack_key(key, sx, sy, sz);
-            cz = (my_n >= (uint32_t)P.min_points) ? node_mean_z(my_n, sum_z, axis_centre(sz, P.oz, P.z_len)) : 0.f;
-            L.key[s] = key; L.mz[s] = cz; L.first[s] = my_first;
-        }
-        lds_barrier();          // (LDS only: the next bucket's loads stay in flight)
-        GNDT_CSTAMP(1);
-        // ---- columns: every node finds the slot of its column and takes a number in it ----
-        if (live) {
-            const uint64_t ck = column_key(key);
-            col = ((column_hash(sx, sy) * 0x85EBCA77u) >> 12) & (uint32_t)(H - 1);
-            for (int probe = 0; probe < H; ++probe) {            // (terminates: the table has as many slots as a bucket has nodes at most)
-                uint32_t head = L.chead[col];
-                if (head == kNoNode) {
-                    head = atomicCAS(&L.chead[col], kNoNode, s);
-                    if (head == kNoNode) { atomicAdd(&L.n_cols, 1u); break; }                           // first node of a new column
-                }
-                if (column_key(L.key[head]) == ck) break;
-                col = (col + 1) & (uint32_t)(H - 1);
-            }
-            kc = atomicAdd(&L.ccnt[col], 1u);
-        }
-        lds_barrier();
-        // every column reserves its rows inside the bucket (one LDS atomic per column: the columns' order inside the bucket is free)
-        for (int c = tid; c < H; c += T) {
-            const uint32_t v = L.ccnt[c];
-            if (v) { L.ccnt[c] = (atomicAdd(&L.row_cursor, v) << 16) | v; if (v > (uint32_t)GNDT_TALL_COLUMN) L.any_tall = 1u; }
-        }
-        lds_barrier();
-        uint32_t cinfo = 0;
-        if (live) {
-            cinfo = L.ccnt[col];
-            L.colnodes[(cinfo >> 16) + kc] = make_uint4(my_first, (uint32_t)sz, __float_as_uint(cz), s);
-        }
-        const bool any_tall = L.any_tall != 0u;                // (uniform: written before the last barrier)
-        if (any_tall && live) {                                // the bucket's nodes by key: what a node of a tall column finds its z neighbours through
-            uint32_t h0 = columns_node_slot(sx, sy, sz, 2u * (uint32_t)H - 1u);
-            for (int probe = 0; probe < 2 * H; ++probe) {
-                if (atomicCAS(&L.nidx[h0], 0u, s + 1u) == 0u) break;
-                h0 = (h0 + 1u) & (2u * (uint32_t)H - 1u);
-            }
-        }
-        lds_barrier();
-        GNDT_CSTAMP(2);
-        // ---- rows: slope label (OcNode::isSlope, map2D.h:66-108), index in column, column size and first-seen index ----
-        uint32_t my_slopes = 0;
-        if (live) {
-            const int za = level_above(sz), zb = level_below(sz);
-            uint32_t icol = 0, cf = 0xFFFFFFFFu;
-            bool up = false, down = false;
-            const uint32_t cbase = cinfo >> 16;
-            const uint32_t ncol = cinfo & 0xFFFFu;
-            uint32_t fl = (my_n >= (uint32_t)P.min_points) ? 1u : 0u;
-            // Tall columns (walls: dozens of levels) look their two z neighbours up in the node index — two short probes — and walk
-            // the column only for what needs every node of it (index in column, the column's first-seen index): three instructions
-            // per node instead of ten.  Short columns find the neighbours during the walk.
-            const bool tall = ncol > (uint32_t)GNDT_TALL_COLUMN;
-            if (tall) {
-#pragma unroll
-                for (int side = 0; side < 2; ++side) {
-                    const int tz = side == 0 ? za : zb;
-                    const unsigned long long tk = pack_key(sx, sy, tz);
-                    uint32_t h0 = columns_node_slot(sx, sy, tz, 2u * (uint32_t)H - 1u);
-                    for (int probe = 0; probe < 2 * H; ++probe) {
-                        const uint32_t e = L.nidx[h0];
-                        if (e == 0u) break;
-                        const uint32_t t = e - 1u;
-                        if (L.key[t] == tk) {
-                            const float oz2 = (L.first[t] < my_first) ? L.mz[t] : 0.f;            // "visited": seen earlier AND has statistics
-                            const bool far = fabsf(oz2 - cz) > P.slope_interval;
-                            if (side == 0) up = far; else down = far;
-                            break;
-                        }
-                        h0 = (h0 + 1u) & (2u * (uint32_t)H - 1u);
-                    }
-                }
-                for (uint32_t k0 = 0; k0 < ncol; k0 += 4) {
-                    uint32_t tf[4];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) tf[j] = L.colnodes[cbase + min(k0 + (uint32_t)j, ncol - 1u)].x;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        if (k0 + (uint32_t)j < ncol) { cf = min(cf, tf[j]); icol += (tf[j] < my_first) ? 1u : 0u; }
-                }
-            } else
-            for (uint32_t k0 = 0; k0 < ncol; k0 += 4) {         // four independent loads in flight, then their four nodes
-                uint4 rr[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) rr[j] = L.colnodes[cbase + min(k0 + (uint32_t)j, ncol - 1u)];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const uint4 r = rr[j];                      // {first-seen, z level, mean z or 0, node slot}
-                    const uint32_t tf = r.x;
-                    if (k0 + (uint32_t)j < ncol && tf != my_first) {     // (first-seen indices of distinct nodes are distinct points)
-                        cf = min(cf, tf);
-                        icol += (tf < my_first) ? 1u : 0u;
-                        const int tz = (int)r.y;
-                        if (tz == za || tz == zb) {
-                            const float oz2 = (tf < my_first) ? __uint_as_float(r.z) : 0.f;     // "visited": seen earlier AND has statistics
-                            const bool far = fabsf(oz2 - cz) > P.slope_interval;
-                            if (tz == za) up = up || far; else down = down || far;
-                        }
-                    }
-                }
-            }
-            cf = min(cf, my_first);
-            if (fl) {
-                bool slope = true;
-                if (P.demand == 0) slope = !up; else down = false;
-                if (slope) { fl |= 2u; if (down) fl |= 4u; ++my_slopes; }
-            }
-            const uint32_t dst = base + cbase + icol;
-            ord_cf[dst] = cf;
-            const uint32_t ow = icol ? icol : (kOrdHeadFlag | ncol);       // (a column's first row carries the column's size)
-            ord_idx[dst] = ow;                                              // what the ordering pass walks ...
-            lk[dst] = make_uint2(((base + s) << kLinkFlagBits) | fl, ow);   // ... and what the emit pass gathers by
-            if (icol == 0) note_column(O, cf, ncol);
-        } else if (tid < H) {
-            ord_idx[base + s] = 0u;                                         // (a slot without a node: no column head)
-        }
-        // counters: aggregated in LDS, one memory-side atomic per bucket and counter, on one of 64 lines
-        GNDT_CSTAMP(3);
-        if (my_slopes) atomicAdd(&L.n_slopes, my_slopes);
-        lds_barrier();
-        if (tid == 0) {
-            uint32_t* const sub = part_sub(pc) + (bucket & (kSubCounters - 1u)) * kSubStride;
-            atomicAdd(&sub[0], L.n_cols);
-            if (L.n_slopes) atomicAdd(&sub[1], L.n_slopes);
-        }
-        lds_barrier();          // (the tables are re-initialised by the next bucket)
-        GNDT_CSTAMP(4);
-#undef GNDT_CSTAMP
     }
 }
 

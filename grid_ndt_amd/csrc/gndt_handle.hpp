@@ -141,13 +141,11 @@ struct gndt_handle {
         double fill1_ratio = 0.0;   // fullest level-1 region / mean seen on this handle (0 = unknown)
         uint64_t hist_cap = 0;     uint32_t* hist = nullptr;
         uint32_t bucket_cap = 0;   uint32_t* totals = nullptr; uint32_t* bucket_base = nullptr;
-        uint64_t stage_cap = 0;    StageRow* stage = nullptr;    // stage_cap: dense staging rows the order arrays below can hold ...
+        uint64_t stage_cap = 0;    StageRow* stage = nullptr;    // stage_cap: staging rows the order arrays below can hold ...
         uint64_t stage_rows_cap = 0;                             // ... and how many StageRow records `stage` holds (the table / TILE / statistics paths;
                                                                  //     the PARTITION strategies stage RawNode records in `raw` instead and never grow it)
+        RawNode* raw = nullptr;  uint64_t raw_cap = 0;          // k_bucket_direct's staging rows (dense, a column's rows adjacent)
         uint32_t *ord_cf = nullptr, *ord_idx = nullptr, *inv = nullptr;
-        uint2* lk = nullptr;               // [stage_cap] k_bucket_columns: {record << 3 | flags, order word} of every staging row (= record slot)
-        RawNode* raw = nullptr;  uint64_t raw_cap = 0;          // k_bucket_direct's nodes: bucket b at b * slots, second-pass buckets behind them
-        uint2* binfo = nullptr;            // [cur_cap] per bucket {first record, nodes}
         uint32_t* row_of = nullptr;        // [stage_cap] row of every staged node (table path: the incremental finalisation emits in place)
         uint32_t* row_ncol = nullptr; uint64_t row_ncol_cap = 0;     // per result row: its column's node count on the column's first row, else 0
         // column order (gndt_partition.hpp ColumnOrder): per bitmap word, and per point index for ncol_at
@@ -229,6 +227,9 @@ struct gndt_handle {
     // strategy AUTO: what the locality sample said last time, for which cloud size, and how many builds ago
     int tile_choice = -1;  uint64_t tile_choice_n = 0;  int tile_choice_age = 0;  double tile_ratio_seen = 0.0;
     unsigned long long* d_sample = nullptr;  unsigned long long* h_sample = nullptr;   // k_tile_sample's two counters (pinned copy)
+    // a locality sample whose answer has not been looked at yet (round 6: a build on a handle that already has room for any answer does
+    // not wait for it — the build it rides in front of takes the handle's last choice, the next one finds the answer)
+    bool sample_pending = false;  uint64_t sample_n = 0;  hipEvent_t sample_ev = nullptr;
     uint32_t* d_sketch = nullptr;  uint32_t* h_sketch = nullptr;                        // k_node_sketch's HyperLogLog registers (pinned copy)
     bool map_in_table = true;   // false after a PARTITION build: the HBM node table does not hold the map
 
@@ -255,7 +256,6 @@ struct gndt_handle {
         bool retry_pass = false;        //   ... and the bucket kernel's second pass behind the first (overflowing 512-slot tables done again with 1024)
         double mean1 = 0.0;             // its mean level-1 region fill (to turn the fullest region into a ratio)
         bool stats_only = false;        // gndt_shard_stats_device: statistics out, no labels / ordering / rows
-        uint32_t raw_first = 0, raw_retry_room = 0;   // record slots of this attempt: buckets x table slots, and the second pass's buckets (1024 each)
         uint64_t captured_gen = 0;      // Handle::realloc_gen when this build was recorded (captured builds only)
         bool captured = false;          // launched on a stream under hipGraph capture: it runs when the graph is replayed, with the
                                         //   buffers it was recorded with — never re-run here with more room (new buffers: the graph holds the old)
@@ -300,6 +300,10 @@ struct Tuning {
                                  //   (200 k-point campus frame 0.0549 -> 0.0535 ms, bridge_ground 0.0647 -> 0.0646: r05 ablation 6h)
     int small_tiles = 1;         // one-level partition of < 1 M points: 1024-point level-1 tiles (a few hundred workgroups instead of a few dozen:
                                  //   campus frame 0.0535 -> 0.0520 ms, bridge_ground 0.0648 -> 0.0608; r05 ablation 6i)
+#ifndef GNDT_THREE_WGS
+#define GNDT_THREE_WGS 1
+#endif
+    int bucket_three_wgs = GNDT_THREE_WGS;    // clouds without locality: the bucket kernel with one record per thread at three workgroups per CU (round 6)
     int fp_bits = 21;            // bits of the bucket kernel's index fingerprint (tests narrow it through gndt_debug_set_fp_bits to force clashes)
     // ... and what gndt_debug_set_option / gndt_debug_enable_stamps can set (process-wide; the library reads no environment variable)
     double tile_ratio = 48.0;    // GNDT_DEBUG_TILE_RATIO   AUTO takes strategy TILE from this many points per partial on (sampled; the
@@ -436,13 +440,13 @@ int table_emit_pending(gndt_handle* h);    // deferred-emit mode: the ordering +
 int build_atomic(gndt_handle* h, const void* xyz_dev, size_t n, size_t stride_bytes, hipStream_t s, bool tile = false,
                  const gndt_handle::Pending* rec = nullptr);
 int locality_sample(gndt_handle* h, const void* xyz_dev, size_t n, size_t stride_bytes, uint32_t tiles, double* ratio, hipStream_t s);
+int locality_sample_begin(gndt_handle* h, const void* xyz_dev, size_t n, size_t stride_bytes, uint32_t tiles, hipStream_t s);   // launched, not awaited
+bool locality_sample_take(gndt_handle* h, bool wait, double* ratio);                                                          // its answer, if there is one
 int sketch_nodes(gndt_handle* h, const void* xyz_dev, size_t n, size_t stride_bytes, hipStream_t s, uint64_t* estimate);   // HyperLogLog over the node keys (waits)
 // ---- gndt_api_build.hip ----
 // tab_end: the table path's end-of-frame bookkeeping (k_tab_end + `advance` points of stream position) done by k_emit_rows
 // partial: incremental finalisation — only rows from the first changed column on are placed and gathered again, touched rows in
 //          front of it are emitted where they are (k_order_dest / k_emit_rows, gndt_partition.hpp)
-// grouped: the staging rows are k_bucket_columns' (a column's rows adjacent; link words; RawNode records): the caller has set mark
-//          m0 + 1 behind that kernel, the scan's mark is m0 + 2
 int launch_order_and_emit(gndt_handle* h, uint64_t words, int m0, hipStream_t s, bool grouped = false, bool counters_to_host = false,
                           bool tab_end = false, uint32_t advance = 0, bool partial = false);
 int partition_launch(gndt_handle* h, gndt_handle::Pending& P);

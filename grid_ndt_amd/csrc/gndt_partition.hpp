@@ -55,17 +55,6 @@ struct PartCounters {
     uint32_t lds_retry;        // buckets whose 512-slot table overflowed and that wait for the second pass with 1024 slots (the retry list's length)
 };
 
-// Per-bucket totals that every workgroup of a kernel adds to at about the same time (k_bucket_columns: columns, slopes) go to one of
-// kSubCounters words, each on a line of its own: atomics on ONE word retire at ~90 per us at the memory side (2 777 buckets x 3 counters
-// of one line took 92 us of a 107 us kernel, profiles/r06_ablation.txt), on 64 lines 64 times that.  They live behind the PartCounters
-// (same allocation), are zeroed by k_part_clear and summed by the kernel that sends the counters home (k_emit_rows<true>).
-constexpr uint32_t kSubCounters = 64, kSubStride = 32, kSubOffsetBytes = 128;
-constexpr size_t kPartCountersBytes = kSubOffsetBytes + (size_t)kSubCounters * kSubStride * 4;
-__host__ __device__ __forceinline__ uint32_t* part_sub(const PartCounters* pc) {
-    return reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(const_cast<PartCounters*>(pc)) + kSubOffsetBytes);
-}
-static_assert(sizeof(PartCounters) <= kSubOffsetBytes, "the sub-counters start behind the counters");
-
 struct alignas(16) StageRow {   // 96 bytes, gathered whole by k_emit_rows (round 1 padded it to 128: a quarter of the node traffic)
     int32_t sx, sy, sz;
     uint32_t count, first, flags;
@@ -75,20 +64,18 @@ struct alignas(16) StageRow {   // 96 bytes, gathered whole by k_emit_rows (roun
 };
 static_assert(sizeof(StageRow) == 96, "StageRow layout");
 
-// A node as k_bucket_direct leaves it (round 6): additive statistics in cell-local coordinates, nothing derived yet.  k_bucket_columns
-// reads the first 16 bytes and sum[2]; k_emit_rows gathers the record whole (six 16-byte loads) and works the moments and the
-// eigen-solve out.  link words name a record by its index << 3 | {has statistics, slope, down}.
+// A staging row of the PARTITION strategies (round 6): the node's additive statistics in cell-local coordinates as the bucket kernel's
+// LDS table held them, plus what its column phases found out — nothing derived.  k_emit_rows<true> gathers the record whole (six
+// 16-byte loads) and works mean, scatter and eigen-solve out, chip-wide; until round 5 k_bucket_direct did the moments itself, one
+// node per thread, in its latency-bound back half.
 struct alignas(16) RawNode {
     unsigned long long key;
     uint32_t count, first;
     double sum[9];              // Sum v (3), Sum v v^T upper triangle (6); v = p - centre(node), fp64
-    uint32_t pad[2];
+    uint32_t info;              // flags (bit 0 has statistics, 1 slope, 2 down) | index in column << 3
+    uint32_t ncol;              // nodes of the column
 };
 static_assert(sizeof(RawNode) == 96, "RawNode layout");
-// lk[i] = {link, order word} of staging row i (k_bucket_columns): the order word is ord_idx's (kOrdHeadFlag | column size on a
-// column's first row, the index in the column elsewhere, 0 on a row nobody staged)
-constexpr uint32_t kLinkFlagBits = 3u;
-constexpr uint64_t kMaxRawNodes = 1ull << (32 - kLinkFlagBits);
 
 // What the producer of the staging rows records for every column, at the column's first-seen point index cf (the
 // row with idx_in_col == 0 does it).  The final row of a node is then
@@ -252,8 +239,6 @@ static __global__ void __launch_bounds__(256) k_part_clear(Counters* __restrict_
     }
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < words; i += (uint64_t)gridDim.x * blockDim.x) { bitmap[i] = 0u; word_weight[i] = 0u; }
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_cursors; i += gridDim.x * blockDim.x) cursors[i] = 0u;   // two-level partition
-    uint32_t* const sub = part_sub(pc);
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < kSubCounters * kSubStride; i += gridDim.x * blockDim.x) sub[i] = 0u;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -850,18 +835,14 @@ constexpr uint32_t kOrdHeadFlag = 0x80000000u;
 // prefix of the word weights out for itself, in LDS (word_weight, words), and looks the word bases up there; workgroup 0 leaves
 // them in word_base as the scan launches would have.  A 200 k-point frame is seven launches of 4-25 us each, two of them the scan.
 constexpr uint32_t kDestScanMax = 1u << 13;
-// LINK (k_bucket_columns' output): the staging rows are the bucket kernel's record slots (see below).
-template <bool SCAN, bool LINK = false>
+template <bool SCAN>
 static __global__ void __launch_bounds__(kBlock) k_order_dest_columns(const uint32_t* __restrict__ ord_cf, const uint32_t* __restrict__ ord_idx,
                                                                       const uint32_t* __restrict__ bitmap, uint32_t* __restrict__ word_base,
                                                                       const uint32_t* __restrict__ ncol_at, uint32_t* __restrict__ inv,
                                                                       const Counters* __restrict__ cnt, const PartCounters* __restrict__ pc,
-                                                                      const uint32_t* __restrict__ word_weight, uint32_t words,
-                                                                      uint32_t slots_first = 0, uint32_t retry_room = 0) {
+                                                                      const uint32_t* __restrict__ word_weight, uint32_t words) {
     if (pc->lds_overflow | pc->stage_overflow | pc->index_overflow | pc->part_overflow) return;
-    // LINK: the staging rows are the bucket kernel's record slots — bucket b's from b * H on, the second pass's behind slots_first —
-    // and a slot nobody staged carries the order word 0 (no column head: skipped below)
-    const uint32_t n = LINK ? slots_first + min(pc->lds_retry, retry_room) * 1024u : cnt->num_nodes;
+    const uint32_t n = cnt->num_nodes;
     __shared__ uint32_t s_base[SCAN ? kDestScanMax : 1];
     __shared__ uint32_t s_wave[kBlock / 64];
     if (SCAN) {
@@ -960,29 +941,17 @@ struct EmitPartial {
     const uint32_t* touched;
 };
 
-// RAW (the PARTITION strategies, round 6): inv holds link words, `stage` is the RawNode array — mean, scatter and eigen-solve from the
-// node's additive statistics here, where the whole chip works on them; row_ncol is the ordering pass's (k_order_dest_columns<., true>).
+// RAW (the PARTITION strategies, round 6): `stage` is an array of RawNode records — mean, scatter and eigen-solve from the node's
+// additive statistics here, where the whole chip works on them.
 template <bool RAW = false>
 static __global__ void __launch_bounds__(kBlock) k_emit_rows(const StageRow* __restrict__ stage, const uint32_t* __restrict__ inv,
                                                       OutView out, uint32_t* __restrict__ row_ncol,
                                                       const Counters* cnt, const PartCounters* __restrict__ pc,
                                                       Counters* __restrict__ host_cnt, PartCounters* __restrict__ host_pc,
                                                       Counters* tab_cnt, uint32_t advance, EmitPartial part, uint32_t capture_id,
-                                                      GridParams P, const uint2* __restrict__ lk, uint32_t out_cap) {
+                                                      GridParams P) {
     // (cnt is NOT __restrict__: on the table path tab_cnt points at the same object and lane 0 writes through it below)
     if (blockIdx.x == 0 && threadIdx.x < 2) {
-        if constexpr (RAW) {
-            // columns and slopes were counted per bucket into the sub-counters (gndt_partition.hpp kSubCounters): their sums are the
-            // totals; and a map of more rows than the result arrays hold is reported (the build is re-run with more), not written
-            if (threadIdx.x == 0) {
-                const uint32_t* sub = part_sub(pc);
-                uint32_t nc = 0, ns = 0;
-                for (uint32_t k = 0; k < kSubCounters; ++k) { nc += sub[k * kSubStride]; ns += sub[k * kSubStride + 1]; }
-                Counters* wc_ = const_cast<Counters*>(cnt);
-                wc_->num_columns = nc; wc_->num_slopes = ns;
-            }
-            if (threadIdx.x == 1 && cnt->num_nodes > out_cap) const_cast<PartCounters*>(pc)->stage_overflow = cnt->num_nodes;
-        }
         if (threadIdx.x == 0 && host_cnt) *host_cnt = *cnt;
         if (threadIdx.x == 1 && host_pc) { *host_pc = *pc; host_pc->capture_id = capture_id; }
         // Table path (gndt_update*): the end-of-frame bookkeeping rides here as well — how many nodes own a column entry, the
@@ -998,7 +967,6 @@ static __global__ void __launch_bounds__(kBlock) k_emit_rows(const StageRow* __r
     }
     if (pc->lds_overflow | pc->stage_overflow | pc->index_overflow | pc->part_overflow) return;
     const uint32_t n = cnt->num_nodes;
-    if (RAW && n > out_cap) return;
     uint32_t r0 = 0;
     if (part.word_base) {
         const uint32_t w0 = cnt->first_word;
@@ -1021,23 +989,19 @@ static __global__ void __launch_bounds__(kBlock) k_emit_rows(const StageRow* __r
     //  two dependent round trips each — index, then row)
     const uint32_t rb_first = r0 + blockIdx.x * blockDim.x + (threadIdx.x & ~63u);
     uint32_t src_next = (rb_first + (uint32_t)lane) < n ? inv[rb_first + (uint32_t)lane] : 0u;
-    // RAW: three dependent gathers per row — staging row, its {link, order word}, the record; the first two are asked for an iteration ahead
-    uint2 e_next = make_uint2(0u, 0u);
-    if (RAW && (rb_first + (uint32_t)lane) < n) e_next = lk[src_next];
     for (uint32_t rb = rb_first; rb < n; rb += gridDim.x * blockDim.x) {   // (wave-uniform)
         const uint32_t r = rb + (uint32_t)lane;
         const uint32_t src = src_next;
-        const uint2 e = e_next;
-        { const uint32_t rn = r + gridDim.x * blockDim.x; src_next = rn < n ? inv[rn] : 0u; if (RAW && rn < n) e_next = lk[src_next]; }
+        { const uint32_t rn = r + gridDim.x * blockDim.x; src_next = rn < n ? inv[rn] : 0u; }
         if (r < n) {
             if constexpr (RAW) {
-                const RawNode rec = reinterpret_cast<const RawNode*>(stage)[e.x >> kLinkFlagBits];      // (the 96-byte record in one piece)
-                const uint32_t fl = e.x & ((1u << kLinkFlagBits) - 1u);
-                row_ncol[r] = (e.y & kOrdHeadFlag) ? (e.y & ~kOrdHeadFlag) : 0u;       // the consumers' column index (gndt_cost.hpp)
+                const RawNode rec = reinterpret_cast<const RawNode*>(stage)[src];      // (the 96-byte record in one piece)
+                const uint32_t fl = rec.info & 7u;
                 int sx, sy, sz;
                 unpack_key(rec.key, sx, sy, sz);
                 out.sx[r] = sx; out.sy[r] = sy; out.sz[r] = sz;
                 out.count[r] = rec.count; out.first_idx[r] = rec.first; out.flags[r] = fl;
+                row_ncol[r] = (rec.info >> 3) == 0u ? rec.ncol : 0u;
                 float mean[3] = {0.f, 0.f, 0.f}, rough = 0.f, normal[3] = {0.f, 0.f, 0.f};
                 double S[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
                 if (fl & 1u) {

@@ -428,9 +428,9 @@ class TwoDmap:
     # ---- phase timing ----
     PHASES = {1: ("clear", "accumulate", "columns", "rows", "bitmap_scan", "rank", "column_scan", "dest", "emit"),
               5: ("clear", "accumulate", "columns", "rows", "bitmap_scan", "rank", "column_scan", "dest", "emit"),
-              2: ("clear", "level1", "layout", "level2", "bucket_build", "columns", "bitmap_scan", "column_scan", "dest", "emit"),
-              3: ("clear", "hist", "offsets", "scatter", "bucket_build", "columns", "bitmap_scan", "column_scan", "dest", "emit"),
-              6: ("clear", "level1", "layout", "ranges", "bucket_build", "columns", "bitmap_scan", "column_scan", "dest", "emit")}
+              2: ("clear", "level1", "layout", "level2", "bucket_build", "bitmap_scan", "rank", "column_scan", "dest", "emit"),
+              3: ("clear", "hist", "offsets", "scatter", "bucket_build", "bitmap_scan", "rank", "column_scan", "dest", "emit"),
+              6: ("clear", "level1", "layout", "ranges", "bucket_build", "bitmap_scan", "rank", "column_scan", "dest", "emit")}
     STRATEGY_NAMES = {1: "atomic", 2: "partition", 3: "partition_exact", 5: "tile", 6: "partition_one_level"}
     # phase -> the kernel that fills it, and what each phase's kernel moves algorithmically (bench.py's roofline line):
     # kernels that stream the cloud 12 B/point, the bucket kernel 12 B/point + 76 B/node, node kernels 76 B/node
