@@ -67,7 +67,7 @@ namespace {
 // otherwise: average load <= 0.5 of `slots` against an estimate that already carries a 20 % margin, i.e. ~0.42 of
 // the slots really used, far below the overflow limit (a table holds `slots` nodes).  (An overflow is not an
 // error: the build is re-run with the larger table / more buckets.)
-uint64_t buckets_for(uint64_t n, uint64_t nodes, int slots, int load_pct) {
+uint64_t buckets_for(uint64_t n, uint64_t nodes, int slots, int load_pct, bool wide = false) {
     const int pts_target = tuning().bucket_points;
     if (pts_target) return std::max<uint64_t>(n / (uint64_t)pts_target, 16);
     // Clouds of up to a few million points do not fill the chip with 2800-point buckets (200 k points: 71 workgroups for 256
@@ -76,7 +76,10 @@ uint64_t buckets_for(uint64_t n, uint64_t nodes, int slots, int load_pct) {
     // Round 4: 3600 (was 2800) for clouds that fill the chip either way — with the fingerprint index a bucket's accumulate phase
     // is shorter and the per-bucket phases weigh more: bench scene 2000 / 2400 / 2800 / 3072 / 3600 / 4000 points per bucket:
     // 0.418 / 0.399 / 0.393 / 0.383 / 0.372 / 0.385 ms per build (node-heavy clouds get their bucket count from the nodes, below).
-    const uint64_t small_cloud = std::min<uint64_t>(3600, std::max<uint64_t>(700, n / 1024));
+    // Round 6: 4000 for the three-workgroups-per-CU kernel (`wide`: one record per thread, 512 records per iteration — bench scene 2600 /
+    // 3000 / 3255 / 3600 / 4000 / 4340 / 5000 points per bucket: bucket kernel 173 / 149 / 136 / 138 / 133 / 131 / 160 us; beyond 4340
+    // too many tables overflow into the second pass).
+    const uint64_t small_cloud = std::min<uint64_t>(wide ? 4000 : 3600, std::max<uint64_t>(700, n / 1024));
     const uint64_t per_bucket = slots >= 1024 ? 6400 : small_cloud;
     const uint64_t node_room = (uint64_t)slots * load_pct;
     const uint64_t want = std::max<uint64_t>(n / per_bucket, (nodes * 100) / node_room);
@@ -131,7 +134,13 @@ int partition_launch(gndt_handle* h, gndt_handle::Pending& P) {
     // 4-13 % with it: fewer buckets than CUs want).  The estimate carries a 20 % margin, so 75 % is ~62 % of the slots really used.
     int load_pct = P.load_pct ? P.load_pct : q.load_pct;
     if (!P.load_pct && n >= (1u << 21)) load_pct = std::max(load_pct, tuning().bucket_load_large);
-    uint64_t Bw = buckets_for(n, nodes_est, bslots, load_pct);
+    // (which bucket kernel this build gets — gndt_bucket3.hpp: three workgroups per CU for clouds without locality — also sizes its buckets)
+    const bool wide_hint = tuning().bucket_three_wgs && !P.stats_only && tuning().interleave < 0 && !(q.pair_ratio < 0.0 || q.pair_ratio > 0.02);
+    // (its buckets are sized by the POINTS — 4000 each — unless the nodes really fill the tables: the estimate carries a 20-30 % margin
+    //  and the second pass takes the tables that overflow all the same; with the 75 % rule the bench scene's hint made 2 730 buckets
+    //  of 3 660 points where 2 500 of 4 000 are 4 % faster)
+    if (wide_hint && bslots == 512 && !P.load_pct && tuning().retry_pass) load_pct = std::max(load_pct, 90);
+    uint64_t Bw = buckets_for(n, nodes_est, bslots, load_pct, wide_hint && bslots == 512);
     // Clouds with few points per node (a million points in half a million nodes): the NODES size the bucket count, and 512-slot
     // tables — which since round 3 hold 512 nodes and no longer overflow on such clouds — would get buckets of a few hundred
     // points, all per-bucket overhead (size sweep: 0.217 against 0.186 ms).  Below 900 points per bucket the 1024-slot tables
@@ -390,7 +399,12 @@ int partition_launch(gndt_handle* h, gndt_handle::Pending& P) {
         // done again by a SECOND PASS with 1024-slot tables over the queued buckets only (round 5) — it used to send the whole build
         // round again.  The pass is launched behind a handle's first builds, behind builds recorded into a hipGraph (a replay cannot
         // be re-run) and for as long as the last build used it; a handle whose clouds never overflow does not pay for the launch.
-        const bool retry = bslots == 512 && tuning().retry_pass && (q.retry_pass || h->capturing);
+        // Round 6: a RECORDED build carries the pass only if nothing is known about this cloud size (a capture on a reserved fresh
+        // handle) or the eager build before it used it: every replay of a recorded pass over an empty list is a launch of 256 x 1024
+        // threads that all leave again (~4 us of a 52 us frame).  A replay whose tables overflow without it is
+        // reported like any replay that does not fit (GNDT_ERR_CAPACITY: build that cloud eagerly, capture again).
+        const bool known_size = q.last_n == n && q.last_est != 0;
+        const bool retry = bslots == 512 && tuning().retry_pass && (q.retry_pass || (h->capturing && !known_size));
         uint32_t* const rlist = retry ? q.range_hi : (uint32_t*)nullptr;
         P.retry_pass = retry;
         // one record per thread at three workgroups per CU for clouds without locality (interleave == 0: the last build counted next

@@ -285,7 +285,10 @@ struct Tuning {
     // constants (each with the measurement that set it) ...
     int bucket_load = 60;        // average LDS-table load (percent) that sizes the bucket count
     int bucket_load_large = 75;  // the same from 2 M points on (the chip is full either way: fuller tables, fewer buckets; 85 / 92 with the second pass behind them: noise, r05 §4)
-    int bucket_points = 0;       // points per bucket (0 = derived: 700 .. 3600 with the cloud's size)
+#ifndef GNDT_BUCKET_POINTS
+#define GNDT_BUCKET_POINTS 0
+#endif
+    int bucket_points = GNDT_BUCKET_POINTS;       // points per bucket (0 = derived: 700 .. 3600 with the cloud's size)
     int bucket_slots = 0;        // LDS table of the first attempt (0 = 512, 1024 on a retry)
     int two_level = -1;          // 0 = never use the two-level partition
     uint32_t l1_wgs = 2048;      // level-1 workgroups (512 are resident: 2048 of them, ~1.2 tiles each, 69 us against 75 with 1024 and 72 with 512 on the bench scene, r05 §5)

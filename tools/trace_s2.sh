@@ -13,7 +13,7 @@ f = glob.glob(sys.argv[1] + "/*/*kernel_trace.csv")[0]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
 # the last complete build: from the last k_part_clear on
 idx = [i for i, r in enumerate(rows) if "k_part_clear" in r["Kernel_Name"]]
-i0 = idx[-2] if len(idx) > 1 else 0
+i0 = idx[-2] if len(idx) > 1 else max(0, len(rows) - 40)       # (no partition build in the trace: the last 40 launches)
 i1 = idx[-1] if len(idx) > 1 else len(rows)
 prev = None
 for r in rows[i0:i1]:
