@@ -181,7 +181,7 @@ int partition_launch(gndt_handle* h, gndt_handle::Pending& P) {
         if ((rc = ensure_stats_buffers(h, stage_want))) return rc;
     } else {
         if ((rc = ensure_stage(h, stage_want, false))) return rc;       // (the order arrays; the rows are RawNode records)
-        if ((rc = ensure_raw(h, q.stage_cap))) return rc;
+        if ((rc = ensure_raw(h, std::max<uint64_t>(P.rows_floor, nodes_est + nodes_est / 8)))) return rc;
         if ((rc = ensure_out(h, q.stage_cap))) return rc;
     }
     BucketRanges ranges{nullptr, nullptr, nullptr, 0u};
@@ -410,14 +410,15 @@ int partition_launch(gndt_handle* h, gndt_handle::Pending& P) {
         // one record per thread at three workgroups per CU for clouds without locality (interleave == 0: the last build counted next
         // to no adjacent records of one node), two records at two workgroups per CU — with the pair folding — for the others
         const bool wide = (interleave == 0u || tuning().bucket_three_wgs == 2) && !P.stats_only && tuning().bucket_three_wgs;
+        const uint64_t rows_cap = std::min<uint64_t>(q.stage_cap, P.stats_only ? q.stage_cap : q.raw_cap);      // staging rows the order arrays AND the records hold
 #define GNDT_LAUNCH_DIRECT(T_, H_, S_, GRID_, RL_, TODO_)                                                                       \
     hipLaunchKernelGGL((k_bucket_direct<T_, H_, S_>), GRID_, dim3(T_), 0, s, bucket_recs, ranges, B, gp, q.raw,    \
-                       (uint32_t)(S_ ? h->st_cap : q.stage_cap), q.ord_cf, q.ord_idx, order, h->d_cnt, q.d_pc, dbg, stats_out, fp_mask, interleave, \
+                       (uint32_t)(S_ ? h->st_cap : rows_cap), q.ord_cf, q.ord_idx, order, h->d_cnt, q.d_pc, dbg, stats_out, fp_mask, interleave, \
                        RL_, TODO_)
         if (bslots == 1024) { if (P.stats_only) GNDT_LAUNCH_DIRECT(1024, 1024, true, bgrid, (uint32_t*)nullptr, (const uint32_t*)nullptr); else GNDT_LAUNCH_DIRECT(1024, 1024, false, bgrid, (uint32_t*)nullptr, (const uint32_t*)nullptr); }
         else if (wide)
             hipLaunchKernelGGL((k_bucket_direct<GNDT_DIRECT_THREADS, 512, false, 1, 6>), bgrid, dim3(GNDT_DIRECT_THREADS), 0, s, bucket_recs, ranges, B, gp, q.raw,
-                               (uint32_t)q.stage_cap, q.ord_cf, q.ord_idx, order, h->d_cnt, q.d_pc, dbg, stats_out, fp_mask, interleave, rlist, (const uint32_t*)nullptr);
+                               (uint32_t)rows_cap, q.ord_cf, q.ord_idx, order, h->d_cnt, q.d_pc, dbg, stats_out, fp_mask, interleave, rlist, (const uint32_t*)nullptr);
         else { if (P.stats_only) GNDT_LAUNCH_DIRECT(GNDT_DIRECT_THREADS, 512, true, bgrid, rlist, (const uint32_t*)nullptr); else GNDT_LAUNCH_DIRECT(GNDT_DIRECT_THREADS, 512, false, bgrid, rlist, (const uint32_t*)nullptr); }
         if (retry) {
             const dim3 rgrid(std::min<uint32_t>(B, 256u));       // (one 1024-thread workgroup per CU; all of them leave at once when nothing is queued)
@@ -435,7 +436,7 @@ int partition_launch(gndt_handle* h, gndt_handle::Pending& P) {
         HIP_TRY(h, hipMemcpyAsync(h->h_cnt, h->d_cnt, sizeof(Counters), hipMemcpyDeviceToHost, s));
     }
     P.bslots = bslots;
-    if (!P.captured) { q.last_n = n; q.last_est = nodes_est; q.last_stage_want = stage_want; q.last_attempt = attempt; q.last_load = P.load_pct; }
+    if (!P.captured) { q.last_n = n; q.last_est = nodes_est; q.last_stage_want = stage_want; q.last_rows_floor = P.rows_floor; q.last_attempt = attempt; q.last_load = P.load_pct; }
     return GNDT_OK;
 }
 
@@ -519,8 +520,9 @@ int partition_begin(gndt_handle* h, const void* xyz_dev, size_t n, size_t stride
     }
     if (similar && q.good_slots == 1024) P.nodes_est = std::max<uint64_t>(P.nodes_est, q.good_est);   // (an estimate that had to be doubled)
     P.est0 = P.nodes_est;
-    P.stage_want = std::max<uint64_t>(q.stage_cap, h->P.max_nodes_hint ? h->P.max_nodes_hint + h->P.max_nodes_hint / 8
-                                                                       : std::max<uint64_t>(4096, P.est_reliable ? P.nodes_est + P.nodes_est / 8 : n / 4));
+    P.rows_floor = h->P.max_nodes_hint ? h->P.max_nodes_hint + h->P.max_nodes_hint / 8
+                                       : std::max<uint64_t>(4096, P.est_reliable ? P.nodes_est + P.nodes_est / 8 : n / 4);
+    P.stage_want = std::max<uint64_t>(q.stage_cap, P.rows_floor);
     const int prev_strategy = h->last_strategy;
     h->last_strategy = GNDT_STRATEGY_PARTITION;
     {
@@ -532,6 +534,7 @@ int partition_begin(gndt_handle* h, const void* xyz_dev, size_t n, size_t stride
     if (P.captured && q.last_n == n && q.last_est) {      // (recorded: sized like the eager build of this cloud size before it)
         P.nodes_est = q.last_est; P.est0 = q.last_est; P.attempt = q.last_attempt; P.load_pct = q.last_load;
         P.stage_want = std::max<uint64_t>(q.stage_cap, q.last_stage_want);
+        P.rows_floor = q.last_rows_floor;
     }
     rc = partition_launch(h, P);
     if (rc) { h->last_strategy = prev_strategy; return rc; }
@@ -633,6 +636,7 @@ int partition_resolve(gndt_handle* h) {
             // guessed n / 4 nodes for a cloud of n / 2 went on to 1024-slot tables with the same wrong estimate and ran a third time)
             if (want > P.stage_want) --P.attempt;
             P.stage_want = want;
+            P.rows_floor = want;
             if (true_nodes > P.nodes_est) { P.nodes_est = true_nodes + true_nodes / 16; P.est_reliable = true; }
             again = true;
         }

@@ -122,14 +122,16 @@ int ensure_stage(gndt_handle* h, uint64_t nodes, bool rows) {
     return GNDT_OK;
 }
 
-// the PARTITION strategies' staging rows (RawNode): as many as the order arrays address
+// the PARTITION strategies' staging rows (RawNode).  Their number is NOT tied to the order arrays': a table-path call between two
+// partition builds may grow those (ensure_stage) without the records having to follow — the bucket kernel is given the smaller of
+// the two capacities (round 6, tools/fuzz_graph.py: tying them made a capture after such a call ask for memory)
 int ensure_raw(gndt_handle* h, uint64_t records) {
     auto& q = h->part;
-    records = std::max<uint64_t>(records, q.stage_cap);
     if (records <= q.raw_cap) return GNDT_OK;
     GNDT_NO_CAPTURE(h, "the bucket kernel's staging rows");
     release_device(h, q.raw);
     q.raw = nullptr; q.raw_cap = 0;
+    records = std::max<uint64_t>(records, std::min<uint64_t>(q.stage_cap, 2 * records));      // (in step with the order arrays where that is cheap)
     HIP_TRY(h, hipMalloc(&q.raw, records * sizeof(RawNode)));
     q.raw_cap = records;
     return GNDT_OK;

@@ -163,7 +163,7 @@ struct gndt_handle {
         // how the last PARTITION attempt of this handle was sized: a build RECORDED into a hipGraph right after it is sized the same
         // way (what the eager build allocated is then enough — what it has learnt since, e.g. "more buckets next time", would ask
         // for buffers a capture cannot allocate)
-        uint64_t last_n = 0, last_est = 0, last_stage_want = 0;  int last_attempt = 0, last_load = 0;
+        uint64_t last_n = 0, last_est = 0, last_stage_want = 0, last_rows_floor = 0;  int last_attempt = 0, last_load = 0;
         double pair_ratio = -1.0;   // share of the last resolved build's records that sat next to one of their own node inside a bucket (< 0: unknown)
         uint64_t retries_total = 0; // builds re-run because a table / region / staging area was too small (gndt_debug_retry_count)
     } part;
@@ -250,6 +250,7 @@ struct gndt_handle {
         int attempt = 0, bslots = 0;
         int load_pct = 0;               // average LDS-table load this build aims at (0: the handle's default)
         uint64_t nodes_est = 0, stage_want = 0, est0 = 0;   // est0: the estimate the first attempt used
+        uint64_t rows_floor = 0;        // staging rows THIS build asks for whatever the handle already has (stage_want also covers what it has)
         bool est_reliable = false;      //   ... and whether it came from a hint / an earlier build rather than the n / 4 guess
         bool two_level = false;         // this attempt used the two-level partition
         bool one_level = false;         //   ... the one-level tile partition (small clouds)

@@ -8,7 +8,7 @@ import tempfile
 import numpy as np
 import pytest
 
-from tests import scenes
+from grid_ndt_amd import scenes
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 

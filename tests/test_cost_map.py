@@ -9,7 +9,7 @@ import pytest
 
 from oracle import oracle
 from tests import host_emulation as he
-from tests import scenes
+from grid_ndt_amd import scenes
 
 FLT_MAX = np.float32(3.4028234663852886e38)
 UP = (0.0, 0.0, 1.0)

@@ -10,7 +10,8 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from tests import host_emulation as he
-from tests import parity, scenes
+from grid_ndt_amd import scenes
+from tests import parity
 
 P = scenes.CAMPUS_PARAMS
 

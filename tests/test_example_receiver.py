@@ -7,7 +7,7 @@ import subprocess
 import numpy as np
 import pytest
 
-from tests import scenes
+from grid_ndt_amd import scenes
 from tests.test_input_side import _write_pcd
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

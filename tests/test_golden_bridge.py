@@ -6,7 +6,8 @@ import os
 import numpy as np
 import pytest
 
-from tests import parity, scenes
+from grid_ndt_amd import scenes
+from tests import parity
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "bridge_ground_expected.npz")
 GOLD_CAMPUS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "campus_100k_expected.npz")

@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 from oracle import oracle
-from tests import scenes
+from grid_ndt_amd import scenes
 
 pytestmark = pytest.mark.gpu
 FLT_MAX = np.float32(3.4028234663852886e38)

@@ -3,7 +3,8 @@ Gates: keys / counts / order / labels bit-exact; covariance within 1e-5 relative
 import numpy as np
 import pytest
 
-from tests import parity, scenes
+from grid_ndt_amd import scenes
+from tests import parity
 
 pytestmark = pytest.mark.gpu
 

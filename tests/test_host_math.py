@@ -5,7 +5,8 @@ import numpy as np
 import pytest
 
 from tests import host_emulation as he
-from tests import parity, scenes
+from grid_ndt_amd import scenes
+from tests import parity
 
 CASES = {
     "bridge_ground": (lambda: scenes.bridge_ground(), scenes.BRIDGE_PARAMS),

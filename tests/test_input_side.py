@@ -7,7 +7,8 @@ import os
 import numpy as np
 import pytest
 
-from tests import parity, scenes
+from grid_ndt_amd import scenes
+from tests import parity
 
 
 def _write_pcd(path, fields, sizes, types, counts, arr_bytes, n, kind, ascii_rows=None, width=None, height=1, with_points=True):

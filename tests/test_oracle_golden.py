@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 from oracle import oracle
-from tests import scenes
+from grid_ndt_amd import scenes
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden", "morton_known_answers.csv")
 
