@@ -32,6 +32,21 @@ int launch_order_and_emit(gndt_handle* h, uint64_t words, int m0, hipStream_t s,
     mark(h, m0 + 1, s);
     mark(h, m0 + 2, s);       // (the column-rank and column-scan passes of earlier versions: phases kept for the ABI, empty)
     mark(h, m0 + 3, s);
+    if (grouped && !partial && !tab_end && words <= (uint64_t)tuning().place_emit_words) {
+        // small clouds: the ordering pass and the emit pass as one kernel in scatter form (gndt_partition.hpp)
+        mark(h, m0 + 4, s);
+        if (dest_scans)
+            hipLaunchKernelGGL(k_place_emit_rows<true>, dim3(grid_for(q.stage_cap)), dim3(kBlock), 0, s, (const RawNode*)q.raw, q.ord_cf, q.ord_idx, q.bitmap, q.word_base,
+                               q.ncol_at, h->out, q.row_ncol, h->d_cnt, q.d_pc, counters_to_host ? h->h_cnt : (Counters*)nullptr,
+                               counters_to_host ? q.h_pc : (PartCounters*)nullptr, h->cur_capture_id, h->pending.gp, (const uint32_t*)q.word_weight, (uint32_t)words);
+        else
+            hipLaunchKernelGGL(k_place_emit_rows<false>, dim3(grid_for(q.stage_cap)), dim3(kBlock), 0, s, (const RawNode*)q.raw, q.ord_cf, q.ord_idx, q.bitmap, q.word_base,
+                               q.ncol_at, h->out, q.row_ncol, h->d_cnt, q.d_pc, counters_to_host ? h->h_cnt : (Counters*)nullptr,
+                               counters_to_host ? q.h_pc : (PartCounters*)nullptr, h->cur_capture_id, h->pending.gp, (const uint32_t*)q.word_weight, (uint32_t)words);
+        HIP_TRY(h, hipGetLastError());
+        mark(h, m0 + 5, s);
+        return GNDT_OK;
+    }
     if (grouped && dest_scans)
         hipLaunchKernelGGL(k_order_dest_columns<true>, dim3(grid_for(q.stage_cap)), dim3(kBlock), 0, s, q.ord_cf, q.ord_idx, q.bitmap, q.word_base,
                            q.ncol_at, q.inv, h->d_cnt, q.d_pc, (const uint32_t*)q.word_weight, (uint32_t)words);

@@ -300,6 +300,11 @@ struct Tuning {
                                  //   stretch of the bucket per lane (2) — or by the last build's locality (-1: 0 without, 2 with; r05 §3)
     int sketch = 1;              // a fresh handle without a hint counts its first cloud's nodes (HyperLogLog pass) instead of guessing n / 4
     int retry_pass = 1;          // 0: never launch the bucket kernel's second pass (an overflowing 512-slot table re-runs the build, as before round 5)
+#ifndef GNDT_PLACE_EMIT_WORDS
+#define GNDT_PLACE_EMIT_WORDS 16384
+#endif
+    int place_emit_words = GNDT_PLACE_EMIT_WORDS;    // PARTITION builds of clouds with up to this many bitmap words (32 points each): ordering + emit as one kernel
+                                                     //   in scatter form (gndt_partition.hpp k_place_emit_rows; 0: never)
     int dest_scans = 1;          // small clouds: the destination pass scans the word weights itself instead of one or two scan launches in front of it
                                  //   (200 k-point campus frame 0.0549 -> 0.0535 ms, bridge_ground 0.0647 -> 0.0646: r05 ablation 6h)
     int small_tiles = 1;         // one-level partition of < 1 M points: 1024-point level-1 tiles (a few hundred workgroups instead of a few dozen:

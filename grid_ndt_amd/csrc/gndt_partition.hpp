@@ -932,6 +932,77 @@ __device__ __forceinline__ void emit_one_row(const StageRow& row, uint32_t r, co
     out.rough[r] = rough;
 }
 
+// Small clouds (round 6): the ordering pass and the emit pass as ONE kernel, in scatter form.  Every staged node works its final row out
+// itself — its ord_cf names the column's place (bitmap word, word base, the few earlier columns of the word), its record the index in
+// the column — reads its record where it lies (consecutive threads, consecutive 96-byte
+// records: no gather), does the moments and the eigen-solve and writes its result row where it belongs.  The writes are pieces of 4 to
+// 24 bytes at scattered rows: the L2 takes them for a map of a few hundred thousand nodes, and a launch of 9-10 us is gone from a
+// 50-60 us build (k_order_dest_columns + k_emit_rows: 9.5 + 9.4 us on the 200 k-point frame; this: see profiles/r06_ablation.txt 6).
+// Larger maps keep the two kernels: their result rows are written in whole lines there.
+// SCAN: as in k_order_dest_columns — every workgroup works the prefix of the word weights out for itself, in LDS.
+template <bool SCAN>
+static __global__ void __launch_bounds__(kBlock) k_place_emit_rows(const RawNode* __restrict__ raw, const uint32_t* __restrict__ ord_cf,
+                                                                   const uint32_t* __restrict__ ord_idx, const uint32_t* __restrict__ bitmap,
+                                                                   uint32_t* __restrict__ word_base, const uint32_t* __restrict__ ncol_at,
+                                                                   OutView out, uint32_t* __restrict__ row_ncol,
+                                                                   const Counters* __restrict__ cnt, const PartCounters* __restrict__ pc,
+                                                                   Counters* __restrict__ host_cnt, PartCounters* __restrict__ host_pc,
+                                                                   uint32_t capture_id, GridParams P,
+                                                                   const uint32_t* __restrict__ word_weight, uint32_t words) {
+    if (blockIdx.x == 0 && threadIdx.x < 2) {
+        if (threadIdx.x == 0 && host_cnt) *host_cnt = *cnt;
+        if (threadIdx.x == 1 && host_pc) { *host_pc = *pc; host_pc->capture_id = capture_id; }
+    }
+    if (pc->lds_overflow | pc->stage_overflow | pc->index_overflow | pc->part_overflow) return;
+    const uint32_t n = cnt->num_nodes;
+    __shared__ uint32_t s_base[SCAN ? kDestScanMax : 1];
+    __shared__ uint32_t s_wave[kBlock / 64];
+    if (SCAN) {
+        for (uint32_t j = threadIdx.x; j < words; j += kBlock) s_base[j] = word_weight[j];
+        __syncthreads();
+        const uint32_t per = ((words + kBlock - 1u) / kBlock) | 1u;
+        const uint32_t j0 = min(threadIdx.x * per, words), j1 = min(j0 + per, words);
+        uint32_t sum = 0;
+        for (uint32_t j = j0; j < j1; ++j) sum += s_base[j];
+        uint32_t incl = sum;
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        for (int off = 1; off < 64; off <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)incl, off, 64); if (lane >= off) incl += t; }
+        if (lane == 63) s_wave[wave] = incl;
+        __syncthreads();
+        uint32_t run = incl - sum;
+        for (int w = 0; w < wave; ++w) run += s_wave[w];
+        for (uint32_t j = j0; j < j1; ++j) { const uint32_t v = s_base[j]; s_base[j] = run; run += v; }
+        __syncthreads();
+        if (blockIdx.x == 0) for (uint32_t j = threadIdx.x; j < words; j += kBlock) word_base[j] = s_base[j];     // (what the scan launches would have left)
+    }
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const RawNode rec = raw[i];                             // (coalesced: staging order)
+        const uint32_t icol = rec.info >> 3, fl = rec.info & 7u;
+        const uint32_t cf = ord_cf[i];                          // (every row of a column carries the column's first-seen index)
+        const uint32_t w = cf >> 5;
+        uint32_t m = bitmap[w] & ((1u << (cf & 31u)) - 1u);    // columns first seen earlier inside the same word
+        uint32_t r = (SCAN ? s_base[w] : word_base[w]) + icol;
+        while (m) { r += ncol_at[(w << 5) + (uint32_t)__builtin_ctz(m)]; m &= m - 1u; }
+        int sx, sy, sz;
+        unpack_key(rec.key, sx, sy, sz);
+        out.sx[r] = sx; out.sy[r] = sy; out.sz[r] = sz;
+        out.count[r] = rec.count; out.first_idx[r] = rec.first; out.flags[r] = fl;
+        row_ncol[r] = icol == 0u ? rec.ncol : 0u;
+        float mean[3] = {0.f, 0.f, 0.f}, rough = 0.f, normal[3] = {0.f, 0.f, 0.f};
+        double S[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        if (fl & 1u) {
+            const double c[3] = {axis_centre(sx, P.ox, P.grid_len), axis_centre(sy, P.oy, P.grid_len), axis_centre(sz, P.oz, P.z_len)};
+            node_moments(rec.count, rec.sum, c, mean, S);
+            node_rough_normal(S, rough, normal);
+        }
+        out.rough[r] = rough;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { out.mean[3 * (size_t)r + k] = mean[k]; out.normal[3 * (size_t)r + k] = normal[k]; }
+#pragma unroll
+        for (int k = 0; k < 6; ++k) out.cov[6 * (size_t)r + k] = (float)S[k];
+    }
+}
+
 // Incremental finalisation (gndt_update*): what k_emit_rows needs to emit only what changed.  Rows in front of
 // word_base[first_word] did not move in this frame; of those, the ones whose node a frame touched (work list `touched`, rows
 // `row_of`) are written again in place, everything from that row on is gathered as usual.
