@@ -745,17 +745,18 @@ int gndt_build_device(gndt_handle* h, const void* xyz_dev, size_t n, size_t stri
                                (h->tile_choice < 0 || ++h->tile_choice_age >= 64 ||
                                 n > h->tile_choice_n + h->tile_choice_n / 4 || n + n / 4 < h->tile_choice_n);
             if (stale) {
-                // A handle that already has room for whatever this cloud turns out to be (gndt_reserve / gndt_warmup, or earlier builds:
-                // staging rows for n / 2 nodes) does not WAIT for the sample — ~50 us of a first build that takes 90: the kernel and its
-                // copy ride in front of this build, which takes the handle's last choice (PARTITION on a fresh handle: never wrong, at
-                // worst 0.09 ms slower than TILE on a 200 k-point depth frame), and the next build finds the answer.  A fresh handle
-                // without room waits as before: the answer also sizes its first tables (partition_begin), and its allocations cost more.
+                // A RE-sample (the cloud size changed by a quarter, or 64 builds have passed) on a handle that has room for whatever the
+                // cloud turns out to be does not WAIT for the answer (~50 us): the kernel and its copy ride in front of this build,
+                // which keeps the handle's last choice, and the next build finds the answer.
                 // (A handle whose node estimate does not come from the sample — a hint, an earlier build — never needs to wait either.)
-                const bool defer = (h->part.stage_cap >= n / 2 && h->part.stage_cap > 0) || h->part.nodes_learned != 0 || h->P.max_nodes_hint != 0;
+                // ... and not for a handle's FIRST sample (round 6, measured: a depth-camera frame — configs[0]'s own kind of cloud — built
+                // by PARTITION because nobody had looked yet took 0.31 ms with a re-run where the awaited sample + TILE take 0.10)
+                const bool defer = h->tile_choice >= 0 &&
+                                   ((h->part.stage_cap >= n / 2 && h->part.stage_cap > 0) || h->part.nodes_learned != 0 || h->P.max_nodes_hint != 0);
                 rc = locality_sample_begin(h, xyz_dev, n, stride_bytes, 64, s);
                 if (rc) return rc;
                 if (!defer) { double ratio = 0.0; if (locality_sample_take(h, true, &ratio)) adopt(ratio, n); }
-                else if (h->tile_choice < 0) { h->tile_choice = 0; h->tile_choice_n = n; h->tile_choice_age = 0; }   // (PARTITION until the answer is in)
+                else { h->tile_choice_age = 0; h->tile_choice_n = n; }                  // (the last choice until the answer is in)
             }
             if (h->tile_choice == 1) strategy = GNDT_STRATEGY_TILE;
         }
