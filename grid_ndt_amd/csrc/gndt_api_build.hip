@@ -799,7 +799,11 @@ int gndt_reserve(gndt_handle* h, uint64_t max_points, uint64_t max_nodes) {
     if (h->pending.active) { const int prc = partition_resolve(h); if (prc) return prc; }
     HIP_TRY(h, hipStreamSynchronize(h->last_stream));              // (buffers may move: nothing may still use them)
     const uint64_t n = max_points;
-    if (!max_nodes) max_nodes = std::max<uint64_t>(n / 4, 1024);
+    // No node count given: a first build sizes itself from n / 4 nodes — or, when strategy AUTO's locality sample finds two or more
+    // points per node and tile, from 1.15 n / ratio <= 0.575 n (partition_begin): what is reserved has to cover that too (round 6:
+    // the campus frame, 0.37 nodes per point, grew its staging arrays in the first build after gndt_reserve(n, 0): 0.26 ms of a
+    // 0.45 ms first call)
+    if (!max_nodes) max_nodes = std::max<uint64_t>(std::max<uint64_t>(n / 4, (n * 3) / 10), 1024);
     max_nodes = std::max<uint64_t>(max_nodes, h->P.max_nodes_hint);      // (the hint is what sizes the first attempt of every build)
     auto& q = h->part;
     int rc;
@@ -968,5 +972,11 @@ int gndt_warmup(gndt_handle* h, uint64_t expected_points) {
         if (known_device) g_warm_points[h->device].store(n, std::memory_order_release);
     }
     if (reserve_points) rc = gndt_reserve(h, reserve_points, h->P.max_nodes_hint);
+    // (what a first build of THIS handle would still allocate: the locality sample's two counters, their pinned mirror, its event)
+    if (!rc && !h->d_sample) {
+        HIP_TRY(h, hipMalloc(&h->d_sample, 2 * sizeof(unsigned long long)));
+        HIP_TRY(h, hipHostMalloc(&h->h_sample, 2 * sizeof(unsigned long long)));
+    }
+    if (!rc && !h->sample_ev) HIP_TRY(h, hipEventCreateWithFlags(&h->sample_ev, hipEventDisableTiming));
     return rc;
 }

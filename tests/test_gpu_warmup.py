@@ -45,7 +45,8 @@ def test_first_build_of_a_warmed_handle_is_the_oracles_map_and_costs_little(scen
         m.sync()
     steady_ms = (time.perf_counter() - t0) / 20 * 1e3
     print(f"warmed first build {first_ms:.3f} ms, awaited steady build {steady_ms:.3f} ms")
-    assert first_ms < 0.5 and first_ms < 4.0 * steady_ms          # (un-warmed: 0.4-1.0 ms, 8-18 x the steady build)
+    # un-warmed: 0.85-1.0 ms, 12-18 x the awaited steady build; warmed 0.14-0.15 (0.26 the first time in a process)
+    assert first_ms < 0.45 and first_ms < 5.0 * steady_ms
 
 
 def test_warmup_leaves_the_handle_as_it_was():
