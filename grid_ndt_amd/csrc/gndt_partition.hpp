@@ -1014,8 +1014,15 @@ struct EmitPartial {
 
 // RAW (the PARTITION strategies, round 6): `stage` is an array of RawNode records — mean, scatter and eigen-solve from the node's
 // additive statistics here, where the whole chip works on them.
+#ifndef GNDT_EMIT_WAVES
+#define GNDT_EMIT_WAVES 0
+#endif
 template <bool RAW = false>
-static __global__ void __launch_bounds__(kBlock) k_emit_rows(const StageRow* __restrict__ stage, const uint32_t* __restrict__ inv,
+static __global__ void __launch_bounds__(kBlock)
+#if GNDT_EMIT_WAVES
+__attribute__((amdgpu_waves_per_eu(GNDT_EMIT_WAVES, GNDT_EMIT_WAVES)))
+#endif
+k_emit_rows(const StageRow* __restrict__ stage, const uint32_t* __restrict__ inv,
                                                       OutView out, uint32_t* __restrict__ row_ncol,
                                                       const Counters* cnt, const PartCounters* __restrict__ pc,
                                                       Counters* __restrict__ host_cnt, PartCounters* __restrict__ host_pc,
