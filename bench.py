@@ -931,7 +931,7 @@ def main():
         # Dominant kernel = the longest phase.  Its algorithmic bytes (DESIGN.md "Roofline accounting"):
         # every kernel that streams the cloud moves 12 B/point; the bucket kernel also emits the nodes
         # (12 B/point + 76 B/node); node-proportional kernels move 76 B/node.
-        kernel_of = m.KERNEL_OF_PHASE
+        kernel_of = m.KERNEL_OF_PHASE_BLOCKED if m.last_strategy() == 7 else m.KERNEL_OF_PHASE
         cand = {k: v for k, v in phases.items() if k in kernel_of}
         dom = max(cand, key=cand.get) if cand else None
         acc_ms = live.get(dom, cand.get(dom, float("nan"))) if dom else float("nan")
@@ -999,7 +999,7 @@ def main():
             ref = parity.ref_from_cloud(small, P)
             _, o = parity.gpu_from_cloud(small, P, device=local)
             out["check"] = parity.compare(o, ref)["ok"]
-        if a.stamps and m.last_strategy() in (2, 3, 4, 6):
+        if a.stamps and m.last_strategy() in (2, 3, 4, 6, 7):
             m.enable_stamps(True)
             m.create2DMap("slope", pts, stream)
             cyc, nb = m.debug_bucket_phases()

@@ -12,7 +12,7 @@ _ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.path.join(_CSRC, "libgndt.so")
 SOURCES = ["gndt_api_core.hip", "gndt_api_table.hip", "gndt_api_build.hip", "gndt_api_dist.hip", "gndt_api_cost.hip",
            "gndt_api_io.hip", "gndt_codec.cpp", "gndt_io.cpp"]
-HEADERS = ["gndt_handle.hpp", "gndt_kernels.hpp", "gndt_table.hpp", "gndt_cost.hpp", "gndt_pack.hpp", "gndt_partition.hpp", "gndt_bucket3.hpp", "gndt_tile.hpp", "gndt_exchange.hpp", "gndt_math.hpp", os.path.join(_ROOT, "include", "gndt.h")]
+HEADERS = ["gndt_handle.hpp", "gndt_kernels.hpp", "gndt_table.hpp", "gndt_cost.hpp", "gndt_pack.hpp", "gndt_partition.hpp", "gndt_bucket3.hpp", "gndt_blocked.hpp", "gndt_tile.hpp", "gndt_exchange.hpp", "gndt_math.hpp", os.path.join(_ROOT, "include", "gndt.h")]
 
 GNDT_OK = 0
 ERR_NAMES = {0: "OK", 1: "INVALID", 2: "NO_DEVICE", 3: "HIP", 4: "KEY_RANGE", 5: "CAPACITY", 6: "NOMEM", 7: "PEER"}

@@ -3,6 +3,7 @@
 
 #include "gndt_handle.hpp"
 #include "gndt_bucket3.hpp"
+#include "gndt_blocked.hpp"
 using namespace gndt;
 using namespace gndt_host;
 
@@ -137,7 +138,16 @@ int partition_launch(gndt_handle* h, gndt_handle::Pending& P) {
     // records from an owner split were compressed where they came from and keep their index words
     const uint32_t compress = (!P.records && (uint64_t)P.first_base + n < (uint64_t)kWeightIndexLimit) ? 1u : 0u;
     const uint32_t part_mode = P.records ? kPartModeRecords : 0u;
-    const GridParams gp = P.gp;                        // as they were at launch (a retry must not pick up a new origin)
+    GridParams gp = P.gp;                              // as they were at launch (a retry must not pick up a new origin)
+    // Blocked buckets (gndt_blocked.hpp): the map of the last build on this handle was a dense, evenly filled box and this cloud has
+    // its size — spatial blocks of 512 nodes as buckets, the bucket kernel addresses its table directly.  Only with the two-level
+    // partition (large clouds), never for records / statistics / a re-run after a blocked attempt failed.
+    // (not under hipGraph capture either: a recorded build is replayed on OTHER clouds, and one that leaves the box cannot be re-run)
+    const bool blocked = tuning().blocked && q.blk_state == 1 && !P.no_block && !P.records && !P.stats_only && attempt == 0 && !h->capturing && !P.captured &&
+                         !tuning().bucket_slots && q.two_level_ok && n >= (1u << 20) &&
+                         h->P.strategy != GNDT_STRATEGY_PARTITION_EXACT && n <= q.blk_n + q.blk_n / 4 && n + n / 4 >= q.blk_n;
+    P.blocked = blocked;
+    if (blocked) gp.blk = q.blk_map;
     const float* p = static_cast<const float*>(P.xyz);
     const float* p2 = static_cast<const float*>(P.xyz2);
     // table size and bucket count for this attempt: 512-slot tables unless that needs too many buckets
@@ -164,6 +174,7 @@ int partition_launch(gndt_handle* h, gndt_handle::Pending& P) {
         const uint64_t b1024 = buckets_for(n, nodes_est, 1024, load_pct);
         if (b1024 >= 384) { bslots = 1024; Bw = b1024; }
     }
+    if (blocked) { bslots = 512; Bw = q.blk_buckets; }       // (one bucket per block of the box)
     // Two-level partition (no counting passes) for large builds; the exact single-level counting partition for small
     // ones, when asked for (GNDT_STRATEGY_PARTITION_EXACT), and after a region overflowed once on this handle.
     const int env_two = tuning().two_level;
@@ -190,7 +201,9 @@ int partition_launch(gndt_handle* h, gndt_handle::Pending& P) {
                      n >= (1u << 14);
     P.two_level = two;
     P.one_level = one;
-    h->last_strategy = two ? GNDT_STRATEGY_PARTITION : (one ? GNDT_STRATEGY_PARTITION_ONE_LEVEL : GNDT_STRATEGY_PARTITION_EXACT);
+    if (blocked && !two) { P.no_block = true; return partition_launch(h, P); }      // (blocked buckets ride on the two partition levels only)
+    h->last_strategy = two ? (blocked ? GNDT_STRATEGY_PARTITION_BLOCKED : GNDT_STRATEGY_PARTITION)
+                           : (one ? GNDT_STRATEGY_PARTITION_ONE_LEVEL : GNDT_STRATEGY_PARTITION_EXACT);
     stage_want = std::max<uint64_t>(stage_want, nodes_est + nodes_est / 8);
     if (P.stats_only) {
         if ((rc = ensure_stats_buffers(h, stage_want))) return rc;
@@ -419,7 +432,7 @@ int partition_launch(gndt_handle* h, gndt_handle::Pending& P) {
         // threads that all leave again (~4 us of a 52 us frame).  A replay whose tables overflow without it is
         // reported like any replay that does not fit (GNDT_ERR_CAPACITY: build that cloud eagerly, capture again).
         const bool known_size = q.last_n == n && q.last_est != 0;
-        const bool retry = bslots == 512 && tuning().retry_pass && (q.retry_pass || (h->capturing && !known_size));
+        const bool retry = !blocked && bslots == 512 && tuning().retry_pass && (q.retry_pass || (h->capturing && !known_size));
         uint32_t* const rlist = retry ? q.range_hi : (uint32_t*)nullptr;
         P.retry_pass = retry;
         // one record per thread at three workgroups per CU for clouds without locality (interleave == 0: the last build counted next
@@ -430,7 +443,10 @@ int partition_launch(gndt_handle* h, gndt_handle::Pending& P) {
     hipLaunchKernelGGL((k_bucket_direct<T_, H_, S_>), GRID_, dim3(T_), 0, s, bucket_recs, ranges, B, gp, q.raw,    \
                        (uint32_t)(S_ ? h->st_cap : rows_cap), q.ord_cf, q.ord_idx, order, h->d_cnt, q.d_pc, dbg, stats_out, fp_mask, interleave, \
                        RL_, TODO_)
-        if (bslots == 1024) { if (P.stats_only) GNDT_LAUNCH_DIRECT(1024, 1024, true, bgrid, (uint32_t*)nullptr, (const uint32_t*)nullptr); else GNDT_LAUNCH_DIRECT(1024, 1024, false, bgrid, (uint32_t*)nullptr, (const uint32_t*)nullptr); }
+        if (blocked)        // (gndt_blocked.hpp: a block of the box per bucket, the table addressed by the key)
+            hipLaunchKernelGGL(k_bucket_blocked<512>, bgrid, dim3(512), 0, s, bucket_recs, ranges, B, gp, q.raw, (uint32_t)rows_cap, q.ord_cf, q.ord_idx, order,
+                               h->d_cnt, q.d_pc, dbg);
+        else if (bslots == 1024) { if (P.stats_only) GNDT_LAUNCH_DIRECT(1024, 1024, true, bgrid, (uint32_t*)nullptr, (const uint32_t*)nullptr); else GNDT_LAUNCH_DIRECT(1024, 1024, false, bgrid, (uint32_t*)nullptr, (const uint32_t*)nullptr); }
         else if (wide)
             hipLaunchKernelGGL((k_bucket_direct<GNDT_DIRECT_THREADS, 512, false, 1, 6>), bgrid, dim3(GNDT_DIRECT_THREADS), 0, s, bucket_recs, ranges, B, gp, q.raw,
                                (uint32_t)rows_cap, q.ord_cf, q.ord_idx, order, h->d_cnt, q.d_pc, dbg, stats_out, fp_mask, interleave, rlist, (const uint32_t*)nullptr);
@@ -596,6 +612,68 @@ int partition_recheck_after_replay(gndt_handle* h) {
 
 // Wait for the pending build and look at its flags; re-run it with more room while they ask for it (the input
 // must still be valid: it is the caller's until gndt_sync / gndt_export returns).
+// Does the map this build has just finished say that the next cloud of its size may take BLOCKED buckets (gndt_blocked.hpp)?  Looked at
+// once per cloud size and handle (one small kernel over the result keys and a host wait), for clouds whose neighbouring records rarely
+// share a node.  Yes if the occupied key box is at most 32 levels high and blocks of 512 nodes (2^shz levels x the columns that leave)
+// hold a few thousand points each, none of them dominated by one node.  A blocked build that meets a record outside the box or an
+// overflowing region says no for good (partition_resolve).
+static void blocked_decide(gndt_handle* h, const gndt_handle::Pending& P) {
+    auto& q = h->part;
+    const uint64_t n = P.n + P.n2;
+    if (!tuning().blocked || P.stats_only || P.records || P.captured || !P.two_level || P.blocked || h->ever_captured) return;
+    if (h->P.strategy != GNDT_STRATEGY_AUTO && h->P.strategy != GNDT_STRATEGY_PARTITION && h->P.strategy != GNDT_STRATEGY_PARTITION_TWO_LEVEL) return;
+    if (q.blk_state != 0 && n <= q.blk_n + q.blk_n / 4 && n + n / 4 >= q.blk_n) return;      // (decided for clouds of this size)
+    q.blk_state = -1; q.blk_n = n;
+    if (!(q.pair_ratio >= 0.0 && q.pair_ratio <= 0.02)) return;                                // (clouds with locality: hot buckets, the pair folding)
+    const uint64_t nodes = h->h_cnt->num_nodes;
+    if (nodes < 1024 || nodes > h->out_cap) return;
+    hipStream_t s = P.s;
+    if (!q.d_extent) {
+        if (hipMalloc(&q.d_extent, 8 * sizeof(uint32_t)) != hipSuccess) { (void)hipGetLastError(); return; }
+        if (hipHostMalloc(&q.h_extent, 8 * sizeof(uint32_t)) != hipSuccess) { (void)hipGetLastError(); return; }
+    }
+    for (int k = 0; k < 8; ++k) q.h_extent[k] = k < 3 ? 0xFFFFFFFFu : 0u;
+    if (hipMemcpyAsync(q.d_extent, q.h_extent, 8 * sizeof(uint32_t), hipMemcpyHostToDevice, s) != hipSuccess) { (void)hipGetLastError(); return; }
+    hipLaunchKernelGGL(k_key_extent, dim3(64), dim3(1024), 0, s, (const int32_t*)h->out.sx, (const int32_t*)h->out.sy, (const int32_t*)h->out.sz,
+                       (const uint32_t*)h->out.count, (uint32_t)nodes, q.d_extent);
+    if (hipMemcpyAsync(q.h_extent, q.d_extent, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
+        (void)hipGetLastError();
+        return;
+    }
+    const int64_t bias = 1ll << 30;
+    const int64_t x0 = (int64_t)q.h_extent[0] - bias, y0 = (int64_t)q.h_extent[1] - bias, z0 = (int64_t)q.h_extent[2] - bias;
+    const int64_t X = (int64_t)q.h_extent[3] - bias - x0 + 1, Y = (int64_t)q.h_extent[4] - bias - y0 + 1, Z = (int64_t)q.h_extent[5] - bias - z0 + 1;
+    const uint64_t biggest = q.h_extent[6];
+    if (X <= 0 || Y <= 0 || Z <= 0 || Z > 32) return;
+    int shz = 0;
+    while ((1 << shz) < Z) ++shz;
+    // taller blocks (more level bits than the box needs) mean fewer columns per block and more blocks: the first height whose blocks
+    // hold at most ~5 000 points
+    for (; shz <= 5; ++shz) {
+        const int shx = (9 - shz + 1) / 2, shy = 9 - shz - shx;
+        const uint64_t nx = (uint64_t)((X + (1ll << shx) - 1) >> shx), ny = (uint64_t)((Y + (1ll << shy) - 1) >> shy);
+        const uint64_t B = nx * ny;
+        if (B < 64 || B > (uint64_t)kMaxFan * kMaxFan) continue;
+        const uint64_t per_block = n / B;
+        if (per_block > 5000) continue;
+        if (per_block < 1500) break;                    // (sparse boxes: mostly empty blocks)
+        if (biggest * 4 > per_block) break;            // (a node that holds a quarter of an average block's points: hot blocks)
+        // how full the box is: nodes per slot of the blocks (an evenly filled box fills its blocks alike)
+        if (nodes * 8 < B * 512) break;                 // (less than an eighth of the slots used: the box is mostly air)
+        // one block of margin on every side and the levels centred in the block's height: the next cloud of the same scene (other
+        // noise, a few points further out) still fits the box
+        const int64_t zpad = ((1ll << shz) - Z) / 2;
+        q.blk_map = BlockMap{1, (int)(x0 - (1ll << shx)), (int)(y0 - (1ll << shy)), (int)(z0 - zpad), shx, shy, shz, (int)nx + 2, (int)ny + 2};
+        q.blk_buckets = (uint32_t)((nx + 2) * (ny + 2));
+        if (q.blk_buckets > (uint64_t)kMaxFan * kMaxFan) { q.blk_map.on = 0; continue; }
+        q.blk_state = 1;
+        if (tuning().verbose)
+            fprintf(stderr, "[gndt] blocked buckets for clouds of ~%llu points: box %lld x %lld x %lld, blocks of %d x %d columns x %d levels, %llu buckets of ~%llu points\n",
+                    (unsigned long long)n, (long long)X, (long long)Y, (long long)Z, 1 << shx, 1 << shy, 1 << shz, (unsigned long long)B, (unsigned long long)per_block);
+        return;
+    }
+}
+
 int partition_resolve(gndt_handle* h) {
     auto& P = h->pending;
     if (!P.active) return GNDT_OK;
@@ -615,7 +693,14 @@ int partition_resolve(gndt_handle* h) {
             fprintf(stderr, "[gndt] build of %zu points, attempt %d (%d-slot tables, %llu nodes expected): region overflow %u, table overflow %u, "
                             "staging overflow %u -> re-run\n", P.n, P.attempt, P.bslots, (unsigned long long)P.nodes_est, q.h_pc->part_overflow,
                     q.h_pc->lds_overflow, q.h_pc->stage_overflow);
-        if (q.h_pc->part_overflow) {                           // a region of the two-level partition was too small: same table
+        if (P.blocked && (q.h_pc->blk_miss | q.h_pc->part_overflow)) {
+            // a record outside the box the blocks were laid out for, or blocks so uneven that a region overflowed: this cloud is
+            // not the dense box the last one was — the same build with hashed buckets, and the handle forgets the box
+            q.blk_state = -1;
+            P.no_block = true;
+            --P.attempt;
+            again = true;
+        } else if (q.h_pc->part_overflow) {                    // a region of the two-level partition was too small: same table
             if (P.one_level) q.one_level_ok = false;           // (one-level: a bucket outgrew its fixed room: counting partition from now on)
             else ++q.two_level_failures;                       // size and estimate again (level-1 regions sized from the fullest
             --P.attempt;                                       // one seen; after two failures the exact counting partition)
@@ -682,7 +767,7 @@ int partition_resolve(gndt_handle* h) {
             if (P.retry_pass && (uint64_t)q.h_pc->lds_retry * 8u > q.last_buckets) q.nodes_learned += q.nodes_learned / 4;
             if (tuning().verbose && P.retry_pass && q.h_pc->lds_retry)
                 fprintf(stderr, "[gndt] %u of %u buckets went through the 1024-slot second pass\n", q.h_pc->lds_retry, q.last_buckets);
-            if (P.n + P.n2) q.pair_ratio = 2.0 * (double)q.h_pc->pairs / (double)(P.n + P.n2);
+            if ((P.n + P.n2) && !P.blocked) q.pair_ratio = 2.0 * (double)q.h_pc->pairs / (double)(P.n + P.n2);      // (the blocked kernel does not count pairs)
             // the larger tables are remembered only if the small ones failed although the estimate was adequate (a first build
             // without a hint guesses n / 4 nodes: its failure says nothing about the cloud)
             const bool est_was_fine = P.est_reliable && P.est0 >= (uint64_t)h->h_cnt->num_nodes;
@@ -695,6 +780,7 @@ int partition_resolve(gndt_handle* h) {
             }
             h->table_dirty = false;
             P.active = false;
+            blocked_decide(h, P);
             return GNDT_OK;
         }
         rc = -1;

@@ -91,6 +91,8 @@ void free_part(gndt_handle* h) {
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (q.h_pc) (void)hipHostFree(q.h_pc);
+    if (q.d_extent) (void)hipFree(q.d_extent);
+    if (q.h_extent) (void)hipHostFree(q.h_extent);
     q = gndt_handle::Part{};
 }
 

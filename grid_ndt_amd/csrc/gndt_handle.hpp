@@ -157,6 +157,10 @@ struct gndt_handle {
         unsigned long long* dbg = nullptr;  uint32_t dbg_buckets = 0;   // diagnostic phase stamps (gndt_debug_enable_stamps)
         uint32_t last_buckets = 0;
         uint64_t nodes_learned = 0;   // node count of the last successful PARTITION build (+20 %)
+        // blocked buckets (gndt_blocked.hpp): 0 = not looked at yet, 1 = the map of the last build is a dense box: the next builds of
+        // clouds of that size take them, -1 = no (or a blocked build failed)
+        int blk_state = 0;  uint64_t blk_n = 0;  BlockMap blk_map{};  uint32_t blk_buckets = 0;
+        uint32_t* d_extent = nullptr;  uint32_t* h_extent = nullptr;      // k_key_extent's seven words and their pinned mirror
         int good_slots = 0; uint64_t good_est = 0, good_n = 0;   // table size / estimate that worked last time
         int good_load = 0;          //   ... and the table load (percent) if it had to be lowered (0: the default)
         int load_pct = 60;          // average LDS-table load (percent) the bucket count aims at
@@ -257,6 +261,8 @@ struct gndt_handle {
         bool retry_pass = false;        //   ... and the bucket kernel's second pass behind the first (overflowing 512-slot tables done again with 1024)
         double mean1 = 0.0;             // its mean level-1 region fill (to turn the fullest region into a ratio)
         bool stats_only = false;        // gndt_shard_stats_device: statistics out, no labels / ordering / rows
+        bool blocked = false;           // this attempt used blocked buckets (gndt_blocked.hpp)
+        bool no_block = false;          //   ... a blocked attempt of this build failed: hashed buckets from here on
         uint64_t captured_gen = 0;      // Handle::realloc_gen when this build was recorded (captured builds only)
         bool captured = false;          // launched on a stream under hipGraph capture: it runs when the graph is replayed, with the
                                         //   buffers it was recorded with — never re-run here with more room (new buffers: the graph holds the old)
@@ -309,6 +315,10 @@ struct Tuning {
                                  //   (200 k-point campus frame 0.0549 -> 0.0535 ms, bridge_ground 0.0647 -> 0.0646: r05 ablation 6h)
     int small_tiles = 1;         // one-level partition of < 1 M points: 1024-point level-1 tiles (a few hundred workgroups instead of a few dozen:
                                  //   campus frame 0.0535 -> 0.0520 ms, bridge_ground 0.0648 -> 0.0608; r05 ablation 6i)
+#ifndef GNDT_BLOCKED
+#define GNDT_BLOCKED 1
+#endif
+    int blocked = GNDT_BLOCKED;  // clouds whose map is a dense, evenly filled box: spatial blocks as buckets, directly addressed tables (round 6)
 #ifndef GNDT_THREE_WGS
 #define GNDT_THREE_WGS 1
 #endif
@@ -384,7 +394,7 @@ inline uint32_t pow2_ceil(uint64_t v) {
 }
 
 inline GridParams grid_params(const gndt_handle* h) {
-    GridParams g;
+    GridParams g{};            // (blk.on = 0: buckets by column hash; partition_launch fills the block map in when it takes the blocked build)
     g.ox = h->origin[0]; g.oy = h->origin[1]; g.oz = h->origin[2];
     g.grid_len = h->P.grid_len; g.z_len = h->P.z_len; g.slope_interval = h->P.slope_interval;
     g.demand = h->P.demand; g.min_points = h->P.min_points;

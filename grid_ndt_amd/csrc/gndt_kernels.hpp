@@ -65,11 +65,21 @@ struct Counters {
                               //   PARTITION build captured after an ATOMIC fallback cleared "slots" read from there — a GPU memory fault)
 };
 
+// Spatially BLOCKED buckets (round 6, gndt_blocked.hpp): a bucket is a block of 2^shx x 2^shy columns x 2^shz levels = 512 nodes of the
+// occupied key box, so a node's place in the bucket's table is computed from its key — no index, no search.  cx = sx > 0 ? sx - 1 : sx
+// (likewise cy, cz) makes the signed indices contiguous (there is no index 0).  on = 0: buckets by column hash (everything else).
+struct BlockMap {
+    int on;
+    int x0, y0, z0;            // smallest contiguous index of the box on every axis
+    int shx, shy, shz;         // log2 of the block's extent; shx + shy + shz = 9
+    int nx, ny;                // blocks along x and y (one layer of blocks: the box is at most 2^shz levels high); buckets = nx * ny
+};
 struct GridParams {
     float ox, oy, oz;
     float grid_len, z_len, slope_interval;
     int demand, min_points;
     float inv_grid, inv_z;     // RN(1 / grid_len), RN(1 / z_len): axis_index_fast (gndt_math.hpp)
+    BlockMap blk;
 };
 
 struct OutView {

@@ -52,6 +52,7 @@ struct PartCounters {
     uint32_t capture_id;       // HOST MIRROR ONLY: which recorded call produced what the mirrors hold (0: a call the host launched itself).
                                //   Stored by the kernel that sends the counters home; the host compares it with what it knows of that
                                //   capture (gndt_sync): a replay it did not see, buffers reallocated since the recording.
+    uint32_t blk_miss;         // blocked buckets (gndt_blocked.hpp): records that do not belong to the block their bucket is (the build is re-run hashed)
     uint32_t lds_retry;        // buckets whose 512-slot table overflowed and that wait for the second pass with 1024 slots (the retry list's length)
 };
 
@@ -110,6 +111,18 @@ __host__ __device__ __forceinline__ uint32_t column_hash(int sx, int sy) {
 __host__ __device__ __forceinline__ uint32_t bucket_of(uint32_t colh, uint32_t B) {
     return (uint32_t)(((uint64_t)(colh >> 8) * (uint64_t)(B & 0xFFFFFFu)) >> 24);
 }
+// contiguous form of a signed index (there is no index 0): ... -2, -1, 1, 2 ... -> ... -2, -1, 0, 1 ...
+__host__ __device__ __forceinline__ int contiguous_index(int s) { return s > 0 ? s - 1 : s; }
+// Bucket of a column.  Hashed (the default), or — GridParams::blk.on — the spatial block the column lies in; a column outside the
+// box the block map was laid out for is clamped into it and `miss` is set (the bucket kernel finds the stranger and the build is
+// re-run with hashed buckets: gndt_blocked.hpp).
+__host__ __device__ __forceinline__ uint32_t column_bucket(int sx, int sy, const GridParams& P, uint32_t B) {
+    if (!P.blk.on) return bucket_of(column_hash(sx, sy), B);
+    int bx = (contiguous_index(sx) - P.blk.x0) >> P.blk.shx, by = (contiguous_index(sy) - P.blk.y0) >> P.blk.shy;
+    bx = bx < 0 ? 0 : (bx >= P.blk.nx ? P.blk.nx - 1 : bx);
+    by = by < 0 ? 0 : (by >= P.blk.ny ? P.blk.ny - 1 : by);
+    return (uint32_t)(bx * P.blk.ny + by);
+}
 // Owner rank of a column when a cloud is sharded over W GPUs and every rank builds the columns it owns (gndt_api_dist.hip).
 // A SECOND hash of the column, independent of column_hash: the buckets and LDS slots of the owner's local build are chosen
 // by column_hash, whose distribution must not be narrowed by the choice of the owner.
@@ -152,7 +165,7 @@ __device__ __forceinline__ uint32_t owner_lookup(const OwnerMap& M, int sx, int 
 constexpr uint32_t kPartModeOwner = 1u;      // digit = owner of the column among B ranks instead of bucket_of(column_hash, B)
 constexpr uint32_t kPartModeRecords = 2u;    // input is 16-B records {x, y, z, index word}: the index word is taken as it is
 __device__ __forceinline__ uint32_t part_digit(int sx, int sy, uint32_t B, uint32_t mode, const OwnerMap& M) {
-    return (mode & kPartModeOwner) ? owner_lookup(M, sx, sy, B) : bucket_of(column_hash(sx, sy), B);
+    return (mode & kPartModeOwner) ? owner_lookup(M, sx, sy, B) : bucket_of(column_hash(sx, sy), B);      // (the counting partition: hashed buckets only)
 }
 __device__ __forceinline__ uint32_t node_slot_hash(uint32_t colh, int sz) {
     uint32_t g = (colh * 0x9E3779B1u) ^ ((uint32_t)sz * 0xC2B2AE3Du);
@@ -235,7 +248,7 @@ static __global__ void __launch_bounds__(256) k_part_clear(Counters* __restrict_
         cnt->num_nodes = 0; cnt->num_columns = 0; cnt->num_slopes = 0; cnt->err_key_range = 0; cnt->err_table_full = 0;
         cnt->part_owned = 1u;                        // (num_nodes counts staged rows from here on, not the table's node list)
         pc->lds_overflow = 0; pc->stage_overflow = 0; pc->index_overflow = 0; pc->part_overflow = 0;
-        pc->max_fill1 = 0; pc->fp_clashes = 0; pc->l1_ticket = 0; pc->small_fallback = 0; pc->pairs = 0; pc->lds_retry = 0;
+        pc->max_fill1 = 0; pc->fp_clashes = 0; pc->l1_ticket = 0; pc->small_fallback = 0; pc->pairs = 0; pc->lds_retry = 0; pc->blk_miss = 0;
     }
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < words; i += (uint64_t)gridDim.x * blockDim.x) { bitmap[i] = 0u; word_weight[i] = 0u; }
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_cursors; i += gridDim.x * blockDim.x) cursors[i] = 0u;   // two-level partition
@@ -612,7 +625,7 @@ __global__ void __launch_bounds__(kTileThreads) __attribute__((amdgpu_waves_per_
                 if constexpr (OWNER) {
                     dig[j] = owner_lookup(M, sx, sy, B);
                 } else {
-                    const uint32_t b = bucket_of(column_hash(sx, sy), B);
+                    const uint32_t b = column_bucket(sx, sy, P, B);
                     dig[j] = r_is_one ? (b >> F2_shift) : (b >> F2_shift) * R + rep;  // F2 is a power of two; sub-region rep of coarse region b >> F2_shift
                     // One record in kSampleEvery votes for its bucket (k_part2_layout sizes the buckets' regions from the
                     // votes).  Chosen by a hash of the point index: a fixed stride would alias with the scan pattern of a
@@ -676,7 +689,7 @@ __global__ void __launch_bounds__(kTileThreads) k_part2_level2(const float4* __r
             int sx, sy;
             bool kok;
             column_of_point(r[j].x, r[j].y, P, sx, sy, kok);
-            dig[j] = bucket_of(column_hash(sx, sy), B) - b0;
+            dig[j] = column_bucket(sx, sy, P, B) - b0;
         }
     }
     tile_partition<PER, FAN>(L, r, dig, nd, cursor2 + b0, 0u, 0ull, 0ull, lo + b0, cap + b0, recs2, pc);

@@ -430,14 +430,16 @@ class TwoDmap:
               5: ("clear", "accumulate", "columns", "rows", "bitmap_scan", "rank", "column_scan", "dest", "emit"),
               2: ("clear", "level1", "layout", "level2", "bucket_build", "bitmap_scan", "rank", "column_scan", "dest", "emit"),
               3: ("clear", "hist", "offsets", "scatter", "bucket_build", "bitmap_scan", "rank", "column_scan", "dest", "emit"),
-              6: ("clear", "level1", "layout", "ranges", "bucket_build", "bitmap_scan", "rank", "column_scan", "dest", "emit")}
-    STRATEGY_NAMES = {1: "atomic", 2: "partition", 3: "partition_exact", 5: "tile", 6: "partition_one_level"}
+              6: ("clear", "level1", "layout", "ranges", "bucket_build", "bitmap_scan", "rank", "column_scan", "dest", "emit"),
+              7: ("clear", "level1", "layout", "level2", "bucket_build", "bitmap_scan", "rank", "column_scan", "dest", "emit")}
+    STRATEGY_NAMES = {1: "atomic", 2: "partition", 3: "partition_exact", 5: "tile", 6: "partition_one_level", 7: "partition_blocked"}
     # phase -> the kernel that fills it, and what each phase's kernel moves algorithmically (bench.py's roofline line):
     # kernels that stream the cloud 12 B/point, the bucket kernel 12 B/point + 76 B/node, node kernels 76 B/node
     KERNEL_OF_PHASE = {"accumulate": "k_accumulate", "hist": "k_part_hist", "scatter": "k_part_scatter",
                        "level1": "k_part2_level1", "level2": "k_part2_level2",
                        "bucket_build": "k_bucket_direct",
                        "columns": "k_tab_columns", "rows": "k_tab_rows", "emit": "k_emit_rows"}
+    KERNEL_OF_PHASE_BLOCKED = dict(KERNEL_OF_PHASE, bucket_build="k_bucket_blocked")      # strategy 7 (gndt_blocked.hpp)
     POINT_PHASES = ("accumulate", "hist", "scatter", "level1", "level2")
     POINT_AND_NODE_PHASES = ("bucket_build",)
 

@@ -63,6 +63,10 @@ enum {
     GNDT_STRATEGY_PARTITION_TWO_LEVEL = 4,  /* the two-level partition whatever the size (PARTITION picks it from 2^20 points) */
     GNDT_STRATEGY_PARTITION_ONE_LEVEL = 6,  /* (reported by gndt_last_strategy only) small clouds: one tile-sort level writes the
                                              * buckets directly; PARTITION / AUTO pick it when the cloud needs at most 512 buckets */
+    GNDT_STRATEGY_PARTITION_BLOCKED = 7,    /* (reported by gndt_last_strategy only) the two partition levels with SPATIAL blocks of 512 nodes as
+                                             * buckets and a bucket kernel that addresses its table directly (no index, no search): taken by AUTO /
+                                             * PARTITION for clouds whose map is a dense, evenly filled box of bounded height (what the previous
+                                             * build on the handle found), abandoned — the build re-run with hashed buckets — when a cloud outgrows it */
     GNDT_STRATEGY_TILE = 5        /* one pass for clouds that keep their scan order: contiguous ranges of the cloud, node table
                                      privatised in LDS per workgroup, ONE partial per distinct node and flush into the HBM node
                                      table (gndt_tile.hpp).  AUTO takes it when a sample of the cloud shows enough points per

@@ -857,10 +857,11 @@ def test_partition_build_replayed_from_a_hip_graph():
     for _ in range(2):                                    # eager builds: every buffer exists, capacities are learnt
         m.create2DMap("slope", buf)
         m.sync()
-    assert m.last_strategy() == 2
+    assert m.last_strategy() in (2, 7)                    # (7: the second eager build of this dense box takes blocked buckets)
     graph = torch.cuda.CUDAGraph()
     with g.graph_capture(graph):
         m.create2DMap("slope", buf)
+    assert m.last_strategy() == 2                         # a RECORDED build never does: its replays see other clouds
     for k in (1, 2):
         buf.copy_(torch.from_numpy(clouds[k][1:]))
         graph.replay()
