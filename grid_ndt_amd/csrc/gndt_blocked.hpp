@@ -23,7 +23,11 @@
 namespace gndt {
 
 struct BlockedLds {            // 47 KB: three workgroups per CU
+#if GNDT_BLOCKED_FIXED
+    unsigned long long sum[9][512];    // FIXED-POINT sums (two's complement): see the accumulate loop
+#else
     double sum[9][512];
+#endif
     uint32_t cnt[512];
     uint32_t first[512];
     uint2 fz[512];             // {first-seen index (0xFFFFFFFF: no node in this slot), fp32 mean z of a node that has statistics, else 0}: what a
@@ -32,6 +36,26 @@ struct BlockedLds {            // 47 KB: three workgroups per CU
     uint32_t wave_tot[8];
     uint32_t n_nodes, n_cols, n_slopes, stage_base, err_range, miss;
 };
+
+// Fixed-point contributions (-DGNDT_BLOCKED_FIXED=1; built, parity-green, measured, NOT the default).  In this kernel the LDS array, not
+// the vector port, is the busy one (63 % against 34 %: profiles/r06_ablation.txt 8) and `ds_add_u64` takes half the time of `ds_add_f64` in
+// isolation (10.2 against 19.9 clocks per wave-instruction at random slots, profiles/r03_lds_atomic_rates.txt) — so the nine sums were
+// kept as 64-bit integers: a contribution x becomes round(x * 2^k) by ONE fused multiply-add against 1.5 * 2^52 (its low mantissa bits
+// ARE the integer for |x * 2^k| < 2^51), the sums are order-independent (bit-identical statistics run to run).  Scales: offsets from the
+// cell centre are below half a cell < 2^e, first moments take 2^(38 - e), second moments 2^(38 - 2 e); a node may hold 2^23 points
+// before a sum could pass 2^61 (beyond: the bucket is a miss).  Measured in one call, twice: bucket kernel 124.0 | 124.0 us against
+// 121.6 | 120.2 with fp64 sums, the accumulate stamps equal (33.6-34.2 k cycles) — the atomic unit's instruction rate is not what the
+// 63 % are made of (bank conflicts and the queue behind them are) — and k_emit_rows 45-46 us against 34.5 (the quantised sums send more
+// nodes through the eigen-solver's slow start).  Fp64 sums stay.
+#ifndef GNDT_BLOCKED_FIXED
+#define GNDT_BLOCKED_FIXED 0      // 1: fixed-point sums (A/B)
+#endif
+constexpr double kFixMagic = 6755399441055744.0;      // 1.5 * 2^52
+constexpr uint32_t kFixMaxCount = 1u << 23;
+__device__ __forceinline__ unsigned long long fix_round(double x, double scale) {
+    const double t = fma(x, scale, kFixMagic);
+    return (unsigned long long)__double_as_longlong(t) - (unsigned long long)__double_as_longlong(kFixMagic);
+}
 
 // One workgroup per bucket (the hardware's dynamic scheduling), three resident per CU.  The staging rows of a bucket are reserved with one
 // memory-side atomic whose answer takes ~3 us; to have it in time the bucket's node count is known the moment the accumulate phase
@@ -53,6 +77,9 @@ __global__ void __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(6, 6))) 
     const uint32_t col_mask = (1u << sh_xy) - 1u, n_levels = 1u << K.shz;
     const double hx = 0.5 * (double)P.grid_len, hz = 0.5 * (double)P.z_len;
     const double ox = (double)P.ox, oy = (double)P.oy, oz = (double)P.oz;
+    const int fix_e = ilogb(fmax(hx, hz)) + 1;                  // half a cell < 2^fix_e on every axis
+    const double scale1 = ldexp(1.0, 38 - fix_e), scale2 = ldexp(1.0, 38 - 2 * fix_e);
+    const double inv1 = ldexp(1.0, fix_e - 38), inv2 = ldexp(1.0, 2 * fix_e - 38);
     for (uint32_t bucket = blockIdx.x; bucket < num_buckets; bucket += gridDim.x) {
 #define GNDT_STAMPB(k) do { if (dbg && tid == 0) dbg[(size_t)bucket * 16 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
         uint32_t lo, hi;
@@ -63,7 +90,7 @@ __global__ void __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(6, 6))) 
         {
             const int s = tid;
 #pragma unroll
-            for (int j = 0; j < 9; ++j) L.sum[j][s] = 0.0;
+            for (int j = 0; j < 9; ++j) L.sum[j][s] = 0;
             L.cnt[s] = 0u; L.first[s] = 0xFFFFFFFFu;
             if (tid == 0) { L.n_nodes = 0; L.n_cols = 0; L.n_slopes = 0; L.stage_base = 0; L.err_range = 0; L.miss = 0; }
         }
@@ -111,9 +138,15 @@ __global__ void __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(6, 6))) 
             old_cnt = 1u;
             if (use) {
                 old_cnt = atomicAdd(&L.cnt[s], cn);
+#if GNDT_BLOCKED_FIXED
+                atomicAdd(&L.sum[0][s], fix_round(w0, scale1)); atomicAdd(&L.sum[1][s], fix_round(w1, scale1)); atomicAdd(&L.sum[2][s], fix_round(w2, scale1));
+                atomicAdd(&L.sum[3][s], fix_round(w0 * v0, scale2)); atomicAdd(&L.sum[4][s], fix_round(w0 * v1, scale2)); atomicAdd(&L.sum[5][s], fix_round(w0 * v2, scale2));
+                atomicAdd(&L.sum[6][s], fix_round(w1 * v1, scale2)); atomicAdd(&L.sum[7][s], fix_round(w1 * v2, scale2)); atomicAdd(&L.sum[8][s], fix_round(w2 * v2, scale2));
+#else
                 atomicAdd(&L.sum[0][s], w0); atomicAdd(&L.sum[1][s], w1); atomicAdd(&L.sum[2][s], w2);
                 atomicAdd(&L.sum[3][s], w0 * v0); atomicAdd(&L.sum[4][s], w0 * v1); atomicAdd(&L.sum[5][s], w0 * v2);
                 atomicAdd(&L.sum[6][s], w1 * v1); atomicAdd(&L.sum[7][s], w1 * v2); atomicAdd(&L.sum[8][s], w2 * v2);
+#endif
                 atomicMin(&L.first[s], cf);
             }
         }
@@ -140,8 +173,13 @@ __global__ void __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(6, 6))) 
         const uint32_t my_n = L.cnt[s], my_first = L.first[s];
         double sums[9];
 #pragma unroll
+#if GNDT_BLOCKED_FIXED
+        for (int j = 0; j < 9; ++j) sums[j] = (double)(long long)L.sum[j][s] * (j < 3 ? inv1 : inv2);
+#else
         for (int j = 0; j < 9; ++j) sums[j] = L.sum[j][s];
+#endif
         const bool live = my_n != 0u;
+        if (my_n > kFixMaxCount) L.miss = 1u;                   // (a node of more points than the fixed-point sums are sized for: hashed buckets)
         const uint32_t col = s & col_mask, lz = s >> sh_xy;
         // signed indices of this slot's node
         const int cxi = bx0 + (int)(col & ((1u << K.shx) - 1u)), cyi = by0 + (int)(col >> K.shx), czi = K.z0 + (int)lz;
@@ -149,6 +187,11 @@ __global__ void __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(6, 6))) 
         const float cz = (live && my_n >= (uint32_t)P.min_points) ? node_mean_z(my_n, sums[2], axis_centre(nsz, P.oz, P.z_len)) : 0.f;
         L.fz[s] = make_uint2(my_first, __float_as_uint(cz));
         lds_barrier();
+        if (L.miss) {                                  // (uniform; nothing of this bucket has left the workgroup but its reservation: the build is re-run)
+            if (tid == 0) atomicAdd(&pc->blk_miss, 1u);
+            lds_barrier();
+            continue;
+        }
         // ---- the column of every node: the slots that differ in the level bits — independent 8-byte reads, no search.  The thread of a
         //      column's level-0 slot walks the column whether that slot holds a node or not: its node count is what the prefix over the
         //      columns (first row of every column inside the bucket) is made of ----
