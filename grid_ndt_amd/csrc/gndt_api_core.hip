@@ -363,6 +363,7 @@ int gndt_set_origin(gndt_handle* h, const float origin_xyz[3]) {
     // a build still pending belongs to the OLD origin: settle it (flags, retries) before the origin moves
     if (h->pending.active) { const int prc = partition_resolve(h); if (prc) return prc; }
     if (h->table_dirty) { h->err = "origin cannot change while the map holds points (call gndt_reset)"; return GNDT_ERR_INVALID; }
+    if (memcmp(h->origin, origin_xyz, 3 * sizeof(float)) != 0) h->part.blk_state = 0;      // (a box of blocked buckets belongs to the keys of the old origin)
     memcpy(h->origin, origin_xyz, 3 * sizeof(float));
     h->origin_set = true;
     return GNDT_OK;

@@ -448,8 +448,9 @@ void gndt_unpack_key(uint64_t key, int32_t* sx, int32_t* sy, int32_t* sz);
  * (bucket_build / accumulate): two events per build instead of eleven. */
 int gndt_set_profiling(gndt_handle* h, int enable);
 int gndt_get_phase_times(gndt_handle* h, double ms_out[GNDT_NUM_PHASES]);
-/* GNDT_STRATEGY_ATOMIC, _PARTITION (two-level), _PARTITION_ONE_LEVEL, _PARTITION_EXACT or _TILE: what the last build actually ran (AUTO resolves,
- * and PARTITION falls back to ATOMIC when a bucket does not fit in LDS). */
+/* GNDT_STRATEGY_ATOMIC, _PARTITION (two-level, hashed buckets), _PARTITION_BLOCKED (two-level, spatial blocks as buckets), _PARTITION_ONE_LEVEL,
+ * _PARTITION_EXACT or _TILE: what the last build actually ran (AUTO resolves, and PARTITION falls back to ATOMIC when a bucket does not
+ * fit in LDS). */
 /* The measurement AUTO bases that choice on, for logs and tuning: `tiles` tiles of 2048 consecutive points spread over the
  * cloud; *points_per_partial = points looked at / distinct nodes met per tile.  Waits for the result. */
 int gndt_locality_sample(gndt_handle* h, const void* xyz_dev, size_t n, size_t stride_bytes, uint32_t tiles, double* points_per_partial,
