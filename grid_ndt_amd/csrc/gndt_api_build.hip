@@ -110,15 +110,32 @@ int ensure_cursors(gndt_handle* h, uint64_t B) {
     auto& q = h->part;
     if (B <= q.cur_cap) return GNDT_OK;
     GNDT_NO_CAPTURE(h, "the partition cursors");
-    for (uint32_t** a : {&q.cursors, &q.range_lo, &q.range_hi, &q.range_cap}) { release_device(h, *a); *a = nullptr; }
+    for (uint32_t** a : {&q.cursors, &q.cursors_alt, &q.range_lo, &q.range_hi, &q.range_cap}) { release_device(h, *a); *a = nullptr; }
     q.cur_cap = 0;
+    q.alt_clean = false;
     const uint64_t c = B + B / 4;
     HIP_TRY(h, hipMalloc(&q.cursors, ((size_t)kMaxFan + 2 * c) * 4));  // [kMaxFan] level 1, [c] level 2, [c] samples
+    HIP_TRY(h, hipMalloc(&q.cursors_alt, ((size_t)kMaxFan + 2 * c) * 4));      // (the set the next eager build takes: FoldClear)
     HIP_TRY(h, hipMalloc(&q.range_lo, c * 4));
     HIP_TRY(h, hipMalloc(&q.range_hi, c * 4));                        // (the retry list)
     HIP_TRY(h, hipMalloc(&q.range_cap, c * 4));
     q.cur_cap = c;
     return GNDT_OK;
+}
+
+// FoldClear (gndt_partition.hpp, Part::cursors_alt): an eager one-level PARTITION build of points (a frame of < 1 M points) takes the
+// cursors / partition counters the level-1 kernel of the build before it zeroed and launches no k_part_clear; its own level-1 kernel
+// zeroes the other set, the bitmap and the Counters.  200 k-point campus frame: 0.0491 -> 0.0472 ms back to back, 0.068 -> 0.0635
+// awaited; bridge_ground 0.0586 -> 0.0574, 0.078 -> 0.074 (profiles/r06_ablation.txt 9).  Returns what that kernel is to zero (words == 0: a k_part_clear launch still prepares THIS build — the first build of a
+// handle, buffers that grew; alt_cursors == nullptr: nothing on the side — records, recorded builds, handles that ever recorded one:
+// a replay works on the set it was recorded with and the host does not see it).
+static FoldClear fold_clear_begin(gndt_handle* h, const gndt_handle::Pending& P, uint64_t words) {
+    auto& q = h->part;
+    if (!tuning().fold_clear || P.records || h->capturing || h->ever_captured || !q.cursors_alt || !q.d_pc_alt) return FoldClear{};
+    const bool clean = q.alt_clean;
+    if (clean) { std::swap(q.cursors, q.cursors_alt); std::swap(q.d_pc, q.d_pc_alt); }
+    q.alt_clean = true;                    // (from this build's level-1 kernel on, in stream order)
+    return FoldClear{q.cursors_alt, (uint32_t)(kMaxFan + 2 * q.cur_cap), q.d_pc_alt, q.bitmap, q.word_weight, clean ? words : 0ull};
 }
 
 // One attempt of the PARTITION build: every launch plus the asynchronous read-back of the counters and overflow
@@ -239,6 +256,9 @@ int partition_launch(gndt_handle* h, gndt_handle::Pending& P) {
         if ((rc = grow_buf(h, q.recs1, q.rec1_cap, (uint64_t)V * cap1))) return rc;
         if ((rc = grow_buf(h, q.recs, q.rec_cap, recs_want))) return rc;
         if ((rc = ensure_cursors(h, B))) return rc;
+        // (no FoldClear here: measured on the bench scene, one call, A B A B: 0.3129 | 0.3143 ms per step with it, 0.3116 | 0.3117 with the
+        //  k_part_clear launch — level 1 and level 2 each a microsecond slower; the one-level partition of a small frame is where it pays)
+        const FoldClear fold{};
         uint32_t* cursor1 = q.cursors;
         uint32_t* cursor2 = q.cursors + kMaxFan;
         uint32_t* est2 = cursor2 + B;
@@ -246,9 +266,11 @@ int partition_launch(gndt_handle* h, gndt_handle::Pending& P) {
         // (a build recorded into a hipGraph always records the reset: its replays must not depend on what the table held at capture time)
         if (h->table_dirty || h->capturing) { if ((rc = do_reset(h, s))) return rc; }
         h->results_valid = false;
-        hipLaunchKernelGGL(k_part_clear, dim3(grid_for(words, 256, 512)), dim3(256), 0, s, h->d_cnt, q.d_pc, q.bitmap, q.word_weight, (uint64_t)words,
-                           q.cursors, (uint32_t)(kMaxFan + 2 * B));
-        HIP_TRY(h, hipGetLastError());
+        if (!fold.words) {
+            hipLaunchKernelGGL(k_part_clear, dim3(grid_for(words, 256, 512)), dim3(256), 0, s, h->d_cnt, q.d_pc, q.bitmap, q.word_weight, (uint64_t)words,
+                               q.cursors, (uint32_t)(kMaxFan + 2 * B));
+            HIP_TRY(h, hipGetLastError());
+        }
         mark(h, 1, s);
         const uint32_t tiles1 = (uint32_t)((P.n + kTile1 - 1) / kTile1), tiles1b = (uint32_t)((P.n2 + kTile1 - 1) / kTile1);
         const uint32_t l1_wgs = tuning().l1_wgs;   // persistent workgroups (2 resident per CU)
@@ -259,16 +281,16 @@ int partition_launch(gndt_handle* h, gndt_handle::Pending& P) {
 #define GNDT_L1(SF_, FAN_)                                                                                                  \
     hipLaunchKernelGGL((k_part2_level1<SF_, FAN_>), g1, dim3(kTileThreads), 0, s, p, (uint64_t)n, P.first_base, gp, B, F1, F2_shift, \
                        R, cursor1, cap1, est2, q.recs1, h->d_cnt, q.d_pc, compress, OwnerMap{nullptr, nullptr, 0u}, q.range_lo,     \
-                       q.range_cap, (uint64_t)q.rec_cap)
+                       q.range_cap, (uint64_t)q.rec_cap, fold)
         // records: the two segments one after the other into the same regions (the cursors carry on; the last launch lays out)
 #define GNDT_L1R(FAN_)                                                                                                      \
     do {                                                                                                                    \
         if (P.n) hipLaunchKernelGGL((k_part2_level1<4, FAN_, true>), g1, dim3(kTileThreads), 0, s, p, (uint64_t)P.n, P.first_base, gp, B, F1, \
                                     F2_shift, R, cursor1, cap1, est2, q.recs1, h->d_cnt, q.d_pc, compress, OwnerMap{nullptr, nullptr, 0u}, \
-                                    P.n2 ? (uint32_t*)nullptr : q.range_lo, q.range_cap, (uint64_t)q.rec_cap);               \
+                                    P.n2 ? (uint32_t*)nullptr : q.range_lo, q.range_cap, (uint64_t)q.rec_cap, FoldClear{});  \
         if (P.n2) hipLaunchKernelGGL((k_part2_level1<4, FAN_, true>), g1b, dim3(kTileThreads), 0, s, p2, (uint64_t)P.n2, P.first_base, gp, B, \
                                      F1, F2_shift, R, cursor1, cap1, est2, q.recs1, h->d_cnt, q.d_pc, compress, OwnerMap{nullptr, nullptr, 0u}, \
-                                     q.range_lo, q.range_cap, (uint64_t)q.rec_cap);                                          \
+                                     q.range_lo, q.range_cap, (uint64_t)q.rec_cap, FoldClear{});                             \
     } while (0)
         if (P.records) { if (wide) GNDT_L1R(512); else GNDT_L1R(256); }
         else if (stride_bytes == 12) { if (wide) GNDT_L1(3, 512); else GNDT_L1(3, 256); }
@@ -293,6 +315,7 @@ int partition_launch(gndt_handle* h, gndt_handle::Pending& P) {
         const uint32_t cap1 = (uint32_t)std::max<uint64_t>(4 * mean, mean + 4096);
         if ((rc = grow_buf(h, q.recs1, q.rec1_cap, (uint64_t)B * cap1))) return rc;
         if ((rc = ensure_cursors(h, B))) return rc;
+        const FoldClear fold = fold_clear_begin(h, P, words);     // (may swap q.cursors / q.d_pc with their clean twins)
         uint32_t* cursor1 = q.cursors;                     // [B <= kMaxFan] the buckets' fills
         uint32_t* est2 = q.cursors + kMaxFan;              // (the kernel's sample votes: not used here, but counted)
         const uint32_t F1 = B, F2_shift = 0, R = 1;
@@ -300,9 +323,11 @@ int partition_launch(gndt_handle* h, gndt_handle::Pending& P) {
         // (a build recorded into a hipGraph always records the reset: its replays must not depend on what the table held at capture time)
         if (h->table_dirty || h->capturing) { if ((rc = do_reset(h, s))) return rc; }
         h->results_valid = false;
-        hipLaunchKernelGGL(k_part_clear, dim3(grid_for(words, 256, 512)), dim3(256), 0, s, h->d_cnt, q.d_pc, q.bitmap, q.word_weight, (uint64_t)words,
-                           q.cursors, (uint32_t)(kMaxFan + B));
-        HIP_TRY(h, hipGetLastError());
+        if (!fold.words) {
+            hipLaunchKernelGGL(k_part_clear, dim3(grid_for(words, 256, 512)), dim3(256), 0, s, h->d_cnt, q.d_pc, q.bitmap, q.word_weight, (uint64_t)words,
+                               q.cursors, (uint32_t)(kMaxFan + B));
+            HIP_TRY(h, hipGetLastError());
+        }
         mark(h, 1, s);
         // small clouds: 1024-point tiles (gndt_partition.hpp: kTilePerSmall), so that the frame is a launch of a few hundred workgroups
         const bool small_tiles = !P.records && n < (1u << 20) && tuning().small_tiles;
@@ -314,19 +339,19 @@ int partition_launch(gndt_handle* h, gndt_handle::Pending& P) {
 #define GNDT_L1(SF_, FAN_)                                                                                                  \
     hipLaunchKernelGGL((k_part2_level1<SF_, FAN_>), g1, dim3(kTileThreads), 0, s, p, (uint64_t)n, P.first_base, gp, B, F1, F2_shift, \
                        R, cursor1, cap1, est2, q.recs1, h->d_cnt, q.d_pc, compress, OwnerMap{nullptr, nullptr, 0u}, (uint32_t*)nullptr, \
-                       (uint32_t*)nullptr, 0ull)
+                       (uint32_t*)nullptr, 0ull, fold)
 #define GNDT_L1S(SF_, FAN_)                                                                                                 \
     hipLaunchKernelGGL((k_part2_level1<SF_, FAN_, false, false, kTilePerSmall>), g1, dim3(kTileThreads), 0, s, p, (uint64_t)n, P.first_base, gp, B, F1, \
                        F2_shift, R, cursor1, cap1, est2, q.recs1, h->d_cnt, q.d_pc, compress, OwnerMap{nullptr, nullptr, 0u}, (uint32_t*)nullptr, \
-                       (uint32_t*)nullptr, 0ull)
+                       (uint32_t*)nullptr, 0ull, fold)
 #define GNDT_L1R(FAN_)                                                                                                      \
     do {                                                                                                                    \
         if (P.n) hipLaunchKernelGGL((k_part2_level1<4, FAN_, true>), g1, dim3(kTileThreads), 0, s, p, (uint64_t)P.n, P.first_base, gp, B, F1, \
                                     F2_shift, R, cursor1, cap1, est2, q.recs1, h->d_cnt, q.d_pc, compress, OwnerMap{nullptr, nullptr, 0u}, \
-                                    (uint32_t*)nullptr, (uint32_t*)nullptr, 0ull);                                           \
+                                    (uint32_t*)nullptr, (uint32_t*)nullptr, 0ull, FoldClear{});                              \
         if (P.n2) hipLaunchKernelGGL((k_part2_level1<4, FAN_, true>), g1b, dim3(kTileThreads), 0, s, p2, (uint64_t)P.n2, P.first_base, gp, B, \
                                      F1, F2_shift, R, cursor1, cap1, est2, q.recs1, h->d_cnt, q.d_pc, compress, OwnerMap{nullptr, nullptr, 0u}, \
-                                     (uint32_t*)nullptr, (uint32_t*)nullptr, 0ull);                                          \
+                                     (uint32_t*)nullptr, (uint32_t*)nullptr, 0ull, FoldClear{});                             \
     } while (0)
         if (small_tiles) {
             if (stride_bytes == 12) { if (wide) GNDT_L1S(3, 512); else GNDT_L1S(3, 256); }

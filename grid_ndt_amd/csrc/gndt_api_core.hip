@@ -87,7 +87,7 @@ int check_ready(gndt_handle* h) {
 void free_part(gndt_handle* h) {
     auto& q = h->part;
     void* ptrs[] = {q.recs, q.recs1, q.cursors, q.range_lo, q.range_hi, q.range_cap, q.hist, q.totals, q.bucket_base, q.stage, q.ord_cf, q.ord_idx, q.inv, q.row_of, q.row_ncol, q.raw,
-                    q.bitmap, q.word_weight, q.word_base, q.bsum_words, q.ncol_at, q.d_pc, q.dbg};
+                    q.bitmap, q.word_weight, q.word_base, q.bsum_words, q.ncol_at, q.d_pc, q.dbg, q.cursors_alt, q.d_pc_alt};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (q.h_pc) (void)hipHostFree(q.h_pc);
@@ -172,8 +172,11 @@ int ensure_part_counters(gndt_handle* h) {
     if (q.d_pc) return GNDT_OK;
     GNDT_NO_CAPTURE(h, "the partition counters");
     HIP_TRY(h, hipMalloc(&q.d_pc, sizeof(PartCounters)));
+    HIP_TRY(h, hipMalloc(&q.d_pc_alt, sizeof(PartCounters)));
     HIP_TRY(h, hipHostMalloc(&q.h_pc, sizeof(PartCounters)));
     { const int rc = zero_device_now(h, q.d_pc, sizeof(PartCounters)); if (rc) return rc; }
+    { const int rc = zero_device_now(h, q.d_pc_alt, sizeof(PartCounters)); if (rc) return rc; }
+    q.alt_clean = false;
     memset(q.h_pc, 0, sizeof(PartCounters));
     return GNDT_OK;
 }

@@ -34,7 +34,7 @@ struct BlockedLds {            // 47 KB: three workgroups per CU
                                //   node's look at its column reads of the others, one 8-byte load per level
     uint32_t cpre[512];        // per COLUMN (the first 2^(shx+shy) entries): first row of the column inside the bucket
     uint32_t wave_tot[8];
-    uint32_t n_nodes, n_cols, n_slopes, stage_base, err_range, miss;
+    uint32_t n_nodes, n_cols, n_slopes, stage_base, err_range, miss, miss2;      // (miss2: raised after the accumulate phase — a word of its own, the first is being read then)
 };
 
 // Fixed-point contributions (-DGNDT_BLOCKED_FIXED=1; built, parity-green, measured, NOT the default).  In this kernel the LDS array, not
@@ -77,6 +77,7 @@ __global__ void __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(6, 6))) 
     const uint32_t col_mask = (1u << sh_xy) - 1u, n_levels = 1u << K.shz;
     const double hx = 0.5 * (double)P.grid_len, hz = 0.5 * (double)P.z_len;
     const double ox = (double)P.ox, oy = (double)P.oy, oz = (double)P.oz;
+    if (blockIdx.x == 0 && tid == 0) { const uint32_t e = pc->l1_err; if (e) atomicAdd(&cnt->err_key_range, e); }   // (FoldClear, gndt_partition.hpp)
     const int fix_e = ilogb(fmax(hx, hz)) + 1;                  // half a cell < 2^fix_e on every axis
     const double scale1 = ldexp(1.0, 38 - fix_e), scale2 = ldexp(1.0, 38 - 2 * fix_e);
     const double inv1 = ldexp(1.0, fix_e - 38), inv2 = ldexp(1.0, 2 * fix_e - 38);
@@ -92,7 +93,7 @@ __global__ void __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(6, 6))) 
 #pragma unroll
             for (int j = 0; j < 9; ++j) L.sum[j][s] = 0;
             L.cnt[s] = 0u; L.first[s] = 0xFFFFFFFFu;
-            if (tid == 0) { L.n_nodes = 0; L.n_cols = 0; L.n_slopes = 0; L.stage_base = 0; L.err_range = 0; L.miss = 0; }
+            if (tid == 0) { L.n_nodes = 0; L.n_cols = 0; L.n_slopes = 0; L.stage_base = 0; L.err_range = 0; L.miss = 0; L.miss2 = 0; }
         }
         lds_barrier();
         GNDT_STAMPB(1);
@@ -179,7 +180,9 @@ __global__ void __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(6, 6))) 
         for (int j = 0; j < 9; ++j) sums[j] = L.sum[j][s];
 #endif
         const bool live = my_n != 0u;
-        if (my_n > kFixMaxCount) L.miss = 1u;                   // (a node of more points than the fixed-point sums are sized for: hashed buckets)
+#if GNDT_BLOCKED_FIXED
+        if (my_n > kFixMaxCount) L.miss2 = 1u;                  // (a node of more points than the fixed-point sums are sized for: hashed buckets)
+#endif
         const uint32_t col = s & col_mask, lz = s >> sh_xy;
         // signed indices of this slot's node
         const int cxi = bx0 + (int)(col & ((1u << K.shx) - 1u)), cyi = by0 + (int)(col >> K.shx), czi = K.z0 + (int)lz;
@@ -187,7 +190,7 @@ __global__ void __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(6, 6))) 
         const float cz = (live && my_n >= (uint32_t)P.min_points) ? node_mean_z(my_n, sums[2], axis_centre(nsz, P.oz, P.z_len)) : 0.f;
         L.fz[s] = make_uint2(my_first, __float_as_uint(cz));
         lds_barrier();
-        if (L.miss) {                                  // (uniform; nothing of this bucket has left the workgroup but its reservation: the build is re-run)
+        if (L.miss2) {                                 // (uniform; nothing of this bucket has left the workgroup but its reservation: the build is re-run)
             if (tid == 0) atomicAdd(&pc->blk_miss, 1u);
             lds_barrier();
             continue;

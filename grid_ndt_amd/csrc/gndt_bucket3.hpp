@@ -744,6 +744,7 @@ __global__ void __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(WAVES, W
     // todo_list: the second pass — the buckets a first pass queued (pc->lds_retry of them), instead of all num_buckets
     __shared__ BucketLds3<H> L;
     const uint32_t count = todo_list ? min(pc->lds_retry, num_buckets) : num_buckets;
+    if (!todo_list && blockIdx.x == 0 && threadIdx.x == 0) { const uint32_t e = pc->l1_err; if (e) atomicAdd(&cnt->err_key_range, e); }   // (FoldClear, gndt_partition.hpp)
     for (uint32_t i = blockIdx.x; i < count; i += gridDim.x) {
         const uint32_t bucket = todo_list ? todo_list[i] : i;
         uint32_t lo, hi;

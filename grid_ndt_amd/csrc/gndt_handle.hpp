@@ -153,6 +153,13 @@ struct gndt_handle {
         uint64_t word_cap = 0;     uint32_t *bitmap = nullptr, *word_weight = nullptr, *word_base = nullptr, *bsum_words = nullptr,
                                             *ncol_at = nullptr;
         PartCounters* d_pc = nullptr;
+        // Round 6: what level 1 needs zeroed BEFORE it starts (the cursors, the partition counters) exists twice; the level-1 kernel of a
+        // build zeroes the set the NEXT build takes (and this build's bitmap / Counters, which nothing reads before the bucket kernel),
+        // so that an eager build is not preceded by a k_part_clear launch (~4.5 us of a 49 us frame).  Not for handles that ever
+        // recorded a hipGraph: a replay uses the set it was recorded with, unseen by the host.
+        uint32_t* cursors_alt = nullptr;
+        PartCounters* d_pc_alt = nullptr;
+        bool alt_clean = false;         // cursors_alt / d_pc_alt are zero (a level-1 kernel launched on this stream left them so)
         PartCounters* h_pc = nullptr;   // pinned
         unsigned long long* dbg = nullptr;  uint32_t dbg_buckets = 0;   // diagnostic phase stamps (gndt_debug_enable_stamps)
         uint32_t last_buckets = 0;
@@ -323,6 +330,10 @@ struct Tuning {
 #define GNDT_THREE_WGS 1
 #endif
     int bucket_three_wgs = GNDT_THREE_WGS;    // clouds without locality: the bucket kernel with one record per thread at three workgroups per CU (round 6)
+#ifndef GNDT_FOLD_CLEAR
+#define GNDT_FOLD_CLEAR 1
+#endif
+    int fold_clear = GNDT_FOLD_CLEAR;    // eager PARTITION builds: no k_part_clear launch — level 1 prepares the next build's cursors / counters (Part::cursors_alt)
     int fp_bits = 21;            // bits of the bucket kernel's index fingerprint (tests narrow it through gndt_debug_set_fp_bits to force clashes)
     // ... and what gndt_debug_set_option / gndt_debug_enable_stamps can set (process-wide; the library reads no environment variable)
     double tile_ratio = 48.0;    // GNDT_DEBUG_TILE_RATIO   AUTO takes strategy TILE from this many points per partial on (sampled; the

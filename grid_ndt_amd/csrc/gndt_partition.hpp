@@ -54,6 +54,17 @@ struct PartCounters {
                                //   capture (gndt_sync): a replay it did not see, buffers reallocated since the recording.
     uint32_t blk_miss;         // blocked buckets (gndt_blocked.hpp): records that do not belong to the block their bucket is (the build is re-run hashed)
     uint32_t lds_retry;        // buckets whose 512-slot table overflowed and that wait for the second pass with 1024 slots (the retry list's length)
+    uint32_t l1_err;           // level 1 with FoldClear: points beyond the key range (the bucket kernel adds them to Counters::err_key_range, which
+                               //   that level-1 launch itself zeroes)
+};
+
+// What a level-1 launch zeroes on the side when no k_part_clear precedes the build (Part::cursors_alt, gndt_handle.hpp): the cursors and
+// partition counters the NEXT build on the handle will take, and THIS build's bitmap, word weights and Counters — none of which a
+// level-1 workgroup reads or adds to (its own cursors / counters were zeroed by the build before).  alt_cursors == nullptr: off.
+struct FoldClear {
+    uint32_t* alt_cursors; uint32_t n_alt;
+    PartCounters* alt_pc;
+    uint32_t* bitmap; uint32_t* weight; uint64_t words;
 };
 
 struct alignas(16) StageRow {   // 96 bytes, gathered whole by k_emit_rows (round 1 padded it to 128: a quarter of the node traffic)
@@ -248,7 +259,7 @@ static __global__ void __launch_bounds__(256) k_part_clear(Counters* __restrict_
         cnt->num_nodes = 0; cnt->num_columns = 0; cnt->num_slopes = 0; cnt->err_key_range = 0; cnt->err_table_full = 0;
         cnt->part_owned = 1u;                        // (num_nodes counts staged rows from here on, not the table's node list)
         pc->lds_overflow = 0; pc->stage_overflow = 0; pc->index_overflow = 0; pc->part_overflow = 0;
-        pc->max_fill1 = 0; pc->fp_clashes = 0; pc->l1_ticket = 0; pc->small_fallback = 0; pc->pairs = 0; pc->lds_retry = 0; pc->blk_miss = 0;
+        pc->max_fill1 = 0; pc->fp_clashes = 0; pc->l1_ticket = 0; pc->small_fallback = 0; pc->pairs = 0; pc->lds_retry = 0; pc->blk_miss = 0; pc->l1_err = 0;
     }
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < words; i += (uint64_t)gridDim.x * blockDim.x) { bitmap[i] = 0u; word_weight[i] = 0u; }
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_cursors; i += gridDim.x * blockDim.x) cursors[i] = 0u;   // two-level partition
@@ -552,7 +563,8 @@ __global__ void __launch_bounds__(kTileThreads) __attribute__((amdgpu_waves_per_
                                                                uint32_t* __restrict__ est2,
                                                                float4* __restrict__ recs1, Counters* __restrict__ cnt,
                                                                PartCounters* __restrict__ pc, uint32_t compress, OwnerMap M,
-                                                               uint32_t* __restrict__ lay_lo, uint32_t* __restrict__ lay_cap, uint64_t rec_capacity) {
+                                                               uint32_t* __restrict__ lay_lo, uint32_t* __restrict__ lay_cap, uint64_t rec_capacity,
+                                                               FoldClear F) {
     constexpr int PER = PER1;
     __shared__ TileLds<PER, FAN> L;
     // Persistent workgroups, software-pipelined: the loads of tile t+1 are in flight while tile t is keyed, sorted
@@ -572,6 +584,17 @@ __global__ void __launch_bounds__(kTileThreads) __attribute__((amdgpu_waves_per_
     };
     uint64_t tile = blockIdx.x;
     if (tile < ntiles) load_tile(tile);
+    const bool fold = F.alt_cursors != nullptr;            // (uniform)
+    if (fold) {                                            // (behind the first tile's loads: stores nobody in this launch looks at)
+        const uint64_t g = (uint64_t)blockIdx.x * kTileThreads + threadIdx.x, gs = (uint64_t)gridDim.x * kTileThreads;
+        for (uint64_t i = g; i < F.words; i += gs) { F.bitmap[i] = 0u; F.weight[i] = 0u; }
+        for (uint64_t i = g; i < F.n_alt; i += gs) F.alt_cursors[i] = 0u;
+        if (g == 0) {
+            *F.alt_pc = PartCounters{};
+            cnt->num_nodes = 0; cnt->num_columns = 0; cnt->num_slopes = 0; cnt->err_key_range = 0; cnt->err_table_full = 0;
+            cnt->part_owned = 1u;
+        }
+    }
     for (; tile < ntiles; tile += gridDim.x) {
         const uint64_t t0 = tile * (kTileThreads * PER);
         const uint32_t rep = R > 1u ? (uint32_t)(tile % R) : 0u;
@@ -617,7 +640,7 @@ __global__ void __launch_bounds__(kTileThreads) __attribute__((amdgpu_waves_per_
             int sx, sy;
             bool kok;
             column_of_point(px, py, P, sx, sy, kok);
-            if (live && !kok) atomicAdd(&cnt->err_key_range, 1u);
+            if (live && !kok) atomicAdd(fold ? &pc->l1_err : &cnt->err_key_range, 1u);
             const bool use = live && kok;
             const bool same = !IDXW && (all8 || (compress && wave_all_identical(px, py, pz, use)));   // 64 identical points -> one weighted record
             dig[j] = 0xFFFFFFFFu;
