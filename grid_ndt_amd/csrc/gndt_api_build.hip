@@ -134,7 +134,7 @@ static FoldClear fold_clear_begin(gndt_handle* h, const gndt_handle::Pending& P,
     if (!tuning().fold_clear || P.records || h->capturing || h->ever_captured || !q.cursors_alt || !q.d_pc_alt) return FoldClear{};
     const bool clean = q.alt_clean;
     if (clean) { std::swap(q.cursors, q.cursors_alt); std::swap(q.d_pc, q.d_pc_alt); }
-    q.alt_clean = true;                    // (from this build's level-1 kernel on, in stream order)
+    q.alt_clean = false;                   // (the other set is the last build's now; partition_launch raises the flag once the level-1 kernel that zeroes it is launched)
     return FoldClear{q.cursors_alt, (uint32_t)(kMaxFan + 2 * q.cur_cap), q.d_pc_alt, q.bitmap, q.word_weight, clean ? words : 0ull};
 }
 
@@ -364,6 +364,7 @@ int partition_launch(gndt_handle* h, gndt_handle::Pending& P) {
 #undef GNDT_L1S
 #undef GNDT_L1R
         HIP_TRY(h, hipGetLastError());
+        if (fold.alt_cursors) q.alt_clean = true;          // (in stream order: the next build's level 1 runs behind this one)
         mark(h, 2, s);
         mark(h, 3, s);
         mark(h, 4, s);
