@@ -120,6 +120,14 @@ int ensure_cursors(gndt_handle* h, uint64_t B) {
     HIP_TRY(h, hipMalloc(&q.range_hi, c * 4));                        // (the retry list)
     HIP_TRY(h, hipMalloc(&q.range_cap, c * 4));
     q.cur_cap = c;
+    // The other set starts clean (FoldClear): a handle's first eager one-level build already goes without the clear launch — after
+    // gndt_reserve / gndt_warmup that is the first build of the process, the one the reference's user waits for.
+    if (q.d_pc_alt && !h->capturing) {
+        HIP_TRY(h, hipMemsetAsync(q.cursors_alt, 0, ((size_t)kMaxFan + 2 * c) * 4, h->own_stream));
+        HIP_TRY(h, hipMemsetAsync(q.d_pc_alt, 0, sizeof(PartCounters), h->own_stream));
+        HIP_TRY(h, hipStreamSynchronize(h->own_stream));
+        q.alt_clean = true;
+    }
     return GNDT_OK;
 }
 
@@ -1084,11 +1092,7 @@ int gndt_warmup(gndt_handle* h, uint64_t expected_points) {
         if (known_device) g_warm_points[h->device].store(n, std::memory_order_release);
     }
     if (reserve_points) rc = gndt_reserve(h, reserve_points, h->P.max_nodes_hint);
-    // (what a first build of THIS handle would still allocate: the locality sample's two counters, their pinned mirror, its event)
-    if (!rc && !h->d_sample) {
-        HIP_TRY(h, hipMalloc(&h->d_sample, 2 * sizeof(unsigned long long)));
-        HIP_TRY(h, hipHostMalloc(&h->h_sample, 2 * sizeof(unsigned long long)));
-    }
-    if (!rc && !h->sample_ev) HIP_TRY(h, hipEventCreateWithFlags(&h->sample_ev, hipEventDisableTiming));
+    // (what a first build of THIS handle would still allocate: the locality sample's counters, their pinned mirror, its event)
+    if (!rc) rc = ensure_sample_buffers(h);
     return rc;
 }

@@ -320,24 +320,30 @@ int table_refinalize(gndt_handle* h) {
     return GNDT_OK;
 }
 
-// strategy ATOMIC from empty; waits for the result (the retry on a full table needs the device-side flags)
+// the sample's three device words (zero between launches: the kernel's last workgroup leaves them so), two pinned words, its event
+int ensure_sample_buffers(gndt_handle* h) {
+    if (!h->d_sample) {
+        GNDT_NO_CAPTURE(h, "the locality sample's buffers");
+        HIP_TRY(h, hipMalloc(&h->d_sample, 3 * sizeof(unsigned long long)));
+        HIP_TRY(h, hipHostMalloc(&h->h_sample, 2 * sizeof(unsigned long long)));
+        { const int rc = zero_device_now(h, h->d_sample, 3 * sizeof(unsigned long long)); if (rc) return rc; }
+    }
+    if (!h->sample_ev) HIP_TRY(h, hipEventCreateWithFlags(&h->sample_ev, hipEventDisableTiming));
+    return GNDT_OK;
+}
+
 int locality_sample_begin(gndt_handle* h, const void* xyz_dev, size_t n, size_t stride_bytes, uint32_t tiles, hipStream_t s) {
     if (stride_bytes != 12 && stride_bytes != 16) { h->err = "stride_bytes must be 12 or 16"; return GNDT_ERR_INVALID; }
     h->sample_pending = false;
     if (n == 0 || tiles == 0) return GNDT_OK;
     GNDT_NO_CAPTURE(h, "the locality sample");
-    if (!h->d_sample) {
-        HIP_TRY(h, hipMalloc(&h->d_sample, 2 * sizeof(unsigned long long)));
-        HIP_TRY(h, hipHostMalloc(&h->h_sample, 2 * sizeof(unsigned long long)));
-    }
-    if (!h->sample_ev) HIP_TRY(h, hipEventCreateWithFlags(&h->sample_ev, hipEventDisableTiming));
+    { const int arc = ensure_sample_buffers(h); if (arc) return arc; }
     tiles = (uint32_t)std::min<uint64_t>(tiles, (n + kTileCheck - 1) / kTileCheck);
-    HIP_TRY(h, hipMemsetAsync(h->d_sample, 0, 2 * sizeof(unsigned long long), s));
+    // (the kernel's last workgroup stores the totals into h_sample and leaves d_sample zero: nothing in front of it, nothing behind it)
     const float* p = static_cast<const float*>(xyz_dev);
-    if (stride_bytes == 12) hipLaunchKernelGGL(k_tile_sample<3>, dim3(tiles), dim3(kTileT), 0, s, p, (uint64_t)n, grid_params(h), tiles, h->d_sample);
-    else hipLaunchKernelGGL(k_tile_sample<4>, dim3(tiles), dim3(kTileT), 0, s, p, (uint64_t)n, grid_params(h), tiles, h->d_sample);
+    if (stride_bytes == 12) hipLaunchKernelGGL(k_tile_sample<3>, dim3(tiles), dim3(kTileT), 0, s, p, (uint64_t)n, grid_params(h), tiles, h->d_sample, h->h_sample);
+    else hipLaunchKernelGGL(k_tile_sample<4>, dim3(tiles), dim3(kTileT), 0, s, p, (uint64_t)n, grid_params(h), tiles, h->d_sample, h->h_sample);
     HIP_TRY(h, hipGetLastError());
-    HIP_TRY(h, hipMemcpyAsync(h->h_sample, h->d_sample, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
     HIP_TRY(h, hipEventRecord(h->sample_ev, s));
     h->sample_pending = true;
     h->sample_n = n;

@@ -237,7 +237,7 @@ struct gndt_handle {
     int last_strategy = GNDT_STRATEGY_ATOMIC;
     // strategy AUTO: what the locality sample said last time, for which cloud size, and how many builds ago
     int tile_choice = -1;  uint64_t tile_choice_n = 0;  int tile_choice_age = 0;  double tile_ratio_seen = 0.0;
-    unsigned long long* d_sample = nullptr;  unsigned long long* h_sample = nullptr;   // k_tile_sample's two counters (pinned copy)
+    unsigned long long* d_sample = nullptr;  unsigned long long* h_sample = nullptr;   // k_tile_sample's counters {points, nodes, ticket} and the pinned words its last workgroup fills
     // a locality sample whose answer has not been looked at yet (round 6: a build on a handle that already has room for any answer does
     // not wait for it — the build it rides in front of takes the handle's last choice, the next one finds the answer)
     bool sample_pending = false;  uint64_t sample_n = 0;  hipEvent_t sample_ev = nullptr;
@@ -471,6 +471,7 @@ int build_atomic(gndt_handle* h, const void* xyz_dev, size_t n, size_t stride_by
                  const gndt_handle::Pending* rec = nullptr);
 int locality_sample(gndt_handle* h, const void* xyz_dev, size_t n, size_t stride_bytes, uint32_t tiles, double* ratio, hipStream_t s);
 int locality_sample_begin(gndt_handle* h, const void* xyz_dev, size_t n, size_t stride_bytes, uint32_t tiles, hipStream_t s);   // launched, not awaited
+int ensure_sample_buffers(gndt_handle* h);
 bool locality_sample_take(gndt_handle* h, bool wait, double* ratio);                                                          // its answer, if there is one
 int sketch_nodes(gndt_handle* h, const void* xyz_dev, size_t n, size_t stride_bytes, hipStream_t s, uint64_t* estimate);   // HyperLogLog over the node keys (waits)
 // ---- gndt_api_build.hip ----

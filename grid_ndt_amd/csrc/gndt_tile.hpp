@@ -228,9 +228,10 @@ k_tile_accumulate(const float* __restrict__ xyz, uint64_t n, uint32_t first_base
 // Locality probe for strategy AUTO: `tiles` tiles of kTileCheck consecutive points spread evenly over the cloud; for each, the
 // number of DISTINCT nodes its points fall into (LDS key table only).  out[0] += points looked at, out[1] += distinct nodes
 // (= partials a flush would send).  points / partials is what strategy TILE gains over one set of atomics per point.
+// out: three device words {points, nodes, ticket}, zero between launches; host_out: two pinned words the last workgroup fills.
 template <int STRIDE_FLOATS>
 __global__ void __launch_bounds__(kTileT) k_tile_sample(const float* __restrict__ xyz, uint64_t n, GridParams P, uint32_t tiles,
-                                                        unsigned long long* __restrict__ out) {
+                                                        unsigned long long* __restrict__ out, unsigned long long* __restrict__ host_out) {
     constexpr int T = kTileT, H = 4096;              // a table a whole tile fits in whatever its locality
     __shared__ unsigned long long key[H];
     __shared__ uint32_t n_new;
@@ -249,7 +250,21 @@ __global__ void __launch_bounds__(kTileT) k_tile_sample(const float* __restrict_
         lds_find_or_insert<H>(key, node_slot3(column_hash(k.sx, k.sy), k.sz), pack_key(k.sx, k.sy, k.sz), &n_new);
     }
     __syncthreads();
-    if (tid == 0) { atomicAdd(&out[0], (unsigned long long)have); atomicAdd(&out[1], (unsigned long long)n_new); }
+    // The totals go home with the LAST workgroup (ticket out[2]): it stores them into the host's pinned words and zeroes the three
+    // device words for the next sample — no memset in front of the kernel, no copy behind it (two stream operations of ~5-8 us each
+    // on the path of a handle's first build, which waits for this answer: round 6).
+    if (tid < 64) {                                    // (the first wave; lanes 0 and 1 carry one total each: their round trips overlap)
+        const unsigned long long mine = tid == 0 ? (unsigned long long)have : (unsigned long long)n_new;
+        if (tid < 2) atomicAdd(&out[tid], mine);
+        __threadfence();                               // (both totals are in before the ticket is taken)
+        int last = 0;
+        if (tid == 0) last = atomicAdd(&out[2], 1ull) == (unsigned long long)gridDim.x - 1ull ? 1 : 0;
+        last = __shfl(last, 0, 64);
+        if (last) {
+            if (tid < 2) host_out[tid] = atomicAdd(&out[tid], 0ull);
+            if (tid < 3) out[tid] = 0ull;
+        }
+    }
 }
 
 }  // namespace gndt

@@ -955,8 +955,12 @@ def test_auto_takes_the_one_pass_tile_strategy_only_where_the_sampled_locality_p
         m.setInterval(P["slope_interval"]); m.setCloudFirst(cloud[0])
         pts = torch.from_numpy(cloud[1:]).cuda()
         ratio = m.locality_sample(pts)
+        # (the kernel's last workgroup sends the totals home and leaves the device words zero: the same answer every time, also with
+        #  builds — which sample again by themselves — and other tile counts in between)
+        assert m.locality_sample(pts) == ratio and m.locality_sample(pts, tiles=7) > 0 and m.locality_sample(pts) == ratio
         m.create2DMap("slope", pts)
         m.sync()
+        assert m.locality_sample(pts) == ratio
         res[name] = (ratio, m.last_strategy(), m.export())
         print(name, "points per partial %.1f" % ratio, "->", m.STRATEGY_NAMES[m.last_strategy()])
     assert res["dense"][0] > 48 and res["dense"][1] == 5
