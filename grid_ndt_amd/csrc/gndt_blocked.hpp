@@ -268,8 +268,8 @@ __global__ void __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(6, 6))) 
         if (my_slopes) atomicAdd(&L.n_slopes, my_slopes);
         lds_barrier();
         if (tid == 0) {
-            if (L.n_cols) atomicAdd(&cnt->num_columns, L.n_cols);
-            if (L.n_slopes) atomicAdd(&cnt->num_slopes, L.n_slopes);
+            // (ONE atomic, on the partition counters' line — PartCounters::cols_slopes: not on the line the row reservations wait on)
+            if (L.n_cols | L.n_slopes) atomicAdd(&pc->cols_slopes, ((unsigned long long)L.n_slopes << 32) | (unsigned long long)L.n_cols);
         }
         GNDT_STAMPB(4);
         lds_barrier();          // (the table is re-initialised by the next bucket)

@@ -624,7 +624,6 @@ __device__ __forceinline__ void bucket_direct_one(BucketLds3<H>& L, const uint32
         kc = atomicAdd(&L.ph.ccnt[col], 1u);
     }
     lds_barrier();
-    if (tid == 0) atomicAdd(&cnt->num_columns, L.n_cols);
     // The rows of a column are staged NEXT TO EACH OTHER, in first-seen order: every column reserves its rows inside the bucket.
     // The ordering pass then works per column (one lookup of the column's place instead of one per node) and the emit pass
     // gathers runs of rows.  The same reservation places the columns' node arrays.
@@ -724,7 +723,8 @@ __device__ __forceinline__ void bucket_direct_one(BucketLds3<H>& L, const uint32
     // counters: aggregated in LDS, ONE memory-side atomic per bucket and counter
     if (my_slopes) atomicAdd(&L.n_slopes, my_slopes);
     lds_barrier();
-    if (tid == 0 && L.n_slopes) atomicAdd(&cnt->num_slopes, L.n_slopes);
+    // (columns and slopes of the bucket in ONE atomic, on the partition counters' line — not on the line every bucket's row reservation waits on)
+    if (tid == 0 && (L.n_cols | L.n_slopes)) atomicAdd(&pc->cols_slopes, ((unsigned long long)L.n_slopes << 32) | (unsigned long long)L.n_cols);
     GNDT_STAMP3(4);
 #undef GNDT_STAMP3
 }

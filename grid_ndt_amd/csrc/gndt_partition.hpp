@@ -56,7 +56,19 @@ struct PartCounters {
     uint32_t lds_retry;        // buckets whose 512-slot table overflowed and that wait for the second pass with 1024 slots (the retry list's length)
     uint32_t l1_err;           // level 1 with FoldClear: points beyond the key range (the bucket kernel adds them to Counters::err_key_range, which
                                //   that level-1 launch itself zeroes)
+    unsigned long long cols_slopes;   // bucket kernels: {columns (low word), slopes (high word)} of the buckets done so far — ONE memory-side atomic
+                               //   per bucket, on THIS line.  They used to be two atomics on Counters' line, where every bucket's row
+                               //   reservation (a returning atomic: the bucket waits for its answer) queued behind them: same-line
+                               //   atomics are served at ~90 per us, 2 809 buckets x 3 is the bench scene's whole bucket kernel.
+                               //   Folded into Counters::num_columns / num_slopes by the kernel that sends the counters home
+                               //   (fold_bucket_counts); bucket kernel 120 -> 105 us, profiles/r06_ablation.txt 11.
 };
+
+// (block 0, thread 0 of k_emit_rows / k_place_emit_rows, in front of the copy to the host's mirror)
+__device__ __forceinline__ void fold_bucket_counts(Counters* cnt, PartCounters* pc) {
+    const unsigned long long cs = pc->cols_slopes;
+    if (cs) { cnt->num_columns += (uint32_t)cs; cnt->num_slopes += (uint32_t)(cs >> 32); pc->cols_slopes = 0ull; }
+}
 
 // What a level-1 launch zeroes on the side when no k_part_clear precedes the build (Part::cursors_alt, gndt_handle.hpp): the cursors and
 // partition counters the NEXT build on the handle will take, and THIS build's bitmap, word weights and Counters — none of which a
@@ -259,7 +271,7 @@ static __global__ void __launch_bounds__(256) k_part_clear(Counters* __restrict_
         cnt->num_nodes = 0; cnt->num_columns = 0; cnt->num_slopes = 0; cnt->err_key_range = 0; cnt->err_table_full = 0;
         cnt->part_owned = 1u;                        // (num_nodes counts staged rows from here on, not the table's node list)
         pc->lds_overflow = 0; pc->stage_overflow = 0; pc->index_overflow = 0; pc->part_overflow = 0;
-        pc->max_fill1 = 0; pc->fp_clashes = 0; pc->l1_ticket = 0; pc->small_fallback = 0; pc->pairs = 0; pc->lds_retry = 0; pc->blk_miss = 0; pc->l1_err = 0;
+        pc->max_fill1 = 0; pc->fp_clashes = 0; pc->l1_ticket = 0; pc->small_fallback = 0; pc->pairs = 0; pc->lds_retry = 0; pc->blk_miss = 0; pc->l1_err = 0; pc->cols_slopes = 0ull;
     }
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < words; i += (uint64_t)gridDim.x * blockDim.x) { bitmap[i] = 0u; word_weight[i] = 0u; }
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_cursors; i += gridDim.x * blockDim.x) cursors[i] = 0u;   // two-level partition
@@ -981,11 +993,12 @@ static __global__ void __launch_bounds__(kBlock) k_place_emit_rows(const RawNode
                                                                    const uint32_t* __restrict__ ord_idx, const uint32_t* __restrict__ bitmap,
                                                                    uint32_t* __restrict__ word_base, const uint32_t* __restrict__ ncol_at,
                                                                    OutView out, uint32_t* __restrict__ row_ncol,
-                                                                   const Counters* __restrict__ cnt, const PartCounters* __restrict__ pc,
+                                                                   Counters* cnt, PartCounters* pc,
                                                                    Counters* __restrict__ host_cnt, PartCounters* __restrict__ host_pc,
                                                                    uint32_t capture_id, GridParams P,
                                                                    const uint32_t* __restrict__ word_weight, uint32_t words) {
     if (blockIdx.x == 0 && threadIdx.x < 2) {
+        if (threadIdx.x == 0) fold_bucket_counts(cnt, pc);
         if (threadIdx.x == 0 && host_cnt) *host_cnt = *cnt;
         if (threadIdx.x == 1 && host_pc) { *host_pc = *pc; host_pc->capture_id = capture_id; }
     }
@@ -1060,12 +1073,13 @@ __attribute__((amdgpu_waves_per_eu(GNDT_EMIT_WAVES, GNDT_EMIT_WAVES)))
 #endif
 k_emit_rows(const StageRow* __restrict__ stage, const uint32_t* __restrict__ inv,
                                                       OutView out, uint32_t* __restrict__ row_ncol,
-                                                      const Counters* cnt, const PartCounters* __restrict__ pc,
+                                                      Counters* cnt, PartCounters* pc,
                                                       Counters* __restrict__ host_cnt, PartCounters* __restrict__ host_pc,
                                                       Counters* tab_cnt, uint32_t advance, EmitPartial part, uint32_t capture_id,
                                                       GridParams P) {
     // (cnt is NOT __restrict__: on the table path tab_cnt points at the same object and lane 0 writes through it below)
     if (blockIdx.x == 0 && threadIdx.x < 2) {
+        if (threadIdx.x == 0) fold_bucket_counts(cnt, pc);
         if (threadIdx.x == 0 && host_cnt) *host_cnt = *cnt;
         if (threadIdx.x == 1 && host_pc) { *host_pc = *pc; host_pc->capture_id = capture_id; }
         // Table path (gndt_update*): the end-of-frame bookkeeping rides here as well — how many nodes own a column entry, the
