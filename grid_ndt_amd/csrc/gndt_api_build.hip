@@ -114,8 +114,8 @@ int ensure_cursors(gndt_handle* h, uint64_t B) {
     q.cur_cap = 0;
     q.alt_clean = false;
     const uint64_t c = B + B / 4;
-    HIP_TRY(h, hipMalloc(&q.cursors, ((size_t)kMaxFan + 2 * c) * 4));  // [kMaxFan] level 1, [c] level 2, [c] samples
-    HIP_TRY(h, hipMalloc(&q.cursors_alt, ((size_t)kMaxFan + 2 * c) * 4));      // (the set the next eager build takes: FoldClear)
+    HIP_TRY(h, hipMalloc(&q.cursors, ((size_t)kCursor1Words + 2 * c) * 4));  // [kCursor1Words] level 1 (a line each), [c] level 2, [c] samples
+    HIP_TRY(h, hipMalloc(&q.cursors_alt, ((size_t)kCursor1Words + 2 * c) * 4));      // (the set the next eager build takes: FoldClear)
     HIP_TRY(h, hipMalloc(&q.range_lo, c * 4));
     HIP_TRY(h, hipMalloc(&q.range_hi, c * 4));                        // (the retry list)
     HIP_TRY(h, hipMalloc(&q.range_cap, c * 4));
@@ -123,7 +123,7 @@ int ensure_cursors(gndt_handle* h, uint64_t B) {
     // The other set starts clean (FoldClear): a handle's first eager one-level build already goes without the clear launch — after
     // gndt_reserve / gndt_warmup that is the first build of the process, the one the reference's user waits for.
     if (q.d_pc_alt && !h->capturing) {
-        HIP_TRY(h, hipMemsetAsync(q.cursors_alt, 0, ((size_t)kMaxFan + 2 * c) * 4, h->own_stream));
+        HIP_TRY(h, hipMemsetAsync(q.cursors_alt, 0, ((size_t)kCursor1Words + 2 * c) * 4, h->own_stream));
         HIP_TRY(h, hipMemsetAsync(q.d_pc_alt, 0, sizeof(PartCounters), h->own_stream));
         HIP_TRY(h, hipStreamSynchronize(h->own_stream));
         q.alt_clean = true;
@@ -143,6 +143,7 @@ static FoldClear fold_clear_begin(gndt_handle* h, const gndt_handle::Pending& P,
     const bool clean = q.alt_clean;
     if (clean) { std::swap(q.cursors, q.cursors_alt); std::swap(q.d_pc, q.d_pc_alt); }
     q.alt_clean = false;                   // (the other set is the last build's now; partition_launch raises the flag once the level-1 kernel that zeroes it is launched)
+    // (what a one-level build uses of a cursor set, and all "clean" means: [0, kMaxFan) dense level-1 cursors + the sample votes behind them)
     return FoldClear{q.cursors_alt, (uint32_t)(kMaxFan + 2 * q.cur_cap), q.d_pc_alt, q.bitmap, q.word_weight, clean ? words : 0ull};
 }
 
@@ -268,7 +269,7 @@ int partition_launch(gndt_handle* h, gndt_handle::Pending& P) {
         //  k_part_clear launch — level 1 and level 2 each a microsecond slower; the one-level partition of a small frame is where it pays)
         const FoldClear fold{};
         uint32_t* cursor1 = q.cursors;
-        uint32_t* cursor2 = q.cursors + kMaxFan;
+        uint32_t* cursor2 = q.cursors + kCursor1Words;
         uint32_t* est2 = cursor2 + B;
         mark(h, 0, s);
         // (a build recorded into a hipGraph always records the reset: its replays must not depend on what the table held at capture time)
@@ -276,7 +277,7 @@ int partition_launch(gndt_handle* h, gndt_handle::Pending& P) {
         h->results_valid = false;
         if (!fold.words) {
             hipLaunchKernelGGL(k_part_clear, dim3(grid_for(words, 256, 512)), dim3(256), 0, s, h->d_cnt, q.d_pc, q.bitmap, q.word_weight, (uint64_t)words,
-                               q.cursors, (uint32_t)(kMaxFan + 2 * B));
+                               q.cursors, (uint32_t)(kCursor1Words + 2 * B));
             HIP_TRY(h, hipGetLastError());
         }
         mark(h, 1, s);
@@ -289,16 +290,16 @@ int partition_launch(gndt_handle* h, gndt_handle::Pending& P) {
 #define GNDT_L1(SF_, FAN_)                                                                                                  \
     hipLaunchKernelGGL((k_part2_level1<SF_, FAN_>), g1, dim3(kTileThreads), 0, s, p, (uint64_t)n, P.first_base, gp, B, F1, F2_shift, \
                        R, cursor1, cap1, est2, q.recs1, h->d_cnt, q.d_pc, compress, OwnerMap{nullptr, nullptr, 0u}, q.range_lo,     \
-                       q.range_cap, (uint64_t)q.rec_cap, fold)
+                       q.range_cap, (uint64_t)q.rec_cap, fold, kCursor1Shift)
         // records: the two segments one after the other into the same regions (the cursors carry on; the last launch lays out)
 #define GNDT_L1R(FAN_)                                                                                                      \
     do {                                                                                                                    \
         if (P.n) hipLaunchKernelGGL((k_part2_level1<4, FAN_, true>), g1, dim3(kTileThreads), 0, s, p, (uint64_t)P.n, P.first_base, gp, B, F1, \
                                     F2_shift, R, cursor1, cap1, est2, q.recs1, h->d_cnt, q.d_pc, compress, OwnerMap{nullptr, nullptr, 0u}, \
-                                    P.n2 ? (uint32_t*)nullptr : q.range_lo, q.range_cap, (uint64_t)q.rec_cap, FoldClear{});  \
+                                    P.n2 ? (uint32_t*)nullptr : q.range_lo, q.range_cap, (uint64_t)q.rec_cap, FoldClear{}, kCursor1Shift);  \
         if (P.n2) hipLaunchKernelGGL((k_part2_level1<4, FAN_, true>), g1b, dim3(kTileThreads), 0, s, p2, (uint64_t)P.n2, P.first_base, gp, B, \
                                      F1, F2_shift, R, cursor1, cap1, est2, q.recs1, h->d_cnt, q.d_pc, compress, OwnerMap{nullptr, nullptr, 0u}, \
-                                     q.range_lo, q.range_cap, (uint64_t)q.rec_cap, FoldClear{});                             \
+                                     q.range_lo, q.range_cap, (uint64_t)q.rec_cap, FoldClear{}, kCursor1Shift);              \
     } while (0)
         if (P.records) { if (wide) GNDT_L1R(512); else GNDT_L1R(256); }
         else if (stride_bytes == 12) { if (wide) GNDT_L1(3, 512); else GNDT_L1(3, 256); }
@@ -325,7 +326,7 @@ int partition_launch(gndt_handle* h, gndt_handle::Pending& P) {
         if ((rc = ensure_cursors(h, B))) return rc;
         const FoldClear fold = fold_clear_begin(h, P, words);     // (may swap q.cursors / q.d_pc with their clean twins)
         uint32_t* cursor1 = q.cursors;                     // [B <= kMaxFan] the buckets' fills
-        uint32_t* est2 = q.cursors + kMaxFan;              // (the kernel's sample votes: not used here, but counted)
+        uint32_t* est2 = q.cursors + kMaxFan;              // (the kernel's sample votes: not used here, but counted; one-level: dense cursors)
         const uint32_t F1 = B, F2_shift = 0, R = 1;
         mark(h, 0, s);
         // (a build recorded into a hipGraph always records the reset: its replays must not depend on what the table held at capture time)
@@ -347,19 +348,19 @@ int partition_launch(gndt_handle* h, gndt_handle::Pending& P) {
 #define GNDT_L1(SF_, FAN_)                                                                                                  \
     hipLaunchKernelGGL((k_part2_level1<SF_, FAN_>), g1, dim3(kTileThreads), 0, s, p, (uint64_t)n, P.first_base, gp, B, F1, F2_shift, \
                        R, cursor1, cap1, est2, q.recs1, h->d_cnt, q.d_pc, compress, OwnerMap{nullptr, nullptr, 0u}, (uint32_t*)nullptr, \
-                       (uint32_t*)nullptr, 0ull, fold)
+                       (uint32_t*)nullptr, 0ull, fold, 0)
 #define GNDT_L1S(SF_, FAN_)                                                                                                 \
     hipLaunchKernelGGL((k_part2_level1<SF_, FAN_, false, false, kTilePerSmall>), g1, dim3(kTileThreads), 0, s, p, (uint64_t)n, P.first_base, gp, B, F1, \
                        F2_shift, R, cursor1, cap1, est2, q.recs1, h->d_cnt, q.d_pc, compress, OwnerMap{nullptr, nullptr, 0u}, (uint32_t*)nullptr, \
-                       (uint32_t*)nullptr, 0ull, fold)
+                       (uint32_t*)nullptr, 0ull, fold, 0)
 #define GNDT_L1R(FAN_)                                                                                                      \
     do {                                                                                                                    \
         if (P.n) hipLaunchKernelGGL((k_part2_level1<4, FAN_, true>), g1, dim3(kTileThreads), 0, s, p, (uint64_t)P.n, P.first_base, gp, B, F1, \
                                     F2_shift, R, cursor1, cap1, est2, q.recs1, h->d_cnt, q.d_pc, compress, OwnerMap{nullptr, nullptr, 0u}, \
-                                    (uint32_t*)nullptr, (uint32_t*)nullptr, 0ull, FoldClear{});                              \
+                                    (uint32_t*)nullptr, (uint32_t*)nullptr, 0ull, FoldClear{}, 0);                              \
         if (P.n2) hipLaunchKernelGGL((k_part2_level1<4, FAN_, true>), g1b, dim3(kTileThreads), 0, s, p2, (uint64_t)P.n2, P.first_base, gp, B, \
                                      F1, F2_shift, R, cursor1, cap1, est2, q.recs1, h->d_cnt, q.d_pc, compress, OwnerMap{nullptr, nullptr, 0u}, \
-                                     (uint32_t*)nullptr, (uint32_t*)nullptr, 0ull, FoldClear{});                             \
+                                     (uint32_t*)nullptr, (uint32_t*)nullptr, 0ull, FoldClear{}, 0);                             \
     } while (0)
         if (small_tiles) {
             if (stride_bytes == 12) { if (wide) GNDT_L1S(3, 512); else GNDT_L1S(3, 256); }

@@ -535,11 +535,11 @@ int owner_split_launch(gndt_handle* h, const void* xyz, size_t n, size_t stride_
         if (stride_bytes == 12)
             hipLaunchKernelGGL((k_part2_level1<3, 256, false, true>), g1, dim3(kTileThreads), 0, s, p, (uint64_t)n, (uint32_t)first_base, gp, W, W, 0u, 1u,
                                q.totals, (uint32_t)cap, (uint32_t*)nullptr, X.send_recs, X.d_split_cnt, q.d_pc, compress, M, (uint32_t*)nullptr,
-                               (uint32_t*)nullptr, 0ull, FoldClear{});
+                               (uint32_t*)nullptr, 0ull, FoldClear{}, 0);
         else
             hipLaunchKernelGGL((k_part2_level1<4, 256, false, true>), g1, dim3(kTileThreads), 0, s, p, (uint64_t)n, (uint32_t)first_base, gp, W, W, 0u, 1u,
                                q.totals, (uint32_t)cap, (uint32_t*)nullptr, X.send_recs, X.d_split_cnt, q.d_pc, compress, M, (uint32_t*)nullptr,
-                               (uint32_t*)nullptr, 0ull, FoldClear{});
+                               (uint32_t*)nullptr, 0ull, FoldClear{}, 0);
         HIP_TRY(h, hipGetLastError());
         X.split_cap = cap;
         uint32_t* h_base = X.h_matrix + kMatrixHostWords;

@@ -441,6 +441,17 @@ constexpr int kTilePer1 = GNDT_TILE_PER1;       // level 1: 4096 records per til
 constexpr int kTilePer2 = GNDT_TILE_PER2;       // level 2: 2048 records per tile (34 KB): four tiles resident per CU
 constexpr bool kWeight512Ok = kTilePer1 * 64 == 512;   // kWeight512Flag: a wave's share of a level-1 tile is the 512 points a weighted record can stand for
 constexpr int kMaxFan = 512;               // fan-out per level: up to 512 x 512 buckets
+// TWO-LEVEL partition: level 1's cursors — one per coarse region, a returning memory-side atomic per region and TILE — lie one per 128-byte
+// line: every tile of the cloud reserves in all of them, and packed into two or three lines (53 regions on the bench scene, 2 442 tiles)
+// the lines' atomic units serve ~130 k lane-operations one after the other.  One call, A B A B: level 1 73.2 | 74.3 -> 71.3 | 70.8 us on the
+// bench scene, 0.808 | 0.787 -> 0.762 | 0.755 ms on the 100 M-point terrain.  NOT for the one-level partition of a small frame (a few
+// hundred cursors met by ~200 tiles: spread out, every tile's reservation touches a few hundred lines — level 1 10.2 -> 12.0 us) nor for
+// level 2's cursors (only met by the ~50 tiles of their own region).  The kernels take the shift as an argument (cshift).
+#ifndef GNDT_CURSOR1_SHIFT
+#define GNDT_CURSOR1_SHIFT 5
+#endif
+constexpr int kCursor1Shift = GNDT_CURSOR1_SHIFT;
+constexpr int kCursor1Words = kMaxFan << kCursor1Shift;      // words the level-1 cursors take in Part::cursors
 constexpr uint32_t kSampleEvery = 64;      // level 1 samples one record in 64 to size the buckets' regions (the hash test below is >> 26)
 
 // FAN = 256 or 512: the fan-out the LDS arrays are sized for (the small variant keeps four level-2 tiles per CU)
@@ -464,7 +475,7 @@ __device__ __forceinline__ void tile_partition(TileLds<PER, FAN>& L, const float
                                                uint32_t nd, uint32_t* __restrict__ cursor, uint32_t cap, uint64_t region0,
                                                uint64_t region_stride, const uint32_t* __restrict__ dbase,
                                                const uint32_t* __restrict__ dcap, float4* __restrict__ out,
-                                               PartCounters* __restrict__ pc) {
+                                               PartCounters* __restrict__ pc, int cshift = 0) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // the regions' bases / capacities do not depend on the tile: requested first, used by the copy-out
     uint32_t my_dbase = 0, my_room = cap;
@@ -480,7 +491,7 @@ __device__ __forceinline__ void tile_partition(TileLds<PER, FAN>& L, const float
     uint32_t c = 0, g = 0;
     if ((uint32_t)tid < nd) {
         c = L.hist[tid];
-        if (c) g = atomicAdd(&cursor[tid], c);
+        if (c) g = atomicAdd(&cursor[(size_t)tid << cshift], c);      // (cshift: kCursor1Shift for level 1's cursors, 0 otherwise)
     }
     uint32_t incl = c;
     for (int o = 1; o < 64; o <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)incl, o, 64); if (lane >= o) incl += t; }
@@ -576,7 +587,7 @@ __global__ void __launch_bounds__(kTileThreads) __attribute__((amdgpu_waves_per_
                                                                float4* __restrict__ recs1, Counters* __restrict__ cnt,
                                                                PartCounters* __restrict__ pc, uint32_t compress, OwnerMap M,
                                                                uint32_t* __restrict__ lay_lo, uint32_t* __restrict__ lay_cap, uint64_t rec_capacity,
-                                                               FoldClear F) {
+                                                               FoldClear F, int cshift) {
     constexpr int PER = PER1;
     __shared__ TileLds<PER, FAN> L;
     // Persistent workgroups, software-pipelined: the loads of tile t+1 are in flight while tile t is keyed, sorted
@@ -672,7 +683,7 @@ __global__ void __launch_bounds__(kTileThreads) __attribute__((amdgpu_waves_per_
                 r[j] = make_float4(px, py, pz, __uint_as_float(idx));
             }
         }
-        tile_partition<PER, FAN>(L, r, dig, OWNER ? B : F1 * R, cursor1, cap1, 0ull, (uint64_t)cap1, nullptr, nullptr, recs1, pc);
+        tile_partition<PER, FAN>(L, r, dig, OWNER ? B : F1 * R, cursor1, cap1, 0ull, (uint64_t)cap1, nullptr, nullptr, recs1, pc, cshift);
         __syncthreads();                                   // the tile's LDS image is reused by the next iteration
     }
     // Two-level partition: the LAST workgroup to get here lays out the buckets' regions for level 2 from everybody's votes
@@ -706,9 +717,10 @@ __global__ void __launch_bounds__(kTileThreads) k_part2_level2(const float4* __r
     __shared__ TileLds<PER, FAN> L;
     const uint32_t v = blockIdx.y, c = v / R;
     // the fullest level-1 region (true count, also beyond its capacity: the host sizes a retry from it)
-    if (blockIdx.x == 0 && threadIdx.x == 0) atomicMax(&pc->max_fill1, cursor1[v]);
+    const uint32_t fill1 = cursor1[(size_t)v << kCursor1Shift];
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicMax(&pc->max_fill1, fill1);
     if (pc->part_overflow) return;                       // level 1 or the layout already gave up: the build is re-run
-    const uint32_t have = min(cursor1[v], cap1);
+    const uint32_t have = min(fill1, cap1);
     const uint32_t t0 = blockIdx.x * (kTileThreads * PER);
     if (t0 >= have) return;
     const uint32_t b0 = c * F2, nd = min(F2, B - b0);
@@ -743,7 +755,7 @@ struct BucketRanges {
 __device__ __forceinline__ void bucket_range(const BucketRanges& R, uint32_t b, uint32_t& lo, uint32_t& hi) {
     if (!R.fill) { lo = R.lo[b]; hi = R.lo[b + 1]; }
     else if (R.lo) { lo = R.lo[b]; hi = lo + min(R.fill[b], R.cap[b]); }
-    else { lo = b * R.stride; hi = lo + min(R.fill[b], R.stride); }
+    else { lo = b * R.stride; hi = lo + min(R.fill[b], R.stride); }      // (one-level partition: level 1's cursors — dense there — are the fills)
 }
 
 // ---------------------------------------------------------------------------------------------
